@@ -1,0 +1,72 @@
+/*
+ * os2s.h — C ABI of libos2s_hip.so: the MI355X (gfx950) kernels behind
+ * OpenSeq2Seq's Encoder / Decoder / Loss / optimizer hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only: device pointers, sizes, a stream handle
+ *     (os2s_stream_t == hipStream_t, passed as void*; NULL = default stream);
+ *   - the caller owns every buffer (PyTorch tensors in the Python host layer);
+ *     no hidden allocation, workspaces are passed in and sized by
+ *     os2s_*_workspace_bytes();
+ *   - returns OS2S_OK (0) or a negative OS2S_ERR_* code; no exceptions cross
+ *     the boundary; kernels are enqueued asynchronously on `stream`;
+ *   - bf16 tensors are passed as uint16_t* (raw bfloat16 bits);
+ *   - activations are channels-last: [B, T, C] with C contiguous, the layout
+ *     the reference's data layers / encoders use
+ *     (open_seq2seq/encoders/tdnn_encoder.py:160-164, "B T F").
+ *
+ * Each declaration cites the reference call site it replaces
+ * (paths relative to NVIDIA/OpenSeq2Seq).
+ */
+#ifndef OS2S_H_
+#define OS2S_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* os2s_stream_t;
+
+enum {
+  OS2S_OK = 0,
+  OS2S_ERR_INVALID_ARG = -1,
+  OS2S_ERR_LAUNCH = -2,
+  OS2S_ERR_UNSUPPORTED = -3,
+  OS2S_ERR_WORKSPACE = -4
+};
+
+/* Library identification: returns the ABI version (bumped on any signature change). */
+int os2s_abi_version(void);
+/* Human-readable description of an error code. */
+const char* os2s_strerror(int code);
+
+/* ------------------------------------------------------------------------
+ * CTC greedy (best-path) decode.
+ * Replaces tf.nn.ctc_greedy_decoder as called by decode_without_lm
+ * (open_seq2seq/decoders/fc_decoders.py:244-251) and mirrors
+ * decoders/ctc_greedy_decoder.cpp:4-45.
+ *   logits      [T, B, V] fp32, time-major (fc_decoders.py:147-148)
+ *   seq_len     [B] int32 valid frames per sample
+ *   blank       blank id (V-1 in the reference, speech2text.py:123-125)
+ *   merge_repeated  collapse repeats before dropping blanks (1 in the reference)
+ * Outputs (dense form of the reference's SparseTensor):
+ *   out_ids     [B, T] int32, first out_len[b] entries valid, rest = -1
+ *   out_len     [B] int32
+ *   neg_sum_logits [B] fp32 = -sum_t max_v logits[t,b,v]  (may be NULL)
+ *   workspace   device scratch of os2s_ctc_greedy_decode_workspace_bytes(T,B)
+ * Ties in the argmax resolve to the lowest class index (first maximum).
+ * ---------------------------------------------------------------------- */
+size_t os2s_ctc_greedy_decode_workspace_bytes(int T, int B);
+int os2s_ctc_greedy_decode(os2s_stream_t stream, const float* logits,
+                           const int32_t* seq_len, int T, int B, int V,
+                           int blank, int merge_repeated, int32_t* out_ids,
+                           int32_t* out_len, float* neg_sum_logits,
+                           void* workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OS2S_H_ */

@@ -1,0 +1,52 @@
+"""ctypes binding of libos2s_hip.so (the C ABI declared in include/os2s.h).
+
+There is no CPU fallback: if the HIP library is missing this raises, loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libos2s_hip.so")
+
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+c_uint64 = ctypes.c_uint64
+
+
+class Os2sError(RuntimeError):
+  pass
+
+
+def lib():
+  """Returns the loaded shared library (loads it on first use)."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise Os2sError(
+          "libos2s_hip.so not found at %s. Build it with "
+          "`python -c 'import __graft_entry__ as g; g.build()'` "
+          "(there is no CPU fallback for the HIP path)." % LIB_PATH)
+    _lib = ctypes.CDLL(LIB_PATH)
+    _lib.os2s_strerror.restype = ctypes.c_char_p
+    _lib.os2s_strerror.argtypes = [c_int]
+    _lib.os2s_abi_version.restype = c_int
+  return _lib
+
+
+def check(code, what=""):
+  if code != 0:
+    msg = lib().os2s_strerror(int(code)).decode()
+    raise Os2sError("%s failed: %s (code %d)" % (what or "os2s call", msg, code))
+
+
+def bind(name, argtypes, restype=c_int):
+  """Returns the C function `name` with its signature attached."""
+  f = getattr(lib(), name)
+  f.argtypes = argtypes
+  f.restype = restype
+  return f

@@ -1,0 +1,209 @@
+// CTC greedy (best-path) decode for gfx950.
+//
+// Reference semantics: tf.nn.ctc_greedy_decoder(logits, seq_len, merge_repeated=True)
+// as used by open_seq2seq/decoders/fc_decoders.py:244-251 (time-major fp32 logits,
+// blank = V-1), equivalently decoders/ctc_greedy_decoder.cpp:4-45 (argmax per
+// frame, first maximum wins, collapse repeats, drop blanks).
+//
+// Two HBM-bound passes:
+//   1. frame_argmax: streams the [T*B, V] logit rows exactly once (coalesced
+//      16-byte loads staged through LDS, one row per lane for small V; one wave
+//      per row with shuffle reduction for large V) and writes the per-frame
+//      argmax id + max value, already transposed to sample-major [B, T].
+//   2. compact: one workgroup per sample; order-preserving stream compaction
+//      (ballot + popcount wave scan, LDS cross-wave offsets) of the frames that
+//      survive merge-repeated / blank removal; also the -sum(max) path score.
+// Algorithmic bytes: T*B*V*4 read + T*B*8 written/re-read + B*T*4 written.
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+constexpr int kArgmaxThreads = 256;
+
+// Small-V path: each lane owns one row. Rows of a block are contiguous in
+// memory ([T*B, V] row-major), so the block's slab is loaded with coalesced
+// dword loads into LDS and each lane then scans its row from LDS. Row stride V
+// words: conflict-free for odd V; for even V we pad the row stride to V+1.
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void frame_argmax_small_v(
+    const float* __restrict__ logits, int rows, int T, int B, int V,
+    int32_t* __restrict__ ids_bt, float* __restrict__ maxv_bt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldv = (V & 1) ? V : V + 1;
+  const int64_t row0 = (int64_t)blockIdx.x * kThreads;
+  const int nrows = (int)min((int64_t)kThreads, (int64_t)rows - row0);
+  const int64_t total = (int64_t)nrows * V;
+  const float* src = logits + row0 * V;
+  // slab base is 16-byte aligned (row0 is a multiple of 256): 16 B/lane loads
+  const int64_t total4 = total >> 2;
+  const float4* src4 = reinterpret_cast<const float4*>(src);
+  for (int64_t i4 = threadIdx.x; i4 < total4; i4 += kThreads) {
+    const float4 v = src4[i4];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    int r = (int)((i4 * 4) / V), c = (int)(i4 * 4 - (int64_t)r * V);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      smem[r * ldv + c] = e[j];
+      if (++c == V) { c = 0; ++r; }
+    }
+  }
+  for (int64_t i = (total4 << 2) + threadIdx.x; i < total; i += kThreads) {
+    int r = (int)(i / V), c = (int)(i - (int64_t)r * V);
+    smem[r * ldv + c] = src[i];
+  }
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r < nrows) {
+    const float* row = smem + r * ldv;
+    float best = row[0];
+    int bi = 0;
+    for (int v = 1; v < V; ++v) {
+      float x = row[v];
+      if (x > best) { best = x; bi = v; }  // strict '>' => first maximum wins
+    }
+    const int64_t g = row0 + r;          // g = t*B + b
+    const int t = (int)(g / B), b = (int)(g - (int64_t)t * B);
+    ids_bt[(int64_t)b * T + t] = bi;
+    maxv_bt[(int64_t)b * T + t] = best;
+  }
+}
+
+// Large-V path: one wave per row, lanes stride over V, shuffle arg-reduction
+// with lowest-index tie-break.
+__global__ __launch_bounds__(256) void frame_argmax_large_v(
+    const float* __restrict__ logits, int rows, int T, int B, int V,
+    int32_t* __restrict__ ids_bt, float* __restrict__ maxv_bt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= rows) return;
+  const float* row = logits + g * V;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) {
+    float x = row[v];
+    if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+  }
+  // NaN-free inputs assumed (as in the reference); all-(-inf) rows give id 0.
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) {
+    if (bi == 0x7fffffff) bi = 0;
+    const int t = (int)(g / B), b = (int)(g - (int64_t)t * B);
+    ids_bt[(int64_t)b * T + t] = bi;
+    maxv_bt[(int64_t)b * T + t] = best;
+  }
+}
+
+constexpr int kCompactThreads = 256;
+
+__global__ __launch_bounds__(kCompactThreads) void greedy_compact(
+    const int32_t* __restrict__ ids_bt, const float* __restrict__ maxv_bt,
+    const int32_t* __restrict__ seq_len, int T, int blank, int merge_repeated,
+    int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
+    float* __restrict__ neg_sum_logits) {
+  __shared__ int wave_cnt[kCompactThreads / 64];
+  __shared__ float wave_sumv[kCompactThreads / 64];
+  __shared__ int base_s;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int len = seq_len[b];
+  len = len < 0 ? 0 : (len > T ? T : len);
+  const int32_t* ids = ids_bt + (int64_t)b * T;
+  const float* mv = maxv_bt + (int64_t)b * T;
+  int32_t* out = out_ids + (int64_t)b * T;
+  if (threadIdx.x == 0) base_s = 0;
+  float acc = 0.f;
+  __syncthreads();
+  for (int t0 = 0; t0 < len; t0 += kCompactThreads) {
+    const int t = t0 + threadIdx.x;
+    bool keep = false;
+    int id = -1;
+    if (t < len) {
+      id = ids[t];
+      acc += mv[t];
+      keep = (id != blank);
+      if (keep && merge_repeated && t > 0 && ids[t - 1] == id) keep = false;
+    }
+    const unsigned long long m = __ballot(keep);
+    const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+    if (keep) out[off + prefix] = id;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int s = 0;
+      for (int w = 0; w < kCompactThreads / 64; ++w) s += wave_cnt[w];
+      base_s += s;
+    }
+    __syncthreads();
+  }
+  const int n = base_s;
+  for (int t = n + threadIdx.x; t < T; t += kCompactThreads) out[t] = -1;
+  // deterministic block reduction of the path score
+  float s = wave_sum(acc);
+  if (lane == 0) wave_sumv[wid] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out_len[b] = n;
+    if (neg_sum_logits) {
+      float tot = 0.f;
+      for (int w = 0; w < kCompactThreads / 64; ++w) tot += wave_sumv[w];
+      neg_sum_logits[b] = -tot;
+    }
+  }
+}
+
+}  // namespace os2s
+
+extern "C" size_t os2s_ctc_greedy_decode_workspace_bytes(int T, int B) {
+  if (T < 0 || B < 0) return 0;
+  return (size_t)T * (size_t)B * (sizeof(int32_t) + sizeof(float));
+}
+
+extern "C" int os2s_ctc_greedy_decode(os2s_stream_t stream_, const float* logits,
+                                      const int32_t* seq_len, int T, int B, int V,
+                                      int blank, int merge_repeated,
+                                      int32_t* out_ids, int32_t* out_len,
+                                      float* neg_sum_logits, void* workspace,
+                                      size_t workspace_bytes) {
+  using namespace os2s;
+  OS2S_REQUIRE(T >= 0 && B >= 0 && V >= 1);
+  OS2S_REQUIRE(out_len != nullptr && seq_len != nullptr);
+  if (B == 0) return OS2S_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (T > 0) {
+    OS2S_REQUIRE(logits && out_ids && workspace);
+    if (workspace_bytes < os2s_ctc_greedy_decode_workspace_bytes(T, B))
+      return OS2S_ERR_WORKSPACE;
+  }
+  int32_t* ids_bt = (int32_t*)workspace;
+  float* maxv_bt = (float*)((char*)workspace + (size_t)T * B * sizeof(int32_t));
+  const int64_t rows = (int64_t)T * B;
+  if (rows > 0) {
+    OS2S_REQUIRE(rows < (1ll << 31));
+    const int ldv = (V & 1) ? V : V + 1;
+    const size_t smem = (size_t)kArgmaxThreads * ldv * sizeof(float);
+    if (smem <= 64 * 1024) {
+      dim3 grid(ceil_div(rows, kArgmaxThreads));
+      hipLaunchKernelGGL(frame_argmax_small_v<kArgmaxThreads>, grid,
+                         dim3(kArgmaxThreads), smem, stream, logits, (int)rows, T,
+                         B, V, ids_bt, maxv_bt);
+    } else {
+      dim3 grid(ceil_div(rows, 4));
+      hipLaunchKernelGGL(frame_argmax_large_v, grid, dim3(256), 0, stream, logits,
+                         (int)rows, T, B, V, ids_bt, maxv_bt);
+    }
+    OS2S_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(greedy_compact, dim3(B), dim3(kCompactThreads), 0, stream,
+                     ids_bt, maxv_bt, seq_len, T, blank, merge_repeated ? 1 : 0,
+                     out_ids, out_len, neg_sum_logits);
+  OS2S_CHECK_LAUNCH();
+  return OS2S_OK;
+}

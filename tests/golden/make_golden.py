@@ -1,0 +1,43 @@
+"""Generates the committed golden fixtures under tests/golden/ from the
+reference checkout (only runnable where /root/reference exists).
+
+  ctc_test_logits.npy  <- ctc_decoder_with_lm/ctc-test.pickle  (float32 [184,1,29])
+  ctc_test_meta.json   <- the expectations asserted by the reference's own test
+                          ctc_decoder_with_lm/ctc-test.py:60-78 and the vocabulary
+                          open_seq2seq/test_utils/toy_speech_data/vocab.txt
+"""
+import json
+import os
+import pickle
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+  with open(os.path.join(REF, "ctc_decoder_with_lm", "ctc-test.pickle"), "rb") as f:
+    seq, label = pickle.load(f, encoding="latin1")
+  seq = np.asarray(seq, dtype=np.float32)
+  assert seq.shape == (184, 1, 29)
+  np.save(os.path.join(OUT, "ctc_test_logits.npy"), seq)
+  with open(os.path.join(REF, "open_seq2seq", "test_utils", "toy_speech_data",
+                         "vocab.txt")) as f:
+    vocab = [line[0] for line in f.read().split("\n") if len(line) > 0]
+  meta = {
+      "source": "ctc_decoder_with_lm/ctc-test.pickle",
+      "label": str(label),
+      "vocab": vocab,
+      # ctc_decoder_with_lm/ctc-test.py:66-67
+      "greedy_text": "then seconds",
+      "greedy_neg_sum_logits": -7079.117,
+      "tol": 1e-3,
+  }
+  with open(os.path.join(OUT, "ctc_test_meta.json"), "w") as f:
+    json.dump(meta, f, indent=1)
+  print("wrote", OUT)
+
+
+if __name__ == "__main__":
+  main()
