@@ -42,6 +42,8 @@ enum {
 int os2s_abi_version(void);
 /* Human-readable description of an error code. */
 const char* os2s_strerror(int code);
+/* Detail of the last failed kernel launch on this thread (HIP error string). */
+const char* os2s_last_error_detail(void);
 
 /* ------------------------------------------------------------------------
  * CTC greedy (best-path) decode.

@@ -31,16 +31,28 @@ def lib():
           "libos2s_hip.so not found at %s. Build it with "
           "`python -c 'import __graft_entry__ as g; g.build()'` "
           "(there is no CPU fallback for the HIP path)." % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so). Device
+    # pointers and streams are only valid inside ONE runtime instance, so make
+    # sure torch's copy is the one already mapped (same soname) before our
+    # library, which links libamdhip64.so.7, is loaded.
+    import torch  # noqa: F401
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tlib):
+      ctypes.CDLL(tlib, mode=ctypes.RTLD_GLOBAL)
     _lib = ctypes.CDLL(LIB_PATH)
     _lib.os2s_strerror.restype = ctypes.c_char_p
     _lib.os2s_strerror.argtypes = [c_int]
     _lib.os2s_abi_version.restype = c_int
+    _lib.os2s_last_error_detail.restype = ctypes.c_char_p
   return _lib
 
 
 def check(code, what=""):
   if code != 0:
     msg = lib().os2s_strerror(int(code)).decode()
+    detail = lib().os2s_last_error_detail().decode()
+    if detail:
+      msg += " [" + detail + "]"
     raise Os2sError("%s failed: %s (code %d)" % (what or "os2s call", msg, code))
 
 

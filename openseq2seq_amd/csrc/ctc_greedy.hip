@@ -191,19 +191,17 @@ extern "C" int os2s_ctc_greedy_decode(os2s_stream_t stream_, const float* logits
     const size_t smem = (size_t)kArgmaxThreads * ldv * sizeof(float);
     if (smem <= 64 * 1024) {
       dim3 grid(ceil_div(rows, kArgmaxThreads));
-      hipLaunchKernelGGL(frame_argmax_small_v<kArgmaxThreads>, grid,
-                         dim3(kArgmaxThreads), smem, stream, logits, (int)rows, T,
-                         B, V, ids_bt, maxv_bt);
+      OS2S_LAUNCH(frame_argmax_small_v<kArgmaxThreads>, grid,
+                  dim3(kArgmaxThreads), smem, stream, logits, (int)rows, T, B, V,
+                  ids_bt, maxv_bt);
     } else {
       dim3 grid(ceil_div(rows, 4));
-      hipLaunchKernelGGL(frame_argmax_large_v, grid, dim3(256), 0, stream, logits,
-                         (int)rows, T, B, V, ids_bt, maxv_bt);
+      OS2S_LAUNCH(frame_argmax_large_v, grid, dim3(256), 0, stream, logits,
+                  (int)rows, T, B, V, ids_bt, maxv_bt);
     }
-    OS2S_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(greedy_compact, dim3(B), dim3(kCompactThreads), 0, stream,
-                     ids_bt, maxv_bt, seq_len, T, blank, merge_repeated ? 1 : 0,
-                     out_ids, out_len, neg_sum_logits);
-  OS2S_CHECK_LAUNCH();
+  OS2S_LAUNCH(greedy_compact, dim3(B), dim3(kCompactThreads), 0, stream,
+              ids_bt, maxv_bt, seq_len, T, blank, merge_repeated ? 1 : 0, out_ids,
+              out_len, neg_sum_logits);
   return OS2S_OK;
 }

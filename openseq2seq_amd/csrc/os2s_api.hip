@@ -1,5 +1,6 @@
 // Library-level entry points of the C ABI.
 #include "os2s_common.hpp"
+#include <cstdio>
 
 extern "C" int os2s_abi_version(void) { return 1; }
 
@@ -13,3 +14,13 @@ extern "C" const char* os2s_strerror(int code) {
     default: return "unknown error";
   }
 }
+
+// Last HIP runtime error seen by a failed launch (diagnostics only).
+static thread_local char g_last_err[256] = "";
+
+extern "C" void os2s_record_hip_error(int hip_error, const char* where) {
+  snprintf(g_last_err, sizeof(g_last_err), "%s: %s (%d)", where,
+           hipGetErrorString((hipError_t)hip_error), hip_error);
+}
+
+extern "C" const char* os2s_last_error_detail(void) { return g_last_err; }

@@ -5,11 +5,21 @@
 
 #include "../../include/os2s.h"
 
-#define OS2S_CHECK_LAUNCH()                                   \
-  do {                                                        \
-    hipError_t e__ = hipGetLastError();                       \
-    if (e__ != hipSuccess) return OS2S_ERR_LAUNCH;            \
+// hipGetLastError() is sticky per thread and also reports benign errors left
+// behind by other HIP users in the process (e.g. PyTorch's event queries), so
+// every launch is bracketed: clear first, then check.
+#define OS2S_LAUNCH(kernel, grid, block, smem, stream, ...)              \
+  do {                                                                   \
+    (void)hipGetLastError();                                             \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);  \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      os2s_record_hip_error((int)e__, #kernel);                          \
+      return OS2S_ERR_LAUNCH;                                            \
+    }                                                                    \
   } while (0)
+
+extern "C" void os2s_record_hip_error(int hip_error, const char* where);
 
 #define OS2S_REQUIRE(cond) \
   do {                     \
