@@ -68,6 +68,42 @@ int os2s_ctc_greedy_decode(os2s_stream_t stream, const float* logits,
                            int32_t* out_len, float* neg_sum_logits,
                            void* workspace, size_t workspace_bytes);
 
+/* ------------------------------------------------------------------------
+ * 1-D convolution as implicit GEMM on the matrix cores (bf16 in, fp32 accumulate).
+ * Replaces tf.layers.conv1d(use_bias=False) of conv_bn_actv / conv_bn_res_bn_actv
+ * (open_seq2seq/parts/cnns/conv_blocks.py:195-206, 78-85, 118-129) including the
+ * sequence mask the TDNN encoder multiplies onto every conv INPUT
+ * (open_seq2seq/encoders/tdnn_encoder.py:185-186, 204-205); with K = 1 it is the
+ * dense layer of FullyConnectedTimeDecoder (decoders/fc_decoders.py:135-148).
+ *
+ *   y[b,t,co] = sum_k sum_ci x[b, t*stride + k*dil - padL, ci] * w[k][co][ci] (+ bias[co])
+ *
+ *   x      [B, Tin, Cin] bf16, channels-last; rows t >= in_len[b] read as zero
+ *          when in_len != NULL (fused mask), rows outside [0,Tin) are padding.
+ *   w      [K, Cout, Cin] bf16 (Cin contiguous). NOTE: the reference (TF) stores
+ *          [K, Cin, Cout]; the host layer transposes on import/export.
+ *   y      bf16 (out_f32 = 0) or fp32 (out_f32 = 1), element strides
+ *          y_stride_b / y_stride_t (channel stride 1) — e.g. time-major logits
+ *          [T, B, V] use y_stride_b = V, y_stride_t = B*V.
+ *   padL   left padding; TF "SAME": total = max((ceil(Tin/stride)-1)*stride +
+ *          (K-1)*dil + 1 - Tin, 0), padL = total/2 (extra pad goes right).
+ *   stats  optional fp32 [os2s_conv1d_num_mtiles(B,Tout), 2, Cout]: per-tile
+ *          per-channel (sum, sum of squares) of the bf16-rounded outputs over the
+ *          tile's valid rows — the partial sums BatchNorm needs (K5 fused).
+ *   accumulate  1: y += result (used to sum data-gradients of several consumers).
+ * The data-gradient of a stride-1 conv is this same entry point applied to dY
+ * with the tap-flipped, transposed weight copy wT[k'][ci][co] = w[K-1-k'][co][ci]
+ * and padL' = (K-1)*dil - padL.
+ * Requirements: Cin % 8 == 0; for bf16 output Cout % 8 == 0 and strides % 8 == 0.
+ * ---------------------------------------------------------------------- */
+int os2s_conv1d_num_mtiles(int B, int Tout);
+int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
+                    void* y, const int32_t* in_len, const float* bias,
+                    float* stats, int B, int Tin, int Cin, int Cout, int K,
+                    int stride, int dil, int padL, int Tout,
+                    long long y_stride_b, long long y_stride_t, int out_f32,
+                    int accumulate);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,54 @@ def ctc_greedy_decode(logits, seq_len, blank=None, merge_repeated=True):
                _ptr(lens), _ptr(neg), _ptr(ws), nbytes),
              "os2s_ctc_greedy_decode")
   return ids, lens, neg
+
+
+# --------------------------------------------------------------------------
+# conv1d (implicit GEMM)
+# --------------------------------------------------------------------------
+c_ll = _lib.ctypes.c_longlong
+
+
+def same_padding(tin, k, stride, dil):
+  """TF 'SAME' padding (asymmetric when stride > 1): returns (tout, pad_left)."""
+  tout = (tin + stride - 1) // stride
+  total = max((tout - 1) * stride + (k - 1) * dil + 1 - tin, 0)
+  return tout, total // 2
+
+
+def valid_padding(tin, k, stride, dil):
+  return (tin - (k - 1) * dil - 1) // stride + 1, 0
+
+
+def conv1d_num_mtiles(B, tout):
+  return int(_fn("os2s_conv1d_num_mtiles", (c_int, c_int))(B, tout))
+
+
+def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
+               bias=None, stats=None, out=None, out_f32=False, accumulate=False,
+               time_major=False):
+  """x [B,Tin,Cin] bf16, w [K,Cout,Cin] bf16 -> y [B,Tout,Cout] (or [Tout,B,Cout]
+  when time_major). pad_left/tout default to TF 'SAME'."""
+  B, Tin, Cin = x.shape
+  K, Cout, Cin2 = w.shape
+  assert Cin == Cin2
+  if pad_left is None or tout is None:
+    tout, pad_left = same_padding(Tin, K, stride, dil)
+  dt = torch.float32 if out_f32 else torch.bfloat16
+  if out is None:
+    shape = (tout, B, Cout) if time_major else (B, tout, Cout)
+    out = torch.empty(shape, dtype=dt, device=x.device)
+  if time_major:
+    ysb, yst = Cout, B * Cout
+  else:
+    ysb, yst = tout * Cout, Cout
+  f = _fn("os2s_conv1d_fwd",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+           c_ll, c_ll, c_int, c_int))
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16),
+               _ptr(out, dt), _ptr(in_len, torch.int32, True),
+               _ptr(bias, torch.float32, True), _ptr(stats, torch.float32, True),
+               B, Tin, Cin, Cout, K, stride, dil, pad_left, tout, ysb, yst,
+               int(out_f32), int(accumulate)), "os2s_conv1d_fwd")
+  return out

@@ -1,0 +1,334 @@
+// Implicit-GEMM 1-D convolution (channels-last, bf16 in, fp32 accumulate) on
+// the gfx950 matrix cores. One kernel serves:
+//   * forward conv1d of the TDNN/Jasper blocks   (tf.layers.conv1d, no bias —
+//     open_seq2seq/parts/cnns/conv_blocks.py:195-206), including the fused
+//     sequence mask on the conv INPUT (tdnn_encoder.py:185-186,204-205);
+//   * 1x1 residual projections (conv_blocks.py:78-85) and plain GEMMs (K = 1);
+//   * data-gradient (dgrad) of a stride-1 conv: the same kernel run on dY with
+//     the tap-flipped / transposed weight copy and padL' = (K-1)*dil - padL.
+//
+//   y[b,t,co] = sum_k sum_ci x[b, t*stride + k*dil - padL, ci] * w[k][co][ci]
+//
+// Design (MI355X-first):
+//   * tile = BM time steps of ONE batch item x BN output channels; the input
+//     time WINDOW (BM-1)*stride + (K-1)*dil + 1 rows x 64 channels is staged in
+//     LDS once per 64-channel chunk and re-used by all K taps (tap k just reads
+//     rows shifted by k*dil) — activations are fetched from L2/HBM once per tile,
+//     not K times; only the [BN x 64] weight tile streams per tap.
+//   * all global->LDS traffic is LDS-DMA (global_load_lds, 16 B/lane); rows out
+//     of range / past the sequence length are sourced from a zero page, so
+//     padding and the sequence mask cost nothing.
+//   * LDS images are 128-B rows with a 16-B-slot XOR swizzle (slot ^= (row>>1)&7)
+//     applied on the DMA *source* address and on the ds_read_b128 side, which is
+//     conflict-free for the 16-lane service groups of ds_read_b128.
+//   * MFMA 32x32x16 bf16, operands swapped (A = weights, B = activations) so each
+//     lane ends up with 4 consecutive output channels of one time row; the
+//     epilogue goes through LDS to emit full 16-B/lane coalesced row stores and
+//     the per-channel (sum, sum^2) partials BatchNorm needs — the conv output
+//     is not re-read to get batch statistics.
+//   * double-buffered LDS; the DMA of step s+1 is in flight during the MFMAs of
+//     step s; one barrier per step; 2 workgroups per CU.
+//   * XCD-aware block order: the blocks resident on one XCD at a time share the
+//     same weight n-tile, so the weight stream is an L2 hit for all but one.
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  void* y;
+  const int32_t* in_len;
+  const float* bias;
+  float* stats;
+  int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
+  long long x_sb, x_st, y_sb, y_st;
+  int out_f32, accumulate;
+  int mtiles_per_b, MT, MT8, NT, nchunks, R, Rpad;
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_igemm_kernel(
+    ConvArgs p) {
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be 32-aligned");
+  static_assert((BN * 8) % (NW * 64) == 0, "weight tile DMA split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+
+  // ---- block -> tile (XCD-aware: see header) ------------------------------
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int n_idx = loc / p.MT8;
+  const int m_idx = (loc - n_idx * p.MT8) * 8 + xcd;
+  if (m_idx >= p.MT) return;
+  const int b = m_idx / p.mtiles_per_b;
+  const int t0 = (m_idx - b * p.mtiles_per_b) * BM;
+  const int n0 = n_idx * BN;
+
+  int len_b = p.Tin;
+  if (p.in_len) {
+    int l = p.in_len[b];
+    len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+  }
+  const int win_t0 = t0 * p.stride - p.padL;
+  const int xbuf_bytes = p.Rpad * 128;
+  char* const xbuf0 = smem;
+  char* const wbuf0 = smem + 2 * xbuf_bytes;
+  const bf16_t* const xb = p.x + (long long)b * p.x_sb;
+  const char* const zero = reinterpret_cast<const char*>(g_zero_page);
+
+  auto stage_x = [&](int c, char* dst) {
+    const int npieces = p.Rpad * 8;  // multiple of 64
+    for (int base = wid * 64; base < npieces; base += NW * 64) {
+      const int q = base + lane;
+      const int r = q >> 3, jj = q & 7;
+      const int j = jj ^ ((r >> 1) & 7);
+      const int tin = win_t0 + r;
+      const int ch = c * 64 + j * 8;
+      const bool ok = (r < p.R) && (tin >= 0) && (tin < len_b) && (ch < p.Cin);
+      const void* src = ok ? (const void*)(xb + (long long)tin * p.x_st + ch)
+                           : (const void*)(zero + jj * 16);
+      dma16(src, dst + base * 16);
+    }
+  };
+  auto stage_w = [&](int c, int k, char* dst) {
+#pragma unroll
+    for (int it = 0; it < (BN * 8) / (NW * 64); ++it) {
+      const int base = (it * NW + wid) * 64;
+      const int q = base + lane;
+      const int row = q >> 3, jj = q & 7;
+      const int j = jj ^ ((row >> 1) & 7);
+      int n = n0 + row;
+      n = n < p.Cout ? n : p.Cout - 1;
+      const int ch = c * 64 + j * 8;
+      const void* src =
+          (ch < p.Cin)
+              ? (const void*)(p.w + ((long long)k * p.Cout + n) * p.Cin + ch)
+              : (const void*)(zero + jj * 16);
+      dma16(src, dst + base * 16);
+    }
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int im = 0; im < MI; ++im)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[in][im][e] = 0.f;
+
+  const int nsteps = p.nchunks * p.K;
+  stage_x(0, xbuf0);
+  stage_w(0, 0, wbuf0);
+  int c = 0, k = 0;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int step = 0; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int kn = k + 1, cn = c;
+    if (kn == p.K) { kn = 0; cn = c + 1; }
+    if (step + 1 < nsteps) {
+      if (kn == 0) stage_x(cn, xbuf0 + (cn & 1) * xbuf_bytes);
+      stage_w(cn, kn, wbuf0 + ((step + 1) & 1) * (BN * 128));
+    }
+    const char* const xs = xbuf0 + (c & 1) * xbuf_bytes;
+    const char* const ws = wbuf0 + (step & 1) * (BN * 128);
+    const int rbase = (wm * WTM + l31) * p.stride + k * p.dil;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int j = kk * 2 + lhi;
+      bf16x8 xa[MI], wb[NI];
+#pragma unroll
+      for (int im = 0; im < MI; ++im) {
+        const int r = rbase + im * 32 * p.stride;
+        xa[im] = *reinterpret_cast<const bf16x8*>(xs + r * 128 + ((j ^ ((r >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int in = 0; in < NI; ++in) {
+        const int n = wn * WTN + in * 32 + l31;
+        wb[in] = *reinterpret_cast<const bf16x8*>(ws + n * 128 + ((j ^ ((n >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int in = 0; in < NI; ++in)
+#pragma unroll
+        for (int im = 0; im < MI; ++im)
+          acc[in][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[in], xa[im], acc[in][im], 0, 0, 0);
+    }
+    c = cn;
+    k = kn;
+  }
+
+  // ---- epilogue ------------------------------------------------------------
+  const int valid_rows = min(BM, p.Tout - t0);
+  if (p.out_f32) {
+    // small/rare path (FC logits): scattered fp32 stores straight from registers
+    float* const yb = reinterpret_cast<float*>(p.y) + (long long)b * p.y_sb;
+#pragma unroll
+    for (int in = 0; in < NI; ++in)
+#pragma unroll
+      for (int im = 0; im < MI; ++im) {
+        const int tt = wm * WTM + im * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int cc = n0 + wn * WTN + in * 32 + 8 * (e >> 2) + 4 * lhi + (e & 3);
+          if (tt < valid_rows && cc < p.Cout) {
+            float v = acc[in][im][e];
+            if (p.bias) v += p.bias[cc];
+            float* dst = yb + (long long)(t0 + tt) * p.y_st + cc;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    return;
+  }
+
+  constexpr int OP = BN * 2 + 16;  // out-tile pitch in bytes
+  __syncthreads();                 // every wave is done reading the staging buffers
+  char* const ot = smem;
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      const int tt = wm * WTM + im * 32 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cc = wn * WTN + in * 32 + 8 * g + 4 * lhi;
+        float v0 = acc[in][im][4 * g + 0], v1 = acc[in][im][4 * g + 1];
+        float v2 = acc[in][im][4 * g + 2], v3 = acc[in][im][4 * g + 3];
+        if (p.bias) {
+          const int gc = n0 + cc;
+          if (gc + 3 < p.Cout) {
+            v0 += p.bias[gc]; v1 += p.bias[gc + 1]; v2 += p.bias[gc + 2]; v3 += p.bias[gc + 3];
+          }
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(v0, v1);
+        pk[1] = pack2bf(v2, v3);
+        *reinterpret_cast<u32x2*>(ot + tt * OP + cc * 2) = pk;
+      }
+    }
+  __syncthreads();
+
+  bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
+  for (int q = tid; q < BM * (BN / 8); q += NTHR) {
+    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+    const int gc = n0 + c8 * 8;
+    if (row < valid_rows && gc < p.Cout) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OP + c8 * 16);
+      bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
+      if (p.accumulate) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      }
+      *reinterpret_cast<u32x4*>(dst) = v;
+    }
+  }
+
+  if (p.stats) {
+    constexpr int CP = BN / 2;       // column pairs
+    constexpr int RG = NTHR / CP;    // row groups
+    static_assert(NTHR % CP == 0, "stats split");
+    const int cp = tid % CP, rg = tid / CP;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    for (int row = rg; row < valid_rows; row += RG) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(ot + row * OP + cp * 4);
+      const float a = bflo(v), bb = bfhi(v);
+      s0 += a; q0 += a * a;
+      s1 += bb; q1 += bb * bb;
+    }
+    float* sc = reinterpret_cast<float*>(smem + BM * OP);  // [RG][BN][2]
+    sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
+    sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
+    sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
+    sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, qq = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        s += sc[(g * BN + tid) * 2 + 0];
+        qq += sc[(g * BN + tid) * 2 + 1];
+      }
+      const int gc = n0 + tid;
+      if (gc < p.Cout) {
+        p.stats[((long long)m_idx * 2 + 0) * p.Cout + gc] = s;
+        p.stats[((long long)m_idx * 2 + 1) * p.Cout + gc] = qq;
+      }
+    }
+  }
+}
+
+constexpr int kConvBM = 128, kConvBN = 128;
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv(hipStream_t stream, ConvArgs& a) {
+  constexpr int NTHR = WM * WN * 64;
+  a.mtiles_per_b = ceil_div(a.Tout, BM);
+  a.MT = a.B * a.mtiles_per_b;
+  a.MT8 = ceil_div(a.MT, 8);
+  a.NT = ceil_div(a.Cout, BN);
+  a.nchunks = ceil_div(a.Cin, 64);
+  a.R = (BM - 1) * a.stride + (a.K - 1) * a.dil + 1;
+  a.Rpad = ceil_div(a.R, 8) * 8;
+  size_t main_bytes = (size_t)2 * a.Rpad * 128 + (size_t)2 * BN * 128;
+  size_t epi_bytes = (size_t)BM * (BN * 2 + 16) + (size_t)(NTHR / (BN / 2)) * BN * 2 * 4;
+  size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
+  static size_t attr_set = 0;
+  if (smem > attr_set) {
+    if (hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return OS2S_ERR_LAUNCH;
+    attr_set = 160 * 1024;
+  }
+  const int grid = a.MT8 * 8 * a.NT;
+  OS2S_LAUNCH((conv1d_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NTHR), smem,
+              stream, a);
+  return OS2S_OK;
+}
+
+}  // namespace os2s
+
+extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
+  return B * os2s::ceil_div(Tout, os2s::kConvBM);
+}
+
+extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x,
+                               const uint16_t* w, void* y, const int32_t* in_len,
+                               const float* bias, float* stats, int B, int Tin,
+                               int Cin, int Cout, int K, int stride, int dil,
+                               int padL, int Tout, long long y_stride_b,
+                               long long y_stride_t, int out_f32, int accumulate) {
+  using namespace os2s;
+  OS2S_REQUIRE(x && w && y);
+  OS2S_REQUIRE(B >= 0 && Tin >= 1 && Tout >= 1 && Cin >= 8 && Cout >= 1 && K >= 1);
+  OS2S_REQUIRE(stride >= 1 && dil >= 1);
+  OS2S_REQUIRE(Cin % 8 == 0);
+  if (!out_f32) OS2S_REQUIRE(Cout % 8 == 0 && y_stride_t % 8 == 0 && y_stride_b % 8 == 0);
+  if (B == 0) return OS2S_OK;
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.in_len = in_len; a.bias = bias; a.stats = stats;
+  a.B = B; a.Tin = Tin; a.Tout = Tout; a.Cin = Cin; a.Cout = Cout; a.K = K;
+  a.stride = stride; a.dil = dil; a.padL = padL;
+  a.x_sb = (long long)Tin * Cin; a.x_st = Cin;
+  a.y_sb = y_stride_b; a.y_st = y_stride_t;
+  a.out_f32 = out_f32; a.accumulate = accumulate;
+  return launch_conv<kConvBM, kConvBN, 2, 2>((hipStream_t)stream, a);
+}

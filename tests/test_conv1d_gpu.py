@@ -1,0 +1,108 @@
+"""GPU parity: os2s_conv1d_fwd (MFMA implicit GEMM) vs the CPU oracle.
+Floating point: inputs are bf16-rounded identically on both sides, the oracle
+accumulates in fp32; tolerance = bf16 output rounding (2^-8 relative) + fp32
+accumulation-order noise: rtol 1e-2, atol 1e-2 * rms(y)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cnn  # noqa: E402
+
+
+def _bf(x):
+  return torch.as_tensor(x).to(torch.bfloat16)
+
+
+def _check(y, ref, extra=1.0):
+  y = y.float().cpu()
+  scale = float(ref.pow(2).mean().sqrt()) + 1e-6
+  torch.testing.assert_close(y, ref, rtol=1e-2 * extra, atol=1e-2 * scale * extra)
+
+
+CASES = [
+    # B, T, Cin, Cout, K, s, d
+    (2, 200, 64, 256, 11, 2, 1),     # Jasper layer 1 (stride 2, asymmetric SAME)
+    (3, 171, 256, 256, 11, 1, 1),    # Jasper B1 (ragged T vs BM=128)
+    (2, 140, 768, 896, 29, 1, 2),    # dilated K=29
+    (2, 130, 896, 1024, 1, 1, 1),    # 1x1
+    (1, 64, 72, 200, 5, 1, 1),       # Cin tail chunk, Cout not multiple of 128
+    (2, 300, 128, 128, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,K,s,d", CASES)
+def test_conv_fwd(cuda, B, T, Cin, Cout, K, s, d):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(B * 1000 + T + K)
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = _bf(torch.randn(K, Cin, Cout, generator=g) * (1.0 / (K * Cin) ** 0.5))
+  lens = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  ref = cnn.conv1d_tf(x.float(), w_tf.float(), s, d, "SAME", mask_len=lens)
+  tout = ref.shape[1]
+  nm = capi.conv1d_num_mtiles(B, tout)
+  stats = torch.full((nm, 2, Cout), float("nan"), device=cuda)
+  y = capi.conv1d_fwd(x.to(cuda), cnn.to_dev_layout(w_tf).to(cuda), stride=s, dil=d,
+                      in_len=lens.to(cuda), stats=stats)
+  torch.cuda.synchronize()
+  assert tuple(y.shape) == (B, tout, Cout)
+  _check(y, ref)
+  # fused BN partial sums: computed from the bf16-ROUNDED outputs
+  yr = y.float().cpu()
+  s1 = stats[:, 0, :].sum(0).cpu()
+  s2 = stats[:, 1, :].sum(0).cpu()
+  torch.testing.assert_close(s1, yr.sum((0, 1)), rtol=1e-4, atol=1e-2)
+  torch.testing.assert_close(s2, yr.pow(2).sum((0, 1)), rtol=1e-4, atol=1e-2)
+
+
+def test_conv_valid_padding_and_accumulate(cuda):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(5)
+  B, T, Cin, Cout, K = 2, 90, 64, 128, 7
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = _bf(torch.randn(K, Cin, Cout, generator=g) * 0.05)
+  ref = cnn.conv1d_tf(x.float(), w_tf.float(), 1, 1, "VALID")
+  tout, pl = capi.valid_padding(T, K, 1, 1)
+  y0 = _bf(torch.randn(B, tout, Cout, generator=g))
+  y = y0.clone().to(cuda)
+  capi.conv1d_fwd(x.to(cuda), cnn.to_dev_layout(w_tf).to(cuda), pad_left=pl, tout=tout,
+                  out=y, accumulate=True)
+  torch.cuda.synchronize()
+  _check(y, ref + y0.float(), extra=2.0)
+
+
+def test_fc_logits_time_major_fp32(cuda):
+  """FullyConnectedTimeDecoder: dense(V=29, bias) -> time-major fp32 logits."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(9)
+  B, T, C, V = 3, 77, 1024, 29
+  x = _bf(torch.randn(B, T, C, generator=g))
+  w_tf = _bf(torch.randn(1, C, V, generator=g) * 0.03)
+  bias = torch.randn(V, generator=g)
+  ref = cnn.conv1d_tf(x.float(), w_tf.float()) + bias
+  y = capi.conv1d_fwd(x.to(cuda), cnn.to_dev_layout(w_tf).to(cuda), bias=bias.to(cuda),
+                      out_f32=True, time_major=True)
+  torch.cuda.synchronize()
+  assert tuple(y.shape) == (T, B, V) and y.dtype == torch.float32
+  torch.testing.assert_close(y.cpu().permute(1, 0, 2), ref, rtol=1e-4, atol=1e-3)
+
+
+def test_dgrad_via_flipped_weights(cuda):
+  """dX of a stride-1 SAME conv == conv of dY with tap-flipped transposed weights."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(11)
+  B, T, Cin, Cout, K, d = 2, 150, 128, 256, 13, 1
+  x = torch.randn(B, T, Cin, generator=g, requires_grad=True)
+  w_tf = _bf(torch.randn(K, Cin, Cout, generator=g) * 0.02)
+  dy = _bf(torch.randn(B, T, Cout, generator=g))
+  y = cnn.conv1d_tf(x, w_tf.float(), 1, d, "SAME")
+  y.backward(dy.float())
+  _, pl = capi.same_padding(T, K, 1, d)
+  # wT[k'][ci][co] = w_dev[K-1-k'][co][ci]  (w_dev = [K,Cout,Cin])
+  w_dev = cnn.to_dev_layout(w_tf)
+  wT = w_dev.flip(0).permute(0, 2, 1).contiguous()
+  dx = capi.conv1d_fwd(dy.to(cuda), wT.to(cuda), pad_left=(K - 1) * d - pl, tout=T)
+  torch.cuda.synchronize()
+  _check(dx, x.grad)
