@@ -104,6 +104,21 @@ int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     long long y_stride_b, long long y_stride_t, int out_f32,
                     int accumulate);
 
+/* ------------------------------------------------------------------------
+ * Weight gradient of os2s_conv1d_fwd (fp32 output, layout [K, Cout, Cin]):
+ *   dW[k][co][ci] (+)= sum_b sum_t dy[b,t,co] * x[b, t*stride + k*dil - padL, ci]
+ * with x rows >= in_len[b] read as zero (the masked conv input). This is the
+ * gradient TF derives for tf.layers.conv1d (conv_blocks.py:195-206); it is
+ * emitted in fp32 because MixedPrecisionOptimizerWrapper casts every gradient
+ * to fp32 first (optimizers/mp_wrapper.py:79).
+ *   accumulate = 0: dW is overwritten.  accumulate = 1: dW += (fp32 atomics; the
+ *   batch may be split across workgroups to fill the chip).
+ * ---------------------------------------------------------------------- */
+int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* dy,
+                      float* dw, const int32_t* in_len, int B, int Tin, int Cin,
+                      int Cout, int K, int stride, int dil, int padL, int Tout,
+                      int accumulate);
+
 #ifdef __cplusplus
 }
 #endif

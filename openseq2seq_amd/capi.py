@@ -117,3 +117,25 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
                B, Tin, Cin, Cout, K, stride, dil, pad_left, tout, ysb, yst,
                int(out_f32), int(accumulate)), "os2s_conv1d_fwd")
   return out
+
+
+def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
+                 out=None, accumulate=False):
+  """x [B,Tin,Cin] bf16, dy [B,Tout,Cout] bf16 -> dW [K,Cout,Cin] fp32."""
+  B, Tin, Cin = x.shape
+  B2, Tout, Cout = dy.shape
+  assert B == B2
+  if pad_left is None:
+    tout, pad_left = same_padding(Tin, K, stride, dil)
+    assert tout == Tout
+  if out is None:
+    assert not accumulate
+    out = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
+  f = _fn("os2s_conv1d_wgrad",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+           c_int, c_int, c_int, c_int, c_int, c_int, c_int))
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(dy, torch.bfloat16),
+               _ptr(out, torch.float32), _ptr(in_len, torch.int32, True), B, Tin,
+               Cin, Cout, K, stride, dil, pad_left, Tout, int(accumulate)),
+             "os2s_conv1d_wgrad")
+  return out

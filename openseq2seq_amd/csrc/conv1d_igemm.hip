@@ -34,8 +34,6 @@
 
 namespace os2s {
 
-__device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
-
 struct ConvArgs {
   const bf16_t* x;
   const bf16_t* w;

@@ -1,0 +1,266 @@
+// Weight-gradient of the channels-last 1-D convolution on the gfx950 matrix cores.
+//
+//   dW[k][co][ci] (+)= sum_b sum_t dY[b,t,co] * X[b, t*stride + k*dil - padL, ci]
+//
+// (the gradient TF derives for tf.layers.conv1d in conv_bn_actv /
+//  conv_bn_res_bn_actv, open_seq2seq/parts/cnns/conv_blocks.py:195-206; X rows
+//  past in_len[b] are zero because the encoder masks every conv input,
+//  tdnn_encoder.py:185-186,204-205). Output is fp32 — the mixed-precision
+//  wrapper casts every gradient to fp32 before anything else touches it
+//  (optimizers/mp_wrapper.py:79), so we never materialise a bf16 gradient.
+//
+// GEMM view per tap: M = Cout, N = Cin, reduction over (b, t). Both operands
+// have the reduction index (time) as their ROW index in memory ([t][c], c
+// contiguous), the opposite of what an MFMA fragment wants (8 consecutive
+// reduction elements per lane), so fragments are fetched with the CDNA4 LDS
+// transpose read ds_read_b64_tr_b16 from row-major [64 t][128 c] LDS tiles.
+//   * tiles arrive by LDS-DMA (16 B/lane); zero page for padding / masked rows;
+//   * 32-byte-unit XOR swizzle (unit ^= (row & 3) << 1) on DMA source + read
+//     side makes every tr read hit 8 distinct units = all 64 banks;
+//   * one workgroup computes TAPS (=2) adjacent taps from ONE dY tile and one
+//     (64 + dil)-row X window: halves L2->LDS bytes per FLOP;
+//   * grid = (co tile, ci tile, batch split) x tap pairs; tap pairs of one tile
+//     are adjacent on one XCD so dY/X tiles are L2 hits for all but the first;
+//   * batch splits are combined with fp32 atomics only when a layer is too
+//     small to fill the chip otherwise.
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+struct WgradArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;
+  const int32_t* in_len;
+  int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
+  int NCO, NCI, NTP, NSPLIT, b_per_split, use_atomic;
+  int xrows, xrows_pad;  // X window rows per 64-step (and padded to x4)
+};
+
+__device__ __forceinline__ void dma16w(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 lds_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4*)p);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
+  constexpr int BT = 64;  // reduction rows per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;  // wave tile 64 (co) x 64 (ci)
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int unit = (loc / p.NTP) * 8 + xcd;
+  const int tp = loc - (loc / p.NTP) * p.NTP;
+  const int nunits = p.NCO * p.NCI * p.NSPLIT;
+  if (unit >= nunits) return;
+  const int split = unit / (p.NCO * p.NCI);
+  const int rem = unit - split * (p.NCO * p.NCI);
+  const int co0 = (rem / p.NCI) * 128, ci0 = (rem % p.NCI) * 128;
+  const int k0 = tp * TAPS;
+  const int ntaps = min(TAPS, p.K - k0);
+
+  const int ybuf_bytes = BT * 256;
+  const int xbuf_bytes = p.xrows_pad * 256;
+  char* const ybuf0 = smem;
+  char* const xbuf0 = smem + 2 * ybuf_bytes;
+  const char* const zero = reinterpret_cast<const char*>(g_zero_page);
+
+  const int b_begin = split * p.b_per_split;
+  const int b_end = min(p.B, b_begin + p.b_per_split);
+  const int tchunks = (p.Tout + BT - 1) / BT;
+  const int nsteps = (b_end - b_begin) * tchunks;
+
+  auto stage = [&](int step, int buf) {
+    const int b = b_begin + step / tchunks;
+    const int t0 = (step - (step / tchunks) * tchunks) * BT;
+    int len_b = p.Tin;
+    if (p.in_len) {
+      int l = p.in_len[b];
+      len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+    }
+    // dY tile: 64 rows x 16 pieces
+    char* yd = ybuf0 + buf * ybuf_bytes;
+    const bf16_t* dyb = p.dy + (long long)b * p.Tout * p.Cout;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int base = (it * 4 + wid) * 64;
+      const int q = base + lane;
+      const int row = q >> 4, ps = q & 15;
+      const int u = (ps >> 1) ^ ((row & 3) << 1);
+      const int ch = co0 + ((u << 1) | (ps & 1)) * 8;
+      const int t = t0 + row;
+      const bool ok = (t < p.Tout) && (ch < p.Cout);
+      const void* src = ok ? (const void*)(dyb + (long long)t * p.Cout + ch)
+                           : (const void*)(zero + ps * 16);
+      dma16w(src, yd + base * 16);
+    }
+    // X window: xrows_pad rows x 16 pieces; LDS row r <-> input time tin0 + r
+    char* xd = xbuf0 + buf * xbuf_bytes;
+    const bf16_t* xb = p.x + (long long)b * p.Tin * p.Cin;
+    const int tin0 = t0 * p.stride + k0 * p.dil - p.padL;
+    const int npieces = p.xrows_pad * 16;
+    for (int base = wid * 64; base < npieces; base += 256) {
+      const int q = base + lane;
+      const int row = q >> 4, ps = q & 15;
+      const int u = (ps >> 1) ^ ((row & 3) << 1);
+      const int ch = ci0 + ((u << 1) | (ps & 1)) * 8;
+      const int tin = tin0 + row;
+      const bool ok = (row < p.xrows) && (tin >= 0) && (tin < len_b) && (ch < p.Cin);
+      const void* src = ok ? (const void*)(xb + (long long)tin * p.Cin + ch)
+                           : (const void*)(zero + ps * 16);
+      dma16w(src, xd + base * 16);
+    }
+  };
+
+  f32x16 acc[TAPS][2][2];
+#pragma unroll
+  for (int a = 0; a < TAPS; ++a)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
+
+  // per-lane constants of the transpose reads
+  const int g16 = (lane >> 4) & 1;   // which 16-column block of the 32-wide MFMA tile
+  const int i16 = lane & 15;
+  const int rsub = i16 >> 2;         // row within the 4-row block this lane addresses
+  const int csub = (i16 & 3) * 8;    // byte offset of its 4-element chunk
+  const int lhi = lane >> 5;
+
+  if (nsteps > 0) stage(0, 0);
+  for (int step = 0; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (step + 1 < nsteps) stage(step + 1, (step + 1) & 1);
+    const char* const ys = ybuf0 + (step & 1) * ybuf_bytes;
+    const char* const xs = xbuf0 + (step & 1) * xbuf_bytes;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      // A fragments (dY^T): rows = time kk*16 + lhi*8 + {0..7}, cols = co
+      bf16x8 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = ((wm * 64 + i * 32) >> 4) + g16;  // logical 32-B unit (16 channels)
+        const int r0 = kk * 16 + lhi * 8 + rsub;
+        const int r1 = r0 + 4;
+        const bf16x4 lo = lds_tr(ys + r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub);
+        const bf16x4 hi = lds_tr(ys + r1 * 256 + ((u ^ ((r1 & 3) << 1)) << 5) + csub);
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int a = 0; a < TAPS; ++a) {
+        if (a < ntaps) {
+          bf16x8 bfr[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int u = ((wn * 64 + j * 32) >> 4) + g16;
+            const int r0 = (kk * 16 + lhi * 8 + rsub) * p.stride + a * p.dil;
+            const int r1 = r0 + 4 * p.stride;
+            const bf16x4 lo = lds_tr(xs + r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub);
+            const bf16x4 hi = lds_tr(xs + r1 * 256 + ((u ^ ((r1 & 3) << 1)) << 5) + csub);
+            bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[a][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[a][i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: fp32 stores / atomics, ci contiguous across lanes ---------
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int a = 0; a < TAPS; ++a) {
+    if (a < ntaps) {
+      float* const dwk = p.dw + (long long)(k0 + a) * p.Cout * p.Cin;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ci = ci0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhi;
+            if (co < p.Cout && ci < p.Cin) {
+              float* dst = dwk + (long long)co * p.Cin + ci;
+              if (p.use_atomic)
+                __hip_atomic_fetch_add(dst, acc[a][i][j][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+              else
+                *dst = acc[a][i][j][e];
+            }
+          }
+        }
+    }
+  }
+}
+
+}  // namespace os2s
+
+// accumulate: 0 = dW is overwritten (one batch split) / must be pre-zeroed by
+// the caller when the kernel decides to split; to keep the contract simple the
+// caller always passes a buffer that is either zero or holds the running sum
+// it wants to add to, and sets accumulate accordingly:
+//   accumulate = 0 : dW = grad       (kernel never splits the batch)
+//   accumulate = 1 : dW += grad      (atomics; batch may be split for occupancy)
+extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
+                                 const uint16_t* dy, float* dw,
+                                 const int32_t* in_len, int B, int Tin, int Cin,
+                                 int Cout, int K, int stride, int dil, int padL,
+                                 int Tout, int accumulate) {
+  using namespace os2s;
+  OS2S_REQUIRE(x && dy && dw);
+  OS2S_REQUIRE(B >= 0 && Tin >= 1 && Tout >= 1 && Cin >= 8 && Cout >= 8 && K >= 1);
+  OS2S_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && stride >= 1 && dil >= 1);
+  if (B == 0) return OS2S_OK;
+  constexpr int TAPS = 2;
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = dw; a.in_len = in_len;
+  a.B = B; a.Tin = Tin; a.Tout = Tout; a.Cin = Cin; a.Cout = Cout; a.K = K;
+  a.stride = stride; a.dil = dil; a.padL = padL;
+  a.NCO = ceil_div(Cout, 128);
+  a.NCI = ceil_div(Cin, 128);
+  a.NTP = ceil_div(K, TAPS);
+  const int base_blocks = a.NCO * a.NCI * a.NTP;
+  int nsplit = 1;
+  if (accumulate) {
+    const int target = 1024;  // ~2 workgroups per CU x 2 waves of blocks
+    nsplit = ceil_div(target, base_blocks);
+    if (nsplit > B) nsplit = B;
+    if (nsplit < 1) nsplit = 1;
+  }
+  a.b_per_split = ceil_div(B, nsplit);
+  a.NSPLIT = ceil_div(B, a.b_per_split);
+  a.use_atomic = accumulate ? 1 : 0;
+  a.xrows = 63 * stride + (TAPS - 1) * dil + 1;
+  a.xrows_pad = ceil_div(a.xrows, 4) * 4;
+  const size_t smem = (size_t)2 * 64 * 256 + (size_t)2 * a.xrows_pad * 256;
+  if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<TAPS>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return OS2S_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nunits = a.NCO * a.NCI * a.NSPLIT;
+  const int grid = ceil_div(nunits, 8) * 8 * a.NTP;
+  OS2S_LAUNCH((conv1d_wgrad_kernel<TAPS>), dim3(grid), dim3(256), smem,
+              (hipStream_t)stream, a);
+  return OS2S_OK;
+}

@@ -80,6 +80,10 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   return (uint32_t)(z >> 32);
 }
 
+// 256 B of zeros: LDS-DMA source for padding rows / masked frames (one copy per
+// translation unit; device code is not linked across TUs).
+static __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace os2s

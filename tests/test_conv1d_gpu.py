@@ -106,3 +106,41 @@ def test_dgrad_via_flipped_weights(cuda):
   dx = capi.conv1d_fwd(dy.to(cuda), wT.to(cuda), pad_left=(K - 1) * d - pl, tout=T)
   torch.cuda.synchronize()
   _check(dx, x.grad)
+
+
+WG_CASES = [
+    (2, 200, 64, 256, 11, 2, 1),
+    (3, 171, 256, 256, 11, 1, 1),
+    (2, 140, 128, 384, 29, 1, 2),
+    (2, 130, 384, 128, 1, 1, 1),
+    (1, 64, 72, 200, 5, 1, 1),
+    (4, 100, 1024, 32, 1, 1, 1),   # FC weight-grad shape (V padded to 32)
+]
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,K,s,d", WG_CASES)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_conv_wgrad(cuda, B, T, Cin, Cout, K, s, d, accumulate):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(B * 77 + T + K)
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = (torch.randn(K, Cin, Cout, generator=g) * 0.05).requires_grad_(True)
+  lens = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  y = cnn.conv1d_tf(x.float(), w_tf, s, d, "SAME", mask_len=lens)
+  dy = _bf(torch.randn(y.shape, generator=g))
+  y.backward(dy.float())
+  ref = cnn.to_dev_layout(w_tf.grad)  # [K,Cout,Cin]
+  if accumulate:
+    base = torch.randn(K, Cout, Cin, generator=g)
+    out = base.clone().to(cuda)
+    capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, stride=s, dil=d, in_len=lens.to(cuda),
+                      out=out, accumulate=True)
+    ref = ref + base
+  else:
+    out = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, stride=s, dil=d,
+                            in_len=lens.to(cuda))
+  torch.cuda.synchronize()
+  scale = float(ref.pow(2).mean().sqrt()) + 1e-6
+  # fp32 accumulation of exact bf16 products: only summation-order noise
+  torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
