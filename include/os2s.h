@@ -119,6 +119,123 @@ int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* d
                       int Cout, int K, int stride, int dil, int padL, int Tout,
                       int accumulate);
 
+/* ------------------------------------------------------------------------
+ * BatchNorm + residual sum + activation + dropout + sequence mask
+ * (conv_bn_actv / conv_bn_res_bn_actv, open_seq2seq/parts/cnns/conv_blocks.py:61-232;
+ *  tf.nn.dropout at encoders/tdnn_encoder.py:255; mask at :185-186,204-205).
+ * All activations bf16 [B,T,C] channels-last; statistics / affine params fp32 [C].
+ * TF fused-BN conventions: normalise with the biased batch variance over all B*T
+ * positions (padded frames included); moving = moving*momentum + batch*(1-momentum)
+ * with Bessel-corrected batch variance.
+ * ---------------------------------------------------------------------- */
+/* partial [nparts,2,C] (sum, sumsq) -> mean/rstd (saved for backward), fused
+ * scale = gamma*rstd, shift = beta - mean*scale; training=0 uses moving stats. */
+int os2s_bn_finalize(os2s_stream_t stream, const float* partial, int nparts, int C,
+                     long long count, const float* gamma, const float* beta,
+                     float eps, float momentum, int training, float* moving_mean,
+                     float* moving_var, float* mean_out, float* rstd_out,
+                     float* scale_out, float* shift_out);
+/* stand-alone statistics partials for producers other than os2s_conv1d_fwd */
+int os2s_bn_stats_num_parts(long long rows);
+int os2s_bn_stats(os2s_stream_t stream, const uint16_t* y, long long rows, int C,
+                  float* partial);
+/* out = seqmask * dropout(act(sum_j y_j*scale_j + shift_j)); act: 0 none, 1 relu,
+ * 2 tanh; J <= 12 inputs (main conv + dense-residual branches). y/scale/shift are
+ * HOST arrays of J device pointers. */
+int os2s_bn_act_fwd(os2s_stream_t stream, int J, const uint16_t* const* y,
+                    const float* const* scale, const float* const* shift,
+                    uint16_t* out, const int32_t* out_len, int B, int T, int C,
+                    int act, float keep_prob, unsigned long long seed);
+/* backward pass 1: dz = dout * mask * dropout' * act'(out) (bf16) and per-channel
+ * partial sums partial[nparts][1+J][C] = {sum dz, sum dz*xhat_j}. */
+int os2s_bn_act_bwd_num_parts(long long rows);
+int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_t* dout,
+                           const uint16_t* out, const uint16_t* const* y,
+                           const float* const* mean, const float* const* rstd,
+                           uint16_t* dz, float* partial, const int32_t* out_len,
+                           int B, int T, int C, int act, float keep_prob,
+                           unsigned long long seed);
+/* reduce the partials for input q-1: dgamma (sum dz*xhat), dbeta (sum dz),
+ * c1 = mean(dz), c2 = mean(dz*xhat) */
+int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, int nparts,
+                         int nq, int q, int C, long long count, float* dgamma,
+                         float* dbeta, int accumulate, float* c1, float* c2);
+/* backward pass 2: dy = gamma*rstd*(dz - c1 - xhat*c2) */
+int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                      const float* gamma, const float* mean, const float* rstd,
+                      const float* c1, const float* c2, uint16_t* dy,
+                      long long rows, int C);
+/* test hook: the keep/drop bits (one byte per 8 consecutive elements) the
+ * dropout of os2s_bn_act_fwd uses for (seed, keep_prob). */
+int os2s_dropout_mask(os2s_stream_t stream, unsigned long long seed, long long n8,
+                      float keep_prob, uint8_t* out);
+
+/* ------------------------------------------------------------------------
+ * CTC loss + gradient w.r.t. logits. Replaces tf.nn.ctc_loss(...,
+ * ignore_longer_outputs_than_inputs=True) + mask_nans + reduce_mean
+ * (open_seq2seq/losses/ctc_loss.py:77-88); blank = V-1 in the reference.
+ *   logits [T,B,V] fp32 time-major (pre-softmax), in_len [B], labels [B,Lmax]
+ *   int32 (only the first label_len[b] entries are read, ctc_loss.py:12-16).
+ *   loss_per_sample [B] (= -log p, 0 for ignored / non-finite samples),
+ *   loss_mean [1] (mean over the whole batch), both optional.
+ *   dlogits [T,B,V] fp32 and/or dlogits_bf16 [B,T,Vpad] bf16 (zero padded
+ *   channels; feeds the FC backward GEMMs) = grad_scale * d(loss_b)/d(logits).
+ * ---------------------------------------------------------------------- */
+size_t os2s_ctc_loss_workspace_bytes(int T, int B, int V, int Lmax);
+int os2s_ctc_loss(os2s_stream_t stream, const float* logits, const int32_t* in_len,
+                  const int32_t* labels, const int32_t* label_len, int T, int B,
+                  int V, int Lmax, int blank, float grad_scale,
+                  float* loss_per_sample, float* loss_mean, float* dlogits,
+                  uint16_t* dlogits_bf16, int Vpad, void* workspace,
+                  size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------
+ * Mixed-precision optimizer step over flat fp32 buffers (device-side skip
+ * decision, no host sync). Replaces MixedPrecisionOptimizerWrapper
+ * (optimizers/mp_wrapper.py:27-122), AutomaticLossScaler Backoff/LogMax
+ * (automatic_loss_scaler.py:50-203), post_process_gradients LARC / global-norm
+ * clip (optimizers.py:289-482), NovoGrad (novograd.py:93-126), TF Momentum /
+ * Adam, and the lr policies (lr_policies.py) evaluated at the device-resident
+ * global step. Tensors start at multiples of os2s_opt_chunk_elems() elements.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int optimizer;               /* 0 SGD, 1 Momentum, 2 NovoGrad, 3 Adam */
+  float beta1, beta2, epsilon, weight_decay;
+  int grad_averaging;          /* NovoGrad: g *= (1-beta1) */
+  int lr_policy;               /* 0 fixed, 1 poly_decay, 2 exp_decay, 3 transformer_policy, 4 cosine_decay */
+  float learning_rate, min_lr, power, decay_rate, max_lr, coefficient;
+  long long decay_steps, begin_decay_at, warmup_steps;
+  int use_staircase_decay, d_model, has_max_lr;
+  int use_larc;
+  float larc_eta, larc_min_update, larc_epsilon;
+  int larc_mode_scale;         /* 0 'clip' (default), 1 'scale' */
+  float clip_global_norm;      /* <= 0: off */
+  int scaler;                  /* 0 static, 1 Backoff, 2 LogMax */
+  float scale_min, scale_max, step_factor;
+  long long step_window;
+  float log_max, lm_beta1, lm_beta2, overflow_std_dev;
+  int world_size;              /* gradients in the buffer are sums over ranks */
+} os2s_opt_config_t;
+
+int os2s_opt_chunk_elems(void);
+size_t os2s_opt_state_bytes(void);
+size_t os2s_opt_config_bytes(void);
+int os2s_opt_init_state(os2s_stream_t stream, void* state, float loss_scale);
+int os2s_opt_step(os2s_stream_t stream, const os2s_opt_config_t* cfg, void* state,
+                  const float* grads, float* weights, float* m1, float* m2,
+                  uint16_t* w16, int nchunks, int ntensors,
+                  const int32_t* chunk_tensor, const int32_t* tensor_chunk_begin,
+                  const float* tensor_l2, const float* tensor_wd_mask,
+                  float* partial, float* tensor_gnorm2, float* tensor_wnorm2,
+                  float* tensor_amax, float* tensor_mult, float* tensor_v);
+int os2s_cast_f32_to_bf16(os2s_stream_t stream, const float* src, uint16_t* dst,
+                          long long n);
+/* batched dgrad copies of conv weights: wT[k'][ci][co] = w[K-1-k'][co][ci];
+ * descs: device array of {int64 src_off, int64 dst_off, int32 K, Cout, Cin, tile_begin} */
+int os2s_conv_weight_dgrad_copy(os2s_stream_t stream, const uint16_t* w16,
+                                uint16_t* wt16, const void* descs, int ndesc,
+                                int total_tiles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,230 @@ def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
                Cin, Cout, K, stride, dil, pad_left, Tout, int(accumulate)),
              "os2s_conv1d_wgrad")
   return out
+
+
+# --------------------------------------------------------------------------
+# BatchNorm (+ residual sum + activation + dropout + mask)
+# --------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+def _ptr_array(tensors, dtype):
+  arr = (c_void_p * len(tensors))()
+  for i, t in enumerate(tensors):
+    arr[i] = _ptr(t, dtype).value
+  return arr
+
+
+def bn_finalize(partial, count, gamma, beta, eps, momentum, training, moving_mean,
+                moving_var, mean_out, rstd_out, scale_out, shift_out):
+  C = scale_out.numel()
+  nparts = 0 if partial is None else partial.shape[0]
+  f = _fn("os2s_bn_finalize",
+          (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_float,
+           c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(partial, torch.float32, True), nparts, C, int(count),
+               _ptr(gamma, torch.float32, True), _ptr(beta, torch.float32, True),
+               float(eps), float(momentum), int(training),
+               _ptr(moving_mean, torch.float32, True), _ptr(moving_var, torch.float32, True),
+               _ptr(mean_out, torch.float32, True), _ptr(rstd_out, torch.float32, True),
+               _ptr(scale_out, torch.float32), _ptr(shift_out, torch.float32)),
+             "os2s_bn_finalize")
+
+
+def bn_stats(y2d):
+  rows, C = y2d.shape
+  n = int(_fn("os2s_bn_stats_num_parts", (c_ll,))(rows))
+  partial = torch.empty((n, 2, C), dtype=torch.float32, device=y2d.device)
+  f = _fn("os2s_bn_stats", (c_void_p, c_void_p, c_ll, c_int, c_void_p))
+  _lib.check(f(_stream(), _ptr(y2d, torch.bfloat16), rows, C, _ptr(partial)), "os2s_bn_stats")
+  return partial
+
+
+def bn_act_fwd(ys, scales, shifts, out, out_len, act, keep_prob, seed):
+  B, T, C = out.shape
+  J = len(ys)
+  f = _fn("os2s_bn_act_fwd",
+          (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+           c_int, c_int, c_int, c_float, c_uint64))
+  _lib.check(f(_stream(), J, _ptr_array(ys, torch.bfloat16),
+               _ptr_array(scales, torch.float32), _ptr_array(shifts, torch.float32),
+               _ptr(out, torch.bfloat16), _ptr(out_len, torch.int32, True), B, T, C,
+               int(act), float(keep_prob), int(seed) & (2**64 - 1)), "os2s_bn_act_fwd")
+  return out
+
+
+def bn_act_bwd_num_parts(rows):
+  return int(_fn("os2s_bn_act_bwd_num_parts", (c_ll,))(rows))
+
+
+def bn_act_bwd_reduce(dout, out, ys, means, rstds, dz, partial, out_len, act, keep_prob,
+                      seed):
+  B, T, C = out.shape
+  J = len(ys)
+  f = _fn("os2s_bn_act_bwd_reduce",
+          (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint64))
+  _lib.check(f(_stream(), J, _ptr(dout, torch.bfloat16), _ptr(out, torch.bfloat16),
+               _ptr_array(ys, torch.bfloat16), _ptr_array(means, torch.float32),
+               _ptr_array(rstds, torch.float32), _ptr(dz, torch.bfloat16),
+               _ptr(partial, torch.float32), _ptr(out_len, torch.int32, True), B, T, C,
+               int(act), float(keep_prob), int(seed) & (2**64 - 1)),
+             "os2s_bn_act_bwd_reduce")
+
+
+def bn_bwd_finalize(partial, q, count, dgamma, dbeta, accumulate, c1, c2):
+  nparts, nq, C = partial.shape
+  f = _fn("os2s_bn_bwd_finalize",
+          (c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_void_p, c_void_p,
+           c_int, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(partial, torch.float32), nparts, nq, q, C, int(count),
+               _ptr(dgamma, torch.float32, True), _ptr(dbeta, torch.float32, True),
+               int(accumulate), _ptr(c1, torch.float32), _ptr(c2, torch.float32)),
+             "os2s_bn_bwd_finalize")
+
+
+def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy):
+  C = dz.shape[-1]
+  rows = dz.numel() // C
+  f = _fn("os2s_bn_bwd_apply",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+           c_void_p, c_void_p, c_ll, c_int))
+  _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(y, torch.bfloat16),
+               _ptr(gamma, torch.float32, True), _ptr(mean, torch.float32),
+               _ptr(rstd, torch.float32), _ptr(c1, torch.float32), _ptr(c2, torch.float32),
+               _ptr(dy, torch.bfloat16), rows, C), "os2s_bn_bwd_apply")
+  return dy
+
+
+def dropout_mask(seed, n_elems, keep_prob, device):
+  """Test hook: boolean keep mask [n_elems] the fused dropout uses."""
+  assert n_elems % 8 == 0
+  out = torch.empty((n_elems // 8,), dtype=torch.uint8, device=device)
+  f = _fn("os2s_dropout_mask", (c_void_p, c_uint64, c_ll, c_float, c_void_p))
+  _lib.check(f(_stream(), int(seed) & (2**64 - 1), n_elems // 8, float(keep_prob),
+               _ptr(out)), "os2s_dropout_mask")
+  bits = (out[:, None].to(torch.int32) >> torch.arange(8, device=device)[None, :]) & 1
+  return bits.reshape(-1).bool()
+
+
+# --------------------------------------------------------------------------
+# CTC loss
+# --------------------------------------------------------------------------
+def ctc_loss(logits, in_len, labels, label_len, blank=None, grad_scale=1.0,
+             want_grad=True, want_grad_bf16=False, vpad=32):
+  """logits [T,B,V] fp32. Returns dict(loss_per_sample, loss_mean, dlogits, dlogits_bf16)."""
+  T, B, V = logits.shape
+  Lmax = labels.shape[1]
+  if blank is None:
+    blank = V - 1
+  dev = logits.device
+  nbytes = int(_fn("os2s_ctc_loss_workspace_bytes", (c_int, c_int, c_int, c_int),
+                   c_size_t)(T, B, V, Lmax))
+  ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+  lps = torch.empty((B,), dtype=torch.float32, device=dev)
+  lm = torch.empty((1,), dtype=torch.float32, device=dev)
+  dl = torch.empty((T, B, V), dtype=torch.float32, device=dev) if want_grad else None
+  dl16 = (torch.empty((B, T, vpad), dtype=torch.bfloat16, device=dev)
+          if want_grad_bf16 else None)
+  f = _fn("os2s_ctc_loss",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+           c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+           c_size_t))
+  _lib.check(f(_stream(), _ptr(logits, torch.float32), _ptr(in_len, torch.int32),
+               _ptr(labels, torch.int32), _ptr(label_len, torch.int32), T, B, V, Lmax,
+               int(blank), float(grad_scale), _ptr(lps), _ptr(lm),
+               _ptr(dl, None, True), _ptr(dl16, None, True), int(vpad), _ptr(ws), nbytes),
+             "os2s_ctc_loss")
+  return {"loss_per_sample": lps, "loss_mean": lm, "dlogits": dl, "dlogits_bf16": dl16}
+
+
+# --------------------------------------------------------------------------
+# optimizer
+# --------------------------------------------------------------------------
+class OptConfig(_lib.ctypes.Structure):
+  """ctypes mirror of os2s_opt_config_t (include/os2s.h)."""
+  _fields_ = [
+      ("optimizer", c_int), ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float),
+      ("weight_decay", c_float), ("grad_averaging", c_int), ("lr_policy", c_int),
+      ("learning_rate", c_float), ("min_lr", c_float), ("power", c_float),
+      ("decay_rate", c_float), ("max_lr", c_float), ("coefficient", c_float),
+      ("decay_steps", c_ll), ("begin_decay_at", c_ll), ("warmup_steps", c_ll),
+      ("use_staircase_decay", c_int), ("d_model", c_int), ("has_max_lr", c_int),
+      ("use_larc", c_int), ("larc_eta", c_float), ("larc_min_update", c_float),
+      ("larc_epsilon", c_float), ("larc_mode_scale", c_int), ("clip_global_norm", c_float),
+      ("scaler", c_int), ("scale_min", c_float), ("scale_max", c_float),
+      ("step_factor", c_float), ("step_window", c_ll), ("log_max", c_float),
+      ("lm_beta1", c_float), ("lm_beta2", c_float), ("overflow_std_dev", c_float),
+      ("world_size", c_int),
+  ]
+
+
+OPT_STATE_FIELDS = [
+    ("global_step", "q"), ("scaler_iteration", "q"), ("last_overflow_iteration", "q"),
+    ("num_skipped", "q"), ("loss_scale", "f"), ("lr", "f"), ("global_grad_norm", "f"),
+    ("grad_amax", "f"), ("has_nan", "i"), ("skip", "i"), ("x_hat", "f"),
+    ("slow_x_hat", "f"), ("xsquared_hat", "f"), ("b1_correction", "f"),
+    ("b2_correction", "f"), ("grad_scale_latched", "f"),
+]
+
+
+def opt_chunk_elems():
+  return int(_fn("os2s_opt_chunk_elems", ())())
+
+
+def opt_state_bytes():
+  n = int(_fn("os2s_opt_state_bytes", (), c_size_t)())
+  assert int(_fn("os2s_opt_config_bytes", (), c_size_t)()) == _lib.ctypes.sizeof(OptConfig), \
+      "OptConfig ctypes mirror out of sync with os2s_opt_config_t"
+  return n
+
+
+def opt_init_state(state, loss_scale):
+  f = _fn("os2s_opt_init_state", (c_void_p, c_void_p, c_float))
+  _lib.check(f(_stream(), _ptr(state, torch.uint8), float(loss_scale)), "os2s_opt_init_state")
+
+
+def opt_read_state(state):
+  """Host copy of the device optimizer state (synchronises)."""
+  import struct
+  raw = bytes(state.cpu().numpy().tobytes())
+  fmt = "<" + "".join(c for _, c in OPT_STATE_FIELDS)
+  vals = struct.unpack(fmt, raw[:struct.calcsize(fmt)])
+  return dict(zip([n for n, _ in OPT_STATE_FIELDS], vals))
+
+
+def opt_step(cfg, state, grads, weights, m1, m2, w16, chunk_tensor, tensor_chunk_begin,
+             tensor_l2, tensor_wd_mask, partial, gnorm2, wnorm2, amax, mult, tensor_v):
+  nchunks = chunk_tensor.numel()
+  ntensors = tensor_chunk_begin.numel() - 1
+  f = _fn("os2s_opt_step",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+           c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _lib.ctypes.byref(cfg), _ptr(state, torch.uint8),
+               _ptr(grads, torch.float32), _ptr(weights, torch.float32),
+               _ptr(m1, torch.float32, True), _ptr(m2, torch.float32, True),
+               _ptr(w16, torch.bfloat16, True), nchunks, ntensors,
+               _ptr(chunk_tensor, torch.int32), _ptr(tensor_chunk_begin, torch.int32),
+               _ptr(tensor_l2, torch.float32, True), _ptr(tensor_wd_mask, torch.float32, True),
+               _ptr(partial, torch.float32), _ptr(gnorm2, torch.float32),
+               _ptr(wnorm2, torch.float32), _ptr(amax, torch.float32),
+               _ptr(mult, torch.float32), _ptr(tensor_v, torch.float32, True)),
+             "os2s_opt_step")
+
+
+def cast_f32_to_bf16(src, dst):
+  n = src.numel()
+  f = _fn("os2s_cast_f32_to_bf16", (c_void_p, c_void_p, c_void_p, c_ll))
+  _lib.check(f(_stream(), _ptr(src, torch.float32), _ptr(dst, torch.bfloat16), n),
+             "os2s_cast_f32_to_bf16")
+
+
+def conv_weight_dgrad_copy(w16, wt16, descs, total_tiles):
+  ndesc = descs.shape[0]
+  f = _fn("os2s_conv_weight_dgrad_copy",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int))
+  _lib.check(f(_stream(), _ptr(w16, torch.bfloat16), _ptr(wt16, torch.bfloat16),
+               _ptr(descs, torch.uint8), ndesc, int(total_tiles)),
+             "os2s_conv_weight_dgrad_copy")

@@ -1,0 +1,525 @@
+// BatchNorm (+ residual sum + activation + dropout + sequence mask) for the
+// conv blocks, channels-last, bf16 I/O with fp32 statistics. HBM-bound kernels:
+// 16-byte vector loads/stores, one pass per tensor, wavefront/LDS reductions.
+//
+// Reference semantics (open_seq2seq/parts/cnns/conv_blocks.py):
+//   conv_bn_actv            :170-232   y = act(BN(conv))
+//   conv_bn_res_bn_actv     :61-168    y = act(BN(conv) + sum_i BN_i(conv1x1_i(res_i)))
+//   followed by tf.nn.dropout (encoders/tdnn_encoder.py:255) and the sequence
+//   mask the encoder multiplies onto the NEXT conv's input (:185-186,204-205),
+//   which we fold into the producer's store.
+// tf.layers.batch_normalization on a 4-D tensor uses the fused kernel
+// (that is why the reference expands dims, conv_blocks.py:208-214):
+//   training: normalise with the biased batch variance; moving statistics are
+//   updated as moving = moving*momentum + batch*(1-momentum) where the batch
+//   variance fed to the moving average carries Bessel's correction n/(n-1)
+//   [TF fused_batch_norm convention — not in /root/reference];
+//   statistics run over ALL B*T positions, padded frames included (Appendix B.2).
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+constexpr int kMaxBnInputs = 12;
+
+// ---------------------------------------------------------------------------
+// finalize: partial (sum, sumsq) -> mean / rstd / fused scale+shift, moving stats
+// ---------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                   int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps,
+                                   float momentum, int training,
+                                   float* __restrict__ moving_mean,
+                                   float* __restrict__ moving_var,
+                                   float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out,
+                                   float* __restrict__ scale_out,
+                                   float* __restrict__ shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+      s += (double)partial[((long long)i * 2 + 0) * C + c];
+      q += (double)partial[((long long)i * 2 + 1) * C + c];
+    }
+    const double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (moving_mean) {
+      const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+      moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+      moving_var[c] = moving_var[c] * momentum + (float)unbiased * (1.f - momentum);
+    }
+  } else {
+    mean = moving_mean[c];
+    var = moving_var[c];
+  }
+  const float rstd = rsqrtf(var + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  const float b = beta ? beta[c] : 0.f;
+  if (mean_out) mean_out[c] = mean;
+  if (rstd_out) rstd_out[c] = rstd;
+  scale_out[c] = g * rstd;
+  shift_out[c] = b - mean * g * rstd;
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone per-channel (sum, sumsq) partials of a [rows, C] bf16 tensor, for
+// producers that do not emit them (same [nparts, 2, C] layout as the conv).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ y,
+                                                       long long rows, int C,
+                                                       int rows_per_block,
+                                                       float* __restrict__ partial) {
+  // thread -> 8-channel group g = tid % G, row lane rl = tid / G
+  __shared__ float red[256 * 16];
+  const int G = min(C / 8, 256);
+  const int RL = 256 / G;
+  const int cg0 = blockIdx.y * G;
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  const int c0 = (cg0 + g) * 8;
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(rows, r0 + rows_per_block);
+  if (c0 < C && rl < RL) {
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(y + r * C + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = bflo(v[e]), b = bfhi(v[e]);
+        s[2 * e] += a; q[2 * e] += a * a;
+        s[2 * e + 1] += b; q[2 * e + 1] += b * b;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[threadIdx.x * 16 + e] = s[e];
+    red[threadIdx.x * 16 + 8 + e] = q[e];
+  }
+  __syncthreads();
+  if (rl == 0 && c0 < C) {
+    for (int e = 0; e < 8; ++e) {
+      float ss = 0.f, qq = 0.f;
+      for (int k = 0; k < RL; ++k) {
+        ss += red[(k * G + g) * 16 + e];
+        qq += red[(k * G + g) * 16 + 8 + e];
+      }
+      partial[((long long)blockIdx.x * 2 + 0) * C + c0 + e] = ss;
+      partial[((long long)blockIdx.x * 2 + 1) * C + c0 + e] = qq;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward apply: out = mask * dropout( act( sum_j y_j*scale_j + shift_j ) )
+// ---------------------------------------------------------------------------
+struct BnActArgs {
+  const bf16_t* y[kMaxBnInputs];
+  const float* scale[kMaxBnInputs];
+  const float* shift[kMaxBnInputs];
+  int J;
+  bf16_t* out;
+  const int32_t* out_len;  // [B] or null: rows t >= out_len[b] are zeroed
+  int B, T, C;
+  int act;                 // 0 none, 1 relu, 2 tanh
+  float keep_prob;         // 1.0 = no dropout
+  unsigned long long seed;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return tanhf(v);
+  return v;
+}
+
+// 8 keep/drop decisions for the 8 channels starting at element index idx8*8:
+// two 64-bit mixes -> eight 16-bit uniforms, keep iff u16 < keep*65536.
+__device__ __forceinline__ uint32_t dropout_bits8(unsigned long long seed,
+                                                  unsigned long long idx8,
+                                                  float keep_prob) {
+  const uint32_t thr = (uint32_t)(keep_prob * 65536.0f);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    unsigned long long z = (idx8 * 2 + h) * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t u = (uint32_t)(z >> (16 * e)) & 0xffffu;
+      bits |= (u < thr ? 1u : 0u) << (h * 4 + e);
+    }
+  }
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs p) {
+  const int C8 = p.C >> 3;
+  const long long total = (long long)p.B * p.T * C8;
+  const float inv_keep = 1.f / p.keep_prob;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const long long row = i / C8;
+    const int c0 = (int)(i - row * C8) * 8;
+    const int b = (int)(row / p.T), t = (int)(row - (long long)b * p.T);
+    u32x4 o = {0u, 0u, 0u, 0u};
+    const bool live = !p.out_len || t < p.out_len[b];
+    if (live) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      for (int j = 0; j < p.J; ++j) {
+        const u32x4 y = *reinterpret_cast<const u32x4*>(p.y[j] + row * p.C + c0);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale[j] + c0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale[j] + c0 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.shift[j] + c0);
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(p.shift[j] + c0 + 4);
+        v[0] += bflo(y[0]) * s0[0] + h0[0]; v[1] += bfhi(y[0]) * s0[1] + h0[1];
+        v[2] += bflo(y[1]) * s0[2] + h0[2]; v[3] += bfhi(y[1]) * s0[3] + h0[3];
+        v[4] += bflo(y[2]) * s1[0] + h1[0]; v[5] += bfhi(y[2]) * s1[1] + h1[1];
+        v[6] += bflo(y[3]) * s1[2] + h1[2]; v[7] += bfhi(y[3]) * s1[3] + h1[3];
+      }
+      uint32_t keep = 0xffu;
+      if (p.keep_prob < 1.f) keep = dropout_bits8(p.seed, (unsigned long long)i, p.keep_prob);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = apply_act(v[e], p.act);
+        if (p.keep_prob < 1.f) a = ((keep >> e) & 1u) ? a * inv_keep : 0.f;
+        v[e] = a;
+      }
+      o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+      o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
+    }
+    *reinterpret_cast<u32x4*>(p.out + row * p.C + c0) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward pass 1: dz = dA * mask * dropout' * act'(out), written as bf16, plus
+// per-channel partial sums  sum(dz)  and  sum(dz * xhat_j)  for every input j.
+// ---------------------------------------------------------------------------
+struct BnBwdReduceArgs {
+  const bf16_t* dout;      // [B,T,C] grad wrt the block output
+  const bf16_t* out;       // saved block output (for act')
+  const bf16_t* y[kMaxBnInputs];
+  const float* mean[kMaxBnInputs];
+  const float* rstd[kMaxBnInputs];
+  int J;
+  bf16_t* dz;              // [B,T,C]
+  float* partial;          // [nblocks_rows][1+J][C]
+  const int32_t* out_len;
+  int B, T, C, act;
+  float keep_prob;
+  unsigned long long seed;
+  int rows_per_block;
+};
+
+template <int J_MAX>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs p) {
+  extern __shared__ float red[];  // [256][(1+J)*8]
+  const int C8 = p.C >> 3;
+  const int G = min(C8, 256);
+  const int RL = 256 / G;
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  const int c0 = (blockIdx.y * G + g) * 8;
+  const bool cvalid = (blockIdx.y * G + g) < C8 && rl < RL;
+  const float inv_keep = 1.f / p.keep_prob;
+  float sd[8];
+  float sx[J_MAX][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sd[e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < J_MAX; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sx[j][e] = 0.f;
+  if (cvalid) {
+    const long long rows = (long long)p.B * p.T;
+    const long long r0 = (long long)blockIdx.x * p.rows_per_block;
+    const long long r1 = min(rows, r0 + p.rows_per_block);
+    for (long long row = r0 + rl; row < r1; row += RL) {
+      const int b = (int)(row / p.T), t = (int)(row - (long long)b * p.T);
+      float dzv[8];
+      const bool live = !p.out_len || t < p.out_len[b];
+      if (live) {
+        const u32x4 d = *reinterpret_cast<const u32x4*>(p.dout + row * p.C + c0);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(p.out + row * p.C + c0);
+        float dv[8] = {bflo(d[0]), bfhi(d[0]), bflo(d[1]), bfhi(d[1]),
+                       bflo(d[2]), bfhi(d[2]), bflo(d[3]), bfhi(d[3])};
+        float ov[8] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1]),
+                       bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+        uint32_t keep = 0xffu;
+        if (p.keep_prob < 1.f)
+          keep = dropout_bits8(p.seed, (unsigned long long)(row * C8 + (c0 >> 3)), p.keep_prob);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float gsc = 1.f;
+          if (p.keep_prob < 1.f) gsc = ((keep >> e) & 1u) ? inv_keep : 0.f;
+          float dact = 1.f;
+          if (p.act == 1) dact = ov[e] > 0.f ? 1.f : 0.f;
+          else if (p.act == 2) {
+            const float th = ov[e] * p.keep_prob;  // tanh(z) of a kept element
+            dact = 1.f - th * th;
+          }
+          dzv[e] = dv[e] * gsc * dact;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dzv[e] = 0.f;
+      }
+      u32x4 w;
+      w[0] = pack2bf(dzv[0], dzv[1]); w[1] = pack2bf(dzv[2], dzv[3]);
+      w[2] = pack2bf(dzv[4], dzv[5]); w[3] = pack2bf(dzv[6], dzv[7]);
+      *reinterpret_cast<u32x4*>(p.dz + row * p.C + c0) = w;
+      // the sums use the bf16-rounded dz, i.e. exactly what pass 2 re-reads
+      const float dr[8] = {bflo(w[0]), bfhi(w[0]), bflo(w[1]), bfhi(w[1]),
+                           bflo(w[2]), bfhi(w[2]), bflo(w[3]), bfhi(w[3])};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sd[e] += dr[e];
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < J_MAX; ++j)
+          if (j < p.J) {
+            const u32x4 y = *reinterpret_cast<const u32x4*>(p.y[j] + row * p.C + c0);
+            const float yv[8] = {bflo(y[0]), bfhi(y[0]), bflo(y[1]), bfhi(y[1]),
+                                 bflo(y[2]), bfhi(y[2]), bflo(y[3]), bfhi(y[3])};
+            // mean/rstd are re-read per row (L1-resident) to keep J*16 floats
+            // out of the register file
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(p.mean[j] + c0);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(p.mean[j] + c0 + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(p.rstd[j] + c0);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(p.rstd[j] + c0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              sx[j][e] += dr[e] * (yv[e] - m0[e]) * q0[e];
+              sx[j][4 + e] += dr[e + 4] * (yv[e + 4] - m1[e]) * q1[e];
+            }
+          }
+      }
+    }
+  }
+  // block reduction over the RL row lanes
+  const int W = (1 + p.J) * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * W + e] = sd[e];
+#pragma unroll
+  for (int j = 0; j < J_MAX; ++j)
+    if (j < p.J) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[threadIdx.x * W + (1 + j) * 8 + e] = sx[j][e];
+    }
+  __syncthreads();
+  if (rl == 0 && (blockIdx.y * G + g) < C8) {
+    for (int q = 0; q < 1 + p.J; ++q)
+      for (int e = 0; e < 8; ++e) {
+        float s = 0.f;
+        for (int k = 0; k < RL; ++k) s += red[(k * G + g) * W + q * 8 + e];
+        p.partial[((long long)blockIdx.x * (1 + p.J) + q) * p.C + c0 + e] = s;
+      }
+  }
+}
+
+// Backward finalize for input j: reduce the partials -> dgamma, dbeta and the two
+// means pass 2 needs (c1 = mean(dz), c2 = mean(dz*xhat)).
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts,
+                                       int nq, int q, int C, double count,
+                                       float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate,
+                                       float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sd = 0.0, sx = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    sd += (double)partial[((long long)i * nq + 0) * C + c];
+    sx += (double)partial[((long long)i * nq + q) * C + c];
+  }
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sd;
+  c1[c] = (float)(sd / count);
+  c2[c] = (float)(sx / count);
+}
+
+// Backward pass 2 for input j: dy = gamma*rstd*(dz - c1 - xhat*c2)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ c1,
+    const float* __restrict__ c2, bf16_t* __restrict__ dy, long long rows, int C) {
+  const int C8 = C >> 3;
+  const long long total = rows * C8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    const long long row = i / C8;
+    const int c0 = (int)(i - row * C8) * 8;
+    const u32x4 d = *reinterpret_cast<const u32x4*>(dz + row * C + c0);
+    const u32x4 yv = *reinterpret_cast<const u32x4*>(y + row * C + c0);
+    float dv[8] = {bflo(d[0]), bfhi(d[0]), bflo(d[1]), bfhi(d[1]),
+                   bflo(d[2]), bfhi(d[2]), bflo(d[3]), bfhi(d[3])};
+    float xv[8] = {bflo(yv[0]), bfhi(yv[0]), bflo(yv[1]), bfhi(yv[1]),
+                   bflo(yv[2]), bfhi(yv[2]), bflo(yv[3]), bfhi(yv[3])};
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float rs = rstd[c0 + e];
+      const float g = gamma ? gamma[c0 + e] : 1.f;
+      const float xh = (xv[e] - mean[c0 + e]) * rs;
+      r[e] = g * rs * (dv[e] - c1[c0 + e] - xh * c2[c0 + e]);
+    }
+    u32x4 o;
+    o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]);
+    o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+    *reinterpret_cast<u32x4*>(dy + row * C + c0) = o;
+  }
+}
+
+__global__ void dropout_mask_kernel(unsigned long long seed, long long n8, float keep,
+                                    uint8_t* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = (uint8_t)dropout_bits8(seed, (unsigned long long)i, keep);
+}
+
+static inline int ew_grid(long long total_threads) {
+  long long b = (total_threads + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace os2s
+
+using namespace os2s;
+
+extern "C" int os2s_bn_finalize(os2s_stream_t stream, const float* partial, int nparts,
+                                int C, long long count, const float* gamma,
+                                const float* beta, float eps, float momentum,
+                                int training, float* moving_mean, float* moving_var,
+                                float* mean_out, float* rstd_out, float* scale_out,
+                                float* shift_out) {
+  OS2S_REQUIRE(C >= 1 && scale_out && shift_out);
+  if (training) OS2S_REQUIRE(partial && nparts >= 1 && count >= 1);
+  else OS2S_REQUIRE(moving_mean && moving_var);
+  OS2S_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0,
+              (hipStream_t)stream, partial, nparts, C, (double)count, gamma, beta, eps,
+              momentum, training, moving_mean, moving_var, mean_out, rstd_out, scale_out,
+              shift_out);
+  return OS2S_OK;
+}
+
+static const int kStatsRowsPerBlock = 512;
+
+extern "C" int os2s_bn_stats_num_parts(long long rows) {
+  return ceil_div(rows, kStatsRowsPerBlock);
+}
+
+extern "C" int os2s_bn_stats(os2s_stream_t stream, const uint16_t* y, long long rows,
+                             int C, float* partial) {
+  OS2S_REQUIRE(y && partial && rows >= 1 && C >= 8 && C % 8 == 0);
+  const int G = (C / 8) < 256 ? (C / 8) : 256;
+  dim3 grid(ceil_div(rows, kStatsRowsPerBlock), ceil_div(C / 8, G));
+  OS2S_LAUNCH(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, rows, C,
+              kStatsRowsPerBlock, partial);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_bn_act_fwd(os2s_stream_t stream, int J, const uint16_t* const* y,
+                               const float* const* scale, const float* const* shift,
+                               uint16_t* out, const int32_t* out_len, int B, int T,
+                               int C, int act, float keep_prob,
+                               unsigned long long seed) {
+  OS2S_REQUIRE(J >= 1 && J <= kMaxBnInputs && out && C % 8 == 0 && C >= 8);
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f && act >= 0 && act <= 2);
+  if ((long long)B * T == 0) return OS2S_OK;
+  BnActArgs a;
+  for (int j = 0; j < J; ++j) {
+    OS2S_REQUIRE(y[j] && scale[j] && shift[j]);
+    a.y[j] = y[j]; a.scale[j] = scale[j]; a.shift[j] = shift[j];
+  }
+  a.J = J; a.out = out; a.out_len = out_len; a.B = B; a.T = T; a.C = C; a.act = act;
+  a.keep_prob = keep_prob; a.seed = seed;
+  const long long total = (long long)B * T * (C / 8);
+  OS2S_LAUNCH(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  return OS2S_OK;
+}
+
+static const int kBwdRowsPerBlock = 256;
+
+extern "C" int os2s_bn_act_bwd_num_parts(long long rows) {
+  return ceil_div(rows, kBwdRowsPerBlock);
+}
+
+extern "C" int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_t* dout,
+                                      const uint16_t* out, const uint16_t* const* y,
+                                      const float* const* mean, const float* const* rstd,
+                                      uint16_t* dz, float* partial, const int32_t* out_len,
+                                      int B, int T, int C, int act, float keep_prob,
+                                      unsigned long long seed) {
+  OS2S_REQUIRE(J >= 1 && J <= kMaxBnInputs && dout && out && dz && partial);
+  OS2S_REQUIRE(C % 8 == 0 && C >= 8 && keep_prob > 0.f && keep_prob <= 1.f);
+  if ((long long)B * T == 0) return OS2S_OK;
+  BnBwdReduceArgs a;
+  for (int j = 0; j < J; ++j) {
+    OS2S_REQUIRE(y[j] && mean[j] && rstd[j]);
+    a.y[j] = y[j]; a.mean[j] = mean[j]; a.rstd[j] = rstd[j];
+  }
+  a.dout = dout; a.out = out; a.J = J; a.dz = dz; a.partial = partial; a.out_len = out_len;
+  a.B = B; a.T = T; a.C = C; a.act = act; a.keep_prob = keep_prob; a.seed = seed;
+  a.rows_per_block = kBwdRowsPerBlock;
+  const int C8 = C / 8;
+  const int G = C8 < 256 ? C8 : 256;
+  dim3 grid(ceil_div((long long)B * T, kBwdRowsPerBlock), ceil_div(C8, G));
+  const size_t smem = (size_t)256 * (1 + J) * 8 * sizeof(float);
+  if (J <= 1) {
+    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  } else if (J <= 4) {
+    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)bn_act_bwd_reduce_kernel<kMaxBnInputs>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return OS2S_ERR_LAUNCH;
+      attr = true;
+    }
+    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<kMaxBnInputs>, grid, dim3(256), smem,
+                (hipStream_t)stream, a);
+  }
+  return OS2S_OK;
+}
+
+extern "C" int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, int nparts,
+                                    int nq, int q, int C, long long count, float* dgamma,
+                                    float* dbeta, int accumulate, float* c1, float* c2) {
+  OS2S_REQUIRE(partial && c1 && c2 && nparts >= 1 && q >= 1 && q < nq && count >= 1);
+  OS2S_LAUNCH(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0,
+              (hipStream_t)stream, partial, nparts, nq, q, C, (double)count, dgamma, dbeta,
+              accumulate, c1, c2);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                                 const float* gamma, const float* mean, const float* rstd,
+                                 const float* c1, const float* c2, uint16_t* dy,
+                                 long long rows, int C) {
+  OS2S_REQUIRE(dz && y && mean && rstd && c1 && c2 && dy && C % 8 == 0);
+  if (rows == 0) return OS2S_OK;
+  OS2S_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
+              (hipStream_t)stream, dz, y, gamma, mean, rstd, c1, c2, dy, rows, C);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_dropout_mask(os2s_stream_t stream, unsigned long long seed,
+                                 long long n8, float keep_prob, uint8_t* out) {
+  OS2S_REQUIRE(out && n8 >= 0);
+  if (n8 == 0) return OS2S_OK;
+  OS2S_LAUNCH(dropout_mask_kernel, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream,
+              seed, n8, keep_prob, out);
+  return OS2S_OK;
+}

@@ -63,3 +63,61 @@ def conv1d_direct_numpy(x, w_tf, stride=1, dil=1, padding="SAME"):
 def to_dev_layout(w_tf):
   """TF kernel [K,Cin,Cout] -> device layout [K,Cout,Cin]."""
   return torch.as_tensor(w_tf).permute(0, 2, 1).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm / conv blocks (conv_blocks.py:61-232)
+# ---------------------------------------------------------------------------
+def batch_norm_train(y, gamma, beta, eps, momentum=None, moving_mean=None,
+                     moving_var=None):
+  """tf.layers.batch_normalization(training=True) on [B,T,1,C] (fused path,
+  conv_blocks.py:208-227): statistics over ALL B*T positions (padded frames
+  included), biased variance for normalisation, Bessel-corrected variance in the
+  moving average, moving = moving*momentum + batch*(1-momentum).
+  Returns (out, mean, var_biased, new_moving_mean, new_moving_var)."""
+  y = torch.as_tensor(y, dtype=torch.float32)
+  C = y.shape[-1]
+  flat = y.reshape(-1, C).double()
+  n = flat.shape[0]
+  mean = flat.mean(0)
+  var = flat.var(0, unbiased=False)
+  out = ((flat - mean) * torch.rsqrt(var + eps)).float() * gamma + beta
+  new_mm = new_mv = None
+  if moving_mean is not None:
+    unb = var * n / max(n - 1, 1)
+    new_mm = moving_mean * momentum + mean.float() * (1 - momentum)
+    new_mv = moving_var * momentum + unb.float() * (1 - momentum)
+  return out.reshape(y.shape), mean.float(), var.float(), new_mm, new_mv
+
+
+def batch_norm_eval(y, gamma, beta, eps, moving_mean, moving_var):
+  return (y - moving_mean) * torch.rsqrt(moving_var + eps) * gamma + beta
+
+
+def act_fn(x, act):
+  if act in (None, "none", 0):
+    return x
+  if act in ("relu", 1):
+    return torch.relu(x)
+  if act in ("tanh", 2):
+    return torch.tanh(x)
+  raise ValueError(act)
+
+
+def seq_mask(lens, T):
+  return (torch.arange(T)[None, :] < torch.as_tensor(lens)[:, None]).float()[:, :, None]
+
+
+def bn_res_act(ys, gammas, betas, eps, act, keep_mask=None, keep_prob=1.0, out_len=None):
+  """act(sum_j BN_j(y_j)) -> dropout -> (mask of the next conv's input).
+  conv_bn_res_bn_actv (conv_blocks.py:61-168) + tf.nn.dropout (tdnn_encoder.py:255:
+  x * mask / keep_prob) + conv_feats * mask (tdnn_encoder.py:185-186,204-205)."""
+  tot = 0
+  for y, g, b in zip(ys, gammas, betas):
+    tot = tot + batch_norm_train(y, g, b, eps)[0]
+  out = act_fn(tot, act)
+  if keep_mask is not None:
+    out = out * keep_mask.float() / keep_prob
+  if out_len is not None:
+    out = out * seq_mask(out_len, out.shape[1])
+  return out

@@ -1,0 +1,108 @@
+"""GPU parity: fused BatchNorm / residual / activation / dropout / mask kernels
+(forward and backward) vs the CPU fp32 oracle (torch autograd on the oracle
+gives the reference gradients). Tolerances: bf16 I/O => rtol 2e-2 on
+activations; fp32 statistics => 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cnn  # noqa: E402
+
+
+def _bf(x):
+  return torch.as_tensor(x).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("B,T,C,J,act,keep", [
+    (3, 50, 256, 1, "relu", 1.0),
+    (2, 77, 384, 3, "relu", 0.8),
+    (2, 33, 768, 11, "relu", 0.7),
+    (2, 40, 512, 1, "tanh", 0.5),
+    (1, 9, 64, 2, "none", 1.0),
+])
+def test_bn_act_fwd_bwd(cuda, B, T, C, J, act, keep):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(B * 100 + T + C + J)
+  eps, mom = 1e-3, 0.9
+  actid = {"none": 0, "relu": 1, "tanh": 2}[act]
+  ys = [_bf(torch.randn(B, T, C, generator=g) * (1 + j) + 0.3 * j) for j in range(J)]
+  gammas = [torch.rand(C, generator=g) + 0.5 for _ in range(J)]
+  betas = [torch.randn(C, generator=g) * 0.1 for _ in range(J)]
+  lens = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  seed = 1234567
+  # ---- forward on the GPU ------------------------------------------------
+  d = cuda
+  scales, shifts, means, rstds = [], [], [], []
+  mm = [torch.zeros(C, device=d) for _ in range(J)]
+  mv = [torch.ones(C, device=d) for _ in range(J)]
+  for j in range(J):
+    y = ys[j].to(d)
+    part = capi.bn_stats(y.reshape(-1, C))
+    sc, sh, me, rs = (torch.empty(C, device=d) for _ in range(4))
+    capi.bn_finalize(part, B * T, gammas[j].to(d), betas[j].to(d), eps, mom, True, mm[j],
+                     mv[j], me, rs, sc, sh)
+    scales.append(sc); shifts.append(sh); means.append(me); rstds.append(rs)
+  out = torch.empty(B, T, C, dtype=torch.bfloat16, device=d)
+  ysd = [y.to(d) for y in ys]
+  capi.bn_act_fwd(ysd, scales, shifts, out, lens.to(d), actid, keep, seed)
+  keep_mask = None
+  if keep < 1.0:
+    keep_mask = capi.dropout_mask(seed, B * T * C, keep, d).reshape(B, T, C).cpu()
+    frac = keep_mask.float().mean().item()
+    assert abs(frac - keep) < 0.02
+  torch.cuda.synchronize()
+  # ---- oracle --------------------------------------------------------------
+  ys32 = [y.float().requires_grad_(True) for y in ys]
+  g32 = [x.clone().requires_grad_(True) for x in gammas]
+  b32 = [x.clone().requires_grad_(True) for x in betas]
+  ref = cnn.bn_res_act(ys32, g32, b32, eps, act, keep_mask, keep, lens)
+  scale = float(ref.detach().pow(2).mean().sqrt()) + 1e-6
+  torch.testing.assert_close(out.float().cpu(), ref.detach(), rtol=2e-2, atol=2e-2 * scale)
+  # statistics + moving averages
+  _, m0, v0, nmm, nmv = cnn.batch_norm_train(ys[0].float(), gammas[0], betas[0], eps, mom,
+                                             torch.zeros(C), torch.ones(C))
+  torch.testing.assert_close(means[0].cpu(), m0, rtol=1e-4, atol=1e-4)
+  torch.testing.assert_close(rstds[0].cpu(), torch.rsqrt(v0 + eps), rtol=1e-4, atol=1e-4)
+  torch.testing.assert_close(mm[0].cpu(), nmm, rtol=1e-4, atol=1e-5)
+  torch.testing.assert_close(mv[0].cpu(), nmv, rtol=1e-4, atol=1e-5)
+  # ---- backward --------------------------------------------------------------
+  dout = _bf(torch.randn(B, T, C, generator=g))
+  ref.backward(dout.float())
+  nparts = capi.bn_act_bwd_num_parts(B * T)
+  partial = torch.empty(nparts, 1 + J, C, device=d)
+  dz = torch.empty(B, T, C, dtype=torch.bfloat16, device=d)
+  capi.bn_act_bwd_reduce(dout.to(d), out, ysd, means, rstds, dz, partial, lens.to(d), actid,
+                         keep, seed)
+  for j in range(J):
+    dgam, dbet, c1, c2 = (torch.empty(C, device=d) for _ in range(4))
+    capi.bn_bwd_finalize(partial, 1 + j, B * T, dgam, dbet, False, c1, c2)
+    dy = torch.empty(B, T, C, dtype=torch.bfloat16, device=d)
+    capi.bn_bwd_apply(dz, ysd[j], gammas[j].to(d), means[j], rstds[j], c1, c2, dy)
+    torch.cuda.synchronize()
+    gs = float(ys32[j].grad.pow(2).mean().sqrt()) + 1e-8
+    # tanh uses the bf16-rounded saved output for act' -> a little looser
+    tol = 4e-2 if act == "tanh" else 2e-2
+    torch.testing.assert_close(dy.float().cpu(), ys32[j].grad, rtol=tol, atol=tol * gs)
+    ggs = float(g32[j].grad.abs().mean()) + 1e-6
+    torch.testing.assert_close(dgam.cpu(), g32[j].grad, rtol=2e-2, atol=2e-2 * ggs)
+    bgs = float(b32[j].grad.abs().mean()) + 1e-6
+    torch.testing.assert_close(dbet.cpu(), b32[j].grad, rtol=2e-2, atol=2e-2 * bgs)
+
+
+def test_bn_eval_mode(cuda):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(3)
+  B, T, C = 2, 20, 128
+  y = _bf(torch.randn(B, T, C, generator=g))
+  gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+  mm, mv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+  sc, sh = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+  capi.bn_finalize(None, 1, gamma.to(cuda), beta.to(cuda), 1e-3, 0.9, False, mm.to(cuda),
+                   mv.to(cuda), None, None, sc, sh)
+  out = torch.empty(B, T, C, dtype=torch.bfloat16, device=cuda)
+  capi.bn_act_fwd([y.to(cuda)], [sc], [sh], out, None, 1, 1.0, 0)
+  ref = torch.relu(cnn.batch_norm_eval(y.float(), gamma, beta, 1e-3, mm, mv))
+  torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-2, atol=2e-2)
