@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
     const float* __restrict__ logp, const int32_t* __restrict__ labels, int Lmax,
     const int32_t* __restrict__ label_len, const int32_t* __restrict__ in_len, int T,
     int B, int V, int blank, int Smax, float* __restrict__ alpha,
-    float* __restrict__ beta, float* __restrict__ loglik, int32_t* __restrict__ valid) {
+    float* __restrict__ beta, double* __restrict__ coff_a, double* __restrict__ coff_b,
+    double* __restrict__ loglik, int32_t* __restrict__ valid) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
   int L = label_len[b];
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
   float* st = reinterpret_cast<float*>(smem_raw + Smax * 4);      // [2][Smax]
   float* lp = st + 2 * Smax;                                      // [kTC][V]
   __shared__ int s_rep;
+  __shared__ float s_wmax[4];
   if (threadIdx.x == 0) s_rep = 0;
   __syncthreads();
   const int32_t* labb = labels + (long long)b * Lmax;
@@ -85,10 +87,14 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
   __syncthreads();
   const bool ok = (Tb > 0) && (L + s_rep <= Tb);
   if (!ok) {
-    if (dir == 0 && threadIdx.x == 0) { loglik[b] = 0.f; valid[b] = 0; }
+    if (dir == 0 && threadIdx.x == 0) { loglik[b] = 0.0; valid[b] = 0; }
     return;
   }
   float* outp = (dir == 0 ? alpha : beta) + (long long)b * T * Smax;
+  double* coff = (dir == 0 ? coff_a : coff_b) + (long long)b * T;
+  // The stored rows are alpha_t(s) - C_t with C_t a running normaliser kept in
+  // double: fp32 alphas that grow like -3.4*t lose ~1e-4 absolute per step.
+  double C = 0.0;
   const float* lpb = logp + (long long)b * T * V;
 
   for (int c0 = 0; c0 < Tb; c0 += kTC) {
@@ -128,14 +134,33 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
         cur[s] = v;
         outp[(long long)t * Smax + s] = v;
       }
+      if (threadIdx.x == 0) coff[t] = C;
       __syncthreads();
+      if ((step & 7) == 7 && step + 1 < Tb) {
+        // renormalise: subtract the row maximum, remember it in C
+        float m = kNegInf;
+        for (int s = threadIdx.x; s < S; s += 256) m = fmaxf(m, cur[s]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+        if (m > kNegInf * 0.5f) {
+          for (int s = threadIdx.x; s < S; s += 256) {
+            const float x = cur[s];
+            cur[s] = x > kNegInf * 0.5f ? x - m : kNegInf;
+          }
+          C += (double)m;
+        }
+        __syncthreads();
+      }
     }
   }
   if (dir == 0 && threadIdx.x == 0) {
     const float* last = st + ((Tb - 1) & 1) * Smax;
-    const float ll = S >= 2 ? lse2(last[S - 1], last[S - 2]) : last[S - 1];
+    const float l2 = S >= 2 ? lse2(last[S - 1], last[S - 2]) : last[S - 1];
+    const double ll = C + (double)l2;
     loglik[b] = ll;
-    valid[b] = (ll > kNegInf * 0.5f && isfinite(ll)) ? 1 : 0;
+    valid[b] = (l2 > kNegInf * 0.5f && isfinite(l2)) ? 1 : 0;
   }
 }
 
@@ -146,7 +171,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ logp, const int32_t* __restrict__ labels, int Lmax,
     const int32_t* __restrict__ label_len, const int32_t* __restrict__ in_len, int T,
     int B, int V, int blank, int Smax, const float* __restrict__ alpha,
-    const float* __restrict__ beta, const float* __restrict__ loglik,
+    const float* __restrict__ beta, const double* __restrict__ coff_a,
+    const double* __restrict__ coff_b, const double* __restrict__ loglik,
     const int32_t* __restrict__ valid, float grad_scale, float* __restrict__ dlogits,
     bf16_t* __restrict__ dlogits_bf16, int Vpad) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -167,15 +193,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const int32_t* labb = labels + (long long)b * Lmax;
     for (int s = threadIdx.x; s < S; s += 256) lab[s] = (s & 1) ? labb[s >> 1] : blank;
     __syncthreads();
-    const float ll = loglik[b];
+    const double ll = loglik[b];
     for (int rr = 0; rr < kGR; ++rr) {
       const int tt = t0 + rr;
       if (tt < Tb) {
+        const float off = (float)(coff_a[(long long)b * T + tt] + coff_b[(long long)b * T + tt] - ll);
         const float* al = alpha + ((long long)b * T + tt) * Smax;
         const float* be = beta + ((long long)b * T + tt) * Smax;
         const float* lpr = logp + ((long long)b * T + tt) * V;
         for (int s = threadIdx.x; s < S; s += 256) {
-          const float x = al[s] + be[s] - lpr[lab[s]] - ll;
+          const float x = (al[s] + be[s] - lpr[lab[s]]) + off;
           e[rr * Smax + s] = x > -80.f ? __expf(x) : 0.f;
         }
       }
@@ -204,14 +231,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 }
 
 // loss[b] = valid ? -ll : 0 (mask_nans), mean over the WHOLE batch.
-__global__ void ctc_finish_kernel(const float* __restrict__ loglik,
+__global__ void ctc_finish_kernel(const double* __restrict__ loglik,
                                   const int32_t* __restrict__ valid, int B,
                                   float* __restrict__ loss_per_sample,
                                   float* __restrict__ loss_mean) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float tot = 0.f;
     for (int b = 0; b < B; ++b) {
-      float l = valid[b] ? -loglik[b] : 0.f;
+      float l = valid[b] ? (float)(-loglik[b]) : 0.f;
       if (!isfinite(l)) l = 0.f;
       if (loss_per_sample) loss_per_sample[b] = l;
       tot += l;
@@ -228,7 +255,8 @@ extern "C" size_t os2s_ctc_loss_workspace_bytes(int T, int B, int V, int Lmax) {
   const size_t Smax = 2 * (size_t)Lmax + 1;
   size_t n = (size_t)B * T * V * 4;        // logp
   n += 2 * (size_t)B * T * Smax * 4;       // alpha, beta
-  n += (size_t)B * 8;                      // loglik, valid
+  n += 2 * (size_t)B * T * 8;              // running normalisers (double)
+  n += (size_t)B * 16;                     // loglik (double), valid
   return n + 256;
 }
 
@@ -248,7 +276,9 @@ extern "C" int os2s_ctc_loss(os2s_stream_t stream_, const float* logits,
   float* logp = (float*)ws; ws += (size_t)B * T * V * 4;
   float* alpha = (float*)ws; ws += (size_t)B * T * Smax * 4;
   float* beta = (float*)ws; ws += (size_t)B * T * Smax * 4;
-  float* ll = (float*)ws; ws += (size_t)B * 4;
+  double* coff_a = (double*)ws; ws += (size_t)B * T * 8;
+  double* coff_b = (double*)ws; ws += (size_t)B * T * 8;
+  double* ll = (double*)ws; ws += (size_t)B * 8;
   int32_t* valid = (int32_t*)ws;
 
   OS2S_LAUNCH(ctc_log_softmax_kernel, dim3(ceil_div((long long)T * B, 256)), dim3(256), 0,
@@ -257,11 +287,11 @@ extern "C" int os2s_ctc_loss(os2s_stream_t stream_, const float* logits,
   const size_t smem_g = (size_t)Smax * 4 * (1 + kGR);
   if (smem_ab > 64 * 1024 || smem_g > 64 * 1024) return OS2S_ERR_UNSUPPORTED;
   OS2S_LAUNCH(ctc_alpha_beta_kernel, dim3(2 * B), dim3(256), smem_ab, stream, logp, labels,
-              Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, ll, valid);
+              Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, coff_a, coff_b, ll, valid);
   if (dlogits || dlogits_bf16) {
     OS2S_LAUNCH(ctc_grad_kernel, dim3(ceil_div(T, kGR), B), dim3(256), smem_g, stream, logp,
-                labels, Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, ll, valid,
-                grad_scale, dlogits, dlogits_bf16, Vpad);
+                labels, Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, coff_a, coff_b,
+                ll, valid, grad_scale, dlogits, dlogits_bf16, Vpad);
   }
   OS2S_LAUNCH(ctc_finish_kernel, dim3(1), dim3(64), 0, stream, ll, valid, B, loss_per_sample,
               loss_mean);
