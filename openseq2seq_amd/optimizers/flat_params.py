@@ -1,0 +1,127 @@
+"""Flat parameter storage for the multi-tensor optimizer kernels.
+
+All trainable tensors live in ONE fp32 master buffer, with matching flat
+buffers for gradients, optimizer moments and the bf16 compute copy (the
+reference's "FP32-master-copy" variables + fp16 variables,
+open_seq2seq/optimizers/mp_wrapper.py:57-97). Every tensor starts at a multiple
+of os2s_opt_chunk_elems() elements so one optimizer chunk belongs to exactly
+one tensor; the flat gradient buffer is also what RCCL all-reduces in buckets.
+Conv kernels additionally keep a tap-flipped transposed bf16 copy that the
+data-gradient convolution consumes (see include/os2s.h, os2s_conv1d_fwd).
+"""
+import struct
+
+import numpy as np
+import torch
+
+from .. import capi
+
+
+class Param(object):
+  __slots__ = ("name", "shape", "index", "offset", "numel", "l2", "kind", "store",
+               "master", "grad", "w16", "wt16", "wt_offset", "trainable_mask")
+
+  def __init__(self, name, shape, kind, l2):
+    self.name, self.shape, self.kind, self.l2 = name, tuple(int(s) for s in shape), kind, l2
+    self.numel = int(np.prod(self.shape))
+    self.master = self.grad = self.w16 = self.wt16 = None
+
+
+class FlatParams(object):
+  """kind: 'conv' ([K,Cout,Cin], gets a dgrad copy), 'dense', 'vector' (BN/bias)."""
+
+  def __init__(self, device):
+    self.device = device
+    self.params = []
+    self._inits = []
+    self.finalized = False
+    self.chunk = capi.opt_chunk_elems()
+
+  def add(self, name, shape, init, kind="dense", l2=0.0):
+    assert not self.finalized
+    for p in self.params:
+      if p.name == name:
+        raise ValueError("duplicate variable " + name)
+    p = Param(name, shape, kind, float(l2))
+    p.index = len(self.params)
+    self.params.append(p)
+    self._inits.append(init)
+    return p
+
+  def finalize(self, need_m2=False):
+    dev, ch = self.device, self.chunk
+    off = 0
+    wt_off = 0
+    begins = []
+    for p in self.params:
+      p.offset = off
+      begins.append(off // ch)
+      off += -(-p.numel // ch) * ch
+      if p.kind == "conv":
+        p.wt_offset = wt_off
+        wt_off += -(-p.numel // 8) * 8
+    self.total = off
+    begins.append(off // ch)
+    self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.m1 = torch.zeros(off, dtype=torch.float32, device=dev)
+    self.m2 = torch.zeros(off, dtype=torch.float32, device=dev) if need_m2 else None
+    self.w16 = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+    self.wt16 = torch.zeros(max(wt_off, 8), dtype=torch.bfloat16, device=dev)
+    nt = len(self.params)
+    chunk_tensor = np.zeros(off // ch, np.int32)
+    for i, p in enumerate(self.params):
+      chunk_tensor[begins[i]:begins[i + 1]] = i
+    self.chunk_tensor = torch.from_numpy(chunk_tensor).to(dev)
+    self.tensor_chunk_begin = torch.tensor(begins, dtype=torch.int32, device=dev)
+    self.tensor_l2 = torch.tensor([p.l2 for p in self.params], dtype=torch.float32, device=dev)
+    self.partial = torch.zeros(off // ch * 4, dtype=torch.float32, device=dev)
+    self.t_gnorm2 = torch.zeros(nt, dtype=torch.float32, device=dev)
+    self.t_wnorm2 = torch.zeros(nt, dtype=torch.float32, device=dev)
+    self.t_amax = torch.zeros(nt, dtype=torch.float32, device=dev)
+    self.t_mult = torch.zeros(nt, dtype=torch.float32, device=dev)
+    self.t_v = torch.zeros(nt, dtype=torch.float32, device=dev)
+    descs = b""
+    tiles = 0
+    for p, init in zip(self.params, self._inits):
+      sl = slice(p.offset, p.offset + p.numel)
+      p.master = self.master[sl].view(p.shape)
+      p.grad = self.grads[sl].view(p.shape)
+      p.w16 = self.w16[sl].view(p.shape)
+      val = init(p.shape) if callable(init) else init
+      p.master.copy_(torch.as_tensor(val, dtype=torch.float32).reshape(p.shape))
+      if p.kind == "conv":
+        K, Cout, Cin = p.shape
+        p.wt16 = self.wt16[p.wt_offset:p.wt_offset + p.numel].view(K, Cin, Cout)
+        descs += struct.pack("<qqiiii", p.offset, p.wt_offset, K, Cout, Cin, tiles)
+        tiles += K * (-(-Cout // 64)) * (-(-Cin // 64))
+    self._wt_tiles = tiles
+    self._wt_descs = (torch.frombuffer(bytearray(descs), dtype=torch.uint8).to(dev)
+                      if tiles else None)
+    self._n_wt = len(descs) // 32
+    self._inits = None
+    self.finalized = True
+    self.refresh_compute_copies()
+    return self
+
+  def refresh_compute_copies(self):
+    """master fp32 -> bf16 compute copy (+ the conv dgrad copies)."""
+    capi.cast_f32_to_bf16(self.master, self.w16)
+    self.refresh_dgrad_copies()
+
+  def refresh_dgrad_copies(self):
+    if self._wt_tiles:
+      capi.conv_weight_dgrad_copy(self.w16, self.wt16, self._wt_descs.view(-1, 32),
+                                  self._wt_tiles)
+
+  def zero_grads(self):
+    self.grads.zero_()
+
+  def num_trainable(self):
+    return sum(p.numel for p in self.params)
+
+  def by_name(self, name):
+    for p in self.params:
+      if p.name == name:
+        return p
+    raise KeyError(name)

@@ -1,0 +1,100 @@
+"""GPU parity: os2s_opt_step (multi-tensor MP optimizer) vs the NumPy oracle
+(oracle/optim.py) over several steps, including an overflow/skip step.
+fp32 elementwise math; per-tensor norms are reduced in a different order =>
+rtol 2e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import optim as oopt  # noqa: E402
+
+SHAPES = [(11, 40, 24), (40,), (40,), (5000,), (3, 16, 8), (1, 29, 64), (29,)]
+
+
+def _setup(cuda, need_m2=False):
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  rng = np.random.RandomState(0)
+  store = FlatParams(cuda)
+  ws = []
+  for i, s in enumerate(SHAPES):
+    w = (rng.randn(*s) * 0.1).astype(np.float32)
+    ws.append(w)
+    store.add("v%d" % i, s, w, kind="conv" if len(s) == 3 else "vector")
+  store.finalize(need_m2=need_m2)
+  return store, ws, rng
+
+
+def _run(cuda, optimizer, opt_params, lr_fn, lr_params, larc=None, clip=None,
+         loss_scaling="Backoff", need_m2=False, nsteps=6, inf_step=2, world=1, l2=None):
+  from openseq2seq_amd.optimizers import lr_policies
+  from openseq2seq_amd.optimizers.optimizers import optimize_loss
+  store, ws, rng = _setup(cuda, need_m2)
+  if l2:
+    store.tensor_l2.copy_(torch.tensor(l2))
+  op = optimize_loss(store, optimizer, opt_params, getattr(lr_policies, lr_fn), lr_params,
+                     larc_params=larc, clip_gradients=clip, loss_scaling=loss_scaling,
+                     world_size=world)
+  scaler = None
+  if loss_scaling == "Backoff":
+    scaler = oopt.BackoffScaler()
+  elif loss_scaling == "LogMax":
+    scaler = oopt.LogMaxScaler()
+  name = optimizer if isinstance(optimizer, str) else optimizer.__name__
+  ref = oopt.RefOptimizer(ws, optimizer=name, opt_params=opt_params,
+                          lr_fn=lambda s: getattr(oopt, lr_fn)(s, **lr_params),
+                          larc_params=larc, clip_gradients=clip, scaler=scaler, l2=l2,
+                          world_size=world)
+  if scaler is None:
+    ref.static_scale = np.float32(loss_scaling)
+  for step in range(nsteps):
+    scale = float(ref.loss_scale)
+    st = op.read_state()
+    assert abs(st["loss_scale"] - scale) <= 1e-6 * scale, (step, st["loss_scale"], scale)
+    grads = [(rng.randn(*s) * 0.01).astype(np.float32) * scale * world for s in SHAPES]
+    if step == inf_step:
+      grads[3][17] = np.inf
+    for p, g in zip(store.params, grads):
+      p.grad.copy_(torch.from_numpy(g))
+    op.run()
+    skipped = ref.step(grads)
+    st = op.read_state()
+    assert bool(st["skip"]) == skipped, step
+    assert st["global_step"] == ref.global_step
+    for p, w in zip(store.params, ref.w):
+      torch.testing.assert_close(p.master.cpu(), torch.from_numpy(w), rtol=2e-4, atol=1e-6)
+      torch.testing.assert_close(p.w16.float().cpu(),
+                                 torch.from_numpy(w).to(torch.bfloat16).float(),
+                                 rtol=1e-2, atol=1e-3)
+  # dgrad copies follow the bf16 weights: wT[k'][ci][co] = w[K-1-k'][co][ci]
+  p0 = store.params[0]
+  torch.testing.assert_close(p0.wt16.float().cpu(),
+                             p0.w16.float().cpu().flip(0).permute(0, 2, 1), rtol=0, atol=0)
+  return op.read_state()
+
+
+def test_novograd_larc_backoff_jasper_cfg(cuda):
+  from openseq2seq_amd.optimizers.novograd import NovoGrad
+  st = _run(cuda, NovoGrad,
+            dict(beta1=0.95, beta2=0.98, epsilon=1e-8, weight_decay=0.001, grad_averaging=False),
+            "poly_decay", dict(learning_rate=0.02, min_lr=1e-5, power=2.0, decay_steps=1000),
+            larc=dict(larc_eta=0.001))
+  assert st["num_skipped"] == 1 and st["loss_scale"] == 2.0 ** 13
+
+
+def test_adam_transformer_policy(cuda):
+  _run(cuda, "Adam", dict(beta1=0.9, beta2=0.997, epsilon=1e-9), "transformer_policy",
+       dict(learning_rate=2.0, warmup_steps=8000, d_model=1024), need_m2=True, world=4)
+
+
+def test_momentum_clip_static_scale(cuda):
+  _run(cuda, "Momentum", dict(momentum=0.9), "exp_decay",
+       dict(learning_rate=0.01, decay_steps=2, decay_rate=0.5, use_staircase_decay=True,
+            min_lr=1e-4), clip=0.5, loss_scaling=128.0, inf_step=-1,
+       l2=[5e-4, 0, 0, 5e-4, 0, 0, 0])
+
+
+def test_sgd_logmax(cuda):
+  _run(cuda, "SGD", {}, "fixed_lr", dict(learning_rate=0.1), loss_scaling="LogMax",
+       inf_step=1)

@@ -1,0 +1,44 @@
+"""CPU: optimizer oracle pins. Reproduces the reference's own relations:
+ * mp_wrapper_test.py:54-56,93-95 — an L2 regulariser gradient of 1e-8 vanishes
+   in half precision without the wrapper and equals 1e-8 (atol 1e-11) when the
+   regulariser acts on the fp32 master copy;
+ * lr policies against closed forms; Backoff scaler trajectory
+   (automatic_loss_scaler.py:78-106)."""
+import numpy as np
+
+from oracle import optim
+
+
+def test_mp_regulariser_gradient_1e8():
+  # fp16(1e-8 * w) underflows; on the fp32 master it survives: grad = scale_reg * w
+  w = np.float32(1.0)
+  reg = np.float32(1e-8)
+  assert np.float16(reg * np.float16(w)) == 0.0
+  o = optim.RefOptimizer([np.array([w])], optimizer="SGD", lr_fn=lambda s: 1.0, l2=[reg])
+  o.step([np.zeros(1, np.float32)])
+  g = (1.0 - o.w[0][0])  # lr = 1 -> applied gradient
+  assert abs(g - 1e-8) < 1e-11 or abs(float(np.float32(w) - np.float32(w - reg)) - g) < 1e-11
+
+
+def test_lr_policies():
+  assert optim.poly_decay(0, 0.02, 1000, power=2.0, min_lr=1e-5) == 0.02
+  assert abs(optim.poly_decay(500, 0.02, 1000, power=2.0, min_lr=1e-5) -
+             ((0.02 - 1e-5) * 0.25 + 1e-5)) < 1e-12
+  assert optim.poly_decay(5000, 0.02, 1000, power=2.0, min_lr=1e-5) == 1e-5
+  # transformer policy: peak at step = warmup-1
+  lr = [optim.transformer_policy(s, 2.0, 1024, 8000) for s in (0, 7999, 8000, 100000)]
+  assert lr[0] < lr[1] and lr[1] >= lr[2] > lr[3]
+  assert abs(lr[1] - 2.0 * 1024 ** -0.5 * 8000 ** -0.5) < 1e-9
+  assert optim.exp_decay(10, 1.0, 5, 0.5, True) == 0.25
+
+
+def test_backoff_trajectory():
+  s = optim.BackoffScaler(step_window=4)
+  assert s.scale == 2.0 ** 14
+  assert s.update(True, 1.0) is True and s.scale == 2.0 ** 13
+  scales = []
+  for _ in range(9):
+    s.update(False, 1.0)
+    scales.append(float(s.scale))
+  # doubles when (iter - last_overflow) % 4 == 0: iterations 4 and 8 (last_overflow=0)
+  assert scales == [2.0 ** 13] * 3 + [2.0 ** 14] * 6
