@@ -179,13 +179,16 @@ int os2s_dropout_mask(os2s_stream_t stream, unsigned long long seed, long long n
  *   loss_per_sample [B] (= -log p, 0 for ignored / non-finite samples),
  *   loss_mean [1] (mean over the whole batch), both optional.
  *   dlogits [T,B,V] fp32 and/or dlogits_bf16 [B,T,Vpad] bf16 (zero padded
- *   channels; feeds the FC backward GEMMs) = grad_scale * d(loss_b)/d(logits).
+ *   channels; feeds the FC backward GEMMs) = grad_scale * d(loss_b)/d(logits),
+ *   additionally multiplied by *grad_scale_dev when that device pointer is not
+ *   NULL (the device-resident loss scale of the mixed-precision optimizer).
  * ---------------------------------------------------------------------- */
 size_t os2s_ctc_loss_workspace_bytes(int T, int B, int V, int Lmax);
 int os2s_ctc_loss(os2s_stream_t stream, const float* logits, const int32_t* in_len,
                   const int32_t* labels, const int32_t* label_len, int T, int B,
                   int V, int Lmax, int blank, float grad_scale,
-                  float* loss_per_sample, float* loss_mean, float* dlogits,
+                  const float* grad_scale_dev, float* loss_per_sample,
+                  float* loss_mean, float* dlogits,
                   uint16_t* dlogits_bf16, int Vpad, void* workspace,
                   size_t workspace_bytes);
 

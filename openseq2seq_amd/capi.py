@@ -250,7 +250,7 @@ def dropout_mask(seed, n_elems, keep_prob, device):
 # CTC loss
 # --------------------------------------------------------------------------
 def ctc_loss(logits, in_len, labels, label_len, blank=None, grad_scale=1.0,
-             want_grad=True, want_grad_bf16=False, vpad=32):
+             want_grad=True, want_grad_bf16=False, vpad=32, grad_scale_dev=None):
   """logits [T,B,V] fp32. Returns dict(loss_per_sample, loss_mean, dlogits, dlogits_bf16)."""
   T, B, V = logits.shape
   Lmax = labels.shape[1]
@@ -267,11 +267,12 @@ def ctc_loss(logits, in_len, labels, label_len, blank=None, grad_scale=1.0,
           if want_grad_bf16 else None)
   f = _fn("os2s_ctc_loss",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-           c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-           c_size_t))
+           c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+           c_void_p, c_size_t))
   _lib.check(f(_stream(), _ptr(logits, torch.float32), _ptr(in_len, torch.int32),
                _ptr(labels, torch.int32), _ptr(label_len, torch.int32), T, B, V, Lmax,
-               int(blank), float(grad_scale), _ptr(lps), _ptr(lm),
+               int(blank), float(grad_scale), _ptr(grad_scale_dev, torch.float32, True),
+               _ptr(lps), _ptr(lm),
                _ptr(dl, None, True), _ptr(dl16, None, True), int(vpad), _ptr(ws), nbytes),
              "os2s_ctc_loss")
   return {"loss_per_sample": lps, "loss_mean": lm, "dlogits": dl, "dlogits_bf16": dl16}

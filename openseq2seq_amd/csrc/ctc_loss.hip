@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     int B, int V, int blank, int Smax, const float* __restrict__ alpha,
     const float* __restrict__ beta, const double* __restrict__ coff_a,
     const double* __restrict__ coff_b, const double* __restrict__ loglik,
-    const int32_t* __restrict__ valid, float grad_scale, float* __restrict__ dlogits,
+    const int32_t* __restrict__ valid, float grad_scale_host,
+    const float* __restrict__ grad_scale_dev, float* __restrict__ dlogits,
     bf16_t* __restrict__ dlogits_bf16, int Vpad) {
+  const float grad_scale = grad_scale_dev ? grad_scale_host * (*grad_scale_dev) : grad_scale_host;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * kGR;
@@ -263,8 +265,9 @@ extern "C" size_t os2s_ctc_loss_workspace_bytes(int T, int B, int V, int Lmax) {
 extern "C" int os2s_ctc_loss(os2s_stream_t stream_, const float* logits,
                              const int32_t* in_len, const int32_t* labels,
                              const int32_t* label_len, int T, int B, int V, int Lmax,
-                             int blank, float grad_scale, float* loss_per_sample,
-                             float* loss_mean, float* dlogits, uint16_t* dlogits_bf16,
+                             int blank, float grad_scale, const float* grad_scale_dev,
+                             float* loss_per_sample, float* loss_mean, float* dlogits,
+                             uint16_t* dlogits_bf16,
                              int Vpad, void* workspace, size_t workspace_bytes) {
   OS2S_REQUIRE(logits && in_len && labels && label_len && workspace);
   OS2S_REQUIRE(T >= 1 && B >= 1 && V >= 2 && Lmax >= 0 && blank >= 0 && blank < V);
@@ -291,7 +294,7 @@ extern "C" int os2s_ctc_loss(os2s_stream_t stream_, const float* logits,
   if (dlogits || dlogits_bf16) {
     OS2S_LAUNCH(ctc_grad_kernel, dim3(ceil_div(T, kGR), B), dim3(256), smem_g, stream, logp,
                 labels, Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, coff_a, coff_b,
-                ll, valid, grad_scale, dlogits, dlogits_bf16, Vpad);
+                ll, valid, grad_scale, grad_scale_dev, dlogits, dlogits_bf16, Vpad);
   }
   OS2S_LAUNCH(ctc_finish_kernel, dim3(1), dim3(64), 0, stream, ll, valid, B, loss_per_sample,
               loss_mean);

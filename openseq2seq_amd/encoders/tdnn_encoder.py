@@ -1,0 +1,136 @@
+"""TDNNEncoder — Jasper / QuartzNet / Wave2Letter+ encoder
+(open_seq2seq/encoders/tdnn_encoder.py:10-265) on the HIP conv/BN kernels.
+
+Same config schema, same bookkeeping as the reference's `_encode` (:87-265):
+mask before every conv input, lengths shrink as ceil(L/stride) for SAME and
+(L-K)//s+1 for VALID, dense residual aggregation (block k sees k inputs),
+dropout on every layer output, NO mask on the final output.
+"""
+from __future__ import absolute_import, division, print_function
+
+import torch
+
+from .encoder import Encoder
+from ..parts.cnns.conv_blocks import (Act, ConvBN, conv_bn_res_bn_actv, xavier_normal_conv,
+                                      glorot_uniform_conv)
+
+
+class TDNNEncoder(Encoder):
+  """General time delay neural network (TDNN) encoder. Fully convolutional model."""
+
+  @staticmethod
+  def get_required_params():
+    return dict(Encoder.get_required_params(), **{
+        'dropout_keep_prob': float,
+        'convnet_layers': list,
+        'activation_fn': None,  # any valid callable
+    })
+
+  @staticmethod
+  def get_optional_params():
+    return dict(Encoder.get_optional_params(), **{
+        'data_format': ['channels_first', 'channels_last'],
+        'normalization': [None, 'batch_norm', 'layer_norm', 'instance_norm'],
+        'bn_momentum': float,
+        'bn_epsilon': float,
+        'use_conv_mask': bool,
+        'drop_block_prob': float,
+        'drop_block_index': int,
+    })
+
+  def __init__(self, params, model, name="w2l_encoder", mode='train'):
+    super(TDNNEncoder, self).__init__(params, model, name, mode)
+    if self.params.get('normalization', 'batch_norm') != 'batch_norm':
+      raise NotImplementedError("only normalization='batch_norm' has HIP kernels so far")
+    if self.params.get('data_format', 'channels_last') != 'channels_last':
+      raise NotImplementedError("HIP path is channels_last (the reference's default)")
+    if self.params.get('drop_block_prob', 0.0) > 0:
+      raise NotImplementedError("stochastic block dropping")
+    self._layers = None
+
+  # ---- variable creation (graph-construction phase of the reference) -----
+  def build(self, store, num_features):
+    p = self.params
+    init_tok = p.get('initializer', None)
+    init_name = getattr(init_tok, "__name__", str(init_tok)).lower()
+    uniform = p.get('initializer_params', {}).get('uniform', True)
+    initializer = glorot_uniform_conv if ("xavier" in init_name and uniform) or \
+        "glorot_uniform" in init_name else xavier_normal_conv
+    l2 = 0.0
+    if p.get('regularizer', None) is not None:
+      l2 = float(p.get('regularizer_params', {}).get('scale', 0.0))
+    mom, eps = p.get('bn_momentum', 0.90), p.get('bn_epsilon', 1e-3)
+    scope = "ForwardPass/" + self._name
+    cin = num_features
+    res_channels = []   # channels of the dense-residual inputs accumulated so far
+    layers = []
+    for ib, blk in enumerate(p['convnet_layers']):
+      if blk['type'] != 'conv1d':
+        raise NotImplementedError("layer type %s has no HIP kernel yet" % blk['type'])
+      residual = blk.get('residual', False)
+      dense = blk.get('residual_dense', False)
+      if residual:
+        if dense:
+          res_channels.append(cin)
+          res_in = list(res_channels)
+        else:
+          res_in = [cin]
+      for ir in range(blk['repeat']):
+        lname = "%s/conv%d%d" % (scope, ib + 1, ir + 1)
+        main = ConvBN(store, lname, lname + "/bn", cin, blk['num_channels'],
+                      blk['kernel_size'][0], blk['stride'][0], blk['dilation'][0] if
+                      'dilation' in blk else 1, blk['padding'], mom, eps, l2, initializer)
+        res = []
+        if residual and ir == blk['repeat'] - 1:
+          for i, rc in enumerate(res_in):
+            rn = (lname + "/res_%d" % i) if dense else (lname + "/res")
+            bn = (lname + "/res_bn_%d" % i) if dense else (lname + "/res_bn")
+            # tf.layers.conv1d(res, filters, 1, use_bias=False): default glorot_uniform
+            res.append(ConvBN(store, rn, bn, rc, blk['num_channels'], 1, 1, 1, "SAME", mom,
+                              eps, l2, glorot_uniform_conv))
+        layers.append(dict(block=ib, rep=ir, main=main, res=res, cfg=blk))
+        cin = blk['num_channels']
+    self._layers = layers
+    self.output_dim = cin
+    return self
+
+  def _encode(self, input_dict):
+    """input_dict['source_tensors'] = [features bf16 [B,T,F], src_length int32 [B]].
+    Returns {'outputs': [B,T',C] bf16, 'src_length': int32 [B]} (+ 'outputs_act')."""
+    source_sequence, src_length = input_dict['source_tensors']
+    tape = input_dict.get('tape', None)
+    seed0 = int(input_dict.get('seed', 0))
+    training = (self._mode == "train")
+    use_mask = self.params.get("use_conv_mask", False)
+    act_fn = self.params['activation_fn']
+    default_keep = self.params['dropout_keep_prob']
+
+    lens = src_length if use_mask else None
+    # the data layer hands over already-padded features; mask the first conv input
+    x = Act(source_sequence, lens, requires_grad=False)
+    residual_aggregation = []
+    layer_res = []
+    nl = len(self._layers)
+    for li, L in enumerate(self._layers):
+      blk, main = L['cfg'], L['main']
+      if L['rep'] == 0 and blk.get('residual', False):
+        if blk.get('residual_dense', False):
+          residual_aggregation.append(x)
+          layer_res = list(residual_aggregation)
+        else:
+          layer_res = [x]
+      s = blk['stride'][0]
+      if blk['padding'] == "VALID":
+        new_len = torch.div(src_length - blk['kernel_size'][0], s, rounding_mode='floor') + 1
+      elif s > 1:
+        new_len = torch.div(src_length + s - 1, s, rounding_mode='floor')
+      else:
+        new_len = src_length
+      src_length = new_len
+      keep = blk.get('dropout_keep_prob', default_keep) if training else 1.0
+      res_in = layer_res if L['res'] else []
+      last = (li == nl - 1)
+      x = conv_bn_res_bn_actv(main, L['res'], x, res_in, src_length if use_mask else None,
+                              act_fn, training, tape, keep_prob=keep,
+                              seed=seed0 * 1000003 + li, mask_output=(use_mask and not last))
+    return {'outputs': x.data, 'src_length': src_length, 'outputs_act': x}

@@ -1,0 +1,209 @@
+"""Model shell — open_seq2seq/models/model.py:112-557 re-hosted on PyTorch-ROCm
+device memory + the HIP kernels.
+
+TF1 builds a graph once (`compile`) and runs it with `sess.run`; here `compile`
+creates the data layer, the plugin objects and their variables (FlatParams), the
+train op (optimize_loss) and the data-parallel gradient reducer, and
+`train_step(batch)` enqueues one forward/backward/optimizer step (the body of the
+reference's hot loop, utils/funcs.py:172-205). One process per GPU; `hvd`-style
+data parallelism is RCCL through torch.distributed (parallel replaced by
+openseq2seq_amd/utils/distributed.py).
+"""
+from __future__ import absolute_import, division, print_function
+
+import abc
+import copy
+import time
+
+import six
+import torch
+
+from ..optimizers.flat_params import FlatParams
+from ..optimizers.optimizers import optimize_loss
+from ..parts.cnns.conv_blocks import Tape
+from ..utils import distributed as dist_utils
+from ..utils.utils import check_params, deco_print
+
+
+@six.add_metaclass(abc.ABCMeta)
+class Model(object):
+  @staticmethod
+  def get_required_params():
+    return {
+        'use_horovod': bool,
+        'batch_size_per_gpu': int,
+        'data_layer': None,
+    }
+
+  @staticmethod
+  def get_optional_params():
+    return {
+        'logdir': str, 'num_gpus': int, 'gpu_ids': list, 'load_model': str,
+        'save_summaries_steps': None, 'print_loss_steps': None,
+        'print_samples_steps': None, 'print_bench_info_steps': None,
+        'save_checkpoint_steps': None, 'num_checkpoints': int,
+        'restore_best_checkpoint': bool, 'eval_steps': int, 'finetune': bool,
+        'eval_batch_size_per_gpu': int, 'hooks': list, 'random_seed': int,
+        'num_epochs': int, 'max_steps': int, 'bench_start': int,
+        'data_layer_params': dict, 'optimizer': None, 'optimizer_params': dict,
+        'freeze_variables_regex': None, 'initializer': None, 'initializer_params': dict,
+        'regularizer': None, 'regularizer_params': dict,
+        'dtype': None,   # tf.float16 / tf.float32 tokens or 'mixed' (bf16 + fp32 masters here)
+        'lr_policy': None, 'lr_policy_params': dict, 'max_grad_norm': float,
+        'larc_params': dict, 'loss_scaling': None, 'loss_scaling_params': dict,
+        'summaries': list, 'iter_size': int, 'lm_vocab_file': str,
+        'processed_data_folder': str,
+        'use_trt': bool, 'trt_precision_mode': str, 'trt_max_workspace_size_bytes': int,
+        'trt_minimum_segment_size': int, 'trt_is_dynamic_op': bool,
+        'trt_maximum_cached_engines': int, 'use_xla_jit': bool,
+    }
+
+  def __init__(self, params, mode="train", hvd=None, device=None):
+    """params/mode as in model.py:112-376. `hvd` is any object with rank()/size()
+    (a torch.distributed adapter: utils/distributed.py) or None."""
+    check_params(params, self.get_required_params(), self.get_optional_params())
+    self._params = copy.deepcopy(params)
+    if self._params.get('iter_size', 1) > 1 and not self._params['use_horovod']:
+      raise ValueError("iter_size is only supported in Horovod mode")
+    if mode not in ['train', 'infer', 'eval', 'interactive_infer']:
+      raise ValueError("Mode has to be one of ['train', 'infer', 'eval', 'interactive_infer']")
+    if 'max_steps' in params and 'num_epochs' in params and mode == "train":
+      raise ValueError("You can't provide both max_steps and num_epochs. "
+                       "Please, remove one of them from the config.")
+    self._mode = mode
+    self._hvd = hvd
+    p = self._params
+    p.setdefault('dtype', 'mixed')
+    p.setdefault('iter_size', 1)
+    p.setdefault('loss_scaling', 1.0)
+    self._device = device or torch.device("cuda", torch.cuda.current_device())
+    # seeds: random_seed + rank (model.py:309-313)
+    rs = p.get('random_seed', int(time.time()))
+    rank = hvd.rank() if hvd is not None else 0
+    self._seed = rs + rank
+    torch.manual_seed(rs)     # identical initial weights on every rank
+    self._step_count = 0
+    self._store = None
+    self._train_op = None
+    self._compiled = False
+    self._data_layer = None
+
+  # ---- accessors mirroring the reference ---------------------------------
+  @property
+  def params(self):
+    return self._params
+
+  @property
+  def mode(self):
+    return self._mode
+
+  @property
+  def hvd(self):
+    return self._hvd
+
+  @property
+  def on_horovod(self):
+    return self._hvd is not None
+
+  def get_data_layer(self, worker_id=0):
+    return self._data_layer
+
+  @property
+  def num_gpus(self):
+    return 1
+
+  @property
+  def store(self):
+    return self._store
+
+  @property
+  def train_op(self):
+    return self._train_op
+
+  # ---- compile ---------------------------------------------------------------
+  def compile(self, force_var_reuse=False, checkpoint=None):
+    """model.py:378-557: build the forward pass objects + variables + train op."""
+    self._store = FlatParams(self._device)
+    self._build_forward_pass_objects(self._store)
+    need_m2 = False
+    if self._mode == "train":
+      from ..optimizers.optimizers import _optimizer_id
+      need_m2 = _optimizer_id(self._params['optimizer']) == 3
+    self._store.finalize(need_m2=need_m2)
+    world = self._hvd.size() if self._hvd is not None else 1
+    if self._hvd is not None and world > 1:
+      # BroadcastGlobalVariablesHook(0) (utils/hooks.py:15-55)
+      dist_utils.broadcast_parameters(self._store, self._extra_state_tensors())
+    if self._mode == "train":
+      p = self._params
+      if 'lr_policy' not in p:
+        raise ValueError("lr_policy has to be specified for train mode")
+      lr_params = dict(p.get('lr_policy_params', {}))
+      # model.py:492-499: decay_steps defaults to the total number of steps
+      import inspect
+      try:
+        func_params = inspect.signature(p['lr_policy']).parameters
+      except (TypeError, ValueError):
+        func_params = {}
+      if 'decay_steps' in func_params and 'decay_steps' not in lr_params:
+        lr_params['decay_steps'] = self._last_step()
+      self._train_op = optimize_loss(
+          self._store, p['optimizer'], p.get('optimizer_params', {}), p['lr_policy'],
+          lr_params, dtype=p['dtype'], clip_gradients=p.get('max_grad_norm', None),
+          summaries=p.get('summaries', None), larc_params=p.get('larc_params', None),
+          loss_scaling=p.get('loss_scaling', 1.0),
+          loss_scaling_params=p.get('loss_scaling_params', None),
+          on_horovod=self.on_horovod, iter_size=p.get('iter_size', 1), world_size=world)
+      self._reducer = dist_utils.GradientReducer(self._store, world) if world > 1 else None
+    self._compiled = True
+    return self
+
+  def _last_step(self):
+    p = self._params
+    if 'max_steps' in p:
+      return p['max_steps']
+    if 'num_epochs' in p and self._data_layer is not None:
+      try:
+        n = self._data_layer.get_size_in_samples()
+        world = self._hvd.size() if self._hvd is not None else 1
+        spe = n // (p['batch_size_per_gpu'] * world * p.get('iter_size', 1))
+        return max(spe * p['num_epochs'], 1)
+      except Exception:
+        pass
+    return 100000
+
+  def _extra_state_tensors(self):
+    return []
+
+  @abc.abstractmethod
+  def _build_forward_pass_objects(self, store):
+    """Create data layer + encoder/decoder/loss objects and their variables."""
+
+  @abc.abstractmethod
+  def _forward_backward(self, batch, tape):
+    """Run forward (and record backward) for one batch; returns the loss tensor [1]."""
+
+  @abc.abstractmethod
+  def _get_num_objects_per_step(self, batch):
+    pass
+
+  # ---- one training step (funcs.py:184: sess.run([train_op, ...])) ----------
+  def train_step(self, batch):
+    assert self._compiled and self._mode == "train"
+    p = self._params
+    iter_size = p.get('iter_size', 1)
+    micro = self._step_count % iter_size
+    if micro == 0:
+      self._store.zero_grads()
+    tape = Tape()
+    loss = self._forward_backward(batch, tape)
+    tape.backward()
+    self._step_count += 1
+    if micro == iter_size - 1:
+      if self._reducer is not None:
+        self._reducer.all_reduce()
+      self._train_op.run()
+    return loss
+
+  def global_step(self):
+    return self._train_op.read_state()["global_step"]

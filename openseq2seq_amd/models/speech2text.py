@@ -1,0 +1,76 @@
+"""Speech2Text — open_seq2seq/models/speech2text.py:74-360 (ASR model shell):
+vocab -> decoder size (+1 for the CTC blank, :100-128), the frames-per-step
+metric (:356-360) and WER helpers (levenshtein :51-71, sparse_tensor_to_chars)."""
+from __future__ import absolute_import, division, print_function
+
+import numpy as np
+import torch
+
+from .encoder_decoder import EncoderDecoderModel
+
+
+def levenshtein(a, b):
+  """Levenshtein distance between sequences a and b (speech2text.py:51-71)."""
+  n, m = len(a), len(b)
+  if n > m:
+    a, b = b, a
+    n, m = m, n
+  current = list(range(n + 1))
+  for i in range(1, m + 1):
+    previous, current = current, [i] + [0] * n
+    for j in range(1, n + 1):
+      add, delete = previous[j] + 1, current[j - 1] + 1
+      change = previous[j - 1]
+      if a[j - 1] != b[i - 1]:
+        change = change + 1
+      current[j] = min(add, delete, change)
+  return current[n]
+
+
+def dense_to_chars(ids, lens, idx2char):
+  """Dense form of sparse_tensor_to_chars (speech2text.py:21-36)."""
+  ids = np.asarray(ids)
+  return ["".join(idx2char[int(c)] for c in ids[b, :int(lens[b])]) for b in range(ids.shape[0])]
+
+
+class Speech2Text(EncoderDecoderModel):
+  def _build_forward_pass_objects(self, store):
+    self._data_layer = self._create_data_layer()
+    dl = self._data_layer
+    # speech2text.py:100-128: decoder gets tgt_vocab_size (+1 blank for CTC)
+    self.params['decoder_params']['tgt_vocab_size'] = dl.params['tgt_vocab_size']
+    self._encoder = self._create_encoder()
+    self._decoder = self._create_decoder()
+    if self.mode in ("train", "eval"):
+      self._loss_computator = self._create_loss()
+    self._encoder.build(store, dl.params['num_audio_features'])
+    self._decoder.build(store, self._encoder.output_dim)
+
+  def _forward_backward(self, batch, tape):
+    """batch: dict(source_tensors=[feats bf16 [B,T,F], src_len int32 [B]],
+                   target_tensors=[tgt int32 [B,L], tgt_len int32 [B]])."""
+    enc = self._encoder.encode({'source_tensors': batch['source_tensors'], 'tape': tape,
+                                'seed': self._seed * 7919 + self._step_count})
+    dec = self._decoder.decode({'encoder_output': enc, 'tape': tape})
+    scale_dev = self._train_op.loss_scale_view if self._train_op is not None else None
+    loss = self._loss_computator.compute_loss({
+        'decoder_output': dec, 'target_tensors': batch['target_tensors'],
+        'loss_scale_dev': scale_dev, 'vpad': self._decoder.Vpad})
+    self._last_decoder_output = dec
+    return loss
+
+  def forward(self, batch):
+    """eval / infer forward pass: returns decoder output dict."""
+    enc = self._encoder.encode({'source_tensors': batch['source_tensors']})
+    return self._decoder.decode({'encoder_output': enc})
+
+  def _get_num_objects_per_step(self, batch):
+    """speech2text.py:356-360: number of INPUT feature frames in the batch."""
+    return batch['source_tensors'][1].sum()
+
+  def _extra_state_tensors(self):
+    out = []
+    for L in self._encoder._layers:
+      for br in [L['main']] + L['res']:
+        out += [br.moving_mean, br.moving_var]
+    return out

@@ -1,0 +1,185 @@
+"""conv_bn_actv / conv_bn_res_bn_actv — the conv blocks of
+open_seq2seq/parts/cnns/conv_blocks.py:61-232, re-hosted on the HIP kernels.
+
+There is no graph compiler here: a layer object owns its parameters, `forward`
+enqueues the kernels and records one backward closure on a Tape; `Tape.backward`
+replays them in reverse. Activations are bf16 [B,T,C] channels-last (the
+reference's data_format="channels_last"), always stored ALREADY multiplied by
+the sequence mask of their length vector — the reference multiplies the mask
+onto every conv input (tdnn_encoder.py:185-186,204-205), we fold that multiply
+into the producer's store.
+"""
+import math
+
+import torch
+
+from ... import capi
+
+ACT_IDS = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+
+
+def act_id(fn):
+  """Maps config tokens (tf.nn.relu, tf.nn.tanh, None, names) to kernel ids."""
+  if fn is None:
+    return 0
+  name = fn if isinstance(fn, str) else getattr(fn, "__name__", str(fn))
+  name = name.lower()
+  if name not in ACT_IDS:
+    raise NotImplementedError("activation %r" % (fn,))
+  return ACT_IDS[name]
+
+
+class Tape(object):
+  def __init__(self):
+    self.ops = []
+
+  def record(self, fn):
+    self.ops.append(fn)
+
+  def backward(self):
+    for fn in reversed(self.ops):
+      fn()
+    self.ops = []
+
+
+class Act(object):
+  """An activation tensor + its valid lengths + (optionally) its gradient."""
+  __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad")
+
+  def __init__(self, data, lens=None, requires_grad=True):
+    self.data, self.lens = data, lens
+    self.grad, self.grad_init = None, False
+    self.requires_grad = requires_grad
+
+  def grad_buffer(self):
+    if self.grad is None:
+      self.grad = torch.empty_like(self.data)
+      self.grad_init = False
+    return self.grad
+
+
+def xavier_normal_conv(shape_dev):
+  """tf.contrib.layers.xavier_initializer(uniform=False) for a conv1d kernel:
+  truncated normal, stddev = sqrt(1.3 * 2 / (fan_in + fan_out)) with
+  fan_in = K*Cin, fan_out = K*Cout. Device layout [K, Cout, Cin]."""
+  K, Cout, Cin = shape_dev
+  std = math.sqrt(1.3 * 2.0 / (K * Cin + K * Cout))
+  w = torch.empty(shape_dev)
+  torch.nn.init.trunc_normal_(w, 0.0, std, -2 * std, 2 * std)
+  return w
+
+
+def glorot_uniform_conv(shape_dev):
+  K, Cout, Cin = shape_dev
+  lim = math.sqrt(6.0 / (K * Cin + K * Cout))
+  return (torch.rand(shape_dev) * 2 - 1) * lim
+
+
+class ConvBN(object):
+  """tf.layers.conv1d(use_bias=False) + tf.layers.batch_normalization: the pair of
+  variables '<name>/kernel' and '<name>/bn/{gamma,beta,moving_mean,moving_variance}'
+  (conv_blocks.py:195-227; residual branches :78-99)."""
+
+  def __init__(self, store, name, bn_name, cin, cout, k, stride=1, dilation=1,
+               padding="SAME", bn_momentum=0.9, bn_epsilon=1e-3, l2=0.0,
+               initializer=xavier_normal_conv):
+    self.name, self.cin, self.cout, self.k = name, cin, cout, k
+    self.stride, self.dil, self.padding = stride, dilation, padding
+    self.momentum, self.eps = bn_momentum, bn_epsilon
+    self.kernel = store.add(name + "/kernel", (k, cout, cin), initializer, kind="conv", l2=l2)
+    self.gamma = store.add(bn_name + "/gamma", (cout,), torch.ones(cout), kind="vector", l2=l2)
+    self.beta = store.add(bn_name + "/beta", (cout,), torch.zeros(cout), kind="vector")
+    dev = store.device
+    self.moving_mean = torch.zeros(cout, dtype=torch.float32, device=dev)
+    self.moving_var = torch.ones(cout, dtype=torch.float32, device=dev)
+
+  def out_geometry(self, tin):
+    if self.padding == "SAME":
+      return capi.same_padding(tin, self.k, self.stride, self.dil)
+    return capi.valid_padding(tin, self.k, self.stride, self.dil)
+
+  def conv_bn_stats(self, x, training):
+    """Returns dict(y, scale, shift, mean, rstd, tout, pad_left)."""
+    B, Tin, _ = x.data.shape
+    tout, pl = self.out_geometry(Tin)
+    dev = x.data.device
+    C = self.cout
+    stats = None
+    if training:
+      stats = torch.empty((capi.conv1d_num_mtiles(B, tout), 2, C), dtype=torch.float32,
+                          device=dev)
+    y = capi.conv1d_fwd(x.data, self.kernel.w16, stride=self.stride, dil=self.dil,
+                        pad_left=pl, tout=tout, in_len=x.lens, stats=stats)
+    sc = torch.empty(C, dtype=torch.float32, device=dev)
+    sh = torch.empty(C, dtype=torch.float32, device=dev)
+    mean = rstd = None
+    if training:
+      mean = torch.empty(C, dtype=torch.float32, device=dev)
+      rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    capi.bn_finalize(stats, B * tout, self.gamma.master, self.beta.master, self.eps,
+                     self.momentum, training, self.moving_mean, self.moving_var, mean, rstd,
+                     sc, sh)
+    return dict(y=y, scale=sc, shift=sh, mean=mean, rstd=rstd, tout=tout, pad_left=pl)
+
+
+def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_fn,
+                        training, tape, keep_prob=1.0, seed=0, mask_output=True):
+  """act(BN(conv(x)) + sum_i BN_i(conv1x1_i(res_i))) -> dropout -> mask.
+
+  main: ConvBN; res_branches: list of ConvBN (1x1) matching res_inputs (list of Act).
+  With no residual branches this is conv_bn_actv (conv_blocks.py:170-232); with them
+  conv_bn_res_bn_actv (:61-168). Dropout is the tf.nn.dropout the encoder applies
+  to the block output (tdnn_encoder.py:255)."""
+  act = act_id(activation_fn)
+  branches = [main] + list(res_branches)
+  inputs = [x] + list(res_inputs)
+  fw = [br.conv_bn_stats(inp, training) for br, inp in zip(branches, inputs)]
+  B = x.data.shape[0]
+  tout, C = fw[0]["tout"], main.cout
+  out = torch.empty((B, tout, C), dtype=torch.bfloat16, device=x.data.device)
+  lens = out_lens if mask_output else None
+  capi.bn_act_fwd([f["y"] for f in fw], [f["scale"] for f in fw], [f["shift"] for f in fw],
+                  out, lens, act, keep_prob if training else 1.0, seed)
+  result = Act(out, out_lens if mask_output else None)
+  if not (training and tape is not None):
+    return result
+
+  def backward():
+    dout = result.grad
+    assert dout is not None, "no gradient reached " + main.name
+    rows = B * tout
+    J = len(branches)
+    dz = torch.empty_like(out)
+    partial = torch.empty((capi.bn_act_bwd_num_parts(rows), 1 + J, C), dtype=torch.float32,
+                          device=out.device)
+    capi.bn_act_bwd_reduce(dout, out, [f["y"] for f in fw], [f["mean"] for f in fw],
+                           [f["rstd"] for f in fw], dz, partial, lens, act, keep_prob, seed)
+    result.grad = None
+    c1 = torch.empty(C, dtype=torch.float32, device=out.device)
+    c2 = torch.empty(C, dtype=torch.float32, device=out.device)
+    for j, (br, inp, f) in enumerate(zip(branches, inputs, fw)):
+      capi.bn_bwd_finalize(partial, 1 + j, rows, br.gamma.grad, br.beta.grad, True, c1, c2)
+      dy = torch.empty_like(f["y"])
+      capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1, c2, dy)
+      f["y"] = None
+      capi.conv1d_wgrad(inp.data, dy, br.k, stride=br.stride, dil=br.dil,
+                        pad_left=f["pad_left"], in_len=inp.lens, out=br.kernel.grad,
+                        accumulate=True)
+      if inp.requires_grad:
+        if br.stride != 1:
+          raise NotImplementedError("data-gradient of a strided conv")
+        g = inp.grad_buffer()
+        tin = inp.data.shape[1]
+        capi.conv1d_fwd(dy, br.kernel.wt16, dil=br.dil,
+                        pad_left=(br.k - 1) * br.dil - f["pad_left"], tout=tin, out=g,
+                        accumulate=inp.grad_init)
+        inp.grad_init = True
+
+  tape.record(backward)
+  return result
+
+
+def conv_bn_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, seed=0,
+                 mask_output=True):
+  return conv_bn_res_bn_actv(layer, [], x, [], out_lens, activation_fn, training, tape,
+                             keep_prob, seed, mask_output)

@@ -1,0 +1,90 @@
+"""Data-parallel plumbing: RCCL over xGMI through torch.distributed (backend
+"nccl" is RCCL on ROCm; "gloo" for the CPU tests), one process per GPU.
+
+Replaces the Horovod pieces of the reference:
+  * hvd.init()/rank()/size()                (run.py:43-49)         -> HvdAdapter
+  * BroadcastGlobalVariablesHook(0)         (utils/hooks.py:15-55)  -> broadcast_parameters
+  * reduce_gradients: hvd.allreduce per gradient tensor
+                                            (optimizers.py:77-104)  -> GradientReducer:
+    the gradients already live in ONE flat fp32 buffer in reverse-topological
+    order of production, so the all-reduce is a handful of large contiguous
+    buckets (sized for xGMI: few, big messages) launched on a side stream. The
+    1/world average is folded into the optimizer kernel (os2s_opt_config_t.world_size).
+  * collect_if_horovod (mpi4py gather)      (utils/utils.py:47-82)  -> gather_objects
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class HvdAdapter(object):
+  """Minimal stand-in for the `hvd` module object the reference passes around."""
+
+  def __init__(self):
+    assert dist.is_initialized()
+
+  def rank(self):
+    return dist.get_rank()
+
+  def size(self):
+    return dist.get_world_size()
+
+  def local_rank(self):
+    return int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_from_env(backend=None):
+  """Initialises torch.distributed from torchrun's env (RANK/WORLD_SIZE/MASTER_*).
+  Returns an HvdAdapter, or None for a single-process run."""
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world <= 1:
+    return None
+  if not dist.is_initialized():
+    if backend is None:
+      backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+      torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    dist.init_process_group(backend=backend)
+  return HvdAdapter()
+
+
+def broadcast_parameters(store, extra_tensors=(), root=0):
+  """Rank-0 values for every variable (masters + non-trainable state)."""
+  dist.broadcast(store.master, src=root)
+  for t in extra_tensors:
+    dist.broadcast(t, src=root)
+  store.refresh_compute_copies()
+
+
+class GradientReducer(object):
+  """Bucketed all-reduce(SUM) of the flat fp32 gradient buffer on a side stream."""
+
+  def __init__(self, store, world_size, bucket_bytes=256 << 20):
+    self.store, self.world = store, world_size
+    n = store.grads.numel()
+    per = max(bucket_bytes // 4, store.chunk)
+    per = (per // store.chunk) * store.chunk
+    self.bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
+    self.stream = torch.cuda.Stream() if store.grads.is_cuda else None
+
+  def all_reduce(self):
+    g = self.store.grads
+    if self.stream is None:
+      for s, e in self.bounds:
+        dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
+      return
+    self.stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(self.stream):
+      for s, e in self.bounds:
+        dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
+    torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def gather_objects(obj, root=0):
+  """collect_if_horovod(..., mode='gather') (utils/utils.py:47-82)."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return [obj]
+  out = [None] * dist.get_world_size() if dist.get_rank() == root else None
+  dist.gather_object(obj, out, dst=root)
+  return out
