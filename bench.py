@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py — the reference's headline measurement on MI355X.
+
+`python bench.py --gpus N --steps K --warmup W` times K full training steps
+(forward + backward + all-reduce + mixed-precision NovoGrad/LARC update) of
+Jasper 10x5 Dense-Residual (BASELINE.json configs[1]) on synthetic 16 kHz-shaped
+feature batches already resident in HBM, one process per GPU (RCCL through
+torch.distributed under torchrun), and prints ONE JSON line on rank 0.
+
+metric  = what `run.py --benchmark` prints as "Avg objects per second"
+          (open_seq2seq/utils/funcs.py:192-218): sum over ranks of INPUT feature
+          frames (sum of src_length, models/speech2text.py:356-360) / wall time.
+roofline = the dominant kernel (implicit-GEMM conv1d on the matrix cores, used by
+          forward and data-gradient): algorithmic FLOPs of its launches / their
+          measured durations (HIP events on the launch stream, live in the timed
+          region) vs the dense bf16 MFMA peak.
+cpu_baseline = the CPU oracle (fp32 restatement of the reference's path, torch-CPU
+          + NumPy NovoGrad) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+  sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--batch", type=int, default=32, help="batch_size_per_gpu (reference: 32)")
+  ap.add_argument("--fixed-frames", type=int, default=0,
+                  help="0: durations U[2,16.7]s (default workload); >0: every utterance has "
+                       "this many frames (1680 = worst-case fixed shape)")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-kernel-timing", action="store_true")
+  return ap.parse_args()
+
+
+class ConvTimer(object):
+  """Wraps capi.conv1d_fwd: HIP events around every launch + algorithmic FLOPs."""
+
+  def __init__(self, capi):
+    self.capi = capi
+    self.orig = capi.conv1d_fwd
+    self.records = []
+    self.enabled = False
+
+  def install(self):
+    timer = self
+
+    def wrapped(x, w, **kw):
+      if not timer.enabled:
+        return timer.orig(x, w, **kw)
+      e0 = torch.cuda.Event(enable_timing=True)
+      e1 = torch.cuda.Event(enable_timing=True)
+      e0.record()
+      out = timer.orig(x, w, **kw)
+      e1.record()
+      B, _, Cin = x.shape
+      K, Cout, _ = w.shape
+      tout = out.shape[0] if kw.get("time_major") else out.shape[1]
+      timer.records.append((e0, e1, 2.0 * B * tout * Cin * Cout * K))
+      return out
+
+    self.capi.conv1d_fwd = wrapped
+    # modules that imported the symbol through `capi.` pick the wrapper up automatically
+
+  def summary(self):
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+    fl = sum(f for _, _, f in self.records)
+    return ms, fl, len(self.records)
+
+
+def cpu_baseline(vocab_size=29):
+  """Oracle training step (fp32, CPU) on a bounded sample of the same workload."""
+  import numpy as np
+  from oracle import tdnn as otdnn, optim as oopt
+  from openseq2seq_amd.configs.jasper import jasper_convnet_layers
+  torch.manual_seed(0)
+  layers = jasper_convnet_layers()
+  B, T = 2, 320
+  ncores = os.cpu_count() or 1
+  nthreads = min(ncores, 64)
+  torch.set_num_threads(nthreads)
+  # weights in TF layout
+  w = {}
+  cin, res = 64, []
+  for ib, blk in enumerate(layers):
+    if blk.get("residual"):
+      res.append(cin)
+    for ir in range(blk["repeat"]):
+      n = "conv%d%d" % (ib + 1, ir + 1)
+      k, c = blk["kernel_size"][0], blk["num_channels"]
+      w[n + "/kernel"] = (torch.randn(k, cin, c) * (2.0 / (k * (cin + c))) ** 0.5).requires_grad_(True)
+      w[n + "/bn/gamma"] = torch.ones(c, requires_grad=True)
+      w[n + "/bn/beta"] = torch.zeros(c, requires_grad=True)
+      if blk.get("residual") and ir == blk["repeat"] - 1:
+        for i, rc in enumerate(res):
+          w[n + "/res_%d/kernel" % i] = (torch.randn(1, rc, c) * (2.0 / (rc + c)) ** 0.5).requires_grad_(True)
+          w[n + "/res_bn_%d/gamma" % i] = torch.ones(c, requires_grad=True)
+          w[n + "/res_bn_%d/beta" % i] = torch.zeros(c, requires_grad=True)
+      cin = c
+  fcw = (torch.randn(1024, vocab_size) * 0.03).requires_grad_(True)
+  fcb = torch.zeros(vocab_size, requires_grad=True)
+  names = sorted(w.keys())
+  tensors = [w[n] for n in names] + [fcw, fcb]
+  opt = oopt.RefOptimizer([t.detach().numpy() for t in tensors], optimizer="NovoGrad",
+                          opt_params=dict(beta1=0.95, beta2=0.98, epsilon=1e-8, weight_decay=0.001),
+                          lr_fn=lambda s: oopt.poly_decay(s, 0.02, 100000, power=2.0, min_lr=1e-5),
+                          larc_params=dict(larc_eta=0.001), scaler=oopt.BackoffScaler())
+  x = torch.randn(B, T, 64)
+  lens = torch.tensor([T, T - 40])
+  labels = torch.randint(0, vocab_size - 1, (B, 30))
+  label_len = torch.tensor([30, 20])
+
+  def step():
+    for t in tensors:
+      t.grad = None
+    out, olen = otdnn.tdnn_encode(x, lens, layers, w)
+    _, loss = otdnn.fc_ctc(out, olen, fcw, fcb, labels, label_len)
+    scale = float(opt.loss_scale)
+    (loss * scale).backward()
+    opt.step([t.grad.numpy() for t in tensors])
+    with torch.no_grad():
+      for t, nw in zip(tensors, opt.w):
+        t.copy_(torch.from_numpy(nw))
+    return float(loss)
+
+  step()  # warm-up
+  nt = 2
+  t0 = time.time()
+  for _ in range(nt):
+    step()
+  dt = (time.time() - t0) / nt
+  frames = int(lens.sum())
+  return {"value": frames / dt, "unit": "frames/sec", "cores": nthreads, "kind": "port",
+          "sample": "Jasper10x5 oracle train step (fp32 torch-CPU + NumPy NovoGrad), B=2, "
+                    "T=320 frames, 1 warm-up + %d timed steps, %.2f s/step" % (nt, dt)}
+
+
+def main():
+  args = parse()
+  from openseq2seq_amd.utils import distributed as dist_utils
+  hvd = dist_utils.init_from_env()
+  rank = hvd.rank() if hvd else 0
+  world = hvd.size() if hvd else 1
+  if args.gpus != world and rank == 0 and world > 1:
+    print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+  dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+  torch.cuda.set_device(dev)
+
+  from openseq2seq_amd import capi
+  from openseq2seq_amd.configs.jasper import jasper10x5_config
+  timer = ConvTimer(capi)
+  if not args.no_kernel_timing:
+    timer.install()
+  model_cls, params = jasper10x5_config(batch_size_per_gpu=args.batch, use_horovod=True,
+                                        max_steps=100000)
+  model = model_cls(params, mode="train", hvd=hvd, device=dev)
+  model.compile()
+  dl = model.get_data_layer()
+  batch = dl.synthetic_batch(dev, seed=1234 + rank,
+                             fixed_frames=args.fixed_frames if args.fixed_frames > 0 else None)
+
+  def barrier():
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    model.train_step(batch)
+  barrier()
+  timer.enabled = not args.no_kernel_timing and rank == 0
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss = model.train_step(batch)
+  barrier()
+  dt = time.perf_counter() - t0
+  timer.enabled = False
+
+  tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+  frames = torch.tensor([float(batch['num_frames'])], dtype=torch.float64, device=dev)
+  padded = torch.tensor([float(batch['padded_frames'])], dtype=torch.float64, device=dev)
+  if world > 1:
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.all_reduce(frames, op=torch.distributed.ReduceOp.SUM)
+    torch.distributed.all_reduce(padded, op=torch.distributed.ReduceOp.SUM)
+  if rank != 0:
+    return
+  dt = float(tmax.item())
+  total_frames = float(frames.item()) * args.steps
+  value = total_frames / dt
+  st = model.train_op.read_state()
+  out = {
+      "metric": "audio-frames/sec/node Jasper10x5 bf16 (train step, objects = input feature frames)",
+      "value": value, "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
+      "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+      "data": "synthetic",
+      "config": {
+          "workload": "Jasper 10x5 DR (jasper10x5_LibriSpeech_nvgrad_masks) full train step: "
+                      "fwd+bwd+RCCL all-reduce+NovoGrad/LARC/Backoff, B=%d/GPU, %s, F=64, V=29" % (
+                          args.batch, ("T=%d fixed" % args.fixed_frames) if args.fixed_frames
+                          else "durations U[2,16.7]s padded to the batch max"),
+          "global_batch": args.batch * world,
+          "frames_per_step": float(frames.item()),
+          "padded_frames_per_step": float(padded.item()),
+          "padded_frames_per_sec": float(padded.item()) * args.steps / dt,
+          "train_gflop_per_padded_frame": 0.9975,
+          "model_tflops": 0.9975e-3 * float(padded.item()) * args.steps / dt,
+          "params_M": model.store.num_trainable() / 1e6,
+          "parallelism": "dp%d" % world,
+          "loss": float(loss.cpu()[0]), "loss_scale": st["loss_scale"],
+          "skipped_steps": st["num_skipped"],
+      },
+  }
+  if not args.no_kernel_timing:
+    ms, fl, n = timer.summary()
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out["roofline"] = {
+        "bound": "mfma", "kernel": "conv1d_igemm_kernel<128,128,2,2> (fwd + dgrad launches)",
+        "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+        "launches_per_step": n / max(args.steps, 1),
+        "avg_launch_ms": ms / max(n, 1),
+        "time_share_of_step": ms / (1000.0 * dt),
+    }
+  if world == 1 and not args.no_cpu_baseline:
+    try:
+      out["cpu_baseline"] = cpu_baseline()
+    except Exception as e:  # the baseline must never break the bench line
+      out["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": 0, "kind": "port",
+                             "sample": "failed: %r" % (e,)}
+  print(json.dumps(out))
+
+
+if __name__ == "__main__":
+  main()
