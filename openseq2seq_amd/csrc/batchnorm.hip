@@ -24,25 +24,41 @@ constexpr int kMaxBnInputs = 12;
 // ---------------------------------------------------------------------------
 // finalize: partial (sum, sumsq) -> mean / rstd / fused scale+shift, moving stats
 // ---------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nparts,
-                                   int C, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps,
-                                   float momentum, int training,
-                                   float* __restrict__ moving_mean,
-                                   float* __restrict__ moving_var,
-                                   float* __restrict__ mean_out,
-                                   float* __restrict__ rstd_out,
-                                   float* __restrict__ scale_out,
-                                   float* __restrict__ shift_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float mean, var;
-  if (training) {
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) {
-      s += (double)partial[((long long)i * 2 + 0) * C + c];
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int nparts, int C, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, int training, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, float* __restrict__ scale_out,
+    float* __restrict__ shift_out) {
+  // 64 channels per block, 4 lanes of partial rows per channel (coalesced over c)
+  __shared__ double sh_s[4][64], sh_q[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0, q = 0.0;
+  if (training && c < C) {
+    int i = pl;
+    for (; i + 12 < nparts; i += 16) {
+      const float a0 = partial[((long long)i * 2) * C + c], b0 = partial[((long long)i * 2 + 1) * C + c];
+      const float a1 = partial[((long long)(i + 4) * 2) * C + c], b1 = partial[((long long)(i + 4) * 2 + 1) * C + c];
+      const float a2 = partial[((long long)(i + 8) * 2) * C + c], b2 = partial[((long long)(i + 8) * 2 + 1) * C + c];
+      const float a3 = partial[((long long)(i + 12) * 2) * C + c], b3 = partial[((long long)(i + 12) * 2 + 1) * C + c];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; i < nparts; i += 4) {
+      s += (double)partial[((long long)i * 2) * C + c];
       q += (double)partial[((long long)i * 2 + 1) * C + c];
     }
+  }
+  sh_s[pl][cl] = s;
+  sh_q[pl][cl] = q;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  float mean, var;
+  if (training) {
+    s = (sh_s[0][cl] + sh_s[1][cl]) + (sh_s[2][cl] + sh_s[3][cl]);
+    q = (sh_q[0][cl] + sh_q[1][cl]) + (sh_q[2][cl] + sh_q[3][cl]);
     const double m = s / count;
     double v = q / count - m * m;
     if (v < 0.0) v = 0.0;
@@ -327,18 +343,35 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
 
 // Backward finalize for input j: reduce the partials -> dgamma, dbeta and the two
 // means pass 2 needs (c1 = mean(dz), c2 = mean(dz*xhat)).
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nparts,
-                                       int nq, int q, int C, double count,
-                                       float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate,
-                                       float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int nparts, int nq, int q, int C, double count,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double sh_d[4][64], sh_x[4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double sd = 0.0, sx = 0.0;
-  for (int i = 0; i < nparts; ++i) {
-    sd += (double)partial[((long long)i * nq + 0) * C + c];
-    sx += (double)partial[((long long)i * nq + q) * C + c];
+  if (c < C) {
+    int i = pl;
+    for (; i + 4 < nparts; i += 8) {
+      const float a0 = partial[((long long)i * nq + 0) * C + c];
+      const float b0 = partial[((long long)i * nq + q) * C + c];
+      const float a1 = partial[((long long)(i + 4) * nq + 0) * C + c];
+      const float b1 = partial[((long long)(i + 4) * nq + q) * C + c];
+      sd += (double)a0 + (double)a1;
+      sx += (double)b0 + (double)b1;
+    }
+    for (; i < nparts; i += 4) {
+      sd += (double)partial[((long long)i * nq + 0) * C + c];
+      sx += (double)partial[((long long)i * nq + q) * C + c];
+    }
   }
+  sh_d[pl][cl] = sd;
+  sh_x[pl][cl] = sx;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  sd = (sh_d[0][cl] + sh_d[1][cl]) + (sh_d[2][cl] + sh_d[3][cl]);
+  sx = (sh_x[0][cl] + sh_x[1][cl]) + (sh_x[2][cl] + sh_x[3][cl]);
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sd;
   c1[c] = (float)(sd / count);
@@ -346,35 +379,58 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int np
 }
 
 // Backward pass 2 for input j: dy = gamma*rstd*(dz - c1 - xhat*c2)
+//   = A*dz + Bq*y + Cc with per-channel A, Bq, Cc held in registers; a thread owns
+// 8 channels and walks rows (4 rows = 8 x 16-B loads in flight).
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ c1,
-    const float* __restrict__ c2, bf16_t* __restrict__ dy, long long rows, int C) {
+    const float* __restrict__ c2, bf16_t* __restrict__ dy, long long rows, int C,
+    int rows_per_block) {
   const int C8 = C >> 3;
-  const long long total = rows * C8;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (long long)gridDim.x * 256) {
-    const long long row = i / C8;
-    const int c0 = (int)(i - row * C8) * 8;
+  const int G = min(C8, 256);
+  const int RL = 256 / G;
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  const int cg = blockIdx.y * G + g;
+  if (cg >= C8 || rl >= RL) return;
+  const int c0 = cg * 8;
+  float A[8], Bq[8], Cc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float rs = rstd[c0 + e];
+    const float gm = gamma ? gamma[c0 + e] : 1.f;
+    A[e] = gm * rs;
+    Bq[e] = -gm * rs * rs * c2[c0 + e];
+    Cc[e] = gm * rs * (mean[c0 + e] * rs * c2[c0 + e] - c1[c0 + e]);
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(rows, r0 + rows_per_block);
+  auto one = [&](const u32x4& d, const u32x4& yv) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = A[2 * e] * bflo(d[e]) + Bq[2 * e] * bflo(yv[e]) + Cc[2 * e];
+      const float hi = A[2 * e + 1] * bfhi(d[e]) + Bq[2 * e + 1] * bfhi(yv[e]) + Cc[2 * e + 1];
+      o[e] = pack2bf(lo, hi);
+    }
+    return o;
+  };
+  long long row = r0 + rl;
+  for (; row + 3LL * RL < r1; row += 4LL * RL) {
+    u32x4 d[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      d[u] = *reinterpret_cast<const u32x4*>(dz + (row + (long long)u * RL) * C + c0);
+      yv[u] = *reinterpret_cast<const u32x4*>(y + (row + (long long)u * RL) * C + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      *reinterpret_cast<u32x4*>(dy + (row + (long long)u * RL) * C + c0) = one(d[u], yv[u]);
+  }
+  for (; row < r1; row += RL) {
     const u32x4 d = *reinterpret_cast<const u32x4*>(dz + row * C + c0);
     const u32x4 yv = *reinterpret_cast<const u32x4*>(y + row * C + c0);
-    float dv[8] = {bflo(d[0]), bfhi(d[0]), bflo(d[1]), bfhi(d[1]),
-                   bflo(d[2]), bfhi(d[2]), bflo(d[3]), bfhi(d[3])};
-    float xv[8] = {bflo(yv[0]), bfhi(yv[0]), bflo(yv[1]), bfhi(yv[1]),
-                   bflo(yv[2]), bfhi(yv[2]), bflo(yv[3]), bfhi(yv[3])};
-    float r[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float rs = rstd[c0 + e];
-      const float g = gamma ? gamma[c0 + e] : 1.f;
-      const float xh = (xv[e] - mean[c0 + e]) * rs;
-      r[e] = g * rs * (dv[e] - c1[c0 + e] - xh * c2[c0 + e]);
-    }
-    u32x4 o;
-    o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]);
-    o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
-    *reinterpret_cast<u32x4*>(dy + row * C + c0) = o;
+    *reinterpret_cast<u32x4*>(dy + row * C + c0) = one(d, yv);
   }
 }
 
@@ -405,14 +461,14 @@ extern "C" int os2s_bn_finalize(os2s_stream_t stream, const float* partial, int 
   OS2S_REQUIRE(C >= 1 && scale_out && shift_out);
   if (training) OS2S_REQUIRE(partial && nparts >= 1 && count >= 1);
   else OS2S_REQUIRE(moving_mean && moving_var);
-  OS2S_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0,
+  OS2S_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0,
               (hipStream_t)stream, partial, nparts, C, (double)count, gamma, beta, eps,
               momentum, training, moving_mean, moving_var, mean_out, rstd_out, scale_out,
               shift_out);
   return OS2S_OK;
 }
 
-static const int kStatsRowsPerBlock = 512;
+static const int kStatsRowsPerBlock = 128;
 
 extern "C" int os2s_bn_stats_num_parts(long long rows) {
   return ceil_div(rows, kStatsRowsPerBlock);
@@ -448,7 +504,7 @@ extern "C" int os2s_bn_act_fwd(os2s_stream_t stream, int J, const uint16_t* cons
   return OS2S_OK;
 }
 
-static const int kBwdRowsPerBlock = 256;
+static const int kBwdRowsPerBlock = 64;
 
 extern "C" int os2s_bn_act_bwd_num_parts(long long rows) {
   return ceil_div(rows, kBwdRowsPerBlock);
@@ -498,7 +554,7 @@ extern "C" int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, 
                                     int nq, int q, int C, long long count, float* dgamma,
                                     float* dbeta, int accumulate, float* c1, float* c2) {
   OS2S_REQUIRE(partial && c1 && c2 && nparts >= 1 && q >= 1 && q < nq && count >= 1);
-  OS2S_LAUNCH(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0,
+  OS2S_LAUNCH(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0,
               (hipStream_t)stream, partial, nparts, nq, q, C, (double)count, dgamma, dbeta,
               accumulate, c1, c2);
   return OS2S_OK;
@@ -510,8 +566,12 @@ extern "C" int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const
                                  long long rows, int C) {
   OS2S_REQUIRE(dz && y && mean && rstd && c1 && c2 && dy && C % 8 == 0);
   if (rows == 0) return OS2S_OK;
-  OS2S_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
-              (hipStream_t)stream, dz, y, gamma, mean, rstd, c1, c2, dy, rows, C);
+  const int C8 = C / 8;
+  const int G = C8 < 256 ? C8 : 256;
+  const int rpb = 64;
+  dim3 grid(ceil_div(rows, rpb), ceil_div(C8, G));
+  OS2S_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, y, gamma, mean,
+              rstd, c1, c2, dy, rows, C, rpb);
   return OS2S_OK;
 }
 

@@ -122,13 +122,52 @@ __global__ __launch_bounds__(256) void mt_grad_stats_kernel(
   }
 }
 
-// ---- pass 2: one workgroup: per-tensor norms, post-processing factors,
-//      NaN/Inf decision, loss-scaler update, lr, NovoGrad second moments ------
-__global__ __launch_bounds__(256) void mt_finalize_kernel(
+// ---- pass 2a: one workgroup per tensor: reduce its chunks' partials ------------
+__global__ __launch_bounds__(256) void mt_tensor_reduce_kernel(
     const float* __restrict__ partial, const int32_t* __restrict__ tensor_chunk_begin,
+    float* __restrict__ tensor_gnorm2, float* __restrict__ tensor_wnorm2,
+    float* __restrict__ tensor_amax, float* __restrict__ tensor_nan) {
+  __shared__ double sh_g[4], sh_w[4];
+  __shared__ float sh_m[4], sh_n[4];
+  const int t = blockIdx.x;
+  const int c0 = tensor_chunk_begin[t], c1 = tensor_chunk_begin[t + 1];
+  double g2 = 0.0, w2 = 0.0;
+  float mx = 0.f, nn = 0.f;
+  for (int c = c0 + threadIdx.x; c < c1; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long long)c * 4);
+    g2 += (double)v[0];
+    w2 += (double)v[1];
+    mx = fmaxf(mx, v[2]);
+    nn = fmaxf(nn, v[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    g2 += __shfl_xor(g2, o, 64);
+    w2 += __shfl_xor(w2, o, 64);
+  }
+  mx = wave_max(mx);
+  nn = wave_max(nn);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sh_g[wid] = g2; sh_w[wid] = w2; sh_m[wid] = mx; sh_n[wid] = nn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g2 = (sh_g[0] + sh_g[1]) + (sh_g[2] + sh_g[3]);
+    w2 = (sh_w[0] + sh_w[1]) + (sh_w[2] + sh_w[3]);
+    mx = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    nn = fmaxf(fmaxf(sh_n[0], sh_n[1]), fmaxf(sh_n[2], sh_n[3]));
+    tensor_gnorm2[t] = (float)g2;
+    tensor_wnorm2[t] = (float)w2;
+    tensor_amax[t] = mx;
+    tensor_nan[t] = (nn > 0.f || g2 != g2) ? 1.f : 0.f;
+  }
+}
+
+// ---- pass 2b: one workgroup: global norm, post-processing factors, NaN/Inf
+//      decision, loss-scaler update, lr, NovoGrad second moments ----------------
+__global__ __launch_bounds__(256) void mt_finalize_kernel(
     int ntensors, os2s_opt_config_t cfg, OptDeviceState* __restrict__ st,
     float* __restrict__ tensor_gnorm2, float* __restrict__ tensor_wnorm2,
-    float* __restrict__ tensor_amax, float* __restrict__ tensor_mult,
+    float* __restrict__ tensor_amax, float* __restrict__ tensor_mult /* in: nan flags */,
     float* __restrict__ tensor_v /* NovoGrad 2nd moments */) {
   __shared__ float sh_f[256];
   __shared__ float sh_m[256];
@@ -139,19 +178,8 @@ __global__ __launch_bounds__(256) void mt_finalize_kernel(
   float tot = 0.f;
   int anynan = 0;
   for (int t = threadIdx.x; t < ntensors; t += 256) {
-    double g2 = 0.0, w2 = 0.0;
-    float mx = 0.f, nn = 0.f;
-    for (int c = tensor_chunk_begin[t]; c < tensor_chunk_begin[t + 1]; ++c) {
-      g2 += (double)partial[c * 4 + 0];
-      w2 += (double)partial[c * 4 + 1];
-      mx = fmaxf(mx, partial[c * 4 + 2]);
-      nn = fmaxf(nn, partial[c * 4 + 3]);
-    }
-    tensor_gnorm2[t] = (float)g2;
-    tensor_wnorm2[t] = (float)w2;
-    tensor_amax[t] = mx;
-    tot += (float)g2;
-    if (nn > 0.f || g2 != g2) anynan = 1;
+    tot += tensor_gnorm2[t];
+    if (tensor_mult[t] > 0.f) anynan = 1;
   }
   if (anynan) atomicOr(&sh_nan, 1);
   sh_f[threadIdx.x] = tot;
@@ -408,9 +436,10 @@ extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg
   OS2S_LAUNCH(opt_latch_scale_kernel, dim3(1), dim3(1), 0, stream, st);
   OS2S_LAUNCH(mt_grad_stats_kernel, dim3(nchunks), dim3(256), 0, stream, grads, weights,
               chunk_tensor, tensor_l2, st, cfg->world_size, partial);
-  OS2S_LAUNCH(mt_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, tensor_chunk_begin,
-              ntensors, *cfg, st, tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult,
-              tensor_v);
+  OS2S_LAUNCH(mt_tensor_reduce_kernel, dim3(ntensors), dim3(256), 0, stream, partial,
+              tensor_chunk_begin, tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult);
+  OS2S_LAUNCH(mt_finalize_kernel, dim3(1), dim3(256), 0, stream, ntensors, *cfg, st,
+              tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult, tensor_v);
   OS2S_LAUNCH(mt_apply_kernel, dim3(nchunks), dim3(256), 0, stream, grads, weights, m1, m2,
               w16, chunk_tensor, tensor_l2, tensor_mult, tensor_wd_mask, *cfg, st);
   return OS2S_OK;
