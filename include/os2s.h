@@ -97,6 +97,8 @@ int os2s_ctc_greedy_decode(os2s_stream_t stream, const float* logits,
  * Requirements: Cin % 8 == 0; for bf16 output Cout % 8 == 0 and strides % 8 == 0.
  * ---------------------------------------------------------------------- */
 int os2s_conv1d_num_mtiles(int B, int Tout);
+/* tuning hook: selects the tile variant (0 = 128x128/4 waves, 1 = 256x128/8 waves) */
+void os2s_conv1d_set_variant(int v);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,
                     float* stats, int B, int Tin, int Cin, int Cout, int K,
@@ -238,6 +240,33 @@ int os2s_cast_f32_to_bf16(os2s_stream_t stream, const float* src, uint16_t* dst,
 int os2s_conv_weight_dgrad_copy(os2s_stream_t stream, const uint16_t* w16,
                                 uint16_t* wt16, const void* descs, int ndesc,
                                 int total_tiles);
+
+/* ------------------------------------------------------------------------
+ * ASR log-mel front end ("logfbank", librosa backend). Replaces the NumPy/librosa
+ * feature extraction the reference runs on the host inside tf.py_func:
+ * get_speech_features_librosa (open_seq2seq/data/speech2text/speech_utils.py:322-441):
+ * gain normalise -> dither -> pre-emphasis -> centred reflect-padded STFT (n_fft 512,
+ * symmetric Hann of win_length zero-padded to n_fft) -> |.|^2 -> mel -> log(.+floor)
+ * -> per-feature (or global) mean/std over time; output is the zero-padded batch
+ * [B, Tpad, n_mels] the data layer hands to the encoder (speech2text.py:313-317).
+ *   signal      [B, Nmax] float32 or int16 PCM (sample_is_int16), n_samples [B]
+ *   window      [n_fft] fp32 device (already centred/zero-padded)
+ *   mel tables  compact form of the [n_mels, n_fft/2+1] basis: for filter m the
+ *               non-zero run starts at bin mel_start[m], has mel_len[m] bins, weights
+ *               mel_wt[j*n_mels + m]
+ *   fixed_gain  > 0: use it; <= 0: 1/(max|x| + 1e-5) per utterance
+ *   frames per utterance = 1 + n_samples/hop (out_len), rows >= that are zero
+ * Only n_fft == 512 and n_mels <= 64 are implemented (OS2S_ERR_UNSUPPORTED otherwise).
+ * ---------------------------------------------------------------------- */
+size_t os2s_logmel_workspace_bytes(int B, int Tmax, int n_mels);
+int os2s_logmel(os2s_stream_t stream, const void* signal, const int32_t* n_samples,
+                int sample_is_int16, int B, long long Nmax, int n_fft, int hop,
+                int n_mels, const float* window, const int32_t* mel_start,
+                const int32_t* mel_len, const float* mel_wt, int mel_maxlen,
+                float preemph, float dither, unsigned long long seed, float fixed_gain,
+                float log_floor, int norm_per_feature, int Tmax, int Tpad,
+                uint16_t* out_bf16, float* out_f32, int32_t* out_len, void* workspace,
+                size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

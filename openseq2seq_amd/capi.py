@@ -367,3 +367,32 @@ def conv_weight_dgrad_copy(w16, wt16, descs, total_tiles):
   _lib.check(f(_stream(), _ptr(w16, torch.bfloat16), _ptr(wt16, torch.bfloat16),
                _ptr(descs, torch.uint8), ndesc, int(total_tiles)),
              "os2s_conv_weight_dgrad_copy")
+
+
+# --------------------------------------------------------------------------
+# log-mel front end
+# --------------------------------------------------------------------------
+def logmel(signal, n_samples, window, mel_start, mel_len, mel_wt, *, hop, n_mels, tmax, tpad,
+           preemph=0.97, dither=0.0, seed=0, fixed_gain=-1.0, log_floor=1e-20,
+           norm_per_feature=True, want_f32=False, n_fft=512):
+  """signal [B,Nmax] float32|int16 -> (features bf16 [B,tpad,n_mels], frames int32 [B], f32|None)."""
+  B, Nmax = signal.shape
+  dev = signal.device
+  is_i16 = signal.dtype == torch.int16
+  assert is_i16 or signal.dtype == torch.float32
+  nbytes = int(_fn("os2s_logmel_workspace_bytes", (c_int, c_int, c_int), c_size_t)(B, tmax, n_mels))
+  ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+  out = torch.empty((B, tpad, n_mels), dtype=torch.bfloat16, device=dev)
+  out32 = torch.empty((B, tpad, n_mels), dtype=torch.float32, device=dev) if want_f32 else None
+  olen = torch.empty((B,), dtype=torch.int32, device=dev)
+  f = _fn("os2s_logmel",
+          (c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_int, c_int, c_void_p,
+           c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_uint64, c_float, c_float,
+           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+  _lib.check(f(_stream(), _ptr(signal), _ptr(n_samples, torch.int32), int(is_i16), B, Nmax,
+               n_fft, hop, n_mels, _ptr(window, torch.float32), _ptr(mel_start, torch.int32),
+               _ptr(mel_len, torch.int32), _ptr(mel_wt, torch.float32), mel_wt.shape[0],
+               float(preemph), float(dither), int(seed) & (2**64 - 1), float(fixed_gain),
+               float(log_floor), int(bool(norm_per_feature)), tmax, tpad, _ptr(out),
+               _ptr(out32, None, True), _ptr(olen), _ptr(ws), nbytes), "os2s_logmel")
+  return out, olen, out32

@@ -304,8 +304,13 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
 
 }  // namespace os2s
 
+static int g_conv_variant = 0;
+// tuning hook (not part of the stable ABI surface used by the host layer)
+extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
+
 extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
-  return B * os2s::ceil_div(Tout, os2s::kConvBM);
+  const int bm = (g_conv_variant == 1) ? 256 : os2s::kConvBM;
+  return B * os2s::ceil_div(Tout, bm);
 }
 
 extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x,
@@ -328,5 +333,6 @@ extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x,
   a.x_sb = (long long)Tin * Cin; a.x_st = Cin;
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
+  if (g_conv_variant == 1) return launch_conv<256, 128, 4, 2>((hipStream_t)stream, a);
   return launch_conv<kConvBM, kConvBN, 2, 2>((hipStream_t)stream, a);
 }

@@ -1,0 +1,114 @@
+"""Speech feature extraction front end — host side of
+open_seq2seq/data/speech2text/speech_utils.py (get_speech_features :275-319,
+get_speech_features_librosa :322-441). The per-sample arithmetic runs on the GPU
+(csrc/logmel.hip, os2s_logmel); the host only prepares constant tables once:
+the analysis window and the mel filterbank (what the reference precomputes with
+librosa.filters.mel in speech2text.py:167-183).
+
+librosa 0.6.3 conventions used by the reference's call sites (librosa itself is not
+vendored in the reference): window passed as the CALLABLE np.hanning => symmetric
+Hann of win_length, zero-padded centred to n_fft; filters.mel defaults htk=False,
+norm=1 => Slaney mel scale with area normalisation.
+"""
+from __future__ import absolute_import, division, print_function
+
+import math
+
+import numpy as np
+import torch
+
+from ... import capi
+
+WINDOWS_FNS = {"hanning": np.hanning, "hamming": np.hamming, "none": None}
+
+
+def _hz_to_mel(f):
+  f = np.asanyarray(f, dtype=np.float64)
+  f_sp, min_log_hz = 200.0 / 3, 1000.0
+  logstep = np.log(6.4) / 27.0
+  return np.where(f >= min_log_hz,
+                  min_log_hz / f_sp + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep,
+                  f / f_sp)
+
+
+def _mel_to_hz(m):
+  m = np.asanyarray(m, dtype=np.float64)
+  f_sp, min_log_hz = 200.0 / 3, 1000.0
+  min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+  return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_basis_slaney(sample_freq, n_fft, n_mels, fmin=0.0, fmax=None):
+  """Equivalent of librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) (htk=False, norm=1)."""
+  fmax = sample_freq / 2.0 if fmax is None else fmax
+  fftfreqs = np.linspace(0, sample_freq / 2.0, 1 + n_fft // 2)
+  mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+  fdiff = np.diff(mel_f)
+  ramps = np.subtract.outer(mel_f, fftfreqs)
+  w = np.zeros((n_mels, 1 + n_fft // 2))
+  for i in range(n_mels):
+    w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+  w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+  return w.astype(np.float32)
+
+
+class LogMelFrontEnd(object):
+  """Constant tables + launcher for the 'logfbank' features of a Speech2TextDataLayer
+  configuration (params as in speech_utils.get_speech_features :275-306)."""
+
+  def __init__(self, params, device):
+    self.device = device
+    sr = params.get('sample_freq', 16000)
+    self.sample_freq = sr
+    if params.get('backend', 'psf') != 'librosa' or params.get('input_type') != 'logfbank':
+      raise NotImplementedError("GPU front end implements backend='librosa', "
+                                "input_type='logfbank' (the Jasper configs)")
+    self.n_mels = params['num_audio_features']
+    window_size = params.get('window_size', 20e-3)
+    window_stride = params.get('window_stride', 10e-3)
+    self.win_length = int(sr * window_size)
+    self.hop = int(sr * window_stride)
+    self.n_fft = params.get('num_fft', None) or 2 ** math.ceil(math.log2(window_size * sr))
+    self.dither = params.get('dither', 0.0)
+    self.norm_per_feature = params.get('norm_per_feature', False)
+    self.gain = params.get('gain', None)
+    self.pad_to = params.get('pad_to', 8)
+    wfn = WINDOWS_FNS[params.get('window', 'hanning')]
+    win = wfn(self.win_length) if wfn is not None else np.ones(self.win_length)
+    full = np.zeros(self.n_fft, np.float32)
+    lp = (self.n_fft - self.win_length) // 2
+    full[lp:lp + self.win_length] = win
+    basis = params.get('mel_basis', None)
+    if basis is None:
+      basis = mel_basis_slaney(sr, self.n_fft, self.n_mels, 0, int(sr / 2))
+    self.mel_basis = np.asarray(basis, np.float32)
+    starts, lens = [], []
+    for m in range(self.n_mels):
+      nz = np.nonzero(self.mel_basis[m])[0]
+      starts.append(int(nz[0]) if len(nz) else 0)
+      lens.append(int(nz[-1] - nz[0] + 1) if len(nz) else 0)
+    maxlen = max(max(lens), 1)
+    wt = np.zeros((maxlen, self.n_mels), np.float32)
+    for m in range(self.n_mels):
+      wt[:lens[m], m] = self.mel_basis[m, starts[m]:starts[m] + lens[m]]
+    self.window = torch.from_numpy(full).to(device)
+    self.mel_start = torch.tensor(starts, dtype=torch.int32, device=device)
+    self.mel_len = torch.tensor(lens, dtype=torch.int32, device=device)
+    self.mel_wt = torch.from_numpy(wt).to(device)
+
+  def frames(self, n_samples):
+    return 1 + int(n_samples) // self.hop
+
+  def __call__(self, signal, n_samples, max_samples=None, seed=0, want_f32=False):
+    """signal [B,Nmax] (float32 or int16, device), n_samples int32 [B] (device).
+    max_samples: host int = max(n_samples) (avoids a device sync); defaults to Nmax.
+    Returns (features bf16 [B,Tpad,F], frames int32 [B], fp32 copy or None)."""
+    nmax = int(max_samples) if max_samples is not None else signal.shape[1]
+    tmax = self.frames(nmax)
+    tpad = -(-tmax // self.pad_to) * self.pad_to if self.pad_to > 0 else tmax
+    return capi.logmel(signal, n_samples, self.window, self.mel_start, self.mel_len,
+                       self.mel_wt, hop=self.hop, n_mels=self.n_mels, tmax=tmax, tpad=tpad,
+                       dither=self.dither, seed=seed,
+                       fixed_gain=self.gain if self.gain is not None else -1.0,
+                       norm_per_feature=self.norm_per_feature, want_f32=want_f32,
+                       n_fft=self.n_fft)
