@@ -1,0 +1,2 @@
+from .decoder import Decoder
+from .fc_decoders import FullyConnectedTimeDecoder, FullyConnectedCTCDecoder

@@ -1,0 +1,2 @@
+from .encoder import Encoder
+from .tdnn_encoder import TDNNEncoder

@@ -1,0 +1,2 @@
+from .loss import Loss
+from .ctc_loss import CTCLoss

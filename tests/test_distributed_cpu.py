@@ -1,0 +1,79 @@
+"""CPU (gloo, world_size 2): the data-parallel plumbing that replaces Horovod —
+bucketed flat-gradient all-reduce (optimizers.py:77-104), rank-0 broadcast of the
+variables (hooks.py:15-55), object gather (utils.py:47-82) — and the world-size
+averaging convention of the optimizer (gradients are SUMS over ranks; the kernel
+divides by world_size)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _Store(object):
+  """CPU stand-in for FlatParams (only what the reducer / broadcast touch)."""
+
+  def __init__(self, n, chunk=4096):
+    self.chunk = chunk
+    self.master = torch.zeros(n)
+    self.grads = torch.zeros(n)
+    self.refreshed = 0
+
+  def refresh_compute_copies(self):
+    self.refreshed += 1
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _worker(rank, world, port, q):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                    WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  from openseq2seq_amd.utils import distributed as du
+  hvd = du.init_from_env(backend="gloo")
+  assert hvd.rank() == rank and hvd.size() == world
+  n = 4096 * 5 + 0
+  st = _Store(n)
+  torch.manual_seed(100 + rank)
+  st.master.copy_(torch.randn(n))
+  extra = torch.full((7,), float(rank))
+  du.broadcast_parameters(st, [extra])
+  ref = torch.Generator().manual_seed(100)
+  torch.manual_seed(100)
+  expect_master = torch.randn(n)
+  ok_bcast = bool(torch.equal(st.master, expect_master)) and float(extra.sum()) == 0.0 \
+      and st.refreshed == 1
+  # gradients: rank r holds (r+1) * base -> sum = 3 * base for world 2
+  base = torch.arange(n, dtype=torch.float32) / n
+  st.grads.copy_(base * (rank + 1))
+  red = du.GradientReducer(st, world, bucket_bytes=4096 * 4 * 2)   # forces 3 buckets
+  assert len(red.bounds) == 3
+  red.all_reduce()
+  ok_sum = bool(torch.allclose(st.grads, base * sum(range(1, world + 1))))
+  objs = du.gather_objects({"rank": rank, "n": rank * 10})
+  ok_gather = (objs is None) if rank != 0 else ([o["n"] for o in objs] == [0, 10])
+  q.put((rank, ok_bcast, ok_sum, ok_gather))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_gloo_world2():
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = [q.get(timeout=120) for _ in range(2)]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  for r in res:
+    assert r[1] and r[2] and r[3], r
