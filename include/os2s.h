@@ -97,6 +97,17 @@ int os2s_ctc_greedy_decode(os2s_stream_t stream, const float* logits,
  * Requirements: Cin % 8 == 0; for bf16 output Cout % 8 == 0 and strides % 8 == 0.
  * ---------------------------------------------------------------------- */
 int os2s_conv1d_num_mtiles(int B, int Tout);
+/* Same with a fused epilogue: y = residual + dropout(act(conv + bias)); act 0 none / 1 relu;
+ * dropout uses the (seed, element_index/8) hash shared by all os2s kernels; residual has
+ * y's layout (bf16 output only). Covers FeedFowardNetwork's Dense+ReLU+dropout
+ * (parts/transformer/ffn_layer.py:51-85) and PrePostProcessingWrapper's dropout + residual
+ * (parts/transformer/common.py:99-106). */
+int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,
+                       const int32_t* in_len, const float* bias, float* stats, int B,
+                       int Tin, int Cin, int Cout, int K, int stride, int dil, int padL,
+                       int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
+                       int accumulate, int act, float keep_prob, unsigned long long seed,
+                       const uint16_t* residual);
 /* tuning hook: selects the tile variant (0 = 128x128/4 waves, 1 = 256x128/8 waves) */
 void os2s_conv1d_set_variant(int v);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
@@ -267,6 +278,68 @@ int os2s_logmel(os2s_stream_t stream, const void* signal, const int32_t* n_sampl
                 float log_floor, int norm_per_feature, int Tmax, int Tpad,
                 uint16_t* out_bf16, float* out_f32, int32_t* out_len, void* workspace,
                 size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------
+ * Transformer NMT path (packed, token-major [N_tokens, hidden] bf16 tensors; sequences
+ * are concatenated without padding, cu_* [B+1] hold token offsets).
+ * ---------------------------------------------------------------------- */
+/* EmbeddingSharedWeights.call (parts/transformer/embedding_layer.py:59-88): gather * sqrt(d),
+ * ids >= V -> pad, pad id 0 -> zero vector; + get_position_encoding (utils.py:28-54) at
+ * pos[n]; + tf.nn.dropout (encoders/transformer_encoder.py:157-161,
+ * decoders/transformer_decoder.py:204-213). The decoder's shift-right is the caller's
+ * index remap. */
+int os2s_embed_fwd(os2s_stream_t stream, const int32_t* ids, const int32_t* pos,
+                   const uint16_t* table, int V, int D, long long N, float emb_scale,
+                   float keep_prob, unsigned long long seed, uint16_t* out);
+/* its gradient: dtable[id] += emb_scale * dropout'(dout[n]) (fp32 atomics) */
+int os2s_embed_bwd(os2s_stream_t stream, const int32_t* ids, const uint16_t* dout, int V,
+                   int D, long long N, float emb_scale, float keep_prob,
+                   unsigned long long seed, float* dtable);
+/* LayerNormalization "layernorm_L2" (parts/transformer/common.py:41-68), D in {512, 1024} */
+int os2s_layernorm_fwd(os2s_stream_t stream, const uint16_t* x, const float* gamma,
+                       const float* beta, float eps, long long N, int D, uint16_t* y,
+                       float* mean, float* rstd);
+int os2s_layernorm_bwd_num_parts(long long N);
+/* dx = dres + LN'(dy); partial [num_parts,2,D] = {sum dy, sum dy*xhat}: reduce with
+ * os2s_bn_bwd_finalize(partial, nparts, 2, 1, D, ...) -> dbeta, dgamma */
+int os2s_layernorm_bwd(os2s_stream_t stream, const uint16_t* dy, const uint16_t* x,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const uint16_t* dres, long long N, int D, uint16_t* dx,
+                       float* partial);
+/* mode 0: d = dout * keepmask/keep (hash mask, PrePostProcessingWrapper dropout);
+ * mode 1: d = dout * (out > 0)/keep (Dense+ReLU+dropout of FeedFowardNetwork) */
+int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out,
+                     int mode, float keep_prob, unsigned long long seed, long long n,
+                     uint16_t* d);
+int os2s_add_bf16(os2s_stream_t stream, const uint16_t* a, const uint16_t* b, long long n,
+                  uint16_t* out);
+/* Attention.call "loung" mode (parts/transformer/attention_layer.py:104-220): per
+ * (batch, head) softmax(scale * q k^T + bias) -> dropout -> @ v, fp32 softmax. Head h owns
+ * channels [h*dh, (h+1)*dh) of each row (split_heads/combine_heads are indexing only).
+ * bias = padding mask (absent keys in the packed layout) and, if causal, the decoder's
+ * lower-triangular band (utils.py:57-79). lse [Nq, H] is saved for the backward, which
+ * recomputes the probabilities. Implemented for dh == 64 and max_len <= 64 (training
+ * lengths of the configs); OS2S_ERR_UNSUPPORTED otherwise. */
+int os2s_attention_fwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* k,
+                       const uint16_t* v, uint16_t* o, float* lse, const int32_t* cu_q,
+                       const int32_t* cu_k, int B, int H, int dh, int max_len,
+                       long long ldq, long long ldk, long long ldv, long long ldo,
+                       int causal, float scale, float keep_prob, unsigned long long seed);
+int os2s_attention_bwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* k,
+                       const uint16_t* v, const uint16_t* d_o, const float* lse,
+                       uint16_t* dq, uint16_t* dk, uint16_t* dv, const int32_t* cu_q,
+                       const int32_t* cu_k, int B, int H, int dh, int max_len,
+                       long long ldq, long long ldk, long long ldv, long long lddo,
+                       long long lddq, long long lddk, long long lddv, int causal,
+                       float scale, float keep_prob, unsigned long long seed);
+/* PaddedCrossEntropyLossWithSmoothing (losses/sequence_loss.py:257-309) over the N
+ * non-pad target rows: row_loss[n] = xent(soft targets) - normalizing constant;
+ * loss_mean = sum/N; dlogits = grad_scale * (*grad_scale_dev) * (softmax - soft_target)
+ * (pass grad_scale = 1/N). logits/dlogits bf16 [N, ld], V % 8 == 0, V <= 40960. */
+int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t* labels,
+                     long long N, int V, long long ld, float label_smoothing,
+                     float grad_scale, const float* grad_scale_dev, float* row_loss,
+                     float* loss_mean, uint16_t* dlogits);
 
 #ifdef __cplusplus
 }

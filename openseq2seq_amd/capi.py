@@ -91,7 +91,7 @@ def conv1d_num_mtiles(B, tout):
 
 def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
                bias=None, stats=None, out=None, out_f32=False, accumulate=False,
-               time_major=False):
+               time_major=False, act=0, keep_prob=1.0, seed=0, residual=None):
   """x [B,Tin,Cin] bf16, w [K,Cout,Cin] bf16 -> y [B,Tout,Cout] (or [Tout,B,Cout]
   when time_major). pad_left/tout default to TF 'SAME'."""
   B, Tin, Cin = x.shape
@@ -107,15 +107,17 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
     ysb, yst = Cout, B * Cout
   else:
     ysb, yst = tout * Cout, Cout
-  f = _fn("os2s_conv1d_fwd",
+  f = _fn("os2s_conv1d_fwd_ex",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-           c_ll, c_ll, c_int, c_int))
+           c_ll, c_ll, c_int, c_int, c_int, c_float, c_uint64, c_void_p))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16),
                _ptr(out, dt), _ptr(in_len, torch.int32, True),
                _ptr(bias, torch.float32, True), _ptr(stats, torch.float32, True),
                B, Tin, Cin, Cout, K, stride, dil, pad_left, tout, ysb, yst,
-               int(out_f32), int(accumulate)), "os2s_conv1d_fwd")
+               int(out_f32), int(accumulate), int(act), float(keep_prob),
+               int(seed) & (2**64 - 1), _ptr(residual, torch.bfloat16, True)),
+             "os2s_conv1d_fwd_ex")
   return out
 
 
@@ -396,3 +398,148 @@ def logmel(signal, n_samples, window, mel_start, mel_len, mel_wt, *, hop, n_mels
                float(log_floor), int(bool(norm_per_feature)), tmax, tpad, _ptr(out),
                _ptr(out32, None, True), _ptr(olen), _ptr(ws), nbytes), "os2s_logmel")
   return out, olen, out32
+
+
+# --------------------------------------------------------------------------
+# Transformer kernels (packed token-major tensors)
+# --------------------------------------------------------------------------
+def gemm(x2d, w, **kw):
+  """x2d [N,Cin] bf16, w [Cout,Cin] bf16 -> [N,Cout]: the K=1 case of conv1d_fwd."""
+  out = kw.pop("out", None)
+  N, Cin = x2d.shape
+  Cout = w.shape[0]
+  if out is not None:
+    out = out.view(1, N, Cout)
+  res = kw.pop("residual", None)
+  if res is not None:
+    res = res.view(1, N, Cout)
+  y = conv1d_fwd(x2d.view(1, N, Cin), w.view(1, Cout, Cin), pad_left=0, tout=N, out=out,
+                 residual=res, **kw)
+  return y.view(N, Cout)
+
+
+def gemm_wgrad(x2d, dy2d, out, accumulate=True):
+  """dW [Cout,Cin] (+)= dy^T x."""
+  N, Cin = x2d.shape
+  Cout = dy2d.shape[1]
+  conv1d_wgrad(x2d.view(1, N, Cin), dy2d.view(1, N, Cout), 1, pad_left=0,
+               out=out.view(1, Cout, Cin), accumulate=accumulate)
+
+
+def embed_fwd(ids, pos, table, emb_scale, keep_prob, seed):
+  N = ids.numel()
+  V, D = table.shape
+  out = torch.empty((N, D), dtype=torch.bfloat16, device=ids.device)
+  f = _fn("os2s_embed_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll,
+                             c_float, c_float, c_uint64, c_void_p))
+  _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(pos, torch.int32),
+               _ptr(table, torch.bfloat16), V, D, N, float(emb_scale), float(keep_prob),
+               int(seed) & (2**64 - 1), _ptr(out)), "os2s_embed_fwd")
+  return out
+
+
+def embed_bwd(ids, dout, dtable, emb_scale, keep_prob, seed):
+  N = ids.numel()
+  V, D = dtable.shape
+  f = _fn("os2s_embed_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_float,
+                             c_float, c_uint64, c_void_p))
+  _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(dout, torch.bfloat16), V, D, N,
+               float(emb_scale), float(keep_prob), int(seed) & (2**64 - 1),
+               _ptr(dtable, torch.float32)), "os2s_embed_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-6, save=True):
+  N, D = x.shape
+  y = torch.empty_like(x)
+  mean = torch.empty(N, dtype=torch.float32, device=x.device) if save else None
+  rstd = torch.empty(N, dtype=torch.float32, device=x.device) if save else None
+  f = _fn("os2s_layernorm_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_ll, c_int,
+                                 c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(gamma, torch.float32),
+               _ptr(beta, torch.float32), float(eps), N, D, _ptr(y),
+               _ptr(mean, None, True), _ptr(rstd, None, True)), "os2s_layernorm_fwd")
+  return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
+  """Returns dx (= dres + LN'(dy)); accumulates dgamma/dbeta."""
+  N, D = x.shape
+  dx = torch.empty_like(x)
+  nparts = int(_fn("os2s_layernorm_bwd_num_parts", (c_ll,))(N))
+  partial = torch.empty((nparts, 2, D), dtype=torch.float32, device=x.device)
+  f = _fn("os2s_layernorm_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_ll, c_int, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(dy, torch.bfloat16), _ptr(x, torch.bfloat16),
+               _ptr(gamma, torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
+               _ptr(dres, torch.bfloat16, True), N, D, _ptr(dx), _ptr(partial)),
+             "os2s_layernorm_bwd")
+  scratch = torch.empty((2, D), dtype=torch.float32, device=x.device)
+  bn_bwd_finalize(partial, 1, 1, dgamma, dbeta, True, scratch[0], scratch[1])
+  return dx
+
+
+def dropout_bwd(dout, keep_prob, seed=0, out=None):
+  """mode 0 (hash mask) when out is None, mode 1 (relu+dropout via saved output) otherwise."""
+  d = torch.empty_like(dout)
+  f = _fn("os2s_dropout_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll,
+                               c_void_p))
+  _lib.check(f(_stream(), _ptr(dout, torch.bfloat16), _ptr(out, torch.bfloat16, True),
+               0 if out is None else 1, float(keep_prob), int(seed) & (2**64 - 1),
+               dout.numel(), _ptr(d)), "os2s_dropout_bwd")
+  return d
+
+
+def add_bf16(a, b, out=None):
+  out = torch.empty_like(a) if out is None else out
+  f = _fn("os2s_add_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))
+  _lib.check(f(_stream(), _ptr(a, torch.bfloat16), _ptr(b, torch.bfloat16), a.numel(),
+               _ptr(out)), "os2s_add_bf16")
+  return out
+
+
+def attention_fwd(q, k, v, cu_q, cu_k, H, max_len, causal, scale, keep_prob=1.0, seed=0):
+  """q [Nq, >=H*64] / k, v [Nk, ...] bf16 row-major views (row stride = .stride(0));
+  returns (o [Nq, H*64], lse [Nq, H])."""
+  Nq = q.shape[0]
+  dh = 64
+  B = cu_q.numel() - 1
+  o = torch.empty((Nq, H * dh), dtype=torch.bfloat16, device=q.device)
+  lse = torch.empty((Nq, H), dtype=torch.float32, device=q.device)
+  f = _fn("os2s_attention_fwd",
+          (c_void_p,) * 8 + (c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_ll, c_int, c_float,
+                             c_float, c_uint64))
+  _lib.check(f(_stream(), c_void_p(q.data_ptr()), c_void_p(k.data_ptr()), c_void_p(v.data_ptr()),
+               _ptr(o), _ptr(lse), _ptr(cu_q, torch.int32), _ptr(cu_k, torch.int32), B, H, dh,
+               int(max_len), q.stride(0), k.stride(0), v.stride(0), o.stride(0), int(causal),
+               float(scale), float(keep_prob), int(seed) & (2**64 - 1)), "os2s_attention_fwd")
+  return o, lse
+
+
+def attention_bwd(q, k, v, d_o, lse, dq, dk, dv, cu_q, cu_k, H, max_len, causal, scale,
+                  keep_prob=1.0, seed=0):
+  B = cu_q.numel() - 1
+  f = _fn("os2s_attention_bwd",
+          (c_void_p,) * 11 + (c_int, c_int, c_int, c_int) + (c_ll,) * 7 + (c_int, c_float, c_float,
+                                                                         c_uint64))
+  _lib.check(f(_stream(), c_void_p(q.data_ptr()), c_void_p(k.data_ptr()), c_void_p(v.data_ptr()),
+               _ptr(d_o, torch.bfloat16), _ptr(lse, torch.float32), c_void_p(dq.data_ptr()),
+               c_void_p(dk.data_ptr()), c_void_p(dv.data_ptr()), _ptr(cu_q, torch.int32),
+               _ptr(cu_k, torch.int32), B, H, 64, int(max_len), q.stride(0), k.stride(0),
+               v.stride(0), d_o.stride(0), dq.stride(0), dk.stride(0), dv.stride(0), int(causal),
+               float(scale), float(keep_prob), int(seed) & (2**64 - 1)), "os2s_attention_bwd")
+
+
+def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=True):
+  """logits [N,V] bf16, labels int32 [N] -> (row_loss [N], loss_mean [1], dlogits|None)."""
+  N, V = logits.shape
+  dev = logits.device
+  row_loss = torch.empty(N, dtype=torch.float32, device=dev)
+  mean = torch.empty(1, dtype=torch.float32, device=dev)
+  dl = torch.empty_like(logits) if want_grad else None
+  f = _fn("os2s_xent_smooth", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_ll, c_float, c_float,
+                               c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(logits, torch.bfloat16), _ptr(labels, torch.int32), N, V,
+               logits.stride(0), float(label_smoothing), 1.0 / N,
+               _ptr(grad_scale_dev, torch.float32, True), _ptr(row_loss), _ptr(mean),
+               _ptr(dl, None, True)), "os2s_xent_smooth")
+  return row_loss, mean, dl

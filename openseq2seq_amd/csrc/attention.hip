@@ -1,0 +1,478 @@
+// Multi-head scaled-dot-product attention (forward + backward) for short
+// sequences (Lq, Lk <= 64: the training regime of the Transformer configs,
+// max_length 56 in example_configs/text2text/en-de/transformer-big.py:104),
+// on PACKED token-major tensors, gfx950.
+//
+// Reference: Attention.call (open_seq2seq/parts/transformer/attention_layer.py:104-220):
+//   q *= depth**-0.5; logits = q k^T (fp32 softmax when activations are half precision)
+//   + bias (-1e9 on padded keys, parts/transformer/utils.py:82-129; causal band for the
+//   decoder self-attention, utils.py:57-79); softmax; dropout(keep = 1-attention_dropout);
+//   weights @ v.  split_heads/combine_heads are pure indexing: head h owns channels
+//   [h*dh, (h+1)*dh) of the [tokens, hidden] projections, so no transposes are needed.
+// Packed layout: sequences are concatenated without padding; cu_q / cu_k [B+1] give the
+// token offsets. Padded keys simply do not exist (== the reference's -1e9 bias, whose
+// exp underflows to exactly 0 in fp32).
+//
+// One WAVE owns one (batch, head): all products are 64x64x64 tiles of
+// v_mfma_f32_32x32x16_bf16, always in the "swapped" orientation (result rows = the
+// contiguous output dimension) so each lane ends up with 4 consecutive output elements
+// (8-byte stores) and the softmax row of a query is lane-local (16+16 registers + one
+// cross-half exchange). Operands whose reduction index is the row index in memory
+// (V in P.V, and dO/K/Q in the backward products) are fetched with ds_read_b64_tr_b16.
+// The backward recomputes P from (q, k, lse) — no [B,H,L,L] tensor is ever stored.
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+constexpr int kL = 64;    // tile edge (max sequence length handled)
+constexpr int kDh = 64;   // head dim
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;   // [Nq, ld], [Nk, ld], [Nk, ld]
+  bf16_t* o;                                           // [Nq, ldo]
+  float* lse;                                          // [Nq, H]
+  const int32_t* cu_q; const int32_t* cu_k;            // [B+1]
+  int B, H;
+  long long ldq, ldk, ldv, ldo;
+  int causal;
+  float scale, keep_prob;
+  unsigned long long seed;
+  // backward only
+  const bf16_t* d_o; bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  long long lddo, lddq, lddk, lddv;
+};
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+  return z;
+}
+
+// k-contiguous operand straight from global: row-major [rows][ld], 8 consecutive k
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, long long ld, int row, int nvalid,
+                                              int kofs) {
+  if (row >= nvalid) return zero8();
+  return *reinterpret_cast<const bf16x8*>(base + (long long)row * ld + kofs);
+}
+
+// ---- LDS images (64 x 64 bf16 = 8 KB each, 128-byte rows) -----------------
+// "kc": row-major, k contiguous, 16-B slot XOR swizzle (conflict-free ds_read_b128)
+__device__ __forceinline__ int kc_off(int row, int k) {   // byte offset of element (row, k)
+  return row * 128 + ((((k >> 3) ^ ((row >> 1) & 7))) << 4) + (k & 7) * 2;
+}
+__device__ __forceinline__ bf16x8 frag_kc(const char* buf, int row, int kslot) {
+  return *reinterpret_cast<const bf16x8*>(buf + row * 128 + ((kslot ^ ((row >> 1) & 7)) << 4));
+}
+// "tr": rows = reduction index, 32-B unit XOR swizzle for ds_read_b64_tr_b16
+__device__ __forceinline__ int tr_off(int row, int m) {   // byte offset of element (row=k, m)
+  const int u = (m >> 4) ^ (((row >> 1) & 1) << 1);
+  return row * 128 + (u << 5) + (m & 15) * 2;
+}
+__device__ __forceinline__ bf16x8 frag_tr(const char* buf, int mtile, int kk, int lane) {
+  // operand[m][k] with m = mtile*32 + (lane&31), k = kk*16 + (lane>>5)*8 + 0..7, from [k][m]
+  const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int unit = mtile * 2 + g16;
+  const int r0 = kk * 16 + (lane >> 5) * 8 + (i16 >> 2);
+  const int r1 = r0 + 4;
+  const int c = (i16 & 3) * 8;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4*)(buf + r0 * 128 +
+                                                   ((unit ^ (((r0 >> 1) & 1) << 1)) << 5) + c));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4*)(buf + r1 * 128 +
+                                                   ((unit ^ (((r1 >> 1) & 1) << 1)) << 5) + c));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// copy a [rows<=64][64] bf16 tile from global into a "tr" LDS image (zero fill)
+__device__ __forceinline__ void stage_tr(char* buf, const bf16_t* base, long long ld, int nvalid,
+                                         int lane) {
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int piece = it * 64 + lane;         // 512 pieces of 16 B
+    const int row = piece >> 3, p8 = piece & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < nvalid) v = *reinterpret_cast<const u32x4*>(base + (long long)row * ld + p8 * 8);
+    *reinterpret_cast<u32x4*>(buf + tr_off(row, p8 * 8)) = v;
+  }
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// S^T tile set: s[i][j][r] : key = i*32 + 4*hi + (r&3) + 8*(r>>2), query = j*32 + (lane&31)
+__device__ __forceinline__ void scores(const AttnArgs& p, const bf16_t* qb, const bf16_t* kb, int Lq,
+                                       int Lk, int lane, f32x16 (&s)[2][2]) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[i][j][e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag_global(kb, p.ldk, i * 32 + l31, Lk, kk * 16 + lhi * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = frag_global(qb, p.ldq, j * 32 + l31, Lq, kk * 16 + lhi * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        s[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], s[i][j], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ int key_of(int i, int r, int lhi) {
+  return i * 32 + 4 * lhi + (r & 3) + 8 * (r >> 2);
+}
+
+// dropout keep bits for the 4 consecutive keys key0..key0+3 of query row (bh, q)
+__device__ __forceinline__ uint32_t attn_keep4(const AttnArgs& p, long long bh, int q, int key0) {
+  const long long e0 = ((bh * kL + q) * kL + key0);
+  return (dropout_bits8(p.seed, (unsigned long long)(e0 >> 3), p.keep_prob) >> (uint32_t)(e0 & 7)) & 0xfu;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+constexpr int kFwdWaves = 4;
+
+__global__ __launch_bounds__(kFwdWaves * 64) void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  long long bh = (long long)blockIdx.x * kFwdWaves + wid;
+  const bool live = bh < (long long)p.B * p.H;
+  if (!live) bh = 0;
+  const int b = (int)(bh / p.H), h = (int)(bh - (long long)b * p.H);
+  const int q0 = p.cu_q[b], k0 = p.cu_k[b];
+  const int Lq = min(p.cu_q[b + 1] - q0, kL), Lk = min(p.cu_k[b + 1] - k0, kL);
+  char* pm = smem + wid * 16384;        // PM[q][key]  (kc image)
+  char* vt = pm + 8192;                 // V[key][d]   (tr image)
+  const bf16_t* qb = p.q + (long long)q0 * p.ldq + h * kDh;
+  const bf16_t* kb = p.k + (long long)k0 * p.ldk + h * kDh;
+  const bf16_t* vb = p.v + (long long)k0 * p.ldv + h * kDh;
+
+  f32x16 s[2][2];
+  scores(p, qb, kb, Lq, Lk, lane, s);
+  stage_tr(vt, vb, p.ldv, Lk, lane);
+  // ---- softmax over keys (rows) for each query column ------------------------
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = j * 32 + l31;
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_of(i, r, lhi);
+        const bool ok = key < Lk && !(p.causal && key > q);
+        const float v = ok ? s[i][j][r] * p.scale : -INFINITY;
+        s[i][j][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = fmaxf(m, xhalf(m));
+    const float msafe = m == -INFINITY ? 0.f : m;
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(s[i][j][r] - msafe);
+        s[i][j][r] = e;
+        l += e;
+      }
+    l += xhalf(l);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (live && lhi == 0 && q < Lq && p.lse) p.lse[(long long)(q0 + q) * p.H + h] = msafe + __logf(l);
+    const float ik = 1.f / p.keep_prob;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key0 = i * 32 + 8 * g + 4 * lhi;
+        uint32_t keep = 0xfu;
+        if (p.keep_prob < 1.f) keep = attn_keep4(p, bh, q, key0);
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pv = s[i][j][4 * g + e] * inv;
+          if (p.keep_prob < 1.f) pv = ((keep >> e) & 1u) ? pv * ik : 0.f;
+          w[e] = pv;
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(w[0], w[1]);
+        pk[1] = pack2bf(w[2], w[3]);
+        *reinterpret_cast<u32x2*>(pm + kc_off(q, key0)) = pk;
+      }
+  }
+  __syncthreads();
+  // ---- O^T[d][q] = sum_key V^T[d][key] * PM^T[key][q] -------------------------
+  f32x16 o[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][j][e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2], bq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag_tr(vt, i, kk, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bq[j] = frag_kc(pm, j * 32 + l31, kk * 2 + lhi);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        o[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], o[i][j], 0, 0, 0);
+  }
+  if (live) {
+    bf16_t* ob = p.o + (long long)q0 * p.ldo + h * kDh;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = j * 32 + l31;
+      if (q < Lq) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = i * 32 + 8 * g + 4 * lhi;
+            u32x2 pk;
+            pk[0] = pack2bf(o[i][j][4 * g], o[i][j][4 * g + 1]);
+            pk[1] = pack2bf(o[i][j][4 * g + 2], o[i][j][4 * g + 3]);
+            *reinterpret_cast<u32x2*>(ob + (long long)q * p.ldo + d0) = pk;
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+constexpr int kBwdWaves = 2;
+
+// generic "A via tr image, B via kc image" 64x64x64 product: D[m][n], m from A image cols
+__device__ __forceinline__ void mm_tr_kc(const char* a_tr, const char* b_kc, int lane, f32x16 (&d)[2][2]) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[i][j][e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag_tr(a_tr, i, kk, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = frag_kc(b_kc, j * 32 + l31, kk * 2 + lhi);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], d[i][j], 0, 0, 0);
+  }
+}
+
+// store D[m=d][n] (lane col n, 4 consecutive d per reg group) to out[n][d], rows n < nvalid
+__device__ __forceinline__ void store_dT(const f32x16 (&d)[2][2], bf16_t* out, long long ld, int nvalid,
+                                         float mul, int lane) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = j * 32 + l31;
+    if (n < nvalid) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = i * 32 + 8 * g + 4 * lhi;
+          u32x2 pk;
+          pk[0] = pack2bf(d[i][j][4 * g] * mul, d[i][j][4 * g + 1] * mul);
+          pk[1] = pack2bf(d[i][j][4 * g + 2] * mul, d[i][j][4 * g + 3] * mul);
+          *reinterpret_cast<u32x2*>(out + (long long)n * ld + d0) = pk;
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  long long bh = (long long)blockIdx.x * kBwdWaves + wid;
+  const bool live = bh < (long long)p.B * p.H;
+  if (!live) bh = 0;
+  const int b = (int)(bh / p.H), h = (int)(bh - (long long)b * p.H);
+  const int q0 = p.cu_q[b], k0 = p.cu_k[b];
+  const int Lq = min(p.cu_q[b + 1] - q0, kL), Lk = min(p.cu_k[b + 1] - k0, kL);
+  char* base = smem + wid * 49152;
+  char* do_tr = base;            // dO[q][d]  tr image (rows = q)
+  char* k_tr = base + 8192;      // K[key][d] tr image (rows = key)
+  char* q_tr = base + 16384;     // Q[q][d]   tr image (rows = q)
+  char* pmT = base + 24576;      // PM^T[key][q] kc image (q contiguous)
+  char* ds = base + 32768;       // dS[q][key]   kc image (key contiguous)
+  char* dsT = base + 40960;      // dS^T[key][q] kc image (q contiguous)
+  const bf16_t* qb = p.q + (long long)q0 * p.ldq + h * kDh;
+  const bf16_t* kb = p.k + (long long)k0 * p.ldk + h * kDh;
+  const bf16_t* vb = p.v + (long long)k0 * p.ldv + h * kDh;
+  const bf16_t* dob = p.d_o + (long long)q0 * p.lddo + h * kDh;
+
+  stage_tr(do_tr, dob, p.lddo, Lq, lane);
+  stage_tr(k_tr, kb, p.ldk, Lk, lane);
+  stage_tr(q_tr, qb, p.ldq, Lq, lane);
+
+  f32x16 s[2][2];
+  scores(p, qb, kb, Lq, Lk, lane, s);
+  // dPM^T[key][q] = sum_d V[key][d] dO[q][d]
+  f32x16 dp[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dp[i][j][e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2], bq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag_global(vb, p.ldv, i * 32 + l31, Lk, kk * 16 + lhi * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bq[j] = frag_global(dob, p.lddo, j * 32 + l31, Lq, kk * 16 + lhi * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        dp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], dp[i][j], 0, 0, 0);
+  }
+  const float ik = 1.f / p.keep_prob;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = j * 32 + l31;
+    const float lse = (q < Lq) ? p.lse[(long long)(q0 + q) * p.H + h] : 0.f;
+    float delta = 0.f;
+    // P, M, and delta = sum_key P*M*dPM
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key0 = i * 32 + 8 * g + 4 * lhi;
+        uint32_t keep = 0xfu;
+        if (p.keep_prob < 1.f) keep = attn_keep4(p, bh, q, key0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e, key = key0 + e;
+          const bool ok = key < Lk && q < Lq && !(p.causal && key > q);
+          const float pv = ok ? __expf(s[i][j][r] * p.scale - lse) : 0.f;
+          float mk = 1.f;
+          if (p.keep_prob < 1.f) mk = ((keep >> e) & 1u) ? ik : 0.f;
+          s[i][j][r] = pv;                 // P
+          dp[i][j][r] *= mk;               // dP = dPM * M
+          delta += pv * dp[i][j][r];
+          // PM^T[key][q] for dV
+          *reinterpret_cast<bf16_t*>(pmT + kc_off(key, q)) = f2bf(pv * mk);
+        }
+      }
+    delta += xhalf(delta);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key0 = i * 32 + 8 * g + 4 * lhi;
+        float w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          w[e] = s[i][j][r] * (dp[i][j][r] - delta);   // dS (w.r.t. the scaled logits)
+          *reinterpret_cast<bf16_t*>(dsT + kc_off(key0 + e, q)) = f2bf(w[e]);
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(w[0], w[1]);
+        pk[1] = pack2bf(w[2], w[3]);
+        *reinterpret_cast<u32x2*>(ds + kc_off(q, key0)) = pk;
+      }
+  }
+  __syncthreads();
+  f32x16 d[2][2];
+  // dV^T[d][key] = sum_q dO^T[d][q] PM[q][key]   (B operand: lane n=key, k=q from PM^T[key][q])
+  mm_tr_kc(do_tr, pmT, lane, d);
+  if (live) store_dT(d, p.dv + (long long)k0 * p.lddv + h * kDh, p.lddv, Lk, 1.f, lane);
+  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q] (B: lane n=q, k=key from dS[q][key])
+  mm_tr_kc(k_tr, ds, lane, d);
+  if (live) store_dT(d, p.dq + (long long)q0 * p.lddq + h * kDh, p.lddq, Lq, p.scale, lane);
+  // dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]   (B: lane n=key, k=q from dS^T[key][q])
+  mm_tr_kc(q_tr, dsT, lane, d);
+  if (live) store_dT(d, p.dk + (long long)k0 * p.lddk + h * kDh, p.lddk, Lk, p.scale, lane);
+}
+
+}  // namespace os2s
+
+using namespace os2s;
+
+static int attn_check(const int32_t* cu_q, const int32_t* cu_k, int B, int H, int dh, int max_len) {
+  if (!cu_q || !cu_k || B < 1 || H < 1) return OS2S_ERR_INVALID_ARG;
+  if (dh != kDh || max_len > kL) return OS2S_ERR_UNSUPPORTED;
+  return OS2S_OK;
+}
+
+extern "C" int os2s_attention_fwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* k,
+                                  const uint16_t* v, uint16_t* o, float* lse,
+                                  const int32_t* cu_q, const int32_t* cu_k, int B, int H, int dh,
+                                  int max_len, long long ldq, long long ldk, long long ldv,
+                                  long long ldo, int causal, float scale, float keep_prob,
+                                  unsigned long long seed) {
+  OS2S_REQUIRE(q && k && v && o);
+  int rc = attn_check(cu_q, cu_k, B, H, dh, max_len);
+  if (rc != OS2S_OK) return rc;
+  OS2S_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.cu_q = cu_q; a.cu_k = cu_k; a.B = B; a.H = H;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.causal = causal; a.scale = scale;
+  a.keep_prob = keep_prob; a.seed = seed;
+  static bool attr = false;
+  const size_t smem = (size_t)kFwdWaves * 16384;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return OS2S_ERR_LAUNCH;
+    attr = true;
+  }
+  OS2S_LAUNCH(attn_fwd_kernel, dim3(ceil_div((long long)B * H, kFwdWaves)), dim3(kFwdWaves * 64),
+              smem, (hipStream_t)stream, a);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_attention_bwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* k,
+                                  const uint16_t* v, const uint16_t* d_o, const float* lse,
+                                  uint16_t* dq, uint16_t* dk, uint16_t* dv, const int32_t* cu_q,
+                                  const int32_t* cu_k, int B, int H, int dh, int max_len,
+                                  long long ldq, long long ldk, long long ldv, long long lddo,
+                                  long long lddq, long long lddk, long long lddv, int causal,
+                                  float scale, float keep_prob, unsigned long long seed) {
+  OS2S_REQUIRE(q && k && v && d_o && lse && dq && dk && dv);
+  int rc = attn_check(cu_q, cu_k, B, H, dh, max_len);
+  if (rc != OS2S_OK) return rc;
+  OS2S_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0);
+  OS2S_REQUIRE(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0);
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.cu_q = cu_q; a.cu_k = cu_k;
+  a.B = B; a.H = H; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.causal = causal; a.scale = scale;
+  a.keep_prob = keep_prob; a.seed = seed; a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  static bool attr = false;
+  const size_t smem = (size_t)kBwdWaves * 49152;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess) return OS2S_ERR_LAUNCH;
+    attr = true;
+  }
+  OS2S_LAUNCH(attn_bwd_kernel, dim3(ceil_div((long long)B * H, kBwdWaves)), dim3(kBwdWaves * 64),
+              smem, (hipStream_t)stream, a);
+  return OS2S_OK;
+}

@@ -154,28 +154,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-// 8 keep/drop decisions for the 8 channels starting at element index idx8*8:
-// two 64-bit mixes -> eight 16-bit uniforms, keep iff u16 < keep*65536.
-__device__ __forceinline__ uint32_t dropout_bits8(unsigned long long seed,
-                                                  unsigned long long idx8,
-                                                  float keep_prob) {
-  const uint32_t thr = (uint32_t)(keep_prob * 65536.0f);
-  uint32_t bits = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    unsigned long long z = (idx8 * 2 + h) * 0x9E3779B97F4A7C15ull + seed;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t u = (uint32_t)(z >> (16 * e)) & 0xffffu;
-      bits |= (u < thr ? 1u : 0u) << (h * 4 + e);
-    }
-  }
-  return bits;
-}
-
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs p) {
   const int C8 = p.C >> 3;
   const long long total = (long long)p.B * p.T * C8;

@@ -45,6 +45,11 @@ struct ConvArgs {
   long long x_sb, x_st, y_sb, y_st;
   int out_f32, accumulate;
   int mtiles_per_b, MT, MT8, NT, nchunks, R, Rpad;
+  // fused epilogue: y = residual + dropout(act(acc + bias))
+  int act;                      // 0 none, 1 relu
+  float keep_prob;              // 1 = no dropout
+  unsigned long long seed;
+  const bf16_t* residual;       // same layout/strides as y (bf16 output only) or null
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
@@ -213,6 +218,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
             v0 += p.bias[gc]; v1 += p.bias[gc + 1]; v2 += p.bias[gc + 2]; v3 += p.bias[gc + 3];
           }
         }
+        if (p.act == 1) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        if (p.keep_prob < 1.f) {
+          // same (seed, element index / 8) convention as the elementwise kernels
+          const long long e0 = ((long long)b * p.Tout + t0 + tt) * p.Cout + n0 + cc;
+          const uint32_t bits = dropout_bits8(p.seed, (unsigned long long)(e0 >> 3), p.keep_prob) >>
+                                (uint32_t)(e0 & 7);
+          const float ik = 1.f / p.keep_prob;
+          v0 = (bits & 1u) ? v0 * ik : 0.f;
+          v1 = (bits & 2u) ? v1 * ik : 0.f;
+          v2 = (bits & 4u) ? v2 * ik : 0.f;
+          v3 = (bits & 8u) ? v3 * ik : 0.f;
+        }
         u32x2 pk;
         pk[0] = pack2bf(v0, v1);
         pk[1] = pack2bf(v2, v3);
@@ -228,6 +247,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
     if (row < valid_rows && gc < p.Cout) {
       u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OP + c8 * 16);
       bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
+      if (p.residual) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(
+            p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      }
       if (p.accumulate) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
 #pragma unroll
@@ -313,13 +339,45 @@ extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
   return B * os2s::ceil_div(Tout, bm);
 }
 
-extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x,
-                               const uint16_t* w, void* y, const int32_t* in_len,
-                               const float* bias, float* stats, int B, int Tin,
-                               int Cin, int Cout, int K, int stride, int dil,
-                               int padL, int Tout, long long y_stride_b,
-                               long long y_stride_t, int out_f32, int accumulate) {
+static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,
+                           const int32_t* in_len, const float* bias, float* stats, int B,
+                           int Tin, int Cin, int Cout, int K, int stride, int dil, int padL,
+                           int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
+                           int accumulate, int act, float keep_prob, unsigned long long seed,
+                           const uint16_t* residual);
+
+extern "C" int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
+                                  void* y, const int32_t* in_len, const float* bias,
+                                  float* stats, int B, int Tin, int Cin, int Cout, int K,
+                                  int stride, int dil, int padL, int Tout,
+                                  long long y_stride_b, long long y_stride_t, int out_f32,
+                                  int accumulate, int act, float keep_prob,
+                                  unsigned long long seed, const uint16_t* residual) {
+  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
+                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, act, keep_prob,
+                         seed, residual);
+}
+
+extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
+                               void* y, const int32_t* in_len, const float* bias, float* stats,
+                               int B, int Tin, int Cin, int Cout, int K, int stride, int dil,
+                               int padL, int Tout, long long y_stride_b, long long y_stride_t,
+                               int out_f32, int accumulate) {
+  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
+                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, 0, 1.f, 0,
+                         nullptr);
+}
+
+static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
+                           const uint16_t* w, void* y, const int32_t* in_len, const float* bias,
+                           float* stats, int B, int Tin, int Cin, int Cout, int K, int stride,
+                           int dil, int padL, int Tout, long long y_stride_b,
+                           long long y_stride_t, int out_f32, int accumulate, int act,
+                           float keep_prob, unsigned long long seed, const uint16_t* residual) {
   using namespace os2s;
+  OS2S_REQUIRE(act == 0 || act == 1);
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
+  if (out_f32) OS2S_REQUIRE(act == 0 && keep_prob == 1.f && residual == nullptr);
   OS2S_REQUIRE(x && w && y);
   OS2S_REQUIRE(B >= 0 && Tin >= 1 && Tout >= 1 && Cin >= 8 && Cout >= 1 && K >= 1);
   OS2S_REQUIRE(stride >= 1 && dil >= 1);
@@ -333,6 +391,7 @@ extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x,
   a.x_sb = (long long)Tin * Cin; a.x_st = Cin;
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
   if (g_conv_variant == 1) return launch_conv<256, 128, 4, 2>((hipStream_t)stream, a);
   return launch_conv<kConvBM, kConvBN, 2, 2>((hipStream_t)stream, a);
 }

@@ -1,0 +1,471 @@
+// Token-wise kernels of the Transformer NMT path (HBM-bound, bf16 I/O, fp32 math),
+// operating on PACKED token-major tensors [N_tokens, hidden]:
+//   * embedding gather * sqrt(d) + sinusoidal position signal + dropout, and its
+//     scatter-add gradient   (parts/transformer/embedding_layer.py:59-88,
+//     parts/transformer/utils.py:28-54, encoders/transformer_encoder.py:150-161,
+//     decoders/transformer_decoder.py:197-213 — the decoder's shift-right is an index
+//     remap done by the caller: ids of the previous position, 0 for the first);
+//   * LayerNormalization (fp32 statistics, eps 1e-6; parts/transformer/common.py:41-68)
+//     forward / backward (the backward also adds the residual-branch gradient of the
+//     pre-norm wrapper, common.py:99-106);
+//   * dropout / relu-dropout backward helpers;
+//   * PaddedCrossEntropyLossWithSmoothing (losses/sequence_loss.py:257-309) fused with
+//     its gradient: one read of the [N, V] logits, one write of dlogits.
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+// ---------------------------------------------------------------------------
+// embedding
+// ---------------------------------------------------------------------------
+// out[n, :] = (id valid ? E[id]*sqrt(D) : 0) + posenc(pos[n]) ; then dropout
+__global__ __launch_bounds__(256) void embed_fwd_kernel(
+    const int32_t* __restrict__ ids, const int32_t* __restrict__ pos,
+    const bf16_t* __restrict__ table, int V, int D, long long N, float emb_scale, float keep_prob,
+    unsigned long long seed, bf16_t* __restrict__ out) {
+  const int D8 = D >> 3;
+  const int half = D >> 1;
+  const float log_inc = logf(1.0e4f) / (float)(half - 1);
+  const float ik = 1.f / keep_prob;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N * D8;
+       i += (long long)gridDim.x * 256) {
+    const long long n = i / D8;
+    const int c0 = (int)(i - n * D8) * 8;
+    int id = ids[n];
+    if (id > V - 1) id = 0;   // out-of-bound ids map to the pad symbol (embedding_layer.py:71-73)
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (id != 0) {            // padding embeddings are zeroed (:79-87)
+      const u32x4 t = *reinterpret_cast<const u32x4*>(table + (long long)id * D + c0);
+      v[0] = bflo(t[0]); v[1] = bfhi(t[0]); v[2] = bflo(t[1]); v[3] = bfhi(t[1]);
+      v[4] = bflo(t[2]); v[5] = bfhi(t[2]); v[6] = bflo(t[3]); v[7] = bfhi(t[3]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= emb_scale;
+    }
+    const float p = (float)pos[n];
+    uint32_t keep = 0xffu;
+    if (keep_prob < 1.f) keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      const int j = c < half ? c : c - half;
+      const float ang = p * __expf(-(float)j * log_inc);
+      float val = v[e] + (c < half ? sinf(ang) : cosf(ang));
+      if (keep_prob < 1.f) val = ((keep >> e) & 1u) ? val * ik : 0.f;
+      v[e] = val;
+    }
+    u32x4 o;
+    o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+    o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
+    *reinterpret_cast<u32x4*>(out + n * D + c0) = o;
+  }
+}
+
+// dE[id] += emb_scale * dropout'(dout[n])   (fp32 atomics into the flat gradient)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(
+    const int32_t* __restrict__ ids, const bf16_t* __restrict__ dout, int V, int D, long long N,
+    float emb_scale, float keep_prob, unsigned long long seed, float* __restrict__ dtable) {
+  const int D8 = D >> 3;
+  const float ik = 1.f / keep_prob;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N * D8;
+       i += (long long)gridDim.x * 256) {
+    const long long n = i / D8;
+    const int c0 = (int)(i - n * D8) * 8;
+    int id = ids[n];
+    if (id > V - 1 || id == 0) continue;
+    const u32x4 t = *reinterpret_cast<const u32x4*>(dout + n * D + c0);
+    float g[8] = {bflo(t[0]), bfhi(t[0]), bflo(t[1]), bfhi(t[1]),
+                  bflo(t[2]), bfhi(t[2]), bflo(t[3]), bfhi(t[3])};
+    uint32_t keep = 0xffu;
+    if (keep_prob < 1.f) keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = g[e] * emb_scale;
+      if (keep_prob < 1.f) x = ((keep >> e) & 1u) ? x * ik : 0.f;
+      if (x != 0.f)
+        __hip_atomic_fetch_add(dtable + (long long)id * D + c0 + e, x, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm: one wave per row
+// ---------------------------------------------------------------------------
+template <int VPL>  // 16-byte vectors per lane: D = 64 * 8 * VPL
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, long long N, bf16_t* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+  constexpr int D = 64 * 8 * VPL;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float v[VPL][8];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(x + row * D + (u * 64 + lane) * 8);
+    v[u][0] = bflo(t[0]); v[u][1] = bfhi(t[0]); v[u][2] = bflo(t[1]); v[u][3] = bfhi(t[1]);
+    v[u][4] = bflo(t[2]); v[u][5] = bfhi(t[2]); v[u][6] = bflo(t[3]); v[u][7] = bfhi(t[3]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[u][e];
+  }
+  const float mean = wave_sum(s) * (1.f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < VPL; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[u][e] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int c0 = (u * 64 + lane) * 8;
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (v[u][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+    u32x4 o;
+    o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]);
+    o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+    *reinterpret_cast<u32x4*>(y + row * D + c0) = o;
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+// dx = dres + rstd * (g*dy - mean_D(g*dy) - xhat * mean_D(g*dy*xhat));
+// per-block partial sums of dbeta = sum dy, dgamma = sum dy*xhat -> partial[blk][2][D]
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    const bf16_t* __restrict__ dres, long long N, int rows_per_block, bf16_t* __restrict__ dx,
+    float* __restrict__ partial) {
+  constexpr int D = 64 * 8 * VPL;
+  __shared__ float red[4][D];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float gb[VPL][8], gg[VPL][8], gm[VPL][8];
+#pragma unroll
+  for (int u = 0; u < VPL; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gb[u][e] = 0.f; gg[u][e] = 0.f;
+      gm[u][e] = gamma[(u * 64 + lane) * 8 + e];
+    }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(N, r0 + rows_per_block);
+  for (long long row = r0 + wid; row < r1; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float dyv[VPL][8], xh[VPL][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+      const int c0 = (u * 64 + lane) * 8;
+      const u32x4 a = *reinterpret_cast<const u32x4*>(dy + row * D + c0);
+      const u32x4 t = *reinterpret_cast<const u32x4*>(x + row * D + c0);
+      dyv[u][0] = bflo(a[0]); dyv[u][1] = bfhi(a[0]); dyv[u][2] = bflo(a[1]); dyv[u][3] = bfhi(a[1]);
+      dyv[u][4] = bflo(a[2]); dyv[u][5] = bfhi(a[2]); dyv[u][6] = bflo(a[3]); dyv[u][7] = bfhi(a[3]);
+      xh[u][0] = bflo(t[0]); xh[u][1] = bfhi(t[0]); xh[u][2] = bflo(t[1]); xh[u][3] = bfhi(t[1]);
+      xh[u][4] = bflo(t[2]); xh[u][5] = bfhi(t[2]); xh[u][6] = bflo(t[3]); xh[u][7] = bfhi(t[3]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[u][e] = (xh[u][e] - mu) * rs;
+        gb[u][e] += dyv[u][e];
+        gg[u][e] += dyv[u][e] * xh[u][e];
+        const float gd = gm[u][e] * dyv[u][e];
+        s1 += gd;
+        s2 += gd * xh[u][e];
+      }
+    }
+    s1 = wave_sum(s1) * (1.f / D);
+    s2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+      const int c0 = (u * 64 + lane) * 8;
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = rs * (gm[u][e] * dyv[u][e] - s1 - xh[u][e] * s2);
+      if (dres) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(dres + row * D + c0);
+        r[0] += bflo(t[0]); r[1] += bfhi(t[0]); r[2] += bflo(t[1]); r[3] += bfhi(t[1]);
+        r[4] += bflo(t[2]); r[5] += bfhi(t[2]); r[6] += bflo(t[3]); r[7] += bfhi(t[3]);
+      }
+      u32x4 o;
+      o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]);
+      o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
+      *reinterpret_cast<u32x4*>(dx + row * D + c0) = o;
+    }
+  }
+  // block reduce the parameter-gradient partials over the 4 waves
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < VPL; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        red[wid][(u * 64 + lane) * 8 + e] = pass == 0 ? gb[u][e] : gg[u][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+      partial[((long long)blockIdx.x * 2 + pass) * D + c] =
+          (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dropout backward helpers
+// ---------------------------------------------------------------------------
+// mode 0: d = dout * keepmask/keep (mask from the hash);  mode 1: d = dout * (out > 0)/keep
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restrict__ dout,
+                                                          const bf16_t* __restrict__ out, int mode,
+                                                          float keep_prob, unsigned long long seed,
+                                                          long long n8, bf16_t* __restrict__ d) {
+  const float ik = 1.f / keep_prob;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8;
+       i += (long long)gridDim.x * 256) {
+    const u32x4 t = reinterpret_cast<const u32x4*>(dout)[i];
+    float g[8] = {bflo(t[0]), bfhi(t[0]), bflo(t[1]), bfhi(t[1]),
+                  bflo(t[2]), bfhi(t[2]), bflo(t[3]), bfhi(t[3])};
+    if (mode == 0) {
+      const uint32_t keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1u) ? g[e] * ik : 0.f;
+    } else {
+      const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
+      const float ov[8] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1]),
+                           bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = ov[e] > 0.f ? g[e] * ik : 0.f;
+    }
+    u32x4 r;
+    r[0] = pack2bf(g[0], g[1]); r[1] = pack2bf(g[2], g[3]);
+    r[2] = pack2bf(g[4], g[5]); r[3] = pack2bf(g[6], g[7]);
+    reinterpret_cast<u32x4*>(d)[i] = r;
+  }
+}
+
+// out = a + b (bf16), used to sum gradient contributions of multi-consumer activations
+__global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a,
+                                                       const bf16_t* __restrict__ b, long long n8,
+                                                       bf16_t* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8;
+       i += (long long)gridDim.x * 256) {
+    const u32x4 x = reinterpret_cast<const u32x4*>(a)[i];
+    const u32x4 y = reinterpret_cast<const u32x4*>(b)[i];
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = pack2bf(bflo(x[e]) + bflo(y[e]), bfhi(x[e]) + bfhi(y[e]));
+    reinterpret_cast<u32x4*>(out)[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// smoothed cross entropy + gradient, one workgroup per row
+// ---------------------------------------------------------------------------
+constexpr int kXentMaxPerThread = 20;   // 16-B vectors per thread -> V <= 256*8*20 = 40960
+
+__global__ __launch_bounds__(256) void xent_smooth_kernel(
+    const bf16_t* __restrict__ logits, const int32_t* __restrict__ labels, int V, long long ld,
+    float confidence, float low_confidence, float normalizing, float grad_scale_host,
+    const float* __restrict__ grad_scale_dev, float* __restrict__ row_loss,
+    bf16_t* __restrict__ dlogits) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const long long row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int V8 = V >> 3;
+  const bf16_t* lr = logits + row * ld;
+  const int label = labels[row];
+  u32x4 buf[kXentMaxPerThread];
+  float mx = -INFINITY, sx = 0.f;
+  // fully unrolled with a compile-time bound: the row stays in registers (a runtime-indexed
+  // array would be demoted to scratch)
+#pragma unroll
+  for (int k = 0; k < kXentMaxPerThread; ++k) {
+    const int i = threadIdx.x + k * 256;
+    u32x4 t = {0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};   // -inf pairs
+    if (i < V8) {
+      t = *reinterpret_cast<const u32x4*>(lr + (long long)i * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = bflo(t[e]), b = bfhi(t[e]);
+        mx = fmaxf(mx, fmaxf(a, b));
+        sx += a + b;
+      }
+    }
+    buf[k] = t;
+  }
+  auto block_reduce = [&](float v, bool is_max) -> float {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      bc = is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))
+                  : (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return bc;
+  };
+  mx = block_reduce(mx, true);
+  sx = block_reduce(sx, false);
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < kXentMaxPerThread; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) se += __expf(bflo(buf[k][e]) - mx) + __expf(bfhi(buf[k][e]) - mx);
+  se = block_reduce(se, false);
+  const float lse = mx + __logf(se);
+  const float x_label = bf2f(lr[label]);
+  // xent = -sum_v t_v logp_v,  t = confidence at label, low elsewhere
+  const float sum_logp = sx - (float)V * lse;
+  const float logp_label = x_label - lse;
+  const float xent = -(confidence * logp_label + low_confidence * (sum_logp - logp_label)) - normalizing;
+  if (threadIdx.x == 0 && row_loss) row_loss[row] = xent;
+  if (dlogits) {
+    const float gs = grad_scale_dev ? grad_scale_host * (*grad_scale_dev) : grad_scale_host;
+    bf16_t* dr = dlogits + row * ld;
+#pragma unroll
+    for (int k = 0; k < kXentMaxPerThread; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i >= V8) continue;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = i * 8 + 2 * e;
+        const float p0 = __expf(bflo(buf[k][e]) - lse), p1 = __expf(bfhi(buf[k][e]) - lse);
+        const float t0 = (c == label) ? confidence : low_confidence;
+        const float t1 = (c + 1 == label) ? confidence : low_confidence;
+        o[e] = pack2bf((p0 - t0) * gs, (p1 - t1) * gs);
+      }
+      *reinterpret_cast<u32x4*>(dr + (long long)i * 8) = o;
+    }
+  }
+}
+
+__global__ void sum_rows_kernel(const float* __restrict__ v, long long n, float mul,
+                                float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)(red[0] * (double)mul);
+}
+
+static inline int ew_blocks(long long work) {
+  long long b = (work + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace os2s
+
+using namespace os2s;
+
+extern "C" int os2s_embed_fwd(os2s_stream_t stream, const int32_t* ids, const int32_t* pos,
+                              const uint16_t* table, int V, int D, long long N, float emb_scale,
+                              float keep_prob, unsigned long long seed, uint16_t* out) {
+  OS2S_REQUIRE(ids && pos && table && out && V >= 1 && D >= 16 && D % 16 == 0 && N >= 0);
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
+  if (N == 0) return OS2S_OK;
+  OS2S_LAUNCH(embed_fwd_kernel, dim3(ew_blocks(N * (D / 8))), dim3(256), 0, (hipStream_t)stream,
+              ids, pos, table, V, D, N, emb_scale, keep_prob, seed, out);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_embed_bwd(os2s_stream_t stream, const int32_t* ids, const uint16_t* dout, int V,
+                              int D, long long N, float emb_scale, float keep_prob,
+                              unsigned long long seed, float* dtable) {
+  OS2S_REQUIRE(ids && dout && dtable && D % 8 == 0 && N >= 0);
+  if (N == 0) return OS2S_OK;
+  OS2S_LAUNCH(embed_bwd_kernel, dim3(ew_blocks(N * (D / 8))), dim3(256), 0, (hipStream_t)stream,
+              ids, dout, V, D, N, emb_scale, keep_prob, seed, dtable);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_layernorm_fwd(os2s_stream_t stream, const uint16_t* x, const float* gamma,
+                                  const float* beta, float eps, long long N, int D, uint16_t* y,
+                                  float* mean, float* rstd) {
+  OS2S_REQUIRE(x && gamma && beta && y && N >= 0);
+  if (N == 0) return OS2S_OK;
+  dim3 grid(ceil_div(N, 4));
+  if (D == 1024) {
+    OS2S_LAUNCH(layernorm_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                N, y, mean, rstd);
+  } else if (D == 512) {
+    OS2S_LAUNCH(layernorm_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                N, y, mean, rstd);
+  } else {
+    return OS2S_ERR_UNSUPPORTED;
+  }
+  return OS2S_OK;
+}
+
+static const int kLnRowsPerBlock = 32;
+extern "C" int os2s_layernorm_bwd_num_parts(long long N) { return ceil_div(N, kLnRowsPerBlock); }
+
+// partial: [num_parts, 2, D] (row 0: sum dy = dbeta, row 1: sum dy*xhat = dgamma); reduce it
+// with os2s_bn_bwd_finalize(partial, nparts, nq=2, q=1, C=D, ...).
+extern "C" int os2s_layernorm_bwd(os2s_stream_t stream, const uint16_t* dy, const uint16_t* x,
+                                  const float* gamma, const float* mean, const float* rstd,
+                                  const uint16_t* dres, long long N, int D, uint16_t* dx,
+                                  float* partial) {
+  OS2S_REQUIRE(dy && x && gamma && mean && rstd && dx && partial && N >= 0);
+  if (N == 0) return OS2S_OK;
+  dim3 grid(ceil_div(N, kLnRowsPerBlock));
+  if (D == 1024) {
+    OS2S_LAUNCH(layernorm_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean,
+                rstd, dres, N, kLnRowsPerBlock, dx, partial);
+  } else if (D == 512) {
+    OS2S_LAUNCH(layernorm_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean,
+                rstd, dres, N, kLnRowsPerBlock, dx, partial);
+  } else {
+    return OS2S_ERR_UNSUPPORTED;
+  }
+  return OS2S_OK;
+}
+
+extern "C" int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out,
+                                int mode, float keep_prob, unsigned long long seed, long long n,
+                                uint16_t* d) {
+  OS2S_REQUIRE(dout && d && n >= 0 && n % 8 == 0 && (mode == 0 || (mode == 1 && out)));
+  if (n == 0) return OS2S_OK;
+  OS2S_LAUNCH(dropout_bwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, dout,
+              out, mode, keep_prob, seed, n / 8, d);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_add_bf16(os2s_stream_t stream, const uint16_t* a, const uint16_t* b, long long n,
+                             uint16_t* out) {
+  OS2S_REQUIRE(a && b && out && n >= 0 && n % 8 == 0);
+  if (n == 0) return OS2S_OK;
+  OS2S_LAUNCH(add_bf16_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, n / 8,
+              out);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t* labels,
+                                long long N, int V, long long ld, float label_smoothing,
+                                float grad_scale, const float* grad_scale_dev, float* row_loss,
+                                float* loss_mean, uint16_t* dlogits) {
+  OS2S_REQUIRE(logits && labels && N >= 1 && V >= 8 && V % 8 == 0 && ld % 8 == 0 && row_loss);
+  if (V > 256 * 8 * kXentMaxPerThread) return OS2S_ERR_UNSUPPORTED;
+  const float confidence = 1.f - label_smoothing;
+  const float low = (1.f - confidence) / (float)(V - 1);
+  const float normalizing =
+      -(confidence * logf(confidence) + (float)(V - 1) * low * logf(low + 1e-20f));
+  OS2S_LAUNCH(xent_smooth_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, logits, labels,
+              V, ld, confidence, low, normalizing, grad_scale, grad_scale_dev, row_loss, dlogits);
+  if (loss_mean) {
+    OS2S_LAUNCH(sum_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, N,
+                1.0f / (float)N, loss_mean);
+  }
+  return OS2S_OK;
+}

@@ -1,0 +1,166 @@
+"""GPU parity of the Transformer kernels vs the CPU fp32 oracle (torch autograd for
+gradients). bf16 I/O: rtol/atol 2e-2 relative to the tensor rms unless noted."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import transformer as ot  # noqa: E402
+
+
+def _bf(x):
+  return x.to(torch.bfloat16)
+
+
+def _close(got, ref, tol=2e-2):
+  got = got.float().cpu()
+  scale = float(ref.detach().pow(2).mean().sqrt()) + 1e-8
+  torch.testing.assert_close(got, ref.detach(), rtol=tol, atol=tol * scale)
+
+
+def _pack(x_padded, lens):
+  return torch.cat([x_padded[b, :lens[b]] for b in range(len(lens))], 0)
+
+
+def _cu(lens, dev):
+  return torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev)
+
+
+@pytest.mark.parametrize("causal,cross", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("keep", [1.0, 0.9])
+def test_attention_fwd_bwd(cuda, causal, cross, keep):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(7 + causal + 2 * cross)
+  B, H, dh = 5, 3, 64
+  D = H * dh
+  lq = [64, 17, 1, 33, 56]
+  lk = [40, 64, 9, 2, 56] if cross else lq
+  q = _bf(torch.randn(sum(lq), D, generator=g))
+  k = _bf(torch.randn(sum(lk), D, generator=g))
+  v = _bf(torch.randn(sum(lk), D, generator=g))
+  do = _bf(torch.randn(sum(lq), D, generator=g))
+  scale = dh ** -0.5
+  d = cuda
+  cq, ck = _cu(lq, d), _cu(lk, d)
+  seed = 99
+  o, lse = capi.attention_fwd(q.to(d), k.to(d), v.to(d), cq, ck, H, 64, causal, scale, keep, seed)
+  dq, dk, dv = (torch.empty(sum(lq), D, dtype=torch.bfloat16, device=d),
+                torch.empty(sum(lk), D, dtype=torch.bfloat16, device=d),
+                torch.empty(sum(lk), D, dtype=torch.bfloat16, device=d))
+  capi.attention_bwd(q.to(d), k.to(d), v.to(d), do.to(d), lse, dq, dk, dv, cq, ck, H, 64, causal,
+                     scale, keep, seed)
+  torch.cuda.synchronize()
+  # oracle per sequence (packed layout has no padding)
+  qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+  outs = []
+  oq = ok = 0
+  for b in range(B):
+    Q = qf[oq:oq + lq[b]].view(lq[b], H, dh).transpose(0, 1)
+    K = kf[ok:ok + lk[b]].view(lk[b], H, dh).transpose(0, 1)
+    V = vf[ok:ok + lk[b]].view(lk[b], H, dh).transpose(0, 1)
+    S = (Q * scale) @ K.transpose(-1, -2)
+    if causal:
+      S = S + ot.get_decoder_self_attention_bias(lq[b])[0, 0][:, :lk[b]]
+    P = torch.softmax(S, -1)
+    if keep < 1.0:
+      # the device mask: element ((b*H+h)*64 + q)*64 + key
+      n = B * H * 64 * 64
+      m = capi.dropout_mask(seed, n, keep, d).cpu().view(B, H, 64, 64)[b, :, :lq[b], :lk[b]]
+      P = P * m.float() / keep
+    outs.append((P @ V).transpose(0, 1).reshape(lq[b], D))
+    oq += lq[b]; ok += lk[b]
+  ref = torch.cat(outs, 0)
+  ref.backward(do.float())
+  _close(o, ref)
+  _close(dq, qf.grad, 3e-2)
+  _close(dk, kf.grad, 3e-2)
+  _close(dv, vf.grad, 3e-2)
+
+
+def test_layernorm_fwd_bwd(cuda):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(1)
+  for D in (1024, 512):
+    N = 77
+    x = _bf(torch.randn(N, D, generator=g) * 2 + 0.5)
+    gam, bet = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    dy = _bf(torch.randn(N, D, generator=g))
+    dres = _bf(torch.randn(N, D, generator=g))
+    y, mean, rstd = capi.layernorm_fwd(x.to(cuda), gam.to(cuda), bet.to(cuda))
+    dgam, dbet = torch.zeros(D, device=cuda), torch.zeros(D, device=cuda)
+    dx = capi.layernorm_bwd(dy.to(cuda), x.to(cuda), gam.to(cuda), mean, rstd, dres.to(cuda), dgam, dbet)
+    torch.cuda.synchronize()
+    xf, gf, bf = x.float().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = ot.layer_norm(xf, gf, bf)
+    ref.backward(dy.float())
+    _close(y, ref)
+    _close(dx, xf.grad + dres.float())
+    _close(dgam, gf.grad)
+    _close(dbet, bf.grad)
+
+
+def test_embedding_fwd_bwd(cuda):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(2)
+  V, D, N = 200, 512, 150
+  table = _bf(torch.randn(V, D, generator=g) * D ** -0.5)
+  ids = torch.randint(0, V + 5, (N,), generator=g).to(torch.int32)   # some pad (0) and oob ids
+  ids[:3] = 0
+  pos = torch.randint(0, 56, (N,), generator=g).to(torch.int32)
+  keep, seed = 0.7, 5
+  out = capi.embed_fwd(ids.to(cuda), pos.to(cuda), table.to(cuda), D ** 0.5, keep, seed)
+  mask = capi.dropout_mask(seed, N * D, keep, cuda).cpu().view(N, D)
+  tf = table.float().requires_grad_(True)
+  ref = ot.embedding(ids.long()[None], tf)[0] + ot.get_position_encoding(56, D)[pos.long()]
+  ref = ref * mask.float() / keep
+  _close(out, ref)
+  dout = _bf(torch.randn(N, D, generator=g))
+  ref.backward(dout.float())
+  dt = torch.zeros(V, D, device=cuda)
+  capi.embed_bwd(ids.to(cuda), dout.to(cuda), dt, D ** 0.5, keep, seed)
+  torch.cuda.synchronize()
+  torch.testing.assert_close(dt.cpu(), tf.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("V", [32768, 1000, 8])
+def test_xent_smooth(cuda, V):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(3)
+  N = 37
+  logits = _bf(torch.randn(N, V, generator=g) * 3)
+  labels = torch.randint(1, V, (N,), generator=g).to(torch.int32)
+  rl, mean, dl = capi.xent_smooth(logits.to(cuda), labels.to(cuda), 0.1)
+  torch.cuda.synchronize()
+  lf = logits.float().requires_grad_(True)
+  ref = ot.padded_xent_smoothing(lf[None], labels[None], 0.1)
+  ref.backward()
+  torch.testing.assert_close(mean.cpu()[0], ref.detach(), rtol=2e-3, atol=2e-3)
+  # dlogits are O(1/N * softmax): compare on that scale
+  gref = lf.grad
+  err = (dl.float().cpu() - gref).abs().max()
+  assert float(err) < 2e-2 * float(gref.abs().max()) + 1e-6
+
+
+def test_gemm_epilogue_relu_dropout_residual(cuda):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(4)
+  N, Cin, Cout = 300, 256, 384
+  x = _bf(torch.randn(N, Cin, generator=g))
+  w = _bf(torch.randn(Cout, Cin, generator=g) * Cin ** -0.5)
+  bias = torch.randn(Cout, generator=g)
+  res = _bf(torch.randn(N, Cout, generator=g))
+  keep, seed = 0.7, 21
+  y = capi.gemm(x.to(cuda), w.to(cuda), bias=bias.to(cuda), act=1, keep_prob=keep, seed=seed,
+                residual=res.to(cuda))
+  mask = capi.dropout_mask(seed, N * Cout, keep, cuda).cpu().view(N, Cout)
+  ref = res.float() + torch.relu(x.float() @ w.float().t() + bias) * mask.float() / keep
+  _close(y, ref)
+  # backward helpers
+  h = capi.gemm(x.to(cuda), w.to(cuda), bias=bias.to(cuda), act=1, keep_prob=keep, seed=seed)
+  dh = _bf(torch.randn(N, Cout, generator=g))
+  d1 = capi.dropout_bwd(dh.to(cuda), keep, out=h)
+  hr = torch.relu(x.float() @ w.float().t() + bias) * mask.float() / keep
+  _close(d1, dh.float() * (hr > 0).float() / keep)
+  d0 = capi.dropout_bwd(dh.to(cuda), keep, seed=seed)
+  _close(d0, dh.float() * mask.float() / keep)
