@@ -1,0 +1,39 @@
+"""Text2Text — open_seq2seq/models/text2text.py:60-241 (NMT model shell): vocabulary sizes
+flow from the data layer into encoder/decoder/loss params (:60-80); the tokens-per-step
+metric counts source + target tokens (:227-241)."""
+from __future__ import absolute_import, division, print_function
+
+from .encoder_decoder import EncoderDecoderModel
+from ..parts.transformer.layers import SeedSeq
+
+
+class Text2Text(EncoderDecoderModel):
+  def _build_forward_pass_objects(self, store):
+    self._data_layer = self._create_data_layer()
+    dl = self._data_layer
+    self.params['encoder_params']['src_vocab_size'] = dl.params['src_vocab_size']
+    self.params['decoder_params']['batch_size'] = self.params['batch_size_per_gpu']
+    self.params['decoder_params']['tgt_vocab_size'] = dl.params['tgt_vocab_size']
+    self.params['loss_params']['batch_size'] = self.params['batch_size_per_gpu']
+    self.params['loss_params']['tgt_vocab_size'] = dl.params['tgt_vocab_size']
+    self._encoder = self._create_encoder()
+    self._decoder = self._create_decoder()
+    if self.mode in ("train", "eval"):
+      self._loss_computator = self._create_loss()
+    self._encoder.build(store)
+    self._decoder.build(store)
+
+  def _forward_backward(self, batch, tape):
+    seeds = SeedSeq(self._seed * 7919 + self._step_count)
+    enc = self._encoder.encode({'source_tensors': batch['source_tensors'], 'tape': tape,
+                                'seeds': seeds, 'packed_source': batch.get('packed_source')})
+    dec = self._decoder.decode({'encoder_output': enc, 'target_tensors': batch['target_tensors'],
+                                'tape': tape, 'packed_target': batch.get('packed_target')})
+    scale_dev = self._train_op.loss_scale_view if self._train_op is not None else None
+    return self._loss_computator.compute_loss({
+        'decoder_output': dec, 'target_tensors': batch['target_tensors'],
+        'loss_scale_dev': scale_dev})
+
+  def _get_num_objects_per_step(self, batch):
+    """text2text.py:227-241: source tokens + target tokens."""
+    return batch['source_tensors'][1].sum() + batch['target_tensors'][1].sum()

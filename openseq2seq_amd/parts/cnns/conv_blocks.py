@@ -44,12 +44,13 @@ class Tape(object):
 
 class Act(object):
   """An activation tensor + its valid lengths + (optionally) its gradient."""
-  __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad")
+  __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad", "res_grad")
 
   def __init__(self, data, lens=None, requires_grad=True):
     self.data, self.lens = data, lens
     self.grad, self.grad_init = None, False
     self.requires_grad = requires_grad
+    self.res_grad = None   # gradient arriving through a residual connection (pre-norm blocks)
 
   def grad_buffer(self):
     if self.grad is None:

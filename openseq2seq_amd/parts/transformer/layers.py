@@ -1,0 +1,252 @@
+"""Building blocks of the Transformer NMT path on packed token-major tensors
+(host layer over the HIP kernels; same arithmetic as
+open_seq2seq/parts/transformer/{attention_layer,ffn_layer,common,embedding_layer}.py).
+
+Every block enqueues its forward kernels and records ONE backward closure on the
+Tape (see parts/cnns/conv_blocks.py). Activations are `Act` holders with 2-D bf16
+data [N_tokens, hidden]. Padding never exists in this layout, so the reference's
+FFN "remove_padding" (ffn_layer.py:56-70) is implicit and extends to every token-wise
+op (LayerNorm, all projections), and padded keys need no -1e9 bias.
+"""
+import math
+
+import torch
+
+from ... import capi
+from ..cnns.conv_blocks import Act
+
+
+class SeedSeq(object):
+  """Distinct dropout streams per op per step."""
+
+  def __init__(self, base):
+    self.base, self.n = int(base), 0
+
+  def next(self):
+    self.n += 1
+    return (self.base * 1000003 + self.n) & ((1 << 62) - 1)
+
+
+def _colsum_into(dy2d, bias_param):
+  """bias.grad += column sums of dy (bf16 [N, C])."""
+  C = dy2d.shape[1]
+  part = capi.bn_stats(dy2d)
+  scratch = torch.empty(2, C, dtype=torch.float32, device=dy2d.device)
+  capi.bn_bwd_finalize(part, 1, 1, None, bias_param.grad, True, scratch[0], scratch[1])
+
+
+def _accumulate_grad(x, dx):
+  if not x.requires_grad:
+    return
+  if x.grad_init and x.grad is not None:
+    capi.add_bf16(x.grad, dx, out=x.grad)
+  else:
+    x.grad = dx
+    x.grad_init = True
+
+
+class Dense(object):
+  """tf.layers.Dense on [N, Cin] rows; kernel stored [1, Cout, Cin] (device layout,
+  = the transpose of TF's [Cin, Cout])."""
+
+  def __init__(self, store, name, cin, cout, use_bias):
+    self.cin, self.cout = cin, cout
+
+    def init(shape):   # tf.layers.Dense default initializer: glorot_uniform
+      lim = math.sqrt(6.0 / (cin + cout))
+      return (torch.rand(shape) * 2 - 1) * lim
+
+    self.kernel = store.add(name + "/kernel", (1, cout, cin), init, kind="conv")
+    self.bias = store.add(name + "/bias", (cout,), torch.zeros(cout), kind="vector") \
+        if use_bias else None
+
+  @property
+  def w(self):
+    return self.kernel.w16.view(self.cout, self.cin)
+
+  def forward(self, x, tape, act=0, keep=1.0, seed=0, residual=None):
+    """y = residual + dropout(act(x W^T + b)); x, residual: Act; returns Act."""
+    y = capi.gemm(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
+                  act=act, keep_prob=keep, seed=seed,
+                  residual=residual.data if residual is not None else None)
+    out = Act(y)
+    if tape is None:
+      return out
+    lin = self
+    assert not (act == 1 and residual is not None)
+
+    def backward():
+      dy = out.grad
+      assert dy is not None, "no gradient reached " + lin.kernel.name
+      if act == 1:
+        dz = capi.dropout_bwd(dy, keep, out=y)         # (y > 0) / keep
+      elif keep < 1.0:
+        dz = capi.dropout_bwd(dy, keep, seed=seed)     # recomputed hash mask / keep
+      else:
+        dz = dy
+      capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
+      if lin.bias is not None:
+        _colsum_into(dz, lin.bias)
+      if x.requires_grad:
+        g = x.grad_buffer()
+        capi.gemm(dz, lin.kernel.wt16.view(lin.cin, lin.cout), out=g, accumulate=x.grad_init)
+        x.grad_init = True
+      if residual is not None:
+        residual.res_grad = dy      # consumed by the pre-norm LayerNorm backward of `residual`
+      out.grad = None
+
+    tape.record(backward)
+    return out
+
+
+class LayerNorm(object):
+  """LayerNormalization 'layernorm_L2' (common.py:41-68): fp32 scale/bias, eps 1e-6."""
+
+  def __init__(self, store, name, hidden, eps=1e-6):
+    self.scale = store.add(name + "/layer_norm_scale", (hidden,), torch.ones(hidden), kind="vector")
+    self.bias = store.add(name + "/layer_norm_bias", (hidden,), torch.zeros(hidden), kind="vector")
+    self.eps = eps
+
+  def forward(self, x, tape):
+    training = tape is not None
+    y, mean, rstd = capi.layernorm_fwd(x.data, self.scale.master, self.bias.master, self.eps,
+                                       save=training)
+    out = Act(y)
+    if not training:
+      return out
+    ln = self
+
+    def backward():
+      dy = out.grad
+      assert dy is not None
+      dres, x.res_grad = x.res_grad, None
+      dx = capi.layernorm_bwd(dy, x.data, ln.scale.master, mean, rstd, dres, ln.scale.grad,
+                              ln.bias.grad)
+      _accumulate_grad(x, dx)
+      out.grad = None
+
+    tape.record(backward)
+    return out
+
+
+class MultiHeadAttention(object):
+  """Attention / SelfAttention (attention_layer.py:23-227), 'loung' mode, no biases.
+  Self-attention uses one fused [3D, D] projection for q,k,v; enc-dec attention a [D, D]
+  query projection and a fused [2D, D] key/value projection. (The reference keeps q, k, v
+  as three Dense kernels; fusing only changes how the same numbers are laid out.)"""
+
+  def __init__(self, store, name, hidden, num_heads, self_attention):
+    self.D, self.H, self.self_att = hidden, num_heads, self_attention
+    self.scale = (hidden // num_heads) ** -0.5
+    if hidden // num_heads != 64:
+      raise NotImplementedError("HIP attention kernel is built for head dim 64")
+    if self_attention:
+      self.qkv = Dense(store, name + "/qkv", hidden, 3 * hidden, False)
+    else:
+      self.q = Dense(store, name + "/q", hidden, hidden, False)
+      self.kv = Dense(store, name + "/kv", hidden, 2 * hidden, False)
+    self.out = Dense(store, name + "/output_transform", hidden, hidden, False)
+
+  def forward(self, x, y, cu_q, cu_k, max_len, causal, tape, seeds, att_keep, post_keep, residual):
+    """x: queries source (Act [Nq,D]); y: keys/values source (Act [Nk,D]) — y is x for
+    self-attention. Returns residual + dropout(W_o attention)."""
+    D, H = self.D, self.H
+    if self.self_att:
+      qkv = self.qkv.forward(x, tape)
+      qv, kv_, vv = qkv.data[:, :D], qkv.data[:, D:2 * D], qkv.data[:, 2 * D:]
+    else:
+      q = self.q.forward(x, tape)
+      kv = self.kv.forward(y, tape)
+      qv, kv_, vv = q.data, kv.data[:, :D], kv.data[:, D:]
+    seed = seeds.next()
+    o, lse = capi.attention_fwd(qv, kv_, vv, cu_q, cu_k, H, max_len, causal, self.scale,
+                                att_keep, seed)
+    oa = Act(o)
+    if tape is not None:
+      att = self
+
+      def backward():
+        d_o = oa.grad
+        assert d_o is not None
+        if att.self_att:
+          g = torch.empty_like(qkv.data)
+          capi.attention_bwd(qv, kv_, vv, d_o, lse, g[:, :D], g[:, D:2 * D], g[:, 2 * D:], cu_q,
+                             cu_k, H, max_len, causal, att.scale, att_keep, seed)
+          qkv.grad = g
+        else:
+          gq = torch.empty_like(q.data)
+          gkv = torch.empty_like(kv.data)
+          capi.attention_bwd(qv, kv_, vv, d_o, lse, gq, gkv[:, :D], gkv[:, D:], cu_q, cu_k, H,
+                             max_len, causal, att.scale, att_keep, seed)
+          q.grad, kv.grad = gq, gkv
+        oa.grad = None
+
+      tape.record(backward)
+    return self.out.forward(oa, tape, keep=post_keep, seed=seeds.next(), residual=residual)
+
+
+class FeedForward(object):
+  """FeedFowardNetwork (ffn_layer.py:25-85): Dense(filter, relu) -> dropout -> Dense(hidden)."""
+
+  def __init__(self, store, name, hidden, filter_size):
+    self.filter_layer = Dense(store, name + "/filter_layer", hidden, filter_size, True)
+    self.output_layer = Dense(store, name + "/output_layer", filter_size, hidden, True)
+
+  def forward(self, x, tape, seeds, relu_keep, post_keep, residual):
+    h = self.filter_layer.forward(x, tape, act=1, keep=relu_keep, seed=seeds.next())
+    return self.output_layer.forward(h, tape, keep=post_keep, seed=seeds.next(), residual=residual)
+
+
+class SharedEmbedding(object):
+  """EmbeddingSharedWeights (embedding_layer.py:26-105): one [V, D] matrix used for the
+  input embeddings of both stacks and, transposed, for the pre-softmax projection."""
+
+  def __init__(self, store, name, vocab_size, hidden, pad_vocab_to_eight=False):
+    if pad_vocab_to_eight and vocab_size % 8:
+      vocab_size += 8 - vocab_size % 8
+    if vocab_size % 8:
+      raise NotImplementedError("vocab size must be a multiple of 8 (use pad_vocab_to_eight)")
+    self.V, self.D = vocab_size, hidden
+
+    def init(shape):   # random_normal_initializer(0, hidden**-0.5)
+      return torch.randn(shape) * hidden ** -0.5
+
+    self.weights = store.add(name + "/embedding_and_softmax/weights", (1, vocab_size, hidden),
+                             init, kind="conv")
+
+  @property
+  def table(self):
+    return self.weights.w16.view(self.V, self.D)
+
+  def embed(self, ids, pos, tape, keep, seed):
+    out = Act(capi.embed_fwd(ids, pos, self.table, self.D ** 0.5, keep, seed))
+    if tape is not None:
+      emb = self
+
+      def backward():
+        if out.grad is not None:
+          capi.embed_bwd(ids, out.grad, emb.weights.grad.view(emb.V, emb.D), emb.D ** 0.5, keep,
+                         seed)
+        out.grad = None
+
+      tape.record(backward)
+    return out
+
+  def linear(self, x, tape):
+    """logits = x E^T  (bf16 [N, V])."""
+    y = capi.gemm(x.data, self.table)
+    out = Act(y)
+    if tape is not None:
+      emb = self
+
+      def backward():
+        dy = out.grad
+        assert dy is not None
+        capi.gemm_wgrad(x.data, dy, emb.weights.grad.view(emb.V, emb.D), accumulate=True)
+        g = x.grad_buffer()
+        capi.gemm(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
+        x.grad_init = True
+        out.grad = None
+
+      tape.record(backward)
+    return out

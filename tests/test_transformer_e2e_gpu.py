@@ -1,0 +1,188 @@
+"""GPU end-to-end parity of the Transformer NMT training path (scaled down:
+d_model 512, 8 heads, filter 1024, 2+2 layers, V=1000): loss and parameter gradients vs
+the CPU fp32 oracle (oracle/transformer.py, padded [B,L] exactly like the reference) —
+the device path runs on PACKED tokens. Dropout is 0 for parity (mask-sharing tests of
+the dropout streams live in tests/test_transformer_kernels_gpu.py). Tolerances: bf16
+storage through ~30 GEMMs: loss rtol 2e-2; gradients cosine >= 0.98, rel-L2 <= 0.2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D, H, F, V, NL = 512, 8, 1024, 1000, 2
+
+
+def _build(cuda, dropout=0.0):
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.transformer_encoder import TransformerEncoder
+  from openseq2seq_amd.decoders.transformer_decoder import TransformerDecoder
+  from openseq2seq_amd.losses.sequence_loss import PaddedCrossEntropyLossWithSmoothing
+  torch.manual_seed(0)
+  store = FlatParams(cuda)
+  enc = TransformerEncoder({"encoder_layers": NL, "hidden_size": D, "num_heads": H,
+                            "attention_dropout": dropout, "filter_size": F, "src_vocab_size": V,
+                            "relu_dropout": dropout, "layer_postprocess_dropout": dropout,
+                            "remove_padding": True, "dtype": "mixed"}, None, mode="train").build(store)
+  dec = TransformerDecoder({"EOS_ID": 1, "layer_postprocess_dropout": dropout,
+                            "num_hidden_layers": NL, "hidden_size": D, "num_heads": H,
+                            "attention_dropout": dropout, "relu_dropout": dropout,
+                            "filter_size": F, "batch_size": 4, "tgt_vocab_size": V, "beam_size": 4,
+                            "alpha": 0.6, "extra_decode_length": 50, "dtype": "mixed"}, None,
+                           mode="train").build(store)
+  loss = PaddedCrossEntropyLossWithSmoothing({"label_smoothing": 0.1, "tgt_vocab_size": V,
+                                              "batch_size": 4, "dtype": "mixed"}, None)
+  store.finalize(need_m2=True)
+  return store, enc, dec, loss
+
+
+def _batch(cuda, B=4, Lmax=20, seed=1):
+  from openseq2seq_amd.parts.transformer import packing
+  rng = np.random.RandomState(seed)
+
+  def draw():
+    lens = rng.randint(3, Lmax + 1, size=B).astype(np.int32)
+    ids = np.zeros((B, int(lens.max())), np.int32)
+    for b in range(B):
+      ids[b, :lens[b] - 1] = rng.randint(4, V, size=lens[b] - 1)
+      ids[b, lens[b] - 1] = 1
+    return ids, lens
+  src, sl = draw()
+  tgt, tl = draw()
+  batch = {'source_tensors': [torch.from_numpy(src).to(cuda), torch.from_numpy(sl).to(cuda)],
+           'target_tensors': [torch.from_numpy(tgt).to(cuda), torch.from_numpy(tl).to(cuda)],
+           'packed_source': packing.to_device(packing.pack_ids(src, sl), cuda),
+           'packed_target': packing.to_device(packing.pack_ids(tgt, tl, shift_right=True), cuda)}
+  return batch, src, sl, tgt, tl
+
+
+def _oracle_params(store):
+  """Device parameters (bf16 compute copies for matrices) -> oracle dict with autograd."""
+  def w(name):   # Dense kernel [1,Cout,Cin] -> [Cin,Cout]
+    return store.by_name(name + "/kernel").w16.float().cpu()[0].t().contiguous().requires_grad_(True)
+
+  def v(name):
+    return store.by_name(name).master.cpu().clone().requires_grad_(True)
+
+  leaves = {}
+
+  def ln(prefix):
+    d = {"scale": v(prefix + "/layer_norm_scale"), "bias": v(prefix + "/layer_norm_bias")}
+    leaves[prefix + "/layer_norm_scale"] = d["scale"]
+    leaves[prefix + "/layer_norm_bias"] = d["bias"]
+    return d
+
+  def att_self(prefix):
+    qkv = w(prefix + "/qkv")
+    leaves[prefix + "/qkv/kernel"] = qkv
+    o = w(prefix + "/output_transform")
+    leaves[prefix + "/output_transform/kernel"] = o
+    return {"q": qkv[:, :D], "k": qkv[:, D:2 * D], "v": qkv[:, 2 * D:], "o": o}
+
+  def att_cross(prefix):
+    q, kv, o = w(prefix + "/q"), w(prefix + "/kv"), w(prefix + "/output_transform")
+    leaves[prefix + "/q/kernel"], leaves[prefix + "/kv/kernel"] = q, kv
+    leaves[prefix + "/output_transform/kernel"] = o
+    return {"q": q, "k": kv[:, :D], "v": kv[:, D:], "o": o}
+
+  def ffn(prefix):
+    d = {"w1": w(prefix + "/filter_layer"), "b1": v(prefix + "/filter_layer/bias"),
+         "w2": w(prefix + "/output_layer"), "b2": v(prefix + "/output_layer/bias")}
+    leaves[prefix + "/filter_layer/kernel"], leaves[prefix + "/filter_layer/bias"] = d["w1"], d["b1"]
+    leaves[prefix + "/output_layer/kernel"], leaves[prefix + "/output_layer/bias"] = d["w2"], d["b2"]
+    return d
+
+  emb = store.by_name("ForwardPass/embedding_and_softmax/weights").w16.float().cpu()[0] \
+      .clone().requires_grad_(True)
+  leaves["ForwardPass/embedding_and_softmax/weights"] = emb
+  e, dc = "ForwardPass/transformer_encoder", "ForwardPass/transformer_decoder"
+  PE = {"emb": emb, "layers": [], "ln_out": ln(e + "/layer_normalization")}
+  PD = {"emb": emb, "layers": [], "ln_out": ln(dc + "/layer_normalization")}
+  for n in range(NL):
+    ls = "%s/layer_%d" % (e, n)
+    PE["layers"].append({"ln1": ln(ls + "/self_attention/layer_normalization"),
+                         "att": att_self(ls + "/self_attention/self_attention"),
+                         "ln2": ln(ls + "/ffn/layer_normalization"),
+                         "ffn": ffn(ls + "/ffn/feed_foward_network")})
+    ls = "%s/layer_%d" % (dc, n)
+    PD["layers"].append({"ln1": ln(ls + "/self_attention/layer_normalization"),
+                         "self": att_self(ls + "/self_attention/self_attention"),
+                         "ln2": ln(ls + "/encdec_attention/layer_normalization"),
+                         "cross": att_cross(ls + "/encdec_attention/attention"),
+                         "ln3": ln(ls + "/ffn/layer_normalization"),
+                         "ffn": ffn(ls + "/ffn/feed_foward_network")})
+  return PE, PD, leaves
+
+
+def test_transformer_small_fwd_bwd(cuda):
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+  from openseq2seq_amd.parts.transformer.layers import SeedSeq
+  from oracle import transformer as ot
+  store, enc, dec, lossf = _build(cuda)
+  batch, src, sl, tgt, tl = _batch(cuda)
+  tape = Tape()
+  store.zero_grads()
+  e = enc.encode({'source_tensors': batch['source_tensors'], 'tape': tape, 'seeds': SeedSeq(1),
+                  'packed_source': batch['packed_source']})
+  d = dec.decode({'encoder_output': e, 'target_tensors': batch['target_tensors'], 'tape': tape,
+                  'packed_target': batch['packed_target']})
+  L = lossf.compute_loss({'decoder_output': d, 'target_tensors': batch['target_tensors']})
+  tape.backward()
+  torch.cuda.synchronize()
+  # ---- oracle on the padded batch ---------------------------------------------
+  PE, PD, leaves = _oracle_params(store)
+  s_ids, t_ids = torch.from_numpy(src).long(), torch.from_numpy(tgt).long()
+  enc_out, bias = ot.encoder(s_ids, PE, H)
+  logits = ot.decoder_pass(t_ids, enc_out, bias, PD, H)
+  loss = ot.padded_xent_smoothing(logits, t_ids, 0.1)
+  loss.backward()
+  torch.testing.assert_close(L.cpu()[0], loss.detach(), rtol=2e-2, atol=2e-2)
+  # packed logits == padded logits at the non-pad positions
+  lg = d["logits"].float().cpu()
+  ref_rows = torch.cat([logits[b, :tl[b]] for b in range(len(tl))], 0).detach()
+  rel = float((lg - ref_rows).norm() / ref_rows.norm())
+  assert rel < 3e-2, rel
+  worst = (1.0, "")
+  for name, leaf in leaves.items():
+    p = store.by_name(name if name.endswith(("scale", "bias", "weights")) or name.endswith("/kernel")
+                      else name)
+    got = p.grad.cpu()
+    ref = leaf.grad
+    if name.endswith("/kernel"):
+      ref = ref.t()[None]
+    elif name.endswith("weights"):
+      ref = ref[None]
+    cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
+    relerr = float((got - ref).norm() / (ref.norm() + 1e-12))
+    worst = min(worst, (cos, name))
+    assert cos > 0.98, (name, cos, relerr)
+    assert relerr < 0.2, (name, cos, relerr)
+  print("worst cosine", worst, "logits rel", rel)
+
+
+def test_transformer_small_trains(cuda):
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+  from openseq2seq_amd.parts.transformer.layers import SeedSeq
+  from openseq2seq_amd.optimizers.optimizers import optimize_loss
+  from openseq2seq_amd.optimizers import lr_policies
+  store, enc, dec, lossf = _build(cuda, dropout=0.1)
+  op = optimize_loss(store, "LazyAdam", dict(beta1=0.9, beta2=0.997, epsilon=1e-9),
+                     lr_policies.transformer_policy,
+                     dict(learning_rate=2.0, warmup_steps=40, d_model=D), loss_scaling="Backoff")
+  batch, *_ = _batch(cuda, B=8, Lmax=24, seed=5)
+  losses = []
+  for step in range(40):
+    tape = Tape()
+    store.zero_grads()
+    e = enc.encode({'source_tensors': batch['source_tensors'], 'tape': tape,
+                    'seeds': SeedSeq(step + 1), 'packed_source': batch['packed_source']})
+    d = dec.decode({'encoder_output': e, 'target_tensors': batch['target_tensors'], 'tape': tape,
+                    'packed_target': batch['packed_target']})
+    L = lossf.compute_loss({'decoder_output': d, 'target_tensors': batch['target_tensors'],
+                            'loss_scale_dev': op.loss_scale_view})
+    tape.backward()
+    op.run()
+    losses.append(float(L.cpu()[0]))
+  st = op.read_state()
+  assert np.isfinite(losses).all() and st["num_skipped"] <= 2
+  assert losses[-1] < 0.6 * losses[0], losses
