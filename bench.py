@@ -42,6 +42,9 @@ def parse():
                   help="0: durations U[2,16.7]s (default workload); >0: every utterance has "
                        "this many frames (1680 = worst-case fixed shape)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-transformer", action="store_true",
+                  help="skip the secondary Transformer-big tokens/sec measurement")
+  ap.add_argument("--transformer-batch", type=int, default=256)
   ap.add_argument("--no-kernel-timing", action="store_true")
   return ap.parse_args()
 
@@ -148,6 +151,52 @@ def cpu_baseline(vocab_size=29):
                     "T=320 frames, 1 warm-up + %d timed steps, %.2f s/step" % (nt, dt)}
 
 
+def bench_transformer(args, hvd, dev, rank, world):
+  """Secondary headline: tokens/sec of Transformer-big (transformer-big.py: B=256 pairs/GPU,
+  lengths U[8,56], V=32768) full train step; objects = src+tgt tokens (text2text.py:227-241)."""
+  from openseq2seq_amd.configs.transformer import transformer_config
+  model_cls, params = transformer_config(batch_size_per_gpu=args.transformer_batch)
+  model = model_cls(params, mode="train", hvd=hvd, device=dev)
+  model.compile()
+  batch = model.get_data_layer().synthetic_batch(dev, seed=1234 + rank)
+
+  def barrier():
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    model.train_step(batch)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss = model.train_step(batch)
+  barrier()
+  dt = time.perf_counter() - t0
+  tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+  toks = torch.tensor([float(batch['num_tokens'])], dtype=torch.float64, device=dev)
+  if world > 1:
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    torch.distributed.all_reduce(toks, op=torch.distributed.ReduceOp.SUM)
+  dt = float(tmax.item())
+  st = model.train_op.read_state()
+  tps = float(toks.item()) * args.steps / dt
+  res = {
+      "metric": "tokens/sec Transformer-big bf16 (train step, objects = src+tgt tokens)",
+      "value": tps, "unit": "tokens/sec", "ms_per_step": 1000.0 * dt / args.steps,
+      "workload": "Transformer-big (transformer-big.py): B=%d pairs/GPU, lengths U[8,56], "
+                  "V=32768, packed tokens, fwd+bwd+all-reduce+Adam" % args.transformer_batch,
+      "tokens_per_step": float(toks.item()),
+      # 0.629 GFLOP per counted token (train), SURVEY §8d
+      "model_tflops": 0.629e-3 * tps,
+      "params_M": model.store.num_trainable() / 1e6,
+      "loss": float(loss.cpu()[0]), "skipped_steps": st["num_skipped"],
+  }
+  del model
+  torch.cuda.empty_cache()
+  return res
+
+
 def main():
   args = parse()
   from openseq2seq_amd.utils import distributed as dist_utils
@@ -195,8 +244,6 @@ def main():
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     torch.distributed.all_reduce(frames, op=torch.distributed.ReduceOp.SUM)
     torch.distributed.all_reduce(padded, op=torch.distributed.ReduceOp.SUM)
-  if rank != 0:
-    return
   dt = float(tmax.item())
   total_frames = float(frames.item()) * args.steps
   value = total_frames / dt
@@ -235,6 +282,21 @@ def main():
         "avg_launch_ms": ms / max(n, 1),
         "time_share_of_step": ms / (1000.0 * dt),
     }
+  if not args.no_transformer:
+    # free the Jasper model first
+    del model
+    torch.cuda.empty_cache()
+    timer.enabled = False
+    try:
+      tr = bench_transformer(args, hvd, dev, rank, world)
+      if rank == 0:
+        out["secondary"] = tr
+    except Exception as e:
+      if rank == 0:
+        out["secondary"] = {"metric": "tokens/sec Transformer-big bf16", "value": None,
+                            "error": repr(e)}
+  if rank != 0:
+    return
   if world == 1 and not args.no_cpu_baseline:
     try:
       out["cpu_baseline"] = cpu_baseline()
