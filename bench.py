@@ -45,6 +45,8 @@ def parse():
   ap.add_argument("--no-transformer", action="store_true",
                   help="skip the secondary Transformer-big tokens/sec measurement")
   ap.add_argument("--transformer-batch", type=int, default=256)
+  ap.add_argument("--only-transformer", action="store_true",
+                  help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
   return ap.parse_args()
 
@@ -208,6 +210,11 @@ def main():
   dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
 
+  if args.only_transformer:
+    tr = bench_transformer(args, hvd, dev, rank, world)
+    if rank == 0:
+      print(json.dumps(tr))
+    return
   from openseq2seq_amd import capi
   from openseq2seq_amd.configs.jasper import jasper10x5_config
   timer = ConvTimer(capi)

@@ -33,7 +33,7 @@ struct WgradArgs {
   float* dw;
   const int32_t* in_len;
   int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
-  int NCO, NCI, NTP, NSPLIT, b_per_split, use_atomic;
+  int NCO, NCI, NTP, NSPLIT, steps_per_split, use_atomic;
   int xrows, xrows_pad;  // X window rows per 64-step (and padded to x4)
 };
 
@@ -74,14 +74,18 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
   char* const xbuf0 = smem + 2 * ybuf_bytes;
   const char* const zero = reinterpret_cast<const char*>(g_zero_page);
 
-  const int b_begin = split * p.b_per_split;
-  const int b_end = min(p.B, b_begin + p.b_per_split);
+  // the reduction index space (batch item, 64-row time chunk) is cut into NSPLIT
+  // contiguous ranges of steps
   const int tchunks = (p.Tout + BT - 1) / BT;
-  const int nsteps = (b_end - b_begin) * tchunks;
+  const int total_steps = p.B * tchunks;
+  const int s_begin = split * p.steps_per_split;
+  const int s_end = min(total_steps, s_begin + p.steps_per_split);
+  const int nsteps = max(0, s_end - s_begin);
 
   auto stage = [&](int step, int buf) {
-    const int b = b_begin + step / tchunks;
-    const int t0 = (step - (step / tchunks) * tchunks) * BT;
+    const int gs = s_begin + step;
+    const int b = gs / tchunks;
+    const int t0 = (gs - b * tchunks) * BT;
     int len_b = p.Tin;
     if (p.in_len) {
       int l = p.in_len[b];
@@ -236,15 +240,17 @@ extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
   a.NCI = ceil_div(Cin, 128);
   a.NTP = ceil_div(K, TAPS);
   const int base_blocks = a.NCO * a.NCI * a.NTP;
+  const int total_steps = B * ceil_div(Tout, 64);
   int nsplit = 1;
   if (accumulate) {
     const int target = 1024;  // ~2 workgroups per CU x 2 waves of blocks
     nsplit = ceil_div(target, base_blocks);
-    if (nsplit > B) nsplit = B;
+    const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;   // >= 8 steps per block
+    if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
   }
-  a.b_per_split = ceil_div(B, nsplit);
-  a.NSPLIT = ceil_div(B, a.b_per_split);
+  a.steps_per_split = ceil_div(total_steps, nsplit);
+  a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
   a.use_atomic = accumulate ? 1 : 0;
   a.xrows = 63 * stride + (TAPS - 1) * dil + 1;
   a.xrows_pad = ceil_div(a.xrows, 4) * 4;
