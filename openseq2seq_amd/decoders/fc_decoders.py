@@ -85,7 +85,7 @@ class FullyConnectedTimeDecoder(Decoder):
                           accumulate=x.grad_init)
           x.grad_init = True
 
-      tape.record(backward)
+      tape.record(backward, [dec.kernel, dec.bias])
     return out
 
 

@@ -65,7 +65,8 @@ class TransformerEncoder(Encoder):
     post_keep = 1.0 - p["layer_postprocess_dropout"] if training else 1.0
     att_keep = 1.0 - p["attention_dropout"] if training else 1.0
     relu_keep = 1.0 - p["relu_dropout"] if training else 1.0
-    x = self.embedding_softmax_layer.embed(pk["ids"], pk["pos"], tape, post_keep, seeds.next())
+    x = self.embedding_softmax_layer.embed(pk["ids"], pk["pos"], tape, post_keep, seeds.next(),
+                                           final_use=True)
     for lyr in self.layers:
       y = lyr["ln1"].forward(x, tape)
       x = lyr["att"].forward(y, y, pk["cu"], pk["cu"], pk["max_len"], False, tape, seeds,

@@ -195,13 +195,15 @@ class Model(object):
     micro = self._step_count % iter_size
     if micro == 0:
       self._store.zero_grads()
-    tape = Tape()
+    last_micro = (micro == iter_size - 1)
+    overlap = self._reducer is not None and last_micro
+    tape = Tape(on_done=self._reducer.mark_done if overlap else None)
     loss = self._forward_backward(batch, tape)
     tape.backward()
     self._step_count += 1
-    if micro == iter_size - 1:
+    if last_micro:
       if self._reducer is not None:
-        self._reducer.all_reduce()
+        self._reducer.finish()
       self._train_op.run()
     return loss
 

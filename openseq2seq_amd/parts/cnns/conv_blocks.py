@@ -30,15 +30,25 @@ def act_id(fn):
 
 
 class Tape(object):
-  def __init__(self):
-    self.ops = []
+  """Reverse-mode tape. `record(fn, params)` also notes which parameters the closure
+  finalises; after each closure `on_done(min offset finalised so far)` lets the
+  data-parallel reducer start the all-reduce of complete gradient buckets."""
 
-  def record(self, fn):
-    self.ops.append(fn)
+  def __init__(self, on_done=None):
+    self.ops = []
+    self.on_done = on_done
+
+  def record(self, fn, params=()):
+    self.ops.append((fn, params))
 
   def backward(self):
-    for fn in reversed(self.ops):
+    low = None
+    for fn, params in reversed(self.ops):
       fn()
+      if self.on_done is not None and params:
+        m = min(p.offset for p in params)
+        low = m if low is None else min(low, m)
+        self.on_done(low)
     self.ops = []
 
 
@@ -176,7 +186,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
                         accumulate=inp.grad_init)
         inp.grad_init = True
 
-  tape.record(backward)
+  tape.record(backward, [p for br in branches for p in (br.kernel, br.gamma, br.beta)])
   return result
 
 

@@ -95,7 +95,7 @@ class Dense(object):
         residual.res_grad = dy      # consumed by the pre-norm LayerNorm backward of `residual`
       out.grad = None
 
-    tape.record(backward)
+    tape.record(backward, [lin.kernel] + ([lin.bias] if lin.bias is not None else []))
     return out
 
 
@@ -125,7 +125,7 @@ class LayerNorm(object):
       _accumulate_grad(x, dx)
       out.grad = None
 
-    tape.record(backward)
+    tape.record(backward, [ln.scale, ln.bias])
     return out
 
 
@@ -218,7 +218,9 @@ class SharedEmbedding(object):
   def table(self):
     return self.weights.w16.view(self.V, self.D)
 
-  def embed(self, ids, pos, tape, keep, seed):
+  def embed(self, ids, pos, tape, keep, seed, final_use=False):
+    """final_use: True for the FIRST use in forward order (= the last closure of the
+    backward pass that touches the shared weights; only then are their gradients final)."""
     out = Act(capi.embed_fwd(ids, pos, self.table, self.D ** 0.5, keep, seed))
     if tape is not None:
       emb = self
@@ -229,7 +231,7 @@ class SharedEmbedding(object):
                          seed)
         out.grad = None
 
-      tape.record(backward)
+      tape.record(backward, [emb.weights] if final_use else ())
     return out
 
   def linear(self, x, tape):

@@ -58,27 +58,59 @@ def broadcast_parameters(store, extra_tensors=(), root=0):
 
 
 class GradientReducer(object):
-  """Bucketed all-reduce(SUM) of the flat fp32 gradient buffer on a side stream."""
+  """Bucketed all-reduce(SUM) of the flat fp32 gradient buffer on a side stream,
+  overlapped with backward.
 
-  def __init__(self, store, world_size, bucket_bytes=256 << 20):
+  Variables are created in forward order, so backward finalises their gradients from
+  the END of the flat buffer towards the start. Each backward closure reports the
+  lowest parameter offset it has finalised (`mark_done`); every bucket that lies
+  entirely above the watermark is all-reduced immediately on the side stream while the
+  remaining backward kernels keep running on the compute stream. `finish()` reduces
+  whatever is left and makes the compute stream wait for the side stream."""
+
+  def __init__(self, store, world_size, bucket_bytes=128 << 20):
     self.store, self.world = store, world_size
     n = store.grads.numel()
     per = max(bucket_bytes // 4, store.chunk)
     per = (per // store.chunk) * store.chunk
     self.bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
     self.stream = torch.cuda.Stream() if store.grads.is_cuda else None
+    self.reset()
 
-  def all_reduce(self):
+  def reset(self):
+    self.watermark = self.store.grads.numel()
+    self.next_bucket = len(self.bounds) - 1
+
+  def _reduce(self, s, e):
     g = self.store.grads
     if self.stream is None:
-      for s, e in self.bounds:
-        dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
+      dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
       return
-    self.stream.wait_stream(torch.cuda.current_stream())
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    self.stream.wait_event(ev)
     with torch.cuda.stream(self.stream):
-      for s, e in self.bounds:
-        dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
-    torch.cuda.current_stream().wait_stream(self.stream)
+      dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
+
+  def mark_done(self, offset):
+    """All gradients at flat offsets >= `offset` are final."""
+    if offset < self.watermark:
+      self.watermark = offset
+    while self.next_bucket >= 0 and self.bounds[self.next_bucket][0] >= self.watermark:
+      s, e = self.bounds[self.next_bucket]
+      self._reduce(s, e)
+      self.next_bucket -= 1
+
+  def finish(self):
+    self.mark_done(0)
+    if self.stream is not None:
+      torch.cuda.current_stream().wait_stream(self.stream)
+    self.reset()
+
+  def all_reduce(self):
+    """Non-overlapped form (everything after backward)."""
+    self.reset()
+    self.finish()
 
 
 def gather_objects(obj, root=0):

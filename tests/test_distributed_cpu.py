@@ -57,6 +57,18 @@ def _worker(rank, world, port, q):
   assert len(red.bounds) == 3
   red.all_reduce()
   ok_sum = bool(torch.allclose(st.grads, base * sum(range(1, world + 1))))
+  # overlapped form: buckets are reduced as the backward watermark moves down
+  st.grads.copy_(base * (rank + 1))
+  red.mark_done(4096 * 4 + 7)          # inside the last bucket: nothing complete yet
+  ok_sum = ok_sum and red.next_bucket == 2
+  red.mark_done(4096 * 4)              # the last bucket [16384, 20480) is complete
+  ok_sum = ok_sum and red.next_bucket == 1
+  ok_sum = ok_sum and bool(torch.allclose(st.grads[16384:], base[16384:] * 3))
+  ok_sum = ok_sum and bool(torch.allclose(st.grads[:16384], base[:16384] * (rank + 1)))
+  red.mark_done(4096 * 2)              # bucket [8192, 16384) now complete
+  ok_sum = ok_sum and red.next_bucket == 0
+  red.finish()
+  ok_sum = ok_sum and bool(torch.allclose(st.grads, base * 3)) and red.next_bucket == 2
   objs = du.gather_objects({"rank": rank, "n": rank * 10})
   ok_gather = (objs is None) if rank != 0 else ([o["n"] for o in objs] == [0, 10])
   q.put((rank, ok_bcast, ok_sum, ok_gather))
