@@ -58,53 +58,73 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
+// BM = rows of ONE time window (one batch item); a workgroup processes NWIN consecutive
+// windows (possibly of different batch items) against the same weight stream, so the
+// M extent of a block is NWIN*BM while the tile granularity in time stays BM.
+template <int BM, int BN, int WM, int WN, int NWIN>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_igemm_kernel(
     ConvArgs p) {
   constexpr int NW = WM * WN, NTHR = NW * 64;
-  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  constexpr int WTM = (BM * NWIN) / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be 32-aligned");
+  static_assert(BM % WTM == 0, "a wave must not straddle two windows");
   static_assert((BN * 8) % (NW * 64) == 0, "weight tile DMA split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
+  const int my_win = (wm * WTM) / BM;            // window this wave computes
+  const int row_in_win = (wm * WTM) % BM;
 
-  // ---- block -> tile (XCD-aware: see header) ------------------------------
+  // ---- block -> tiles (XCD-aware: see header) ------------------------------
   const int bid = blockIdx.x;
   const int xcd = bid & 7, loc = bid >> 3;
   const int n_idx = loc / p.MT8;
-  const int m_idx = (loc - n_idx * p.MT8) * 8 + xcd;
-  if (m_idx >= p.MT) return;
-  const int b = m_idx / p.mtiles_per_b;
-  const int t0 = (m_idx - b * p.mtiles_per_b) * BM;
+  const int m_first = ((loc - n_idx * p.MT8) * 8 + xcd) * NWIN;
+  if (m_first >= p.MT) return;
   const int n0 = n_idx * BN;
-
-  int len_b = p.Tin;
-  if (p.in_len) {
-    int l = p.in_len[b];
-    len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+  int wb[NWIN], wt0[NWIN], wlen[NWIN], wwin[NWIN];
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) {
+    const int m = m_first + w;
+    const bool live = m < p.MT;
+    wb[w] = live ? m / p.mtiles_per_b : 0;
+    wt0[w] = live ? (m - wb[w] * p.mtiles_per_b) * BM : 0;
+    int len_b = p.Tin;
+    if (p.in_len) {
+      int l = p.in_len[wb[w]];
+      len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+    }
+    wlen[w] = live ? len_b : 0;                   // dead window: every row reads as zero
+    wwin[w] = wt0[w] * p.stride - p.padL;
   }
-  const int win_t0 = t0 * p.stride - p.padL;
-  const int xbuf_bytes = p.Rpad * 128;
+  static_assert(NWIN == 1 || NWIN == 2, "window selects below are written for <= 2 windows");
+  // select by compare (a runtime-indexed register array would be demoted to scratch)
+  const int my_b = (NWIN == 1 || my_win == 0) ? wb[0] : wb[NWIN - 1];
+  const int my_t0 = (NWIN == 1 || my_win == 0) ? wt0[0] : wt0[NWIN - 1];
+  const int win_bytes = p.Rpad * 128;
+  const int xbuf_bytes = NWIN * win_bytes;
   char* const xbuf0 = smem;
   char* const wbuf0 = smem + 2 * xbuf_bytes;
-  const bf16_t* const xb = p.x + (long long)b * p.x_sb;
   const char* const zero = reinterpret_cast<const char*>(g_zero_page);
 
   auto stage_x = [&](int c, char* dst) {
     const int npieces = p.Rpad * 8;  // multiple of 64
-    for (int base = wid * 64; base < npieces; base += NW * 64) {
-      const int q = base + lane;
-      const int r = q >> 3, jj = q & 7;
-      const int j = jj ^ ((r >> 1) & 7);
-      const int tin = win_t0 + r;
-      const int ch = c * 64 + j * 8;
-      const bool ok = (r < p.R) && (tin >= 0) && (tin < len_b) && (ch < p.Cin);
-      const void* src = ok ? (const void*)(xb + (long long)tin * p.x_st + ch)
-                           : (const void*)(zero + jj * 16);
-      dma16(src, dst + base * 16);
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w) {
+      const bf16_t* const xb = p.x + (long long)wb[w] * p.x_sb;
+      for (int base = wid * 64; base < npieces; base += NW * 64) {
+        const int q = base + lane;
+        const int r = q >> 3, jj = q & 7;
+        const int j = jj ^ ((r >> 1) & 7);
+        const int tin = wwin[w] + r;
+        const int ch = c * 64 + j * 8;
+        const bool ok = (r < p.R) && (tin >= 0) && (tin < wlen[w]) && (ch < p.Cin);
+        const void* src = ok ? (const void*)(xb + (long long)tin * p.x_st + ch)
+                             : (const void*)(zero + jj * 16);
+        dma16(src, dst + w * win_bytes + base * 16);
+      }
     }
   };
   auto stage_w = [&](int c, int k, char* dst) {
@@ -147,9 +167,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
       if (kn == 0) stage_x(cn, xbuf0 + (cn & 1) * xbuf_bytes);
       stage_w(cn, kn, wbuf0 + ((step + 1) & 1) * (BN * 128));
     }
-    const char* const xs = xbuf0 + (c & 1) * xbuf_bytes;
+    const char* const xs = xbuf0 + (c & 1) * xbuf_bytes + my_win * win_bytes;
     const char* const ws = wbuf0 + (step & 1) * (BN * 128);
-    const int rbase = (wm * WTM + l31) * p.stride + k * p.dil;
+    const int rbase = (row_in_win + l31) * p.stride + k * p.dil;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int j = kk * 2 + lhi;
@@ -175,15 +195,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
   }
 
   // ---- epilogue ------------------------------------------------------------
-  const int valid_rows = min(BM, p.Tout - t0);
   if (p.out_f32) {
     // small/rare path (FC logits): scattered fp32 stores straight from registers
+    const int b = my_b, t0 = my_t0;
+    const int valid_rows = (m_first + my_win < p.MT) ? min(BM, p.Tout - t0) : 0;
     float* const yb = reinterpret_cast<float*>(p.y) + (long long)b * p.y_sb;
 #pragma unroll
     for (int in = 0; in < NI; ++in)
 #pragma unroll
       for (int im = 0; im < MI; ++im) {
-        const int tt = wm * WTM + im * 32 + l31;
+        const int tt = row_in_win + im * 32 + l31;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int cc = n0 + wn * WTN + in * 32 + 8 * (e >> 2) + 4 * lhi + (e & 3);
@@ -206,7 +227,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
   for (int in = 0; in < NI; ++in)
 #pragma unroll
     for (int im = 0; im < MI; ++im) {
-      const int tt = wm * WTM + im * 32 + l31;
+      const int tt = wm * WTM + im * 32 + l31;   // row in the block's (NWIN*BM)-row out tile
+      const int b = my_b, t0 = my_t0 - my_win * BM;   // t0 + tt = time of this row
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cc = wn * WTN + in * 32 + 8 * g + 4 * lhi;
@@ -240,12 +262,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
     }
   __syncthreads();
 
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) {
+  const int b = wb[w], t0 = wt0[w];
+  const int valid_rows = (m_first + w < p.MT) ? min(BM, p.Tout - t0) : 0;
+  const char* const otw = ot + w * BM * OP;
   bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
   for (int q = tid; q < BM * (BN / 8); q += NTHR) {
     const int row = q / (BN / 8), c8 = q - row * (BN / 8);
     const int gc = n0 + c8 * 8;
     if (row < valid_rows && gc < p.Cout) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * OP + c8 * 16);
+      u32x4 v = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
       bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
       if (p.residual) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(
@@ -263,20 +290,28 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
       *reinterpret_cast<u32x4*>(dst) = v;
     }
   }
+  }
 
   if (p.stats) {
     constexpr int CP = BN / 2;       // column pairs
     constexpr int RG = NTHR / CP;    // row groups
     static_assert(NTHR % CP == 0, "stats split");
     const int cp = tid % CP, rg = tid / CP;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w) {
+    if (m_first + w >= p.MT) break;
+    const int m_idx = m_first + w;
+    const int valid_rows = min(BM, p.Tout - wt0[w]);
+    const char* const otw = ot + w * BM * OP;
+    if (w > 0) __syncthreads();      // scratch re-use between windows
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     for (int row = rg; row < valid_rows; row += RG) {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(ot + row * OP + cp * 4);
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4);
       const float a = bflo(v), bb = bfhi(v);
       s0 += a; q0 += a * a;
       s1 += bb; q1 += bb * bb;
     }
-    float* sc = reinterpret_cast<float*>(smem + BM * OP);  // [RG][BN][2]
+    float* sc = reinterpret_cast<float*>(smem + NWIN * BM * OP);  // [RG][BN][2]
     sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
     sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
     sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
@@ -295,35 +330,36 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
         p.stats[((long long)m_idx * 2 + 1) * p.Cout + gc] = qq;
       }
     }
+    }
   }
 }
 
 constexpr int kConvBM = 128, kConvBN = 128;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NWIN>
 static int launch_conv(hipStream_t stream, ConvArgs& a) {
   constexpr int NTHR = WM * WN * 64;
   a.mtiles_per_b = ceil_div(a.Tout, BM);
   a.MT = a.B * a.mtiles_per_b;
-  a.MT8 = ceil_div(a.MT, 8);
+  a.MT8 = ceil_div(ceil_div(a.MT, NWIN), 8);
   a.NT = ceil_div(a.Cout, BN);
   a.nchunks = ceil_div(a.Cin, 64);
   a.R = (BM - 1) * a.stride + (a.K - 1) * a.dil + 1;
   a.Rpad = ceil_div(a.R, 8) * 8;
-  size_t main_bytes = (size_t)2 * a.Rpad * 128 + (size_t)2 * BN * 128;
-  size_t epi_bytes = (size_t)BM * (BN * 2 + 16) + (size_t)(NTHR / (BN / 2)) * BN * 2 * 4;
+  size_t main_bytes = (size_t)2 * NWIN * a.Rpad * 128 + (size_t)2 * BN * 128;
+  size_t epi_bytes = (size_t)NWIN * BM * (BN * 2 + 16) + (size_t)(NTHR / (BN / 2)) * BN * 2 * 4;
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static size_t attr_set = 0;
   if (smem > attr_set) {
-    if (hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN>,
+    if (hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN, NWIN>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return OS2S_ERR_LAUNCH;
     attr_set = 160 * 1024;
   }
   const int grid = a.MT8 * 8 * a.NT;
-  OS2S_LAUNCH((conv1d_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(NTHR), smem,
+  OS2S_LAUNCH((conv1d_igemm_kernel<BM, BN, WM, WN, NWIN>), dim3(grid), dim3(NTHR), smem,
               stream, a);
   return OS2S_OK;
 }
@@ -335,8 +371,7 @@ static int g_conv_variant = 0;
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
 
 extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
-  const int bm = (g_conv_variant == 1) ? 256 : os2s::kConvBM;
-  return B * os2s::ceil_div(Tout, bm);
+  return B * os2s::ceil_div(Tout, os2s::kConvBM);
 }
 
 static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,
@@ -392,6 +427,16 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
   a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
-  if (g_conv_variant == 1) return launch_conv<256, 128, 4, 2>((hipStream_t)stream, a);
-  return launch_conv<kConvBM, kConvBN, 2, 2>((hipStream_t)stream, a);
+  if (g_conv_variant == 2) {
+    // two windows, 4 waves, 128x64 wave tiles (0.75 LDS fragment reads per MFMA)
+    const int rc = launch_conv<kConvBM, kConvBN, 2, 2, 2>((hipStream_t)stream, a);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  }
+  if (g_conv_variant == 1) {
+    // two 128-row windows per 8-wave workgroup; falls back when the double-buffered
+    // windows do not fit in LDS (large stride / very long kernels)
+    const int rc = launch_conv<kConvBM, kConvBN, 4, 2, 2>((hipStream_t)stream, a);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  }
+  return launch_conv<kConvBM, kConvBN, 2, 2, 1>((hipStream_t)stream, a);
 }
