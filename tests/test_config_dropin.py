@@ -1,0 +1,56 @@
+"""CPU: the reference's own example configs load UNCHANGED through the same runpy path
+(utils/utils.py:521) and resolve to the MI355X-native plugin classes; CLI overrides of
+nested leaves work as in the reference (utils.py:535-543)."""
+import os
+
+import pytest
+
+REF = "/root/reference/example_configs"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+
+
+def test_jasper_config_loads_and_maps():
+  from openseq2seq_amd.utils.utils import get_base_config
+  cfg = os.path.join(REF, "speech2text", "jasper10x5_LibriSpeech_nvgrad_masks.py")
+  args, base, model_cls, mod = get_base_config(
+      ["--config_file=" + cfg, "--mode=train", "--benchmark", "--bench_steps=7",
+       "--batch_size_per_gpu=4", "--lr_policy_params/learning_rate=0.01"])
+  import openseq2seq_amd as impl
+  from openseq2seq_amd.models.speech2text import Speech2Text
+  from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
+  from openseq2seq_amd.optimizers.novograd import NovoGrad
+  from openseq2seq_amd.configs.jasper import jasper_convnet_layers
+  assert model_cls is Speech2Text and base["encoder"] is TDNNEncoder and base["optimizer"] is NovoGrad
+  assert base["batch_size_per_gpu"] == 4 and base["lr_policy_params"]["learning_rate"] == 0.01
+  assert args.bench_steps == 7
+  # the programmatic config used by bench.py is the same network
+  assert base["encoder_params"]["convnet_layers"] == jasper_convnet_layers()
+  enc = TDNNEncoder(base["encoder_params"], None, mode="train")      # check_params passes
+  assert enc.params["activation_fn"].__name__ == "relu"
+  assert "tensorflow" not in __import__("sys").modules or \
+      getattr(__import__("sys").modules["tensorflow"], "__version__", "").endswith("shim") is False
+
+
+def test_transformer_big_config_loads_and_maps():
+  from openseq2seq_amd.utils.utils import get_base_config
+  cfg = os.path.join(REF, "text2text", "en-de", "transformer-big.py")
+  _, base, model_cls, mod = get_base_config(["--config_file=" + cfg, "--mode=train"])
+  from openseq2seq_amd.models.text2text import Text2Text
+  from openseq2seq_amd.encoders.transformer_encoder import TransformerEncoder
+  from openseq2seq_amd.decoders.transformer_decoder import TransformerDecoder
+  from openseq2seq_amd.losses.sequence_loss import PaddedCrossEntropyLossWithSmoothing
+  from openseq2seq_amd.optimizers.optimizers import _optimizer_id
+  assert model_cls is Text2Text and base["encoder"] is TransformerEncoder
+  assert base["decoder"] is TransformerDecoder and base["loss"] is PaddedCrossEntropyLossWithSmoothing
+  assert _optimizer_id(base["optimizer"]) == 3                      # LazyAdam -> Adam kernel
+  assert base["lr_policy"].__name__ == "transformer_policy"
+  assert mod["train_params"]["data_layer_params"]["max_length"] == 56
+  p = dict(base["encoder_params"], src_vocab_size=32768)
+  TransformerEncoder(p, None, mode="train")                          # schema accepted
+
+
+def test_unknown_param_is_rejected():
+  from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
+  with pytest.raises(ValueError):
+    TDNNEncoder({"dropout_keep_prob": 0.5, "convnet_layers": [], "activation_fn": None,
+                 "bogus": 1}, None)
