@@ -341,6 +341,34 @@ int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t
                      float grad_scale, const float* grad_scale_dev, float* row_loss,
                      float* loss_mean, uint16_t* dlogits);
 
+/* ------------------------------------------------------------------------
+ * Recurrent layers (one direction of one layer per call; the time loop is inside).
+ *   cell 0: cuDNN GRU  (tf.contrib.cudnn_rnn.CudnnGRU, encoders/ds2_encoder.py:294-328)
+ *   cell 1: cuDNN LSTM (CudnnLSTM, encoders/tacotron2_encoder.py:254-263), gates i,f,g,o
+ *   cell 2: tf.nn.rnn_cell.LSTMCell (encoders/rnn_encoders.py:292-300,
+ *           parts/rnns/utils.py:17-89), gates i,j,f,o with forget_bias
+ * gx [B,T,G*H] bf16 = input projections of all steps (x Wx^T + input bias; computed by
+ * the caller with os2s_conv1d_fwd); wh [G*H,H] bf16; bh [G*H] fp32 recurrent bias or NULL;
+ * lens [B] or NULL: dynamic_rnn semantics (state passes through and outputs are zero
+ * past a sequence end; reverse=1 processes each sequence from ITS last frame);
+ * y [B,T,H] bf16 outputs; gates [B,T,4H] bf16 and c_seq [B,T,H] fp32 are saved for the
+ * backward (may be NULL for inference). Initial states are zero.
+ * Backward: dy [B,T,H] -> dgx (and dgr, the recurrent-side gate gradients, which differ
+ * from dgx only for the GRU candidate gate; pass NULL for LSTMs). The caller derives
+ * dX = dgx Wx, dWx = dgx^T X, dWh = dgr^T H_prev (time-shifted outputs), biases = column
+ * sums with the GEMM/wgrad entry points.
+ * ---------------------------------------------------------------------- */
+size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
+int os2s_rnn_layer_fwd(os2s_stream_t stream, int cell, const uint16_t* gx, const uint16_t* wh,
+                       const float* bh, const int32_t* lens, int B, int T, int H, int reverse,
+                       float forget_bias, uint16_t* y, uint16_t* gates, float* c_seq,
+                       void* workspace, size_t workspace_bytes);
+size_t os2s_rnn_bwd_workspace_bytes(int B, int H);
+int os2s_rnn_layer_bwd(os2s_stream_t stream, int cell, const uint16_t* whT, const int32_t* lens,
+                       const uint16_t* dy, const uint16_t* y, const uint16_t* gates,
+                       const float* c_seq, int B, int T, int H, int reverse, float forget_bias,
+                       uint16_t* dgx, uint16_t* dgr, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -543,3 +543,48 @@ def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=
                _ptr(grad_scale_dev, torch.float32, True), _ptr(row_loss), _ptr(mean),
                _ptr(dl, None, True)), "os2s_xent_smooth")
   return row_loss, mean, dl
+
+
+# --------------------------------------------------------------------------
+# recurrent layers
+# --------------------------------------------------------------------------
+CELL_GRU_CUDNN, CELL_LSTM_CUDNN, CELL_LSTM_TF = 0, 1, 2
+
+
+def rnn_layer_fwd(cell, gx, wh, bh, lens, H, reverse, forget_bias=1.0, save=True):
+  """gx [B,T,G*H] bf16, wh [G*H,H] bf16 -> (y [B,T,H], gates|None, c_seq|None)."""
+  B, T, GH = gx.shape
+  dev = gx.device
+  y = torch.empty((B, T, H), dtype=torch.bfloat16, device=dev)
+  gates = torch.empty((B, T, 4 * H), dtype=torch.bfloat16, device=dev) if save else None
+  c_seq = (torch.empty((B, T, H), dtype=torch.float32, device=dev)
+           if (save and cell != CELL_GRU_CUDNN) else None)
+  n = int(_fn("os2s_rnn_fwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
+  ws = torch.empty((n,), dtype=torch.uint8, device=dev)
+  f = _fn("os2s_rnn_layer_fwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t))
+  _lib.check(f(_stream(), int(cell), _ptr(gx, torch.bfloat16), _ptr(wh, torch.bfloat16),
+               _ptr(bh, torch.float32, True), _ptr(lens, torch.int32, True), B, T, H,
+               int(bool(reverse)), float(forget_bias), _ptr(y), _ptr(gates, None, True),
+               _ptr(c_seq, None, True), _ptr(ws), n), "os2s_rnn_layer_fwd")
+  return y, gates, c_seq
+
+
+def rnn_layer_bwd(cell, whT, lens, dy, y, gates, c_seq, H, reverse, forget_bias=1.0):
+  """-> (dgx [B,T,G*H], dgr [B,T,G*H] (GRU) or dgx again (LSTM))."""
+  B, T, _ = dy.shape
+  G = 3 if cell == CELL_GRU_CUDNN else 4
+  dev = dy.device
+  dgx = torch.empty((B, T, G * H), dtype=torch.bfloat16, device=dev)
+  dgr = torch.empty_like(dgx) if cell == CELL_GRU_CUDNN else None
+  n = int(_fn("os2s_rnn_bwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
+  ws = torch.empty((n,), dtype=torch.uint8, device=dev)
+  f = _fn("os2s_rnn_layer_bwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                 c_void_p, c_size_t))
+  _lib.check(f(_stream(), int(cell), _ptr(whT, torch.bfloat16), _ptr(lens, torch.int32, True),
+               _ptr(dy, torch.bfloat16), _ptr(y, torch.bfloat16), _ptr(gates, torch.bfloat16),
+               _ptr(c_seq, torch.float32, True), B, T, H, int(bool(reverse)), float(forget_bias),
+               _ptr(dgx), _ptr(dgr, None, True), _ptr(ws), n), "os2s_rnn_layer_bwd")
+  return dgx, (dgr if dgr is not None else dgx)

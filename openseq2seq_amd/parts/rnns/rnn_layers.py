@@ -1,0 +1,109 @@
+"""Recurrent layers on the HIP RNN kernels (csrc/rnn.hip): cuDNN-form GRU / LSTM
+(tf.contrib.cudnn_rnn.CudnnGRU/CudnnLSTM, encoders/ds2_encoder.py:294-328,
+encoders/tacotron2_encoder.py:254-263) and tf.nn.rnn_cell.LSTMCell under
+(bidirectional_)dynamic_rnn (encoders/rnn_encoders.py:221-305, parts/rnns/utils.py:17-89).
+
+One `RNNDirection` = one direction of one layer: the input projection of all time steps is
+one MFMA GEMM per input tensor (a bidirectional lower layer is consumed as two tensors, so
+no concat is materialised), the recurrence is os2s_rnn_layer_fwd/bwd, and the weight
+gradients are GEMMs over the saved gate gradients (h_{t-1} enters as a time-shifted
+operand of the wgrad kernel)."""
+import math
+
+import torch
+
+from ... import capi
+from ..cnns.conv_blocks import Act
+from ..transformer.layers import _colsum_into
+
+CELLS = {"gru_cudnn": capi.CELL_GRU_CUDNN, "lstm_cudnn": capi.CELL_LSTM_CUDNN,
+         "lstm_tf": capi.CELL_LSTM_TF}
+
+
+class RNNDirection(object):
+  def __init__(self, store, name, cell, input_sizes, hidden, reverse=False, forget_bias=1.0):
+    self.cell_name, self.cell = cell, CELLS[cell]
+    self.H, self.G = hidden, 3 if cell == "gru_cudnn" else 4
+    self.reverse, self.forget_bias = reverse, (forget_bias if cell == "lstm_tf" else 0.0)
+    GH = self.G * hidden
+    tot_in = sum(input_sizes)
+
+    def init_w(fan_in):
+      def f(shape):   # glorot-uniform over the full [in + H, G*H] matrix (TF LSTMCell default)
+        lim = math.sqrt(6.0 / (fan_in + hidden + GH))
+        return (torch.rand(shape) * 2 - 1) * lim
+      return f
+
+    self.wx = [store.add("%s/wx_%d" % (name, i), (1, GH, n), init_w(tot_in), kind="conv")
+               for i, n in enumerate(input_sizes)]
+    self.wh = store.add(name + "/wh", (1, GH, hidden), init_w(tot_in), kind="conv")
+    self.bx = store.add(name + "/bias", (GH,), torch.zeros(GH), kind="vector")
+    self.bh = store.add(name + "/bias_h", (GH,), torch.zeros(GH), kind="vector") \
+        if cell != "lstm_tf" else None
+
+  def forward(self, xs, lens, tape):
+    """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H]."""
+    B, T, _ = xs[0].data.shape
+    H, G = self.H, self.G
+    GH = G * H
+    gx = None
+    for i, (x, w) in enumerate(zip(xs, self.wx)):
+      gx = capi.gemm(x.data.reshape(B * T, -1), w.w16.view(GH, -1),
+                     bias=self.bx.master if i == 0 else None, out=gx, accumulate=i > 0)
+    gx3 = gx.view(B, T, GH)
+    training = tape is not None
+    y, gates, c_seq = capi.rnn_layer_fwd(self.cell, gx3, self.wh.w16.view(GH, H),
+                                         self.bh.master if self.bh is not None else None, lens, H,
+                                         self.reverse, self.forget_bias, save=training)
+    out = Act(y, lens)
+    if not training:
+      return out
+    layer = self
+
+    def backward():
+      dy = out.grad
+      assert dy is not None
+      dgx, dgr = capi.rnn_layer_bwd(layer.cell, layer.wh.wt16.view(H, GH), lens, dy, y, gates,
+                                    c_seq, H, layer.reverse, layer.forget_bias)
+      d2 = dgx.view(B * T, GH)
+      for x, w in zip(xs, layer.wx):
+        capi.gemm_wgrad(x.data.reshape(B * T, -1), d2, w.grad.view(GH, -1), accumulate=True)
+        if x.requires_grad:
+          g = x.grad_buffer()
+          capi.gemm(d2, w.wt16.view(-1, GH), out=g.view(B * T, -1), accumulate=x.grad_init)
+          x.grad_init = True
+      _colsum_into(d2, layer.bx)
+      if layer.bh is not None:
+        _colsum_into(dgr.view(B * T, GH), layer.bh)
+      # dWh += dgr^T . h_{t-1}: h_{t-1} is y shifted by one step in processing order
+      capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if layer.reverse else 1), in_len=lens,
+                        out=layer.wh.grad, accumulate=True)
+      out.grad = None
+
+    tape.record(backward, [layer.wh, layer.bx] + layer.wx + ([layer.bh] if layer.bh else []))
+    return out
+
+
+class BiRNNStack(object):
+  """num_layers x (forward + backward direction); layer l > 0 consumes both directions of
+  layer l-1 (cuDNN 'bidirectional' stacking / tf.bidirectional_dynamic_rnn per layer)."""
+
+  def __init__(self, store, name, cell, input_size, hidden, num_layers, bidirectional=True,
+               forget_bias=1.0):
+    self.layers = []
+    in_sizes = [input_size]
+    for l in range(num_layers):
+      dirs = [RNNDirection(store, "%s/layer_%d/fw" % (name, l), cell, in_sizes, hidden, False,
+                           forget_bias)]
+      if bidirectional:
+        dirs.append(RNNDirection(store, "%s/layer_%d/bw" % (name, l), cell, in_sizes, hidden,
+                                 True, forget_bias))
+      self.layers.append(dirs)
+      in_sizes = [hidden] * len(dirs)
+    self.out_sizes = in_sizes
+
+  def forward(self, x, lens, tape):
+    xs = [x]
+    for dirs in self.layers:
+      xs = [d.forward(xs, lens, tape) for d in dirs]
+    return xs          # list of Act (1 or 2 directions), each [B,T,H]
