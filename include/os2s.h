@@ -131,6 +131,11 @@ int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* d
                       float* dw, const int32_t* in_len, int B, int Tin, int Cin,
                       int Cout, int K, int stride, int dil, int padL, int Tout,
                       int accumulate);
+/* same with x rows x_row_stride elements apart (x is a channel slice of a wider tensor) */
+int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                         const uint16_t* dy, float* dw, const int32_t* in_len, int B, int Tin,
+                         int Cin, int Cout, int K, int stride, int dil, int padL, int Tout,
+                         int accumulate);
 
 /* ------------------------------------------------------------------------
  * BatchNorm + residual sum + activation + dropout + sequence mask
@@ -351,7 +356,8 @@ int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t
  * the caller with os2s_conv1d_fwd); wh [G*H,H] bf16; bh [G*H] fp32 recurrent bias or NULL;
  * lens [B] or NULL: dynamic_rnn semantics (state passes through and outputs are zero
  * past a sequence end; reverse=1 processes each sequence from ITS last frame);
- * y [B,T,H] bf16 outputs; gates [B,T,4H] bf16 and c_seq [B,T,H] fp32 are saved for the
+ * y: bf16 outputs, row (b,t) at y + (b*T+t)*ldy (ldy >= H: both directions of a layer can
+ * write the two halves of one [B,T,2H] tensor); gates [B,T,4H] bf16 and c_seq [B,T,H] fp32 are saved for the
  * backward (may be NULL for inference). Initial states are zero.
  * Backward: dy [B,T,H] -> dgx (and dgr, the recurrent-side gate gradients, which differ
  * from dgx only for the GRU candidate gate; pass NULL for LSTMs). The caller derives
@@ -361,13 +367,28 @@ int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t
 size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
 int os2s_rnn_layer_fwd(os2s_stream_t stream, int cell, const uint16_t* gx, const uint16_t* wh,
                        const float* bh, const int32_t* lens, int B, int T, int H, int reverse,
-                       float forget_bias, uint16_t* y, uint16_t* gates, float* c_seq,
-                       void* workspace, size_t workspace_bytes);
+                       float forget_bias, uint16_t* y, long long ldy, uint16_t* gates,
+                       float* c_seq, void* workspace, size_t workspace_bytes);
 size_t os2s_rnn_bwd_workspace_bytes(int B, int H);
 int os2s_rnn_layer_bwd(os2s_stream_t stream, int cell, const uint16_t* whT, const int32_t* lens,
-                       const uint16_t* dy, const uint16_t* y, const uint16_t* gates,
-                       const float* c_seq, int B, int T, int H, int reverse, float forget_bias,
-                       uint16_t* dgx, uint16_t* dgr, void* workspace, size_t workspace_bytes);
+                       const uint16_t* dy, long long lddy, const uint16_t* y, long long ldy,
+                       const uint16_t* gates, const float* c_seq, int B, int T, int H, int reverse,
+                       float forget_bias, uint16_t* dgx, uint16_t* dgr, void* workspace,
+                       size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------
+ * conv2d (time x frequency) of DeepSpeech2 (tf.layers.conv2d in conv_bn_actv,
+ * encoders/ds2_encoder.py:252-266) on the 1-D implicit-GEMM kernel: activations are
+ * flattened to [B, T, F*C]; the frequency convolution becomes the banded channel mixing
+ *   wexp[kt][(fo,co)][(fi,ci)] = w[kt][fi - fo*sF + padF][ci][co]
+ * (w: fp32 master kernel [KT,KF,Cin,Cout], TF layout). expand builds wexp (bf16,
+ * [KT][Fo*Cout][Fi*Cin] = the os2s_conv1d_fwd weight layout); reduce folds the gradient
+ * of wexp (fp32, from os2s_conv1d_wgrad) back: dw += ... .
+ * ---------------------------------------------------------------------- */
+int os2s_conv2d_toeplitz_expand(os2s_stream_t stream, const float* w, int KT, int KF, int Cin,
+                                int Cout, int Fi, int Fo, int sF, int padF, uint16_t* wexp);
+int os2s_conv2d_toeplitz_reduce(os2s_stream_t stream, const float* dwexp, int KT, int KF, int Cin,
+                                int Cout, int Fi, int Fo, int sF, int padF, float* dw);
 
 #ifdef __cplusplus
 }

@@ -123,7 +123,8 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
 
 def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
                  out=None, accumulate=False):
-  """x [B,Tin,Cin] bf16, dy [B,Tout,Cout] bf16 -> dW [K,Cout,Cin] fp32."""
+  """x [B,Tin,Cin] bf16 (may be a channel-slice view of a wider tensor),
+  dy [B,Tout,Cout] bf16 -> dW [K,Cout,Cin] fp32."""
   B, Tin, Cin = x.shape
   B2, Tout, Cout = dy.shape
   assert B == B2
@@ -133,13 +134,14 @@ def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
   if out is None:
     assert not accumulate
     out = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
-  f = _fn("os2s_conv1d_wgrad",
-          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+  assert x.stride(2) == 1 and x.stride(0) == Tin * x.stride(1)
+  f = _fn("os2s_conv1d_wgrad_ex",
+          (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
            c_int, c_int, c_int, c_int, c_int, c_int, c_int))
-  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(dy, torch.bfloat16),
+  _lib.check(f(_stream(), c_void_p(x.data_ptr()), x.stride(1), _ptr(dy, torch.bfloat16),
                _ptr(out, torch.float32), _ptr(in_len, torch.int32, True), B, Tin,
                Cin, Cout, K, stride, dil, pad_left, Tout, int(accumulate)),
-             "os2s_conv1d_wgrad")
+             "os2s_conv1d_wgrad_ex")
   return out
 
 
@@ -551,28 +553,33 @@ def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=
 CELL_GRU_CUDNN, CELL_LSTM_CUDNN, CELL_LSTM_TF = 0, 1, 2
 
 
-def rnn_layer_fwd(cell, gx, wh, bh, lens, H, reverse, forget_bias=1.0, save=True):
-  """gx [B,T,G*H] bf16, wh [G*H,H] bf16 -> (y [B,T,H], gates|None, c_seq|None)."""
+def rnn_layer_fwd(cell, gx, wh, bh, lens, H, reverse, forget_bias=1.0, save=True, y=None):
+  """gx [B,T,G*H] bf16, wh [G*H,H] bf16 -> (y, gates|None, c_seq|None). `y` may be a
+  [B,T,H] channel-slice VIEW of a wider [B,T,ld] tensor (both directions share one buffer)."""
   B, T, GH = gx.shape
   dev = gx.device
-  y = torch.empty((B, T, H), dtype=torch.bfloat16, device=dev)
+  if y is None:
+    y = (torch.zeros if lens is not None else torch.empty)((B, T, H), dtype=torch.bfloat16,
+                                                           device=dev)
+  assert y.stride(2) == 1 and y.stride(0) == T * y.stride(1)
   gates = torch.empty((B, T, 4 * H), dtype=torch.bfloat16, device=dev) if save else None
   c_seq = (torch.empty((B, T, H), dtype=torch.float32, device=dev)
            if (save and cell != CELL_GRU_CUDNN) else None)
   n = int(_fn("os2s_rnn_fwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
   ws = torch.empty((n,), dtype=torch.uint8, device=dev)
   f = _fn("os2s_rnn_layer_fwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_float, c_void_p, c_ll, c_void_p, c_void_p,
                                  c_void_p, c_size_t))
   _lib.check(f(_stream(), int(cell), _ptr(gx, torch.bfloat16), _ptr(wh, torch.bfloat16),
                _ptr(bh, torch.float32, True), _ptr(lens, torch.int32, True), B, T, H,
-               int(bool(reverse)), float(forget_bias), _ptr(y), _ptr(gates, None, True),
-               _ptr(c_seq, None, True), _ptr(ws), n), "os2s_rnn_layer_fwd")
+               int(bool(reverse)), float(forget_bias), c_void_p(y.data_ptr()), y.stride(1),
+               _ptr(gates, None, True), _ptr(c_seq, None, True), _ptr(ws), n),
+             "os2s_rnn_layer_fwd")
   return y, gates, c_seq
 
 
 def rnn_layer_bwd(cell, whT, lens, dy, y, gates, c_seq, H, reverse, forget_bias=1.0):
-  """-> (dgx [B,T,G*H], dgr [B,T,G*H] (GRU) or dgx again (LSTM))."""
+  """dy / y may be channel-slice views. -> (dgx [B,T,G*H], dgr (GRU) or dgx again (LSTM))."""
   B, T, _ = dy.shape
   G = 3 if cell == CELL_GRU_CUDNN else 4
   dev = dy.device
@@ -580,11 +587,12 @@ def rnn_layer_bwd(cell, whT, lens, dy, y, gates, c_seq, H, reverse, forget_bias=
   dgr = torch.empty_like(dgx) if cell == CELL_GRU_CUDNN else None
   n = int(_fn("os2s_rnn_bwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
   ws = torch.empty((n,), dtype=torch.uint8, device=dev)
-  f = _fn("os2s_rnn_layer_bwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
-                                 c_void_p, c_size_t))
+  f = _fn("os2s_rnn_layer_bwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
+                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_size_t))
   _lib.check(f(_stream(), int(cell), _ptr(whT, torch.bfloat16), _ptr(lens, torch.int32, True),
-               _ptr(dy, torch.bfloat16), _ptr(y, torch.bfloat16), _ptr(gates, torch.bfloat16),
-               _ptr(c_seq, torch.float32, True), B, T, H, int(bool(reverse)), float(forget_bias),
-               _ptr(dgx), _ptr(dgr, None, True), _ptr(ws), n), "os2s_rnn_layer_bwd")
+               c_void_p(dy.data_ptr()), dy.stride(1), c_void_p(y.data_ptr()), y.stride(1),
+               _ptr(gates, torch.bfloat16), _ptr(c_seq, torch.float32, True), B, T, H,
+               int(bool(reverse)), float(forget_bias), _ptr(dgx), _ptr(dgr, None, True), _ptr(ws),
+               n), "os2s_rnn_layer_bwd")
   return dgx, (dgr if dgr is not None else dgx)

@@ -35,6 +35,7 @@ struct WgradArgs {
   int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
   int NCO, NCI, NTP, NSPLIT, steps_per_split, use_atomic;
   int xrows, xrows_pad;  // X window rows per 64-step (and padded to x4)
+  long long x_ld;        // x row stride in elements (>= Cin; channel slice of a wider tensor)
 };
 
 __device__ __forceinline__ void dma16w(const void* gsrc, char* lds_wave_base) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
     }
     // X window: xrows_pad rows x 16 pieces; LDS row r <-> input time tin0 + r
     char* xd = xbuf0 + buf * xbuf_bytes;
-    const bf16_t* xb = p.x + (long long)b * p.Tin * p.Cin;
+    const bf16_t* xb = p.x + (long long)b * p.Tin * p.x_ld;
     const int tin0 = t0 * p.stride + k0 * p.dil - p.padL;
     const int npieces = p.xrows_pad * 16;
     for (int base = wid * 64; base < npieces; base += 256) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
       const int ch = ci0 + ((u << 1) | (ps & 1)) * 8;
       const int tin = tin0 + row;
       const bool ok = (row < p.xrows) && (tin >= 0) && (tin < len_b) && (ch < p.Cin);
-      const void* src = ok ? (const void*)(xb + (long long)tin * p.Cin + ch)
+      const void* src = ok ? (const void*)(xb + (long long)tin * p.x_ld + ch)
                            : (const void*)(zero + ps * 16);
       dma16w(src, xd + base * 16);
     }
@@ -221,12 +222,26 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
 // it wants to add to, and sets accumulate accordingly:
 //   accumulate = 0 : dW = grad       (kernel never splits the batch)
 //   accumulate = 1 : dW += grad      (atomics; batch may be split for occupancy)
+extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                                    const uint16_t* dy, float* dw, const int32_t* in_len, int B,
+                                    int Tin, int Cin, int Cout, int K, int stride, int dil,
+                                    int padL, int Tout, int accumulate);
+
 extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
                                  const uint16_t* dy, float* dw,
                                  const int32_t* in_len, int B, int Tin, int Cin,
                                  int Cout, int K, int stride, int dil, int padL,
                                  int Tout, int accumulate) {
+  return os2s_conv1d_wgrad_ex(stream, x, Cin, dy, dw, in_len, B, Tin, Cin, Cout, K, stride, dil,
+                              padL, Tout, accumulate);
+}
+
+extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                                    const uint16_t* dy, float* dw, const int32_t* in_len, int B,
+                                    int Tin, int Cin, int Cout, int K, int stride, int dil,
+                                    int padL, int Tout, int accumulate) {
   using namespace os2s;
+  OS2S_REQUIRE(x_row_stride >= Cin && x_row_stride % 8 == 0);
   OS2S_REQUIRE(x && dy && dw);
   OS2S_REQUIRE(B >= 0 && Tin >= 1 && Tout >= 1 && Cin >= 8 && Cout >= 8 && K >= 1);
   OS2S_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && stride >= 1 && dil >= 1);
@@ -235,7 +250,7 @@ extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.in_len = in_len;
   a.B = B; a.Tin = Tin; a.Tout = Tout; a.Cin = Cin; a.Cout = Cout; a.K = K;
-  a.stride = stride; a.dil = dil; a.padL = padL;
+  a.stride = stride; a.dil = dil; a.padL = padL; a.x_ld = x_row_stride;
   a.NCO = ceil_div(Cout, 128);
   a.NCI = ceil_div(Cin, 128);
   a.NTP = ceil_div(K, TAPS);

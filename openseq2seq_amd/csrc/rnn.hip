@@ -42,7 +42,8 @@ struct RnnStepArgs {
   bf16_t* h_next16;        // [B, H]
   float* h32;              // [B, H] fp32 state (in/out)
   float* c32;              // [B, H] (LSTM)
-  bf16_t* y;               // [B, T, H] outputs of this direction
+  bf16_t* y;               // outputs of this direction: row (b,t) at y + (b*T+t)*ldy
+  long long ldy;
   bf16_t* gates;           // [B, T, Gs*H] saved activations (Gs = 4)
   float* c_seq;            // [B, T, H] saved cell states (LSTM)
 };
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void rnn_step_fwd_kernel(RnnStepArgs p) {
       u32x2 yo;
       yo[0] = pack2bf(hnew[0], hnew[1]);
       yo[1] = pack2bf(hnew[2], hnew[3]);
-      *reinterpret_cast<u32x2*>(p.y + ((long long)b * p.T + t) * H + j) = yo;
+      *reinterpret_cast<u32x2*>(p.y + ((long long)b * p.T + t) * p.ldy + j) = yo;
     }
     f32x4 hw = {hnew[0], hnew[1], hnew[2], hnew[3]};
     *reinterpret_cast<f32x4*>(p.h32 + (long long)b * H + j) = hw;
@@ -176,7 +177,8 @@ struct RnnBwdArgs {
   int cell, B, T, H, G, reverse, step, first;
   const bf16_t* whT;        // [H, G*H]  transposed recurrent weights
   const int32_t* lens;
-  const bf16_t* dy;         // [B, T, H]
+  const bf16_t* dy;         // row (b,t) at dy + (b*T+t)*lddy
+  long long lddy, ldy;
   const bf16_t* gates;      // [B, T, 4*H] saved activations
   const float* c_seq;       // [B, T, H] (LSTM)
   const bf16_t* y;          // [B, T, H] forward outputs (GRU needs h_{t-1})
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
     }
     f32x4 carry = {0.f, 0.f, 0.f, 0.f};
     if (!p.first) carry = *reinterpret_cast<const f32x4*>(p.dh_carry + (long long)b * H + j);
-    const u32x2 dyv = *reinterpret_cast<const u32x2*>(p.dy + ((long long)b * p.T + t) * H + j);
+    const u32x2 dyv = *reinterpret_cast<const u32x2*>(p.dy + ((long long)b * p.T + t) * p.lddy + j);
     float dh[4] = {bflo(dyv[0]) + acc[4 * q] + carry[0], bfhi(dyv[0]) + acc[4 * q + 1] + carry[1],
                    bflo(dyv[1]) + acc[4 * q + 2] + carry[2], bfhi(dyv[1]) + acc[4 * q + 3] + carry[3]};
     float sv[4][4];
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
     if (p.cell == kGruCudnn) {
       float hprev[4] = {0.f, 0.f, 0.f, 0.f};
       if (has_prev) {
-        const u32x2 hv = *reinterpret_cast<const u32x2*>(p.y + ((long long)b * p.T + tp) * H + j);
+        const u32x2 hv = *reinterpret_cast<const u32x2*>(p.y + ((long long)b * p.T + tp) * p.ldy + j);
         hprev[0] = bflo(hv[0]); hprev[1] = bfhi(hv[0]); hprev[2] = bflo(hv[1]); hprev[3] = bfhi(hv[1]);
       }
 #pragma unroll
@@ -325,7 +327,7 @@ extern "C" size_t os2s_rnn_fwd_workspace_bytes(int B, int H) {
 extern "C" int os2s_rnn_layer_fwd(os2s_stream_t stream_, int cell, const uint16_t* gx,
                                   const uint16_t* wh, const float* bh, const int32_t* lens, int B,
                                   int T, int H, int reverse, float forget_bias, uint16_t* y,
-                                  uint16_t* gates, float* c_seq, void* workspace,
+                                  long long ldy, uint16_t* gates, float* c_seq, void* workspace,
                                   size_t workspace_bytes) {
   OS2S_REQUIRE(gx && wh && y && workspace && B >= 1 && T >= 1 && H >= 8 && H % 8 == 0);
   OS2S_REQUIRE(cell >= 0 && cell <= 2);
@@ -338,11 +340,15 @@ extern "C" int os2s_rnn_layer_fwd(os2s_stream_t stream_, int cell, const uint16_
   float* c32 = (float*)ws;
   if (hipMemsetAsync(workspace, 0, (size_t)B * H * 12, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
   // outputs past the sequence ends are zero
-  if (hipMemsetAsync(y, 0, (size_t)B * T * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+  OS2S_REQUIRE(ldy >= H && ldy % 4 == 0);
+  if (lens) {   // outputs past the sequence ends are zero (rows are ldy apart)
+    if (hipMemset2DAsync(y, (size_t)ldy * 2, 0, (size_t)H * 2, (size_t)B * T, stream) != hipSuccess)
+      return OS2S_ERR_LAUNCH;
+  }
   RnnStepArgs a;
   a.cell = cell; a.B = B; a.T = T; a.H = H; a.G = rnn_gates(cell); a.reverse = reverse;
   a.forget_bias = forget_bias; a.gx = gx; a.wh = wh; a.bh = bh; a.lens = lens; a.h32 = h32;
-  a.c32 = c32; a.y = y; a.gates = gates; a.c_seq = c_seq;
+  a.c32 = c32; a.y = y; a.ldy = ldy; a.gates = gates; a.c_seq = c_seq;
   dim3 grid(ceil_div(H, 32), ceil_div(B, 32));
   for (int s = 0; s < T; ++s) {
     a.step = s;
@@ -360,8 +366,9 @@ extern "C" size_t os2s_rnn_bwd_workspace_bytes(int B, int H) {
 }
 
 extern "C" int os2s_rnn_layer_bwd(os2s_stream_t stream_, int cell, const uint16_t* whT,
-                                  const int32_t* lens, const uint16_t* dy, const uint16_t* y,
-                                  const uint16_t* gates, const float* c_seq, int B, int T, int H,
+                                  const int32_t* lens, const uint16_t* dy, long long lddy,
+                                  const uint16_t* y, long long ldy, const uint16_t* gates,
+                                  const float* c_seq, int B, int T, int H,
                                   int reverse, float forget_bias, uint16_t* dgx, uint16_t* dgr,
                                   void* workspace, size_t workspace_bytes) {
   OS2S_REQUIRE(whT && dy && y && gates && dgx && workspace && B >= 1 && T >= 1 && H % 8 == 0);
@@ -383,7 +390,8 @@ extern "C" int os2s_rnn_layer_bwd(os2s_stream_t stream_, int cell, const uint16_
     return OS2S_ERR_LAUNCH;
   RnnBwdArgs a;
   a.cell = cell; a.B = B; a.T = T; a.H = H; a.G = G; a.reverse = reverse; a.whT = whT;
-  a.lens = lens; a.dy = dy; a.gates = gates; a.c_seq = c_seq; a.y = y; a.dgx = dgx; a.dgr = dgr;
+  a.lens = lens; a.dy = dy; a.lddy = lddy; a.ldy = ldy; a.gates = gates; a.c_seq = c_seq; a.y = y;
+  a.dgx = dgx; a.dgr = dgr;
   a.dh_carry = dhc; a.dc_carry = dcc; a.forget_bias = forget_bias;
   dim3 grid(ceil_div(H, 32), ceil_div(B, 32));
   for (int s = T - 1; s >= 0; --s) {

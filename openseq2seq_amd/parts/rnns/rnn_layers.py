@@ -41,8 +41,11 @@ class RNNDirection(object):
     self.bh = store.add(name + "/bias_h", (GH,), torch.zeros(GH), kind="vector") \
         if cell != "lstm_tf" else None
 
-  def forward(self, xs, lens, tape):
-    """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H]."""
+  def forward(self, xs, lens, tape, y_view=None, dy_view_fn=None):
+    """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H].
+    y_view: optional [B,T,H] channel-slice view to write the outputs into (the two
+    directions of a layer share one [B,T,2H] tensor); dy_view_fn() then returns the matching
+    slice of the shared gradient."""
     B, T, _ = xs[0].data.shape
     H, G = self.H, self.G
     GH = G * H
@@ -54,14 +57,14 @@ class RNNDirection(object):
     training = tape is not None
     y, gates, c_seq = capi.rnn_layer_fwd(self.cell, gx3, self.wh.w16.view(GH, H),
                                          self.bh.master if self.bh is not None else None, lens, H,
-                                         self.reverse, self.forget_bias, save=training)
+                                         self.reverse, self.forget_bias, save=training, y=y_view)
     out = Act(y, lens)
     if not training:
       return out
     layer = self
 
     def backward():
-      dy = out.grad
+      dy = dy_view_fn() if dy_view_fn is not None else out.grad
       assert dy is not None
       dgx, dgr = capi.rnn_layer_bwd(layer.cell, layer.wh.wt16.view(H, GH), lens, dy, y, gates,
                                     c_seq, H, layer.reverse, layer.forget_bias)
@@ -85,25 +88,53 @@ class RNNDirection(object):
 
 
 class BiRNNStack(object):
-  """num_layers x (forward + backward direction); layer l > 0 consumes both directions of
-  layer l-1 (cuDNN 'bidirectional' stacking / tf.bidirectional_dynamic_rnn per layer)."""
+  """num_layers x (forward + backward direction). The two directions of a layer write the two
+  halves of ONE [B,T,2H] tensor (no concat), which the next layer / the following dense
+  layer consumes as a single input (cuDNN 'bidirectional' stacking;
+  tf.bidirectional_dynamic_rnn + tf.concat, ds2_encoder.py:294-380). Optional dropout between
+  layers (cuDNN RNN `dropout`)."""
 
   def __init__(self, store, name, cell, input_size, hidden, num_layers, bidirectional=True,
                forget_bias=1.0):
     self.layers = []
-    in_sizes = [input_size]
+    self.H, self.ndir = hidden, 2 if bidirectional else 1
+    in_size = input_size
     for l in range(num_layers):
-      dirs = [RNNDirection(store, "%s/layer_%d/fw" % (name, l), cell, in_sizes, hidden, False,
+      dirs = [RNNDirection(store, "%s/layer_%d/fw" % (name, l), cell, [in_size], hidden, False,
                            forget_bias)]
       if bidirectional:
-        dirs.append(RNNDirection(store, "%s/layer_%d/bw" % (name, l), cell, in_sizes, hidden,
+        dirs.append(RNNDirection(store, "%s/layer_%d/bw" % (name, l), cell, [in_size], hidden,
                                  True, forget_bias))
       self.layers.append(dirs)
-      in_sizes = [hidden] * len(dirs)
-    self.out_sizes = in_sizes
+      in_size = hidden * self.ndir
+    self.output_dim = in_size
 
-  def forward(self, x, lens, tape):
-    xs = [x]
-    for dirs in self.layers:
-      xs = [d.forward(xs, lens, tape) for d in dirs]
-    return xs          # list of Act (1 or 2 directions), each [B,T,H]
+  def forward(self, x, lens, tape, keep_prob=1.0, seeds=None):
+    """x: Act [B,T,In] -> Act [B,T,ndir*H]."""
+    H = self.H
+    cur = x
+    for li, dirs in enumerate(self.layers):
+      B, T, _ = cur.data.shape
+      ybuf = (torch.zeros if lens is not None else torch.empty)(
+          (B, T, H * self.ndir), dtype=torch.bfloat16, device=cur.data.device)
+      out = Act(ybuf, lens)
+      for d, layer in enumerate(dirs):
+        layer.forward([cur], lens, tape, y_view=ybuf[:, :, d * H:(d + 1) * H],
+                      dy_view_fn=(lambda o=out, d=d: o.grad[:, :, d * H:(d + 1) * H]))
+      cur = out
+      if keep_prob < 1.0 and li < len(self.layers) - 1:
+        seed = seeds.next() if seeds is not None else li + 1
+        dropped = Act(capi.dropout_bwd(cur.data.view(-1, cur.data.shape[-1]), keep_prob,
+                                       seed=seed).view_as(cur.data), lens)
+        if tape is not None:
+          src = cur
+
+          def backward(dropped=dropped, src=src, seed=seed):
+            g = capi.dropout_bwd(dropped.grad.view(-1, dropped.grad.shape[-1]), keep_prob,
+                                 seed=seed).view_as(dropped.grad)
+            src.grad, src.grad_init = g, True
+            dropped.grad = None
+
+          tape.record(backward)
+        cur = dropped
+    return cur
