@@ -596,3 +596,21 @@ def rnn_layer_bwd(cell, whT, lens, dy, y, gates, c_seq, H, reverse, forget_bias=
                int(bool(reverse)), float(forget_bias), _ptr(dgx), _ptr(dgr, None, True), _ptr(ws),
                n), "os2s_rnn_layer_bwd")
   return dgx, (dgr if dgr is not None else dgx)
+
+
+# --------------------------------------------------------------------------
+# conv2d via banded channel mixing (DS2)
+# --------------------------------------------------------------------------
+def conv2d_toeplitz_expand(w, Fi, Fo, sF, padF, out):
+  KT, KF, Cin, Cout = w.shape
+  f = _fn("os2s_conv2d_toeplitz_expand", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,))
+  _lib.check(f(_stream(), _ptr(w, torch.float32), KT, KF, Cin, Cout, Fi, Fo, sF, padF,
+               _ptr(out, torch.bfloat16)), "os2s_conv2d_toeplitz_expand")
+  return out
+
+
+def conv2d_toeplitz_reduce(dwexp, Fi, Fo, sF, padF, dw):
+  KT, KF, Cin, Cout = dw.shape
+  f = _fn("os2s_conv2d_toeplitz_reduce", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,))
+  _lib.check(f(_stream(), _ptr(dwexp, torch.float32), KT, KF, Cin, Cout, Fi, Fo, sF, padF,
+               _ptr(dw, torch.float32)), "os2s_conv2d_toeplitz_reduce")

@@ -1,0 +1,96 @@
+"""GPU parity of the DeepSpeech2 encoder path (scaled down: F=32, two conv2d+BN+ReLU
+layers with the reference's strides [2,2]/[1,2], 2-layer bidirectional cuDNN-form GRU,
+dense+ReLU) + FC-CTC: outputs, loss and all parameter gradients vs the CPU fp32 oracle.
+Dropout off for parity. Tolerances as in test_jasper_e2e_gpu (bf16 storage)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONV = [{"kernel_size": [11, 41], "stride": [2, 2], "num_channels": 32, "padding": "SAME"},
+        {"kernel_size": [11, 21], "stride": [1, 2], "num_channels": 32, "padding": "SAME"}]
+
+
+def test_ds2_small_fwd_bwd(cuda):
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.ds2_encoder import DeepSpeech2Encoder
+  from openseq2seq_amd.decoders.fc_decoders import FullyConnectedCTCDecoder
+  from openseq2seq_amd.losses.ctc_loss import CTCLoss
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+  from oracle import ds2 as ods, tdnn as otdnn
+  torch.manual_seed(0)
+  Fr, H, NH = 32, 64, 128
+  store = FlatParams(cuda)
+  enc = DeepSpeech2Encoder({"conv_layers": CONV, "num_rnn_layers": 2, "rnn_cell_dim": H,
+                            "use_cudnn_rnn": True, "rnn_type": "cudnn_gru",
+                            "rnn_unidirectional": False, "row_conv": False, "n_hidden": NH,
+                            "dropout_keep_prob": 1.0, "activation_fn": "relu",
+                            "data_format": "channels_first", "dtype": "mixed"}, None,
+                           mode="train").build(store, Fr)
+  dec = FullyConnectedCTCDecoder({"tgt_vocab_size": 29, "dtype": "mixed"}, None,
+                                 mode="train").build(store, NH)
+  lossf = CTCLoss({"dtype": "mixed"}, None)
+  store.finalize()
+  g = torch.Generator().manual_seed(1)
+  B, T = 3, 60
+  x = torch.randn(B, T, Fr, generator=g).to(torch.bfloat16)
+  lens = torch.tensor([60, 44, 31], dtype=torch.int32)
+  labels = torch.randint(0, 28, (B, 8), generator=g).to(torch.int32)
+  label_len = torch.tensor([8, 5, 3], dtype=torch.int32)
+  tape = Tape()
+  store.zero_grads()
+  e = enc.encode({"source_tensors": [x.to(cuda), lens.to(cuda)], "tape": tape, "seed": 1})
+  d = dec.decode({"encoder_output": e, "tape": tape})
+  L = lossf.compute_loss({"decoder_output": d, "target_tensors": [labels.to(cuda), label_len.to(cuda)]})
+  tape.backward()
+  torch.cuda.synchronize()
+  assert e["src_length"].cpu().tolist() == [30, 22, 16]
+  # ---- oracle -------------------------------------------------------------------
+  W, leaves = {}, {}
+  for i in (1, 2):
+    n = "ForwardPass/ds2_encoder/conv%d" % i
+    k = store.by_name(n + "/kernel")
+    # the device multiplies with the bf16 expansion of the fp32 master
+    W["conv%d/kernel" % i] = k.master.cpu().to(torch.bfloat16).float().requires_grad_(True)
+    W["conv%d/bn/gamma" % i] = store.by_name(n + "/bn/gamma").master.cpu().clone().requires_grad_(True)
+    W["conv%d/bn/beta" % i] = store.by_name(n + "/bn/beta").master.cpu().clone().requires_grad_(True)
+    leaves[n + "/kernel"] = W["conv%d/kernel" % i]
+    leaves[n + "/bn/gamma"] = W["conv%d/bn/gamma" % i]
+    leaves[n + "/bn/beta"] = W["conv%d/bn/beta" % i]
+  width = enc.convs[-1].Fo * 32
+  gru = torch.nn.GRU(width, H, num_layers=2, batch_first=True, bidirectional=True)
+  with torch.no_grad():
+    for l, dirs in enumerate(enc.rnn.layers):
+      for dd, layer in enumerate(dirs):
+        sfx = "_l%d%s" % (l, "_reverse" if dd else "")
+        getattr(gru, "weight_ih" + sfx).copy_(layer.wx[0].w16.float().cpu()[0])
+        getattr(gru, "weight_hh" + sfx).copy_(layer.wh.w16.float().cpu()[0])
+        getattr(gru, "bias_ih" + sfx).copy_(layer.bx.master.cpu())
+        getattr(gru, "bias_hh" + sfx).copy_(layer.bh.master.cpu())
+        leaves[layer.wx[0].name] = getattr(gru, "weight_ih" + sfx)
+        leaves[layer.wh.name] = getattr(gru, "weight_hh" + sfx)
+  fcw = enc.fc.kernel.w16.float().cpu()[0].t().contiguous().requires_grad_(True)
+  fcb = enc.fc.bias.master.cpu().clone().requires_grad_(True)
+  leaves[enc.fc.kernel.name], leaves[enc.fc.bias.name] = fcw, fcb
+  dw = dec.kernel.w16.float().cpu()[0, :29, :].t().contiguous().requires_grad_(True)
+  db = dec.bias.master.cpu()[:29].clone().requires_grad_(True)
+  out = ods.ds2_encode(x.float(), CONV, W, gru, fcw, fcb)
+  logits, loss = otdnn.fc_ctc(out, e["src_length"].cpu(), dw, db, labels, label_len)
+  loss.backward()
+  lg = d["logits"].cpu()
+  rel = float((lg - logits.detach()).norm() / logits.detach().norm())
+  assert rel < 3e-2, rel
+  torch.testing.assert_close(L.cpu()[0], loss.detach(), rtol=2e-2, atol=2e-2)
+  worst = (1.0, "")
+  for name, leaf in leaves.items():
+    got = store.by_name(name).grad.cpu()
+    ref = leaf.grad
+    if name == enc.fc.kernel.name:
+      ref = ref.t()[None]
+    elif got.dim() == 3:
+      ref = ref[None]
+    cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
+    relerr = float((got - ref).norm() / (ref.norm() + 1e-12))
+    worst = min(worst, (cos, name))
+    assert cos > 0.98 and relerr < 0.2, (name, cos, relerr)
+  print("worst cosine", worst, "logits rel", rel)
