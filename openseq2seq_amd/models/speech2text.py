@@ -69,8 +69,12 @@ class Speech2Text(EncoderDecoderModel):
     return batch['source_tensors'][1].sum()
 
   def _extra_state_tensors(self):
+    """Non-trainable state broadcast with the variables (BatchNorm moving statistics)."""
     out = []
-    for L in self._encoder._layers:
+    enc = self._encoder
+    for L in getattr(enc, "_layers", None) or []:
       for br in [L['main']] + L['res']:
         out += [br.moving_mean, br.moving_var]
+    for c in getattr(enc, "convs", None) or []:
+      out += [c.moving_mean, c.moving_var]
     return out
