@@ -108,7 +108,9 @@ int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
                        int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
                        int accumulate, int act, float keep_prob, unsigned long long seed,
                        const uint16_t* residual);
-/* tuning hook: selects the tile variant (0 = 128x128/4 waves, 1 = 256x128/8 waves) */
+/* tuning hook: 3 (default) = 128x128 tile / 4 waves, X window single-buffered when K >= 8
+ * (3 workgroups per CU); 0 = always double-buffered; 1 = two 128-row windows / 8 waves;
+ * 2 = two windows / 4 waves with 128x64 wave tiles */
 void os2s_conv1d_set_variant(int v);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,

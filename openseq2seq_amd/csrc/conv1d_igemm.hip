@@ -61,8 +61,8 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
 // BM = rows of ONE time window (one batch item); a workgroup processes NWIN consecutive
 // windows (possibly of different batch items) against the same weight stream, so the
 // M extent of a block is NWIN*BM while the tile granularity in time stays BM.
-template <int BM, int BN, int WM, int WN, int NWIN>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_igemm_kernel(
+template <int BM, int BN, int WM, int WN, int NWIN, bool XSINGLE = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1) void conv1d_igemm_kernel(
     ConvArgs p) {
   constexpr int NW = WM * WN, NTHR = NW * 64;
   constexpr int WTM = (BM * NWIN) / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
   const int win_bytes = p.Rpad * 128;
   const int xbuf_bytes = NWIN * win_bytes;
   char* const xbuf0 = smem;
-  char* const wbuf0 = smem + 2 * xbuf_bytes;
+  char* const wbuf0 = smem + (XSINGLE ? 1 : 2) * xbuf_bytes;
   const char* const zero = reinterpret_cast<const char*>(g_zero_page);
 
   auto stage_x = [&](int c, char* dst) {
@@ -159,15 +159,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
   int c = 0, k = 0;
   const int l31 = lane & 31, lhi = lane >> 5;
   for (int step = 0; step < nsteps; ++step) {
+    if (XSINGLE && k == 0 && step > 0) {
+      // single X buffer: everyone is done with the previous chunk's window -> refill it
+      __syncthreads();
+      stage_x(c, xbuf0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int kn = k + 1, cn = c;
     if (kn == p.K) { kn = 0; cn = c + 1; }
     if (step + 1 < nsteps) {
-      if (kn == 0) stage_x(cn, xbuf0 + (cn & 1) * xbuf_bytes);
+      if (!XSINGLE && kn == 0) stage_x(cn, xbuf0 + (cn & 1) * xbuf_bytes);
       stage_w(cn, kn, wbuf0 + ((step + 1) & 1) * (BN * 128));
     }
-    const char* const xs = xbuf0 + (c & 1) * xbuf_bytes + my_win * win_bytes;
+    const char* const xs = xbuf0 + (XSINGLE ? 0 : (c & 1) * xbuf_bytes) + my_win * win_bytes;
     const char* const ws = wbuf0 + (step & 1) * (BN * 128);
     const int rbase = (row_in_win + l31) * p.stride + k * p.dil;
 #pragma unroll
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? 2 : 1) void conv1d_ig
 
 constexpr int kConvBM = 128, kConvBN = 128;
 
-template <int BM, int BN, int WM, int WN, int NWIN>
+template <int BM, int BN, int WM, int WN, int NWIN, bool XSINGLE = false>
 static int launch_conv(hipStream_t stream, ConvArgs& a) {
   constexpr int NTHR = WM * WN * 64;
   a.mtiles_per_b = ceil_div(a.Tout, BM);
@@ -346,27 +351,27 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
   a.nchunks = ceil_div(a.Cin, 64);
   a.R = (BM - 1) * a.stride + (a.K - 1) * a.dil + 1;
   a.Rpad = ceil_div(a.R, 8) * 8;
-  size_t main_bytes = (size_t)2 * NWIN * a.Rpad * 128 + (size_t)2 * BN * 128;
+  size_t main_bytes = (size_t)(XSINGLE ? 1 : 2) * NWIN * a.Rpad * 128 + (size_t)2 * BN * 128;
   size_t epi_bytes = (size_t)NWIN * BM * (BN * 2 + 16) + (size_t)(NTHR / (BN / 2)) * BN * 2 * 4;
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static size_t attr_set = 0;
   if (smem > attr_set) {
-    if (hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN, NWIN>,
+    if (hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN, NWIN, XSINGLE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return OS2S_ERR_LAUNCH;
     attr_set = 160 * 1024;
   }
   const int grid = a.MT8 * 8 * a.NT;
-  OS2S_LAUNCH((conv1d_igemm_kernel<BM, BN, WM, WN, NWIN>), dim3(grid), dim3(NTHR), smem,
+  OS2S_LAUNCH((conv1d_igemm_kernel<BM, BN, WM, WN, NWIN, XSINGLE>), dim3(grid), dim3(NTHR), smem,
               stream, a);
   return OS2S_OK;
 }
 
 }  // namespace os2s
 
-static int g_conv_variant = 0;
+static int g_conv_variant = 3;   // default: single-buffered X window (3 workgroups/CU) for K >= 8
 // tuning hook (not part of the stable ABI surface used by the host layer)
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
 
@@ -427,6 +432,10 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
   a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
+  if (g_conv_variant == 3 && K >= 8) {
+    // single-buffered X window: 3 workgroups per CU
+    return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>((hipStream_t)stream, a);
+  }
   if (g_conv_variant == 2) {
     // two windows, 4 waves, 128x64 wave tiles (0.75 LDS fragment reads per MFMA)
     const int rc = launch_conv<kConvBM, kConvBN, 2, 2, 2>((hipStream_t)stream, a);
