@@ -49,13 +49,18 @@ __device__ __forceinline__ bf16x4 lds_tr(const char* p) {
       (__attribute__((address_space(3))) bf16x4*)p);
 }
 
-template <int TAPS>
-__global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
+// COT = output-channel extent of the block tile (128: 4 waves, 2 workgroups/CU;
+// 256: 8 waves, 1 workgroup/CU, 0.74x the L2->LDS bytes per FLOP — the 128 tile runs at the
+// 64 B/clk/CU L2 port limit on the big layers).
+template <int TAPS, int COT>
+__global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_kernel(WgradArgs p) {
   constexpr int BT = 64;  // reduction rows per step
+  constexpr int NW = COT / 32, NTHR = NW * 64, NSUB = COT / 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;  // wave tile 64 (co) x 64 (ci)
+  const int ysub = wm >> 1, wmi = wm & 1;  // 128-channel dY sub-image, 64-row half inside it
 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, loc = bid >> 3;
@@ -65,11 +70,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
   if (unit >= nunits) return;
   const int split = unit / (p.NCO * p.NCI);
   const int rem = unit - split * (p.NCO * p.NCI);
-  const int co0 = (rem / p.NCI) * 128, ci0 = (rem % p.NCI) * 128;
+  const int co0 = (rem / p.NCI) * COT, ci0 = (rem % p.NCI) * 128;
   const int k0 = tp * TAPS;
   const int ntaps = min(TAPS, p.K - k0);
 
-  const int ybuf_bytes = BT * 256;
+  const int ybuf_bytes = NSUB * BT * 256;
   const int xbuf_bytes = p.xrows_pad * 256;
   char* const ybuf0 = smem;
   char* const xbuf0 = smem + 2 * ybuf_bytes;
@@ -96,12 +101,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
     char* yd = ybuf0 + buf * ybuf_bytes;
     const bf16_t* dyb = p.dy + (long long)b * p.Tout * p.Cout;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int base = (it * 4 + wid) * 64;
+    for (int it = 0; it < (NSUB * 16) / NW; ++it) {
+      const int base = (it * NW + wid) * 64;
       const int q = base + lane;
-      const int row = q >> 4, ps = q & 15;
+      const int sub = q >> 10, row = (q & 1023) >> 4, ps = q & 15;
       const int u = (ps >> 1) ^ ((row & 3) << 1);
-      const int ch = co0 + ((u << 1) | (ps & 1)) * 8;
+      const int ch = co0 + sub * 128 + ((u << 1) | (ps & 1)) * 8;
       const int t = t0 + row;
       const bool ok = (t < p.Tout) && (ch < p.Cout);
       const void* src = ok ? (const void*)(dyb + (long long)t * p.Cout + ch)
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
     const bf16_t* xb = p.x + (long long)b * p.Tin * p.x_ld;
     const int tin0 = t0 * p.stride + k0 * p.dil - p.padL;
     const int npieces = p.xrows_pad * 16;
-    for (int base = wid * 64; base < npieces; base += 256) {
+    for (int base = wid * 64; base < npieces; base += NTHR) {
       const int q = base + lane;
       const int row = q >> 4, ps = q & 15;
       const int u = (ps >> 1) ^ ((row & 3) << 1);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (step + 1 < nsteps) stage(step + 1, (step + 1) & 1);
-    const char* const ys = ybuf0 + (step & 1) * ybuf_bytes;
+    const char* const ys = ybuf0 + (step & 1) * ybuf_bytes + ysub * (BT * 256);
     const char* const xs = xbuf0 + (step & 1) * xbuf_bytes;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_wgrad_kernel(WgradArgs p) {
       bf16x8 af[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int u = ((wm * 64 + i * 32) >> 4) + g16;  // logical 32-B unit (16 channels)
+        const int u = ((wmi * 64 + i * 32) >> 4) + g16;  // logical 32-B unit (16 channels)
         const int r0 = kk * 16 + lhi * 8 + rsub;
         const int r1 = r0 + 4;
         const bf16x4 lo = lds_tr(ys + r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub);
@@ -247,18 +252,21 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   OS2S_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && stride >= 1 && dil >= 1);
   if (B == 0) return OS2S_OK;
   constexpr int TAPS = 2;
+  // the 256-wide tile pays off once there are enough 256-channel tiles to fill the chip
+  const bool wide = (Cout % 256 == 0) && (K >= 8) && (Cout >= 512);
+  const int COT = wide ? 256 : 128;
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.in_len = in_len;
   a.B = B; a.Tin = Tin; a.Tout = Tout; a.Cin = Cin; a.Cout = Cout; a.K = K;
   a.stride = stride; a.dil = dil; a.padL = padL; a.x_ld = x_row_stride;
-  a.NCO = ceil_div(Cout, 128);
+  a.NCO = ceil_div(Cout, COT);
   a.NCI = ceil_div(Cin, 128);
   a.NTP = ceil_div(K, TAPS);
   const int base_blocks = a.NCO * a.NCI * a.NTP;
   const int total_steps = B * ceil_div(Tout, 64);
   int nsplit = 1;
   if (accumulate) {
-    const int target = 1024;  // ~2 workgroups per CU x 2 waves of blocks
+    const int target = wide ? 512 : 1024;  // ~2 waves of workgroups
     nsplit = ceil_div(target, base_blocks);
     const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;   // >= 8 steps per block
     if (nsplit > max_split) nsplit = max_split;
@@ -269,19 +277,23 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   a.use_atomic = accumulate ? 1 : 0;
   a.xrows = 63 * stride + (TAPS - 1) * dil + 1;
   a.xrows_pad = ceil_div(a.xrows, 4) * 4;
-  const size_t smem = (size_t)2 * 64 * 256 + (size_t)2 * a.xrows_pad * 256;
+  const size_t smem = (size_t)2 * 64 * 2 * COT + (size_t)2 * a.xrows_pad * 256;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<TAPS>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<TAPS, 128>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<TAPS, 256>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OS2S_ERR_LAUNCH;
     attr_set = true;
   }
   const int nunits = a.NCO * a.NCI * a.NSPLIT;
   const int grid = ceil_div(nunits, 8) * 8 * a.NTP;
-  OS2S_LAUNCH((conv1d_wgrad_kernel<TAPS>), dim3(grid), dim3(256), smem,
-              (hipStream_t)stream, a);
+  if (wide) {
+    OS2S_LAUNCH((conv1d_wgrad_kernel<TAPS, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+  } else {
+    OS2S_LAUNCH((conv1d_wgrad_kernel<TAPS, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  }
   return OS2S_OK;
 }

@@ -115,6 +115,8 @@ WG_CASES = [
     (2, 130, 384, 128, 1, 1, 1),
     (1, 64, 72, 200, 5, 1, 1),
     (4, 100, 1024, 32, 1, 1, 1),   # FC weight-grad shape (V padded to 32)
+    (2, 150, 192, 512, 11, 1, 1),  # 256-wide output-channel tile variant
+    (3, 100, 256, 768, 9, 1, 2),
 ]
 
 
