@@ -377,6 +377,24 @@ int os2s_rnn_layer_bwd(os2s_stream_t stream, int cell, const uint16_t* whT, cons
                        const uint16_t* gates, const float* c_seq, int B, int T, int H, int reverse,
                        float forget_bias, uint16_t* dgx, uint16_t* dgr, void* workspace,
                        size_t workspace_bytes);
+/* Both directions of a bidirectional layer (tf.nn.bidirectional_dynamic_rnn /
+ * cuDNN direction="bidirectional", encoders/ds2_encoder.py:304-321) in ONE launch per time
+ * step: ndir = 1 or 2 descriptors with the same meaning as the arguments above; the
+ * workspace is ndir x os2s_rnn_{fwd,bwd}_workspace_bytes. */
+typedef struct os2s_rnn_dir_fwd {
+  const uint16_t* gx; const uint16_t* wh; const float* bh;
+  uint16_t* y; long long ldy; uint16_t* gates; float* c_seq; int reverse;
+} os2s_rnn_dir_fwd_t;
+typedef struct os2s_rnn_dir_bwd {
+  const uint16_t* whT; const uint16_t* dy; long long lddy; const uint16_t* y; long long ldy;
+  const uint16_t* gates; const float* c_seq; uint16_t* dgx; uint16_t* dgr; int reverse;
+} os2s_rnn_dir_bwd_t;
+int os2s_rnn_layer_fwd_multi(os2s_stream_t stream, int cell, int ndir,
+                             const os2s_rnn_dir_fwd_t* dirs, const int32_t* lens, int B, int T,
+                             int H, float forget_bias, void* workspace, size_t workspace_bytes);
+int os2s_rnn_layer_bwd_multi(os2s_stream_t stream, int cell, int ndir,
+                             const os2s_rnn_dir_bwd_t* dirs, const int32_t* lens, int B, int T,
+                             int H, float forget_bias, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------
  * conv2d (time x frequency) of DeepSpeech2 (tf.layers.conv2d in conv_bn_actv,

@@ -553,49 +553,95 @@ def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=
 CELL_GRU_CUDNN, CELL_LSTM_CUDNN, CELL_LSTM_TF = 0, 1, 2
 
 
-def rnn_layer_fwd(cell, gx, wh, bh, lens, H, reverse, forget_bias=1.0, save=True, y=None):
-  """gx [B,T,G*H] bf16, wh [G*H,H] bf16 -> (y, gates|None, c_seq|None). `y` may be a
-  [B,T,H] channel-slice VIEW of a wider [B,T,ld] tensor (both directions share one buffer)."""
-  B, T, GH = gx.shape
-  dev = gx.device
-  if y is None:
-    y = (torch.zeros if lens is not None else torch.empty)((B, T, H), dtype=torch.bfloat16,
-                                                           device=dev)
-  assert y.stride(2) == 1 and y.stride(0) == T * y.stride(1)
-  gates = torch.empty((B, T, 4 * H), dtype=torch.bfloat16, device=dev) if save else None
-  c_seq = (torch.empty((B, T, H), dtype=torch.float32, device=dev)
-           if (save and cell != CELL_GRU_CUDNN) else None)
-  n = int(_fn("os2s_rnn_fwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
+class _RnnDirFwd(_lib.ctypes.Structure):
+  _fields_ = [("gx", c_void_p), ("wh", c_void_p), ("bh", c_void_p), ("y", c_void_p),
+              ("ldy", c_ll), ("gates", c_void_p), ("c_seq", c_void_p), ("reverse", c_int)]
+
+
+class _RnnDirBwd(_lib.ctypes.Structure):
+  _fields_ = [("whT", c_void_p), ("dy", c_void_p), ("lddy", c_ll), ("y", c_void_p), ("ldy", c_ll),
+              ("gates", c_void_p), ("c_seq", c_void_p), ("dgx", c_void_p), ("dgr", c_void_p),
+              ("reverse", c_int)]
+
+
+def _addr(t):
+  return None if t is None else t.data_ptr()
+
+
+def rnn_layer_fwd_multi(cell, dirs, lens, H, forget_bias=1.0, save=True):
+  """dirs: list (1 or 2) of dict(gx [B,T,G*H] bf16, wh [G*H,H] bf16, bh fp32|None, y view|None,
+  reverse). All directions advance in one launch per time step. Returns a list of
+  (y, gates|None, c_seq|None). A `y` may be a [B,T,H] channel-slice VIEW of a wider
+  [B,T,ld] tensor (both directions of a layer share one buffer)."""
+  B, T, GH = dirs[0]["gx"].shape
+  dev = dirs[0]["gx"].device
+  nd = len(dirs)
+  arr = (_RnnDirFwd * nd)()
+  outs = []
+  for i, d in enumerate(dirs):
+    gx = d["gx"]
+    assert gx.dtype == torch.bfloat16 and gx.is_contiguous() and gx.shape == (B, T, GH)
+    y = d.get("y")
+    if y is None:
+      y = (torch.zeros if lens is not None else torch.empty)((B, T, H), dtype=torch.bfloat16,
+                                                             device=dev)
+    assert y.stride(2) == 1 and y.stride(0) == T * y.stride(1)
+    gates = torch.empty((B, T, 4 * H), dtype=torch.bfloat16, device=dev) if save else None
+    c_seq = (torch.empty((B, T, H), dtype=torch.float32, device=dev)
+             if (save and cell != CELL_GRU_CUDNN) else None)
+    arr[i].gx, arr[i].wh = _ptr(gx, torch.bfloat16), _ptr(d["wh"], torch.bfloat16)
+    arr[i].bh = _ptr(d.get("bh"), torch.float32, True)
+    arr[i].y, arr[i].ldy = y.data_ptr(), y.stride(1)
+    arr[i].gates, arr[i].c_seq = _addr(gates), _addr(c_seq)
+    arr[i].reverse = int(bool(d["reverse"]))
+    outs.append((y, gates, c_seq))
+  n = nd * int(_fn("os2s_rnn_fwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
   ws = torch.empty((n,), dtype=torch.uint8, device=dev)
-  f = _fn("os2s_rnn_layer_fwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_int, c_int, c_int, c_float, c_void_p, c_ll, c_void_p, c_void_p,
-                                 c_void_p, c_size_t))
-  _lib.check(f(_stream(), int(cell), _ptr(gx, torch.bfloat16), _ptr(wh, torch.bfloat16),
-               _ptr(bh, torch.float32, True), _ptr(lens, torch.int32, True), B, T, H,
-               int(bool(reverse)), float(forget_bias), c_void_p(y.data_ptr()), y.stride(1),
-               _ptr(gates, None, True), _ptr(c_seq, None, True), _ptr(ws), n),
-             "os2s_rnn_layer_fwd")
-  return y, gates, c_seq
+  f = _fn("os2s_rnn_layer_fwd_multi", (c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_float, c_void_p, c_size_t))
+  _lib.check(f(_stream(), int(cell), nd, _lib.ctypes.byref(arr), _ptr(lens, torch.int32, True), B, T,
+               H, float(forget_bias), _ptr(ws), n), "os2s_rnn_layer_fwd_multi")
+  return outs
+
+
+def rnn_layer_fwd(cell, gx, wh, bh, lens, H, reverse, forget_bias=1.0, save=True, y=None):
+  return rnn_layer_fwd_multi(cell, [dict(gx=gx, wh=wh, bh=bh, y=y, reverse=reverse)], lens, H,
+                             forget_bias, save)[0]
+
+
+def rnn_layer_bwd_multi(cell, dirs, lens, H, forget_bias=1.0):
+  """dirs: list of dict(whT, dy, y, gates, c_seq, reverse); dy / y may be channel-slice views.
+  Returns a list of (dgx [B,T,G*H], dgr (GRU) or dgx again (LSTM))."""
+  B, T, _ = dirs[0]["dy"].shape
+  G = 3 if cell == CELL_GRU_CUDNN else 4
+  dev = dirs[0]["dy"].device
+  nd = len(dirs)
+  arr = (_RnnDirBwd * nd)()
+  outs = []
+  for i, d in enumerate(dirs):
+    dy, y = d["dy"], d["y"]
+    dgx = torch.empty((B, T, G * H), dtype=torch.bfloat16, device=dev)
+    dgr = torch.empty_like(dgx) if cell == CELL_GRU_CUDNN else None
+    arr[i].whT = _ptr(d["whT"], torch.bfloat16)
+    arr[i].dy, arr[i].lddy = dy.data_ptr(), dy.stride(1)
+    arr[i].y, arr[i].ldy = y.data_ptr(), y.stride(1)
+    arr[i].gates = _ptr(d["gates"], torch.bfloat16)
+    arr[i].c_seq = _ptr(d.get("c_seq"), torch.float32, True)
+    arr[i].dgx, arr[i].dgr = dgx.data_ptr(), _addr(dgr)
+    arr[i].reverse = int(bool(d["reverse"]))
+    outs.append((dgx, dgr if dgr is not None else dgx))
+  n = nd * int(_fn("os2s_rnn_bwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
+  ws = torch.empty((n,), dtype=torch.uint8, device=dev)
+  f = _fn("os2s_rnn_layer_bwd_multi", (c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_float, c_void_p, c_size_t))
+  _lib.check(f(_stream(), int(cell), nd, _lib.ctypes.byref(arr), _ptr(lens, torch.int32, True), B, T,
+               H, float(forget_bias), _ptr(ws), n), "os2s_rnn_layer_bwd_multi")
+  return outs
 
 
 def rnn_layer_bwd(cell, whT, lens, dy, y, gates, c_seq, H, reverse, forget_bias=1.0):
-  """dy / y may be channel-slice views. -> (dgx [B,T,G*H], dgr (GRU) or dgx again (LSTM))."""
-  B, T, _ = dy.shape
-  G = 3 if cell == CELL_GRU_CUDNN else 4
-  dev = dy.device
-  dgx = torch.empty((B, T, G * H), dtype=torch.bfloat16, device=dev)
-  dgr = torch.empty_like(dgx) if cell == CELL_GRU_CUDNN else None
-  n = int(_fn("os2s_rnn_bwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
-  ws = torch.empty((n,), dtype=torch.uint8, device=dev)
-  f = _fn("os2s_rnn_layer_bwd", (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
-                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
-                                 c_void_p, c_void_p, c_size_t))
-  _lib.check(f(_stream(), int(cell), _ptr(whT, torch.bfloat16), _ptr(lens, torch.int32, True),
-               c_void_p(dy.data_ptr()), dy.stride(1), c_void_p(y.data_ptr()), y.stride(1),
-               _ptr(gates, torch.bfloat16), _ptr(c_seq, torch.float32, True), B, T, H,
-               int(bool(reverse)), float(forget_bias), _ptr(dgx), _ptr(dgr, None, True), _ptr(ws),
-               n), "os2s_rnn_layer_bwd")
-  return dgx, (dgr if dgr is not None else dgx)
+  return rnn_layer_bwd_multi(cell, [dict(whT=whT, dy=dy, y=y, gates=gates, c_seq=c_seq,
+                                         reverse=reverse)], lens, H, forget_bias)[0]
 
 
 # --------------------------------------------------------------------------

@@ -19,25 +19,25 @@
 // into MFMA A fragments, no LDS), multiplies with the previous hidden state (bf16 copy) on
 // the matrix cores in the swapped orientation (rows = hidden units), so all G gates of a
 // (unit, sample) pair land in the same lane/register and the cell non-linearity, the state
-// update and every store are lane-local. The backward step fuses "dh_{t-1} = dgates_t . Wh"
+// update and every store are lane-local. The step is latency-bound (B is 16..128), so the
+// reduction dimension is split over the waves of the workgroup with batched loads
+// (rnn_tile.hpp), and the two directions of a bidirectional layer run in ONE launch
+// (blockIdx.z = direction). The backward step fuses "dh_{t-1} = dgates_t . Wh"
 // with the gate derivatives of step t-1 the same way, using the transposed weight copy.
 // dWh, dWx, dX and the bias gradients are large GEMMs over the saved gate gradients, done
 // by the caller with the conv/wgrad kernels (h_{t-1} as a time-shifted operand).
 #include "os2s_common.hpp"
+#include "rnn_tile.hpp"
 
 namespace os2s {
 
 enum { kGruCudnn = 0, kLstmCudnn = 1, kLstmTf = 2 };
+constexpr int kRnnWaves = 8;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-
-struct RnnStepArgs {
-  int cell, B, T, H, G, reverse, step;
-  float forget_bias;
+struct RnnDirFwd {
   const bf16_t* gx;        // [B, T, G*H]  input projections (+ input bias)
   const bf16_t* wh;        // [G*H, H]
   const float* bh;         // [G*H] recurrent bias or null
-  const int32_t* lens;     // [B] or null
   const bf16_t* h_prev16;  // [B, H]
   bf16_t* h_next16;        // [B, H]
   float* h32;              // [B, H] fp32 state (in/out)
@@ -46,6 +46,13 @@ struct RnnStepArgs {
   long long ldy;
   bf16_t* gates;           // [B, T, Gs*H] saved activations (Gs = 4)
   float* c_seq;            // [B, T, H] saved cell states (LSTM)
+  int reverse;
+};
+struct RnnStepArgs {
+  int cell, B, T, H, G, step;
+  float forget_bias;
+  const int32_t* lens;     // [B] or null
+  RnnDirFwd d[2];          // blockIdx.z selects the direction
 };
 
 // t index processed by sample b at loop step s, or -1 if the sample is past its length
@@ -55,46 +62,30 @@ __device__ __forceinline__ int time_of(int s, int len, int reverse) {
 }
 
 template <int G>
-__global__ __launch_bounds__(64) void rnn_step_fwd_kernel(RnnStepArgs p) {
-  const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+__global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_fwd_kernel(RnnStepArgs pa) {
+  __shared__ float red[kRnnWaves * 16 * 64];
+  const RnnDirFwd& p = pa.d[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  const int H = p.H;
-  f32x16 acc[G];
+  const int H = pa.H;
+  f32x16 accw[G];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-  const int jrow = min(j0 + l31, H - 1);
-  const int brow = b0 + l31;
-  const bf16_t* hp = p.h_prev16 + (long long)min(brow, p.B - 1) * H;
-  for (int k = 0; k < H; k += 16) {
-    const int ko = k + lhi * 8;
-    bf16x8 bfrag;
-    if (brow < p.B && ko < H) bfrag = *reinterpret_cast<const bf16x8*>(hp + ko);
-    else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bfrag[e] = (__bf16)0.f;
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      bf16x8 a;
-      if (ko < H) a = *reinterpret_cast<const bf16x8*>(p.wh + ((long long)g * H + jrow) * H + ko);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = (__bf16)0.f;
-      }
-      acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[g], 0, 0, 0);
-    }
-  }
+    for (int e = 0; e < 16; ++e) accw[g][e] = 0.f;
+  tile_gemm_splitk<G, kRnnWaves, 2>(p.wh, H, H, j0, H, p.h_prev16, H, b0, pa.B, H, accw);
+  float acc[G][4];
+  tile_reduce_quarters<G, kRnnWaves>(accw, red, acc);
+  if (wave >= 4) return;
   // lane: column b = b0 + l31; rows j = j0 + 4*lhi + (r&3) + 8*(r>>2)
   const int b = b0 + l31;
-  if (b >= p.B) return;
-  const int len = p.lens ? min(max(p.lens[b], 0), p.T) : p.T;
-  const int t = time_of(p.step, len, p.reverse);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  if (b >= pa.B) return;
+  const int len = pa.lens ? min(max(pa.lens[b], 0), pa.T) : pa.T;
+  const int t = time_of(pa.step, len, p.reverse);
+  {
+    const int q = wave;   // this wave's quarter of the tile rows
     const int j = j0 + 8 * q + 4 * lhi;
-    if (j >= H) continue;
+    if (j >= H) return;
     float hprev[4], hnew[4];
     const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h32 + (long long)b * H + j);
 #pragma unroll
@@ -108,15 +99,15 @@ __global__ __launch_bounds__(64) void rnn_step_fwd_kernel(RnnStepArgs p) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const u32x2 gxv = *reinterpret_cast<const u32x2*>(
-            p.gx + ((long long)b * p.T + t) * (G * H) + (long long)g * H + j);
+            p.gx + ((long long)b * pa.T + t) * (G * H) + (long long)g * H + j);
         pre[g][0] = bflo(gxv[0]); pre[g][1] = bfhi(gxv[0]);
         pre[g][2] = bflo(gxv[1]); pre[g][3] = bfhi(gxv[1]);
       }
       float sv[4][4];   // saved activations
-      if (p.cell == kGruCudnn) {
+      if (pa.cell == kGruCudnn) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int r = 4 * q + e;
+          const int r = e;
           const float br = p.bh ? p.bh[j + e] : 0.f, bz = p.bh ? p.bh[H + j + e] : 0.f;
           const float bn = p.bh ? p.bh[2 * H + j + e] : 0.f;
           const float rg = sigmoidf_(pre[0][e] + acc[0][r] + br);
@@ -131,19 +122,19 @@ __global__ __launch_bounds__(64) void rnn_step_fwd_kernel(RnnStepArgs p) {
         f32x4 cn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int r = 4 * q + e;
+          const int r = e;
           float a0 = pre[0][e] + acc[0][r], a1 = pre[1][e] + acc[1][r];
           float a2 = pre[2][e] + acc[2][r], a3 = pre[3][e] + acc[3][r];
           if (p.bh) { a0 += p.bh[j + e]; a1 += p.bh[H + j + e]; a2 += p.bh[2 * H + j + e]; a3 += p.bh[3 * H + j + e]; }
           float ig, fg, gg, og;
-          if (p.cell == kLstmCudnn) { ig = sigmoidf_(a0); fg = sigmoidf_(a1); gg = tanhf(a2); og = sigmoidf_(a3); }
-          else { ig = sigmoidf_(a0); gg = tanhf(a1); fg = sigmoidf_(a2 + p.forget_bias); og = sigmoidf_(a3); }
+          if (pa.cell == kLstmCudnn) { ig = sigmoidf_(a0); fg = sigmoidf_(a1); gg = tanhf(a2); og = sigmoidf_(a3); }
+          else { ig = sigmoidf_(a0); gg = tanhf(a1); fg = sigmoidf_(a2 + pa.forget_bias); og = sigmoidf_(a3); }
           cn[e] = cv[e] * fg + ig * gg;
           hnew[e] = tanhf(cn[e]) * og;
           sv[0][e] = ig; sv[1][e] = fg; sv[2][e] = gg; sv[3][e] = og;
         }
         *reinterpret_cast<f32x4*>(p.c32 + (long long)b * H + j) = cn;
-        if (p.c_seq) *reinterpret_cast<f32x4*>(p.c_seq + ((long long)b * p.T + t) * H + j) = cn;
+        if (p.c_seq) *reinterpret_cast<f32x4*>(p.c_seq + ((long long)b * pa.T + t) * H + j) = cn;
       }
       if (p.gates) {
 #pragma unroll
@@ -151,13 +142,13 @@ __global__ __launch_bounds__(64) void rnn_step_fwd_kernel(RnnStepArgs p) {
           u32x2 pk;
           pk[0] = pack2bf(sv[g][0], sv[g][1]);
           pk[1] = pack2bf(sv[g][2], sv[g][3]);
-          *reinterpret_cast<u32x2*>(p.gates + ((long long)b * p.T + t) * (4 * H) + (long long)g * H + j) = pk;
+          *reinterpret_cast<u32x2*>(p.gates + ((long long)b * pa.T + t) * (4 * H) + (long long)g * H + j) = pk;
         }
       }
       u32x2 yo;
       yo[0] = pack2bf(hnew[0], hnew[1]);
       yo[1] = pack2bf(hnew[2], hnew[3]);
-      *reinterpret_cast<u32x2*>(p.y + ((long long)b * p.T + t) * p.ldy + j) = yo;
+      *reinterpret_cast<u32x2*>(p.y + ((long long)b * pa.T + t) * p.ldy + j) = yo;
     }
     f32x4 hw = {hnew[0], hnew[1], hnew[2], hnew[3]};
     *reinterpret_cast<f32x4*>(p.h32 + (long long)b * H + j) = hw;
@@ -173,10 +164,8 @@ __global__ __launch_bounds__(64) void rnn_step_fwd_kernel(RnnStepArgs p) {
 // derivatives of step s, written to dgx[b, t, :] and to the compact [B, G*H] buffer the
 // next (earlier) step multiplies with Wh^T.
 // ---------------------------------------------------------------------------
-struct RnnBwdArgs {
-  int cell, B, T, H, G, reverse, step, first;
+struct RnnDirBwd {
   const bf16_t* whT;        // [H, G*H]  transposed recurrent weights
-  const int32_t* lens;
   const bf16_t* dy;         // row (b,t) at dy + (b*T+t)*lddy
   long long lddy, ldy;
   const bf16_t* gates;      // [B, T, 4*H] saved activations
@@ -188,41 +177,38 @@ struct RnnBwdArgs {
   bf16_t* dgr;              // [B, T, G*H]  same on the recurrent side (GRU: differs for n) or null
   float* dh_carry;          // [B, H] fp32: direct (non-matmul) part of dh flowing to s-1
   float* dc_carry;          // [B, H] fp32 (LSTM)
+  int reverse;
+};
+struct RnnBwdArgs {
+  int cell, B, T, H, G, step, first;
   float forget_bias;
+  const int32_t* lens;
+  RnnDirBwd d[2];
 };
 
 template <int G>
-__global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
-  const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+__global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_bwd_kernel(RnnBwdArgs pa) {
+  __shared__ float red[kRnnWaves * 16 * 64];
+  const RnnDirBwd& p = pa.d[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  const int H = p.H, GH = G * p.H;
-  f32x16 acc;
+  const int H = pa.H, GH = G * pa.H;
+  float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+  if (!pa.first) {
+    f32x16 accw[1];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  if (!p.first) {
-    const int jrow = min(j0 + l31, H - 1);
-    const int brow = b0 + l31;
-    const bf16_t* dgp = p.dg_next + (long long)min(brow, p.B - 1) * GH;
-    for (int k = 0; k < GH; k += 16) {
-      const int ko = k + lhi * 8;
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(p.whT + (long long)jrow * GH + ko);
-      bf16x8 bfrag;
-      if (brow < p.B) bfrag = *reinterpret_cast<const bf16x8*>(dgp + ko);
-      else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bfrag[e] = (__bf16)0.f;
-      }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc, 0, 0, 0);
-    }
+    for (int e = 0; e < 16; ++e) accw[0][e] = 0.f;
+    tile_gemm_splitk<1, kRnnWaves, 4>(p.whT, GH, 0, j0, H, p.dg_next, GH, b0, pa.B, GH, accw);
+    tile_reduce_quarters<1, kRnnWaves>(accw, red, acc);
   }
+  if (wave >= 4) return;
   const int b = b0 + l31;
-  if (b >= p.B) return;
-  const int len = p.lens ? min(max(p.lens[b], 0), p.T) : p.T;
-  const int t = time_of(p.step, len, p.reverse);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int j = j0 + 8 * q + 4 * lhi;
-    if (j >= H) continue;
+  if (b >= pa.B) return;
+  const int len = pa.lens ? min(max(pa.lens[b], 0), pa.T) : pa.T;
+  const int t = time_of(pa.step, len, p.reverse);
+  {
+    const int j = j0 + 8 * wave + 4 * lhi;
+    if (j >= H) return;
     bf16_t* dgc = p.dg_cur + (long long)b * GH;
     if (t < 0) {
       // inactive sample: its dg_next is zero (nothing was active later either) and the
@@ -232,29 +218,29 @@ __global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
         u32x2 z = {0u, 0u};
         *reinterpret_cast<u32x2*>(dgc + (long long)g * H + j) = z;
       }
-      continue;
+      return;
     }
     f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-    if (!p.first) carry = *reinterpret_cast<const f32x4*>(p.dh_carry + (long long)b * H + j);
-    const u32x2 dyv = *reinterpret_cast<const u32x2*>(p.dy + ((long long)b * p.T + t) * p.lddy + j);
-    float dh[4] = {bflo(dyv[0]) + acc[4 * q] + carry[0], bfhi(dyv[0]) + acc[4 * q + 1] + carry[1],
-                   bflo(dyv[1]) + acc[4 * q + 2] + carry[2], bfhi(dyv[1]) + acc[4 * q + 3] + carry[3]};
+    if (!pa.first) carry = *reinterpret_cast<const f32x4*>(p.dh_carry + (long long)b * H + j);
+    const u32x2 dyv = *reinterpret_cast<const u32x2*>(p.dy + ((long long)b * pa.T + t) * p.lddy + j);
+    float dh[4] = {bflo(dyv[0]) + acc[0][0] + carry[0], bfhi(dyv[0]) + acc[0][1] + carry[1],
+                   bflo(dyv[1]) + acc[0][2] + carry[2], bfhi(dyv[1]) + acc[0][3] + carry[3]};
     float sv[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x2 v = *reinterpret_cast<const u32x2*>(p.gates + ((long long)b * p.T + t) * (4 * H) +
+      const u32x2 v = *reinterpret_cast<const u32x2*>(p.gates + ((long long)b * pa.T + t) * (4 * H) +
                                                       (long long)g * H + j);
       sv[g][0] = bflo(v[0]); sv[g][1] = bfhi(v[0]); sv[g][2] = bflo(v[1]); sv[g][3] = bfhi(v[1]);
     }
     // previous time index in processing order (s-1): t-1 forward, t+1 reverse
     const int tp = p.reverse ? t + 1 : t - 1;
-    const bool has_prev = p.step > 0;
+    const bool has_prev = pa.step > 0;
     float dpre[G][4];
     f32x4 ncarry;
-    if (p.cell == kGruCudnn) {
+    if (pa.cell == kGruCudnn) {
       float hprev[4] = {0.f, 0.f, 0.f, 0.f};
       if (has_prev) {
-        const u32x2 hv = *reinterpret_cast<const u32x2*>(p.y + ((long long)b * p.T + tp) * p.ldy + j);
+        const u32x2 hv = *reinterpret_cast<const u32x2*>(p.y + ((long long)b * pa.T + tp) * p.ldy + j);
         hprev[0] = bflo(hv[0]); hprev[1] = bfhi(hv[0]); hprev[2] = bflo(hv[1]); hprev[3] = bfhi(hv[1]);
       }
 #pragma unroll
@@ -272,10 +258,10 @@ __global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
       }
     } else {
       f32x4 dcarry = {0.f, 0.f, 0.f, 0.f};
-      if (!p.first) dcarry = *reinterpret_cast<const f32x4*>(p.dc_carry + (long long)b * H + j);
-      const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * p.T + t) * H + j);
+      if (!pa.first) dcarry = *reinterpret_cast<const f32x4*>(p.dc_carry + (long long)b * H + j);
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * pa.T + t) * H + j);
       f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
-      if (has_prev) cprev = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * p.T + tp) * H + j);
+      if (has_prev) cprev = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * pa.T + tp) * H + j);
       f32x4 ndc;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -287,7 +273,7 @@ __global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
         const float dfx = dc * cprev[e] * fg * (1.f - fg);
         const float dgx_ = dc * ig * (1.f - gg * gg);
         ndc[e] = dc * fg;
-        if (p.cell == kLstmCudnn) { dpre[0][e] = dix; dpre[1][e] = dfx; dpre[2][e] = dgx_; dpre[3 % G][e] = dox; }
+        if (pa.cell == kLstmCudnn) { dpre[0][e] = dix; dpre[1][e] = dfx; dpre[2][e] = dgx_; dpre[3 % G][e] = dox; }
         else { dpre[0][e] = dix; dpre[1][e] = dgx_; dpre[2][e] = dfx; dpre[3 % G][e] = dox; }
         ncarry[e] = 0.f;
       }
@@ -300,15 +286,15 @@ __global__ __launch_bounds__(64) void rnn_step_bwd_kernel(RnnBwdArgs p) {
       u32x2 pk;
       pk[0] = pack2bf(dpre[g][0], dpre[g][1]);
       pk[1] = pack2bf(dpre[g][2], dpre[g][3]);
-      *reinterpret_cast<u32x2*>(p.dgx + ((long long)b * p.T + t) * GH + (long long)g * H + j) = pk;
+      *reinterpret_cast<u32x2*>(p.dgx + ((long long)b * pa.T + t) * GH + (long long)g * H + j) = pk;
       u32x2 rk = pk;
-      if (p.cell == kGruCudnn && g == 2) {   // the recurrent n-gate term sees r * dnpre
+      if (pa.cell == kGruCudnn && g == 2) {   // the recurrent n-gate term sees r * dnpre
         rk[0] = pack2bf(sv[3][0], sv[3][1]);
         rk[1] = pack2bf(sv[3][2], sv[3][3]);
       }
       *reinterpret_cast<u32x2*>(dgc + (long long)g * H + j) = rk;
       if (p.dgr)
-        *reinterpret_cast<u32x2*>(p.dgr + ((long long)b * p.T + t) * GH + (long long)g * H + j) = rk;
+        *reinterpret_cast<u32x2*>(p.dgr + ((long long)b * pa.T + t) * GH + (long long)g * H + j) = rk;
     }
   }
 }
@@ -319,9 +305,54 @@ using namespace os2s;
 
 static int rnn_gates(int cell) { return cell == kGruCudnn ? 3 : 4; }
 
-// workspace: h16[2][B,H] bf16 + h32[B,H] + c32[B,H] fp32
+// workspace per direction: h16[2][B,H] bf16 + h32[B,H] + c32[B,H] fp32
 extern "C" size_t os2s_rnn_fwd_workspace_bytes(int B, int H) {
   return (size_t)B * H * (2 * 2 + 4 + 4) + 256;
+}
+
+extern "C" int os2s_rnn_layer_fwd_multi(os2s_stream_t stream_, int cell, int ndir,
+                                        const os2s_rnn_dir_fwd_t* dirs, const int32_t* lens,
+                                        int B, int T, int H, float forget_bias, void* workspace,
+                                        size_t workspace_bytes) {
+  OS2S_REQUIRE(dirs && workspace && (ndir == 1 || ndir == 2));
+  OS2S_REQUIRE(B >= 1 && T >= 1 && H >= 8 && H % 8 == 0 && cell >= 0 && cell <= 2);
+  const size_t per_dir = os2s_rnn_fwd_workspace_bytes(B, H);
+  if (workspace_bytes < per_dir * ndir) return OS2S_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(workspace, 0, per_dir * ndir, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+  RnnStepArgs a;
+  a.cell = cell; a.B = B; a.T = T; a.H = H; a.G = rnn_gates(cell);
+  a.forget_bias = forget_bias; a.lens = lens;
+  bf16_t* h16[2][2];
+  for (int d = 0; d < ndir; ++d) {
+    const os2s_rnn_dir_fwd_t& s = dirs[d];
+    OS2S_REQUIRE(s.gx && s.wh && s.y && s.ldy >= H && s.ldy % 4 == 0);
+    char* ws = (char*)workspace + per_dir * d;
+    h16[d][0] = (bf16_t*)ws; ws += (size_t)B * H * 2;
+    h16[d][1] = (bf16_t*)ws; ws += (size_t)B * H * 2;
+    RnnDirFwd& k = a.d[d];
+    k.gx = (const bf16_t*)s.gx; k.wh = (const bf16_t*)s.wh; k.bh = s.bh;
+    k.h32 = (float*)ws; ws += (size_t)B * H * 4;
+    k.c32 = (float*)ws;
+    k.y = (bf16_t*)s.y; k.ldy = s.ldy; k.gates = (bf16_t*)s.gates; k.c_seq = s.c_seq;
+    k.reverse = s.reverse;
+    if (lens) {   // outputs past the sequence ends are zero (rows are ldy apart)
+      if (hipMemset2DAsync(s.y, (size_t)s.ldy * 2, 0, (size_t)H * 2, (size_t)B * T, stream) != hipSuccess)
+        return OS2S_ERR_LAUNCH;
+    }
+  }
+  if (ndir == 1) a.d[1] = a.d[0];
+  dim3 grid(ceil_div(H, 32), ceil_div(B, 32), ndir);
+  for (int s = 0; s < T; ++s) {
+    a.step = s;
+    for (int d = 0; d < ndir; ++d) {
+      a.d[d].h_prev16 = h16[d][s & 1];
+      a.d[d].h_next16 = h16[d][(s & 1) ^ 1];
+    }
+    if (a.G == 3) { OS2S_LAUNCH(rnn_step_fwd_kernel<3>, grid, dim3(64 * kRnnWaves), 0, stream, a); }
+    else { OS2S_LAUNCH(rnn_step_fwd_kernel<4>, grid, dim3(64 * kRnnWaves), 0, stream, a); }
+  }
+  return OS2S_OK;
 }
 
 extern "C" int os2s_rnn_layer_fwd(os2s_stream_t stream_, int cell, const uint16_t* gx,
@@ -329,40 +360,65 @@ extern "C" int os2s_rnn_layer_fwd(os2s_stream_t stream_, int cell, const uint16_
                                   int T, int H, int reverse, float forget_bias, uint16_t* y,
                                   long long ldy, uint16_t* gates, float* c_seq, void* workspace,
                                   size_t workspace_bytes) {
-  OS2S_REQUIRE(gx && wh && y && workspace && B >= 1 && T >= 1 && H >= 8 && H % 8 == 0);
-  OS2S_REQUIRE(cell >= 0 && cell <= 2);
-  if (workspace_bytes < os2s_rnn_fwd_workspace_bytes(B, H)) return OS2S_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  char* ws = (char*)workspace;
-  bf16_t* h16a = (bf16_t*)ws; ws += (size_t)B * H * 2;
-  bf16_t* h16b = (bf16_t*)ws; ws += (size_t)B * H * 2;
-  float* h32 = (float*)ws; ws += (size_t)B * H * 4;
-  float* c32 = (float*)ws;
-  if (hipMemsetAsync(workspace, 0, (size_t)B * H * 12, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
-  // outputs past the sequence ends are zero
-  OS2S_REQUIRE(ldy >= H && ldy % 4 == 0);
-  if (lens) {   // outputs past the sequence ends are zero (rows are ldy apart)
-    if (hipMemset2DAsync(y, (size_t)ldy * 2, 0, (size_t)H * 2, (size_t)B * T, stream) != hipSuccess)
-      return OS2S_ERR_LAUNCH;
-  }
-  RnnStepArgs a;
-  a.cell = cell; a.B = B; a.T = T; a.H = H; a.G = rnn_gates(cell); a.reverse = reverse;
-  a.forget_bias = forget_bias; a.gx = gx; a.wh = wh; a.bh = bh; a.lens = lens; a.h32 = h32;
-  a.c32 = c32; a.y = y; a.ldy = ldy; a.gates = gates; a.c_seq = c_seq;
-  dim3 grid(ceil_div(H, 32), ceil_div(B, 32));
-  for (int s = 0; s < T; ++s) {
-    a.step = s;
-    a.h_prev16 = (s & 1) ? h16b : h16a;
-    a.h_next16 = (s & 1) ? h16a : h16b;
-    if (a.G == 3) { OS2S_LAUNCH(rnn_step_fwd_kernel<3>, grid, dim3(64), 0, stream, a); }
-    else { OS2S_LAUNCH(rnn_step_fwd_kernel<4>, grid, dim3(64), 0, stream, a); }
-  }
-  return OS2S_OK;
+  os2s_rnn_dir_fwd_t d;
+  d.gx = gx; d.wh = wh; d.bh = bh; d.y = y; d.ldy = ldy; d.gates = gates; d.c_seq = c_seq;
+  d.reverse = reverse;
+  return os2s_rnn_layer_fwd_multi(stream_, cell, 1, &d, lens, B, T, H, forget_bias, workspace,
+                                  workspace_bytes);
 }
 
-// workspace: dg[2][B,G*H] bf16 + dh_carry[B,H] + dc_carry[B,H] fp32
+// workspace per direction: dg[2][B,G*H] bf16 + dh_carry[B,H] + dc_carry[B,H] fp32
 extern "C" size_t os2s_rnn_bwd_workspace_bytes(int B, int H) {
   return (size_t)B * H * (2 * 4 * 2 + 4 + 4) + 256;
+}
+
+extern "C" int os2s_rnn_layer_bwd_multi(os2s_stream_t stream_, int cell, int ndir,
+                                        const os2s_rnn_dir_bwd_t* dirs, const int32_t* lens,
+                                        int B, int T, int H, float forget_bias, void* workspace,
+                                        size_t workspace_bytes) {
+  OS2S_REQUIRE(dirs && workspace && (ndir == 1 || ndir == 2));
+  OS2S_REQUIRE(B >= 1 && T >= 1 && H % 8 == 0 && cell >= 0 && cell <= 2);
+  const size_t per_dir = os2s_rnn_bwd_workspace_bytes(B, H);
+  if (workspace_bytes < per_dir * ndir) return OS2S_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int G = rnn_gates(cell);
+  if (hipMemsetAsync(workspace, 0, per_dir * ndir, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+  RnnBwdArgs a;
+  a.cell = cell; a.B = B; a.T = T; a.H = H; a.G = G; a.lens = lens; a.forget_bias = forget_bias;
+  bf16_t* dg[2][2];
+  for (int d = 0; d < ndir; ++d) {
+    const os2s_rnn_dir_bwd_t& s = dirs[d];
+    OS2S_REQUIRE(s.whT && s.dy && s.y && s.gates && s.dgx);
+    if (cell != kGruCudnn) OS2S_REQUIRE(s.c_seq);
+    char* ws = (char*)workspace + per_dir * d;
+    dg[d][0] = (bf16_t*)ws; ws += (size_t)B * 4 * H * 2;
+    dg[d][1] = (bf16_t*)ws; ws += (size_t)B * 4 * H * 2;
+    RnnDirBwd& k = a.d[d];
+    k.whT = (const bf16_t*)s.whT; k.dy = (const bf16_t*)s.dy; k.lddy = s.lddy; k.ldy = s.ldy;
+    k.gates = (const bf16_t*)s.gates; k.c_seq = s.c_seq; k.y = (const bf16_t*)s.y;
+    k.dgx = (bf16_t*)s.dgx; k.dgr = (bf16_t*)s.dgr;
+    k.dh_carry = (float*)ws; ws += (size_t)B * H * 4;
+    k.dc_carry = (float*)ws;
+    k.reverse = s.reverse;
+    // gate gradients of frames past the sequence ends are zero
+    if (hipMemsetAsync(s.dgx, 0, (size_t)B * T * G * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+    if (s.dgr && hipMemsetAsync(s.dgr, 0, (size_t)B * T * G * H * 2, stream) != hipSuccess)
+      return OS2S_ERR_LAUNCH;
+  }
+  if (ndir == 1) a.d[1] = a.d[0];
+  dim3 grid(ceil_div(H, 32), ceil_div(B, 32), ndir);
+  for (int s = T - 1; s >= 0; --s) {
+    a.step = s;
+    a.first = (s == T - 1);
+    const int par = (T - 1 - s) & 1;
+    for (int d = 0; d < ndir; ++d) {
+      a.d[d].dg_next = dg[d][par];
+      a.d[d].dg_cur = dg[d][par ^ 1];
+    }
+    if (G == 3) { OS2S_LAUNCH(rnn_step_bwd_kernel<3>, grid, dim3(64 * kRnnWaves), 0, stream, a); }
+    else { OS2S_LAUNCH(rnn_step_bwd_kernel<4>, grid, dim3(64 * kRnnWaves), 0, stream, a); }
+  }
+  return OS2S_OK;
 }
 
 extern "C" int os2s_rnn_layer_bwd(os2s_stream_t stream_, int cell, const uint16_t* whT,
@@ -371,36 +427,9 @@ extern "C" int os2s_rnn_layer_bwd(os2s_stream_t stream_, int cell, const uint16_
                                   const float* c_seq, int B, int T, int H,
                                   int reverse, float forget_bias, uint16_t* dgx, uint16_t* dgr,
                                   void* workspace, size_t workspace_bytes) {
-  OS2S_REQUIRE(whT && dy && y && gates && dgx && workspace && B >= 1 && T >= 1 && H % 8 == 0);
-  OS2S_REQUIRE(cell >= 0 && cell <= 2);
-  if (cell != kGruCudnn) OS2S_REQUIRE(c_seq);
-  if (workspace_bytes < os2s_rnn_bwd_workspace_bytes(B, H)) return OS2S_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int G = rnn_gates(cell);
-  char* ws = (char*)workspace;
-  bf16_t* dga = (bf16_t*)ws; ws += (size_t)B * 4 * H * 2;
-  bf16_t* dgb = (bf16_t*)ws; ws += (size_t)B * 4 * H * 2;
-  float* dhc = (float*)ws; ws += (size_t)B * H * 4;
-  float* dcc = (float*)ws;
-  if (hipMemsetAsync(workspace, 0, os2s_rnn_bwd_workspace_bytes(B, H) - 256, stream) != hipSuccess)
-    return OS2S_ERR_LAUNCH;
-  // gate gradients of frames past the sequence ends are zero
-  if (hipMemsetAsync(dgx, 0, (size_t)B * T * G * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
-  if (dgr && hipMemsetAsync(dgr, 0, (size_t)B * T * G * H * 2, stream) != hipSuccess)
-    return OS2S_ERR_LAUNCH;
-  RnnBwdArgs a;
-  a.cell = cell; a.B = B; a.T = T; a.H = H; a.G = G; a.reverse = reverse; a.whT = whT;
-  a.lens = lens; a.dy = dy; a.lddy = lddy; a.ldy = ldy; a.gates = gates; a.c_seq = c_seq; a.y = y;
-  a.dgx = dgx; a.dgr = dgr;
-  a.dh_carry = dhc; a.dc_carry = dcc; a.forget_bias = forget_bias;
-  dim3 grid(ceil_div(H, 32), ceil_div(B, 32));
-  for (int s = T - 1; s >= 0; --s) {
-    a.step = s;
-    a.first = (s == T - 1);
-    a.dg_next = ((T - 1 - s) & 1) ? dgb : dga;
-    a.dg_cur = ((T - 1 - s) & 1) ? dga : dgb;
-    if (G == 3) { OS2S_LAUNCH(rnn_step_bwd_kernel<3>, grid, dim3(64), 0, stream, a); }
-    else { OS2S_LAUNCH(rnn_step_bwd_kernel<4>, grid, dim3(64), 0, stream, a); }
-  }
-  return OS2S_OK;
+  os2s_rnn_dir_bwd_t d;
+  d.whT = whT; d.dy = dy; d.lddy = lddy; d.y = y; d.ldy = ldy; d.gates = gates; d.c_seq = c_seq;
+  d.dgx = dgx; d.dgr = dgr; d.reverse = reverse;
+  return os2s_rnn_layer_bwd_multi(stream_, cell, 1, &d, lens, B, T, H, forget_bias, workspace,
+                                  workspace_bytes);
 }

@@ -1,0 +1,88 @@
+// Small-batch "recurrent GEMM" tile shared by the RNN and attention-decoder step kernels.
+//
+// A recurrent step multiplies a [B, K] state (B <= a few hundred rows) with a [N, K] weight
+// matrix. It is latency-, not throughput-bound: one 32x32 output tile per workgroup, the
+// reduction dimension split over the NW waves of the workgroup (each wave issues all loads
+// of UNR k-slices before its MFMAs, so the L2 latency is paid once per UNR slices instead
+// of once per slice), partial tiles summed through LDS. The orientation is swapped
+// (rows = output units, columns = batch) so that all G gates of one (unit, sample) pair end
+// up in the same lane and the cell non-linearity is lane-local.
+#pragma once
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+// acc[g] += W[g*gate_stride + j, 0:K] . In[b, 0:K]  for the 32 rows j = j0.. and 32 columns
+// b = b0.. of this workgroup; this wave covers k-slices wave, wave+NW, ...
+// MFMA 32x32x16 operand layout: lane supplies 8 consecutive k at (lane>>5)*8 for row lane&31.
+template <int G, int NW, int UNR = 4>
+__device__ __forceinline__ void tile_gemm_splitk(const bf16_t* __restrict__ w, long long ldw,
+                                                 long long gate_stride, int j0, int n_rows,
+                                                 const bf16_t* __restrict__ in, long long ldin,
+                                                 int b0, int n_batch, int K, f32x16 (&acc)[G]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int jrow = min(j0 + l31, n_rows - 1);
+  const int brow = b0 + l31;
+  const bool bvalid = brow < n_batch;
+  const bf16_t* ip = in + (long long)min(brow, n_batch - 1) * ldin + lhi * 8;
+  const bf16_t* wp = w + (long long)jrow * ldw + lhi * 8;
+  const int niter = (K + 15) >> 4;
+  for (int it0 = wave; it0 < niter; it0 += NW * UNR) {
+    bf16x8 a[UNR][G], bb[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int it = it0 + u * NW;
+      const int ko = it * 16 + lhi * 8;
+      const bool kv = (it < niter) && (ko < K);
+      if (kv && bvalid) bb[u] = *reinterpret_cast<const bf16x8*>(ip + it * 16);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[u][e] = (__bf16)0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (kv) a[u][g] = *reinterpret_cast<const bf16x8*>(wp + (long long)g * gate_stride * ldw + it * 16);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[u][g][e] = (__bf16)0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][g], bb[u], acc[g], 0, 0, 0);
+  }
+}
+
+// Sum the NW partial tiles; wave q (< 4) receives rows 8q'+... of its quarter:
+// out[g][e] = sum_w acc_w[g][4*wave + e]. `red` is NW*16*64 floats of LDS.
+// Accumulator layout: acc[r] is row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31, so the
+// quarter q = r>>2 of wave q is rows j0 + 8q + 4*(lane>>5) + e.
+template <int G, int NW>
+__device__ __forceinline__ void tile_reduce_quarters(f32x16 (&acc)[G], float* red,
+                                                     float (&out)[G][4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[g][r];
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 16 + 4 * wave + e) * 64 + lane];
+        out[g][e] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+}  // namespace os2s

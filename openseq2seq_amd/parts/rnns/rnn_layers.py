@@ -41,50 +41,75 @@ class RNNDirection(object):
     self.bh = store.add(name + "/bias_h", (GH,), torch.zeros(GH), kind="vector") \
         if cell != "lstm_tf" else None
 
-  def forward(self, xs, lens, tape, y_view=None, dy_view_fn=None):
-    """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H].
-    y_view: optional [B,T,H] channel-slice view to write the outputs into (the two
-    directions of a layer share one [B,T,2H] tensor); dy_view_fn() then returns the matching
-    slice of the shared gradient."""
+  def input_projection(self, xs):
     B, T, _ = xs[0].data.shape
-    H, G = self.H, self.G
-    GH = G * H
+    GH = self.G * self.H
     gx = None
     for i, (x, w) in enumerate(zip(xs, self.wx)):
       gx = capi.gemm(x.data.reshape(B * T, -1), w.w16.view(GH, -1),
                      bias=self.bx.master if i == 0 else None, out=gx, accumulate=i > 0)
-    gx3 = gx.view(B, T, GH)
-    training = tape is not None
-    y, gates, c_seq = capi.rnn_layer_fwd(self.cell, gx3, self.wh.w16.view(GH, H),
-                                         self.bh.master if self.bh is not None else None, lens, H,
-                                         self.reverse, self.forget_bias, save=training, y=y_view)
-    out = Act(y, lens)
-    if not training:
-      return out
-    layer = self
+    return gx.view(B, T, GH)
 
-    def backward():
-      dy = dy_view_fn() if dy_view_fn is not None else out.grad
-      assert dy is not None
-      dgx, dgr = capi.rnn_layer_bwd(layer.cell, layer.wh.wt16.view(H, GH), lens, dy, y, gates,
-                                    c_seq, H, layer.reverse, layer.forget_bias)
-      d2 = dgx.view(B * T, GH)
-      for x, w in zip(xs, layer.wx):
-        capi.gemm_wgrad(x.data.reshape(B * T, -1), d2, w.grad.view(GH, -1), accumulate=True)
-        if x.requires_grad:
-          g = x.grad_buffer()
-          capi.gemm(d2, w.wt16.view(-1, GH), out=g.view(B * T, -1), accumulate=x.grad_init)
-          x.grad_init = True
-      _colsum_into(d2, layer.bx)
-      if layer.bh is not None:
-        _colsum_into(dgr.view(B * T, GH), layer.bh)
-      # dWh += dgr^T . h_{t-1}: h_{t-1} is y shifted by one step in processing order
-      capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if layer.reverse else 1), in_len=lens,
-                        out=layer.wh.grad, accumulate=True)
-      out.grad = None
+  def params(self):
+    return [self.wh, self.bx] + self.wx + ([self.bh] if self.bh is not None else [])
 
-    tape.record(backward, [layer.wh, layer.bx] + layer.wx + ([layer.bh] if layer.bh else []))
-    return out
+  def weight_backward(self, xs, lens, y, dgx, dgr):
+    """dX, dWx, dWh and the bias gradients from the saved gate gradients."""
+    B, T, _ = xs[0].data.shape
+    H, GH = self.H, self.G * self.H
+    d2 = dgx.view(B * T, GH)
+    for x, w in zip(xs, self.wx):
+      capi.gemm_wgrad(x.data.reshape(B * T, -1), d2, w.grad.view(GH, -1), accumulate=True)
+      if x.requires_grad:
+        g = x.grad_buffer()
+        capi.gemm(d2, w.wt16.view(-1, GH), out=g.view(B * T, -1), accumulate=x.grad_init)
+        x.grad_init = True
+    _colsum_into(d2, self.bx)
+    if self.bh is not None:
+      _colsum_into(dgr.view(B * T, GH), self.bh)
+    # dWh += dgr^T . h_{t-1}: h_{t-1} is y shifted by one step in processing order
+    capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if self.reverse else 1), in_len=lens,
+                      out=self.wh.grad, accumulate=True)
+
+  def forward(self, xs, lens, tape, y_view=None, dy_view_fn=None):
+    """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H].
+    y_view: optional [B,T,H] channel-slice view to write the outputs into;
+    dy_view_fn() then returns the matching slice of the shared gradient."""
+    return rnn_directions_forward([self], xs, lens, tape, [y_view],
+                                  [dy_view_fn] if dy_view_fn is not None else None)[0]
+
+
+def rnn_directions_forward(dirs, xs, lens, tape, y_views=None, dy_view_fns=None):
+  """Runs 1 or 2 `RNNDirection`s of the same cell/size over the same inputs with ONE kernel
+  launch per time step (os2s_rnn_layer_{fwd,bwd}_multi). Returns one Act per direction."""
+  d0 = dirs[0]
+  H = d0.H
+  training = tape is not None
+  y_views = y_views or [None] * len(dirs)
+  gxs = [d.input_projection(xs) for d in dirs]
+  res = capi.rnn_layer_fwd_multi(
+      d0.cell, [dict(gx=gx, wh=d.wh.w16.view(d.G * H, H),
+                     bh=d.bh.master if d.bh is not None else None, y=yv, reverse=d.reverse)
+                for d, gx, yv in zip(dirs, gxs, y_views)],
+      lens, H, d0.forget_bias, save=training)
+  outs = [Act(r[0], lens) for r in res]
+  if not training:
+    return outs
+
+  def backward():
+    dys = [f() for f in dy_view_fns] if dy_view_fns is not None else [o.grad for o in outs]
+    assert all(g is not None for g in dys)
+    grads = capi.rnn_layer_bwd_multi(
+        d0.cell, [dict(whT=d.wh.wt16.view(H, d.G * H), dy=dy, y=r[0], gates=r[1], c_seq=r[2],
+                       reverse=d.reverse) for d, dy, r in zip(dirs, dys, res)],
+        lens, H, d0.forget_bias)
+    for d, r, (dgx, dgr) in zip(dirs, res, grads):
+      d.weight_backward(xs, lens, r[0], dgx, dgr)
+    for o in outs:
+      o.grad = None
+
+  tape.record(backward, [p for d in dirs for p in d.params()])
+  return outs
 
 
 class BiRNNStack(object):
@@ -118,9 +143,9 @@ class BiRNNStack(object):
       ybuf = (torch.zeros if lens is not None else torch.empty)(
           (B, T, H * self.ndir), dtype=torch.bfloat16, device=cur.data.device)
       out = Act(ybuf, lens)
-      for d, layer in enumerate(dirs):
-        layer.forward([cur], lens, tape, y_view=ybuf[:, :, d * H:(d + 1) * H],
-                      dy_view_fn=(lambda o=out, d=d: o.grad[:, :, d * H:(d + 1) * H]))
+      rnn_directions_forward(
+          dirs, [cur], lens, tape, [ybuf[:, :, d * H:(d + 1) * H] for d in range(len(dirs))],
+          [(lambda o=out, d=d: o.grad[:, :, d * H:(d + 1) * H]) for d in range(len(dirs))])
       cur = out
       if keep_prob < 1.0 and li < len(self.layers) - 1:
         seed = seeds.next() if seeds is not None else li + 1
