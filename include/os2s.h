@@ -397,6 +397,84 @@ int os2s_rnn_layer_bwd_multi(os2s_stream_t stream, int cell, int ndir,
                              int H, float forget_bias, void* workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------
+ * Attention-RNN decoder loop: the AttentionWrapper cell that tf.contrib.seq2seq.dynamic_decode
+ * steps in RNNDecoderWithAttention (gnmt / gnmt_v2: decoders/rnn_decoders.py:147-321,
+ * parts/rnns/gnmt.py:32-79) and Tacotron2Decoder (decoders/tacotron2_decoder.py:257-420):
+ *   per step t:  cat0[t] = [dropout(attention_{t-1}) (M), h0_{t-1} (H)]
+ *                h0 = LSTMCell(gx0[t] + cat0[t] Wcat0^T)            (gates i,j,f,o; forget_bias)
+ *                [L == 2: cat1[t] = [dropout_out(h0_t), h1_{t-1}];  h1 = LSTMCell(cat1[t] Wcat1^T + bias1)]
+ *                query = dropout_out(h_top) Wq^T
+ *                score_s = nv . tanh(keys_s + query [+ location_s] [+ b]),  masked softmax over s < src_len
+ *                   score_mode 0: nv = v (Bahdanau, parts/rnns/attention_wrapper.py:536-539)
+ *                              1: nv = g v/|v|, bias b (normalised Bahdanau, :520-535)
+ *                              2: location-sensitive (:641-715, 749-878): location_s = dense_w^T
+ *                                 (conv1d_SAME(cumulative alignments; conv_w [K,F], conv_b) at s),
+ *                                 cumulative state += alignments after the step; bias b iff use_bias
+ *                attention_t = context = sum_s align_s values_s   (attention_layer_size = None)
+ * Everything outside the recurrence is the caller's (GEMM entry points): gx0 = inputs W_in^T
+ * + bias for all steps, keys = values W_mem^T, layers above the attention cell, projections.
+ * All state lives in caller-owned sequence buffers (zero them before t = 0):
+ *   cat[l]   bf16 [B, T+1, Kc_l]  (Kc_0 = M+H, Kc_1 = 2H): row t = input of step t
+ *   c_seq[l] fp32 [B, T, H], gates[l] bf16 [B, T, 4H] (saved for backward; gates may be NULL
+ *   for inference), cum_seq fp32 [B, T+1, S] (mode 2; row t = state before step t),
+ *   align_seq fp32 [B, T, S], q_seq fp32 [B, T, U]
+ *   y_top: dropped top-cell outputs, row (b,t) at y_top + b*y_top_bs + t*y_top_ts (bf16)
+ *   ctx:   raw contexts, row (b,t) at ctx + b*ctx_bs + t*ctx_ts (bf16)
+ * so os2s_attn_decoder_fwd may be called for any step range [t_begin, t_end): the whole
+ * teacher-forced sequence at once, or one step at a time for greedy / free-running decoding.
+ * tgt_len (or NULL): steps t >= tgt_len[b] leave sample b untouched (impute_finished).
+ * Dropout masks come from the library's counter hash: attention-input dropout indexes the
+ * logical [B, T+1, M] tensor (row t+1 = attention_t), output dropout [B, T, H] per layer.
+ * Limits: H % 8 == 0, M % 8 == 0, U % 128 == 0 and <= 512, loc_f <= 64.
+ * ---------------------------------------------------------------------- */
+typedef struct os2s_attn_decoder {
+  int B, T, S, L, H, M, U;
+  int score_mode, use_bias, loc_k, loc_f;
+  int t_begin, t_end;
+  float forget_bias;
+  float attn_in_keep; unsigned long long attn_in_seed;
+  float out_keep; unsigned long long out_seed[2];
+  /* parameters */
+  const uint16_t* wcat[2];      /* bf16 [4H, Kc_l] */
+  const float* bias[2];         /* fp32 [4H] or NULL */
+  const uint16_t* wq;           /* bf16 [U, H] */
+  const float* v; const float* g; const float* b;                 /* [U], [1], [U] */
+  const float* conv_w; const float* conv_b; const float* dense_w; /* [K,F], [F], [F,U] */
+  /* inputs */
+  const uint16_t* gx0;          /* bf16 [B, T, 4H] */
+  const uint16_t* keys;         /* bf16 [B, S, U] */
+  const uint16_t* values;       /* bf16 [B, S, M], zero past src_len */
+  const int32_t* src_len; const int32_t* tgt_len;
+  /* state / saved sequences / outputs */
+  uint16_t* cat[2]; float* c_seq[2]; uint16_t* gates[2];
+  float* cum_seq; float* align_seq; float* q_seq;
+  uint16_t* y_top; long long y_top_bs, y_top_ts;
+  uint16_t* ctx; long long ctx_bs, ctx_ts;
+} os2s_attn_decoder_t;
+
+/* Backward through all T steps (t_begin = 0, t_end = T). Inputs: dy_top / dctx_ext = gradients
+ * of the y_top / ctx rows (either may be NULL), wcatT[l] = bf16 [Kc_l, 4H] transposed
+ * weights. Outputs: dg[l] bf16 [B,T,4H] gate gradients (caller: dWcat_l = dg_l^T cat_l,
+ * d gx0 = dg_0), dq_seq bf16 [B,T,U] (dWq = dq^T y_top, db = column sums), dkeys fp32
+ * [B,S,U], dmem bf16 [B,S,M] = gradient of `values`, dctx_seq bf16 [B,T,M] scratch; the
+ * small score parameters are ACCUMULATED into dv [U], dg_scalar [1], dconv_w, dconv_b,
+ * ddense_w (fp32). */
+typedef struct os2s_attn_decoder_grads {
+  const uint16_t* wcatT[2];
+  const uint16_t* dy_top; long long dy_top_bs, dy_top_ts;
+  const uint16_t* dctx_ext; long long dctx_bs, dctx_ts;
+  uint16_t* dg[2];
+  uint16_t* dq_seq; uint16_t* dctx_seq; float* dkeys; uint16_t* dmem;
+  float* dv; float* dg_scalar; float* dconv_w; float* dconv_b; float* ddense_w;
+} os2s_attn_decoder_grads_t;
+
+int os2s_attn_decoder_fwd(os2s_stream_t stream, const os2s_attn_decoder_t* d);
+size_t os2s_attn_decoder_bwd_workspace_bytes(const os2s_attn_decoder_t* d);
+int os2s_attn_decoder_bwd(os2s_stream_t stream, const os2s_attn_decoder_t* d,
+                          const os2s_attn_decoder_grads_t* grads, void* workspace,
+                          size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------
  * conv2d (time x frequency) of DeepSpeech2 (tf.layers.conv2d in conv_bn_actv,
  * encoders/ds2_encoder.py:252-266) on the 1-D implicit-GEMM kernel: activations are
  * flattened to [B, T, F*C]; the frequency convolution becomes the banded channel mixing

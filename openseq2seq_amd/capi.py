@@ -660,3 +660,137 @@ def conv2d_toeplitz_reduce(dwexp, Fi, Fo, sF, padF, dw):
   f = _fn("os2s_conv2d_toeplitz_reduce", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,))
   _lib.check(f(_stream(), _ptr(dwexp, torch.float32), KT, KF, Cin, Cout, Fi, Fo, sF, padF,
                _ptr(dw, torch.float32)), "os2s_conv2d_toeplitz_reduce")
+
+
+# --------------------------------------------------------------------------
+# attention-RNN decoder loop (NMT gnmt / Tacotron2)
+# --------------------------------------------------------------------------
+SCORE_BAHDANAU, SCORE_BAHDANAU_NORM, SCORE_LOCATION = 0, 1, 2
+c_ull = _lib.ctypes.c_ulonglong
+
+
+class _AttnDecoder(_lib.ctypes.Structure):
+  _fields_ = [(n, c_int) for n in ("B", "T", "S", "L", "H", "M", "U", "score_mode", "use_bias",
+                                   "loc_k", "loc_f", "t_begin", "t_end")] + [
+      ("forget_bias", c_float), ("attn_in_keep", c_float), ("attn_in_seed", c_ull),
+      ("out_keep", c_float), ("out_seed", c_ull * 2),
+      ("wcat", c_void_p * 2), ("bias", c_void_p * 2), ("wq", c_void_p),
+      ("v", c_void_p), ("g", c_void_p), ("b", c_void_p),
+      ("conv_w", c_void_p), ("conv_b", c_void_p), ("dense_w", c_void_p),
+      ("gx0", c_void_p), ("keys", c_void_p), ("values", c_void_p),
+      ("src_len", c_void_p), ("tgt_len", c_void_p),
+      ("cat", c_void_p * 2), ("c_seq", c_void_p * 2), ("gates", c_void_p * 2),
+      ("cum_seq", c_void_p), ("align_seq", c_void_p), ("q_seq", c_void_p),
+      ("y_top", c_void_p), ("y_top_bs", c_ll), ("y_top_ts", c_ll),
+      ("ctx", c_void_p), ("ctx_bs", c_ll), ("ctx_ts", c_ll)]
+
+
+class _AttnDecoderGrads(_lib.ctypes.Structure):
+  _fields_ = [("wcatT", c_void_p * 2),
+              ("dy_top", c_void_p), ("dy_top_bs", c_ll), ("dy_top_ts", c_ll),
+              ("dctx_ext", c_void_p), ("dctx_bs", c_ll), ("dctx_ts", c_ll),
+              ("dg", c_void_p * 2), ("dq_seq", c_void_p), ("dctx_seq", c_void_p),
+              ("dkeys", c_void_p), ("dmem", c_void_p), ("dv", c_void_p), ("dg_scalar", c_void_p),
+              ("dconv_w", c_void_p), ("dconv_b", c_void_p), ("ddense_w", c_void_p)]
+
+
+class AttnDecoder(object):
+  """Owns the sequence buffers of one os2s_attn_decoder_{fwd,bwd} call (see include/os2s.h).
+  `y_top` / `ctx` may be channel-slice views of a wider [B,T,ld] tensor (Tacotron's
+  concat(cell output, context) is then never materialised by a copy)."""
+
+  def __init__(self, B, T, S, L, H, M, U, mode, device, use_bias=False, loc_k=0, loc_f=0,
+               forget_bias=1.0, attn_in_keep=1.0, attn_in_seed=0, out_keep=1.0, out_seeds=(0, 0),
+               save=True, y_top=None, ctx=None):
+    self.dims = dict(B=B, T=T, S=S, L=L, H=H, M=M, U=U)
+    self.mode, self.use_bias, self.loc_k, self.loc_f = mode, use_bias, loc_k, loc_f
+    self.forget_bias, self.attn_in_keep, self.attn_in_seed = forget_bias, attn_in_keep, attn_in_seed
+    self.out_keep, self.out_seeds = out_keep, tuple(out_seeds)
+    bf, f32 = torch.bfloat16, torch.float32
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+    kc = [M + H, 2 * H]
+    self.cat = [z((B, T + 1, kc[l]), bf) for l in range(L)]
+    self.c_seq = [z((B, T, H), f32) for l in range(L)]
+    self.gates = [z((B, T, 4 * H), bf) if save else None for l in range(L)]
+    self.cum_seq = z((B, T + 1, S), f32) if mode == SCORE_LOCATION else None
+    self.align_seq = z((B, T, S), f32)
+    self.q_seq = z((B, T, U), f32)
+    self.y_top = y_top if y_top is not None else z((B, T, H), bf)
+    self.ctx = ctx if ctx is not None else z((B, T, M), bf)
+    for t in (self.y_top, self.ctx):
+      assert t.dtype == bf and t.stride(2) == 1
+    self.params = None
+    self.inputs = None
+
+  def set_params(self, wcat, wq, v, bias=(None, None), g=None, b=None, conv_w=None, conv_b=None,
+                 dense_w=None):
+    self.params = dict(wcat=list(wcat), bias=list(bias) + [None] * (2 - len(bias)), wq=wq, v=v, g=g,
+                       b=b, conv_w=conv_w, conv_b=conv_b, dense_w=dense_w)
+
+  def _desc(self, t_begin, t_end):
+    d, p, i = _AttnDecoder(), self.params, self.inputs
+    for k, val in self.dims.items():
+      setattr(d, k, val)
+    L = self.dims["L"]
+    d.score_mode, d.use_bias, d.loc_k, d.loc_f = self.mode, int(self.use_bias), self.loc_k, self.loc_f
+    d.t_begin, d.t_end = t_begin, t_end
+    d.forget_bias, d.attn_in_keep, d.attn_in_seed = self.forget_bias, self.attn_in_keep, self.attn_in_seed
+    d.out_keep = self.out_keep
+    for l in range(2):
+      d.out_seed[l] = self.out_seeds[l]
+      d.wcat[l] = _addr(p["wcat"][l]) if l < L else None
+      d.bias[l] = _addr(p["bias"][l]) if l < L else None
+      d.cat[l] = _addr(self.cat[l]) if l < L else None
+      d.c_seq[l] = _addr(self.c_seq[l]) if l < L else None
+      d.gates[l] = _addr(self.gates[l]) if l < L else None
+    for k in ("wq", "v", "g", "b", "conv_w", "conv_b", "dense_w"):
+      setattr(d, k, _addr(p[k]))
+    for k in ("gx0", "keys", "values", "src_len", "tgt_len"):
+      setattr(d, k, _addr(i[k]))
+    d.cum_seq, d.align_seq, d.q_seq = _addr(self.cum_seq), _addr(self.align_seq), _addr(self.q_seq)
+    d.y_top, d.y_top_bs, d.y_top_ts = self.y_top.data_ptr(), self.y_top.stride(0), self.y_top.stride(1)
+    d.ctx, d.ctx_bs, d.ctx_ts = self.ctx.data_ptr(), self.ctx.stride(0), self.ctx.stride(1)
+    return d
+
+  def set_inputs(self, gx0, keys, values, src_len, tgt_len=None):
+    for t in (gx0, keys, values):
+      assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    assert src_len.dtype == torch.int32 and (tgt_len is None or tgt_len.dtype == torch.int32)
+    self.inputs = dict(gx0=gx0, keys=keys, values=values, src_len=src_len, tgt_len=tgt_len)
+
+  def forward(self, t_begin=0, t_end=None):
+    t_end = self.dims["T"] if t_end is None else t_end
+    d = self._desc(t_begin, t_end)
+    f = _fn("os2s_attn_decoder_fwd", (c_void_p, c_void_p))
+    _lib.check(f(_stream(), _lib.ctypes.byref(d)), "os2s_attn_decoder_fwd")
+
+  def backward(self, wcatT, dy_top=None, dctx_ext=None, dv=None, dg=None, dconv_w=None,
+               dconv_b=None, ddense_w=None):
+    """Returns dict(dg=[L x bf16 [B,T,4H]], dq_seq, dkeys fp32, dmem bf16)."""
+    B, T, S, L, H, M, U = (self.dims[k] for k in "BTSLHMU")
+    dev = self.align_seq.device
+    bf = torch.bfloat16
+    out = dict(dg=[torch.empty((B, T, 4 * H), dtype=bf, device=dev) for _ in range(L)],
+               dq_seq=torch.empty((B, T, U), dtype=bf, device=dev),
+               dkeys=torch.empty((B, S, U), dtype=torch.float32, device=dev),
+               dmem=torch.empty((B, S, M), dtype=bf, device=dev))
+    dctx_seq = torch.empty((B, T, M), dtype=bf, device=dev)
+    g = _AttnDecoderGrads()
+    for l in range(2):
+      g.wcatT[l] = _addr(wcatT[l]) if l < L else None
+      g.dg[l] = _addr(out["dg"][l]) if l < L else None
+    if dy_top is not None:
+      g.dy_top, g.dy_top_bs, g.dy_top_ts = dy_top.data_ptr(), dy_top.stride(0), dy_top.stride(1)
+    if dctx_ext is not None:
+      g.dctx_ext, g.dctx_bs, g.dctx_ts = dctx_ext.data_ptr(), dctx_ext.stride(0), dctx_ext.stride(1)
+    g.dq_seq, g.dctx_seq, g.dkeys, g.dmem = (_addr(out["dq_seq"]), _addr(dctx_seq),
+                                             _addr(out["dkeys"]), _addr(out["dmem"]))
+    g.dv, g.dg_scalar = _addr(dv), _addr(dg)
+    g.dconv_w, g.dconv_b, g.ddense_w = _addr(dconv_w), _addr(dconv_b), _addr(ddense_w)
+    d = self._desc(0, T)
+    n = int(_fn("os2s_attn_decoder_bwd_workspace_bytes", (c_void_p,), c_size_t)(_lib.ctypes.byref(d)))
+    ws = torch.empty((n,), dtype=torch.uint8, device=dev)
+    f = _fn("os2s_attn_decoder_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+    _lib.check(f(_stream(), _lib.ctypes.byref(d), _lib.ctypes.byref(g), _ptr(ws), n),
+               "os2s_attn_decoder_bwd")
+    return out
