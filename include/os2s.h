@@ -297,11 +297,14 @@ int os2s_logmel(os2s_stream_t stream, const void* signal, const int32_t* n_sampl
  * index remap. */
 int os2s_embed_fwd(os2s_stream_t stream, const int32_t* ids, const int32_t* pos,
                    const uint16_t* table, int V, int D, long long N, float emb_scale,
-                   float keep_prob, unsigned long long seed, uint16_t* out);
-/* its gradient: dtable[id] += emb_scale * dropout'(dout[n]) (fp32 atomics) */
+                   float keep_prob, unsigned long long seed, uint16_t* out, int plain_lookup);
+/* its gradient: dtable[id] += emb_scale * dropout'(dout[n]) (fp32 atomics).
+ * plain_lookup = 1: tf.nn.embedding_lookup as the RNN encoders/decoders use it
+ * (encoders/rnn_encoders.py:283-289, decoders/rnn_decoders.py:262-266): no pad zeroing,
+ * no position signal (pos may be NULL). */
 int os2s_embed_bwd(os2s_stream_t stream, const int32_t* ids, const uint16_t* dout, int V,
                    int D, long long N, float emb_scale, float keep_prob,
-                   unsigned long long seed, float* dtable);
+                   unsigned long long seed, float* dtable, int plain_lookup);
 /* LayerNormalization "layernorm_L2" (parts/transformer/common.py:41-68), D in {512, 1024} */
 int os2s_layernorm_fwd(os2s_stream_t stream, const uint16_t* x, const float* gamma,
                        const float* beta, float eps, long long N, int D, uint16_t* y,
@@ -341,12 +344,21 @@ int os2s_attention_bwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* 
                        float scale, float keep_prob, unsigned long long seed);
 /* PaddedCrossEntropyLossWithSmoothing (losses/sequence_loss.py:257-309) over the N
  * non-pad target rows: row_loss[n] = xent(soft targets) - normalizing constant;
- * loss_mean = sum/N; dlogits = grad_scale * (*grad_scale_dev) * (softmax - soft_target)
- * (pass grad_scale = 1/N). logits/dlogits bf16 [N, ld], V % 8 == 0, V <= 40960. */
+ * loss_mean = grad_scale * sum(row_loss); dlogits = grad_scale * (*grad_scale_dev) *
+ * (softmax - soft_target). Pass grad_scale = 1/N for the token mean (Transformer) or
+ * 1/batch_size with label_smoothing = 0 for BasicSequenceLoss (losses/sequence_loss.py:53-114:
+ * sparse softmax xent summed over time, divided by the batch size).
+ * logits/dlogits bf16 [N, ld], V % 8 == 0, V <= 40960; columns >= V_valid are vocabulary
+ * padding (treated as -inf logits, zero gradient). */
 int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t* labels,
-                     long long N, int V, long long ld, float label_smoothing,
+                     long long N, int V, int V_valid, long long ld, float label_smoothing,
                      float grad_scale, const float* grad_scale_dev, float* row_loss,
                      float* loss_mean, uint16_t* dlogits);
+/* rows with label < 0 are masked positions (weight 0: no loss, zero gradient). */
+/* tf.argmax(logits, -1) over the first V_valid columns of bf16 rows (decoders'
+ * 'outputs', decoders/rnn_decoders.py:318, GreedyEmbeddingHelper sampling). */
+int os2s_argmax_rows(os2s_stream_t stream, const uint16_t* x, long long N, int V_valid,
+                     long long ld, int32_t* out);
 
 /* ------------------------------------------------------------------------
  * Recurrent layers (one direction of one layer per call; the time loop is inside).

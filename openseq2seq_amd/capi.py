@@ -428,26 +428,27 @@ def gemm_wgrad(x2d, dy2d, out, accumulate=True):
                out=out.view(1, Cout, Cin), accumulate=accumulate)
 
 
-def embed_fwd(ids, pos, table, emb_scale, keep_prob, seed):
+def embed_fwd(ids, pos, table, emb_scale, keep_prob, seed, plain=False):
+  """pos=None with plain=True: tf.nn.embedding_lookup (+ dropout)."""
   N = ids.numel()
   V, D = table.shape
   out = torch.empty((N, D), dtype=torch.bfloat16, device=ids.device)
   f = _fn("os2s_embed_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll,
-                             c_float, c_float, c_uint64, c_void_p))
-  _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(pos, torch.int32),
+                             c_float, c_float, c_uint64, c_void_p, c_int))
+  _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(pos, torch.int32, plain),
                _ptr(table, torch.bfloat16), V, D, N, float(emb_scale), float(keep_prob),
-               int(seed) & (2**64 - 1), _ptr(out)), "os2s_embed_fwd")
+               int(seed) & (2**64 - 1), _ptr(out), int(plain)), "os2s_embed_fwd")
   return out
 
 
-def embed_bwd(ids, dout, dtable, emb_scale, keep_prob, seed):
+def embed_bwd(ids, dout, dtable, emb_scale, keep_prob, seed, plain=False):
   N = ids.numel()
   V, D = dtable.shape
   f = _fn("os2s_embed_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_float,
-                             c_float, c_uint64, c_void_p))
+                             c_float, c_uint64, c_void_p, c_int))
   _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(dout, torch.bfloat16), V, D, N,
                float(emb_scale), float(keep_prob), int(seed) & (2**64 - 1),
-               _ptr(dtable, torch.float32)), "os2s_embed_bwd")
+               _ptr(dtable, torch.float32), int(plain)), "os2s_embed_bwd")
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-6, save=True):
@@ -531,20 +532,33 @@ def attention_bwd(q, k, v, d_o, lse, dq, dk, dv, cu_q, cu_k, H, max_len, causal,
                float(scale), float(keep_prob), int(seed) & (2**64 - 1)), "os2s_attention_bwd")
 
 
-def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=True):
-  """logits [N,V] bf16, labels int32 [N] -> (row_loss [N], loss_mean [1], dlogits|None)."""
+def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=True,
+                v_valid=None, grad_scale=None):
+  """logits [N,V] bf16, labels int32 [N] -> (row_loss [N], loss [1], dlogits|None).
+  loss = grad_scale * sum(row_loss) (default grad_scale = 1/N: the token mean)."""
   N, V = logits.shape
   dev = logits.device
   row_loss = torch.empty(N, dtype=torch.float32, device=dev)
   mean = torch.empty(1, dtype=torch.float32, device=dev)
   dl = torch.empty_like(logits) if want_grad else None
-  f = _fn("os2s_xent_smooth", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_ll, c_float, c_float,
-                               c_void_p, c_void_p, c_void_p, c_void_p))
+  f = _fn("os2s_xent_smooth", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_ll, c_float,
+                               c_float, c_void_p, c_void_p, c_void_p, c_void_p))
   _lib.check(f(_stream(), _ptr(logits, torch.bfloat16), _ptr(labels, torch.int32), N, V,
-               logits.stride(0), float(label_smoothing), 1.0 / N,
+               V if v_valid is None else int(v_valid), logits.stride(0), float(label_smoothing),
+               1.0 / N if grad_scale is None else float(grad_scale),
                _ptr(grad_scale_dev, torch.float32, True), _ptr(row_loss), _ptr(mean),
                _ptr(dl, None, True)), "os2s_xent_smooth")
   return row_loss, mean, dl
+
+
+def argmax_rows(x2d, v_valid=None):
+  """bf16 [N, ld] -> int32 [N] argmax over the first v_valid columns."""
+  N, V = x2d.shape
+  out = torch.empty(N, dtype=torch.int32, device=x2d.device)
+  f = _fn("os2s_argmax_rows", (c_void_p, c_void_p, c_ll, c_int, c_ll, c_void_p))
+  _lib.check(f(_stream(), _ptr(x2d, torch.bfloat16), N, V if v_valid is None else int(v_valid),
+               x2d.stride(0), _ptr(out)), "os2s_argmax_rows")
+  return out
 
 
 # --------------------------------------------------------------------------

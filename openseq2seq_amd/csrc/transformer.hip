@@ -22,7 +22,7 @@ namespace os2s {
 __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const int32_t* __restrict__ ids, const int32_t* __restrict__ pos,
     const bf16_t* __restrict__ table, int V, int D, long long N, float emb_scale, float keep_prob,
-    unsigned long long seed, bf16_t* __restrict__ out) {
+    unsigned long long seed, bf16_t* __restrict__ out, int plain) {
   const int D8 = D >> 3;
   const int half = D >> 1;
   const float log_inc = logf(1.0e4f) / (float)(half - 1);
@@ -33,17 +33,18 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const int c0 = (int)(i - n * D8) * 8;
     int id = ids[n];
     if (id > V - 1) id = 0;   // out-of-bound ids map to the pad symbol (embedding_layer.py:71-73)
+    if (id < 0) id = 0;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (id != 0) {            // padding embeddings are zeroed (:79-87)
+    if (id != 0 || plain) {   // padding embeddings are zeroed (:79-87); plain = tf.nn.embedding_lookup
       const u32x4 t = *reinterpret_cast<const u32x4*>(table + (long long)id * D + c0);
       v[0] = bflo(t[0]); v[1] = bfhi(t[0]); v[2] = bflo(t[1]); v[3] = bfhi(t[1]);
       v[4] = bflo(t[2]); v[5] = bfhi(t[2]); v[6] = bflo(t[3]); v[7] = bfhi(t[3]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= emb_scale;
     }
-    const float p = (float)pos[n];
+    const float p = pos ? (float)pos[n] : 0.f;
     uint32_t keep = 0xffu;
     if (keep_prob < 1.f) keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
 #pragma unroll
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
       const int c = c0 + e;
       const int j = c < half ? c : c - half;
       const float ang = p * __expf(-(float)j * log_inc);
-      float val = v[e] + (c < half ? sinf(ang) : cosf(ang));
+      float val = v[e] + (pos ? (c < half ? sinf(ang) : cosf(ang)) : 0.f);
       if (keep_prob < 1.f) val = ((keep >> e) & 1u) ? val * ik : 0.f;
       v[e] = val;
     }
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
 // dE[id] += emb_scale * dropout'(dout[n])   (fp32 atomics into the flat gradient)
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int32_t* __restrict__ ids, const bf16_t* __restrict__ dout, int V, int D, long long N,
-    float emb_scale, float keep_prob, unsigned long long seed, float* __restrict__ dtable) {
+    float emb_scale, float keep_prob, unsigned long long seed, float* __restrict__ dtable,
+    int plain) {
   const int D8 = D >> 3;
   const float ik = 1.f / keep_prob;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N * D8;
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const long long n = i / D8;
     const int c0 = (int)(i - n * D8) * 8;
     int id = ids[n];
-    if (id > V - 1 || id == 0) continue;
+    if (id > V - 1 || id < 0) id = 0;
+    if (id == 0 && !plain) continue;
     const u32x4 t = *reinterpret_cast<const u32x4*>(dout + n * D + c0);
     float g[8] = {bflo(t[0]), bfhi(t[0]), bflo(t[1]), bfhi(t[1]),
                   bflo(t[2]), bfhi(t[2]), bflo(t[3]), bfhi(t[3])};
@@ -267,8 +270,8 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict_
 constexpr int kXentMaxPerThread = 20;   // 16-B vectors per thread -> V <= 256*8*20 = 40960
 
 __global__ __launch_bounds__(256) void xent_smooth_kernel(
-    const bf16_t* __restrict__ logits, const int32_t* __restrict__ labels, int V, long long ld,
-    float confidence, float low_confidence, float normalizing, float grad_scale_host,
+    const bf16_t* __restrict__ logits, const int32_t* __restrict__ labels, int V, int v_valid,
+    long long ld, float confidence, float low_confidence, float normalizing, float grad_scale_host,
     const float* __restrict__ grad_scale_dev, float* __restrict__ row_loss,
     bf16_t* __restrict__ dlogits) {
   __shared__ float red[4];
@@ -278,6 +281,15 @@ __global__ __launch_bounds__(256) void xent_smooth_kernel(
   const int V8 = V >> 3;
   const bf16_t* lr = logits + row * ld;
   const int label = labels[row];
+  if (label < 0) {   // masked position (sequence_mask weight 0): no loss, no gradient
+    if (threadIdx.x == 0 && row_loss) row_loss[row] = 0.f;
+    if (dlogits) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      for (int i = threadIdx.x; i < V8; i += 256)
+        *reinterpret_cast<u32x4*>(dlogits + row * ld + (long long)i * 8) = z;
+    }
+    return;
+  }
   u32x4 buf[kXentMaxPerThread];
   float mx = -INFINITY, sx = 0.f;
   // fully unrolled with a compile-time bound: the row stays in registers (a runtime-indexed
@@ -288,11 +300,19 @@ __global__ __launch_bounds__(256) void xent_smooth_kernel(
     u32x4 t = {0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};   // -inf pairs
     if (i < V8) {
       t = *reinterpret_cast<const u32x4*>(lr + (long long)i * 8);
+      if (i * 8 + 8 > v_valid) {   // vocabulary padding columns: -inf logits, no probability mass
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = i * 8 + 2 * e;
+          if (c >= v_valid) t[e] = (t[e] & 0xffff0000u) | 0xff80u;
+          if (c + 1 >= v_valid) t[e] = (t[e] & 0x0000ffffu) | 0xff800000u;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float a = bflo(t[e]), b = bfhi(t[e]);
         mx = fmaxf(mx, fmaxf(a, b));
-        sx += a + b;
+        sx += (a > -INFINITY ? a : 0.f) + (b > -INFINITY ? b : 0.f);
       }
     }
     buf[k] = t;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(256) void xent_smooth_kernel(
   const float lse = mx + __logf(se);
   const float x_label = bf2f(lr[label]);
   // xent = -sum_v t_v logp_v,  t = confidence at label, low elsewhere
-  const float sum_logp = sx - (float)V * lse;
+  const float sum_logp = sx - (float)v_valid * lse;
   const float logp_label = x_label - lse;
   const float xent = -(confidence * logp_label + low_confidence * (sum_logp - logp_label)) - normalizing;
   if (threadIdx.x == 0 && row_loss) row_loss[row] = xent;
@@ -335,13 +355,35 @@ __global__ __launch_bounds__(256) void xent_smooth_kernel(
       for (int e = 0; e < 4; ++e) {
         const int c = i * 8 + 2 * e;
         const float p0 = __expf(bflo(buf[k][e]) - lse), p1 = __expf(bfhi(buf[k][e]) - lse);
-        const float t0 = (c == label) ? confidence : low_confidence;
-        const float t1 = (c + 1 == label) ? confidence : low_confidence;
+        const float t0 = (c == label) ? confidence : (c < v_valid ? low_confidence : 0.f);
+        const float t1 = (c + 1 == label) ? confidence : (c + 1 < v_valid ? low_confidence : 0.f);
         o[e] = pack2bf((p0 - t0) * gs, (p1 - t1) * gs);
       }
       *reinterpret_cast<u32x4*>(dr + (long long)i * 8) = o;
     }
   }
+}
+
+// argmax over the first v_valid columns of each bf16 row (first maximum wins, as tf.argmax)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const bf16_t* __restrict__ x, long long N,
+                                                          int v_valid, long long ld,
+                                                          int32_t* __restrict__ out) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < v_valid; c += 64) {
+    const float v = bf2f(x[row * ld + c]);
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
 }
 
 __global__ void sum_rows_kernel(const float* __restrict__ v, long long n, float mul,
@@ -371,22 +413,25 @@ using namespace os2s;
 
 extern "C" int os2s_embed_fwd(os2s_stream_t stream, const int32_t* ids, const int32_t* pos,
                               const uint16_t* table, int V, int D, long long N, float emb_scale,
-                              float keep_prob, unsigned long long seed, uint16_t* out) {
-  OS2S_REQUIRE(ids && pos && table && out && V >= 1 && D >= 16 && D % 16 == 0 && N >= 0);
+                              float keep_prob, unsigned long long seed, uint16_t* out,
+                              int plain_lookup) {
+  OS2S_REQUIRE(ids && table && out && V >= 1 && D >= 16 && D % 16 == 0 && N >= 0);
+  OS2S_REQUIRE(pos || plain_lookup);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
   if (N == 0) return OS2S_OK;
   OS2S_LAUNCH(embed_fwd_kernel, dim3(ew_blocks(N * (D / 8))), dim3(256), 0, (hipStream_t)stream,
-              ids, pos, table, V, D, N, emb_scale, keep_prob, seed, out);
+              ids, pos, table, V, D, N, emb_scale, keep_prob, seed, out, plain_lookup);
   return OS2S_OK;
 }
 
 extern "C" int os2s_embed_bwd(os2s_stream_t stream, const int32_t* ids, const uint16_t* dout, int V,
                               int D, long long N, float emb_scale, float keep_prob,
-                              unsigned long long seed, float* dtable) {
+                              unsigned long long seed, float* dtable,
+                              int plain_lookup) {
   OS2S_REQUIRE(ids && dout && dtable && D % 8 == 0 && N >= 0);
   if (N == 0) return OS2S_OK;
   OS2S_LAUNCH(embed_bwd_kernel, dim3(ew_blocks(N * (D / 8))), dim3(256), 0, (hipStream_t)stream,
-              ids, dout, V, D, N, emb_scale, keep_prob, seed, dtable);
+              ids, dout, V, D, N, emb_scale, keep_prob, seed, dtable, plain_lookup);
   return OS2S_OK;
 }
 
@@ -451,21 +496,32 @@ extern "C" int os2s_add_bf16(os2s_stream_t stream, const uint16_t* a, const uint
   return OS2S_OK;
 }
 
+extern "C" int os2s_argmax_rows(os2s_stream_t stream, const uint16_t* x, long long N, int V_valid,
+                                long long ld, int32_t* out) {
+  OS2S_REQUIRE(x && out && N >= 0 && V_valid >= 1 && ld >= V_valid);
+  if (N == 0) return OS2S_OK;
+  OS2S_LAUNCH(argmax_rows_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, x, N,
+              V_valid, ld, out);
+  return OS2S_OK;
+}
+
 extern "C" int os2s_xent_smooth(os2s_stream_t stream, const uint16_t* logits, const int32_t* labels,
-                                long long N, int V, long long ld, float label_smoothing,
-                                float grad_scale, const float* grad_scale_dev, float* row_loss,
-                                float* loss_mean, uint16_t* dlogits) {
+                                long long N, int V, int V_valid, long long ld,
+                                float label_smoothing, float grad_scale,
+                                const float* grad_scale_dev, float* row_loss, float* loss_mean,
+                                uint16_t* dlogits) {
   OS2S_REQUIRE(logits && labels && N >= 1 && V >= 8 && V % 8 == 0 && ld % 8 == 0 && row_loss);
+  OS2S_REQUIRE(V_valid >= 2 && V_valid <= V);
   if (V > 256 * 8 * kXentMaxPerThread) return OS2S_ERR_UNSUPPORTED;
   const float confidence = 1.f - label_smoothing;
-  const float low = (1.f - confidence) / (float)(V - 1);
+  const float low = (1.f - confidence) / (float)(V_valid - 1);
   const float normalizing =
-      -(confidence * logf(confidence) + (float)(V - 1) * low * logf(low + 1e-20f));
+      -(confidence * logf(confidence) + (float)(V_valid - 1) * low * logf(low + 1e-20f));
   OS2S_LAUNCH(xent_smooth_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, logits, labels,
-              V, ld, confidence, low, normalizing, grad_scale, grad_scale_dev, row_loss, dlogits);
+              V, V_valid, ld, confidence, low, normalizing, grad_scale, grad_scale_dev, row_loss, dlogits);
   if (loss_mean) {
     OS2S_LAUNCH(sum_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, N,
-                1.0f / (float)N, loss_mean);
+                grad_scale, loss_mean);
   }
   return OS2S_OK;
 }

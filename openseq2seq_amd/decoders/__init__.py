@@ -1,3 +1,4 @@
 from .decoder import Decoder
 from .fc_decoders import FullyConnectedTimeDecoder, FullyConnectedCTCDecoder
 from .transformer_decoder import TransformerDecoder
+from .rnn_decoders import RNNDecoderWithAttention

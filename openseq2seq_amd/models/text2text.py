@@ -21,6 +21,8 @@ class Text2Text(EncoderDecoderModel):
     if self.mode in ("train", "eval"):
       self._loss_computator = self._create_loss()
     self._encoder.build(store)
+    if hasattr(self._encoder, "output_dim"):    # attention memory depth for RNN decoders
+      self._decoder.params['_memory_dim'] = self._encoder.output_dim
     self._decoder.build(store)
 
   def _forward_backward(self, batch, tape):

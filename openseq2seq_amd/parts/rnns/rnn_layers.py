@@ -80,13 +80,15 @@ class RNNDirection(object):
 
 
 def rnn_directions_forward(dirs, xs, lens, tape, y_views=None, dy_view_fns=None):
-  """Runs 1 or 2 `RNNDirection`s of the same cell/size over the same inputs with ONE kernel
-  launch per time step (os2s_rnn_layer_{fwd,bwd}_multi). Returns one Act per direction."""
+  """Runs 1 or 2 `RNNDirection`s of the same cell/size with ONE kernel launch per time step
+  (os2s_rnn_layer_{fwd,bwd}_multi). `xs` is a list of Act shared by the directions, or one
+  such list per direction. Returns one Act per direction."""
   d0 = dirs[0]
   H = d0.H
   training = tape is not None
   y_views = y_views or [None] * len(dirs)
-  gxs = [d.input_projection(xs) for d in dirs]
+  xs_per = xs if isinstance(xs[0], (list, tuple)) else [xs] * len(dirs)
+  gxs = [d.input_projection(x) for d, x in zip(dirs, xs_per)]
   res = capi.rnn_layer_fwd_multi(
       d0.cell, [dict(gx=gx, wh=d.wh.w16.view(d.G * H, H),
                      bh=d.bh.master if d.bh is not None else None, y=yv, reverse=d.reverse)
@@ -103,8 +105,8 @@ def rnn_directions_forward(dirs, xs, lens, tape, y_views=None, dy_view_fns=None)
         d0.cell, [dict(whT=d.wh.wt16.view(H, d.G * H), dy=dy, y=r[0], gates=r[1], c_seq=r[2],
                        reverse=d.reverse) for d, dy, r in zip(dirs, dys, res)],
         lens, H, d0.forget_bias)
-    for d, r, (dgx, dgr) in zip(dirs, res, grads):
-      d.weight_backward(xs, lens, r[0], dgx, dgr)
+    for d, x, r, (dgx, dgr) in zip(dirs, xs_per, res, grads):
+      d.weight_backward(x, lens, r[0], dgx, dgr)
     for o in outs:
       o.grad = None
 

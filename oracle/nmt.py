@@ -1,0 +1,59 @@
+"""ORACLE (test infrastructure only): CPU fp32 restatement of the RNN NMT model
+(example_configs/text2text/en-de/en-de-nmt-small.py): BidirectionalRNNEncoderWithEmbedding
+(encoders/rnn_encoders.py:221-305) -> RNNDecoderWithAttention, gnmt / gnmt_v2
+(decoders/rnn_decoders.py:147-321, parts/rnns/gnmt.py:32-79) -> BasicSequenceLoss
+(losses/sequence_loss.py:53-114). Dropout is off (keep probabilities 1.0); the dropout
+plumbing of the kernels is pinned separately in tests/test_attn_decoder_gpu.py.
+PARITY STATUS: unpinned by the reference (no value tests). The sub-blocks are
+cross-checked in tests/test_oracle_rnn.py and tests/test_oracle_attn_decoder.py."""
+import torch
+import torch.nn.functional as F
+
+from . import attn_decoder as oad
+from . import rnn as orn
+
+
+def encoder(P, ids, lens):
+  """P['emb'] [V,E]; P['fw'] / P['bw']: list of layers dict(wx [4H,In], wh [4H,H], b [4H])."""
+  x = P["emb"][ids.long()]
+  outs = []
+  for key, rev in (("fw", False), ("bw", True)):
+    if key not in P:
+      continue
+    h = x
+    for lyr in P[key]:
+      h = orn.lstm_tf(h, lens, lyr["wx"].t(), lyr["wh"].t(), lyr["b"], lyr.get("forget_bias", 1.0), rev)
+    outs.append(h)
+  return torch.cat(outs, -1)
+
+
+def decoder_logits(P, enc_out, src_len, tgt, tgt_len, attention_type="gnmt_v2"):
+  """Teacher-forced logits [B,T,V]. P['demb'] [V,E]; P['cell']: dict for
+  oracle.attn_decoder.attention_decoder + 'w_in' [4H,E], 'b0' [4H]; P['upper']: list of
+  dict(wx_h [4H,H], wx_a [4H,M], wh [4H,H], b [4H]); P['proj'] [V,H]."""
+  x = P["demb"][tgt.long()]
+  c = P["cell"]
+  gx0 = x @ c["w_in"].t() + c["b0"]
+  r = oad.attention_decoder(c, gx0, enc_out, src_len, tgt_len, None, None, c.get("forget_bias", 1.0),
+                            "bahdanau_norm")
+  top, ctx = r["y"], r["ctx"]
+  if attention_type == "gnmt":
+    ctx = torch.cat([torch.zeros_like(ctx[:, :1]), ctx[:, :-1]], 1)
+  for lyr in P["upper"]:
+    wx = torch.cat([lyr["wx_h"], lyr["wx_a"]], 1)
+    top = orn.lstm_tf(torch.cat([top, ctx], -1), tgt_len, wx.t(), lyr["wh"].t(), lyr["b"],
+                      lyr.get("forget_bias", 1.0), False)
+  return top @ P["proj"].t()
+
+
+def basic_sequence_loss(logits, tgt, tgt_len, batch_size, average_across_timestep=False):
+  """offset_target_by_one + sequence_mask(len - 1) + sparse softmax xent, sum / batch."""
+  B, T, V = logits.shape
+  cur = min(tgt.shape[1], T) - 1
+  lg = logits[:, :cur]
+  lab = tgt[:, 1:1 + cur].long()
+  mask = (torch.arange(cur)[None, :] < (torch.as_tensor(tgt_len)[:, None] - 1)).to(logits.dtype)
+  xe = F.cross_entropy(lg.reshape(-1, V), lab.reshape(-1), reduction="none").view(B, cur)
+  if average_across_timestep:
+    return (xe * mask).mean()
+  return (xe * mask).sum() / batch_size
