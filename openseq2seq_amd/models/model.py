@@ -207,5 +207,14 @@ class Model(object):
       self._train_op.run()
     return loss
 
+  def copy_weights_from(self, other):
+    """Variable sharing between the train and the eval model (the reference builds the
+    eval graph with reuse=True, utils.py:838-846): same build code => same flat layout."""
+    assert self._store.total == other._store.total
+    self._store.master.copy_(other._store.master)
+    self._store.refresh_compute_copies()
+    for mine, theirs in zip(self._extra_state_tensors(), other._extra_state_tensors()):
+      mine.copy_(theirs)
+
   def global_step(self):
     return self._train_op.read_state()["global_step"]

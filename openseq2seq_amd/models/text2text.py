@@ -36,6 +36,35 @@ class Text2Text(EncoderDecoderModel):
         'decoder_output': dec, 'target_tensors': batch['target_tensors'],
         'loss_scale_dev': scale_dev})
 
+  def infer_batch(self, batch):
+    """eval / infer: encoder + greedy decoding (models/text2text.py:98-190 without the
+    printing). Returns (ids int32 [B, steps], lengths [B])."""
+    assert self.mode in ("eval", "infer")
+    enc = self._encoder.encode({'source_tensors': batch['source_tensors'],
+                                'packed_source': batch.get('packed_source')})
+    dec = self._decoder.decode({'encoder_output': enc})
+    return dec['outputs'][0], dec['final_sequence_lengths']
+
+  def evaluate(self, device=None, max_batches=None):
+    """Greedy-decodes the eval set and scores it against the targets: corpus BLEU-4 (the
+    reference prints "Eval BLUE score", text2text.py:192-225) and exact-match rate."""
+    from ..utils.metrics import corpus_bleu
+    dl = self.get_data_layer()
+    hyps, refs = [], []
+    for n, batch in enumerate(dl.iterate_batches(device or self._device, drop_remainder=False)):
+      if max_batches is not None and n >= max_batches:
+        break
+      ids, lens = self.infer_batch(batch)
+      ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+      tgt, tl = batch['target_tensors'][0].cpu().numpy(), batch['target_tensors'][1].cpu().numpy()
+      for b in range(ids.shape[0]):
+        h = [int(t) for t in ids[b, :lens[b]] if t not in (0, 1, 2)]
+        r = [int(t) for t in tgt[b, :tl[b]] if t not in (0, 1, 2)]
+        hyps.append(h)
+        refs.append(r)
+    exact = sum(1 for h, r in zip(hyps, refs) if h == r) / max(len(hyps), 1)
+    return {"bleu": corpus_bleu(refs, hyps), "exact_match": exact, "samples": len(hyps)}
+
   def _get_num_objects_per_step(self, batch):
     """text2text.py:227-241: source tokens + target tokens."""
     return batch['source_tensors'][1].sum() + batch['target_tensors'][1].sum()

@@ -188,6 +188,10 @@ def create_model(args, base_config, config_module, base_model, hvd, device=None)
     train_config['bench_start'] = args.bench_start if args.bench_start is not None else 10
   if args.mode in ("train", "train_eval"):
     model = base_model(params=train_config, mode="train", hvd=hvd, device=device)
+    if args.mode == "train_eval":
+      # utils.py:838-846: a second model in eval mode sharing the variables
+      model.eval_model = base_model(params=eval_config, mode="eval", hvd=hvd, device=device)
+      model.eval_model.compile()
   elif args.mode == "eval":
     model = base_model(params=eval_config, mode="eval", hvd=hvd, device=device)
   else:

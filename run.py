@@ -23,9 +23,19 @@ def train(model, args):
   bench_start = p.get('bench_start', 10)
   dl = model.get_data_layer()
   rank = model.hvd.rank() if model.hvd else 0
-  batch = dl.synthetic_batch(model._device, seed=1234 + rank)
+  batches = None
+  if hasattr(dl, "has_files") and dl.has_files():   # real line files (e.g. the toy reversal corpus)
+    batches = dl.iterate_batches(model._device, seed=1234 + rank)
+  else:
+    batch = dl.synthetic_batch(model._device, seed=1234 + rank)
+  eval_model = getattr(model, "eval_model", None)
+  eval_steps = p.get('eval_steps', None)
   total_time, total_objects = 0.0, 0.0
   for step in range(max_steps):
+    if batches is not None:
+      batch = next(batches)
+    if eval_model is not None and eval_steps and step > 0 and step % eval_steps == 0:
+      run_eval(model, eval_model, rank)
     torch.cuda.synchronize()
     t0 = time.time()
     loss = model.train_step(batch)
@@ -48,6 +58,15 @@ def train(model, args):
     deco_print("Avg objects per second: {:.3f}".format(total_objects / total_time))
 
 
+def run_eval(model, eval_model, rank):
+  eval_model.copy_weights_from(model)
+  res = eval_model.evaluate()
+  if rank == 0:
+    deco_print("Validation: Eval BLUE score: %.4f  exact match: %.4f  (%d samples)"
+               % (res["bleu"], res["exact_match"], res["samples"]))
+  return res
+
+
 def main():
   args, base_config, base_model, config_module = get_base_config(sys.argv[1:])
   hvd = dist_utils.init_from_env() if base_config.get('use_horovod', False) else None
@@ -55,6 +74,8 @@ def main():
     raise NotImplementedError("mode %s: only the training path is re-hosted so far" % args.mode)
   model = create_model(args, base_config, config_module, base_model, hvd)
   train(model, args)
+  if getattr(model, "eval_model", None) is not None:
+    run_eval(model, model.eval_model, model.hvd.rank() if model.hvd else 0)
 
 
 if __name__ == '__main__':

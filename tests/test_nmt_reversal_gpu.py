@@ -1,0 +1,30 @@
+"""Convergence test on the toy reversal corpus with the en-de-nmt-small architecture
+(BASELINE.json configs[0]) — the reference's own acceptance test for its RNN NMT path is of
+this kind (toy reversal task, BLEU > 0.9: SURVEY.md 4 / 8c). 400 steps of the full config
+through run.py's train loop, then greedy decoding of the dev set."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch):
+  sys.path.insert(0, REPO)
+  import run
+  from openseq2seq_amd.test_utils.create_reversed_examples import create_data
+  from openseq2seq_amd.utils.utils import create_model, get_base_config
+  monkeypatch.chdir(tmp_path)
+  create_data(train_corpus_size=10000, dev_corpus_size=256, test_corpus_size=8,
+              data_path="toy_text_data", seed=0)
+  cfg = os.path.join(REPO, "example_configs/text2text/toy-reversal/nmt-small-reversal.py")
+  args, base_config, base_model, config_module = get_base_config(
+      ["--config_file=" + cfg, "--mode=train_eval", "--max_steps=400", "--print_loss_steps=100"])
+  model = create_model(args, base_config, config_module, base_model, None)
+  run.train(model, args)
+  res = run.run_eval(model, model.eval_model, 0)
+  assert res["samples"] == 256
+  assert res["bleu"] > 0.9, res
