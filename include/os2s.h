@@ -487,6 +487,29 @@ int os2s_attn_decoder_bwd(os2s_stream_t stream, const os2s_attn_decoder_t* d,
                           size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------
+ * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:
+ *   mode 0: tf.losses.mean_squared_error, 1: absolute_difference (l1_norm), both with
+ *           weights = sequence_mask(lens) and SUM_BY_NONZERO_WEIGHTS: sum / (F * sum_b len_b)
+ *   mode 2: masked tf.nn.sigmoid_cross_entropy_with_logits / sum(mask)   (stop token, F = 1)
+ * pred bf16 rows (b,t) at pred + (b*T+t)*ld_pred (F columns used), target fp32 likewise;
+ * loss[0] += weight * term; dpred (same layout as pred, may be NULL) = weight * (*grad_scale_dev)
+ * * d term / d pred. partial: fp32 [os2s_tts_loss_num_parts(B,T)] scratch. lens NULL = no mask.
+ * ---------------------------------------------------------------------- */
+int os2s_tts_loss_num_parts(int B, int T);
+int os2s_tts_loss(os2s_stream_t stream, const uint16_t* pred, long long ld_pred,
+                  const float* target, long long ld_target, const int32_t* lens, int B, int T,
+                  int F, int mode, float weight, const float* grad_scale_dev, float* partial,
+                  float* loss, uint16_t* dpred);
+/* tf.exp on the magnitude branch (decoders/tacotron2_decoder.py:541-542) and its gradient
+ * helper y = a * b; out[b,c] (+)= sum_t x[b,t,c] (gradient of a vector tiled over time:
+ * the style embedding, encoders/tacotron2_encoder.py:168-172). n % 8 == 0. */
+int os2s_exp_fwd(os2s_stream_t stream, const uint16_t* x, long long n, uint16_t* y);
+int os2s_mul_bf16(os2s_stream_t stream, const uint16_t* a, const uint16_t* b, long long n,
+                  uint16_t* y);
+int os2s_sum_time(os2s_stream_t stream, const uint16_t* x, long long ld, int B, int T, int C,
+                  float* out, int accumulate);
+
+/* ------------------------------------------------------------------------
  * conv2d (time x frequency) of DeepSpeech2 (tf.layers.conv2d in conv_bn_actv,
  * encoders/ds2_encoder.py:252-266) on the 1-D implicit-GEMM kernel: activations are
  * flattened to [B, T, F*C]; the frequency convolution becomes the banded channel mixing

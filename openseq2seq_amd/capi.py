@@ -808,3 +808,53 @@ class AttnDecoder(object):
     _lib.check(f(_stream(), _lib.ctypes.byref(d), _lib.ctypes.byref(g), _ptr(ws), n),
                "os2s_attn_decoder_bwd")
     return out
+
+
+# --------------------------------------------------------------------------
+# text-to-speech loss terms and small element-wise ops
+# --------------------------------------------------------------------------
+LOSS_MSE, LOSS_L1, LOSS_SIGMOID_XENT = 0, 1, 2
+
+
+def tts_loss(pred, target, lens, F, mode, weight, loss, grad_scale_dev=None, want_grad=True):
+  """pred bf16 [B,T,ld>=F], target fp32 [B,T,ld_t>=F] (both may be column-slice views);
+  loss fp32 [1] is accumulated. Returns dpred (same shape/strides as a fresh [B,T,ld] tensor;
+  columns >= F untouched/zero) or None."""
+  B, T = pred.shape[0], pred.shape[1]
+  assert pred.stride(2) == 1 and pred.stride(0) == T * pred.stride(1)
+  assert target.stride(2) == 1 and target.stride(0) == T * target.stride(1)
+  dev = pred.device
+  nparts = int(_fn("os2s_tts_loss_num_parts", (c_int, c_int))(B, T))
+  partial = torch.empty(nparts, dtype=torch.float32, device=dev)
+  dpred = torch.zeros((B, T, pred.stride(1)), dtype=torch.bfloat16, device=dev) if want_grad else None
+  f = _fn("os2s_tts_loss", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int,
+                            c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), c_void_p(pred.data_ptr()), pred.stride(1), c_void_p(target.data_ptr()),
+               target.stride(1), _ptr(lens, torch.int32, True), B, T, F, mode, float(weight),
+               _ptr(grad_scale_dev, torch.float32, True), _ptr(partial), _ptr(loss, torch.float32),
+               _ptr(dpred, None, True)), "os2s_tts_loss")
+  return dpred
+
+
+def exp_fwd(x):
+  y = torch.empty_like(x)
+  _lib.check(_fn("os2s_exp_fwd", (c_void_p, c_void_p, c_ll, c_void_p))(
+      _stream(), _ptr(x, torch.bfloat16), x.numel(), _ptr(y)), "os2s_exp_fwd")
+  return y
+
+
+def mul_bf16(a, b):
+  y = torch.empty_like(a)
+  _lib.check(_fn("os2s_mul_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))(
+      _stream(), _ptr(a, torch.bfloat16), _ptr(b, torch.bfloat16), a.numel(), _ptr(y)), "os2s_mul_bf16")
+  return y
+
+
+def sum_time(x, out, accumulate=False):
+  """x bf16 [B,T,C] (may be a channel-slice view) -> out fp32 [B,C] (+)= sum over T."""
+  B, T, C = x.shape
+  assert x.stride(2) == 1 and x.stride(0) == T * x.stride(1)
+  _lib.check(_fn("os2s_sum_time", (c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_int))(
+      _stream(), c_void_p(x.data_ptr()), x.stride(1), B, T, C, _ptr(out, torch.float32),
+      int(accumulate)), "os2s_sum_time")
+  return out

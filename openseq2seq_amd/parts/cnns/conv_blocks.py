@@ -194,3 +194,25 @@ def conv_bn_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.
                  mask_output=True):
   return conv_bn_res_bn_actv(layer, [], x, [], out_lens, activation_fn, training, tape,
                              keep_prob, seed, mask_output)
+
+
+def accumulate_grad(x, g):
+  """x.grad (+)= g for an Act consumed by several ops."""
+  if not x.requires_grad:
+    return
+  if x.grad_init and x.grad is not None:
+    capi.add_bf16(x.grad, g, out=x.grad)
+  else:
+    x.grad, x.grad_init = g, True
+
+
+def reshape_act(x, shape, tape, lens=None):
+  """A view of an Act with another shape ([B,T,C] <-> [B*T,C]); gradients flow back."""
+  v = Act(x.data.view(*shape), lens, requires_grad=x.requires_grad)
+  if tape is not None and x.requires_grad:
+    def backward():
+      if v.grad is not None:
+        accumulate_grad(x, v.grad.reshape(x.data.shape))
+      v.grad = None
+    tape.record(backward)
+  return v
