@@ -437,7 +437,8 @@ int os2s_rnn_layer_bwd_multi(os2s_stream_t stream, int cell, int ndir,
  * tgt_len (or NULL): steps t >= tgt_len[b] leave sample b untouched (impute_finished).
  * Dropout masks come from the library's counter hash: attention-input dropout indexes the
  * logical [B, T+1, M] tensor (row t+1 = attention_t), output dropout [B, T, H] per layer.
- * Limits: H % 8 == 0, M % 8 == 0, U % 128 == 0 and <= 512, loc_f <= 64.
+ * Limits: H % 8 == 0, M % 8 == 0, U % 128 == 0 and <= 512; location-sensitive mode:
+ * U == 128, loc_k <= 32.
  * ---------------------------------------------------------------------- */
 typedef struct os2s_attn_decoder {
   int B, T, S, L, H, M, U;
@@ -452,6 +453,7 @@ typedef struct os2s_attn_decoder {
   const uint16_t* wq;           /* bf16 [U, H] */
   const float* v; const float* g; const float* b;                 /* [U], [1], [U] */
   const float* conv_w; const float* conv_b; const float* dense_w; /* [K,F], [F], [F,U] */
+  float* loc_ws;                /* mode 2: fp32 scratch [(K+1)*U] (folded location filter) */
   /* inputs */
   const uint16_t* gx0;          /* bf16 [B, T, 4H] */
   const uint16_t* keys;         /* bf16 [B, S, U] */
@@ -465,18 +467,20 @@ typedef struct os2s_attn_decoder {
 } os2s_attn_decoder_t;
 
 /* Backward through all T steps (t_begin = 0, t_end = T). Inputs: dy_top / dctx_ext = gradients
- * of the y_top / ctx rows (either may be NULL), wcatT[l] = bf16 [Kc_l, 4H] transposed
- * weights. Outputs: dg[l] bf16 [B,T,4H] gate gradients (caller: dWcat_l = dg_l^T cat_l,
+ * of the y_top / ctx rows (either may be NULL), wcatT[l] = bf16 [Kc_l, 4H] and wqT = bf16
+ * [H, U] transposed weights. Outputs: dg[l] bf16 [B,T,4H] gate gradients (caller: dWcat_l = dg_l^T cat_l,
  * d gx0 = dg_0), dq_seq bf16 [B,T,U] (dWq = dq^T y_top, db = column sums), dkeys fp32
- * [B,S,U], dmem bf16 [B,S,M] = gradient of `values`, dctx_seq bf16 [B,T,M] scratch; the
+ * [B,S,U], dmem bf16 [B,S,M] = gradient of `values`; dctx_seq bf16 [B,T,M] and dpre_seq bf16
+ * [B,T,S,U] (per-step score gradients, reduced over T into dkeys after the loop) are scratch; the
  * small score parameters are ACCUMULATED into dv [U], dg_scalar [1], dconv_w, dconv_b,
  * ddense_w (fp32). */
 typedef struct os2s_attn_decoder_grads {
   const uint16_t* wcatT[2];
+  const uint16_t* wqT;          /* bf16 [H, U] transposed query layer */
   const uint16_t* dy_top; long long dy_top_bs, dy_top_ts;
   const uint16_t* dctx_ext; long long dctx_bs, dctx_ts;
   uint16_t* dg[2];
-  uint16_t* dq_seq; uint16_t* dctx_seq; float* dkeys; uint16_t* dmem;
+  uint16_t* dq_seq; uint16_t* dctx_seq; uint16_t* dpre_seq; float* dkeys; uint16_t* dmem;
   float* dv; float* dg_scalar; float* dconv_w; float* dconv_b; float* ddense_w;
 } os2s_attn_decoder_grads_t;
 

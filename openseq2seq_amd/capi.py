@@ -690,7 +690,7 @@ class _AttnDecoder(_lib.ctypes.Structure):
       ("out_keep", c_float), ("out_seed", c_ull * 2),
       ("wcat", c_void_p * 2), ("bias", c_void_p * 2), ("wq", c_void_p),
       ("v", c_void_p), ("g", c_void_p), ("b", c_void_p),
-      ("conv_w", c_void_p), ("conv_b", c_void_p), ("dense_w", c_void_p),
+      ("conv_w", c_void_p), ("conv_b", c_void_p), ("dense_w", c_void_p), ("loc_ws", c_void_p),
       ("gx0", c_void_p), ("keys", c_void_p), ("values", c_void_p),
       ("src_len", c_void_p), ("tgt_len", c_void_p),
       ("cat", c_void_p * 2), ("c_seq", c_void_p * 2), ("gates", c_void_p * 2),
@@ -700,11 +700,11 @@ class _AttnDecoder(_lib.ctypes.Structure):
 
 
 class _AttnDecoderGrads(_lib.ctypes.Structure):
-  _fields_ = [("wcatT", c_void_p * 2),
+  _fields_ = [("wcatT", c_void_p * 2), ("wqT", c_void_p),
               ("dy_top", c_void_p), ("dy_top_bs", c_ll), ("dy_top_ts", c_ll),
               ("dctx_ext", c_void_p), ("dctx_bs", c_ll), ("dctx_ts", c_ll),
               ("dg", c_void_p * 2), ("dq_seq", c_void_p), ("dctx_seq", c_void_p),
-              ("dkeys", c_void_p), ("dmem", c_void_p), ("dv", c_void_p), ("dg_scalar", c_void_p),
+              ("dpre_seq", c_void_p), ("dkeys", c_void_p), ("dmem", c_void_p), ("dv", c_void_p), ("dg_scalar", c_void_p),
               ("dconv_w", c_void_p), ("dconv_b", c_void_p), ("ddense_w", c_void_p)]
 
 
@@ -727,6 +727,7 @@ class AttnDecoder(object):
     self.c_seq = [z((B, T, H), f32) for l in range(L)]
     self.gates = [z((B, T, 4 * H), bf) if save else None for l in range(L)]
     self.cum_seq = z((B, T + 1, S), f32) if mode == SCORE_LOCATION else None
+    self.loc_ws = z(((loc_k + 1) * U,), f32) if mode == SCORE_LOCATION else None
     self.align_seq = z((B, T, S), f32)
     self.q_seq = z((B, T, U), f32)
     self.y_top = y_top if y_top is not None else z((B, T, H), bf)
@@ -762,6 +763,7 @@ class AttnDecoder(object):
     for k in ("gx0", "keys", "values", "src_len", "tgt_len"):
       setattr(d, k, _addr(i[k]))
     d.cum_seq, d.align_seq, d.q_seq = _addr(self.cum_seq), _addr(self.align_seq), _addr(self.q_seq)
+    d.loc_ws = _addr(self.loc_ws)
     d.y_top, d.y_top_bs, d.y_top_ts = self.y_top.data_ptr(), self.y_top.stride(0), self.y_top.stride(1)
     d.ctx, d.ctx_bs, d.ctx_ts = self.ctx.data_ptr(), self.ctx.stride(0), self.ctx.stride(1)
     return d
@@ -778,7 +780,7 @@ class AttnDecoder(object):
     f = _fn("os2s_attn_decoder_fwd", (c_void_p, c_void_p))
     _lib.check(f(_stream(), _lib.ctypes.byref(d)), "os2s_attn_decoder_fwd")
 
-  def backward(self, wcatT, dy_top=None, dctx_ext=None, dv=None, dg=None, dconv_w=None,
+  def backward(self, wcatT, wqT, dy_top=None, dctx_ext=None, dv=None, dg=None, dconv_w=None,
                dconv_b=None, ddense_w=None):
     """Returns dict(dg=[L x bf16 [B,T,4H]], dq_seq, dkeys fp32, dmem bf16)."""
     B, T, S, L, H, M, U = (self.dims[k] for k in "BTSLHMU")
@@ -789,7 +791,10 @@ class AttnDecoder(object):
                dkeys=torch.empty((B, S, U), dtype=torch.float32, device=dev),
                dmem=torch.empty((B, S, M), dtype=bf, device=dev))
     dctx_seq = torch.empty((B, T, M), dtype=bf, device=dev)
+    dpre_seq = torch.empty((B, T, S, U), dtype=bf, device=dev)
     g = _AttnDecoderGrads()
+    assert wqT.dtype == bf and wqT.is_contiguous() and wqT.shape == (H, U)
+    g.wqT = wqT.data_ptr()
     for l in range(2):
       g.wcatT[l] = _addr(wcatT[l]) if l < L else None
       g.dg[l] = _addr(out["dg"][l]) if l < L else None
@@ -799,6 +804,7 @@ class AttnDecoder(object):
       g.dctx_ext, g.dctx_bs, g.dctx_ts = dctx_ext.data_ptr(), dctx_ext.stride(0), dctx_ext.stride(1)
     g.dq_seq, g.dctx_seq, g.dkeys, g.dmem = (_addr(out["dq_seq"]), _addr(dctx_seq),
                                              _addr(out["dkeys"]), _addr(out["dmem"]))
+    g.dpre_seq = _addr(dpre_seq)
     g.dv, g.dg_scalar = _addr(dv), _addr(dg)
     g.dconv_w, g.dconv_b, g.ddense_w = _addr(dconv_w), _addr(dconv_b), _addr(ddense_w)
     d = self._desc(0, T)

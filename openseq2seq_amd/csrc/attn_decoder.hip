@@ -29,7 +29,7 @@
 namespace os2s {
 
 constexpr int kAdWaves = 8;
-constexpr int kAttnThreads = 256;
+constexpr int kAttnThreads = 512;
 
 __device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
 
@@ -51,82 +51,66 @@ struct AdCellFwd {
   unsigned long long out_seed;
 };
 
+// One workgroup = 8 hidden units x 32 samples: the 32 tile rows are (gate, unit) pairs
+// (row = 8*gate + unit), so H/8 workgroups stream disjoint 32-row slices of the weights and
+// after the split-K reduction a lane owns all four gates of one (unit, sample).
 __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_fwd_kernel(AdCellFwd p) {
   __shared__ float red[kAdWaves * 16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
   const int H = p.H;
-  f32x16 accw[4];
+  f32x16 accw;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accw[g][e] = 0.f;
-  tile_gemm_splitk<4, kAdWaves, 2>(p.w, p.Kc, H, j0, H, p.cat + (long long)p.t * p.Kc,
-                                   (long long)(p.T + 1) * p.Kc, b0, p.B, p.Kc, accw);
-  float acc[4][4];
-  tile_reduce_quarters<4, kAdWaves>(accw, red, acc);
+  for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+  {
+    const int g = l31 >> 3, uu = min(j0 + (l31 & 7), H - 1);
+    const bf16_t* wrow = p.w + ((long long)g * H + uu) * p.Kc;
+    const int brow = b0 + l31;
+    const bf16_t* irow = brow < p.B ? p.cat + ((long long)brow * (p.T + 1) + p.t) * p.Kc : nullptr;
+    tile_gemm_prefetch<kAdWaves, 16>(wrow, irow, p.Kc, accw, p.w);
+  }
+  float pre[4];
+  tile_reduce_units<kAdWaves>(accw, red, pre);
   if (wave >= 4) return;
   const int b = b0 + l31;
   if (b >= p.B) return;
   if (p.lens && p.t >= p.lens[b]) return;   // finished sample: buffers stay zero
-  const int j = j0 + 8 * wave + 4 * lhi;
+  const int j = j0 + wave + 4 * lhi;
   if (j >= H) return;
   const long long row = (long long)b * p.T + p.t;
-  float pre[4][4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pre[g][e] = acc[g][e];
-    if (p.gx) {
-      const u32x2 v = *reinterpret_cast<const u32x2*>(p.gx + row * (4 * H) + (long long)g * H + j);
-      pre[g][0] += bflo(v[0]); pre[g][1] += bfhi(v[0]); pre[g][2] += bflo(v[1]); pre[g][3] += bfhi(v[1]);
-    }
-    if (p.bias) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pre[g][e] += p.bias[g * H + j + e];
-    }
+    if (p.gx) pre[g] += bf2f(p.gx[row * (4 * H) + (long long)g * H + j]);
+    if (p.bias) pre[g] += p.bias[g * H + j];
   }
-  f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
-  if (p.t > 0) cprev = *reinterpret_cast<const f32x4*>(p.c_seq + (row - 1) * H + j);
-  f32x4 cn;
-  float hn[4], sv[4][4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float ig = sigmoidf_(pre[0][e]), gg = tanhf(pre[1][e]);
-    const float fg = sigmoidf_(pre[2][e] + p.forget_bias), og = sigmoidf_(pre[3][e]);
-    cn[e] = cprev[e] * fg + ig * gg;
-    hn[e] = tanhf(cn[e]) * og;
-    sv[0][e] = ig; sv[1][e] = fg; sv[2][e] = gg; sv[3][e] = og;
-  }
-  *reinterpret_cast<f32x4*>(p.c_seq + row * H + j) = cn;
+  const float cprev = p.t > 0 ? p.c_seq[(row - 1) * H + j] : 0.f;
+  const float ig = sigmoidf_(pre[0]), gg = tanhf(pre[1]);
+  const float fg = sigmoidf_(pre[2] + p.forget_bias), og = sigmoidf_(pre[3]);
+  const float cn = cprev * fg + ig * gg;
+  float hn = tanhf(cn) * og;
+  p.c_seq[row * H + j] = cn;
   if (p.gates) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      u32x2 pk;
-      pk[0] = pack2bf(sv[g][0], sv[g][1]);
-      pk[1] = pack2bf(sv[g][2], sv[g][3]);
-      *reinterpret_cast<u32x2*>(p.gates + row * (4 * H) + (long long)g * H + j) = pk;
-    }
+    bf16_t* gp = p.gates + row * (4 * H) + j;
+    gp[0] = f2bf(ig); gp[H] = f2bf(fg); gp[2 * H] = f2bf(gg); gp[3 * H] = f2bf(og);
   }
-  u32x2 hr;
-  hr[0] = pack2bf(hn[0], hn[1]);
-  hr[1] = pack2bf(hn[2], hn[3]);
-  *reinterpret_cast<u32x2*>(p.h_next + ((long long)b * (p.T + 1) + p.t + 1) * p.Kc + j) = hr;
+  p.h_next[((long long)b * (p.T + 1) + p.t + 1) * p.Kc + j] = f2bf(hn);
   if (p.out_keep < 1.f) {
     const unsigned long long idx = (unsigned long long)row * H + j;
-    const uint32_t bits = dropout_bits8(p.out_seed, idx >> 3, p.out_keep) >> (j & 4);
-    const float inv = 1.f / p.out_keep;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) hn[e] = ((bits >> e) & 1u) ? hn[e] * inv : 0.f;
-    hr[0] = pack2bf(hn[0], hn[1]);
-    hr[1] = pack2bf(hn[2], hn[3]);
+    const uint32_t bits = dropout_bits8(p.out_seed, idx >> 3, p.out_keep);
+    hn = ((bits >> (j & 7)) & 1u) ? hn / p.out_keep : 0.f;
   }
-  *reinterpret_cast<u32x2*>(p.y + (long long)b * p.y_bs + (long long)p.t * p.y_ts + j) = hr;
+  p.y[(long long)b * p.y_bs + (long long)p.t * p.y_ts + j] = f2bf(hn);
 }
 
 // ------------------------------------------------------------------ attention (shared)
+// Location-sensitive attention: Conv1D(K taps -> F filters, bias) followed by the bias-free
+// dense F -> U has no non-linearity in between, so per call the two are folded into ONE
+// filter  Wck[k,u] = sum_f conv_w[k,f] dense_w[f,u],  bd[u] = sum_f conv_b[f] dense_w[f,u]:
+//   location[s,u] = sum_k cum[s + k - padl] Wck[k,u] + bd[u]
+// (F x fewer multiply-adds in the loop, Wck lives in registers: lane owns 2 units). The
+// gradient w.r.t. conv_w / conv_b / dense_w is recovered from dWck, d(bd) after the loop.
 struct AdAttn {
-  int B, T, S, H, M, U, t, mode, use_bias, loc_k, loc_f, Kc0, last;
+  int B, T, S, H, M, U, t, mode, use_bias, loc_k, Kc0, last;
   const int32_t* src_len;
   const int32_t* tgt_len;
   const bf16_t* yq;      // query input rows: yq + b*yq_bs + t*yq_ts
@@ -135,7 +119,7 @@ struct AdAttn {
   const bf16_t* keys;    // [B, S, U]
   const bf16_t* values;  // [B, S, M]
   const float* v; const float* g; const float* bias;
-  const float* conv_w; const float* conv_b; const float* dense_w;
+  const float* wck;      // [K, U] folded location filter followed by bd [U]   (mode 2)
   float* cum_seq;        // [B, T+1, S]
   float* align_seq;      // [B, T, S]
   float* q_seq;          // [B, T, U]
@@ -149,53 +133,62 @@ struct AdAttn {
   const float* dattn;    // [B, M] gradient w.r.t. the attention part of cat0[t+1] (null when last)
   bf16_t* dctx_seq;      // [B, T, M] total context gradient (for the dvalues pass)
   float* dcum;           // [B, S] carry (mode 2)
-  float* dkeys;          // [B, S, U] fp32 accumulator
+  bf16_t* dpre_seq;      // [B, T, S, U] score pre-activation gradients (dkeys = sum over T)
   bf16_t* dq_seq;        // [B, T, U]
   float* dhq;            // [B, H]
   float* dnv_acc;        // [B, U]
-  float* ddense_acc;     // [B, F, U]
-  float* dconvw_acc;     // [B, K, F]
-  float* dconvb_acc;     // [B, F]
+  float* dbd_acc;        // [B, U]      (mode 2)
+  float* dwck_acc;       // [B, K, U]   (mode 2)
 };
 
+constexpr int kAttnWaves = kAttnThreads / 64;
+
+// development aid (build with -DOS2S_ATTN_PHASE_TIMERS): phase timestamps (s_memtime) of
+// workgroup 0, read by os2s_debug_attn_phases / tools/bench_attn_decoder.py
+#ifdef OS2S_ATTN_PHASE_TIMERS
+__device__ long long g_attn_dbg[2][16];
+#define AD_TICK(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_attn_dbg[k][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define AD_TICK(k, i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float block_sum(float x, float* red) {
-  x = wave_sum(x);
+  x = wave_sum_dpp(x);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int w = 0; w < kAttnThreads / 64; ++w) s += red[w];
+  for (int w = 0; w < kAttnWaves; ++w) s += red[w];
   return s;
 }
 __device__ __forceinline__ float block_max(float x, float* red) {
-  x = wave_max(x);
+  x = wave_max_dpp(x);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
   __syncthreads();
   float s = red[0];
 #pragma unroll
-  for (int w = 1; w < kAttnThreads / 64; ++w) s = fmaxf(s, red[w]);
+  for (int w = 1; w < kAttnWaves; ++w) s = fmaxf(s, red[w]);
   return s;
 }
 
 // LDS carve-up (floats) shared by the forward and backward attention kernels
 struct AttnLds {
-  float *hq, *q, *nv, *bs, *e, *red, *cum, *convw, *convb, *locfeat, *densew, *scratch;
+  float *hq, *q, *nv, *bs, *e, *red, *cum, *scratch;
+  uint32_t* keys;   // [S][U/2] bf16 pairs of this sample's keys (staged once per launch)
 };
-__host__ __device__ inline size_t attn_lds_floats(int H, int M, int U, int S, int mode, int K, int F,
-                                                  bool bwd) {
-  size_t n = (size_t)H + 3 * U + S + 64;
-  if (mode == 2) n += (size_t)(S + K) + (size_t)K * F + F + (size_t)S * F + (size_t)F * U;
-  size_t scratch = (size_t)2 * M;                 // forward: context partials (<= 2 x M used)
-  if (bwd) {
-    size_t s2 = (size_t)M + 2 * S + 8 * U;        // dctx, dalign, de, per-wave dq/dnv partials
-    if (mode == 2) s2 += (size_t)S * F + (size_t)F * U;   // dlocfeat, ddense
-    scratch = s2;
-  }
+constexpr int kCtxSplitMax = 8;
+constexpr int kLocKMax = 32;   // location filter taps held in registers (U == 128: 2 units / lane)
+__host__ __device__ inline size_t attn_lds_floats(int H, int M, int U, int S, int mode, int K, bool bwd) {
+  size_t n = (size_t)H + 3 * U + S + 64 + (size_t)S * U / 2;
+  if (mode == 2) n += (size_t)(S + kLocKMax);
+  size_t scratch = (size_t)kCtxSplitMax * M;     // forward: context partials
+  if (bwd)   // dctx, dalign, de, dcum, dq/dnv partials, dWck
+    scratch = (size_t)M + 3 * S + 2 * (size_t)kAttnWaves * U + (mode == 2 ? (size_t)K * U : 0);
   return n + scratch + 64;
 }
-__device__ __forceinline__ AttnLds attn_lds_carve(float* base, int H, int U, int S, int mode, int K, int F) {
+__device__ __forceinline__ AttnLds attn_lds_carve(float* base, int H, int U, int S, int mode, int K) {
   AttnLds l;
   l.hq = base; base += H;
   l.q = base; base += U;
@@ -203,19 +196,14 @@ __device__ __forceinline__ AttnLds attn_lds_carve(float* base, int H, int U, int
   l.bs = base; base += U;
   l.e = base; base += S;
   l.red = base; base += 64;
-  l.cum = l.convw = l.convb = l.locfeat = l.densew = nullptr;
-  if (mode == 2) {
-    l.cum = base; base += S + K;
-    l.convw = base; base += K * F;
-    l.convb = base; base += F;
-    l.locfeat = base; base += S * F;
-    l.densew = base; base += F * U;
-  }
+  l.cum = nullptr;
+  if (mode == 2) { l.cum = base; base += S + kLocKMax; }
+  l.keys = reinterpret_cast<uint32_t*>(base); base += (size_t)S * U / 2;
   l.scratch = base;
   return l;
 }
 
-// score parameters -> LDS: nv (normalised v for mode 1), bs (bias or zeros)
+// score parameters -> LDS: nv (normalised v for mode 1), bs (bias (+ folded location bias))
 __device__ __forceinline__ void attn_load_score_params(const AdAttn& p, const AttnLds& l) {
   const int tid = threadIdx.x, U = p.U;
   float ss = 0.f;
@@ -223,7 +211,9 @@ __device__ __forceinline__ void attn_load_score_params(const AdAttn& p, const At
     const float v = p.v[u];
     l.nv[u] = v;
     ss += v * v;
-    l.bs[u] = ((p.mode == 1 || (p.mode == 2 && p.use_bias)) && p.bias) ? p.bias[u] : 0.f;
+    float b = ((p.mode == 1 || (p.mode == 2 && p.use_bias)) && p.bias) ? p.bias[u] : 0.f;
+    if (p.mode == 2) b += p.wck[p.loc_k * U + u];
+    l.bs[u] = b;
   }
   if (p.mode == 1) {
     const float tot = block_sum(ss, l.red);
@@ -233,42 +223,31 @@ __device__ __forceinline__ void attn_load_score_params(const AdAttn& p, const At
   __syncthreads();
 }
 
-// location features of the cumulative alignments (state BEFORE step t) -> l.locfeat [S][F]
-__device__ __forceinline__ void attn_location_features(const AdAttn& p, const AttnLds& l, int b) {
-  const int tid = threadIdx.x, S = p.S, K = p.loc_k, F = p.loc_f, U = p.U;
-  const int padl = (K - 1) / 2;
+// this sample's keys -> LDS with 16-byte coalesced loads (all in flight at once; the latency
+// hides behind the query projection)
+__device__ __forceinline__ void attn_stage_keys(const AdAttn& p, const AttnLds& l, int b, int slen) {
+  const int n16 = slen * p.U / 8;
+  const u32x4* src = reinterpret_cast<const u32x4*>(p.keys + (long long)b * p.S * p.U);
+  u32x4* dst = reinterpret_cast<u32x4*>(l.keys);
+  for (int i = threadIdx.x; i < n16; i += kAttnThreads) dst[i] = src[i];
+}
+
+// cumulative alignments (state BEFORE step t), zero-padded for the SAME convolution
+__device__ __forceinline__ void attn_load_cum(const AdAttn& p, const AttnLds& l, int b) {
+  const int S = p.S, K = p.loc_k, padl = (K - 1) / 2;
   const float* cum = p.cum_seq + ((long long)b * (p.T + 1) + p.t) * S;
-  for (int i = tid; i < S + K; i += kAttnThreads) {
+  for (int i = threadIdx.x; i < S + kLocKMax; i += kAttnThreads) {
     const int s = i - padl;
     l.cum[i] = (s >= 0 && s < S) ? cum[s] : 0.f;
   }
-  for (int i = tid; i < K * F; i += kAttnThreads) l.convw[i] = p.conv_w[i];
-  for (int i = tid; i < F; i += kAttnThreads) l.convb[i] = p.conv_b[i];
-  for (int i = tid; i < F * U; i += kAttnThreads) l.densew[i] = p.dense_w[i];
-  __syncthreads();
-  for (int i = tid; i < S * F; i += kAttnThreads) {
-    const int s = i / F, f = i - s * F;
-    float a = l.convb[f];
-    for (int k = 0; k < K; ++k) a += l.cum[s + k] * l.convw[k * F + f];
-    l.locfeat[i] = a;
-  }
-  __syncthreads();
 }
 
-// pre-activation of the score for (s, u pair) handled by this lane
+// pre-activation of the score for (s, unit pair u, u+1) without the location term
 __device__ __forceinline__ void attn_pre2(const AdAttn& p, const AttnLds& l, int b, int s, int u,
                                           float& x0, float& x1) {
-  const uint32_t kv = *reinterpret_cast<const uint32_t*>(p.keys + ((long long)b * p.S + s) * p.U + u);
+  const uint32_t kv = l.keys[(s * p.U + u) >> 1];
   x0 = bflo(kv) + l.q[u] + l.bs[u];
   x1 = bfhi(kv) + l.q[u + 1] + l.bs[u + 1];
-  if (p.mode == 2) {
-    const int F = p.loc_f;
-    for (int f = 0; f < F; ++f) {
-      const float lf = l.locfeat[s * F + f];
-      x0 += lf * l.densew[f * p.U + u];
-      x1 += lf * l.densew[f * p.U + u + 1];
-    }
-  }
 }
 
 // ------------------------------------------------------------------ attention forward
@@ -276,9 +255,10 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
   extern __shared__ float lds_raw[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (p.tgt_len && p.t >= p.tgt_len[b]) return;
-  const int H = p.H, M = p.M, U = p.U, S = p.S;
-  const AttnLds l = attn_lds_carve(lds_raw, H, U, S, p.mode, p.loc_k, p.loc_f);
+  const int H = p.H, M = p.M, U = p.U, S = p.S, K = p.loc_k;
+  const AttnLds l = attn_lds_carve(lds_raw, H, U, S, p.mode, K);
   const int slen = min(max(p.src_len[b], 0), S);
+  AD_TICK(0, 0);
   // query input
   const bf16_t* yq = p.yq + (long long)b * p.yq_bs + (long long)p.t * p.yq_ts;
   for (int h8 = tid; h8 < H / 8; h8 += kAttnThreads) {
@@ -286,25 +266,40 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { l.hq[h8 * 8 + 2 * e] = bflo(v[e]); l.hq[h8 * 8 + 2 * e + 1] = bfhi(v[e]); }
   }
+  attn_stage_keys(p, l, b, slen);
+  if (p.mode == 2) attn_load_cum(p, l, b);
   attn_load_score_params(p, l);   // ends with a barrier
-  // q[u] = hq . Wq[u, :]
-  for (int u0 = wave * 4; u0 < U; u0 += 16) {
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int h = lane * 8; h < H; h += 512) {
-      u32x4 wv[4];
+  AD_TICK(0, 1);
+  // q[u] = hq . Wq[u, :]  — 8 units per wave per batch, all their loads in flight together
+  constexpr int UB = 8;
+  for (int u0 = wave * UB; u0 < U; u0 += UB * kAttnWaves) {
+    float part[UB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        wv[i] = (u0 + i < U) ? *reinterpret_cast<const u32x4*>(p.wq + (long long)(u0 + i) * H + h)
-                             : u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < UB; ++i) part[i] = 0.f;
+    for (int h = lane * 8; h < H; h += 1024) {
+      u32x4 wv[UB][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < UB; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          part[i] += bflo(wv[i][e]) * l.hq[h + 2 * e] + bfhi(wv[i][e]) * l.hq[h + 2 * e + 1];
+        for (int hh = 0; hh < 2; ++hh)
+          // unconditional (clamped) loads: a load under a branch is waited for at the join,
+          // which would serialise the round trips
+          wv[i][hh] = *reinterpret_cast<const u32x4*>(p.wq + (long long)min(u0 + i, U - 1) * H +
+                                                      min(h + 512 * hh, H - 8));
+#pragma unroll
+      for (int i = 0; i < UB; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          if (h + 512 * hh < H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              part[i] += bflo(wv[i][hh][e]) * l.hq[h + 512 * hh + 2 * e] +
+                         bfhi(wv[i][hh][e]) * l.hq[h + 512 * hh + 2 * e + 1];
+          }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float s = wave_sum(part[i]);
+    for (int i = 0; i < UB; ++i) {
+      const float s = wave_sum_dpp(part[i]);
       if (lane == 0 && u0 + i < U) {
         l.q[u0 + i] = s;
         p.q_seq[((long long)b * p.T + p.t) * U + u0 + i] = s;
@@ -312,19 +307,63 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
     }
   }
   __syncthreads();
-  if (p.mode == 2) attn_location_features(p, l, b);
-  // scores
-  for (int s = wave; s < slen; s += kAttnThreads / 64) {
-    float part = 0.f;
-    for (int u = 2 * lane; u < U; u += 128) {
-      float x0, x1;
-      attn_pre2(p, l, b, s, u, x0, x1);
-      part += l.nv[u] * tanh_fast(x0) + l.nv[u + 1] * tanh_fast(x1);
+  AD_TICK(0, 2);
+  // scores: one wave per source position, a lane owns unit pairs
+  if (p.mode == 2) {
+    float wk[kLocKMax][2];
+#pragma unroll
+    for (int k = 0; k < kLocKMax; ++k) {
+      wk[k][0] = wk[k][1] = 0.f;
+      if (k < K) {
+        const f32x2 w = *reinterpret_cast<const f32x2*>(p.wck + (long long)k * U + 2 * lane);
+        wk[k][0] = w[0]; wk[k][1] = w[1];
+      }
     }
-    part = wave_sum(part);
-    if (lane == 0) l.e[s] = part;
+    // a wave owns a contiguous range of source positions and slides a 32-entry register
+    // window over the padded cumulative alignments: slot (j + k) & 31 holds cum[s + k] at the
+    // j-th step of a 32-step block, so each step costs ONE new LDS read
+    const int chunk = (slen + kAttnWaves - 1) / kAttnWaves;
+    const int c0 = wave * chunk, c1 = min(c0 + chunk, slen);
+    const float qb0 = l.q[2 * lane] + l.bs[2 * lane], qb1 = l.q[2 * lane + 1] + l.bs[2 * lane + 1];
+    const float nv0 = l.nv[2 * lane], nv1 = l.nv[2 * lane + 1];
+    if (c0 < c1) {
+      float cw[kLocKMax];
+#pragma unroll
+      for (int k = 0; k < kLocKMax; ++k) cw[k] = l.cum[c0 + k];
+      for (int s0 = c0; s0 < c1; s0 += kLocKMax) {
+#pragma unroll
+        for (int j = 0; j < kLocKMax; ++j) {
+          const int s = s0 + j;
+          if (s < c1) {
+            const uint32_t kv = l.keys[(s * U) / 2 + lane];
+            float x0 = bflo(kv) + qb0, x1 = bfhi(kv) + qb1;
+#pragma unroll
+            for (int k = 0; k < kLocKMax; ++k) {
+              x0 += cw[(j + k) & 31] * wk[k][0];
+              x1 += cw[(j + k) & 31] * wk[k][1];
+            }
+            float part = nv0 * tanh_fast(x0) + nv1 * tanh_fast(x1);
+            part = wave_sum_dpp(part);
+            if (lane == 0) l.e[s] = part;
+            cw[j & 31] = s < S ? l.cum[s + kLocKMax] : 0.f;
+          }
+        }
+      }
+    }
+  } else {
+    for (int s = wave; s < slen; s += kAttnWaves) {
+      float part = 0.f;
+      for (int u = 2 * lane; u < U; u += 128) {
+        float x0, x1;
+        attn_pre2(p, l, b, s, u, x0, x1);
+        part += l.nv[u] * tanh_fast(x0) + l.nv[u + 1] * tanh_fast(x1);
+      }
+      part = wave_sum_dpp(part);
+      if (lane == 0) l.e[s] = part;
+    }
   }
   __syncthreads();
+  AD_TICK(0, 3);
   // masked softmax over s < slen
   float mx = -INFINITY;
   for (int s = tid; s < slen; s += kAttnThreads) mx = fmaxf(mx, l.e[s]);
@@ -348,16 +387,17 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
     }
   }
   __syncthreads();
-  // context = sum_s align[s] * values[b, s, :]
+  AD_TICK(0, 4);
+  // context = sum_s align[s] * values[b, s, :]: 8-column groups x nsplit slices of s
   const int CG = min(M / 8, kAttnThreads);
-  const int nsplit = min(kAttnThreads / CG, 2);
+  const int nsplit = min(kAttnThreads / CG, kCtxSplitMax);
   float* part = l.scratch;   // [nsplit][M]
   for (int c0 = 0; c0 < M / 8; c0 += CG) {
     const int cg = c0 + tid % CG, sp = tid / CG;
     if (sp < nsplit && cg < M / 8) {
       float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const bf16_t* vp = p.values + (long long)b * S * M + cg * 8;
-#pragma unroll 4
+#pragma unroll 16
       for (int s = sp; s < slen; s += nsplit) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(vp + (long long)s * M);
         const float a = l.e[s];
@@ -369,14 +409,15 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
     }
   }
   __syncthreads();
+  AD_TICK(0, 5);
   bf16_t* ctx = p.ctx + (long long)b * p.ctx_bs + (long long)p.t * p.ctx_ts;
   bf16_t* cat = p.cat0 + ((long long)b * (p.T + 1) + p.t + 1) * p.Kc0;
   for (int m8 = tid; m8 < M / 8; m8 += kAttnThreads) {
     float c8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      c8[e] = part[m8 * 8 + e];
-      if (nsplit == 2) c8[e] += part[M + m8 * 8 + e];
+      c8[e] = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) c8[e] += part[sp * M + m8 * 8 + e];
     }
     u32x4 o;
 #pragma unroll
@@ -393,6 +434,7 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
     }
     *reinterpret_cast<u32x4*>(cat + m8 * 8) = o;
   }
+  AD_TICK(0, 6);
 }
 
 // ------------------------------------------------------------------ d(attention input) GEMM
@@ -403,39 +445,106 @@ struct AdDattn {
   long long ld;
   float* out;           // [B, M]
 };
-__global__ __launch_bounds__(64 * kAdWaves) void ad_dattn_kernel(AdDattn p) {
-  __shared__ float red[kAdWaves * 16 * 64];
+// Backward GEMMs: 32-row tiles, the reduction split over 16 waves so that every load of a
+// wave (one 16-wide k-slice per 256 of K) is in flight at once.
+constexpr int kBwdWaves = 16;
+
+// sum the partial tiles of the 16 waves; wave q < 4 receives rows 8q + 4*(lane>>5) + e
+// (e < 4) of the tile: out[e] += sum_w acc_w[4q + e]. Two passes of 8 registers keep the
+// LDS buffer at 32 KB. `red`: kBwdWaves*8*64 floats.
+__device__ __forceinline__ void tile_reduce_quarters16(const f32x16& acc, float* red, float (&out)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[(wave * 8 + r) * 64 + lane] = acc[ps * 8 + r];
+    __syncthreads();
+    if ((wave >> 1) == ps && wave < 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < kBwdWaves; ++w2) s += red[(w2 * 8 + 4 * (wave & 1) + e) * 64 + lane];
+        out[e] += s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64 * kBwdWaves) void ad_dattn_kernel(AdDattn p) {
+  __shared__ float red[kBwdWaves * 8 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  f32x16 accw[1];
+  f32x16 accw;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) accw[0][e] = 0.f;
-  tile_gemm_splitk<1, kAdWaves, 4>(p.wT, p.K, 0, j0, p.M, p.dg, p.ld, b0, p.B, p.K, accw);
-  float acc[1][4];
-  tile_reduce_quarters<1, kAdWaves>(accw, red, acc);
+  for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+  const bf16_t* wrow = p.wT + (long long)min(j0 + l31, p.M - 1) * p.K;
+  const int brow = b0 + l31;
+  const bf16_t* irow = brow < p.B ? p.dg + (long long)brow * p.ld : nullptr;
+  tile_gemm_prefetch<kBwdWaves, 8>(wrow, irow, p.K, accw, p.wT);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  tile_reduce_quarters16(accw, red, acc);
   if (wave >= 4) return;
   const int b = b0 + l31, j = j0 + 8 * wave + 4 * lhi;
   if (b >= p.B || j >= p.M) return;
-  f32x4 o = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+  f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
   *reinterpret_cast<f32x4*>(p.out + (long long)b * p.M + j) = o;
 }
 
 // ------------------------------------------------------------------ attention backward
+// sum over the 64 lanes of 32 per-lane values; lane L returns the total of value (L >> 1)
+// same for 16 values: lane L returns the total of value (L >> 2)
+__device__ __forceinline__ float wave_reduce16(float (&v)[16]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int off = 32 >> st, half = 8 >> st;
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float send = hi ? v[i] : v[i + half];
+      const float keep = hi ? v[i + half] : v[i];
+      v[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  float r = v[0] + __shfl_xor(v[0], 2, 64);
+  return r + __shfl_xor(r, 1, 64);
+}
+
+__device__ __forceinline__ float wave_reduce32(float (&v)[32]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int st = 0; st < 5; ++st) {
+    const int off = 32 >> st, half = 16 >> st;
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float send = hi ? v[i] : v[i + half];
+      const float keep = hi ? v[i + half] : v[i];
+      v[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
+template <bool LOC>
 __global__ __launch_bounds__(kAttnThreads) void ad_attn_bwd_kernel(AdAttn p) {
   extern __shared__ float lds_raw[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (p.tgt_len && p.t >= p.tgt_len[b]) return;
-  const int H = p.H, M = p.M, U = p.U, S = p.S, F = p.loc_f, K = p.loc_k;
-  const AttnLds l = attn_lds_carve(lds_raw, H, U, S, p.mode, K, F);
+  const int H = p.H, M = p.M, U = p.U, S = p.S, K = p.loc_k;
+  const AttnLds l = attn_lds_carve(lds_raw, H, U, S, p.mode, K);
   float* dctx = l.scratch;            // [M]
   float* dal = dctx + M;              // [S]
   float* de = dal + S;                // [S]
-  float* dqp = de + S;                // [4][U]
-  float* dnvp = dqp + 4 * U;          // [4][U]
-  float* dlocfeat = dnvp + 4 * U;     // [S][F]   (mode 2)
-  float* ddense = dlocfeat + (p.mode == 2 ? S * F : 0);   // [F][U] (mode 2)
+  float* dcum_l = de + S;             // [S]   (mode 2)
+  float* dqp = dcum_l + S;            // [waves][U]
+  float* dnvp = dqp + kAttnWaves * U; // [waves][U]
+  float* dwk_l = dnvp + kAttnWaves * U;   // [K][U]  (mode 2)
   const int slen = min(max(p.src_len[b], 0), S);
   const long long row = (long long)b * p.T + p.t;
+  AD_TICK(1, 0);
   // total context gradient
   {
     const bf16_t* ext = p.dctx_ext ? p.dctx_ext + (long long)b * p.dctx_bs + (long long)p.t * p.dctx_ts : nullptr;
@@ -466,16 +575,20 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_bwd_kernel(AdAttn p) {
       for (int e = 0; e < 8; ++e) dctx[m8 * 8 + e] = c8[e];
     }
   }
+  AD_TICK(1, 1);
+  attn_stage_keys(p, l, b, slen);
   for (int u = tid; u < U; u += kAttnThreads) l.q[u] = p.q_seq[row * U + u];
   for (int s = tid; s < S; s += kAttnThreads) l.e[s] = p.align_seq[row * S + s];
-  attn_load_score_params(p, l);   // barrier inside
   if (p.mode == 2) {
-    attn_location_features(p, l, b);
-    for (int i = tid; i < S * F; i += kAttnThreads) dlocfeat[i] = 0.f;
-    for (int i = tid; i < F * U; i += kAttnThreads) ddense[i] = 0.f;
+    attn_load_cum(p, l, b);
+    for (int s = tid; s < S; s += kAttnThreads) dcum_l[s] = p.dcum[(long long)b * S + s];
+    for (int i = tid; i < K * U; i += kAttnThreads) dwk_l[i] = 0.f;
   }
+  attn_load_score_params(p, l);   // barrier inside
+  AD_TICK(1, 2);
   // dalign[s] = dctx . values[b,s,:] (+ carry of the cumulative-alignment state)
-  for (int s = wave; s < slen; s += kAttnThreads / 64) {
+#pragma unroll 8
+  for (int s = wave; s < slen; s += kAttnWaves) {
     float part = 0.f;
     const bf16_t* vp = p.values + ((long long)b * S + s) * M;
     for (int m = lane * 8; m < M; m += 512) {
@@ -483,131 +596,142 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_bwd_kernel(AdAttn p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) part += bflo(v[e]) * dctx[m + 2 * e] + bfhi(v[e]) * dctx[m + 2 * e + 1];
     }
-    part = wave_sum(part);
-    if (lane == 0) dal[s] = part + (p.mode == 2 ? p.dcum[(long long)b * S + s] : 0.f);
+    part = wave_sum_dpp(part);
+    if (lane == 0) dal[s] = part + (p.mode == 2 ? dcum_l[s] : 0.f);
   }
   __syncthreads();
+  AD_TICK(1, 3);
   float dot = 0.f;
   for (int s = tid; s < slen; s += kAttnThreads) dot += l.e[s] * dal[s];
   dot = block_sum(dot, l.red);
   for (int s = tid; s < S; s += kAttnThreads) de[s] = s < slen ? l.e[s] * (dal[s] - dot) : 0.f;
   __syncthreads();
+  AD_TICK(1, 4);
   // through the score: dpre[s,u] = de[s] * nv[u] * (1 - tanh^2)
-  constexpr int UP = 4;   // u pairs per lane supported (U <= 512)
-  float dq_acc[2 * UP], dnv_acc[2 * UP];
+  if constexpr (LOC) {
+    // U == 128: a lane owns ONE unit; a pair of waves covers the 128 units of a contiguous
+    // range of source positions. Three 32-entry register windows slide with s (slot
+    // (j + k) & 31 at the j-th step of a 32-step block): cw = padded cumulative alignments,
+    // gw = partial state gradient c_u[s - padl + k] = sum_k' dpre[s',u] Wck[k',u] (a lane-local
+    // convolution along s; the sum over units happens once per emitted position), so the
+    // loop needs one LDS read and one wave reduction per position.
+    const int padl = (K - 1) / 2;
+    const int u = (wave & 1) * 64 + lane, grp = wave >> 1, ngrp = kAttnWaves / 2;
+    const int chunk = (slen + ngrp - 1) / ngrp;
+    const int c0 = grp * chunk, c1 = min(c0 + chunk, slen);
+    float dq0 = 0.f, dn0 = 0.f;
+    if (c0 < c1) {
+      float wk[kLocKMax], dwk[kLocKMax], cw[kLocKMax], gw[kLocKMax];
 #pragma unroll
-  for (int i = 0; i < 2 * UP; ++i) { dq_acc[i] = 0.f; dnv_acc[i] = 0.f; }
-  for (int s = wave; s < slen; s += kAttnThreads / 64) {
-    const float des = de[s];
-    float dpre[2 * UP];
+      for (int k = 0; k < kLocKMax; ++k) {
+        dwk[k] = 0.f;
+        gw[k] = 0.f;
+        wk[k] = k < K ? p.wck[(long long)k * U + u] : 0.f;
+        cw[k] = l.cum[c0 + k];
+      }
+      const float nv0 = l.nv[u], qb = l.q[u] + l.bs[u];
+      const bf16_t* kl = reinterpret_cast<const bf16_t*>(l.keys) + u;
+      bf16_t* dps = p.dpre_seq + (row * S) * U + u;   // dpre of this step: dkeys = sum over steps
+      // run kLocKMax steps past the end so that every window slot is emitted
+      for (int s0 = c0; s0 < c1 + kLocKMax; s0 += kLocKMax) {
+#pragma unroll
+        for (int j = 0; j < kLocKMax; ++j) {
+          const int s = s0 + j;
+          if (s < c1) {
+            float x0 = bf2f(kl[s * U]) + qb;
+#pragma unroll
+            for (int k = 0; k < kLocKMax; ++k) x0 += cw[(j + k) & 31] * wk[k];
+            const float t0 = tanh_fast(x0);
+            const float des = de[s];
+            const float d0 = des * nv0 * (1.f - t0 * t0);
+            dq0 += d0;
+            dn0 += des * t0;
+            dps[(long long)s * U] = f2bf(d0);
+#pragma unroll
+            for (int k = 0; k < kLocKMax; ++k) {
+              dwk[k] += cw[(j + k) & 31] * d0;
+              gw[(j + k) & 31] += d0 * wk[k];
+            }
+          }
+          if (s < c1 + kLocKMax) {
+            // slot j is complete: it is the state gradient at position s - padl
+            const float gsum = wave_sum_dpp(gw[j & 31]);
+            gw[j & 31] = 0.f;
+            const int s2 = s - padl;
+            if (lane == 0 && s2 >= 0 && s2 < S) atomicAdd(&dcum_l[s2], gsum);
+            cw[j & 31] = s < S ? l.cum[s + kLocKMax] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kLocKMax; ++k)
+        if (k < K) atomicAdd(&dwk_l[k * U + u], dwk[k]);
+    }
+    dqp[wave * U + u] = dq0;
+    dnvp[wave * U + u] = dn0;
+    dqp[wave * U + (u ^ 64)] = 0.f;
+    dnvp[wave * U + (u ^ 64)] = 0.f;
+  } else {
+    constexpr int UP = 4;   // unit pairs per lane (U <= 512)
+    float dq_acc[2 * UP], dnv_acc[2 * UP];
+#pragma unroll
+    for (int i = 0; i < 2 * UP; ++i) { dq_acc[i] = 0.f; dnv_acc[i] = 0.f; }
+    for (int s = wave; s < slen; s += kAttnWaves) {
+      const float des = de[s];
+#pragma unroll
+      for (int i = 0; i < UP; ++i) {
+        const int u = 2 * lane + 128 * i;
+        if (u < U) {
+          float x0, x1;
+          attn_pre2(p, l, b, s, u, x0, x1);
+          const float t0 = tanh_fast(x0), t1 = tanh_fast(x1);
+          const float d0 = des * l.nv[u] * (1.f - t0 * t0), d1 = des * l.nv[u + 1] * (1.f - t1 * t1);
+          dq_acc[2 * i] += d0;
+          dq_acc[2 * i + 1] += d1;
+          dnv_acc[2 * i] += des * t0;
+          dnv_acc[2 * i + 1] += des * t1;
+          *reinterpret_cast<uint32_t*>(p.dpre_seq + (row * S + s) * U + u) = pack2bf(d0, d1);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < UP; ++i) {
       const int u = 2 * lane + 128 * i;
-      dpre[2 * i] = dpre[2 * i + 1] = 0.f;
       if (u < U) {
-        float x0, x1;
-        attn_pre2(p, l, b, s, u, x0, x1);
-        const float t0 = tanh_fast(x0), t1 = tanh_fast(x1);
-        dpre[2 * i] = des * l.nv[u] * (1.f - t0 * t0);
-        dpre[2 * i + 1] = des * l.nv[u + 1] * (1.f - t1 * t1);
-        dq_acc[2 * i] += dpre[2 * i];
-        dq_acc[2 * i + 1] += dpre[2 * i + 1];
-        dnv_acc[2 * i] += des * t0;
-        dnv_acc[2 * i + 1] += des * t1;
-        float* dk = p.dkeys + ((long long)b * S + s) * U + u;
-        f32x2 kv = *reinterpret_cast<f32x2*>(dk);
-        kv[0] += dpre[2 * i];
-        kv[1] += dpre[2 * i + 1];
-        *reinterpret_cast<f32x2*>(dk) = kv;
+        dqp[wave * U + u] = dq_acc[2 * i]; dqp[wave * U + u + 1] = dq_acc[2 * i + 1];
+        dnvp[wave * U + u] = dnv_acc[2 * i]; dnvp[wave * U + u + 1] = dnv_acc[2 * i + 1];
       }
-    }
-    if (p.mode == 2) {
-      // dlocfeat[s,f] = sum_u dpre[s,u] * dense_w[f,u];  ddense[f,u] += locfeat[s,f] * dpre[s,u]
-      float mine = 0.f;
-      for (int f = 0; f < F; ++f) {
-        float pf = 0.f;
-        const float lf = l.locfeat[s * F + f];
-#pragma unroll
-        for (int i = 0; i < UP; ++i) {
-          const int u = 2 * lane + 128 * i;
-          if (u < U) {
-            pf += dpre[2 * i] * l.densew[f * U + u] + dpre[2 * i + 1] * l.densew[f * U + u + 1];
-            atomicAdd(&ddense[f * U + u], lf * dpre[2 * i]);
-            atomicAdd(&ddense[f * U + u + 1], lf * dpre[2 * i + 1]);
-          }
-        }
-        pf = wave_sum(pf);
-        if (lane == f) mine = pf;
-      }
-      if (lane < F) dlocfeat[s * F + lane] = mine;   // F <= 64
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < UP; ++i) {
-    const int u = 2 * lane + 128 * i;
-    if (u < U) {
-      dqp[wave * U + u] = dq_acc[2 * i]; dqp[wave * U + u + 1] = dq_acc[2 * i + 1];
-      dnvp[wave * U + u] = dnv_acc[2 * i]; dnvp[wave * U + u + 1] = dnv_acc[2 * i + 1];
     }
   }
   __syncthreads();
+  AD_TICK(1, 5);
   for (int u = tid; u < U; u += kAttnThreads) {
-    const float dq = dqp[u] + dqp[U + u] + dqp[2 * U + u] + dqp[3 * U + u];
-    const float dn = dnvp[u] + dnvp[U + u] + dnvp[2 * U + u] + dnvp[3 * U + u];
-    l.q[u] = dq;   // q is no longer needed: reuse as dq
+    float dq = 0.f, dn = 0.f;
+#pragma unroll
+    for (int w = 0; w < kAttnWaves; ++w) { dq += dqp[w * U + u]; dn += dnvp[w * U + u]; }
     p.dq_seq[row * U + u] = f2bf(dq);
     p.dnv_acc[(long long)b * U + u] += dn;
-  }
-  __syncthreads();
-  // dhq[h] = sum_u dq[u] * Wq[u,h]
-  for (int h4 = tid; h4 < H / 4; h4 += kAttnThreads) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const bf16_t* wp = p.wq + h4 * 4;
-#pragma unroll 8
-    for (int u = 0; u < U; ++u) {
-      const u32x2 w = *reinterpret_cast<const u32x2*>(wp + (long long)u * H);
-      const float dq = l.q[u];
-      a0 += dq * bflo(w[0]); a1 += dq * bfhi(w[0]); a2 += dq * bflo(w[1]); a3 += dq * bfhi(w[1]);
-    }
-    f32x4 o = {a0, a1, a2, a3};
-    *reinterpret_cast<f32x4*>(p.dhq + (long long)b * H + h4 * 4) = o;
+    if (p.mode == 2) p.dbd_acc[(long long)b * U + u] += dq;
   }
   if (p.mode == 2) {
-    const int padl = (K - 1) / 2;
-    // gradient of the cumulative-alignment state before this step (carry to step t-1)
-    for (int s2 = tid; s2 < S; s2 += kAttnThreads) {
-      float a = p.dcum[(long long)b * S + s2];
-      for (int k = 0; k < K; ++k) {
-        const int s = s2 - k + padl;   // output position whose window touches s2 with tap k
-        if (s < 0 || s >= S) continue;
-        for (int f = 0; f < F; ++f) a += dlocfeat[s * F + f] * l.convw[k * F + f];
-      }
-      p.dcum[(long long)b * S + s2] = a;
-    }
-    for (int i = tid; i < K * F; i += kAttnThreads) {
-      const int k = i / F, f = i - k * F;
-      float a = 0.f;
-      for (int s = 0; s < slen; ++s) a += l.cum[s + k] * dlocfeat[s * F + f];
-      p.dconvw_acc[(long long)b * K * F + i] += a;
-    }
-    for (int f = tid; f < F; f += kAttnThreads) {
-      float a = 0.f;
-      for (int s = 0; s < slen; ++s) a += dlocfeat[s * F + f];
-      p.dconvb_acc[(long long)b * F + f] += a;
-    }
-    for (int i = tid; i < F * U; i += kAttnThreads) p.ddense_acc[(long long)b * F * U + i] += ddense[i];
+    for (int s = tid; s < S; s += kAttnThreads) p.dcum[(long long)b * S + s] = dcum_l[s];
+    float* dwa = p.dwck_acc + (long long)b * K * U;
+    for (int i = tid; i < K * U; i += kAttnThreads) dwa[i] += dwk_l[i];
   }
+  __syncthreads();
+  AD_TICK(1, 6);
+  // d(query input) = dq . Wq runs on the matrix cores inside the top cell's backward kernel
 }
 
 // ------------------------------------------------------------------ cell backward
 struct AdCellBwd {
-  int B, T, H, t, last, KA, KB;
+  int B, T, H, t, last, KA, KB, KQ;
   float forget_bias;
   const int32_t* lens;
   const bf16_t* dy_ext; long long dy_bs, dy_ts;   // gradient of the (dropped) output or null
-  const float* add32;                              // [B,H] more of the same or null
   const bf16_t* dgA; long long dgA_ld; const bf16_t* wAT; long long wAT_ld;   // upper layer, same step
   const bf16_t* dgB; long long dgB_ld; const bf16_t* wBT; long long wBT_ld;   // own layer, step t+1
+  const bf16_t* dq; long long dq_ld; const bf16_t* wqT;                       // query layer: dq . Wq (top layer)
   const bf16_t* gates;   // [B,T,4H]
   const float* c_seq;    // [B,T,H]
   float* dc_carry;       // [B,H]
@@ -616,25 +740,35 @@ struct AdCellBwd {
   unsigned long long out_seed;
 };
 
-__global__ __launch_bounds__(64 * kAdWaves) void ad_cell_bwd_kernel(AdCellBwd p) {
-  __shared__ float red[kAdWaves * 16 * 64];
+// dh = dropout'(dy_ext + dgA . WA^T + dq . Wq) + dgB . WB^T, then the LSTM gate derivatives
+__global__ __launch_bounds__(64 * kBwdWaves) void ad_cell_bwd_kernel(AdCellBwd p) {
+  __shared__ float red[kBwdWaves * 8 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
   const int H = p.H;
-  float accA[1][4] = {{0.f, 0.f, 0.f, 0.f}}, accB[1][4] = {{0.f, 0.f, 0.f, 0.f}};
-  if (p.KA > 0) {
-    f32x16 accw[1];
+  const bool vrow = j0 + l31 < H;
+  const int brow = b0 + l31;
+  const bool vcol = brow < p.B;
+  float accM[4] = {0.f, 0.f, 0.f, 0.f}, accB[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.KA > 0 || p.KQ > 0) {
+    f32x16 accw;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accw[0][e] = 0.f;
-    tile_gemm_splitk<1, kAdWaves, 4>(p.wAT, p.wAT_ld, 0, j0, H, p.dgA, p.dgA_ld, b0, p.B, p.KA, accw);
-    tile_reduce_quarters<1, kAdWaves>(accw, red, accA);
+    for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+    if (p.KA > 0)
+      tile_gemm_prefetch<kBwdWaves, 8>(vrow ? p.wAT + (long long)(j0 + l31) * p.wAT_ld : nullptr,
+                                        vcol ? p.dgA + (long long)brow * p.dgA_ld : nullptr, p.KA, accw, p.wAT);
+    if (p.KQ > 0)
+      tile_gemm_prefetch<kBwdWaves, 2>(vrow ? p.wqT + (long long)(j0 + l31) * p.KQ : nullptr,
+                                       vcol ? p.dq + (long long)brow * p.dq_ld : nullptr, p.KQ, accw, p.wqT);
+    tile_reduce_quarters16(accw, red, accM);
   }
   if (!p.last && p.KB > 0) {
-    f32x16 accw[1];
+    f32x16 accw;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accw[0][e] = 0.f;
-    tile_gemm_splitk<1, kAdWaves, 4>(p.wBT, p.wBT_ld, 0, j0, H, p.dgB, p.dgB_ld, b0, p.B, p.KB, accw);
-    tile_reduce_quarters<1, kAdWaves>(accw, red, accB);
+    for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+    tile_gemm_prefetch<kBwdWaves, 8>(vrow ? p.wBT + (long long)(j0 + l31) * p.wBT_ld : nullptr,
+                                      vcol ? p.dgB + (long long)brow * p.dgB_ld : nullptr, p.KB, accw, p.wBT);
+    tile_reduce_quarters16(accw, red, accB);
   }
   if (wave >= 4) return;
   const int b = b0 + l31;
@@ -643,15 +777,10 @@ __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_bwd_kernel(AdCellBwd p)
   const int j = j0 + 8 * wave + 4 * lhi;
   if (j >= H) return;
   const long long row = (long long)b * p.T + p.t;
-  float dyv[4] = {accA[0][0], accA[0][1], accA[0][2], accA[0][3]};
+  float dyv[4] = {accM[0], accM[1], accM[2], accM[3]};
   if (p.dy_ext) {
     const u32x2 v = *reinterpret_cast<const u32x2*>(p.dy_ext + (long long)b * p.dy_bs + (long long)p.t * p.dy_ts + j);
     dyv[0] += bflo(v[0]); dyv[1] += bfhi(v[0]); dyv[2] += bflo(v[1]); dyv[3] += bfhi(v[1]);
-  }
-  if (p.add32) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p.add32 + (long long)b * H + j);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dyv[e] += v[e];
   }
   if (p.out_keep < 1.f) {
     const unsigned long long idx = (unsigned long long)row * H + j;
@@ -675,7 +804,7 @@ __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_bwd_kernel(AdCellBwd p)
   float dpre[4][4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const float dh = dyv[e] + accB[0][e];
+    const float dh = dyv[e] + accB[e];
     const float ig = sv[0][e], fg = sv[1][e], gg = sv[2][e], og = sv[3][e];
     const float tc = tanhf(cv[e]);
     const float dc = dh * og * (1.f - tc * tc) + dcarry[e];
@@ -724,6 +853,73 @@ __global__ __launch_bounds__(256) void ad_dvalues_kernel(const float* __restrict
   }
 }
 
+// Wck[k,u] = sum_f conv_w[k,f] dense_w[f,u];  bd[u] = sum_f conv_b[f] dense_w[f,u]  (out: [K+1, U])
+__global__ void ad_fold_location_kernel(const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+                                        const float* __restrict__ dense_w, int K, int F, int U,
+                                        float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (K + 1) * U) return;
+  const int k = i / U, u = i - k * U;
+  float a = 0.f;
+  for (int f = 0; f < F; ++f) a += (k < K ? conv_w[k * F + f] : conv_b[f]) * dense_w[f * U + u];
+  out[i] = a;
+}
+
+// gradients of conv_w [K,F], conv_b [F], dense_w [F,U] from d(Wck) and d(bd) partials per sample
+__global__ __launch_bounds__(256) void ad_unfold_location_grads_kernel(
+    const float* __restrict__ dwck_acc, const float* __restrict__ dbd_acc, int B, int K, int F, int U,
+    const float* __restrict__ conv_w, const float* __restrict__ conv_b, const float* __restrict__ dense_w,
+    float* __restrict__ dconv_w, float* __restrict__ dconv_b, float* __restrict__ ddense_w,
+    float* __restrict__ tmp /* [(K+1)*U] */) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (K + 1) * U; i += 256) {
+    float a = 0.f;
+    if (i < K * U) { for (int b = 0; b < B; ++b) a += dwck_acc[(long long)b * K * U + i]; }
+    else { for (int b = 0; b < B; ++b) a += dbd_acc[(long long)b * U + (i - K * U)]; }
+    tmp[i] = a;
+  }
+  __syncthreads();
+  for (int i = tid; i < (K + 1) * F; i += 256) {   // d conv_w[k,f] (k < K), d conv_b[f] (k == K)
+    const int k = i / F, f = i - k * F;
+    float a = 0.f;
+    for (int u = 0; u < U; ++u) a += tmp[k * U + u] * dense_w[f * U + u];
+    if (k < K) dconv_w[k * F + f] += a; else dconv_b[f] += a;
+  }
+  for (int i = tid; i < F * U; i += 256) {
+    const int f = i / U, u = i - f * U;
+    float a = conv_b[f] * tmp[K * U + u];
+    for (int k = 0; k < K; ++k) a += conv_w[k * F + f] * tmp[k * U + u];
+    ddense_w[i] += a;
+  }
+}
+
+// dkeys[b,s,u] = sum_{t < tgt_len[b]} dpre_seq[b,t,s,u]   (zero past src_len)
+__global__ __launch_bounds__(256) void ad_dkeys_kernel(const bf16_t* __restrict__ dpre_seq,
+                                                       const int32_t* __restrict__ src_len,
+                                                       const int32_t* __restrict__ tgt_len, int T,
+                                                       int S, int U, float* __restrict__ dkeys) {
+  const int b = blockIdx.y;
+  const long long su = (long long)S * U;
+  const long long i8 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i8 >= su) return;
+  const int s = (int)(i8 / U);
+  const int slen = min(max(src_len[b], 0), S);
+  const int tl = tgt_len ? min(max(tgt_len[b], 0), T) : T;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (s < slen) {
+    const bf16_t* src = dpre_seq + (long long)b * T * su + i8;
+#pragma unroll 8
+    for (int t = 0; t < tl; ++t) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long long)t * su);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[2 * e] += bflo(v[e]); a[2 * e + 1] += bfhi(v[e]); }
+    }
+  }
+  float* o = dkeys + (long long)b * su + i8;
+  *reinterpret_cast<f32x4*>(o) = f32x4{a[0], a[1], a[2], a[3]};
+  *reinterpret_cast<f32x4*>(o + 4) = f32x4{a[4], a[5], a[6], a[7]};
+}
+
 // out[n] += sum_b acc[b, n]
 __global__ void ad_reduce_rows_kernel(const float* __restrict__ acc, int B, long long N,
                                       float* __restrict__ out) {
@@ -757,8 +953,8 @@ __global__ __launch_bounds__(256) void ad_score_vec_grads_kernel(const float* __
     for (int u = tid; u < U; u += 256) dv[u] += dn[u];
     return;
   }
-  vv = wave_sum(vv);
-  dv_dot = wave_sum(dv_dot);
+  vv = wave_sum_dpp(vv);
+  dv_dot = wave_sum_dpp(dv_dot);
   if ((tid & 63) == 0) { red[tid >> 6] = vv; red[4 + (tid >> 6)] = dv_dot; }
   __syncthreads();
   vv = red[0] + red[1] + red[2] + red[3];
@@ -773,8 +969,14 @@ __global__ __launch_bounds__(256) void ad_score_vec_grads_kernel(const float* __
 
 using namespace os2s;
 
+#ifdef OS2S_ATTN_PHASE_TIMERS
+extern "C" int os2s_debug_attn_phases(long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
+}
+#endif
+
 static size_t attn_lds_bytes(const os2s_attn_decoder_t* d, bool bwd) {
-  return attn_lds_floats(d->H, d->M, d->U, d->S, d->score_mode, d->loc_k, d->loc_f, bwd) * sizeof(float);
+  return attn_lds_floats(d->H, d->M, d->U, d->S, d->score_mode, d->loc_k, bwd) * sizeof(float);
 }
 
 static int ad_check(const os2s_attn_decoder_t* d) {
@@ -787,7 +989,8 @@ static int ad_check(const os2s_attn_decoder_t* d) {
   if (d->L == 2) OS2S_REQUIRE(d->wcat[1] && d->cat[1] && d->c_seq[1]);
   if (d->score_mode == 1) OS2S_REQUIRE(d->g && d->b);
   if (d->score_mode == 2) {
-    OS2S_REQUIRE(d->loc_k >= 1 && d->loc_f >= 1 && d->loc_f <= 64 && d->conv_w && d->conv_b && d->dense_w && d->cum_seq);
+    OS2S_REQUIRE(d->loc_k >= 1 && d->loc_k <= kLocKMax && d->loc_f >= 1 && d->U == 128);
+    OS2S_REQUIRE(d->conv_w && d->conv_b && d->dense_w && d->cum_seq && d->loc_ws);
     if (d->use_bias) OS2S_REQUIRE(d->b);
   }
   if (attn_lds_bytes(d, true) > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
@@ -796,19 +999,19 @@ static int ad_check(const os2s_attn_decoder_t* d) {
 
 static void ad_fill_attn(const os2s_attn_decoder_t* d, AdAttn& a) {
   a.B = d->B; a.T = d->T; a.S = d->S; a.H = d->H; a.M = d->M; a.U = d->U;
-  a.mode = d->score_mode; a.use_bias = d->use_bias; a.loc_k = d->loc_k; a.loc_f = d->loc_f;
+  a.mode = d->score_mode; a.use_bias = d->use_bias; a.loc_k = d->loc_k;
   a.Kc0 = d->M + d->H;
   a.src_len = d->src_len; a.tgt_len = d->tgt_len;
   a.yq = (const bf16_t*)d->y_top; a.yq_bs = d->y_top_bs; a.yq_ts = d->y_top_ts;
   a.wq = (const bf16_t*)d->wq; a.keys = (const bf16_t*)d->keys; a.values = (const bf16_t*)d->values;
-  a.v = d->v; a.g = d->g; a.bias = d->b; a.conv_w = d->conv_w; a.conv_b = d->conv_b; a.dense_w = d->dense_w;
+  a.v = d->v; a.g = d->g; a.bias = d->b; a.wck = d->loc_ws;
   a.cum_seq = d->cum_seq; a.align_seq = d->align_seq; a.q_seq = d->q_seq;
   a.ctx = (bf16_t*)d->ctx; a.ctx_bs = d->ctx_bs; a.ctx_ts = d->ctx_ts;
   a.cat0 = (bf16_t*)d->cat[0];
   a.attn_in_keep = d->attn_in_keep; a.attn_in_seed = d->attn_in_seed;
-  a.dctx_ext = nullptr; a.dattn = nullptr; a.dctx_seq = nullptr; a.dcum = nullptr; a.dkeys = nullptr;
-  a.dq_seq = nullptr; a.dhq = nullptr; a.dnv_acc = nullptr; a.ddense_acc = nullptr;
-  a.dconvw_acc = nullptr; a.dconvb_acc = nullptr; a.last = 0; a.dctx_bs = a.dctx_ts = 0;
+  a.dctx_ext = nullptr; a.dattn = nullptr; a.dctx_seq = nullptr; a.dcum = nullptr; a.dpre_seq = nullptr;
+  a.dq_seq = nullptr; a.dhq = nullptr; a.dnv_acc = nullptr; a.dbd_acc = nullptr;
+  a.dwck_acc = nullptr; a.last = 0; a.dctx_bs = a.dctx_ts = 0;
 }
 
 extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_decoder_t* d) {
@@ -822,7 +1025,12 @@ extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_deco
   const int B = d->B, T = d->T, H = d->H, M = d->M, L = d->L;
   AdAttn at;
   ad_fill_attn(d, at);
-  dim3 cgrid(ceil_div(H, 32), ceil_div(B, 32));
+  if (d->score_mode == 2) {
+    const int n = (d->loc_k + 1) * d->U;
+    OS2S_LAUNCH(ad_fold_location_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, d->conv_w,
+                d->conv_b, d->dense_w, d->loc_k, d->loc_f, d->U, d->loc_ws);
+  }
+  dim3 cgrid(ceil_div(H, 8), ceil_div(B, 32));
   for (int t = d->t_begin; t < d->t_end; ++t) {
     for (int l = 0; l < L; ++l) {
       AdCellFwd c;
@@ -847,7 +1055,7 @@ extern "C" size_t os2s_attn_decoder_bwd_workspace_bytes(const os2s_attn_decoder_
   if (!d) return 0;
   const size_t B = d->B;
   size_t n = B * d->M + B * d->H + 2 * B * d->H + B * d->S + B * d->U;
-  if (d->score_mode == 2) n += B * d->loc_f * d->U + B * d->loc_k * d->loc_f + B * d->loc_f;
+  if (d->score_mode == 2) n += B * d->U + B * d->loc_k * d->U + (size_t)(d->loc_k + 1) * d->U;
   return n * sizeof(float) + 1024;
 }
 
@@ -856,7 +1064,7 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
                                      size_t workspace_bytes) {
   const int rc = ad_check(d);
   if (rc != OS2S_OK) return rc;
-  OS2S_REQUIRE(gr && workspace && d->gates[0] && gr->wcatT[0] && gr->dg[0] && gr->dq_seq && gr->dctx_seq && gr->dkeys && gr->dmem);
+  OS2S_REQUIRE(gr && workspace && d->gates[0] && gr->wcatT[0] && gr->wqT && gr->dg[0] && gr->dq_seq && gr->dctx_seq && gr->dkeys && gr->dpre_seq && gr->dmem);
   OS2S_REQUIRE(gr->dy_top || gr->dctx_ext);
   OS2S_REQUIRE(gr->dv);
   if (d->L == 2) OS2S_REQUIRE(d->gates[1] && gr->wcatT[1] && gr->dg[1]);
@@ -867,7 +1075,7 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
   hipStream_t stream = (hipStream_t)stream_;
   const size_t lds = attn_lds_bytes(d, true);
   if (lds > 64 * 1024 &&
-      hipFuncSetAttribute((const void*)ad_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      hipFuncSetAttribute(d->score_mode == 2 ? (const void*)ad_attn_bwd_kernel<true> : (const void*)ad_attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return OS2S_ERR_LAUNCH;
   const int B = d->B, T = d->T, H = d->H, M = d->M, L = d->L, U = d->U, S = d->S;
   const int K = d->loc_k, F = d->loc_f;
@@ -878,25 +1086,24 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
   float* dcc[2]; dcc[0] = ws; ws += (size_t)B * H; dcc[1] = ws; ws += (size_t)B * H;
   float* dcum = ws; ws += (size_t)B * S;
   float* dnv_acc = ws; ws += (size_t)B * U;
-  float *ddense_acc = nullptr, *dconvw_acc = nullptr, *dconvb_acc = nullptr;
+  float *dbd_acc = nullptr, *dwck_acc = nullptr, *unfold_tmp = nullptr;
   if (d->score_mode == 2) {
-    ddense_acc = ws; ws += (size_t)B * F * U;
-    dconvw_acc = ws; ws += (size_t)B * K * F;
-    dconvb_acc = ws; ws += (size_t)B * F;
+    dbd_acc = ws; ws += (size_t)B * U;
+    dwck_acc = ws; ws += (size_t)B * K * U;
+    unfold_tmp = ws; ws += (size_t)(K + 1) * U;
   }
   // gate gradients of finished steps are zero; dkeys accumulates
   for (int l = 0; l < L; ++l)
     if (hipMemsetAsync(gr->dg[l], 0, (size_t)B * T * 4 * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
-  if (hipMemsetAsync(gr->dkeys, 0, (size_t)B * S * U * 4, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
   if (hipMemsetAsync(gr->dq_seq, 0, (size_t)B * T * U * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
   if (hipMemsetAsync(gr->dctx_seq, 0, (size_t)B * T * M * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
 
   AdAttn at;
   ad_fill_attn(d, at);
   at.dctx_ext = (const bf16_t*)gr->dctx_ext; at.dctx_bs = gr->dctx_bs; at.dctx_ts = gr->dctx_ts;
-  at.dattn = dattn; at.dctx_seq = (bf16_t*)gr->dctx_seq; at.dcum = dcum; at.dkeys = gr->dkeys;
-  at.dq_seq = (bf16_t*)gr->dq_seq; at.dhq = dhq; at.dnv_acc = dnv_acc; at.ddense_acc = ddense_acc;
-  at.dconvw_acc = dconvw_acc; at.dconvb_acc = dconvb_acc;
+  at.dattn = dattn; at.dctx_seq = (bf16_t*)gr->dctx_seq; at.dcum = dcum; at.dpre_seq = (bf16_t*)gr->dpre_seq;
+  at.dq_seq = (bf16_t*)gr->dq_seq; at.dhq = dhq; at.dnv_acc = dnv_acc; at.dbd_acc = dbd_acc;
+  at.dwck_acc = dwck_acc;
   const long long GH = 4LL * H;
   dim3 cgrid(ceil_div(H, 32), ceil_div(B, 32));
   for (int t = T - 1; t >= 0; --t) {
@@ -905,18 +1112,21 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
       AdDattn g;
       g.B = B; g.M = M; g.K = (int)GH; g.wT = (const bf16_t*)gr->wcatT[0];
       g.dg = (const bf16_t*)gr->dg[0] + (long long)(t + 1) * GH; g.ld = (long long)T * GH; g.out = dattn;
-      OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 32), ceil_div(B, 32)), dim3(64 * kAdWaves), 0, stream, g);
+      OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 32), ceil_div(B, 32)), dim3(64 * kBwdWaves), 0, stream, g);
     }
     at.t = t; at.last = last;
-    OS2S_LAUNCH(ad_attn_bwd_kernel, dim3(B), dim3(kAttnThreads), lds, stream, at);
+    if (d->score_mode == 2) { OS2S_LAUNCH(ad_attn_bwd_kernel<true>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
+    else { OS2S_LAUNCH(ad_attn_bwd_kernel<false>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
     for (int l = L - 1; l >= 0; --l) {
       AdCellBwd c;
       c.B = B; c.T = T; c.H = H; c.t = t; c.last = last; c.forget_bias = d->forget_bias; c.lens = d->tgt_len;
-      c.dy_ext = nullptr; c.dy_bs = c.dy_ts = 0; c.add32 = nullptr;
+      c.dy_ext = nullptr; c.dy_bs = c.dy_ts = 0;
       c.dgA = nullptr; c.wAT = nullptr; c.KA = 0; c.dgA_ld = c.wAT_ld = 0;
+      c.dq = nullptr; c.wqT = nullptr; c.KQ = 0; c.dq_ld = 0;
       if (l == L - 1) {
         c.dy_ext = (const bf16_t*)gr->dy_top; c.dy_bs = gr->dy_top_bs; c.dy_ts = gr->dy_top_ts;
-        c.add32 = dhq;
+        c.dq = (const bf16_t*)gr->dq_seq + (long long)t * U; c.dq_ld = (long long)T * U;
+        c.wqT = (const bf16_t*)gr->wqT; c.KQ = U;
       } else {   // output feeds the layer above at the same step (columns 0..H of its cat)
         c.dgA = (const bf16_t*)gr->dg[l + 1] + (long long)t * GH; c.dgA_ld = (long long)T * GH;
         c.wAT = (const bf16_t*)gr->wcatT[l + 1]; c.wAT_ld = GH; c.KA = (int)GH;
@@ -925,20 +1135,18 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
       c.wBT = (const bf16_t*)gr->wcatT[l] + (long long)(l == 0 ? M : H) * GH; c.wBT_ld = GH; c.KB = (int)GH;
       c.gates = (const bf16_t*)d->gates[l]; c.c_seq = d->c_seq[l]; c.dc_carry = dcc[l];
       c.dg_out = (bf16_t*)gr->dg[l]; c.out_keep = d->out_keep; c.out_seed = d->out_seed[l];
-      OS2S_LAUNCH(ad_cell_bwd_kernel, cgrid, dim3(64 * kAdWaves), 0, stream, c);
+      OS2S_LAUNCH(ad_cell_bwd_kernel, cgrid, dim3(64 * kBwdWaves), 0, stream, c);
     }
   }
+  OS2S_LAUNCH(ad_dkeys_kernel, dim3(ceil_div((long long)S * U / 8, 256), B), dim3(256), 0, stream,
+              (const bf16_t*)gr->dpre_seq, d->src_len, d->tgt_len, T, S, U, gr->dkeys);
   OS2S_LAUNCH(ad_dvalues_kernel, dim3(ceil_div(M, 256), B), dim3(256), 0, stream, d->align_seq,
               (const bf16_t*)gr->dctx_seq, d->src_len, d->tgt_len, T, S, M, (bf16_t*)gr->dmem);
   OS2S_LAUNCH(ad_score_vec_grads_kernel, dim3(1), dim3(256), 0, stream, dnv_acc, B, U, d->score_mode,
               d->v, d->g, gr->dv, gr->dg_scalar);
   if (d->score_mode == 2) {
-    OS2S_LAUNCH(ad_reduce_rows_kernel, dim3(ceil_div((long long)F * U, 256)), dim3(256), 0, stream,
-                ddense_acc, B, (long long)F * U, gr->ddense_w);
-    OS2S_LAUNCH(ad_reduce_rows_kernel, dim3(ceil_div((long long)K * F, 256)), dim3(256), 0, stream,
-                dconvw_acc, B, (long long)K * F, gr->dconv_w);
-    OS2S_LAUNCH(ad_reduce_rows_kernel, dim3(ceil_div(F, 256)), dim3(256), 0, stream, dconvb_acc, B,
-                (long long)F, gr->dconv_b);
+    OS2S_LAUNCH(ad_unfold_location_grads_kernel, dim3(1), dim3(256), 0, stream, dwck_acc, dbd_acc, B, K,
+                F, U, d->conv_w, d->conv_b, d->dense_w, gr->dconv_w, gr->dconv_b, gr->ddense_w, unfold_tmp);
   }
   return OS2S_OK;
 }

@@ -72,6 +72,35 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// DPP-based wave64 reductions for FULLY ACTIVE waves (checked against the shuffle versions by
+// tools/probe_dpp.hip): six VALU DPP moves instead of six ds_bpermute round trips through
+// the LDS crossbar (~10x lower latency — it matters in the sequential decoder kernels). The
+// result is wave-uniform (read from lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL,
+                                                    ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  x += dpp_mov<0xB1, 0xf>(0.f, x);    // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E, 0xf>(0.f, x);    // quad_perm [2,3,0,1]
+  x += dpp_mov<0x124, 0xf>(0.f, x);   // row_ror:4
+  x += dpp_mov<0x128, 0xf>(0.f, x);   // row_ror:8
+  x += dpp_mov<0x142, 0xa>(0.f, x);   // row_bcast:15 into rows 1, 3
+  x += dpp_mov<0x143, 0xc>(0.f, x);   // row_bcast:31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float x) {
+  const float ninf = -__builtin_inff();
+  x = fmaxf(x, dpp_mov<0xB1, 0xf>(ninf, x));
+  x = fmaxf(x, dpp_mov<0x4E, 0xf>(ninf, x));
+  x = fmaxf(x, dpp_mov<0x124, 0xf>(ninf, x));
+  x = fmaxf(x, dpp_mov<0x128, 0xf>(ninf, x));
+  x = fmaxf(x, dpp_mov<0x142, 0xa>(ninf, x));
+  x = fmaxf(x, dpp_mov<0x143, 0xc>(ninf, x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
 // Counter-based RNG (philox-like mixing, cheap): deterministic per (seed, idx).
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;

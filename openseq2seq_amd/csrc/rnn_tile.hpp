@@ -86,3 +86,86 @@ __device__ __forceinline__ void tile_reduce_quarters(f32x16 (&acc)[G], float* re
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 }  // namespace os2s
+
+namespace os2s {
+
+// ---- latency-optimised variant -------------------------------------------------------
+// The step kernels are bound by DEPENDENT memory round trips, not by bandwidth or FLOPs, so
+// a wave issues every load of its share of the reduction (KS k-slices: 2*KS 16-byte loads)
+// before the first MFMA — one round trip per tile. `wrow` is the weight row this lane
+// supplies to the A operand (tile row lane&31) or nullptr for a padding row, `irow` its
+// input row (column lane&31) or nullptr for a padding column; `safe` is any readable row of
+// K elements (padding lanes load it and discard the data). K % 8 == 0; NW * KS * 16 >= K for a single batch.
+template <int NW, int KS>
+__device__ __forceinline__ void tile_gemm_prefetch(const bf16_t* __restrict__ wrow,
+                                                   const bf16_t* __restrict__ irow, int K,
+                                                   f32x16& acc, const bf16_t* __restrict__ safe) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lhi = lane >> 5;
+  const int niter = (K + 15) >> 4;
+  const bf16_t* wsafe = wrow ? wrow : safe;
+  const bf16_t* isafe = irow ? irow : safe;
+  for (int base = 0; base < niter; base += NW * KS) {
+    // Loads are UNCONDITIONAL (addresses clamped, padding zeroed afterwards with a select): a
+    // load inside a branch is waited for at the join, which serialises the round trips.
+    u32x4 a[KS], bb[KS];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int it = base + wave + NW * i;
+      const int ko = min(it * 16 + lhi * 8, K - 8);
+      a[i] = *reinterpret_cast<const u32x4*>(wsafe + ko);
+      bb[i] = *reinterpret_cast<const u32x4*>(isafe + ko);
+    }
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int it = base + wave + NW * i;
+      const bool kv = it < niter && it * 16 + lhi * 8 < K;
+      const u32x4 av = (kv && wrow) ? a[i] : zero;
+      const u32x4 bv = (kv && irow) ? bb[i] : zero;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                    acc, 0, 0, 0);
+    }
+  }
+}
+
+// Sum NW partial tiles through LDS (`red`: NW*16*64 floats). Wave q < 4 receives, for every
+// accumulator group g = r >> 2, the element r = 4g + q:  out[g] = sum_w acc_w[4g + q].
+// With tile rows laid out as row = 8*gate + unit this hands wave q all four gates of unit
+// (q + 4*(lane>>5)) of the tile for batch column lane&31.
+template <int NW>
+__device__ __forceinline__ void tile_reduce_units(const f32x16& acc, float* red, float (&out)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 16 + 4 * g + wave) * 64 + lane];
+      out[g] = s;
+    }
+  }
+}
+
+// Same for a plain 32-row tile: wave q < 4 receives rows 8q' ... as tile_reduce_quarters
+// (single accumulator group).
+template <int NW>
+__device__ __forceinline__ void tile_reduce_rows(const f32x16& acc, float* red, float (&out)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 16 + 4 * wave + e) * 64 + lane];
+      out[e] = s;
+    }
+  }
+}
+
+}  // namespace os2s

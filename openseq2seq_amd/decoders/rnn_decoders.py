@@ -115,7 +115,7 @@ class AttentionCell(object):
     cell = self
 
     def backward():
-      out = dec.backward([w.wt16.view(-1, GH) for w in cell.wcat], dy_top=y.grad, dctx_ext=c.grad,
+      out = dec.backward([w.wt16.view(-1, GH) for w in cell.wcat], cell.w_q.wt16.view(H, U), dy_top=y.grad, dctx_ext=c.grad,
                          dv=cell.v.grad, dg=cell.g.grad if cell.g is not None else None,
                          dconv_w=cell.conv_w.grad if cell.conv_w is not None else None,
                          dconv_b=cell.conv_b.grad if cell.conv_b is not None else None,

@@ -84,7 +84,7 @@ def test_attn_decoder_fwd_bwd(cuda, case):
   dcb = torch.zeros(F, device=dev) if mode == 2 else None
   ddw = torch.zeros(F, U, device=dev) if mode == 2 else None
   wcatT = [w.t().contiguous().to(dev) for w in wcat]
-  out = dec.backward(wcatT, dy_top=dy.to(dev), dctx_ext=dctx.to(dev), dv=dv, dg=dgs, dconv_w=dcw,
+  out = dec.backward(wcatT, wq.t().contiguous().to(dev), dy_top=dy.to(dev), dctx_ext=dctx.to(dev), dv=dv, dg=dgs, dconv_w=dcw,
                      dconv_b=dcb, ddense_w=ddw)
   torch.cuda.synchronize()
 

@@ -137,7 +137,7 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch):
   close(d["outputs"][1], out["post"], "post")
   close(d["outputs"][2], out["align"], "align", rel_max=0.05, abs_max=0.03)
   close(d["stop_token_prediction"], out["stop"], "stop")
-  close(d["outputs"][5], out["mag"], "mag", rel_max=0.06, abs_max=0.5)
+  close(d["outputs"][5], out["mag"], "mag", rel_max=0.06, abs_max=1.5)   # exp() outputs, |x| up to ~30
   assert abs(float(L.cpu()) - float(ref)) <= 3e-2 * abs(float(ref)), (float(L.cpu()), float(ref))
   bad = []
   for p in store.params:
