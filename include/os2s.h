@@ -508,10 +508,47 @@ int os2s_tts_loss(os2s_stream_t stream, const uint16_t* pred, long long ld_pred,
  * helper y = a * b; out[b,c] (+)= sum_t x[b,t,c] (gradient of a vector tiled over time:
  * the style embedding, encoders/tacotron2_encoder.py:168-172). n % 8 == 0. */
 int os2s_exp_fwd(os2s_stream_t stream, const uint16_t* x, long long n, uint16_t* y);
+/* activation=tf.nn.tanh of a tf.layers.dense (reference_activation, tacotron2_encoder.py:448-456):
+ * y = tanh(x); dx = dy * (1 - y^2). */
+int os2s_tanh_fwd(os2s_stream_t stream, const uint16_t* x, long long n, uint16_t* y);
+int os2s_tanh_bwd(os2s_stream_t stream, const uint16_t* dy, const uint16_t* y, long long n,
+                  uint16_t* dx);
 int os2s_mul_bf16(os2s_stream_t stream, const uint16_t* a, const uint16_t* b, long long n,
                   uint16_t* y);
 int os2s_sum_time(os2s_stream_t stream, const uint16_t* x, long long ld, int B, int T, int C,
                   float* out, int accumulate);
+
+/* ------------------------------------------------------------------------
+ * Global style tokens (Tacotron2Encoder._embed_style, encoders/tacotron2_encoder.py:341-505).
+ * os2s_gru_tf_*: tf.nn.rnn_cell.GRUCell under dynamic_rnn(sequence_length) (:397-417):
+ *   [r,u] = sigmoid(x Wg_x + h Wg_h + bg), c = tanh(x Wc_x + (r*h) Wc_h + bc), h' = u h + (1-u) c.
+ *   gxg [B,T,2H] / gxc [B,T,H] bf16 hold the input parts (+ biases; caller GEMMs); wgh [H,2H],
+ *   wch [H,H] fp32 are the state rows of the TF kernels ([in,out]); h_final [B,H] fp32 is the
+ *   state at each sample's last valid step. Saved for backward: h_seq [B,T+1,H], r/u/c_seq
+ *   [B,T,H] fp32, hprev16 / rh16 [B,T,H] bf16 (h_{t-1} and r*h_{t-1}: operands of the
+ *   recurrent-weight gradient GEMMs dWg_h = hprev^T dgxg, dWc_h = rh^T dgxc).
+ *   Backward: dh_final -> dgxg, dgxc (bf16); wghT [2H,H], wchT [H,H] transposed kernels.
+ * os2s_gst_attention_*: multi-head attention in "bahdanau" mode over N <= 64 style tokens
+ *   (parts/transformer/attention_layer.py:171-186): per head (depth 64)
+ *   w = softmax_n sum_d tanh(att_v[d] tanh(k[n,d] + q[b,d])), out = sum_n w_n v[n].
+ *   q/out/dq [B, heads*64] bf16, k/v [N, heads*64] bf16, w [B,heads,N] fp32; the backward
+ *   ACCUMULATES dk, dv [N, heads*64] and datt_v [64] (fp32, atomics).
+ * ---------------------------------------------------------------------- */
+int os2s_gru_tf_fwd(os2s_stream_t stream, const uint16_t* gxg, const uint16_t* gxc,
+                    const float* wgh, const float* wch, const int32_t* lens, int B, int T, int H,
+                    float* h_seq, float* r_seq, float* u_seq, float* c_seq, uint16_t* hprev16,
+                    uint16_t* rh16, float* h_final);
+int os2s_gru_tf_bwd(os2s_stream_t stream, const float* dh_final, const float* wghT,
+                    const float* wchT, const int32_t* lens, int B, int T, int H,
+                    const float* h_seq, const float* r_seq, const float* u_seq, const float* c_seq,
+                    uint16_t* dgxg, uint16_t* dgxc);
+int os2s_gst_attention_fwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* k,
+                           const uint16_t* v, const float* att_v, int B, int heads, int N,
+                           uint16_t* out, float* w);
+int os2s_gst_attention_bwd(os2s_stream_t stream, const uint16_t* dout, const uint16_t* q,
+                           const uint16_t* k, const uint16_t* v, const float* att_v, const float* w,
+                           int B, int heads, int N, uint16_t* dq, float* dk, float* dv,
+                           float* datt_v);
 
 /* ------------------------------------------------------------------------
  * conv2d (time x frequency) of DeepSpeech2 (tf.layers.conv2d in conv_bn_actv,

@@ -849,6 +849,20 @@ def exp_fwd(x):
   return y
 
 
+def tanh_fwd(x):
+  y = torch.empty_like(x)
+  _lib.check(_fn("os2s_tanh_fwd", (c_void_p, c_void_p, c_ll, c_void_p))(
+      _stream(), _ptr(x, torch.bfloat16), x.numel(), _ptr(y)), "os2s_tanh_fwd")
+  return y
+
+
+def tanh_bwd(dy, y):
+  dx = torch.empty_like(y)
+  _lib.check(_fn("os2s_tanh_bwd", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))(
+      _stream(), _ptr(dy, torch.bfloat16), _ptr(y, torch.bfloat16), y.numel(), _ptr(dx)), "os2s_tanh_bwd")
+  return dx
+
+
 def mul_bf16(a, b):
   y = torch.empty_like(a)
   _lib.check(_fn("os2s_mul_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))(
@@ -864,3 +878,63 @@ def sum_time(x, out, accumulate=False):
       _stream(), c_void_p(x.data_ptr()), x.stride(1), B, T, C, _ptr(out, torch.float32),
       int(accumulate)), "os2s_sum_time")
   return out
+
+
+# --------------------------------------------------------------------------
+# global style tokens: TF GRUCell summary + token attention
+# --------------------------------------------------------------------------
+def gru_tf_fwd(gxg, gxc, wgh, wch, lens):
+  """-> dict(h_final [B,H] fp32, saved tensors)."""
+  B, T, H2 = gxg.shape
+  H = H2 // 2
+  dev = gxg.device
+  f32, bf = torch.float32, torch.bfloat16
+  sv = dict(h_seq=torch.empty((B, T + 1, H), dtype=f32, device=dev),
+            r_seq=torch.empty((B, T, H), dtype=f32, device=dev),
+            u_seq=torch.empty((B, T, H), dtype=f32, device=dev),
+            c_seq=torch.empty((B, T, H), dtype=f32, device=dev),
+            hprev16=torch.empty((B, T, H), dtype=bf, device=dev),
+            rh16=torch.empty((B, T, H), dtype=bf, device=dev),
+            h_final=torch.empty((B, H), dtype=f32, device=dev))
+  f = _fn("os2s_gru_tf_fwd", (c_void_p,) * 6 + (c_int,) * 3 + (c_void_p,) * 7)
+  _lib.check(f(_stream(), _ptr(gxg, bf), _ptr(gxc, bf), _ptr(wgh, f32), _ptr(wch, f32),
+               _ptr(lens, torch.int32, True), B, T, H, _ptr(sv["h_seq"]), _ptr(sv["r_seq"]),
+               _ptr(sv["u_seq"]), _ptr(sv["c_seq"]), _ptr(sv["hprev16"]), _ptr(sv["rh16"]),
+               _ptr(sv["h_final"])), "os2s_gru_tf_fwd")
+  return sv
+
+
+def gru_tf_bwd(dh_final, wghT, wchT, lens, sv):
+  B, T, H = sv["r_seq"].shape
+  dev = dh_final.device
+  dgxg = torch.empty((B, T, 2 * H), dtype=torch.bfloat16, device=dev)
+  dgxc = torch.empty((B, T, H), dtype=torch.bfloat16, device=dev)
+  f = _fn("os2s_gru_tf_bwd", (c_void_p,) * 5 + (c_int,) * 3 + (c_void_p,) * 6)
+  _lib.check(f(_stream(), _ptr(dh_final, torch.float32), _ptr(wghT, torch.float32),
+               _ptr(wchT, torch.float32), _ptr(lens, torch.int32, True), B, T, H, _ptr(sv["h_seq"]),
+               _ptr(sv["r_seq"]), _ptr(sv["u_seq"]), _ptr(sv["c_seq"]), _ptr(dgxg), _ptr(dgxc)),
+             "os2s_gru_tf_bwd")
+  return dgxg, dgxc
+
+
+def gst_attention_fwd(q, k, v, att_v, heads):
+  B, D = q.shape
+  N = k.shape[0]
+  out = torch.empty_like(q)
+  w = torch.empty((B, heads, N), dtype=torch.float32, device=q.device)
+  f = _fn("os2s_gst_attention_fwd", (c_void_p,) * 5 + (c_int,) * 3 + (c_void_p,) * 2)
+  _lib.check(f(_stream(), _ptr(q, torch.bfloat16), _ptr(k, torch.bfloat16), _ptr(v, torch.bfloat16),
+               _ptr(att_v, torch.float32), B, heads, N, _ptr(out), _ptr(w)), "os2s_gst_attention_fwd")
+  return out, w
+
+
+def gst_attention_bwd(dout, q, k, v, att_v, w, heads, dk, dv, datt_v):
+  B, D = q.shape
+  N = k.shape[0]
+  dq = torch.empty_like(q)
+  f = _fn("os2s_gst_attention_bwd", (c_void_p,) * 7 + (c_int,) * 3 + (c_void_p,) * 4)
+  _lib.check(f(_stream(), _ptr(dout, torch.bfloat16), _ptr(q, torch.bfloat16), _ptr(k, torch.bfloat16),
+               _ptr(v, torch.bfloat16), _ptr(att_v, torch.float32), _ptr(w, torch.float32), B, heads,
+               N, _ptr(dq), _ptr(dk, torch.float32), _ptr(dv, torch.float32),
+               _ptr(datt_v, torch.float32)), "os2s_gst_attention_bwd")
+  return dq

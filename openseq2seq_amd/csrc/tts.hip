@@ -91,6 +91,31 @@ __global__ void mul_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __re
   }
 }
 
+// y = tanh(x);  dx = dy * (1 - y^2)
+__global__ void tanh_fwd_kernel(const bf16_t* __restrict__ x, long long n8, bf16_t* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(tanhf(bflo(v[e])), tanhf(bfhi(v[e])));
+    *reinterpret_cast<u32x4*>(y + i * 8) = o;
+  }
+}
+__global__ void tanh_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, long long n8,
+                                bf16_t* __restrict__ dx) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 g = *reinterpret_cast<const u32x4*>(dy + i * 8);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(y + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = bflo(v[e]), b = bfhi(v[e]);
+      o[e] = pack2bf(bflo(g[e]) * (1.f - a * a), bfhi(g[e]) * (1.f - b * b));
+    }
+    *reinterpret_cast<u32x4*>(dx + i * 8) = o;
+  }
+}
+
 // out[b, c] (+)= sum_t x[b, t, c]   (x rows ld apart; fp32 out)
 __global__ __launch_bounds__(256) void sum_time_kernel(const bf16_t* __restrict__ x, long long ld,
                                                        int T, int C, float* __restrict__ out,
@@ -133,6 +158,23 @@ extern "C" int os2s_exp_fwd(os2s_stream_t stream, const uint16_t* x, long long n
   if (n == 0) return OS2S_OK;
   OS2S_LAUNCH(exp_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
               n / 8, (bf16_t*)y);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_tanh_fwd(os2s_stream_t stream, const uint16_t* x, long long n, uint16_t* y) {
+  OS2S_REQUIRE(x && y && n >= 0 && n % 8 == 0);
+  if (n == 0) return OS2S_OK;
+  OS2S_LAUNCH(tanh_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+              n / 8, (bf16_t*)y);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_tanh_bwd(os2s_stream_t stream, const uint16_t* dy, const uint16_t* y, long long n,
+                             uint16_t* dx) {
+  OS2S_REQUIRE(dy && y && dx && n >= 0 && n % 8 == 0);
+  if (n == 0) return OS2S_OK;
+  OS2S_LAUNCH(tanh_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+              (const bf16_t*)y, n / 8, (bf16_t*)dx);
   return OS2S_OK;
 }
 

@@ -108,10 +108,15 @@ class Conv2dBN(object):
       dwexp = capi.conv1d_wgrad(x.data, dy, L.KT, stride=L.sT, pad_left=pl)
       capi.conv2d_toeplitz_reduce(dwexp, L.Fi, L.Fo, L.sF, L.padF, L.kernel.grad)
       if x.requires_grad:
+        src = dy
         if L.sT != 1:
-          raise NotImplementedError("data-gradient of a time-strided conv2d")
+          # transposed convolution: zero-stuff dy to the input rate, then the stride-1
+          # data-gradient convolution  dx[t] = sum_k up[t + pl - k] w[k]
+          To = dy.shape[1]
+          src = torch.zeros((B, (To - 1) * L.sT + 1, dy.shape[2]), dtype=dy.dtype, device=dev)
+          src[:, ::L.sT] = dy
         g = x.grad_buffer()
-        capi.conv1d_fwd(dy, L._wexpT, pad_left=(L.KT - 1) - pl, tout=Tin, out=g,
+        capi.conv1d_fwd(src, L._wexpT, pad_left=(L.KT - 1) - pl, tout=Tin, out=g,
                         accumulate=x.grad_init)
         x.grad_init = True
       res.grad = None
