@@ -19,6 +19,27 @@ def _cmp(got, ref, name, cos_min=0.98, rel_max=0.2):
   return None if (cos > cos_min and rel < rel_max) else (name, round(cos, 4), round(rel, 4))
 
 
+def style_oracle_params(enc, leaf):
+  """fp32 leaves of a StyleEncoder's parameters in the layout oracle.gst.style_encoder takes."""
+  bf = lambda t: t.to(torch.bfloat16).float()
+  H, W = enc.H, enc.in_dim
+  P = {"convs": [(leaf(c.kernel, bf(c.kernel.master.cpu())), leaf(c.gamma, c.gamma.master.cpu()),
+                  leaf(c.beta, c.beta.master.cpu())) for c in enc.convs]}
+  wgx = leaf(enc.wg_x, enc.wg_x.w16.float().cpu().view(2 * H, W))
+  wgh = leaf(enc.wg_h, enc.wg_h.master.cpu())
+  wcx = leaf(enc.wc_x, enc.wc_x.w16.float().cpu().view(H, W))
+  wch = leaf(enc.wc_h, enc.wc_h.master.cpu())
+  P["wg"] = torch.cat([wgx.t(), wgh], 0)
+  P["wc"] = torch.cat([wcx.t(), wch], 0)
+  P["bg"], P["bc"] = leaf(enc.bg, enc.bg.master.cpu()), leaf(enc.bc, enc.bc.master.cpu())
+  d2 = lambda dn: leaf(dn.kernel, dn.kernel.w16.float().cpu().view(dn.cout, dn.cin))
+  P["ref_w"], P["ref_b"] = d2(enc.ref).t(), leaf(enc.ref.bias, enc.ref.bias.master.cpu())
+  P["wq"], P["wk"], P["wv"], P["wo"] = d2(enc.q).t(), d2(enc.k).t(), d2(enc.v).t(), d2(enc.o).t()
+  P["att_v"] = leaf(enc.att_v, enc.att_v.master.cpu())
+  P["tokens"] = enc.tokens.cpu()
+  return P
+
+
 def test_style_encoder_fwd_bwd(cuda):
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.parts.tacotron.gst import StyleEncoder
@@ -55,22 +76,7 @@ def test_style_encoder_fwd_bwd(cuda):
     leaves[p.name] = t
     return t
 
-  bf = lambda t: t.to(torch.bfloat16).float()
-  H, W = enc.H, enc.in_dim
-  P = {"convs": [(leaf(c.kernel, bf(c.kernel.master.cpu())), leaf(c.gamma, c.gamma.master.cpu()),
-                  leaf(c.beta, c.beta.master.cpu())) for c in enc.convs]}
-  wgx = leaf(enc.wg_x, enc.wg_x.w16.float().cpu().view(2 * H, W))
-  wgh = leaf(enc.wg_h, enc.wg_h.master.cpu())
-  wcx = leaf(enc.wc_x, enc.wc_x.w16.float().cpu().view(H, W))
-  wch = leaf(enc.wc_h, enc.wc_h.master.cpu())
-  P["wg"] = torch.cat([wgx.t(), wgh], 0)
-  P["wc"] = torch.cat([wcx.t(), wch], 0)
-  P["bg"], P["bc"] = leaf(enc.bg, enc.bg.master.cpu()), leaf(enc.bc, enc.bc.master.cpu())
-  d2 = lambda dn: leaf(dn.kernel, dn.kernel.w16.float().cpu().view(dn.cout, dn.cin))
-  P["ref_w"], P["ref_b"] = d2(enc.ref).t(), leaf(enc.ref.bias, enc.ref.bias.master.cpu())
-  P["wq"], P["wk"], P["wv"], P["wo"] = d2(enc.q).t(), d2(enc.k).t(), d2(enc.v).t(), d2(enc.o).t()
-  P["att_v"] = leaf(enc.att_v, enc.att_v.master.cpu())
-  P["tokens"] = enc.tokens.cpu()
+  P = style_oracle_params(enc, leaf)
   ref = ogst.style_encoder(P, spec.float(), lens, CONVS, 2)
   (ref * dout.float()).sum().backward()
   rel = float((out.data.float().cpu() - ref.detach()).norm() / ref.detach().norm())

@@ -27,7 +27,13 @@ def _cmp(got, ref, name, cos_min=0.985, rel_max=0.17):
   return None if (cos > cos_min and rel < rel_max) else (name, round(cos, 4), round(rel, 4))
 
 
-def test_tacotron2_small_fwd_bwd(cuda, monkeypatch):
+STYLE = {"conv_layers": [{"kernel_size": [3, 3], "stride": [2, 2], "num_channels": 16, "padding": "SAME"}] * 2,
+         "num_rnn_layers": 1, "rnn_cell_dim": 32, "rnn_unidirectional": True, "rnn_type": "GRUCell",
+         "emb_size": 64, "attention_layer_size": 64, "num_tokens": 10, "num_heads": 1}
+
+
+@pytest.mark.parametrize("style", [False, True])
+def test_tacotron2_small_fwd_bwd(cuda, monkeypatch, style):
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders import Tacotron2Encoder
   from openseq2seq_amd.decoders import Tacotron2Decoder
@@ -40,11 +46,14 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch):
   torch.manual_seed(0)
   V, E, Henc, H, NM, NG = 40, 64, 32, 64, 16, 24
   store = FlatParams(cuda)
-  enc = Tacotron2Encoder({"cnn_dropout_prob": 0.0, "rnn_dropout_prob": 0.0, "src_emb_size": E,
-                          "conv_layers": CONVS, "activation_fn": "relu", "num_rnn_layers": 1,
-                          "rnn_cell_dim": Henc, "use_cudnn_rnn": True, "rnn_type": "CudnnLSTM",
-                          "rnn_unidirectional": False, "dtype": "mixed"}, None, mode="train")
-  enc.build(store, src_vocab_size=V)
+  ep = {"cnn_dropout_prob": 0.0, "rnn_dropout_prob": 0.0, "src_emb_size": E,
+        "conv_layers": CONVS, "activation_fn": "relu", "num_rnn_layers": 1,
+        "rnn_cell_dim": Henc, "use_cudnn_rnn": True, "rnn_type": "CudnnLSTM",
+        "rnn_unidirectional": False, "dtype": "mixed"}
+  if style:
+    ep.update({"style_embedding_enable": True, "style_embedding_params": STYLE})
+  enc = Tacotron2Encoder(ep, None, mode="train")
+  enc.build(store, src_vocab_size=V, num_style_features=NM)
   dec = Tacotron2Decoder({"attention_layer_size": 128, "attention_type": "location",
                           "attention_bias": True, "decoder_cell_units": H,
                           "decoder_cell_type": "LSTMCell", "decoder_layers": 2, "dropout_prob": 0.0,
@@ -70,7 +79,10 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch):
   stop = (torch.arange(T)[None, :] >= (spec_len[:, None] - 2)).float()
   tape = Tape()
   store.zero_grads()
-  e = enc.encode({"source_tensors": [text.to(cuda), text_len.to(cuda)], "tape": tape, "seeds": SeedSeq(5)})
+  srcs = [text.to(cuda), text_len.to(cuda)]
+  if style:      # style_input "wav": the target mel itself + its length
+    srcs += [spec[..., :NM].contiguous().to(cuda), spec_len.to(cuda)]
+  e = enc.encode({"source_tensors": srcs, "tape": tape, "seeds": SeedSeq(5)})
   tgt = [spec.to(cuda), stop.to(cuda), spec_len.to(cuda)]
   d = dec.decode({"encoder_output": e, "target_tensors": tgt, "tape": tape})
   L = lossf.compute_loss({"decoder_output": d, "target_tensors": tgt})
@@ -122,7 +134,18 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch):
         "postnet": [convbn(cv) for cv in dec.postnet],
         "mag": {"c0": convbn(dec.mag[0]), "c1": convbn(dec.mag[1]),
                 "proj": leaf(dec.mag_proj, (dec.n_mag_pad, 512), rows=NG)}}
-  enc_out = otac.encoder(EP, text, lstm)
+  style_vec = None
+  if style:
+    from oracle import gst as ogst
+    from test_gst_gpu import style_oracle_params
+
+    def leaf2(p, t):
+      t = t.clone().requires_grad_(True)
+      leaves[p.name] = (t, None)
+      return t
+    SP = style_oracle_params(enc.style, leaf2)
+    style_vec = ogst.style_encoder(SP, spec[..., :NM], spec_len, STYLE["conv_layers"], 1)
+  enc_out = otac.encoder(EP, text, lstm, style=style_vec)
   out = otac.decoder(DP, enc_out, text_len, spec[..., :NM], ["tanh", "tanh", None])
   ref = otac.text2speech_loss(out, spec, stop, spec_len, NM, NG)
   ref.backward()
