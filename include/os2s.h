@@ -491,6 +491,22 @@ int os2s_attn_decoder_bwd(os2s_stream_t stream, const os2s_attn_decoder_t* d,
                           size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------
+ * TTS spectrogram features: get_speech_features (data/text2speech/speech_utils.py:98-182) =
+ * librosa.stft(y, n_fft) [hop = n_fft/4 by default, periodic Hann(n_fft) passed in `window`,
+ * centre=True with reflect padding] -> |X|^mag_power -> out_mag[b,t,:n_mag] =
+ * log(clip(mag, data_min_mag)) and out_mel[b,t,:] = log(clip(mel_basis . mag, data_min_mel)).
+ * signal fp32 [B, sig_stride], n_samples [B]; frames t >= 1 + n_samples/hop are filled with
+ * pad_mel / pad_mag. The mel basis is passed in compact form (per filter: first bin, length,
+ * weights mel_wt[i * n_mels + m]). Either output may be NULL. fp32 [B, T, *].
+ * ---------------------------------------------------------------------- */
+int os2s_tts_spectrogram(os2s_stream_t stream, const float* signal, long long sig_stride,
+                         const int32_t* n_samples, const float* window, int B, int n_fft, int hop,
+                         int T, int mag_power, float data_min_mag, float data_min_mel, int n_mag,
+                         int n_mels, const int32_t* mel_start, const int32_t* mel_len,
+                         const float* mel_wt, int mel_maxlen, float* out_mel, float* out_mag,
+                         float pad_mel, float pad_mag);
+
+/* ------------------------------------------------------------------------
  * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:
  *   mode 0: tf.losses.mean_squared_error, 1: absolute_difference (l1_norm), both with
  *           weights = sequence_mask(lens) and SUM_BY_NONZERO_WEIGHTS: sum / (F * sum_b len_b)

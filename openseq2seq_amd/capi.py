@@ -938,3 +938,22 @@ def gst_attention_bwd(dout, q, k, v, att_v, w, heads, dk, dv, datt_v):
                N, _ptr(dq), _ptr(dk, torch.float32), _ptr(dv, torch.float32),
                _ptr(datt_v, torch.float32)), "os2s_gst_attention_bwd")
   return dq
+
+
+def tts_spectrogram(signal, n_samples, window, *, n_fft, hop, T, mag_power, data_min_mag, data_min_mel,
+                    n_mag, n_mels, mel_start=None, mel_len=None, mel_wt=None, pad_mel=0.0, pad_mag=0.0):
+  """signal fp32 [B, N] -> (mel fp32 [B,T,n_mels] | None, log-mag fp32 [B,T,n_mag] | None)."""
+  B = signal.shape[0]
+  dev = signal.device
+  f32 = torch.float32
+  mel = torch.empty((B, T, n_mels), dtype=f32, device=dev) if n_mels else None
+  mag = torch.empty((B, T, n_mag), dtype=f32, device=dev) if n_mag else None
+  f = _fn("os2s_tts_spectrogram", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_void_p, c_void_p, c_float, c_float))
+  _lib.check(f(_stream(), _ptr(signal, f32), signal.stride(0), _ptr(n_samples, torch.int32),
+               _ptr(window, f32), B, n_fft, hop, T, mag_power, float(data_min_mag), float(data_min_mel),
+               n_mag or 0, n_mels or 0, _ptr(mel_start, torch.int32, True), _ptr(mel_len, torch.int32, True),
+               _ptr(mel_wt, f32, True), 0 if mel_wt is None else mel_wt.shape[0], _ptr(mel, None, True),
+               _ptr(mag, None, True), float(pad_mel), float(pad_mag)), "os2s_tts_spectrogram")
+  return mel, mag
