@@ -57,7 +57,9 @@ def parse():
 
 
 class ConvTimer(object):
-  """Wraps capi.conv1d_fwd: HIP events around every launch + algorithmic FLOPs."""
+  """Wraps capi.conv1d_fwd: HIP events around every launch + the FLOPs it EXECUTES: the dense
+  2*B*Tout*Cin*Cout*K scaled by the fraction of 128-row time tiles that are not skipped as
+  exact zeros (input window past in_len) or as never-read outputs (tile past out_len)."""
 
   def __init__(self, capi):
     self.capi = capi
@@ -76,18 +78,44 @@ class ConvTimer(object):
       e0.record()
       out = timer.orig(x, w, **kw)
       e1.record()
-      B, _, Cin = x.shape
+      B, tin, Cin = x.shape
       K, Cout, _ = w.shape
       tout = out.shape[0] if kw.get("time_major") else out.shape[1]
-      timer.records.append((e0, e1, 2.0 * B * tout * Cin * Cout * K))
+      stride, dil = kw.get("stride", 1), kw.get("dil", 1)
+      pl = kw.get("pad_left")
+      if pl is None:
+        pl = timer.capi.same_padding(tin, K, stride, dil)[1]
+      timer.records.append((e0, e1, 2.0 * B * tout * Cin * Cout * K,
+                            (kw.get("in_len"), kw.get("out_len"), tin, tout, stride, pl)))
       return out
 
     self.capi.conv1d_fwd = wrapped
     # modules that imported the symbol through `capi.` pick the wrapper up automatically
 
+  @staticmethod
+  def _live_fraction(geom, cache):
+    in_len, out_len, tin, tout, stride, pl = geom
+    if in_len is None and out_len is None:
+      return 1.0
+    ntile = -(-tout // 128)
+    t0 = torch.arange(ntile)[None, :] * 128
+    live = torch.ones((1, ntile), dtype=torch.bool)
+    for ln, is_in in ((in_len, True), (out_len, False)):
+      if ln is None:
+        continue
+      key = ln.data_ptr()
+      if key not in cache:
+        cache[key] = ln.cpu().to(torch.int64)
+      l = cache[key][:, None]
+      live = live & ((t0 * stride - pl < l.clamp(max=tin)) if is_in else (t0 < l))
+    return float(live.float().mean())
+
   def summary(self):
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-    fl = sum(f for _, _, f in self.records)
+    cache = {}
+    ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+    dense = sum(r[2] for r in self.records)
+    fl = sum(r[2] * self._live_fraction(r[3], cache) for r in self.records)
+    self.dense_flops = dense
     return ms, fl, len(self.records)
 
 
@@ -336,6 +364,10 @@ def main():
         "launches_per_step": n / max(args.steps, 1),
         "avg_launch_ms": ms / max(n, 1),
         "time_share_of_step": ms / (1000.0 * dt),
+        "executed_flop_fraction": fl / max(timer.dense_flops, 1.0),
+        "dense_equivalent_tflops": timer.dense_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+        "note": "achieved = FLOPs of the executed (non-skipped) time tiles / HIP-event time; "
+                "tiles whose input window is all padding are exact zeros and are not multiplied",
     }
   if not args.no_transformer:
     # free the Jasper model first

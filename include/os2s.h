@@ -107,7 +107,12 @@ int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
                        int Tin, int Cin, int Cout, int K, int stride, int dil, int padL,
                        int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
                        int accumulate, int act, float keep_prob, unsigned long long seed,
-                       const uint16_t* residual);
+                       const uint16_t* residual, const int32_t* out_len);
+/* Ragged batches: tiles whose whole input window lies past in_len[b] skip the matrix work
+ * (their output is the exact zero / bias tile); with out_len != NULL output tiles that start
+ * at t >= out_len[b] are not computed or stored at all (data gradients: the consumer masks
+ * those rows, encoders/tdnn_encoder.py:185-186,204-205). os2s_conv1d_wgrad likewise visits
+ * only the (sample, 64-row) chunks whose X window starts before in_len[b]. */
 /* tuning hook: 3 (default) = 128x128 tile / 4 waves, X window single-buffered when K >= 8
  * (3 workgroups per CU); 0 = always double-buffered; 1 = two 128-row windows / 8 waves;
  * 2 = two windows / 4 waves with 128x64 wave tiles */

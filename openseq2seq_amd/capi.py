@@ -91,7 +91,7 @@ def conv1d_num_mtiles(B, tout):
 
 def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
                bias=None, stats=None, out=None, out_f32=False, accumulate=False,
-               time_major=False, act=0, keep_prob=1.0, seed=0, residual=None):
+               time_major=False, act=0, keep_prob=1.0, seed=0, residual=None, out_len=None):
   """x [B,Tin,Cin] bf16, w [K,Cout,Cin] bf16 -> y [B,Tout,Cout] (or [Tout,B,Cout]
   when time_major). pad_left/tout default to TF 'SAME'."""
   B, Tin, Cin = x.shape
@@ -110,13 +110,14 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
   f = _fn("os2s_conv1d_fwd_ex",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-           c_ll, c_ll, c_int, c_int, c_int, c_float, c_uint64, c_void_p))
+           c_ll, c_ll, c_int, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16),
                _ptr(out, dt), _ptr(in_len, torch.int32, True),
                _ptr(bias, torch.float32, True), _ptr(stats, torch.float32, True),
                B, Tin, Cin, Cout, K, stride, dil, pad_left, tout, ysb, yst,
                int(out_f32), int(accumulate), int(act), float(keep_prob),
-               int(seed) & (2**64 - 1), _ptr(residual, torch.bfloat16, True)),
+               int(seed) & (2**64 - 1), _ptr(residual, torch.bfloat16, True),
+               _ptr(out_len, torch.int32, True)),
              "os2s_conv1d_fwd_ex")
   return out
 

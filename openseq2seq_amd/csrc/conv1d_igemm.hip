@@ -39,6 +39,7 @@ struct ConvArgs {
   const bf16_t* w;
   void* y;
   const int32_t* in_len;
+  const int32_t* out_len;   // rows t >= out_len[b] of the OUTPUT are never read by the caller
   const float* bias;
   float* stats;
   int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
@@ -99,6 +100,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
     wlen[w] = live ? len_b : 0;                   // dead window: every row reads as zero
     wwin[w] = wt0[w] * p.stride - p.padL;
   }
+  // Exact-zero shortcuts (ragged batches are padded to the longest utterance):
+  //  * every row of the input window lies past in_len -> the accumulators stay zero, the
+  //    MFMA loop is skipped (the epilogue still stores the zero tile + zero BN partials);
+  //  * the whole output tile lies past out_len -> nobody reads it, nothing is done at all.
+  bool dead_in = true;
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) dead_in = dead_in && (wwin[w] >= wlen[w] || m_first + w >= p.MT);
+  if (p.out_len) {
+    bool dead_out = true;
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w)
+      dead_out = dead_out && (m_first + w >= p.MT || wt0[w] >= p.out_len[wb[w]]);
+    if (dead_out) return;
+  }
   static_assert(NWIN == 1 || NWIN == 2, "window selects below are written for <= 2 windows");
   // select by compare (a runtime-indexed register array would be demoted to scratch)
   const int my_b = (NWIN == 1 || my_win == 0) ? wb[0] : wb[NWIN - 1];
@@ -153,9 +168,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[in][im][e] = 0.f;
 
-  const int nsteps = p.nchunks * p.K;
-  stage_x(0, xbuf0);
-  stage_w(0, 0, wbuf0);
+  const int nsteps = dead_in ? 0 : p.nchunks * p.K;
+  if (!dead_in) {
+    stage_x(0, xbuf0);
+    stage_w(0, 0, wbuf0);
+  }
   int c = 0, k = 0;
   const int l31 = lane & 31, lhi = lane >> 5;
   for (int step = 0; step < nsteps; ++step) {
@@ -384,7 +401,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
                            int Tin, int Cin, int Cout, int K, int stride, int dil, int padL,
                            int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
                            int accumulate, int act, float keep_prob, unsigned long long seed,
-                           const uint16_t* residual);
+                           const uint16_t* residual, const int32_t* out_len);
 
 extern "C" int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                                   void* y, const int32_t* in_len, const float* bias,
@@ -392,10 +409,11 @@ extern "C" int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const
                                   int stride, int dil, int padL, int Tout,
                                   long long y_stride_b, long long y_stride_t, int out_f32,
                                   int accumulate, int act, float keep_prob,
-                                  unsigned long long seed, const uint16_t* residual) {
+                                  unsigned long long seed, const uint16_t* residual,
+                                  const int32_t* out_len) {
   return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
                          padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, act, keep_prob,
-                         seed, residual);
+                         seed, residual, out_len);
 }
 
 extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
@@ -405,7 +423,7 @@ extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const ui
                                int out_f32, int accumulate) {
   return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
                          padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, 0, 1.f, 0,
-                         nullptr);
+                         nullptr, nullptr);
 }
 
 static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
@@ -413,7 +431,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
                            float* stats, int B, int Tin, int Cin, int Cout, int K, int stride,
                            int dil, int padL, int Tout, long long y_stride_b,
                            long long y_stride_t, int out_f32, int accumulate, int act,
-                           float keep_prob, unsigned long long seed, const uint16_t* residual) {
+                           float keep_prob, unsigned long long seed, const uint16_t* residual, const int32_t* out_len) {
   using namespace os2s;
   OS2S_REQUIRE(act == 0 || act == 1);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
@@ -425,7 +443,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
   if (!out_f32) OS2S_REQUIRE(Cout % 8 == 0 && y_stride_t % 8 == 0 && y_stride_b % 8 == 0);
   if (B == 0) return OS2S_OK;
   ConvArgs a;
-  a.x = x; a.w = w; a.y = y; a.in_len = in_len; a.bias = bias; a.stats = stats;
+  a.x = x; a.w = w; a.y = y; a.in_len = in_len; a.out_len = out_len; a.bias = bias; a.stats = stats;
   a.B = B; a.Tin = Tin; a.Tout = Tout; a.Cin = Cin; a.Cout = Cout; a.K = K;
   a.stride = stride; a.dil = dil; a.padL = padL;
   a.x_sb = (long long)Tin * Cin; a.x_st = Cin;

@@ -80,18 +80,39 @@ __global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_ke
   char* const xbuf0 = smem + 2 * ybuf_bytes;
   const char* const zero = reinterpret_cast<const char*>(g_zero_page);
 
-  // the reduction index space (batch item, 64-row time chunk) is cut into NSPLIT
-  // contiguous ranges of steps
+  // The reduction index space is (batch item, 64-row time chunk). X rows past in_len[b] are
+  // exact zeros (masked conv inputs), so chunks whose whole X window lies past the sequence
+  // end contribute nothing and are not visited: only the LIVE steps are cut into NSPLIT
+  // contiguous ranges (every workgroup derives the same enumeration from in_len).
   const int tchunks = (p.Tout + BT - 1) / BT;
-  const int total_steps = p.B * tchunks;
-  const int s_begin = split * p.steps_per_split;
-  const int s_end = min(total_steps, s_begin + p.steps_per_split);
+  auto nlive = [&](int b) -> int {
+    if (!p.in_len) return tchunks;
+    const int l = min(max(p.in_len[b], 0), p.Tin);
+    if (l <= 0) return 0;
+    return min(tchunks, (l + p.padL + BT * p.stride - 1) / (BT * p.stride));
+  };
+  int total_live = 0;
+  for (int b = 0; b < p.B; ++b) total_live += nlive(b);
+  const int sps = (total_live + p.NSPLIT - 1) / p.NSPLIT;
+  const int s_begin = split * sps;
+  const int s_end = min(total_live, s_begin + sps);
   const int nsteps = max(0, s_end - s_begin);
+  int cur_b = 0, cur_c = 0;   // cursor of the NEXT step to stage
+  {
+    int acc_steps = 0;
+    while (cur_b < p.B && acc_steps + nlive(cur_b) <= s_begin) { acc_steps += nlive(cur_b); ++cur_b; }
+    cur_c = s_begin - acc_steps;
+  }
 
   auto stage = [&](int step, int buf) {
-    const int gs = s_begin + step;
-    const int b = gs / tchunks;
-    const int t0 = (gs - b * tchunks) * BT;
+    const int b = min(cur_b, p.B - 1);
+    const int t0 = cur_c * BT;
+    ++cur_c;
+    if (cur_c >= nlive(b)) {
+      cur_c = 0;
+      ++cur_b;
+      while (cur_b < p.B && nlive(cur_b) == 0) ++cur_b;
+    }
     int len_b = p.Tin;
     if (p.in_len) {
       int l = p.in_len[b];

@@ -183,7 +183,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
         tin = inp.data.shape[1]
         capi.conv1d_fwd(dy, br.kernel.wt16, dil=br.dil,
                         pad_left=(br.k - 1) * br.dil - f["pad_left"], tout=tin, out=g,
-                        accumulate=inp.grad_init)
+                        accumulate=inp.grad_init, out_len=inp.lens)
         inp.grad_init = True
 
   tape.record(backward, [p for br in branches for p in (br.kernel, br.gamma, br.beta)])
