@@ -31,6 +31,9 @@
 //   * XCD-aware block order: the blocks resident on one XCD at a time share the
 //     same weight n-tile, so the weight stream is an L2 hit for all but one.
 #include "os2s_common.hpp"
+#include <array>
+#include <map>
+#include <mutex>
 
 namespace os2s {
 
@@ -388,7 +391,12 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
 
 }  // namespace os2s
 
-static int g_conv_variant = 3;   // default: single-buffered X window (3 workgroups/CU) for K >= 8
+// -1 (default) = pick per problem shape between the 128x128 tile (variant 3 / 0) and the
+// 256x256 tile (variant 5) by timing both once — the lazily built kernel cache of the ABI
+// contract; which one wins is decided by tile quantisation against the 256 CUs (e.g. B*T' =
+// 28k rows: Cout 512 -> 224 256^2 tiles = one round at 975 TF/s vs 824; Cout 640 -> 336 tiles
+// = 1.3 rounds at 712 vs 913).
+static int g_conv_variant = -1;
 // tuning hook (not part of the stable ABI surface used by the host layer)
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
 
@@ -450,9 +458,58 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
   a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
+  if (g_conv_variant == -1) {
+    const int base = K >= 8 ? 3 : 0;
+    auto run = [&](int v) -> int {
+      if (v == 5) return launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
+      if (v == 3) return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>((hipStream_t)stream, a);
+      return launch_conv<kConvBM, kConvBN, 2, 2, 1>((hipStream_t)stream, a);
+    };
+    const bool tunable = Cout >= 256 && !accumulate && !residual && !out_f32;
+    static std::mutex mu;
+    static std::map<std::array<int, 8>, int> cache;
+    const std::array<int, 8> key = {B, Tin, Cin, Cout, K, stride, dil, Tout};
+    int choice = -1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = cache.find(key);
+      if (it != cache.end()) choice = it->second;
+    }
+    if (choice < 0 && Cout < 256) choice = base;
+    if (choice < 0 && !tunable) return run(base);     // decided by a later tunable call of this shape
+    if (choice < 0) {
+      float best = 1e30f;
+      choice = base;
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run(base);
+      for (int v : {base, 5}) {
+        if (run(v) != OS2S_OK) continue;              // warm-up (also: unsupported LDS size)
+        hipEventRecord(e0, (hipStream_t)stream);
+        for (int r = 0; r < 3; ++r) run(v);
+        hipEventRecord(e1, (hipStream_t)stream);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms > 0.f && ms < best) { best = ms; choice = v; }
+      }
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+      std::lock_guard<std::mutex> lk(mu);
+      cache[key] = choice;
+    }
+    return run(choice);
+  }
   if (g_conv_variant == 3 && K >= 8) {
     // single-buffered X window: 3 workgroups per CU
     return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>((hipStream_t)stream, a);
+  }
+  if (g_conv_variant >= 4 && g_conv_variant <= 6) {
+    // experiments with 256-wide output-channel tiles
+    int rc = OS2S_ERR_UNSUPPORTED;
+    if (g_conv_variant == 4) rc = launch_conv<kConvBM, 256, 2, 4, 2, true>((hipStream_t)stream, a);
+    if (g_conv_variant == 5) rc = launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
+    if (g_conv_variant == 6) rc = launch_conv<kConvBM, 256, 2, 2, 1, true>((hipStream_t)stream, a);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
   }
   if (g_conv_variant == 2) {
     // two windows, 4 waves, 128x64 wave tiles (0.75 LDS fragment reads per MFMA)

@@ -6,7 +6,7 @@ from openseq2seq_amd import capi
 
 dev = torch.device("cuda:0")
 from openseq2seq_amd import _lib
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else -1
 _lib.lib().os2s_conv1d_set_variant(variant)
 print("variant", variant)
 B, T = 32, 840
