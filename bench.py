@@ -45,6 +45,8 @@ def parse():
   ap.add_argument("--no-transformer", action="store_true",
                   help="skip the secondary Transformer-big tokens/sec measurement")
   ap.add_argument("--transformer-batch", type=int, default=256)
+  ap.add_argument("--only-quartznet", action="store_true",
+                  help="QuartzNet 15x5 (separable convolutions) train step only: frames/sec")
   ap.add_argument("--only-tacotron", action="store_true",
                   help="Tacotron2 (tacotron_gst.py shapes) train step only: mel frames/sec")
   ap.add_argument("--no-style", action="store_true", help="Tacotron2 without the GST style encoder")
@@ -243,6 +245,27 @@ def main():
   dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
 
+  if args.only_quartznet:
+    from openseq2seq_amd.configs.quartznet import quartznet15x5_config
+    model_cls, params = quartznet15x5_config()
+    model = model_cls(params, mode="train", hvd=hvd, device=dev)
+    model.compile()
+    batch = model.get_data_layer().synthetic_batch(dev, seed=1234 + rank)
+    for _ in range(args.warmup):
+      model.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      loss = model.train_step(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+      print(json.dumps({"metric": "audio-frames/sec QuartzNet15x5 bf16 (train step)",
+                        "value": batch['num_frames'] * args.steps / dt, "unit": "frames/sec",
+                        "ms_per_step": 1000 * dt / args.steps, "n_gpus": world,
+                        "params_M": model.store.num_trainable() / 1e6,
+                        "loss": float(loss.cpu()[0])}))
+    return
   if args.only_tacotron:
     from openseq2seq_amd.configs.tacotron import tacotron_gst_config
     model_cls, params = tacotron_gst_config(style=not args.no_style)

@@ -512,6 +512,23 @@ int os2s_tts_spectrogram(os2s_stream_t stream, const float* signal, long long si
                          float pad_mel, float pad_mag);
 
 /* ------------------------------------------------------------------------
+ * Depthwise half of tf.layers.separable_conv1d (layer type "sep_conv1d",
+ * parts/cnns/conv_blocks.py:11-16; QuartzNet): y[b,t,c] = sum_k x[b, t*stride + k*dil -
+ * padL, c] * w[k,c]; x, y bf16 channels-last, w fp32 [K, C] (TF depthwise_kernel [K, C, 1]),
+ * x rows >= in_len[b] read as zero, output tiles past out_len[b] are skipped (may be NULL).
+ * flip_taps = 1 applies w[K-1-k] (the data gradient: call with x = dz, padL' = (K-1)*dil -
+ * padL, stride 1). os2s_depthwise_conv1d_wgrad ACCUMULATES dw[k,c] += sum_{b,t} dy[b,t,c] *
+ * x[b, t*stride + k*dil - padL, c] (fp32 atomics). The pointwise half is os2s_conv1d_fwd, K = 1.
+ * ---------------------------------------------------------------------- */
+int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const float* w, uint16_t* y,
+                              const int32_t* in_len, const int32_t* out_len, int B, int Tin,
+                              int Tout, int C, int K, int stride, int dil, int padL,
+                              int flip_taps);
+int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* dy,
+                                float* dw, const int32_t* in_len, int B, int Tin, int Tout, int C,
+                                int K, int stride, int dil, int padL);
+
+/* ------------------------------------------------------------------------
  * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:
  *   mode 0: tf.losses.mean_squared_error, 1: absolute_difference (l1_norm), both with
  *           weights = sequence_mask(lens) and SUM_BY_NONZERO_WEIGHTS: sum / (F * sum_b len_b)

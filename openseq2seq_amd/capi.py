@@ -958,3 +958,34 @@ def tts_spectrogram(signal, n_samples, window, *, n_fft, hop, T, mag_power, data
                _ptr(mel_wt, f32, True), 0 if mel_wt is None else mel_wt.shape[0], _ptr(mel, None, True),
                _ptr(mag, None, True), float(pad_mel), float(pad_mag)), "os2s_tts_spectrogram")
   return mel, mag
+
+
+# --------------------------------------------------------------------------
+# depthwise conv1d (sep_conv1d)
+# --------------------------------------------------------------------------
+def depthwise_conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None, out_len=None,
+                         flip=False):
+  """x bf16 [B,Tin,C], w fp32 [K,C] -> y bf16 [B,Tout,C]."""
+  B, Tin, C = x.shape
+  K = w.shape[0]
+  if pad_left is None or tout is None:
+    tout, pad_left = same_padding(Tin, K, stride, dil)
+  y = (torch.zeros if out_len is not None else torch.empty)((B, tout, C), dtype=torch.bfloat16, device=x.device)
+  f = _fn("os2s_depthwise_conv1d_fwd", (c_void_p,) * 6 + (c_int,) * 9)
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.float32), _ptr(y),
+               _ptr(in_len, torch.int32, True), _ptr(out_len, torch.int32, True), B, Tin, tout, C, K,
+               stride, dil, pad_left, int(flip)), "os2s_depthwise_conv1d_fwd")
+  return y
+
+
+def depthwise_conv1d_wgrad(x, dy, dw, *, stride=1, dil=1, pad_left=None, in_len=None):
+  """dw fp32 [K,C] += sum dy * shifted x."""
+  B, Tin, C = x.shape
+  K = dw.shape[0]
+  tout = dy.shape[1]
+  if pad_left is None:
+    pad_left = same_padding(Tin, K, stride, dil)[1]
+  f = _fn("os2s_depthwise_conv1d_wgrad", (c_void_p,) * 5 + (c_int,) * 8)
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32),
+               _ptr(in_len, torch.int32, True), B, Tin, tout, C, K, stride, dil, pad_left),
+             "os2s_depthwise_conv1d_wgrad")

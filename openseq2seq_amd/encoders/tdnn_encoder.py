@@ -11,7 +11,7 @@ from __future__ import absolute_import, division, print_function
 import torch
 
 from .encoder import Encoder
-from ..parts.cnns.conv_blocks import (Act, ConvBN, conv_bn_res_bn_actv, xavier_normal_conv,
+from ..parts.cnns.conv_blocks import (Act, ConvBN, SepConvBN, conv_bn_res_bn_actv, xavier_normal_conv,
                                       glorot_uniform_conv)
 
 
@@ -65,8 +65,9 @@ class TDNNEncoder(Encoder):
     res_channels = []   # channels of the dense-residual inputs accumulated so far
     layers = []
     for ib, blk in enumerate(p['convnet_layers']):
-      if blk['type'] != 'conv1d':
+      if blk['type'] not in ('conv1d', 'sep_conv1d'):
         raise NotImplementedError("layer type %s has no HIP kernel yet" % blk['type'])
+      Layer = SepConvBN if blk['type'] == 'sep_conv1d' else ConvBN
       residual = blk.get('residual', False)
       dense = blk.get('residual_dense', False)
       if residual:
@@ -77,7 +78,7 @@ class TDNNEncoder(Encoder):
           res_in = [cin]
       for ir in range(blk['repeat']):
         lname = "%s/conv%d%d" % (scope, ib + 1, ir + 1)
-        main = ConvBN(store, lname, lname + "/bn", cin, blk['num_channels'],
+        main = Layer(store, lname, lname + "/bn", cin, blk['num_channels'],
                       blk['kernel_size'][0], blk['stride'][0], blk['dilation'][0] if
                       'dilation' in blk else 1, blk['padding'], mom, eps, l2, initializer)
         res = []
@@ -86,8 +87,9 @@ class TDNNEncoder(Encoder):
             rn = (lname + "/res_%d" % i) if dense else (lname + "/res")
             bn = (lname + "/res_bn_%d" % i) if dense else (lname + "/res_bn")
             # tf.layers.conv1d(res, filters, 1, use_bias=False): default glorot_uniform
-            res.append(ConvBN(store, rn, bn, rc, blk['num_channels'], 1, 1, 1, "SAME", mom,
-                              eps, l2, glorot_uniform_conv))
+            # residual branches go through the block's own layer type (conv_blocks.py:66,79-85)
+            res.append(Layer(store, rn, bn, rc, blk['num_channels'], 1, 1, 1, "SAME", mom,
+                             eps, l2, glorot_uniform_conv))
         layers.append(dict(block=ib, rep=ir, main=main, res=res, cfg=blk))
         cin = blk['num_channels']
     self._layers = layers

@@ -132,6 +132,91 @@ class ConvBN(object):
                      sc, sh)
     return dict(y=y, scale=sc, shift=sh, mean=mean, rstd=rstd, tout=tout, pad_left=pl)
 
+  def trainable(self):
+    return [self.kernel, self.gamma, self.beta]
+
+  def backward_branch(self, inp, dy, f):
+    """Weight and data gradients of the convolution given dy = d(conv output)."""
+    capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
+                      pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
+                      accumulate=True)
+    if inp.requires_grad:
+      if self.stride != 1:
+        raise NotImplementedError("data-gradient of a strided conv")
+      g = inp.grad_buffer()
+      tin = inp.data.shape[1]
+      capi.conv1d_fwd(dy, self.kernel.wt16, dil=self.dil,
+                      pad_left=(self.k - 1) * self.dil - f["pad_left"], tout=tin, out=g,
+                      accumulate=inp.grad_init, out_len=inp.lens)
+      inp.grad_init = True
+
+
+class SepConvBN(ConvBN):
+  """tf.layers.separable_conv1d(use_bias=False) + batch norm (layer type "sep_conv1d",
+  conv_blocks.py:11-16): variables '<name>/depthwise_kernel' [K, Cin] (TF: [K, Cin, 1]),
+  '<name>/pointwise_kernel' [1, Cout, Cin] (TF: [1, Cin, Cout]) and the BN pair. Residual
+  branches of a separable block are separable too with k = 1 (:66,79-85)."""
+
+  def __init__(self, store, name, bn_name, cin, cout, k, stride=1, dilation=1,
+               padding="SAME", bn_momentum=0.9, bn_epsilon=1e-3, l2=0.0,
+               initializer=xavier_normal_conv):
+    self.name, self.cin, self.cout, self.k = name, cin, cout, k
+    self.stride, self.dil, self.padding = stride, dilation, padding
+    self.momentum, self.eps = bn_momentum, bn_epsilon
+
+    def dw_init(shape):   # same initializer family over the TF shape [K, Cin, 1]
+      return initializer((shape[0], 1, shape[1]))[:, 0, :] if shape[0] * shape[1] > 0 else torch.zeros(shape)
+
+    self.depthwise = store.add(name + "/depthwise_kernel", (k, cin), dw_init, kind="vector", l2=l2)
+    self.kernel = store.add(name + "/pointwise_kernel", (1, cout, cin), initializer, kind="conv", l2=l2)
+    self.gamma = store.add(bn_name + "/gamma", (cout,), torch.ones(cout), kind="vector", l2=l2)
+    self.beta = store.add(bn_name + "/beta", (cout,), torch.zeros(cout), kind="vector")
+    dev = store.device
+    self.moving_mean = torch.zeros(cout, dtype=torch.float32, device=dev)
+    self.moving_var = torch.ones(cout, dtype=torch.float32, device=dev)
+
+  def conv_bn_stats(self, x, training):
+    B, Tin, _ = x.data.shape
+    tout, pl = self.out_geometry(Tin)
+    dev = x.data.device
+    C = self.cout
+    z = capi.depthwise_conv1d_fwd(x.data, self.depthwise.master, stride=self.stride, dil=self.dil,
+                                  pad_left=pl, tout=tout, in_len=x.lens)
+    stats = None
+    if training:
+      stats = torch.empty((capi.conv1d_num_mtiles(B, tout), 2, C), dtype=torch.float32, device=dev)
+    y = capi.conv1d_fwd(z, self.kernel.w16, pad_left=0, tout=tout, stats=stats)
+    sc = torch.empty(C, dtype=torch.float32, device=dev)
+    sh = torch.empty(C, dtype=torch.float32, device=dev)
+    mean = rstd = None
+    if training:
+      mean = torch.empty(C, dtype=torch.float32, device=dev)
+      rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    capi.bn_finalize(stats, B * tout, self.gamma.master, self.beta.master, self.eps,
+                     self.momentum, training, self.moving_mean, self.moving_var, mean, rstd,
+                     sc, sh)
+    return dict(y=y, scale=sc, shift=sh, mean=mean, rstd=rstd, tout=tout, pad_left=pl,
+                z=z if training else None)
+
+  def trainable(self):
+    return [self.depthwise, self.kernel, self.gamma, self.beta]
+
+  def backward_branch(self, inp, dy, f):
+    z = f["z"]
+    capi.conv1d_wgrad(z, dy, 1, pad_left=0, out=self.kernel.grad, accumulate=True)
+    dz = capi.conv1d_fwd(dy, self.kernel.wt16, pad_left=0, tout=z.shape[1])
+    f["z"] = None
+    capi.depthwise_conv1d_wgrad(inp.data, dz, self.depthwise.grad, stride=self.stride, dil=self.dil,
+                                pad_left=f["pad_left"], in_len=inp.lens)
+    if inp.requires_grad:
+      if self.stride != 1:
+        raise NotImplementedError("data-gradient of a strided separable conv")
+      tin = inp.data.shape[1]
+      dx = capi.depthwise_conv1d_fwd(dz, self.depthwise.master, dil=self.dil,
+                                     pad_left=(self.k - 1) * self.dil - f["pad_left"], tout=tin,
+                                     out_len=inp.lens, flip=True)
+      accumulate_grad(inp, dx)
+
 
 def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_fn,
                         training, tape, keep_prob=1.0, seed=0, mask_output=True):
@@ -173,20 +258,9 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
       dy = torch.empty_like(f["y"])
       capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1, c2, dy)
       f["y"] = None
-      capi.conv1d_wgrad(inp.data, dy, br.k, stride=br.stride, dil=br.dil,
-                        pad_left=f["pad_left"], in_len=inp.lens, out=br.kernel.grad,
-                        accumulate=True)
-      if inp.requires_grad:
-        if br.stride != 1:
-          raise NotImplementedError("data-gradient of a strided conv")
-        g = inp.grad_buffer()
-        tin = inp.data.shape[1]
-        capi.conv1d_fwd(dy, br.kernel.wt16, dil=br.dil,
-                        pad_left=(br.k - 1) * br.dil - f["pad_left"], tout=tin, out=g,
-                        accumulate=inp.grad_init, out_len=inp.lens)
-        inp.grad_init = True
+      br.backward_branch(inp, dy, f)
 
-  tape.record(backward, [p for br in branches for p in (br.kernel, br.gamma, br.beta)])
+  tape.record(backward, [p for br in branches for p in br.trainable()])
   return result
 
 

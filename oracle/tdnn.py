@@ -71,14 +71,23 @@ def tdnn_encode(x, src_len, convnet_layers, weights, activation="relu", use_conv
         mask = cnn.seq_mask(src_len, T)
       em = emulate_bf16
       # conv outputs are stored in bf16; their gradients (BN backward) too
-      y = _r(cnn.conv1d_tf(feats, weights[name + "/kernel"], s, d, blk["padding"]), em)
+      sep = blk.get("type", "conv1d") == "sep_conv1d"
+      if sep:
+        y = _r(cnn.sep_conv1d_tf(feats, weights[name + "/depthwise_kernel"],
+                                 weights[name + "/pointwise_kernel"], s, d, blk["padding"]), em)
+      else:
+        y = _r(cnn.conv1d_tf(feats, weights[name + "/kernel"], s, d, blk["padding"]), em)
       tot = cnn.batch_norm_train(y, weights[name + "/bn/gamma"], weights[name + "/bn/beta"],
                                  bn_eps)[0]
       if residual and ir == blk["repeat"] - 1:
         for i, r in enumerate(layer_res):
           rn = (name + "/res_%d" % i) if dense else (name + "/res")
           bn = (name + "/res_bn_%d" % i) if dense else (name + "/res_bn")
-          ry = _r(cnn.conv1d_tf(r, weights[rn + "/kernel"], 1, 1, "SAME"), em)
+          if sep:   # residual branches use the block's layer type with k = 1 (conv_blocks.py:66,79-85)
+            ry = _r(cnn.sep_conv1d_tf(r, weights[rn + "/depthwise_kernel"],
+                                      weights[rn + "/pointwise_kernel"], 1, 1, "SAME"), em)
+          else:
+            ry = _r(cnn.conv1d_tf(r, weights[rn + "/kernel"], 1, 1, "SAME"), em)
           tot = tot + cnn.batch_norm_train(ry, weights[bn + "/gamma"], weights[bn + "/beta"],
                                            bn_eps)[0]
       tot = _r(tot, em, fwd=False, bwd=True)      # dz is stored in bf16
