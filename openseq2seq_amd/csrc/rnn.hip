@@ -61,102 +61,72 @@ __device__ __forceinline__ int time_of(int s, int len, int reverse) {
   return reverse ? len - 1 - s : s;
 }
 
+// One workgroup = 8 hidden units x 32 samples of one direction: the 32 MFMA tile rows are
+// (gate, unit) pairs (row = 8*gate + unit; G = 3 leaves rows 24..31 empty), so H/8 workgroups
+// stream disjoint slices of the recurrent weights and after the split-K reduction a lane
+// owns all gates of one (unit, sample).
 template <int G>
 __global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_fwd_kernel(RnnStepArgs pa) {
   __shared__ float red[kRnnWaves * 16 * 64];
   const RnnDirFwd& p = pa.d[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
   const int H = pa.H;
-  f32x16 accw[G];
+  f32x16 accw;
 #pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accw[g][e] = 0.f;
-  tile_gemm_splitk<G, kRnnWaves, 2>(p.wh, H, H, j0, H, p.h_prev16, H, b0, pa.B, H, accw);
-  float acc[G][4];
-  tile_reduce_quarters<G, kRnnWaves>(accw, red, acc);
+  for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+  {
+    const int g = l31 >> 3, uu = min(j0 + (l31 & 7), H - 1);
+    const bf16_t* wrow = g < G ? p.wh + ((long long)g * H + uu) * H : nullptr;
+    const int brow = b0 + l31;
+    const bf16_t* irow = brow < pa.B ? p.h_prev16 + (long long)brow * H : nullptr;
+    tile_gemm_prefetch<kRnnWaves, 8>(wrow, irow, H, accw, p.wh);
+  }
+  float acc[4];
+  tile_reduce_units<kRnnWaves>(accw, red, acc);
   if (wave >= 4) return;
-  // lane: column b = b0 + l31; rows j = j0 + 4*lhi + (r&3) + 8*(r>>2)
   const int b = b0 + l31;
   if (b >= pa.B) return;
+  const int j = j0 + wave + 4 * lhi;
+  if (j >= H) return;
   const int len = pa.lens ? min(max(pa.lens[b], 0), pa.T) : pa.T;
   const int t = time_of(pa.step, len, p.reverse);
-  {
-    const int q = wave;   // this wave's quarter of the tile rows
-    const int j = j0 + 8 * q + 4 * lhi;
-    if (j >= H) return;
-    float hprev[4], hnew[4];
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h32 + (long long)b * H + j);
+  const float hprev = p.h32[(long long)b * H + j];
+  float hnew = hprev;      // past the sequence end the state passes through (dynamic_rnn)
+  if (t >= 0) {
+    const long long row = (long long)b * pa.T + t;
+    float pre[G];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) hprev[e] = hv[e];
-    if (t < 0) {
-      // past the sequence end: state passes through, no output (dynamic_rnn semantics)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) hnew[e] = hprev[e];
+    for (int g = 0; g < G; ++g) pre[g] = bf2f(p.gx[row * (G * H) + (long long)g * H + j]);
+    float sv[4];
+    if (pa.cell == kGruCudnn) {
+      const float br = p.bh ? p.bh[j] : 0.f, bz = p.bh ? p.bh[H + j] : 0.f, bn = p.bh ? p.bh[2 * H + j] : 0.f;
+      const float rg = sigmoidf_(pre[0] + acc[0] + br);
+      const float zg = sigmoidf_(pre[1] + acc[1] + bz);
+      const float hn = acc[2] + bn;
+      const float ng = tanhf(pre[2] + rg * hn);
+      hnew = (1.f - zg) * ng + zg * hprev;
+      sv[0] = rg; sv[1] = zg; sv[2] = ng; sv[3] = hn;
     } else {
-      float pre[G][4];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const u32x2 gxv = *reinterpret_cast<const u32x2*>(
-            p.gx + ((long long)b * pa.T + t) * (G * H) + (long long)g * H + j);
-        pre[g][0] = bflo(gxv[0]); pre[g][1] = bfhi(gxv[0]);
-        pre[g][2] = bflo(gxv[1]); pre[g][3] = bfhi(gxv[1]);
-      }
-      float sv[4][4];   // saved activations
-      if (pa.cell == kGruCudnn) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = e;
-          const float br = p.bh ? p.bh[j + e] : 0.f, bz = p.bh ? p.bh[H + j + e] : 0.f;
-          const float bn = p.bh ? p.bh[2 * H + j + e] : 0.f;
-          const float rg = sigmoidf_(pre[0][e] + acc[0][r] + br);
-          const float zg = sigmoidf_(pre[1][e] + acc[1][r] + bz);
-          const float hn = acc[2][r] + bn;
-          const float ng = tanhf(pre[2][e] + rg * hn);
-          hnew[e] = (1.f - zg) * ng + zg * hprev[e];
-          sv[0][e] = rg; sv[1][e] = zg; sv[2][e] = ng; sv[3][e] = hn;
-        }
-      } else {
-        const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c32 + (long long)b * H + j);
-        f32x4 cn;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = e;
-          float a0 = pre[0][e] + acc[0][r], a1 = pre[1][e] + acc[1][r];
-          float a2 = pre[2][e] + acc[2][r], a3 = pre[3][e] + acc[3][r];
-          if (p.bh) { a0 += p.bh[j + e]; a1 += p.bh[H + j + e]; a2 += p.bh[2 * H + j + e]; a3 += p.bh[3 * H + j + e]; }
-          float ig, fg, gg, og;
-          if (pa.cell == kLstmCudnn) { ig = sigmoidf_(a0); fg = sigmoidf_(a1); gg = tanhf(a2); og = sigmoidf_(a3); }
-          else { ig = sigmoidf_(a0); gg = tanhf(a1); fg = sigmoidf_(a2 + pa.forget_bias); og = sigmoidf_(a3); }
-          cn[e] = cv[e] * fg + ig * gg;
-          hnew[e] = tanhf(cn[e]) * og;
-          sv[0][e] = ig; sv[1][e] = fg; sv[2][e] = gg; sv[3][e] = og;
-        }
-        *reinterpret_cast<f32x4*>(p.c32 + (long long)b * H + j) = cn;
-        if (p.c_seq) *reinterpret_cast<f32x4*>(p.c_seq + ((long long)b * pa.T + t) * H + j) = cn;
-      }
-      if (p.gates) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 pk;
-          pk[0] = pack2bf(sv[g][0], sv[g][1]);
-          pk[1] = pack2bf(sv[g][2], sv[g][3]);
-          *reinterpret_cast<u32x2*>(p.gates + ((long long)b * pa.T + t) * (4 * H) + (long long)g * H + j) = pk;
-        }
-      }
-      u32x2 yo;
-      yo[0] = pack2bf(hnew[0], hnew[1]);
-      yo[1] = pack2bf(hnew[2], hnew[3]);
-      *reinterpret_cast<u32x2*>(p.y + ((long long)b * pa.T + t) * p.ldy + j) = yo;
+      float a0 = pre[0] + acc[0], a1 = pre[1] + acc[1], a2 = pre[2] + acc[2], a3 = pre[G - 1] + acc[3];
+      if (p.bh) { a0 += p.bh[j]; a1 += p.bh[H + j]; a2 += p.bh[2 * H + j]; a3 += p.bh[3 * H + j]; }
+      float ig, fg, gg, og;
+      if (pa.cell == kLstmCudnn) { ig = sigmoidf_(a0); fg = sigmoidf_(a1); gg = tanhf(a2); og = sigmoidf_(a3); }
+      else { ig = sigmoidf_(a0); gg = tanhf(a1); fg = sigmoidf_(a2 + pa.forget_bias); og = sigmoidf_(a3); }
+      const float cn = p.c32[(long long)b * H + j] * fg + ig * gg;
+      hnew = tanhf(cn) * og;
+      sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og;
+      p.c32[(long long)b * H + j] = cn;
+      if (p.c_seq) p.c_seq[row * H + j] = cn;
     }
-    f32x4 hw = {hnew[0], hnew[1], hnew[2], hnew[3]};
-    *reinterpret_cast<f32x4*>(p.h32 + (long long)b * H + j) = hw;
-    u32x2 h16;
-    h16[0] = pack2bf(hnew[0], hnew[1]);
-    h16[1] = pack2bf(hnew[2], hnew[3]);
-    *reinterpret_cast<u32x2*>(p.h_next16 + (long long)b * H + j) = h16;
+    if (p.gates) {
+      bf16_t* gp = p.gates + row * (4 * H) + j;
+      gp[0] = f2bf(sv[0]); gp[H] = f2bf(sv[1]); gp[2 * H] = f2bf(sv[2]); gp[3 * H] = f2bf(sv[3]);
+    }
+    p.y[row * p.ldy + j] = f2bf(hnew);
   }
+  p.h32[(long long)b * H + j] = hnew;
+  p.h_next16[(long long)b * H + j] = f2bf(hnew);
 }
 
 // ---------------------------------------------------------------------------
@@ -342,7 +312,7 @@ extern "C" int os2s_rnn_layer_fwd_multi(os2s_stream_t stream_, int cell, int ndi
     }
   }
   if (ndir == 1) a.d[1] = a.d[0];
-  dim3 grid(ceil_div(H, 32), ceil_div(B, 32), ndir);
+  dim3 grid(ceil_div(H, 8), ceil_div(B, 32), ndir);
   for (int s = 0; s < T; ++s) {
     a.step = s;
     for (int d = 0; d < ndir; ++d) {
