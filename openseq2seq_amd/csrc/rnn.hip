@@ -72,6 +72,29 @@ __global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_fwd_kernel(RnnStepArg
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
   const int H = pa.H;
+  // the epilogue operands of this lane's (unit, sample) are fetched BEFORE the GEMM so that
+  // their round trip overlaps the weight stream instead of following it
+  const int eb = b0 + l31, ej = j0 + (wave & 3) + 4 * lhi;
+  const bool evalid = wave < 4 && eb < pa.B && ej < H;
+  int t = -1;
+  float hprev = 0.f, cprev = 0.f, pre[G], bv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < G; ++g) pre[g] = 0.f;
+  if (evalid) {
+    const int len = pa.lens ? min(max(pa.lens[eb], 0), pa.T) : pa.T;
+    t = time_of(pa.step, len, p.reverse);
+    hprev = p.h32[(long long)eb * H + ej];
+    if (pa.cell != kGruCudnn) cprev = p.c32[(long long)eb * H + ej];
+    if (t >= 0) {
+      const long long row = (long long)eb * pa.T + t;
+#pragma unroll
+      for (int g = 0; g < G; ++g) pre[g] = bf2f(p.gx[row * (G * H) + (long long)g * H + ej]);
+    }
+    if (p.bh) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) bv[g] = p.bh[g * H + ej];
+    }
+  }
   f32x16 accw;
 #pragma unroll
   for (int e = 0; e < 16; ++e) accw[e] = 0.f;
@@ -84,36 +107,26 @@ __global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_fwd_kernel(RnnStepArg
   }
   float acc[4];
   tile_reduce_units<kRnnWaves>(accw, red, acc);
-  if (wave >= 4) return;
-  const int b = b0 + l31;
-  if (b >= pa.B) return;
-  const int j = j0 + wave + 4 * lhi;
-  if (j >= H) return;
-  const int len = pa.lens ? min(max(pa.lens[b], 0), pa.T) : pa.T;
-  const int t = time_of(pa.step, len, p.reverse);
-  const float hprev = p.h32[(long long)b * H + j];
+  if (!evalid) return;
+  const int b = eb, j = ej;
   float hnew = hprev;      // past the sequence end the state passes through (dynamic_rnn)
   if (t >= 0) {
     const long long row = (long long)b * pa.T + t;
-    float pre[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) pre[g] = bf2f(p.gx[row * (G * H) + (long long)g * H + j]);
     float sv[4];
     if (pa.cell == kGruCudnn) {
-      const float br = p.bh ? p.bh[j] : 0.f, bz = p.bh ? p.bh[H + j] : 0.f, bn = p.bh ? p.bh[2 * H + j] : 0.f;
-      const float rg = sigmoidf_(pre[0] + acc[0] + br);
-      const float zg = sigmoidf_(pre[1] + acc[1] + bz);
-      const float hn = acc[2] + bn;
+      const float rg = sigmoidf_(pre[0] + acc[0] + bv[0]);
+      const float zg = sigmoidf_(pre[1] + acc[1] + bv[1]);
+      const float hn = acc[2] + bv[2];
       const float ng = tanhf(pre[2] + rg * hn);
       hnew = (1.f - zg) * ng + zg * hprev;
       sv[0] = rg; sv[1] = zg; sv[2] = ng; sv[3] = hn;
     } else {
-      float a0 = pre[0] + acc[0], a1 = pre[1] + acc[1], a2 = pre[2] + acc[2], a3 = pre[G - 1] + acc[3];
-      if (p.bh) { a0 += p.bh[j]; a1 += p.bh[H + j]; a2 += p.bh[2 * H + j]; a3 += p.bh[3 * H + j]; }
+      const float a0 = pre[0] + acc[0] + bv[0], a1 = pre[1] + acc[1] + bv[1];
+      const float a2 = pre[2] + acc[2] + bv[2], a3 = pre[G - 1] + acc[3] + bv[3];
       float ig, fg, gg, og;
       if (pa.cell == kLstmCudnn) { ig = sigmoidf_(a0); fg = sigmoidf_(a1); gg = tanhf(a2); og = sigmoidf_(a3); }
       else { ig = sigmoidf_(a0); gg = tanhf(a1); fg = sigmoidf_(a2 + pa.forget_bias); og = sigmoidf_(a3); }
-      const float cn = p.c32[(long long)b * H + j] * fg + ig * gg;
+      const float cn = cprev * fg + ig * gg;
       hnew = tanhf(cn) * og;
       sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og;
       p.c32[(long long)b * H + j] = cn;
