@@ -27,6 +27,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
   sys.path.insert(0, REPO)
 
+# the host driver only supports dmabuf IPC (RCCL / cross-process tensors need it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -45,6 +48,9 @@ def parse():
   ap.add_argument("--no-transformer", action="store_true",
                   help="skip the secondary Transformer-big tokens/sec measurement")
   ap.add_argument("--transformer-batch", type=int, default=256)
+  ap.add_argument("--only-nmt", action="store_true", help="en-de-nmt-small train step only: tokens/sec")
+  ap.add_argument("--no-other-configs", action="store_true",
+                  help="skip the short measurements of the other BASELINE configs (N=1 only)")
   ap.add_argument("--only-quartznet", action="store_true",
                   help="QuartzNet 15x5 (separable convolutions) train step only: frames/sec")
   ap.add_argument("--only-tacotron", action="store_true",
@@ -234,6 +240,30 @@ def bench_transformer(args, hvd, dev, rank, world):
   return res
 
 
+def bench_simple(spec, steps, warmup, hvd, dev, rank, world):
+  """One model of BASELINE.json's other configs: K timed train steps on a synthetic batch."""
+  import importlib
+  mod, fn, kw, metric, count_key, unit = spec
+  model_cls, params = getattr(importlib.import_module(mod), fn)(**kw)
+  model = model_cls(params, mode="train", hvd=hvd, device=dev)
+  model.compile()
+  batch = model.get_data_layer().synthetic_batch(dev, seed=1234 + rank)
+  for _ in range(warmup):
+    model.train_step(batch)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    loss = model.train_step(batch)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  res = {"metric": metric, "value": batch[count_key] * steps / dt, "unit": unit,
+         "ms_per_step": 1000 * dt / steps, "n_gpus": world, "steps": steps,
+         "params_M": model.store.num_trainable() / 1e6, "loss": float(loss.cpu()[0])}
+  del model
+  torch.cuda.empty_cache()
+  return res
+
+
 def main():
   args = parse()
   from openseq2seq_amd.utils import distributed as dist_utils
@@ -245,70 +275,24 @@ def main():
   dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
 
-  if args.only_quartznet:
-    from openseq2seq_amd.configs.quartznet import quartznet15x5_config
-    model_cls, params = quartznet15x5_config()
-    model = model_cls(params, mode="train", hvd=hvd, device=dev)
-    model.compile()
-    batch = model.get_data_layer().synthetic_batch(dev, seed=1234 + rank)
-    for _ in range(args.warmup):
-      model.train_step(batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      loss = model.train_step(batch)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if rank == 0:
-      print(json.dumps({"metric": "audio-frames/sec QuartzNet15x5 bf16 (train step)",
-                        "value": batch['num_frames'] * args.steps / dt, "unit": "frames/sec",
-                        "ms_per_step": 1000 * dt / args.steps, "n_gpus": world,
-                        "params_M": model.store.num_trainable() / 1e6,
-                        "loss": float(loss.cpu()[0])}))
-    return
-  if args.only_tacotron:
-    from openseq2seq_amd.configs.tacotron import tacotron_gst_config
-    model_cls, params = tacotron_gst_config(style=not args.no_style)
-    model = model_cls(params, mode="train", hvd=hvd, device=dev)
-    model.compile()
-    batch = model.get_data_layer().synthetic_batch(dev, seed=1234 + rank)
-    for _ in range(args.warmup):
-      model.train_step(batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      loss = model.train_step(batch)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if rank == 0:
-      print(json.dumps({"metric": "mel-frames/sec Tacotron2-GST bf16 (train step)",
-                        "value": batch['num_frames'] * args.steps / dt, "unit": "frames/sec",
-                        "ms_per_step": 1000 * dt / args.steps, "n_gpus": world,
-                        "decoder_steps": int(batch['target_tensors'][0].shape[1]),
-                        "params_M": model.store.num_trainable() / 1e6,
-                        "loss": float(loss.cpu()[0])}))
-    return
-  if args.only_ds2:
-    from openseq2seq_amd.configs.ds2 import ds2_large_config
-    model_cls, params = ds2_large_config()
-    model = model_cls(params, mode="train", hvd=hvd, device=dev)
-    model.compile()
-    batch = model.get_data_layer().synthetic_batch(dev, seed=1234 + rank)
-    for _ in range(args.warmup):
-      model.train_step(batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-      loss = model.train_step(batch)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if rank == 0:
-      print(json.dumps({"metric": "audio-frames/sec DeepSpeech2-large bf16 (train step)",
-                        "value": batch['num_frames'] * args.steps / dt, "unit": "frames/sec",
-                        "ms_per_step": 1000 * dt / args.steps, "n_gpus": world,
-                        "params_M": model.store.num_trainable() / 1e6,
-                        "loss": float(loss.cpu()[0])}))
-    return
+  simple = {
+      "quartznet": ("openseq2seq_amd.configs.quartznet", "quartznet15x5_config", {},
+                    "audio-frames/sec QuartzNet15x5 bf16 (train step)", "num_frames", "frames/sec"),
+      "tacotron": ("openseq2seq_amd.configs.tacotron", "tacotron_gst_config", {"style": not args.no_style},
+                   "mel-frames/sec Tacotron2-GST bf16 (train step)", "num_frames", "frames/sec"),
+      "ds2": ("openseq2seq_amd.configs.ds2", "ds2_large_config", {},
+              "audio-frames/sec DeepSpeech2-large bf16 (train step)", "num_frames", "frames/sec"),
+      "nmt": ("openseq2seq_amd.configs.nmt", "nmt_small_config", {},
+              "tokens/sec en-de-nmt-small bf16 (train step, synthetic 32k-vocab batches)", "num_tokens",
+              "tokens/sec"),
+  }
+  for key, flag in (("quartznet", args.only_quartznet), ("tacotron", args.only_tacotron),
+                    ("ds2", args.only_ds2), ("nmt", args.only_nmt)):
+    if flag:
+      res = bench_simple(simple[key], args.steps, args.warmup, hvd, dev, rank, world)
+      if rank == 0:
+        print(json.dumps(res))
+      return
   if args.only_transformer:
     tr = bench_transformer(args, hvd, dev, rank, world)
     if rank == 0:
@@ -407,6 +391,14 @@ def main():
                             "error": repr(e)}
   if rank != 0:
     return
+  if not args.no_other_configs and world == 1:
+    others = {}
+    for key in ("nmt", "ds2", "tacotron", "quartznet"):
+      try:
+        others[key] = bench_simple(simple[key], 3, 2, hvd, dev, rank, world)
+      except Exception as e:   # never lose the headline line to a secondary measurement
+        others[key] = {"error": repr(e)}
+    out["other_configs"] = others
   if world == 1 and not args.no_cpu_baseline:
     try:
       out["cpu_baseline"] = cpu_baseline()
