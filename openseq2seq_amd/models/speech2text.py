@@ -33,6 +33,29 @@ def dense_to_chars(ids, lens, idx2char):
   return ["".join(idx2char[int(c)] for c in ids[b, :int(lens[b])]) for b in range(ids.shape[0])]
 
 
+def wer_counts(true_texts, pred_texts):
+  """Word-level edit distance and reference word count summed over samples — the two sums
+  evaluate() returns per batch (speech2text.py:316-340)."""
+  total_lev = total_words = 0.0
+  for t, p in zip(true_texts, pred_texts):
+    total_lev += levenshtein(t.split(), p.split())
+    total_words += len(t.split())
+  return total_lev, total_words
+
+
+def finalize_wer(results):
+  """finalize_evaluation (speech2text.py:342-354): 'Eval WER' = sum(lev) / sum(words) over
+  all (word_lev, word_count) pairs collected from the evaluation batches."""
+  lev = sum(r[0] for r in results)
+  words = sum(r[1] for r in results)
+  return {"Eval WER": 1.0 * lev / max(words, 1e-30)}
+
+
+def sample_wer(true_text, pred_text):
+  """'Sample WER' of maybe_print_logs (speech2text.py:244-268)."""
+  return levenshtein(true_text.split(), pred_text.split()) / len(true_text.split())
+
+
 class Speech2Text(EncoderDecoderModel):
   def _build_forward_pass_objects(self, store):
     self._data_layer = self._create_data_layer()
@@ -63,6 +86,22 @@ class Speech2Text(EncoderDecoderModel):
     """eval / infer forward pass: returns decoder output dict."""
     enc = self._encoder.encode({'source_tensors': batch['source_tensors']})
     return self._decoder.decode({'encoder_output': enc})
+
+  def evaluate_batch(self, batch):
+    """evaluate() of the reference (speech2text.py:316-340): greedy CTC decode of the batch,
+    detokenise predictions and targets, return (word edit distance, word count)."""
+    from .. import capi
+    dl = self.get_data_layer()
+    idx2char = dl.params['idx2char']
+    dec = self.forward(batch)
+    ids, lens = capi.ctc_greedy_decode(dec['logits'], dec['src_length'])[:2]
+    pred = dense_to_chars(ids.cpu().numpy(), lens.cpu().numpy(), idx2char)
+    tgt, tgt_len = batch['target_tensors']
+    true = dense_to_chars(tgt.cpu().numpy(), tgt_len.cpu().numpy(), idx2char)
+    return wer_counts(true, pred)
+
+  def finalize_evaluation(self, results_per_batch, training_step=None):
+    return finalize_wer(results_per_batch)
 
   def _get_num_objects_per_step(self, batch):
     """speech2text.py:356-360: number of INPUT feature frames in the batch."""
