@@ -366,6 +366,67 @@ int os2s_argmax_rows(os2s_stream_t stream, const uint16_t* x, long long N, int V
                      long long ld, int32_t* out);
 
 /* ------------------------------------------------------------------------
+ * Transformer beam-search inference: the device side of
+ * SequenceBeamSearch (parts/transformer/beam_search.py:62-383) and of the incremental
+ * decoder step (decoders/transformer_decoder.py:232-326).
+ *
+ * Loop state (caller-allocated device buffers, L1 = max_decode_length + 1):
+ *   status     int32[4]  {running, cur_index, ticket, max_decode_length}
+ *   alive_seq  int32[2][B][beam][L1]   ping-pong: step i reads plane i&1, writes the other
+ *   fin_seq    int32[2][B][beam][L1]
+ *   alive_lp   f32[B][beam]  fin_scores f32[B][beam]  fin_flags int32[B][beam]
+ * os2s_beam_init = _create_initial_state (:96-161). os2s_beam_step = one _search_step
+ * (:205-383) on this step's logits [B*beam, V] (row stride ld; bf16, or fp32 when
+ * logits_f32) followed by _continue_search (:163-203) for the next iteration: it clears
+ * status[0] when the search is over, and every kernel of a later os2s_beam_step call is
+ * then a no-op (the host may enqueue ahead and poll status only every few steps). INF =
+ * 32768 (:26); tf.nn.top_k order (descending, lower index first among equals); lnorm[len]
+ * = ((5 + len) / 6)^alpha for len = 0..max_decode_length (fp32, host-computed, :424-426).
+ * parent[B*beam] receives the flat row (b*beam + old beam) each new alive beam descends
+ * from — gather per-beam caches with os2s_gather_rows. topk_lp / topk_idx [B, 2*beam]
+ * optionally receive the step's top-2*beam log-probs / flat candidate indices (tests).
+ * Needs 2*beam <= 64 and V >= 2*beam. os2s_beam_finalize = search() epilogue (:85-94).
+ * ---------------------------------------------------------------------- */
+int os2s_beam_chunks(int V);
+long long os2s_beam_workspace_bytes(int B, int beam, int V);
+int os2s_beam_init(os2s_stream_t stream, int B, int beam, int max_decode_length,
+                   const int32_t* initial_ids, int32_t* status, int32_t* alive_seq,
+                   int32_t* fin_seq, float* alive_lp, float* fin_scores, int32_t* fin_flags);
+int os2s_beam_step(os2s_stream_t stream, const void* logits, int logits_f32, long long ld, int B,
+                   int beam, int V, int max_decode_length, int eos_id, const float* lnorm,
+                   int32_t* status, int32_t* alive_seq, int32_t* fin_seq, float* alive_lp,
+                   float* fin_scores, int32_t* fin_flags, int32_t* parent, float* topk_lp,
+                   int32_t* topk_idx, void* workspace);
+int os2s_beam_finalize(os2s_stream_t stream, int B, int beam, int max_decode_length,
+                       const int32_t* status, const int32_t* alive_seq, const int32_t* fin_seq,
+                       const float* alive_lp, const float* fin_scores, const int32_t* fin_flags,
+                       int32_t* out_seq, float* out_scores);
+/* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 4) — _gather_beams (:505-537) with
+ * flat row indices. If enable != NULL and enable[0] == 0 the rows are copied unpermuted
+ * (pass the beam status so that a finished search stops permuting its caches). */
+int os2s_gather_rows(os2s_stream_t stream, const void* src, const int32_t* idx, long long rows,
+                     long long row_bytes, const int32_t* enable, void* dst);
+/* Decoder self-attention for ONE new position per beam row (SelfAttention with cache,
+ * parts/transformer/attention_layer.py:133-139): appends knew/vnew [N, H*dh] (row stride
+ * ldnew) to the append-only caches [N, Tmax, H*dh] at slot `step`, sets
+ * ancestry[n, step] = n, and attends over positions 0..step of beam n's history, position j
+ * living in cache row ancestry[n, j] ([N, Tmax] int32, permuted by the beam search instead
+ * of the caches). If status_dev != NULL the step is read from status_dev[1] (device-side
+ * loop index). dh == 64. */
+int os2s_decode_self_attention(os2s_stream_t stream, const uint16_t* q, long long ldq,
+                               const uint16_t* knew, const uint16_t* vnew, long long ldnew,
+                               uint16_t* kcache, uint16_t* vcache, int32_t* ancestry, int N,
+                               int H, int dh, int Tmax, int step, const int32_t* status_dev,
+                               float scale, uint16_t* o, long long ldo);
+/* Encoder-decoder attention for one query per beam row over the PACKED encoder keys/values
+ * [N_src, ldkv] projected once per sentence; beam row n attends sentence n / beam
+ * (tokens cu_k[b] .. cu_k[b+1]). */
+int os2s_decode_cross_attention(os2s_stream_t stream, const uint16_t* q, long long ldq,
+                                const uint16_t* k, const uint16_t* v, long long ldkv,
+                                const int32_t* cu_k, int beam, int N, int H, int dh,
+                                int max_len, float scale, uint16_t* o, long long ldo);
+
+/* ------------------------------------------------------------------------
  * Recurrent layers (one direction of one layer per call; the time loop is inside).
  *   cell 0: cuDNN GRU  (tf.contrib.cudnn_rnn.CudnnGRU, encoders/ds2_encoder.py:294-328)
  *   cell 1: cuDNN LSTM (CudnnLSTM, encoders/tacotron2_encoder.py:254-263), gates i,f,g,o

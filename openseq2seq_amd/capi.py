@@ -563,6 +563,112 @@ def argmax_rows(x2d, v_valid=None):
 
 
 # --------------------------------------------------------------------------
+# Transformer beam search / incremental decoding
+# --------------------------------------------------------------------------
+class BeamState(object):
+  """Device-resident loop state of SequenceBeamSearch (see include/os2s.h)."""
+
+  def __init__(self, initial_ids, beam, vocab_size, max_decode_length, alpha, eos_id, debug=False):
+    import numpy as np
+    dev = initial_ids.device
+    B = int(initial_ids.shape[0])
+    self.B, self.beam, self.V, self.max_len, self.eos = B, int(beam), int(vocab_size), int(max_decode_length), int(eos_id)
+    L1 = self.max_len + 1
+    self.status = torch.zeros(4, dtype=torch.int32, device=dev)
+    self.alive_seq = torch.empty((2, B, beam, L1), dtype=torch.int32, device=dev)
+    self.fin_seq = torch.empty((2, B, beam, L1), dtype=torch.int32, device=dev)
+    self.alive_lp = torch.empty((B, beam), dtype=torch.float32, device=dev)
+    self.fin_scores = torch.empty((B, beam), dtype=torch.float32, device=dev)
+    self.fin_flags = torch.empty((B, beam), dtype=torch.int32, device=dev)
+    self.parent = torch.zeros(B * beam, dtype=torch.int32, device=dev)
+    lengths = np.arange(L1, dtype=np.float32)
+    lnorm = np.power(((np.float32(5.0) + lengths) / np.float32(6.0)).astype(np.float32), np.float32(alpha)).astype(np.float32)
+    self.lnorm = torch.from_numpy(lnorm).to(dev)
+    wsb = _fn("os2s_beam_workspace_bytes", (c_int, c_int, c_int), c_ll)
+    self.ws = torch.empty(max(int(wsb(B, beam, self.V)), 16), dtype=torch.uint8, device=dev)
+    self.topk_lp = torch.zeros((B, 2 * beam), dtype=torch.float32, device=dev) if debug else None
+    self.topk_idx = torch.zeros((B, 2 * beam), dtype=torch.int32, device=dev) if debug else None
+    f = _fn("os2s_beam_init", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 7)
+    _lib.check(f(_stream(), B, beam, self.max_len, _ptr(initial_ids, torch.int32), _ptr(self.status),
+                 _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp), _ptr(self.fin_scores),
+                 _ptr(self.fin_flags)), "os2s_beam_init")
+
+  def alive_ids(self, i):
+    """[B*beam, i+1] view of the alive sequences at loop index i."""
+    return self.alive_seq[i & 1].view(self.B * self.beam, -1)[:, :i + 1]
+
+  def step(self, logits):
+    """One _search_step on logits [B*beam, >=V] (bf16 or fp32, row-contiguous)."""
+    N = self.B * self.beam
+    assert logits.shape[0] == N and logits.stride(1) == 1 and logits.shape[1] >= self.V
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+      raise TypeError("logits must be fp32 or bf16")
+    f = _fn("os2s_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int)
+            + (c_void_p,) * 11)
+    _lib.check(f(_stream(), c_void_p(logits.data_ptr()), int(logits.dtype == torch.float32),
+                 logits.stride(0), self.B, self.beam, self.V, self.max_len, self.eos, _ptr(self.lnorm),
+                 _ptr(self.status), _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp),
+                 _ptr(self.fin_scores), _ptr(self.fin_flags), _ptr(self.parent),
+                 _ptr(self.topk_lp, allow_none=True), _ptr(self.topk_idx, allow_none=True),
+                 _ptr(self.ws)), "os2s_beam_step")
+
+  def read_status(self):
+    s = self.status.cpu()
+    return bool(s[0]), int(s[1])
+
+  def finalize(self):
+    out_seq = torch.empty((self.B, self.beam, self.max_len + 1), dtype=torch.int32, device=self.status.device)
+    out_scores = torch.empty((self.B, self.beam), dtype=torch.float32, device=self.status.device)
+    f = _fn("os2s_beam_finalize", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 8)
+    _lib.check(f(_stream(), self.B, self.beam, self.max_len, _ptr(self.status), _ptr(self.alive_seq),
+                 _ptr(self.fin_seq), _ptr(self.alive_lp), _ptr(self.fin_scores), _ptr(self.fin_flags),
+                 _ptr(out_seq), _ptr(out_scores)), "os2s_beam_finalize")
+    return out_seq, out_scores
+
+
+def gather_rows(src, idx, enable=None, out=None):
+  """out[r] = src[idx[r]] along dim 0 (rows of >= 4 bytes, multiple of 4)."""
+  assert src.is_contiguous() and idx.dtype == torch.int32
+  rows = int(idx.shape[0])
+  row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
+  if out is None:
+    out = torch.empty((rows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+  f = _fn("os2s_gather_rows", (c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(src), _ptr(idx), rows, row_bytes, _ptr(enable, allow_none=True),
+               _ptr(out)), "os2s_gather_rows")
+  return out
+
+
+def decode_self_attention(q, knew, vnew, kcache, vcache, ancestry, H, step, scale, status=None):
+  """q/knew/vnew: bf16 [N, D] column slices of one row-major buffer; caches [N, Tmax, D]."""
+  N, D = q.shape
+  Tmax = kcache.shape[1]
+  o = torch.empty((N, D), dtype=torch.bfloat16, device=q.device)
+  assert knew.stride(0) == vnew.stride(0) and q.stride(1) == 1 and knew.stride(1) == 1
+  f = _fn("os2s_decode_self_attention", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                         c_float, c_void_p, c_ll))
+  _lib.check(f(_stream(), c_void_p(q.data_ptr()), q.stride(0), c_void_p(knew.data_ptr()),
+               c_void_p(vnew.data_ptr()), knew.stride(0), _ptr(kcache, torch.bfloat16),
+               _ptr(vcache, torch.bfloat16), _ptr(ancestry, torch.int32), N, H, D // H, Tmax, int(step),
+               _ptr(status, allow_none=True), float(scale), _ptr(o), D), "os2s_decode_self_attention")
+  return o
+
+
+def decode_cross_attention(q, k, v, cu_k, beam, H, max_len, scale):
+  """q bf16 [N, D]; k, v: column slices [N_src, D] of the packed encoder projections."""
+  N, D = q.shape
+  o = torch.empty((N, D), dtype=torch.bfloat16, device=q.device)
+  assert k.stride(0) == v.stride(0) and k.stride(1) == 1 and q.stride(1) == 1
+  f = _fn("os2s_decode_cross_attention", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_ll))
+  _lib.check(f(_stream(), c_void_p(q.data_ptr()), q.stride(0), c_void_p(k.data_ptr()),
+               c_void_p(v.data_ptr()), k.stride(0), _ptr(cu_k, torch.int32), int(beam), N, H, D // H,
+               int(max_len), float(scale), _ptr(o), D), "os2s_decode_cross_attention")
+  return o
+
+
+# --------------------------------------------------------------------------
 # recurrent layers
 # --------------------------------------------------------------------------
 CELL_GRU_CUDNN, CELL_LSTM_CUDNN, CELL_LSTM_TF = 0, 1, 2

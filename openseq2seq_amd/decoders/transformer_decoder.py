@@ -2,11 +2,17 @@
 open_seq2seq/decoders/transformer_decoder.py:20-230 on the HIP kernels (packed token
 layout): shifted shared embedding + position signal + dropout, N x [causal self-attention,
 encoder-decoder attention, FFN] in pre-norm residual form, final LayerNorm, tied softmax
-projection. Beam-search prediction (:232-326) is the next row of SURVEY §8f."""
+projection; and beam-search prediction (predict, :232-326): an incremental decoder step on one
+new position per beam row (append-only K/V caches + an ancestry table, encoder K/V projected
+once) driven by parts/transformer/beam_search.sequence_beam_search."""
 from __future__ import absolute_import, division, print_function
+
+import torch
 
 from .decoder import Decoder
 from .. import capi
+from ..parts.cnns.conv_blocks import Act
+from ..parts.transformer import beam_search
 from ..parts.transformer import layers as L
 from ..parts.transformer import packing
 
@@ -54,7 +60,7 @@ class TransformerDecoder(Decoder):
 
   def _decode(self, input_dict):
     if 'target_tensors' not in input_dict:
-      raise NotImplementedError("beam-search predict() is not built yet (SURVEY §8f rank 1)")
+      return self.predict(input_dict)
     enc = input_dict['encoder_output']
     emb = enc['embedding_softmax_layer']
     training = (self.mode == "train")
@@ -86,3 +92,73 @@ class TransformerDecoder(Decoder):
     logits = emb.linear(out, tape)
     return {"logits": logits.data, "logits_act": logits, "packed_target": pt,
             "outputs": None, "final_state": None, "final_sequence_lengths": None}
+
+  # ---- inference: beam search (transformer_decoder.py:232-326) --------------------------------
+  def _get_symbols_to_logits_fn(self, enc, beam, N, Tmax):
+    """The incremental decoder step. State outside the beam-search cache: per-layer K/V
+    caches [N, Tmax, D] (append-only) and the encoder K/V projections; inside it: the
+    int32 ancestry table [N, Tmax] (which cache row holds position j of this beam)."""
+    p = self.params
+    D, H = p["hidden_size"], p["num_heads"]
+    emb = enc['embedding_softmax_layer']
+    ps = enc['packed_source']
+    enc_out = enc['outputs_act']
+    dev = enc_out.data.device
+    scale = (D // H) ** -0.5
+    kc = [torch.empty((N, Tmax, D), dtype=torch.bfloat16, device=dev) for _ in self.layers]
+    vc = [torch.empty((N, Tmax, D), dtype=torch.bfloat16, device=dev) for _ in self.layers]
+    enc_kv = [lyr["cross"].kv.forward(enc_out, None).data for lyr in self.layers]
+    pos = torch.arange(Tmax, dtype=torch.int32, device=dev)[:, None].expand(Tmax, N).contiguous()
+
+    def symbols_to_logits_fn(ids, i, cache):
+      anc = cache["ancestry"]
+      last = ids[:, -1].contiguous()
+      x = emb.embed(last, pos[i], None, 1.0, 0)      # id 0 (the initial id) embeds to zeros
+      for l, lyr in enumerate(self.layers):
+        y = lyr["ln1"].forward(x, None)
+        qkv = lyr["self_att"].qkv.forward(y, None).data
+        o = capi.decode_self_attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], kc[l], vc[l], anc,
+                                       H, i, scale)
+        x = lyr["self_att"].out.forward(Act(o), None, residual=x)
+        y = lyr["ln2"].forward(x, None)
+        q = lyr["cross"].q.forward(y, None).data
+        o = capi.decode_cross_attention(q, enc_kv[l][:, :D], enc_kv[l][:, D:], ps["cu"], beam, H,
+                                        ps["max_len"], scale)
+        x = lyr["cross"].out.forward(Act(o), None, residual=x)
+        y = lyr["ln3"].forward(x, None)
+        x = lyr["ffn"].forward(y, None, None, 1.0, 1.0, residual=x)
+      out = self.output_normalization.forward(x, None)
+      return emb.linear(out, None).data, cache
+
+    return symbols_to_logits_fn
+
+  def predict(self, input_dict):
+    enc = input_dict['encoder_output']
+    p = self.params
+    src = enc['encoder_input']
+    B, input_length = int(src.shape[0]), int(src.shape[1])
+    max_decode_length = input_length + p["extra_decode_length"]
+    beam = p["beam_size"]
+    dev = src.device
+    fn = self._get_symbols_to_logits_fn(enc, beam, B * beam, max_decode_length)
+    initial_ids = torch.zeros(B, dtype=torch.int32, device=dev)
+    cache = {"ancestry": torch.zeros((B, max_decode_length), dtype=torch.int32, device=dev)}
+    emb = enc['embedding_softmax_layer']
+    decoded_ids, scores = beam_search.sequence_beam_search(
+        fn, initial_ids, cache, emb.V, beam, p["alpha"], max_decode_length, p["EOS_ID"])
+    top_decoded_ids = decoded_ids[:, 0, 1:].contiguous()
+    # the reference re-runs decode_pass on the decoded ids only to fill "logits", which no
+    # consumer of the infer/eval modes reads (models/text2text.py:84-225); ask for it explicitly
+    logits = None
+    if input_dict.get('return_logits', False):
+      lens = self.sequence_lengths(top_decoded_ids)
+      logits = self._decode(dict(input_dict, target_tensors=[top_decoded_ids, lens]))["logits"]
+    return {"logits": logits, "outputs": [top_decoded_ids], "scores": scores,
+            "final_state": None, "final_sequence_lengths": None}
+
+  def sequence_lengths(self, ids):
+    """Tokens up to and including the first EOS (whole row if none)."""
+    eos = (ids == self.params["EOS_ID"])
+    T = ids.shape[1]
+    first = torch.where(eos.any(1), eos.float().argmax(1) + 1, torch.full((ids.shape[0],), T, device=ids.device))
+    return first.to(torch.int32)

@@ -37,13 +37,16 @@ class Text2Text(EncoderDecoderModel):
         'loss_scale_dev': scale_dev})
 
   def infer_batch(self, batch):
-    """eval / infer: encoder + greedy decoding (models/text2text.py:98-190 without the
-    printing). Returns (ids int32 [B, steps], lengths [B])."""
+    """eval / infer: encoder + greedy (RNN) or beam-search (Transformer) decoding
+    (models/text2text.py:98-190 without the printing). Returns (ids int32 [B, steps], lengths [B])."""
     assert self.mode in ("eval", "infer")
     enc = self._encoder.encode({'source_tensors': batch['source_tensors'],
                                 'packed_source': batch.get('packed_source')})
     dec = self._decoder.decode({'encoder_output': enc})
-    return dec['outputs'][0], dec['final_sequence_lengths']
+    ids, lens = dec['outputs'][0], dec['final_sequence_lengths']
+    if lens is None:     # Transformer beam search: rows are zero-padded after the first EOS
+      lens = self._decoder.sequence_lengths(ids)
+    return ids, lens
 
   def evaluate(self, device=None, max_batches=None):
     """Greedy-decodes the eval set and scores it against the targets: corpus BLEU-4 (the

@@ -130,6 +130,12 @@ def optimize_loss(store, optimizer, optimizer_params, learning_rate_decay_fn,
   cfg, scale = build_opt_config(optimizer, optimizer_params, learning_rate_decay_fn,
                                 lr_policy_params or {}, larc_params, loss_scaling,
                                 loss_scaling_params, clip_gradients, dtype, world_size)
+  if iter_size > 1 and not on_horovod:
+    raise ValueError("iter_size is only supported in Horovod mode")
+  # optimizers.py:208-255: every micro-step adds grad / iter_size to the accumulator and the
+  # update all-reduce-averages the accumulator. The flat gradient buffer holds the plain SUM
+  # over micro-steps and ranks, so one division by world_size * iter_size is the same algebra.
+  cfg.world_size = int(world_size) * int(iter_size)
   if cfg.optimizer == 3 and store.m2 is None:
     raise ValueError("Adam needs FlatParams.finalize(need_m2=True)")
   return TrainOp(store, cfg, scale)

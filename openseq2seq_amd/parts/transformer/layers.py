@@ -193,8 +193,9 @@ class FeedForward(object):
     self.output_layer = Dense(store, name + "/output_layer", filter_size, hidden, True)
 
   def forward(self, x, tape, seeds, relu_keep, post_keep, residual):
-    h = self.filter_layer.forward(x, tape, act=1, keep=relu_keep, seed=seeds.next())
-    return self.output_layer.forward(h, tape, keep=post_keep, seed=seeds.next(), residual=residual)
+    s1, s2 = (seeds.next(), seeds.next()) if seeds is not None else (0, 0)
+    h = self.filter_layer.forward(x, tape, act=1, keep=relu_keep, seed=s1)
+    return self.output_layer.forward(h, tape, keep=post_keep, seed=s2, residual=residual)
 
 
 class SharedEmbedding(object):

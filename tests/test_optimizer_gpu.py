@@ -98,3 +98,39 @@ def test_momentum_clip_static_scale(cuda):
 def test_sgd_logmax(cuda):
   _run(cuda, "SGD", {}, "fixed_lr", dict(learning_rate=0.1), loss_scaling="LogMax",
        inf_step=1)
+
+
+def test_iter_size_algebra_kat(cuda):
+  """The reference's iter_size known answer (optimizers/optimizers_test.py:27-80): a linear
+  least-squares model, SGD lr 0.1, iter_size 8; after accumulating 4 micro-steps and then
+  applying, var == v - 0.1 * 4 * (grad / 8), the accumulator is zero again, and nothing
+  moves during the accumulating micro-steps (fp32 masters: atol 1e-6; the reference states 1e-7 on its fp64-free TF graph)."""
+  from openseq2seq_amd.optimizers import lr_policies
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.optimizers.optimizers import optimize_loss
+  n_samples = n_hid = 10
+  iter_size = 8
+  np.random.seed(0)
+  X = np.random.rand(n_samples, n_hid)
+  y = np.random.rand(n_samples, 1)
+  store = FlatParams(cuda)
+  w0 = (np.random.rand(n_hid, 1).astype(np.float32) - 0.5)
+  p = store.add("dense/kernel", (n_hid, 1), w0, kind="vector")
+  store.finalize()
+  op = optimize_loss(store, "SGD", {}, lr_policies.fixed_lr, dict(learning_rate=0.1), dtype="float32",
+                     loss_scaling=1.0, iter_size=iter_size, on_horovod=True, world_size=1)
+  for _ in range(3):
+    v = p.master.cpu().numpy().astype(np.float64)
+    store.zero_grads()
+    assert float(p.grad.abs().max()) == 0.0
+    g = 2 * (X.T.dot(X).dot(v) - X.T.dot(y)) / X.shape[0]     # d(mse)/dw of one micro-step
+    true_g = g / iter_size
+    gt = torch.from_numpy(g.astype(np.float32)).to(cuda)
+    for k in range(1, 5):                                       # four accumulating micro-steps
+      p.grad.add_(gt)
+      np.testing.assert_allclose(p.grad.cpu().numpy() / iter_size, true_g * k, atol=1e-6)
+      np.testing.assert_allclose(p.master.cpu().numpy(), v)
+    op.run()
+    np.testing.assert_allclose(p.master.cpu().numpy(), v - 0.1 * true_g * 4, atol=1e-6)
+  with pytest.raises(ValueError):
+    optimize_loss(store, "SGD", {}, lr_policies.fixed_lr, dict(learning_rate=0.1), iter_size=2)
