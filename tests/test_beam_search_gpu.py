@@ -172,7 +172,7 @@ def test_decode_cross_attention(cuda):
 
 
 # ---- Transformer decoder: incremental step vs decode_pass, beam search consistency ----------------
-def _tiny_transformer(cuda, V=200, D=256, H=4, NL=2, beam=4, extra=6):
+def _tiny_transformer(cuda, V=200, D=512, H=8, NL=2, beam=4, extra=6):
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders.transformer_encoder import TransformerEncoder
   from openseq2seq_amd.decoders.transformer_decoder import TransformerDecoder
