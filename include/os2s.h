@@ -384,19 +384,23 @@ int os2s_argmax_rows(os2s_stream_t stream, const uint16_t* x, long long N, int V
  * = ((5 + len) / 6)^alpha for len = 0..max_decode_length (fp32, host-computed, :424-426).
  * parent[B*beam] receives the flat row (b*beam + old beam) each new alive beam descends
  * from — gather per-beam caches with os2s_gather_rows. topk_lp / topk_idx [B, 2*beam]
- * optionally receive the step's top-2*beam log-probs / flat candidate indices (tests).
+ * optionally receive the step's top-2*beam log-probs / flat candidate indices (tests);
+ * last_ids / pos [B*beam] (optional) are kept equal to the last token and the position
+ * (= cur_index) of every alive beam, so that a decoder step can be driven entirely from
+ * device state (no host-side loop index: the step is hipGraph-capturable).
  * Needs 2*beam <= 64 and V >= 2*beam. os2s_beam_finalize = search() epilogue (:85-94).
  * ---------------------------------------------------------------------- */
 int os2s_beam_chunks(int V);
 long long os2s_beam_workspace_bytes(int B, int beam, int V);
 int os2s_beam_init(os2s_stream_t stream, int B, int beam, int max_decode_length,
                    const int32_t* initial_ids, int32_t* status, int32_t* alive_seq,
-                   int32_t* fin_seq, float* alive_lp, float* fin_scores, int32_t* fin_flags);
+                   int32_t* fin_seq, float* alive_lp, float* fin_scores, int32_t* fin_flags,
+                   int32_t* last_ids, int32_t* pos);
 int os2s_beam_step(os2s_stream_t stream, const void* logits, int logits_f32, long long ld, int B,
                    int beam, int V, int max_decode_length, int eos_id, const float* lnorm,
                    int32_t* status, int32_t* alive_seq, int32_t* fin_seq, float* alive_lp,
                    float* fin_scores, int32_t* fin_flags, int32_t* parent, float* topk_lp,
-                   int32_t* topk_idx, void* workspace);
+                   int32_t* topk_idx, int32_t* last_ids, int32_t* pos, void* workspace);
 int os2s_beam_finalize(os2s_stream_t stream, int B, int beam, int max_decode_length,
                        const int32_t* status, const int32_t* alive_seq, const int32_t* fin_seq,
                        const float* alive_lp, const float* fin_scores, const int32_t* fin_flags,
@@ -406,6 +410,14 @@ int os2s_beam_finalize(os2s_stream_t stream, int B, int beam, int max_decode_len
  * (pass the beam status so that a finished search stops permuting its caches). */
 int os2s_gather_rows(os2s_stream_t stream, const void* src, const int32_t* idx, long long rows,
                      long long row_bytes, const int32_t* enable, void* dst);
+/* Y[M,N] = act(X[M,K] . W[N,K]^T + bias) (+ residual) for SMALL M (decoding steps: M =
+ * batch*beam rows): one 32x32 output tile per workgroup, K split over its 8 waves with all
+ * loads issued up front — the latency-bound regime where the training GEMM
+ * (os2s_conv1d_fwd, K=1) leaves most CUs idle. bf16 in/out, fp32 accumulate/bias; relu != 0
+ * applies ReLU before the residual add. N % 4 == 0, K % 8 == 0. */
+int os2s_gemm_skinny(os2s_stream_t stream, const uint16_t* x, long long ldx, const uint16_t* w,
+                     long long ldw, const float* bias, const uint16_t* residual, long long ldr,
+                     int M, int N, int K, int relu, uint16_t* y, long long ldy);
 /* Decoder self-attention for ONE new position per beam row (SelfAttention with cache,
  * parts/transformer/attention_layer.py:133-139): appends knew/vnew [N, H*dh] (row stride
  * ldnew) to the append-only caches [N, Tmax, H*dh] at slot `step`, sets

@@ -421,6 +421,22 @@ def gemm(x2d, w, **kw):
   return y.view(N, Cout)
 
 
+def gemm_skinny(x2d, w, bias=None, relu=False, residual=None):
+  """x2d [M,K] bf16 (row stride free), w [N,K] bf16 -> [M,N]; for small M (decoding steps)."""
+  M, K = x2d.shape
+  N = w.shape[0]
+  y = torch.empty((M, N), dtype=torch.bfloat16, device=x2d.device)
+  assert x2d.stride(1) == 1 and w.stride(1) == 1 and (residual is None or residual.stride(1) == 1)
+  f = _fn("os2s_gemm_skinny", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_ll,
+                               c_int, c_int, c_int, c_int, c_void_p, c_ll))
+  _lib.check(f(_stream(), c_void_p(x2d.data_ptr()), x2d.stride(0), c_void_p(w.data_ptr()), w.stride(0),
+               _ptr(bias, torch.float32, True),
+               c_void_p(residual.data_ptr()) if residual is not None else c_void_p(0),
+               residual.stride(0) if residual is not None else 0, M, N, K, int(bool(relu)), _ptr(y), N),
+             "os2s_gemm_skinny")
+  return y
+
+
 def gemm_wgrad(x2d, dy2d, out, accumulate=True):
   """dW [Cout,Cin] (+)= dy^T x."""
   N, Cin = x2d.shape
@@ -588,10 +604,18 @@ class BeamState(object):
     self.ws = torch.empty(max(int(wsb(B, beam, self.V)), 16), dtype=torch.uint8, device=dev)
     self.topk_lp = torch.zeros((B, 2 * beam), dtype=torch.float32, device=dev) if debug else None
     self.topk_idx = torch.zeros((B, 2 * beam), dtype=torch.int32, device=dev) if debug else None
-    f = _fn("os2s_beam_init", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 7)
-    _lib.check(f(_stream(), B, beam, self.max_len, _ptr(initial_ids, torch.int32), _ptr(self.status),
-                 _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp), _ptr(self.fin_scores),
-                 _ptr(self.fin_flags)), "os2s_beam_init")
+    self.last_ids = torch.empty(B * beam, dtype=torch.int32, device=dev)
+    self.pos = torch.empty(B * beam, dtype=torch.int32, device=dev)
+    self.initial_ids = initial_ids
+    self.reset()
+
+  def reset(self):
+    """_create_initial_state."""
+    f = _fn("os2s_beam_init", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 9)
+    _lib.check(f(_stream(), self.B, self.beam, self.max_len, _ptr(self.initial_ids, torch.int32),
+                 _ptr(self.status), _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp),
+                 _ptr(self.fin_scores), _ptr(self.fin_flags), _ptr(self.last_ids), _ptr(self.pos)),
+               "os2s_beam_init")
 
   def alive_ids(self, i):
     """[B*beam, i+1] view of the alive sequences at loop index i."""
@@ -604,13 +628,13 @@ class BeamState(object):
     if logits.dtype not in (torch.float32, torch.bfloat16):
       raise TypeError("logits must be fp32 or bf16")
     f = _fn("os2s_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int)
-            + (c_void_p,) * 11)
+            + (c_void_p,) * 13)
     _lib.check(f(_stream(), c_void_p(logits.data_ptr()), int(logits.dtype == torch.float32),
                  logits.stride(0), self.B, self.beam, self.V, self.max_len, self.eos, _ptr(self.lnorm),
                  _ptr(self.status), _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp),
                  _ptr(self.fin_scores), _ptr(self.fin_flags), _ptr(self.parent),
                  _ptr(self.topk_lp, allow_none=True), _ptr(self.topk_idx, allow_none=True),
-                 _ptr(self.ws)), "os2s_beam_step")
+                 _ptr(self.last_ids), _ptr(self.pos), _ptr(self.ws)), "os2s_beam_step")
 
   def read_status(self):
     s = self.status.cpu()

@@ -10,19 +10,21 @@
 //
 // Device formulation. The loop state lives in HBM for the whole search (ping-pong sequence
 // buffers, log-probs, scores, flags) and three launches advance it by one step:
-//   lse       one workgroup per beam row: logsumexp of the V logits (one read of the row)
-//   chunk     one workgroup per 4096-candidate chunk: k = 2*beam rounds of arg-max over
-//             64-bit keys (order-preserving float bits : ~flat index), i.e. tf.nn.top_k
-//             order — descending value, lower index first among equals
-//   select    one workgroup per batch item: merge the chunk winners, then the (tiny) alive /
-//             finished bookkeeping and the sequence gathers, and the loop condition
+//   row       one 1024-thread workgroup per beam row keeps the row in registers (one 16-byte
+//             read per 8 logits): logsumexp, candidate log-probs, then k = 2*beam rounds of
+//             wave-level arg-max (DPP) over 64-bit keys (order-preserving float bits : ~flat
+//             index) = tf.nn.top_k order: descending value, lower index first among equals;
+//             the 16 waves' winners are merged by wave 0.  (V > 65536: lse + chunk kernels.)
+//   select    one workgroup per batch item: merge the row winners, then the alive / finished
+//             bookkeeping (stable ranks computed in parallel), the sequence gathers and the
+//             loop condition
 // The loop condition is evaluated on the device (status[0] = running): once it clears every
 // kernel of later steps is a no-op, so the host may enqueue steps ahead and poll the flag
 // only every few steps without changing the result. Caches are NOT gathered here: the
 // select kernel emits the parent row of every new alive beam and the caller gathers whatever
 // it keeps per beam (os2s_gather_rows) — for the Transformer that is only an int32 ancestry
 // table, the K/V caches never move (decode_attention.hip).
-// The pass is HBM/latency bound: the logits row is read twice (lse, chunk).
+// The pass is HBM/latency bound: the logits are read exactly once.
 #include "os2s_common.hpp"
 
 namespace os2s {
@@ -136,9 +138,158 @@ __global__ __launch_bounds__(kChunkThreads) void beam_chunk_topk_kernel(
   block_topk_regs<kChunkPer>(key, k, cand + ((long long)n * gridDim.x + chunk) * k, red);
 }
 
+// ---- wave-level top-k machinery -----------------------------------------------------------------
+// u32 max over a fully active wave with DPP moves (see wave_max_dpp in os2s_common.hpp)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov_u32(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t x) {
+  x = max(x, dpp_mov_u32<0xB1, 0xf>(x));
+  x = max(x, dpp_mov_u32<0x4E, 0xf>(x));
+  x = max(x, dpp_mov_u32<0x124, 0xf>(x));
+  x = max(x, dpp_mov_u32<0x128, 0xf>(x));
+  x = max(x, dpp_mov_u32<0x142, 0xa>(x));
+  x = max(x, dpp_mov_u32<0x143, 0xc>(x));
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// arg-max of 64-bit keys over the wave: high words first, then low words among the leaders
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long best) {
+  const uint32_t hi = (uint32_t)(best >> 32), lo = (uint32_t)best;
+  const uint32_t hmax = wave_max_u32_dpp(hi);
+  const uint32_t lmax = wave_max_u32_dpp(hi == hmax ? lo : 0u);
+  return ((unsigned long long)hmax << 32) | lmax;
+}
+
+// k rounds over keys held in LDS, `per` keys per lane at pool[e * 64 + lane] (0 = empty);
+// the keys are consumed (zeroed). Winners go to out[0..k) in descending order. One wave.
+__device__ __forceinline__ void wave_topk_lds(unsigned long long* pool, int per, int k,
+                                              unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long best = 0;
+  int best_e = 0;
+  for (int e = 0; e < per; ++e) {
+    const unsigned long long kk = pool[e * 64 + lane];
+    if (kk > best) { best = kk; best_e = e; }
+  }
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long win = wave_max_key(best);
+    if (lane == 0) out[r] = win;
+    if (win != 0 && best == win) {
+      pool[best_e * 64 + lane] = 0;
+      best = 0;
+      for (int e = 0; e < per; ++e) {
+        const unsigned long long kk = pool[e * 64 + lane];
+        if (kk > best) { best = kk; best_e = e; }
+      }
+    }
+  }
+}
+
+// ---- fused row kernel: logsumexp + candidate log-probs + top-k of one beam row --------------------
+// 1024 threads, PER columns per thread (8 consecutive columns per 16-byte load for bf16).
+template <typename T> struct RowVec;
+template <> struct RowVec<bf16_t> { static constexpr int W = 8; };
+template <> struct RowVec<float> { static constexpr int W = 4; };
+
+template <typename T, int PER>
+__global__ __launch_bounds__(1024) void beam_row_topk_kernel(
+    const T* __restrict__ logits, long long ld, int V, int beam, int k,
+    const float* __restrict__ alive_lp, const int32_t* __restrict__ status,
+    unsigned long long* __restrict__ cand) {
+  if (!status[0]) return;
+  constexpr int W = RowVec<T>::W;
+  __shared__ float red[16];
+  __shared__ unsigned long long wk[16 * kMaxKeep];       // per-wave winners, then the merge pool
+  __shared__ unsigned long long pool[16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x;
+  const T* row = logits + (long long)n * ld;
+  const bool vec_ok = ((((unsigned long long)row) | ((unsigned long long)ld * sizeof(T))) & 15ull) == 0;
+  float val[PER];
+  // element e = it*W + j  <->  column (it*1024 + tid)*W + j
+#pragma unroll
+  for (int it = 0; it < PER / W; ++it) {
+    const int v0 = (it * 1024 + tid) * W;
+    if (vec_ok && v0 + W <= V) {
+      if constexpr (W == 8) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(row + v0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { val[it * 8 + 2 * j] = bflo(q[j]); val[it * 8 + 2 * j + 1] = bfhi(q[j]); }
+      } else {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(row + v0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[it * 4 + j] = q[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < W; ++j) val[it * W + j] = v0 + j < V ? load_logit(row + v0 + j) : -INFINITY;
+    }
+  }
+  auto col_of = [&](int e) { return ((e / W) * 1024 + tid) * W + (e % W); };
+  // ---- logsumexp ---------------------------------------------------------------------------------
+  float m = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) m = fmaxf(m, val[e]);
+  m = wave_max_dpp(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  const float ms = (m == -INFINITY || m == INFINITY) ? 0.f : m;
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) sum += col_of(e) < V ? expf(val[e] - ms) : 0.f;
+  sum = wave_sum_dpp(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) sum += red[w];
+  const float lse = logf(sum) + ms;
+  const float a = alive_lp[n];
+  const uint32_t fbase = (uint32_t)((n % beam) * V);
+  // ---- per-wave top-k from registers ---------------------------------------------------------------
+  unsigned long long removed = 0;
+  auto key_of = [&](int e) -> unsigned long long {
+    const int v = col_of(e);
+    if (v >= V || ((removed >> e) & 1ull)) return 0ull;
+    return make_key((val[e] - lse) + a, fbase + (uint32_t)v);     // _log_prob_from_logits + alive
+  };
+  unsigned long long best = 0;
+  int best_e = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const unsigned long long kk = key_of(e);
+    if (kk > best) { best = kk; best_e = e; }
+  }
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long win = wave_max_key(best);
+    if (lane == 0) wk[wave * k + r] = win;
+    if (win != 0 && best == win) {
+      removed |= 1ull << best_e;
+      best = 0;
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        const unsigned long long kk = key_of(e);
+        if (kk > best) { best = kk; best_e = e; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- wave 0 merges the 16*k winners -----------------------------------------------------------------
+  if (wave == 0) {
+    const int total = 16 * k, per = (total + 63) >> 6;
+    for (int e = 0; e < per; ++e) pool[e * 64 + lane] = e * 64 + lane < total ? wk[e * 64 + lane] : 0ull;
+    wave_topk_lds(pool, per, k, cand + (long long)n * k);
+  }
+}
+
 struct BeamStepArgs {
-  const unsigned long long* cand;   // [B, beam*chunks, k]
-  int ncand;                        // beam * chunks * k
+  const unsigned long long* cand;   // [B, ncand]
+  int ncand;                        // candidates per batch item (beam * k, or beam * chunks * k)
   int B, beam, k, V, L1, eos;
   const float* lnorm;               // [max_len + 1] length normalisation per length
   int32_t* status;
@@ -151,93 +302,80 @@ struct BeamStepArgs {
   int32_t* stop;                    // [B]
   float* topk_lp;                   // [B, k]  (debug / tests; may be null)
   int32_t* topk_idx;                // [B, k]
+  int32_t* last_ids;                // [B*beam] last token of every new alive beam (may be null)
+  int32_t* pos;                     // [B*beam] its position = cur_index + 1   (may be null)
 };
 
-__global__ __launch_bounds__(256) void beam_select_kernel(BeamStepArgs p) {
+constexpr int kSelThreads = 128;          // >= beam + 2*beam entries of the finished merge
+
+__global__ __launch_bounds__(kSelThreads) void beam_select_kernel(BeamStepArgs p) {
   if (!p.status[0]) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned long long pool[];   // ncand keys
-  __shared__ unsigned long long red[8];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long pool[];   // 64 * per keys
   __shared__ unsigned long long win[kMaxKeep];
-  __shared__ float lp[kMaxKeep];
-  __shared__ int pb[kMaxKeep], id[kMaxKeep], fin[kMaxKeep];
+  __shared__ float lp[kMaxKeep], av[kMaxKeep], fs[kMaxKeep + kMaxKeep / 2];
+  __shared__ int pb[kMaxKeep], id[kMaxKeep], fin[kMaxKeep], ff[kMaxKeep + kMaxKeep / 2];
   __shared__ int a_sel[kMaxKeep];          // alive: candidate index per new beam
   __shared__ int f_sel[kMaxKeep];          // finished: source (< beam: old slot, else beam + c)
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  __shared__ float nfs[kMaxKeep];
+  __shared__ int nff[kMaxKeep];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = p.status[1];
   const int beam = p.beam, k = p.k, L1 = p.L1;
   const int cur = i & 1, nxt = cur ^ 1;
-  for (int e = tid; e < p.ncand; e += 256) pool[e] = p.cand[(long long)b * p.ncand + e];
-  __syncthreads();
-  // ---- merge: k rounds over the pool -------------------------------------------------------
-  for (int r = 0; r < k; ++r) {
-    unsigned long long best = 0;
-    for (int e = tid; e < p.ncand; e += 256) best = pool[e] > best ? pool[e] : best;
-    best = wave_max_u64(best);
-    if ((tid & 63) == 0) red[(r & 1) * 4 + wave] = best;
-    __syncthreads();
-    const unsigned long long* rr = red + (r & 1) * 4;
-    unsigned long long w = rr[0];
-    w = rr[1] > w ? rr[1] : w;
-    w = rr[2] > w ? rr[2] : w;
-    w = rr[3] > w ? rr[3] : w;
-    if (tid == 0) win[r] = w;
-    for (int e = tid; e < p.ncand; e += 256)
-      if (pool[e] == w) pool[e] = 0;
-    __syncthreads();
+  // ---- merge the row winners: top k of the batch item (wave 0) --------------------------------------
+  const int per = (p.ncand + 63) >> 6;
+  if (wave == 0) {
+    for (int e = 0; e < per; ++e)
+      pool[e * 64 + lane] = e * 64 + lane < p.ncand ? p.cand[(long long)b * p.ncand + e * 64 + lane] : 0ull;
+    wave_topk_lds(pool, per, k, win);
   }
-  // ---- bookkeeping (serial, k <= 64) -------------------------------------------------------
-  if (tid == 0) {
-    for (int c = 0; c < k; ++c) {
-      const uint32_t flat = key_index(win[c]);
-      lp[c] = key_value(win[c]);
-      pb[c] = (int)(flat / (uint32_t)p.V);
-      id[c] = (int)(flat % (uint32_t)p.V);
-      fin[c] = id[c] == p.eos;
-      if (p.topk_lp) { p.topk_lp[b * k + c] = lp[c]; p.topk_idx[b * k + c] = (int)flat; }
-    }
-    // alive: top `beam` of lp + fin * -INF (stable)
-    float av[kMaxKeep];
-    bool used[kMaxKeep];
-    for (int c = 0; c < k; ++c) { av[c] = lp[c] + (fin[c] ? 1.f : 0.f) * -kBeamInf; used[c] = false; }
-    for (int s = 0; s < beam; ++s) {
-      int bi = -1;
-      for (int c = 0; c < k; ++c)
-        if (!used[c] && (bi < 0 || av[c] > av[bi])) bi = c;
-      used[bi] = true;
-      a_sel[s] = bi;
-    }
-    // finished: [old (beam) ; new (k)] by score (stable)
-    const float ln = p.lnorm[i + 1];
-    float fs[kMaxKeep * 2];
-    int ff[kMaxKeep * 2];
-    bool fu[kMaxKeep * 2];
-    for (int j = 0; j < beam; ++j) { fs[j] = p.fin_scores[b * beam + j]; ff[j] = p.fin_flags[b * beam + j]; fu[j] = false; }
-    for (int c = 0; c < k; ++c) {
-      fs[beam + c] = __fdiv_rn(lp[c], ln) + (1.f - (fin[c] ? 1.f : 0.f)) * -kBeamInf;
-      ff[beam + c] = fin[c];
-      fu[beam + c] = false;
-    }
-    float nfs[kMaxKeep]; int nff[kMaxKeep];
-    for (int s = 0; s < beam; ++s) {
-      int bi = -1;
-      for (int c = 0; c < beam + k; ++c)
-        if (!fu[c] && (bi < 0 || fs[c] > fs[bi])) bi = c;
-      fu[bi] = true;
-      f_sel[s] = bi;
-      nfs[s] = fs[bi];
-      nff[s] = ff[bi];
-    }
-    float alp0 = 0.f;
-    for (int s = 0; s < beam; ++s) {
-      const float v = av[a_sel[s]];
-      if (s == 0) alp0 = v;
-      p.alive_lp[b * beam + s] = v;
-      p.parent[b * beam + s] = b * beam + pb[a_sel[s]];
-      p.fin_scores[b * beam + s] = nfs[s];
-      p.fin_flags[b * beam + s] = nff[s];
-    }
-    // _continue_search for the NEXT iteration
-    const float best_alive = __fdiv_rn(alp0, p.lnorm[p.status[3]]);
+  __syncthreads();
+  // ---- per-candidate quantities (thread c < k) --------------------------------------------------------
+  const float ln = p.lnorm[i + 1];
+  if (tid < k) {
+    const uint32_t flat = key_index(win[tid]);
+    const float l = key_value(win[tid]);
+    const int tok = (int)(flat % (uint32_t)p.V);
+    const float f = tok == p.eos ? 1.f : 0.f;
+    lp[tid] = l;
+    pb[tid] = (int)(flat / (uint32_t)p.V);
+    id[tid] = tok;
+    fin[tid] = tok == p.eos;
+    av[tid] = l + f * -kBeamInf;                                    // _get_new_alive_state
+    fs[beam + tid] = __fdiv_rn(l, ln) + (1.f - f) * -kBeamInf;      // _get_new_finished_state
+    ff[beam + tid] = tok == p.eos;
+    if (p.topk_lp) { p.topk_lp[b * k + tid] = l; p.topk_idx[b * k + tid] = (int)flat; }
+  }
+  if (tid < beam) {
+    fs[tid] = p.fin_scores[b * beam + tid];
+    ff[tid] = p.fin_flags[b * beam + tid];
+  }
+  __syncthreads();
+  // ---- stable descending ranks: entry e goes to slot #{e' : v[e'] > v[e] or (== and e' < e)} ----------
+  if (tid < k) {
+    const float v = av[tid];
+    int rank = 0;
+    for (int c = 0; c < k; ++c) rank += (av[c] > v || (av[c] == v && c < tid)) ? 1 : 0;
+    if (rank < beam) a_sel[rank] = tid;
+  }
+  if (tid < beam + k) {
+    const float v = fs[tid];
+    int rank = 0;
+    for (int c = 0; c < beam + k; ++c) rank += (fs[c] > v || (fs[c] == v && c < tid)) ? 1 : 0;
+    if (rank < beam) { f_sel[rank] = tid; nfs[rank] = v; nff[rank] = ff[tid]; }
+  }
+  __syncthreads();
+  if (tid < beam) {
+    const int c = a_sel[tid];
+    p.alive_lp[b * beam + tid] = av[c];
+    p.parent[b * beam + tid] = b * beam + pb[c];
+    p.fin_scores[b * beam + tid] = nfs[tid];
+    p.fin_flags[b * beam + tid] = nff[tid];
+    if (p.last_ids) p.last_ids[b * beam + tid] = id[c];
+    if (p.pos) p.pos[b * beam + tid] = i + 1;
+  }
+  if (tid == 0) {      // _continue_search for the NEXT iteration
+    const float best_alive = __fdiv_rn(av[a_sel[0]], p.lnorm[p.status[3]]);
     float lowest = INFINITY;
     bool any = false;
     for (int s = 0; s < beam; ++s) {
@@ -247,14 +385,13 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamStepArgs p) {
     lowest += (1.f - (any ? 1.f : 0.f)) * -kBeamInf;
     p.stop[b] = lowest > best_alive;
   }
-  __syncthreads();
   // ---- sequences ---------------------------------------------------------------------------
   const long long plane = (long long)p.B * beam * L1;
   const int32_t* a_in = p.alive_seq + cur * plane + (long long)b * beam * L1;
   int32_t* a_out = p.alive_seq + nxt * plane + (long long)b * beam * L1;
   const int32_t* f_in = p.fin_seq + cur * plane + (long long)b * beam * L1;
   int32_t* f_out = p.fin_seq + nxt * plane + (long long)b * beam * L1;
-  for (int e = tid; e < beam * (i + 2); e += 256) {
+  for (int e = tid; e < beam * (i + 2); e += kSelThreads) {
     const int s = e / (i + 2), t = e - s * (i + 2);
     const int c = a_sel[s];
     a_out[s * L1 + t] = t <= i ? a_in[pb[c] * L1 + t] : id[c];
@@ -283,7 +420,8 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamStepArgs p) {
 
 __global__ void beam_init_kernel(int B, int beam, int L1, int max_len, const int32_t* __restrict__ initial_ids,
                                  int32_t* status, int32_t* alive_seq, int32_t* fin_seq,
-                                 float* alive_lp, float* fin_scores, int32_t* fin_flags) {
+                                 float* alive_lp, float* fin_scores, int32_t* fin_flags,
+                                 int32_t* last_ids, int32_t* pos) {
   const long long plane = (long long)B * beam * L1;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   for (long long e = gid; e < 2 * plane; e += (long long)gridDim.x * blockDim.x) {
@@ -297,6 +435,8 @@ __global__ void beam_init_kernel(int B, int beam, int L1, int max_len, const int
     alive_lp[e] = (e % beam) == 0 ? 0.f : -INFINITY;
     fin_scores[e] = -kBeamInf;
     fin_flags[e] = 0;
+    if (last_ids) last_ids[e] = initial_ids[e / beam];
+    if (pos) pos[e] = 0;
   }
   if (gid == 0) {
     status[0] = max_len > 0;     // _continue_search on the initial state: nothing finished yet
@@ -355,14 +495,14 @@ extern "C" long long os2s_beam_workspace_bytes(int B, int beam, int V) {
 extern "C" int os2s_beam_init(os2s_stream_t stream, int B, int beam, int max_decode_length,
                               const int32_t* initial_ids, int32_t* status, int32_t* alive_seq,
                               int32_t* fin_seq, float* alive_lp, float* fin_scores,
-                              int32_t* fin_flags) {
+                              int32_t* fin_flags, int32_t* last_ids, int32_t* pos) {
   OS2S_REQUIRE(B >= 1 && beam >= 1 && 2 * beam <= kMaxKeep && max_decode_length >= 0);
   OS2S_REQUIRE(initial_ids && status && alive_seq && fin_seq && alive_lp && fin_scores && fin_flags);
   const int L1 = max_decode_length + 1;
   const long long n = 2LL * B * beam * L1;
   OS2S_LAUNCH(beam_init_kernel, dim3((unsigned)min((long long)1024, (n + 255) / 256)), dim3(256), 0,
               (hipStream_t)stream, B, beam, L1, max_decode_length, initial_ids, status, alive_seq,
-              fin_seq, alive_lp, fin_scores, fin_flags);
+              fin_seq, alive_lp, fin_scores, fin_flags, last_ids, pos);
   return OS2S_OK;
 }
 
@@ -371,8 +511,9 @@ extern "C" int os2s_beam_step(os2s_stream_t stream, const void* logits, int logi
                               const float* lnorm, int32_t* status, int32_t* alive_seq,
                               int32_t* fin_seq, float* alive_lp, float* fin_scores,
                               int32_t* fin_flags, int32_t* parent, float* topk_lp,
-                              int32_t* topk_idx, void* workspace) {
+                              int32_t* topk_idx, int32_t* last_ids, int32_t* pos, void* workspace) {
   OS2S_REQUIRE(B >= 1 && beam >= 1 && 2 * beam <= kMaxKeep && V >= 2 * beam && ld >= V);
+  OS2S_REQUIRE(3 * beam <= kSelThreads);
   OS2S_REQUIRE((long long)beam * V < (1LL << 31));
   OS2S_REQUIRE(logits && lnorm && status && alive_seq && fin_seq && alive_lp && fin_scores &&
                fin_flags && parent && workspace);
@@ -382,24 +523,43 @@ extern "C" int os2s_beam_step(os2s_stream_t stream, const void* logits, int logi
   float* lse = (float*)((char*)workspace + cand_bytes);
   int32_t* stop = (int32_t*)((char*)lse + (((long long)N * 4 + 7) / 8) * 8);
   hipStream_t s = (hipStream_t)stream;
-  if (logits_f32) {
-    OS2S_LAUNCH(beam_lse_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)logits, ld, V, status, lse);
-    OS2S_LAUNCH(beam_chunk_topk_kernel<float>, dim3(chunks, N), dim3(kChunkThreads), 0, s,
-                (const float*)logits, ld, V, beam, k, lse, alive_lp, status, cand);
-  } else {
-    OS2S_LAUNCH(beam_lse_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)logits, ld, V, status, lse);
-    OS2S_LAUNCH(beam_chunk_topk_kernel<bf16_t>, dim3(chunks, N), dim3(kChunkThreads), 0, s,
-                (const bf16_t*)logits, ld, V, beam, k, lse, alive_lp, status, cand);
+  int ncand;
+  if (V <= 65536) {      // fused: one workgroup per beam row
+    ncand = beam * k;
+#define OS2S_ROW_TOPK(T, PER)                                                                       \
+  OS2S_LAUNCH((beam_row_topk_kernel<T, PER>), dim3(N), dim3(1024), 0, s, (const T*)logits, ld, V, \
+              beam, k, alive_lp, status, cand)
+    if (logits_f32) {
+      if (V <= 8192) OS2S_ROW_TOPK(float, 8);
+      else if (V <= 32768) OS2S_ROW_TOPK(float, 32);
+      else OS2S_ROW_TOPK(float, 64);
+    } else {
+      if (V <= 8192) OS2S_ROW_TOPK(bf16_t, 8);
+      else if (V <= 32768) OS2S_ROW_TOPK(bf16_t, 32);
+      else OS2S_ROW_TOPK(bf16_t, 64);
+    }
+#undef OS2S_ROW_TOPK
+  } else {               // very large vocabularies: separate logsumexp, 4096-candidate chunks
+    ncand = beam * chunks * k;
+    if (logits_f32) {
+      OS2S_LAUNCH(beam_lse_kernel<float>, dim3(N), dim3(256), 0, s, (const float*)logits, ld, V, status, lse);
+      OS2S_LAUNCH(beam_chunk_topk_kernel<float>, dim3(chunks, N), dim3(kChunkThreads), 0, s,
+                  (const float*)logits, ld, V, beam, k, lse, alive_lp, status, cand);
+    } else {
+      OS2S_LAUNCH(beam_lse_kernel<bf16_t>, dim3(N), dim3(256), 0, s, (const bf16_t*)logits, ld, V, status, lse);
+      OS2S_LAUNCH(beam_chunk_topk_kernel<bf16_t>, dim3(chunks, N), dim3(kChunkThreads), 0, s,
+                  (const bf16_t*)logits, ld, V, beam, k, lse, alive_lp, status, cand);
+    }
   }
   BeamStepArgs a;
-  a.cand = cand; a.ncand = beam * chunks * k;
+  a.cand = cand; a.ncand = ncand;
   a.B = B; a.beam = beam; a.k = k; a.V = V; a.L1 = max_decode_length + 1; a.eos = eos_id;
   a.lnorm = lnorm; a.status = status; a.alive_seq = alive_seq; a.fin_seq = fin_seq;
   a.alive_lp = alive_lp; a.fin_scores = fin_scores; a.fin_flags = fin_flags; a.parent = parent;
-  a.stop = stop; a.topk_lp = topk_lp; a.topk_idx = topk_idx;
-  const size_t smem = (size_t)a.ncand * 8;
+  a.stop = stop; a.topk_lp = topk_lp; a.topk_idx = topk_idx; a.last_ids = last_ids; a.pos = pos;
+  const size_t smem = (size_t)((a.ncand + 63) / 64) * 64 * 8;
   OS2S_REQUIRE(smem <= 48 * 1024);
-  OS2S_LAUNCH(beam_select_kernel, dim3(B), dim3(256), smem, s, a);
+  OS2S_LAUNCH(beam_select_kernel, dim3(B), dim3(kSelThreads), smem, s, a);
   return OS2S_OK;
 }
 

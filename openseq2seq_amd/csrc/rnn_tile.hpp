@@ -96,7 +96,9 @@ namespace os2s {
 // supplies to the A operand (tile row lane&31) or nullptr for a padding row, `irow` its
 // input row (column lane&31) or nullptr for a padding column; `safe` is any readable row of
 // K elements (padding lanes load it and discard the data). K % 8 == 0; NW * KS * 16 >= K for a single batch.
-template <int NW, int KS>
+// CONTIG: wave w takes KS consecutive k-slices (whole 128-byte lines of a row per wave)
+// instead of slices w, w+NW, ... (each line shared by 4 waves).
+template <int NW, int KS, bool CONTIG = false>
 __device__ __forceinline__ void tile_gemm_prefetch(const bf16_t* __restrict__ wrow,
                                                    const bf16_t* __restrict__ irow, int K,
                                                    f32x16& acc, const bf16_t* __restrict__ safe) {
@@ -111,14 +113,14 @@ __device__ __forceinline__ void tile_gemm_prefetch(const bf16_t* __restrict__ wr
     const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      const int it = base + wave + NW * i;
+      const int it = CONTIG ? base + wave * KS + i : base + wave + NW * i;
       const int ko = min(it * 16 + lhi * 8, K - 8);
       a[i] = *reinterpret_cast<const u32x4*>(wsafe + ko);
       bb[i] = *reinterpret_cast<const u32x4*>(isafe + ko);
     }
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      const int it = base + wave + NW * i;
+      const int it = CONTIG ? base + wave * KS + i : base + wave + NW * i;
       const bool kv = it < niter && it * 16 + lhi * 8 < K;
       const u32x4 av = (kv && wrow) ? a[i] : zero;
       const u32x4 bv = (kv && irow) ? bb[i] : zero;

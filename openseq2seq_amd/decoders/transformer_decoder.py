@@ -110,15 +110,14 @@ class TransformerDecoder(Decoder):
     enc_kv = [lyr["cross"].kv.forward(enc_out, None).data for lyr in self.layers]
     pos = torch.arange(Tmax, dtype=torch.int32, device=dev)[:, None].expand(Tmax, N).contiguous()
 
-    def symbols_to_logits_fn(ids, i, cache):
+    def step(last, positions, i, status, cache):
       anc = cache["ancestry"]
-      last = ids[:, -1].contiguous()
-      x = emb.embed(last, pos[i], None, 1.0, 0)      # id 0 (the initial id) embeds to zeros
+      x = emb.embed(last, positions, None, 1.0, 0)   # id 0 (the initial id) embeds to zeros
       for l, lyr in enumerate(self.layers):
         y = lyr["ln1"].forward(x, None)
         qkv = lyr["self_att"].qkv.forward(y, None).data
         o = capi.decode_self_attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], kc[l], vc[l], anc,
-                                       H, i, scale)
+                                       H, i, scale, status=status)
         x = lyr["self_att"].out.forward(Act(o), None, residual=x)
         y = lyr["ln2"].forward(x, None)
         q = lyr["cross"].q.forward(y, None).data
@@ -130,6 +129,14 @@ class TransformerDecoder(Decoder):
       out = self.output_normalization.forward(x, None)
       return emb.linear(out, None).data, cache
 
+    def symbols_to_logits_fn(ids, i, cache):
+      return step(ids[:, -1].contiguous(), pos[i], i, None, cache)
+
+    def device_step_fn(state, cache):
+      """Same step, loop index / last ids / positions read from the beam state on the device."""
+      return step(state.last_ids, state.pos, 0, state.status, cache)
+
+    symbols_to_logits_fn.device_step_fn = device_step_fn
     return symbols_to_logits_fn
 
   def predict(self, input_dict):
@@ -145,7 +152,8 @@ class TransformerDecoder(Decoder):
     cache = {"ancestry": torch.zeros((B, max_decode_length), dtype=torch.int32, device=dev)}
     emb = enc['embedding_softmax_layer']
     decoded_ids, scores = beam_search.sequence_beam_search(
-        fn, initial_ids, cache, emb.V, beam, p["alpha"], max_decode_length, p["EOS_ID"])
+        fn, initial_ids, cache, emb.V, beam, p["alpha"], max_decode_length, p["EOS_ID"],
+        device_step_fn=fn.device_step_fn if input_dict.get('use_graph', True) else None)
     top_decoded_ids = decoded_ids[:, 0, 1:].contiguous()
     # the reference re-runs decode_pass on the decoded ids only to fill "logits", which no
     # consumer of the infer/eval modes reads (models/text2text.py:84-225); ask for it explicitly

@@ -34,15 +34,69 @@ def _expand_to_beam_size(tensor, beam_size):
   return capi.gather_rows(tensor.contiguous(), idx)
 
 
+def _leaves(nested, out=None):
+  out = [] if out is None else out
+  if isinstance(nested, dict):
+    for k in sorted(nested):
+      _leaves(nested[k], out)
+  elif isinstance(nested, (list, tuple)):
+    for v in nested:
+      _leaves(v, out)
+  else:
+    out.append(nested)
+  return out
+
+
+def _graph_search(state, device_step_fn, cache, max_decode_length, poll_every):
+  """The loop as replays of ONE captured hipGraph: `device_step_fn(state, cache)` reads the
+  loop index, last tokens and positions from device state (state.status / last_ids / pos), so
+  a step has no host-side arguments. The step is launch-bound when run eagerly (~90 small
+  kernels); a graph replay removes the per-launch host cost."""
+  leaves = _leaves(cache)
+  tmp = [torch.empty_like(t) for t in leaves]
+
+  def one_step():
+    logits, _ = device_step_fn(state, cache)
+    state.step(logits)
+    for t, buf in zip(leaves, tmp):       # in-place permutation through a scratch copy
+      capi.gather_rows(t, state.parent, enable=state.status, out=buf)
+      t.copy_(buf)
+
+  one_step()            # warm-up outside the capture (one-time kernel attribute / autotune calls)
+  state.reset()
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    one_step()
+  state.reset()         # the capture itself does not execute, but keep the contract explicit
+  i = 0
+  while i < max_decode_length:
+    graph.replay()
+    i += 1
+    if i % poll_every == 0 or i == max_decode_length:
+      running, _ = state.read_status()
+      if not running:
+        break
+
+
 def sequence_beam_search(symbols_to_logits_fn, initial_ids, initial_cache, vocab_size, beam_size,
-                         alpha, max_decode_length, eos_id, poll_every=4, debug_state=None):
-  """Returns (top sequences int32 [B, beam, steps + 1], scores fp32 [B, beam])."""
+                         alpha, max_decode_length, eos_id, poll_every=4, debug_state=None,
+                         device_step_fn=None):
+  """Returns (top sequences int32 [B, beam, steps + 1], scores fp32 [B, beam]).
+  device_step_fn(state, cache) -> (logits, cache): optional variant of symbols_to_logits_fn
+  that takes the loop index / last ids from device state; the loop then runs as hipGraph
+  replays (same kernels, same results)."""
   initial_ids = initial_ids.to(torch.int32).contiguous()
   B = int(initial_ids.shape[0])
   max_decode_length = int(max_decode_length)
   state = capi.BeamState(initial_ids, beam_size, vocab_size, max_decode_length, alpha, eos_id,
                          debug=debug_state is not None)
   cache = _map(lambda t: _expand_to_beam_size(t, beam_size), initial_cache)
+  if device_step_fn is not None and max_decode_length > 0:
+    _graph_search(state, device_step_fn, cache, max_decode_length, max(poll_every, 8))
+    _, steps = state.read_status()
+    out_seq, out_scores = state.finalize()
+    return out_seq[:, :, :steps + 1], out_scores
   i = 0
   while i < max_decode_length:
     logits, cache = symbols_to_logits_fn(state.alive_ids(i), i, cache)

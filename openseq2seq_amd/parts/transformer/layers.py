@@ -16,6 +16,10 @@ from ... import capi
 from ..cnns.conv_blocks import Act
 
 
+SKINNY_MAX_ROWS = 512
+SKINNY_LOGITS = False    # [256 x 32768 x 1024]: the LDS-tiled kernel wins (60 vs 139 us)
+
+
 class SeedSeq(object):
   """Distinct dropout streams per op per step."""
 
@@ -66,6 +70,10 @@ class Dense(object):
 
   def forward(self, x, tape, act=0, keep=1.0, seed=0, residual=None):
     """y = residual + dropout(act(x W^T + b)); x, residual: Act; returns Act."""
+    if tape is None and keep >= 1.0 and x.data.shape[0] <= SKINNY_MAX_ROWS:
+      # decoding step: a few hundred rows — latency-bound kernel (csrc/gemm_skinny.hip)
+      return Act(capi.gemm_skinny(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
+                                  relu=(act == 1), residual=residual.data if residual is not None else None))
     y = capi.gemm(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
                   act=act, keep_prob=keep, seed=seed,
                   residual=residual.data if residual is not None else None)
@@ -237,6 +245,8 @@ class SharedEmbedding(object):
 
   def linear(self, x, tape):
     """logits = x E^T  (bf16 [N, V])."""
+    if tape is None and x.data.shape[0] <= SKINNY_MAX_ROWS and SKINNY_LOGITS:
+      return Act(capi.gemm_skinny(x.data, self.table))
     y = capi.gemm(x.data, self.table)
     out = Act(y)
     if tape is not None:
