@@ -34,6 +34,7 @@ constexpr int kChunkThreads = 256;
 constexpr int kChunkPer = 16;             // candidates per thread
 constexpr int kChunk = kChunkThreads * kChunkPer;
 constexpr int kMaxKeep = 64;              // 2*beam <= 64
+constexpr int kListCap = 4096;            // >= (kMaxKeep - 1) * 64 + 1 candidates above the threshold
 
 // status words (int32): 0 running, 1 cur_index, 2 ticket, 3 max_decode_length
 __device__ __forceinline__ unsigned long long make_key(float v, uint32_t flat) {
@@ -200,8 +201,11 @@ __global__ __launch_bounds__(1024) void beam_row_topk_kernel(
   if (!status[0]) return;
   constexpr int W = RowVec<T>::W;
   __shared__ float red[16];
-  __shared__ unsigned long long wk[16 * kMaxKeep];       // per-wave winners, then the merge pool
+  __shared__ unsigned long long wk[16 * kMaxKeep];       // per-wave top-k of the thread maxima
   __shared__ unsigned long long pool[16 * 64];
+  __shared__ unsigned long long thr[kMaxKeep];
+  __shared__ unsigned long long list[kListCap];          // elements >= threshold
+  __shared__ int count;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
   const T* row = logits + (long long)n * ld;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(1024) void beam_row_topk_kernel(
   const float ms = (m == -INFINITY || m == INFINITY) ? 0.f : m;
   float sum = 0.f;
 #pragma unroll
-  for (int e = 0; e < PER; ++e) sum += col_of(e) < V ? expf(val[e] - ms) : 0.f;
+  for (int e = 0; e < PER; ++e) sum += col_of(e) < V ? __expf(val[e] - ms) : 0.f;
   sum = wave_sum_dpp(sum);
   if (lane == 0) red[wave] = sum;
   __syncthreads();
@@ -251,39 +255,54 @@ __global__ __launch_bounds__(1024) void beam_row_topk_kernel(
   const float lse = logf(sum) + ms;
   const float a = alive_lp[n];
   const uint32_t fbase = (uint32_t)((n % beam) * V);
-  // ---- per-wave top-k from registers ---------------------------------------------------------------
-  unsigned long long removed = 0;
-  auto key_of = [&](int e) -> unsigned long long {
-    const int v = col_of(e);
-    if (v >= V || ((removed >> e) & 1ull)) return 0ull;
-    return make_key((val[e] - lse) + a, fbase + (uint32_t)v);     // _log_prob_from_logits + alive
-  };
-  unsigned long long best = 0;
-  int best_e = 0;
+  // ---- candidate keys; threshold = k-th largest of the 1024 per-thread maxima ---------------------------
+  // Every row-level top-k element is >= that threshold, and at most (k-1)*PER + 1 elements are
+  // (only the k-1 threads whose maximum beats it can hold more than one), so they fit a small
+  // LDS list that wave 0 then ranks exactly.
+  uint32_t ordv[PER];                       // order-preserving bits of the candidate log-prob
+  unsigned long long tbest = 0;
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
-    const unsigned long long kk = key_of(e);
-    if (kk > best) { best = kk; best_e = e; }
+    const int v = col_of(e);
+    uint32_t u = __float_as_uint((val[e] - lse) + a);     // _log_prob_from_logits + alive log-prob
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    ordv[e] = v < V ? u : 0u;
+    const unsigned long long kk = v < V ? (((unsigned long long)u << 32) | (unsigned long long)(~(fbase + (uint32_t)v))) : 0ull;
+    tbest = kk > tbest ? kk : tbest;
   }
-  for (int r = 0; r < k; ++r) {
-    const unsigned long long win = wave_max_key(best);
-    if (lane == 0) wk[wave * k + r] = win;
-    if (win != 0 && best == win) {
-      removed |= 1ull << best_e;
-      best = 0;
+  {
+    unsigned long long best = tbest;
+    for (int r = 0; r < k; ++r) {
+      const unsigned long long win = wave_max_key(best);
+      if (lane == 0) wk[wave * k + r] = win;
+      if (best == win) best = 0;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int total = 16 * k, per = (total + 63) >> 6;
+    for (int e = 0; e < per; ++e) pool[e * 64 + lane] = e * 64 + lane < total ? wk[e * 64 + lane] : 0ull;
+    wave_topk_lds(pool, per, k, thr);
+    if (lane == 0) count = 0;
+  }
+  __syncthreads();
+  const unsigned long long tau = thr[k - 1];
+  const uint32_t tau_hi = (uint32_t)(tau >> 32);
 #pragma unroll
-      for (int e = 0; e < PER; ++e) {
-        const unsigned long long kk = key_of(e);
-        if (kk > best) { best = kk; best_e = e; }
+  for (int e = 0; e < PER; ++e) {
+    if (ordv[e] >= tau_hi && ordv[e] != 0u) {
+      const unsigned long long kk = ((unsigned long long)ordv[e] << 32) | (unsigned long long)(~(fbase + (uint32_t)col_of(e)));
+      if (kk >= tau) {
+        const int slot = atomicAdd(&count, 1);
+        if (slot < kListCap) list[slot] = kk;
       }
     }
   }
   __syncthreads();
-  // ---- wave 0 merges the 16*k winners -----------------------------------------------------------------
   if (wave == 0) {
-    const int total = 16 * k, per = (total + 63) >> 6;
-    for (int e = 0; e < per; ++e) pool[e * 64 + lane] = e * 64 + lane < total ? wk[e * 64 + lane] : 0ull;
-    wave_topk_lds(pool, per, k, cand + (long long)n * k);
+    const int total = min(count, kListCap), per = (total + 63) >> 6;
+    for (int e = total + lane; e < per * 64; e += 64) list[e] = 0ull;       // pad the last stripe
+    wave_topk_lds(list, per, k, cand + (long long)n * k);
   }
 }
 

@@ -14,10 +14,11 @@
 //    (os2s_gather_rows with the parent rows from os2s_beam_step);
 //  * encoder-decoder attention: K/V of the packed encoder output are projected once per
 //    sentence; beam row n reads sentence n / beam.
-// One wave per (beam row, head): 64 lanes score 64 keys at a time against the query held
-// in registers (each lane reads one 128-byte key row), softmax over the wave (DPP), then the
-// value reduction with lanes split 4 keys x 16 channel-quads (8-byte loads) and a final
-// 2-step butterfly. Pure HBM/latency work: bytes = 2 * len * 128 B per (row, head).
+// One wave per (beam row, head), lanes = 8 key groups x 8 sixteen-byte channel chunks: every
+// wave load reads 8 whole 128-byte K (or V) rows, the score is an 8-lane DPP sum, each group
+// keeps an online softmax (running max, sum, 8 output channels per lane) over its keys and the
+// groups are merged with three butterfly steps — a single pass, no LDS.
+// Pure HBM/latency work: bytes = 2 * len * 128 B per (row, head).
 #include "os2s_common.hpp"
 
 namespace os2s {
@@ -41,14 +42,27 @@ struct DecAttnArgs {
   bf16_t* o; long long ldo;
 };
 
+__device__ __forceinline__ float sum8_dpp(float x) {     // sum over aligned groups of 8 lanes
+  x += dpp_mov<0xB1, 0xf>(0.f, x);     // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E, 0xf>(0.f, x);     // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141, 0xf>(0.f, x);    // row_half_mirror: lane i <-> 7 - i
+  return x;
+}
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { f[2 * w] = bflo(v[w]); f[2 * w + 1] = bfhi(v[w]); }
+}
+
+// One wave per (beam row, head). Lane = (key group g = lane >> 3, 16-byte channel chunk
+// c = lane & 7): a wave load covers 8 whole 128-byte key (or value) rows. Each group runs an
+// online softmax over its keys (j = 8*it + g); the 8 groups are merged at the end.
 template <bool SELF>
 __global__ __launch_bounds__(kDaHeads * 64) void decode_attention_kernel(DecAttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x, h = blockIdx.y * kDaHeads + wave;
   if (h >= p.H) return;
-  float* sc = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * p.max_len;
-  int* rowi = reinterpret_cast<int*>(sc + p.max_len);
+  const int g = lane >> 3, c = lane & 7;
   const int step = SELF ? (p.step_dev ? p.step_dev[1] : p.step) : 0;
   if (SELF && step >= p.max_len) return;     // search already stopped at the last slot
   int len, base = 0;
@@ -65,85 +79,70 @@ __global__ __launch_bounds__(kDaHeads * 64) void decode_attention_kernel(DecAttn
     p.vw[((long long)n * p.ld_row) + (long long)step * p.ld_t + hoff + lane] = p.vnew[(long long)n * p.ldnew + hoff + lane];
     if (h == 0 && lane == 0) p.anc[(long long)n * p.anc_ld + step] = n;
   }
-  // ---- query: 64 bf16, identical in every lane ------------------------------------------------
-  u32x4 qv[8];
-  {
-    const u32x4* qp = reinterpret_cast<const u32x4*>(p.q + (long long)n * p.ldq + hoff);
+  float q8[8];
+  unpack8(*reinterpret_cast<const u32x4*>(p.q + (long long)n * p.ldq + hoff + c * 8), q8);
+  float m = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = qp[e];
-  }
-  // ---- scores -----------------------------------------------------------------------------------
-  float m = -INFINITY;
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   for (int j0 = 0; j0 < len; j0 += 64) {
-    const int j = j0 + lane;
-    float s = -INFINITY;
-    if (j < len) {
-      const bf16_t* kp;
-      int row = 0;
-      if (SELF) {
-        row = j == step ? n : p.anc[(long long)n * p.anc_ld + j];
-        kp = j == step ? p.knew + (long long)n * p.ldnew + hoff
-                       : p.k + (long long)row * p.ld_row + (long long)j * p.ld_t + hoff;
-      } else {
-        kp = p.k + (long long)(base + j) * p.ld_t + hoff;
-      }
-      const u32x4* kq = reinterpret_cast<const u32x4*>(kp);
-      float acc = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const u32x4 kv = kq[e];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          acc += bflo(kv[w]) * bflo(qv[e][w]);
-          acc += bfhi(kv[w]) * bfhi(qv[e][w]);
-        }
-      }
-      s = acc * p.scale;
-      sc[j] = s;
-      rowi[j] = row;
+    int rowv = n;
+    if (SELF) {
+      const int jj = j0 + lane;
+      if (jj < len && jj != step) rowv = p.anc[(long long)n * p.anc_ld + jj];
     }
-    m = fmaxf(m, s);
-  }
-  m = wave_max_dpp(m);
-  float l = 0.f;
-  for (int j = lane; j < len; j += 64) {
-    const float e = __expf(sc[j] - m);
-    sc[j] = e;
-    l += e;
-  }
-  l = wave_sum_dpp(l);
-  const float inv = l > 0.f ? 1.f / l : 0.f;
-  // (LDS writes above are read below by other lanes of the same wave)
-  __builtin_amdgcn_wave_barrier();
-  // ---- weighted values: lane = (key group jg, channel quad dq) --------------------------------
-  const int jg = lane >> 4, dq = lane & 15;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int j0 = 0; j0 < len; j0 += 4) {
-    const int j = j0 + jg;
-    if (j < len) {
-      const bf16_t* vp;
+    const int nit = min(8, (len - j0 + 7) >> 3);
+    for (int it = 0; it < nit; ++it) {
+      const int j = j0 + it * 8 + g;
+      const bool valid = j < len;
+      const int jc = valid ? j : len - 1;
+      const bf16_t *kp, *vp;
       if (SELF) {
-        vp = j == step ? p.vnew + (long long)n * p.ldnew + hoff
-                       : p.v + (long long)rowi[j] * p.ld_row + (long long)j * p.ld_t + hoff;
+        const int row = __shfl(rowv, it * 8 + g, 64);
+        const bool fresh = jc == step;
+        const long long off = fresh ? (long long)n * p.ldnew : (long long)row * p.ld_row + (long long)jc * p.ld_t;
+        kp = (fresh ? p.knew : p.k) + off + hoff + c * 8;
+        vp = (fresh ? p.vnew : p.v) + off + hoff + c * 8;
       } else {
-        vp = p.v + (long long)(base + j) * p.ld_t + hoff;
+        kp = p.k + (long long)(base + jc) * p.ld_t + hoff + c * 8;
+        vp = p.v + (long long)(base + jc) * p.ld_t + hoff + c * 8;
       }
-      const u32x2 vv = *reinterpret_cast<const u32x2*>(vp + dq * 4);
-      const float w = sc[j];
-      a0 += w * bflo(vv[0]); a1 += w * bfhi(vv[0]);
-      a2 += w * bflo(vv[1]); a3 += w * bfhi(vv[1]);
+      const u32x4 kq = *reinterpret_cast<const u32x4*>(kp);
+      const u32x4 vq = *reinterpret_cast<const u32x4*>(vp);
+      float k8[8], v8[8];
+      unpack8(kq, k8);
+      unpack8(vq, v8);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += k8[e] * q8[e];
+      s = sum8_dpp(s) * p.scale;
+      if (!valid) s = -INFINITY;
+      const float mn = fmaxf(m, s);
+      const float corr = m == -INFINITY ? 0.f : __expf(m - mn);
+      const float pe = valid ? __expf(s - mn) : 0.f;
+      l = l * corr + pe;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = acc[e] * corr + pe * v8[e];
+      m = mn;
     }
   }
+  // ---- merge the 8 key groups (lanes with equal c) ------------------------------------------------
 #pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {
-    a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64);
-    a2 += __shfl_xor(a2, o, 64); a3 += __shfl_xor(a3, o, 64);
+  for (int off = 8; off <= 32; off <<= 1) {
+    const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+    const float mn = fmaxf(m, mo);
+    const float a = m == -INFINITY ? 0.f : __expf(m - mn);
+    const float b = mo == -INFINITY ? 0.f : __expf(mo - mn);
+    l = l * a + lo * b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] * a + __shfl_xor(acc[e], off, 64) * b;
+    m = mn;
   }
-  if (jg == 0) {
-    u32x2 out;
-    out[0] = pack2bf(a0 * inv, a1 * inv);
-    out[1] = pack2bf(a2 * inv, a3 * inv);
-    *reinterpret_cast<u32x2*>(p.o + (long long)n * p.ldo + hoff + dq * 4) = out;
+  if (g == 0) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o[w] = pack2bf(acc[2 * w] * inv, acc[2 * w + 1] * inv);
+    *reinterpret_cast<u32x4*>(p.o + (long long)n * p.ldo + hoff + c * 8) = o;
   }
 }
 
@@ -154,8 +153,7 @@ using namespace os2s;
 static int launch_decode_attention(hipStream_t s, const DecAttnArgs& a, int N, bool self) {
   OS2S_REQUIRE(N >= 1 && a.H >= 1 && a.max_len >= 1);
   const int gy = (a.H + kDaHeads - 1) / kDaHeads;
-  const size_t smem = (size_t)kDaHeads * 2 * a.max_len * 4;
-  OS2S_REQUIRE(smem <= 64 * 1024);
+  const size_t smem = 0;
   if (self)
     OS2S_LAUNCH(decode_attention_kernel<true>, dim3(N, gy), dim3(kDaHeads * 64), smem, s, a);
   else
@@ -172,7 +170,7 @@ extern "C" int os2s_decode_self_attention(os2s_stream_t stream, const uint16_t* 
   OS2S_REQUIRE(q && knew && vnew && kcache && vcache && ancestry && o);
   if (dh != kDaDh) return OS2S_ERR_UNSUPPORTED;
   OS2S_REQUIRE(Tmax >= 1 && step >= 0 && step < Tmax);
-  OS2S_REQUIRE(ldq % 8 == 0 && ldnew % 8 == 0 && ldo % 4 == 0);
+  OS2S_REQUIRE(ldq % 8 == 0 && ldnew % 8 == 0 && ldo % 8 == 0);
   DecAttnArgs a = {};
   const long long D = (long long)H * dh;
   a.q = q; a.ldq = ldq; a.k = kcache; a.v = vcache; a.ld_t = D; a.ld_row = D * Tmax;
@@ -188,7 +186,7 @@ extern "C" int os2s_decode_cross_attention(os2s_stream_t stream, const uint16_t*
                                            int max_len, float scale, uint16_t* o, long long ldo) {
   OS2S_REQUIRE(q && k && v && cu_k && o && beam >= 1);
   if (dh != kDaDh) return OS2S_ERR_UNSUPPORTED;
-  OS2S_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0);
+  OS2S_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0);
   DecAttnArgs a = {};
   a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ld_t = ldkv; a.cu_k = cu_k; a.beam = beam;
   a.H = H; a.max_len = max_len; a.scale = scale; a.o = o; a.ldo = ldo;
