@@ -48,6 +48,8 @@ def parse():
   ap.add_argument("--no-transformer", action="store_true",
                   help="skip the secondary Transformer-big tokens/sec measurement")
   ap.add_argument("--transformer-batch", type=int, default=256)
+  ap.add_argument("--only-transformer-infer", action="store_true",
+                  help="Transformer-big beam-search inference only: decoded positions/sec")
   ap.add_argument("--only-nmt", action="store_true", help="en-de-nmt-small train step only: tokens/sec")
   ap.add_argument("--no-other-configs", action="store_true",
                   help="skip the short measurements of the other BASELINE configs (N=1 only)")
@@ -264,6 +266,35 @@ def bench_simple(spec, steps, warmup, hvd, dev, rank, world):
   return res
 
 
+def bench_transformer_infer(dev, batch=64, reps=2):
+  """Transformer-big beam-search inference (beam 4, alpha 0.6, extra_decode_length 50 as in
+  transformer-big.py): random-init weights almost never emit EOS, so every sentence decodes
+  the full input_length + 50 positions — the worst case. Reports decoded beam positions/sec
+  (B * beam * steps / time) and ms per decoding step, encoder included."""
+  from openseq2seq_amd.configs.transformer import transformer_config
+  model_cls, params = transformer_config(batch_size_per_gpu=batch)
+  model = model_cls(params, mode="infer", hvd=None, device=dev)
+  model.compile()
+  data = model.get_data_layer().synthetic_batch(dev, seed=7)
+  best = None
+  for _ in range(reps + 1):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids, _ = model.infer_batch(data)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    best = dt if best is None else min(best, dt)
+  steps = int(ids.shape[1])
+  beam = params["decoder_params"]["beam_size"]
+  res = {"metric": "beam positions/sec Transformer-big bf16 beam-search inference",
+         "value": batch * beam * steps / best, "unit": "positions/sec",
+         "ms_per_decode_step": 1000 * best / steps, "decode_steps": steps, "sentences": batch,
+         "beam_size": beam, "ms_per_batch": 1000 * best}
+  del model
+  torch.cuda.empty_cache()
+  return res
+
+
 def main():
   args = parse()
   from openseq2seq_amd.utils import distributed as dist_utils
@@ -293,6 +324,10 @@ def main():
       if rank == 0:
         print(json.dumps(res))
       return
+  if args.only_transformer_infer:
+    if rank == 0:
+      print(json.dumps(bench_transformer_infer(dev)))
+    return
   if args.only_transformer:
     tr = bench_transformer(args, hvd, dev, rank, world)
     if rank == 0:
@@ -398,6 +433,10 @@ def main():
         others[key] = bench_simple(simple[key], 3, 2, hvd, dev, rank, world)
       except Exception as e:   # never lose the headline line to a secondary measurement
         others[key] = {"error": repr(e)}
+    try:
+      others["transformer_beam_search"] = bench_transformer_infer(dev)
+    except Exception as e:
+      others["transformer_beam_search"] = {"error": repr(e)}
     out["other_configs"] = others
   if world == 1 and not args.no_cpu_baseline:
     try:

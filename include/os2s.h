@@ -333,8 +333,10 @@ int os2s_add_bf16(os2s_stream_t stream, const uint16_t* a, const uint16_t* b, lo
  * channels [h*dh, (h+1)*dh) of each row (split_heads/combine_heads are indexing only).
  * bias = padding mask (absent keys in the packed layout) and, if causal, the decoder's
  * lower-triangular band (utils.py:57-79). lse [Nq, H] is saved for the backward, which
- * recomputes the probabilities. Implemented for dh == 64 and max_len <= 64 (training
- * lengths of the configs); OS2S_ERR_UNSUPPORTED otherwise. */
+ * recomputes the probabilities. dh == 64. Training (backward, attention dropout) is
+ * implemented for max_len <= 64 (the length-filtered training sets of the configs); the
+ * forward without dropout takes any max_len (eval / infer batches): one wave per 64-query
+ * tile walks the key tiles with an online softmax. OS2S_ERR_UNSUPPORTED otherwise. */
 int os2s_attention_fwd(os2s_stream_t stream, const uint16_t* q, const uint16_t* k,
                        const uint16_t* v, uint16_t* o, float* lse, const int32_t* cu_q,
                        const int32_t* cu_k, int B, int H, int dh, int max_len,

@@ -252,6 +252,129 @@ __global__ __launch_bounds__(kFwdWaves * 64) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// forward for sequences longer than one tile (inference: eval / infer batches are not
+// length-filtered like the training set). One wave per (batch, head, 64-query tile) walks the
+// key tiles with an online softmax; per-lane state because a lane's MFMA column IS its query.
+// No dropout on this path (keep_prob == 1).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kFwdWaves * 64) void attn_fwd_long_kernel(AttnArgs p, int q_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const long long work = (long long)blockIdx.x * kFwdWaves + wid;
+  if (work >= (long long)p.B * p.H * q_tiles) return;       // waves are independent (own LDS slice)
+  const long long bh = work / q_tiles;
+  const int qt = (int)(work - bh * q_tiles);
+  const int b = (int)(bh / p.H), h = (int)(bh - (long long)b * p.H);
+  const int q0 = p.cu_q[b], k0 = p.cu_k[b];
+  const int Lq_tot = p.cu_q[b + 1] - q0, Lk_tot = p.cu_k[b + 1] - k0;
+  const int qs = qt * kL;
+  if (qs >= Lq_tot) return;
+  const int Lq = min(Lq_tot - qs, kL);
+  char* pm = smem + wid * 16384;        // P[q][key]  (kc image)
+  char* vt = pm + 8192;                 // V[key][d]  (tr image)
+  const bf16_t* qb = p.q + (long long)(q0 + qs) * p.ldq + h * kDh;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  f32x16 o[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[i][j][e] = 0.f;
+  const int nkt = p.causal ? min(qt + 1, (Lk_tot + kL - 1) / kL) : (Lk_tot + kL - 1) / kL;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ks = kt * kL;
+    const int Lk = min(Lk_tot - ks, kL);
+    const bf16_t* kb = p.k + (long long)(k0 + ks) * p.ldk + h * kDh;
+    const bf16_t* vb = p.v + (long long)(k0 + ks) * p.ldv + h * kDh;
+    f32x16 s[2][2];
+    scores(p, qb, kb, Lq, Lk, lane, s);
+    stage_tr(vt, vb, p.ldv, Lk, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = j * 32 + l31;
+      float mt = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_of(i, r, lhi);
+          const bool ok = key < Lk && !(p.causal && ks + key > qs + q);
+          const float v = ok ? s[i][j][r] * p.scale : -INFINITY;
+          s[i][j][r] = v;
+          mt = fmaxf(mt, v);
+        }
+      mt = fmaxf(mt, xhalf(mt));
+      const float mn = fmaxf(m_run[j], mt);
+      const float msafe = mn == -INFINITY ? 0.f : mn;
+      const float corr = m_run[j] == -INFINITY ? 0.f : __expf(m_run[j] - msafe);
+      float lsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __expf(s[i][j][r] - msafe);      // exp(-inf) = 0 for masked keys
+          s[i][j][r] = e;
+          lsum += e;
+        }
+      lsum += xhalf(lsum);
+      l_run[j] = l_run[j] * corr + lsum;
+      m_run[j] = mn;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][j][e] *= corr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int key0 = i * 32 + 8 * g + 4 * lhi;
+          u32x2 pk;
+          pk[0] = pack2bf(s[i][j][4 * g], s[i][j][4 * g + 1]);
+          pk[1] = pack2bf(s[i][j][4 * g + 2], s[i][j][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(pm + kc_off(q, key0)) = pk;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 a[2], bq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = frag_tr(vt, i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bq[j] = frag_kc(pm, j * 32 + l31, kk * 2 + lhi);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          o[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], o[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  bf16_t* ob = p.o + (long long)(q0 + qs) * p.ldo + h * kDh;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = j * 32 + l31;
+    if (q < Lq) {
+      const float inv = l_run[j] > 0.f ? 1.f / l_run[j] : 0.f;
+      if (lhi == 0 && p.lse)
+        p.lse[(long long)(q0 + qs + q) * p.H + h] = (m_run[j] == -INFINITY ? 0.f : m_run[j]) + __logf(l_run[j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = i * 32 + 8 * g + 4 * lhi;
+          u32x2 pk;
+          pk[0] = pack2bf(o[i][j][4 * g] * inv, o[i][j][4 * g + 1] * inv);
+          pk[1] = pack2bf(o[i][j][4 * g + 2] * inv, o[i][j][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2*>(ob + (long long)q * p.ldo + d0) = pk;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
 constexpr int kBwdWaves = 2;
@@ -428,7 +551,7 @@ extern "C" int os2s_attention_fwd(os2s_stream_t stream, const uint16_t* q, const
                                   long long ldo, int causal, float scale, float keep_prob,
                                   unsigned long long seed) {
   OS2S_REQUIRE(q && k && v && o);
-  int rc = attn_check(cu_q, cu_k, B, H, dh, max_len);
+  int rc = attn_check(cu_q, cu_k, B, H, dh, max_len > kL ? kL : max_len);
   if (rc != OS2S_OK) return rc;
   OS2S_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
@@ -436,8 +559,21 @@ extern "C" int os2s_attention_fwd(os2s_stream_t stream, const uint16_t* q, const
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.cu_q = cu_q; a.cu_k = cu_k; a.B = B; a.H = H;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.causal = causal; a.scale = scale;
   a.keep_prob = keep_prob; a.seed = seed;
-  static bool attr = false;
   const size_t smem = (size_t)kFwdWaves * 16384;
+  if (max_len > kL) {      // multi-tile forward (inference); no attention dropout on this path
+    if (keep_prob < 1.f) return OS2S_ERR_UNSUPPORTED;
+    static bool attr_long = false;
+    if (!attr_long) {
+      if (hipFuncSetAttribute((const void*)attn_fwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem) != hipSuccess) return OS2S_ERR_LAUNCH;
+      attr_long = true;
+    }
+    const int q_tiles = (max_len + kL - 1) / kL;
+    OS2S_LAUNCH(attn_fwd_long_kernel, dim3(ceil_div((long long)B * H * q_tiles, kFwdWaves)),
+                dim3(kFwdWaves * 64), smem, (hipStream_t)stream, a, q_tiles);
+    return OS2S_OK;
+  }
+  static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess) return OS2S_ERR_LAUNCH;

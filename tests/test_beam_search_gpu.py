@@ -233,10 +233,12 @@ def test_incremental_step_matches_decode_pass(cuda):
     torch.testing.assert_close(logits.float().cpu(), full[:, i], atol=6e-2, rtol=3e-2)
 
 
-def test_transformer_beam_search_consistency(cuda):
+@pytest.mark.parametrize("Lmax", [9, 90])
+def test_transformer_beam_search_consistency(cuda, Lmax):
+  """Lmax 90: sources / decoded targets longer than one attention tile (multi-tile forward)."""
   V = 200
   store, enc, dec = _tiny_transformer(cuda, V=V)
-  src, sl = _src_batch(cuda, V, B=4, seed=2)
+  src, sl = _src_batch(cuda, V, B=4, Lmax=Lmax, seed=2)
   e = enc.encode({'source_tensors': [src, sl]})
   out = dec.decode({'encoder_output': e})
   ids, scores = out["outputs"][0], out["scores"]

@@ -164,3 +164,33 @@ def test_gemm_epilogue_relu_dropout_residual(cuda):
   _close(d1, dh.float() * (hr > 0).float() / keep)
   d0 = capi.dropout_bwd(dh.to(cuda), keep, seed=seed)
   _close(d0, dh.float() * mask.float() / keep)
+
+
+@pytest.mark.parametrize("causal,cross", [(False, False), (True, False), (False, True)])
+def test_attention_fwd_long(cuda, causal, cross):
+  """Multi-tile forward (sequences > 64 tokens, inference): same fp32 reference, atol 2e-2."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(11 + causal + 2 * cross)
+  B, H, dh = 5, 3, 64
+  D = H * dh
+  lq = [200, 17, 65, 128, 1]
+  lk = [70, 300, 9, 64, 129] if cross else lq
+  q = _bf(torch.randn(sum(lq), D, generator=g))
+  k = _bf(torch.randn(sum(lk), D, generator=g))
+  v = _bf(torch.randn(sum(lk), D, generator=g))
+  scale = dh ** -0.5
+  o, lse = capi.attention_fwd(q.to(cuda), k.to(cuda), v.to(cuda), _cu(lq, cuda), _cu(lk, cuda), H,
+                              max(max(lq), max(lk)), causal, scale)
+  oq = ok = 0
+  for b in range(B):
+    Q = q[oq:oq + lq[b]].float().view(lq[b], H, dh).transpose(0, 1)
+    K = k[ok:ok + lk[b]].float().view(lk[b], H, dh).transpose(0, 1)
+    V = v[ok:ok + lk[b]].float().view(lk[b], H, dh).transpose(0, 1)
+    S = (Q * scale) @ K.transpose(-1, -2)
+    if causal:
+      S = S + torch.triu(torch.full((lq[b], lk[b]), -1e9), diagonal=1)
+    ref = (torch.softmax(S, -1) @ V).transpose(0, 1).reshape(lq[b], D)
+    torch.testing.assert_close(o[oq:oq + lq[b]].float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    ref_lse = torch.logsumexp(S, -1).transpose(0, 1)
+    torch.testing.assert_close(lse[oq:oq + lq[b]].cpu(), ref_lse, atol=2e-3, rtol=1e-3)
+    oq += lq[b]; ok += lk[b]
