@@ -368,6 +368,26 @@ int os2s_argmax_rows(os2s_stream_t stream, const uint16_t* x, long long N, int V
                      long long ld, int32_t* out);
 
 /* ------------------------------------------------------------------------
+ * Speech data-layer augmentation on the device (data/speech2text/speech_utils.py):
+ * os2s_augment_signal = normalize_signal (:225-231) -> speed perturbation by band-limited
+ * sinc resampling (augment_audio_signal :234-272 calls resampy.resample(..., 'kaiser_best');
+ * the resampy interpolation loop is restated, the half-window table interp_win[nwin]
+ * (num_zeros * num_table + 1 taps) comes from the caller) -> additive Gaussian noise.
+ * Per sample b: n_out[b] = int(n_in[b] * ratio[b]) output samples (ratio 1.0 = copy),
+ * noise_amp[b] = 10^(dB/20) (0 = none; noise_amp may be NULL). fixed_gain > 0 overrides the
+ * 1/(max|x| + 1e-5) normalisation. out: fp32 [B, nout_max], zero beyond n_out. absmax_scratch:
+ * B uint32. os2s_spec_augment zeroes the half-open boxes masks[b][m] = (t0, t1, f0, f1) of
+ * bf16 features [B, T, F] (SpecAugment :419-433; the random draws stay on the host).
+ * ---------------------------------------------------------------------- */
+int os2s_augment_signal(os2s_stream_t stream, const void* signal, int is_int16, int B,
+                        long long nmax, const int32_t* n_in, const int32_t* n_out,
+                        const double* ratio, const float* noise_amp, float fixed_gain,
+                        const float* interp_win, int nwin, int num_table, unsigned long long seed,
+                        uint32_t* absmax_scratch, float* out, long long nout_max);
+int os2s_spec_augment(os2s_stream_t stream, uint16_t* feats, int B, int T, int F,
+                      const int32_t* masks, int n_masks);
+
+/* ------------------------------------------------------------------------
  * Transformer beam-search inference: the device side of
  * SequenceBeamSearch (parts/transformer/beam_search.py:62-383) and of the incremental
  * decoder step (decoders/transformer_decoder.py:232-326).

@@ -403,6 +403,34 @@ def logmel(signal, n_samples, window, mel_start, mel_len, mel_wt, *, hop, n_mels
   return out, olen, out32
 
 
+def augment_signal(signal, n_in, n_out, ratio, noise_amp, interp_win, num_table, nout_max, seed=0,
+                   fixed_gain=-1.0):
+  """signal [B,Nmax] int16|float32 -> normalised, speed-perturbed, noised fp32 [B,nout_max]."""
+  B, Nmax = signal.shape
+  dev = signal.device
+  is_i16 = signal.dtype == torch.int16
+  assert is_i16 or signal.dtype == torch.float32
+  out = torch.empty((B, int(nout_max)), dtype=torch.float32, device=dev)
+  scratch = torch.empty(B, dtype=torch.int32, device=dev)
+  f = _fn("os2s_augment_signal", (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_float, c_void_p, c_int, c_int, c_uint64, c_void_p, c_void_p,
+                                  c_ll))
+  _lib.check(f(_stream(), _ptr(signal), int(is_i16), B, Nmax, _ptr(n_in, torch.int32),
+               _ptr(n_out, torch.int32), _ptr(ratio, torch.float64), _ptr(noise_amp, torch.float32, True),
+               float(fixed_gain), _ptr(interp_win, torch.float32), interp_win.numel(), int(num_table),
+               int(seed) & (2**64 - 1), _ptr(scratch), _ptr(out), int(nout_max)), "os2s_augment_signal")
+  return out
+
+
+def spec_augment(feats, masks):
+  """feats bf16 [B,T,F] (in place); masks int32 [B, n_masks, 4] = (t0, t1, f0, f1)."""
+  B, T, F = feats.shape
+  f = _fn("os2s_spec_augment", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int))
+  _lib.check(f(_stream(), _ptr(feats, torch.bfloat16), B, T, F, _ptr(masks, torch.int32), masks.shape[1]),
+             "os2s_spec_augment")
+  return feats
+
+
 # --------------------------------------------------------------------------
 # Transformer kernels (packed token-major tensors)
 # --------------------------------------------------------------------------

@@ -112,3 +112,28 @@ class LogMelFrontEnd(object):
                        fixed_gain=self.gain if self.gain is not None else -1.0,
                        norm_per_feature=self.norm_per_feature, want_f32=want_f32,
                        n_fft=self.n_fft)
+
+
+# ---- speed perturbation filter (resampy 'kaiser_best') --------------------------------------------
+KAISER_BEST = dict(num_zeros=64, precision=9, rolloff=0.9475937167399596, beta=14.769656459379492)
+
+
+def sinc_window(num_zeros=64, precision=9, rolloff=0.945, beta=14.769656459379492):
+  """resampy.filters.sinc_window with a Kaiser taper: the right half of the band-limited
+  interpolation filter, num_zeros * 2^precision + 1 taps (resampy's published construction;
+  'kaiser_best' = KAISER_BEST). Returns (interp_win float32, num_table = 2^precision)."""
+  num_bits = 2 ** precision
+  n = num_bits * num_zeros
+  sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+  taper = np.kaiser(2 * n + 1, beta)[n:]
+  return (taper * sinc_win).astype(np.float32), num_bits
+
+
+def read_wav(filename):
+  """scipy.io.wavfile.read as used by get_speech_features_from_file (speech_utils.py:186-196):
+  (sample_freq, int16 / float32 mono signal)."""
+  from scipy.io import wavfile
+  sample_freq, signal = wavfile.read(filename)
+  if signal.ndim > 1:
+    signal = signal[:, 0]
+  return sample_freq, signal

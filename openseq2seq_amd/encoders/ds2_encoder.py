@@ -46,6 +46,9 @@ class Conv2dBN(object):
     dev = store.device
     self.moving_mean = torch.zeros(c_out, device=dev)
     self.moving_var = torch.ones(c_out, device=dev)
+    if hasattr(store, "add_state"):
+      store.add_state(name + "/bn/moving_mean", self.moving_mean)
+      store.add_state(name + "/bn/moving_variance", self.moving_var)
     self.cin_f, self.cout_f = f_in * c_in, self.Fo * c_out
     if self.cin_f % 8 or self.cout_f % 8:
       raise NotImplementedError("F*C must be a multiple of 8")

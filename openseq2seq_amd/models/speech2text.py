@@ -103,6 +103,41 @@ class Speech2Text(EncoderDecoderModel):
   def finalize_evaluation(self, results_per_batch, training_step=None):
     return finalize_wer(results_per_batch)
 
+  def infer_batch(self, batch):
+    """infer() of the reference (speech2text.py:299-313): greedy transcripts + sample ids."""
+    from .. import capi
+    dec = self.forward(batch)
+    ids, lens = capi.ctc_greedy_decode(dec['logits'], dec['src_length'])[:2]
+    preds = dense_to_chars(ids.cpu().numpy(), lens.cpu().numpy(), self.get_data_layer().params['idx2char'])
+    return preds, batch['source_ids'].cpu().numpy()
+
+  def finalize_inference(self, results_per_batch, output_file):
+    """speech2text.py:315-354: restore the file order, write wav_filename,predicted_transcript."""
+    import csv
+    preds, ids = [], []
+    for result, idx in results_per_batch:
+      preds.extend(result)
+      ids.extend(idx)
+    preds = np.array(preds, dtype=object)[np.argsort(np.hstack(ids))] if len(preds) else preds
+    files = [f[0] for f in self.get_data_layer().all_files]
+    with open(output_file, "w", newline="", encoding="utf-8") as f:
+      w = csv.writer(f)
+      w.writerow(["wav_filename", "predicted_transcript"])
+      for name, text in zip(files, preds):
+        w.writerow([name, text])
+
+  def evaluate(self, device=None, max_batches=None):
+    """One pass over the eval data layer's files (run.py eval / train_eval): 'Eval WER'."""
+    dl = self.get_data_layer()
+    results = []
+    for n, batch in enumerate(dl.iterate_batches(device or self._device, drop_remainder=False)):
+      if max_batches is not None and n >= max_batches:
+        break
+      results.append(self.evaluate_batch(batch))
+    out = self.finalize_evaluation(results)
+    out["samples_batches"] = len(results)
+    return out
+
   def _get_num_objects_per_step(self, batch):
     """speech2text.py:356-360: number of INPUT feature frames in the batch."""
     return batch['source_tensors'][1].sum()

@@ -48,6 +48,19 @@ class Text2Text(EncoderDecoderModel):
       lens = self._decoder.sequence_lengths(ids)
     return ids, lens
 
+  def finalize_inference(self, results_per_batch, output_file):
+    """models/text2text.py:112-124: one decoded sentence per line (special tokens dropped)."""
+    import codecs
+    dl = self.get_data_layer()
+    idx2seq = getattr(dl, "tgt_idx2seq", None) or {}
+    delim = dl.params.get("delimiter", " ")
+    with codecs.open(output_file, "w", "utf-8") as fout:
+      for ids, lens in results_per_batch:
+        ids, lens = ids.cpu().numpy(), lens.cpu().numpy()
+        for b in range(ids.shape[0]):
+          toks = [int(t) for t in ids[b, :lens[b]] if int(t) not in (0, 1, 2, 3)]
+          fout.write(delim.join(idx2seq.get(t, str(t)) for t in toks) + "\n")
+
   def evaluate(self, device=None, max_batches=None):
     """Greedy-decodes the eval set and scores it against the targets: corpus BLEU-4 (the
     reference prints "Eval BLUE score", text2text.py:192-225) and exact-match rate."""

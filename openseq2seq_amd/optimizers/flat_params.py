@@ -33,6 +33,7 @@ class FlatParams(object):
   def __init__(self, device):
     self.device = device
     self.params = []
+    self.state = {}       # named non-trainable variables (BatchNorm moving statistics)
     self._inits = []
     self.finalized = False
     self.chunk = capi.opt_chunk_elems()
@@ -47,6 +48,13 @@ class FlatParams(object):
     self.params.append(p)
     self._inits.append(init)
     return p
+
+  def add_state(self, name, tensor):
+    """Registers a non-trainable variable under its reference name (checkpoints)."""
+    if name in self.state:
+      raise ValueError("duplicate state variable " + name)
+    self.state[name] = tensor
+    return tensor
 
   def finalize(self, need_m2=False):
     dev, ch = self.device, self.chunk

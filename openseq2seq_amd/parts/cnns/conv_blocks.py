@@ -103,6 +103,9 @@ class ConvBN(object):
     dev = store.device
     self.moving_mean = torch.zeros(cout, dtype=torch.float32, device=dev)
     self.moving_var = torch.ones(cout, dtype=torch.float32, device=dev)
+    if hasattr(store, "add_state"):
+      store.add_state(bn_name + "/moving_mean", self.moving_mean)
+      store.add_state(bn_name + "/moving_variance", self.moving_var)
 
   def out_geometry(self, tin):
     if self.padding == "SAME":
@@ -174,6 +177,9 @@ class SepConvBN(ConvBN):
     dev = store.device
     self.moving_mean = torch.zeros(cout, dtype=torch.float32, device=dev)
     self.moving_var = torch.ones(cout, dtype=torch.float32, device=dev)
+    if hasattr(store, "add_state"):
+      store.add_state(bn_name + "/moving_mean", self.moving_mean)
+      store.add_state(bn_name + "/moving_variance", self.moving_var)
 
   def conv_bn_stats(self, x, training):
     B, Tin, _ = x.data.shape

@@ -1,0 +1,172 @@
+"""Checkpoint I/O under the reference's variable names and TensorFlow layouts.
+
+The reference saves tf.train.Saver checkpoints (utils/funcs.py:117-144, utils/hooks.py:227-236)
+and restores by NAME and SHAPE (utils/helpers.py:462-553), falling back from a half-precision
+variable to its 'Loss_Optimization/FP32-master-copy/<name>' twin. TensorFlow is not available
+here, so the container is a NumPy .npz (one array per variable) — INTEGRATION.md §6 gives the
+ten-line script that converts a TF checkpoint to / from it with tf.train.load_checkpoint. What
+this module guarantees is the part that matters for exchanging weights: every array is stored
+under the reference's variable name, in the reference's layout:
+
+  conv1d kernel   device [K, Cout, Cin]        -> tf.layers.conv1d  [K, Cin, Cout]
+  dense kernel    device [1, Cout, Cin]        -> tf.layers.dense   [Cin, Cout]
+  fused qkv / kv  device [1, 3D|2D, D]         -> .../q/kernel, .../k/kernel, .../v/kernel  [D, D]
+  shared embedding device [1, V, D]            -> embedding_and_softmax/weights [V, D]
+  depthwise       device [K, C]                -> separable_conv1d depthwise_kernel [K, C, 1]
+  BatchNorm       gamma / beta / moving_mean / moving_variance  (fp32, as is)
+  anything else   as is (conv2d kernels are already [KT, KF, Cin, Cout]; recurrent kernels keep the
+                  device gate order — see DESIGN.md)
+
+In mixed precision the fp32 master values are written under BOTH the plain name and the
+master-copy name, so either restore path of helpers.py finds them. Optimizer slots, the
+global step and the loss-scaler state are stored under 'OS2S/...' keys (own format).
+"""
+from __future__ import absolute_import, division, print_function
+
+import os
+import re
+
+import numpy as np
+import torch
+
+MASTER_PREFIX = "Loss_Optimization/FP32-master-copy/"
+LATEST_FILENAME = "checkpoint"
+
+
+def _is_dense(name):
+  return not re.search(r"/conv\d*[^/]*/kernel$|pointwise_kernel$", name)
+
+
+def export_param(name, shape, kind, arr):
+  """device array -> [(tf_name, tf_array)]."""
+  if name.endswith("/qkv/kernel") or name.endswith("/kv/kernel"):
+    base = name[:name.rindex("/", 0, len(name) - len("/kernel"))]
+    parts = ("q", "k", "v") if name.endswith("/qkv/kernel") else ("k", "v")
+    D = shape[2]
+    return [("%s/%s/kernel" % (base, t), arr[0, i * D:(i + 1) * D, :].T.copy()) for i, t in enumerate(parts)]
+  if name.endswith("embedding_and_softmax/weights"):
+    return [(name, arr[0].copy())]
+  if kind == "conv":
+    if shape[0] == 1 and _is_dense(name):
+      return [(name, arr[0].T.copy())]
+    return [(name, np.transpose(arr, (0, 2, 1)).copy())]
+  if name.endswith("/depthwise_kernel"):
+    return [(name, arr[:, :, None].copy())]
+  return [(name, arr.copy())]
+
+
+def import_param(name, shape, kind, tf_arrays):
+  """inverse of export_param; returns the device-layout array or None if names are missing."""
+  def get(n):
+    if n in tf_arrays:
+      return np.asarray(tf_arrays[n], np.float32)
+    if MASTER_PREFIX + n in tf_arrays:
+      return np.asarray(tf_arrays[MASTER_PREFIX + n], np.float32)
+    return None
+  if name.endswith("/qkv/kernel") or name.endswith("/kv/kernel"):
+    base = name[:name.rindex("/", 0, len(name) - len("/kernel"))]
+    parts = ("q", "k", "v") if name.endswith("/qkv/kernel") else ("k", "v")
+    mats = [get("%s/%s/kernel" % (base, t)) for t in parts]
+    if any(m is None for m in mats):
+      return None
+    return np.concatenate([m.T for m in mats], axis=0)[None]
+  a = get(name)
+  if a is None:
+    return None
+  if name.endswith("embedding_and_softmax/weights"):
+    return a[None]
+  if kind == "conv":
+    if shape[0] == 1 and _is_dense(name):
+      return a.T[None]
+    return np.transpose(a, (0, 2, 1))
+  if name.endswith("/depthwise_kernel"):
+    return a[:, :, 0]
+  return a
+
+
+def model_variables(model):
+  """{reference name: fp32 array in TF layout} for every variable of the model."""
+  store = model.store
+  out = {}
+  mixed = model.params.get("dtype", "mixed") == "mixed"
+  for p in store.params:
+    arr = p.master.detach().cpu().numpy()
+    for tf_name, tf_arr in export_param(p.name, p.shape, p.kind, arr):
+      out[tf_name] = tf_arr
+      if mixed and p.kind != "vector":      # only half-precision variables have master copies
+        out[MASTER_PREFIX + tf_name] = tf_arr
+  for name, t in store.state.items():
+    out[name] = t.detach().cpu().numpy().copy()
+  return out
+
+
+def save(model, logdir, step=None):
+  """Writes <logdir>/model.ckpt-<step>.npz and the TF-style 'checkpoint' index file."""
+  os.makedirs(logdir, exist_ok=True)
+  arrays = model_variables(model)
+  store = model.store
+  train_op = getattr(model, "_train_op", None)
+  if step is None:
+    step = model.global_step() if train_op is not None else 0
+  arrays["global_step"] = np.asarray(step, np.int64)
+  if train_op is not None:
+    arrays["OS2S/opt/m1"] = store.m1.detach().cpu().numpy()
+    if store.m2 is not None:
+      arrays["OS2S/opt/m2"] = store.m2.detach().cpu().numpy()
+    arrays["OS2S/opt/state"] = train_op.state.detach().cpu().numpy()
+    arrays["OS2S/opt/t_v"] = store.t_v.detach().cpu().numpy()
+  prefix = "model.ckpt-%d" % int(step)
+  np.savez(os.path.join(logdir, prefix + ".npz"), **arrays)
+  with open(os.path.join(logdir, LATEST_FILENAME), "w") as f:
+    f.write('model_checkpoint_path: "%s"\n' % prefix)
+  return os.path.join(logdir, prefix)
+
+
+def latest_checkpoint(logdir):
+  """tf.train.latest_checkpoint: the prefix named by <logdir>/checkpoint, or None."""
+  path = os.path.join(logdir, LATEST_FILENAME)
+  if not os.path.exists(path):
+    return None
+  m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', open(path).read())
+  if not m:
+    return None
+  prefix = m.group(1)
+  return prefix if os.path.isabs(prefix) else os.path.join(logdir, prefix)
+
+
+def read_step(prefix):
+  """The training step stored with the checkpoint (global_step)."""
+  path = prefix if prefix.endswith(".npz") else prefix + ".npz"
+  return int(np.load(path)["global_step"])
+
+
+def load(model, prefix, restore_optimizer=True, strict=True):
+  """Restores by name and shape (helpers.py:462-553). Returns the list of variables that were
+  not found (empty with strict=True, which raises instead)."""
+  path = prefix if prefix.endswith(".npz") else prefix + ".npz"
+  data = np.load(path)
+  store = model.store
+  missing = []
+  for p in store.params:
+    a = import_param(p.name, p.shape, p.kind, data)
+    if a is None or tuple(a.shape) != tuple(p.shape):
+      missing.append(p.name)
+      continue
+    p.master.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+  for name, t in store.state.items():
+    if name in data and tuple(data[name].shape) == tuple(t.shape):
+      t.copy_(torch.from_numpy(np.asarray(data[name], np.float32)))
+    else:
+      missing.append(name)
+  if missing and strict:
+    raise ValueError("checkpoint %s lacks (or mis-shapes) variables: %s" % (path, ", ".join(missing[:8])))
+  store.refresh_compute_copies()
+  train_op = getattr(model, "_train_op", None)
+  if restore_optimizer and train_op is not None and "OS2S/opt/state" in data:
+    if data["OS2S/opt/m1"].shape == tuple(store.m1.shape):
+      store.m1.copy_(torch.from_numpy(data["OS2S/opt/m1"]))
+      if store.m2 is not None and "OS2S/opt/m2" in data:
+        store.m2.copy_(torch.from_numpy(data["OS2S/opt/m2"]))
+      train_op.state.copy_(torch.from_numpy(data["OS2S/opt/state"]))
+      store.t_v.copy_(torch.from_numpy(data["OS2S/opt/t_v"]))
+  return missing

@@ -3,8 +3,10 @@
 `python run.py --config_file=<cfg> --mode=train [--benchmark --bench_steps N
 --bench_start K] [--<nested/param>=value ...]`; under torchrun (one process per GPU) the
 data-parallel path runs over RCCL. The reference's own example_configs load unchanged.
-Implemented modes: train (incl. --benchmark; synthetic batches when dataset files are
-absent). The hot loop mirrors utils/funcs.py:172-218 (objects/sec accounting)."""
+Modes: train / train_eval (incl. --benchmark; synthetic batches when the dataset files are
+absent), eval and infer (from the latest checkpoint in logdir). The hot loop mirrors
+utils/funcs.py:172-218 (objects/sec accounting); checkpoints are written under the reference's
+variable names (openseq2seq_amd/utils/checkpoint.py)."""
 from __future__ import print_function
 
 import sys
@@ -12,6 +14,7 @@ import time
 
 import torch
 
+from openseq2seq_amd.utils import checkpoint
 from openseq2seq_amd.utils import distributed as dist_utils
 from openseq2seq_amd.utils.utils import create_model, deco_print, get_base_config
 
@@ -30,8 +33,19 @@ def train(model, args):
     batch = dl.synthetic_batch(model._device, seed=1234 + rank)
   eval_model = getattr(model, "eval_model", None)
   eval_steps = p.get('eval_steps', None)
+  logdir = p.get('logdir', None)
+  save_steps = p.get('save_checkpoint_steps', None)
+  first_step = 0
+  if logdir and (args.continue_learning or p.get('load_model')):
+    prefix = checkpoint.latest_checkpoint(p.get('load_model') or logdir)
+    if prefix is not None:
+      checkpoint.load(model, prefix, restore_optimizer=args.continue_learning)
+      if args.continue_learning:
+        first_step = checkpoint.read_step(prefix)
+      if rank == 0:
+        deco_print("Restored checkpoint %s (step %d)" % (prefix, first_step))
   total_time, total_objects = 0.0, 0.0
-  for step in range(max_steps):
+  for step in range(first_step, max_steps):
     if batches is not None:
       batch = next(batches)
     if eval_model is not None and eval_steps and step > 0 and step % eval_steps == 0:
@@ -47,6 +61,10 @@ def train(model, args):
     ps = p.get('print_loss_steps', None)
     if ps and step % ps == 0 and rank == 0:
       deco_print("step %d loss %.4f time per step %.3fs" % (step, float(loss.cpu()[0]), dt))
+    if logdir and save_steps and rank == 0 and step > 0 and step % save_steps == 0:
+      checkpoint.save(model, logdir, step)
+  if logdir and rank == 0 and not args.benchmark:
+    deco_print("Saved checkpoint %s" % checkpoint.save(model, logdir, max_steps))
   if model.hvd and model.hvd.size() > 1:
     t = torch.tensor([total_objects], dtype=torch.float64, device=model._device)
     torch.distributed.all_reduce(t)
@@ -59,20 +77,53 @@ def train(model, args):
 
 
 def run_eval(model, eval_model, rank):
-  eval_model.copy_weights_from(model)
+  if model is not None:
+    eval_model.copy_weights_from(model)
   res = eval_model.evaluate()
   if rank == 0:
-    deco_print("Validation: Eval BLUE score: %.4f  exact match: %.4f  (%d samples)"
-               % (res["bleu"], res["exact_match"], res["samples"]))
+    if "bleu" in res:
+      deco_print("Validation: Eval BLUE score: %.4f  exact match: %.4f  (%d samples)"
+                 % (res["bleu"], res["exact_match"], res["samples"]))
+    else:
+      deco_print("Validation: " + "  ".join("%s: %s" % kv for kv in sorted(res.items())))
   return res
+
+
+def restore_latest(model, rank):
+  logdir = model.params.get('load_model') or model.params.get('logdir')
+  prefix = checkpoint.latest_checkpoint(logdir) if logdir else None
+  if prefix is None:
+    raise IOError("no checkpoint found in %r (eval / infer need a trained model)" % (logdir,))
+  checkpoint.load(model, prefix, restore_optimizer=False)
+  if rank == 0:
+    deco_print("Restored checkpoint %s" % prefix)
+
+
+def infer(model, args, rank):
+  """utils/funcs.py:223-290: run the infer data layer once, hand the per-batch results to
+  finalize_inference."""
+  dl = model.get_data_layer()
+  results = [model.infer_batch(b) for b in dl.iterate_batches(model._device, drop_remainder=False)]
+  if rank == 0:
+    model.finalize_inference(results, args.infer_output_file)
+    deco_print("Finished inference: %d batches -> %s" % (len(results), args.infer_output_file))
 
 
 def main():
   args, base_config, base_model, config_module = get_base_config(sys.argv[1:])
   hvd = dist_utils.init_from_env() if base_config.get('use_horovod', False) else None
-  if args.mode not in ("train", "train_eval"):
-    raise NotImplementedError("mode %s: only the training path is re-hosted so far" % args.mode)
   model = create_model(args, base_config, config_module, base_model, hvd)
+  rank = hvd.rank() if hvd else 0
+  if args.mode == "eval":
+    restore_latest(model, rank)
+    run_eval(None, model, rank)
+    return
+  if args.mode == "infer":
+    restore_latest(model, rank)
+    infer(model, args, rank)
+    return
+  if args.mode not in ("train", "train_eval"):
+    raise NotImplementedError("mode %s" % args.mode)
   train(model, args)
   if getattr(model, "eval_model", None) is not None:
     run_eval(model, model.eval_model, model.hvd.rank() if model.hvd else 0)
