@@ -246,14 +246,21 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
   }
 
   constexpr int OP = BN * 2 + 16;  // out-tile pitch in bytes
-  __syncthreads();                 // every wave is done reading the staging buffers
+  // The out tile is staged through LDS (coalesced 16-B row stores + the BN partial sums). Wide
+  // tiles do not fit all windows at once: stage EW windows per pass.
+  constexpr bool EPI_SPLIT = (size_t)NWIN * BM * OP > 112 * 1024;
+  constexpr int EW = EPI_SPLIT ? 1 : NWIN;
   char* const ot = smem;
+#pragma unroll
+  for (int w0 = 0; w0 < NWIN; w0 += EW) {
+  __syncthreads();                 // staging buffers / previous pass are no longer read
+  if (my_win >= w0 && my_win < w0 + EW) {
 #pragma unroll
   for (int in = 0; in < NI; ++in)
 #pragma unroll
     for (int im = 0; im < MI; ++im) {
-      const int tt = wm * WTM + im * 32 + l31;   // row in the block's (NWIN*BM)-row out tile
-      const int b = my_b, t0 = my_t0 - my_win * BM;   // t0 + tt = time of this row
+      const int tt = wm * WTM + im * 32 + l31 - w0 * BM;   // row in this pass's out tile
+      const int b = my_b, t0 = my_t0 - (my_win - w0) * BM;   // t0 + tt = time of this row
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cc = wn * WTN + in * 32 + 8 * g + 4 * lhi;
@@ -285,13 +292,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
         *reinterpret_cast<u32x2*>(ot + tt * OP + cc * 2) = pk;
       }
     }
+  }
   __syncthreads();
 
 #pragma unroll
-  for (int w = 0; w < NWIN; ++w) {
+  for (int w = w0; w < w0 + EW; ++w) {
   const int b = wb[w], t0 = wt0[w];
   const int valid_rows = (m_first + w < p.MT) ? min(BM, p.Tout - t0) : 0;
-  const char* const otw = ot + w * BM * OP;
+  const char* const otw = ot + (w - w0) * BM * OP;
   bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
   for (int q = tid; q < BM * (BN / 8); q += NTHR) {
     const int row = q / (BN / 8), c8 = q - row * (BN / 8);
@@ -319,28 +327,30 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
 
   if (p.stats) {
     constexpr int CP = BN / 2;       // column pairs
-    constexpr int RG = NTHR / CP;    // row groups
-    static_assert(NTHR % CP == 0, "stats split");
+    constexpr int RG = (NTHR / CP) > 0 ? (NTHR / CP) : 1;    // row groups
     const int cp = tid % CP, rg = tid / CP;
 #pragma unroll
-    for (int w = 0; w < NWIN; ++w) {
+    for (int w = w0; w < w0 + EW; ++w) {
     if (m_first + w >= p.MT) break;
     const int m_idx = m_first + w;
     const int valid_rows = min(BM, p.Tout - wt0[w]);
-    const char* const otw = ot + w * BM * OP;
-    if (w > 0) __syncthreads();      // scratch re-use between windows
+    const char* const otw = ot + (w - w0) * BM * OP;
+    if (w > w0) __syncthreads();      // scratch re-use between windows
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (rg < RG)
     for (int row = rg; row < valid_rows; row += RG) {
       const uint32_t v = *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4);
       const float a = bflo(v), bb = bfhi(v);
       s0 += a; q0 += a * a;
       s1 += bb; q1 += bb * bb;
     }
-    float* sc = reinterpret_cast<float*>(smem + NWIN * BM * OP);  // [RG][BN][2]
+    float* sc = reinterpret_cast<float*>(smem + EW * BM * OP);  // [RG][BN][2]
+    if (rg < RG) {
     sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
     sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
     sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
     sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
+    }
     __syncthreads();
     if (tid < BN) {
       float s = 0.f, qq = 0.f;
@@ -357,6 +367,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
     }
     }
   }
+  }
 }
 
 constexpr int kConvBM = 128, kConvBN = 128;
@@ -372,7 +383,10 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
   a.R = (BM - 1) * a.stride + (a.K - 1) * a.dil + 1;
   a.Rpad = ceil_div(a.R, 8) * 8;
   size_t main_bytes = (size_t)(XSINGLE ? 1 : 2) * NWIN * a.Rpad * 128 + (size_t)2 * BN * 128;
-  size_t epi_bytes = (size_t)NWIN * BM * (BN * 2 + 16) + (size_t)(NTHR / (BN / 2)) * BN * 2 * 4;
+  constexpr size_t kOP = BN * 2 + 16;
+  constexpr int kEW = ((size_t)NWIN * BM * kOP > 112 * 1024) ? 1 : NWIN;
+  constexpr int kRG = (NTHR / (BN / 2)) > 0 ? (NTHR / (BN / 2)) : 1;
+  size_t epi_bytes = (size_t)kEW * BM * kOP + (size_t)kRG * BN * 2 * 4;
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static size_t attr_set = 0;
@@ -391,8 +405,9 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
 
 }  // namespace os2s
 
-// -1 (default) = pick per problem shape between the 128x128 tile (variant 3 / 0) and the
-// 256x256 tile (variant 5) by timing both once — the lazily built kernel cache of the ABI
+// -1 (default) = pick per problem shape between the 128x128 tile (variant 3 / 0), the
+// 256x256 tile (variant 5) and the 256x320 / 256x384 tiles (variants 8 / 9: Cout = 640 / 768
+// in ONE round of workgroups) by timing them once — the lazily built kernel cache of the ABI
 // contract; which one wins is decided by tile quantisation against the 256 CUs (e.g. B*T' =
 // 28k rows: Cout 512 -> 224 256^2 tiles = one round at 975 TF/s vs 824; Cout 640 -> 336 tiles
 // = 1.3 rounds at 712 vs 913).
@@ -462,6 +477,8 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
     const int base = K >= 8 ? 3 : 0;
     auto run = [&](int v) -> int {
       if (v == 5) return launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
+      if (v == 8) return launch_conv<kConvBM, 320, 4, 2, 2, true>((hipStream_t)stream, a);
+      if (v == 9) return launch_conv<kConvBM, 384, 4, 2, 2, true>((hipStream_t)stream, a);
       if (v == 3) return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>((hipStream_t)stream, a);
       return launch_conv<kConvBM, kConvBN, 2, 2, 1>((hipStream_t)stream, a);
     };
@@ -482,7 +499,9 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
       choice = base;
       hipEvent_t e0, e1;
       if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run(base);
-      for (int v : {base, 5}) {
+      for (int v : {base, 5, 8, 9}) {
+        if (v == 8 && Cout < 512) continue;           // 256x320 / 256x384 tiles: wide layers only
+        if (v == 9 && Cout < 640) continue;
         if (run(v) != OS2S_OK) continue;              // warm-up (also: unsupported LDS size)
         hipEventRecord(e0, (hipStream_t)stream);
         for (int r = 0; r < 3; ++r) run(v);
@@ -509,6 +528,15 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
     if (g_conv_variant == 4) rc = launch_conv<kConvBM, 256, 2, 4, 2, true>((hipStream_t)stream, a);
     if (g_conv_variant == 5) rc = launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
     if (g_conv_variant == 6) rc = launch_conv<kConvBM, 256, 2, 2, 1, true>((hipStream_t)stream, a);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  }
+  if (g_conv_variant == 9)
+    return launch_conv<kConvBM, 384, 4, 2, 2, true>((hipStream_t)stream, a);
+  if (g_conv_variant == 7 || g_conv_variant == 8) {
+    // 256 x 384 / 256 x 320 tiles: one round of workgroups for Cout = 768 / 640
+    int rc = OS2S_ERR_UNSUPPORTED;
+    if (g_conv_variant == 7) rc = launch_conv<kConvBM, 384, 2, 4, 2, true>((hipStream_t)stream, a);
+    if (g_conv_variant == 8) rc = launch_conv<kConvBM, 320, 4, 2, 2, true>((hipStream_t)stream, a);
     if (rc != OS2S_ERR_UNSUPPORTED) return rc;
   }
   if (g_conv_variant == 2) {

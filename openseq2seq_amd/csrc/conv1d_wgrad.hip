@@ -23,6 +23,8 @@
 //     are adjacent on one XCD so dY/X tiles are L2 hits for all but the first;
 //   * batch splits are combined with fp32 atomics only when a layer is too
 //     small to fill the chip otherwise.
+#include <stdlib.h>
+
 #include "os2s_common.hpp"
 
 namespace os2s {
@@ -272,7 +274,14 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   OS2S_REQUIRE(B >= 0 && Tin >= 1 && Tout >= 1 && Cin >= 8 && Cout >= 8 && K >= 1);
   OS2S_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && stride >= 1 && dil >= 1);
   if (B == 0) return OS2S_OK;
-  constexpr int TAPS = 2;
+  // taps per workgroup: the dY tile of a step is reused by every tap, so L2->LDS bytes per
+  // FLOP fall as 1/TAPS (2 taps: 173 FLOP/B, 3 taps: 257 FLOP/B — the kernels run against
+  // the ~7.3 TB/s L2->CU delivery limit, not against MFMA); 3 x 64 accumulator registers fit
+  // the 256-register budget of 2 waves/SIMD.
+  // (measured: the 3-tap instantiation needs 256 VGPRs + 84 B/lane of scratch and is 20-25 %
+  // SLOWER than 2 taps on every Jasper layer — kept selectable for future register work.)
+  int TAPS = 2;
+  if (const char* f = getenv("OS2S_WGRAD_TAPS")) { const int v = atoi(f); if (v == 2 || v == 3) TAPS = v; }
   // the 256-wide tile pays off once there are enough 256-channel tiles to fill the chip
   const bool wide = (Cout % 256 == 0) && (K >= 8) && (Cout >= 512);
   const int COT = wide ? 256 : 128;
@@ -293,6 +302,10 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
   }
+  if (const char* f = getenv("OS2S_WGRAD_NSPLIT")) {      // tuning hook (tools/bench_wgrad_shapes.py)
+    const int v = atoi(f);
+    if (v >= 1 && accumulate) nsplit = v > total_steps ? total_steps : v;
+  }
   a.steps_per_split = ceil_div(total_steps, nsplit);
   a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
   a.use_atomic = accumulate ? 1 : 0;
@@ -302,9 +315,13 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<TAPS, 128>,
+    if (hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<2, 128>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<TAPS, 256>,
+        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<2, 256>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<3, 128>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<3, 256>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return OS2S_ERR_LAUNCH;
     attr_set = true;
@@ -312,9 +329,15 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   const int nunits = a.NCO * a.NCI * a.NSPLIT;
   const int grid = ceil_div(nunits, 8) * 8 * a.NTP;
   if (wide) {
-    OS2S_LAUNCH((conv1d_wgrad_kernel<TAPS, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+    if (TAPS == 3)
+      OS2S_LAUNCH((conv1d_wgrad_kernel<3, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+    else
+      OS2S_LAUNCH((conv1d_wgrad_kernel<2, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
   } else {
-    OS2S_LAUNCH((conv1d_wgrad_kernel<TAPS, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+    if (TAPS == 3)
+      OS2S_LAUNCH((conv1d_wgrad_kernel<3, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+    else
+      OS2S_LAUNCH((conv1d_wgrad_kernel<2, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
   }
   return OS2S_OK;
 }

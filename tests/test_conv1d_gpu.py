@@ -146,3 +146,38 @@ def test_conv_wgrad(cuda, B, T, Cin, Cout, K, s, d, accumulate):
   scale = float(ref.pow(2).mean().sqrt()) + 1e-6
   # fp32 accumulation of exact bf16 products: only summation-order noise
   torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize("variant", [3, 5, 7, 8])
+@pytest.mark.parametrize("B,T,Cin,Cout,K,s,d", [
+    (3, 300, 128, 768, 9, 1, 1), (2, 260, 192, 640, 5, 1, 2), (3, 200, 64, 200, 3, 1, 1),
+    (2, 140, 128, 384, 7, 2, 1)])
+def test_conv_fwd_tile_variants(cuda, variant, B, T, Cin, Cout, K, s, d):
+  """Every tile shape of the autotune pool (128x128, 256x256, 256x384, 256x320) on the same
+  problems, incl. Cout that is not a multiple of the tile and ragged lengths; output, the fused
+  ReLU/residual epilogue and the BN partial sums."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(B * 1000 + T + K + Cout)
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = _bf(torch.randn(K, Cin, Cout, generator=g) * (1.0 / (K * Cin) ** 0.5))
+  lens = torch.randint(T // 2, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  ref = cnn.conv1d_tf(x.float(), w_tf.float(), s, d, "SAME", mask_len=lens)
+  tout = ref.shape[1]
+  res = _bf(torch.randn(B, tout, Cout, generator=g))
+  nm = capi.conv1d_num_mtiles(B, tout)
+  stats = torch.full((nm, 2, Cout), float("nan"), device=cuda)
+  _lib.lib().os2s_conv1d_set_variant(variant)
+  try:
+    y = capi.conv1d_fwd(x.to(cuda), cnn.to_dev_layout(w_tf).to(cuda), stride=s, dil=d,
+                        in_len=lens.to(cuda), stats=stats)
+    y2 = capi.conv1d_fwd(x.to(cuda), cnn.to_dev_layout(w_tf).to(cuda), stride=s, dil=d,
+                         in_len=lens.to(cuda), act=1, residual=res.to(cuda))
+    torch.cuda.synchronize()
+  finally:
+    _lib.lib().os2s_conv1d_set_variant(-1)
+  _check(y, ref)
+  _check(y2, torch.relu(ref) + res.float(), extra=2.0)
+  yr = y.float().cpu()
+  torch.testing.assert_close(stats[:, 0, :].sum(0).cpu(), yr.sum((0, 1)), rtol=1e-4, atol=1e-2)
+  torch.testing.assert_close(stats[:, 1, :].sum(0).cpu(), yr.pow(2).sum((0, 1)), rtol=1e-4, atol=1e-2)
