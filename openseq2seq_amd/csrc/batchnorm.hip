@@ -24,29 +24,32 @@ constexpr int kMaxBnInputs = 12;
 // ---------------------------------------------------------------------------
 // finalize: partial (sum, sumsq) -> mean / rstd / fused scale+shift, moving stats
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+constexpr int kFinLanes = 16;     // partial-row lanes per channel (x 64 channels = 1024 threads)
+
+__global__ __launch_bounds__(64 * kFinLanes) void bn_finalize_kernel(
     const float* __restrict__ partial, int nparts, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float momentum, int training, float* __restrict__ moving_mean,
     float* __restrict__ moving_var, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, float* __restrict__ scale_out,
     float* __restrict__ shift_out) {
-  // 64 channels per block, 4 lanes of partial rows per channel (coalesced over c)
-  __shared__ double sh_s[4][64], sh_q[4][64];
+  // 64 channels per block, kFinLanes lanes of partial rows per channel (coalesced over c): the
+  // kernel is a latency chain over nparts / kFinLanes dependent-free loads, launched ~100x / step
+  __shared__ double sh_s[kFinLanes][64], sh_q[kFinLanes][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s = 0.0, q = 0.0;
   if (training && c < C) {
     int i = pl;
-    for (; i + 12 < nparts; i += 16) {
+    for (; i + 3 * kFinLanes < nparts; i += 4 * kFinLanes) {
       const float a0 = partial[((long long)i * 2) * C + c], b0 = partial[((long long)i * 2 + 1) * C + c];
-      const float a1 = partial[((long long)(i + 4) * 2) * C + c], b1 = partial[((long long)(i + 4) * 2 + 1) * C + c];
-      const float a2 = partial[((long long)(i + 8) * 2) * C + c], b2 = partial[((long long)(i + 8) * 2 + 1) * C + c];
-      const float a3 = partial[((long long)(i + 12) * 2) * C + c], b3 = partial[((long long)(i + 12) * 2 + 1) * C + c];
+      const float a1 = partial[((long long)(i + kFinLanes) * 2) * C + c], b1 = partial[((long long)(i + kFinLanes) * 2 + 1) * C + c];
+      const float a2 = partial[((long long)(i + 2 * kFinLanes) * 2) * C + c], b2 = partial[((long long)(i + 2 * kFinLanes) * 2 + 1) * C + c];
+      const float a3 = partial[((long long)(i + 3 * kFinLanes) * 2) * C + c], b3 = partial[((long long)(i + 3 * kFinLanes) * 2 + 1) * C + c];
       s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
       q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    for (; i < nparts; i += 4) {
+    for (; i < nparts; i += kFinLanes) {
       s += (double)partial[((long long)i * 2) * C + c];
       q += (double)partial[((long long)i * 2 + 1) * C + c];
     }
@@ -57,8 +60,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
   if (pl != 0 || c >= C) return;
   float mean, var;
   if (training) {
-    s = (sh_s[0][cl] + sh_s[1][cl]) + (sh_s[2][cl] + sh_s[3][cl]);
-    q = (sh_q[0][cl] + sh_q[1][cl]) + (sh_q[2][cl] + sh_q[3][cl]);
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int l = 0; l < kFinLanes; ++l) { s += sh_s[l][cl]; q += sh_q[l][cl]; }
     const double m = s / count;
     double v = q / count - m * m;
     if (v < 0.0) v = 0.0;
@@ -321,25 +325,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
 
 // Backward finalize for input j: reduce the partials -> dgamma, dbeta and the two
 // means pass 2 needs (c1 = mean(dz), c2 = mean(dz*xhat)).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nparts, int nq, int q, int C, double count,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
     float* __restrict__ c1, float* __restrict__ c2) {
-  __shared__ double sh_d[4][64], sh_x[4][64];
+  __shared__ double sh_d[kFinLanes][64], sh_x[kFinLanes][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double sd = 0.0, sx = 0.0;
   if (c < C) {
     int i = pl;
-    for (; i + 4 < nparts; i += 8) {
+    for (; i + kFinLanes < nparts; i += 2 * kFinLanes) {
       const float a0 = partial[((long long)i * nq + 0) * C + c];
       const float b0 = partial[((long long)i * nq + q) * C + c];
-      const float a1 = partial[((long long)(i + 4) * nq + 0) * C + c];
-      const float b1 = partial[((long long)(i + 4) * nq + q) * C + c];
+      const float a1 = partial[((long long)(i + kFinLanes) * nq + 0) * C + c];
+      const float b1 = partial[((long long)(i + kFinLanes) * nq + q) * C + c];
       sd += (double)a0 + (double)a1;
       sx += (double)b0 + (double)b1;
     }
-    for (; i < nparts; i += 4) {
+    for (; i < nparts; i += kFinLanes) {
       sd += (double)partial[((long long)i * nq + 0) * C + c];
       sx += (double)partial[((long long)i * nq + q) * C + c];
     }
@@ -348,8 +352,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
   sh_x[pl][cl] = sx;
   __syncthreads();
   if (pl != 0 || c >= C) return;
-  sd = (sh_d[0][cl] + sh_d[1][cl]) + (sh_d[2][cl] + sh_d[3][cl]);
-  sx = (sh_x[0][cl] + sh_x[1][cl]) + (sh_x[2][cl] + sh_x[3][cl]);
+  sd = 0.0; sx = 0.0;
+#pragma unroll
+  for (int l = 0; l < kFinLanes; ++l) { sd += sh_d[l][cl]; sx += sh_x[l][cl]; }
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sd;
   c1[c] = (float)(sd / count);
@@ -439,7 +444,7 @@ extern "C" int os2s_bn_finalize(os2s_stream_t stream, const float* partial, int 
   OS2S_REQUIRE(C >= 1 && scale_out && shift_out);
   if (training) OS2S_REQUIRE(partial && nparts >= 1 && count >= 1);
   else OS2S_REQUIRE(moving_mean && moving_var);
-  OS2S_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0,
+  OS2S_LAUNCH(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * kFinLanes), 0,
               (hipStream_t)stream, partial, nparts, C, (double)count, gamma, beta, eps,
               momentum, training, moving_mean, moving_var, mean_out, rstd_out, scale_out,
               shift_out);
@@ -532,7 +537,7 @@ extern "C" int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, 
                                     int nq, int q, int C, long long count, float* dgamma,
                                     float* dbeta, int accumulate, float* c1, float* c2) {
   OS2S_REQUIRE(partial && c1 && c2 && nparts >= 1 && q >= 1 && q < nq && count >= 1);
-  OS2S_LAUNCH(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0,
+  OS2S_LAUNCH(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * kFinLanes), 0,
               (hipStream_t)stream, partial, nparts, nq, q, C, (double)count, dgamma, dbeta,
               accumulate, c1, c2);
   return OS2S_OK;
