@@ -28,3 +28,24 @@ def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch):
   res = run.run_eval(model, model.eval_model, 0)
   assert res["samples"] == 256
   assert res["bleu"] > 0.9, res
+
+
+def test_transformer_learns_reversal_with_beam_search(cuda, tmp_path, monkeypatch):
+  """The Transformer counterpart (the reference's toy-reversal/nmt-reversal-TT.py at d_model 512):
+  training path + beam-search inference (beam 5, alpha 1.0) end to end; BLEU on the dev set."""
+  sys.path.insert(0, REPO)
+  import run
+  from openseq2seq_amd.test_utils.create_reversed_examples import create_data
+  from openseq2seq_amd.utils.utils import create_model, get_base_config
+  monkeypatch.chdir(tmp_path)
+  create_data(train_corpus_size=10000, dev_corpus_size=256, test_corpus_size=8,
+              data_path="toy_text_data", seed=0)
+  cfg = os.path.join(REPO, "example_configs/text2text/toy-reversal/transformer-reversal-512.py")
+  args, base_config, base_model, config_module = get_base_config(
+      ["--config_file=" + cfg, "--mode=train_eval", "--max_steps=800", "--print_loss_steps=200",
+       "--eval_steps=10000"])
+  model = create_model(args, base_config, config_module, base_model, None)
+  run.train(model, args)
+  res = run.run_eval(model, model.eval_model, 0)
+  assert res["samples"] == 256
+  assert res["bleu"] > 0.9, res
