@@ -432,6 +432,20 @@ int os2s_beam_finalize(os2s_stream_t stream, int B, int beam, int max_decode_len
  * (pass the beam status so that a finished search stops permuting its caches). */
 int os2s_gather_rows(os2s_stream_t stream, const void* src, const int32_t* idx, long long rows,
                      long long row_bytes, const int32_t* enable, void* dst);
+/* Plain library GEMM through hipBLASLt (the fused ops stay on the hand-written kernels):
+ * C[M,N] (row-major; bf16, or fp32 when c_f32) = op(A)[M,K] . op(B)[K,N] + beta * C, bf16
+ * inputs, fp32 accumulation. A is stored [M,K] (a_is_T = 0) or [K,M] (1), row stride lda; B is
+ * stored [K,N] (b_is_T = 0) or [N,K] (1), row stride ldb. Replaces the tf.layers.Dense matmuls of
+ * the Transformer blocks and their data / weight gradients (x W^T: B = W [N,K], b_is_T = 1;
+ * dx = dz W: b_is_T = 0; dW += dy^T x: A = dy, a_is_T = 1, c_f32 = 1, beta = 1). */
+int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_T, long long lda,
+                   const uint16_t* B, int b_is_T, long long ldb, void* C, int c_f32,
+                   long long ldc, int M, int N, int K, float beta);
+/* In place on bf16 y [rows, C]: y = residual + dropout(act(y + bias)) — the epilogue of a Dense
+ * layer whose matmul ran in os2s_matmul_lt (same semantics and dropout stream as the fused
+ * epilogue of os2s_conv1d_fwd_ex with K = 1; act 1 = ReLU). bias / residual may be NULL. */
+int os2s_dense_epilogue(os2s_stream_t stream, uint16_t* y, const float* bias, long long rows, int C,
+                        int act, float keep_prob, unsigned long long seed, const uint16_t* residual);
 /* Y[M,N] = act(X[M,K] . W[N,K]^T + bias) (+ residual) for SMALL M (decoding steps: M =
  * batch*beam rows): one 32x32 output tile per workgroup, K split over its 8 waves with all
  * loads issued up front — the latency-bound regime where the training GEMM

@@ -449,6 +449,33 @@ def gemm(x2d, w, **kw):
   return y.view(N, Cout)
 
 
+def matmul_lt(a, b, a_is_t=False, b_is_t=False, out=None, out_f32=False, beta=0.0):
+  """out[M,N] = op(a) @ op(b) (+ beta * out) via hipBLASLt; a, b bf16 2-D (row stride free)."""
+  M, K = (a.shape[1], a.shape[0]) if a_is_t else (a.shape[0], a.shape[1])
+  K2, N = (b.shape[1], b.shape[0]) if b_is_t else (b.shape[0], b.shape[1])
+  assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
+  if out is None:
+    assert beta == 0.0
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+  assert out.stride(1) == 1 and tuple(out.shape) == (M, N)
+  f = _fn("os2s_matmul_lt", (c_void_p, c_void_p, c_int, c_ll, c_void_p, c_int, c_ll, c_void_p, c_int, c_ll,
+                            c_int, c_int, c_int, c_float))
+  _lib.check(f(_stream(), c_void_p(a.data_ptr()), int(a_is_t), a.stride(0), c_void_p(b.data_ptr()), int(b_is_t),
+               b.stride(0), c_void_p(out.data_ptr()), int(out.dtype == torch.float32), out.stride(0), M, N, K,
+               float(beta)), "os2s_matmul_lt")
+  return out
+
+
+def dense_epilogue(y, bias=None, act=0, keep_prob=1.0, seed=0, residual=None):
+  """In place: y = residual + dropout(act(y + bias)) on bf16 [rows, C]."""
+  rows, C = y.shape
+  f = _fn("os2s_dense_epilogue", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_float, c_uint64, c_void_p))
+  _lib.check(f(_stream(), _ptr(y, torch.bfloat16), _ptr(bias, torch.float32, True), rows, C, int(act),
+               float(keep_prob), int(seed) & (2**64 - 1), _ptr(residual, torch.bfloat16, True)),
+             "os2s_dense_epilogue")
+  return y
+
+
 def gemm_skinny(x2d, w, bias=None, relu=False, residual=None):
   """x2d [M,K] bf16 (row stride free), w [N,K] bf16 -> [M,N]; for small M (decoding steps)."""
   M, K = x2d.shape

@@ -1,0 +1,89 @@
+// Plain library GEMMs through hipBLASLt.
+//
+// The hand-written MFMA kernels of this library carry the fused ops (implicit-GEMM conv with
+// window reuse + BN statistics, attention, the decoding-step GEMMs, recurrent steps). A bare
+// C = op(A) . op(B) (+ beta C) with tokens x hidden shapes — the q/k/v, vocabulary and
+// feed-forward projections of the Transformer (tf.layers.Dense calls in
+// open_seq2seq/parts/transformer/{attention_layer,ffn_layer,embedding_layer}.py), their data
+// gradients and their weight gradients — is exactly what the vendor library is tuned for
+// (measured on MI355X, bf16, M = 16384: 1.0-1.5 PFLOP/s vs 0.63-0.92 for the in-tree 1x1-conv
+// GEMM, whose 128/256-row tiles meet the L2->LDS delivery limit first), so those go here.
+// Row-major in, row-major out; descriptors + heuristics are cached per problem.
+#include <hipblaslt/hipblaslt.h>
+
+#include <array>
+#include <map>
+#include <mutex>
+
+#include "os2s_common.hpp"
+
+namespace {
+
+struct LtPlan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  bool ok = false;
+};
+
+hipblasLtHandle_t g_handle = nullptr;
+void* g_ws = nullptr;
+constexpr size_t kWsBytes = 64ull << 20;
+std::mutex g_mu;
+std::map<std::array<long long, 10>, LtPlan> g_plans;
+
+}  // namespace
+
+// C[M,N] (row-major, bf16 or fp32) = op(A)[M,K] . op(B)[K,N] + beta * C, bf16 inputs, fp32
+// accumulation. A is stored [M,K] (a_is_T = 0) or [K,M] (1); B is stored [K,N] (0) or [N,K] (1).
+extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_T, long long lda,
+                              const uint16_t* B, int b_is_T, long long ldb, void* C, int c_f32,
+                              long long ldc, int M, int N, int K, float beta) {
+  OS2S_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N);
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_handle) {
+    if (hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return OS2S_ERR_LAUNCH;
+    if (hipMalloc(&g_ws, kWsBytes) != hipSuccess) return OS2S_ERR_LAUNCH;
+  }
+  const std::array<long long, 10> key = {M, N, K, a_is_T, b_is_T, lda, ldb, ldc, c_f32, beta != 0.f};
+  LtPlan& pl = g_plans[key];
+  if (!pl.ok) {
+    // row-major C = op(A) op(B)  <=>  column-major C^T[N,M] = op(B)^T op(A)^T
+    if (hipblasLtMatmulDescCreate(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS)
+      return OS2S_ERR_LAUNCH;
+    const hipblasOperation_t ta = b_is_T ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    const hipblasOperation_t tb = a_is_T ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+    hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+    // first operand = the B buffer: stored [K,N] -> column-major N x K; stored [N,K] -> K x N
+    if (hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, b_is_T ? K : N, b_is_T ? N : K, ldb) != HIPBLAS_STATUS_SUCCESS ||
+        hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, a_is_T ? M : K, a_is_T ? K : M, lda) != HIPBLAS_STATUS_SUCCESS ||
+        hipblasLtMatrixLayoutCreate(&pl.lc, c_f32 ? HIP_R_32F : HIP_R_16BF, N, M, ldc) != HIPBLAS_STATUS_SUCCESS)
+      return OS2S_ERR_LAUNCH;
+    hipblasLtMatmulPreference_t pref;
+    if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return OS2S_ERR_LAUNCH;
+    uint64_t ws = kWsBytes;
+    hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
+    hipblasLtMatmulHeuristicResult_t res[1];
+    int found = 0;
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, pl.desc, pl.la, pl.lb, pl.lc, pl.lc,
+                                                               pref, 1, res, &found);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
+      os2s_record_hip_error((int)st, "hipblasLtMatmulAlgoGetHeuristic");
+      return OS2S_ERR_UNSUPPORTED;
+    }
+    pl.algo = res[0].algo;
+    pl.ws = res[0].workspaceSize;
+    pl.ok = true;
+  }
+  const float alpha = 1.f;
+  const hipblasStatus_t st = hipblasLtMatmul(g_handle, pl.desc, &alpha, B, pl.la, A, pl.lb, &beta, C, pl.lc, C,
+                                             pl.lc, &pl.algo, g_ws, pl.ws, (hipStream_t)stream);
+  if (st != HIPBLAS_STATUS_SUCCESS) {
+    os2s_record_hip_error((int)st, "hipblasLtMatmul");
+    return OS2S_ERR_LAUNCH;
+  }
+  return OS2S_OK;
+}

@@ -249,6 +249,50 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// y = residual + dropout(act(y + bias)) in place on bf16 [rows, C]: the epilogue of a Dense
+// layer whose matmul ran in the vendor GEMM (same dropout stream as the fused conv epilogue:
+// element index / 8 -> dropout_bits8). One HBM pass; C % 8 == 0.
+__global__ __launch_bounds__(256) void dense_epilogue_kernel(bf16_t* __restrict__ y,
+                                                             const float* __restrict__ bias, int C,
+                                                             int act, float keep_prob,
+                                                             unsigned long long seed,
+                                                             const bf16_t* __restrict__ residual,
+                                                             long long n8) {
+  const float ik = 1.f / keep_prob;
+  const int c8 = C >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8;
+       i += (long long)gridDim.x * 256) {
+    const u32x4 t = reinterpret_cast<const u32x4*>(y)[i];
+    float g[8] = {bflo(t[0]), bfhi(t[0]), bflo(t[1]), bfhi(t[1]),
+                  bflo(t[2]), bfhi(t[2]), bflo(t[3]), bfhi(t[3])};
+    if (bias) {
+      const int c0 = (int)(i % c8) * 8;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c0);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + c0 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[e] += b0[e]; g[4 + e] += b1[e]; }
+    }
+    if (act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = fmaxf(g[e], 0.f);
+    }
+    if (keep_prob < 1.f) {
+      const uint32_t keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1u) ? g[e] * ik : 0.f;
+    }
+    if (residual) {
+      const u32x4 r = reinterpret_cast<const u32x4*>(residual)[i];
+      g[0] += bflo(r[0]); g[1] += bfhi(r[0]); g[2] += bflo(r[1]); g[3] += bfhi(r[1]);
+      g[4] += bflo(r[2]); g[5] += bfhi(r[2]); g[6] += bflo(r[3]); g[7] += bfhi(r[3]);
+    }
+    u32x4 o;
+    o[0] = pack2bf(g[0], g[1]); o[1] = pack2bf(g[2], g[3]);
+    o[2] = pack2bf(g[4], g[5]); o[3] = pack2bf(g[6], g[7]);
+    reinterpret_cast<u32x4*>(y)[i] = o;
+  }
+}
+
 // out = a + b (bf16), used to sum gradient contributions of multi-consumer activations
 __global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a,
                                                        const bf16_t* __restrict__ b, long long n8,
@@ -484,6 +528,18 @@ extern "C" int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, cons
   if (n == 0) return OS2S_OK;
   OS2S_LAUNCH(dropout_bwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, dout,
               out, mode, keep_prob, seed, n / 8, d);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_dense_epilogue(os2s_stream_t stream, uint16_t* y, const float* bias, long long rows,
+                                   int C, int act, float keep_prob, unsigned long long seed,
+                                   const uint16_t* residual) {
+  OS2S_REQUIRE(y && rows >= 0 && C >= 8 && C % 8 == 0 && (act == 0 || act == 1));
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
+  if (rows == 0) return OS2S_OK;
+  const long long n8 = rows * (C / 8);
+  OS2S_LAUNCH(dense_epilogue_kernel, dim3(ew_blocks(n8)), dim3(256), 0, (hipStream_t)stream, y, bias, C,
+              act, keep_prob, seed, residual, n8);
   return OS2S_OK;
 }
 

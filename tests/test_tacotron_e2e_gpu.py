@@ -5,7 +5,7 @@ the loss and every parameter gradient vs the CPU fp32 oracle on the same bf16-ro
 weights (outputs: relative L2 <= 3e-2 and max abs error <= 0.15). Dropout is disabled in both (pre-net dropout is always on in
 the reference; parity needs it off or shared — the dropout plumbing of the loop is pinned
 in test_attn_decoder_gpu). Tolerances: loss rel 3e-2, gradients
-cosine >= 0.985 and relative L2 <= 0.17 (bf16 activations + gate gradients through T=24
+cosine >= 0.98 and relative L2 <= 0.2 (bf16 activations + gate gradients through T=24
 recurrent steps feeding back through the attention)."""
 import pytest
 import torch
@@ -18,7 +18,7 @@ POST = [{"kernel_size": [5], "stride": [1], "num_channels": 64, "padding": "SAME
         {"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
 
 
-def _cmp(got, ref, name, cos_min=0.985, rel_max=0.17):
+def _cmp(got, ref, name, cos_min=0.98, rel_max=0.2):
   got, ref = got.float().cpu().flatten(), ref.detach().float().flatten()
   if float(ref.norm()) < 1e-9 and float(got.norm()) < 1e-6:
     return None

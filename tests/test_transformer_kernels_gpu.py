@@ -194,3 +194,56 @@ def test_attention_fwd_long(cuda, causal, cross):
     ref_lse = torch.logsumexp(S, -1).transpose(0, 1)
     torch.testing.assert_close(lse[oq:oq + lq[b]].cpu(), ref_lse, atol=2e-3, rtol=1e-3)
     oq += lq[b]; ok += lk[b]
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1024, 512), (4096, 3072, 1024), (77, 40, 72)])
+def test_matmul_lt(cuda, M, N, K):
+  """os2s_matmul_lt (hipBLASLt) in the three roles of a Dense layer vs fp32 references on the
+  same bf16 inputs: forward x W^T, data gradient dz W, weight gradient dW += dy^T x (fp32 out,
+  beta 1). bf16 outputs: rtol 1e-2; fp32 output: 2e-3 of the rms."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(M + N + K)
+  x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+  w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+  dz = _bf(torch.randn(M, N, generator=g)).to(cuda)
+  y = capi.matmul_lt(x, w, b_is_t=True)
+  ref = x.float() @ w.float().t()
+  torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=2e-2)
+  dx = capi.matmul_lt(dz, w)
+  ref = dz.float() @ w.float()
+  torch.testing.assert_close(dx.float(), ref, rtol=1e-2, atol=2e-2 * float(ref.std()))
+  # accumulate into an existing bf16 buffer
+  dx2 = capi.matmul_lt(dz, w, out=dx.clone(), beta=1.0)
+  torch.testing.assert_close(dx2.float(), 2 * ref, rtol=2e-2, atol=4e-2 * float(ref.std()))
+  base = torch.randn(N, K, generator=g).to(cuda)
+  dw = capi.matmul_lt(dz, x, a_is_t=True, out=base.clone(), beta=1.0)
+  ref = base + dz.float().t() @ x.float()
+  torch.testing.assert_close(dw, ref, rtol=2e-3, atol=2e-3 * float(ref.std()))
+  # strided views (column slices of fused projections)
+  wide = _bf(torch.randn(M, 2 * K, generator=g)).to(cuda)
+  y2 = capi.matmul_lt(wide[:, K:], w, b_is_t=True)
+  torch.testing.assert_close(y2.float(), wide[:, K:].float() @ w.float().t(), rtol=1e-2, atol=2e-2)
+
+
+def test_dense_epilogue_matches_fused_gemm(cuda):
+  """os2s_matmul_lt + os2s_dense_epilogue == the fused in-tree GEMM epilogue (bias, ReLU, dropout
+  with the same (seed, element) stream, residual): identical dropout pattern, values to bf16
+  rounding of the intermediate (atol 3e-2)."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(3)
+  M, K, N = 500, 256, 1024
+  x = _bf(torch.randn(M, K, generator=g)).to(cuda)
+  w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
+  b = torch.randn(N, generator=g).to(cuda)
+  r = _bf(torch.randn(M, N, generator=g)).to(cuda)
+  for act, keep, res in ((1, 0.7, None), (0, 0.9, r), (0, 1.0, r), (1, 1.0, None)):
+    fused = capi.gemm(x, w, bias=b, act=act, keep_prob=keep, seed=11, residual=res)
+    y = capi.matmul_lt(x, w, b_is_t=True)
+    capi.dense_epilogue(y, bias=b, act=act, keep_prob=keep, seed=11, residual=res)
+    torch.testing.assert_close(y.float(), fused.float(), atol=3e-2, rtol=2e-2)
+    if keep < 1.0 and act == 0:      # dropped elements are exactly the residual (or 0)
+      base = res.float() if res is not None else torch.zeros_like(y, dtype=torch.float32)
+      # (a kept element can round onto the residual in one path only: allow 0.1 % disagreement)
+      assert float(((y.float() == base) != (fused.float() == base)).float().mean()) < 1e-3
+      frac = float((y.float() == base).float().mean())
+      assert abs(frac - (1 - keep)) < 0.02
