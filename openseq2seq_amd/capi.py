@@ -434,8 +434,27 @@ def spec_augment(feats, masks):
 # --------------------------------------------------------------------------
 # Transformer kernels (packed token-major tensors)
 # --------------------------------------------------------------------------
+LT_MIN_ROWS = 256     # plain matmuls with at least this many rows go to the vendor GEMM
+
+
+def _lt_unsupported(e):
+  return "unsupported" in str(e).lower()
+
+
 def gemm(x2d, w, **kw):
-  """x2d [N,Cin] bf16, w [Cout,Cin] bf16 -> [N,Cout]: the K=1 case of conv1d_fwd."""
+  """x2d [N,Cin] bf16, w [Cout,Cin] bf16 -> [N,Cout]. A bare matmul (no bias / activation /
+  dropout / residual / fp32 output) runs in hipBLASLt (os2s_matmul_lt); everything with a fused
+  epilogue is the K=1 case of the in-tree conv1d_fwd kernel."""
+  plain = (all(kw.get(k) is None for k in ("bias", "residual", "stats", "in_len", "out_len"))
+           and not kw.get("act", 0) and not kw.get("out_f32", False) and not kw.get("time_major", False)
+           and kw.get("keep_prob", 1.0) >= 1.0)
+  if plain and x2d.shape[0] >= LT_MIN_ROWS and x2d.stride(1) == 1 and w.stride(1) == 1:
+    out_t = kw.get("out", None)
+    try:
+      return matmul_lt(x2d, w, b_is_t=True, out=out_t, beta=1.0 if kw.get("accumulate", False) else 0.0)
+    except _lib.Os2sError as e:
+      if not _lt_unsupported(e):
+        raise
   out = kw.pop("out", None)
   N, Cin = x2d.shape
   Cout = w.shape[0]
@@ -493,9 +512,16 @@ def gemm_skinny(x2d, w, bias=None, relu=False, residual=None):
 
 
 def gemm_wgrad(x2d, dy2d, out, accumulate=True):
-  """dW [Cout,Cin] (+)= dy^T x."""
+  """dW [Cout,Cin] (+)= dy^T x (fp32)."""
   N, Cin = x2d.shape
   Cout = dy2d.shape[1]
+  if N >= LT_MIN_ROWS and x2d.stride(1) == 1 and dy2d.stride(1) == 1 and out.stride(1) == 1:
+    try:
+      matmul_lt(dy2d, x2d, a_is_t=True, out=out, beta=1.0 if accumulate else 0.0)
+      return
+    except _lib.Os2sError as e:
+      if not _lt_unsupported(e):
+        raise
   conv1d_wgrad(x2d.view(1, N, Cin), dy2d.view(1, N, Cout), 1, pad_left=0,
                out=out.view(1, Cout, Cin), accumulate=accumulate)
 
