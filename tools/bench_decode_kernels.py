@@ -49,8 +49,8 @@ def main():
     t4 = timeit(lambda: capi.gemm_skinny(inp, w))
     del os.environ["OS2S_SKINNY_VARIANT"]
     t5 = timeit(lambda: capi.gemm_skinny(inp, w))
-    t2 = timeit(lambda: capi.gemm(inp, w))
-    print("gemm %-18s reg %6.1f  lds64 %6.1f  lds32 %6.1f  wide %6.1f  auto %6.1f  igemm %6.1f us  (W %.1f MB)"
+    t2 = timeit(lambda: capi.matmul_lt(inp, w, b_is_t=True))
+    print("gemm %-18s reg %6.1f  lds64 %6.1f  lds32 %6.1f  wide %6.1f  auto %6.1f  hipBLASLt %6.1f us  (W %.1f MB)"
           % (name, t, t1, t3, t4, t5, t2, n * k * 2 / 1e6), flush=True)
   Tmax, step = 106, 50
   kc, vc = bf(N, Tmax, D), bf(N, Tmax, D)
