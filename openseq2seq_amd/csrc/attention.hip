@@ -377,7 +377,8 @@ __global__ __launch_bounds__(kFwdWaves * 64) void attn_fwd_long_kernel(AttnArgs 
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-constexpr int kBwdWaves = 2;
+constexpr int kBwdWaves = 1;            // one wave per workgroup: LDS per wave decides occupancy
+constexpr int kBwdLdsPerWave = 24576;   // 3 images (was 6 = 48 KB -> 2 waves per CU)
 
 // generic "A via tr image, B via kc image" 64x64x64 product: D[m][n], m from A image cols
 __device__ __forceinline__ void mm_tr_kc(const char* a_tr, const char* b_kc, int lane, f32x16 (&d)[2][2]) {
@@ -395,6 +396,29 @@ __device__ __forceinline__ void mm_tr_kc(const char* a_tr, const char* b_kc, int
     for (int i = 0; i < 2; ++i) a[i] = frag_tr(a_tr, i, kk, lane);
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[j] = frag_kc(b_kc, j * 32 + l31, kk * 2 + lhi);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], d[i][j], 0, 0, 0);
+  }
+}
+
+// D[m][n] = sum_k A^T-image[k][m] * B^T-image[k][n]: both operands fetched with transpose reads
+__device__ __forceinline__ void mm_tr_tr(const char* a_tr, const char* b_tr, int lane, f32x16 (&d)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[i][j][e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag_tr(a_tr, i, kk, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = frag_tr(b_tr, j, kk, lane);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -435,21 +459,20 @@ __global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
   const int b = (int)(bh / p.H), h = (int)(bh - (long long)b * p.H);
   const int q0 = p.cu_q[b], k0 = p.cu_k[b];
   const int Lq = min(p.cu_q[b + 1] - q0, kL), Lk = min(p.cu_k[b + 1] - k0, kL);
-  char* base = smem + wid * 49152;
-  char* do_tr = base;            // dO[q][d]  tr image (rows = q)
-  char* k_tr = base + 8192;      // K[key][d] tr image (rows = key)
-  char* q_tr = base + 16384;     // Q[q][d]   tr image (rows = q)
-  char* pmT = base + 24576;      // PM^T[key][q] kc image (q contiguous)
-  char* ds = base + 32768;       // dS[q][key]   kc image (key contiguous)
-  char* dsT = base + 40960;      // dS^T[key][q] kc image (q contiguous)
+  // One transpose-read image is re-staged between the three gradient products (dO, then K, then
+  // Q), and P.M / dS are stored once, [q][key], and consumed by transpose reads (dV, dK) or
+  // row reads (dQ): 24 KB of LDS per wave instead of 48 KB, i.e. 6 waves per CU instead of 2 —
+  // the kernel is a latency chain per (batch, head), so resident waves are what hides it.
+  char* base = smem + wid * kBwdLdsPerWave;
+  char* tr_img = base;           // dO[q][d] / K[key][d] / Q[q][d] tr image (rows = reduction index)
+  char* pm = base + 8192;        // PM[q][key] tr image (rows = q)
+  char* ds = base + 16384;       // dS[q][key] tr image (rows = q); also read row-wise for dQ
   const bf16_t* qb = p.q + (long long)q0 * p.ldq + h * kDh;
   const bf16_t* kb = p.k + (long long)k0 * p.ldk + h * kDh;
   const bf16_t* vb = p.v + (long long)k0 * p.ldv + h * kDh;
   const bf16_t* dob = p.d_o + (long long)q0 * p.lddo + h * kDh;
 
-  stage_tr(do_tr, dob, p.lddo, Lq, lane);
-  stage_tr(k_tr, kb, p.ldk, Lk, lane);
-  stage_tr(q_tr, qb, p.ldq, Lq, lane);
+  stage_tr(tr_img, dob, p.lddo, Lq, lane);
 
   f32x16 s[2][2];
   scores(p, qb, kb, Lq, Lk, lane, s);
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
     const int q = j * 32 + l31;
     const float lse = (q < Lq) ? p.lse[(long long)(q0 + q) * p.H + h] : 0.f;
     float delta = 0.f;
-    // P, M, and delta = sum_key P*M*dPM
+    // P, M, and delta = sum_key P*M*dPM; PM[q][key] goes to LDS (4 consecutive keys per store)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -488,6 +511,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
         const int key0 = i * 32 + 8 * g + 4 * lhi;
         uint32_t keep = 0xfu;
         if (p.keep_prob < 1.f) keep = attn_keep4(p, bh, q, key0);
+        float pmv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e, key = key0 + e;
@@ -498,9 +522,12 @@ __global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
           s[i][j][r] = pv;                 // P
           dp[i][j][r] *= mk;               // dP = dPM * M
           delta += pv * dp[i][j][r];
-          // PM^T[key][q] for dV
-          *reinterpret_cast<bf16_t*>(pmT + kc_off(key, q)) = f2bf(pv * mk);
+          pmv[e] = pv * mk;
         }
+        u32x2 pk;
+        pk[0] = pack2bf(pmv[0], pmv[1]);
+        pk[1] = pack2bf(pmv[2], pmv[3]);
+        *reinterpret_cast<u32x2*>(pm + tr_off(q, key0)) = pk;
       }
     delta += xhalf(delta);
 #pragma unroll
@@ -513,24 +540,48 @@ __global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           w[e] = s[i][j][r] * (dp[i][j][r] - delta);   // dS (w.r.t. the scaled logits)
-          *reinterpret_cast<bf16_t*>(dsT + kc_off(key0 + e, q)) = f2bf(w[e]);
         }
         u32x2 pk;
         pk[0] = pack2bf(w[0], w[1]);
         pk[1] = pack2bf(w[2], w[3]);
-        *reinterpret_cast<u32x2*>(ds + kc_off(q, key0)) = pk;
+        *reinterpret_cast<u32x2*>(ds + tr_off(q, key0)) = pk;
       }
   }
   __syncthreads();
   f32x16 d[2][2];
-  // dV^T[d][key] = sum_q dO^T[d][q] PM[q][key]   (B operand: lane n=key, k=q from PM^T[key][q])
-  mm_tr_kc(do_tr, pmT, lane, d);
+  // dV^T[d][key] = sum_q dO[q][d] PM[q][key]: both operands by transpose reads (rows = q)
+  mm_tr_tr(tr_img, pm, lane, d);
+  __syncthreads();                      // every fragment of the dO image has been read
+  stage_tr(tr_img, kb, p.ldk, Lk, lane);
   if (live) store_dT(d, p.dv + (long long)k0 * p.lddv + h * kDh, p.lddv, Lk, 1.f, lane);
-  // dQ^T[d][q] = scale * sum_key K^T[d][key] dS^T[key][q] (B: lane n=q, k=key from dS[q][key])
-  mm_tr_kc(k_tr, ds, lane, d);
+  __syncthreads();
+  // dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]: B operand = 8 consecutive keys of row q
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) d[i][j][e] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2], bq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = frag_tr(tr_img, i, kk, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      bq[j] = *reinterpret_cast<const bf16x8*>(ds + tr_off(j * 32 + l31, kk * 16 + lhi * 8));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], d[i][j], 0, 0, 0);
+  }
+  __syncthreads();
+  stage_tr(tr_img, qb, p.ldq, Lq, lane);
   if (live) store_dT(d, p.dq + (long long)q0 * p.lddq + h * kDh, p.lddq, Lq, p.scale, lane);
-  // dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]   (B: lane n=key, k=q from dS^T[key][q])
-  mm_tr_kc(q_tr, dsT, lane, d);
+  __syncthreads();
+  // dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key]: both operands by transpose reads (rows = q)
+  mm_tr_tr(tr_img, ds, lane, d);
   if (live) store_dT(d, p.dk + (long long)k0 * p.lddk + h * kDh, p.lddk, Lk, p.scale, lane);
 }
 
@@ -602,7 +653,7 @@ extern "C" int os2s_attention_bwd(os2s_stream_t stream, const uint16_t* q, const
   a.keep_prob = keep_prob; a.seed = seed; a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
   a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   static bool attr = false;
-  const size_t smem = (size_t)kBwdWaves * 49152;
+  const size_t smem = (size_t)kBwdWaves * kBwdLdsPerWave;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess) return OS2S_ERR_LAUNCH;
