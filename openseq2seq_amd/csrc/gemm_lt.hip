@@ -65,17 +65,50 @@ extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_
     if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return OS2S_ERR_LAUNCH;
     uint64_t ws = kWsBytes;
     hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
-    hipblasLtMatmulHeuristicResult_t res[1];
+    constexpr int kCand = 32;
+    hipblasLtMatmulHeuristicResult_t res[kCand];
     int found = 0;
     const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, pl.desc, pl.la, pl.lb, pl.lc, pl.lc,
-                                                               pref, 1, res, &found);
+                                                               pref, kCand, res, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
       os2s_record_hip_error((int)st, "hipblasLtMatmulAlgoGetHeuristic");
       return OS2S_ERR_UNSUPPORTED;
     }
-    pl.algo = res[0].algo;
-    pl.ws = res[0].workspaceSize;
+    // The heuristic's first choice is often not the fastest for tall reductions into small
+    // outputs (weight gradients: 128x128 tiles on a 1024x1024 output use 64 of 256 CUs): time the
+    // candidates once per problem into a scratch D and keep the best (lazily built plan cache).
+    int best = 0;
+    if (found > 1) {
+      void* scratch = nullptr;
+      const size_t dbytes = (size_t)M * (size_t)ldc * (c_f32 ? 4 : 2);
+      hipEvent_t e0, e1;
+      if (hipMalloc(&scratch, dbytes) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+          hipEventCreate(&e1) == hipSuccess) {
+        const float one = 1.f, zero = 0.f;
+        float best_ms = 1e30f;
+        for (int c = 0; c < found; ++c) {
+          if (res[c].state != HIPBLAS_STATUS_SUCCESS || res[c].workspaceSize > kWsBytes) continue;
+          auto run = [&]() {
+            return hipblasLtMatmul(g_handle, pl.desc, &one, B, pl.la, A, pl.lb, &zero, scratch, pl.lc, scratch,
+                                   pl.lc, &res[c].algo, g_ws, res[c].workspaceSize, (hipStream_t)stream);
+          };
+          if (run() != HIPBLAS_STATUS_SUCCESS) continue;      // warm-up
+          hipEventRecord(e0, (hipStream_t)stream);
+          run(); run();
+          hipEventRecord(e1, (hipStream_t)stream);
+          hipEventSynchronize(e1);
+          float ms = 0.f;
+          hipEventElapsedTime(&ms, e0, e1);
+          if (ms > 0.f && ms < best_ms) { best_ms = ms; best = c; }
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+      }
+      if (scratch) hipFree(scratch);
+    }
+    pl.algo = res[best].algo;
+    pl.ws = res[best].workspaceSize;
     pl.ok = true;
   }
   const float alpha = 1.f;
