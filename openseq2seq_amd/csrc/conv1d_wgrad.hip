@@ -178,10 +178,12 @@ __global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_ke
     if (step + 1 < nsteps) stage(step + 1, (step + 1) & 1);
     const char* const ys = ybuf0 + (step & 1) * ybuf_bytes + ysub * (BT * 256);
     const char* const xs = xbuf0 + (step & 1) * xbuf_bytes;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      // A fragments (dY^T): rows = time kk*16 + lhi*8 + {0..7}, cols = co
-      bf16x8 af[2];
+    // Software pipeline inside the wave: the transpose reads of k-slice kk+1 are issued before
+    // the MFMAs of slice kk (the compiler otherwise waits for each group of reads right before
+    // the MFMAs that consume it, leaving the matrix pipe idle for an LDS round trip per group).
+    struct Frags { bf16x8 af[2]; bf16x8 bfr[TAPS][2]; };
+    auto load_frags = [&](int kk) {
+      Frags f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int u = ((wmi * 64 + i * 32) >> 4) + g16;  // logical 32-B unit (16 channels)
@@ -189,28 +191,34 @@ __global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_ke
         const int r1 = r0 + 4;
         const bf16x4 lo = lds_tr(ys + r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub);
         const bf16x4 hi = lds_tr(ys + r1 * 256 + ((u ^ ((r1 & 3) << 1)) << 5) + csub);
-        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        f.af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
-      for (int a = 0; a < TAPS; ++a) {
-        if (a < ntaps) {
-          bf16x8 bfr[2];
+      for (int a = 0; a < TAPS; ++a)   // a tap past K (last group of an odd K) reads valid LDS rows; its tile is not stored
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int u = ((wn * 64 + j * 32) >> 4) + g16;
-            const int r0 = (kk * 16 + lhi * 8 + rsub) * p.stride + a * p.dil;
-            const int r1 = r0 + 4 * p.stride;
-            const bf16x4 lo = lds_tr(xs + r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub);
-            const bf16x4 hi = lds_tr(xs + r1 * 256 + ((u ^ ((r1 & 3) << 1)) << 5) + csub);
-            bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[a][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[a][i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          const int u = ((wn * 64 + j * 32) >> 4) + g16;
+          const int r0 = (kk * 16 + lhi * 8 + rsub) * p.stride + a * p.dil;
+          const int r1 = r0 + 4 * p.stride;
+          const bf16x4 lo = lds_tr(xs + r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub);
+          const bf16x4 hi = lds_tr(xs + r1 * 256 + ((u ^ ((r1 & 3) << 1)) << 5) + csub);
+          f.bfr[a][j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-      }
+      return f;
+    };
+    Frags cur = load_frags(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      Frags nxt;
+      if (kk < 3) nxt = load_frags(kk + 1);
+#pragma unroll
+      for (int a = 0; a < TAPS; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[a][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.af[i], cur.bfr[a][j], acc[a][i][j], 0, 0, 0);
+      if (kk < 3) cur = nxt;
     }
   }
 
