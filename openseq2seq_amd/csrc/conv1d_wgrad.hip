@@ -288,8 +288,8 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   // the 256-register budget of 2 waves/SIMD.
   // (measured: the 3-tap instantiation needs 256 VGPRs + 84 B/lane of scratch and is 20-25 %
   // SLOWER than 2 taps on every Jasper layer — kept selectable for future register work.)
-  int TAPS = 2;
-  if (const char* f = getenv("OS2S_WGRAD_TAPS")) { const int v = atoi(f); if (v == 2 || v == 3) TAPS = v; }
+  int TAPS = K == 1 ? 1 : 2;      // 1x1 convs: one accumulator set, no idle tap slot
+  if (const char* f = getenv("OS2S_WGRAD_TAPS")) { const int v = atoi(f); if ((v == 2 || v == 3) && K > 1) TAPS = v; }
   // the 256-wide tile pays off once there are enough 256-channel tiles to fill the chip
   const bool wide = (Cout % 256 == 0) && (K >= 8) && (Cout >= 512);
   const int COT = wide ? 256 : 128;
@@ -327,6 +327,10 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<2, 256>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<1, 128>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<1, 256>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<3, 128>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<3, 256>,
@@ -339,11 +343,15 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   if (wide) {
     if (TAPS == 3)
       OS2S_LAUNCH((conv1d_wgrad_kernel<3, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+    else if (TAPS == 1)
+      OS2S_LAUNCH((conv1d_wgrad_kernel<1, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
     else
       OS2S_LAUNCH((conv1d_wgrad_kernel<2, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
   } else {
     if (TAPS == 3)
       OS2S_LAUNCH((conv1d_wgrad_kernel<3, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+    else if (TAPS == 1)
+      OS2S_LAUNCH((conv1d_wgrad_kernel<1, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
     else
       OS2S_LAUNCH((conv1d_wgrad_kernel<2, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
   }
