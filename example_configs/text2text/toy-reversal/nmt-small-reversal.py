@@ -104,3 +104,39 @@ eval_params = {
     "special_tokens_already_in_vocab": False,
   },
 }
+
+# inference as in en-de-nmt-small.py: the same variables under the beam-search decoder
+from open_seq2seq.decoders import BeamSearchRNNDecoderWithAttention
+
+infer_params = {
+  "batch_size_per_gpu": 8,
+  "decoder": BeamSearchRNNDecoderWithAttention,
+  "decoder_params": {
+    "beam_width": 10,
+    "length_penalty": 1.0,
+    "core_cell": tf.nn.rnn_cell.LSTMCell,
+    "core_cell_params": {"num_units": 512, "forget_bias": 1.0},
+    "decoder_layers": 2,
+    "decoder_dp_input_keep_prob": 0.8,
+    "decoder_dp_output_keep_prob": 1.0,
+    "decoder_use_skip_connections": False,
+    "GO_SYMBOL": SpecialTextTokens.S_ID.value,
+    "END_SYMBOL": SpecialTextTokens.EOS_ID.value,
+    "PAD_SYMBOL": SpecialTextTokens.PAD_ID.value,
+    "tgt_emb_size": 512,
+    "attention_type": "gnmt_v2",
+    "attention_layer_size": 512,
+  },
+  "data_layer": ParallelTextDataLayer,
+  "data_layer_params": {
+    "src_vocab_file": data_root + "vocab/source.txt",
+    "tgt_vocab_file": data_root + "vocab/target.txt",
+    "source_file": data_root + "test/source.txt",
+    "target_file": data_root + "test/source.txt",   # unused by infer
+    "delimiter": " ",
+    "shuffle": False,
+    "repeat": False,
+    "max_length": 256,
+    "special_tokens_already_in_vocab": False,
+  },
+}

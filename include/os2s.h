@@ -427,6 +427,18 @@ int os2s_beam_finalize(os2s_stream_t stream, int B, int beam, int max_decode_len
                        const int32_t* status, const int32_t* alive_seq, const int32_t* fin_seq,
                        const float* alive_lp, const float* fin_scores, const int32_t* fin_flags,
                        int32_t* out_seq, float* out_scores);
+/* One step of tf.contrib.seq2seq.BeamSearchDecoder (_beam_search_step) as driven by
+ * BeamSearchRNNDecoderWithAttention (decoders/rnn_decoders.py:324-532): logits [B*beam, V] ->
+ * top `beam` continuations per batch item by (log-prob total) / ((5 + length) / 6)^weight, finished
+ * beams continue with END at no cost, at time 0 only beam 0 competes. State arrays [B*beam]
+ * (log_probs: init {0, -inf, ...}; finished, lengths: init 0) are updated in place; word_ids,
+ * parent (flat parent ROW) and scores receive the step outputs (gather decoder state with
+ * os2s_gather_rows; trace the final sequences back through parent). V <= 65536, beam <= 64. */
+long long os2s_tf_beam_workspace_bytes(int B, int beam);
+int os2s_tf_beam_step(os2s_stream_t stream, const void* logits, int logits_f32, long long ld, int B,
+                      int beam, int V, int eos_id, int time, float length_penalty_weight,
+                      float* log_probs, int32_t* finished, int32_t* lengths, int32_t* word_ids,
+                      int32_t* parent, float* scores, void* workspace);
 /* dst[r] = src[idx[r]] for rows of row_bytes (multiple of 4) — _gather_beams (:505-537) with
  * flat row indices. If enable != NULL and enable[0] == 0 the rows are copied unpermuted
  * (pass the beam status so that a finished search stops permuting its caches). */

@@ -731,6 +731,34 @@ class BeamState(object):
     return out_seq, out_scores
 
 
+class TfBeamState(object):
+  """State of tf.contrib.seq2seq.BeamSearchDecoder on the device (os2s_tf_beam_step)."""
+
+  def __init__(self, B, beam, vocab_size, eos_id, length_penalty_weight, device):
+    self.B, self.beam, self.V, self.eos, self.lpw = int(B), int(beam), int(vocab_size), int(eos_id), float(length_penalty_weight)
+    N = self.B * self.beam
+    lp = torch.full((self.B, self.beam), float("-inf"), dtype=torch.float32)
+    lp[:, 0] = 0.0
+    self.log_probs = lp.reshape(-1).to(device)
+    self.finished = torch.zeros(N, dtype=torch.int32, device=device)
+    self.lengths = torch.zeros(N, dtype=torch.int32, device=device)
+    self.word_ids = torch.zeros(N, dtype=torch.int32, device=device)
+    self.parent = torch.zeros(N, dtype=torch.int32, device=device)
+    self.scores = torch.zeros(N, dtype=torch.float32, device=device)
+    wsb = _fn("os2s_tf_beam_workspace_bytes", (c_int, c_int), c_ll)
+    self.ws = torch.empty(int(wsb(self.B, self.beam)), dtype=torch.uint8, device=device)
+
+  def step(self, logits, time):
+    N = self.B * self.beam
+    assert logits.shape[0] == N and logits.stride(1) == 1 and logits.shape[1] >= self.V
+    f = _fn("os2s_tf_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_float)
+            + (c_void_p,) * 7)
+    _lib.check(f(_stream(), c_void_p(logits.data_ptr()), int(logits.dtype == torch.float32), logits.stride(0),
+                 self.B, self.beam, self.V, self.eos, int(time), self.lpw, _ptr(self.log_probs),
+                 _ptr(self.finished), _ptr(self.lengths), _ptr(self.word_ids), _ptr(self.parent),
+                 _ptr(self.scores), _ptr(self.ws)), "os2s_tf_beam_step")
+
+
 def gather_rows(src, idx, enable=None, out=None):
   """out[r] = src[idx[r]] along dim 0 (rows of >= 4 bytes, multiple of 4)."""
   assert src.is_contiguous() and idx.dtype == torch.int32

@@ -193,12 +193,32 @@ template <typename T> struct RowVec;
 template <> struct RowVec<bf16_t> { static constexpr int W = 8; };
 template <> struct RowVec<float> { static constexpr int W = 4; };
 
+// tf.contrib.seq2seq.BeamSearchDecoder scoring of a row (RNN decoders): finished beams put all
+// mass on END, candidates are ranked by total log-prob / ((5 + length) / 6)^weight, at time 0
+// only beam 0 competes. finished == nullptr selects the Transformer scoring (alive log-prob +
+// log-softmax).
+struct TfRowMode {
+  const int32_t* finished;
+  const int32_t* lengths;
+  float lpw;
+  int eos, time;
+  float* lse_out;
+};
+
+__device__ __forceinline__ float tf_length_penalty(int len, float w) {
+  return w == 0.f ? 1.f : powf((5.f + (float)len) / 6.f, w);
+}
+
 template <typename T, int PER>
 __global__ __launch_bounds__(1024) void beam_row_topk_kernel(
     const T* __restrict__ logits, long long ld, int V, int beam, int k,
     const float* __restrict__ alive_lp, const int32_t* __restrict__ status,
-    unsigned long long* __restrict__ cand) {
+    unsigned long long* __restrict__ cand, TfRowMode tf) {
   if (!status[0]) return;
+  if (tf.finished && tf.time == 0 && (blockIdx.x % beam) != 0) {     // identical start beams
+    if ((int)threadIdx.x < k) cand[(long long)blockIdx.x * k + threadIdx.x] = 0ull;
+    return;
+  }
   constexpr int W = RowVec<T>::W;
   __shared__ float red[16];
   __shared__ unsigned long long wk[16 * kMaxKeep];       // per-wave top-k of the thread maxima
@@ -255,6 +275,16 @@ __global__ __launch_bounds__(1024) void beam_row_topk_kernel(
   const float lse = logf(sum) + ms;
   const float a = alive_lp[n];
   const uint32_t fbase = (uint32_t)((n % beam) * V);
+  const bool tf_mode = tf.finished != nullptr;
+  bool row_fin = false;
+  float lp_other = 1.f, lp_eos = 1.f;
+  if (tf_mode) {
+    row_fin = tf.finished[n] != 0;
+    const int len = tf.lengths[n];
+    lp_eos = tf_length_penalty(len, tf.lpw);                     // END adds no length
+    lp_other = tf_length_penalty(len + (row_fin ? 0 : 1), tf.lpw);
+    if (tid == 0 && tf.lse_out) tf.lse_out[n] = lse;
+  }
   // ---- candidate keys; threshold = k-th largest of the 1024 per-thread maxima ---------------------------
   // Every row-level top-k element is >= that threshold, and at most (k-1)*PER + 1 elements are
   // (only the k-1 threads whose maximum beats it can hold more than one), so they fit a small
@@ -264,10 +294,16 @@ __global__ __launch_bounds__(1024) void beam_row_topk_kernel(
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     const int v = col_of(e);
-    uint32_t u = __float_as_uint((val[e] - lse) + a);     // _log_prob_from_logits + alive log-prob
+    float cand_v = (val[e] - lse) + a;                    // _log_prob_from_logits + alive log-prob
+    bool valid = v < V;
+    if (tf_mode) {
+      if (row_fin) { valid = valid && v == tf.eos; cand_v = __fdiv_rn(a, lp_eos); }
+      else cand_v = __fdiv_rn(cand_v, v == tf.eos ? lp_eos : lp_other);
+    }
+    uint32_t u = __float_as_uint(cand_v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    ordv[e] = v < V ? u : 0u;
-    const unsigned long long kk = v < V ? (((unsigned long long)u << 32) | (unsigned long long)(~(fbase + (uint32_t)v))) : 0ull;
+    ordv[e] = valid ? u : 0u;
+    const unsigned long long kk = valid ? (((unsigned long long)u << 32) | (unsigned long long)(~(fbase + (uint32_t)v))) : 0ull;
     tbest = kk > tbest ? kk : tbest;
   }
   {
@@ -547,7 +583,7 @@ extern "C" int os2s_beam_step(os2s_stream_t stream, const void* logits, int logi
     ncand = beam * k;
 #define OS2S_ROW_TOPK(T, PER)                                                                       \
   OS2S_LAUNCH((beam_row_topk_kernel<T, PER>), dim3(N), dim3(1024), 0, s, (const T*)logits, ld, V, \
-              beam, k, alive_lp, status, cand)
+              beam, k, alive_lp, status, cand, TfRowMode{nullptr, nullptr, 0.f, 0, 0, nullptr})
     if (logits_f32) {
       if (V <= 8192) OS2S_ROW_TOPK(float, 8);
       else if (V <= 32768) OS2S_ROW_TOPK(float, 32);
@@ -579,6 +615,101 @@ extern "C" int os2s_beam_step(os2s_stream_t stream, const void* logits, int logi
   const size_t smem = (size_t)((a.ncand + 63) / 64) * 64 * 8;
   OS2S_REQUIRE(smem <= 48 * 1024);
   OS2S_LAUNCH(beam_select_kernel, dim3(B), dim3(kSelThreads), smem, s, a);
+  return OS2S_OK;
+}
+
+namespace os2s {
+
+// Merge the per-row winners of one batch item and advance the BeamSearchDecoder state.
+struct TfSelectArgs {
+  const unsigned long long* cand;   // [B*beam, k]
+  const void* logits; int logits_f32; long long ld;
+  const float* lse;                 // [N]
+  int B, beam, V, eos;
+  float* log_probs; int32_t* finished; int32_t* lengths;     // [N] in/out
+  int32_t* word_ids; int32_t* parent; float* scores;         // [N] out
+};
+
+__global__ __launch_bounds__(64) void tf_beam_select_kernel(TfSelectArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long pool[];
+  __shared__ unsigned long long win[kMaxKeep];
+  __shared__ float old_lp[kMaxKeep];
+  __shared__ int old_fin[kMaxKeep], old_len[kMaxKeep];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int beam = p.beam, k = beam, ncand = beam * k;
+  const int per = (ncand + 63) >> 6;
+  for (int e = 0; e < per; ++e)
+    pool[e * 64 + lane] = e * 64 + lane < ncand ? p.cand[(long long)b * ncand + e * 64 + lane] : 0ull;
+  if (lane < beam) {
+    old_lp[lane] = p.log_probs[b * beam + lane];
+    old_fin[lane] = p.finished[b * beam + lane];
+    old_len[lane] = p.lengths[b * beam + lane];
+  }
+  wave_topk_lds(pool, per, k, win);
+  __syncthreads();
+  if (lane < beam) {
+    const uint32_t flat = key_index(win[lane]);
+    const int pb = (int)(flat / (uint32_t)p.V), v = (int)(flat % (uint32_t)p.V);
+    const int prow = b * beam + pb;
+    const bool pf = old_fin[pb] != 0;
+    float total = old_lp[pb];
+    if (!pf) {
+      const float x = p.logits_f32 ? reinterpret_cast<const float*>(p.logits)[(long long)prow * p.ld + v]
+                                   : bf2f(reinterpret_cast<const bf16_t*>(p.logits)[(long long)prow * p.ld + v]);
+      total += x - p.lse[prow];
+    }
+    const int n = b * beam + lane;
+    p.log_probs[n] = total;
+    p.finished[n] = pf || v == p.eos;
+    p.lengths[n] = old_len[pb] + (pf ? 0 : 1);
+    p.word_ids[n] = v;
+    p.parent[n] = prow;
+    p.scores[n] = key_value(win[lane]);
+  }
+}
+
+}  // namespace os2s
+
+extern "C" long long os2s_tf_beam_workspace_bytes(int B, int beam) {
+  const long long N = (long long)B * beam;
+  return N * beam * 8 + ((N * 4 + 7) / 8) * 8 + 16;
+}
+
+extern "C" int os2s_tf_beam_step(os2s_stream_t stream, const void* logits, int logits_f32, long long ld,
+                                 int B, int beam, int V, int eos_id, int time,
+                                 float length_penalty_weight, float* log_probs, int32_t* finished,
+                                 int32_t* lengths, int32_t* word_ids, int32_t* parent, float* scores,
+                                 void* workspace) {
+  OS2S_REQUIRE(B >= 1 && beam >= 1 && beam <= kMaxKeep && V >= beam && V <= 65536 && ld >= V && time >= 0);
+  OS2S_REQUIRE(logits && log_probs && finished && lengths && word_ids && parent && scores && workspace);
+  OS2S_REQUIRE((long long)beam * V < (1LL << 31));
+  const int N = B * beam, k = beam;
+  unsigned long long* cand = (unsigned long long*)workspace;
+  float* lse = (float*)((char*)workspace + (long long)N * k * 8);
+  int32_t* one = (int32_t*)((char*)lse + (((long long)N * 4 + 7) / 8) * 8);     // "running" flag = 1
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(one, 1, 16, s) != hipSuccess) return OS2S_ERR_LAUNCH;     // non-zero = running
+  const TfRowMode tf = {finished, lengths, length_penalty_weight, eos_id, time, lse};
+#define OS2S_ROW_TOPK_TF(T, PER)                                                                   \
+  OS2S_LAUNCH((beam_row_topk_kernel<T, PER>), dim3(N), dim3(1024), 0, s, (const T*)logits, ld, V, \
+              beam, k, log_probs, one, cand, tf)
+  if (logits_f32) {
+    if (V <= 8192) OS2S_ROW_TOPK_TF(float, 8);
+    else if (V <= 32768) OS2S_ROW_TOPK_TF(float, 32);
+    else OS2S_ROW_TOPK_TF(float, 64);
+  } else {
+    if (V <= 8192) OS2S_ROW_TOPK_TF(bf16_t, 8);
+    else if (V <= 32768) OS2S_ROW_TOPK_TF(bf16_t, 32);
+    else OS2S_ROW_TOPK_TF(bf16_t, 64);
+  }
+#undef OS2S_ROW_TOPK_TF
+  TfSelectArgs a;
+  a.cand = cand; a.logits = logits; a.logits_f32 = logits_f32; a.ld = ld; a.lse = lse;
+  a.B = B; a.beam = beam; a.V = V; a.eos = eos_id;
+  a.log_probs = log_probs; a.finished = finished; a.lengths = lengths;
+  a.word_ids = word_ids; a.parent = parent; a.scores = scores;
+  const size_t smem = (size_t)((beam * k + 63) / 64) * 64 * 8;
+  OS2S_LAUNCH(tf_beam_select_kernel, dim3(B), dim3(64), smem, s, a);
   return OS2S_OK;
 }
 

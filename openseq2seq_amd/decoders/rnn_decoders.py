@@ -340,6 +340,114 @@ class RNNDecoderWithAttention(Decoder):
             'final_sequence_lengths': lengths, 'vocab_size': V}
 
 
+class BeamSearchRNNDecoderWithAttention(RNNDecoderWithAttention):
+  """open_seq2seq/decoders/rnn_decoders.py:324-532: the same variables as RNNDecoderWithAttention,
+  decoded with tf.contrib.seq2seq.BeamSearchDecoder (beam_width, length_penalty =
+  length_penalty_weight) for at most 2 x max source length steps; outputs =
+  predicted_ids[:, :, 0]. The per-step scoring / top-k / state update runs on the device
+  (os2s_tf_beam_step); decoder state rows are re-gathered by parent beam every step."""
+
+  @staticmethod
+  def get_optional_params():
+    return dict(RNNDecoderWithAttention.get_optional_params(), **{
+        'length_penalty': float, 'beam_width': int,
+    })
+
+  def __init__(self, params, model, name='rnn_decoder_with_attention', mode='train'):
+    super(BeamSearchRNNDecoderWithAttention, self).__init__(params, model, name, mode)
+    if self._mode != 'infer':
+      raise ValueError("BeamSearch decoder only supports infer mode, but got {}".format(self._mode))
+    self._length_penalty_weight = self.params.get('length_penalty', 0.0)
+    self._beam_width = self.params.get('beam_width', 1)
+
+  def _decode(self, input_dict):
+    enc = input_dict['encoder_output']
+    enc_act = enc.get('outputs_act') or Act(enc['outputs'], enc['src_lengths'], requires_grad=False)
+    return self._beam_search(enc_act, enc['src_lengths'])
+
+  @staticmethod
+  def _reorder(view, parent):
+    tmp = view.contiguous()
+    view.copy_(capi.gather_rows(tmp, parent))
+
+  def _beam_search(self, enc_act, src_len):
+    import numpy as np
+    B, S, M = enc_act.data.shape
+    W = self._beam_width
+    N = B * W
+    dev = enc_act.data.device
+    T = 2 * int(src_len.max().item())
+    H, GH, Vp, V = self.H, 4 * self.H, self.Vpad, self._tgt_vocab_size
+    # tile_batch: every sentence repeated beam_width times
+    tile = (torch.arange(N, dtype=torch.int32, device=dev) // W).to(torch.int32)
+    mem = Act(capi.gather_rows(enc_act.data.contiguous(), tile), None)
+    slen = capi.gather_rows(src_len.to(torch.int32).view(B, 1).contiguous(), tile).view(N)
+    seeds = SeedSeq(31)
+    cell = self.cell
+    loop = cell._new_loop(N, T, S, dev, False, 1.0, 1.0, seeds)
+    keys = cell.memory(mem, None)
+    gx0 = torch.zeros((N, T, GH), dtype=torch.bfloat16, device=dev)
+    loop.set_inputs(gx0, keys, mem.data, slen, None)
+    st = capi.TfBeamState(B, W, V, self.END_SYMBOL, self._length_penalty_weight, dev)
+    ids = torch.full((N,), self.GO_SYMBOL, dtype=torch.int32, device=dev)
+    hist_ids, hist_par = [], []
+    for t in range(T):
+      e = capi.embed_fwd(ids, None, self.embedding.table.w16, 1.0, 1.0, 0, plain=True)
+      gx0[:, t] = capi.gemm(e, cell.w_in.w16.view(GH, -1), bias=cell.bias[0].master)
+      loop.forward(t, t + 1)
+      if self.gnmt:
+        top = Act(loop.y_top[:, :t + 1].contiguous())
+        att = loop.ctx[:, :t + 1]
+        if self.params['attention_type'] == 'gnmt':
+          att = torch.cat([torch.zeros_like(att[:, :1]), att[:, :-1]], 1)
+        att = Act(att.contiguous())
+        for layer in self.upper:
+          top = rnn_directions_forward([layer], [top, att], None, None)[0]
+        feat = top.data[:, t].contiguous()
+      else:
+        feat = loop.ctx[:, t].contiguous()
+      lg = capi.gemm(feat, self.proj.w16.view(Vp, self.out_in))
+      st.step(lg, t)
+      hist_ids.append(st.word_ids.clone())
+      hist_par.append(st.parent.clone())
+      ids = st.word_ids.clone()
+      # the next step reads these state rows: they follow their beams
+      for l in range(cell.L):
+        self._reorder(loop.cat[l][:, t + 1], st.parent)
+        self._reorder(loop.c_seq[l][:, t], st.parent)
+      if loop.cum_seq is not None:
+        self._reorder(loop.cum_seq[:, t + 1], st.parent)
+      if self.gnmt:      # the upper layers re-run over the prefix: it is part of the beam state
+        self._reorder(loop.y_top[:, :t + 1], st.parent)
+        self._reorder(loop.ctx[:, :t + 1], st.parent)
+      if bool(st.finished.all()):
+        break
+    steps = len(hist_ids)
+    step_ids = torch.stack(hist_ids).view(steps, B, W).cpu().numpy()
+    parents = (torch.stack(hist_par).view(steps, B, W).cpu().numpy() % W)
+    lengths = st.lengths.view(B, W).cpu().numpy()
+    pred = np.full((steps, B, W), self.END_SYMBOL, np.int32)     # gather_tree (finalize)
+    for b in range(B):
+      L = min(int(lengths[b].max()), steps)
+      for w in range(W):
+        parent = w
+        for t in range(L - 1, -1, -1):
+          pred[t, b, w] = step_ids[t, b, parent]
+          parent = parents[t, b, parent]
+        seen = False
+        for t in range(L):
+          if seen:
+            pred[t, b, w] = self.END_SYMBOL
+          elif pred[t, b, w] == self.END_SYMBOL:
+            seen = True
+    predicted_ids = torch.from_numpy(np.ascontiguousarray(np.transpose(pred, (1, 0, 2)))).to(dev)
+    top = predicted_ids[:, :, 0].contiguous()
+    return {'logits': top, 'outputs': [top], 'predicted_ids': predicted_ids,
+            'scores': st.scores.view(B, W), 'final_state': None,
+            'final_sequence_lengths': torch.from_numpy(lengths[:, 0].astype(np.int32)).to(dev),
+            'beam_sequence_lengths': lengths, 'vocab_size': V}
+
+
 def _shift_time(x, tape):
   """y[:, t] = x[:, t-1] (zeros at t = 0): the attention of the previous step."""
   y = torch.zeros_like(x.data)

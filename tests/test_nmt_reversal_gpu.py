@@ -28,6 +28,17 @@ def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch):
   res = run.run_eval(model, model.eval_model, 0)
   assert res["samples"] == 256
   assert res["bleu"] > 0.9, res
+  # infer mode of the same config = BeamSearchRNNDecoderWithAttention (beam 10, GNMT length
+  # penalty) restored from the checkpoint the training loop wrote; output file vs reversed sources
+  args, base_config, base_model, config_module = get_base_config(
+      ["--config_file=" + cfg, "--mode=infer", "--infer_output_file=out.txt"])
+  imodel = create_model(args, base_config, config_module, base_model, None)
+  run.restore_latest(imodel, 0)
+  run.infer(imodel, args, 0)
+  src = [l.split() for l in open("toy_text_data/test/source.txt").read().strip().splitlines()]
+  hyp = [l.split() for l in open("out.txt").read().strip().splitlines()]
+  assert len(hyp) == len(src) == 8
+  assert sum(h == list(reversed(s_)) for h, s_ in zip(hyp, src)) >= 6, (hyp, src)
 
 
 def test_transformer_learns_reversal_with_beam_search(cuda, tmp_path, monkeypatch):
