@@ -121,7 +121,11 @@ def load_config_module(config_file):
     sys.path.insert(0, repo)
   import open_seq2seq  # noqa: F401  (installs the alias finder)
   with _tensorflow_token_module() as tf:
-    return runpy.run_path(config_file, init_globals={'tf': tf})
+    # DL_REPLACE: the bare placeholder name text2speech/tacotron_gst.py expects the user to
+    # substitute (dataset location); predefined so that the unedited config still loads and
+    # falls back to synthetic batches when the files are absent
+    return runpy.run_path(config_file, init_globals={
+        'tf': tf, 'DL_REPLACE': os.environ.get('DL_REPLACE', '[REPLACE THIS TO THE PATH WITH YOUR DATA]')})
 
 
 def get_base_config(args):

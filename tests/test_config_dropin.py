@@ -54,3 +54,28 @@ def test_unknown_param_is_rejected():
   with pytest.raises(ValueError):
     TDNNEncoder({"dropout_keep_prob": 0.5, "convnet_layers": [], "activation_fn": None,
                  "bogus": 1}, None)
+
+
+def test_baseline_configs_load_unchanged():
+  """The example configs BASELINE.json names (plus their infer / eval variants) load through the
+  reference's own runpy path and resolve to classes of this package."""
+  from openseq2seq_amd.utils.utils import get_base_config
+  import openseq2seq_amd.decoders as D
+  import openseq2seq_amd.encoders as E
+  import openseq2seq_amd.models as M
+  cases = {
+      "text2text/en-de/en-de-nmt-small.py": (M.Text2Text, E.BidirectionalRNNEncoderWithEmbedding,
+                                             D.RNNDecoderWithAttention),
+      "speech2text/ds2_large_8gpus.py": (M.Speech2Text, E.DeepSpeech2Encoder, D.FullyConnectedCTCDecoder),
+      "speech2text/quartznet15x5_LibriSpeech.py": (M.Speech2Text, E.TDNNEncoder, D.FullyConnectedCTCDecoder),
+      "text2speech/tacotron_gst.py": (M.Text2SpeechTacotron, E.Tacotron2Encoder, D.Tacotron2Decoder),
+      "text2text/en-de/transformer-base.py": (M.Text2Text, E.TransformerEncoder, D.TransformerDecoder),
+  }
+  for rel, (model, enc, dec) in cases.items():
+    for mode in ("train", "infer"):
+      _, base, model_cls, mod = get_base_config(["--config_file=" + os.path.join(REF, rel), "--mode=" + mode])
+      assert model_cls is model and base["encoder"] is enc and base["decoder"] is dec, (rel, mode)
+  _, _, _, mod = get_base_config(["--config_file=" + os.path.join(REF, "text2text/en-de/en-de-nmt-small.py"),
+                                  "--mode=infer"])
+  assert mod["infer_params"]["decoder"] is D.BeamSearchRNNDecoderWithAttention
+  assert mod["infer_params"]["decoder_params"]["beam_width"] == 10
