@@ -548,6 +548,9 @@ int os2s_rnn_layer_bwd_multi(os2s_stream_t stream, int cell, int ndir,
  *                              2: location-sensitive (:641-715, 749-878): location_s = dense_w^T
  *                                 (conv1d_SAME(cumulative alignments; conv_w [K,F], conv_b) at s),
  *                                 cumulative state += alignments after the step; bias b iff use_bias
+ *                              3: Luong (multiplicative, tf.contrib.seq2seq.LuongAttention as built by
+ *                                 decoders/rnn_decoders.py:100-111): score_s = keys_s . query with the
+ *                                 query = cell output (pass wq = identity, U == H; v is ignored)
  *                attention_t = context = sum_s align_s values_s   (attention_layer_size = None)
  * Everything outside the recurrence is the caller's (GEMM entry points): gx0 = inputs W_in^T
  * + bias for all steps, keys = values W_mem^T, layers above the attention cell, projections.

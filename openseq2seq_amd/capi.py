@@ -919,7 +919,7 @@ def conv2d_toeplitz_reduce(dwexp, Fi, Fo, sF, padF, dw):
 # --------------------------------------------------------------------------
 # attention-RNN decoder loop (NMT gnmt / Tacotron2)
 # --------------------------------------------------------------------------
-SCORE_BAHDANAU, SCORE_BAHDANAU_NORM, SCORE_LOCATION = 0, 1, 2
+SCORE_BAHDANAU, SCORE_BAHDANAU_NORM, SCORE_LOCATION, SCORE_LUONG = 0, 1, 2, 3
 c_ull = _lib.ctypes.c_ulonglong
 
 

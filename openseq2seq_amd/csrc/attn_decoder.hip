@@ -354,9 +354,14 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_fwd_kernel(AdAttn p) {
     for (int s = wave; s < slen; s += kAttnWaves) {
       float part = 0.f;
       for (int u = 2 * lane; u < U; u += 128) {
-        float x0, x1;
-        attn_pre2(p, l, b, s, u, x0, x1);
-        part += l.nv[u] * tanh_fast(x0) + l.nv[u + 1] * tanh_fast(x1);
+        if (p.mode == 3) {        // Luong: score = keys . query (query = cell output, w_q = I)
+          const uint32_t kv = l.keys[(s * U + u) >> 1];
+          part += bflo(kv) * l.q[u] + bfhi(kv) * l.q[u + 1];
+        } else {
+          float x0, x1;
+          attn_pre2(p, l, b, s, u, x0, x1);
+          part += l.nv[u] * tanh_fast(x0) + l.nv[u + 1] * tanh_fast(x1);
+        }
       }
       part = wave_sum_dpp(part);
       if (lane == 0) l.e[s] = part;
@@ -682,15 +687,23 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_bwd_kernel(AdAttn p) {
       for (int i = 0; i < UP; ++i) {
         const int u = 2 * lane + 128 * i;
         if (u < U) {
-          float x0, x1;
-          attn_pre2(p, l, b, s, u, x0, x1);
-          const float t0 = tanh_fast(x0), t1 = tanh_fast(x1);
-          const float d0 = des * l.nv[u] * (1.f - t0 * t0), d1 = des * l.nv[u + 1] * (1.f - t1 * t1);
-          dq_acc[2 * i] += d0;
-          dq_acc[2 * i + 1] += d1;
-          dnv_acc[2 * i] += des * t0;
-          dnv_acc[2 * i + 1] += des * t1;
-          *reinterpret_cast<uint32_t*>(p.dpre_seq + (row * S + s) * U + u) = pack2bf(d0, d1);
+          if (p.mode == 3) {      // Luong: d score / d key = query, d score / d query = key
+            const uint32_t kv = l.keys[(s * U + u) >> 1];
+            dq_acc[2 * i] += des * bflo(kv);
+            dq_acc[2 * i + 1] += des * bfhi(kv);
+            *reinterpret_cast<uint32_t*>(p.dpre_seq + (row * S + s) * U + u) =
+                pack2bf(des * l.q[u], des * l.q[u + 1]);
+          } else {
+            float x0, x1;
+            attn_pre2(p, l, b, s, u, x0, x1);
+            const float t0 = tanh_fast(x0), t1 = tanh_fast(x1);
+            const float d0 = des * l.nv[u] * (1.f - t0 * t0), d1 = des * l.nv[u + 1] * (1.f - t1 * t1);
+            dq_acc[2 * i] += d0;
+            dq_acc[2 * i + 1] += d1;
+            dnv_acc[2 * i] += des * t0;
+            dnv_acc[2 * i + 1] += des * t1;
+            *reinterpret_cast<uint32_t*>(p.dpre_seq + (row * S + s) * U + u) = pack2bf(d0, d1);
+          }
         }
       }
     }
@@ -982,7 +995,8 @@ static size_t attn_lds_bytes(const os2s_attn_decoder_t* d, bool bwd) {
 static int ad_check(const os2s_attn_decoder_t* d) {
   OS2S_REQUIRE(d && d->B >= 1 && d->T >= 1 && d->S >= 1 && (d->L == 1 || d->L == 2));
   OS2S_REQUIRE(d->H % 8 == 0 && d->M % 8 == 0 && d->U % 128 == 0 && d->U <= 512);
-  OS2S_REQUIRE(d->score_mode >= 0 && d->score_mode <= 2);
+  OS2S_REQUIRE(d->score_mode >= 0 && d->score_mode <= 3);
+  if (d->score_mode == 3) OS2S_REQUIRE(d->U == d->H);     // Luong: the query IS the cell output
   OS2S_REQUIRE(d->t_begin >= 0 && d->t_begin <= d->t_end && d->t_end <= d->T);
   OS2S_REQUIRE(d->wcat[0] && d->wq && d->v && d->keys && d->values && d->src_len && d->gx0);
   OS2S_REQUIRE(d->cat[0] && d->c_seq[0] && d->align_seq && d->q_seq && d->y_top && d->ctx);

@@ -55,9 +55,18 @@ class AttentionCell(object):
       self.bias.append(store.add(scope + "/cell_%d/bias" % l, (GH,), torch.zeros(GH), kind="vector"))
     att = scope + "/attention"
     self.w_mem = store.add(att + "/memory_layer/kernel", (1, U, M), glorot(M, U), kind="conv")
-    self.w_q = store.add(att + "/query_layer/kernel", (1, U, H), glorot(H, U), kind="conv")
-    self.v = store.add(att + "/attention_v", (U,), lambda s: (torch.rand(s) * 2 - 1) * math.sqrt(3.0 / U),
-                       kind="vector")
+    self.luong = mode == capi.SCORE_LUONG
+    if self.luong:
+      # LuongAttention has no query layer and no score vector: the query is the cell output
+      if U != H:
+        raise ValueError("luong attention: attention_layer_size must equal the cell size")
+      self.w_q = self.v = None
+      self._eye = torch.eye(U, dtype=torch.bfloat16, device=store.device)
+      self._zero_v = torch.zeros(U, dtype=torch.float32, device=store.device)
+    else:
+      self.w_q = store.add(att + "/query_layer/kernel", (1, U, H), glorot(H, U), kind="conv")
+      self.v = store.add(att + "/attention_v", (U,), lambda s: (torch.rand(s) * 2 - 1) * math.sqrt(3.0 / U),
+                         kind="vector")
     self.g = self.b = self.conv_w = self.conv_b = self.dense_w = None
     if mode == capi.SCORE_BAHDANAU_NORM:
       self.g = store.add(att + "/attention_g", (1,), torch.full((1,), math.sqrt(1.0 / U)), kind="vector")
@@ -72,7 +81,7 @@ class AttentionCell(object):
       self.dense_w = store.add(att + "/location_dense/kernel", (loc_f, U), glorot(loc_f, U), kind="vector")
 
   def params(self):
-    ps = [self.w_in, self.w_mem, self.w_q, self.v] + self.wcat + self.bias
+    ps = [self.w_in, self.w_mem] + ([] if self.luong else [self.w_q, self.v]) + self.wcat + self.bias
     return ps + [p for p in (self.g, self.b, self.conv_w, self.conv_b, self.dense_w) if p is not None]
 
   def _new_loop(self, B, T, S, dev, training, attn_in_keep, out_keep, seeds, y_top=None, ctx=None):
@@ -83,8 +92,10 @@ class AttentionCell(object):
                            attn_in_seed=seeds.next(), out_keep=out_keep,
                            out_seeds=(seeds.next(), seeds.next()), save=training, y_top=y_top, ctx=ctx)
     GH = 4 * self.H
-    dec.set_params([w.w16.view(GH, -1) for w in self.wcat], self.w_q.w16.view(self.U, self.H),
-                   self.v.master, bias=[None] + [b.master for b in self.bias[1:]], g=m(self.g),
+    dec.set_params([w.w16.view(GH, -1) for w in self.wcat],
+                   self._eye if self.luong else self.w_q.w16.view(self.U, self.H),
+                   self._zero_v if self.luong else self.v.master,
+                   bias=[None] + [b.master for b in self.bias[1:]], g=m(self.g),
                    b=m(self.b), conv_w=m(self.conv_w), conv_b=m(self.conv_b), dense_w=m(self.dense_w))
     return dec
 
@@ -115,8 +126,10 @@ class AttentionCell(object):
     cell = self
 
     def backward():
-      out = dec.backward([w.wt16.view(-1, GH) for w in cell.wcat], cell.w_q.wt16.view(H, U), dy_top=y.grad, dctx_ext=c.grad,
-                         dv=cell.v.grad, dg=cell.g.grad if cell.g is not None else None,
+      out = dec.backward([w.wt16.view(-1, GH) for w in cell.wcat],
+                         cell._eye if cell.luong else cell.w_q.wt16.view(H, U), dy_top=y.grad, dctx_ext=c.grad,
+                         dv=torch.zeros_like(cell._zero_v) if cell.luong else cell.v.grad,
+                         dg=cell.g.grad if cell.g is not None else None,
                          dconv_w=cell.conv_w.grad if cell.conv_w is not None else None,
                          dconv_b=cell.conv_b.grad if cell.conv_b is not None else None,
                          ddense_w=cell.dense_w.grad if cell.dense_w is not None else None)
@@ -133,8 +146,9 @@ class AttentionCell(object):
         capi.gemm(dg0, cell.w_in.wt16.view(-1, GH), out=g.view(B * T, -1), accumulate=x.grad_init)
         x.grad_init = True
       dq2 = out["dq_seq"].view(B * T, U)
-      capi.gemm_wgrad(dec.y_top.reshape(B * T, H) if dec.y_top.is_contiguous() else
-                      dec.y_top.contiguous().view(B * T, H), dq2, cell.w_q.grad.view(U, H), accumulate=True)
+      if not cell.luong:
+        capi.gemm_wgrad(dec.y_top.reshape(B * T, H) if dec.y_top.is_contiguous() else
+                        dec.y_top.contiguous().view(B * T, H), dq2, cell.w_q.grad.view(U, H), accumulate=True)
       if cell.b is not None:
         _colsum_into(dq2, cell.b)
       # memory layer + encoder outputs
@@ -194,8 +208,8 @@ class RNNDecoderWithAttention(Decoder):
       raise NotImplementedError("decoder_use_skip_connections (gnmt_residual_fn)")
     if p.get('decoder_dp_output_keep_prob', 1.0) != 1.0:
       raise NotImplementedError("decoder_dp_output_keep_prob != 1.0")
-    if p['attention_type'] == 'luong':
-      raise NotImplementedError("luong (multiplicative) attention; bahdanau / gnmt / gnmt_v2 are built")
+    if p['attention_type'] == 'luong' and p.get('luong_scale', False):
+      raise NotImplementedError("luong_scale=True (the learned scalar of LuongAttention)")
     if p.get('time_major', False):
       raise NotImplementedError("time_major")
 
@@ -216,6 +230,8 @@ class RNNDecoderWithAttention(Decoder):
       loop_layers = 1
     else:
       mode = capi.SCORE_BAHDANAU_NORM if p.get('bahdanau_normalize', False) else capi.SCORE_BAHDANAU
+      if at == 'luong':
+        mode = capi.SCORE_LUONG
       loop_layers = nl
       if nl > 2:
         raise NotImplementedError("more than 2 layers inside the attention loop")

@@ -120,6 +120,10 @@ def attention_decoder(p, gx0, memory, src_len, tgt_len=None, attn_in_mask=None, 
       score = (p["v"] * torch.tanh(pre)).sum(-1)
     elif mode == "bahdanau_norm":
       score = bahdanau_score(q, keys, p["v"], p["g"], p["b"])
+    elif mode == "luong":
+      # LuongAttention (attention_wrapper.py, _luong_score): score = keys . query, the query is
+      # the cell output itself (no query layer; depth must equal num_units), scale=False
+      score = (keys * x[:, None, :]).sum(-1)
     else:
       score = bahdanau_score(q, keys, p["v"])
     al = masked_softmax(score, mask)

@@ -60,3 +60,32 @@ def test_transformer_learns_reversal_with_beam_search(cuda, tmp_path, monkeypatc
   res = run.run_eval(model, model.eval_model, 0)
   assert res["samples"] == 256
   assert res["bleu"] > 0.9, res
+
+
+def test_luong_rr_config_learns_reversal(cuda, tmp_path, monkeypatch):
+  """The reference's own RNN acceptance configuration (toy-reversal/nmt-reversal-RR.py:
+  LSTM-128, Luong attention, Adam + gradient clipping): greedy BLEU after 800 steps, then beam
+  search (infer mode) from the checkpoint."""
+  sys.path.insert(0, REPO)
+  import run
+  from openseq2seq_amd.test_utils.create_reversed_examples import create_data
+  from openseq2seq_amd.utils.utils import create_model, get_base_config
+  monkeypatch.chdir(tmp_path)
+  create_data(train_corpus_size=10000, dev_corpus_size=256, test_corpus_size=8,
+              data_path="toy_text_data", seed=0)
+  cfg = os.path.join(REPO, "example_configs/text2text/toy-reversal/nmt-reversal-RR.py")
+  args, base_config, base_model, config_module = get_base_config(
+      ["--config_file=" + cfg, "--mode=train_eval", "--max_steps=800", "--print_loss_steps=200",
+       "--eval_steps=10000"])
+  model = create_model(args, base_config, config_module, base_model, None)
+  run.train(model, args)
+  res = run.run_eval(model, model.eval_model, 0)
+  assert res["samples"] == 256 and res["bleu"] > 0.9, res
+  args, base_config, base_model, config_module = get_base_config(
+      ["--config_file=" + cfg, "--mode=infer", "--infer_output_file=out.txt"])
+  imodel = create_model(args, base_config, config_module, base_model, None)
+  run.restore_latest(imodel, 0)
+  run.infer(imodel, args, 0)
+  src = [l.split() for l in open("toy_text_data/test/source.txt").read().strip().splitlines()]
+  hyp = [l.split() for l in open("out.txt").read().strip().splitlines()]
+  assert sum(h == list(reversed(s_)) for h, s_ in zip(hyp, src)) >= 6, (hyp, src)
