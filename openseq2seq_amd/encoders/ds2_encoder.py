@@ -149,8 +149,6 @@ class DeepSpeech2Encoder(Encoder):
 
   def __init__(self, params, model, name="ds2_encoder", mode='train'):
     super(DeepSpeech2Encoder, self).__init__(params, model, name, mode)
-    if self.params['row_conv']:
-      raise NotImplementedError("row_conv")
     if self.params['rnn_type'] not in ('cudnn_gru', 'gru', 'cudnn_lstm', 'lstm'):
       raise NotImplementedError("rnn_type " + self.params['rnn_type'])
 
@@ -176,6 +174,10 @@ class DeepSpeech2Encoder(Encoder):
                             cell, width, p['rnn_cell_dim'], p['num_rnn_layers'],
                             bidirectional=not p['rnn_unidirectional'])
       width = self.rnn.output_dim
+    self.row_conv = None
+    if p['row_conv'] and p.get('row_conv_width', 8) >= 2:       # ds2_encoder.py:41-42, 361-375
+      from ..parts.cnns.conv_blocks import DepthwiseBN
+      self.row_conv = DepthwiseBN(store, scope + "/row_conv", width, p.get('row_conv_width', 8), mom, eps, l2)
     self.fc = Dense(store, scope + "/fully_connected", width, p['n_hidden'], True)
     self.fc.kernel.l2 = l2
     self.output_dim = p['n_hidden']
@@ -197,6 +199,10 @@ class DeepSpeech2Encoder(Encoder):
       x = layer.forward(x, self.params['activation_fn'], training, tape if training else None)
     if self.rnn is not None:
       x = self.rnn.forward(x, None, tape if training else None, keep_prob=keep, seeds=seeds)
+    if self.row_conv is not None:
+      from ..parts.cnns.conv_blocks import conv_bn_actv
+      x = conv_bn_actv(self.row_conv, x, None, self.params['activation_fn'], training,
+                       tape if training else None)
     B, T, W = x.data.shape
     x2 = Act(x.data.view(B * T, W), None)
     if training and tape is not None:

@@ -44,8 +44,6 @@ class TDNNEncoder(Encoder):
       raise NotImplementedError("only normalization='batch_norm' has HIP kernels so far")
     if self.params.get('data_format', 'channels_last') != 'channels_last':
       raise NotImplementedError("HIP path is channels_last (the reference's default)")
-    if self.params.get('drop_block_prob', 0.0) > 0:
-      raise NotImplementedError("stochastic block dropping")
     self._layers = None
 
   # ---- variable creation (graph-construction phase of the reference) -----
@@ -134,5 +132,7 @@ class TDNNEncoder(Encoder):
       last = (li == nl - 1)
       x = conv_bn_res_bn_actv(main, L['res'], x, res_in, src_length if use_mask else None,
                               act_fn, training, tape, keep_prob=keep,
-                              seed=seed0 * 1000003 + li, mask_output=(use_mask and not last))
+                              seed=seed0 * 1000003 + li, mask_output=(use_mask and not last),
+                              drop_block_prob=self.params.get('drop_block_prob', 0.0),
+                              drop_block=(self.params.get('drop_block_index', -1) == L['block']))
     return {'outputs': x.data, 'src_length': src_length, 'outputs_act': x}

@@ -224,18 +224,92 @@ class SepConvBN(ConvBN):
       accumulate_grad(inp, dx)
 
 
+class DepthwiseBN(ConvBN):
+  """Depthwise ("row" / in-plane) convolution over time + batch norm: the row_conv layer of
+  DeepSpeech2 (encoders/ds2_encoder.py:38-83: tf.nn.depthwise_conv2d with a [width, 1, C, 1] filter,
+  SAME padding, then tf.layers.batch_normalization and the activation). Variables '<name>/w'
+  [K, C] (TF: [K, 1, C, 1]) and '<name>/bn/{gamma,beta}'. Same branch interface as ConvBN, so
+  conv_bn_actv runs it."""
+
+  def __init__(self, store, name, channels, k, bn_momentum=0.99, bn_epsilon=1e-3, l2=0.0):
+    self.name, self.cin, self.cout, self.k = name, channels, channels, k
+    self.stride, self.dil, self.padding = 1, 1, "SAME"
+    self.momentum, self.eps = bn_momentum, bn_epsilon
+
+    def init(shape):   # tf.get_variable default: glorot_uniform over [K, 1, C, 1]
+      lim = math.sqrt(6.0 / (shape[0] * shape[1] + shape[0]))
+      return (torch.rand(shape) * 2 - 1) * lim
+
+    self.depthwise = store.add(name + "/w", (k, channels), init, kind="vector", l2=l2)
+    self.gamma = store.add(name + "/bn/gamma", (channels,), torch.ones(channels), kind="vector", l2=l2)
+    self.beta = store.add(name + "/bn/beta", (channels,), torch.zeros(channels), kind="vector")
+    dev = store.device
+    self.moving_mean = torch.zeros(channels, dtype=torch.float32, device=dev)
+    self.moving_var = torch.ones(channels, dtype=torch.float32, device=dev)
+    if hasattr(store, "add_state"):
+      store.add_state(name + "/bn/moving_mean", self.moving_mean)
+      store.add_state(name + "/bn/moving_variance", self.moving_var)
+
+  def conv_bn_stats(self, x, training):
+    B, Tin, C = x.data.shape
+    tout, pl = self.out_geometry(Tin)
+    dev = x.data.device
+    y = capi.depthwise_conv1d_fwd(x.data, self.depthwise.master, stride=1, dil=1, pad_left=pl,
+                                  tout=tout, in_len=x.lens)
+    stats = capi.bn_stats(y.view(B * tout, C)) if training else None
+    sc = torch.empty(C, dtype=torch.float32, device=dev)
+    sh = torch.empty(C, dtype=torch.float32, device=dev)
+    mean = rstd = None
+    if training:
+      mean = torch.empty(C, dtype=torch.float32, device=dev)
+      rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    capi.bn_finalize(stats, B * tout, self.gamma.master, self.beta.master, self.eps,
+                     self.momentum, training, self.moving_mean, self.moving_var, mean, rstd, sc, sh)
+    return dict(y=y, scale=sc, shift=sh, mean=mean, rstd=rstd, tout=tout, pad_left=pl)
+
+  def trainable(self):
+    return [self.depthwise, self.gamma, self.beta]
+
+  def backward_branch(self, inp, dy, f):
+    capi.depthwise_conv1d_wgrad(inp.data, dy, self.depthwise.grad, stride=1, dil=1,
+                                pad_left=f["pad_left"], in_len=inp.lens)
+    if inp.requires_grad:
+      tin = inp.data.shape[1]
+      dx = capi.depthwise_conv1d_fwd(dy, self.depthwise.master, dil=1,
+                                     pad_left=(self.k - 1) - f["pad_left"], tout=tin,
+                                     out_len=inp.lens, flip=True)
+      accumulate_grad(inp, dx)
+
+
 def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_fn,
-                        training, tape, keep_prob=1.0, seed=0, mask_output=True):
+                        training, tape, keep_prob=1.0, seed=0, mask_output=True,
+                        drop_block_prob=0.0, drop_block=False):
   """act(BN(conv(x)) + sum_i BN_i(conv1x1_i(res_i))) -> dropout -> mask.
 
   main: ConvBN; res_branches: list of ConvBN (1x1) matching res_inputs (list of Act).
   With no residual branches this is conv_bn_actv (conv_blocks.py:170-232); with them
   conv_bn_res_bn_actv (:61-168). Dropout is the tf.nn.dropout the encoder applies
-  to the block output (tdnn_encoder.py:255)."""
+  to the block output (tdnn_encoder.py:255).
+
+  Stochastic block dropping (:156-164): in training one uniform draw per block and step; below
+  drop_block_prob the output is act(sum of the residual branches) — the main branch is still
+  evaluated (its BatchNorm moving statistics update: `bn` is built outside the tf.cond) but takes
+  no part in the output and gets no gradient. In eval, drop_block selects the same path."""
   act = act_id(activation_fn)
   branches = [main] + list(res_branches)
   inputs = [x] + list(res_inputs)
   fw = [br.conv_bn_stats(inp, training) for br, inp in zip(branches, inputs)]
+  dropped = False
+  if res_branches and drop_block_prob > 0:
+    if training:
+      import random
+      dropped = random.Random(int(seed) * 2654435761 % (2 ** 31)).random() < drop_block_prob
+    else:
+      dropped = bool(drop_block)
+  if dropped:
+    tout0 = fw[0]["tout"]
+    branches, inputs, fw = branches[1:], inputs[1:], fw[1:]
+    fw[0]["tout"] = tout0
   B = x.data.shape[0]
   tout, C = fw[0]["tout"], main.cout
   out = torch.empty((B, tout, C), dtype=torch.bfloat16, device=x.data.device)
@@ -248,6 +322,8 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
 
   def backward():
     dout = result.grad
+    if dout is None and drop_block_prob > 0:
+      return      # every consumer of this layer sat in a dropped block: its gradient is zero
     assert dout is not None, "no gradient reached " + main.name
     rows = B * tout
     J = len(branches)
@@ -266,7 +342,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
       f["y"] = None
       br.backward_branch(inp, dy, f)
 
-  tape.record(backward, [p for br in branches for p in br.trainable()])
+  tape.record(backward, [p for br in [main] + list(res_branches) for p in br.trainable()])
   return result
 
 

@@ -38,3 +38,15 @@ def ds2_encode(x, conv_layers, W, gru, fc_w, fc_b, bn_eps=1e-3, keep_mask=None, 
   if keep_mask is not None:
     o = o * keep_mask.float() / keep
   return o
+
+
+def row_conv(x, w, gamma, beta, eps=1e-3, act=torch.relu):
+  """row_conv (ds2_encoder.py:38-83): depthwise conv over time, filter w [K, C] (TF [K,1,C,1]),
+  SAME padding (left (K-1)//2), batch norm with batch statistics, activation. x [B,T,C]."""
+  B, T, C = x.shape
+  K = w.shape[0]
+  _, pl, pr = cnn.same_pad(T, K, 1, 1)
+  xp = F.pad(x.transpose(1, 2), (pl, pr))
+  y = F.conv1d(xp, w.t()[:, None, :], groups=C).transpose(1, 2)
+  yn = cnn.batch_norm_train(y, gamma, beta, eps)[0]
+  return act(yn)

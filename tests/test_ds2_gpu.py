@@ -94,3 +94,59 @@ def test_ds2_small_fwd_bwd(cuda):
     worst = min(worst, (cos, name))
     assert cos > 0.98 and relerr < 0.2, (name, cos, relerr)
   print("worst cosine", worst, "logits rel", rel)
+
+
+def test_row_conv_layer_and_unidirectional_encoder(cuda):
+  """row_conv (depthwise conv over time + BN + ReLU) fwd/bwd vs the fp32 oracle (bf16 storage:
+  output atol 3e-2, gradients cosine >= 0.99), then the unidirectional DS2 encoder with
+  row_conv=True end to end (shapes, finite loss gradients, variable names)."""
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.parts.cnns.conv_blocks import Act, DepthwiseBN, Tape, conv_bn_actv
+  from openseq2seq_amd.encoders.ds2_encoder import DeepSpeech2Encoder
+  from oracle import ds2 as ods
+  torch.manual_seed(0)
+  store = FlatParams(cuda)
+  C, K = 128, 8
+  layer = DepthwiseBN(store, "ForwardPass/ds2_encoder/row_conv", C, K)
+  store.finalize()
+  g = torch.Generator().manual_seed(2)
+  x = torch.randn(3, 50, C, generator=g).to(torch.bfloat16)
+  dy = torch.randn(3, 50, C, generator=g).to(torch.bfloat16)
+  xa = Act(x.to(cuda), None)
+  tape = Tape()
+  store.zero_grads()
+  out = conv_bn_actv(layer, xa, None, "relu", True, tape)
+  out.grad = dy.to(cuda)
+  tape.backward()
+  w = layer.depthwise.master.cpu().clone().requires_grad_(True)
+  gm = layer.gamma.master.cpu().clone().requires_grad_(True)
+  bt = layer.beta.master.cpu().clone().requires_grad_(True)
+  xr = x.float().clone().requires_grad_(True)
+  ref = ods.row_conv(xr, w, gm, bt)
+  (ref * dy.float()).sum().backward()
+  torch.testing.assert_close(out.data.float().cpu(), ref.detach(), atol=3e-2, rtol=3e-2)
+  for got, want, name in ((layer.depthwise.grad, w.grad, "w"), (layer.gamma.grad, gm.grad, "gamma"),
+                          (layer.beta.grad, bt.grad, "beta"), (xa.grad.float(), xr.grad, "dx")):
+    cos = float(torch.nn.functional.cosine_similarity(got.cpu().flatten(), want.flatten(), dim=0))
+    assert cos > 0.99, (name, cos)
+  # unidirectional encoder with the row convolution
+  store2 = FlatParams(cuda)
+  enc = DeepSpeech2Encoder({"conv_layers": CONV, "num_rnn_layers": 1, "rnn_cell_dim": 64,
+                            "use_cudnn_rnn": True, "rnn_type": "cudnn_gru", "rnn_unidirectional": True,
+                            "row_conv": True, "row_conv_width": 8, "n_hidden": 128,
+                            "dropout_keep_prob": 1.0, "activation_fn": "relu",
+                            "data_format": "channels_first", "dtype": "mixed"}, None,
+                           mode="train").build(store2, 32)
+  store2.finalize()
+  names = [p.name for p in store2.params]
+  assert "ForwardPass/ds2_encoder/row_conv/w" in names and "ForwardPass/ds2_encoder/row_conv/bn/gamma" in names
+  tape = Tape()
+  store2.zero_grads()
+  xin = torch.randn(2, 40, 32, generator=g).to(torch.bfloat16).to(cuda)
+  e = enc.encode({"source_tensors": [xin, torch.tensor([40, 25], dtype=torch.int32, device=cuda)],
+                  "tape": tape, "seed": 1})
+  assert tuple(e["outputs"].shape) == (2, 20, 128)
+  e["outputs_act"].grad = torch.ones_like(e["outputs"])
+  tape.backward()
+  gw = store2.by_name("ForwardPass/ds2_encoder/row_conv/w").grad
+  assert torch.isfinite(gw).all() and float(gw.abs().max()) > 0

@@ -152,3 +152,48 @@ def test_jasper_small_trains(cuda):
   assert st["global_step"] == 30 and st["num_skipped"] == 0
   assert np.isfinite(losses).all()
   assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_stochastic_block_drop(cuda):
+  """drop_block_prob (conv_blocks.py:156-164): a dropped block outputs act(sum of its residual
+  branches); its main conv gets no gradient but its BatchNorm moving statistics still update.
+  Eval: drop_block_index selects the block."""
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+
+  def build(mode, **extra):
+    torch.manual_seed(0)
+    store = FlatParams(cuda)
+    layers = [dict(l, dropout_keep_prob=1.0) for l in LAYERS[:3]]
+    enc = TDNNEncoder(dict({"convnet_layers": layers, "dropout_keep_prob": 1.0, "activation_fn": "relu",
+                            "use_conv_mask": True, "dtype": "mixed"}, **extra), None, mode=mode).build(store, 64)
+    store.finalize()
+    return store, enc
+
+  g = torch.Generator().manual_seed(4)
+  x = torch.randn(2, 64, 64, generator=g).to(torch.bfloat16).to(cuda)
+  lens = torch.tensor([64, 40], dtype=torch.int32, device=cuda)
+  store, enc = build("train", drop_block_prob=1.0)
+  tape = Tape()
+  out = enc.encode({'source_tensors': [x, lens], 'tape': tape, 'seed': 3})['outputs_act']
+  out.grad = torch.ones_like(out.data)
+  store.zero_grads()
+  tape.backward()
+  last_main = [L['main'] for L in enc._layers if L['res']]
+  assert len(last_main) == 2
+  for m in last_main:
+    assert float(m.kernel.grad.abs().max()) == 0.0 and float(m.gamma.grad.abs().max()) == 0.0
+    assert float(m.moving_mean.abs().max()) > 0.0           # statistics were still computed
+  others = [L['main'] for L in enc._layers if not L['res']]
+  assert any(float(m.kernel.grad.abs().max()) > 0 for m in others)
+  res_k = enc._layers[2]['res'][0].kernel
+  assert float(res_k.grad.abs().max()) > 0.0
+  # eval: dropping block 1 changes the output, dropping no block reproduces the plain network
+  _, e_plain = build("eval")
+  _, e_none = build("eval", drop_block_prob=0.5, drop_block_index=-1)
+  _, e_drop = build("eval", drop_block_prob=0.5, drop_block_index=1)
+  y0 = e_plain.encode({'source_tensors': [x, lens]})['outputs']
+  y1 = e_none.encode({'source_tensors': [x, lens]})['outputs']
+  y2 = e_drop.encode({'source_tensors': [x, lens]})['outputs']
+  assert torch.equal(y0, y1) and not torch.equal(y0, y2)
