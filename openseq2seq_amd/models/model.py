@@ -12,6 +12,7 @@ openseq2seq_amd/utils/distributed.py).
 from __future__ import absolute_import, division, print_function
 
 import abc
+import os
 import copy
 import time
 
@@ -154,7 +155,9 @@ class Model(object):
           loss_scaling=p.get('loss_scaling', 1.0),
           loss_scaling_params=p.get('loss_scaling_params', None),
           on_horovod=self.on_horovod, iter_size=p.get('iter_size', 1), world_size=world)
-      self._reducer = dist_utils.GradientReducer(self._store, world) if world > 1 else None
+      # OS2S_FORCE_REDUCER: exercise the RCCL side-stream path with a one-rank group (tools/)
+      force = self._hvd is not None and os.environ.get("OS2S_FORCE_REDUCER", "") == "1"
+      self._reducer = dist_utils.GradientReducer(self._store, world) if (world > 1 or force) else None
     self._compiled = True
     return self
 

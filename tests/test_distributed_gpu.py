@@ -1,0 +1,19 @@
+"""GPU: the data-parallel path (RCCL process group, bucketed all-reduce of the flat gradient
+buffer on a side stream overlapped with backward) exercised with a one-rank group — the only
+multi-process configuration a 1-GPU box allows. World size 2 is covered on CPU with gloo
+(tests/test_distributed_cpu.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_rccl_path_matches_plain_run(cuda):
+  repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dist_single_rank_check.py")],
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+  assert r.returncode == 0 and "OK: reducer active in dist run: True" in r.stdout, r.stdout[-2000:]
