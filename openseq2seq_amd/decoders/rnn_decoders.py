@@ -20,7 +20,7 @@ import torch
 
 from .decoder import Decoder
 from .. import capi
-from ..encoders.rnn_encoders import Embedding, cell_spec, dropout_act
+from ..encoders.rnn_encoders import Embedding, cell_spec, dropout_act, residual_add
 from ..parts.cnns.conv_blocks import Act
 from ..parts.rnns.rnn_layers import RNNDirection, rnn_directions_forward
 from ..parts.transformer.layers import SeedSeq, _colsum_into
@@ -204,14 +204,15 @@ class RNNDecoderWithAttention(Decoder):
     self._tgt_vocab_size, self._tgt_emb_size = p['tgt_vocab_size'], p['tgt_emb_size']
     if p.get('weight_tied', False):
       raise NotImplementedError("weight_tied")
-    if p['decoder_use_skip_connections']:
-      raise NotImplementedError("decoder_use_skip_connections (gnmt_residual_fn)")
+    if p['decoder_use_skip_connections'] and not p['attention_type'].startswith('gnmt'):
+      raise NotImplementedError("decoder_use_skip_connections outside the GNMT attention cells")
     if p.get('decoder_dp_output_keep_prob', 1.0) != 1.0:
       raise NotImplementedError("decoder_dp_output_keep_prob != 1.0")
     if p['attention_type'] == 'luong' and p.get('luong_scale', False):
       raise NotImplementedError("luong_scale=True (the learned scalar of LuongAttention)")
     if p.get('time_major', False):
       raise NotImplementedError("time_major")
+    self._skip = bool(p['decoder_use_skip_connections'])
 
   def build(self, store, memory_dim=None):
     p = self.params
@@ -281,9 +282,13 @@ class RNNDecoderWithAttention(Decoder):
       att_in = ctx
       if self.params['attention_type'] == 'gnmt':      # upper layers see the PREVIOUS attention
         att_in = _shift_time(ctx, tape)
-      for layer in self.upper:
+      for li, layer in enumerate(self.upper):
         xs = [dropout_act(top, keep, seeds.next(), tape), dropout_act(att_in, keep, seeds.next(), tape)]
-        top = rnn_directions_forward([layer], xs, tgt_len, tape)[0]
+        y = rnn_directions_forward([layer], xs, tgt_len, tape)[0]
+        # _add_residual_wrapper(cells, start_ind=1) with gnmt_residual_fn (rnn_decoders.py:138-146,
+        # parts/rnns/gnmt.py): from the second upper layer on, out += the layer-input part of the
+        # cell inputs (not the attention part, not dropped)
+        top = residual_add(y, top, tape) if (self._skip and li >= 1) else y
     else:
       top = ctx      # AttentionWrapper default output_attention=True: the attention vector
     feat = top.data.reshape(B * T, self.out_in)
@@ -336,8 +341,9 @@ class RNNDecoderWithAttention(Decoder):
         if self.params['attention_type'] == 'gnmt':
           att = torch.cat([torch.zeros_like(att[:, :1]), att[:, :-1]], 1)
         att = Act(att.contiguous())
-        for layer in self.upper:      # upper layers re-run over the prefix (state is implicit)
-          top = rnn_directions_forward([layer], [top, att], None, None)[0]
+        for li, layer in enumerate(self.upper):   # upper layers re-run over the prefix (state is implicit)
+          y = rnn_directions_forward([layer], [top, att], None, None)[0]
+          top = residual_add(y, top, None) if (self._skip and li >= 1) else y
         feat = top.data[:, t].contiguous()
       else:
         feat = loop.ctx[:, t].contiguous()
@@ -417,8 +423,9 @@ class BeamSearchRNNDecoderWithAttention(RNNDecoderWithAttention):
         if self.params['attention_type'] == 'gnmt':
           att = torch.cat([torch.zeros_like(att[:, :1]), att[:, :-1]], 1)
         att = Act(att.contiguous())
-        for layer in self.upper:
-          top = rnn_directions_forward([layer], [top, att], None, None)[0]
+        for li, layer in enumerate(self.upper):
+          y = rnn_directions_forward([layer], [top, att], None, None)[0]
+          top = residual_add(y, top, None) if (self._skip and li >= 1) else y
         feat = top.data[:, t].contiguous()
       else:
         feat = loop.ctx[:, t].contiguous()

@@ -75,6 +75,24 @@ def dropout_act(x, keep, seed, tape):
   return out
 
 
+def residual_add(y, x, tape):
+  """tf.contrib.rnn.ResidualWrapper: out = y + x (x = the layer's raw, undropped input)."""
+  out = Act(capi.add_bf16(y.data, x.data), y.lens)
+  if tape is not None:
+    def backward():
+      g = out.grad
+      for t in (y, x):
+        if t.requires_grad:
+          if t.grad_init and t.grad is not None:
+            capi.add_bf16(t.grad, g, out=t.grad)
+          else:
+            t.grad, t.grad_init = g.clone(), True
+      out.grad = None
+
+    tape.record(backward)
+  return out
+
+
 class BidirectionalRNNEncoderWithEmbedding(Encoder):
   @staticmethod
   def get_required_params():
@@ -179,3 +197,59 @@ class UnidirectionalRNNEncoderWithEmbedding(BidirectionalRNNEncoderWithEmbedding
 
   def __init__(self, params, model, name="unidir_rnn_encoder_with_emb", mode='train'):
     super(UnidirectionalRNNEncoderWithEmbedding, self).__init__(params, model, name, mode)
+
+
+class GNMTLikeEncoderWithEmbedding(BidirectionalRNNEncoderWithEmbedding):
+  """encoders/rnn_encoders.py:320-470: embedding -> ONE bidirectional LSTM layer (no dropout)
+  -> encoder_layers - 1 unidirectional layers (DropoutWrapper input dropout), every
+  unidirectional layer but the first wrapped in a ResidualWrapper. Output depth = num_units."""
+
+  def __init__(self, params, model, name="gnmt_encoder_with_emb", mode='train'):
+    Encoder.__init__(self, params, model, name, mode)
+    self._src_vocab_size = self.params['src_vocab_size']
+    self._src_emb_size = self.params['src_emb_size']
+    if self.params['encoder_layers'] < 2:
+      raise ValueError("GNMT encoder must have at least 2 layers")
+    if self.params.get('encoder_dp_output_keep_prob', 1.0) != 1.0:
+      raise NotImplementedError("encoder_dp_output_keep_prob != 1.0")
+    if self.params.get('time_major', False):
+      raise NotImplementedError("time_major layouts (batch-major [B,S,...] only)")
+
+  def build(self, store):
+    p = self.params
+    cell, H, fb = cell_spec(p['core_cell'], p['core_cell_params'])
+    self.H = H
+    self.output_dim = H
+    scope = "ForwardPass/" + self._name
+    self.embedding = Embedding(store, scope + "/EncoderEmbeddingMatrix", self._src_vocab_size,
+                               self._src_emb_size)
+    self.l1 = [RNNDirection(store, "%s/Level1%s/lstm_cell" % (scope, tag), cell, [self._src_emb_size], H,
+                            reverse=(d == 1), forget_bias=fb) for d, tag in enumerate(("FW", "BW"))]
+    self.uni = []
+    cin = 2 * H
+    for l in range(p['encoder_layers'] - 1):
+      self.uni.append(RNNDirection(store, "%s/UniDirLevel/multi_rnn_cell/cell_%d/lstm_cell" % (scope, l),
+                                   cell, [cin], H, reverse=False, forget_bias=fb))
+      cin = H
+    return self
+
+  def _encode(self, input_dict):
+    ids, lens = input_dict['source_tensors'][0], input_dict['source_tensors'][1]
+    B, S = ids.shape
+    training = self._mode == "train"
+    tape = input_dict.get('tape') if training else None
+    seeds = input_dict.get('seeds') or SeedSeq(19)
+    keep = self.params.get('encoder_dp_input_keep_prob', 1.0) if training else 1.0
+    H = self.H
+    emb = self.embedding.lookup(ids.reshape(-1).contiguous(), tape)
+    emb = Act(emb.data.view(B, S, -1), lens) if tape is None else self._view3(emb, B, S, lens, tape)
+    l1 = Act(torch.zeros((B, S, 2 * H), dtype=torch.bfloat16, device=ids.device), lens)
+    rnn_directions_forward(self.l1, [[emb], [emb]], lens, tape,
+                           [l1.data[:, :, d * H:(d + 1) * H] for d in range(2)],
+                           [(lambda o=l1, d=d: o.grad[:, :, d * H:(d + 1) * H]) for d in range(2)])
+    cur = l1
+    for l, layer in enumerate(self.uni):
+      y = rnn_directions_forward([layer], [[dropout_act(cur, keep, seeds.next(), tape)]], lens, tape)[0]
+      cur = residual_add(y, cur, tape) if l > 0 else y
+    return {'outputs': cur.data, 'outputs_act': cur, 'state': None, 'src_lengths': lens,
+            'encoder_input': ids, 'seeds': seeds}

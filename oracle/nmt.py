@@ -27,7 +27,23 @@ def encoder(P, ids, lens):
   return torch.cat(outs, -1)
 
 
-def decoder_logits(P, enc_out, src_len, tgt, tgt_len, attention_type="gnmt_v2"):
+def gnmt_like_encoder(P, ids, lens):
+  """GNMTLikeEncoderWithEmbedding (encoders/rnn_encoders.py:320-470): one bidirectional layer
+  (P['l1fw'], P['l1bw']), then unidirectional layers P['uni'] — each but the first with a residual
+  connection (tf.contrib.rnn.ResidualWrapper)."""
+  x = P["emb"][ids.long()]
+  outs = []
+  for key, rev in (("l1fw", False), ("l1bw", True)):
+    lyr = P[key]
+    outs.append(orn.lstm_tf(x, lens, lyr["wx"].t(), lyr["wh"].t(), lyr["b"], lyr.get("forget_bias", 1.0), rev))
+  h = torch.cat(outs, -1)
+  for l, lyr in enumerate(P["uni"]):
+    y = orn.lstm_tf(h, lens, lyr["wx"].t(), lyr["wh"].t(), lyr["b"], lyr.get("forget_bias", 1.0), False)
+    h = y + h if l > 0 else y
+  return h
+
+
+def decoder_logits(P, enc_out, src_len, tgt, tgt_len, attention_type="gnmt_v2", skip=False):
   """Teacher-forced logits [B,T,V]. P['demb'] [V,E]; P['cell']: dict for
   oracle.attn_decoder.attention_decoder + 'w_in' [4H,E], 'b0' [4H]; P['upper']: list of
   dict(wx_h [4H,H], wx_a [4H,M], wh [4H,H], b [4H]); P['proj'] [V,H]."""
@@ -39,10 +55,13 @@ def decoder_logits(P, enc_out, src_len, tgt, tgt_len, attention_type="gnmt_v2"):
   top, ctx = r["y"], r["ctx"]
   if attention_type == "gnmt":
     ctx = torch.cat([torch.zeros_like(ctx[:, :1]), ctx[:, :-1]], 1)
-  for lyr in P["upper"]:
+  for li, lyr in enumerate(P["upper"]):
     wx = torch.cat([lyr["wx_h"], lyr["wx_a"]], 1)
-    top = orn.lstm_tf(torch.cat([top, ctx], -1), tgt_len, wx.t(), lyr["wh"].t(), lyr["b"],
-                      lyr.get("forget_bias", 1.0), False)
+    y = orn.lstm_tf(torch.cat([top, ctx], -1), tgt_len, wx.t(), lyr["wh"].t(), lyr["b"],
+                    lyr.get("forget_bias", 1.0), False)
+    # decoder_use_skip_connections: ResidualWrapper(gnmt_residual_fn) on the upper cells from the
+    # second one on (rnn_decoders.py:138-146): + the layer-input part of the cell inputs
+    top = y + top if (skip and li >= 1) else y
   return top @ P["proj"].t()
 
 

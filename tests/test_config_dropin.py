@@ -70,6 +70,8 @@ def test_baseline_configs_load_unchanged():
       "speech2text/quartznet15x5_LibriSpeech.py": (M.Speech2Text, E.TDNNEncoder, D.FullyConnectedCTCDecoder),
       "text2speech/tacotron_gst.py": (M.Text2SpeechTacotron, E.Tacotron2Encoder, D.Tacotron2Decoder),
       "text2text/en-de/transformer-base.py": (M.Text2Text, E.TransformerEncoder, D.TransformerDecoder),
+      "text2text/en-de/en-de-gnmt-like-4GPUs.py": (M.Text2Text, E.GNMTLikeEncoderWithEmbedding,
+                                                   D.RNNDecoderWithAttention),
   }
   for rel, (model, enc, dec) in cases.items():
     for mode in ("train", "infer"):
