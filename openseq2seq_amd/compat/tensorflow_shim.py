@@ -42,6 +42,7 @@ minimum = _Token("minimum")
 maximum = _Token("maximum")
 glorot_uniform_initializer = _Token("glorot_uniform_initializer")
 random_normal_initializer = _Token("random_normal_initializer")
+random_uniform_initializer = _Token("random_uniform_initializer")
 truncated_normal_initializer = _Token("truncated_normal_initializer")
 constant_initializer = _Token("constant_initializer")
 

@@ -20,7 +20,7 @@ import torch
 
 from .decoder import Decoder
 from .. import capi
-from ..encoders.rnn_encoders import Embedding, cell_spec, dropout_act, residual_add
+from ..encoders.rnn_encoders import Embedding, apply_scope_initializer, cell_spec, dropout_act, residual_add
 from ..parts.cnns.conv_blocks import Act
 from ..parts.rnns.rnn_layers import RNNDirection, rnn_directions_forward
 from ..parts.transformer.layers import SeedSeq, _colsum_into
@@ -216,6 +216,7 @@ class RNNDecoderWithAttention(Decoder):
 
   def build(self, store, memory_dim=None):
     p = self.params
+    first_param = len(store.params)
     cell, H, fb = cell_spec(p['core_cell'], p.get('core_cell_params', {}))
     self.H, self.U = H, p['attention_layer_size']
     self.M = memory_dim if memory_dim is not None else p.get('_memory_dim', 2 * H)
@@ -253,6 +254,7 @@ class RNNDecoderWithAttention(Decoder):
 
     self.out_in = out_in
     self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
+    apply_scope_initializer(store, first_param, p)
     return self
 
   # ---------------------------------------------------------------- training / scoring pass

@@ -75,6 +75,34 @@ def dropout_act(x, keep, seed, tape):
   return out
 
 
+def apply_scope_initializer(store, first, params):
+  """tf.variable_scope(initializer=...) of Encoder/Decoder.encode (encoder.py / decoder.py): the
+  configured initializer replaces the default of every variable created without an explicit one
+  — kernels, embedding matrices, attention_v (LSTM biases, attention_g / attention_b have their
+  own). Only random_uniform_initializer (the GNMT configs) needs handling here: the built-in
+  default of this package is already glorot_uniform."""
+  tok = params.get('initializer', None)
+  name = getattr(tok, "__name__", str(tok))
+  if "random_uniform" not in name:
+    return
+  ip = params.get('initializer_params', {}) or {}
+  lo, hi = float(ip.get('minval', 0.0)), float(ip.get('maxval', 1.0))
+  for i in range(first, len(store.params)):
+    p = store.params[i]
+    if p.kind in ("conv", "dense") or p.name.endswith("attention_v"):
+      keep_zero_pad = p.name.endswith("/dense/kernel")      # vocabulary padding rows stay zero
+      old = store._inits[i]
+
+      def init(shape, lo=lo, hi=hi, old=old, keep=keep_zero_pad):
+        w = torch.rand(shape) * (hi - lo) + lo
+        if keep:
+          ref = old(shape) if callable(old) else old
+          w = torch.where(torch.as_tensor(ref) == 0, torch.zeros_like(w), w)
+        return w
+
+      store._inits[i] = init
+
+
 def residual_add(y, x, tape):
   """tf.contrib.rnn.ResidualWrapper: out = y + x (x = the layer's raw, undropped input)."""
   out = Act(capi.add_bf16(y.data, x.data), y.lens)
@@ -123,6 +151,7 @@ class BidirectionalRNNEncoderWithEmbedding(Encoder):
 
   def build(self, store):
     p = self.params
+    first = len(store.params)
     cell, H, fb = cell_spec(p['core_cell'], p['core_cell_params'])
     self.H = H
     self.output_dim = H * (2 if self._bidirectional else 1)
@@ -138,6 +167,7 @@ class BidirectionalRNNEncoderWithEmbedding(Encoder):
             reverse=(d == 1), forget_bias=fb))
         cin = H
       self.stacks.append(layers)
+    apply_scope_initializer(store, first, p)
     return self
 
   def _encode(self, input_dict):
@@ -217,6 +247,7 @@ class GNMTLikeEncoderWithEmbedding(BidirectionalRNNEncoderWithEmbedding):
 
   def build(self, store):
     p = self.params
+    first = len(store.params)
     cell, H, fb = cell_spec(p['core_cell'], p['core_cell_params'])
     self.H = H
     self.output_dim = H
@@ -231,6 +262,7 @@ class GNMTLikeEncoderWithEmbedding(BidirectionalRNNEncoderWithEmbedding):
       self.uni.append(RNNDirection(store, "%s/UniDirLevel/multi_rnn_cell/cell_%d/lstm_cell" % (scope, l),
                                    cell, [cin], H, reverse=False, forget_bias=fb))
       cin = H
+    apply_scope_initializer(store, first, p)
     return self
 
   def _encode(self, input_dict):
