@@ -202,8 +202,7 @@ class RNNDecoderWithAttention(Decoder):
     self._batch_size = p['batch_size']
     self.GO_SYMBOL, self.END_SYMBOL = p['GO_SYMBOL'], p['END_SYMBOL']
     self._tgt_vocab_size, self._tgt_emb_size = p['tgt_vocab_size'], p['tgt_emb_size']
-    if p.get('weight_tied', False):
-      raise NotImplementedError("weight_tied")
+    self._weight_tied = bool(p.get('weight_tied', False))
     if p['decoder_use_skip_connections'] and not p['attention_type'].startswith('gnmt'):
       raise NotImplementedError("decoder_use_skip_connections outside the GNMT attention cells")
     if p.get('decoder_dp_output_keep_prob', 1.0) != 1.0:
@@ -223,7 +222,10 @@ class RNNDecoderWithAttention(Decoder):
     scope = "ForwardPass/" + self._name
     V, E = self._tgt_vocab_size, self._tgt_emb_size
     self.Vpad = _round8(V)
-    self.embedding = Embedding(store, scope + "/DecoderEmbeddingMatrix", V, E)
+    if self._weight_tied and not (p['attention_type'].startswith('gnmt') and E == H):
+      raise NotImplementedError("weight_tied needs a GNMT decoder whose top cell size equals tgt_emb_size")
+    if not self._weight_tied:
+      self.embedding = Embedding(store, scope + "/DecoderEmbeddingMatrix", V, E)
     at = p['attention_type']
     self.gnmt = at.startswith('gnmt')
     nl = p['decoder_layers']
@@ -254,6 +256,8 @@ class RNNDecoderWithAttention(Decoder):
 
     self.out_in = out_in
     self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
+    if self._weight_tied:      # the embedding IS the (transposed) output projection
+      self.embedding = Embedding(store, None, V, E, table=self.proj)
     apply_scope_initializer(store, first_param, p)
     return self
 
@@ -308,7 +312,7 @@ class RNNDecoderWithAttention(Decoder):
         top.grad_init = True
         logits.grad = None
 
-      tape.record(backward, [self.proj])
+      tape.record(backward, [] if self._weight_tied else [self.proj])
     return {'logits': logits.data, 'logits_act': logits, 'vocab_size': self._tgt_vocab_size,
             'outputs': None, 'final_state': None, 'final_sequence_lengths': tgt_len,
             'lazy_outputs': lambda: [capi.argmax_rows(logits2, self._tgt_vocab_size).view(B, T)]}

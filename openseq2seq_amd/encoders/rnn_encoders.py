@@ -28,12 +28,33 @@ def cell_spec(core_cell, core_cell_params):
   return "lstm_tf", int(core_cell_params["num_units"]), float(core_cell_params.get("forget_bias", 1.0))
 
 
+class _SharedTable(object):
+  """[V', E] views of a parameter stored as [1, V', E] (the decoder's output projection when
+  weight_tied: decoders/rnn_decoders.py:189-194 uses transpose(dense/kernel) as the embedding)."""
+
+  def __init__(self, param, dim):
+    self.param, self.dim = param, dim
+    self.name = param.name
+
+  @property
+  def w16(self):
+    return self.param.w16.view(-1, self.dim)
+
+  @property
+  def grad(self):
+    return self.param.grad.view(-1, self.dim)
+
+
 class Embedding(object):
   """tf.get_variable [V, E] + tf.nn.embedding_lookup (+ the first DropoutWrapper's input
   dropout fused into the gather)."""
 
-  def __init__(self, store, name, vocab, dim):
+  def __init__(self, store, name, vocab, dim, table=None):
+    """table: an existing [*, >=vocab, dim] parameter to share (weight tying) instead of a new one."""
     self.vocab, self.dim = vocab, dim
+    if table is not None:
+      self.table = _SharedTable(table, dim)
+      return
 
     def init(shape):   # the model-level initializer (glorot_uniform in the NMT configs)
       lim = math.sqrt(6.0 / (vocab + dim))
@@ -51,7 +72,7 @@ class Embedding(object):
         capi.embed_bwd(ids_flat, out.grad, emb.table.grad, 1.0, keep, seed, plain=True)
         out.grad = None
 
-      tape.record(backward, [emb.table])
+      tape.record(backward, [emb.table.param if isinstance(emb.table, _SharedTable) else emb.table])
     return out
 
 

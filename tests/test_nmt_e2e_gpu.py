@@ -153,8 +153,10 @@ def test_basic_sequence_loss_equals_smoothing0(cuda):
   assert float(la.grad.reshape(B * T, V)[~rows].abs().max()) == 0.0
 
 
-def test_gnmt_like_encoder_and_skip_connections(cuda):
-  """en-de-gnmt-like architecture scaled down: GNMTLikeEncoderWithEmbedding (1 bidirectional + 2
+@pytest.mark.parametrize("weight_tied", [False, True])
+def test_gnmt_like_encoder_and_skip_connections(cuda, weight_tied):
+  """(weight_tied: en-de-gnmt-like-weight-tied-2GPUs.py — the decoder embedding is the transposed
+  output projection.) en-de-gnmt-like architecture scaled down: GNMTLikeEncoderWithEmbedding (1 bidirectional + 2
   unidirectional layers, residual on the last) -> 3-layer gnmt_v2 decoder with
   decoder_use_skip_connections; loss, logits and every gradient vs the fp32 oracle."""
   from openseq2seq_amd.optimizers.flat_params import FlatParams
@@ -176,8 +178,11 @@ def test_gnmt_like_encoder_and_skip_connections(cuda):
       {"GO_SYMBOL": 2, "END_SYMBOL": 1, "tgt_vocab_size": V, "tgt_emb_size": E,
        "attention_layer_size": 128, "attention_type": "gnmt_v2", "core_cell": "LSTMCell",
        "core_cell_params": cellp, "decoder_layers": 3, "decoder_use_skip_connections": True,
-       "decoder_dp_input_keep_prob": 1.0, "batch_size": 4, "dtype": "mixed"}, None, mode="train")
+       "decoder_dp_input_keep_prob": 1.0, "batch_size": 4, "dtype": "mixed", "weight_tied": weight_tied},
+      None, mode="train")
   dec.build(store, memory_dim=enc.output_dim)
+  assert (store.params[-1].name.endswith("dense/kernel")) and \
+      any(p.name.endswith("DecoderEmbeddingMatrix") for p in store.params) == (not weight_tied)
   lossf = BasicSequenceLoss({"tgt_vocab_size": V, "batch_size": 4, "offset_target_by_one": True,
                              "average_across_timestep": False, "do_mask": True, "dtype": "mixed"}, None)
   store.finalize()
@@ -221,10 +226,11 @@ def test_gnmt_like_encoder_and_skip_connections(cuda):
   cell = dict(wcat=[leaf(c.wcat[0], (4 * H, M + H))], bias=[None], wq=leaf(c.w_q, (U, H)),
               wmem=leaf(c.w_mem, (U, M)), v=leaf(c.v, None, False), g=leaf(c.g, None, False),
               b=leaf(c.b, None, False), w_in=leaf(c.w_in, (4 * H, -1)), b0=leaf(c.bias[0], None, False))
-  D = {"demb": leaf(dec.embedding.table), "cell": cell,
+  proj_leaf = leaf(dec.proj, (dec.Vpad, -1))
+  D = {"demb": proj_leaf if weight_tied else leaf(dec.embedding.table), "cell": cell,
        "upper": [dict(wx_h=leaf(l.wx[0], (4 * H, H)), wx_a=leaf(l.wx[1], (4 * H, M)),
                       wh=leaf(l.wh, (4 * H, H)), b=leaf(l.bx, None, False)) for l in dec.upper],
-       "proj": leaf(dec.proj, (dec.Vpad, -1))}
+       "proj": proj_leaf}
   enc_out = onmt.gnmt_like_encoder(P, src, src_len)
   logits = onmt.decoder_logits(D, enc_out, src_len, tgt, tgt_len, "gnmt_v2", skip=True)[..., :V]
   ref = onmt.basic_sequence_loss(logits, tgt, tgt_len, 4)
