@@ -726,6 +726,44 @@ int os2s_conv2d_toeplitz_expand(os2s_stream_t stream, const float* w, int KT, in
 int os2s_conv2d_toeplitz_reduce(os2s_stream_t stream, const float* dwexp, int KT, int KF, int Cin,
                                 int Cout, int Fi, int Fo, int sF, int padF, float* dw);
 
+/* ------------------------------------------------------------------------
+ * CTC prefix beam search with a word n-gram language model — HOST entry
+ * points: every pointer is host memory, no stream. Replaces the reference's only native code on
+ * this path, the CPU TensorFlow op CTCBeamSearchDecoderWithLM
+ * (ctc_decoder_with_lm/beam_search.cc:452-804; Step :245-380, TopPaths :398-429, end-of-sequence
+ * rescoring :730-739) with WordLMBeamScorer (ctc_decoder_with_lm/beam_search.h:32-217), as bound
+ * by FullyConnectedCTCDecoder.decode_with_lm (open_seq2seq/decoders/fc_decoders.py:206-235).
+ *
+ * os2s_ctc_scorer_create: lm_path = an ARPA text file (any order <= 8), or a KenLM binary of the
+ *   type the reference's op loads (QuantArrayTrieModel, beam_search.h:22) — order 2 only, the one
+ *   layout the reference ships a sample of (ctc-test-lm.binary); other binaries return
+ *   OS2S_ERR_UNSUPPORTED (convert with the ARPA file they were built from). trie_path = the text
+ *   letter trie written by generate_trie (trie_node.h:46-82); alphabet_path = one label per line
+ *   (alphabet.h:24-40), C - 1 labels, blank = C - 1 is implied. alpha weighs log10 P(word |
+ *   history), beta is the per-word bonus, trie_weight weighs the letter-prefix score.
+ * os2s_ctc_scorer_ngram_score: log10 P(words[n-1] | words[..n-2]) exactly as ScoreNGram
+ *   (beam_search.h:172-200) pads / truncates the history; -100 for an out-of-vocabulary word.
+ * os2s_ctc_beam_search: logits fp32, element (t, b, c) at logits[t*ld_t + b*ld_b + c] (raw
+ *   logits; each frame is log-softmax normalised inside, beam_search.cc:262-271); seq_len [B];
+ *   scorer may be NULL (plain tf.nn.ctc_beam_search_decoder semantics). n_threads <= 0: one per
+ *   host core, capped at B. Outputs: out_ids [B, top_paths, T] int32 padded with -1,
+ *   out_len [B, top_paths], out_log_prob [B, top_paths] (natural-log beam scores, best first).
+ * ---------------------------------------------------------------------- */
+int os2s_ctc_scorer_create(const char* lm_path, const char* trie_path, const char* alphabet_path,
+                           float alpha, float beta, float trie_weight, void** scorer);
+void os2s_ctc_scorer_destroy(void* scorer);
+int os2s_ctc_scorer_ngram_score(const void* scorer, const char* const* words, int n_words,
+                                float* log10_prob);
+/* The reference's generate_trie tool (ctc_decoder_with_lm/generate_trie.cpp:32-64): one
+ * TrieNode::Insert per whitespace-separated word of vocab_path with its unigram log10
+ * probability from the null context; writes the text trie the scorer reads. */
+int os2s_ctc_generate_trie(const char* alphabet_path, const char* lm_path, const char* vocab_path,
+                           const char* trie_path);
+int os2s_ctc_beam_search(const float* logits, long long ld_t, long long ld_b,
+                         const int32_t* seq_len, int T, int B, int C, int beam_width,
+                         int top_paths, int merge_repeated, const void* scorer, int n_threads,
+                         int32_t* out_ids, int32_t* out_len, float* out_log_prob);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,11 +44,11 @@ def _run(cmd, **kw):
 
 def hip_sources():
   return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
-                if f.endswith(".hip"))
+                if f.endswith(".hip") or f.endswith(".cpp"))
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-  """Compile every csrc/*.hip for gfx950 and link libos2s_hip.so."""
+  """Compile every csrc/*.hip for gfx950 (and the host-only csrc/*.cpp) and link libos2s_hip.so."""
   if shutil.which(HIPCC) is None and not os.path.exists(HIPCC):
     raise RuntimeError("hipcc not found (looked for %s)" % HIPCC)
   headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
@@ -58,7 +58,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
   objs = []
   jobs = []
   for s in srcs:
-    o = s[:-4] + ".o"
+    o = os.path.splitext(s)[0] + ".o"
     objs.append(o)
     if force or _newer(o, [s] + headers):
       jobs.append((s, o))

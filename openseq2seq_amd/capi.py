@@ -1228,3 +1228,62 @@ def depthwise_conv1d_wgrad(x, dy, dw, *, stride=1, dil=1, pad_left=None, in_len=
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32),
                _ptr(in_len, torch.int32, True), B, Tin, tout, C, K, stride, dil, pad_left),
              "os2s_depthwise_conv1d_wgrad")
+
+
+# --------------------------------------------------------------------------
+# CTC prefix beam search with an n-gram language model (host entry points)
+# --------------------------------------------------------------------------
+class CtcScorer(object):
+  """Handle of os2s_ctc_scorer_create (language model + letter trie + alphabet)."""
+
+  def __init__(self, lm_path, trie_path, alphabet_path, alpha, beta, trie_weight=0.1):
+    import ctypes
+    self._h = ctypes.c_void_p(0)
+    self._destroy = _fn("os2s_ctc_scorer_destroy", (c_void_p,), None)
+    f = _fn("os2s_ctc_scorer_create", (ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_float,
+                                       c_float, c_float, ctypes.POINTER(ctypes.c_void_p)))
+    _lib.check(f(str(lm_path).encode(), str(trie_path).encode(), str(alphabet_path).encode(),
+                 float(alpha), float(beta), float(trie_weight), ctypes.byref(self._h)),
+               "os2s_ctc_scorer_create(%s, %s, %s)" % (lm_path, trie_path, alphabet_path))
+
+  @property
+  def handle(self):
+    return self._h
+
+  def ngram_score(self, words):
+    import ctypes
+    arr = (ctypes.c_char_p * len(words))(*[w.encode() for w in words])
+    out = c_float(0)
+    f = _fn("os2s_ctc_scorer_ngram_score", (c_void_p, ctypes.POINTER(ctypes.c_char_p), c_int,
+                                            ctypes.POINTER(c_float)))
+    _lib.check(f(self._h, arr, len(words), ctypes.byref(out)), "os2s_ctc_scorer_ngram_score")
+    return out.value
+
+  def __del__(self):
+    h, self._h = getattr(self, "_h", None), None
+    if h and getattr(self, "_destroy", None) is not None:
+      self._destroy(h)
+
+
+def ctc_beam_search(logits, seq_len, beam_width, scorer=None, top_paths=1, merge_repeated=False,
+                    n_threads=0):
+  """logits [T,B,C] float32 HOST tensor (time-major, raw logits), seq_len [B] int32 host tensor.
+  Returns (ids [B,top_paths,T] int32 padded with -1, lens [B,top_paths], log_probs [B,top_paths]),
+  host tensors. The reference's op is CPU-only as well (beam_search.cc:803)."""
+  if logits.is_cuda or seq_len.is_cuda:
+    raise ValueError("ctc_beam_search is a host entry point: pass CPU tensors")
+  logits = logits.contiguous().float()
+  seq_len = seq_len.contiguous().to(torch.int32)
+  T, B, C = logits.shape
+  ids = torch.empty((B, top_paths, max(T, 1)), dtype=torch.int32)
+  lens = torch.empty((B, top_paths), dtype=torch.int32)
+  lp = torch.empty((B, top_paths), dtype=torch.float32)
+  f = _fn("os2s_ctc_beam_search", (c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p))
+  if T == 0:
+    raise ValueError("empty logits")
+  _lib.check(f(logits.data_ptr(), B * C, C, seq_len.data_ptr(), T, B, C, int(beam_width),
+               int(top_paths), int(bool(merge_repeated)), scorer.handle if scorer else None,
+               int(n_threads), ids.data_ptr(), lens.data_ptr(), lp.data_ptr()),
+             "os2s_ctc_beam_search")
+  return ids, lens, lp

@@ -90,9 +90,12 @@ class FullyConnectedTimeDecoder(Decoder):
 
 
 class FullyConnectedCTCDecoder(FullyConnectedTimeDecoder):
-  """FC over time + CTC greedy text generation (fc_decoders.py:160-251). The
-  language-model beam search op of the reference (KenLM custom TF op, :197-240) is
-  a CPU post-processing step outside the hot path and is not provided."""
+  """FC over time + CTC text generation (fc_decoders.py:160-251): greedy decode on the GPU,
+  or — `use_language_model` — the prefix beam search with a word n-gram language model
+  (:197-240). The reference binds a CPU-only custom TF op through `decoder_library_path`; here
+  it is the host entry point os2s_ctc_beam_search of the same C-ABI library, so
+  `decoder_library_path` is accepted and ignored. `lm_path`: ARPA text or the KenLM binary
+  layout the reference ships a sample of (see include/os2s.h)."""
 
   @staticmethod
   def get_required_params():
@@ -110,8 +113,22 @@ class FullyConnectedCTCDecoder(FullyConnectedTimeDecoder):
     super(FullyConnectedCTCDecoder, self).__init__(params, model, name, mode)
     self.params['use_language_model'] = self.params.get('use_language_model', False)
     if self.params['use_language_model']:
-      raise NotImplementedError(
-          "CTC beam search with a KenLM language model is outside the GPU hot path")
+      p = self.params
+      # one scorer (language model + letter trie) per decoder, as the op holds one (beam_search.cc:757)
+      scorer = capi.CtcScorer(p['lm_path'], p['trie_path'], p['alphabet_config_path'],
+                              p['alpha'], p['beta'], p.get('trie_weight', 0.1))
+
+      def decode_with_lm(logits, decoder_input, beam_width=p['beam_width'], top_paths=1,
+                         merge_repeated=False):
+        # fc_decoders.py:206-235; the logits leave the GPU here, as they do for the CPU op
+        seq_len = decoder_input['encoder_output']['src_length']
+        ids, lens, _ = capi.ctc_beam_search(logits.float().cpu(), seq_len.cpu(), beam_width,
+                                            scorer, top_paths=top_paths,
+                                            merge_repeated=merge_repeated)
+        return [(ids[:, 0].to(logits.device), lens[:, 0].to(logits.device))]
+
+      self.params['logits_to_outputs_func'] = decode_with_lm
+      return
 
     def decode_without_lm(logits, decoder_input, merge_repeated=True):
       # fc_decoders.py:244-251: greedy decode on fp32 logits, neg_sum_logits discarded

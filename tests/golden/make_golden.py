@@ -5,10 +5,13 @@ reference checkout (only runnable where /root/reference exists).
   ctc_test_meta.json   <- the expectations asserted by the reference's own test
                           ctc_decoder_with_lm/ctc-test.py:60-78 and the vocabulary
                           open_seq2seq/test_utils/toy_speech_data/vocab.txt
+  ctc_test_lm.binary   <- ctc_decoder_with_lm/ctc-test-lm.binary (1.4 KB KenLM bigram model, data)
+  ctc_test_lm.trie     <- ctc_decoder_with_lm/ctc-test-lm.trie   (1.1 KB letter trie, data)
 """
 import json
 import os
 import pickle
+import shutil
 
 import numpy as np
 
@@ -32,8 +35,18 @@ def main():
       # ctc_decoder_with_lm/ctc-test.py:66-67
       "greedy_text": "then seconds",
       "greedy_neg_sum_logits": -7079.117,
+      # ctc_decoder_with_lm/ctc-test.py:36-78: beam width 16, merge_repeated False
+      "beam_width": 16,
+      "beam_text": "then seconds",
+      "beam_log_prob": -1.1842575,
+      "lm_text": "ten seconds",
+      "lm_log_prob": -4.619581,
+      "lm_alpha": 2.0, "lm_beta": 0.5, "lm_trie_weight": 0.1,
       "tol": 1e-3,
   }
+  for src, dst in (("ctc-test-lm.binary", "ctc_test_lm.binary"), ("ctc-test-lm.trie", "ctc_test_lm.trie")):
+    shutil.copyfile(os.path.join(REF, "ctc_decoder_with_lm", src), os.path.join(OUT, dst))
+    os.chmod(os.path.join(OUT, dst), 0o644)
   with open(os.path.join(OUT, "ctc_test_meta.json"), "w") as f:
     json.dump(meta, f, indent=1)
   print("wrote", OUT)
