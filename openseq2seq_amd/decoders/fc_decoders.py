@@ -63,7 +63,9 @@ class FullyConnectedTimeDecoder(Decoder):
     logits = capi.conv1d_fwd(x.data, w, bias=self.bias.master[:V].contiguous(), out_f32=True,
                              time_major=True)
     out = {'logits': logits, 'src_length': enc['src_length']}
-    if 'logits_to_outputs_func' in self.params:
+    # text generation is only fetched outside training (the reference's graph has the op in
+    # every mode but evaluates it on demand); a training step asks through decode_outputs()
+    if 'logits_to_outputs_func' in self.params and self._mode != "train":
       out['outputs'] = self.params['logits_to_outputs_func'](logits, input_dict)
     if self._mode == "train" and tape is not None:
       dec = self
@@ -87,6 +89,14 @@ class FullyConnectedTimeDecoder(Decoder):
 
       tape.record(backward, [dec.kernel, dec.bias])
     return out
+
+
+def decode_outputs(decoder, decoder_output, encoder_src_length=None):
+  """'outputs' of a decoder output dict, computed now if the pass skipped it (train mode)."""
+  if 'outputs' in decoder_output:
+    return decoder_output['outputs']
+  fn = decoder.params['logits_to_outputs_func']
+  return fn(decoder_output['logits'], {'encoder_output': {'src_length': decoder_output['src_length']}})
 
 
 class FullyConnectedCTCDecoder(FullyConnectedTimeDecoder):

@@ -87,6 +87,12 @@ class Speech2Text(EncoderDecoderModel):
     enc = self._encoder.encode({'source_tensors': batch['source_tensors']})
     return self._decoder.decode({'encoder_output': enc})
 
+  def _decoded(self, dec):
+    """Decoded label ids of a decoder output: the decoder's own text generation (greedy, or the
+    language-model beam search when `use_language_model`), dense form of the SparseTensor."""
+    from ..decoders.fc_decoders import decode_outputs
+    return decode_outputs(self._decoder, dec)[0]
+
   def evaluate_batch(self, batch):
     """evaluate() of the reference (speech2text.py:316-340): greedy CTC decode of the batch,
     detokenise predictions and targets, return (word edit distance, word count)."""
@@ -94,7 +100,7 @@ class Speech2Text(EncoderDecoderModel):
     dl = self.get_data_layer()
     idx2char = dl.params['idx2char']
     dec = self.forward(batch)
-    ids, lens = capi.ctc_greedy_decode(dec['logits'], dec['src_length'])[:2]
+    ids, lens = self._decoded(dec)
     pred = dense_to_chars(ids.cpu().numpy(), lens.cpu().numpy(), idx2char)
     tgt, tgt_len = batch['target_tensors']
     true = dense_to_chars(tgt.cpu().numpy(), tgt_len.cpu().numpy(), idx2char)
@@ -104,10 +110,14 @@ class Speech2Text(EncoderDecoderModel):
     return finalize_wer(results_per_batch)
 
   def infer_batch(self, batch):
-    """infer() of the reference (speech2text.py:299-313): greedy transcripts + sample ids."""
-    from .. import capi
+    """infer() of the reference (speech2text.py:287-313): transcripts + sample ids; with
+    decoder_params['infer_logits_to_pickle'] the per-utterance logits [T, C] instead (input of
+    the offline language-model rescoring, scripts/decode.py)."""
     dec = self.forward(batch)
-    ids, lens = capi.ctc_greedy_decode(dec['logits'], dec['src_length'])[:2]
+    if self.params['decoder_params'].get('infer_logits_to_pickle', False):
+      logits = dec['logits'].transpose(0, 1).float().cpu().numpy()      # [B, T, C]
+      return [logits[i] for i in range(logits.shape[0])], batch['source_ids'].cpu().numpy()
+    ids, lens = self._decoded(dec)
     preds = dense_to_chars(ids.cpu().numpy(), lens.cpu().numpy(), self.get_data_layer().params['idx2char'])
     return preds, batch['source_ids'].cpu().numpy()
 
@@ -118,8 +128,22 @@ class Speech2Text(EncoderDecoderModel):
     for result, idx in results_per_batch:
       preds.extend(result)
       ids.extend(idx)
-    preds = np.array(preds, dtype=object)[np.argsort(np.hstack(ids))] if len(preds) else preds
+    order = np.argsort(np.hstack(ids)) if len(preds) else []
+    preds = [preds[i] for i in order]
     files = [f[0] for f in self.get_data_layer().all_files]
+    if self.params['decoder_params'].get('infer_logits_to_pickle', False):
+      # speech2text.py:327-346: {"logits": {file: [T, C]}, "step_size": seconds per frame, "vocab"}
+      import pickle
+      dl = self.get_data_layer()
+      scale = 1
+      for key in ('convnet_layers', 'conv_layers', 'cnn_layers'):
+        for c in self._encoder.params.get(key) or []:
+          scale *= c["stride"][0]
+      dump = {"logits": dict(zip(files, preds)), "step_size": scale * dl.params["window_stride"],
+              "vocab": dl.params['idx2char']}
+      with open(output_file, "wb") as f:
+        pickle.dump(dump, f, protocol=pickle.HIGHEST_PROTOCOL)
+      return
     with open(output_file, "w", newline="", encoding="utf-8") as f:
       w = csv.writer(f)
       w.writerow(["wav_filename", "predicted_transcript"])

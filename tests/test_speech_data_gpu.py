@@ -205,7 +205,9 @@ base_params = {
   },
   "decoder": FullyConnectedCTCDecoder,
   "decoder_params": {"initializer": "xavier_initializer", "use_language_model": False,
-                     "infer_logits_to_pickle": False},
+                     "infer_logits_to_pickle": False, "beam_width": 16, "alpha": 1.0, "beta": 0.0,
+                     "trie_weight": 0.1, "lm_path": "", "trie_path": "", "alphabet_config_path": "",
+                     "decoder_library_path": ""},
   "loss": CTCLoss, "loss_params": {},
   "data_layer": Speech2TextDataLayer,
   "data_layer_params": {"num_audio_features": 64, "input_type": "logfbank", "vocab_file": None,
@@ -258,6 +260,30 @@ def test_run_py_train_eval_infer_checkpoints(cuda, tmp_path):
   rows = list(csv.reader(open(inf)))
   assert rows[0] == ["wav_filename", "predicted_transcript"] and len(rows) == 6
   assert [r[0] for r in rows[1:]] == [r[0] for r in dev_rows]
+  # language-model beam search as the decoder's text generation (fc_decoders.py:197-240): the
+  # reference's sample bigram model only knows "ten seconds", so every word it emits is one of those
+  gold = os.path.join(repo, "tests", "golden")
+  alphabet = str(tmp_path / "alphabet.txt")
+  with open(alphabet, "w") as f:
+    f.write("\n".join([" "] + [chr(ord("a") + i) for i in range(26)] + ["'"]) + "\n")
+  inf_lm = str(tmp_path / "infer_lm.csv")
+  run("--mode=infer", "--infer_output_file=" + inf_lm, "--decoder_params/use_language_model=True",
+      "--decoder_params/lm_path=" + os.path.join(gold, "ctc_test_lm.binary"),
+      "--decoder_params/trie_path=" + os.path.join(gold, "ctc_test_lm.trie"),
+      "--decoder_params/alphabet_config_path=" + alphabet, "--decoder_params/beam_width=64",
+      "--decoder_params/alpha=4.0", "--decoder_params/beta=0.0", "--decoder_params/trie_weight=1.0",
+      "--decoder_params/decoder_library_path=ctc_decoder_with_lm/libctc_decoder_with_kenlm.so")
+  rows_lm = list(csv.reader(open(inf_lm)))
+  assert len(rows_lm) == 6 and [r[0] for r in rows_lm[1:]] == [r[0] for r in dev_rows]
+  assert rows_lm[1:] != rows[1:]
+  # logits dump for the offline rescoring script (speech2text.py:327-346)
+  import pickle
+  dump_path = str(tmp_path / "logits.pkl")
+  run("--mode=infer", "--infer_output_file=" + dump_path, "--decoder_params/infer_logits_to_pickle=True")
+  dump = pickle.load(open(dump_path, "rb"))
+  assert sorted(dump["logits"]) == sorted(r[0] for r in dev_rows) and abs(dump["step_size"] - 0.02) < 1e-9
+  lg = dump["logits"][dev_rows[0][0]]
+  assert lg.ndim == 2 and lg.shape[1] == 29 and dump["vocab"][0] == " "
   # --continue_learning resumes from the stored global step
   out = run("--mode=train", "--continue_learning", "--max_steps=35")
   assert "Restored checkpoint" in out and "(step 30)" in out
