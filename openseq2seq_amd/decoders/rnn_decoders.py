@@ -224,10 +224,26 @@ class RNNDecoderWithAttention(Decoder):
     self.Vpad = _round8(V)
     if self._weight_tied and not (p['attention_type'].startswith('gnmt') and E == H):
       raise NotImplementedError("weight_tied needs a GNMT decoder whose top cell size equals tgt_emb_size")
-    if not self._weight_tied:
-      self.embedding = Embedding(store, scope + "/DecoderEmbeddingMatrix", V, E)
     at = p['attention_type']
     self.gnmt = at.startswith('gnmt')
+    out_in = H if self.gnmt else self.M
+
+    def init(shape):
+      lim = math.sqrt(6.0 / (out_in + V))
+      w = (torch.rand(shape) * 2 - 1) * lim
+      w[:, V:, :] = 0.0          # vocabulary padding rows
+      return w
+
+    self.out_in = out_in
+    if self._weight_tied:
+      # the embedding IS the (transposed) output projection. The shared variable sits where the
+      # embedding matrix would (first decoder variable): its gradient is complete only after the
+      # embedding backward, the last decoder closure to run, and the overlapped gradient reducer
+      # relies on variables becoming final in reverse creation order.
+      self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
+      self.embedding = Embedding(store, None, V, E, table=self.proj)
+    else:
+      self.embedding = Embedding(store, scope + "/DecoderEmbeddingMatrix", V, E)
     nl = p['decoder_layers']
     if self.gnmt:
       mode = capi.SCORE_BAHDANAU_NORM
@@ -246,18 +262,8 @@ class RNNDecoderWithAttention(Decoder):
       for l in range(1, nl):
         self.upper.append(RNNDirection(store, "%s/multi_rnn_cell/cell_%d/lstm_cell" % (scope, l),
                                        cell, [H, self.M], H, reverse=False, forget_bias=fb))
-    out_in = H if self.gnmt else self.M
-
-    def init(shape):
-      lim = math.sqrt(6.0 / (out_in + V))
-      w = (torch.rand(shape) * 2 - 1) * lim
-      w[:, V:, :] = 0.0          # vocabulary padding rows
-      return w
-
-    self.out_in = out_in
-    self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
-    if self._weight_tied:      # the embedding IS the (transposed) output projection
-      self.embedding = Embedding(store, None, V, E, table=self.proj)
+    if not self._weight_tied:
+      self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
     apply_scope_initializer(store, first_param, p)
     return self
 

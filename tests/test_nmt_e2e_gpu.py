@@ -181,8 +181,10 @@ def test_gnmt_like_encoder_and_skip_connections(cuda, weight_tied):
        "decoder_dp_input_keep_prob": 1.0, "batch_size": 4, "dtype": "mixed", "weight_tied": weight_tied},
       None, mode="train")
   dec.build(store, memory_dim=enc.output_dim)
-  assert (store.params[-1].name.endswith("dense/kernel")) and \
-      any(p.name.endswith("DecoderEmbeddingMatrix") for p in store.params) == (not weight_tied)
+  assert any(p.name.endswith("DecoderEmbeddingMatrix") for p in store.params) == (not weight_tied)
+  if weight_tied:      # shared variable at the embedding's position: final last in backward
+    names = [q.name for q in store.params if q.name.startswith("ForwardPass/" + dec._name)]
+    assert names[0] == dec.proj.name
   lossf = BasicSequenceLoss({"tgt_vocab_size": V, "batch_size": 4, "offset_target_by_one": True,
                              "average_across_timestep": False, "do_mask": True, "dtype": "mixed"}, None)
   store.finalize()
