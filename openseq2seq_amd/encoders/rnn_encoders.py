@@ -179,15 +179,17 @@ class BidirectionalRNNEncoderWithEmbedding(Encoder):
     scope = "ForwardPass/" + self._name
     self.embedding = Embedding(store, scope + "/EncoderEmbeddingMatrix", self._src_vocab_size,
                                self._src_emb_size)
-    self.stacks = []   # [direction][layer]
-    for d, tag in enumerate(("FW", "BW")[:2 if self._bidirectional else 1]):
-      layers, cin = [], self._src_emb_size
-      for l in range(p['encoder_layers']):
-        layers.append(RNNDirection(
+    # variables are created in execution order (layer by layer, both directions of a layer run in
+    # one kernel sequence): the overlapped gradient reducer needs them final in reverse creation order
+    tags = ("FW", "BW")[:2 if self._bidirectional else 1]
+    self.stacks = [[] for _ in tags]   # [direction][layer]
+    cin = self._src_emb_size
+    for l in range(p['encoder_layers']):
+      for d, tag in enumerate(tags):
+        self.stacks[d].append(RNNDirection(
             store, "%s/%s/multi_rnn_cell/cell_%d/lstm_cell" % (scope, tag, l), cell, [cin], H,
             reverse=(d == 1), forget_bias=fb))
-        cin = H
-      self.stacks.append(layers)
+      cin = H
     apply_scope_initializer(store, first, p)
     return self
 

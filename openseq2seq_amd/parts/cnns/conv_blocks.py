@@ -30,9 +30,13 @@ def act_id(fn):
 
 
 class Tape(object):
-  """Reverse-mode tape. `record(fn, params)` also notes which parameters the closure
-  finalises; after each closure `on_done(min offset finalised so far)` lets the
-  data-parallel reducer start the all-reduce of complete gradient buckets."""
+  """Reverse-mode tape. `record(fn, params)` also notes which parameters the closure writes
+  gradients of. A parameter is FINAL once every closure that lists it has run; after each
+  closure `on_done(w)` tells the data-parallel reducer the watermark w: every parameter at a flat
+  offset >= w is final (parameters no closure lists receive no gradient), so complete gradient
+  buckets above it can be all-reduced while the rest of backward runs. Variables are created in
+  forward order, so the watermark normally falls with every closure; a variable used out of
+  creation order (a tied embedding, say) only delays it."""
 
   def __init__(self, on_done=None):
     self.ops = []
@@ -42,13 +46,29 @@ class Tape(object):
     self.ops.append((fn, params))
 
   def backward(self):
-    low = None
+    if self.on_done is None:
+      for fn, _ in reversed(self.ops):
+        fn()
+      self.ops = []
+      return
+    pending, by_id = {}, {}
+    for _, params in self.ops:
+      for p in params:
+        pending[id(p)] = pending.get(id(p), 0) + 1
+        by_id[id(p)] = p
+    order = sorted(by_id.values(), key=lambda p: -p.offset)
+    ptr = 0
     for fn, params in reversed(self.ops):
       fn()
-      if self.on_done is not None and params:
-        m = min(p.offset for p in params)
-        low = m if low is None else min(low, m)
-        self.on_done(low)
+      if params:
+        for p in params:
+          pending[id(p)] -= 1
+        moved = False
+        while ptr < len(order) and pending[id(order[ptr])] == 0:
+          ptr += 1
+          moved = True
+        if moved:
+          self.on_done(order[ptr - 1].offset)
     self.ops = []
 
 

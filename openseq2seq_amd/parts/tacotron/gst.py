@@ -64,9 +64,9 @@ class StyleEncoder(object):
     self.q = Dense(store, a + "/q", 128, att, False)
     self.k = Dense(store, a + "/k", E, att, False)
     self.v = Dense(store, a + "/v", E, att, False)
-    self.o = Dense(store, a + "/output_transform", att, att, False)
     self.att_v = store.add(a + "/attention_v", (64,), lambda s: (torch.rand(s) * 2 - 1) * math.sqrt(3.0 / 64),
                            kind="vector")
+    self.o = Dense(store, a + "/output_transform", att, att, False)
     # trainable=False random tokens (:475-486): not part of the parameter store
     g = torch.Generator().manual_seed(20190501)
     self.tokens = ((torch.rand(self.N, E, generator=g) * 2 - 1)).to(store.device)

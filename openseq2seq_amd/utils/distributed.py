@@ -75,6 +75,11 @@ class GradientReducer(object):
     per = (per // store.chunk) * store.chunk
     self.bounds = [(s, min(s + per, n)) for s in range(0, n, per)]
     self.stream = torch.cuda.Stream() if store.grads.is_cuda else None
+    # OS2S_CHECK_REDUCER=1 (one-rank debugging aid): keep a copy of every bucket as it is handed
+    # to the all-reduce and verify at finish() that no backward closure wrote to it afterwards —
+    # i.e. that variables really become final in the order mark_done() assumes
+    self.check = os.environ.get("OS2S_CHECK_REDUCER", "") == "1" and world_size == 1
+    self._snap = []
     self.reset()
 
   def reset(self):
@@ -83,6 +88,8 @@ class GradientReducer(object):
 
   def _reduce(self, s, e):
     g = self.store.grads
+    if self.check:
+      self._snap.append((s, e, g[s:e].clone()))
     if self.stream is None:
       dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
       return
@@ -105,6 +112,14 @@ class GradientReducer(object):
     self.mark_done(0)
     if self.stream is not None:
       torch.cuda.current_stream().wait_stream(self.stream)
+    if self.check:
+      for s, e, snap in self._snap:
+        if not torch.equal(snap, self.store.grads[s:e]):
+          bad = (snap != self.store.grads[s:e]).nonzero()[0].item() + s
+          names = [p.name for p in self.store.params if p.offset <= bad < p.offset + p.numel]
+          raise RuntimeError("gradient bucket [%d, %d) was reduced before it was final (offset %d, %s)"
+                             % (s, e, bad, names))
+      self._snap = []
     self.reset()
 
   def all_reduce(self):

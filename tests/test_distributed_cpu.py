@@ -89,3 +89,36 @@ def test_gloo_world2():
     assert p.exitcode == 0
   for r in res:
     assert r[1] and r[2] and r[3], r
+
+
+def test_tape_watermark_waits_for_out_of_order_and_shared_variables():
+  """The watermark handed to the reducer only passes a variable once EVERY closure listing it
+  has run, whatever the creation order (tied embeddings, a variable created after its consumer)."""
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+
+  class P(object):
+    def __init__(self, offset):
+      self.offset = offset
+
+  emb, l1, l2, late, proj = P(0), P(100), P(200), P(300), P(400)
+  marks, ran = [], []
+  tape = Tape(on_done=marks.append)
+  # forward order: embedding(emb), layer1(l1), [late is created after l2 but used before it],
+  # layer `late`, layer2(l2), projection(proj) which also writes the tied emb gradient
+  tape.record(lambda: ran.append("emb"), [emb])
+  tape.record(lambda: ran.append("l1"), [l1])
+  tape.record(lambda: ran.append("late"), [late])
+  tape.record(lambda: ran.append("l2"), [l2])
+  tape.record(lambda: ran.append("proj"), [proj, emb])
+  tape.record(lambda: ran.append("loss"))
+  tape.backward()
+  assert ran == ["loss", "proj", "l2", "late", "l1", "emb"]
+  # after proj: 400 final. after l2: `late` (300) above it is still pending -> no progress.
+  # after late: 300 and 200 final -> 200. then 100, then 0 (emb listed twice: final at the end)
+  assert marks == [400, 200, 100, 0]
+  assert tape.ops == []
+  # without a reducer the closures simply run
+  t2 = Tape()
+  t2.record(lambda: ran.append("x"), [emb])
+  t2.backward()
+  assert ran[-1] == "x"

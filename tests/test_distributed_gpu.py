@@ -17,3 +17,14 @@ def test_single_rank_rccl_path_matches_plain_run(cuda):
   r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dist_single_rank_check.py")],
                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
   assert r.returncode == 0 and "OK: reducer active in dist run: True" in r.stdout, r.stdout[-2000:]
+
+
+def test_gradients_are_final_when_their_bucket_is_reduced(cuda):
+  """Every model family, overlapped reducer with 1 MB buckets on a one-rank RCCL group and
+  OS2S_CHECK_REDUCER=1: no backward closure may write into a bucket after it was all-reduced
+  (shared variables — tied embeddings — are the ones that could)."""
+  repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  r = subprocess.run([sys.executable, os.path.join(repo, "tools", "reducer_finality_check.py")],
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=900)
+  assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:]
