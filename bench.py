@@ -295,6 +295,24 @@ def bench_transformer_infer(dev, batch=64, reps=2):
   return res
 
 
+def committed_pmc_traffic():
+  """HBM bytes per launch of the dominant kernel from the committed PMC pass of this workload
+  (tools/pmc_bench_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction
+  applied). Counters cannot be collected inside the timed run, so the JSON line carries the
+  number of the newest profiles/*_pmc_bench_traffic.json, or null if there is none."""
+  import glob
+  here = os.path.dirname(os.path.abspath(__file__))
+  files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_bench_traffic.json")))
+  if not files:
+    return None, None
+  try:
+    with open(files[-1]) as f:
+      d = json.load(f)
+    return float(d["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+  except Exception:
+    return None, None
+
+
 def main():
   args = parse()
   from openseq2seq_amd.utils import distributed as dist_utils
@@ -399,10 +417,11 @@ def main():
   if not args.no_kernel_timing:
     ms, fl, n = timer.summary()
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic, traffic_src = committed_pmc_traffic()
     out["roofline"] = {
-        "bound": "mfma", "kernel": "conv1d_igemm_kernel<128,128,2,2> (fwd + dgrad launches)",
+        "bound": "mfma", "kernel": "conv1d_igemm_kernel, all tile variants (fwd + dgrad launches)",
         "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_step": n / max(args.steps, 1),
         "avg_launch_ms": ms / max(n, 1),
         "time_share_of_step": ms / (1000.0 * dt),
