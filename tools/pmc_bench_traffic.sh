@@ -7,7 +7,7 @@ TAG=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_bench_traffic_$TAG
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no_transformer --no_other_configs --no_cpu_baseline --no_kernel_timing"
+CMD="python bench.py --steps 2 --warmup 1 --no-transformer --no-other-configs --no-cpu-baseline --no-kernel-timing"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o c -- $CMD > $OUT/f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -o c -- $CMD > $OUT/w.log 2>&1
 python - <<PY
