@@ -503,13 +503,15 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
         if (v == 8 && Cout < 512) continue;           // 256x320 / 256x384 tiles: wide layers only
         if (v == 9 && Cout < 640) continue;
         if (run(v) != OS2S_OK) continue;              // warm-up (also: unsupported LDS size)
-        hipEventRecord(e0, (hipStream_t)stream);
-        for (int r = 0; r < 3; ++r) run(v);
-        hipEventRecord(e1, (hipStream_t)stream);
-        hipEventSynchronize(e1);
-        float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (ms > 0.f && ms < best) { best = ms; choice = v; }
+        for (int rep = 0; rep < 3; ++rep) {           // best of three timings: the clock ramps
+          hipEventRecord(e0, (hipStream_t)stream);
+          for (int r = 0; r < 3; ++r) run(v);
+          hipEventRecord(e1, (hipStream_t)stream);
+          hipEventSynchronize(e1);
+          float ms = 0.f;
+          hipEventElapsedTime(&ms, e0, e1);
+          if (ms > 0.f && ms < best) { best = ms; choice = v; }
+        }
       }
       hipEventDestroy(e0);
       hipEventDestroy(e1);
