@@ -499,6 +499,9 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
       choice = base;
       hipEvent_t e0, e1;
       if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run(base);
+      // other streams (the weight-gradient side stream of the host layer) must be idle while the
+      // candidates are timed; tuning happens once per shape, outside any graph capture
+      hipDeviceSynchronize();
       for (int v : {base, 5, 8, 9}) {
         if (v == 8 && Cout < 512) continue;           // 256x320 / 256x384 tiles: wide layers only
         if (v == 9 && Cout < 640) continue;

@@ -28,8 +28,23 @@ struct LtPlan {
 };
 
 hipblasLtHandle_t g_handle = nullptr;
-void* g_ws = nullptr;
 constexpr size_t kWsBytes = 64ull << 20;
+// one workspace per stream: matmuls enqueued on different streams may run concurrently. A
+// stream that is being captured into a graph must not allocate: it gets the workspace created
+// with the handle (graph replays are serialised on their launch stream).
+void* g_ws_capture = nullptr;
+std::map<hipStream_t, void*> g_ws_by_stream;
+
+void* stream_workspace(hipStream_t s) {
+  auto it = g_ws_by_stream.find(s);
+  if (it != g_ws_by_stream.end()) return it->second;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return g_ws_capture;
+  void* p = nullptr;
+  if (hipMalloc(&p, kWsBytes) != hipSuccess) return nullptr;
+  g_ws_by_stream[s] = p;
+  return p;
+}
 std::mutex g_mu;
 std::map<std::array<long long, 10>, LtPlan> g_plans;
 
@@ -44,8 +59,10 @@ extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_handle) {
     if (hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return OS2S_ERR_LAUNCH;
-    if (hipMalloc(&g_ws, kWsBytes) != hipSuccess) return OS2S_ERR_LAUNCH;
+    if (hipMalloc(&g_ws_capture, kWsBytes) != hipSuccess) return OS2S_ERR_WORKSPACE;
   }
+  void* const g_ws = stream_workspace((hipStream_t)stream);
+  if (!g_ws) return OS2S_ERR_WORKSPACE;
   const std::array<long long, 10> key = {M, N, K, a_is_T, b_is_T, lda, ldb, ldc, c_f32, beta != 0.f};
   LtPlan& pl = g_plans[key];
   if (!pl.ok) {
@@ -87,6 +104,7 @@ extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_
           hipEventCreate(&e1) == hipSuccess) {
         const float one = 1.f, zero = 0.f;
         float best_ms = 1e30f;
+        hipDeviceSynchronize();      // no other stream's work under the timings
         for (int c = 0; c < found; ++c) {
           if (res[c].state != HIPBLAS_STATUS_SUCCESS || res[c].workspaceSize > kWsBytes) continue;
           auto run = [&]() {

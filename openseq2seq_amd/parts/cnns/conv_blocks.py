@@ -10,6 +10,7 @@ onto every conv input (tdnn_encoder.py:185-186,204-205), we fold that multiply
 into the producer's store.
 """
 import math
+import os
 
 import torch
 
@@ -27,6 +28,62 @@ def act_id(fn):
   if name not in ACT_IDS:
     raise NotImplementedError("activation %r" % (fn,))
   return ACT_IDS[name]
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+  """Side stream for work that may overlap the main stream inside one backward closure
+  (OS2S_WGRAD_STREAM=0 keeps everything on one stream)."""
+  if os.environ.get("OS2S_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
+    return None
+  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  st = _SIDE_STREAMS.get(key)
+  if st is None:
+    st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+  return st
+
+
+class on_side_stream(object):
+  """`with on_side_stream(device, *operands):` enqueues the body on the side stream, ordered
+  after everything the current stream has enqueued so far. For parameter-gradient kernels:
+  nothing in the rest of backward reads their result, the main stream re-joins at the end of
+  `Tape.backward` and the gradient reducer waits for the side stream itself. `operands` are the
+  tensors the body reads that the main stream's closures release afterwards (their memory is kept
+  until the side stream is done). With OS2S_WGRAD_STREAM=0 the body runs on the current stream."""
+
+  def __init__(self, device, *operands):
+    self.side = _side_stream(device)
+    self.operands = operands
+    self.ctx = None
+
+  def __enter__(self):
+    if self.side is not None:
+      self.side.wait_stream(torch.cuda.current_stream())
+      self.ctx = torch.cuda.stream(self.side)
+      self.ctx.__enter__()
+    return self
+
+  def __exit__(self, *exc):
+    if self.side is not None:
+      self.ctx.__exit__(*exc)
+      for t in self.operands:
+        if t is not None:
+          t.record_stream(self.side)
+    return False
+
+
+def side_streams():
+  return list(_SIDE_STREAMS.values())
+
+
+def join_side_streams():
+  """The current stream waits for everything enqueued on the side streams so far."""
+  if _SIDE_STREAMS:
+    cur = torch.cuda.current_stream()
+    for st in _SIDE_STREAMS.values():
+      cur.wait_stream(st)
 
 
 class Tape(object):
@@ -50,6 +107,7 @@ class Tape(object):
       for fn, _ in reversed(self.ops):
         fn()
       self.ops = []
+      join_side_streams()
       return
     pending, by_id = {}, {}
     for _, params in self.ops:
@@ -70,6 +128,7 @@ class Tape(object):
         if moved:
           self.on_done(order[ptr - 1].offset)
     self.ops = []
+    join_side_streams()
 
 
 class Act(object):
@@ -159,10 +218,16 @@ class ConvBN(object):
     return [self.kernel, self.gamma, self.beta]
 
   def backward_branch(self, inp, dy, f):
-    """Weight and data gradients of the convolution given dy = d(conv output)."""
-    capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
-                      pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
-                      accumulate=True)
+    """Weight and data gradients of the convolution given dy = d(conv output). Nothing in the
+    rest of backward depends on the weight gradient, so it runs on a side stream: its
+    workgroups fill the CUs the data-gradient kernels leave idle in their last, partial round of
+    tiles, and it overlaps the HBM-bound BatchNorm backward kernels of the layers below. The
+    main stream re-joins at the end of `Tape.backward`; the gradient reducer waits for the side
+    stream on its own stream."""
+    with on_side_stream(dy.device, inp.data, dy):
+      capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
+                        pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
+                        accumulate=True)
     if inp.requires_grad:
       if self.stride != 1:
         raise NotImplementedError("data-gradient of a strided conv")
@@ -229,11 +294,13 @@ class SepConvBN(ConvBN):
 
   def backward_branch(self, inp, dy, f):
     z = f["z"]
-    capi.conv1d_wgrad(z, dy, 1, pad_left=0, out=self.kernel.grad, accumulate=True)
+    with on_side_stream(dy.device, z, dy):          # parameter gradients: see ConvBN.backward_branch
+      capi.conv1d_wgrad(z, dy, 1, pad_left=0, out=self.kernel.grad, accumulate=True)
     dz = capi.conv1d_fwd(dy, self.kernel.wt16, pad_left=0, tout=z.shape[1])
     f["z"] = None
-    capi.depthwise_conv1d_wgrad(inp.data, dz, self.depthwise.grad, stride=self.stride, dil=self.dil,
-                                pad_left=f["pad_left"], in_len=inp.lens)
+    with on_side_stream(dy.device, inp.data, dz):
+      capi.depthwise_conv1d_wgrad(inp.data, dz, self.depthwise.grad, stride=self.stride, dil=self.dil,
+                                  pad_left=f["pad_left"], in_len=inp.lens)
     if inp.requires_grad:
       if self.stride != 1:
         raise NotImplementedError("data-gradient of a strided separable conv")

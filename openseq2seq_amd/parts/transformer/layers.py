@@ -13,7 +13,7 @@ import math
 import torch
 
 from ... import capi
-from ..cnns.conv_blocks import Act
+from ..cnns.conv_blocks import Act, on_side_stream
 
 
 SKINNY_MAX_ROWS = 512
@@ -105,10 +105,12 @@ class Dense(object):
         dz = capi.dropout_bwd(dy, keep, seed=seed)     # recomputed hash mask / keep
       else:
         dz = dy
-      # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs
-      capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
-      if lin.bias is not None:
-        _colsum_into(dz, lin.bias)
+      # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs. Nothing else in backward reads dW:
+      # it goes to the side stream (see ConvBN.backward_branch) and overlaps the chain below
+      with on_side_stream(dz.device, dz, x.data):
+        capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
+        if lin.bias is not None:
+          _colsum_into(dz, lin.bias)
       if x.requires_grad:
         g = x.grad_buffer()
         capi.matmul_lt(dz, lin.w, out=g, beta=1.0 if x.grad_init else 0.0)
@@ -269,7 +271,8 @@ class SharedEmbedding(object):
       def backward():
         dy = out.grad
         assert dy is not None
-        capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
+        with on_side_stream(dy.device, dy, x.data):
+          capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
         g = x.grad_buffer()
         capi.matmul_lt(dy, emb.table, out=g, beta=1.0 if x.grad_init else 0.0)
         x.grad_init = True

@@ -88,15 +88,20 @@ class GradientReducer(object):
 
   def _reduce(self, s, e):
     g = self.store.grads
-    if self.check:
-      self._snap.append((s, e, g[s:e].clone()))
     if self.stream is None:
+      if self.check:
+        self._snap.append((s, e, g[s:e].clone()))
       dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
       return
+    from ..parts.cnns.conv_blocks import side_streams
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
     self.stream.wait_event(ev)
+    for st in side_streams():       # weight-gradient kernels enqueued off the main stream
+      self.stream.wait_stream(st)
     with torch.cuda.stream(self.stream):
+      if self.check:
+        self._snap.append((s, e, g[s:e].clone()))
       dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
 
   def mark_done(self, offset):
