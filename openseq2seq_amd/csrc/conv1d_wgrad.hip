@@ -304,7 +304,11 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   const int total_steps = B * ceil_div(Tout, 64);
   int nsplit = 1;
   if (accumulate) {
-    const int target = wide ? 512 : 1024;  // ~2 waves of workgroups
+    // ~1 round of workgroups: the kernel shares the GPU with the data-gradient chain (side
+    // stream), where fewer, longer workgroups and fewer atomic passes over dW win slightly
+    // (Jasper step 56.1 -> 55.7 ms; 2 rounds were better when the kernel ran alone)
+    int target = wide ? 256 : 512;
+    if (const char* f = getenv("OS2S_WGRAD_TARGET")) { const int v = atoi(f); if (v > 0) target = v; }
     nsplit = ceil_div(target, base_blocks);
     const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;   // >= 8 steps per block
     if (nsplit > max_split) nsplit = max_split;
