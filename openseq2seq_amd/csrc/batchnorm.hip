@@ -221,7 +221,7 @@ struct BnBwdReduceArgs {
 
 template <int J_MAX>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs p) {
-  extern __shared__ float red[];  // [256][(1+J)*8]
+  __shared__ float red[256 * 8];
   const int C8 = p.C >> 3;
   const int G = min(C8, 256);
   const int RL = 256 / G;
@@ -287,40 +287,49 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
             const u32x4 y = *reinterpret_cast<const u32x4*>(p.y[j] + row * p.C + c0);
             const float yv[8] = {bflo(y[0]), bfhi(y[0]), bflo(y[1]), bfhi(y[1]),
                                  bflo(y[2]), bfhi(y[2]), bflo(y[3]), bfhi(y[3])};
-            // mean/rstd are re-read per row (L1-resident) to keep J*16 floats
-            // out of the register file
-            const f32x4 m0 = *reinterpret_cast<const f32x4*>(p.mean[j] + c0);
-            const f32x4 m1 = *reinterpret_cast<const f32x4*>(p.mean[j] + c0 + 4);
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(p.rstd[j] + c0);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(p.rstd[j] + c0 + 4);
+            // only sum(dz * y) is accumulated per row: sum(dz * xhat) = rstd * (sum(dz * y) -
+            // mean * sum(dz)) is formed once per thread below (no per-row mean / rstd loads)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              sx[j][e] += dr[e] * (yv[e] - m0[e]) * q0[e];
-              sx[j][4 + e] += dr[e + 4] * (yv[e + 4] - m1[e]) * q1[e];
-            }
+            for (int e = 0; e < 8; ++e) sx[j][e] += dr[e] * yv[e];
           }
       }
     }
   }
-  // block reduction over the RL row lanes
-  const int W = (1 + p.J) * 8;
+  // block reduction over the RL row lanes, one quantity (dz sum, then each input's dz*xhat sum)
+  // at a time through an 8 KB LDS buffer: the footprint does not grow with the number of
+  // residual inputs, so the 12-input instantiation keeps its occupancy
+  const bool writer = rl == 0 && (blockIdx.y * G + g) < C8;
+  auto reduce_q = [&](const float (&v)[8], int q) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[threadIdx.x * W + e] = sd[e];
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = v[e];
+    __syncthreads();
+    if (writer) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s = 0.f;
+        for (int k = 0; k < RL; ++k) s += red[(k * G + g) * 8 + e];
+        p.partial[((long long)blockIdx.x * (1 + p.J) + q) * p.C + c0 + e] = s;
+      }
+    }
+    __syncthreads();
+  };
+  reduce_q(sd, 0);
 #pragma unroll
   for (int j = 0; j < J_MAX; ++j)
     if (j < p.J) {
+      if (cvalid) {
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(p.mean[j] + c0);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(p.mean[j] + c0 + 4);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(p.rstd[j] + c0);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(p.rstd[j] + c0 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) red[threadIdx.x * W + (1 + j) * 8 + e] = sx[j][e];
-    }
-  __syncthreads();
-  if (rl == 0 && (blockIdx.y * G + g) < C8) {
-    for (int q = 0; q < 1 + p.J; ++q)
-      for (int e = 0; e < 8; ++e) {
-        float s = 0.f;
-        for (int k = 0; k < RL; ++k) s += red[(k * G + g) * W + q * 8 + e];
-        p.partial[((long long)blockIdx.x * (1 + p.J) + q) * p.C + c0 + e] = s;
+        for (int e = 0; e < 4; ++e) {
+          sx[j][e] = q0[e] * (sx[j][e] - m0[e] * sd[e]);
+          sx[j][4 + e] = q1[e] * (sx[j][4 + e] - m1[e] * sd[4 + e]);
+        }
       }
-  }
+      reduce_q(sx[j], 1 + j);
+    }
 }
 
 // Backward finalize for input j: reduce the partials -> dgamma, dbeta and the two
@@ -513,20 +522,12 @@ extern "C" int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_
   const int C8 = C / 8;
   const int G = C8 < 256 ? C8 : 256;
   dim3 grid(ceil_div((long long)B * T, kBwdRowsPerBlock), ceil_div(C8, G));
-  const size_t smem = (size_t)256 * (1 + J) * 8 * sizeof(float);
+  const size_t smem = 0;
   if (J <= 1) {
     OS2S_LAUNCH(bn_act_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, a);
   } else if (J <= 4) {
     OS2S_LAUNCH(bn_act_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute((const void*)bn_act_bwd_reduce_kernel<kMaxBnInputs>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess)
-        return OS2S_ERR_LAUNCH;
-      attr = true;
-    }
     OS2S_LAUNCH(bn_act_bwd_reduce_kernel<kMaxBnInputs>, grid, dim3(256), smem,
                 (hipStream_t)stream, a);
   }
