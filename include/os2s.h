@@ -752,6 +752,10 @@ int os2s_conv2d_toeplitz_reduce(os2s_stream_t stream, const float* dwexp, int KT
 int os2s_ctc_scorer_create(const char* lm_path, const char* trie_path, const char* alphabet_path,
                            float alpha, float beta, float trie_weight, void** scorer);
 void os2s_ctc_scorer_destroy(void* scorer);
+/* SetAlpha / SetBeta / SetTrieWeight of the scorer (beam_search.h:150-160): re-weight without
+ * re-reading the model (grid search over alpha, beta: scripts/decode.py). Not thread-safe
+ * against a running os2s_ctc_beam_search on the same scorer. */
+int os2s_ctc_scorer_set_weights(void* scorer, float alpha, float beta, float trie_weight);
 int os2s_ctc_scorer_ngram_score(const void* scorer, const char* const* words, int n_words,
                                 float* log10_prob);
 /* The reference's generate_trie tool (ctc_decoder_with_lm/generate_trie.cpp:32-64): one

@@ -1250,6 +1250,10 @@ class CtcScorer(object):
   def handle(self):
     return self._h
 
+  def set_weights(self, alpha, beta, trie_weight=0.1):
+    f = _fn("os2s_ctc_scorer_set_weights", (c_void_p, c_float, c_float, c_float))
+    _lib.check(f(self._h, float(alpha), float(beta), float(trie_weight)), "os2s_ctc_scorer_set_weights")
+
   def ngram_score(self, words):
     import ctypes
     arr = (ctypes.c_char_p * len(words))(*[w.encode() for w in words])
@@ -1287,3 +1291,11 @@ def ctc_beam_search(logits, seq_len, beam_width, scorer=None, top_paths=1, merge
                int(n_threads), ids.data_ptr(), lens.data_ptr(), lp.data_ptr()),
              "os2s_ctc_beam_search")
   return ids, lens, lp
+
+
+def ctc_generate_trie(alphabet_path, lm_path, vocab_path, trie_path):
+  """The reference's generate_trie tool (ctc_decoder_with_lm/generate_trie.cpp)."""
+  import ctypes
+  f = _fn("os2s_ctc_generate_trie", (ctypes.c_char_p,) * 4)
+  _lib.check(f(str(alphabet_path).encode(), str(lm_path).encode(), str(vocab_path).encode(),
+               str(trie_path).encode()), "os2s_ctc_generate_trie")

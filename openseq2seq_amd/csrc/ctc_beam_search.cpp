@@ -692,6 +692,14 @@ extern "C" int os2s_ctc_scorer_create(const char* lm_path, const char* trie_path
   return OS2S_OK;
 }
 
+// WordLMBeamScorer::SetAlpha / SetBeta / SetTrieWeight (beam_search.h:150-160)
+extern "C" int os2s_ctc_scorer_set_weights(void* scorer, float alpha, float beta, float trie_weight) {
+  if (!scorer) return OS2S_ERR_INVALID_ARG;
+  Scorer* s = static_cast<Scorer*>(scorer);
+  s->alpha = alpha; s->beta = beta; s->trie_weight = trie_weight;
+  return OS2S_OK;
+}
+
 extern "C" void os2s_ctc_scorer_destroy(void* scorer) { delete static_cast<Scorer*>(scorer); }
 
 extern "C" int os2s_ctc_scorer_ngram_score(const void* scorer, const char* const* words, int n_words,
