@@ -185,6 +185,11 @@ int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_t* dout,
 int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, int nparts,
                          int nq, int q, int C, long long count, float* dgamma,
                          float* dbeta, int accumulate, float* c1, float* c2);
+/* The same for all J inputs of a residual block end in one launch: partial is
+ * [nparts, 1 + J, C], dgamma / dbeta are J pointers (entries may be NULL), c1 / c2 are [J, C]. */
+int os2s_bn_bwd_finalize_multi(os2s_stream_t stream, const float* partial, int nparts, int J,
+                               int C, long long count, float* const* dgamma,
+                               float* const* dbeta, int accumulate, float* c1, float* c2);
 /* backward pass 2: dy = gamma*rstd*(dz - c1 - xhat*c2) */
 int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
                       const float* gamma, const float* mean, const float* rstd,

@@ -227,6 +227,22 @@ def bn_bwd_finalize(partial, q, count, dgamma, dbeta, accumulate, c1, c2):
              "os2s_bn_bwd_finalize")
 
 
+def bn_bwd_finalize_multi(partial, count, dgammas, dbetas, accumulate, c1, c2):
+  """All J inputs of a block end in one launch: c1, c2 are [J, C] (row j for input j)."""
+  import ctypes
+  nparts, nq, C = partial.shape
+  J = nq - 1
+  assert len(dgammas) == J and len(dbetas) == J and tuple(c1.shape) == (J, C) == tuple(c2.shape)
+  arr = ctypes.c_void_p * J
+  dg = arr(*[t.data_ptr() if t is not None else None for t in dgammas])
+  db = arr(*[t.data_ptr() if t is not None else None for t in dbetas])
+  f = _fn("os2s_bn_bwd_finalize_multi",
+          (c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p, c_void_p, c_int, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(partial, torch.float32), nparts, J, C, int(count), dg, db,
+               int(accumulate), _ptr(c1, torch.float32), _ptr(c2, torch.float32)),
+             "os2s_bn_bwd_finalize_multi")
+
+
 def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy):
   C = dz.shape[-1]
   rows = dz.numel() // C

@@ -334,6 +334,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
 
 // Backward finalize for input j: reduce the partials -> dgamma, dbeta and the two
 // means pass 2 needs (c1 = mean(dz), c2 = mean(dz*xhat)).
+struct BnFinMulti {
+  float* dgamma[kMaxBnInputs];
+  float* dbeta[kMaxBnInputs];
+};
+
+// All inputs of a block end in ONE launch (blockIdx.y = input): c1 / c2 are [J, C].
+__global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_multi_kernel(
+    const float* __restrict__ partial, int nparts, int nq, int C, double count, BnFinMulti ptrs,
+    int accumulate, float* __restrict__ c1_all, float* __restrict__ c2_all);
+
 __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nparts, int nq, int q, int C, double count,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
@@ -369,6 +379,47 @@ __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_kernel(
   c1[c] = (float)(sd / count);
   c2[c] = (float)(sx / count);
 }
+
+__global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_multi_kernel(
+    const float* __restrict__ partial, int nparts, int nq, int C, double count, BnFinMulti ptrs,
+    int accumulate, float* __restrict__ c1_all, float* __restrict__ c2_all) {
+  const int q = 1 + blockIdx.y;
+  float* const dgamma = ptrs.dgamma[blockIdx.y];
+  float* const dbeta = ptrs.dbeta[blockIdx.y];
+  float* const c1 = c1_all + (long long)blockIdx.y * C;
+  float* const c2 = c2_all + (long long)blockIdx.y * C;
+  __shared__ double sh_d[kFinLanes][64], sh_x[kFinLanes][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double sd = 0.0, sx = 0.0;
+  if (c < C) {
+    int i = pl;
+    for (; i + kFinLanes < nparts; i += 2 * kFinLanes) {
+      const float a0 = partial[((long long)i * nq + 0) * C + c];
+      const float b0 = partial[((long long)i * nq + q) * C + c];
+      const float a1 = partial[((long long)(i + kFinLanes) * nq + 0) * C + c];
+      const float b1 = partial[((long long)(i + kFinLanes) * nq + q) * C + c];
+      sd += (double)a0 + (double)a1;
+      sx += (double)b0 + (double)b1;
+    }
+    for (; i < nparts; i += kFinLanes) {
+      sd += (double)partial[((long long)i * nq + 0) * C + c];
+      sx += (double)partial[((long long)i * nq + q) * C + c];
+    }
+  }
+  sh_d[pl][cl] = sd;
+  sh_x[pl][cl] = sx;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  sd = 0.0; sx = 0.0;
+#pragma unroll
+  for (int l = 0; l < kFinLanes; ++l) { sd += sh_d[l][cl]; sx += sh_x[l][cl]; }
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sd;
+  c1[c] = (float)(sd / count);
+  c2[c] = (float)(sx / count);
+}
+
 
 // Backward pass 2 for input j: dy = gamma*rstd*(dz - c1 - xhat*c2)
 //   = A*dz + Bq*y + Cc with per-channel A, Bq, Cc held in registers; a thread owns
@@ -541,6 +592,19 @@ extern "C" int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, 
   OS2S_LAUNCH(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * kFinLanes), 0,
               (hipStream_t)stream, partial, nparts, nq, q, C, (double)count, dgamma, dbeta,
               accumulate, c1, c2);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_bn_bwd_finalize_multi(os2s_stream_t stream, const float* partial, int nparts,
+                                          int J, int C, long long count, float* const* dgamma,
+                                          float* const* dbeta, int accumulate, float* c1,
+                                          float* c2) {
+  OS2S_REQUIRE(partial && c1 && c2 && dgamma && dbeta && nparts >= 1 && J >= 1 && J <= kMaxBnInputs &&
+               count >= 1);
+  BnFinMulti ptrs;
+  for (int j = 0; j < J; ++j) { ptrs.dgamma[j] = dgamma[j]; ptrs.dbeta[j] = dbeta[j]; }
+  OS2S_LAUNCH(bn_bwd_finalize_multi_kernel, dim3(ceil_div(C, 64), J), dim3(64 * kFinLanes), 0,
+              (hipStream_t)stream, partial, nparts, 1 + J, C, (double)count, ptrs, accumulate, c1, c2);
   return OS2S_OK;
 }
 

@@ -420,12 +420,14 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     capi.bn_act_bwd_reduce(dout, out, [f["y"] for f in fw], [f["mean"] for f in fw],
                            [f["rstd"] for f in fw], dz, partial, lens, act, keep_prob, seed)
     result.grad = None
-    c1 = torch.empty(C, dtype=torch.float32, device=out.device)
-    c2 = torch.empty(C, dtype=torch.float32, device=out.device)
+    # dgamma / dbeta / the two means of every branch in ONE launch
+    c1 = torch.empty((J, C), dtype=torch.float32, device=out.device)
+    c2 = torch.empty((J, C), dtype=torch.float32, device=out.device)
+    capi.bn_bwd_finalize_multi(partial, rows, [br.gamma.grad for br in branches],
+                               [br.beta.grad for br in branches], True, c1, c2)
     for j, (br, inp, f) in enumerate(zip(branches, inputs, fw)):
-      capi.bn_bwd_finalize(partial, 1 + j, rows, br.gamma.grad, br.beta.grad, True, c1, c2)
       dy = torch.empty_like(f["y"])
-      capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1, c2, dy)
+      capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1[j], c2[j], dy)
       f["y"] = None
       br.backward_branch(inp, dy, f)
 
