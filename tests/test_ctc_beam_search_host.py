@@ -210,3 +210,33 @@ def test_scorer_errors(tmp_path, kat):
     f.write(" \na\nb\n")
   with pytest.raises(_lib.Os2sError):
     capi.CtcScorer(os.path.join(GOLD, "ctc_test_lm.binary"), trie, short, 1.0, 0.0)
+
+
+def test_raw_ctypes_binding_as_documented(kat):
+  """The stub of INTEGRATION.md §3 verbatim: plain ctypes + NumPy, no torch, no capi."""
+  import ctypes
+  from openseq2seq_amd.build import LIB_PATH
+  meta, seq, alphabet_path = kat
+  lib = ctypes.CDLL(LIB_PATH)
+  lib.os2s_ctc_scorer_create.argtypes = [ctypes.c_char_p] * 3 + [ctypes.c_float] * 3 + [ctypes.POINTER(ctypes.c_void_p)]
+  lib.os2s_ctc_beam_search.argtypes = ([ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p]
+                                       + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3)
+  lib.os2s_ctc_scorer_destroy.argtypes = [ctypes.c_void_p]
+  lib.os2s_ctc_scorer_destroy.restype = None
+  scorer = ctypes.c_void_p()
+  assert lib.os2s_ctc_scorer_create(os.path.join(GOLD, "ctc_test_lm.binary").encode(),
+                                    os.path.join(GOLD, "ctc_test_lm.trie").encode(), alphabet_path.encode(),
+                                    meta["lm_alpha"], meta["lm_beta"], meta["lm_trie_weight"],
+                                    ctypes.byref(scorer)) == 0
+  logits = np.ascontiguousarray(seq.numpy(), dtype=np.float32)
+  T, B, C = logits.shape
+  seq_len = np.array([T], dtype=np.int32)
+  ids = np.empty((B, 1, T), np.int32)
+  lens = np.empty((B, 1), np.int32)
+  logp = np.empty((B, 1), np.float32)
+  rc = lib.os2s_ctc_beam_search(logits.ctypes.data, B * C, C, seq_len.ctypes.data, T, B, C, meta["beam_width"], 1, 0,
+                                scorer, 0, ids.ctypes.data, lens.ctypes.data, logp.ctypes.data)
+  assert rc == 0
+  assert "".join(meta["vocab"][c] for c in ids[0, 0, :lens[0, 0]]) == meta["lm_text"]
+  assert abs(float(logp[0, 0]) - meta["lm_log_prob"]) < meta["tol"]
+  lib.os2s_ctc_scorer_destroy(scorer)
