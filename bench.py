@@ -171,7 +171,6 @@ class ConvTimer(object):
 
 def cpu_baseline(vocab_size=29):
   """Oracle training step (fp32, CPU) on a bounded sample of the same workload."""
-  import numpy as np
   from oracle import tdnn as otdnn, optim as oopt
   from openseq2seq_amd.configs.jasper import jasper_convnet_layers
   torch.manual_seed(0)

@@ -9,7 +9,7 @@ from __future__ import absolute_import, division, print_function
 import torch
 
 from .encoder import Encoder
-from .rnn_encoders import Embedding, dropout_act
+from .rnn_encoders import Embedding
 from .. import capi
 from ..parts.cnns.conv_blocks import Act, ConvBN, conv_bn_actv, reshape_act, xavier_normal_conv
 from ..parts.rnns.rnn_layers import RNNDirection, rnn_directions_forward

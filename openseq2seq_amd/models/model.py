@@ -23,7 +23,7 @@ from ..optimizers.flat_params import FlatParams
 from ..optimizers.optimizers import optimize_loss
 from ..parts.cnns.conv_blocks import Tape
 from ..utils import distributed as dist_utils
-from ..utils.utils import check_params, deco_print
+from ..utils.utils import check_params
 
 
 @six.add_metaclass(abc.ABCMeta)

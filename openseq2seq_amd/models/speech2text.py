@@ -4,7 +4,6 @@ metric (:356-360) and WER helpers (levenshtein :51-71, sparse_tensor_to_chars)."
 from __future__ import absolute_import, division, print_function
 
 import numpy as np
-import torch
 
 from .encoder_decoder import EncoderDecoderModel
 
@@ -96,7 +95,6 @@ class Speech2Text(EncoderDecoderModel):
   def evaluate_batch(self, batch):
     """evaluate() of the reference (speech2text.py:316-340): greedy CTC decode of the batch,
     detokenise predictions and targets, return (word edit distance, word count)."""
-    from .. import capi
     dl = self.get_data_layer()
     idx2char = dl.params['idx2char']
     dec = self.forward(batch)
