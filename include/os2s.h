@@ -773,6 +773,32 @@ int os2s_ctc_beam_search(const float* logits, long long ld_t, long long ld_b,
                          int top_paths, int merge_repeated, const void* scorer, int n_threads,
                          int32_t* out_ids, int32_t* out_len, float* out_log_prob);
 
+/* ------------------------------------------------------------------------
+ * The reference's second CTC decoder — the `ctc_decoders` module of decoders/ (swig wrapper used
+ * offline by scripts/decode.py): prefix beam search over softmax PROBABILITIES with an external
+ * scorer and a dictionary constraint. HOST entry points (host pointers, no stream).
+ * Replaces Scorer(alpha, beta, model_path, vocabulary) (decoders/scorer.cpp:16-52; reset_params,
+ * is_character_based, get_max_order, get_dict_size) and ctc_beam_search_decoder(_batch)
+ * (decoders/ctc_beam_search_decoder.cpp:18-178, 420-459): vocabulary = the n_vocab labels without
+ * the blank (blank = C - 1); the dictionary is every language-model word spellable with the
+ * vocabulary; lm_path as for os2s_ctc_scorer_create. probs element (t, b, c) at
+ * probs[t*ld_t + b*ld_b + c]; cutoff_prob / cutoff_top_n prune the labels of a frame
+ * (decoder_utils.cpp:7-37; the reference's defaults are 1.0 and 40). scorer may be NULL.
+ * Outputs as os2s_ctc_beam_search: out_ids [B, top_paths, T] padded with -1, out_len, out_score
+ * (natural-log acoustic score + alpha * log10 LM + beta per word, as the reference mixes them).
+ * ---------------------------------------------------------------------- */
+int os2s_ctc_dict_scorer_create(const char* lm_path, const char* const* vocabulary, int n_vocab,
+                                double alpha, double beta, void** scorer);
+void os2s_ctc_dict_scorer_destroy(void* scorer);
+int os2s_ctc_dict_scorer_set_weights(void* scorer, double alpha, double beta);
+int os2s_ctc_dict_scorer_info(const void* scorer, int* is_character_based, int* max_order,
+                              int* dict_size);
+int os2s_ctc_dict_beam_search(const float* probs, long long ld_t, long long ld_b,
+                              const int32_t* seq_len, int T, int B, int C, int beam_size,
+                              double cutoff_prob, int cutoff_top_n, int top_paths,
+                              const void* scorer, int n_threads, int32_t* out_ids,
+                              int32_t* out_len, float* out_score);
+
 #ifdef __cplusplus
 }
 #endif

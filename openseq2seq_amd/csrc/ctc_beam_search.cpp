@@ -751,3 +751,374 @@ extern "C" int os2s_ctc_beam_search(const float* logits, long long ld_t, long lo
   }
   return status.load();
 }
+
+// =============================================================================================
+// The reference's second decoder: the `ctc_decoders` module (decoders/*.cpp, a swig wrapper
+// around a prefix beam search over softmax PROBABILITIES with an external scorer and a dictionary
+// constraint), used offline by scripts/decode.py. Restated from
+// decoders/ctc_beam_search_decoder.cpp:18-178, path_trie.cpp:37-158, scorer.cpp:71-230,
+// decoder_utils.cpp:7-95. The OpenFST dictionary (a minimised automaton of {word + ' '}) is a
+// character trie here: any deterministic automaton of that language answers the two questions
+// the decoder asks (is there an arc, is the state final) identically.
+// =============================================================================================
+namespace {
+
+constexpr float kFltMax = std::numeric_limits<float>::max();
+constexpr float kFltMin = std::numeric_limits<float>::min();
+constexpr float kNeg = -kFltMax;
+constexpr double kOovScore = -1000.0;
+
+template <typename T>
+inline T lse2(T x, T y) {
+  if (x <= -std::numeric_limits<T>::max()) return y;
+  if (y <= -std::numeric_limits<T>::max()) return x;
+  const T m = std::max(x, y);
+  return std::log(std::exp(x - m) + std::exp(y - m)) + m;
+}
+
+struct DictScorer {
+  NGramLM lm;
+  std::vector<std::string> alphabet;
+  double alpha = 0.0, beta = 0.0;
+  bool char_based = true;
+  int space_id = -1, max_order = 0, dict_size = 0;
+  int V = 0;
+  std::vector<int32_t> arcs;     // [state][label] -> state or -1
+  std::vector<char> final_;
+
+  int32_t arc(int32_t state, int label) const { return arcs[(size_t)state * V + label]; }
+
+  // scorer.cpp:71-90
+  double log_cond_prob(const std::vector<uint32_t>& ids) const {
+    uint32_t hist[32];
+    int nh = 0;
+    double p = 0.0;
+    for (uint32_t w : ids) {
+      if (w == 0) return kOovScore;
+      p = lm.score(hist, nh, w);
+      if (nh == 32) { memmove(hist, hist + 1, sizeof(uint32_t) * 31); --nh; }
+      hist[nh++] = w;
+    }
+    return p;
+  }
+};
+
+struct PNode {
+  float b_prev = kNeg, nb_prev = kNeg, b_cur = kNeg, nb_cur = kNeg, score = kNeg;
+  int character = -1;
+  PNode* parent = nullptr;
+  bool exists = true;
+  int32_t dict_state = 0;
+  std::vector<std::pair<int, PNode*>> children;
+};
+
+void free_tree(PNode* n) {
+  for (auto& c : n->children) free_tree(c.second);
+  delete n;
+}
+
+struct DictDecoder {
+  const DictScorer* sc;      // may be null
+  bool use_dict;
+  int V;                     // labels without blank
+
+  // path_trie.cpp:37-86
+  PNode* get_path_trie(PNode* n, int c) const {
+    for (auto& ch : n->children)
+      if (ch.first == c) {
+        PNode* k = ch.second;
+        if (!k->exists) {
+          k->exists = true;
+          k->b_prev = k->nb_prev = k->b_cur = k->nb_cur = kNeg;
+        }
+        return k;
+      }
+    int32_t state = 0;
+    if (use_dict) {
+      const int32_t nxt = sc->arc(n->dict_state, c);
+      if (nxt < 0) {
+        if (sc->final_[n->dict_state]) n->dict_state = 0;     // re-armed; this attempt is refused
+        return nullptr;
+      }
+      state = nxt;
+    }
+    PNode* k = new PNode;
+    k->character = c; k->parent = n; k->dict_state = state;
+    n->children.emplace_back(c, k);
+    return k;
+  }
+  // walks up to (not including) a node whose character == stop, or the root, or max_steps
+  static PNode* path_vec(PNode* n, int stop, size_t max_steps, std::vector<int>* out) {
+    out->clear();
+    while (!(n->character == stop || n->character == -1 || out->size() == max_steps)) {
+      out->push_back(n->character);
+      n = n->parent;
+    }
+    std::reverse(out->begin(), out->end());
+    return n;
+  }
+  static void iterate(PNode* n, std::vector<PNode*>* out) {
+    if (n->exists) {
+      n->b_prev = n->b_cur; n->nb_prev = n->nb_cur;
+      n->b_cur = n->nb_cur = kNeg;
+      n->score = lse2(n->b_prev, n->nb_prev);
+      out->push_back(n);
+    }
+    for (size_t i = 0; i < n->children.size(); ++i) iterate(n->children[i].second, out);
+  }
+  static void remove(PNode* n) {
+    n->exists = false;
+    if (n->children.empty()) {
+      PNode* p = n->parent;
+      for (auto it = p->children.begin(); it != p->children.end(); ++it)
+        if (it->second == n) { p->children.erase(it); break; }
+      if (p->children.empty() && !p->exists) remove(p);
+      delete n;
+    }
+  }
+  static bool compare(const PNode* x, const PNode* y) {
+    if (x->score == y->score) return x->character != y->character && x->character < y->character;
+    return x->score > y->score;
+  }
+  // scorer.cpp:166-200 (word ids instead of strings; "" and unknown words map to 0 = OOV)
+  void make_ngram(PNode* prefix, std::vector<uint32_t>* ngram) const {
+    ngram->clear();
+    std::vector<int> vec;
+    std::string word;
+    PNode* cur = prefix;
+    for (int order = 0; order < sc->max_order; ++order) {
+      PNode* nn;
+      if (sc->char_based) { nn = path_vec(cur, sc->space_id, 1, &vec); cur = nn; }
+      else { nn = path_vec(cur, sc->space_id, (size_t)-1, &vec); cur = nn->parent; }
+      word.clear();
+      for (int c : vec) word += sc->alphabet[c];
+      ngram->push_back(sc->lm.word_index(word));
+      if (nn->character == -1) {
+        for (int i = 0; i < sc->max_order - order - 1; ++i) ngram->push_back(sc->lm.bos);
+        break;
+      }
+    }
+    std::reverse(ngram->begin(), ngram->end());
+  }
+
+  int run(const float* probs, long long ld, int T, int beam_size, double cutoff_prob, int cutoff_top_n,
+          int top_paths, int32_t* out_ids, int out_ld, int32_t* out_len, float* out_score) const {
+    const int C = V + 1, blank = V;
+    int space = -2;
+    if (sc) space = sc->space_id >= 0 ? sc->space_id : -2;
+    PNode* root = new PNode;
+    root->score = root->b_prev = 0.f;
+    std::vector<PNode*> prefixes{root};
+    std::vector<std::pair<int, double>> pidx;
+    std::vector<std::pair<int, float>> lpidx;
+    std::vector<uint32_t> ngram;
+    for (int t = 0; t < T; ++t) {
+      const float* prob = probs + (long long)t * ld;
+      float min_cutoff = kNeg;
+      bool full_beam = false;
+      if (sc) {
+        const size_t n = std::min(prefixes.size(), (size_t)beam_size);
+        std::sort(prefixes.begin(), prefixes.begin() + n, compare);
+        min_cutoff = prefixes[n - 1]->score + std::log(prob[blank]) - (float)std::max(0.0, sc->beta);
+        full_beam = n == (size_t)beam_size;
+      }
+      // decoder_utils.cpp:7-37
+      pidx.clear();
+      for (int i = 0; i < C; ++i) pidx.emplace_back(i, (double)prob[i]);
+      size_t cutoff_len = C;
+      if (cutoff_prob < 1.0 || (size_t)cutoff_top_n < cutoff_len) {
+        std::sort(pidx.begin(), pidx.end(),
+                  [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.second > b.second; });
+        if (cutoff_prob < 1.0) {
+          double cum = 0.0;
+          cutoff_len = 0;
+          for (size_t i = 0; i < pidx.size(); ++i) {
+            cum += pidx[i].second;
+            cutoff_len += 1;
+            if (cum >= cutoff_prob || cutoff_len >= (size_t)cutoff_top_n) break;
+          }
+        }
+      }
+      lpidx.clear();
+      for (size_t i = 0; i < cutoff_len; ++i)
+        lpidx.emplace_back(pidx[i].first, (float)std::log(pidx[i].second + kFltMin));
+      for (auto& cl : lpidx) {
+        const int c = cl.first;
+        const float lp = cl.second;
+        for (size_t i = 0; i < prefixes.size() && i < (size_t)beam_size; ++i) {
+          PNode* prefix = prefixes[i];
+          if (full_beam && lp + prefix->score < min_cutoff) break;
+          if (c == blank) {
+            prefix->b_cur = lse2(prefix->b_cur, lp + prefix->score);
+            continue;
+          }
+          if (c == prefix->character) prefix->nb_cur = lse2(prefix->nb_cur, lp + prefix->nb_prev);
+          PNode* nn = get_path_trie(prefix, c);
+          if (!nn) continue;
+          float log_p = kNeg;
+          if (c == prefix->character && prefix->b_prev > kNeg) log_p = lp + prefix->b_prev;
+          else if (c != prefix->character) log_p = lp + prefix->score;
+          if (sc && (c == space || sc->char_based)) {
+            make_ngram(sc->char_based ? nn : prefix, &ngram);
+            const float score = (float)(sc->log_cond_prob(ngram) * sc->alpha);
+            log_p += score;
+            log_p += (float)sc->beta;
+          }
+          nn->nb_cur = lse2(nn->nb_cur, log_p);
+        }
+      }
+      prefixes.clear();
+      iterate(root, &prefixes);
+      if (prefixes.size() >= (size_t)beam_size) {
+        std::nth_element(prefixes.begin(), prefixes.begin() + beam_size, prefixes.end(), compare);
+        for (size_t i = beam_size; i < prefixes.size(); ++i) remove(prefixes[i]);
+        prefixes.resize(beam_size);
+      }
+    }
+    if (sc && !sc->char_based) {
+      for (size_t i = 0; i < (size_t)beam_size && i < prefixes.size(); ++i) {
+        PNode* p = prefixes[i];
+        if (p->character != -1 && p->character != space) {
+          make_ngram(p, &ngram);
+          p->score += (float)(sc->log_cond_prob(ngram) * sc->alpha + sc->beta);
+        }
+      }
+    }
+    const size_t n = std::min(prefixes.size(), (size_t)beam_size);
+    std::sort(prefixes.begin(), prefixes.begin() + n, compare);
+    int rc = OS2S_OK;
+    if ((size_t)top_paths > n) rc = OS2S_ERR_INVALID_ARG;
+    std::vector<int> path;
+    for (int k = 0; k < top_paths && rc == OS2S_OK; ++k) {
+      path_vec(prefixes[k], -1, (size_t)-1, &path);
+      if ((int)path.size() > out_ld) { rc = OS2S_ERR_INVALID_ARG; break; }
+      for (int j = 0; j < out_ld; ++j) out_ids[(long long)k * out_ld + j] = j < (int)path.size() ? path[j] : -1;
+      out_len[k] = (int)path.size();
+      out_score[k] = prefixes[k]->score;
+    }
+    free_tree(root);
+    return rc;
+  }
+};
+
+}  // namespace
+
+// Scorer(alpha, beta, model_path, vocabulary) of decoders/scorer.cpp:16-52
+extern "C" int os2s_ctc_dict_scorer_create(const char* lm_path, const char* const* vocabulary, int n_vocab,
+                                           double alpha, double beta, void** scorer) {
+  if (!lm_path || !vocabulary || n_vocab < 1 || !scorer) return OS2S_ERR_INVALID_ARG;
+  std::unique_ptr<DictScorer> s(new DictScorer);
+  s->alpha = alpha; s->beta = beta;
+  const int rc = load_lm(lm_path, &s->lm);
+  if (rc != OS2S_OK) return rc;
+  s->max_order = s->lm.order;
+  s->V = n_vocab;
+  std::unordered_map<std::string, int> char_map;
+  for (int i = 0; i < n_vocab; ++i) {
+    if (!vocabulary[i]) return OS2S_ERR_INVALID_ARG;
+    s->alphabet.emplace_back(vocabulary[i]);
+    if (s->alphabet.back() == " ") s->space_id = i;
+    char_map[s->alphabet.back()] = i;
+  }
+  auto utf8_chars = [](const std::string& w, std::vector<std::string>* out) {
+    out->clear();
+    for (size_t p = 0; p < w.size();) {
+      size_t q = p + 1;
+      while (q < w.size() && ((unsigned char)w[q] & 0xc0) == 0x80) ++q;
+      out->emplace_back(w, p, q - p);
+      p = q;
+    }
+  };
+  std::vector<std::string> chars;
+  for (auto& kv : s->lm.words) {
+    if (kv.first == "<unk>" || kv.first == "<s>" || kv.first == "</s>") continue;
+    utf8_chars(kv.first, &chars);
+    if (chars.size() > 1) s->char_based = false;
+  }
+  if (!s->char_based) {
+    // fill_dictionary(add_space = true), scorer.cpp:203-230
+    s->arcs.assign((size_t)n_vocab, -1);
+    s->final_.assign(1, 0);
+    for (auto& kv : s->lm.words) {
+      utf8_chars(kv.first, &chars);
+      std::vector<int> seq;
+      bool ok = !chars.empty();
+      for (auto& ch : chars) {
+        auto it = char_map.find(ch);
+        if (it == char_map.end()) { ok = false; break; }
+        seq.push_back(it->second);
+      }
+      if (!ok) continue;
+      if (s->space_id >= 0) seq.push_back(s->space_id);
+      int32_t st = 0;
+      for (int l : seq) {
+        int32_t nxt = s->arcs[(size_t)st * n_vocab + l];
+        if (nxt < 0) {
+          nxt = (int32_t)s->final_.size();
+          s->final_.push_back(0);
+          s->arcs.resize(s->arcs.size() + n_vocab, -1);
+          s->arcs[(size_t)st * n_vocab + l] = nxt;
+        }
+        st = nxt;
+      }
+      s->final_[st] = 1;
+      s->dict_size++;
+    }
+  }
+  *scorer = s.release();
+  return OS2S_OK;
+}
+
+extern "C" void os2s_ctc_dict_scorer_destroy(void* scorer) { delete static_cast<DictScorer*>(scorer); }
+
+// reset_params / is_character_based / get_max_order / get_dict_size of the reference's Scorer
+extern "C" int os2s_ctc_dict_scorer_set_weights(void* scorer, double alpha, double beta) {
+  if (!scorer) return OS2S_ERR_INVALID_ARG;
+  static_cast<DictScorer*>(scorer)->alpha = alpha;
+  static_cast<DictScorer*>(scorer)->beta = beta;
+  return OS2S_OK;
+}
+
+extern "C" int os2s_ctc_dict_scorer_info(const void* scorer, int* is_character_based, int* max_order,
+                                         int* dict_size) {
+  if (!scorer) return OS2S_ERR_INVALID_ARG;
+  const DictScorer* s = static_cast<const DictScorer*>(scorer);
+  if (is_character_based) *is_character_based = s->char_based;
+  if (max_order) *max_order = s->max_order;
+  if (dict_size) *dict_size = s->dict_size;
+  return OS2S_OK;
+}
+
+extern "C" int os2s_ctc_dict_beam_search(const float* probs, long long ld_t, long long ld_b,
+                                         const int32_t* seq_len, int T, int B, int C, int beam_size,
+                                         double cutoff_prob, int cutoff_top_n, int top_paths,
+                                         const void* scorer, int n_threads, int32_t* out_ids,
+                                         int32_t* out_len, float* out_score) {
+  if (!probs || !seq_len || !out_ids || !out_len || !out_score) return OS2S_ERR_INVALID_ARG;
+  if (T < 1 || B < 1 || C < 2 || beam_size < 1 || top_paths < 1 || top_paths > beam_size || cutoff_top_n < 1)
+    return OS2S_ERR_INVALID_ARG;
+  const DictScorer* s = static_cast<const DictScorer*>(scorer);
+  if (s && s->V != C - 1) return OS2S_ERR_INVALID_ARG;
+  for (int b = 0; b < B; ++b)
+    if (seq_len[b] < 0 || seq_len[b] > T) return OS2S_ERR_INVALID_ARG;
+  int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  nt = std::max(1, std::min(nt, B));
+  std::atomic<int> next(0), status(OS2S_OK);
+  auto work = [&]() {
+    DictDecoder dec;
+    dec.sc = s; dec.use_dict = s && !s->char_based; dec.V = C - 1;
+    for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+      const int rc = dec.run(probs + (long long)b * ld_b, ld_t, seq_len[b], beam_size, cutoff_prob, cutoff_top_n,
+                             top_paths, out_ids + (long long)b * top_paths * T, T,
+                             out_len + (long long)b * top_paths, out_score + (long long)b * top_paths);
+      if (rc != OS2S_OK) status.store(rc);
+    }
+  };
+  if (nt == 1) work();
+  else {
+    std::vector<std::thread> pool;
+    for (int i = 0; i < nt; ++i) pool.emplace_back(work);
+    for (auto& th : pool) th.join();
+  }
+  return status.load();
+}

@@ -6,13 +6,14 @@ one decoding pass written as CSV): the input is the pickle `run.py --mode=infer`
 decoder_params['infer_logits_to_pickle'] = True (models/speech2text.py:327-346) and the csv of
 file names (+ transcripts for `eval`).
 
-The reference script calls a second, separately built decoder (the swig module under
-decoders/, OpenFST dictionary + KenLM). Here the decoding is the prefix beam search of the C-ABI
-library (os2s_ctc_beam_search: the reference's in-graph decoder, ctc_decoder_with_lm/), which
-takes the raw logits and a letter trie next to the language model:
-  --trie          the text trie of generate_trie; built on the fly from the unigrams of an ARPA
-                  model if omitted
-  --trie_weight   weight of the letter-prefix score (the in-graph decoder's trie_weight)
+Two decoders of the C-ABI library can do the rescoring (--decoder):
+  ctc_decoders         (default) the decoder the reference script uses: the `ctc_decoders` module of
+                       decoders/ (softmax probabilities, dictionary built from the LM vocabulary,
+                       score = alpha * log10 P(word | history) + beta per word) — os2s_ctc_dict_*
+  ctc_decoder_with_lm  the reference's in-graph decoder (raw logits, letter trie):
+      --trie          the text trie of generate_trie; built on the fly from the unigrams of an
+                      ARPA model if omitted
+      --trie_weight   weight of the letter-prefix score
 The language model is an ARPA file or a KenLM binary of the supported layout (include/os2s.h).
 """
 from __future__ import absolute_import, division, print_function
@@ -40,6 +41,7 @@ def parse(argv=None):
                   help="CSV file with audio filenames (and ground truth transcriptions for 'eval' mode)")
   ap.add_argument("--lm", required=True, help="language model: ARPA text or KenLM binary")
   ap.add_argument("--vocab", required=True, help="vocab file with characters (alphabet)")
+  ap.add_argument("--decoder", default="ctc_decoders", choices=["ctc_decoders", "ctc_decoder_with_lm"])
   ap.add_argument("--trie", help="letter trie (generate_trie format); default: built from the ARPA unigrams")
   ap.add_argument("--trie_weight", type=float, default=0.1)
   ap.add_argument("--alpha", type=float, required=True, help="value of LM weight")
@@ -149,46 +151,66 @@ def main(argv=None):
   batch, lens = batch_logits(logits, names)
   if batch.shape[2] != len(alphabet) + 1:
     raise SystemExit("logits have %d classes, the alphabet %d labels (+ blank)" % (batch.shape[2], len(alphabet)))
+  def greedy_texts():
+    out = []
+    for b in range(len(names)):
+      best = batch[:int(lens[b]), b].argmax(-1).tolist()
+      s_, prev = [], -1
+      for c in best:
+        if c != prev and c != len(alphabet):
+          s_.append(alphabet[c])
+        prev = c
+      out.append("".join(s_))
+    return out
+
   with tempfile.TemporaryDirectory() as workdir:
-    trie = args.trie or build_trie(args, alphabet, workdir)
-    scorer = capi.CtcScorer(args.lm, trie, args.vocab, args.alpha, args.beta, args.trie_weight)
+    if args.decoder == "ctc_decoders":
+      from openseq2seq_amd import ctc_decoders
+      scorer = ctc_decoders.Scorer(args.alpha, args.beta, args.lm, alphabet)
+      x = batch.numpy()
+      x = np.exp(x - x.max(-1, keepdims=True))
+      probs = x / x.sum(-1, keepdims=True)
+      split = [probs[:int(lens[b]), b] for b in range(len(names))]
+
+      def decode(alpha, beta, n_best):
+        scorer.reset_params(alpha, beta)
+        res = ctc_decoders.ctc_beam_search_decoder_batch(split, alphabet, args.beam_width, os.cpu_count() or 1,
+                                                         ext_scoring_func=scorer)
+        return [r[:n_best] for r in res]
+    else:
+      trie = args.trie or build_trie(args, alphabet, workdir)
+      scorer = capi.CtcScorer(args.lm, trie, args.vocab, args.alpha, args.beta, args.trie_weight)
+
+      def decode(alpha, beta, n_best):
+        scorer.set_weights(alpha, beta, args.trie_weight)
+        ids, ln, lp = capi.ctc_beam_search(batch, lens, args.beam_width, scorer, top_paths=n_best)
+        return [[(float(lp[b, k]), texts_from_ids(ids, ln, alphabet, k)[b]) for k in range(n_best)]
+                for b in range(len(names))]
+
     if args.mode == "eval":
-      # greedy (best path) decode on the host: argmax, merge repeats, drop blanks
-      greedy = []
-      for b, n in enumerate(names):
-        best = batch[:int(lens[b]), b].argmax(-1).tolist()
-        s, prev = [], -1
-        for c in best:
-          if c != prev and c != len(alphabet):
-            s.append(alphabet[c])
-          prev = c
-        greedy.append("".join(s))
-      print("Greedy WER = {:.4f}".format(word_error_rate(labels, greedy)))
+      print("Greedy WER = {:.4f}".format(word_error_rate(labels, greedy_texts())))
       best = {"wer": 1e6, "alpha": 0.0, "beta": 0.0, "beams": None}
+      n_best = min(args.beam_width, 8) if args.dump_all_beams_to else 1
       for alpha in np.arange(args.alpha, args.alpha_max + args.alpha_step / 10.0, args.alpha_step):
         for beta in np.arange(args.beta, args.beta_max + args.beta_step / 10.0, args.beta_step):
-          scorer.set_weights(alpha, beta, args.trie_weight)
-          top = min(args.beam_width, 8) if args.dump_all_beams_to else 1
-          ids, ln, lp = capi.ctc_beam_search(batch, lens, args.beam_width, scorer, top_paths=top)
-          wer = word_error_rate(labels, texts_from_ids(ids, ln, alphabet))
+          res = decode(alpha, beta, n_best)
+          wer = word_error_rate(labels, [r[0][1] for r in res])
           if wer < best["wer"]:
-            best.update(wer=wer, alpha=alpha, beta=beta, beams=(ids, ln, lp))
+            best.update(wer=wer, alpha=alpha, beta=beta, beams=res)
           print("alpha={:.2f}, beta={:.2f}: WER={:.4f}".format(alpha, beta, wer))
       print("BEST: alpha={:.2f}, beta={:.2f}, WER={:.4f}".format(best["alpha"], best["beta"], best["wer"]))
       if args.dump_all_beams_to:
-        ids, ln, lp = best["beams"]
         with open(args.dump_all_beams_to, "w", encoding="utf-8") as f:
-          for b in range(ids.shape[0]):
+          for beam in best["beams"]:
             f.write("B=>>>>>>>>\n")
-            for k in range(ids.shape[1]):
-              f.write("{} 0.0 0.0 {}\n".format(float(lp[b, k]), texts_from_ids(ids, ln, alphabet, k)[b]))
+            for score, text in beam:
+              f.write("{} 0.0 0.0 {}\n".format(score, text))
             f.write("E=>>>>>>>>\n")
       return best
     if args.mode == "infer":
       if not args.infer_output_file:
         raise SystemExit("--infer_output_file is required in 'infer' mode")
-      ids, ln, _ = capi.ctc_beam_search(batch, lens, args.beam_width, scorer)
-      preds = texts_from_ids(ids, ln, alphabet)
+      preds = [r[0][1] for r in decode(args.alpha, args.beta, 1)]
       with open(args.infer_output_file, "w", newline="", encoding="utf-8") as f:
         w = csv.writer(f)
         w.writerow(["wav_filename", "transcript"])

@@ -43,7 +43,7 @@ def _main():
 def test_eval_grid_search_and_infer(tmp_path, capsys):
   meta, logits, labels, vocab = _inputs(tmp_path)
   main = _main()
-  common = ["--logits", logits, "--labels", labels, "--vocab", vocab,
+  common = ["--logits", logits, "--labels", labels, "--vocab", vocab, "--decoder", "ctc_decoder_with_lm",
             "--lm", os.path.join(GOLD, "ctc_test_lm.binary"), "--trie", os.path.join(GOLD, "ctc_test_lm.trie"),
             "--beam_width", "16"]
   beams = str(tmp_path / "beams.txt")
@@ -70,5 +70,22 @@ def test_trie_built_from_arpa_unigrams(tmp_path, capsys):
             "\\2-grams:\n-0.1898795\t<s> ten\n-0.1898795\tten seconds\n-0.1898795\tseconds </s>\n\n\\end\\\n")
   main = _main()
   best = main(["--logits", logits, "--labels", labels, "--vocab", vocab, "--lm", arpa, "--beam_width", "16",
-               "--mode", "eval", "--alpha", "2.0", "--beta", "0.5"])
+               "--decoder", "ctc_decoder_with_lm", "--mode", "eval", "--alpha", "2.0", "--beta", "0.5"])
   assert best["wer"] == 0.0
+
+
+def test_default_decoder_is_the_reference_scripts_decoder(tmp_path, capsys):
+  """--decoder ctc_decoders (default): the module scripts/decode.py of the reference calls."""
+  meta, logits, labels, vocab = _inputs(tmp_path)
+  main = _main()
+  common = ["--logits", logits, "--labels", labels, "--vocab", vocab, "--beam_width", "16",
+            "--lm", os.path.join(GOLD, "ctc_test_lm.binary")]
+  beams = str(tmp_path / "beams.txt")
+  best = main(common + ["--mode", "eval", "--alpha", "2.0", "--beta", "0.5", "--dump_all_beams_to", beams])
+  out = capsys.readouterr().out
+  assert "Greedy WER = 0.5000" in out and "alpha=2.00, beta=0.50: WER=0.0000" in out
+  assert abs(best["beams"][0][0][0] + 4.0845) < 1e-3         # scripts/ctc_decoders_test.py:79
+  assert open(beams).read().count("E=>>>>>>>>") == 2
+  res = str(tmp_path / "out.csv")
+  main(common + ["--mode", "infer", "--alpha", "2.0", "--beta", "0.5", "--infer_output_file", res])
+  assert list(csv.reader(open(res)))[1] == ["a.wav", "ten seconds"]
