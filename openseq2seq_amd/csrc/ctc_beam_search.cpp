@@ -870,6 +870,7 @@ struct DictDecoder {
     n->exists = false;
     if (n->children.empty()) {
       PNode* p = n->parent;
+      if (!p) return;      // the root is never freed here (an ancestor of every surviving prefix)
       for (auto it = p->children.begin(); it != p->children.end(); ++it)
         if (it->second == n) { p->children.erase(it); break; }
       if (p->children.empty() && !p->exists) remove(p);
