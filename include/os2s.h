@@ -739,10 +739,20 @@ int os2s_conv2d_toeplitz_reduce(os2s_stream_t stream, const float* dwexp, int KT
  * rescoring :730-739) with WordLMBeamScorer (ctc_decoder_with_lm/beam_search.h:32-217), as bound
  * by FullyConnectedCTCDecoder.decode_with_lm (open_seq2seq/decoders/fc_decoders.py:206-235).
  *
- * os2s_ctc_scorer_create: lm_path = an ARPA text file (any order <= 8), or a KenLM binary of the
- *   type the reference's op loads (QuantArrayTrieModel, beam_search.h:22) — order 2 only, the one
- *   layout the reference ships a sample of (ctc-test-lm.binary); other binaries return
- *   OS2S_ERR_UNSUPPORTED (convert with the ARPA file they were built from). trie_path = the text
+ * os2s_ctc_scorer_create: lm_path = an ARPA text file (any order <= 8), or a KenLM binary
+ *   (format version 5) in one of the two layouts the reference ships a sample of:
+ *     - model type 5, the type the reference's op loads (QuantArrayTrieModel, beam_search.h:22),
+ *       order 2 (ctc-test-lm.binary);
+ *     - model type 0 (probing hash tables, kenlm's default; order <= 8): after the common header
+ *       and n-gram counts, the vocabulary {u32 version, u32 bound} + B(count[0]) packed 12-byte
+ *       buckets {u64 MurmurHash64A(word), u32 id}, B(n) = max(n + 1, (u64)(multiplier * n));
+ *       (count[0] + 1) unigrams {f32 prob, f32 backoff}; per middle order B(count) buckets
+ *       {u64 key, f32 prob, f32 backoff}; highest order B(count) packed {u64 key, f32 prob};
+ *       key(w1..wn) = combine(..combine(combine(wn, wn-1), wn-2).., w1), combine(c, w) =
+ *       c * 8978948897894561157 ^ (1 + w) * 17894857484156487943; empty bucket = key 0; the sign
+ *       bit of a stored probability is a flag; word strings follow in id order
+ *       (toy_speech_data/toy_data-lm.binary);
+ *   other binaries return OS2S_ERR_UNSUPPORTED (use the ARPA file they were built from). trie_path = the text
  *   letter trie written by generate_trie (trie_node.h:46-82); alphabet_path = one label per line
  *   (alphabet.h:24-40), C - 1 labels, blank = C - 1 is implied. alpha weighs log10 P(word |
  *   history), beta is the per-word bonus, trie_weight weighs the letter-prefix score.

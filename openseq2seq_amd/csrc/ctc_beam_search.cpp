@@ -41,6 +41,7 @@
 namespace {
 
 constexpr float kLogZero = -std::numeric_limits<float>::infinity();
+constexpr int kMaxLmOrder = 8;
 
 inline float log_sum_exp(float a, float b) {
   if (a == kLogZero) return b;
@@ -58,6 +59,22 @@ struct NGramLM {
   uint32_t bos = 0;
   std::vector<std::vector<Entry>> entries;                // [order][node]
   std::vector<std::unordered_map<uint64_t, uint32_t>> index;   // order n>=2: (ctx node, word) -> node
+
+  // kenlm "probing" binaries: orders >= 2 are only known by the chained 64-bit hash of their
+  // word ids (hashed[n-1]); the forward trie above stays empty for them
+  bool use_hash = false;
+  std::vector<std::unordered_map<uint64_t, Entry>> hashed;
+  static uint64_t combine(uint64_t current, uint32_t next) {       // lm/search_hashed.hh (kenlm)
+    return (current * 8978948897894561157ULL) ^ ((uint64_t)(1 + next) * 17894857484156487943ULL);
+  }
+  // entry of the n-gram ids[0..n): keyed by its LAST word first, then the preceding ones
+  const Entry* lookup_hashed(const uint32_t* ids, int n) const {
+    if (n == 1) return ids[0] < entries[0].size() ? &entries[0][ids[0]] : nullptr;
+    uint64_t node = ids[n - 1];
+    for (int i = n - 2; i >= 0; --i) node = combine(node, ids[i]);
+    auto it = hashed[n - 1].find(node);
+    return it == hashed[n - 1].end() ? nullptr : &it->second;
+  }
 
   uint32_t word_index(const std::string& w) const {
     auto it = words.find(w);
@@ -93,6 +110,22 @@ struct NGramLM {
     const int nc = std::min(nh, order - 1);
     const uint32_t* ctx = hist + (nh - nc);
     uint32_t key[16];
+    if (use_hash) {
+      for (int start = 0; start <= nc; ++start) {
+        const int n = nc - start;
+        for (int i = 0; i < n; ++i) key[i] = ctx[start + i];
+        key[n] = w;
+        const Entry* e = lookup_hashed(key, n + 1);
+        if (!e) continue;
+        float p = e->prob;
+        for (int s = 0; s < start; ++s) {
+          const Entry* b = lookup_hashed(ctx + s, nc - s);
+          if (b) p += b->backoff;
+        }
+        return p;
+      }
+      return -100.f;
+    }
     for (int start = 0; start <= nc; ++start) {
       const int n = nc - start;
       for (int i = 0; i < n; ++i) key[i] = ctx[start + i];
@@ -206,7 +239,69 @@ inline int required_bits(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } re
 
 const char kKenlmMagic[] = "mmap lm http://kheafield.com/code format version 5\n";
 
-// KenLM binary, model type 5 (quantised array trie), order 2. Layout in os2s.h / oracle.
+// KenLM binary, model type 0 (probing hash tables, kenlm's default; what the ctc_decoders scorer
+// loads through LoadVirtual). Layout: include/os2s.h — validated on the reference's
+// toy_data-lm.binary (every stored key reproduced by the hash chain, every context sums to 1).
+int read_kenlm_probing(const std::vector<unsigned char>& d, size_t size, NGramLM* lm) {
+  size_t off = 0x58;
+  const int order = d[off];
+  float mult;
+  memcpy(&mult, d.data() + off + 4, 4);
+  if (order < 1 || order > kMaxLmOrder || !d[off + 12]) return OS2S_ERR_UNSUPPORTED;
+  std::vector<uint64_t> counts(order);
+  if (off + 20 + 8 * (size_t)order > size) return OS2S_ERR_INVALID_ARG;
+  memcpy(counts.data(), d.data() + off + 20, 8 * (size_t)order);
+  off = (off + 20 + 8 * (size_t)order + 7) & ~(size_t)7;
+  auto buckets = [&](uint64_t n) { return std::max<uint64_t>(n + 1, (uint64_t)(mult * (float)n)); };
+  off += 8 + 12 * buckets(counts[0]);
+  if (off + 8 * (counts[0] + 1) > size) return OS2S_ERR_INVALID_ARG;
+  lm->order = order;
+  lm->entries.assign(order, {});
+  lm->index.assign(order, {});
+  lm->hashed.assign(order, {});
+  lm->use_hash = true;
+  lm->words.clear();
+  lm->entries[0].resize(counts[0]);
+  for (uint64_t w = 0; w < counts[0]; ++w) {
+    float pb[2];
+    memcpy(pb, d.data() + off + 8 * w, 8);
+    lm->entries[0][w] = NGramLM::Entry{-fabsf(pb[0]), pb[1]};     // sign bit = flag
+  }
+  off += 8 * (counts[0] + 1);
+  for (int n = 2; n <= order; ++n) {
+    const uint64_t nb = buckets(counts[n - 1]);
+    const size_t esz = n < order ? 16 : 12;
+    if (off + esz * nb > size) return OS2S_ERR_INVALID_ARG;
+    auto& tab = lm->hashed[n - 1];
+    tab.reserve(counts[n - 1] * 2);
+    for (uint64_t i = 0; i < nb; ++i) {
+      uint64_t key;
+      float pb[2] = {0.f, 0.f};
+      memcpy(&key, d.data() + off + esz * i, 8);
+      memcpy(pb, d.data() + off + esz * i + 8, esz - 8);
+      if (key) tab[key] = NGramLM::Entry{-fabsf(pb[0]), n < order ? pb[1] : 0.f};
+    }
+    if (tab.size() != counts[n - 1]) return OS2S_ERR_INVALID_ARG;
+    off += esz * nb;
+  }
+  // strings in id order
+  size_t p = off;
+  for (uint64_t i = 0; i < counts[0] && p < size; ++i) {
+    const char* str = (const char*)d.data() + p;
+    const size_t len = strnlen(str, size - p);
+    lm->words[std::string(str, len)] = (uint32_t)i;
+    p += len + 1;
+  }
+  if (lm->words.size() != counts[0]) return OS2S_ERR_INVALID_ARG;
+  auto unk = lm->words.find("<unk>");
+  auto bos = lm->words.find("<s>");
+  if (unk == lm->words.end() || unk->second != 0 || bos == lm->words.end()) return OS2S_ERR_INVALID_ARG;
+  lm->bos = bos->second;
+  return OS2S_OK;
+}
+
+// KenLM binary: model type 0 (above) or model type 5 (quantised array trie), order 2. Layout in
+// os2s.h / oracle.
 int read_kenlm_binary(const std::string& path, NGramLM* lm) {
   std::ifstream in(path, std::ios::binary);
   if (!in) return OS2S_ERR_INVALID_ARG;
@@ -219,6 +314,7 @@ int read_kenlm_binary(const std::string& path, NGramLM* lm) {
   uint32_t model_type;
   memcpy(&model_type, d.data() + off + 8, 4);
   const int has_vocab = d[off + 12];
+  if (model_type == 0) return read_kenlm_probing(d, size, lm);
   if (model_type != 5 || order != 2) return OS2S_ERR_UNSUPPORTED;
   if (!has_vocab) return OS2S_ERR_INVALID_ARG;
   uint64_t counts[2];

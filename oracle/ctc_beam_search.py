@@ -225,16 +225,42 @@ def build_letter_trie(words, alphabet, unigram_score):
 class NGramLM(object):
   """ngrams[n-1]: {tuple(word ids): (log10 prob, log10 backoff)}.  Word id 0 is <unk>."""
 
-  def __init__(self, order, vocab, ngrams):
+  def __init__(self, order, vocab, ngrams, hashed=None):
     self.order, self.vocab, self.ngrams = order, vocab, ngrams
+    # kenlm "probing" models: orders >= 2 are only known by the 64-bit hash of their word ids
+    # (hashed[n-1]: {key: (prob, backoff)}); ngrams[0] still holds the unigrams
+    self.hashed = hashed
     self.words = {w: i for i, w in enumerate(vocab)}
     self.bos = self.words["<s>"]
 
   def index(self, w):
     return self.words.get(w, 0)
 
+  def _lookup(self, key):
+    """(prob, backoff) of the n-gram `key` (tuple of word ids) or None."""
+    if self.hashed is None:
+      return self.ngrams[len(key) - 1].get(key)
+    if len(key) == 1:
+      return self.ngrams[0].get(key)
+    node = key[-1]                       # kenlm keys an n-gram by its LAST word first ...
+    for w in reversed(key[:-1]):         # ... then the preceding words, most recent first
+      node = combine_word_hash(node, w)
+    return self.hashed[len(key) - 1].get(node)
+
   def score(self, hist, wid):
     """log10 P(wid | hist) by back-off over the last order-1 words of hist."""
+    if self.hashed is not None:
+      ctx = tuple(hist[-(self.order - 1):]) if self.order > 1 else ()
+      for start in range(len(ctx) + 1):
+        e = self._lookup(ctx[start:] + (wid,))
+        if e is not None:
+          p = e[0]
+          for s in range(start):
+            b = self._lookup(ctx[s:])
+            if b is not None:
+              p += b[1]
+          return p
+      raise KeyError("unigram %d missing" % wid)
     ctx = tuple(hist[-(self.order - 1):]) if self.order > 1 else ()
     # longest context that exists as an n-gram prefix is irrelevant: walk from the longest
     for start in range(len(ctx) + 1):
@@ -404,10 +430,81 @@ def read_kenlm_quant_array_trie(path):
   return NGramLM(2, vocab, [uni_d, bi_d])
 
 
+def combine_word_hash(current, nxt):
+  """lm/search_hashed.hh (kenlm): the chained key of the probing tables."""
+  mask = (1 << 64) - 1
+  return ((int(current) * 8978948897894561157) & mask) ^ (((1 + int(nxt)) * 17894857484156487943) & mask)
+
+
+def read_kenlm_probing(path):
+  """KenLM binary, model type 0 (PROBING, kenlm's default) — the `ctc_decoders` scorer loads any
+  type through lm::ngram::LoadVirtual (decoders/scorer.cpp:56-63); the reference ships a trigram
+  sample, open_seq2seq/test_utils/toy_speech_data/toy_data-lm.binary. Layout (restated; every
+  piece is validated on that file: all 115 + 108 stored keys are reproduced by the hash chain,
+  the vocabulary hashes match the strings, and every context sums to probability 1):
+    header as for the trie models; then the vocabulary: {u32 version, u32 bound} + B(count[0])
+    packed 12-byte buckets {u64 MurmurHash64A(word), u32 id}, B(n) = max(n + 1, int(multiplier *
+    n)), empty = key 0, ids in ARPA order (= the order of the strings at the end of the file);
+    unigrams: (count[0] + 1) x {f32 prob, f32 backoff};
+    per middle order n: B(count[n-1]) x {u64 key, f32 prob, f32 backoff};
+    highest order: B(count[-1]) x packed {u64 key, f32 prob};
+    key of (w1 .. wn) = combine(...combine(combine(wn, wn-1), wn-2)..., w1).
+  The sign bit of a stored probability is a flag: value = -|x|."""
+  with open(path, "rb") as f:
+    d = f.read()
+  if d[:len(KENLM_MAGIC)] != KENLM_MAGIC:
+    raise ValueError("not a KenLM binary (format version 5)")
+  off = 0x58
+  order = d[off]
+  mult, = struct.unpack_from("<f", d, off + 4)
+  model_type, = struct.unpack_from("<I", d, off + 8)
+  if model_type != 0 or not d[off + 12]:
+    raise NotImplementedError("not a probing model with vocabulary")
+  counts = struct.unpack_from("<%dQ" % order, d, off + 20)
+  off = (off + 20 + 8 * order + 7) & ~7
+
+  def buckets(n):
+    return max(n + 1, int(np.float32(mult) * np.float32(n)))
+
+  off += 8 + 12 * buckets(counts[0])
+  uni = {}
+  for w in range(counts[0]):
+    p, b = struct.unpack_from("<ff", d, off + 8 * w)
+    uni[(w,)] = (-abs(p), b)
+  off += 8 * (counts[0] + 1)
+  hashed = [None]
+  for n in range(2, order + 1):
+    tab, nb = {}, buckets(counts[n - 1])
+    if n < order:
+      for i in range(nb):
+        k, p, b = struct.unpack_from("<Qff", d, off + 16 * i)
+        if k:
+          tab[k] = (-abs(p), b)
+      off += 16 * nb
+    else:
+      for i in range(nb):
+        k, p = struct.unpack_from("<Qf", d, off + 12 * i)
+        if k:
+          tab[k] = (-abs(p), 0.0)
+      off += 12 * nb
+    if len(tab) != counts[n - 1]:
+      raise ValueError("order %d: %d keys, header says %d" % (n, len(tab), counts[n - 1]))
+    hashed.append(tab)
+  vocab = [x.decode("utf-8") for x in d[off:].split(b"\0")[:counts[0]]]
+  if len(vocab) != counts[0] or vocab[0] != "<unk>":
+    raise ValueError("vocabulary strings")
+  return NGramLM(order, vocab, [uni] + [dict() for _ in range(order - 1)], hashed=hashed)
+
+
 def load_lm(path):
   with open(path, "rb") as f:
     head = f.read(len(KENLM_MAGIC))
-  return read_kenlm_quant_array_trie(path) if head == KENLM_MAGIC else read_arpa(path)
+  if head != KENLM_MAGIC:
+    return read_arpa(path)
+  with open(path, "rb") as f:
+    f.seek(0x60)
+    model_type, = struct.unpack("<I", f.read(4))
+  return read_kenlm_probing(path) if model_type == 0 else read_kenlm_quant_array_trie(path)
 
 
 # ------------------------------------------------------------------------------------------

@@ -7,6 +7,8 @@ reference checkout (only runnable where /root/reference exists).
                           open_seq2seq/test_utils/toy_speech_data/vocab.txt
   ctc_test_lm.binary   <- ctc_decoder_with_lm/ctc-test-lm.binary (1.4 KB KenLM bigram model, data)
   ctc_test_lm.trie     <- ctc_decoder_with_lm/ctc-test-lm.trie   (1.1 KB letter trie, data)
+  toy_data_lm.binary   <- open_seq2seq/test_utils/toy_speech_data/toy_data-lm.binary (7.6 KB KenLM
+                          trigram model in the probing layout, data)
 """
 import json
 import os
@@ -47,6 +49,9 @@ def main():
   for src, dst in (("ctc-test-lm.binary", "ctc_test_lm.binary"), ("ctc-test-lm.trie", "ctc_test_lm.trie")):
     shutil.copyfile(os.path.join(REF, "ctc_decoder_with_lm", src), os.path.join(OUT, dst))
     os.chmod(os.path.join(OUT, dst), 0o644)
+  shutil.copyfile(os.path.join(REF, "open_seq2seq", "test_utils", "toy_speech_data", "toy_data-lm.binary"),
+                  os.path.join(OUT, "toy_data_lm.binary"))
+  os.chmod(os.path.join(OUT, "toy_data_lm.binary"), 0o644)
   with open(os.path.join(OUT, "ctc_test_meta.json"), "w") as f:
     json.dump(meta, f, indent=1)
   print("wrote", OUT)

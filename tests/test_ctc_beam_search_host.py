@@ -145,11 +145,16 @@ def test_scorer_errors(tmp_path, kat):
   # a KenLM binary of another model type / order is refused, not misread
   with open(os.path.join(GOLD, "ctc_test_lm.binary"), "rb") as f:
     d = bytearray(f.read())
-  d[0x60] = 0          # model type: probing hash tables
-  other = str(tmp_path / "probing.binary")
+  d[0x60] = 2          # model type: unquantised trie — a layout the reference ships no sample of
+  other = str(tmp_path / "trie.binary")
   with open(other, "wb") as f:
     f.write(bytes(d))
   with pytest.raises(_lib.Os2sError, match="(?i)unsupported"):
+    capi.CtcScorer(other, trie, alpha_path, 1.0, 0.0)
+  d[0x60] = 0          # claims to be a probing model but is not laid out as one: refused as well
+  with open(other, "wb") as f:
+    f.write(bytes(d))
+  with pytest.raises(_lib.Os2sError):
     capi.CtcScorer(other, trie, alpha_path, 1.0, 0.0)
   # alphabet / trie size mismatch (trie_node.h:73-79)
   short = str(tmp_path / "short_alphabet.txt")
