@@ -46,6 +46,18 @@ int main() {
     rc = os2s_ctc_dict_beam_search(probs.data(), B * C, C, sl.data(), T, B, C, beam, 0.98, 5, 1, nullptr, 1, ids.data(), len.data(), lp.data());
     printf("beam %d dict-decoder (no scorer, pruned) rc %d len0 %d\n", beam, rc, len[0]);
   }
+  {   // probing-layout model (trigram sample)
+    std::string plm = std::string(G) + "toy_data_lm.binary";
+    void* ps = nullptr;
+    rc = os2s_ctc_dict_scorer_create(plm.c_str(), vp.data(), (int)vp.size(), 1.0, 0.3, &ps);
+    int cb = -1, mo = -1, dsz = -1;
+    os2s_ctc_dict_scorer_info(ps, &cb, &mo, &dsz);
+    printf("probing dict scorer rc %d order %d dict %d\n", rc, mo, dsz);
+    std::vector<int32_t> ids((size_t)B * T), len(B); std::vector<float> lp(B);
+    rc = os2s_ctc_dict_beam_search(probs.data(), B * C, C, sl.data(), T, B, C, 16, 1.0, 40, 1, ps, 2, ids.data(), len.data(), lp.data());
+    printf("probing dict decode rc %d\n", rc);
+    os2s_ctc_dict_scorer_destroy(ps);
+  }
   const char* words[2] = {"ten", "seconds"}; float p = 0;
   os2s_ctc_scorer_ngram_score(sc, words, 2, &p); printf("ngram %f\n", p);
   rc = os2s_ctc_generate_trie("/tmp/alpha.txt", lm.c_str(), "/tmp/alpha.txt", "/tmp/out.trie");
