@@ -149,14 +149,21 @@ bool read_arpa(const std::string& path, NGramLM* lm) {
   std::string line;
   while (std::getline(in, line) && line.compare(0, 6, "\\data\\") != 0) {}
   int order = 0;
+  std::vector<size_t> declared(16, 0);
   while (std::getline(in, line) && line.compare(0, 6, "ngram ") == 0) {
     const int n = atoi(line.c_str() + 6);
     order = std::max(order, n);
+    const size_t eq = line.find('=');
+    if (n >= 1 && n <= 15 && eq != std::string::npos) declared[n] = strtoull(line.c_str() + eq + 1, nullptr, 10);
   }
   if (order < 1 || order > 15) return false;
   lm->order = order;
   lm->entries.assign(order, {});
   lm->index.assign(order, {});
+  for (int n = 1; n <= order; ++n) {            // sized once from the header: no rehashing on big models
+    lm->entries[n - 1].reserve(declared[n] + 1);
+    if (n > 1) lm->index[n - 1].reserve(declared[n]);
+  }
   lm->words.clear();
   lm->words["<unk>"] = 0;
   lm->entries[0].push_back(NGramLM::Entry{-100.f, 0.f});
