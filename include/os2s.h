@@ -108,15 +108,37 @@ int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
                        int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
                        int accumulate, int act, float keep_prob, unsigned long long seed,
                        const uint16_t* residual, const int32_t* out_len);
-/* Ragged batches: tiles whose whole input window lies past in_len[b] skip the matrix work
- * (their output is the exact zero / bias tile); with out_len != NULL output tiles that start
- * at t >= out_len[b] are not computed or stored at all (data gradients: the consumer masks
- * those rows, encoders/tdnn_encoder.py:185-186,204-205). os2s_conv1d_wgrad likewise visits
- * only the (sample, 64-row) chunks whose X window starts before in_len[b]. */
-/* tuning hook: 3 (default) = 128x128 tile / 4 waves, X window single-buffered when K >= 8
- * (3 workgroups per CU); 0 = always double-buffered; 1 = two 128-row windows / 8 waves;
- * 2 = two windows / 4 waves with 128x64 wave tiles */
+/* Ragged batches: windows (128 output rows of one sample) whose whole input window lies past
+ * in_len[b] cost no matrix work (their output is the exact zero tile, their BatchNorm partials
+ * are zero); with out_len != NULL output windows that start at t >= out_len[b] are not computed
+ * or stored at all (data gradients: the consumer masks those rows,
+ * encoders/tdnn_encoder.py:185-186,204-205). os2s_conv1d_wgrad likewise visits only the
+ * (sample, 64-row) chunks whose X window starts before in_len[b].
+ *
+ * os2s_conv1d_fwd_ws: the same call with a caller-owned workspace of
+ * os2s_conv1d_workspace_bytes() bytes. The workspace lets the library split the last partial
+ * round of workgroups of a launch over the input channels (fp32 partial tiles, deterministic
+ * reduction by the last arriver); its first 4096 bytes are int32 tickets that must be ZERO
+ * before the first use (the library leaves them zero). One workspace per stream: launches that
+ * may overlap must not share one. Without a workspace (os2s_conv1d_fwd_ex / os2s_conv1d_fwd)
+ * results are identical up to fp32 summation order, only the load balance differs.
+ * The tile choice is a fixed function of the problem shape; no timing, no hidden state. */
+size_t os2s_conv1d_workspace_bytes(void);
+int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,
+                       const int32_t* in_len, const float* bias, float* stats, int B,
+                       int Tin, int Cin, int Cout, int K, int stride, int dil, int padL,
+                       int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
+                       int accumulate, int act, float keep_prob, unsigned long long seed,
+                       const uint16_t* residual, const int32_t* out_len, void* workspace,
+                       size_t workspace_bytes);
+/* experiment / test hook: force a tile. -1 (default) = by shape; 0 = 128x128 tile, X window
+ * double-buffered; 3 = 128x128, X window single-buffered when K >= 8 (3 workgroups per CU);
+ * 5 = 256x256 lockstep tile; 10 = ping-pong kernel (256x256, balanced over live windows) */
 void os2s_conv1d_set_variant(int v);
+/* experiment hook: f > 0 forces the tail split factor of the ping-pong kernel (-1 = cost model) */
+void os2s_conv1d_set_split(int f);
+/* experiment hook (tools/pp_timeline.py): per-slot time stamps of the ping-pong kernel */
+void os2s_conv1d_set_debug(void* stamps, int fixed_w);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,
                     float* stats, int B, int Tin, int Cin, int Cout, int K,

@@ -23,7 +23,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-Wno-unused-result",
-]
+] + os.environ.get("OS2S_EXTRA_HIPFLAGS", "").split()   # experiments (e.g. -DOS2S_PP_PRIO=1)
 
 
 def _newer(target: str, deps) -> bool:
@@ -46,7 +46,7 @@ def hip_sources():
                 if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
+def build_hip(force: bool = False, verbose: bool = False, only=None) -> str:
   """Compile every csrc/*.hip for gfx950 (and the host-only csrc/*.cpp) and link libos2s_hip.so."""
   if shutil.which(HIPCC) is None and not os.path.exists(HIPCC):
     raise RuntimeError("hipcc not found (looked for %s)" % HIPCC)
@@ -59,7 +59,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
   for s in srcs:
     o = os.path.splitext(s)[0] + ".o"
     objs.append(o)
-    if force or _newer(o, [s] + headers):
+    if (force and (only is None or os.path.basename(s) in only)) or _newer(o, [s] + headers):
       jobs.append((s, o))
 
   def cc(job):

@@ -89,11 +89,28 @@ def conv1d_num_mtiles(B, tout):
   return int(_fn("os2s_conv1d_num_mtiles", (c_int, c_int))(B, tout))
 
 
+_conv_ws = {}
+
+
+def conv1d_workspace(device):
+  """Caller-owned workspace of os2s_conv1d_fwd_ws (tickets zeroed once): one per (device,
+  stream) — launches that may overlap must not share one."""
+  key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+  ws = _conv_ws.get(key)
+  if ws is None:
+    n = int(_fn("os2s_conv1d_workspace_bytes", (), c_size_t)())
+    ws = torch.zeros((n,), dtype=torch.uint8, device=device)
+    _conv_ws[key] = ws
+  return ws
+
+
 def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
                bias=None, stats=None, out=None, out_f32=False, accumulate=False,
-               time_major=False, act=0, keep_prob=1.0, seed=0, residual=None, out_len=None):
+               time_major=False, act=0, keep_prob=1.0, seed=0, residual=None, out_len=None,
+               use_workspace=True):
   """x [B,Tin,Cin] bf16, w [K,Cout,Cin] bf16 -> y [B,Tout,Cout] (or [Tout,B,Cout]
-  when time_major). pad_left/tout default to TF 'SAME'."""
+  when time_major). pad_left/tout default to TF 'SAME'. use_workspace=False: no split of the
+  last partial round of workgroups (same results up to fp32 summation order)."""
   B, Tin, Cin = x.shape
   K, Cout, Cin2 = w.shape
   assert Cin == Cin2
@@ -107,18 +124,21 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
     ysb, yst = Cout, B * Cout
   else:
     ysb, yst = tout * Cout, Cout
-  f = _fn("os2s_conv1d_fwd_ex",
+  ws = conv1d_workspace(x.device) if use_workspace else None
+  f = _fn("os2s_conv1d_fwd_ws",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-           c_ll, c_ll, c_int, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p))
+           c_ll, c_ll, c_int, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p,
+           c_void_p, c_size_t))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16),
                _ptr(out, dt), _ptr(in_len, torch.int32, True),
                _ptr(bias, torch.float32, True), _ptr(stats, torch.float32, True),
                B, Tin, Cin, Cout, K, stride, dil, pad_left, tout, ysb, yst,
                int(out_f32), int(accumulate), int(act), float(keep_prob),
                int(seed) & (2**64 - 1), _ptr(residual, torch.bfloat16, True),
-               _ptr(out_len, torch.int32, True)),
-             "os2s_conv1d_fwd_ex")
+               _ptr(out_len, torch.int32, True), _ptr(ws, None, True),
+               ws.numel() if ws is not None else 0),
+             "os2s_conv1d_fwd_ws")
   return out
 
 

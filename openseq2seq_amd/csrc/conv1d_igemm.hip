@@ -32,6 +32,7 @@
 //     same weight n-tile, so the weight stream is an L2 hit for all but one.
 #include "os2s_common.hpp"
 #include <array>
+#include <type_traits>
 #include <map>
 #include <mutex>
 
@@ -54,12 +55,187 @@ struct ConvArgs {
   float keep_prob;              // 1 = no dropout
   unsigned long long seed;
   const bf16_t* residual;       // same layout/strides as y (bf16 output only) or null
+  // ping-pong kernel only: split-unit workspace (fp32 partial tiles + one ticket per split unit)
+  float* ws_slabs;
+  int* ws_cnt;
+  int ws_nslabs, ncu;
+  int force_split;              // experiment hook: > 0 forces the tail split factor
+  unsigned long long* dbg;      // experiment hook: slot time stamps [4 wg][2 waves][48 steps][9]
+  int dbg_fixed_w;              // experiment hook: every step reads the weight tile of step 0
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)gsrc,
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Epilogue shared by the tile kernels: fused bias / ReLU / dropout / residual, bf16 pack, LDS
+// transpose to full 16-B row stores, per-channel (sum, sum^2) partials for BatchNorm.
+template <int BM, int BN, int WM, int WN, int NWIN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
+                                              f32x16 (&acc)[(BN / WN) / 32][((BM * NWIN) / WM) / 32],
+                                              char* smem, int tid, int lane, int wid,
+                                              const int (&wmid)[NWIN], int n0,
+                                              const int (&wb)[NWIN], const int (&wt0)[NWIN]) {
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int WTM = (BM * NWIN) / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  const int wm = wid / WN, wn = wid % WN;
+  const int my_win = (wm * WTM) / BM;
+  const int row_in_win = (wm * WTM) % BM;
+  const int my_b = (NWIN == 1 || my_win == 0) ? wb[0] : wb[NWIN - 1];
+  const int my_t0 = (NWIN == 1 || my_win == 0) ? wt0[0] : wt0[NWIN - 1];
+  // wmid[w] = window id (row of the BN partial sums) or -1 for a window slot with no work
+  const int my_mid = (NWIN == 1 || my_win == 0) ? wmid[0] : wmid[NWIN - 1];
+  const int l31 = lane & 31, lhi = lane >> 5;
+  if (p.out_f32) {
+    // small/rare path (FC logits): scattered fp32 stores straight from registers
+    const int b = my_b, t0 = my_t0;
+    const int valid_rows = (my_mid >= 0) ? min(BM, p.Tout - t0) : 0;
+    float* const yb = reinterpret_cast<float*>(p.y) + (long long)b * p.y_sb;
+#pragma unroll
+    for (int in = 0; in < NI; ++in)
+#pragma unroll
+      for (int im = 0; im < MI; ++im) {
+        const int tt = row_in_win + im * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int cc = n0 + wn * WTN + in * 32 + 8 * (e >> 2) + 4 * lhi + (e & 3);
+          if (tt < valid_rows && cc < p.Cout) {
+            float v = acc[in][im][e];
+            if (p.bias) v += p.bias[cc];
+            float* dst = yb + (long long)(t0 + tt) * p.y_st + cc;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    return;
+  }
+
+  constexpr int OP = BN * 2 + 16;  // out-tile pitch in bytes
+  // The out tile is staged through LDS (coalesced 16-B row stores + the BN partial sums). Wide
+  // tiles do not fit all windows at once: stage EW windows per pass.
+  constexpr bool EPI_SPLIT = (size_t)NWIN * BM * OP > 112 * 1024;
+  constexpr int EW = EPI_SPLIT ? 1 : NWIN;
+  char* const ot = smem;
+#pragma unroll
+  for (int w0 = 0; w0 < NWIN; w0 += EW) {
+  __syncthreads();                 // staging buffers / previous pass are no longer read
+  if (my_win >= w0 && my_win < w0 + EW) {
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      const int tt = wm * WTM + im * 32 + l31 - w0 * BM;   // row in this pass's out tile
+      const int b = my_b, t0 = my_t0 - (my_win - w0) * BM;   // t0 + tt = time of this row
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cc = wn * WTN + in * 32 + 8 * g + 4 * lhi;
+        float v0 = acc[in][im][4 * g + 0], v1 = acc[in][im][4 * g + 1];
+        float v2 = acc[in][im][4 * g + 2], v3 = acc[in][im][4 * g + 3];
+        if (p.bias) {
+          const int gc = n0 + cc;
+          if (gc + 3 < p.Cout) {
+            v0 += p.bias[gc]; v1 += p.bias[gc + 1]; v2 += p.bias[gc + 2]; v3 += p.bias[gc + 3];
+          }
+        }
+        if (p.act == 1) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        if (p.keep_prob < 1.f) {
+          // same (seed, element index / 8) convention as the elementwise kernels
+          const long long e0 = ((long long)b * p.Tout + t0 + tt) * p.Cout + n0 + cc;
+          const uint32_t bits = dropout_bits8(p.seed, (unsigned long long)(e0 >> 3), p.keep_prob) >>
+                                (uint32_t)(e0 & 7);
+          const float ik = 1.f / p.keep_prob;
+          v0 = (bits & 1u) ? v0 * ik : 0.f;
+          v1 = (bits & 2u) ? v1 * ik : 0.f;
+          v2 = (bits & 4u) ? v2 * ik : 0.f;
+          v3 = (bits & 8u) ? v3 * ik : 0.f;
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(v0, v1);
+        pk[1] = pack2bf(v2, v3);
+        *reinterpret_cast<u32x2*>(ot + tt * OP + cc * 2) = pk;
+      }
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int w = w0; w < w0 + EW; ++w) {
+  const int b = wb[w], t0 = wt0[w];
+  const int valid_rows = (wmid[w] >= 0) ? min(BM, p.Tout - t0) : 0;
+  const char* const otw = ot + (w - w0) * BM * OP;
+  bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
+  for (int q = tid; q < BM * (BN / 8); q += NTHR) {
+    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+    const int gc = n0 + c8 * 8;
+    if (row < valid_rows && gc < p.Cout) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
+      bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
+      if (p.residual) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(
+            p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      }
+      if (p.accumulate) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      }
+      *reinterpret_cast<u32x4*>(dst) = v;
+    }
+  }
+  }
+
+  if (p.stats) {
+    constexpr int CP = BN / 2;       // column pairs
+    constexpr int RG = (NTHR / CP) > 0 ? (NTHR / CP) : 1;    // row groups
+    const int cp = tid % CP, rg = tid / CP;
+#pragma unroll
+    for (int w = w0; w < w0 + EW; ++w) {
+    if (wmid[w] < 0) break;
+    const int m_idx = wmid[w];
+    const int valid_rows = min(BM, p.Tout - wt0[w]);
+    const char* const otw = ot + (w - w0) * BM * OP;
+    if (w > w0) __syncthreads();      // scratch re-use between windows
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (rg < RG)
+    for (int row = rg; row < valid_rows; row += RG) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4);
+      const float a = bflo(v), bb = bfhi(v);
+      s0 += a; q0 += a * a;
+      s1 += bb; q1 += bb * bb;
+    }
+    float* sc = reinterpret_cast<float*>(smem + EW * BM * OP);  // [RG][BN][2]
+    if (rg < RG) {
+    sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
+    sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
+    sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
+    sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, qq = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        s += sc[(g * BN + tid) * 2 + 0];
+        qq += sc[(g * BN + tid) * 2 + 1];
+      }
+      const int gc = n0 + tid;
+      if (gc < p.Cout) {
+        p.stats[((long long)m_idx * 2 + 0) * p.Cout + gc] = s;
+        p.stats[((long long)m_idx * 2 + 1) * p.Cout + gc] = qq;
+      }
+    }
+    }
+  }
+  }
 }
 
 // BM = rows of ONE time window (one batch item); a workgroup processes NWIN consecutive
@@ -219,155 +395,442 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
     k = kn;
   }
 
-  // ---- epilogue ------------------------------------------------------------
-  if (p.out_f32) {
-    // small/rare path (FC logits): scattered fp32 stores straight from registers
-    const int b = my_b, t0 = my_t0;
-    const int valid_rows = (m_first + my_win < p.MT) ? min(BM, p.Tout - t0) : 0;
-    float* const yb = reinterpret_cast<float*>(p.y) + (long long)b * p.y_sb;
+  int wmid[NWIN];
 #pragma unroll
-    for (int in = 0; in < NI; ++in)
+  for (int w = 0; w < NWIN; ++w) wmid[w] = (m_first + w < p.MT) ? m_first + w : -1;
+  conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong kernel for the stride-1 layers with K >= 5 (the bulk of the Jasper FLOPs).
+//
+// Tile: two 128-row time windows x BN = 256 output channels, 8 waves. Waves 0-3 ("group A")
+// compute window 0, waves 4-7 ("group B") window 1; wave w and wave w+4 sit on the same SIMD.
+// Both groups stream the SAME weight tile, so a workgroup reads the weights once per 256 rows.
+//
+// The loop is cut into barrier-delimited slots in which one wave of every SIMD issues MFMAs
+// (COMPUTE) while its partner fetches the fragments of its next item from LDS (LOAD) — the
+// matrix pipe never waits for ds_read latency, address arithmetic or a barrier skew of the
+// wave that feeds it. An item is (64-channel step, 64-row half of the wave's 128 x 64 tile):
+// 16 MFMA 32x32x16 = 512 matrix-pipe cycles per slot.
+//
+//   slot        4s         4s+1        4s+2        4s+3
+//   group A   LOAD(2s)   COMP(2s)   LOAD(2s+1)  COMP(2s+1)
+//   group B   COMP(2s-1) LOAD(2s)   COMP(2s)    LOAD(2s+1)
+//
+// LDS: X windows double-buffered per 64-channel chunk (re-used by all K taps), weight tile
+// [256 x 64] double-buffered per step. The weight fragments of a step are read once (LOAD of
+// the even item) and kept in registers, so a weight buffer is busy in 2 slots out of 8. ALL DMA
+// is issued by the wave that is in its odd LOAD slot (measured: a DMA instruction issued between
+// MFMAs costs the matrix pipe ~45 cycles): LOAD(2s+1) first drains what LOAD(2s-1) issued
+// (vmcnt(0) after a whole step of flight time — nothing to count), then issues the weight tile
+// of step s+2 and one instruction of the X window of chunk c+1 (during the first steps of chunk
+// c; needs K > number of such instructions per wave).
+//
+// Work distribution (what the kernel is really about — the loop above runs at ~1.4 PFLOP/s per
+// busy CU, an unbalanced launch wastes half of it):
+//   * live windows only. Every wave derives the live-window list of the ragged batch from
+//     in_len / out_len with one wave scan (B <= 64): window pairs are formed over the
+//     COMPACTED list, so no workgroup is half padding and no workgroup is dispatched for
+//     padding at all. Dead windows of a forward call get their zero rows / zero BatchNorm
+//     partials from a few store-only workgroups at the end of the grid.
+//   * unit = (window pair, n-tile), enumerated so that consecutive workgroups (= the 8 XCDs
+//     round-robin) hold DIFFERENT pairs and the n-tiles of one pair follow each other on the
+//     same XCD: the X windows are fetched into one L2 only, every weight n-tile stream is
+//     shared by the workgroups of an XCD that run in lockstep.
+//   * U units on G CUs: the first floor(U/G)*G units run whole; the remaining r = U mod G units
+//     are split f ways over the input-channel chunks (f chosen per launch, on the device, from
+//     a fixed cost model) so that the tail costs ~1/f of a round instead of a full one. The
+//     pieces of a unit leave fp32 partial tiles in a workspace; the piece that arrives last
+//     (agent-scope release / acquire around one atomic ticket) sums them in piece order —
+//     deterministic — and runs the epilogue. No spinning, so no co-residency assumption.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPpBN = 256;
+constexpr int kPpSlabFloats = 256 * 256;           // one fp32 partial tile
+constexpr int kPpZeroWin = 2;                      // dead windows per store-only workgroup
+#ifndef OS2S_PP_PRIO
+#define OS2S_PP_PRIO 0                             // experiment: s_setprio(1) around the MFMA runs
+#endif
+
+__device__ __forceinline__ void pp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// DBG: per-slot s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py)
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
+  constexpr int BM = 128, BN = kPpBN, NWIN = 2, WM = 2, WN = 4;
+  constexpr int MI = 4, NI = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wn = wid & 3;
+
+  // ---- live windows per sample, inclusive scan over the batch (one value per lane) ----------
+  int nw = 0;
+  if (lane < p.B) {
+    if (p.out_len) {
+      // data-gradient call: rows >= out_len are never read by the caller
+      int lo = p.out_len[lane];
+      lo = lo < 0 ? 0 : (lo < p.Tout ? lo : p.Tout);
+      nw = (lo + BM - 1) / BM;
+    } else {
+      int len = p.Tin;
+      if (p.in_len) {
+        const int l = p.in_len[lane];
+        len = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+      }
+      nw = len > 0 ? (len + p.padL + BM - 1) / BM : 0;   // windows with a real input row
+    }
+    nw = nw < p.mtiles_per_b ? nw : p.mtiles_per_b;
+  }
+  int scan = nw;
 #pragma unroll
-      for (int im = 0; im < MI; ++im) {
-        const int tt = row_in_win + im * 32 + l31;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int cc = n0 + wn * WTN + in * 32 + 8 * (e >> 2) + 4 * lhi + (e & 3);
-          if (tt < valid_rows && cc < p.Cout) {
-            float v = acc[in][im][e];
-            if (p.bias) v += p.bias[cc];
-            float* dst = yb + (long long)(t0 + tt) * p.y_st + cc;
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(scan, o, 64);
+    if (lane >= o) scan += t;
+  }
+  const int L = __builtin_amdgcn_readlane(scan, 63);
+  const int P = (L + 1) >> 1, U = P * p.NT, G = p.ncu;
+  const int S = p.nchunks * p.K;
+
+  // ---- tail split factor (same decision in every workgroup: pure function of the launch) -----
+  const int q = U / G, r = U - q * G;
+  int f = 1;
+  if (p.force_split > 0 && p.ws_slabs) {
+    f = p.force_split;
+    while (f > 1 && (f > p.nchunks || r * f > p.ws_nslabs)) --f;
+    if (r == 0) f = 1;
+  } else if (r > 0 && p.ws_slabs) {
+    // cost of the tail in microseconds (fitted on MI355X, tools/bench_conv_split.py): a round of
+    // whole units takes S steps x 1.18 us; a split unit adds ~40 us (pipeline fill, partial-tile
+    // store + release, epilogue of the reducer), ~8 us per partial tile the reducer reads back
+    // and 0.17 us per piece of aggregate workspace traffic
+    const float round_us = 1.18f * S;
+    float best = round_us;
+    for (int ff = 2; ff <= 8; ++ff) {
+      if (ff > p.nchunks || r * ff > p.ws_nslabs) break;
+      const float t = (float)((r * ff + G - 1) / G) * round_us / ff + 40.f + 8.f * ff +
+                      0.17f * (r * ff);
+      if (t < 0.95f * best) { best = t; f = ff; }
+    }
+  }
+  const int nfull = f > 1 ? U - r : U;
+  const int nwork = nfull + (f > 1 ? r * f : 0);
+  const int bid = blockIdx.x;
+
+  if (bid >= nwork) {
+    // ---- store-only role: zero rows + zero BN partials of the dead windows (forward calls)
+    const int z = (int)gridDim.x - 1 - bid;
+    if (p.out_len || p.out_f32 || z >= (p.MT + kPpZeroWin - 1) / kPpZeroWin) return;
+    for (int m = z * kPpZeroWin; m < (z + 1) * kPpZeroWin && m < p.MT; ++m) {
+      const int b = m / p.mtiles_per_b, j = m - b * p.mtiles_per_b;
+      if (j < __shfl(nw, b, 64)) continue;
+      const int t0 = j * BM, rows = min(BM, p.Tout - t0);
+      if (!p.accumulate) {
+        bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
+        const int c8n = p.Cout >> 3;
+        const u32x4 zv = {0u, 0u, 0u, 0u};
+        for (int e = tid; e < rows * c8n; e += 512) {
+          const int row = e / c8n, c8 = e - row * c8n;
+          u32x4 v = zv;
+          if (p.residual)
+            v = *reinterpret_cast<const u32x4*>(p.residual + (long long)b * p.y_sb +
+                                                (long long)(t0 + row) * p.y_st + c8 * 8);
+          *reinterpret_cast<u32x4*>(yb + (long long)(t0 + row) * p.y_st + c8 * 8) = v;
         }
       }
+      if (p.stats)
+        for (int e = tid; e < 2 * p.Cout; e += 512) p.stats[(long long)m * 2 * p.Cout + e] = 0.f;
+    }
     return;
   }
 
-  constexpr int OP = BN * 2 + 16;  // out-tile pitch in bytes
-  // The out tile is staged through LDS (coalesced 16-B row stores + the BN partial sums). Wide
-  // tiles do not fit all windows at once: stage EW windows per pass.
-  constexpr bool EPI_SPLIT = (size_t)NWIN * BM * OP > 112 * 1024;
-  constexpr int EW = EPI_SPLIT ? 1 : NWIN;
-  char* const ot = smem;
+  // ---- work role: (unit rank, piece) -> (window pair, n-tile, chunk range) --------------------
+  int rank = bid, piece = 0, npiece = 1;
+  if (bid >= nfull) {
+    const int i = bid - nfull;
+    rank = nfull + i / f;
+    piece = i - (i / f) * f;
+    npiece = f;
+  }
+  int xcd, loc;
+  {
+    const int P8 = (P + 7) >> 3, rem = P - 8 * (P8 - 1), base = (P8 - 1) * p.NT * 8;
+    if (rank < base) { xcd = rank & 7; loc = rank >> 3; }
+    else { const int i = rank - base; loc = (P8 - 1) * p.NT + i / rem; xcd = i - (i / rem) * rem; }
+  }
+  const int pair = (loc / p.NT) * 8 + xcd;
+  const int n_idx = loc - (loc / p.NT) * p.NT;
+  const int n0 = n_idx * BN;
+  int wb[NWIN], wt0[NWIN], wlen[NWIN], wwin[NWIN], wmid[NWIN];
 #pragma unroll
-  for (int w0 = 0; w0 < NWIN; w0 += EW) {
-  __syncthreads();                 // staging buffers / previous pass are no longer read
-  if (my_win >= w0 && my_win < w0 + EW) {
+  for (int w = 0; w < NWIN; ++w) {
+    const int i = 2 * pair + w;
+    const bool live = i < L;
+    const int b = live ? __builtin_popcountll(__ballot(scan <= i)) : 0;
+    const int before = b > 0 ? __shfl(scan, b - 1, 64) : 0;
+    wb[w] = b;
+    wt0[w] = live ? (i - before) * BM : 0;
+    int len_b = p.Tin;
+    if (p.in_len) {
+      const int l = p.in_len[b];
+      len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+    }
+    wlen[w] = live ? len_b : 0;                     // dead slot: every row reads as zero
+    wwin[w] = wt0[w] - p.padL;                      // stride 1
+    wmid[w] = live ? b * p.mtiles_per_b + (i - before) : -1;
+  }
+  const int c_beg = __builtin_amdgcn_readfirstlane(piece * p.nchunks / npiece);
+  const int c_end = __builtin_amdgcn_readfirstlane((piece + 1) * p.nchunks / npiece);
+
+  const int win_bytes = p.Rpad * 128;
+  const int xbuf_bytes = NWIN * win_bytes;
+  char* const xbuf0 = smem;
+  char* const wbuf0 = smem + 2 * xbuf_bytes;
+  char* const dump = wbuf0 + 2 * BN * 128;          // 1 KB landing zone of padding DMAs
+  const int rb_per_win = p.Rpad >> 3;               // DMA instructions (8 rows each) per window
+  const int nxi = (rb_per_win + 3) >> 2;            // X DMA instructions per wave per chunk
+
+  // All global->LDS traffic goes through buffer descriptors (LDS-DMA, 16 B per lane): the
+  // per-lane byte offset is fixed for the whole kernel, the chunk / tap position sits in the
+  // scalar offset, and the hardware range check supplies the zeros — rows before the sequence
+  // start (negative offset = huge unsigned), rows past in_len (num_records = len rows) and the
+  // dead window slot (num_records = 0) — so a DMA costs two scalar and one vector instruction.
+  // A wave stages rows of its OWN group's window only: one descriptor, no selects in the loop.
+  __amdgpu_buffer_rsrc_t xrs;
+  {
+    const int b_own = grp ? wb[1] : wb[0];
+    const int len_own = grp ? wlen[1] : wlen[0];
+    const bf16_t* xb = p.x + (long long)b_own * p.x_sb;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)xb);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)xb >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane(len_own * (int)p.x_st * 2);
+    xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes,
+                                            0x00020000);
+  }
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, 0, (int)((long long)p.K * p.Cout * p.Cin * 2), 0x00020000);
+  // one DMA instruction = 8 rows x 128 B of an X window. Instruction n (n < nxi) of a chunk
+  // issued by wave (grp, wq) covers row group rb = wq + 4 n of the group's window; every wave
+  // issues exactly nxi per chunk (the surplus ones read out of range and land in `dump`).
+  // per-lane byte offset inside the 8-row group: row (lane >> 3), 16-B slot jj ^ swizzle(row);
+  // the swizzle term (row >> 1) & 7 of row rb*8 + (lane >> 3) flips bit 2 for odd rb
+  const int xlane = (lane >> 3) * (int)p.x_st * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  const int xrow0 = __builtin_amdgcn_readfirstlane((grp ? wwin[1] : wwin[0]) * (int)p.x_st * 2);
+  const int xgrp_bytes = __builtin_amdgcn_readfirstlane(8 * (int)p.x_st * 2);
+  auto stage_x = [&](int c, int n) {
+    const int rb = (wid & 3) + 4 * n;
+    const bool real = rb < rb_per_win;
+    char* dst = real ? xbuf0 + (c & 1) * xbuf_bytes + grp * win_bytes + rb * 1024 : dump;
+    // rows before the sequence start give a negative (= huge unsigned) offset -> zeros
+    const int srow = real ? xrow0 + rb * xgrp_bytes : (int)0x80000000;
+    const int vo = (xlane ^ ((rb & 1) << 6)) + srow;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16,
+                                             vo, __builtin_amdgcn_readfirstlane(c * 128), 0, 0);
+  };
+  // weight tile rows handled by this lane (4 DMA instructions of 8 rows per wave and step)
+  int wsrc[4];
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) {
+    const int row = (pi * 8 + wid) * 8 + (lane >> 3), jj = lane & 7;
+    const int j = jj ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < p.Cout ? n : p.Cout - 1;
+    wsrc[pi] = (n * p.Cin + j * 8) * 2;
+  }
+  const int w_kstride = __builtin_amdgcn_readfirstlane(p.Cout * p.Cin * 2);
+  auto stage_w = [&](int c, int k, int par) {
+    const int soff = __builtin_amdgcn_readfirstlane((DBG && p.dbg_fixed_w) ? 0 : k * w_kstride + c * 128);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(wbuf0 + par * (BN * 128) + (pi * 8 + wid) * 1024),
+          16, wsrc[pi], soff, 0, 0);
+  };
+
+  f32x16 acc[NI][MI];
 #pragma unroll
   for (int in = 0; in < NI; ++in)
 #pragma unroll
-    for (int im = 0; im < MI; ++im) {
-      const int tt = wm * WTM + im * 32 + l31 - w0 * BM;   // row in this pass's out tile
-      const int b = my_b, t0 = my_t0 - (my_win - w0) * BM;   // t0 + tt = time of this row
+    for (int im = 0; im < MI; ++im)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cc = wn * WTN + in * 32 + 8 * g + 4 * lhi;
-        float v0 = acc[in][im][4 * g + 0], v1 = acc[in][im][4 * g + 1];
-        float v2 = acc[in][im][4 * g + 2], v3 = acc[in][im][4 * g + 3];
-        if (p.bias) {
-          const int gc = n0 + cc;
-          if (gc + 3 < p.Cout) {
-            v0 += p.bias[gc]; v1 += p.bias[gc + 1]; v2 += p.bias[gc + 2]; v3 += p.bias[gc + 3];
-          }
-        }
-        if (p.act == 1) {
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        }
-        if (p.keep_prob < 1.f) {
-          // same (seed, element index / 8) convention as the elementwise kernels
-          const long long e0 = ((long long)b * p.Tout + t0 + tt) * p.Cout + n0 + cc;
-          const uint32_t bits = dropout_bits8(p.seed, (unsigned long long)(e0 >> 3), p.keep_prob) >>
-                                (uint32_t)(e0 & 7);
-          const float ik = 1.f / p.keep_prob;
-          v0 = (bits & 1u) ? v0 * ik : 0.f;
-          v1 = (bits & 2u) ? v1 * ik : 0.f;
-          v2 = (bits & 4u) ? v2 * ik : 0.f;
-          v3 = (bits & 8u) ? v3 * ik : 0.f;
-        }
-        u32x2 pk;
-        pk[0] = pack2bf(v0, v1);
-        pk[1] = pack2bf(v2, v3);
-        *reinterpret_cast<u32x2*>(ot + tt * OP + cc * 2) = pk;
-      }
-    }
-  }
-  __syncthreads();
+      for (int e = 0; e < 16; ++e) acc[in][im][e] = 0.f;
 
+  const int nsteps = (c_end - c_beg) * p.K;
+  {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int n = 0; n < nxi; ++n) stage_x(c_beg, n);
+    stage_w(c_beg, 0, 0);
+    if (nsteps > 1) stage_w(p.K > 1 ? c_beg : c_beg + 1, p.K > 1 ? 1 : 0, 1);
+    // fragment offsets of the weight tile: row = wn*64 + in*32 + l31, fixed for the kernel
+    int woff[4];
 #pragma unroll
-  for (int w = w0; w < w0 + EW; ++w) {
-  const int b = wb[w], t0 = wt0[w];
-  const int valid_rows = (m_first + w < p.MT) ? min(BM, p.Tout - t0) : 0;
-  const char* const otw = ot + (w - w0) * BM * OP;
-  bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
-  for (int q = tid; q < BM * (BN / 8); q += NTHR) {
-    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
-    const int gc = n0 + c8 * 8;
-    if (row < valid_rows && gc < p.Cout) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
-      bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
-      if (p.residual) {
-        const u32x4 o = *reinterpret_cast<const u32x4*>(
-            p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+    for (int kk = 0; kk < 4; ++kk)
+      woff[kk] = (wn * 64 + l31) * 128 + (((kk * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp) pp_barrier();                          // group B runs one slot behind group A
+
+    int c = c_beg, k = 0;   // step s
+    int cw = c_beg, kw = 0; // step s + 2
+    for (int i = 0; i < 2; ++i) { if (++kw == p.K) { kw = 0; ++cw; } }
+
+    unsigned long long* const tl = reinterpret_cast<unsigned long long*>(dump + 1024);
+    const bool rec = DBG && p.dbg && bid < 4 && lane == 0 && (wid & 3) == 0;
+    auto stamp = [&](int s, int i) {
+      if (DBG && rec && s < 48) tl[(grp * 48 + s) * 9 + i] = __builtin_readcyclecounter();
+    };
+    // LDS byte addresses of this lane's X fragments (k-step kk, rows l31 + 32 i of the window)
+    // for the CURRENT step; refreshed for the next step in the odd LOAD slot, which has slack
+    const char* xad[4];
+    auto set_xad = [&](int cc, int kk_tap) {
+      const int r0 = l31 + kk_tap * p.dil;
+      const int m = (r0 >> 1) & 7;
+      const char* const xrow = xbuf0 + (cc & 1) * xbuf_bytes + grp * win_bytes + r0 * 128;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      for (int kk = 0; kk < 4; ++kk) xad[kk] = xrow + (((kk * 2 + lhi) ^ m) << 4);
+    };
+    set_xad(c, k);
+    auto step = [&](auto PAR, int s) {
+      constexpr int PB = decltype(PAR)::value;
+      const char* const ws = wbuf0 + PB * (BN * 128);
+      bf16x8 wf[NI][4], xf[2][4];
+      // ---- LOAD(2s): weight fragments of the step + X fragments of rows 0..63 -----------------
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+          wf[in][kk] = *reinterpret_cast<const bf16x8*>(ws + woff[kk] + in * 4096);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          xf[i2][kk] = *reinterpret_cast<const bf16x8*>(xad[kk] + i2 * 4096);
       }
-      if (p.accumulate) {
-        const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(s, 0);
+      pp_barrier();
+      stamp(s, 1);
+      // ---- COMPUTE(2s): nothing but MFMAs — any other instruction of this wave (a DMA issue
+      //      costs ~45 cycles) would come straight out of the matrix pipe's time
+      if (OS2S_PP_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
-      }
-      *reinterpret_cast<u32x4*>(dst) = v;
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+            acc[in][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in][kk], xf[i2][kk],
+                                                                  acc[in][i2], 0, 0, 0);
+      if (OS2S_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+      stamp(s, 2);
+      pp_barrier();
+      stamp(s, 3);
+      // ---- LOAD(2s+1): X fragments of rows 64..127, then the DMA traffic of the step: drain what
+      //      the previous odd slot issued (a whole step of flight time), issue the weight tile of
+      //      step s+2 (its buffer was last read in LOAD(2s)) and one X instruction of the next
+      //      chunk, and prepare the fragment addresses of step s+1
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          xf[i2][kk] = *reinterpret_cast<const bf16x8*>(xad[kk] + (2 + i2) * 4096);
+      if (DBG) stamp(s, 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(s, 5);
+      if (s + 2 < nsteps) stage_w(cw, kw, PB);
+      if (k < nxi && c + 1 < c_end) stage_x(c + 1, k);
+      if (++k == p.K) { k = 0; ++c; }
+      if (++kw == p.K) { kw = 0; ++cw; }
+      set_xad(c, k);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_barrier();
+      stamp(s, 6);
+      // ---- COMPUTE(2s+1)
+      if (OS2S_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+            acc[in][2 + i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in][kk], xf[i2][kk],
+                                                                      acc[in][2 + i2], 0, 0, 0);
+      if (OS2S_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+      stamp(s, 7);
+      pp_barrier();
+      stamp(s, 8);
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+      step(std::integral_constant<int, 0>{}, s);
+      if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
     }
-  }
+    if (!grp) pp_barrier();
+    if (DBG && p.dbg && bid < 4) {
+      __syncthreads();
+      for (int i = tid; i < 2 * 48 * 9; i += 512) p.dbg[bid * 2 * 48 * 9 + i] = tl[i];
+    }
   }
 
-  if (p.stats) {
-    constexpr int CP = BN / 2;       // column pairs
-    constexpr int RG = (NTHR / CP) > 0 ? (NTHR / CP) : 1;    // row groups
-    const int cp = tid % CP, rg = tid / CP;
+  if (npiece > 1) {
+    // ---- split unit: publish the partial tile, take a ticket; the last arriver reduces ---------
+    const int sidx = rank - nfull;
+    float* const slab0 = p.ws_slabs + (size_t)sidx * f * kPpSlabFloats;
+    float* const mine = slab0 + (size_t)piece * kPpSlabFloats;
 #pragma unroll
-    for (int w = w0; w < w0 + EW; ++w) {
-    if (m_first + w >= p.MT) break;
-    const int m_idx = m_first + w;
-    const int valid_rows = min(BM, p.Tout - wt0[w]);
-    const char* const otw = ot + (w - w0) * BM * OP;
-    if (w > w0) __syncthreads();      // scratch re-use between windows
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    if (rg < RG)
-    for (int row = rg; row < valid_rows; row += RG) {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4);
-      const float a = bflo(v), bb = bfhi(v);
-      s0 += a; q0 += a * a;
-      s1 += bb; q1 += bb * bb;
-    }
-    float* sc = reinterpret_cast<float*>(smem + EW * BM * OP);  // [RG][BN][2]
-    if (rg < RG) {
-    sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
-    sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
-    sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
-    sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
+    for (int in = 0; in < NI; ++in)
+#pragma unroll
+      for (int im = 0; im < MI; ++im)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v = {acc[in][im][4 * g4], acc[in][im][4 * g4 + 1], acc[in][im][4 * g4 + 2],
+                     acc[in][im][4 * g4 + 3]};
+          *reinterpret_cast<f32x4*>(mine + ((((in * MI + im) * 4 + g4) * 512 + tid) << 2)) = v;
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(p.ws_cnt + sidx, 1, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+      *reinterpret_cast<volatile int*>(smem) = old;
     }
     __syncthreads();
-    if (tid < BN) {
-      float s = 0.f, qq = 0.f;
+    const int old = *reinterpret_cast<volatile int*>(smem);
+    if (old != f - 1) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.ws_cnt + sidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // piece order (deterministic), 8 independent 16-B loads in flight per thread
 #pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        s += sc[(g * BN + tid) * 2 + 0];
-        qq += sc[(g * BN + tid) * 2 + 1];
+    for (int in = 0; in < NI; ++in)
+#pragma unroll
+      for (int ih = 0; ih < MI / 2; ++ih) {
+        f32x4 sum[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sum[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jj = 0; jj < f; ++jj) {
+          const float* const sl = slab0 + (size_t)jj * kPpSlabFloats;
+          f32x4 t[8];
+#pragma unroll
+          for (int v = 0; v < 8; ++v)
+            t[v] = *reinterpret_cast<const f32x4*>(
+                sl + ((((in * MI + ih * 2 + (v >> 2)) * 4 + (v & 3)) * 512 + tid) << 2));
+#pragma unroll
+          for (int v = 0; v < 8; ++v) sum[v] += t[v];
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[in][ih * 2 + (v >> 2)][4 * (v & 3) + e] = sum[v][e];
       }
-      const int gc = n0 + tid;
-      if (gc < p.Cout) {
-        p.stats[((long long)m_idx * 2 + 0) * p.Cout + gc] = s;
-        p.stats[((long long)m_idx * 2 + 1) * p.Cout + gc] = qq;
-      }
-    }
-    }
   }
-  }
+  conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
 }
 
 constexpr int kConvBM = 128, kConvBN = 128;
@@ -389,34 +852,113 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
   size_t epi_bytes = (size_t)kEW * BM * kOP + (size_t)kRG * BN * 2 * 4;
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
-  static size_t attr_set = 0;
-  if (smem > attr_set) {
-    if (hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN, NWIN, XSINGLE>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return OS2S_ERR_LAUNCH;
-    attr_set = 160 * 1024;
-  }
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1d_igemm_kernel<BM, BN, WM, WN, NWIN, XSINGLE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
   const int grid = a.MT8 * 8 * a.NT;
   OS2S_LAUNCH((conv1d_igemm_kernel<BM, BN, WM, WN, NWIN, XSINGLE>), dim3(grid), dim3(NTHR), smem,
               stream, a);
   return OS2S_OK;
 }
 
+// Ping-pong kernel launcher; OS2S_ERR_UNSUPPORTED when the shape is outside its envelope
+// (stride 1, Cin a multiple of 64, K long enough to spread the X prefetch, B <= 64, LDS budget).
+// workspace = [1024 int32 tickets, zero on entry and on exit][fp32 partial tiles]; without one
+// the tail of the launch is not split.
+constexpr size_t kPpTicketBytes = 4096;
+static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size_t workspace_bytes) {
+  constexpr int BM = 128, BN = kPpBN, NWIN = 2, NTHR = 512;
+  if (a.stride != 1 || a.Cin % 64 != 0 || a.out_f32 || a.B > 64) return OS2S_ERR_UNSUPPORTED;
+  a.mtiles_per_b = ceil_div(a.Tout, BM);
+  a.MT = a.B * a.mtiles_per_b;
+  a.MT8 = 0;
+  a.NT = ceil_div(a.Cout, BN);
+  a.nchunks = a.Cin / 64;
+  a.R = (BM - 1) + (a.K - 1) * a.dil + 1;
+  a.Rpad = ceil_div(a.R, 8) * 8;
+  const int nxi = (a.Rpad / 8 + 3) / 4;
+  if (a.K <= nxi) return OS2S_ERR_UNSUPPORTED;
+  const bool dbg = a.dbg != nullptr || a.dbg_fixed_w;
+  const size_t main_bytes = (size_t)4 * a.Rpad * 128 + (size_t)2 * BN * 128 + 1024 + (dbg ? 2 * 48 * 9 * 8 : 0);
+  constexpr size_t kOP = BN * 2 + 16;
+  constexpr int kEW = ((size_t)NWIN * BM * kOP > 112 * 1024) ? 1 : NWIN;
+  constexpr int kRG = NTHR / (BN / 2);
+  const size_t epi_bytes = (size_t)kEW * BM * kOP + (size_t)kRG * BN * 2 * 4;
+  const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  static int ncu = 256;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1d_pp_kernel<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc == hipSuccess)
+      attr_rc = hipFuncSetAttribute((const void*)conv1d_pp_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n;
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  a.ncu = ncu;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0;
+  const size_t slab_bytes = (size_t)kPpSlabFloats * 4;
+  if (workspace && workspace_bytes >= kPpTicketBytes + 2 * slab_bytes) {
+    a.ws_cnt = reinterpret_cast<int*>(workspace);
+    a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kPpTicketBytes);
+    size_t n = (workspace_bytes - kPpTicketBytes) / slab_bytes;
+    const size_t cap = (size_t)3 * ncu;
+    a.ws_nslabs = (int)(n < cap ? n : cap);
+  }
+  // upper bound of the grid (the live-window count is only known on the device): every unit of
+  // the padded batch + the pieces of a split tail + the store-only workgroups; surplus
+  // workgroups exit at once
+  const int umax = ceil_div(a.MT, NWIN) * a.NT;
+  const int nzero = a.out_len ? 0 : ceil_div(a.MT, kPpZeroWin);
+  const int grid = umax + a.ws_nslabs + nzero;
+  if (dbg) {
+    OS2S_LAUNCH(conv1d_pp_kernel<true>, dim3(grid), dim3(NTHR), smem, stream, a);
+  } else {
+    OS2S_LAUNCH(conv1d_pp_kernel<false>, dim3(grid), dim3(NTHR), smem, stream, a);
+  }
+  return OS2S_OK;
+}
+
 }  // namespace os2s
 
-// -1 (default) = pick per problem shape between the 128x128 tile (variant 3 / 0), the
-// 256x256 tile (variant 5) and the 256x320 / 256x384 tiles (variants 8 / 9: Cout = 640 / 768
-// in ONE round of workgroups) by timing them once — the lazily built kernel cache of the ABI
-// contract; which one wins is decided by tile quantisation against the 256 CUs (e.g. B*T' =
-// 28k rows: Cout 512 -> 224 256^2 tiles = one round at 975 TF/s vs 824; Cout 640 -> 336 tiles
-// = 1.3 rounds at 712 vs 913).
+// Tile choice is a fixed function of the problem shape (no timing, no hidden state):
+//   * ping-pong kernel (256 x 256 per workgroup, balanced over the live windows) whenever the
+//     shape is inside its envelope and the layer is at least 448 channels wide (below that a
+//     whole unit is shorter than the fixed costs of its workgroup);
+//   * otherwise the lockstep kernel: 256 x 256 tile for wide 1x1 / short-K layers with enough
+//     rows to fill the chip, else the 128 x 128 tile (single-buffered X window for K >= 8).
+// os2s_conv1d_set_variant(v >= 0) forces a tile for experiments and tests:
+//   0 = 128x128, X window double-buffered   3 = 128x128, X window single-buffered when K >= 8
+//   5 = 256x256 lockstep                   10 = ping-pong
 static int g_conv_variant = -1;
-// tuning hook (not part of the stable ABI surface used by the host layer)
+static int g_conv_split = -1;
+static unsigned long long* g_conv_dbg = nullptr;
+static int g_conv_fixed_w = 0;
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
+extern "C" void os2s_conv1d_set_split(int f) { g_conv_split = f; }
+// experiment hook (tools/pp_timeline.py): device buffer of 4*2*48*9 uint64 slot time stamps;
+// fixed_w = every step streams the weight tile of step 0 (always an L2 hit)
+extern "C" void os2s_conv1d_set_debug(void* stamps, int fixed_w) {
+  g_conv_dbg = (unsigned long long*)stamps;
+  g_conv_fixed_w = fixed_w;
+}
 
 extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
   return B * os2s::ceil_div(Tout, os2s::kConvBM);
+}
+
+extern "C" size_t os2s_conv1d_workspace_bytes(void) {
+  return os2s::kPpTicketBytes + (size_t)3 * 256 * os2s::kPpSlabFloats * 4;
 }
 
 static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,
@@ -424,37 +966,8 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
                            int Tin, int Cin, int Cout, int K, int stride, int dil, int padL,
                            int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
                            int accumulate, int act, float keep_prob, unsigned long long seed,
-                           const uint16_t* residual, const int32_t* out_len);
-
-extern "C" int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
-                                  void* y, const int32_t* in_len, const float* bias,
-                                  float* stats, int B, int Tin, int Cin, int Cout, int K,
-                                  int stride, int dil, int padL, int Tout,
-                                  long long y_stride_b, long long y_stride_t, int out_f32,
-                                  int accumulate, int act, float keep_prob,
-                                  unsigned long long seed, const uint16_t* residual,
-                                  const int32_t* out_len) {
-  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
-                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, act, keep_prob,
-                         seed, residual, out_len);
-}
-
-extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
-                               void* y, const int32_t* in_len, const float* bias, float* stats,
-                               int B, int Tin, int Cin, int Cout, int K, int stride, int dil,
-                               int padL, int Tout, long long y_stride_b, long long y_stride_t,
-                               int out_f32, int accumulate) {
-  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
-                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, 0, 1.f, 0,
-                         nullptr, nullptr);
-}
-
-static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
-                           const uint16_t* w, void* y, const int32_t* in_len, const float* bias,
-                           float* stats, int B, int Tin, int Cin, int Cout, int K, int stride,
-                           int dil, int padL, int Tout, long long y_stride_b,
-                           long long y_stride_t, int out_f32, int accumulate, int act,
-                           float keep_prob, unsigned long long seed, const uint16_t* residual, const int32_t* out_len) {
+                           const uint16_t* residual, const int32_t* out_len, void* workspace,
+                           size_t workspace_bytes) {
   using namespace os2s;
   OS2S_REQUIRE(act == 0 || act == 1);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
@@ -473,87 +986,65 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x,
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
   a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
-  if (g_conv_variant == -1) {
-    const int base = K >= 8 ? 3 : 0;
-    auto run = [&](int v) -> int {
-      if (v == 5) return launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
-      if (v == 8) return launch_conv<kConvBM, 320, 4, 2, 2, true>((hipStream_t)stream, a);
-      if (v == 9) return launch_conv<kConvBM, 384, 4, 2, 2, true>((hipStream_t)stream, a);
-      if (v == 3) return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>((hipStream_t)stream, a);
-      return launch_conv<kConvBM, kConvBN, 2, 2, 1>((hipStream_t)stream, a);
-    };
-    const bool tunable = Cout >= 256 && !accumulate && !residual && !out_f32;
-    static std::mutex mu;
-    static std::map<std::array<int, 8>, int> cache;
-    const std::array<int, 8> key = {B, Tin, Cin, Cout, K, stride, dil, Tout};
-    int choice = -1;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      auto it = cache.find(key);
-      if (it != cache.end()) choice = it->second;
-    }
-    if (choice < 0 && Cout < 256) choice = base;
-    if (choice < 0 && !tunable) return run(base);     // decided by a later tunable call of this shape
-    if (choice < 0) {
-      float best = 1e30f;
-      choice = base;
-      hipEvent_t e0, e1;
-      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run(base);
-      // other streams (the weight-gradient side stream of the host layer) must be idle while the
-      // candidates are timed; tuning happens once per shape, outside any graph capture
-      hipDeviceSynchronize();
-      for (int v : {base, 5, 8, 9}) {
-        if (v == 8 && Cout < 512) continue;           // 256x320 / 256x384 tiles: wide layers only
-        if (v == 9 && Cout < 640) continue;
-        if (run(v) != OS2S_OK) continue;              // warm-up (also: unsupported LDS size)
-        for (int rep = 0; rep < 3; ++rep) {           // best of three timings: the clock ramps
-          hipEventRecord(e0, (hipStream_t)stream);
-          for (int r = 0; r < 3; ++r) run(v);
-          hipEventRecord(e1, (hipStream_t)stream);
-          hipEventSynchronize(e1);
-          float ms = 0.f;
-          hipEventElapsedTime(&ms, e0, e1);
-          if (ms > 0.f && ms < best) { best = ms; choice = v; }
-        }
-      }
-      hipEventDestroy(e0);
-      hipEventDestroy(e1);
-      std::lock_guard<std::mutex> lk(mu);
-      cache[key] = choice;
-    }
-    return run(choice);
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256;
+  a.force_split = g_conv_split;
+  a.dbg = g_conv_dbg; a.dbg_fixed_w = g_conv_fixed_w;
+  hipStream_t st = (hipStream_t)stream;
+  int v = g_conv_variant;
+  if (v < 0) {
+    v = K >= 8 ? 3 : 0;
+    if (Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;
+    if (Cout >= 448) v = 10;
   }
-  if (g_conv_variant == 3 && K >= 8) {
-    // single-buffered X window: 3 workgroups per CU
-    return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>((hipStream_t)stream, a);
-  }
-  if (g_conv_variant >= 4 && g_conv_variant <= 6) {
-    // experiments with 256-wide output-channel tiles
-    int rc = OS2S_ERR_UNSUPPORTED;
-    if (g_conv_variant == 4) rc = launch_conv<kConvBM, 256, 2, 4, 2, true>((hipStream_t)stream, a);
-    if (g_conv_variant == 5) rc = launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
-    if (g_conv_variant == 6) rc = launch_conv<kConvBM, 256, 2, 2, 1, true>((hipStream_t)stream, a);
+  if (v == 10) {
+    // the dense-residual / accumulate epilogue variants are all supported by the ping-pong kernel
+    const int rc = launch_conv_pp(st, a, workspace, workspace_bytes);
     if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+    v = K >= 8 ? 3 : 0;
+    if (g_conv_variant < 0 && Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;
   }
-  if (g_conv_variant == 9)
-    return launch_conv<kConvBM, 384, 4, 2, 2, true>((hipStream_t)stream, a);
-  if (g_conv_variant == 7 || g_conv_variant == 8) {
-    // 256 x 384 / 256 x 320 tiles: one round of workgroups for Cout = 768 / 640
-    int rc = OS2S_ERR_UNSUPPORTED;
-    if (g_conv_variant == 7) rc = launch_conv<kConvBM, 384, 2, 4, 2, true>((hipStream_t)stream, a);
-    if (g_conv_variant == 8) rc = launch_conv<kConvBM, 320, 4, 2, 2, true>((hipStream_t)stream, a);
+  if (v == 5) {
+    const int rc = launch_conv<kConvBM, 256, 2, 4, 2, false>(st, a);
     if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+    v = K >= 8 ? 3 : 0;
   }
-  if (g_conv_variant == 2) {
-    // two windows, 4 waves, 128x64 wave tiles (0.75 LDS fragment reads per MFMA)
-    const int rc = launch_conv<kConvBM, kConvBN, 2, 2, 2>((hipStream_t)stream, a);
-    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
-  }
-  if (g_conv_variant == 1) {
-    // two 128-row windows per 8-wave workgroup; falls back when the double-buffered
-    // windows do not fit in LDS (large stride / very long kernels)
-    const int rc = launch_conv<kConvBM, kConvBN, 4, 2, 2>((hipStream_t)stream, a);
-    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
-  }
-  return launch_conv<kConvBM, kConvBN, 2, 2, 1>((hipStream_t)stream, a);
+  if (v == 3 && K >= 8) return launch_conv<kConvBM, kConvBN, 2, 2, 1, true>(st, a);
+  return launch_conv<kConvBM, kConvBN, 2, 2, 1>(st, a);
+}
+
+extern "C" int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
+                                  void* y, const int32_t* in_len, const float* bias,
+                                  float* stats, int B, int Tin, int Cin, int Cout, int K,
+                                  int stride, int dil, int padL, int Tout,
+                                  long long y_stride_b, long long y_stride_t, int out_f32,
+                                  int accumulate, int act, float keep_prob,
+                                  unsigned long long seed, const uint16_t* residual,
+                                  const int32_t* out_len, void* workspace,
+                                  size_t workspace_bytes) {
+  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
+                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, act, keep_prob,
+                         seed, residual, out_len, workspace, workspace_bytes);
+}
+
+extern "C" int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
+                                  void* y, const int32_t* in_len, const float* bias,
+                                  float* stats, int B, int Tin, int Cin, int Cout, int K,
+                                  int stride, int dil, int padL, int Tout,
+                                  long long y_stride_b, long long y_stride_t, int out_f32,
+                                  int accumulate, int act, float keep_prob,
+                                  unsigned long long seed, const uint16_t* residual,
+                                  const int32_t* out_len) {
+  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
+                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, act, keep_prob,
+                         seed, residual, out_len, nullptr, 0);
+}
+
+extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
+                               void* y, const int32_t* in_len, const float* bias, float* stats,
+                               int B, int Tin, int Cin, int Cout, int K, int stride, int dil,
+                               int padL, int Tout, long long y_stride_b, long long y_stride_t,
+                               int out_f32, int accumulate) {
+  return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
+                         padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, 0, 1.f, 0,
+                         nullptr, nullptr, nullptr, 0);
 }

@@ -148,12 +148,12 @@ def test_conv_wgrad(cuda, B, T, Cin, Cout, K, s, d, accumulate):
   torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
 
 
-@pytest.mark.parametrize("variant", [3, 5, 7, 8])
+@pytest.mark.parametrize("variant", [0, 3, 5, 10])
 @pytest.mark.parametrize("B,T,Cin,Cout,K,s,d", [
     (3, 300, 128, 768, 9, 1, 1), (2, 260, 192, 640, 5, 1, 2), (3, 200, 64, 200, 3, 1, 1),
     (2, 140, 128, 384, 7, 2, 1)])
 def test_conv_fwd_tile_variants(cuda, variant, B, T, Cin, Cout, K, s, d):
-  """Every tile shape of the autotune pool (128x128, 256x256, 256x384, 256x320) on the same
+  """Every tile (128x128 with double / single X buffer, 256x256 lockstep, ping-pong) FORCED on the same
   problems, incl. Cout that is not a multiple of the tile and ragged lengths; output, the fused
   ReLU/residual epilogue and the BN partial sums."""
   from openseq2seq_amd import capi, _lib
@@ -181,3 +181,106 @@ def test_conv_fwd_tile_variants(cuda, variant, B, T, Cin, Cout, K, s, d):
   yr = y.float().cpu()
   torch.testing.assert_close(stats[:, 0, :].sum(0).cpu(), yr.sum((0, 1)), rtol=1e-4, atol=1e-2)
   torch.testing.assert_close(stats[:, 1, :].sum(0).cpu(), yr.pow(2).sum((0, 1)), rtol=1e-4, atol=1e-2)
+
+
+PP_CASES = [
+    # B, T, Cin, Cout, K, d  — envelope of the ping-pong kernel (stride 1, Cin % 64 == 0)
+    (3, 420, 256, 512, 17, 1),     # several windows per sample, odd window count per sample
+    (2, 300, 320, 640, 21, 1),     # Cout = 2.5 tiles of 256, 5 chunks x 21 taps = odd step count
+    (2, 700, 128, 768, 25, 1),     # long sequence
+    (2, 333, 768, 896, 29, 2),     # dilated K = 29: largest X window (157 KB of LDS)
+    (5, 129, 64, 256, 11, 1),      # single chunk, 2 windows per sample, second nearly empty
+]
+
+
+@pytest.mark.parametrize("use_ws", [True, False])
+@pytest.mark.parametrize("B,T,Cin,Cout,K,d", PP_CASES)
+def test_conv_pingpong_kernel(cuda, use_ws, B, T, Cin, Cout, K, d):
+  """The ping-pong kernel (conv1d_pp_kernel) forced on Jasper-shaped layers with ragged lengths
+  (dead windows, odd live-window counts), with a workspace (the tail of the launch is split over
+  the input channels and reduced by the last arriver) and without: forward + BN partial sums
+  (dead windows must read as zero rows / zero partials) vs the fp32 oracle, and the
+  data-gradient call (tap-flipped weights, out_len skipping) vs autograd of the oracle.
+  Tolerance: bf16 output rounding, rtol 1e-2 / atol 1e-2 rms."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(B * 1000 + T + K + Cout)
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = _bf(torch.randn(K, Cin, Cout, generator=g) * (1.0 / (K * Cin) ** 0.5))
+  lens = torch.randint(T // 4, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  lens[-1] = max(1, T // 5)            # whole windows of this sample are padding
+  xr = x.float().clone().requires_grad_(True)
+  ref = cnn.conv1d_tf(xr, w_tf.float(), 1, d, "SAME", mask_len=lens)
+  dy = _bf(torch.randn(B, T, Cout, generator=g))
+  mask = (torch.arange(T)[None, :] < lens[:, None]).float()[:, :, None]
+  (ref * dy.float() * mask).sum().backward()     # dY is masked by the consumer (out_len rows)
+  nm = capi.conv1d_num_mtiles(B, T)
+  stats = torch.full((nm, 2, Cout), float("nan"), device=cuda)
+  w_dev = cnn.to_dev_layout(w_tf)
+  wT = w_dev.flip(0).permute(0, 2, 1).contiguous()
+  _, pl = capi.same_padding(T, K, 1, d)
+  dym = _bf(dy.float() * mask)
+  _lib.lib().os2s_conv1d_set_variant(10)
+  try:
+    y = torch.full((B, T, Cout), 5.0, dtype=torch.bfloat16, device=cuda)
+    capi.conv1d_fwd(x.to(cuda), w_dev.to(cuda), dil=d, in_len=lens.to(cuda), stats=stats, out=y,
+                    use_workspace=use_ws)
+    dx = torch.full((B, T, Cin), 7.0, dtype=torch.bfloat16, device=cuda)
+    capi.conv1d_fwd(dym.to(cuda), wT.to(cuda), dil=d, pad_left=(K - 1) * d - pl, tout=T,
+                    in_len=lens.to(cuda), out_len=lens.to(cuda), out=dx, use_workspace=use_ws)
+    torch.cuda.synchronize()
+  finally:
+    _lib.lib().os2s_conv1d_set_variant(-1)
+  _check(y, ref.detach())
+  yr = y.float().cpu()
+  assert bool(torch.isfinite(stats).all())
+  torch.testing.assert_close(stats[:, 0, :].sum(0).cpu(), yr.sum((0, 1)), rtol=1e-4, atol=1e-2)
+  torch.testing.assert_close(stats[:, 1, :].sum(0).cpu(), yr.pow(2).sum((0, 1)), rtol=1e-4, atol=1e-2)
+  if use_ws:   # the tickets are left zero
+    assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0
+  # data gradient: rows below out_len must match autograd (rows past out_len are don't-care:
+  # their tiles may be skipped, the consumer masks them)
+  dxc = dx.float().cpu()
+  gx = xr.grad
+  for b in range(B):
+    n = int(lens[b])
+    scale = float(gx[b, :n].pow(2).mean().sqrt()) + 1e-6
+    torch.testing.assert_close(dxc[b, :n], gx[b, :n], rtol=1e-2, atol=1e-2 * scale)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_conv_pingpong_full_size_vs_lockstep_tile(cuda, ragged):
+  """BASELINE-size layer (Jasper B9/B10: B=32, T'=840, 768 -> 768, K=25; 336 units on 256 CUs, so
+  the dense launch has one full round + a split tail, the ragged one a single partial round).
+  Size-independent property instead of the (slow) CPU oracle: without a workspace the ping-pong
+  kernel accumulates in the same (chunk, tap) order as the oracle-checked 128x128 tile ->
+  outputs and BN partial sums are BIT-IDENTICAL; with the workspace the split tail only changes
+  the fp32 summation order (bf16 outputs within 1 ulp = 2^-8 relative), and two runs agree
+  bitwise (deterministic reduction)."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(77)
+  B, T, C, K = 32, 840, 768, 25
+  x = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  w = _bf(torch.randn(K, C, C, generator=g) * (1.0 / (K * C) ** 0.5)).to(cuda)
+  lens = None
+  if ragged:
+    lens = torch.randint(100, T + 1, (B,), generator=g).to(torch.int32)
+    lens[3] = T
+    lens = lens.to(cuda)
+  nm = capi.conv1d_num_mtiles(B, T)
+  outs = {}
+  try:
+    for name, v, ws in (("tile", 3, False), ("pp", 10, False), ("pp_ws", 10, True), ("pp_ws2", 10, True)):
+      _lib.lib().os2s_conv1d_set_variant(v)
+      st = torch.full((nm, 2, C), float("nan"), device=cuda)
+      y = capi.conv1d_fwd(x, w, in_len=lens, stats=st, use_workspace=ws)
+      torch.cuda.synchronize()
+      outs[name] = (y, st)
+  finally:
+    _lib.lib().os2s_conv1d_set_variant(-1)
+  assert torch.equal(outs["pp"][0], outs["tile"][0])
+  assert torch.equal(outs["pp"][1], outs["tile"][1])
+  assert torch.equal(outs["pp_ws"][0], outs["pp_ws2"][0]) and torch.equal(outs["pp_ws"][1], outs["pp_ws2"][1])
+  a, b = outs["pp_ws"][0].float(), outs["tile"][0].float()
+  assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
+  torch.testing.assert_close(outs["pp_ws"][1].sum(0), outs["tile"][1].sum(0), rtol=1e-3, atol=1e-1)

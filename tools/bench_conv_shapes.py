@@ -1,29 +1,47 @@
 """conv1d fwd at the Jasper 10x5 block shapes (B=32, T=840 after the stride-2 layer) for the tile
-variants: ms and TF/s per (shape, variant). Usage: python tools/bench_conv_shapes.py [variants...]"""
+variants, dense and with the ragged lengths of the bench batch: ms and executed TF/s per
+(shape, variant). Usage: python tools/bench_conv_shapes.py [variants...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from openseq2seq_amd import capi, _lib
 dev = torch.device("cuda:0")
-shapes = [(32, 840, 256, 256, 11), (32, 840, 384, 384, 13), (32, 840, 512, 512, 17),
-          (32, 840, 640, 640, 21), (32, 840, 768, 768, 25), (32, 840, 768, 896, 29), (32, 840, 896, 1024, 1)]
-variants = [int(v) for v in sys.argv[1:]] or [3, 5]
+B, T = 32, 840
+shapes = [(256, 256, 11), (384, 384, 13), (512, 512, 17), (640, 640, 21), (768, 768, 25),
+          (768, 896, 29)]
+variants = [int(v) for v in sys.argv[1:]] or [3, 5, 10]
+rng = np.random.RandomState(1234)
+dur = rng.uniform(2.0, 16.7, size=B)
+lens_np = np.minimum((1 + (dur * 16000).astype(np.int64) // 160 + 1) // 2, T).astype(np.int32)
+live = float(lens_np.sum()) / (B * T)
+print("ragged batch: live frame fraction %.3f" % live)
 res = {}
-for v in variants:
-  _lib.lib().os2s_conv1d_set_variant(v)
-  for B, T, cin, cout, K in shapes:
-    x = torch.randn(B, T, cin, device=dev).to(torch.bfloat16)
-    w = (torch.randn(K, cout, cin, device=dev) * 0.02).to(torch.bfloat16)
-    y = torch.empty(B, T, cout, device=dev, dtype=torch.bfloat16)
-    dil = 2 if K == 29 else 1
-    for _ in range(3): capi.conv1d_fwd(x, w, out=y, dil=dil)
-    torch.cuda.synchronize()
+def timeit(fn, n=10):
+  for _ in range(3): fn()
+  torch.cuda.synchronize()
+  best = 1e9
+  for _ in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10): capi.conv1d_fwd(x, w, out=y, dil=dil)
+    for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    res[(v, cin, cout, K)] = (ms, 2.0 * B * T * cin * cout * K / ms / 1e9)
-for B, T, cin, cout, K in shapes:
+    best = min(best, e0.elapsed_time(e1) / n)
+  return best
+for cin, cout, K in shapes:
+  x = torch.randn(B, T, cin, device=dev).to(torch.bfloat16)
+  w = (torch.randn(K, cout, cin, device=dev) * 0.02).to(torch.bfloat16)
+  y = torch.empty(B, T, cout, device=dev, dtype=torch.bfloat16)
+  nm = capi.conv1d_num_mtiles(B, T)
+  stats = torch.empty(nm, 2, cout, device=dev)
+  rag = torch.from_numpy(lens_np).to(dev)
+  dil = 2 if K == 29 else 1
+  for v in variants:
+    _lib.lib().os2s_conv1d_set_variant(v)
+    ms_d = timeit(lambda: capi.conv1d_fwd(x, w, out=y, dil=dil, stats=stats))
+    ms_r = timeit(lambda: capi.conv1d_fwd(x, w, out=y, dil=dil, stats=stats, in_len=rag))
+    fl = 2.0 * B * T * cin * cout * K
+    res[(v, cin, cout, K)] = (ms_d, fl / ms_d / 1e9, ms_r, fl * live / ms_r / 1e9)
+  _lib.lib().os2s_conv1d_set_variant(-1)
   print("C %4d->%4d K %2d: " % (cin, cout, K) + "  ".join(
-      "v%d %.3f ms %5.0f TF/s" % (v, res[(v, cin, cout, K)][0], res[(v, cin, cout, K)][1]) for v in variants))
+      "v%d %.3f ms %4.0f TF | rag %.3f ms %4.0f TF(live)" % ((v,) + res[(v, cin, cout, K)]) for v in variants), flush=True)
