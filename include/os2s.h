@@ -165,6 +165,21 @@ int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, long long x_ro
                          const uint16_t* dy, float* dw, const int32_t* in_len, int B, int Tin,
                          int Cin, int Cout, int K, int stride, int dil, int padL, int Tout,
                          int accumulate);
+/* Same with a caller-owned workspace (os2s_conv1d_workspace_bytes(), zero tickets, one per
+ * stream — the contract of os2s_conv1d_fwd_ws). Stride-1 layers with K >= 2 run on a kernel that
+ * cuts the reduction over the live (sample, 64-row) chunks when a layer has too few
+ * (co, ci, tap) tiles to fill the chip; partial tiles are reduced in a fixed order by one
+ * owner per tile, which also adds the previous dW when accumulate = 1: no fp32 atomics, results
+ * are run-to-run identical. */
+int os2s_conv1d_wgrad_ws(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                         const uint16_t* dy, float* dw, const int32_t* in_len, int B, int Tin,
+                         int Cin, int Cout, int K, int stride, int dil, int padL, int Tout,
+                         int accumulate, void* workspace, size_t workspace_bytes);
+/* experiment / test hook: variant 0 = lockstep kernel, 1 / -1 = by shape; split > 0 forces the
+ * reduction split factor of the ping-pong kernel (-1 = cost model) */
+void os2s_conv1d_wgrad_set_variant(int variant, int split);
+/* experiment hook (tools/pp_timeline.py): per-slot time stamps of the ping-pong wgrad kernel */
+void os2s_conv1d_wgrad_set_debug(void* stamps, int mode);
 
 /* ------------------------------------------------------------------------
  * BatchNorm + residual sum + activation + dropout + sequence mask

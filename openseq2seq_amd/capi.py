@@ -143,7 +143,7 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
 
 
 def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
-                 out=None, accumulate=False):
+                 out=None, accumulate=False, use_workspace=True):
   """x [B,Tin,Cin] bf16 (may be a channel-slice view of a wider tensor),
   dy [B,Tout,Cout] bf16 -> dW [K,Cout,Cin] fp32."""
   B, Tin, Cin = x.shape
@@ -156,13 +156,15 @@ def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
     assert not accumulate
     out = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
   assert x.stride(2) == 1 and x.stride(0) == Tin * x.stride(1)
-  f = _fn("os2s_conv1d_wgrad_ex",
+  ws = conv1d_workspace(x.device) if use_workspace else None
+  f = _fn("os2s_conv1d_wgrad_ws",
           (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-           c_int, c_int, c_int, c_int, c_int, c_int, c_int))
+           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t))
   _lib.check(f(_stream(), c_void_p(x.data_ptr()), x.stride(1), _ptr(dy, torch.bfloat16),
                _ptr(out, torch.float32), _ptr(in_len, torch.int32, True), B, Tin,
-               Cin, Cout, K, stride, dil, pad_left, Tout, int(accumulate)),
-             "os2s_conv1d_wgrad_ex")
+               Cin, Cout, K, stride, dil, pad_left, Tout, int(accumulate), _ptr(ws, None, True),
+               ws.numel() if ws is not None else 0),
+             "os2s_conv1d_wgrad_ws")
   return out
 
 

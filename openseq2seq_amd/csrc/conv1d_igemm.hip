@@ -31,6 +31,7 @@
 //   * XCD-aware block order: the blocks resident on one XCD at a time share the
 //     same weight n-tile, so the weight stream is an L2 hit for all but one.
 #include "os2s_common.hpp"
+#include "os2s_split_reduce.hpp"
 #include <array>
 #include <type_traits>
 #include <map>
@@ -447,7 +448,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
 //     deterministic — and runs the epilogue. No spinning, so no co-residency assumption.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPpBN = 256;
-constexpr int kPpSlabFloats = 256 * 256;           // one fp32 partial tile
 constexpr int kPpZeroWin = 2;                      // dead windows per store-only workgroup
 #ifndef OS2S_PP_PRIO
 #define OS2S_PP_PRIO 0                             // experiment: s_setprio(1) around the MFMA runs
@@ -505,18 +505,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
     while (f > 1 && (f > p.nchunks || r * f > p.ws_nslabs)) --f;
     if (r == 0) f = 1;
   } else if (r > 0 && p.ws_slabs) {
-    // cost of the tail in microseconds (fitted on MI355X, tools/bench_conv_split.py): a round of
-    // whole units takes S steps x 1.18 us; a split unit adds ~40 us (pipeline fill, partial-tile
-    // store + release, epilogue of the reducer), ~8 us per partial tile the reducer reads back
-    // and 0.17 us per piece of aggregate workspace traffic
-    const float round_us = 1.18f * S;
-    float best = round_us;
-    for (int ff = 2; ff <= 8; ++ff) {
-      if (ff > p.nchunks || r * ff > p.ws_nslabs) break;
-      const float t = (float)((r * ff + G - 1) / G) * round_us / ff + 40.f + 8.f * ff +
-                      0.17f * (r * ff);
-      if (t < 0.95f * best) { best = t; f = ff; }
-    }
+    // a round of whole units takes S steps x 1.18 us (tools/bench_conv_split.py)
+    f = split_factor(r, G, 1.18f * S, p.nchunks < 8 ? p.nchunks : 8, p.ws_nslabs);
   }
   const int nfull = f > 1 ? U - r : U;
   const int nwork = nfull + (f > 1 ? r * f : 0);
@@ -777,58 +767,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
   if (npiece > 1) {
     // ---- split unit: publish the partial tile, take a ticket; the last arriver reduces ---------
     const int sidx = rank - nfull;
-    float* const slab0 = p.ws_slabs + (size_t)sidx * f * kPpSlabFloats;
-    float* const mine = slab0 + (size_t)piece * kPpSlabFloats;
-#pragma unroll
-    for (int in = 0; in < NI; ++in)
-#pragma unroll
-      for (int im = 0; im < MI; ++im)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          f32x4 v = {acc[in][im][4 * g4], acc[in][im][4 * g4 + 1], acc[in][im][4 * g4 + 2],
-                     acc[in][im][4 * g4 + 3]};
-          *reinterpret_cast<f32x4*>(mine + ((((in * MI + im) * 4 + g4) * 512 + tid) << 2)) = v;
-        }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int old = __hip_atomic_fetch_add(p.ws_cnt + sidx, 1, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-      *reinterpret_cast<volatile int*>(smem) = old;
-    }
-    __syncthreads();
-    const int old = *reinterpret_cast<volatile int*>(smem);
-    if (old != f - 1) return;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(p.ws_cnt + sidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    // piece order (deterministic), 8 independent 16-B loads in flight per thread
-#pragma unroll
-    for (int in = 0; in < NI; ++in)
-#pragma unroll
-      for (int ih = 0; ih < MI / 2; ++ih) {
-        f32x4 sum[8];
-#pragma unroll
-        for (int v = 0; v < 8; ++v) sum[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int jj = 0; jj < f; ++jj) {
-          const float* const sl = slab0 + (size_t)jj * kPpSlabFloats;
-          f32x4 t[8];
-#pragma unroll
-          for (int v = 0; v < 8; ++v)
-            t[v] = *reinterpret_cast<const f32x4*>(
-                sl + ((((in * MI + ih * 2 + (v >> 2)) * 4 + (v & 3)) * 512 + tid) << 2));
-#pragma unroll
-          for (int v = 0; v < 8; ++v) sum[v] += t[v];
-        }
-#pragma unroll
-        for (int v = 0; v < 8; ++v)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[in][ih * 2 + (v >> 2)][4 * (v & 3) + e] = sum[v][e];
-      }
+    auto at = [&](int v) -> f32x16& { return acc[v >> 2][v & 3]; };
+    if (!split_publish_and_reduce(at, p.ws_slabs + (size_t)sidx * f * kSplitSlabFloats,
+                                  p.ws_cnt + sidx, piece, f, smem, tid))
+      return;
   }
   conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
 }
@@ -869,7 +811,6 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
 // (stride 1, Cin a multiple of 64, K long enough to spread the X prefetch, B <= 64, LDS budget).
 // workspace = [1024 int32 tickets, zero on entry and on exit][fp32 partial tiles]; without one
 // the tail of the launch is not split.
-constexpr size_t kPpTicketBytes = 4096;
 static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size_t workspace_bytes) {
   constexpr int BM = 128, BN = kPpBN, NWIN = 2, NTHR = 512;
   if (a.stride != 1 || a.Cin % 64 != 0 || a.out_f32 || a.B > 64) return OS2S_ERR_UNSUPPORTED;
@@ -907,11 +848,11 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
   a.ncu = ncu;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0;
-  const size_t slab_bytes = (size_t)kPpSlabFloats * 4;
-  if (workspace && workspace_bytes >= kPpTicketBytes + 2 * slab_bytes) {
+  const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+  if (workspace && workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
     a.ws_cnt = reinterpret_cast<int*>(workspace);
-    a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kPpTicketBytes);
-    size_t n = (workspace_bytes - kPpTicketBytes) / slab_bytes;
+    a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+    size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
     const size_t cap = (size_t)3 * ncu;
     a.ws_nslabs = (int)(n < cap ? n : cap);
   }
@@ -958,7 +899,7 @@ extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
 }
 
 extern "C" size_t os2s_conv1d_workspace_bytes(void) {
-  return os2s::kPpTicketBytes + (size_t)3 * 256 * os2s::kPpSlabFloats * 4;
+  return os2s::kSplitTicketBytes + (size_t)3 * 256 * os2s::kSplitSlabFloats * 4;
 }
 
 static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,

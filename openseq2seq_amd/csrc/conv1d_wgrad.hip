@@ -26,6 +26,8 @@
 #include <stdlib.h>
 
 #include "os2s_common.hpp"
+#include "os2s_split_reduce.hpp"
+#include <mutex>
 
 namespace os2s {
 
@@ -37,7 +39,15 @@ struct WgradArgs {
   int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
   int NCO, NCI, NTP, NSPLIT, steps_per_split, use_atomic;
   int xrows, xrows_pad;  // X window rows per 64-step (and padded to x4)
+  int xbuf_bytes, steptab_bytes;   // ping-pong kernel: X ring slot size, step table size
   long long x_ld;        // x row stride in elements (>= Cin; channel slice of a wider tensor)
+  int accumulate;
+  // ping-pong kernel: split-unit workspace (os2s_split_reduce.hpp)
+  float* ws_slabs;
+  int* ws_cnt;
+  int ws_nslabs, ncu, force_split;
+  unsigned long long* dbg;   // experiment hook: slot time stamps [4 wg][2 waves][48 steps][10]
+  int dbg_mode;              // experiment hook (DBG kernel): 1 no dY DMA, 2 no X DMA, 4 frozen cursor
 };
 
 __device__ __forceinline__ void dma16w(const void* gsrc, char* lds_wave_base) {
@@ -250,53 +260,496 @@ __global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_ke
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong weight-gradient kernel (stride 1, K >= 2): same slot structure as conv1d_pp_kernel.
+//
+// Workgroup tile: 128 output channels x 128 input channels x FOUR adjacent taps, 8 waves, from
+// one dY tile [64 t][128 co] and one (64 + 3 dil)-row X window [t][128 ci] per reduction step
+// (34 KB of LDS-DMA per 32 MFMAs per wave — the DMA issue of the loading wave, ~75 cycles per
+// 1-KB instruction, is what bounds the odd slot; a 256 x 128 x 2-tap tile needs 49 KB).
+// Waves 0-3 ("group A") accumulate taps k0, k0+1, waves 4-7 ("group B") taps k0+2, k0+3. A wave
+// owns 64 co x 64 ci of each of its two taps (128 accumulator registers); an item is one 64-row
+// reduction step of one tap = 16 MFMA 32x32x16. Wave w and wave w+4 share a SIMD: in every
+// barrier-delimited slot one of them issues its 16 MFMAs while the other fetches fragments
+// (transpose reads, ds_read_b64_tr_b16: the reduction index is the ROW index of both operands
+// in memory) and issues the LDS-DMA of the step two ahead.
+//
+//   LOAD(2s)   : dY fragments of step s (kept for both taps) + X fragments of the first tap
+//   LOAD(2s+1) : X fragments of the second tap; drain the DMA issued one step ago; issue step
+//                s+2 (X into a ring of 3 — the other group still reads the X window of step s in
+//                ITS odd slot — dY into a ring of 2: dY is only read in even slots)
+//
+// The reduction runs over the LIVE 64-row chunks of the ragged batch only (rows past in_len are
+// zero conv inputs). Units (co tile, ci tile, tap quad) that do not fill the last round of
+// workgroups are cut f ways along the reduction and reduced deterministically by the last
+// arriver (os2s_split_reduce.hpp): no fp32 atomics, dW written once by one owner.
+// ---------------------------------------------------------------------------------------------
+// Transpose read as inline assembly (32-bit LDS byte address + immediate offset). hipcc (ROCm
+// 7.2) drains vmcnt(0) in front of the first LDS read it can see after an LDS-DMA issue, which
+// here would wait for the tiles of step s+2 one COMPUTE slot after they were requested; these
+// reads only ever touch tiles whose DMA was drained explicitly (vmcnt(0) + barrier, above).
+// The compiler does not count them in lgkmcnt either: every LOAD slot ends with an explicit
+// s_waitcnt lgkmcnt(0) followed by a scheduling barrier before the first use.
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr_asm(unsigned addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// one bf16x8 MFMA operand = rows r0 and r0+4 (1024 B apart) of k-slice KK (4096 B apart)
+template <int KK>
+__device__ __forceinline__ bf16x8 lds_frag(unsigned addr) {
+  const bf16x4 lo = lds_tr_asm<KK * 4096>(addr);
+  const bf16x4 hi = lds_tr_asm<KK * 4096 + 1024>(addr);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ void wpp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int kWppTaps = 4;
+
+// DBG: per-slot s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py)
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
+  constexpr int BT = 64, COT = 128, CIT = 128;
+  constexpr int YBUF = BT * 256;                           // dY tile [64 rows][128 ch]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wq = wid & 3;
+  const int wm = wq >> 1, wn = wq & 1;                     // co 64-half, ci 64-half
+
+  // ---- live 64-row chunks per sample (one value per lane, B <= 64), inclusive scan -----------
+  const int tchunks = (p.Tout + BT - 1) / BT;
+  int nl = 0, len_l = 0;
+  if (lane < p.B) {
+    len_l = p.Tin;
+    if (p.in_len) {
+      const int l = p.in_len[lane];
+      len_l = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+    }
+    nl = len_l > 0 ? (len_l + p.padL + BT - 1) / BT : 0;
+    nl = nl < tchunks ? nl : tchunks;
+  }
+  int scan = nl;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(scan, o, 64);
+    if (lane >= o) scan += t;
+  }
+  const int total_live = __builtin_amdgcn_readlane(scan, 63);
+
+  // ---- block -> (unit, piece) -------------------------------------------------------------
+  const int U = p.NCO * p.NCI * p.NTP, G = p.ncu;
+  const int q = U / G, r = U - q * G;
+  int f = 1;
+  {
+    int fmax = total_live / 8;                             // >= 8 steps per piece
+    fmax = fmax > 16 ? 16 : fmax;
+    if (p.force_split > 0 && p.ws_slabs) {
+      f = p.force_split < fmax ? p.force_split : (fmax > 1 ? fmax : 1);
+      while (f > 1 && r * f > p.ws_nslabs) --f;
+      if (r == 0) f = 1;
+    } else if (r > 0 && p.ws_slabs) {
+      f = split_factor(r, G, 1.1f * total_live, fmax, p.ws_nslabs);
+    }
+  }
+  const int nfull = f > 1 ? U - r : U;
+  const int nwork = nfull + (f > 1 ? r * f : 0);
+  const int bid = blockIdx.x;
+  if (bid >= nwork) return;
+  int rank = bid, piece = 0, npiece = 1;
+  if (bid >= nfull) {
+    const int i = bid - nfull;
+    rank = nfull + i / f;
+    piece = i - (i / f) * f;
+    npiece = f;
+  }
+  // tap quads of one (co, ci) tile are adjacent ranks: they stream the same dY / X rows
+  const int tp = rank % p.NTP;
+  const int rem = rank / p.NTP;
+  const int co0 = (rem / p.NCI) * COT, ci0 = (rem % p.NCI) * CIT;
+  const int k0 = tp * kWppTaps;
+  const int sps = (total_live + npiece - 1) / npiece;
+  const int s_begin = __builtin_amdgcn_readfirstlane(min(piece * sps, total_live));
+  const int s_end = __builtin_amdgcn_readfirstlane(min(total_live, s_begin + sps));
+  const int nsteps = s_end - s_begin;
+
+  // LDS: dY ring (2 x 16 KB) | X ring (3 x xbuf_bytes, each rounded up to whole 8-wave DMA
+  // rounds so that no wave needs a predicate for its first two X instructions) | step table
+  const int xbuf_bytes = p.xbuf_bytes;
+  char* const ybuf0 = smem;
+  char* const xbuf0 = smem + 2 * YBUF;
+  int* const steptab = reinterpret_cast<int*>(xbuf0 + 3 * xbuf_bytes);
+
+  // ---- step table: entry i = (sample, 64-row chunk, in_len) of reduction step s_begin + i ------
+  // built once by the lanes that own a sample; the loop then needs no cursor logic, no branch
+  // and no global scalar load: one LDS dword per step, read a step ahead.
+  {
+    const int excl = scan - nl;
+    for (int c = 0; c < tchunks; ++c) {
+      const int idx = excl + c - s_begin;
+      if (lane < p.B && c < nl && idx >= 0 && idx < nsteps && wid == 0)
+        steptab[idx] = lane | (c << 8) | (len_l << 16);
+    }
+  }
+
+  // ---- DMA: per-lane byte offsets are fixed for the kernel ------------------------------------
+  // dY tile: 64 rows x 16 pieces of 16 B = 16 instructions, 2 per wave. LDS piece q of a 256-B
+  // row holds the channel block given by the 32-B-unit XOR swizzle (as the tr reads expect).
+  int yv[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int qq = (it * 8 + wid) * 64 + lane;
+    const int row = qq >> 4, ps = qq & 15;
+    const int u = (ps >> 1) ^ ((row & 3) << 1);
+    const int ch = co0 + ((u << 1) | (ps & 1)) * 8;
+    yv[it] = ch < p.Cout ? (row * p.Cout + ch) * 2 : (int)0x80000000;
+  }
+  // X window: xrows rows x 16 pieces, 3 instructions per wave (24 x 4 rows >= 64 + 3 dil rows);
+  // lanes past the window / past Cin carry an offset that stays out of range after the row
+  // offset of the step is added (|row offset| < 2^30, see the launcher)
+  int xv[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    const int qq = (n * 8 + wid) * 64 + lane;
+    const int row = qq >> 4, ps = qq & 15;
+    const int u = (ps >> 1) ^ ((row & 3) << 1);
+    const int ch = ci0 + ((u << 1) | (ps & 1)) * 8;
+    xv[n] = (ch < p.Cin && row < p.xrows) ? (row * (int)p.x_ld + ch) * 2 : (int)0x80000000;
+  }
+  const bool x3 = 16 + wid < ((p.xrows * 16 + 63) >> 6);   // does this wave own a third X instruction
+  const unsigned long long dy_base = (unsigned long long)p.dy, x_base = (unsigned long long)p.x;
+  const int ycol_bytes = __builtin_amdgcn_readfirstlane(p.Cout * 2);
+  const int xcol_bytes = __builtin_amdgcn_readfirstlane((int)p.x_ld * 2);
+  const unsigned long long xsample_bytes = (unsigned long long)p.Tin * (unsigned long long)p.x_ld * 2ull;
+  // stage the tiles of the step described by table entry `ent`
+  auto stage = [&](int ent, int ybuf_idx, int xbuf_idx) {
+    const int b = ent & 0xff, t0 = ((ent >> 8) & 0xff) * BT, len_b = (int)((unsigned)ent >> 16);
+    // dY rows t0.. of sample b; num_records up to the sample end (rows >= Tout read as zeros)
+    const unsigned long long yb = dy_base + (unsigned long long)(unsigned)(b * p.Tout + t0) * (unsigned)ycol_bytes;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)yb, 0, (p.Tout - t0) * ycol_bytes, 0x00020000);
+    char* const yd = ybuf0 + ybuf_idx * YBUF;
+    if (!(DBG && (p.dbg_mode & 1)))
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          yrs, (__attribute__((address_space(3))) void*)(yd + (it * 8 + wid) * 1024), 16, yv[it], 0, 0, 0);
+    // X rows of sample b, num_records = in_len rows: rows < 0 (a negative offset) and rows >=
+    // in_len read as zeros
+    const unsigned long long xb = x_base + (unsigned long long)(unsigned)b * xsample_bytes;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)xb, 0, len_b * xcol_bytes, 0x00020000);
+    const int xro = (t0 + k0 * p.dil - p.padL) * xcol_bytes;
+    char* const xd = xbuf0 + xbuf_idx * xbuf_bytes;
+    if (!(DBG && (p.dbg_mode & 2))) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            xrs, (__attribute__((address_space(3))) void*)(xd + (n * 8 + wid) * 1024), 16,
+            xv[n] + xro, 0, 0, 0);
+      if (x3)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            xrs, (__attribute__((address_space(3))) void*)(xd + (16 + wid) * 1024), 16, xv[2] + xro, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2][2];                                     // [tap of the pair][i][j]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[e][i][j][v] = 0.f;
+
+  const int lhi = lane >> 5;
+  if (nsteps > 0) {
+    // per-lane constants of the transpose reads (relative to the tile base)
+    const int g16 = (lane >> 4) & 1;   // which 16-column block of the 32-wide MFMA tile
+    const int i16 = lane & 15;
+    const int rsub = i16 >> 2;         // row within the 4-row block this lane addresses
+    const int csub = (i16 & 3) * 8;    // byte offset of its 4-element chunk
+    int ya[2], xa[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = 4 * wm + 2 * i + g16;
+      ya[i] = (lhi * 8 + rsub) * 256 + ((u ^ ((rsub & 3) << 1)) << 5) + csub;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r0 = lhi * 8 + rsub + (2 * grp + e) * p.dil;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int u = 4 * wn + 2 * j + g16;
+        xa[e][j] = r0 * 256 + ((u ^ ((r0 & 3) << 1)) << 5) + csub;
+      }
+    }
+    __syncthreads();                                       // step table complete
+    stage(__builtin_amdgcn_readfirstlane(steptab[0]), 0, 0);
+    if (nsteps > 1) stage(__builtin_amdgcn_readfirstlane(steptab[1]), 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp) wpp_barrier();                                // group B runs one slot behind group A
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    unsigned long long* const tl = reinterpret_cast<unsigned long long*>(xbuf0 + 3 * xbuf_bytes + p.steptab_bytes);
+    const unsigned tab0 = lds0 + 2 * YBUF + 3 * xbuf_bytes;
+    const bool rec = DBG && p.dbg && bid < 4 && lane == 0 && (wid & 3) == 0;
+    auto stamp = [&](int s, int i) {
+      if (DBG && rec && s < 48) tl[(grp * 48 + s) * 10 + i] = __builtin_readcyclecounter();
+    };
+    int xi = 0;                                            // ring slot of the current step's X
+    for (int s = 0; s < nsteps; ++s) {
+      const unsigned ys = lds0 + (s & 1) * YBUF;
+      const unsigned xs = lds0 + 2 * YBUF + xi * xbuf_bytes;
+      bf16x8 xf[2][4], yf[2][4];
+      // ---- LOAD(2s): also the table entry of step s+2 (consumed in the odd slot)
+      int ent_v;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(ent_v) : "v"(tab0 + (s + 2 < nsteps ? s + 2 : s) * 4) : "memory");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        yf[i][0] = lds_frag<0>(ys + ya[i]); yf[i][1] = lds_frag<1>(ys + ya[i]);
+        yf[i][2] = lds_frag<2>(ys + ya[i]); yf[i][3] = lds_frag<3>(ys + ya[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        xf[j][0] = lds_frag<0>(xs + xa[0][j]); xf[j][1] = lds_frag<1>(xs + xa[0][j]);
+        xf[j][2] = lds_frag<2>(xs + xa[0][j]); xf[j][3] = lds_frag<3>(xs + xa[0][j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(s, 0);
+      wpp_barrier();
+      stamp(s, 1);
+      // ---- COMPUTE(2s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[0][i][j], 0, 0, 0);
+      stamp(s, 2);
+      wpp_barrier();
+      stamp(s, 3);
+      // ---- LOAD(2s+1): X fragments of the second tap; then drain the DMA issued one step ago
+      //      and issue step s+2 (X slot (s+2) % 3 was last read one step ago, the dY slot in the
+      //      even slots of this step)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        xf[j][0] = lds_frag<0>(xs + xa[1][j]); xf[j][1] = lds_frag<1>(xs + xa[1][j]);
+        xf[j][2] = lds_frag<2>(xs + xa[1][j]); xf[j][3] = lds_frag<3>(xs + xa[1][j]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(s, 4); }
+      {
+        int x2 = xi + 2;
+        x2 = x2 >= 3 ? x2 - 3 : x2;
+        if (s + 2 < nsteps) stage(__builtin_amdgcn_readfirstlane(ent_v), s & 1, x2);
+        xi = xi + 1 >= 3 ? 0 : xi + 1;
+      }
+      stamp(s, 5);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(s, 6);
+      wpp_barrier();
+      stamp(s, 7);
+      // ---- COMPUTE(2s+1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[1][i][j], 0, 0, 0);
+      stamp(s, 8);
+      wpp_barrier();
+      stamp(s, 9);
+    }
+    if (!grp) wpp_barrier();
+    if (DBG && p.dbg && bid < 4) {
+      __syncthreads();
+      for (int i = tid; i < 2 * 48 * 10; i += 512) p.dbg[bid * 2 * 48 * 10 + i] = tl[i];
+    }
+  }
+  __syncthreads();
+
+  if (npiece > 1) {
+    const int sidx = rank - nfull;
+    auto at = [&](int v) -> f32x16& { return acc[v >> 2][(v >> 1) & 1][v & 1]; };
+    if (!split_publish_and_reduce(at, p.ws_slabs + (size_t)sidx * f * kSplitSlabFloats,
+                                  p.ws_cnt + sidx, piece, f, smem, tid))
+      return;
+  }
+
+  // ---- epilogue: the one owner of the tile writes dW (fp32), ci contiguous across lanes -------
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int tap = k0 + 2 * grp + e;
+    if (tap < p.K) {
+      float* const dwk = p.dw + (long long)tap * p.Cout * p.Cin;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ci = ci0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int co = co0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lhi;
+            if (co < p.Cout && ci < p.Cin) {
+              float* dst = dwk + (long long)co * p.Cin + ci;
+              float val = acc[e][i][j][v];
+              if (p.accumulate) val += *dst;
+              *dst = val;
+            }
+          }
+        }
+    }
+  }
+}
+
 }  // namespace os2s
 
-// accumulate: 0 = dW is overwritten (one batch split) / must be pre-zeroed by
-// the caller when the kernel decides to split; to keep the contract simple the
-// caller always passes a buffer that is either zero or holds the running sum
-// it wants to add to, and sets accumulate accordingly:
-//   accumulate = 0 : dW = grad       (kernel never splits the batch)
-//   accumulate = 1 : dW += grad      (atomics; batch may be split for occupancy)
-extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+// accumulate = 0 : dW = grad;  accumulate = 1 : dW += grad.
+// With a workspace (os2s_conv1d_workspace_bytes(), zero tickets, one per stream — the same
+// contract as os2s_conv1d_fwd_ws) the ping-pong kernel spreads small layers over the chip by
+// cutting the reduction; its result is deterministic and written by one owner per element.
+// The lockstep kernel (stride > 1, K = 1, narrow layers) splits the batch with fp32 atomics when
+// accumulate = 1 and the layer is too small to fill the chip otherwise.
+static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                             const uint16_t* dy, float* dw, const int32_t* in_len, int B,
+                             int Tin, int Cin, int Cout, int K, int stride, int dil,
+                             int padL, int Tout, int accumulate, void* workspace,
+                             size_t workspace_bytes);
+
+static int g_wgrad_variant = -1;   // experiment / test hook: 0 = lockstep kernel, 1 = ping-pong
+static int g_wgrad_split = -1;
+static unsigned long long* g_wgrad_dbg = nullptr;
+static int g_wgrad_dbg_mode = 0;
+extern "C" void os2s_conv1d_wgrad_set_debug(void* stamps, int mode) {
+  g_wgrad_dbg = (unsigned long long*)stamps;
+  g_wgrad_dbg_mode = mode;
+}
+extern "C" void os2s_conv1d_wgrad_set_variant(int v, int split) {
+  g_wgrad_variant = v;
+  g_wgrad_split = split;
+}
+
+extern "C" int os2s_conv1d_wgrad_ws(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
                                     const uint16_t* dy, float* dw, const int32_t* in_len, int B,
                                     int Tin, int Cin, int Cout, int K, int stride, int dil,
-                                    int padL, int Tout, int accumulate);
-
-extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
-                                 const uint16_t* dy, float* dw,
-                                 const int32_t* in_len, int B, int Tin, int Cin,
-                                 int Cout, int K, int stride, int dil, int padL,
-                                 int Tout, int accumulate) {
-  return os2s_conv1d_wgrad_ex(stream, x, Cin, dy, dw, in_len, B, Tin, Cin, Cout, K, stride, dil,
-                              padL, Tout, accumulate);
+                                    int padL, int Tout, int accumulate, void* workspace,
+                                    size_t workspace_bytes) {
+  return conv1d_wgrad_impl(stream, x, x_row_stride, dy, dw, in_len, B, Tin, Cin, Cout, K, stride,
+                           dil, padL, Tout, accumulate, workspace, workspace_bytes);
 }
 
 extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
                                     const uint16_t* dy, float* dw, const int32_t* in_len, int B,
                                     int Tin, int Cin, int Cout, int K, int stride, int dil,
                                     int padL, int Tout, int accumulate) {
+  return conv1d_wgrad_impl(stream, x, x_row_stride, dy, dw, in_len, B, Tin, Cin, Cout, K, stride,
+                           dil, padL, Tout, accumulate, nullptr, 0);
+}
+
+extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
+                                 const uint16_t* dy, float* dw,
+                                 const int32_t* in_len, int B, int Tin, int Cin,
+                                 int Cout, int K, int stride, int dil, int padL,
+                                 int Tout, int accumulate) {
+  return conv1d_wgrad_impl(stream, x, Cin, dy, dw, in_len, B, Tin, Cin, Cout, K, stride, dil,
+                           padL, Tout, accumulate, nullptr, 0);
+}
+
+static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                             const uint16_t* dy, float* dw, const int32_t* in_len, int B,
+                             int Tin, int Cin, int Cout, int K, int stride, int dil,
+                             int padL, int Tout, int accumulate, void* workspace,
+                             size_t workspace_bytes) {
   using namespace os2s;
   OS2S_REQUIRE(x_row_stride >= Cin && x_row_stride % 8 == 0);
   OS2S_REQUIRE(x && dy && dw);
   OS2S_REQUIRE(B >= 0 && Tin >= 1 && Tout >= 1 && Cin >= 8 && Cout >= 8 && K >= 1);
   OS2S_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && stride >= 1 && dil >= 1);
   if (B == 0) return OS2S_OK;
-  // taps per workgroup: the dY tile of a step is reused by every tap, so L2->LDS bytes per
-  // FLOP fall as 1/TAPS (2 taps: 173 FLOP/B, 3 taps: 257 FLOP/B — the kernels run against
-  // the ~7.3 TB/s L2->CU delivery limit, not against MFMA); 3 x 64 accumulator registers fit
-  // the 256-register budget of 2 waves/SIMD.
-  // (measured: the 3-tap instantiation needs 256 VGPRs + 84 B/lane of scratch and is 20-25 %
-  // SLOWER than 2 taps on every Jasper layer — kept selectable for future register work.)
-  int TAPS = K == 1 ? 1 : 2;      // 1x1 convs: one accumulator set, no idle tap slot
-  if (const char* f = getenv("OS2S_WGRAD_TAPS")) { const int v = atoi(f); if ((v == 2 || v == 3) && K > 1) TAPS = v; }
-  // the 256-wide tile pays off once there are enough 256-channel tiles to fill the chip
-  const bool wide = (Cout % 256 == 0) && (K >= 8) && (Cout >= 512);
-  const int COT = wide ? 256 : 128;
   WgradArgs a;
   a.x = x; a.dy = dy; a.dw = dw; a.in_len = in_len;
   a.B = B; a.Tin = Tin; a.Tout = Tout; a.Cin = Cin; a.Cout = Cout; a.K = K;
   a.stride = stride; a.dil = dil; a.padL = padL; a.x_ld = x_row_stride;
+  a.accumulate = accumulate ? 1 : 0;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
+  a.dbg = g_wgrad_dbg; a.dbg_mode = g_wgrad_dbg_mode;
+
+  // ---- ping-pong kernel ------------------------------------------------------------------
+  const bool pp_shape = stride == 1 && K >= 2 && B <= 64 && Cout >= 128 && Cin >= 64 &&
+                        Tin < 65536 && Tout <= 255 * 64 && 63 + 3 * dil + 1 <= 96 &&
+                        (long long)Tin * x_row_stride * 2 < (1ll << 30) &&
+                        (long long)Tin * x_row_stride * 2 < (1ll << 31) &&
+                        (long long)Tout * Cout * 2 < (1ll << 31);
+  // (co, ci, tap pair) tiles of the ping-pong kernel; very small layers (< 40 tiles) are faster on
+  // the 128 x 128 tiles of the lockstep kernel
+  const int pp_units = ceil_div(Cout, 128) * ceil_div(Cin, 128) * ceil_div(K, kWppTaps);
+  if (pp_shape && g_wgrad_variant != 0 && (g_wgrad_variant == 1 || pp_units >= 40)) {
+    a.NCO = ceil_div(Cout, 128);
+    a.NCI = ceil_div(Cin, 128);
+    a.NTP = ceil_div(K, kWppTaps);
+    a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
+    a.xrows = 63 + (kWppTaps - 1) * dil + 1;
+    a.xrows_pad = ceil_div(a.xrows, 4) * 4;
+    a.xbuf_bytes = 24 * 1024;                         // 3 DMA rounds of 8 waves x 1 KB
+    a.steptab_bytes = ceil_div(B * ceil_div(Tout, 64) * 4, 16) * 16;
+    const size_t smem = (size_t)2 * 64 * 256 + (size_t)3 * a.xbuf_bytes + a.steptab_bytes + (a.dbg ? 2 * 48 * 10 * 8 : 0);
+    if (smem <= 160 * 1024) {
+      static std::once_flag once;
+      static hipError_t attr_rc = hipSuccess;
+      static int ncu = 256;
+      std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute((const void*)conv1d_wgrad_pp_kernel<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_rc == hipSuccess)
+          attr_rc = hipFuncSetAttribute((const void*)conv1d_wgrad_pp_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+          ncu = n;
+      });
+      if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+      a.ncu = ncu;
+      const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+      if (workspace && workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
+        a.ws_cnt = reinterpret_cast<int*>(workspace);
+        a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+        size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
+        const size_t cap = (size_t)3 * ncu;
+        a.ws_nslabs = (int)(n < cap ? n : cap);
+      }
+      // upper bound of the grid (the split factor is decided on the device from the live
+      // length of the batch): whole units, or up to 16 pieces of each unit of the tail
+      const int U = a.NCO * a.NCI * a.NTP;
+      const int r = U % ncu;
+      int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
+      const int grid = U + pieces;
+      if (a.dbg) {
+        OS2S_LAUNCH(conv1d_wgrad_pp_kernel<true>, dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+      } else {
+        OS2S_LAUNCH(conv1d_wgrad_pp_kernel<false>, dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
+      }
+      return OS2S_OK;
+    }
+  }
+
+  // ---- lockstep kernel ---------------------------------------------------------------------
+  const int TAPS = K == 1 ? 1 : 2;      // 1x1 convs: one accumulator set, no idle tap slot
+  // the 256-wide tile pays off once there are enough 256-channel tiles to fill the chip
+  const bool wide = (Cout % 256 == 0) && (K >= 8) && (Cout >= 512);
+  const int COT = wide ? 256 : 128;
   a.NCO = ceil_div(Cout, COT);
   a.NCI = ceil_div(Cin, 128);
   a.NTP = ceil_div(K, TAPS);
@@ -306,17 +759,11 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   if (accumulate) {
     // ~1 round of workgroups: the kernel shares the GPU with the data-gradient chain (side
     // stream), where fewer, longer workgroups and fewer atomic passes over dW win slightly
-    // (Jasper step 56.1 -> 55.7 ms; 2 rounds were better when the kernel ran alone)
-    int target = wide ? 256 : 512;
-    if (const char* f = getenv("OS2S_WGRAD_TARGET")) { const int v = atoi(f); if (v > 0) target = v; }
+    const int target = wide ? 256 : 512;
     nsplit = ceil_div(target, base_blocks);
     const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;   // >= 8 steps per block
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
-  }
-  if (const char* f = getenv("OS2S_WGRAD_NSPLIT")) {      // tuning hook (tools/bench_wgrad_shapes.py)
-    const int v = atoi(f);
-    if (v >= 1 && accumulate) nsplit = v > total_steps ? total_steps : v;
   }
   a.steps_per_split = ceil_div(total_steps, nsplit);
   a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
@@ -325,8 +772,9 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
   a.xrows_pad = ceil_div(a.xrows, 4) * 4;
   const size_t smem = (size_t)2 * 64 * 2 * COT + (size_t)2 * a.xrows_pad * 256;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag once2;
+  static hipError_t attr_rc2 = hipSuccess;
+  std::call_once(once2, [] {
     if (hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<2, 128>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<2, 256>,
@@ -334,27 +782,19 @@ extern "C" int os2s_conv1d_wgrad_ex(os2s_stream_t stream, const uint16_t* x, lon
         hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<1, 128>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<1, 256>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<3, 128>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv1d_wgrad_kernel<3, 256>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return OS2S_ERR_LAUNCH;
-    attr_set = true;
-  }
+      attr_rc2 = hipErrorUnknown;
+  });
+  if (attr_rc2 != hipSuccess) return OS2S_ERR_LAUNCH;
   const int nunits = a.NCO * a.NCI * a.NSPLIT;
   const int grid = ceil_div(nunits, 8) * 8 * a.NTP;
   if (wide) {
-    if (TAPS == 3)
-      OS2S_LAUNCH((conv1d_wgrad_kernel<3, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
-    else if (TAPS == 1)
+    if (TAPS == 1)
       OS2S_LAUNCH((conv1d_wgrad_kernel<1, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
     else
       OS2S_LAUNCH((conv1d_wgrad_kernel<2, 256>), dim3(grid), dim3(512), smem, (hipStream_t)stream, a);
   } else {
-    if (TAPS == 3)
-      OS2S_LAUNCH((conv1d_wgrad_kernel<3, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
-    else if (TAPS == 1)
+    if (TAPS == 1)
       OS2S_LAUNCH((conv1d_wgrad_kernel<1, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
     else
       OS2S_LAUNCH((conv1d_wgrad_kernel<2, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);

@@ -284,3 +284,66 @@ def test_conv_pingpong_full_size_vs_lockstep_tile(cuda, ragged):
   a, b = outs["pp_ws"][0].float(), outs["tile"][0].float()
   assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
   torch.testing.assert_close(outs["pp_ws"][1].sum(0), outs["tile"][1].sum(0), rtol=1e-3, atol=1e-1)
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout,K,d", [(3, 420, 256, 512, 17, 1), (2, 333, 320, 640, 21, 1),
+                                              (2, 300, 768, 896, 29, 2), (4, 200, 128, 256, 2, 1),
+                                              (2, 150, 192, 200, 5, 1)])
+@pytest.mark.parametrize("split", [1, 3, -1])
+def test_conv_wgrad_pingpong_kernel(cuda, B, T, Cin, Cout, K, d, split):
+  """conv1d_wgrad_pp_kernel forced (odd tap counts, Cin / Cout tails, ragged lengths with dead
+  chunks) with the reduction unsplit, cut 3 ways and by the cost model: vs autograd of the fp32
+  oracle (only fp32 summation-order noise: rtol 2e-3), accumulate on top of a previous dW, and
+  run-to-run bitwise reproducibility (no atomics)."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(B * 77 + T + K + Cout)
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = (torch.randn(K, Cin, Cout, generator=g) * 0.05).requires_grad_(True)
+  lens = torch.randint(T // 4, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  lens[-1] = max(1, T // 6)
+  y = cnn.conv1d_tf(x.float(), w_tf, 1, d, "SAME", mask_len=lens)
+  dy = _bf(torch.randn(y.shape, generator=g))
+  y.backward(dy.float())
+  ref = cnn.to_dev_layout(w_tf.grad)
+  base = torch.randn(K, Cout, Cin, generator=g)
+  L = _lib.lib()
+  L.os2s_conv1d_wgrad_set_variant(1, split)
+  try:
+    o1 = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
+    o2 = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
+    o3 = base.clone().to(cuda)
+    capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda), out=o3, accumulate=True)
+    torch.cuda.synchronize()
+  finally:
+    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+  scale = float(ref.pow(2).mean().sqrt()) + 1e-6
+  torch.testing.assert_close(o1.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
+  assert torch.equal(o1, o2)
+  torch.testing.assert_close(o3.cpu(), ref + base, rtol=2e-3, atol=2e-3 * scale)
+  assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0
+
+
+def test_conv_wgrad_pingpong_full_size_vs_lockstep(cuda):
+  """BASELINE-size layer (B=32, T'=840, 768 -> 768, K=25, ragged): unsplit, the ping-pong kernel
+  adds the live 64-row chunks in the same order as the oracle-checked lockstep kernel -> dW is
+  BIT-IDENTICAL; split by the cost model it differs by fp32 summation order only."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(5)
+  B, T, C, K = 32, 840, 768, 25
+  x = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  dy = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  lens = torch.randint(100, T + 1, (B,), generator=g).to(torch.int32).to(cuda)
+  L = _lib.lib()
+  try:
+    L.os2s_conv1d_wgrad_set_variant(0, -1)
+    ref = capi.conv1d_wgrad(x, dy, K, in_len=lens)
+    L.os2s_conv1d_wgrad_set_variant(1, 1)
+    a = capi.conv1d_wgrad(x, dy, K, in_len=lens)
+    L.os2s_conv1d_wgrad_set_variant(1, 4)
+    b = capi.conv1d_wgrad(x, dy, K, in_len=lens)
+    torch.cuda.synchronize()
+  finally:
+    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+  assert torch.equal(a, ref)
+  torch.testing.assert_close(b, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))

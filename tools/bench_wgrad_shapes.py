@@ -1,37 +1,46 @@
-"""conv1d wgrad at the Jasper 10x5 block shapes (B=32, T=840 dense, or ragged with --ragged):
-ms and TF/s per shape for forced batch-split factors. Usage: bench_wgrad_shapes.py [--ragged] [nsplit...]"""
+"""conv1d wgrad at the Jasper block shapes (B=32, T'=840), lockstep kernel vs ping-pong kernel with
+forced split factors, dense and ragged: ms per launch and executed TF/s."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from openseq2seq_amd import capi
+from openseq2seq_amd import capi, _lib
 dev = torch.device("cuda:0")
-args = sys.argv[1:]
-ragged = "--ragged" in args
-splits = [a for a in args if a != "--ragged"] or ["auto"]
-shapes = [(32, 840, 256, 256, 11), (32, 840, 384, 384, 13), (32, 840, 512, 512, 17),
-          (32, 840, 640, 640, 21), (32, 840, 768, 768, 25), (32, 840, 768, 896, 29), (32, 840, 896, 1024, 1)]
-rng = np.random.RandomState(0)
-for B, T, cin, cout, K in shapes:
-  x = torch.randn(B, T, cin, device=dev).to(torch.bfloat16)
-  dy = torch.randn(B, T, cout, device=dev).to(torch.bfloat16)
-  lens = torch.full((B,), T, dtype=torch.int32)
-  if ragged:
-    lens = torch.from_numpy(rng.randint(100, T + 1, size=B).astype(np.int32)); lens[0] = T
-  frac = float(lens.sum()) / (B * T)
-  dw = torch.zeros(K, cout, cin, device=dev)
-  dil = 2 if K == 29 else 1
-  out = []
-  for sp in splits:
-    if sp == "auto": os.environ.pop("OS2S_WGRAD_NSPLIT", None)
-    else: os.environ["OS2S_WGRAD_NSPLIT"] = sp
-    f = lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, in_len=lens.to(dev), out=dw, accumulate=True)
-    for _ in range(2): f()
-    torch.cuda.synchronize()
+B, T = 32, 840
+shapes = [(256, 256, 11), (384, 384, 13), (512, 512, 17), (640, 640, 21), (768, 768, 25), (768, 896, 29)]
+rng = np.random.RandomState(1234)
+dur = rng.uniform(2.0, 16.7, size=B)
+lens_np = np.minimum((1 + (dur * 16000).astype(np.int64) // 160 + 1) // 2, T).astype(np.int32)
+def timeit(fn, n=10):
+  for _ in range(3): fn()
+  torch.cuda.synchronize()
+  best = 1e9
+  for _ in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(8): f()
+    for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 8
-    out.append("split %s %.3f ms %5.0f TF/s" % (sp, ms, 2.0 * B * T * frac * cin * cout * K / ms / 1e9))
-  print("C %4d->%4d K %2d (live %.2f): " % (cin, cout, K, frac) + "  ".join(out), flush=True)
+    best = min(best, e0.elapsed_time(e1) / n)
+  return best
+L = _lib.lib()
+for cin, cout, K in shapes:
+  x = torch.randn(B, T, cin, device=dev).to(torch.bfloat16)
+  dy = torch.randn(B, T, cout, device=dev).to(torch.bfloat16)
+  dw = torch.zeros(K, cout, cin, device=dev)
+  dil = 2 if K == 29 else 1
+  _, pl = capi.same_padding(T, K, 1, dil)
+  for name, ln in (("dense", None), ("ragged", lens_np)):
+    lens = None if ln is None else torch.from_numpy(ln).to(dev)
+    live = 1.0 if ln is None else float(ln.sum()) / (B * T)
+    fl = 2.0 * B * T * cin * cout * K * live
+    out = []
+    L.os2s_conv1d_wgrad_set_variant(0, -1)
+    t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
+    out.append("lockstep %.3f ms %4.0f TF" % (t, fl / t / 1e9))
+    for f in (-1, 1, 2, 3, 4, 6, 8, 12, 16):
+      L.os2s_conv1d_wgrad_set_variant(1, f)
+      t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
+      out.append("f%d %.3f" % (f, t) + (" %4.0f TF" % (fl / t / 1e9) if f == -1 else ""))
+    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+    units = ((cout + 127) // 128) * ((cin + 127) // 128) * ((K + 3) // 4)
+    print("C %4d->%4d K %2d %-6s units %3d: %s" % (cin, cout, K, name, units, "  ".join(out)), flush=True)

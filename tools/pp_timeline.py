@@ -36,3 +36,29 @@ for cin, cout, K, fixed in [(768, 768, 25, 0), (768, 768, 25, 1), (512, 512, 17,
       step = prev_end[:, 9] - prev_end[:, 0]
       print("  wg %d group %s: step %6.0f cyc (min %5.0f max %5.0f) | " % (wg, "AB"[g], step.mean(), step.min(), step.max()) +
             " ".join("%s %4.0f" % (n, v) for n, v in zip(names, d.mean(0))))
+
+# ---- weight-gradient kernel -----------------------------------------------------------------
+L.os2s_conv1d_wgrad_set_debug.argtypes = [_lib.c_void_p, _lib.c_int]
+for cin, cout, K, mode in [(768, 768, 25, 0), (768, 768, 25, 1), (768, 768, 25, 2), (768, 768, 25, 3), (768, 768, 25, 4), (768, 768, 25, 7)]:
+  x = torch.randn(B, T, cin, device=dev).to(torch.bfloat16)
+  dy = torch.randn(B, T, cout, device=dev).to(torch.bfloat16)
+  st = torch.zeros(4 * 2 * 48 * 10, dtype=torch.int64, device=dev)
+  L.os2s_conv1d_wgrad_set_variant(1, 1)
+  for _ in range(3): capi.conv1d_wgrad(x, dy, K)
+  torch.cuda.synchronize()
+  L.os2s_conv1d_wgrad_set_debug(_lib.c_void_p(st.data_ptr()), mode)
+  capi.conv1d_wgrad(x, dy, K)
+  torch.cuda.synchronize()
+  L.os2s_conv1d_wgrad_set_debug(_lib.c_void_p(0), 0)
+  L.os2s_conv1d_wgrad_set_variant(-1, -1)
+  t = st.cpu().numpy().reshape(4, 2, 48, 10).astype(np.float64)
+  print("wgrad C %d->%d K %d dbg_mode %d (1 no dY DMA, 2 no X DMA, 4 frozen cursor)" % (cin, cout, K, mode))
+  names = ["LOADe", "bar", "COMPe", "bar", "LOADo(rd+vm)", "dma", "lgkm", "bar", "COMPo", "bar"]
+  for wg in range(1):
+    for g in range(2):
+      a = t[wg, g, 4:44]
+      prev_end = np.concatenate([t[wg, g, 3:43, 9:10], a], axis=1)
+      d = np.diff(prev_end, axis=1)
+      step = prev_end[:, 10] - prev_end[:, 0]
+      print("  wg %d group %s: step %6.0f cyc | " % (wg, "AB"[g], step.mean()) +
+            " ".join("%s %4.0f" % (n, v) for n, v in zip(names, d.mean(0))))
