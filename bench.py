@@ -63,7 +63,25 @@ def parse():
   ap.add_argument("--only-transformer", action="store_true",
                   help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
+  ap.add_argument("--launcher-dry-run", action="store_true",
+                  help="exercise only the multi-rank launcher and the timing collectives (no GPU "
+                       "work: runs on CPU over gloo); prints the JSON line with value null")
   return ap.parse_args()
+
+
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher: re-execute this script as N ranks of ONE node
+  under torch.distributed.run (one process per GPU, RCCL over xGMI; rendezvous on 127.0.0.1 — the
+  reference relies on an external `mpirun -np N`, run.py:43-49). Returns the launcher's exit code."""
+  import socket
+  import subprocess
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+         "--master-addr", "127.0.0.1", "--master-port", str(port),
+         os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.call(cmd)
 
 
 class ConvTimer(object):
@@ -352,16 +370,53 @@ def committed_pmc_traffic():
     return None, None
 
 
+def launcher_dry_run(args, hvd, rank, world):
+  """The multi-rank plumbing of the bench without GPU work: barrier, MAX-over-ranks of the timed
+  interval, SUM of the per-rank units — on whatever backend the process group has (gloo on CPU)."""
+  import torch.distributed as dist
+  dev = torch.device("cpu")
+  if world > 1:
+    dist.barrier()
+  t0 = time.perf_counter()
+  time.sleep(0.01 * (rank + 1))            # ranks finish at different times: MAX must pick the slowest
+  if world > 1:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+  units = torch.tensor([1000.0 * (rank + 1)], dtype=torch.float64, device=dev)
+  if world > 1:
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(units, op=dist.ReduceOp.SUM)
+  if rank == 0:
+    print(json.dumps({"metric": "launcher dry run (no GPU work)", "value": None, "unit": "frames/sec",
+                      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1000.0 * float(tmax.item()), "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                      "config": {"workload": "launcher dry run", "global_batch": args.batch * world,
+                                 "parallelism": "dp%d" % world,
+                                 "backend": dist.get_backend() if world > 1 else "none",
+                                 "units_sum_over_ranks": float(units.item())}}))
+
+
 def main():
   args = parse()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(spawn_ranks(args.gpus))      # one process per GPU; this process only waits for them
   from openseq2seq_amd.utils import distributed as dist_utils
   hvd = dist_utils.init_from_env()
   rank = hvd.rank() if hvd else 0
   world = hvd.size() if hvd else 1
-  if args.gpus != world and rank == 0 and world > 1:
-    print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+  if args.gpus != world:
+    raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) "
+                     "(WORLD_SIZE=%s)" % (args.gpus, world, os.environ.get("WORLD_SIZE")))
+  if args.launcher_dry_run:
+    launcher_dry_run(args, hvd, rank, world)
+    return
   dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
+  if rank == 0 and world > 1:
+    print("bench.py: %d ranks, backend %s (RCCL), one process per GPU" % (
+        world, torch.distributed.get_backend()), file=sys.stderr)
 
   simple = {
       "quartznet": ("openseq2seq_amd.configs.quartznet", "quartznet15x5_config", {},

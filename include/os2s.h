@@ -264,7 +264,7 @@ int os2s_ctc_loss(os2s_stream_t stream, const float* logits, const int32_t* in_l
  * decision, no host sync). Replaces MixedPrecisionOptimizerWrapper
  * (optimizers/mp_wrapper.py:27-122), AutomaticLossScaler Backoff/LogMax
  * (automatic_loss_scaler.py:50-203), post_process_gradients LARC / global-norm
- * clip (optimizers.py:289-482), NovoGrad (novograd.py:93-126), TF Momentum /
+ * clip (optimizers.py:289-482), NovoGrad (novograd.py:93-126, AS WRITTEN — see novograd_ema), TF Momentum /
  * Adam, and the lr policies (lr_policies.py) evaluated at the device-resident
  * global step. Tensors start at multiples of os2s_opt_chunk_elems() elements.
  * ---------------------------------------------------------------------- */
@@ -285,6 +285,10 @@ typedef struct {
   long long step_window;
   float log_max, lm_beta1, lm_beta2, overflow_std_dev;
   int world_size;              /* gradients in the buffer are sums over ranks */
+  int novograd_ema;            /* 0 (reference): v_t = |g_t|^2 every step — the reference graph
+                                * never assigns nvgrad2_ema* (novograd.py:107-113: the tf.cond result
+                                * only replaces the Python list entry), so beta2 is dead there;
+                                * 1: v_t = beta2 v_{t-1} + (1-beta2) |g_t|^2 (the published NovoGrad) */
 } os2s_opt_config_t;
 
 int os2s_opt_chunk_elems(void);

@@ -338,7 +338,7 @@ class OptConfig(_lib.ctypes.Structure):
       ("scaler", c_int), ("scale_min", c_float), ("scale_max", c_float),
       ("step_factor", c_float), ("step_window", c_ll), ("log_max", c_float),
       ("lm_beta1", c_float), ("lm_beta2", c_float), ("overflow_std_dev", c_float),
-      ("world_size", c_int),
+      ("world_size", c_int), ("novograd_ema", c_int),
   ]
 
 

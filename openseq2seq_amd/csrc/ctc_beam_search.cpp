@@ -160,7 +160,15 @@ bool read_arpa(const std::string& path, NGramLM* lm) {
   lm->order = order;
   lm->entries.assign(order, {});
   lm->index.assign(order, {});
-  for (int n = 1; n <= order; ++n) {            // sized once from the header: no rehashing on big models
+  // sized once from the header (no rehashing on big models) — but an n-gram line is at least 4
+  // bytes, so a declared count above file_size / 4 is a corrupt header, not a reason to allocate
+  size_t file_bytes = 0;
+  {
+    std::ifstream sz(path, std::ios::binary | std::ios::ate);
+    if (sz) file_bytes = (size_t)sz.tellg();
+  }
+  for (int n = 1; n <= order; ++n) {
+    if (declared[n] > file_bytes / 4 + 1) return false;
     lm->entries[n - 1].reserve(declared[n] + 1);
     if (n > 1) lm->index[n - 1].reserve(declared[n]);
   }
@@ -259,6 +267,12 @@ int read_kenlm_probing(const std::vector<unsigned char>& d, size_t size, NGramLM
   if (off + 20 + 8 * (size_t)order > size) return OS2S_ERR_INVALID_ARG;
   memcpy(counts.data(), d.data() + off + 20, 8 * (size_t)order);
   off = (off + 20 + 8 * (size_t)order + 7) & ~(size_t)7;
+  // every stored entry takes at least 8 bytes: counts beyond size / 8 (or a multiplier that is
+  // not a small finite number) can only come from a corrupt header and would overflow the
+  // offset arithmetic below
+  if (!(mult >= 1.f && mult <= 16.f)) return OS2S_ERR_INVALID_ARG;
+  for (int n = 0; n < order; ++n)
+    if (counts[n] > size / 8) return OS2S_ERR_INVALID_ARG;
   auto buckets = [&](uint64_t n) { return std::max<uint64_t>(n + 1, (uint64_t)(mult * (float)n)); };
   off += 8 + 12 * buckets(counts[0]);
   if (off + 8 * (counts[0] + 1) > size) return OS2S_ERR_INVALID_ARG;
@@ -701,15 +715,22 @@ struct Decoder {
 
 }  // namespace
 
+// Every model file goes through here. The counts in a model header are untrusted input: a
+// corrupt file must come back as a status code, never as an exception crossing the C ABI
+// (no exceptions cross the boundary).
 static int load_lm(const char* lm_path, NGramLM* lm) {
-  std::ifstream in(lm_path, std::ios::binary);
-  if (!in) return OS2S_ERR_INVALID_ARG;
-  char head[sizeof(kKenlmMagic)] = {0};
-  in.read(head, sizeof(kKenlmMagic) - 1);
-  in.close();
-  if (memcmp(head, kKenlmMagic, sizeof(kKenlmMagic) - 1) == 0) return read_kenlm_binary(lm_path, lm);
-  if (!read_arpa(lm_path, lm)) return OS2S_ERR_INVALID_ARG;
-  return lm->order > kMaxOrder ? OS2S_ERR_UNSUPPORTED : OS2S_OK;
+  try {
+    std::ifstream in(lm_path, std::ios::binary);
+    if (!in) return OS2S_ERR_INVALID_ARG;
+    char head[sizeof(kKenlmMagic)] = {0};
+    in.read(head, sizeof(kKenlmMagic) - 1);
+    in.close();
+    if (memcmp(head, kKenlmMagic, sizeof(kKenlmMagic) - 1) == 0) return read_kenlm_binary(lm_path, lm);
+    if (!read_arpa(lm_path, lm)) return OS2S_ERR_INVALID_ARG;
+    return lm->order > kMaxOrder ? OS2S_ERR_UNSUPPORTED : OS2S_OK;
+  } catch (const std::exception&) {           // bad_alloc / length_error from a hostile header
+    return OS2S_ERR_INVALID_ARG;
+  }
 }
 
 // generate_trie.cpp:32-64 + TrieNode::Insert / WriteToStream (trie_node.h:46-50,122-163)

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void mt_finalize_kernel(
   }
   __syncthreads();
   const float gnorm = s_gn;
+  if (threadIdx.x == 0 && cfg.clip_global_norm > 0.f && !(gnorm == gnorm)) sh_nan = 1;
   const long long step = st->global_step;
   const float lr = lr_policy_value(cfg, step);
   // clip by global norm: scale = clip * min(1/norm, 1/clip)  (optimizers.py:447-449)
@@ -214,8 +215,12 @@ __global__ __launch_bounds__(256) void mt_finalize_kernel(
       f *= u;
     }
     tensor_mult[t] = f;          // provisional: post-processing factor only
-    amax = fmaxf(amax, tensor_amax[t] * f);
-    if (!(f == f)) atomicOr(&sh_nan, 1);
+    // an Inf gradient under global-norm clipping: norm = inf -> clip scale 0 -> the clipped
+    // gradient is inf * 0 = NaN in the reference (_clip_by_global_norm), check_grads sees has_nan
+    // and the step is skipped. fmaxf would silently drop that NaN, so test the product itself.
+    const float am = tensor_amax[t] * f;
+    amax = fmaxf(amax, am);
+    if (!(f == f) || !(am == am)) atomicOr(&sh_nan, 1);
   }
   sh_m[threadIdx.x] = amax;
   __syncthreads();
@@ -266,14 +271,18 @@ __global__ __launch_bounds__(256) void mt_finalize_kernel(
   }
   __syncthreads();
   if (st->skip) return;
-  // NovoGrad: v = (v == 0) ? |g|^2 : b2*v + (1-b2)*|g|^2 on the post-processed grad;
-  // fold 1/sqrt(v + eps) (and grad_averaging) into the per-tensor multiplier.
+  // NovoGrad second moment on the post-processed grad; 1/sqrt(v + eps) (and grad_averaging) is
+  // folded into the per-tensor multiplier. The reference graph AS WRITTEN (novograd.py:100-115)
+  // reads the nvgrad2_ema variables but never assigns them — the tf.cond result only replaces
+  // the Python list entry — so they stay 0 and every step takes the `g_2` branch: v_t = |g_t|^2,
+  // beta2 unused. That is the default here (novograd_ema = 0: results identical to the
+  // reference); novograd_ema = 1 keeps the moving average of the published algorithm.
   if (cfg.optimizer == 2) {
     for (int t = threadIdx.x; t < ntensors; t += 256) {
       const float f = tensor_mult[t];
       const float g2 = tensor_gnorm2[t] * f * f;
       float v = tensor_v[t];
-      v = (v == 0.f) ? g2 : (v * cfg.beta2 + g2 * (1.f - cfg.beta2));
+      v = (v == 0.f || !cfg.novograd_ema) ? g2 : (v * cfg.beta2 + g2 * (1.f - cfg.beta2));
       tensor_v[t] = v;
       tensor_mult[t] = f / sqrtf(v + cfg.epsilon);
     }

@@ -47,8 +47,9 @@ class FullyConnectedTimeDecoder(Decoder):
       return w
 
     self.kernel = store.add(scope + "/kernel", (1, self.Vpad, n_hidden), init_kernel,
-                            kind="conv", l2=l2)
-    self.bias = store.add(scope + "/bias", (self.Vpad,), torch.zeros(self.Vpad), kind="vector")
+                            kind="conv", l2=l2, logical_out=V)
+    self.bias = store.add(scope + "/bias", (self.Vpad,), torch.zeros(self.Vpad), kind="vector",
+                          logical_out=V)
     return self
 
   def _decode(self, input_dict):

@@ -240,7 +240,8 @@ class RNNDecoderWithAttention(Decoder):
       # embedding matrix would (first decoder variable): its gradient is complete only after the
       # embedding backward, the last decoder closure to run, and the overlapped gradient reducer
       # relies on variables becoming final in reverse creation order.
-      self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
+      self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv",
+                            logical_out=V)
       self.embedding = Embedding(store, None, V, E, table=self.proj)
     else:
       self.embedding = Embedding(store, scope + "/DecoderEmbeddingMatrix", V, E)
@@ -263,7 +264,8 @@ class RNNDecoderWithAttention(Decoder):
         self.upper.append(RNNDirection(store, "%s/multi_rnn_cell/cell_%d/lstm_cell" % (scope, l),
                                        cell, [H, self.M], H, reverse=False, forget_bias=fb))
     if not self._weight_tied:
-      self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv")
+      self.proj = store.add(scope + "/dense/kernel", (1, self.Vpad, out_in), init, kind="conv",
+                            logical_out=V)
     apply_scope_initializer(store, first_param, p)
     return self
 

@@ -161,7 +161,10 @@ class Model(object):
     self._compiled = True
     return self
 
-  def _last_step(self):
+  def _last_step(self, default=100000):
+    """models/model.py:346-365: `max_steps`, else num_epochs * steps_in_epoch with
+    steps_in_epoch = dataset size // (batch_size_per_gpu * workers * iter_size). `default` when
+    the data layer cannot tell its size (synthetic batches: the dataset files are absent)."""
     p = self._params
     if 'max_steps' in p:
       return p['max_steps']
@@ -173,7 +176,13 @@ class Model(object):
         return max(spe * p['num_epochs'], 1)
       except Exception:
         pass
-    return 100000
+    return default
+
+  @property
+  def last_step(self):
+    """The step the training loop stops at and the final checkpoint is labelled with (the same
+    number the lr schedule's decay_steps default to)."""
+    return self._last_step()
 
   def _extra_state_tensors(self):
     return []

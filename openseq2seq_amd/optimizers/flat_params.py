@@ -19,11 +19,14 @@ from .. import capi
 
 class Param(object):
   __slots__ = ("name", "shape", "index", "offset", "numel", "l2", "kind", "store",
-               "master", "grad", "w16", "wt16", "wt_offset", "trainable_mask")
+               "master", "grad", "w16", "wt16", "wt_offset", "trainable_mask", "logical_out")
 
-  def __init__(self, name, shape, kind, l2):
+  def __init__(self, name, shape, kind, l2, logical_out=None):
     self.name, self.shape, self.kind, self.l2 = name, tuple(int(s) for s in shape), kind, l2
     self.numel = int(np.prod(self.shape))
+    # output layers padded to an MFMA-friendly width: number of REAL output units (rows of a
+    # [1, Vpad, H] kernel / entries of a [Vpad] bias); checkpoints carry the logical shape
+    self.logical_out = logical_out
     self.master = self.grad = self.w16 = self.wt16 = None
 
 
@@ -38,12 +41,12 @@ class FlatParams(object):
     self.finalized = False
     self.chunk = capi.opt_chunk_elems()
 
-  def add(self, name, shape, init, kind="dense", l2=0.0):
+  def add(self, name, shape, init, kind="dense", l2=0.0, logical_out=None):
     assert not self.finalized
     for p in self.params:
       if p.name == name:
         raise ValueError("duplicate variable " + name)
-    p = Param(name, shape, kind, float(l2))
+    p = Param(name, shape, kind, float(l2), logical_out)
     p.index = len(self.params)
     self.params.append(p)
     self._inits.append(init)

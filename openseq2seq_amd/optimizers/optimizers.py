@@ -60,6 +60,7 @@ def build_opt_config(optimizer, optimizer_params, learning_rate_decay_fn,
     d = dict(NovoGrad.DEFAULTS, **op)
     cfg.beta1, cfg.beta2, cfg.epsilon = d["beta1"], d["beta2"], d["epsilon"]
     cfg.weight_decay, cfg.grad_averaging = d["weight_decay"], int(bool(d["grad_averaging"]))
+    cfg.novograd_ema = int(bool(d["ema_second_moment"]))
   elif oid == 1:
     cfg.beta1 = op.get("momentum", 0.9)
   elif oid == 3:

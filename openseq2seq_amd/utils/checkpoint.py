@@ -37,8 +37,17 @@ def _is_dense(name):
   return not re.search(r"/conv\d*[^/]*/kernel$|pointwise_kernel$", name)
 
 
-def export_param(name, shape, kind, arr):
-  """device array -> [(tf_name, tf_array)]."""
+def export_param(name, shape, kind, arr, logical_out=None):
+  """device array -> [(tf_name, tf_array)]. Output layers padded to an MFMA-friendly width
+  (FullyConnectedCTCDecoder V=29 -> 32 rows, RNN decoders V -> multiple of 8) are written with
+  the reference's LOGICAL shape: only the first `logical_out` output units."""
+  if logical_out is not None:
+    if kind == "conv" and len(shape) == 3 and shape[0] == 1:
+      arr = arr[:, :logical_out, :]
+      shape = (1, logical_out, shape[2])
+    elif len(shape) == 1:
+      arr = arr[:logical_out]
+      shape = (logical_out,)
   if name.endswith("/qkv/kernel") or name.endswith("/kv/kernel"):
     base = name[:name.rindex("/", 0, len(name) - len("/kernel"))]
     parts = ("q", "k", "v") if name.endswith("/qkv/kernel") else ("k", "v")
@@ -55,8 +64,25 @@ def export_param(name, shape, kind, arr):
   return [(name, arr.copy())]
 
 
-def import_param(name, shape, kind, tf_arrays):
-  """inverse of export_param; returns the device-layout array or None if names are missing."""
+def import_param(name, shape, kind, tf_arrays, logical_out=None):
+  """inverse of export_param; returns the device-layout array or None if names are missing.
+  A layer stored with its logical width is zero-padded back to the device width."""
+  if logical_out is not None:
+    if kind == "conv" and len(shape) == 3 and shape[0] == 1:
+      a = import_param(name, (1, logical_out, shape[2]), kind, tf_arrays)
+      if a is None or a.shape[1] not in (logical_out, shape[1]):
+        return a
+      out = np.zeros(shape, np.float32)
+      out[:, :a.shape[1], :] = a
+      return out
+    if len(shape) == 1:
+      a = import_param(name, (logical_out,), kind, tf_arrays)
+      if a is None or a.shape[0] not in (logical_out, shape[0]):
+        return a
+      out = np.zeros(shape, np.float32)
+      out[:a.shape[0]] = a
+      return out
+
   def get(n):
     if n in tf_arrays:
       return np.asarray(tf_arrays[n], np.float32)
@@ -91,7 +117,7 @@ def model_variables(model):
   mixed = model.params.get("dtype", "mixed") == "mixed"
   for p in store.params:
     arr = p.master.detach().cpu().numpy()
-    for tf_name, tf_arr in export_param(p.name, p.shape, p.kind, arr):
+    for tf_name, tf_arr in export_param(p.name, p.shape, p.kind, arr, getattr(p, "logical_out", None)):
       out[tf_name] = tf_arr
       if mixed and p.kind != "vector":      # only half-precision variables have master copies
         out[MASTER_PREFIX + tf_name] = tf_arr
@@ -148,7 +174,7 @@ def load(model, prefix, restore_optimizer=True, strict=True):
   store = model.store
   missing = []
   for p in store.params:
-    a = import_param(p.name, p.shape, p.kind, data)
+    a = import_param(p.name, p.shape, p.kind, data, getattr(p, "logical_out", None))
     if a is None or tuple(a.shape) != tuple(p.shape):
       missing.append(p.name)
       continue

@@ -191,12 +191,18 @@ class RefOptimizer(object):
       self.skipped += 1
       return True
     p = self.p
-    if self.opt == "NovoGrad":    # novograd.py:108-126
+    if self.opt == "NovoGrad":    # novograd.py:100-126
       b1, b2 = p.get("beta1", 0.95), p.get("beta2", 0.98)
       eps, wd = p.get("epsilon", 1e-8), p.get("weight_decay", 0.0)
+      # novograd.py:107-113 AS WRITTEN: `self._grads_ema[i] = tf.cond(tf.equal(var, 0.), g_2, ...)`
+      # rebinds the Python list entry to the cond's output tensor; the tf variable nvgrad2_ema<i>
+      # is never assigned, stays 0, and the cond takes the g_2 branch on every session.run:
+      # v_t = |g_t|^2, beta2 is dead. `ema_second_moment` (not a reference parameter) selects the
+      # moving average of the published algorithm instead.
+      use_ema = bool(p.get("ema_second_moment", False))
       for i, (x, w) in enumerate(zip(g, self.w)):
         g2 = f(np.sum(np.square(x.astype(np.float64))))
-        self.ema[i] = g2 if self.ema[i] == 0 else f(self.ema[i] * b2 + g2 * (1 - b2))
+        self.ema[i] = g2 if (self.ema[i] == 0 or not use_ema) else f(self.ema[i] * b2 + g2 * (1 - b2))
         x = x * f(1.0 / np.sqrt(self.ema[i] + eps))
         if wd > 0:
           x = x + f(wd) * w

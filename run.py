@@ -22,7 +22,9 @@ from openseq2seq_amd.utils.utils import create_model, deco_print, get_base_confi
 def train(model, args):
   """utils/funcs.py:22-220 reduced to the hot loop + benchmark timing."""
   p = model.params
-  max_steps = p.get('max_steps', 100)
+  # models/model.py:346-365 / utils/funcs.py:45: stop at max_steps, else num_epochs * steps_in_epoch
+  # (100 steps when neither can be known: synthetic batches without dataset files)
+  max_steps = model._last_step(default=100)
   bench_start = p.get('bench_start', 10)
   dl = model.get_data_layer()
   rank = model.hvd.rank() if model.hvd else 0

@@ -46,3 +46,33 @@ def test_committed_pmc_traffic_is_what_bench_reports():
   with open(os.path.join(REPO, src)) as f:
     t = json.load(f)
   assert abs(t["hbm_bytes_per_launch"] - d["roofline"]["traffic"]) < 1.0
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+  """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (the driver's
+  scaling command; the reference relies on `mpirun -np N`, run.py:43-49). Dry run of the launcher
+  and of the timing collectives on CPU over gloo: the line reports n_gpus = 2, the SUM over ranks
+  of the per-rank units and the MAX over ranks of the timed interval (rank 1 is the slower one)."""
+  import subprocess
+  import sys
+  env = dict(os.environ)
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launcher-dry-run"],
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout          # rank 0 only
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2"
+  assert d["config"]["units_sum_over_ranks"] == 3000.0
+  assert d["ms_per_step"] >= 19.0           # rank 1 sleeps 20 ms: MAX over ranks, not rank 0's 10 ms
+
+
+def test_bench_refuses_a_world_size_mismatch():
+  import subprocess
+  import sys
+  env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+  r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launcher-dry-run"],
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+  assert r.returncode != 0 and "--gpus 2" in r.stderr

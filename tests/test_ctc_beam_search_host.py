@@ -156,6 +156,14 @@ def test_scorer_errors(tmp_path, kat):
     f.write(bytes(d))
   with pytest.raises(_lib.Os2sError):
     capi.CtcScorer(other, trie, alpha_path, 1.0, 0.0)
+  # a hostile ARPA header (absurd n-gram counts) comes back as a status code: nothing may be
+  # allocated from it and no C++ exception may cross the C ABI
+  bad = str(tmp_path / "bad.arpa")
+  with open(bad, "w") as f:
+    f.write("\\data\\\nngram 1=3\nngram 2=99999999999999\n\n\\1-grams:\n-1.0\t<unk>\n-1.0\ta\t-0.5\n-1.0\tb\t-0.5\n\n"
+            "\\2-grams:\n-0.3\ta b\n\n\\end\\\n")
+  with pytest.raises(_lib.Os2sError):
+    capi.CtcScorer(bad, trie, alpha_path, 1.0, 0.0)
   # alphabet / trie size mismatch (trie_node.h:73-79)
   short = str(tmp_path / "short_alphabet.txt")
   with open(short, "w") as f:

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 from oracle import optim as oopt  # noqa: E402
 
 SHAPES = [(11, 40, 24), (40,), (40,), (5000,), (3, 16, 8), (1, 29, 64), (29,)]
+_LAST = {}
 
 
 def _setup(cuda, need_m2=False):
@@ -31,6 +32,7 @@ def _run(cuda, optimizer, opt_params, lr_fn, lr_params, larc=None, clip=None,
   from openseq2seq_amd.optimizers import lr_policies
   from openseq2seq_amd.optimizers.optimizers import optimize_loss
   store, ws, rng = _setup(cuda, need_m2)
+  _LAST["store"] = store
   if l2:
     store.tensor_l2.copy_(torch.tensor(l2))
   op = optimize_loss(store, optimizer, opt_params, getattr(lr_policies, lr_fn), lr_params,
@@ -81,6 +83,33 @@ def test_novograd_larc_backoff_jasper_cfg(cuda):
             "poly_decay", dict(learning_rate=0.02, min_lr=1e-5, power=2.0, decay_steps=1000),
             larc=dict(larc_eta=0.001))
   assert st["num_skipped"] == 1 and st["loss_scale"] == 2.0 ** 13
+
+
+def test_novograd_second_moment_modes(cuda):
+  """Default = the reference graph as written (v_t = |g_t|^2 every step, beta2 dead:
+  novograd.py:107-113 never assigns nvgrad2_ema*); ema_second_moment=True = the moving average of
+  the published algorithm. Both against the oracle; the two trajectories must differ."""
+  from openseq2seq_amd.optimizers.novograd import NovoGrad
+  outs = []
+  for ema in (False, True):
+    _run(cuda, NovoGrad, dict(beta1=0.95, beta2=0.5, epsilon=1e-8, weight_decay=0.001,
+                              ema_second_moment=ema),
+         "poly_decay", dict(learning_rate=0.02, min_lr=1e-5, power=2.0, decay_steps=1000),
+         larc=dict(larc_eta=0.001), inf_step=-1)
+    outs.append(_LAST["store"].master.clone())
+  assert not torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("scaling", ["Backoff", "LogMax"])
+def test_inf_gradient_under_global_norm_clip_is_an_overflow(cuda, scaling):
+  """An Inf gradient with max_grad_norm set (tacotron_mixed: clip 1 + Backoff): the global norm is
+  inf, the clip factor 0, the clipped gradient inf * 0 = NaN -> the reference's check_grads
+  reports has_nan and the step is skipped (optimizers.py:388-482, mp_wrapper.py:114-120). The
+  weights must stay finite and the scaler must see an overflow."""
+  st = _run(cuda, "Momentum", dict(momentum=0.9), "fixed_lr", dict(learning_rate=0.01),
+            clip=1.0, loss_scaling=scaling, inf_step=1, nsteps=4)
+  assert st["num_skipped"] == 1
+  assert bool(torch.isfinite(_LAST["store"].master).all())
 
 
 def test_adam_transformer_policy(cuda):

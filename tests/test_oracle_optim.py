@@ -42,3 +42,28 @@ def test_backoff_trajectory():
     scales.append(float(s.scale))
   # doubles when (iter - last_overflow) % 4 == 0: iterations 4 and 8 (last_overflow=0)
   assert scales == [2.0 ** 13] * 3 + [2.0 ** 14] * 6
+
+
+def test_novograd_second_moment_follows_the_reference_graph_as_written():
+  """novograd.py:107-113: `self._grads_ema[i] = tf.cond(tf.equal(self._grads_ema[i], 0.), lambda:
+  g_2, lambda: ema*beta2 + g_2*(1-beta2))` rebinds the Python list entry; the variable
+  nvgrad2_ema<i> is never assigned and stays 0, so each session.run takes the g_2 branch:
+  v_t = |g_t|^2 and beta2 has no effect. The oracle's default must reproduce exactly that; the
+  `ema_second_moment` switch (not a reference parameter) gives the published moving average."""
+  import numpy as np
+  from oracle import optim as oopt
+  w0 = [np.full((4,), 0.5, np.float32)]
+  g1 = [np.array([3.0, 0.0, 0.0, 4.0], np.float32)]      # |g|^2 = 25
+  g2 = [np.array([0.0, 1.0, 0.0, 0.0], np.float32)]      # |g|^2 = 1
+  for b2 in (0.5, 0.98):
+    ref = oopt.RefOptimizer(w0, optimizer="NovoGrad", opt_params=dict(beta1=0.0, beta2=b2, epsilon=0.0),
+                            lr_fn=lambda s: 1.0)
+    ref.step(g1); ref.step(g2)
+    assert float(ref.ema[0]) == 1.0                       # not 0.5*25 + 0.5*1
+    # beta1 = 0, lr = 1: the second update is exactly g2 / sqrt(|g2|^2)
+    np.testing.assert_allclose(ref.w[0], np.array([0.5 - 0.6, 0.5 - 1.0, 0.5, 0.5 - 0.8], np.float32), rtol=1e-6)
+  ema = oopt.RefOptimizer(w0, optimizer="NovoGrad",
+                          opt_params=dict(beta1=0.0, beta2=0.5, epsilon=0.0, ema_second_moment=True),
+                          lr_fn=lambda s: 1.0)
+  ema.step(g1); ema.step(g2)
+  assert float(ema.ema[0]) == 13.0
