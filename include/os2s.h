@@ -139,6 +139,21 @@ void os2s_conv1d_set_variant(int v);
 void os2s_conv1d_set_split(int f);
 /* experiment hook (tools/pp_timeline.py): per-slot time stamps of the ping-pong kernel */
 void os2s_conv1d_set_debug(void* stamps, int fixed_w);
+/* Up to 16 independent 1x1 convolutions over the same batch geometry (B, T, lengths) in ONE
+ * launch: y_i[b,t,:] (+)= x_i[b,t,:] . w_i^T, bf16 out, optional BatchNorm partials per group
+ * (layout as os2s_conv1d_fwd). Replaces the dense-residual branches of conv_bn_res_bn_actv
+ * (parts/cnns/conv_blocks.py:78-85: tf.layers.conv1d(kernel_size=1) per residual input, up to 10
+ * per Jasper block) and, with the transposed weights and out_len, their data gradients.
+ * `groups` is a HOST array (copied into the launch). */
+typedef struct {
+  const uint16_t* x;   /* [B, T, Cin]  bf16 */
+  const uint16_t* w;   /* [1, Cout, Cin] bf16 */
+  void* y;             /* [B, T, Cout] bf16 */
+  float* stats;        /* [os2s_conv1d_num_mtiles(B,T), 2, Cout] or NULL */
+  int Cin, Cout, accumulate;
+} os2s_conv_group_t;
+int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* groups, int ngroups,
+                             const int32_t* in_len, const int32_t* out_len, int B, int T);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,
                     float* stats, int B, int Tin, int Cin, int Cout, int K,

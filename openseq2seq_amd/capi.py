@@ -142,6 +142,34 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
   return out
 
 
+class _ConvGroup(_lib.ctypes.Structure):
+  _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("stats", c_void_p),
+              ("Cin", c_int), ("Cout", c_int), ("accumulate", c_int)]
+
+
+def conv1x1_fwd_grouped(items, in_len=None, out_len=None):
+  """items: list of dict(x [B,T,Cin] bf16, w [1,Cout,Cin] bf16, y [B,T,Cout] bf16, stats or None,
+  accumulate) — up to 16 independent 1x1 convolutions over the same (B, T, lengths) in ONE
+  launch (os2s_conv1x1_fwd_grouped); longer lists are cut into several launches."""
+  B, T, _ = items[0]["x"].shape
+  f = _fn("os2s_conv1x1_fwd_grouped",
+          (c_void_p, _lib.ctypes.POINTER(_ConvGroup), c_int, c_void_p, c_void_p, c_int, c_int))
+  outs = [it["y"].data_ptr() for it in items]
+  assert len(set(outs)) == len(outs), "two groups of one launch must not write the same tensor"
+  for i0 in range(0, len(items), 16):
+    part = items[i0:i0 + 16]
+    arr = (_ConvGroup * len(part))()
+    for g, it in zip(arr, part):
+      x, w, y = it["x"], it["w"], it["y"]
+      assert x.shape[0] == B and x.shape[1] == T and w.shape[0] == 1 and w.shape[2] == x.shape[2]
+      assert tuple(y.shape) == (B, T, w.shape[1]) and x.is_contiguous() and y.is_contiguous()
+      g.x, g.w, g.y = _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16), _ptr(y, torch.bfloat16)
+      g.stats = _ptr(it.get("stats"), torch.float32, True)
+      g.Cin, g.Cout, g.accumulate = x.shape[2], w.shape[1], int(bool(it.get("accumulate", False)))
+    _lib.check(f(_stream(), arr, len(part), _ptr(in_len, torch.int32, True),
+                 _ptr(out_len, torch.int32, True), B, T), "os2s_conv1x1_fwd_grouped")
+
+
 def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
                  out=None, accumulate=False, use_workspace=True):
   """x [B,Tin,Cin] bf16 (may be a channel-slice view of a wider tensor),

@@ -242,9 +242,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
 // BM = rows of ONE time window (one batch item); a workgroup processes NWIN consecutive
 // windows (possibly of different batch items) against the same weight stream, so the
 // M extent of a block is NWIN*BM while the tile granularity in time stays BM.
-template <int BM, int BN, int WM, int WN, int NWIN, bool XSINGLE = false>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1) void conv1d_igemm_kernel(
-    ConvArgs p) {
+template <int BM, int BN, int WM, int WN, int NWIN, bool XSINGLE>
+__device__ __forceinline__ void conv_tile_body(const ConvArgs& p, const int bid) {
   constexpr int NW = WM * WN, NTHR = NW * 64;
   constexpr int WTM = (BM * NWIN) / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be 32-aligned");
@@ -259,7 +258,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
   const int row_in_win = (wm * WTM) % BM;
 
   // ---- block -> tiles (XCD-aware: see header) ------------------------------
-  const int bid = blockIdx.x;
   const int xcd = bid & 7, loc = bid >> 3;
   const int n_idx = loc / p.MT8;
   const int m_first = ((loc - n_idx * p.MT8) * 8 + xcd) * NWIN;
@@ -400,6 +398,52 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
 #pragma unroll
   for (int w = 0; w < NWIN; ++w) wmid[w] = (m_first + w < p.MT) ? m_first + w : -1;
   conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
+}
+
+template <int BM, int BN, int WM, int WN, int NWIN, bool XSINGLE = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1) void conv1d_igemm_kernel(
+    ConvArgs p) {
+  conv_tile_body<BM, BN, WM, WN, NWIN, XSINGLE>(p, blockIdx.x);
+}
+
+// Grouped launch: up to kMaxConvGroups independent 1x1 convolutions (same batch geometry and
+// lengths; own input, weights, output, BatchNorm partials, channel counts) in ONE grid — the
+// dense-residual 1x1 branches of a Jasper block end (conv_blocks.py:78-85: up to 10 per block,
+// 55 per pass) and their data gradients. Each is a few microseconds of matrix work; launched
+// one by one they cost ~45 us apiece.
+constexpr int kMaxConvGroups = 16;
+struct ConvGroup {
+  const bf16_t* x;
+  const bf16_t* w;
+  void* y;
+  float* stats;
+  int Cin, Cout, accumulate, tile_begin;
+};
+struct ConvGroupTable {
+  int ngroups, total_tiles;
+  ConvGroup g[kMaxConvGroups];
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_igemm_grouped_kernel(ConvArgs p, ConvGroupTable gt) {
+  const int bid = blockIdx.x;
+  if (bid >= gt.total_tiles) return;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxConvGroups; ++i)
+    if (i < gt.ngroups && bid >= gt.g[i].tile_begin) gi = i;
+  // select the group's fields without indexing the table by a runtime value in registers
+  ConvGroup g = gt.g[0];
+#pragma unroll
+  for (int i = 1; i < kMaxConvGroups; ++i)
+    if (i == gi) g = gt.g[i];
+  p.x = g.x; p.w = g.w; p.y = g.y; p.stats = g.stats;
+  p.Cin = g.Cin; p.Cout = g.Cout; p.accumulate = g.accumulate;
+  p.x_sb = (long long)p.Tin * g.Cin; p.x_st = g.Cin;
+  p.y_sb = (long long)p.Tout * g.Cout; p.y_st = g.Cout;
+  p.NT = (g.Cout + BN - 1) / BN;
+  p.nchunks = (g.Cin + 63) / 64;
+  conv_tile_body<BM, BN, WM, WN, 1, false>(p, bid - g.tile_begin);
 }
 
 
@@ -988,4 +1032,55 @@ extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const ui
   return conv1d_fwd_impl(stream, x, w, y, in_len, bias, stats, B, Tin, Cin, Cout, K, stride, dil,
                          padL, Tout, y_stride_b, y_stride_t, out_f32, accumulate, 0, 1.f, 0,
                          nullptr, nullptr, nullptr, 0);
+}
+
+// Grouped 1x1 convolutions (see conv1d_igemm_grouped_kernel). groups is a HOST array.
+extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* groups,
+                                        int ngroups, const int32_t* in_len,
+                                        const int32_t* out_len, int B, int T) {
+  using namespace os2s;
+  OS2S_REQUIRE(groups && ngroups >= 1 && ngroups <= kMaxConvGroups && B >= 0 && T >= 1);
+  if (B == 0) return OS2S_OK;
+  constexpr int BM = 128, BN = 128;
+  ConvArgs a;
+  a.x = nullptr; a.w = nullptr; a.y = nullptr; a.stats = nullptr;
+  a.in_len = in_len; a.out_len = out_len; a.bias = nullptr;
+  a.B = B; a.Tin = T; a.Tout = T; a.Cin = 0; a.Cout = 0; a.K = 1;
+  a.stride = 1; a.dil = 1; a.padL = 0;
+  a.x_sb = 0; a.x_st = 0; a.y_sb = 0; a.y_st = 0;
+  a.out_f32 = 0; a.accumulate = 0; a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
+  a.dbg = nullptr; a.dbg_fixed_w = 0;
+  a.mtiles_per_b = ceil_div(T, BM);
+  a.MT = B * a.mtiles_per_b;
+  a.MT8 = ceil_div(a.MT, 8);
+  a.NT = 0; a.nchunks = 0;
+  a.R = BM; a.Rpad = BM;
+  ConvGroupTable gt;
+  gt.ngroups = ngroups;
+  int tiles = 0;
+  for (int i = 0; i < ngroups; ++i) {
+    const os2s_conv_group_t& g = groups[i];
+    OS2S_REQUIRE(g.x && g.w && g.y && g.Cin >= 8 && g.Cout >= 8 && g.Cin % 8 == 0 && g.Cout % 8 == 0);
+    gt.g[i].x = g.x; gt.g[i].w = g.w; gt.g[i].y = g.y; gt.g[i].stats = g.stats;
+    gt.g[i].Cin = g.Cin; gt.g[i].Cout = g.Cout; gt.g[i].accumulate = g.accumulate ? 1 : 0;
+    gt.g[i].tile_begin = tiles;
+    tiles += a.MT8 * 8 * ceil_div(g.Cout, BN);
+  }
+  for (int i = ngroups; i < kMaxConvGroups; ++i) gt.g[i] = gt.g[0];
+  gt.total_tiles = tiles;
+  const size_t main_bytes = (size_t)2 * a.Rpad * 128 + (size_t)2 * BN * 128;
+  constexpr size_t kOP = BN * 2 + 16;
+  const size_t epi_bytes = (size_t)BM * kOP + (size_t)4 * BN * 2 * 4;
+  const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1d_igemm_grouped_kernel<128, 128, 2, 2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  OS2S_LAUNCH((conv1d_igemm_grouped_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), smem,
+              (hipStream_t)stream, a, gt);
+  return OS2S_OK;
 }

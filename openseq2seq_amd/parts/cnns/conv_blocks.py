@@ -203,6 +203,11 @@ class ConvBN(object):
                           device=dev)
     y = capi.conv1d_fwd(x.data, self.kernel.w16, stride=self.stride, dil=self.dil,
                         pad_left=pl, tout=tout, in_len=x.lens, stats=stats)
+    return self.bn_from_stats(y, stats, B, tout, training, pl)
+
+  def bn_from_stats(self, y, stats, B, tout, training, pl=0):
+    """BatchNorm scale / shift (and the moving-statistics update) from the conv's fused partials."""
+    dev, C = y.device, self.cout
     sc = torch.empty(C, dtype=torch.float32, device=dev)
     sh = torch.empty(C, dtype=torch.float32, device=dev)
     mean = rstd = None
@@ -217,6 +222,12 @@ class ConvBN(object):
   def trainable(self):
     return [self.kernel, self.gamma, self.beta]
 
+  def backward_weights(self, inp, dy, f):
+    with on_side_stream(dy.device, inp.data, dy):
+      capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
+                        pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
+                        accumulate=True)
+
   def backward_branch(self, inp, dy, f):
     """Weight and data gradients of the convolution given dy = d(conv output). Nothing in the
     rest of backward depends on the weight gradient, so it runs on a side stream: its
@@ -224,10 +235,7 @@ class ConvBN(object):
     tiles, and it overlaps the HBM-bound BatchNorm backward kernels of the layers below. The
     main stream re-joins at the end of `Tape.backward`; the gradient reducer waits for the side
     stream on its own stream."""
-    with on_side_stream(dy.device, inp.data, dy):
-      capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
-                        pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
-                        accumulate=True)
+    self.backward_weights(inp, dy, f)
     if inp.requires_grad:
       if self.stride != 1:
         raise NotImplementedError("data-gradient of a strided conv")
@@ -385,7 +393,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
   act = act_id(activation_fn)
   branches = [main] + list(res_branches)
   inputs = [x] + list(res_inputs)
-  fw = [br.conv_bn_stats(inp, training) for br, inp in zip(branches, inputs)]
+  fw = [main.conv_bn_stats(x, training)] + grouped_conv1x1_bn_stats(res_branches, res_inputs, training)
   dropped = False
   if res_branches and drop_block_prob > 0:
     if training:
@@ -425,14 +433,59 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     c2 = torch.empty((J, C), dtype=torch.float32, device=out.device)
     capi.bn_bwd_finalize_multi(partial, rows, [br.gamma.grad for br in branches],
                                [br.beta.grad for br in branches], True, c1, c2)
+    grouped = []        # plain 1x1 residual branches: their data gradients go out in one launch
     for j, (br, inp, f) in enumerate(zip(branches, inputs, fw)):
       dy = torch.empty_like(f["y"])
       capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1[j], c2[j], dy)
       f["y"] = None
-      br.backward_branch(inp, dy, f)
+      if j > 0 and _is_plain_1x1(br) and len(branches) > 2:
+        br.backward_weights(inp, dy, f)
+        if inp.requires_grad:
+          grouped.append((br, inp, dy))
+      else:
+        br.backward_branch(inp, dy, f)
+    if grouped:
+      items = []
+      for br, inp, dy in grouped:
+        items.append(dict(x=dy, w=br.kernel.wt16, y=inp.grad_buffer(), accumulate=inp.grad_init))
+        inp.grad_init = True
+      capi.conv1x1_fwd_grouped(items, out_len=grouped[0][1].lens)
 
   tape.record(backward, [p for br in [main] + list(res_branches) for p in br.trainable()])
   return result
+
+
+def _is_plain_1x1(br):
+  return type(br) is ConvBN and br.k == 1 and br.stride == 1
+
+
+def grouped_conv1x1_bn_stats(branches, inputs, training):
+  """conv_bn_stats of the 1x1 residual branches of a block end, the convolutions in ONE launch
+  (os2s_conv1x1_fwd_grouped) when there are several plain 1x1 branches; anything else (separable
+  branches, a single branch) goes through the branch's own conv_bn_stats."""
+  plain = [i for i, br in enumerate(branches) if _is_plain_1x1(br)]
+  if len(plain) < 2 or len({tuple(inputs[i].data.shape[:2]) for i in plain}) != 1 or \
+     len({id(inputs[i].lens) for i in plain}) != 1:
+    return [br.conv_bn_stats(inp, training) for br, inp in zip(branches, inputs)]
+  out = [None] * len(branches)
+  items = []
+  for i in plain:
+    br, x = branches[i], inputs[i]
+    B, T, _ = x.data.shape
+    dev = x.data.device
+    stats = torch.empty((capi.conv1d_num_mtiles(B, T), 2, br.cout), dtype=torch.float32,
+                        device=dev) if training else None
+    y = torch.empty((B, T, br.cout), dtype=torch.bfloat16, device=dev)
+    items.append(dict(x=x.data, w=br.kernel.w16, y=y, stats=stats))
+    out[i] = (y, stats)
+  capi.conv1x1_fwd_grouped(items, in_len=inputs[plain[0]].lens)
+  for i, br in enumerate(branches):
+    if out[i] is None:
+      out[i] = br.conv_bn_stats(inputs[i], training)
+    else:
+      y, stats = out[i]
+      out[i] = br.bn_from_stats(y, stats, inputs[i].data.shape[0], inputs[i].data.shape[1], training)
+  return out
 
 
 def conv_bn_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, seed=0,

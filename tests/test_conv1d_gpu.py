@@ -347,3 +347,42 @@ def test_conv_wgrad_pingpong_full_size_vs_lockstep(cuda):
     L.os2s_conv1d_wgrad_set_variant(-1, -1)
   assert torch.equal(a, ref)
   torch.testing.assert_close(b, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+def test_conv1x1_grouped_equals_single_launches(cuda):
+  """os2s_conv1x1_fwd_grouped (the dense-residual branches of a block end in one launch; their data
+  gradients with accumulate / out_len) is the same tile code as the single-layer launch: outputs
+  and BatchNorm partials must be BIT-IDENTICAL, group by group, ragged lengths included."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(21)
+  B, T = 3, 300
+  lens = torch.tensor([300, 170, 40], dtype=torch.int32, device=cuda)
+  shapes = [(256, 768), (384, 768), (640, 768), (768, 200), (64, 128)]
+  nm = capi.conv1d_num_mtiles(B, T)
+  items, ref = [], []
+  for cin, cout in shapes:
+    x = _bf(torch.randn(B, T, cin, generator=g)).to(cuda)
+    w = _bf(torch.randn(1, cout, cin, generator=g) * 0.05).to(cuda)
+    y = torch.full((B, T, cout), 3.0, dtype=torch.bfloat16, device=cuda)
+    st = torch.full((nm, 2, cout), float("nan"), device=cuda)
+    items.append(dict(x=x, w=w, y=y, stats=st))
+    st2 = torch.full((nm, 2, cout), float("nan"), device=cuda)
+    ref.append((capi.conv1d_fwd(x, w, pad_left=0, tout=T, in_len=lens, stats=st2), st2))
+  capi.conv1x1_fwd_grouped(items, in_len=lens)
+  torch.cuda.synchronize()
+  for it, (y, st) in zip(items, ref):
+    assert torch.equal(it["y"], y) and torch.equal(it["stats"], st)
+  # data-gradient form: accumulate into existing buffers, rows past out_len untouched
+  items2, ref2 = [], []
+  for cin, cout in shapes[:3]:
+    dy = _bf(torch.randn(B, T, cout, generator=g)).to(cuda)
+    wt = _bf(torch.randn(1, cin, cout, generator=g) * 0.05).to(cuda)
+    base = _bf(torch.randn(B, T, cin, generator=g)).to(cuda)
+    a, b = base.clone(), base.clone()
+    capi.conv1d_fwd(dy, wt, pad_left=0, tout=T, out=a, accumulate=True, out_len=lens)
+    items2.append(dict(x=dy, w=wt, y=b, accumulate=True))
+    ref2.append(a)
+  capi.conv1x1_fwd_grouped(items2, out_len=lens)
+  torch.cuda.synchronize()
+  for it, a in zip(items2, ref2):
+    assert torch.equal(it["y"], a)
