@@ -225,13 +225,27 @@ class ConvTimer(object):
     return ms, fl, n
 
 
-def cpu_baseline(vocab_size=29):
-  """Oracle training step (fp32, CPU) on a bounded sample of the same workload."""
+def tensorflow_probe():
+  """SURVEY 8d plan (1): the reference's own TF1 CPU path as the baseline when TensorFlow is
+  importable on the bench host. It is not part of this image (and /root/reference does not travel
+  to the GPU box), so the probe documents its absence in the JSON line and the oracle port is
+  timed instead."""
+  try:
+    import tensorflow as tf  # noqa: F401
+    return {"tensorflow": getattr(tf, "__version__", "?")}
+  except Exception as e:
+    return {"tensorflow": None, "reason": type(e).__name__}
+
+
+def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
+  """Oracle training step (fp32 torch-CPU + NumPy NovoGrad/LARC/Backoff: oracle/tdnn.py,
+  oracle/optim.py) on a bounded SUB-BATCH OF THE SAME synthetic batch the GPU was timed on: its
+  shortest utterance (features, length and labels as in the batch). 3 warm-up steps, then >= 5
+  timed steps (as many as fit the time budget)."""
   from oracle import tdnn as otdnn, optim as oopt
   from openseq2seq_amd.configs.jasper import jasper_convnet_layers
   torch.manual_seed(0)
   layers = jasper_convnet_layers()
-  B, T = 2, 320
   ncores = os.cpu_count() or 1
   nthreads = min(ncores, 64)
   torch.set_num_threads(nthreads)
@@ -261,10 +275,14 @@ def cpu_baseline(vocab_size=29):
                           opt_params=dict(beta1=0.95, beta2=0.98, epsilon=1e-8, weight_decay=0.001),
                           lr_fn=lambda s: oopt.poly_decay(s, 0.02, 100000, power=2.0, min_lr=1e-5),
                           larc_params=dict(larc_eta=0.001), scaler=oopt.BackoffScaler())
-  x = torch.randn(B, T, 64)
-  lens = torch.tensor([T, T - 40])
-  labels = torch.randint(0, vocab_size - 1, (B, 30))
-  label_len = torch.tensor([30, 20])
+  feats, frames = [t.cpu() for t in batch["source_tensors"]]
+  tgt, tlen = [t.cpu() for t in batch["target_tensors"]]
+  pick = torch.argsort(frames)[:1]
+  lens = frames[pick].to(torch.int64)
+  T = int(-(-int(lens.max()) // 8) * 8)
+  x = feats[pick, :T].float()
+  label_len = tlen[pick].to(torch.int64)
+  labels = tgt[pick, :int(label_len.max())].to(torch.int64)
 
   def step():
     for t in tensors:
@@ -279,16 +297,62 @@ def cpu_baseline(vocab_size=29):
         t.copy_(torch.from_numpy(nw))
     return float(loss)
 
-  step()  # warm-up
-  nt = 2
+  t_w = time.time()
+  for _ in range(3):
+    step()
+  per = (time.time() - t_w) / 3
+  nt = max(5, min(12, int(max(budget_s - 3 * per, 0.0) / max(per, 1e-3))))
   t0 = time.time()
   for _ in range(nt):
     step()
   dt = (time.time() - t0) / nt
-  frames = int(lens.sum())
-  return {"value": frames / dt, "unit": "frames/sec", "cores": nthreads, "kind": "port",
-          "sample": "Jasper10x5 oracle train step (fp32 torch-CPU + NumPy NovoGrad), B=2, "
-                    "T=320 frames, 1 warm-up + %d timed steps, %.2f s/step" % (nt, dt)}
+  nframes = int(lens.sum())
+  out = {"value": nframes / dt, "unit": "frames/sec", "cores": nthreads, "kind": "port",
+         "sample": "Jasper10x5 oracle train step (fp32 torch-CPU + NumPy NovoGrad) on the shortest "
+                   "utterance of the bench batch (%d frames, padded to %d), 3 warm-up + %d "
+                   "timed steps, %.2f s/step" % (int(lens[0]), T, nt, dt)}
+  out.update(tensorflow_probe())
+  return out
+
+
+def bench_frontend(dev, batch_size, seed=1234, reps=20):
+  """The log-mel front end (get_speech_features_librosa, speech_utils.py:322-441) as
+  its own timed stage: int16 PCM of the bench batch's durations resident in HBM -> normalised
+  bf16 features [B, Tpad, 64]. HBM-bound: algorithmic bytes = PCM read once + features written
+  once (+ the fp32 pass of the per-feature normalisation)."""
+  import numpy as np
+  from openseq2seq_amd.data.speech2text.speech_utils import LogMelFrontEnd
+  params = dict(sample_freq=16000, backend="librosa", input_type="logfbank", num_audio_features=64,
+                window_size=20e-3, window_stride=10e-3, dither=1e-5, norm_per_feature=True,
+                window="hanning", num_fft=512, pad_to=16)
+  fe = LogMelFrontEnd(params, dev)
+  rng = np.random.RandomState(seed)
+  dur = rng.uniform(2.0, 16.7, size=batch_size)
+  ns = (dur * 16000).astype(np.int32)
+  nmax = int(ns.max())
+  pcm = torch.randint(-20000, 20000, (batch_size, nmax), dtype=torch.int16, device=dev)
+  n_samples = torch.from_numpy(ns).to(dev)
+  for _ in range(3):
+    feats, frames, _ = fe(pcm, n_samples, max_samples=nmax, seed=1)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for i in range(reps):
+    feats, frames, _ = fe(pcm, n_samples, max_samples=nmax, seed=i)
+  e1.record()
+  torch.cuda.synchronize()
+  ms = e0.elapsed_time(e1) / reps
+  nframes = int((1 + ns // fe.hop).sum())
+  tpad = feats.shape[1]
+  # PCM read (2 B/sample) + bf16 features written (128 B/frame) + the fp32 feature plane written and
+  # re-read by the per-feature normalisation (2 x 256 B/frame)
+  algo = float(ns.sum()) * 2.0 + nframes * (128.0 + 512.0)
+  return {"metric": "audio-frames/sec log-mel front end (int16 PCM -> normalised bf16 features)",
+          "value": nframes / (ms * 1e-3), "unit": "frames/sec", "ms_per_batch": ms,
+          "frames_per_batch": nframes, "padded_frames": int(batch_size * tpad),
+          "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": 8000.0,
+                       "unit": "GB/s", "frac": algo / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                       "algorithmic_bytes": algo}}
 
 
 def bench_transformer(args, hvd, dev, rank, world):
@@ -327,8 +391,11 @@ def bench_transformer(args, hvd, dev, rank, world):
       "workload": "Transformer-big (transformer-big.py): B=%d pairs/GPU, lengths U[8,56], "
                   "V=32768, packed tokens, fwd+bwd+all-reduce+Adam" % args.transformer_batch,
       "tokens_per_step": float(toks.item()),
-      # 0.629 GFLOP per counted token (train), SURVEY §8d
-      "model_tflops": 0.629e-3 * tps,
+      # 0.629 GFLOP per counted token (train), SURVEY 8d: the packed layout executes exactly the
+      # counted tokens, so the whole-step rate IS an executed-FLOP rate (GEMMs + attention)
+      "roofline": {"bound": "mfma", "kernel": "whole train step (dense GEMMs dominate)",
+                   "achieved": 0.629e-3 * tps, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": 0.629e-3 * tps / BF16_DENSE_PEAK_TFLOPS, "traffic": None},
       "params_M": model.store.num_trainable() / 1e6,
       "loss": float(loss.cpu()[0]), "skipped_steps": st["num_skipped"],
   }
@@ -539,7 +606,9 @@ def main():
           "padded_frames_per_step": float(padded.item()),
           "padded_frames_per_sec": float(padded.item()) * args.steps / dt,
           "train_gflop_per_padded_frame": 0.9975,
-          "model_tflops": 0.9975e-3 * float(padded.item()) * args.steps / dt,
+          # dense-equivalent rate: counts the FLOPs of padded frames too, 36 % of which are never
+          # executed (all-padding tiles are skipped); roofline.achieved counts executed FLOPs only
+          "dense_equivalent_tflops_whole_step": 0.9975e-3 * float(padded.item()) * args.steps / dt,
           "params_M": model.store.num_trainable() / 1e6,
           "parallelism": "dp%d" % world,
           "loss": float(loss.cpu()[0]), "loss_scale": st["loss_scale"],
@@ -595,9 +664,14 @@ def main():
     except Exception as e:
       others["transformer_beam_search"] = {"error": repr(e)}
     out["other_configs"] = others
+  if world == 1:
+    try:
+      out["frontend"] = bench_frontend(dev, args.batch)
+    except Exception as e:
+      out["frontend"] = {"error": repr(e)}
   if world == 1 and not args.no_cpu_baseline:
     try:
-      out["cpu_baseline"] = cpu_baseline()
+      out["cpu_baseline"] = cpu_baseline(batch)
     except Exception as e:  # the baseline must never break the bench line
       out["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": 0, "kind": "port",
                              "sample": "failed: %r" % (e,)}
