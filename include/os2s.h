@@ -154,6 +154,15 @@ typedef struct {
 } os2s_conv_group_t;
 int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* groups, int ngroups,
                              const int32_t* in_len, const int32_t* out_len, int B, int T);
+/* Plain GEMM, hand-written for the gfx950 matrix cores (csrc/gemm_pp.hip):
+ *   C[M,N] (+)= A[M,K] . W[N,K]^T, C = residual + dropout(act(. + bias)) as in os2s_conv1d_fwd_ex.
+ * Replaces tf.layers.Dense of the Transformer (parts/transformer/attention_layer.py:54-62,125-127,
+ * 219; ffn_layer.py:51-85; the tied softmax, embedding_layer.py:90-105) and, applied to the
+ * transposed weight copy, its data gradient. A has row stride lda (elements), W is contiguous
+ * [N, K], K % 64 == 0; bf16 output needs N % 8 == 0 and ldc % 8 == 0. */
+int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W, void* C,
+                 long long ldc, int M, int N, int K, const float* bias, int act, float keep_prob,
+                 unsigned long long seed, const uint16_t* residual, int accumulate, int out_f32);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,
                     float* stats, int B, int Tin, int Cin, int Cout, int K,

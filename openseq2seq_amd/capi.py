@@ -534,6 +534,28 @@ def gemm(x2d, w, **kw):
   return y.view(N, Cout)
 
 
+def gemm_nt(a, w, out=None, bias=None, act=0, keep_prob=1.0, seed=0, residual=None,
+            accumulate=False, out_f32=False):
+  """out[M,N] (+)= a[M,K] @ w[N,K]^T with the fused epilogue residual + dropout(act(. + bias));
+  the hand-written MFMA GEMM (os2s_gemm_nt). a: bf16, row stride free; w: bf16 contiguous."""
+  M, K = a.shape
+  N, K2 = w.shape
+  assert K == K2 and a.stride(1) == 1 and w.is_contiguous()
+  if out is None:
+    assert not accumulate
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+  assert out.stride(1) == 1 and tuple(out.shape) == (M, N)
+  assert residual is None or (residual.stride(1) == 1 and residual.stride(0) == out.stride(0))
+  f = _fn("os2s_gemm_nt", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                          c_void_p, c_int, c_float, c_uint64, c_void_p, c_int, c_int))
+  _lib.check(f(_stream(), c_void_p(a.data_ptr()), a.stride(0), c_void_p(w.data_ptr()),
+               c_void_p(out.data_ptr()), out.stride(0), M, N, K, _ptr(bias, torch.float32, True),
+               int(act), float(keep_prob), int(seed) & (2**64 - 1),
+               c_void_p(residual.data_ptr()) if residual is not None else c_void_p(0),
+               int(bool(accumulate)), int(out.dtype == torch.float32)), "os2s_gemm_nt")
+  return out
+
+
 def matmul_lt(a, b, a_is_t=False, b_is_t=False, out=None, out_f32=False, beta=0.0):
   """out[M,N] = op(a) @ op(b) (+ beta * out) via hipBLASLt; a, b bf16 2-D (row stride free)."""
   M, K = (a.shape[1], a.shape[0]) if a_is_t else (a.shape[0], a.shape[1])

@@ -1,0 +1,208 @@
+// Shared by the implicit-GEMM convolution kernels (conv1d_igemm.hip) and the plain GEMM
+// (gemm_pp.hip): kernel argument block, LDS-DMA helper and the fused epilogue.
+#pragma once
+#include "os2s_common.hpp"
+
+namespace os2s {
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  void* y;
+  const int32_t* in_len;
+  const int32_t* out_len;   // rows t >= out_len[b] of the OUTPUT are never read by the caller
+  const float* bias;
+  float* stats;
+  int B, Tin, Tout, Cin, Cout, K, stride, dil, padL;
+  long long x_sb, x_st, y_sb, y_st;
+  int out_f32, accumulate;
+  int mtiles_per_b, MT, MT8, NT, nchunks, R, Rpad;
+  // fused epilogue: y = residual + dropout(act(acc + bias))
+  int act;                      // 0 none, 1 relu
+  float keep_prob;              // 1 = no dropout
+  unsigned long long seed;
+  const bf16_t* residual;       // same layout/strides as y (bf16 output only) or null
+  // ping-pong kernel only: split-unit workspace (fp32 partial tiles + one ticket per split unit)
+  float* ws_slabs;
+  int* ws_cnt;
+  int ws_nslabs, ncu;
+  int force_split;              // experiment hook: > 0 forces the tail split factor
+  unsigned long long* dbg;      // experiment hook: slot time stamps [4 wg][2 waves][48 steps][9]
+  int dbg_fixed_w;              // experiment hook: every step reads the weight tile of step 0
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Epilogue shared by the tile kernels: fused bias / ReLU / dropout / residual, bf16 pack, LDS
+// transpose to full 16-B row stores, per-channel (sum, sum^2) partials for BatchNorm.
+template <int BM, int BN, int WM, int WN, int NWIN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
+                                              f32x16 (&acc)[(BN / WN) / 32][((BM * NWIN) / WM) / 32],
+                                              char* smem, int tid, int lane, int wid,
+                                              const int (&wmid)[NWIN], int n0,
+                                              const int (&wb)[NWIN], const int (&wt0)[NWIN]) {
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int WTM = (BM * NWIN) / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+  const int wm = wid / WN, wn = wid % WN;
+  const int my_win = (wm * WTM) / BM;
+  const int row_in_win = (wm * WTM) % BM;
+  const int my_b = (NWIN == 1 || my_win == 0) ? wb[0] : wb[NWIN - 1];
+  const int my_t0 = (NWIN == 1 || my_win == 0) ? wt0[0] : wt0[NWIN - 1];
+  // wmid[w] = window id (row of the BN partial sums) or -1 for a window slot with no work
+  const int my_mid = (NWIN == 1 || my_win == 0) ? wmid[0] : wmid[NWIN - 1];
+  const int l31 = lane & 31, lhi = lane >> 5;
+  if (p.out_f32) {
+    // small/rare path (FC logits): scattered fp32 stores straight from registers
+    const int b = my_b, t0 = my_t0;
+    const int valid_rows = (my_mid >= 0) ? min(BM, p.Tout - t0) : 0;
+    float* const yb = reinterpret_cast<float*>(p.y) + (long long)b * p.y_sb;
+#pragma unroll
+    for (int in = 0; in < NI; ++in)
+#pragma unroll
+      for (int im = 0; im < MI; ++im) {
+        const int tt = row_in_win + im * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int cc = n0 + wn * WTN + in * 32 + 8 * (e >> 2) + 4 * lhi + (e & 3);
+          if (tt < valid_rows && cc < p.Cout) {
+            float v = acc[in][im][e];
+            if (p.bias) v += p.bias[cc];
+            float* dst = yb + (long long)(t0 + tt) * p.y_st + cc;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    return;
+  }
+
+  constexpr int OP = BN * 2 + 16;  // out-tile pitch in bytes
+  // The out tile is staged through LDS (coalesced 16-B row stores + the BN partial sums). Wide
+  // tiles do not fit all windows at once: stage EW windows per pass.
+  constexpr bool EPI_SPLIT = (size_t)NWIN * BM * OP > 112 * 1024;
+  constexpr int EW = EPI_SPLIT ? 1 : NWIN;
+  char* const ot = smem;
+#pragma unroll
+  for (int w0 = 0; w0 < NWIN; w0 += EW) {
+  __syncthreads();                 // staging buffers / previous pass are no longer read
+  if (my_win >= w0 && my_win < w0 + EW) {
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      const int tt = wm * WTM + im * 32 + l31 - w0 * BM;   // row in this pass's out tile
+      const int b = my_b, t0 = my_t0 - (my_win - w0) * BM;   // t0 + tt = time of this row
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cc = wn * WTN + in * 32 + 8 * g + 4 * lhi;
+        float v0 = acc[in][im][4 * g + 0], v1 = acc[in][im][4 * g + 1];
+        float v2 = acc[in][im][4 * g + 2], v3 = acc[in][im][4 * g + 3];
+        if (p.bias) {
+          const int gc = n0 + cc;
+          if (gc + 3 < p.Cout) {
+            v0 += p.bias[gc]; v1 += p.bias[gc + 1]; v2 += p.bias[gc + 2]; v3 += p.bias[gc + 3];
+          }
+        }
+        if (p.act == 1) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        if (p.keep_prob < 1.f) {
+          // same (seed, element index / 8) convention as the elementwise kernels
+          const long long e0 = ((long long)b * p.Tout + t0 + tt) * p.Cout + n0 + cc;
+          const uint32_t bits = dropout_bits8(p.seed, (unsigned long long)(e0 >> 3), p.keep_prob) >>
+                                (uint32_t)(e0 & 7);
+          const float ik = 1.f / p.keep_prob;
+          v0 = (bits & 1u) ? v0 * ik : 0.f;
+          v1 = (bits & 2u) ? v1 * ik : 0.f;
+          v2 = (bits & 4u) ? v2 * ik : 0.f;
+          v3 = (bits & 8u) ? v3 * ik : 0.f;
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(v0, v1);
+        pk[1] = pack2bf(v2, v3);
+        *reinterpret_cast<u32x2*>(ot + tt * OP + cc * 2) = pk;
+      }
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int w = w0; w < w0 + EW; ++w) {
+  const int b = wb[w], t0 = wt0[w];
+  const int valid_rows = (wmid[w] >= 0) ? min(BM, p.Tout - t0) : 0;
+  const char* const otw = ot + (w - w0) * BM * OP;
+  bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
+  for (int q = tid; q < BM * (BN / 8); q += NTHR) {
+    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+    const int gc = n0 + c8 * 8;
+    if (row < valid_rows && gc < p.Cout) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
+      bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
+      if (p.residual) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(
+            p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      }
+      if (p.accumulate) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+      }
+      *reinterpret_cast<u32x4*>(dst) = v;
+    }
+  }
+  }
+
+  if (p.stats) {
+    constexpr int CP = BN / 2;       // column pairs
+    constexpr int RG = (NTHR / CP) > 0 ? (NTHR / CP) : 1;    // row groups
+    const int cp = tid % CP, rg = tid / CP;
+#pragma unroll
+    for (int w = w0; w < w0 + EW; ++w) {
+    if (wmid[w] < 0) break;
+    const int m_idx = wmid[w];
+    const int valid_rows = min(BM, p.Tout - wt0[w]);
+    const char* const otw = ot + (w - w0) * BM * OP;
+    if (w > w0) __syncthreads();      // scratch re-use between windows
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (rg < RG)
+    for (int row = rg; row < valid_rows; row += RG) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4);
+      const float a = bflo(v), bb = bfhi(v);
+      s0 += a; q0 += a * a;
+      s1 += bb; q1 += bb * bb;
+    }
+    float* sc = reinterpret_cast<float*>(smem + EW * BM * OP);  // [RG][BN][2]
+    if (rg < RG) {
+    sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
+    sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
+    sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
+    sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, qq = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        s += sc[(g * BN + tid) * 2 + 0];
+        qq += sc[(g * BN + tid) * 2 + 1];
+      }
+      const int gc = n0 + tid;
+      if (gc < p.Cout) {
+        p.stats[((long long)m_idx * 2 + 0) * p.Cout + gc] = s;
+        p.stats[((long long)m_idx * 2 + 1) * p.Cout + gc] = qq;
+      }
+    }
+    }
+  }
+  }
+}
+
+}  // namespace os2s

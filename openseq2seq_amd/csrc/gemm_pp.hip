@@ -1,0 +1,255 @@
+// Plain GEMM on the gfx950 matrix cores, hand-written (no vendor library):
+//
+//   C[M,N] (bf16, or fp32) (+)= A[M,K] . W[N,K]^T  (+ bias, ReLU, dropout, residual)
+//
+// Both operands are K-contiguous ("NT"): the tf.layers.Dense calls of the Transformer
+// (open_seq2seq/parts/transformer/attention_layer.py:54-62,125-127,219, ffn_layer.py:51-85,
+// the tied softmax of embedding_layer.py:90-105) and — with the transposed weight copies the
+// parameter store keeps next to every bf16 weight — their data gradients. The weight gradient
+// (reduction over the rows of both operands) is the K = 1 case of conv1d_wgrad.
+//
+// Same ping-pong structure as conv1d_pp_kernel: tile 256 x 256, 8 waves, waves 0-3 own rows
+// 0..127, waves 4-7 rows 128..255 (wave tile 128 x 64, 128 accumulator registers); wave w and
+// wave w+4 share a SIMD and alternate between issuing 16 MFMA 32x32x16 (COMPUTE) and fetching
+// fragments from LDS + issuing LDS-DMA (LOAD), one s_barrier per slot. A step is 64 deep; an
+// item is one 64-row half of the wave tile:
+//
+//   LOAD(2s)   : W fragments of step s (kept for both items) + A fragments of rows 0..63;
+//                issue the group's OWN half of the A tile of step s+2 (ring of 3: nobody else
+//                reads that half, its previous content was last read one step ago)
+//   LOAD(2s+1) : A fragments of rows 64..127; drain everything but the 4 DMA just issued
+//                (counted vmcnt); issue the W tile of step s+2 (ring of 2: W is read in even
+//                slots only)
+//
+// Every LOAD slot carries exactly 4 LDS-DMA instructions per wave (16 KB per CU per slot): a
+// 256 x 256 tile moves 64 KB per step through the L2->LDS path (128 FLOP per byte — there is no
+// tap reuse as in the convolution), and a CU keeps only ~16 KB of such requests in flight; issued
+// as one burst per step the same traffic ran at 0.5x the speed.
+#include <mutex>
+#include <type_traits>
+
+#include "conv1d_common.hpp"
+
+namespace os2s {
+
+__device__ __forceinline__ void gpp_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ConvArgs is used as the argument block so that the fused epilogue is literally the convolution's:
+// B = 1, Tout = M rows, Cin = K, Cout = N, x = A (row stride x_st), w = W [N, K] contiguous.
+// MT = number of 128-row windows, MT8 = 256-row blocks per XCD, NT = 256-column tiles.
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
+  constexpr int BM = 128, BN = 256, NWIN = 2, WM = 2, WN = 4;
+  constexpr int MI = 4, NI = 2;
+  constexpr int TILE = 256 * 128;                        // one operand tile: 256 rows x 64 k (bf16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wn = wid & 3;
+
+  // ---- block -> (256-row block, n-tile): per XCD, groups of gm row blocks sweep the n-tiles
+  // together (rows of A stay in that L2, every weight panel is shared by gm workgroups) ---------
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int mg = loc / (p.NT * gm), rr = loc - mg * (p.NT * gm);
+  const int n_idx = rr / gm, mi = rr - n_idx * gm;
+  const int m_blk = (mg * gm + mi) * 8 + xcd;
+  const int m_first = m_blk * NWIN;
+  if (m_first >= p.MT) return;
+  const int n0 = n_idx * BN;
+  int wb[NWIN], wt0[NWIN], wmid[NWIN];
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) {
+    wb[w] = 0;
+    wt0[w] = (m_first + w) * BM;
+    wmid[w] = (m_first + w < p.MT) ? m_first + w : -1;
+  }
+
+  char* const abuf0 = smem;                              // A tiles: ring of 3 x 32 KB
+  char* const wbuf0 = smem + 3 * TILE;                   // W tiles: ring of 2 x 32 KB
+  // LDS-DMA through buffer descriptors: rows past M / N are out of range of the descriptor and
+  // read as zeros; the k position of the tile sits in the scalar offset
+  const int m0 = m_first * BM + grp * BM;                // first row of this group's half
+  const long long a_bytes = (long long)(p.Tout - m0) * p.x_st * 2;
+  const unsigned long long ab = (unsigned long long)p.x + (unsigned long long)m0 * (unsigned long long)p.x_st * 2ull;
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)ab, 0, (int)(a_bytes < 0 ? 0 : (a_bytes < 0x7fffffffll ? a_bytes : 0x7fffffffll)), 0x00020000);
+  const long long w_bytes = (long long)(p.Cout - n0) * p.Cin * 2;
+  const unsigned long long wbs = (unsigned long long)p.w + (unsigned long long)n0 * (unsigned long long)p.Cin * 2ull;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)wbs, 0, (int)(w_bytes < 0x7fffffffll ? w_bytes : 0x7fffffffll), 0x00020000);
+  int av[4], wv[4];
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) {
+    // A: 16 instructions per 128-row half, 4 per wave of the group; W: 32 per tile, 4 per wave
+    const int arow = (pi * 4 + wn) * 8 + (lane >> 3), wrow = (pi * 8 + wid) * 8 + (lane >> 3);
+    const int jj = lane & 7;
+    av[pi] = (arow * (int)p.x_st + (jj ^ ((arow >> 1) & 7)) * 8) * 2;
+    wv[pi] = (wrow * p.Cin + (jj ^ ((wrow >> 1) & 7)) * 8) * 2;
+  }
+  auto stage_a = [&](int kt, int buf) {                  // this group's half of the A tile
+    const int soff = __builtin_amdgcn_readfirstlane(kt * 128);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          ars, (__attribute__((address_space(3))) void*)(abuf0 + buf * TILE + grp * (TILE / 2) + (pi * 4 + wn) * 1024),
+          16, av[pi], soff, 0, 0);
+  };
+  auto stage_w = [&](int kt, int buf) {
+    const int soff = __builtin_amdgcn_readfirstlane(kt * 128);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(wbuf0 + buf * TILE + (pi * 8 + wid) * 1024), 16,
+          wv[pi], soff, 0, 0);
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int im = 0; im < MI; ++im)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[in][im][e] = 0.f;
+
+  const int nsteps = p.nchunks;                          // 64-deep steps
+  {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // fragment offsets inside a tile: 16-B slot (kk*2 + lhi) ^ swizzle(row)
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int sw = ((kk * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4;
+      aoff[kk] = (grp * 128 + l31) * 128 + sw;
+      woff[kk] = (wn * 64 + l31) * 128 + sw;
+    }
+    stage_a(0, 0);
+    stage_w(0, 0);
+    if (nsteps > 1) { stage_a(1, 1); stage_w(1, 1); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp) gpp_barrier();                              // group B runs one slot behind group A
+
+    int ai = 0;                                          // ring slot of the current A tile
+    auto step = [&](auto PAR, int s) {
+      constexpr int PB = decltype(PAR)::value;
+      const char* const as = abuf0 + ai * TILE;
+      const char* const ws = wbuf0 + PB * TILE;
+      const bool more = s + 2 < nsteps;
+      bf16x8 wf[NI][4], af[2][4];
+      // ---- LOAD(2s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+          wf[in][kk] = *reinterpret_cast<const bf16x8*>(ws + woff[kk] + in * 4096);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          af[i2][kk] = *reinterpret_cast<const bf16x8*>(as + aoff[kk] + i2 * 4096);
+      }
+      {
+        int a2 = ai + 2;
+        a2 = a2 >= 3 ? a2 - 3 : a2;
+        if (more) stage_a(s + 2, a2);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      gpp_barrier();
+      // ---- COMPUTE(2s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+            acc[in][i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in][kk], af[i2][kk], acc[in][i2], 0, 0, 0);
+      gpp_barrier();
+      // ---- LOAD(2s+1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+          af[i2][kk] = *reinterpret_cast<const bf16x8*>(as + aoff[kk] + (2 + i2) * 4096);
+      // everything older than the 4 A-tile instructions issued in LOAD(2s) must have landed: the
+      // W tile of step s+1 (issued a step ago) is read right after the next barrier pair
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        stage_w(s + 2, PB);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      ai = ai + 1 >= 3 ? 0 : ai + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      gpp_barrier();
+      // ---- COMPUTE(2s+1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+            acc[in][2 + i2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in][kk], af[i2][kk], acc[in][2 + i2], 0, 0, 0);
+      gpp_barrier();
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+      step(std::integral_constant<int, 0>{}, s);
+      if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+    }
+    if (!grp) gpp_barrier();
+  }
+  __syncthreads();
+  conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
+}
+
+}  // namespace os2s
+
+// C[M,N] = A[M,K] . W[N,K]^T with the fused epilogue C = residual + dropout(act(. + bias)),
+// optional accumulation into C (bf16) and fp32 output. lda / ldc / residual row stride in
+// elements; W is contiguous [N, K].
+extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
+                            void* C, long long ldc, int M, int N, int K, const float* bias, int act,
+                            float keep_prob, unsigned long long seed, const uint16_t* residual,
+                            int accumulate, int out_f32) {
+  using namespace os2s;
+  OS2S_REQUIRE(A && W && C && M >= 1 && N >= 1 && K >= 64 && K % 64 == 0);
+  OS2S_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N);
+  OS2S_REQUIRE(act == 0 || act == 1);
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
+  if (out_f32) OS2S_REQUIRE(act == 0 && keep_prob == 1.f && residual == nullptr);
+  if (!out_f32) OS2S_REQUIRE(N % 8 == 0 && ldc % 8 == 0);
+  OS2S_REQUIRE((long long)K * 2 * 256 < (1ll << 31) && lda * 2 * 256 < (1ll << 31));
+  ConvArgs a;
+  a.x = A; a.w = W; a.y = C; a.in_len = nullptr; a.out_len = nullptr; a.bias = bias; a.stats = nullptr;
+  a.B = 1; a.Tin = M; a.Tout = M; a.Cin = K; a.Cout = N; a.K = 1; a.stride = 1; a.dil = 1; a.padL = 0;
+  a.x_sb = 0; a.x_st = lda; a.y_sb = 0; a.y_st = ldc;
+  a.out_f32 = out_f32; a.accumulate = accumulate; a.act = act; a.keep_prob = keep_prob; a.seed = seed;
+  a.residual = residual;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
+  a.dbg = nullptr; a.dbg_fixed_w = 0;
+  a.mtiles_per_b = ceil_div(M, 128);
+  a.MT = a.mtiles_per_b;
+  a.NT = ceil_div(N, 256);
+  a.nchunks = K / 64;
+  a.R = 128; a.Rpad = 128;
+  const int mblocks = ceil_div(a.MT, 2);
+  const int per_xcd = ceil_div(mblocks, 8);
+  const int gm = per_xcd < 4 ? per_xcd : 4;
+  const int mgroups = ceil_div(per_xcd, gm);
+  a.MT8 = per_xcd;
+  const size_t main_bytes = (size_t)5 * 256 * 128;    // A ring of 3 + W ring of 2 = 160 KB
+  constexpr size_t kOP = 256 * 2 + 16;
+  const size_t epi_bytes = (size_t)128 * kOP + (size_t)4 * 256 * 2 * 4;
+  const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  const int grid = 8 * mgroups * gm * a.NT;
+  OS2S_LAUNCH(gemm_pp_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, a, gm);
+  return OS2S_OK;
+}

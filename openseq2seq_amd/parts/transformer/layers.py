@@ -18,6 +18,11 @@ from ..cnns.conv_blocks import Act
 
 SKINNY_MAX_ROWS = 512
 LT_FUSED_DENSE = True
+# GEMM back end of the Dense / tied-softmax layers: 'lt' = hipBLASLt for bare matmuls (+ one
+# elementwise pass for the epilogue), 'pp' = the hand-written MFMA GEMM with fused epilogues
+# (csrc/gemm_pp.hip) for forward and data gradient, the in-tree weight-gradient kernel for dW
+import os as _os
+GEMM_BACKEND = _os.environ.get("OS2S_GEMM", "lt")
 SKINNY_LOGITS = False    # [256 x 32768 x 1024]: the LDS-tiled kernel wins (60 vs 139 us)
 
 
@@ -76,10 +81,11 @@ class Dense(object):
       return Act(capi.gemm_skinny(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
                                   relu=(act == 1), residual=residual.data if residual is not None else None))
     plain = act == 0 and keep >= 1.0 and residual is None and self.bias is None
-    # the matmul runs in the vendor GEMM (csrc/gemm_lt.hip); bias / ReLU / dropout / residual
-    # follow in one elementwise pass, which is cheaper than the in-tree fused GEMM except for the
-    # square [D, D] projections (measured: 0.060 vs 0.031 + 0.03 ms at 16k tokens)
-    if plain:
+    if GEMM_BACKEND == "pp" and self.cin % 64 == 0:
+      y = capi.gemm_nt(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
+                       act=act, keep_prob=keep, seed=seed,
+                       residual=residual.data if residual is not None else None)
+    elif plain:
       y = capi.matmul_lt(x.data, self.w, b_is_t=True)
     elif max(self.cin, self.cout) > min(self.cin, self.cout) and LT_FUSED_DENSE:
       y = capi.matmul_lt(x.data, self.w, b_is_t=True)
@@ -108,12 +114,19 @@ class Dense(object):
       # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs
       # (kept on the main stream: on a side stream it wins 10 % over 20 steps but LOSES 11 % once
       # the GPU sits at its power limit — 26.6 vs 24.0 ms/step over 300 steps)
-      capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
+      if GEMM_BACKEND == "pp":
+        capi.conv1d_wgrad(x.data.view(1, -1, lin.cin), dz.view(1, -1, lin.cout), 1, pad_left=0,
+                          out=lin.kernel.grad, accumulate=True)
+      else:
+        capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
       if lin.bias is not None:
         _colsum_into(dz, lin.bias)
       if x.requires_grad:
         g = x.grad_buffer()
-        capi.matmul_lt(dz, lin.w, out=g, beta=1.0 if x.grad_init else 0.0)
+        if GEMM_BACKEND == "pp" and lin.cout % 64 == 0:
+          capi.gemm_nt(dz, lin.kernel.wt16.view(lin.cin, lin.cout), out=g, accumulate=x.grad_init)
+        else:
+          capi.matmul_lt(dz, lin.w, out=g, beta=1.0 if x.grad_init else 0.0)
         x.grad_init = True
       if residual is not None:
         residual.res_grad = dy      # consumed by the pre-norm LayerNorm backward of `residual`
@@ -263,7 +276,10 @@ class SharedEmbedding(object):
     """logits = x E^T  (bf16 [N, V])."""
     if tape is None and x.data.shape[0] <= SKINNY_MAX_ROWS and SKINNY_LOGITS:
       return Act(capi.gemm_skinny(x.data, self.table))
-    y = capi.matmul_lt(x.data, self.table, b_is_t=True)
+    if GEMM_BACKEND == "pp" and self.D % 64 == 0:
+      y = capi.gemm_nt(x.data, self.table)
+    else:
+      y = capi.matmul_lt(x.data, self.table, b_is_t=True)
     out = Act(y)
     if tape is not None:
       emb = self
@@ -271,9 +287,14 @@ class SharedEmbedding(object):
       def backward():
         dy = out.grad
         assert dy is not None
-        capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
         g = x.grad_buffer()
-        capi.matmul_lt(dy, emb.table, out=g, beta=1.0 if x.grad_init else 0.0)
+        if GEMM_BACKEND == "pp" and emb.V % 64 == 0:
+          capi.conv1d_wgrad(x.data.view(1, -1, emb.D), dy.view(1, -1, emb.V), 1, pad_left=0,
+                            out=emb.weights.grad, accumulate=True)
+          capi.gemm_nt(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
+        else:
+          capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
+          capi.matmul_lt(dy, emb.table, out=g, beta=1.0 if x.grad_init else 0.0)
         x.grad_init = True
         out.grad = None
 

@@ -1,0 +1,56 @@
+"""GPU parity of the hand-written GEMM (os2s_gemm_nt, csrc/gemm_pp.hip) against an fp32 reference
+of the same bf16-rounded inputs: plain, with the fused epilogue (bias + ReLU + dropout, residual),
+accumulating, fp32 output, ragged M / N edges and a strided A. Tolerance: bf16 output rounding
+(rtol 1e-2, atol 1e-2 rms); fp32 output: summation order only (rtol 2e-3)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+  return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 1024, 1024), (515, 200, 4096), (3000, 4096, 1024),
+                                   (129, 32768, 128), (64, 72, 192)])
+def test_gemm_nt_plain(cuda, M, N, K):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(M + N + K)
+  a = _bf(torch.randn(M, K, generator=g)).to(cuda)
+  w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(cuda)
+  ref = a.float() @ w.float().t()
+  y = capi.gemm_nt(a, w)
+  torch.cuda.synchronize()
+  scale = float(ref.pow(2).mean().sqrt())
+  torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2 * scale)
+  y32 = capi.gemm_nt(a, w, out_f32=True)
+  torch.testing.assert_close(y32, ref, rtol=2e-3, atol=2e-3 * scale)
+
+
+def test_gemm_nt_epilogue_accumulate_and_strided_a(cuda):
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(3)
+  M, N, K = 700, 1024, 512
+  big = _bf(torch.randn(M, 3 * K, generator=g)).to(cuda)
+  a = big[:, K:2 * K]                                   # row stride 3K
+  w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(cuda)
+  bias = torch.randn(N, generator=g).to(cuda)
+  res = _bf(torch.randn(M, N, generator=g)).to(cuda)
+  z = a.float() @ w.float().t() + bias
+  y = capi.gemm_nt(a, w, bias=bias, act=1)
+  torch.testing.assert_close(y.float(), torch.relu(z), rtol=1e-2, atol=2e-2)
+  y = capi.gemm_nt(a, w, bias=bias, residual=res)
+  torch.testing.assert_close(y.float(), z + res.float(), rtol=1e-2, atol=3e-2)
+  # dropout: same (seed, element / 8) hash as the elementwise kernels
+  keep = 0.7
+  y = capi.gemm_nt(a, w, bias=bias, act=1, keep_prob=keep, seed=11)
+  ref = capi.dense_epilogue(_bf(a.float() @ w.float().t()).contiguous(), bias=bias, act=1, keep_prob=keep, seed=11)
+  kept = (y != 0) | (ref != 0)
+  assert abs(float((y != 0).float().mean()) - float((ref != 0).float().mean())) < 1e-3
+  torch.testing.assert_close(y.float()[kept], ref.float()[kept], rtol=2e-2, atol=3e-2)
+  # accumulate into an existing bf16 buffer (data gradients of several consumers)
+  base = _bf(torch.randn(M, N, generator=g)).to(cuda)
+  acc = base.clone()
+  capi.gemm_nt(a, w, out=acc, accumulate=True)
+  torch.testing.assert_close(acc.float(), base.float() + a.float() @ w.float().t(), rtol=1e-2, atol=3e-2)
