@@ -58,6 +58,8 @@ def parse():
   ap.add_argument("--only-tacotron", action="store_true",
                   help="Tacotron2 (tacotron_gst.py shapes) train step only: mel frames/sec")
   ap.add_argument("--no-style", action="store_true", help="Tacotron2 without the GST style encoder")
+  ap.add_argument("--no-fp8", action="store_true",
+                  help="Tacotron2 with bf16 decoder weights (default: e4m3 copies, BASELINE configs[4])")
   ap.add_argument("--only-ds2", action="store_true",
                   help="run only the DeepSpeech2-large train step (BASELINE configs[2])")
   ap.add_argument("--only-transformer", action="store_true",
@@ -421,6 +423,7 @@ def bench_simple(spec, steps, warmup, hvd, dev, rank, world):
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   res = {"metric": metric, "value": batch[count_key] * steps / dt, "unit": unit,
+         "dtype": "fp8-weights" if kw.get("fp8_weights") else "bf16",
          "ms_per_step": 1000 * dt / steps, "n_gpus": world, "steps": steps,
          "params_M": model.store.num_trainable() / 1e6, "loss": float(loss.cpu()[0])}
   del model
@@ -526,8 +529,10 @@ def main():
   simple = {
       "quartznet": ("openseq2seq_amd.configs.quartznet", "quartznet15x5_config", {},
                     "audio-frames/sec QuartzNet15x5 bf16 (train step)", "num_frames", "frames/sec"),
-      "tacotron": ("openseq2seq_amd.configs.tacotron", "tacotron_gst_config", {"style": not args.no_style},
-                   "mel-frames/sec Tacotron2-GST bf16 (train step)", "num_frames", "frames/sec"),
+      "tacotron": ("openseq2seq_amd.configs.tacotron", "tacotron_gst_config",
+                   {"style": not args.no_style, "fp8_weights": not args.no_fp8},
+                   "mel-frames/sec Tacotron2-GST (train step; bf16 activations, %s decoder LSTM weights)"
+                   % ("bf16" if args.no_fp8 else "fp8 e4m3"), "num_frames", "frames/sec"),
       "ds2": ("openseq2seq_amd.configs.ds2", "ds2_large_config", {},
               "audio-frames/sec DeepSpeech2-large bf16 (train step)", "num_frames", "frames/sec"),
       "nmt": ("openseq2seq_amd.configs.nmt", "nmt_small_config", {},

@@ -663,6 +663,11 @@ typedef struct os2s_attn_decoder {
   float* cum_seq; float* align_seq; float* q_seq;
   uint16_t* y_top; long long y_top_bs, y_top_ts;
   uint16_t* ctx; long long ctx_bs, ctx_ts;
+  /* optional e4m3 copies of wcat[l] (os2s_quantize_rows_e4m3) with one fp32 scale per row: when
+   * non-NULL the FORWARD cell kernels stream these instead of the bf16 weights (half the bytes
+   * per time step); activations, accumulation and the backward pass are unchanged */
+  const uint8_t* wcat8[2];
+  const float* wcat8_scale[2];
 } os2s_attn_decoder_t;
 
 /* Backward through all T steps (t_begin = 0, t_end = T). Inputs: dy_top / dctx_ext = gradients
@@ -683,6 +688,11 @@ typedef struct os2s_attn_decoder_grads {
   float* dv; float* dg_scalar; float* dconv_w; float* dconv_b; float* ddense_w;
 } os2s_attn_decoder_grads_t;
 
+/* fp8 weight storage (BASELINE.json configs[4]: Tacotron2 decode with fp8 weights; the reference has
+ * no fp8 — models/model.py:88 — so the policy is this library's): q[r,k] = e4m3(w[r,k] / scale[r]),
+ * scale[r] = max_k |w[r,k]| / 448, OCP e4m3fn. w bf16 [rows, K], K % 8 == 0. */
+int os2s_quantize_rows_e4m3(os2s_stream_t stream, const uint16_t* w, int rows, int K, uint8_t* q,
+                            float* scale);
 int os2s_attn_decoder_fwd(os2s_stream_t stream, const os2s_attn_decoder_t* d);
 size_t os2s_attn_decoder_bwd_workspace_bytes(const os2s_attn_decoder_t* d);
 int os2s_attn_decoder_bwd(os2s_stream_t stream, const os2s_attn_decoder_t* d,

@@ -1024,7 +1024,21 @@ class _AttnDecoder(_lib.ctypes.Structure):
       ("cat", c_void_p * 2), ("c_seq", c_void_p * 2), ("gates", c_void_p * 2),
       ("cum_seq", c_void_p), ("align_seq", c_void_p), ("q_seq", c_void_p),
       ("y_top", c_void_p), ("y_top_bs", c_ll), ("y_top_ts", c_ll),
-      ("ctx", c_void_p), ("ctx_bs", c_ll), ("ctx_ts", c_ll)]
+      ("ctx", c_void_p), ("ctx_bs", c_ll), ("ctx_ts", c_ll),
+      ("wcat8", c_void_p * 2), ("wcat8_scale", c_void_p * 2)]
+
+
+def quantize_rows_e4m3(w2d, q=None, scale=None):
+  """bf16 [rows, K] -> (uint8 e4m3 [rows, K], fp32 per-row scale [rows]); w ~= q * scale[:, None]."""
+  rows, K = w2d.shape
+  assert w2d.dtype == torch.bfloat16 and w2d.is_contiguous()
+  if q is None:
+    q = torch.empty((rows, K), dtype=torch.uint8, device=w2d.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=w2d.device)
+  f = _fn("os2s_quantize_rows_e4m3", (c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(w2d, torch.bfloat16), rows, K, _ptr(q, torch.uint8), _ptr(scale, torch.float32)),
+             "os2s_quantize_rows_e4m3")
+  return q, scale
 
 
 class _AttnDecoderGrads(_lib.ctypes.Structure):
@@ -1068,7 +1082,11 @@ class AttnDecoder(object):
   def set_params(self, wcat, wq, v, bias=(None, None), g=None, b=None, conv_w=None, conv_b=None,
                  dense_w=None):
     self.params = dict(wcat=list(wcat), bias=list(bias) + [None] * (2 - len(bias)), wq=wq, v=v, g=g,
-                       b=b, conv_w=conv_w, conv_b=conv_b, dense_w=dense_w)
+                       b=b, conv_w=conv_w, conv_b=conv_b, dense_w=dense_w, wcat8=None)
+
+  def set_fp8_weights(self, wcat8):
+    """wcat8: per layer (q uint8 [4H, Kc], scale fp32 [4H]) from quantize_rows_e4m3, or None."""
+    self.params["wcat8"] = wcat8
 
   def _desc(self, t_begin, t_end):
     d, p, i = _AttnDecoder(), self.params, self.inputs
@@ -1082,6 +1100,9 @@ class AttnDecoder(object):
     for l in range(2):
       d.out_seed[l] = self.out_seeds[l]
       d.wcat[l] = _addr(p["wcat"][l]) if l < L else None
+      w8 = p.get("wcat8")
+      d.wcat8[l] = _addr(w8[l][0]) if (w8 is not None and l < L) else None
+      d.wcat8_scale[l] = _addr(w8[l][1]) if (w8 is not None and l < L) else None
       d.bias[l] = _addr(p["bias"][l]) if l < L else None
       d.cat[l] = _addr(self.cat[l]) if l < L else None
       d.c_seq[l] = _addr(self.c_seq[l]) if l < L else None

@@ -17,7 +17,8 @@ def _conv(k, c, act=None, two_d=False):
   return d
 
 
-def tacotron_gst_config(batch_size_per_gpu=32, max_steps=100000, style=True, dtype="mixed"):
+def tacotron_gst_config(batch_size_per_gpu=32, max_steps=100000, style=True, dtype="mixed",
+                        fp8_weights=False):
   enc = {
       "cnn_dropout_prob": 0.5, "rnn_dropout_prob": 0., "src_emb_size": 512,
       "conv_layers": [_conv(5, 512, False)] * 3, "activation_fn": "relu",
@@ -52,6 +53,9 @@ def tacotron_gst_config(batch_size_per_gpu=32, max_steps=100000, style=True, dty
           "postnet_keep_dropout_prob": 0.5, "postnet_data_format": "channels_last",
           "postnet_conv_layers": [_conv(5, 512, "tanh")] * 4 + [_conv(5, -1, None)],
           "mask_decoder_sequence": True, "parallel_iterations": 32,
+          # BASELINE.json configs[4] "fp8 weights": e4m3 copies of the decoder LSTM stack's recurrent
+          # weights (our extension; the reference has no fp8)
+          "fp8_weights": bool(fp8_weights),
       },
       "loss": Text2SpeechLoss, "loss_params": {"use_mask": True},
       "data_layer": Text2SpeechDataLayer,

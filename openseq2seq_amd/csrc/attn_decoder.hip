@@ -40,6 +40,8 @@ struct AdCellFwd {
   const int32_t* lens;
   const bf16_t* cat;   // [B, T+1, Kc]
   const bf16_t* w;     // [4H, Kc]
+  const uint8_t* w8;   // e4m3 copy of w [4H, Kc] (or null) ...
+  const float* w8_scale;  // ... and its per-row scales [4H]
   const float* bias;   // [4H] or null
   const bf16_t* gx;    // [B, T, 4H] or null
   float* c_seq;        // [B, T, H]
@@ -64,10 +66,14 @@ __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_fwd_kernel(AdCellFwd p)
   for (int e = 0; e < 16; ++e) accw[e] = 0.f;
   {
     const int g = l31 >> 3, uu = min(j0 + (l31 & 7), H - 1);
-    const bf16_t* wrow = p.w + ((long long)g * H + uu) * p.Kc;
     const int brow = b0 + l31;
     const bf16_t* irow = brow < p.B ? p.cat + ((long long)brow * (p.T + 1) + p.t) * p.Kc : nullptr;
-    tile_gemm_prefetch<kAdWaves, 16>(wrow, irow, p.Kc, accw, p.w);
+    if (p.w8) {
+      tile_gemm_prefetch_w8<kAdWaves, 16>(p.w8 + ((long long)g * H + uu) * p.Kc, irow, p.Kc, accw, p.w8, p.cat);
+    } else {
+      const bf16_t* wrow = p.w + ((long long)g * H + uu) * p.Kc;
+      tile_gemm_prefetch<kAdWaves, 16>(wrow, irow, p.Kc, accw, p.w);
+    }
   }
   float pre[4];
   tile_reduce_units<kAdWaves>(accw, red, pre);
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_fwd_kernel(AdCellFwd p)
   const long long row = (long long)b * p.T + p.t;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
+    if (p.w8) pre[g] *= p.w8_scale[g * H + j];       // per-row scale of the e4m3 weights
     if (p.gx) pre[g] += bf2f(p.gx[row * (4 * H) + (long long)g * H + j]);
     if (p.bias) pre[g] += p.bias[g * H + j];
   }
@@ -1051,6 +1058,8 @@ extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_deco
       c.B = B; c.T = T; c.H = H; c.t = t; c.forget_bias = d->forget_bias; c.lens = d->tgt_len;
       c.Kc = l == 0 ? M + H : 2 * H;
       c.cat = (const bf16_t*)d->cat[l]; c.w = (const bf16_t*)d->wcat[l]; c.bias = d->bias[l];
+      c.w8 = d->wcat8[l]; c.w8_scale = d->wcat8_scale[l];
+      if (c.w8 && !c.w8_scale) return OS2S_ERR_INVALID_ARG;
       c.gx = l == 0 ? (const bf16_t*)d->gx0 : nullptr;
       c.c_seq = d->c_seq[l]; c.gates = (bf16_t*)d->gates[l];
       c.h_next = (bf16_t*)d->cat[l] + (l == 0 ? M : H);
@@ -1162,5 +1171,53 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
     OS2S_LAUNCH(ad_unfold_location_grads_kernel, dim3(1), dim3(256), 0, stream, dwck_acc, dbd_acc, B, K,
                 F, U, d->conv_w, d->conv_b, d->dense_w, gr->dconv_w, gr->dconv_b, gr->ddense_w, unfold_tmp);
   }
+  return OS2S_OK;
+}
+
+// ---- e4m3 weight copies -----------------------------------------------------------------------
+// q[r, k] = e4m3(w[r, k] / scale[r]), scale[r] = max_k |w[r, k]| / 448 (OCP e4m3fn: largest finite
+// value 448; an all-zero row gets scale 1). One wave per row, two passes over the row.
+namespace os2s {
+__global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const bf16_t* __restrict__ w, int rows,
+                                                               int K, uint8_t* __restrict__ q,
+                                                               float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bf16_t* wr = w + (long long)r * K;
+  float amax = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wr + k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(bflo(v[e])), fabsf(bfhi(v[e]))));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax / 448.f : 1.f;
+  const float inv = 1.f / sc;
+  if (lane == 0) scale[r] = sc;
+  for (int k = lane * 8; k < K; k += 512) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(wr + k);
+    u32x2 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float a0 = fminf(fmaxf(bflo(v[2 * h]) * inv, -448.f), 448.f);
+      const float a1 = fminf(fmaxf(bfhi(v[2 * h]) * inv, -448.f), 448.f);
+      const float a2 = fminf(fmaxf(bflo(v[2 * h + 1]) * inv, -448.f), 448.f);
+      const float a3 = fminf(fmaxf(bfhi(v[2 * h + 1]) * inv, -448.f), 448.f);
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+      o[h] = (uint32_t)pk;
+    }
+    *reinterpret_cast<u32x2*>(q + (long long)r * K + k) = o;
+  }
+}
+}  // namespace os2s
+
+extern "C" int os2s_quantize_rows_e4m3(os2s_stream_t stream, const uint16_t* w, int rows, int K,
+                                       uint8_t* q, float* scale) {
+  using namespace os2s;
+  OS2S_REQUIRE(w && q && scale && rows >= 1 && K >= 8 && K % 8 == 0);
+  OS2S_LAUNCH(quantize_rows_e4m3_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, w,
+              rows, K, q, scale);
   return OS2S_OK;
 }

@@ -170,4 +170,47 @@ __device__ __forceinline__ void tile_reduce_rows(const f32x16& acc, float* red, 
   }
 }
 
+// Same with the WEIGHT operand stored as OCP e4m3 (1 byte per element, one fp32 scale per row
+// applied by the caller to the finished dot product): 8 bytes per lane and k-slice instead of 16
+// — the step kernels stream the whole weight matrix once per time step, so halving its bytes
+// halves the L2/MALL traffic of the recurrence. The bytes are widened to bf16 in registers
+// (v_cvt_scalef32_pk_bf16_fp8, exact: every e4m3 value is a bf16 value) and go through the same
+// bf16 MFMA; activations stay bf16.
+template <int NW, int KS>
+__device__ __forceinline__ void tile_gemm_prefetch_w8(const uint8_t* __restrict__ wrow,
+                                                      const bf16_t* __restrict__ irow, int K,
+                                                      f32x16& acc, const uint8_t* __restrict__ wsafe_,
+                                                      const bf16_t* __restrict__ isafe_) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lhi = lane >> 5;
+  const int niter = (K + 15) >> 4;
+  const uint8_t* wsafe = wrow ? wrow : wsafe_;
+  const bf16_t* isafe = irow ? irow : isafe_;
+  for (int base = 0; base < niter; base += NW * KS) {
+    u32x2 a[KS];
+    u32x4 bb[KS];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int it = base + wave + NW * i;
+      const int ko = min(it * 16 + lhi * 8, K - 8);
+      a[i] = *reinterpret_cast<const u32x2*>(wsafe + ko);
+      bb[i] = *reinterpret_cast<const u32x4*>(isafe + ko);
+    }
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int it = base + wave + NW * i;
+      const bool kv = it < niter && it * 16 + lhi * 8 < K;
+      u32x4 av;
+      av[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a[i][0], 1.0f, false));
+      av[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a[i][0], 1.0f, true));
+      av[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a[i][1], 1.0f, false));
+      av[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a[i][1], 1.0f, true));
+      av = (kv && wrow) ? av : zero;
+      const u32x4 bv = (kv && irow) ? bb[i] : zero;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                    acc, 0, 0, 0);
+    }
+  }
+}
+
 }  // namespace os2s

@@ -97,7 +97,28 @@ class AttentionCell(object):
                    self._zero_v if self.luong else self.v.master,
                    bias=[None] + [b.master for b in self.bias[1:]], g=m(self.g),
                    b=m(self.b), conv_w=m(self.conv_w), conv_b=m(self.conv_b), dense_w=m(self.dense_w))
+    if getattr(self, "fp8_weights", False):
+      dec.set_fp8_weights(self.fp8_copies())
     return dec
+
+  def fp8_copies(self):
+    """e4m3 copies (+ per-row scales) of the recurrent weight matrices the time loop streams every
+    step, re-quantised whenever the bf16 weights changed (optimizer step, checkpoint load): the
+    forward cell kernels read these, the backward pass keeps the bf16 weights (gradients are taken
+    straight through the quantisation)."""
+    store = getattr(self.wcat[0], "store", None)
+    ver = getattr(store, "version", None) if store is not None else None
+    cache = getattr(self, "_fp8_cache", None)
+    GH = 4 * self.H
+    if cache is None:
+      cache = self._fp8_cache = {"ver": object(), "w8": [capi.quantize_rows_e4m3(w.w16.view(GH, -1))
+                                                        for w in self.wcat]}
+      cache["ver"] = ver
+    elif ver is None or cache["ver"] != ver:
+      for (q, sc), w in zip(cache["w8"], self.wcat):
+        capi.quantize_rows_e4m3(w.w16.view(GH, -1), q, sc)
+      cache["ver"] = ver
+    return cache["w8"]
 
   def memory(self, enc, tape):
     """values (already zero past the source lengths) -> keys = memory_layer(values)."""

@@ -49,6 +49,9 @@ class Tacotron2Decoder(Decoder):
         'postnet_keep_dropout_prob': float, 'mask_decoder_sequence': bool,
         'attention_bias': bool, 'zoneout_prob': float, 'dropout_prob': float,
         'parallel_iterations': int,
+        # extension (BASELINE.json configs[4] "fp8 weights"; the reference has no fp8): the recurrent
+        # weight matrices of the decoder LSTM stack are streamed as OCP e4m3 with per-row scales
+        'fp8_weights': bool,
     })
 
   def __init__(self, params, model, name='tacotron_2_decoder', mode='train'):
@@ -95,6 +98,7 @@ class Tacotron2Decoder(Decoder):
     self.cell = AttentionCell(store, scope + "/attention_wrapper", pu, H, self.M,
                               p['attention_layer_size'], p['decoder_layers'], capi.SCORE_LOCATION,
                               1.0, use_bias=p.get('attention_bias', False), loc_k=32, loc_f=32)
+    self.cell.fp8_weights = bool(p.get('fp8_weights', False))
     for w in [self.cell.w_in, self.cell.w_mem, self.cell.w_q] + self.cell.wcat:
       w.l2 = l2
     self.out_proj = Dense(store, scope + "/output_proj", H + self.M, self.n_mel, True)

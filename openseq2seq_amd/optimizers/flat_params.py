@@ -48,6 +48,7 @@ class FlatParams(object):
         raise ValueError("duplicate variable " + name)
     p = Param(name, shape, kind, float(l2), logical_out)
     p.index = len(self.params)
+    p.store = self
     self.params.append(p)
     self._inits.append(init)
     return p
@@ -121,6 +122,9 @@ class FlatParams(object):
     self.refresh_dgrad_copies()
 
   def refresh_dgrad_copies(self):
+    # every path that changes the bf16 weights ends here (optimizer step, checkpoint load, weight
+    # copy): consumers that keep derived copies (fp8 weight copies) compare this counter
+    self.version = getattr(self, "version", 0) + 1
     if self._wt_tiles:
       capi.conv_weight_dgrad_copy(self.w16, self.wt16, self._wt_descs.view(-1, 32),
                                   self._wt_tiles)
