@@ -351,6 +351,18 @@ int os2s_conv_weight_dgrad_copy(os2s_stream_t stream, const uint16_t* w16,
  *   frames per utterance = 1 + n_samples/hop (out_len), rows >= that are zero
  * Only n_fft == 512 and n_mels <= 64 are implemented (OS2S_ERR_UNSUPPORTED otherwise).
  * ---------------------------------------------------------------------- */
+/* 'spectrogram' features of the python_speech_features backend (get_speech_features_psf,
+ * open_seq2seq/data/speech2text/speech_utils.py:444-535; the DeepSpeech2 configs: 160 bins of a
+ * 320-point spectrum): int16 re-quantisation of the gain-normalised signal, frames of n_win samples
+ * every n_step (zero-padded tail, symmetric Hann), 10 log10(|rfft|^2 / n_win) clipped at 1e-30,
+ * first num_features bins, (x - mean) / std over the utterance INCLUDING the zero frames that round
+ * the frame count up to a multiple of pad_to. out_len[b] = that frame count (<= Tpad required);
+ * rows past it are zero. */
+size_t os2s_psf_spectrogram_workspace_bytes(int B, int Tpad, int num_features);
+int os2s_psf_spectrogram(os2s_stream_t stream, const void* signal, int sample_is_int16,
+                         const int32_t* n_samples, int B, long long Nmax, int n_win, int n_step,
+                         int pad_to, int num_features, int Tpad, uint16_t* out_bf16, float* out_f32,
+                         int32_t* out_len, void* workspace, size_t workspace_bytes);
 size_t os2s_logmel_workspace_bytes(int B, int Tmax, int n_mels);
 int os2s_logmel(os2s_stream_t stream, const void* signal, const int32_t* n_samples,
                 int sample_is_int16, int B, long long Nmax, int n_fft, int hop,

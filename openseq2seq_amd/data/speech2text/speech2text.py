@@ -220,10 +220,10 @@ class Speech2TextDataLayer(DataLayer):
     noise (os2s_augment_signal) when any sample asks for it, log-mel features (os2s_logmel),
     SpecAugment boxes (os2s_spec_augment)."""
     from ... import capi
-    from .speech_utils import KAISER_BEST, LogMelFrontEnd, sinc_window
+    from .speech_utils import KAISER_BEST, make_front_end, sinc_window
     p = self.params
     if self._front is None or self._front.device != device:
-      self._front = LogMelFrontEnd(p, device)
+      self._front = make_front_end(p, device)
       win, self._num_table = sinc_window(**KAISER_BEST)
       self._interp_win = torch.from_numpy(win).to(device)
     B = len(exs)
@@ -240,7 +240,9 @@ class Speech2TextDataLayer(DataLayer):
           torch.tensor([e['ratio'] for e in exs], dtype=torch.float64, device=device),
           torch.tensor([e['amp'] for e in exs], dtype=torch.float32, device=device),
           self._interp_win, self._num_table, int(n_out.max()), seed=seed,
-          fixed_gain=p.get('gain') if p.get('gain') is not None else -1.0)
+          # psf path: augmentation runs on the raw samples, the feature kernel normalises
+          # (speech_utils.py:469-473); librosa path: normalise first (:334-356)
+          fixed_gain=1.0 if self._psf() else (p.get('gain') if p.get('gain') is not None else -1.0))
       feats, frames, _ = self._front_call(sig, n_out, seed, fixed_gain=1.0)
     else:
       feats, frames, _ = self._front_call(sig, n_out, seed)
@@ -315,8 +317,15 @@ class Speech2TextDataLayer(DataLayer):
       stop.set()
 
   # ------------------------------------------------------------------------
+  def _psf(self):
+    return self.params.get('backend', 'psf') == 'psf' and self.params.get('input_type') == 'spectrogram'
+
   def frames_for_samples(self, n_samples):
-    hop = int(self.params.get('sample_freq', 16000) * self.params.get('window_stride', 10e-3))
+    sr = self.params.get('sample_freq', 16000)
+    hop = int(sr * self.params.get('window_stride', 10e-3))
+    if self._psf():     # framesig: 1 + ceil((n - win) / hop), before the pad_to rounding
+      win = int(sr * self.params.get('window_size', 20e-3))
+      return 1 if n_samples <= win else 1 + -(-(n_samples - win) // hop)
     return 1 + n_samples // hop
 
   def synthetic_batch(self, device, seed, fixed_frames=None, min_dur=2.0):

@@ -61,8 +61,8 @@ class LogMelFrontEnd(object):
     sr = params.get('sample_freq', 16000)
     self.sample_freq = sr
     if params.get('backend', 'psf') != 'librosa' or params.get('input_type') != 'logfbank':
-      raise NotImplementedError("GPU front end implements backend='librosa', "
-                                "input_type='logfbank' (the Jasper configs)")
+      raise NotImplementedError("GPU front ends: backend='librosa' + input_type='logfbank' (the Jasper "
+                                "configs) and backend='psf' + input_type='spectrogram' (DeepSpeech2)")
     self.n_mels = params['num_audio_features']
     window_size = params.get('window_size', 20e-3)
     window_stride = params.get('window_stride', 10e-3)
@@ -112,6 +112,47 @@ class LogMelFrontEnd(object):
                        fixed_gain=self.gain if self.gain is not None else -1.0,
                        norm_per_feature=self.norm_per_feature, want_f32=want_f32,
                        n_fft=self.n_fft)
+
+
+class PsfSpectrogramFrontEnd(object):
+  """Launcher for the 'spectrogram' features of the python_speech_features backend
+  (get_speech_features_psf, speech_utils.py:444-535; the DeepSpeech2 configs). Same call
+  signature as LogMelFrontEnd; dither / gain / norm_per_feature do not exist on this path."""
+
+  def __init__(self, params, device):
+    self.device = device
+    sr = params.get('sample_freq', 16000)
+    self.sample_freq = sr
+    if params.get('backend', 'psf') != 'psf' or params.get('input_type') != 'spectrogram':
+      raise NotImplementedError("PsfSpectrogramFrontEnd implements backend='psf', input_type='spectrogram'")
+    self.num_features = params['num_audio_features']
+    self.win_length = int(sr * params.get('window_size', 20e-3))
+    self.hop = int(sr * params.get('window_stride', 10e-3))
+    self.pad_to = params.get('pad_to', 8)
+    self.gain = None
+    if self.num_features > self.win_length // 2 + 1:        # speech_utils.py:501-502
+      raise AssertionError("num_features for spectrogram should be <= (sample_freq * window_size // 2 + 1)")
+
+  def frames(self, n_samples):
+    n = int(n_samples)
+    f = 1 if n <= self.win_length else 1 + -(-(n - self.win_length) // self.hop)
+    if self.pad_to > 0 and f % self.pad_to:
+      f += self.pad_to - f % self.pad_to
+    return f
+
+  def __call__(self, signal, n_samples, max_samples=None, seed=0, want_f32=False):
+    nmax = int(max_samples) if max_samples is not None else signal.shape[1]
+    return capi.psf_spectrogram(signal, n_samples, n_win=self.win_length, n_step=self.hop,
+                                pad_to=self.pad_to, num_features=self.num_features,
+                                tpad=self.frames(nmax), want_f32=want_f32)
+
+
+def make_front_end(params, device):
+  """The GPU front end of a Speech2TextDataLayer configuration: log-mel (librosa backend, the
+  Jasper / wav2letter configs) or psf spectrogram (the DeepSpeech2 configs)."""
+  if params.get('backend', 'psf') == 'psf' and params.get('input_type') == 'spectrogram':
+    return PsfSpectrogramFrontEnd(params, device)
+  return LogMelFrontEnd(params, device)
 
 
 # ---- speed perturbation filter (resampy 'kaiser_best') --------------------------------------------

@@ -120,3 +120,56 @@ def get_speech_features_librosa(signal, sample_freq, num_features, features_type
     std_dev = np.std(features, axis=norm_axis)
   features = (features - mean) / std_dev
   return features, audio_duration
+
+
+# ---- psf backend, 'spectrogram' features (the DeepSpeech2 configs) ---------------------------------
+# open_seq2seq/data/speech2text/speech_utils.py:444-535 (get_speech_features_psf). The frame /
+# spectrum arithmetic is delegated to python_speech_features (requirements.txt:9, version 0.6 on
+# PyPI; NOT vendored under /root/reference) and restated here from its published sigproc module:
+#   framesig(sig, frame_len, frame_step, winfunc): numframes = 1 if len <= frame_len else
+#       1 + ceil((len - frame_len) / frame_step); the signal is zero-padded to
+#       (numframes-1)*frame_step + frame_len; frame i = padded[i*step : i*step + frame_len] * winfunc(frame_len)
+#   magspec  = |numpy.fft.rfft(frames, NFFT)|;  powspec = magspec**2 / NFFT
+#   logpowspec(frames, NFFT, norm=1): ps = powspec; ps[ps <= 1e-30] = 1e-30; lps = 10*log10(ps);
+#       return lps - max(lps)
+# PARITY STATUS: "parity unpinned" for the values (the reference's test, speech_utils_test.py:45-85,
+# pins shapes, mean ~ 0, std ~ 1 and the num_features assertion — reproduced in
+# tests/test_oracle_speech_features.py); the DFT is cross-checked against a direct O(N^2) sum.
+def psf_framesig(sig, frame_len, frame_step, winfunc=np.hanning):
+  slen = len(sig)
+  numframes = 1 if slen <= frame_len else 1 + int(math.ceil((1.0 * slen - frame_len) / frame_step))
+  padlen = int((numframes - 1) * frame_step + frame_len)
+  padsignal = np.concatenate((np.asarray(sig, np.float64), np.zeros((padlen - slen,))))
+  idx = np.arange(frame_len)[None, :] + (np.arange(numframes) * frame_step)[:, None]
+  return padsignal[idx] * winfunc(frame_len)[None, :]
+
+
+def psf_logpowspec(frames, nfft, norm=True):
+  ps = np.square(np.abs(np.fft.rfft(frames, nfft))) / nfft
+  ps[ps <= 1e-30] = 1e-30
+  lps = 10.0 * np.log10(ps)
+  return lps - np.max(lps) if norm else lps
+
+
+def get_speech_features_psf_spectrogram(signal, sample_freq, num_features, pad_to=8,
+                                        window_size=20e-3, window_stride=10e-3):
+  """speech_utils.py:473-535, features_type='spectrogram' (no augmentation): returns
+  (features float32 [frames, num_features], audio_duration)."""
+  signal = (normalize_signal(np.asarray(signal).astype(np.float32)) * 32767.0).astype(np.int16)
+  audio_duration = len(signal) * 1.0 / sample_freq
+  n_window_size = int(sample_freq * window_size)
+  n_window_stride = int(sample_freq * window_stride)
+  length = 1 + int(math.ceil((1.0 * signal.shape[0] - n_window_size) / n_window_stride))
+  if pad_to > 0 and length % pad_to != 0:
+    pad_size = (pad_to - length % pad_to) * n_window_stride
+    signal = np.pad(signal, (0, pad_size), mode='constant')
+  frames = psf_framesig(signal, n_window_size, n_window_stride, np.hanning)
+  features = psf_logpowspec(frames, n_window_size)
+  assert num_features <= n_window_size // 2 + 1, \
+      "num_features for spectrogram should be <= (sample_freq * window_size // 2 + 1)"
+  features = features[:, :num_features]
+  if pad_to > 0:
+    assert features.shape[0] % pad_to == 0
+  mean = np.mean(features)
+  std_dev = np.std(features)
+  return ((features - mean) / std_dev).astype(np.float32), audio_duration

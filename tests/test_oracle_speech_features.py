@@ -47,3 +47,58 @@ def test_mel_filterbank_properties():
   f = np.array([0., 500., 1000., 4000., 8000.])
   np.testing.assert_allclose(sf.mel_to_hz(sf.hz_to_mel(f)), f, atol=1e-9)
   assert abs(sf.hz_to_mel(1000.0) - 15.0) < 1e-12
+
+
+# ---- psf backend, 'spectrogram' (the DeepSpeech2 configs) -----------------------------------------
+def _speechlike(n, seed):
+  rng = np.random.RandomState(seed)
+  t = np.arange(n) / 16000.0
+  return (0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * rng.randn(n)).astype(np.float32)
+
+
+def test_psf_spectrogram_reference_relations():
+  """speech_utils_test.py:45-85 restated for the psf 'spectrogram' branch: shape
+  [frames % pad_to == 0, num_features], mean ~ 0, std ~ 1, and the num_features assertion."""
+  import pytest
+  for n, pad_to, F in [(16000, 8, 161), (23456, 8, 160), (5000, 16, 96), (48000, 0, 160)]:
+    feats, dur = sf.get_speech_features_psf_spectrogram(_speechlike(n, n), 16000, F, pad_to=pad_to)
+    frames = 1 + int(np.ceil((n - 320) / 160.0))
+    if pad_to:
+      frames = -(-frames // pad_to) * pad_to
+    assert feats.shape == (frames, F)
+    assert abs(feats.mean()) < 1e-3 and abs(feats.std() - 1.0) < 1e-3
+    assert dur == n / 16000.0
+  with pytest.raises(AssertionError):
+    sf.get_speech_features_psf_spectrogram(_speechlike(16000, 0), 16000, 162)
+
+
+def test_psf_logpowspec_against_direct_dft():
+  """psf_logpowspec (rfft) == 10 log10(|sum x e^{-2 pi i k n / N}|^2 / N) by the definition."""
+  x = _speechlike(2000, 3) * 1000
+  frames = sf.psf_framesig(x, 320, 160)
+  assert frames.shape == (1 + int(np.ceil((2000 - 320) / 160.0)), 320)
+  np.testing.assert_allclose(frames[0], x[:320].astype(np.float64) * np.hanning(320))
+  # the tail frame is zero-padded
+  last = (frames.shape[0] - 1) * 160
+  assert np.all(frames[-1][2000 - last:] == 0)
+  n = np.arange(320)
+  k = np.arange(161)
+  dft = frames @ np.exp(-2j * np.pi * np.outer(n, k) / 320)
+  want = 10 * np.log10(np.maximum(np.abs(dft) ** 2 / 320, 1e-30))
+  got = sf.psf_logpowspec(frames, 320, norm=False)
+  np.testing.assert_allclose(got, want, atol=1e-6)
+  np.testing.assert_allclose(sf.psf_logpowspec(frames, 320), want - want.max(), atol=1e-6)
+
+
+def test_psf_spectrogram_int16_and_padding_rows():
+  """int16 input goes through the same gain normalisation; the pad_to rows are the -300 dB
+  floor of an all-zero frame and enter mean / std."""
+  x = _speechlike(16000 + 37, 5)
+  xi = (x / np.abs(x).max() * 20000).astype(np.int16)
+  fa, _ = sf.get_speech_features_psf_spectrogram(xi, 16000, 160, pad_to=8)
+  assert fa.shape[0] % 8 == 0
+  real = 1 + int(np.ceil((len(xi) - 320) / 160.0))
+  assert real < fa.shape[0]
+  # frame `real` still overlaps the last 37 samples; the rows after it are all-zero frames and
+  # hold one constant (the floor), far below every other row
+  assert np.ptp(fa[real + 1:]) == 0.0 and fa[real + 1:].max() < fa[:real + 1].min()
