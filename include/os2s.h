@@ -351,6 +351,11 @@ int os2s_conv_weight_dgrad_copy(os2s_stream_t stream, const uint16_t* w16,
  *   frames per utterance = 1 + n_samples/hop (out_len), rows >= that are zero
  * Only n_fft == 512 and n_mels <= 64 are implemented (OS2S_ERR_UNSUPPORTED otherwise).
  * ---------------------------------------------------------------------- */
+/* CRC-32C (Castagnoli) of a host buffer, extendable: crc = os2s_crc32c(0, a, na);
+ * crc = os2s_crc32c(crc, b, nb). Used by the TensorBundle checkpoint reader / writer
+ * (tf.train.Saver files: open_seq2seq/utils/funcs.py:117-144, utils/helpers.py:462-553). Host only. */
+uint32_t os2s_crc32c(uint32_t init, const void* data, size_t n);
+
 /* 'spectrogram' features of the python_speech_features backend (get_speech_features_psf,
  * open_seq2seq/data/speech2text/speech_utils.py:444-535; the DeepSpeech2 configs: 160 bins of a
  * 320-point spectrum): int16 re-quantisation of the gain-normalised signal, frames of n_win samples

@@ -2,11 +2,11 @@
 
 The reference saves tf.train.Saver checkpoints (utils/funcs.py:117-144, utils/hooks.py:227-236)
 and restores by NAME and SHAPE (utils/helpers.py:462-553), falling back from a half-precision
-variable to its 'Loss_Optimization/FP32-master-copy/<name>' twin. TensorFlow is not available
-here, so the container is a NumPy .npz (one array per variable) — INTEGRATION.md §6 gives the
-ten-line script that converts a TF checkpoint to / from it with tf.train.load_checkpoint. What
-this module guarantees is the part that matters for exchanging weights: every array is stored
-under the reference's variable name, in the reference's layout:
+variable to its 'Loss_Optimization/FP32-master-copy/<name>' twin. The container is the
+reference's own: a TensorFlow V2 checkpoint (<prefix>.index + <prefix>.data-00000-of-00001),
+read and written by utils/tensor_bundle.py without TensorFlow; a NumPy .npz with the same keys
+(format='npz', the round-1 container) is still read and written. Every array is stored under the
+reference's variable name, in the reference's layout:
 
   conv1d kernel   device [K, Cout, Cin]        -> tf.layers.conv1d  [K, Cin, Cout]
   dense kernel    device [1, Cout, Cin]        -> tf.layers.dense   [Cin, Cout]
@@ -126,8 +126,22 @@ def model_variables(model):
   return out
 
 
-def save(model, logdir, step=None):
-  """Writes <logdir>/model.ckpt-<step>.npz and the TF-style 'checkpoint' index file."""
+def open_checkpoint(prefix):
+  """name -> array mapping of a checkpoint prefix: a TensorBundle (tf.train.Saver V2 files) when
+  <prefix>.index exists, else <prefix>.npz."""
+  from . import tensor_bundle
+  if prefix.endswith(".npz"):
+    return np.load(prefix)
+  if tensor_bundle.is_bundle(prefix):
+    return tensor_bundle.BundleReader(prefix)
+  if os.path.exists(prefix + ".npz"):
+    return np.load(prefix + ".npz")
+  return tensor_bundle.BundleReader(prefix)       # raises the reference-style "not found" error
+
+
+def save(model, logdir, step=None, format="tf"):
+  """Writes <logdir>/model.ckpt-<step> (format 'tf': .index + .data-00000-of-00001; 'npz': .npz)
+  and the 'checkpoint' state file tf.train.latest_checkpoint reads."""
   os.makedirs(logdir, exist_ok=True)
   arrays = model_variables(model)
   store = model.store
@@ -142,9 +156,15 @@ def save(model, logdir, step=None):
     arrays["OS2S/opt/state"] = train_op.state.detach().cpu().numpy()
     arrays["OS2S/opt/t_v"] = store.t_v.detach().cpu().numpy()
   prefix = "model.ckpt-%d" % int(step)
-  np.savez(os.path.join(logdir, prefix + ".npz"), **arrays)
+  if format == "npz":
+    np.savez(os.path.join(logdir, prefix + ".npz"), **arrays)
+  elif format == "tf":
+    from . import tensor_bundle
+    tensor_bundle.write_bundle(os.path.join(logdir, prefix), arrays)
+  else:
+    raise ValueError("checkpoint format must be 'tf' or 'npz'")
   with open(os.path.join(logdir, LATEST_FILENAME), "w") as f:
-    f.write('model_checkpoint_path: "%s"\n' % prefix)
+    f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (prefix, prefix))
   return os.path.join(logdir, prefix)
 
 
@@ -162,15 +182,14 @@ def latest_checkpoint(logdir):
 
 def read_step(prefix):
   """The training step stored with the checkpoint (global_step)."""
-  path = prefix if prefix.endswith(".npz") else prefix + ".npz"
-  return int(np.load(path)["global_step"])
+  return int(open_checkpoint(prefix)["global_step"])
 
 
 def load(model, prefix, restore_optimizer=True, strict=True):
   """Restores by name and shape (helpers.py:462-553). Returns the list of variables that were
   not found (empty with strict=True, which raises instead)."""
-  path = prefix if prefix.endswith(".npz") else prefix + ".npz"
-  data = np.load(path)
+  path = prefix
+  data = open_checkpoint(prefix)
   store = model.store
   missing = []
   for p in store.params:

@@ -243,8 +243,11 @@ def test_run_py_train_eval_infer_checkpoints(cuda, tmp_path):
 
   out = run("--mode=train_eval")
   assert "Eval WER" in out and "Saved checkpoint" in out
-  ck = np.load(os.path.join(logdir, "model.ckpt-30.npz"))
-  names = set(ck.files)
+  from openseq2seq_amd.utils import tensor_bundle
+  assert os.path.exists(os.path.join(logdir, "model.ckpt-30.index"))         # tf.train.Saver V2 files
+  assert os.path.exists(os.path.join(logdir, "model.ckpt-30.data-00000-of-00001"))
+  ck = tensor_bundle.BundleReader(os.path.join(logdir, "model.ckpt-30"))
+  names = set(ck.keys())
   k = "ForwardPass/w2l_encoder/conv11/kernel"
   assert k in names and "Loss_Optimization/FP32-master-copy/" + k in names
   assert ck[k].shape == (11, 64, 128)                       # TF conv1d layout [K, Cin, Cout]
@@ -298,11 +301,11 @@ def test_checkpoint_roundtrip_transformer_layout(cuda, tmp_path):
   m1 = cls(params, mode="train", hvd=None, device=cuda)
   m1.compile()
   prefix = checkpoint.save(m1, str(tmp_path), 7)
-  ck = np.load(prefix + ".npz")
+  ck = checkpoint.open_checkpoint(prefix)
   base = "ForwardPass/transformer_encoder/layer_0/self_attention/self_attention"
   for t in "qkv":
     assert ck["%s/%s/kernel" % (base, t)].shape == (512, 512)
-  assert base + "/qkv/kernel" not in ck.files
+  assert base + "/qkv/kernel" not in ck
   assert ck["ForwardPass/embedding_and_softmax/weights"].shape == (96, 512)
   qkv = m1.store.by_name(base + "/qkv/kernel").master.cpu().numpy()
   assert np.array_equal(ck[base + "/k/kernel"], qkv[0, 512:1024].T)
