@@ -256,6 +256,14 @@ int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* 
                       const float* gamma, const float* mean, const float* rstd,
                       const float* c1, const float* c2, uint16_t* dy,
                       long long rows, int C);
+/* The same on a ragged [B, T, C] batch: rows t >= out_len[b] + margin are written as zeros without
+ * reading dz / y. `margin` = how far past the sequence end the consumers of dy look — (K-1)*dilation
+ * for the data- and weight-gradient convolutions of a K-tap layer (dy is not zero there: the batch
+ * statistics run over padded frames too). out_len NULL = every row. */
+int os2s_bn_bwd_apply_ragged(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                             const float* gamma, const float* mean, const float* rstd,
+                             const float* c1, const float* c2, uint16_t* dy,
+                             const int32_t* out_len, int margin, int B, int T, int C);
 /* test hook: the keep/drop bits (one byte per 8 consecutive elements) the
  * dropout of os2s_bn_act_fwd uses for (seed, keep_prob). */
 int os2s_dropout_mask(os2s_stream_t stream, unsigned long long seed, long long n8,

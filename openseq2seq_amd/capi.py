@@ -293,9 +293,22 @@ def bn_bwd_finalize_multi(partial, count, dgammas, dbetas, accumulate, c1, c2):
              "os2s_bn_bwd_finalize_multi")
 
 
-def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy):
+def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0):
+  """out_len / margin (dz [B,T,C]): rows t >= out_len[b] + margin are written as zeros unread —
+  margin = (K-1)*dilation of the convolution whose gradients consume dy."""
   C = dz.shape[-1]
   rows = dz.numel() // C
+  if out_len is not None:
+    B, T = dz.shape[0], dz.shape[1]
+    f = _fn("os2s_bn_bwd_apply_ragged",
+            (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+             c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int))
+    _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(y, torch.bfloat16),
+                 _ptr(gamma, torch.float32, True), _ptr(mean, torch.float32),
+                 _ptr(rstd, torch.float32), _ptr(c1, torch.float32), _ptr(c2, torch.float32),
+                 _ptr(dy, torch.bfloat16), _ptr(out_len, torch.int32), int(margin), B, T, C),
+               "os2s_bn_bwd_apply_ragged")
+    return dy
   f = _fn("os2s_bn_bwd_apply",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_void_p, c_void_p, c_ll, c_int))

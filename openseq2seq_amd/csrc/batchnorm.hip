@@ -158,44 +158,158 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs p) {
+// Thread layout of the row-walking kernels below: a workgroup covers trows consecutive rows of
+// the flattened [B*T, C] tensor x G 8-channel groups (g_tiling below: 32 groups = 512 contiguous
+// bytes per row and 32 / 64 rows per workgroup measured best; the kernels are bound by how many
+// wavefronts are in flight, not by the segment width); thread -> group g = tid % G, fixed for
+// the thread's whole walk so the
+// per-channel constants live in registers, and row lane rl = tid / G. Rows are walked kTileU at a
+// time so that every thread keeps >= 4 independent 16-B loads per tensor in flight; (b, t) of a
+// row is tracked incrementally (no per-row division).
+constexpr int kTileU = 4;
+
+struct TileMap {
+  int G, RL, g, rl, cg;
+  bool cvalid;
+  __device__ __forceinline__ TileMap(int C8, int gmax) {
+    G = min(C8, gmax);
+    RL = 256 / G;
+    g = threadIdx.x % G;
+    rl = threadIdx.x / G;
+    cg = blockIdx.y * G + g;
+    cvalid = cg < C8 && rl < RL;
+  }
+};
+static inline int tile_cblocks(int C8, int gmax) { return ceil_div(C8, C8 < gmax ? C8 : gmax); }
+
+// {channel groups per workgroup, rows per workgroup} of bn_act_fwd / bn_act_bwd_reduce / bn_bwd_apply
+// defaults from tools/bench_bn_sweep.py on MI355X (Jasper shapes, working set rotated out of the MALL)
+static int g_tiling[3][2] = {{32, 32}, {32, 64}, {32, 64}};
+
+struct RowCursor {
+  long long row;
+  int b, t, T, len;
+  const int32_t* lens;
+  __device__ __forceinline__ void init(long long r, int T_, const int32_t* lens_) {
+    row = r; T = T_; lens = lens_;
+    b = (int)((unsigned long long)r / (unsigned)T_);
+    t = (int)(r - (long long)b * T_);
+    len = lens_ ? lens_[b] : T_;
+  }
+  __device__ __forceinline__ bool live() const { return t < len; }
+  // step; only valid while row stays < B*T (callers check the row bound first)
+  __device__ __forceinline__ void advance(int n, long long rows) {
+    row += n; t += n;
+    if (t >= T && row < rows) {
+      do { t -= T; ++b; } while (t >= T);
+      len = lens ? lens[b] : T;
+    }
+  }
+};
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&o)[8]) {
+  o[0] = bflo(v[0]); o[1] = bfhi(v[0]); o[2] = bflo(v[1]); o[3] = bfhi(v[1]);
+  o[4] = bflo(v[2]); o[5] = bfhi(v[2]); o[6] = bflo(v[3]); o[7] = bfhi(v[3]);
+}
+
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  u32x4 o;
+  o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+  o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
+  return o;
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs p, int gmax, int trows) {
   const int C8 = p.C >> 3;
-  const long long total = (long long)p.B * p.T * C8;
+  const TileMap tm(C8, gmax);
+  if (!tm.cvalid) return;
+  const int rl = tm.rl, cg = tm.cg, RL = tm.RL;
+  const int c0 = cg * 8;
+  const long long rows = (long long)p.B * p.T;
+  const long long r0 = (long long)blockIdx.x * trows;
+  const long long r1 = min(rows, r0 + trows);
   const float inv_keep = 1.f / p.keep_prob;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (long long)gridDim.x * 256) {
-    const long long row = i / C8;
-    const int c0 = (int)(i - row * C8) * 8;
-    const int b = (int)(row / p.T), t = (int)(row - (long long)b * p.T);
-    u32x4 o = {0u, 0u, 0u, 0u};
-    const bool live = !p.out_len || t < p.out_len[b];
-    if (live) {
-      float v[8];
+  float sc[8], sh[8];
+  if (SINGLE) {
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale[0] + c0);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale[0] + c0 + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.shift[0] + c0);
+    const f32x4 h1 = *reinterpret_cast<const f32x4*>(p.shift[0] + c0 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sh[e] = h0[e]; sh[4 + e] = h1[e]; }
+  }
+  RowCursor cur;
+  if (r0 + rl < r1) cur.init(r0 + rl, p.T, p.out_len);
+  for (long long base = r0 + rl; base < r1; base += (long long)kTileU * RL) {
+    long long rw[kTileU];
+    bool ok[kTileU], lv[kTileU];
+    float v[kTileU][8];
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+      rw[u] = base + (long long)u * RL;
+      ok[u] = rw[u] < r1;
+      lv[u] = ok[u] && cur.live();
+      if (ok[u]) cur.advance(RL, rows);
+    }
+    if (SINGLE) {
+      u32x4 y[kTileU];
+#pragma unroll
+      for (int u = 0; u < kTileU; ++u)
+        if (lv[u]) y[u] = *reinterpret_cast<const u32x4*>(p.y[0] + rw[u] * p.C + c0);
+#pragma unroll
+      for (int u = 0; u < kTileU; ++u)
+        if (lv[u]) {
+          float yv[8];
+          unpack8(y[u], yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[u][e] = yv[e] * sc[e] + sh[e];
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kTileU; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
       for (int j = 0; j < p.J; ++j) {
-        const u32x4 y = *reinterpret_cast<const u32x4*>(p.y[j] + row * p.C + c0);
+        u32x4 y[kTileU];
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u)
+          if (lv[u]) y[u] = *reinterpret_cast<const u32x4*>(p.y[j] + rw[u] * p.C + c0);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale[j] + c0);
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.scale[j] + c0 + 4);
         const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.shift[j] + c0);
         const f32x4 h1 = *reinterpret_cast<const f32x4*>(p.shift[j] + c0 + 4);
-        v[0] += bflo(y[0]) * s0[0] + h0[0]; v[1] += bfhi(y[0]) * s0[1] + h0[1];
-        v[2] += bflo(y[1]) * s0[2] + h0[2]; v[3] += bfhi(y[1]) * s0[3] + h0[3];
-        v[4] += bflo(y[2]) * s1[0] + h1[0]; v[5] += bfhi(y[2]) * s1[1] + h1[1];
-        v[6] += bflo(y[3]) * s1[2] + h1[2]; v[7] += bfhi(y[3]) * s1[3] + h1[3];
-      }
-      uint32_t keep = 0xffu;
-      if (p.keep_prob < 1.f) keep = dropout_bits8(p.seed, (unsigned long long)i, p.keep_prob);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float a = apply_act(v[e], p.act);
-        if (p.keep_prob < 1.f) a = ((keep >> e) & 1u) ? a * inv_keep : 0.f;
-        v[e] = a;
+        for (int u = 0; u < kTileU; ++u)
+          if (lv[u]) {
+            float yv[8];
+            unpack8(y[u], yv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[u][e] += yv[e] * s0[e] + h0[e];
+              v[u][4 + e] += yv[4 + e] * s1[e] + h1[e];
+            }
+          }
       }
-      o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-      o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
     }
-    *reinterpret_cast<u32x4*>(p.out + row * p.C + c0) = o;
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+      if (!ok[u]) continue;
+      u32x4 o = {0u, 0u, 0u, 0u};
+      if (lv[u]) {
+        uint32_t keep = 0xffu;
+        if (p.keep_prob < 1.f)
+          keep = dropout_bits8(p.seed, (unsigned long long)(rw[u] * C8 + cg), p.keep_prob);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = apply_act(v[u][e], p.act);
+          if (p.keep_prob < 1.f) a = ((keep >> e) & 1u) ? a * inv_keep : 0.f;
+          v[u][e] = a;
+        }
+        o = pack8(v[u]);
+      }
+      *reinterpret_cast<u32x4*>(p.out + rw[u] * p.C + c0) = o;
+    }
   }
 }
 
@@ -220,14 +334,14 @@ struct BnBwdReduceArgs {
 };
 
 template <int J_MAX>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs p) {
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs p, int gmax) {
   __shared__ float red[256 * 8];
   const int C8 = p.C >> 3;
-  const int G = min(C8, 256);
-  const int RL = 256 / G;
-  const int g = threadIdx.x % G, rl = threadIdx.x / G;
-  const int c0 = (blockIdx.y * G + g) * 8;
-  const bool cvalid = (blockIdx.y * G + g) < C8 && rl < RL;
+  const int trows = p.rows_per_block;
+  const TileMap tm(C8, gmax);
+  const int g = tm.g, rl = tm.rl, cg = tm.cg, RL = tm.RL, G = tm.G;
+  const bool cvalid = tm.cvalid;
+  const int c0 = cg * 8;
   const float inv_keep = 1.f / p.keep_prob;
   float sd[8];
   float sx[J_MAX][8];
@@ -239,66 +353,81 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
     for (int e = 0; e < 8; ++e) sx[j][e] = 0.f;
   if (cvalid) {
     const long long rows = (long long)p.B * p.T;
-    const long long r0 = (long long)blockIdx.x * p.rows_per_block;
-    const long long r1 = min(rows, r0 + p.rows_per_block);
-    for (long long row = r0 + rl; row < r1; row += RL) {
-      const int b = (int)(row / p.T), t = (int)(row - (long long)b * p.T);
-      float dzv[8];
-      const bool live = !p.out_len || t < p.out_len[b];
-      if (live) {
-        const u32x4 d = *reinterpret_cast<const u32x4*>(p.dout + row * p.C + c0);
-        const u32x4 o = *reinterpret_cast<const u32x4*>(p.out + row * p.C + c0);
-        float dv[8] = {bflo(d[0]), bfhi(d[0]), bflo(d[1]), bfhi(d[1]),
-                       bflo(d[2]), bfhi(d[2]), bflo(d[3]), bfhi(d[3])};
-        float ov[8] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1]),
-                       bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
-        uint32_t keep = 0xffu;
-        if (p.keep_prob < 1.f)
-          keep = dropout_bits8(p.seed, (unsigned long long)(row * C8 + (c0 >> 3)), p.keep_prob);
+    const long long r0 = (long long)blockIdx.x * trows;
+    const long long r1 = min(rows, r0 + trows);
+    RowCursor cur;
+    if (r0 + rl < r1) cur.init(r0 + rl, p.T, p.out_len);
+    for (long long base = r0 + rl; base < r1; base += (long long)kTileU * RL) {
+      long long rw[kTileU];
+      bool ok[kTileU], lv[kTileU];
+      u32x4 d[kTileU], o[kTileU];
+      float dr[kTileU][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float gsc = 1.f;
-          if (p.keep_prob < 1.f) gsc = ((keep >> e) & 1u) ? inv_keep : 0.f;
-          float dact = 1.f;
-          if (p.act == 1) dact = ov[e] > 0.f ? 1.f : 0.f;
-          else if (p.act == 2) {
-            const float th = ov[e] * p.keep_prob;  // tanh(z) of a kept element
-            dact = 1.f - th * th;
-          }
-          dzv[e] = dv[e] * gsc * dact;
+      for (int u = 0; u < kTileU; ++u) {
+        rw[u] = base + (long long)u * RL;
+        ok[u] = rw[u] < r1;
+        lv[u] = ok[u] && cur.live();
+        if (ok[u]) cur.advance(RL, rows);
+        if (lv[u]) {
+          d[u] = *reinterpret_cast<const u32x4*>(p.dout + rw[u] * p.C + c0);
+          o[u] = *reinterpret_cast<const u32x4*>(p.out + rw[u] * p.C + c0);
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dzv[e] = 0.f;
       }
-      u32x4 w;
-      w[0] = pack2bf(dzv[0], dzv[1]); w[1] = pack2bf(dzv[2], dzv[3]);
-      w[2] = pack2bf(dzv[4], dzv[5]); w[3] = pack2bf(dzv[6], dzv[7]);
-      *reinterpret_cast<u32x4*>(p.dz + row * p.C + c0) = w;
-      // the sums use the bf16-rounded dz, i.e. exactly what pass 2 re-reads
-      const float dr[8] = {bflo(w[0]), bfhi(w[0]), bflo(w[1]), bfhi(w[1]),
-                           bflo(w[2]), bfhi(w[2]), bflo(w[3]), bfhi(w[3])};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sd[e] += dr[e];
-      if (live) {
+      for (int u = 0; u < kTileU; ++u) {
+        if (!ok[u]) continue;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (lv[u]) {
+          float dv[8], ov[8], dzv[8];
+          unpack8(d[u], dv);
+          unpack8(o[u], ov);
+          uint32_t keep = 0xffu;
+          if (p.keep_prob < 1.f)
+            keep = dropout_bits8(p.seed, (unsigned long long)(rw[u] * C8 + cg), p.keep_prob);
 #pragma unroll
-        for (int j = 0; j < J_MAX; ++j)
-          if (j < p.J) {
-            const u32x4 y = *reinterpret_cast<const u32x4*>(p.y[j] + row * p.C + c0);
-            const float yv[8] = {bflo(y[0]), bfhi(y[0]), bflo(y[1]), bfhi(y[1]),
-                                 bflo(y[2]), bfhi(y[2]), bflo(y[3]), bfhi(y[3])};
-            // only sum(dz * y) is accumulated per row: sum(dz * xhat) = rstd * (sum(dz * y) -
-            // mean * sum(dz)) is formed once per thread below (no per-row mean / rstd loads)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sx[j][e] += dr[e] * yv[e];
+          for (int e = 0; e < 8; ++e) {
+            float gsc = 1.f;
+            if (p.keep_prob < 1.f) gsc = ((keep >> e) & 1u) ? inv_keep : 0.f;
+            float dact = 1.f;
+            if (p.act == 1) dact = ov[e] > 0.f ? 1.f : 0.f;
+            else if (p.act == 2) {
+              const float th = ov[e] * p.keep_prob;  // tanh(z) of a kept element
+              dact = 1.f - th * th;
+            }
+            dzv[e] = dv[e] * gsc * dact;
           }
+          w = pack8(dzv);
+        }
+        *reinterpret_cast<u32x4*>(p.dz + rw[u] * p.C + c0) = w;
+        // the sums use the bf16-rounded dz, i.e. exactly what pass 2 re-reads
+        unpack8(w, dr[u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sd[e] += dr[u][e];
       }
+      // only sum(dz * y) is accumulated per row: sum(dz * xhat) = rstd * (sum(dz * y) -
+      // mean * sum(dz)) is formed once per thread below (no per-row mean / rstd loads)
+#pragma unroll
+      for (int j = 0; j < J_MAX; ++j)
+        if (j < p.J) {
+          u32x4 y[kTileU];
+#pragma unroll
+          for (int u = 0; u < kTileU; ++u)
+            if (lv[u]) y[u] = *reinterpret_cast<const u32x4*>(p.y[j] + rw[u] * p.C + c0);
+#pragma unroll
+          for (int u = 0; u < kTileU; ++u)
+            if (lv[u]) {
+              float yv[8];
+              unpack8(y[u], yv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) sx[j][e] += dr[u][e] * yv[e];
+            }
+        }
     }
   }
-  // block reduction over the RL row lanes, one quantity (dz sum, then each input's dz*xhat sum)
+  // block reduction over the row lanes, one quantity (dz sum, then each input's dz*xhat sum)
   // at a time through an 8 KB LDS buffer: the footprint does not grow with the number of
   // residual inputs, so the 12-input instantiation keeps its occupancy
-  const bool writer = rl == 0 && (blockIdx.y * G + g) < C8;
+  const bool writer = rl == 0 && cg < C8;
   auto reduce_q = [&](const float (&v)[8], int q) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = v[e];
@@ -428,52 +557,68 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ c1,
-    const float* __restrict__ c2, bf16_t* __restrict__ dy, long long rows, int C,
-    int rows_per_block) {
+    const float* __restrict__ c2, bf16_t* __restrict__ dy, const int32_t* __restrict__ out_len,
+    int margin, int B, int T, int C, int gmax, int trows) {
   const int C8 = C >> 3;
-  const int G = min(C8, 256);
-  const int RL = 256 / G;
-  const int g = threadIdx.x % G, rl = threadIdx.x / G;
-  const int cg = blockIdx.y * G + g;
-  if (cg >= C8 || rl >= RL) return;
+  const TileMap tm(C8, gmax);
+  if (!tm.cvalid) return;
+  const int rl = tm.rl, cg = tm.cg, RL = tm.RL;
   const int c0 = cg * 8;
   float A[8], Bq[8], Cc[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float rs = rstd[c0 + e];
-    const float gm = gamma ? gamma[c0 + e] : 1.f;
-    A[e] = gm * rs;
-    Bq[e] = -gm * rs * rs * c2[c0 + e];
-    Cc[e] = gm * rs * (mean[c0 + e] * rs * c2[c0 + e] - c1[c0 + e]);
-  }
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r1 = min(rows, r0 + rows_per_block);
-  auto one = [&](const u32x4& d, const u32x4& yv) {
-    u32x4 o;
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 rs4 = *reinterpret_cast<const f32x4*>(rstd + c0 + 4 * h);
+    const f32x4 me4 = *reinterpret_cast<const f32x4*>(mean + c0 + 4 * h);
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(c1 + c0 + 4 * h);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(c2 + c0 + 4 * h);
+    f32x4 gm4 = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) gm4 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4 * h);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = A[2 * e] * bflo(d[e]) + Bq[2 * e] * bflo(yv[e]) + Cc[2 * e];
-      const float hi = A[2 * e + 1] * bfhi(d[e]) + Bq[2 * e + 1] * bfhi(yv[e]) + Cc[2 * e + 1];
-      o[e] = pack2bf(lo, hi);
+      const float rs = rs4[e], gm = gm4[e];
+      A[4 * h + e] = gm * rs;
+      Bq[4 * h + e] = -gm * rs * rs * b4[e];
+      Cc[4 * h + e] = gm * rs * (me4[e] * rs * b4[e] - a4[e]);
     }
-    return o;
-  };
-  long long row = r0 + rl;
-  for (; row + 3LL * RL < r1; row += 4LL * RL) {
-    u32x4 d[4], yv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      d[u] = *reinterpret_cast<const u32x4*>(dz + (row + (long long)u * RL) * C + c0);
-      yv[u] = *reinterpret_cast<const u32x4*>(y + (row + (long long)u * RL) * C + c0);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      *reinterpret_cast<u32x4*>(dy + (row + (long long)u * RL) * C + c0) = one(d[u], yv[u]);
   }
-  for (; row < r1; row += RL) {
-    const u32x4 d = *reinterpret_cast<const u32x4*>(dz + row * C + c0);
-    const u32x4 yv = *reinterpret_cast<const u32x4*>(y + row * C + c0);
-    *reinterpret_cast<u32x4*>(dy + row * C + c0) = one(d, yv);
+  const long long rows = (long long)B * T;
+  const long long r0 = (long long)blockIdx.x * trows;
+  const long long r1 = min(rows, r0 + trows);
+  RowCursor cur;
+  if (r0 + rl < r1) cur.init(r0 + rl, T, out_len);
+  for (long long base = r0 + rl; base < r1; base += (long long)kTileU * RL) {
+    long long rw[kTileU];
+    bool ok[kTileU], lv[kTileU];
+    u32x4 d[kTileU], yv[kTileU];
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+      rw[u] = base + (long long)u * RL;
+      ok[u] = rw[u] < r1;
+      lv[u] = ok[u] && cur.t < cur.len + margin;
+      if (ok[u]) cur.advance(RL, rows);
+      if (lv[u]) {
+        d[u] = *reinterpret_cast<const u32x4*>(dz + rw[u] * C + c0);
+        yv[u] = *reinterpret_cast<const u32x4*>(y + rw[u] * C + c0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+      if (!ok[u]) continue;
+      // rows at or past out_len[b] + margin are written as zeros WITHOUT reading dz / y: the caller
+      // states with `margin` how far past the sequence end its consumers look (the data- and
+      // weight-gradient convolutions reach (K-1)*dilation rows into the padding; dy is NOT zero
+      // there: -gamma*rstd*(c1 + xhat*c2) flows back through the batch statistics)
+      u32x4 o = {0u, 0u, 0u, 0u};
+      if (lv[u]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = A[2 * e] * bflo(d[u][e]) + Bq[2 * e] * bflo(yv[u][e]) + Cc[2 * e];
+          const float hi = A[2 * e + 1] * bfhi(d[u][e]) + Bq[2 * e + 1] * bfhi(yv[u][e]) + Cc[2 * e + 1];
+          o[e] = pack2bf(lo, hi);
+        }
+      }
+      *reinterpret_cast<u32x4*>(dy + rw[u] * C + c0) = o;
+    }
   }
 }
 
@@ -542,15 +687,30 @@ extern "C" int os2s_bn_act_fwd(os2s_stream_t stream, int J, const uint16_t* cons
   }
   a.J = J; a.out = out; a.out_len = out_len; a.B = B; a.T = T; a.C = C; a.act = act;
   a.keep_prob = keep_prob; a.seed = seed;
-  const long long total = (long long)B * T * (C / 8);
-  OS2S_LAUNCH(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a);
+  const int gmax = g_tiling[0][0], trows = g_tiling[0][1];
+  dim3 grid(ceil_div((long long)B * T, trows), tile_cblocks(C / 8, gmax));
+  if (J == 1) {
+    OS2S_LAUNCH(bn_act_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, gmax, trows);
+  } else {
+    OS2S_LAUNCH(bn_act_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, gmax, trows);
+  }
   return OS2S_OK;
 }
 
-static const int kBwdRowsPerBlock = 64;
+
+
+// Benchmark / test hook: tiling of kernel `which` (0 bn_act_fwd, 1 bn_act_bwd_reduce, 2 bn_bwd_apply).
+// Not thread-safe; the reduce tiling also sets what os2s_bn_act_bwd_num_parts returns.
+extern "C" int os2s_bn_set_tiling(int which, int groups_per_block, int rows_per_block) {
+  OS2S_REQUIRE(which >= 0 && which < 3 && groups_per_block >= 8 && groups_per_block <= 256);
+  OS2S_REQUIRE(rows_per_block >= 8 && rows_per_block <= 1024);
+  g_tiling[which][0] = groups_per_block;
+  g_tiling[which][1] = rows_per_block;
+  return OS2S_OK;
+}
 
 extern "C" int os2s_bn_act_bwd_num_parts(long long rows) {
-  return ceil_div(rows, kBwdRowsPerBlock);
+  return ceil_div(rows, g_tiling[1][1]);
 }
 
 extern "C" int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_t* dout,
@@ -569,18 +729,18 @@ extern "C" int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_
   }
   a.dout = dout; a.out = out; a.J = J; a.dz = dz; a.partial = partial; a.out_len = out_len;
   a.B = B; a.T = T; a.C = C; a.act = act; a.keep_prob = keep_prob; a.seed = seed;
-  a.rows_per_block = kBwdRowsPerBlock;
+  a.rows_per_block = g_tiling[1][1];
   const int C8 = C / 8;
-  const int G = C8 < 256 ? C8 : 256;
-  dim3 grid(ceil_div((long long)B * T, kBwdRowsPerBlock), ceil_div(C8, G));
+  const int gmax = g_tiling[1][0];
+  dim3 grid(ceil_div((long long)B * T, a.rows_per_block), tile_cblocks(C8, gmax));
   const size_t smem = 0;
   if (J <= 1) {
-    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, a, gmax);
   } else if (J <= 4) {
-    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a, gmax);
   } else {
     OS2S_LAUNCH(bn_act_bwd_reduce_kernel<kMaxBnInputs>, grid, dim3(256), smem,
-                (hipStream_t)stream, a);
+                (hipStream_t)stream, a, gmax);
   }
   return OS2S_OK;
 }
@@ -608,19 +768,35 @@ extern "C" int os2s_bn_bwd_finalize_multi(os2s_stream_t stream, const float* par
   return OS2S_OK;
 }
 
+static int bn_bwd_apply_launch(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                               const float* gamma, const float* mean, const float* rstd,
+                               const float* c1, const float* c2, uint16_t* dy,
+                               const int32_t* out_len, int margin, int B, int T, int C) {
+  const int gmax = g_tiling[2][0], trows = g_tiling[2][1];
+  dim3 grid(ceil_div((long long)B * T, trows), tile_cblocks(C / 8, gmax));
+  OS2S_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, y, gamma, mean,
+              rstd, c1, c2, dy, out_len, margin, B, T, C, gmax, trows);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_bn_bwd_apply_ragged(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                                        const float* gamma, const float* mean, const float* rstd,
+                                        const float* c1, const float* c2, uint16_t* dy,
+                                        const int32_t* out_len, int margin, int B, int T, int C) {
+  OS2S_REQUIRE(dz && y && mean && rstd && c1 && c2 && dy && C % 8 == 0 && B >= 0 && T >= 0);
+  OS2S_REQUIRE(margin >= 0);
+  if ((long long)B * T == 0) return OS2S_OK;
+  return bn_bwd_apply_launch(stream, dz, y, gamma, mean, rstd, c1, c2, dy, out_len, margin, B, T, C);
+}
+
 extern "C" int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
                                  const float* gamma, const float* mean, const float* rstd,
                                  const float* c1, const float* c2, uint16_t* dy,
                                  long long rows, int C) {
   OS2S_REQUIRE(dz && y && mean && rstd && c1 && c2 && dy && C % 8 == 0);
+  OS2S_REQUIRE(rows >= 0 && rows < (1LL << 31));
   if (rows == 0) return OS2S_OK;
-  const int C8 = C / 8;
-  const int G = C8 < 256 ? C8 : 256;
-  const int rpb = 64;
-  dim3 grid(ceil_div(rows, rpb), ceil_div(C8, G));
-  OS2S_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, y, gamma, mean,
-              rstd, c1, c2, dy, rows, C, rpb);
-  return OS2S_OK;
+  return bn_bwd_apply_launch(stream, dz, y, gamma, mean, rstd, c1, c2, dy, nullptr, 0, 1, (int)rows, C);
 }
 
 extern "C" int os2s_dropout_mask(os2s_stream_t stream, unsigned long long seed,

@@ -436,7 +436,11 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     grouped = []        # plain 1x1 residual branches: their data gradients go out in one launch
     for j, (br, inp, f) in enumerate(zip(branches, inputs, fw)):
       dy = torch.empty_like(f["y"])
-      capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1[j], c2[j], dy)
+      # a plain convolution's gradients read dy at most (K-1)*dilation rows past the sequence end
+      # (wgrad pairs it with the masked input, dgrad only produces live rows): the rest is not computed
+      ragged = lens is not None and type(br) is ConvBN and br.stride == 1
+      capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1[j], c2[j], dy,
+                        out_len=lens if ragged else None, margin=(br.k - 1) * br.dil)
       f["y"] = None
       if j > 0 and _is_plain_1x1(br) and len(branches) > 2:
         br.backward_weights(inp, dy, f)

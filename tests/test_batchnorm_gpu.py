@@ -21,6 +21,8 @@ def _bf(x):
     (2, 33, 768, 11, "relu", 0.7),
     (2, 40, 512, 1, "tanh", 0.5),
     (1, 9, 64, 2, "none", 1.0),
+    (5, 150, 640, 2, "relu", 0.8),      # row tiles straddle utterances, partial channel block
+    (3, 201, 896, 1, "relu", 0.9),
 ])
 def test_bn_act_fwd_bwd(cuda, B, T, C, J, act, keep):
   from openseq2seq_amd import capi
@@ -90,6 +92,16 @@ def test_bn_act_fwd_bwd(cuda, B, T, C, J, act, keep):
     torch.testing.assert_close(dgam.cpu(), g32[j].grad, rtol=2e-2, atol=2e-2 * ggs)
     bgs = float(b32[j].grad.abs().mean()) + 1e-6
     torch.testing.assert_close(dbet.cpu(), b32[j].grad, rtol=2e-2, atol=2e-2 * bgs)
+    # ragged variant: bit-identical on rows t < len + margin, zeros (unread) beyond
+    margin = 5
+    dyr = torch.full((B, T, C), 7.0, dtype=torch.bfloat16, device=d)
+    capi.bn_bwd_apply(dz, ysd[j], gammas[j].to(d), means[j], rstds[j], c1, c2, dyr,
+                      out_len=lens.to(d), margin=margin)
+    torch.cuda.synchronize()
+    t_idx = torch.arange(T)[None, :, None]
+    keep_rows = (t_idx < (lens[:, None, None] + margin)).expand(B, T, C)
+    want = torch.where(keep_rows, dy.cpu().float(), torch.zeros(()))
+    assert torch.equal(dyr.cpu().float(), want)
 
 
 def test_bn_eval_mode(cuda):
