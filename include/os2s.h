@@ -135,6 +135,11 @@ int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
  * double-buffered; 3 = 128x128, X window single-buffered when K >= 8 (3 workgroups per CU);
  * 5 = 256x256 lockstep tile; 10 = ping-pong kernel (256x256, balanced over live windows) */
 void os2s_conv1d_set_variant(int v);
+/* experiment / test hook for the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers):
+ * 0 (default) and 1 = lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows
+ * whenever its envelope allows (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as
+ * a measured alternative */
+void os2s_conv1x1_set_variant(int v);
 /* experiment hook: f > 0 forces the tail split factor of the ping-pong kernel (-1 = cost model) */
 void os2s_conv1d_set_split(int f);
 /* experiment hook (tools/pp_timeline.py): per-slot time stamps of the ping-pong kernel */

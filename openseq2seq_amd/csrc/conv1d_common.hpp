@@ -37,6 +37,24 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Group table of the grouped 1x1 launches (conv1d_igemm_grouped_kernel, conv1x1_pp_kernel): every
+// group has its own input, weights, output, BatchNorm partials and channel counts; tile_begin =
+// first workgroup (igemm) / sum of the previous groups' 256-column tiles (ping-pong kernel).
+constexpr int kMaxConvGroups = 16;
+struct ConvGroup {
+  const bf16_t* x;
+  const bf16_t* w;
+  void* y;
+  float* stats;
+  int Cin, Cout, accumulate, tile_begin;
+};
+struct ConvGroupTable {
+  int ngroups, total_tiles;
+  ConvGroup g[kMaxConvGroups];
+};
+// gemm_pp.hip: the groups on the 256 x 256 ping-pong tile (OS2S_ERR_UNSUPPORTED outside its envelope)
+int launch_conv1x1_pp(hipStream_t stream, ConvArgs a, ConvGroupTable gt);
+
 // Epilogue shared by the tile kernels: fused bias / ReLU / dropout / residual, bf16 pack, LDS
 // transpose to full 16-B row stores, per-channel (sum, sum^2) partials for BatchNorm.
 template <int BM, int BN, int WM, int WN, int NWIN>

@@ -212,18 +212,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN <= 4) ? (XSINGLE ? 3 : 2) : 1
 // dense-residual 1x1 branches of a Jasper block end (conv_blocks.py:78-85: up to 10 per block,
 // 55 per pass) and their data gradients. Each is a few microseconds of matrix work; launched
 // one by one they cost ~45 us apiece.
-constexpr int kMaxConvGroups = 16;
-struct ConvGroup {
-  const bf16_t* x;
-  const bf16_t* w;
-  void* y;
-  float* stats;
-  int Cin, Cout, accumulate, tile_begin;
-};
-struct ConvGroupTable {
-  int ngroups, total_tiles;
-  ConvGroup g[kMaxConvGroups];
-};
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv1d_igemm_grouped_kernel(ConvArgs p, ConvGroupTable gt) {
@@ -739,6 +727,9 @@ extern "C" void os2s_conv1d_set_debug(void* stamps, int fixed_w) {
   g_conv_fixed_w = fixed_w;
 }
 
+static int g_conv1x1_variant = 0;
+extern "C" void os2s_conv1x1_set_variant(int v) { g_conv1x1_variant = v; }
+
 extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
   return B * os2s::ceil_div(Tout, os2s::kConvBM);
 }
@@ -782,6 +773,17 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
     if (Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;
     if (Cout >= 448) v = 10;
   }
+  if ((v == 10 || v == 11) && K == 1 && g_conv1x1_variant == 2 && residual == nullptr && Cout >= 256 &&
+      y_stride_t == Cout && y_stride_b == (long long)Tout * Cout) {
+    // a wide 1x1 layer is the one-group case of the grouped ping-pong launch
+    ConvGroupTable gt;
+    gt.ngroups = 1;
+    gt.g[0].x = x; gt.g[0].w = w; gt.g[0].y = y; gt.g[0].stats = stats;
+    gt.g[0].Cin = Cin; gt.g[0].Cout = Cout; gt.g[0].accumulate = accumulate ? 1 : 0; gt.g[0].tile_begin = 0;
+    const int rc = launch_conv1x1_pp(st, a, gt);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  }
+  if (v == 11) v = 10;
   if (v == 10) {
     // the dense-residual / accumulate epilogue variants are all supported by the ping-pong kernel
     const int rc = launch_conv_pp(st, a, workspace, workspace_bytes);
@@ -851,7 +853,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   a.x_sb = 0; a.x_st = 0; a.y_sb = 0; a.y_st = 0;
   a.out_f32 = 0; a.accumulate = 0; a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
-  a.dbg = nullptr; a.dbg_fixed_w = 0;
+  a.dbg = g_conv_dbg; a.dbg_fixed_w = 0;     // experiment hook (conv1x1_pp_kernel phase stamps)
   a.mtiles_per_b = ceil_div(T, BM);
   a.MT = B * a.mtiles_per_b;
   a.MT8 = ceil_div(a.MT, 8);
@@ -870,6 +872,14 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   }
   for (int i = ngroups; i < kMaxConvGroups; ++i) gt.g[i] = gt.g[0];
   gt.total_tiles = tiles;
+  // The 256 x 256 ping-pong tile (conv1x1_pp_kernel) is available behind os2s_conv1x1_set_variant(2)
+  // only: a 1x1 unit is 4-12 steps of matrix work followed by 128 KB of output, one workgroup per CU
+  // cannot overlap the two (measured: epilogue 25 us of a 40 us unit; Jasper step +1 ms), while two
+  // or three lockstep workgroups per CU do.
+  if (g_conv1x1_variant == 2) {
+    const int rc = launch_conv1x1_pp((hipStream_t)stream, a, gt);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  }
   const size_t main_bytes = (size_t)2 * a.Rpad * 128 + (size_t)2 * BN * 128;
   constexpr size_t kOP = BN * 2 + 16;
   const size_t epi_bytes = (size_t)BM * kOP + (size_t)4 * BN * 2 * 4;

@@ -38,45 +38,31 @@ __device__ __forceinline__ void gpp_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// ConvArgs is used as the argument block so that the fused epilogue is literally the convolution's:
-// B = 1, Tout = M rows, Cin = K, Cout = N, x = A (row stride x_st), w = W [N, K] contiguous.
-// MT = number of 128-row windows, MT8 = 256-row blocks per XCD, NT = 256-column tiles.
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
+// One 256 x 256 tile: main loop + the convolution's fused epilogue. a_half / a_bytes describe the
+// 128 rows this wave's GROUP owns (first row, bytes that may be read from there: rows past it are
+// out of the descriptor's range and read as zeros); everything else comes from p: x_st = row
+// stride of A, Cin = reduction length (multiple of 64, nchunks = Cin / 64), w = W [Cout, Cin].
+__device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half, long long a_bytes, int n0,
+                                         const int (&wb)[2], const int (&wt0)[2], const int (&wmid)[2],
+                                         char* smem, unsigned long long* stamps = nullptr) {
   constexpr int BM = 128, BN = 256, NWIN = 2, WM = 2, WN = 4;
   constexpr int MI = 4, NI = 2;
   constexpr int TILE = 256 * 128;                        // one operand tile: 256 rows x 64 k (bf16)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2, wn = wid & 3;
-
-  // ---- block -> (256-row block, n-tile): per XCD, groups of gm row blocks sweep the n-tiles
-  // together (rows of A stay in that L2, every weight panel is shared by gm workgroups) ---------
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, loc = bid >> 3;
-  const int mg = loc / (p.NT * gm), rr = loc - mg * (p.NT * gm);
-  const int n_idx = rr / gm, mi = rr - n_idx * gm;
-  const int m_blk = (mg * gm + mi) * 8 + xcd;
-  const int m_first = m_blk * NWIN;
-  if (m_first >= p.MT) return;
-  const int n0 = n_idx * BN;
-  int wb[NWIN], wt0[NWIN], wmid[NWIN];
-#pragma unroll
-  for (int w = 0; w < NWIN; ++w) {
-    wb[w] = 0;
-    wt0[w] = (m_first + w) * BM;
-    wmid[w] = (m_first + w < p.MT) ? m_first + w : -1;
-  }
-
   char* const abuf0 = smem;                              // A tiles: ring of 3 x 32 KB
   char* const wbuf0 = smem + 3 * TILE;                   // W tiles: ring of 2 x 32 KB
-  // LDS-DMA through buffer descriptors: rows past M / N are out of range of the descriptor and
-  // read as zeros; the k position of the tile sits in the scalar offset
-  const int m0 = m_first * BM + grp * BM;                // first row of this group's half
-  const long long a_bytes = (long long)(p.Tout - m0) * p.x_st * 2;
-  const unsigned long long ab = (unsigned long long)p.x + (unsigned long long)m0 * (unsigned long long)p.x_st * 2ull;
-  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)ab, 0, (int)(a_bytes < 0 ? 0 : (a_bytes < 0x7fffffffll ? a_bytes : 0x7fffffffll)), 0x00020000);
+  // LDS-DMA through buffer descriptors: rows past the end of A / W are out of range of the
+  // descriptor and read as zeros; the k position of the tile sits in the scalar offset
+  __amdgpu_buffer_rsrc_t ars;
+  {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)a_half);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)a_half >> 32));
+    const long long cl = a_bytes < 0 ? 0 : (a_bytes < 0x7fffffffll ? a_bytes : 0x7fffffffll);
+    const int bytes = __builtin_amdgcn_readfirstlane((int)cl);
+    ars = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+  }
   const long long w_bytes = (long long)(p.Cout - n0) * p.Cin * 2;
   const unsigned long long wbs = (unsigned long long)p.w + (unsigned long long)n0 * (unsigned long long)p.Cin * 2ull;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -131,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
     if (nsteps > 1) { stage_a(1, 1); stage_w(1, 1); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (stamps && tid == 0) stamps[2] = __builtin_readcyclecounter();
     if (grp) gpp_barrier();                              // group B runs one slot behind group A
 
     int ai = 0;                                          // ring slot of the current A tile
@@ -200,7 +187,189 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
     if (!grp) gpp_barrier();
   }
   __syncthreads();
+  if (stamps && tid == 0) stamps[3] = __builtin_readcyclecounter();
   conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
+  if (stamps) {
+    __syncthreads();
+    if (tid == 0) stamps[4] = __builtin_readcyclecounter();
+  }
+}
+
+// ConvArgs is used as the argument block so that the fused epilogue is literally the convolution's:
+// B = 1, Tout = M rows, Cin = K, Cout = N, x = A (row stride x_st), w = W [N, K] contiguous.
+// MT = number of 128-row windows, MT8 = 256-row blocks per XCD, NT = 256-column tiles.
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
+  constexpr int BM = 128, BN = 256, NWIN = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid >> 2;
+  // ---- block -> (256-row block, n-tile): per XCD, groups of gm row blocks sweep the n-tiles
+  // together (rows of A stay in that L2, every weight panel is shared by gm workgroups) ---------
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int mg = loc / (p.NT * gm), rr = loc - mg * (p.NT * gm);
+  const int n_idx = rr / gm, mi = rr - n_idx * gm;
+  const int m_blk = (mg * gm + mi) * 8 + xcd;
+  const int m_first = m_blk * NWIN;
+  if (m_first >= p.MT) return;
+  const int n0 = n_idx * BN;
+  int wb[NWIN], wt0[NWIN], wmid[NWIN];
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) {
+    wb[w] = 0;
+    wt0[w] = (m_first + w) * BM;
+    wmid[w] = (m_first + w < p.MT) ? m_first + w : -1;
+  }
+  const int m0 = m_first * BM + grp * BM;                // first row of this group's half
+  gpp_tile(p, p.x + (long long)m0 * p.x_st, (long long)(p.Tout - m0) * p.x_st * 2, n0, wb, wt0, wmid, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolutions of a ragged batch on the same tile: up to kMaxConvGroups independent
+// convolutions with the same batch geometry and lengths (the dense-residual branches of a Jasper
+// block end and their data gradients, conv_blocks.py:78-85; a single group = a plain K = 1 layer)
+// in ONE grid. A 128-row half of a tile is a LIVE window (b, t0) of the batch: the windows with
+// at least one real row are enumerated on the device from in_len / out_len (one wave scan,
+// B <= 64) and paired over the compacted list, exactly as in conv1d_pp_kernel; rows at or past
+// in_len[b] are outside the group's descriptor and read as zeros. Dead windows of a forward call
+// get their zero rows / zero BatchNorm partials from store-only workgroups at the end of the grid.
+// Unit = (group, window pair, 256-column tile); units of one pair sit on one XCD (its rows are
+// fetched into one L2), consecutive workgroups hold different pairs.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGppZeroWin = 2;
+
+__global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(ConvArgs p, ConvGroupTable gt) {
+  constexpr int BM = 128, BN = 256, NWIN = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;
+  // experiment hook: phase time stamps of the first 2048 work units (8 x uint64 each: entry,
+  // unit decoded, pipeline filled, main loop done, epilogue done, steps)
+  unsigned long long* const stamps = (p.dbg && blockIdx.x < 2048) ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
+  if (stamps && tid == 0) stamps[0] = __builtin_readcyclecounter();
+  // ---- live windows per sample, inclusive scan over the batch (one value per lane) ----------
+  int nw = 0;
+  if (lane < p.B) {
+    int len = p.Tin;
+    if (p.in_len) { const int l = p.in_len[lane]; len = l < 0 ? 0 : (l < len ? l : len); }
+    if (p.out_len) { const int l = p.out_len[lane]; len = l < 0 ? 0 : (l < len ? l : len); }
+    nw = (len + BM - 1) / BM;
+    nw = nw < p.mtiles_per_b ? nw : p.mtiles_per_b;
+  }
+  int scan = nw;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(scan, o, 64);
+    if (lane >= o) scan += t;
+  }
+  const int L = __builtin_amdgcn_readlane(scan, 63);
+  const int P = (L + 1) >> 1;
+  const int nwork = P * gt.total_tiles;                  // total_tiles = sum of the groups' n-tiles
+  const int bid = blockIdx.x;
+
+  if (bid >= nwork) {
+    // ---- store-only role (forward calls): zero rows + zero BN partials of the dead windows ----
+    const int z = (int)gridDim.x - 1 - bid;
+    const int zper = (p.MT + kGppZeroWin - 1) / kGppZeroWin;
+    if (p.out_len || z >= zper * gt.ngroups) return;
+    const int gi = z / zper, zb = z - gi * zper;
+    ConvGroup g = gt.g[0];
+#pragma unroll
+    for (int i = 1; i < kMaxConvGroups; ++i)
+      if (i == gi) g = gt.g[i];
+    for (int m = zb * kGppZeroWin; m < (zb + 1) * kGppZeroWin && m < p.MT; ++m) {
+      const int b = m / p.mtiles_per_b, j = m - b * p.mtiles_per_b;
+      if (j < __shfl(nw, b, 64)) continue;
+      const int t0 = j * BM, rows = min(BM, p.Tout - t0);
+      if (!g.accumulate) {
+        bf16_t* const yb = reinterpret_cast<bf16_t*>(g.y) + ((long long)b * p.Tout + t0) * g.Cout;
+        const u32x4 zv = {0u, 0u, 0u, 0u};
+        for (int e = tid; e < rows * (g.Cout >> 3); e += 512) *reinterpret_cast<u32x4*>(yb + (long long)e * 8) = zv;
+      }
+      if (g.stats)
+        for (int e = tid; e < 2 * g.Cout; e += 512) g.stats[(long long)m * 2 * g.Cout + e] = 0.f;
+    }
+    return;
+  }
+
+  // ---- work role: bid -> (group, unit rank inside the group) -> (window pair, n-tile) ---------
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxConvGroups; ++i)
+    if (i < gt.ngroups && bid >= gt.g[i].tile_begin * P) gi = i;
+  ConvGroup g = gt.g[0];
+#pragma unroll
+  for (int i = 1; i < kMaxConvGroups; ++i)
+    if (i == gi) g = gt.g[i];
+  p.x = g.x; p.w = g.w; p.y = g.y; p.stats = g.stats;
+  p.Cin = g.Cin; p.Cout = g.Cout; p.accumulate = g.accumulate;
+  p.x_sb = (long long)p.Tin * g.Cin; p.x_st = g.Cin;
+  p.y_sb = (long long)p.Tout * g.Cout; p.y_st = g.Cout;
+  p.NT = (g.Cout + BN - 1) / BN;
+  p.nchunks = g.Cin / 64;
+  const int rank = bid - g.tile_begin * P;
+  int xcd, loc;
+  {
+    const int P8 = (P + 7) >> 3, rem = P - 8 * (P8 - 1), base = (P8 - 1) * p.NT * 8;
+    if (rank < base) { xcd = rank & 7; loc = rank >> 3; }
+    else { const int i = rank - base; loc = (P8 - 1) * p.NT + i / rem; xcd = i - (i / rem) * rem; }
+  }
+  const int pair = (loc / p.NT) * 8 + xcd;
+  const int n_idx = loc - (loc / p.NT) * p.NT;
+  int wb[NWIN], wt0[NWIN], wlen[NWIN], wmid[NWIN];
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) {
+    const int i = 2 * pair + w;
+    const bool live = i < L;
+    const int b = live ? __builtin_popcountll(__ballot(scan <= i)) : 0;
+    const int before = b > 0 ? __shfl(scan, b - 1, 64) : 0;
+    wb[w] = b;
+    wt0[w] = live ? (i - before) * BM : 0;
+    int len_b = p.Tin;
+    if (p.in_len) {
+      const int l = p.in_len[b];
+      len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+    }
+    wlen[w] = live ? len_b : 0;                          // dead slot: every row reads as zero
+    wmid[w] = live ? b * p.mtiles_per_b + (i - before) : -1;
+  }
+  const int b_own = grp ? wb[1] : wb[0], t_own = grp ? wt0[1] : wt0[0], len_own = grp ? wlen[1] : wlen[0];
+  if (stamps && tid == 0) { stamps[1] = __builtin_readcyclecounter(); stamps[5] = (unsigned long long)p.nchunks; }
+  gpp_tile(p, p.x + (long long)b_own * p.x_sb + (long long)t_own * p.x_st,
+           (long long)(len_own - t_own) * p.x_st * 2, n_idx * BN, wb, wt0, wmid, smem, stamps);
+}
+
+// Host side of conv1x1_pp_kernel. `a` carries the batch geometry (B, Tin = Tout = T, in_len, out_len)
+// and the epilogue switches shared by all groups; groups[i].tile_begin is filled here.
+int launch_conv1x1_pp(hipStream_t stream, ConvArgs a, ConvGroupTable gt) {
+  if (a.B > 64 || a.K != 1 || a.stride != 1 || a.padL != 0 || a.Tin != a.Tout || a.out_f32)
+    return OS2S_ERR_UNSUPPORTED;
+  int nt = 0;
+  for (int i = 0; i < gt.ngroups; ++i) {
+    const ConvGroup& g = gt.g[i];
+    if (g.Cin % 64 != 0 || g.Cin < 64 || g.Cout % 8 != 0) return OS2S_ERR_UNSUPPORTED;
+    if ((long long)g.Cin * 2 * 256 >= (1ll << 31)) return OS2S_ERR_UNSUPPORTED;
+    gt.g[i].tile_begin = nt;
+    nt += ceil_div(g.Cout, 256);
+  }
+  for (int i = gt.ngroups; i < kMaxConvGroups; ++i) gt.g[i] = gt.g[0];
+  gt.total_tiles = nt;
+  a.mtiles_per_b = ceil_div(a.Tout, 128);
+  a.MT = a.B * a.mtiles_per_b;
+  a.R = 128; a.Rpad = 128;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1x1_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  const int pmax = ceil_div(a.MT, 2);
+  const int nzero = a.out_len ? 0 : ceil_div(a.MT, kGppZeroWin) * gt.ngroups;
+  const size_t smem = (size_t)5 * 256 * 128;            // A ring of 3 + W ring of 2 (> epilogue staging)
+  OS2S_LAUNCH(conv1x1_pp_kernel, dim3(pmax * nt + nzero), dim3(512), smem, stream, a, gt);
+  return OS2S_OK;
 }
 
 }  // namespace os2s
