@@ -1,6 +1,8 @@
 // Shared by the implicit-GEMM convolution kernels (conv1d_igemm.hip) and the plain GEMM
 // (gemm_pp.hip): kernel argument block, LDS-DMA helper and the fused epilogue.
 #pragma once
+#include <type_traits>
+
 #include "os2s_common.hpp"
 
 namespace os2s {
@@ -35,6 +37,17 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)gsrc,
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// The out tile of all NWIN windows is staged through LDS in one pass when it fits next to the
+// BatchNorm scratch (the 256 x 256 tiles: 135 KB + 16 KB of the 160 KB), else window by window.
+constexpr size_t kEpiSplitBytes = 140 * 1024;
+template <int BM, int BN, int NWIN, int NTHR>
+constexpr size_t conv_epilogue_lds_bytes() {
+  constexpr size_t OP = BN * 2 + 16;
+  constexpr int EW = (NWIN * BM * OP > kEpiSplitBytes) ? 1 : NWIN;
+  constexpr int RG = (NTHR / (BN / 2)) > 0 ? (NTHR / (BN / 2)) : 1;
+  return (size_t)EW * BM * OP + (size_t)EW * RG * BN * 2 * 4;
 }
 
 // Group table of the grouped 1x1 launches (conv1d_igemm_grouped_kernel, conv1x1_pp_kernel): every
@@ -98,16 +111,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     return;
   }
 
+#ifdef OS2S_EPI_STAMPS   // development aid: cycle stamps of the epilogue phases (tools/conv1x1_phases.py)
+  unsigned long long* const est = (p.dbg && blockIdx.x < 2048) ? p.dbg + (size_t)blockIdx.x * 24 + 8 : nullptr;
+  int esi = 0;
+#define OS2S_EPI_STAMP() do { if (est && tid == 0 && esi < 16) est[esi] = __builtin_readcyclecounter(); ++esi; } while (0)
+#else
+#define OS2S_EPI_STAMP() do {} while (0)
+#endif
   constexpr int OP = BN * 2 + 16;  // out-tile pitch in bytes
   // The out tile is staged through LDS (coalesced 16-B row stores + the BN partial sums). Wide
   // tiles do not fit all windows at once: stage EW windows per pass.
-  constexpr bool EPI_SPLIT = (size_t)NWIN * BM * OP > 112 * 1024;
+  constexpr bool EPI_SPLIT = (size_t)NWIN * BM * OP > kEpiSplitBytes;
   constexpr int EW = EPI_SPLIT ? 1 : NWIN;
   char* const ot = smem;
 #pragma unroll
   for (int w0 = 0; w0 < NWIN; w0 += EW) {
+  OS2S_EPI_STAMP();
   __syncthreads();                 // staging buffers / previous pass are no longer read
-  if (my_win >= w0 && my_win < w0 + EW) {
+  OS2S_EPI_STAMP();
+  // accumulators -> bf16 out tile in LDS. The dropout variant is a separate instantiation behind a
+  // UNIFORM branch: written as `if (p.keep_prob < 1.f)` inside the loop the compiler if-converts
+  // it and evaluates the 64-bit hash of dropout_bits8 for every 4 values even when nothing is
+  // dropped (measured: 26k of the 54k cycles of a 256 x 256 epilogue, ~12 us per staging pass).
+  auto stage_tile = [&](auto DROP) {
+  unsigned long long seed = p.seed;
+  // the hash must not be speculated above the uniform branch either (it is pure arithmetic, LLVM
+  // hoists it): tie it to a volatile asm that only executes on the dropout path
+  if constexpr (decltype(DROP)::value) asm volatile("" : "+s"(seed));
 #pragma unroll
   for (int in = 0; in < NI; ++in)
 #pragma unroll
@@ -128,10 +158,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
         if (p.act == 1) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         }
-        if (p.keep_prob < 1.f) {
+        if constexpr (decltype(DROP)::value) {
           // same (seed, element index / 8) convention as the elementwise kernels
           const long long e0 = ((long long)b * p.Tout + t0 + tt) * p.Cout + n0 + cc;
-          const uint32_t bits = dropout_bits8(p.seed, (unsigned long long)(e0 >> 3), p.keep_prob) >>
+          const uint32_t bits = dropout_bits8(seed, (unsigned long long)(e0 >> 3), p.keep_prob) >>
                                 (uint32_t)(e0 & 7);
           const float ik = 1.f / p.keep_prob;
           v0 = (bits & 1u) ? v0 * ik : 0.f;
@@ -145,8 +175,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
         *reinterpret_cast<u32x2*>(ot + tt * OP + cc * 2) = pk;
       }
     }
+  };
+  if (my_win >= w0 && my_win < w0 + EW) {
+    if (__builtin_amdgcn_readfirstlane(p.keep_prob < 1.f ? 1 : 0)) stage_tile(std::true_type{});
+    else stage_tile(std::false_type{});
   }
+  OS2S_EPI_STAMP();
   __syncthreads();
+  OS2S_EPI_STAMP();
 
 #pragma unroll
   for (int w = w0; w < w0 + EW; ++w) {
@@ -154,70 +190,98 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
   const int valid_rows = (wmid[w] >= 0) ? min(BM, p.Tout - t0) : 0;
   const char* const otw = ot + (w - w0) * BM * OP;
   bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
-  for (int q = tid; q < BM * (BN / 8); q += NTHR) {
+  constexpr int NQ = (BM * (BN / 8) + NTHR - 1) / NTHR;     // 16-B chunks per thread
+  // all LDS reads of the thread first, then its global stores: written as one loop the stores
+  // wait for their ds_read one by one
+  u32x4 v[NQ];
+  bool ok[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + i * NTHR;
+    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+    ok[i] = q < BM * (BN / 8) && row < valid_rows && n0 + c8 * 8 < p.Cout;
+    if (ok[i]) v[i] = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = tid + i * NTHR;
     const int row = q / (BN / 8), c8 = q - row * (BN / 8);
     const int gc = n0 + c8 * 8;
-    if (row < valid_rows && gc < p.Cout) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
+    if (ok[i]) {
       bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
       if (p.residual) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(
             p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+          v[i][e] = pack2bf(bflo(v[i][e]) + bflo(o[e]), bfhi(v[i][e]) + bfhi(o[e]));
       }
       if (p.accumulate) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[e] = pack2bf(bflo(v[e]) + bflo(o[e]), bfhi(v[e]) + bfhi(o[e]));
+          v[i][e] = pack2bf(bflo(v[i][e]) + bflo(o[e]), bfhi(v[i][e]) + bfhi(o[e]));
       }
-      *reinterpret_cast<u32x4*>(dst) = v;
+      *reinterpret_cast<u32x4*>(dst) = v[i];
     }
   }
   }
 
+  OS2S_EPI_STAMP();
   if (p.stats) {
     constexpr int CP = BN / 2;       // column pairs
     constexpr int RG = (NTHR / CP) > 0 ? (NTHR / CP) : 1;    // row groups
+    constexpr int RPT = (BM + RG - 1) / RG;                  // rows per thread
     const int cp = tid % CP, rg = tid / CP;
+    // every window of the pass has its own scratch [RG][BN][2]: one barrier for all of them
 #pragma unroll
     for (int w = w0; w < w0 + EW; ++w) {
-    if (wmid[w] < 0) break;
-    const int m_idx = wmid[w];
-    const int valid_rows = min(BM, p.Tout - wt0[w]);
-    const char* const otw = ot + (w - w0) * BM * OP;
-    if (w > w0) __syncthreads();      // scratch re-use between windows
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    if (rg < RG)
-    for (int row = rg; row < valid_rows; row += RG) {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4);
-      const float a = bflo(v), bb = bfhi(v);
-      s0 += a; q0 += a * a;
-      s1 += bb; q1 += bb * bb;
-    }
-    float* sc = reinterpret_cast<float*>(smem + EW * BM * OP);  // [RG][BN][2]
-    if (rg < RG) {
-    sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
-    sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
-    sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
-    sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float s = 0.f, qq = 0.f;
+      if (wmid[w] < 0) continue;
+      const int valid_rows = min(BM, p.Tout - wt0[w]);
+      const char* const otw = ot + (w - w0) * BM * OP;
+      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+      if (rg < RG) {
+        // constant trip count + predicate: the LDS reads issue back to back (a `row < valid_rows`
+        // loop bound made every read wait for the previous one)
+        uint32_t vv[RPT];
 #pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        s += sc[(g * BN + tid) * 2 + 0];
-        qq += sc[(g * BN + tid) * 2 + 1];
-      }
-      const int gc = n0 + tid;
-      if (gc < p.Cout) {
-        p.stats[((long long)m_idx * 2 + 0) * p.Cout + gc] = s;
-        p.stats[((long long)m_idx * 2 + 1) * p.Cout + gc] = qq;
+        for (int i = 0; i < RPT; ++i) {
+          const int row = rg + i * RG;
+          vv[i] = row < valid_rows ? *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const float a = bflo(vv[i]), bb = bfhi(vv[i]);
+          s0 += a; q0 += a * a;
+          s1 += bb; q1 += bb * bb;
+        }
+        float* sc = reinterpret_cast<float*>(smem + EW * BM * OP) + (size_t)(w - w0) * RG * BN * 2;
+        sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;
+        sc[(rg * BN + cp * 2 + 0) * 2 + 1] = q0;
+        sc[(rg * BN + cp * 2 + 1) * 2 + 0] = s1;
+        sc[(rg * BN + cp * 2 + 1) * 2 + 1] = q1;
       }
     }
+    OS2S_EPI_STAMP();
+    __syncthreads();
+    OS2S_EPI_STAMP();
+#pragma unroll
+    for (int w = w0; w < w0 + EW; ++w) {
+      if (wmid[w] < 0) continue;
+      const float* sc = reinterpret_cast<const float*>(smem + EW * BM * OP) + (size_t)(w - w0) * RG * BN * 2;
+      for (int c = tid; c < BN; c += NTHR) {
+        float s = 0.f, qq = 0.f;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          s += sc[(g * BN + c) * 2 + 0];
+          qq += sc[(g * BN + c) * 2 + 1];
+        }
+        const int gc = n0 + c;
+        if (gc < p.Cout) {
+          p.stats[((long long)wmid[w] * 2 + 0) * p.Cout + gc] = s;
+          p.stats[((long long)wmid[w] * 2 + 1) * p.Cout + gc] = qq;
+        }
+      }
     }
   }
   }

@@ -621,10 +621,7 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
   a.R = (BM - 1) * a.stride + (a.K - 1) * a.dil + 1;
   a.Rpad = ceil_div(a.R, 8) * 8;
   size_t main_bytes = (size_t)(XSINGLE ? 1 : 2) * NWIN * a.Rpad * 128 + (size_t)2 * BN * 128;
-  constexpr size_t kOP = BN * 2 + 16;
-  constexpr int kEW = ((size_t)NWIN * BM * kOP > 112 * 1024) ? 1 : NWIN;
-  constexpr int kRG = (NTHR / (BN / 2)) > 0 ? (NTHR / (BN / 2)) : 1;
-  size_t epi_bytes = (size_t)kEW * BM * kOP + (size_t)kRG * BN * 2 * 4;
+  size_t epi_bytes = conv_epilogue_lds_bytes<BM, BN, NWIN, NTHR>();
   size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static std::once_flag once;
@@ -659,9 +656,7 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   const bool dbg = a.dbg != nullptr || a.dbg_fixed_w;
   const size_t main_bytes = (size_t)4 * a.Rpad * 128 + (size_t)2 * BN * 128 + 1024 + (dbg ? 2 * 48 * 9 * 8 : 0);
   constexpr size_t kOP = BN * 2 + 16;
-  constexpr int kEW = ((size_t)NWIN * BM * kOP > 112 * 1024) ? 1 : NWIN;
-  constexpr int kRG = NTHR / (BN / 2);
-  const size_t epi_bytes = (size_t)kEW * BM * kOP + (size_t)kRG * BN * 2 * 4;
+  const size_t epi_bytes = conv_epilogue_lds_bytes<BM, BN, NWIN, NTHR>();
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   static std::once_flag once;
@@ -882,7 +877,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   }
   const size_t main_bytes = (size_t)2 * a.Rpad * 128 + (size_t)2 * BN * 128;
   constexpr size_t kOP = BN * 2 + 16;
-  const size_t epi_bytes = (size_t)BM * kOP + (size_t)4 * BN * 2 * 4;
+  const size_t epi_bytes = conv_epilogue_lds_bytes<BM, BN, 1, 256>();
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;

@@ -237,6 +237,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
 // fetched into one L2), consecutive workgroups hold different pairs.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGppZeroWin = 2;
+#ifdef OS2S_EPI_STAMPS
+constexpr int kGppStampStride = 24;
+#else
+constexpr int kGppStampStride = 8;
+#endif
 
 __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(ConvArgs p, ConvGroupTable gt) {
   constexpr int BM = 128, BN = 256, NWIN = 2;
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(ConvArgs p, ConvGrou
   const int grp = wid >> 2;
   // experiment hook: phase time stamps of the first 2048 work units (8 x uint64 each: entry,
   // unit decoded, pipeline filled, main loop done, epilogue done, steps)
-  unsigned long long* const stamps = (p.dbg && blockIdx.x < 2048) ? p.dbg + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* const stamps = (p.dbg && blockIdx.x < 2048) ? p.dbg + (size_t)blockIdx.x * kGppStampStride : nullptr;
   if (stamps && tid == 0) stamps[0] = __builtin_readcyclecounter();
   // ---- live windows per sample, inclusive scan over the batch (one value per lane) ----------
   int nw = 0;
@@ -409,7 +414,7 @@ extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long l
   a.MT8 = per_xcd;
   const size_t main_bytes = (size_t)5 * 256 * 128;    // A ring of 3 + W ring of 2 = 160 KB
   constexpr size_t kOP = 256 * 2 + 16;
-  const size_t epi_bytes = (size_t)128 * kOP + (size_t)4 * 256 * 2 * 4;
+  const size_t epi_bytes = conv_epilogue_lds_bytes<128, 256, 2, 512>();
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;

@@ -255,7 +255,8 @@ def test_run_py_train_eval_infer_checkpoints(cuda, tmp_path):
   assert "ForwardPass/w2l_encoder/conv11/bn/moving_variance" in names and int(ck["global_step"]) == 30
   fc = [n for n in names if n.endswith("fully_connected/kernel") and not n.startswith("Loss_")]
   assert len(fc) == 1 and ck[fc[0]].shape[0] == 128        # tf.layers.dense layout [Cin, Cout]
-  assert open(os.path.join(logdir, "checkpoint")).read().strip() == 'model_checkpoint_path: "model.ckpt-30"'
+  assert open(os.path.join(logdir, "checkpoint")).read().splitlines() == [
+      'model_checkpoint_path: "model.ckpt-30"', 'all_model_checkpoint_paths: "model.ckpt-30"']
   out = run("--mode=eval")
   assert "Restored checkpoint" in out and "Eval WER" in out
   inf = str(tmp_path / "infer.csv")

@@ -7,7 +7,8 @@ import torch
 from openseq2seq_amd import capi, _lib
 
 dev = torch.device("cuda:0")
-B = 32
+B = int(os.environ.get("PH_B", "32"))
+NG = int(os.environ.get("PH_GROUPS", "10"))
 rng = np.random.RandomState(0)
 lens_np = (rng.uniform(2.0, 16.7, B) * 50).astype(np.int32) + 1
 T = int(-(-lens_np.max() // 16) * 16)
@@ -15,7 +16,7 @@ lens = torch.from_numpy(lens_np).to(dev)
 L = _lib.lib()
 L.os2s_conv1d_set_debug.argtypes = [_lib.c_void_p, _lib.c_int]
 nm = capi.conv1d_num_mtiles(B, T)
-cins = [256, 256, 256, 384, 384, 512, 512, 640, 640, 768]
+cins = [256, 256, 256, 384, 384, 512, 512, 640, 640, 768][10 - NG:]
 cout = 768
 for variant in (1, 2):
   items = []
@@ -33,16 +34,23 @@ for variant in (1, 2):
   e1.record(); torch.cuda.synchronize()
   print("variant %d: %.1f us / launch" % (variant, e0.elapsed_time(e1) / 5 * 1e3))
   if variant == 2:
-    st = torch.zeros(2048 * 8, dtype=torch.int64, device=dev)
+    STRIDE = int(os.environ.get("PH_STRIDE", "8"))     # 24 with a -DOS2S_EPI_STAMPS build
+    st = torch.zeros(2048 * STRIDE, dtype=torch.int64, device=dev)
     L.os2s_conv1d_set_debug(_lib.c_void_p(st.data_ptr()), 0)
     e0.record()
     capi.conv1x1_fwd_grouped(items, in_len=lens)
     e1.record(); torch.cuda.synchronize()
     L.os2s_conv1d_set_debug(_lib.c_void_p(0), 0)
     us = e0.elapsed_time(e1) * 1e3
-    t = st.cpu().numpy().reshape(2048, 8).astype(np.float64)
+    full = st.cpu().numpy().reshape(2048, STRIDE).astype(np.float64)
+    t = full[:, :8]
     ok = t[:, 4] > 0
     t = t[ok]
+    if STRIDE > 8:
+      e = full[ok][:, 8:24]
+      n = int((e[0] > 0).sum())
+      base = t[ok][:, 3:4]
+      print("  epilogue stamps (cycles after main loop end), mean over units:", " ".join("%6.0f" % v for v in (e[:, :n] - base).mean(0)))
     print("stamped units %d; launch %.1f us (counters are per XCD: only differences inside a unit are used)" % (ok.sum(), us))
     for steps in sorted(set(t[:, 5].astype(int))):
       m = t[t[:, 5] == steps]
