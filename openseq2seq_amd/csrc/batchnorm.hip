@@ -333,7 +333,10 @@ struct BnBwdReduceArgs {
   int rows_per_block;
 };
 
-template <int J_MAX>
+// U = rows in flight per thread: 4 for the single-input instantiation, fewer for the residual block
+// ends (their per-input accumulators already take 32 / 96 registers; with U = 4 the 12-input
+// instantiation ran at one wave per SIMD)
+template <int J_MAX, int kTileU>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs p, int gmax) {
   __shared__ float red[256 * 8];
   const int C8 = p.C >> 3;
@@ -735,11 +738,11 @@ extern "C" int os2s_bn_act_bwd_reduce(os2s_stream_t stream, int J, const uint16_
   dim3 grid(ceil_div((long long)B * T, a.rows_per_block), tile_cblocks(C8, gmax));
   const size_t smem = 0;
   if (J <= 1) {
-    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, a, gmax);
+    OS2S_LAUNCH((bn_act_bwd_reduce_kernel<1, 4>), grid, dim3(256), smem, (hipStream_t)stream, a, gmax);
   } else if (J <= 4) {
-    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<4>, grid, dim3(256), smem, (hipStream_t)stream, a, gmax);
+    OS2S_LAUNCH((bn_act_bwd_reduce_kernel<4, 2>), grid, dim3(256), smem, (hipStream_t)stream, a, gmax);
   } else {
-    OS2S_LAUNCH(bn_act_bwd_reduce_kernel<kMaxBnInputs>, grid, dim3(256), smem,
+    OS2S_LAUNCH((bn_act_bwd_reduce_kernel<kMaxBnInputs, 1>), grid, dim3(256), smem,
                 (hipStream_t)stream, a, gmax);
   }
   return OS2S_OK;

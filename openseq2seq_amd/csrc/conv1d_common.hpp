@@ -191,38 +191,62 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
   const char* const otw = ot + (w - w0) * BM * OP;
   bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
   constexpr int NQ = (BM * (BN / 8) + NTHR - 1) / NTHR;     // 16-B chunks per thread
-  // all LDS reads of the thread first, then its global stores: written as one loop the stores
-  // wait for their ds_read one by one
-  u32x4 v[NQ];
-  bool ok[NQ];
+  static_assert((BM * (BN / 8)) % NTHR == 0, "whole number of chunks per thread");
+  // Two phases — every read of the thread (LDS tile, residual rows, previous output when
+  // accumulating), then the adds and the stores — and a branch-free path for tiles that lie
+  // completely inside the output: interleaved, the compiler keeps load -> wait -> store order
+  // (the stores may alias the next load), and a bounds test around a store puts an
+  // s_waitcnt vmcnt(0) in front of it; both made the data-gradient launches (accumulate = 1)
+  // pay one memory round trip per 16 bytes.
+  const bool inside = __builtin_amdgcn_readfirstlane((valid_rows == BM && n0 + BN <= p.Cout) ? 1 : 0);
+  u32x4 v[NQ], ro[NQ], ao[NQ];
+  if (inside) {
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int q = tid + i * NTHR;
-    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
-    ok[i] = q < BM * (BN / 8) && row < valid_rows && n0 + c8 * 8 < p.Cout;
-    if (ok[i]) v[i] = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
-  }
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * NTHR;
+      const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+      v[i] = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
+      const long long off = (long long)(t0 + row) * p.y_st + n0 + c8 * 8;
+      if (p.residual) ro[i] = *reinterpret_cast<const u32x4*>(p.residual + (long long)b * p.y_sb + off);
+      if (p.accumulate) ao[i] = *reinterpret_cast<const u32x4*>(yb + off);
+    }
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    const int q = tid + i * NTHR;
-    const int row = q / (BN / 8), c8 = q - row * (BN / 8);
-    const int gc = n0 + c8 * 8;
-    if (ok[i]) {
-      bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * NTHR;
+      const int row = q / (BN / 8), c8 = q - row * (BN / 8);
       if (p.residual) {
-        const u32x4 o = *reinterpret_cast<const u32x4*>(
-            p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[i][e] = pack2bf(bflo(v[i][e]) + bflo(o[e]), bfhi(v[i][e]) + bfhi(o[e]));
+          v[i][e] = pack2bf(bflo(v[i][e]) + bflo(ro[i][e]), bfhi(v[i][e]) + bfhi(ro[i][e]));
       }
       if (p.accumulate) {
-        const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[i][e] = pack2bf(bflo(v[i][e]) + bflo(o[e]), bfhi(v[i][e]) + bfhi(o[e]));
+          v[i][e] = pack2bf(bflo(v[i][e]) + bflo(ao[i][e]), bfhi(v[i][e]) + bfhi(ao[i][e]));
       }
-      *reinterpret_cast<u32x4*>(dst) = v[i];
+      *reinterpret_cast<u32x4*>(yb + (long long)(t0 + row) * p.y_st + n0 + c8 * 8) = v[i];
+    }
+  } else {
+    for (int i = 0; i < NQ; ++i) {
+      const int q = tid + i * NTHR;
+      const int row = q / (BN / 8), c8 = q - row * (BN / 8);
+      const int gc = n0 + c8 * 8;
+      if (row < valid_rows && gc < p.Cout) {
+        u32x4 x = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
+        bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
+        if (p.residual) {
+          const u32x4 o = *reinterpret_cast<const u32x4*>(
+              p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = pack2bf(bflo(x[e]) + bflo(o[e]), bfhi(x[e]) + bfhi(o[e]));
+        }
+        if (p.accumulate) {
+          const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = pack2bf(bflo(x[e]) + bflo(o[e]), bfhi(x[e]) + bfhi(o[e]));
+        }
+        *reinterpret_cast<u32x4*>(dst) = x;
+      }
     }
   }
   }

@@ -588,28 +588,61 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   }
 
   // ---- epilogue: the one owner of the tile writes dW (fp32), ci contiguous across lanes -------
+  // accumulate: ALL previous values of a tap's 64 elements are loaded first, then added and stored
+  // (written element by element the compiler must keep load -> wait -> store order because the
+  // stores may alias the next load: 128 serial memory round trips per lane)
+  // Tiles completely inside [Cout, Cin] (every Jasper layer) take a branch-free path: with a bounds
+  // test around each store every store sits in its own basic block and gets a vmcnt(0) in front.
   const int l31 = lane & 31;
+  const bool inside = __builtin_amdgcn_readfirstlane((co0 + 128 <= p.Cout && ci0 + 128 <= p.Cin) ? 1 : 0);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int tap = k0 + 2 * grp + e;
     if (tap < p.K) {
       float* const dwk = p.dw + (long long)tap * p.Cout * p.Cin;
+      if (inside) {
+        float* const base = dwk + (long long)(co0 + wm * 64 + 4 * lhi) * p.Cin + ci0 + wn * 64 + l31;
+        float old[2][2][16];
+        if (p.accumulate) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ci = ci0 + wn * 64 + j * 32 + l31;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int co = co0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lhi;
-            if (co < p.Cout && ci < p.Cin) {
-              float* dst = dwk + (long long)co * p.Cin + ci;
-              float val = acc[e][i][j][v];
-              if (p.accumulate) val += *dst;
-              *dst = val;
+              for (int v = 0; v < 16; ++v)
+                old[i][j][v] = base[(long long)(i * 32 + (v & 3) + 8 * (v >> 2)) * p.Cin + j * 32];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int v = 0; v < 16; ++v) acc[e][i][j][v] += old[i][j][v];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+              base[(long long)(i * 32 + (v & 3) + 8 * (v >> 2)) * p.Cin + j * 32] = acc[e][i][j][v];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const int co = co0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lhi;
+              if (co < p.Cout && ci < p.Cin) {
+                float* dst = dwk + (long long)co * p.Cin + ci;
+                float val = acc[e][i][j][v];
+                if (p.accumulate) val += *dst;
+                *dst = val;
+              }
             }
           }
-        }
+      }
     }
   }
 }
