@@ -1,0 +1,73 @@
+#!/bin/bash
+# One call that produces every profile committed under profiles/ for a round:
+#   <tag>_bench_default.json(.err)        python bench.py (the driver's command)
+#   <tag>_jasper_kernel_stats.csv         rocprofv3 --kernel-trace --stats of the Jasper step (bench streams)
+#   <tag>_jasper_kernel_stats_serial.csv  the same with the weight-gradient stream folded into the main
+#                                         stream (OS2S_WGRAD_STREAM=0): every kernel alone on the GPU
+#   <tag>_pmc_bench_traffic.json          FETCH_SIZE / WRITE_SIZE per launch of the conv kernels (separate
+#                                         --pmc passes, gfx950 correction) — bench.py reads the newest one
+#   <tag>_pmc_mfma_busy.json              SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE per
+#                                         kernel (conv fwd+dgrad ping-pong, lockstep, wgrad)
+# Usage on the GPU box: bash tools/profile_round.sh r02
+TAG=${1:-rXX}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/profile_$TAG
+mkdir -p $OUT
+timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+tail -c 600 $OUT/${TAG}_bench_default.json; echo
+J="python bench.py --no-transformer --no-other-configs --no-cpu-baseline --no-kernel-timing"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o jasper -- $J --steps 8 --warmup 3 > $OUT/ks.log 2>&1
+cp $OUT/ks/jasper_kernel_stats.csv $OUT/${TAG}_jasper_kernel_stats.csv
+OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kss -o jasper -- $J --steps 8 --warmup 3 > $OUT/kss.log 2>&1
+cp $OUT/kss/jasper_kernel_stats.csv $OUT/${TAG}_jasper_kernel_stats_serial.csv
+P="$J --steps 2 --warmup 1"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o c -- $P > $OUT/f.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -o c -- $P > $OUT/w.log 2>&1
+OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT/m -o c -- $P > $OUT/m.log 2>&1
+python - <<PY
+import csv, glob, json, collections
+FAM = [("conv1d_pp_kernel", "conv fwd+dgrad, ping-pong tile"), ("conv1d_igemm_grouped_kernel", "grouped 1x1 fwd+dgrad, lockstep tile"),
+       ("conv1d_igemm_kernel", "conv fwd+dgrad, lockstep tile"), ("conv1d_wgrad_pp_kernel", "wgrad, ping-pong tile"),
+       ("conv1d_wgrad_kernel", "wgrad, lockstep tile")]
+def fam(name):
+    for k, _ in FAM:
+        if k in name: return k
+    return None
+def collect(sub):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = fam(r["Kernel_Name"])
+            if k is None: continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    return agg, cnt
+fa, fc = collect("f"); wa, wc = collect("w"); ma, mc = collect("m")
+per = {}
+tf = tw = n = 0.0
+for k, desc in FAM:
+    if k not in fa: continue
+    nf = fc[(k, "FETCH_SIZE")]; nw = wc[(k, "WRITE_SIZE")]
+    f = fa[k]["FETCH_SIZE"] / max(nf, 1); w = wa[k]["WRITE_SIZE"] / max(nw, 1)
+    per[k] = {"what": desc, "launches": nf, "FETCH_SIZE_KB_per_launch_raw": f, "WRITE_SIZE_KB_per_launch_raw": w,
+              "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    if "wgrad" not in k:
+        tf += fa[k]["FETCH_SIZE"]; tw += wa[k]["WRITE_SIZE"]; n += nf
+out = {"command": "$P", "kernel": "conv1d_pp_kernel + conv1d_igemm_kernel + conv1d_igemm_grouped_kernel (the launches bench.py's roofline block times: fwd + dgrad)",
+       "launches": n, "FETCH_SIZE_KB_per_launch_raw": tf / max(n, 1), "WRITE_SIZE_KB_per_launch_raw": tw / max(n, 1),
+       "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled; WRITE_SIZE as reported (MI355X_MICROARCH.md)",
+       "hbm_bytes_per_launch": (2.0 * tf / max(n, 1) + tw / max(n, 1)) * 1024.0, "per_kernel": per}
+json.dump(out, open("$OUT/${TAG}_pmc_bench_traffic.json", "w"), indent=1)
+busy = {"command": "OS2S_WGRAD_STREAM=0 $P", "note": "per-launch means; SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: mfma_duty_cycle = MFMA_BUSY / (128 x GRBM_GUI_ACTIVE)", "per_kernel": {}}
+for k, desc in FAM:
+    if k not in ma: continue
+    e = {c: ma[k][c] / mc[(k, c)] for c in ma[k]}
+    e["launches"] = mc[(k, "SQ_VALU_MFMA_BUSY_CYCLES")]
+    if e.get("GRBM_GUI_ACTIVE"):
+        e["mfma_duty_cycle"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * e["GRBM_GUI_ACTIVE"])   # GRBM summed over 8 XCDs
+    e["what"] = desc
+    busy["per_kernel"][k] = e
+json.dump(busy, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
+print(json.dumps({k: (v["hbm_bytes_per_launch"]) for k, v in per.items()}))
+print(json.dumps({k: v.get("mfma_duty_cycle") for k, v in busy["per_kernel"].items()}))
+PY
+ls -la $OUT/*.json $OUT/*.csv
