@@ -702,13 +702,25 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
 
 // Tile choice is a fixed function of the problem shape (no timing, no hidden state):
 //   * ping-pong kernel (256 x 256 per workgroup, balanced over the live windows) whenever the
-//     shape is inside its envelope and the layer is at least 448 channels wide (below that a
-//     whole unit is shorter than the fixed costs of its workgroup);
+//     shape is inside its envelope and the layer is at least 320 channels wide (the 256-channel
+//     layers: a whole unit is shorter than the fixed costs of its workgroup, 0.057 vs 0.054 ms);
 //   * otherwise the lockstep kernel: 256 x 256 tile for wide 1x1 / short-K layers with enough
 //     rows to fill the chip, else the 128 x 128 tile (single-buffered X window for K >= 8).
 // os2s_conv1d_set_variant(v >= 0) forces a tile for experiments and tests:
 //   0 = 128x128, X window double-buffered   3 = 128x128, X window single-buffered when K >= 8
 //   5 = 256x256 lockstep                   10 = ping-pong
+// experiment knob read once from the environment (A/B runs on one box: tools/r2_probe31.sh)
+static int env_int(const char* name, int dflt) {
+  static std::mutex mu;
+  static std::map<std::string, int> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(name);
+  if (it != cache.end()) return it->second;
+  const char* v = getenv(name);
+  const int r = v ? atoi(v) : dflt;
+  cache[name] = r;
+  return r;
+}
 static int g_conv_variant = -1;
 static int g_conv_split = -1;
 static unsigned long long* g_conv_dbg = nullptr;
@@ -766,7 +778,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
   if (v < 0) {
     v = K >= 8 ? 3 : 0;
     if (Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;
-    if (Cout >= 448) v = 10;
+    if (Cout >= env_int("OS2S_PP_MIN_COUT", 320)) v = 10;
   }
   if ((v == 10 || v == 11) && K == 1 && g_conv1x1_variant == 2 && residual == nullptr && Cout >= 256 &&
       y_stride_t == Cout && y_stride_b == (long long)Tout * Cout) {

@@ -78,15 +78,16 @@ __device__ __forceinline__ bool split_publish_and_reduce(At&& at, float* slab0, 
 
 // Tail-split decision shared by the ping-pong kernels: U units on G CUs, r = U mod G units left
 // for the last round; cut them f ways when the model says the tail gets shorter. Costs in
-// microseconds, fitted on MI355X (tools/bench_conv_split.py): a split unit adds ~40 us (pipeline
-// fill, partial-tile store + release, reducer epilogue), ~8 us per partial tile the reducer
-// reads back and 0.17 us per piece of aggregate workspace traffic.
+// microseconds, fitted on MI355X (tools/bench_conv_split.py, tools/bench_wgrad_shapes.py; refitted
+// after the epilogue work of round 2): a split unit adds ~20 us (pipeline fill, partial-tile store
+// + release, reducer epilogue), ~1.5 us per partial tile the reducer reads back and 0.17 us per
+// piece of aggregate workspace traffic.
 __device__ __forceinline__ int split_factor(int r, int G, float round_us, int fmax, int max_pieces) {
   int f = 1;
   float best = round_us;
   for (int ff = 2; ff <= fmax; ++ff) {
     if (r * ff > max_pieces) break;
-    const float t = (float)((r * ff + G - 1) / G) * round_us / ff + 40.f + 8.f * ff + 0.17f * (r * ff);
+    const float t = (float)((r * ff + G - 1) / G) * round_us / ff + 20.f + 1.5f * ff + 0.17f * (r * ff);
     if (t < 0.95f * best) { best = t; f = ff; }
   }
   return f;
