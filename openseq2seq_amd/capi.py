@@ -5,6 +5,7 @@ validates dtype / contiguity / device, passes raw pointers + the current HIP
 stream, and raises Os2sError on a non-zero status.
 """
 import functools
+import os
 
 import torch
 
@@ -533,7 +534,10 @@ def spec_augment(feats, masks):
 # --------------------------------------------------------------------------
 # Transformer kernels (packed token-major tensors)
 # --------------------------------------------------------------------------
-LT_MIN_ROWS = 256     # plain matmuls with at least this many rows go to the vendor GEMM
+LT_MIN_ROWS = 256     # plain matmuls with at least this many rows go to the big-tile GEMMs
+# Back end of the bare matmuls (no fused epilogue): 'pp' (default) = the in-tree ping-pong MFMA
+# kernels (os2s_gemm_nt / conv1d_wgrad1x1_pp_kernel), 'lt' = hipBLASLt (kept for A/B runs)
+USE_LT = os.environ.get("OS2S_GEMM", "pp") == "lt"
 
 
 def _lt_unsupported(e):
@@ -549,11 +553,15 @@ def gemm(x2d, w, **kw):
            and kw.get("keep_prob", 1.0) >= 1.0)
   if plain and x2d.shape[0] >= LT_MIN_ROWS and x2d.stride(1) == 1 and w.stride(1) == 1:
     out_t = kw.get("out", None)
-    try:
-      return matmul_lt(x2d, w, b_is_t=True, out=out_t, beta=1.0 if kw.get("accumulate", False) else 0.0)
-    except _lib.Os2sError as e:
-      if not _lt_unsupported(e):
-        raise
+    if USE_LT:
+      try:
+        return matmul_lt(x2d, w, b_is_t=True, out=out_t, beta=1.0 if kw.get("accumulate", False) else 0.0)
+      except _lib.Os2sError as e:
+        if not _lt_unsupported(e):
+          raise
+    elif (x2d.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous() and x2d.stride(0) % 8 == 0
+          and (out_t is None or (out_t.stride(1) == 1 and out_t.stride(0) % 8 == 0))):
+      return gemm_nt(x2d, w, out=out_t, accumulate=bool(kw.get("accumulate", False)))
   out = kw.pop("out", None)
   N, Cin = x2d.shape
   Cout = w.shape[0]
@@ -636,14 +644,18 @@ def gemm_wgrad(x2d, dy2d, out, accumulate=True):
   """dW [Cout,Cin] (+)= dy^T x (fp32)."""
   N, Cin = x2d.shape
   Cout = dy2d.shape[1]
-  if N >= LT_MIN_ROWS and x2d.stride(1) == 1 and dy2d.stride(1) == 1 and out.stride(1) == 1:
+  if USE_LT and N >= LT_MIN_ROWS and x2d.stride(1) == 1 and dy2d.stride(1) == 1 and out.stride(1) == 1:
     try:
       matmul_lt(dy2d, x2d, a_is_t=True, out=out, beta=1.0 if accumulate else 0.0)
       return
     except _lib.Os2sError as e:
       if not _lt_unsupported(e):
         raise
-  conv1d_wgrad(x2d.view(1, N, Cin), dy2d.view(1, N, Cout), 1, pad_left=0,
+  if dy2d.stride(1) != 1 or dy2d.stride(0) != Cout:
+    dy2d = dy2d.contiguous()
+  if x2d.stride(1) != 1 or x2d.stride(0) % 8:
+    x2d = x2d.contiguous()
+  conv1d_wgrad(x2d.unsqueeze(0), dy2d.unsqueeze(0), 1, pad_left=0,
                out=out.view(1, Cout, Cin), accumulate=accumulate)
 
 

@@ -377,212 +377,154 @@ __global__ __launch_bounds__(kFwdWaves * 64) void attn_fwd_long_kernel(AttnArgs 
 // ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
-constexpr int kBwdWaves = 1;            // one wave per workgroup: LDS per wave decides occupancy
-constexpr int kBwdLdsPerWave = 24576;   // 3 images (was 6 = 48 KB -> 2 waves per CU)
+// One WORKGROUP of four waves per (batch, head); wave (wi, wj) owns the 32 x 32 quadrant
+// (wi, wj) of every 64 x 64 product. The kernel is a latency chain per (batch, head) — global
+// loads, two products, the softmax algebra, three gradient products — so what matters is how
+// short a wave's share of the chain is and how many waves a CU holds to hide it: a quarter of
+// the loads, MFMAs and transcendental work per wave, ~100 registers (the one-wave version held
+// three full 64 x 64 accumulator sets = 256 registers) and 40 KB of LDS per workgroup = 16 waves
+// per CU instead of 6. dO, K and Q are staged ONCE, up front, as transpose-read images (the
+// one-wave version re-staged one image between the gradient products, each a global round trip
+// in the middle of the chain).
+constexpr int kBwdThreads = 256;
+constexpr int kBwdLds = 5 * 8192;       // dO, K, Q images + PM + dS (the delta exchange aliases dS)
 
-// generic "A via tr image, B via kc image" 64x64x64 product: D[m][n], m from A image cols
-__device__ __forceinline__ void mm_tr_kc(const char* a_tr, const char* b_kc, int lane, f32x16 (&d)[2][2]) {
-  const int l31 = lane & 31, lhi = lane >> 5;
+// copy a [rows<=64][64] bf16 tile from global into a "tr" LDS image (zero fill), 256 threads
+__device__ __forceinline__ void stage_tr4(char* buf, const bf16_t* base, long long ld, int nvalid, int tid) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) d[i][j][e] = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2], b[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = frag_tr(a_tr, i, kk, lane);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = frag_kc(b_kc, j * 32 + l31, kk * 2 + lhi);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], d[i][j], 0, 0, 0);
+  for (int it = 0; it < 2; ++it) {
+    const int piece = it * kBwdThreads + tid;   // 512 pieces of 16 B
+    const int row = piece >> 3, p8 = piece & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < nvalid) v = *reinterpret_cast<const u32x4*>(base + (long long)row * ld + p8 * 8);
+    *reinterpret_cast<u32x4*>(buf + tr_off(row, p8 * 8)) = v;
   }
 }
 
-// D[m][n] = sum_k A^T-image[k][m] * B^T-image[k][n]: both operands fetched with transpose reads
-__device__ __forceinline__ void mm_tr_tr(const char* a_tr, const char* b_tr, int lane, f32x16 (&d)[2][2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) d[i][j][e] = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2], b[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = frag_tr(a_tr, i, kk, lane);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = frag_tr(b_tr, j, kk, lane);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], d[i][j], 0, 0, 0);
-  }
-}
-
-// store D[m=d][n] (lane col n, 4 consecutive d per reg group) to out[n][d], rows n < nvalid
-__device__ __forceinline__ void store_dT(const f32x16 (&d)[2][2], bf16_t* out, long long ld, int nvalid,
-                                         float mul, int lane) {
+// store quadrant D[m = d block i][n block j] (lane col n, 4 consecutive d per reg group) to
+// out[n][d], rows n < nvalid
+__device__ __forceinline__ void store_dT_quad(const f32x16& d, int i, int j, bf16_t* out, long long ld,
+                                              int nvalid, float mul, int lane) {
   const int l31 = lane & 31, lhi = lane >> 5;
+  const int n = j * 32 + l31;
+  if (n < nvalid) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = j * 32 + l31;
-    if (n < nvalid) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d0 = i * 32 + 8 * g + 4 * lhi;
-          u32x2 pk;
-          pk[0] = pack2bf(d[i][j][4 * g] * mul, d[i][j][4 * g + 1] * mul);
-          pk[1] = pack2bf(d[i][j][4 * g + 2] * mul, d[i][j][4 * g + 3] * mul);
-          *reinterpret_cast<u32x2*>(out + (long long)n * ld + d0) = pk;
-        }
+    for (int g = 0; g < 4; ++g) {
+      const int d0 = i * 32 + 8 * g + 4 * lhi;
+      u32x2 pk;
+      pk[0] = pack2bf(d[4 * g] * mul, d[4 * g + 1] * mul);
+      pk[1] = pack2bf(d[4 * g + 2] * mul, d[4 * g + 3] * mul);
+      *reinterpret_cast<u32x2*>(out + (long long)n * ld + d0) = pk;
     }
   }
 }
 
-__global__ __launch_bounds__(kBwdWaves * 64) void attn_bwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(kBwdThreads) void attn_bwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 1, wj = wid & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
-  long long bh = (long long)blockIdx.x * kBwdWaves + wid;
-  const bool live = bh < (long long)p.B * p.H;
-  if (!live) bh = 0;
+  const long long bh = blockIdx.x;
   const int b = (int)(bh / p.H), h = (int)(bh - (long long)b * p.H);
   const int q0 = p.cu_q[b], k0 = p.cu_k[b];
   const int Lq = min(p.cu_q[b + 1] - q0, kL), Lk = min(p.cu_k[b + 1] - k0, kL);
-  // One transpose-read image is re-staged between the three gradient products (dO, then K, then
-  // Q), and P.M / dS are stored once, [q][key], and consumed by transpose reads (dV, dK) or
-  // row reads (dQ): 24 KB of LDS per wave instead of 48 KB, i.e. 6 waves per CU instead of 2 —
-  // the kernel is a latency chain per (batch, head), so resident waves are what hides it.
-  char* base = smem + wid * kBwdLdsPerWave;
-  char* tr_img = base;           // dO[q][d] / K[key][d] / Q[q][d] tr image (rows = reduction index)
-  char* pm = base + 8192;        // PM[q][key] tr image (rows = q)
-  char* ds = base + 16384;       // dS[q][key] tr image (rows = q); also read row-wise for dQ
+  char* const do_img = smem;            // dO[q][d]   tr image (rows = q)
+  char* const k_img = smem + 8192;      // K[key][d]  tr image (rows = key)
+  char* const q_img = smem + 16384;     // Q[q][d]    tr image (rows = q)
+  char* const pm = smem + 24576;        // PM[q][key] tr image (rows = q)
+  char* const ds = smem + 32768;        // dS[q][key] tr image (rows = q); also read row-wise for dQ
+  float* const dbuf = reinterpret_cast<float*>(ds);   // [2][64] partial deltas, before dS is written
   const bf16_t* qb = p.q + (long long)q0 * p.ldq + h * kDh;
   const bf16_t* kb = p.k + (long long)k0 * p.ldk + h * kDh;
   const bf16_t* vb = p.v + (long long)k0 * p.ldv + h * kDh;
   const bf16_t* dob = p.d_o + (long long)q0 * p.lddo + h * kDh;
 
-  stage_tr(tr_img, dob, p.lddo, Lq, lane);
+  // ---- every global read of the workgroup is issued here -----------------------------------
+  bf16x8 fk[4], fq[4], fv[4], fdo[4];
+  const int key_row = wi * 32 + l31, q_row = wj * 32 + l31;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    fk[kk] = frag_global(kb, p.ldk, key_row, Lk, kk * 16 + lhi * 8);
+    fq[kk] = frag_global(qb, p.ldq, q_row, Lq, kk * 16 + lhi * 8);
+    fv[kk] = frag_global(vb, p.ldv, key_row, Lk, kk * 16 + lhi * 8);
+    fdo[kk] = frag_global(dob, p.lddo, q_row, Lq, kk * 16 + lhi * 8);
+  }
+  const int q = q_row;
+  const float lse = (q < Lq) ? p.lse[(long long)(q0 + q) * p.H + h] : 0.f;
+  stage_tr4(do_img, dob, p.lddo, Lq, tid);
+  stage_tr4(k_img, kb, p.ldk, Lk, tid);
+  stage_tr4(q_img, qb, p.ldq, Lq, tid);
 
-  f32x16 s[2][2];
-  scores(p, qb, kb, Lq, Lk, lane, s);
-  // dPM^T[key][q] = sum_d V[key][d] dO[q][d]
-  f32x16 dp[2][2];
+  // ---- S^T[key][q] = K Q^T and dPM^T[key][q] = V dO^T, this wave's quadrant -------------------
+  f32x16 s, dp;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dp[i][j][e] = 0.f;
+  for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2], bq[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = frag_global(vb, p.ldv, i * 32 + l31, Lk, kk * 16 + lhi * 8);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bq[j] = frag_global(dob, p.lddo, j * 32 + l31, Lq, kk * 16 + lhi * 8);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        dp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], dp[i][j], 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[kk], fq[kk], s, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[kk], fdo[kk], dp, 0, 0, 0);
   }
+  // ---- P, M, partial delta = sum over this wave's 32 keys of P * M * dPM; PM[q][key] to LDS ------
   const float ik = 1.f / p.keep_prob;
+  float delta = 0.f;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = j * 32 + l31;
-    const float lse = (q < Lq) ? p.lse[(long long)(q0 + q) * p.H + h] : 0.f;
-    float delta = 0.f;
-    // P, M, and delta = sum_key P*M*dPM; PM[q][key] goes to LDS (4 consecutive keys per store)
+  for (int g = 0; g < 4; ++g) {
+    const int key0 = wi * 32 + 8 * g + 4 * lhi;
+    uint32_t keep = 0xfu;
+    if (p.keep_prob < 1.f) keep = attn_keep4(p, bh, q, key0);
+    float pmv[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e, key = key0 + e;
+      const bool ok = key < Lk && q < Lq && !(p.causal && key > q);
+      const float pv = ok ? __expf(s[r] * p.scale - lse) : 0.f;
+      float mk = 1.f;
+      if (p.keep_prob < 1.f) mk = ((keep >> e) & 1u) ? ik : 0.f;
+      s[r] = pv;                  // P
+      dp[r] *= mk;                // dP = dPM * M
+      delta += pv * dp[r];
+      pmv[e] = pv * mk;
+    }
+    u32x2 pk;
+    pk[0] = pack2bf(pmv[0], pmv[1]);
+    pk[1] = pack2bf(pmv[2], pmv[3]);
+    *reinterpret_cast<u32x2*>(pm + tr_off(q, key0)) = pk;
+  }
+  delta += xhalf(delta);
+  if (lhi == 0) dbuf[wi * 64 + q] = delta;
+  __syncthreads();
+  delta += dbuf[(wi ^ 1) * 64 + q];      // the other 32 keys of this query (wave (1 - wi, wj))
+  __syncthreads();                        // dbuf is overwritten by the dS image next
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int key0 = i * 32 + 8 * g + 4 * lhi;
-        uint32_t keep = 0xfu;
-        if (p.keep_prob < 1.f) keep = attn_keep4(p, bh, q, key0);
-        float pmv[4];
+  for (int g = 0; g < 4; ++g) {
+    const int key0 = wi * 32 + 8 * g + 4 * lhi;
+    float w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e, key = key0 + e;
-          const bool ok = key < Lk && q < Lq && !(p.causal && key > q);
-          const float pv = ok ? __expf(s[i][j][r] * p.scale - lse) : 0.f;
-          float mk = 1.f;
-          if (p.keep_prob < 1.f) mk = ((keep >> e) & 1u) ? ik : 0.f;
-          s[i][j][r] = pv;                 // P
-          dp[i][j][r] *= mk;               // dP = dPM * M
-          delta += pv * dp[i][j][r];
-          pmv[e] = pv * mk;
-        }
-        u32x2 pk;
-        pk[0] = pack2bf(pmv[0], pmv[1]);
-        pk[1] = pack2bf(pmv[2], pmv[3]);
-        *reinterpret_cast<u32x2*>(pm + tr_off(q, key0)) = pk;
-      }
-    delta += xhalf(delta);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int key0 = i * 32 + 8 * g + 4 * lhi;
-        float w[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          w[e] = s[i][j][r] * (dp[i][j][r] - delta);   // dS (w.r.t. the scaled logits)
-        }
-        u32x2 pk;
-        pk[0] = pack2bf(w[0], w[1]);
-        pk[1] = pack2bf(w[2], w[3]);
-        *reinterpret_cast<u32x2*>(ds + tr_off(q, key0)) = pk;
-      }
+    for (int e = 0; e < 4; ++e) w[e] = s[4 * g + e] * (dp[4 * g + e] - delta);   // dS (w.r.t. the scaled logits)
+    u32x2 pk;
+    pk[0] = pack2bf(w[0], w[1]);
+    pk[1] = pack2bf(w[2], w[3]);
+    *reinterpret_cast<u32x2*>(ds + tr_off(q, key0)) = pk;
   }
   __syncthreads();
-  f32x16 d[2][2];
-  // dV^T[d][key] = sum_q dO[q][d] PM[q][key]: both operands by transpose reads (rows = q)
-  mm_tr_tr(tr_img, pm, lane, d);
-  __syncthreads();                      // every fragment of the dO image has been read
-  stage_tr(tr_img, kb, p.ldk, Lk, lane);
-  if (live) store_dT(d, p.dv + (long long)k0 * p.lddv + h * kDh, p.lddv, Lk, 1.f, lane);
-  __syncthreads();
-  // dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]: B operand = 8 consecutive keys of row q
+  // ---- the three gradient products, quadrant (wi = d block, wj = key / query block) ------------
+  f32x16 dv, dq, dk;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) d[i][j][e] = 0.f;
+  for (int e = 0; e < 16; ++e) { dv[e] = 0.f; dq[e] = 0.f; dk[e] = 0.f; }
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2], bq[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = frag_tr(tr_img, i, kk, lane);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      bq[j] = *reinterpret_cast<const bf16x8*>(ds + tr_off(j * 32 + l31, kk * 16 + lhi * 8));
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        d[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], d[i][j], 0, 0, 0);
+    // dV^T[d][key] = sum_q dO[q][d] PM[q][key]: both operands by transpose reads (rows = q)
+    dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(do_img, wi, kk, lane), frag_tr(pm, wj, kk, lane), dv, 0, 0, 0);
+    // dQ^T[d][q] = scale * sum_key K[key][d] dS[q][key]: B operand = 8 consecutive keys of row q
+    const bf16x8 dsrow = *reinterpret_cast<const bf16x8*>(ds + tr_off(wj * 32 + l31, kk * 16 + lhi * 8));
+    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(k_img, wi, kk, lane), dsrow, dq, 0, 0, 0);
+    // dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key]: both operands by transpose reads (rows = q)
+    dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(q_img, wi, kk, lane), frag_tr(ds, wj, kk, lane), dk, 0, 0, 0);
   }
-  __syncthreads();
-  stage_tr(tr_img, qb, p.ldq, Lq, lane);
-  if (live) store_dT(d, p.dq + (long long)q0 * p.lddq + h * kDh, p.lddq, Lq, p.scale, lane);
-  __syncthreads();
-  // dK^T[d][key] = scale * sum_q Q[q][d] dS[q][key]: both operands by transpose reads (rows = q)
-  mm_tr_tr(tr_img, ds, lane, d);
-  if (live) store_dT(d, p.dk + (long long)k0 * p.lddk + h * kDh, p.lddk, Lk, p.scale, lane);
+  store_dT_quad(dv, wi, wj, p.dv + (long long)k0 * p.lddv + h * kDh, p.lddv, Lk, 1.f, lane);
+  store_dT_quad(dq, wi, wj, p.dq + (long long)q0 * p.lddq + h * kDh, p.lddq, Lq, p.scale, lane);
+  store_dT_quad(dk, wi, wj, p.dk + (long long)k0 * p.lddk + h * kDh, p.lddk, Lk, p.scale, lane);
 }
 
 }  // namespace os2s
@@ -653,13 +595,12 @@ extern "C" int os2s_attention_bwd(os2s_stream_t stream, const uint16_t* q, const
   a.keep_prob = keep_prob; a.seed = seed; a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
   a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   static bool attr = false;
-  const size_t smem = (size_t)kBwdWaves * kBwdLdsPerWave;
+  const size_t smem = (size_t)kBwdLds;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess) return OS2S_ERR_LAUNCH;
     attr = true;
   }
-  OS2S_LAUNCH(attn_bwd_kernel, dim3(ceil_div((long long)B * H, kBwdWaves)), dim3(kBwdWaves * 64),
-              smem, (hipStream_t)stream, a);
+  OS2S_LAUNCH(attn_bwd_kernel, dim3((unsigned)((long long)B * H)), dim3(kBwdThreads), smem, (hipStream_t)stream, a);
   return OS2S_OK;
 }

@@ -648,6 +648,332 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ping-pong weight gradient of the K = 1 convolution = the weight gradient of tf.layers.Dense
+// (Transformer projections, attention_layer.py:54-62 / ffn_layer.py:51-85 / embedding_layer.py:
+// 90-105; the FC and 1x1 layers of the other models):
+//
+//   dW[co][ci] (+)= sum_b sum_{t < len_b} dY[b,t,co] * X[b,t,ci]
+//
+// a "TN" GEMM: the reduction index is the ROW index of both operands, so both fragments come
+// from transpose reads as in conv1d_wgrad_pp_kernel. With one tap there is no X-window reuse;
+// the tile is therefore the plain GEMM's 256 co x 256 ci (64 KB of LDS-DMA per 64-row step for
+// 32 MFMAs per wave, the ratio of gemm_pp.hip) and the slot / ring structure is gemm_pp's:
+//
+//   group A (waves 0-3) owns co rows 0..127 of the tile, group B (waves 4-7) rows 128..255; a
+//   wave owns 128 co x 64 ci (128 accumulator registers); an item = one 64-co half = 16 MFMA.
+//   LOAD(2s)   : X fragments of step s (kept for both items) + dY fragments of the first item;
+//                issue the group's OWN dY half [64 t][128 co] of step s+2 (ring of 3)
+//   LOAD(2s+1) : dY fragments of the second item; drain all DMA but the 4 just issued (counted
+//                vmcnt); issue the X tile [64 t][256 ci] of step s+2 (ring of 2: X is read in
+//                even slots only)
+//
+// Every LOAD slot carries exactly 4 LDS-DMA instructions per wave. The reduction runs over the
+// live 64-row chunks of the ragged batch; the (sample, chunk) of a step is derived from the
+// per-lane scan of live chunks with one ballot (no table: the 160 KB of LDS are the two rings).
+// Rows at or past len_b are outside the step's buffer descriptors (both operands) and read as
+// zeros. The output is small against the reduction (a 1024 x 1024 Dense kernel is 16 tiles for
+// 130 steps), so the units of the last partial round are cut up to 16 ways along the reduction
+// and reduced by the last arriver (os2s_split_reduce.hpp): deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad1x1_pp_kernel(WgradArgs p) {
+  constexpr int BT = 64;
+  constexpr int TILE = BT * 256 * 2;                       // [64 rows][256 ch] bf16 = 32 KB
+  constexpr int HALF = TILE / 2;                           // one [64][128] sub-image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wn = wid & 3;
+
+  // ---- live 64-row chunks per sample (one value per lane, B <= 64), inclusive scan -----------
+  const int tchunks = (p.Tout + BT - 1) / BT;
+  int nl = 0, len_l = 0;
+  if (lane < p.B) {
+    len_l = p.Tout;
+    if (p.in_len) {
+      const int l = p.in_len[lane];
+      len_l = l < 0 ? 0 : (l < p.Tout ? l : p.Tout);
+    }
+    nl = (len_l + BT - 1) / BT;
+    nl = nl < tchunks ? nl : tchunks;
+  }
+  int scan = nl;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(scan, o, 64);
+    if (lane >= o) scan += t;
+  }
+  const int total_live = __builtin_amdgcn_readlane(scan, 63);
+
+  // ---- block -> (unit, piece): as conv1d_wgrad_pp_kernel ----------------------------------------
+  const int U = p.NCO * p.NCI, G = p.ncu;
+  const int q = U / G, r = U - q * G;
+  int f = 1;
+  {
+    int fmax = total_live / 8;                             // >= 8 steps per piece
+    fmax = fmax > 16 ? 16 : fmax;
+    if (p.force_split > 0 && p.ws_slabs) {
+      f = p.force_split < fmax ? p.force_split : (fmax > 1 ? fmax : 1);
+      while (f > 1 && r * f > p.ws_nslabs) --f;
+      if (r == 0) f = 1;
+    } else if (r > 0 && p.ws_slabs) {
+      f = split_factor(r, G, 1.1f * total_live, fmax, p.ws_nslabs);
+    }
+  }
+  const int nfull = f > 1 ? U - r : U;
+  const int nwork = nfull + (f > 1 ? r * f : 0);
+  const int bid = blockIdx.x;
+  if (bid >= nwork) return;
+  int rank = bid, piece = 0, npiece = 1;
+  if (bid >= nfull) {
+    const int i = bid - nfull;
+    rank = nfull + i / f;
+    piece = i - (i / f) * f;
+    npiece = f;
+  }
+  // the ci tiles of one co tile are adjacent ranks: they stream the same dY columns together
+  const int co0 = (rank / p.NCI) * 256, ci0 = (rank % p.NCI) * 256;
+  const int sps = (total_live + npiece - 1) / npiece;
+  const int s_begin = __builtin_amdgcn_readfirstlane(min(piece * sps, total_live));
+  const int s_end = __builtin_amdgcn_readfirstlane(min(total_live, s_begin + sps));
+  const int nsteps = s_end - s_begin;
+
+  // ---- DMA: per-lane byte offsets are fixed for the kernel --------------------------------------
+  // an instruction moves 4 rows x 256 B of a [64][128] sub-image; LDS piece ps of a row holds the
+  // channel block given by the 32-B-unit XOR swizzle (as the transpose reads expect)
+  int yv[4], xv[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    {
+      const int qq = (it * 4 + wn) * 64 + lane;
+      const int row = qq >> 4, ps = qq & 15;
+      const int u = (ps >> 1) ^ ((row & 3) << 1);
+      const int ch = co0 + grp * 128 + ((u << 1) | (ps & 1)) * 8;
+      yv[it] = ch < p.Cout ? (row * p.Cout + ch) * 2 : (int)0x80000000;
+    }
+    {
+      const int idx = it * 8 + wid;
+      const int qq = (idx & 15) * 64 + lane;
+      const int row = qq >> 4, ps = qq & 15;
+      const int u = (ps >> 1) ^ ((row & 3) << 1);
+      const int ch = ci0 + (idx >> 4) * 128 + ((u << 1) | (ps & 1)) * 8;
+      xv[it] = ch < p.Cin ? (row * (int)p.x_ld + ch) * 2 : (int)0x80000000;
+    }
+  }
+  const unsigned long long dy_base = (unsigned long long)p.dy, x_base = (unsigned long long)p.x;
+  const int ycol_bytes = __builtin_amdgcn_readfirstlane(p.Cout * 2);
+  const int xcol_bytes = __builtin_amdgcn_readfirstlane((int)p.x_ld * 2);
+  // (sample, first row, length) of live step i: the samples whose inclusive scan is <= i lie before it
+  auto entry = [&](int i, int& b, int& t0, int& len_b) {
+    const unsigned long long m = __ballot(scan <= i);
+    int bb = __builtin_popcountll(m);
+    bb = bb < p.B ? bb : p.B - 1;
+    b = __builtin_amdgcn_readfirstlane(bb);
+    const int before = b > 0 ? __builtin_amdgcn_readlane(scan, b - 1) : 0;
+    t0 = (i - before) * BT;
+    len_b = __builtin_amdgcn_readlane(len_l, b);
+  };
+  auto stage_y = [&](int b, int t0, int len_b, int slot) {   // this group's dY half
+    int rows = len_b - t0;
+    rows = rows < 0 ? 0 : (rows > BT ? BT : rows);
+    rows = __builtin_amdgcn_readfirstlane(rows);          // (a clamp compiles to v_med3: keep the descriptor scalar)
+    const unsigned long long base =
+        dy_base + ((unsigned long long)(unsigned)b * (unsigned)p.Tout + (unsigned)t0) * (unsigned)ycol_bytes;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ycol_bytes, 0x00020000);
+    char* const dst = smem + slot * TILE + grp * HALF;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs, (__attribute__((address_space(3))) void*)(dst + (it * 4 + wn) * 1024), 16, yv[it], 0, 0, 0);
+  };
+  auto stage_x = [&](int b, int t0, int len_b, int slot) {
+    int rows = len_b - t0;
+    rows = rows < 0 ? 0 : (rows > BT ? BT : rows);
+    rows = __builtin_amdgcn_readfirstlane(rows);          // (a clamp compiles to v_med3: keep the descriptor scalar)
+    const unsigned long long base =
+        x_base + ((unsigned long long)(unsigned)b * (unsigned)p.Tin + (unsigned)t0) * (unsigned)xcol_bytes;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * xcol_bytes, 0x00020000);
+    char* const dst = smem + 3 * TILE + slot * TILE;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs, (__attribute__((address_space(3))) void*)(dst + (it * 8 + wid) * 1024), 16, xv[it], 0, 0, 0);
+  };
+
+  f32x16 acc[2][2][2];                                     // [co half of the group][i][j]
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[e][i][j][v] = 0.f;
+
+  const int lhi = lane >> 5;
+  if (nsteps > 0) {
+    // per-lane constants of the transpose reads (relative to the sub-image base)
+    const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+    const int rsub = i16 >> 2, csub = (i16 & 3) * 8;
+    int ya[2][2], xa[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = 4 * e + 2 * i + g16;
+        ya[e][i] = grp * HALF + (lhi * 8 + rsub) * 256 + ((u ^ ((rsub & 3) << 1)) << 5) + csub;
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = 4 * (wn & 1) + 2 * j + g16;
+      xa[j] = (wn >> 1) * HALF + (lhi * 8 + rsub) * 256 + ((u ^ ((rsub & 3) << 1)) << 5) + csub;
+    }
+    {
+      int b, t0, len_b;
+      entry(s_begin, b, t0, len_b);
+      stage_y(b, t0, len_b, 0);
+      stage_x(b, t0, len_b, 0);
+      // only step 0 has to land before the loop starts; the 8 instructions of step 1 are drained by
+      // the counted wait of LOAD(1)
+      if (nsteps > 1) {
+        entry(s_begin + 1, b, t0, len_b);
+        stage_y(b, t0, len_b, 1);
+        stage_x(b, t0, len_b, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    wpp_barrier();                                         // (__syncthreads() would drain vmcnt(0) again)
+    if (grp) wpp_barrier();                                // group B runs one slot behind group A
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+    int yi = 0;                                            // ring slot of the current step's dY
+    for (int s = 0; s < nsteps; ++s) {
+      const unsigned ys = lds0 + yi * TILE;
+      const unsigned xs = lds0 + 3 * TILE + (s & 1) * TILE;
+      const bool more = s + 2 < nsteps;
+      bf16x8 xf[2][4], yf[2][4];
+      // ---- LOAD(2s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        xf[j][0] = lds_frag<0>(xs + xa[j]); xf[j][1] = lds_frag<1>(xs + xa[j]);
+        xf[j][2] = lds_frag<2>(xs + xa[j]); xf[j][3] = lds_frag<3>(xs + xa[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        yf[i][0] = lds_frag<0>(ys + ya[0][i]); yf[i][1] = lds_frag<1>(ys + ya[0][i]);
+        yf[i][2] = lds_frag<2>(ys + ya[0][i]); yf[i][3] = lds_frag<3>(ys + ya[0][i]);
+      }
+      int b2 = 0, t2 = 0, l2 = 0;
+      if (more) {
+        entry(s_begin + s + 2, b2, t2, l2);
+        int y2 = yi + 2;
+        y2 = y2 >= 3 ? y2 - 3 : y2;
+        stage_y(b2, t2, l2, y2);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wpp_barrier();
+      // ---- COMPUTE(2s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[0][i][j], 0, 0, 0);
+      wpp_barrier();
+      // ---- LOAD(2s+1): the tiles of step s+1 (issued a step ago) must have landed before the
+      //      next barrier pair; only the 4 dY instructions of this step may stay in flight
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        yf[i][0] = lds_frag<0>(ys + ya[1][i]); yf[i][1] = lds_frag<1>(ys + ya[1][i]);
+        yf[i][2] = lds_frag<2>(ys + ya[1][i]); yf[i][3] = lds_frag<3>(ys + ya[1][i]);
+      }
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        stage_x(b2, t2, l2, s & 1);
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      yi = yi + 1 >= 3 ? 0 : yi + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wpp_barrier();
+      // ---- COMPUTE(2s+1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[1][i][j], 0, 0, 0);
+      wpp_barrier();
+    }
+    if (!grp) wpp_barrier();
+  }
+  __syncthreads();
+
+  if (npiece > 1) {
+    const int sidx = rank - nfull;
+    auto at = [&](int v) -> f32x16& { return acc[v >> 2][(v >> 1) & 1][v & 1]; };
+    if (!split_publish_and_reduce(at, p.ws_slabs + (size_t)sidx * f * kSplitSlabFloats,
+                                  p.ws_cnt + sidx, piece, f, smem, tid))
+      return;
+  }
+
+  // ---- epilogue: the one owner of the tile writes dW (fp32), ci contiguous across lanes; the
+  //      accumulate path loads all 64 old values of a co half before the adds (see above) ---------
+  const int l31 = lane & 31;
+  const bool inside = __builtin_amdgcn_readfirstlane((co0 + 256 <= p.Cout && ci0 + 256 <= p.Cin) ? 1 : 0);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int cob = co0 + grp * 128 + e * 64, cib = ci0 + wn * 64;
+    if (inside) {
+      float* const base = p.dw + (long long)(cob + 4 * lhi) * p.Cin + cib + l31;
+      float old[2][2][16];
+      if (p.accumulate) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+              old[i][j][v] = base[(long long)(i * 32 + (v & 3) + 8 * (v >> 2)) * p.Cin + j * 32];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[e][i][j][v] += old[i][j][v];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            base[(long long)(i * 32 + (v & 3) + 8 * (v >> 2)) * p.Cin + j * 32] = acc[e][i][j][v];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ci = cib + j * 32 + l31;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int co = cob + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lhi;
+            if (co < p.Cout && ci < p.Cin) {
+              float* dst = p.dw + (long long)co * p.Cin + ci;
+              float val = acc[e][i][j][v];
+              if (p.accumulate) val += *dst;
+              *dst = val;
+            }
+          }
+        }
+    }
+  }
+}
+
 }  // namespace os2s
 
 // accumulate = 0 : dW = grad;  accumulate = 1 : dW += grad.
@@ -666,7 +992,22 @@ static int wgrad_pp_min_units() {   // experiment knob (A/B runs on one box); de
   static const int v = [] { const char* e = getenv("OS2S_WGRAD_PP_MIN_UNITS"); return e ? atoi(e) : 8; }();
   return v;
 }
-static int g_wgrad_variant = -1;   // experiment / test hook: 0 = lockstep kernel, 1 = ping-pong
+// K = 1: the 256 x 256 ping-pong tile needs a long reduction per output tile to pay for its
+// pipeline fill and the split reduction (OS2S_WGRAD1X1_PP: 0 = never, 1 = whenever the shape
+// allows, unset = by shape)
+static bool wgrad1x1_pp_auto(int B, int T, int Cin, int Cout, bool have_ws) {
+  static const int mode = [] { const char* e = getenv("OS2S_WGRAD1X1_PP"); return e ? atoi(e) : -1; }();
+  if (mode == 0) return false;
+  if (mode == 1) return true;
+  // measured (tools/bench_dense_shapes.py, 8300 rows): 2048 x 1024 and larger beat the lockstep
+  // kernel and hipBLASLt (0.073 vs 0.082 / 0.075 ms; 32768 x 1024: 0.465 vs 1.03 / 0.526 ms); a
+  // 1024 x 1024 output is 16 tiles cut 16 ways and loses to the lockstep kernel (0.071 vs 0.054 ms),
+  // as do the ragged B = 32 residual branches of Jasper below 1024 channels
+  const long long rows = (long long)B * T;
+  const int units = os2s::ceil_div(Cout, 256) * os2s::ceil_div(Cin, 256);
+  return have_ws && rows >= 2048 && units >= 32;
+}
+static int g_wgrad_variant = -1;   // experiment / test hook: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong
 static int g_wgrad_split = -1;
 static unsigned long long* g_wgrad_dbg = nullptr;
 static int g_wgrad_dbg_mode = 0;
@@ -781,6 +1122,46 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
       }
       return OS2S_OK;
     }
+  }
+
+  // ---- ping-pong kernel of the K = 1 case (Dense weight gradients) ----------------------------
+  const bool pp1_shape = K == 1 && stride == 1 && padL == 0 && Tin == Tout && B <= 64 &&
+                         Cout >= 128 && Cin >= 128 && x_row_stride * 2 * 64 < (1ll << 30) &&
+                         (long long)Cout * 2 * 64 < (1ll << 30);
+  if (pp1_shape && g_wgrad_variant != 0 && g_wgrad_variant != 1 &&
+      (g_wgrad_variant == 2 || wgrad1x1_pp_auto(B, Tout, Cin, Cout, workspace != nullptr))) {
+    a.NCO = ceil_div(Cout, 256);
+    a.NCI = ceil_div(Cin, 256);
+    a.NTP = 1;
+    a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
+    a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;
+    static std::once_flag once1;
+    static hipError_t attr_rc1 = hipSuccess;
+    static int ncu1 = 256;
+    std::call_once(once1, [] {
+      attr_rc1 = hipFuncSetAttribute((const void*)conv1d_wgrad1x1_pp_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) == hipSuccess &&
+          hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        ncu1 = n;
+    });
+    if (attr_rc1 != hipSuccess) return OS2S_ERR_LAUNCH;
+    a.ncu = ncu1;
+    const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+    if (workspace && workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
+      a.ws_cnt = reinterpret_cast<int*>(workspace);
+      a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+      size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
+      const size_t cap = (size_t)3 * ncu1;
+      a.ws_nslabs = (int)(n < cap ? n : cap);
+    }
+    const int U = a.NCO * a.NCI;
+    const int r = U % ncu1;
+    const int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
+    OS2S_LAUNCH(conv1d_wgrad1x1_pp_kernel, dim3(U + pieces), dim3(512), (size_t)160 * 1024,
+                (hipStream_t)stream, a);
+    return OS2S_OK;
   }
 
   // ---- lockstep kernel ---------------------------------------------------------------------

@@ -112,11 +112,19 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
       aoff[kk] = (grp * 128 + l31) * 128 + sw;
       woff[kk] = (wn * 64 + l31) * 128 + sw;
     }
+    // only step 0 has to land before the loop starts (a CU keeps ~16 KB of LDS-DMA in flight: the
+    // 128 KB of two steps were 8-10 k cycles of pipeline fill); the tiles of step 1 are drained by
+    // the counted wait of LOAD(1) like those of every later step
     stage_a(0, 0);
     stage_w(0, 0);
-    if (nsteps > 1) { stage_a(1, 1); stage_w(1, 1); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (nsteps > 1) {
+      stage_a(1, 1);
+      stage_w(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    gpp_barrier();                                       // (__syncthreads() would drain vmcnt(0) again)
     if (stamps && tid == 0) stamps[2] = __builtin_readcyclecounter();
     if (grp) gpp_barrier();                              // group B runs one slot behind group A
 
@@ -197,19 +205,31 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
 
 // ConvArgs is used as the argument block so that the fused epilogue is literally the convolution's:
 // B = 1, Tout = M rows, Cin = K, Cout = N, x = A (row stride x_st), w = W [N, K] contiguous.
-// MT = number of 128-row windows, MT8 = 256-row blocks per XCD, NT = 256-column tiles.
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm) {
+// MT = number of 128-row windows, MT8 = 256-row blocks per XCD in the main part, NT = 256-column tiles.
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm, int main_grid, int rem) {
   constexpr int BM = 128, BN = 256, NWIN = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wid >> 2;
-  // ---- block -> (256-row block, n-tile): per XCD, groups of gm row blocks sweep the n-tiles
-  // together (rows of A stay in that L2, every weight panel is shared by gm workgroups) ---------
   const int bid = blockIdx.x;
-  const int xcd = bid & 7, loc = bid >> 3;
-  const int mg = loc / (p.NT * gm), rr = loc - mg * (p.NT * gm);
-  const int n_idx = rr / gm, mi = rr - n_idx * gm;
-  const int m_blk = (mg * gm + mi) * 8 + xcd;
+  int m_blk, n_idx;
+  if (bid < main_grid) {
+    // ---- main part, 8 * MT8 row blocks: per XCD, groups of gm row blocks sweep the n-tiles together
+    // (rows of A stay in that L2, every weight panel is shared by gm workgroups) -------------------
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int mg = loc / (p.NT * gm), rr = loc - mg * (p.NT * gm);
+    n_idx = rr / gm;
+    const int mi = rr - n_idx * gm;
+    if (mg * gm + mi >= p.MT8) return;
+    m_blk = (mg * gm + mi) * 8 + xcd;
+  } else {
+    // ---- the last rem < 8 row blocks: their tiles go round the XCDs one by one (given to XCD 0..rem-1
+    // as whole row blocks, 8300 rows = 33 blocks put 5 blocks on XCD 0 and 4 on the others: the
+    // 32768-column vocabulary GEMM ran 20 rounds of tiles on XCD 0 and 16 elsewhere) -----------------
+    const int t = bid - main_grid;
+    n_idx = t / rem;
+    m_blk = p.MT8 * 8 + (t - n_idx * rem);
+  }
   const int m_first = m_blk * NWIN;
   if (m_first >= p.MT) return;
   const int n0 = n_idx * BN;
@@ -408,10 +428,11 @@ extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long l
   a.nchunks = K / 64;
   a.R = 128; a.Rpad = 128;
   const int mblocks = ceil_div(a.MT, 2);
-  const int per_xcd = ceil_div(mblocks, 8);
-  const int gm = per_xcd < 4 ? per_xcd : 4;
-  const int mgroups = ceil_div(per_xcd, gm);
-  a.MT8 = per_xcd;
+  const int full8 = mblocks / 8, rem = mblocks % 8;
+  const int gm = full8 < 4 ? (full8 > 0 ? full8 : 1) : 4;
+  const int mgroups = ceil_div(full8, gm);
+  a.MT8 = full8;
+  const int main_grid = 8 * mgroups * gm * a.NT;
   const size_t main_bytes = (size_t)5 * 256 * 128;    // A ring of 3 + W ring of 2 = 160 KB
   constexpr size_t kOP = 256 * 2 + 16;
   const size_t epi_bytes = conv_epilogue_lds_bytes<128, 256, 2, 512>();
@@ -423,7 +444,7 @@ extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long l
                                   160 * 1024);
   });
   if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
-  const int grid = 8 * mgroups * gm * a.NT;
-  OS2S_LAUNCH(gemm_pp_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, a, gm);
+  const int grid = main_grid + rem * a.NT;
+  OS2S_LAUNCH(gemm_pp_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, a, gm, main_grid, rem > 0 ? rem : 1);
   return OS2S_OK;
 }

@@ -13,7 +13,7 @@ import math
 import torch
 
 from ... import capi
-from ..cnns.conv_blocks import Act
+from ..cnns.conv_blocks import Act, on_side_stream
 
 
 SKINNY_MAX_ROWS = 512
@@ -22,7 +22,12 @@ LT_FUSED_DENSE = True
 # elementwise pass for the epilogue), 'pp' = the hand-written MFMA GEMM with fused epilogues
 # (csrc/gemm_pp.hip) for forward and data gradient, the in-tree weight-gradient kernel for dW
 import os as _os
-GEMM_BACKEND = _os.environ.get("OS2S_GEMM", "lt")
+GEMM_BACKEND = _os.environ.get("OS2S_GEMM", "pp")
+# Dense weight gradients on the side stream (as the conv families do): most Dense GEMMs of a
+# Transformer-big step are 132 tiles on 256 CUs (8300 tokens x 1024 columns), the split weight
+# gradient fills the other half of the chip. 22.1 -> 20.3 ms/step, sustained over 300 steps
+# (OS2S_DENSE_WGRAD_STREAM=0 keeps them on the main stream)
+DENSE_WGRAD_STREAM = _os.environ.get("OS2S_DENSE_WGRAD_STREAM", "1") == "1"
 SKINNY_LOGITS = False    # [256 x 32768 x 1024]: the LDS-tiled kernel wins (60 vs 139 us)
 
 
@@ -115,8 +120,13 @@ class Dense(object):
       # (kept on the main stream: on a side stream it wins 10 % over 20 steps but LOSES 11 % once
       # the GPU sits at its power limit — 26.6 vs 24.0 ms/step over 300 steps)
       if GEMM_BACKEND == "pp":
-        capi.conv1d_wgrad(x.data.view(1, -1, lin.cin), dz.view(1, -1, lin.cout), 1, pad_left=0,
-                          out=lin.kernel.grad, accumulate=True)
+        if DENSE_WGRAD_STREAM:
+          with on_side_stream(dz.device, x.data, dz):
+            capi.conv1d_wgrad(x.data.view(1, -1, lin.cin), dz.view(1, -1, lin.cout), 1, pad_left=0,
+                              out=lin.kernel.grad, accumulate=True)
+        else:
+          capi.conv1d_wgrad(x.data.view(1, -1, lin.cin), dz.view(1, -1, lin.cout), 1, pad_left=0,
+                            out=lin.kernel.grad, accumulate=True)
       else:
         capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
       if lin.bias is not None:

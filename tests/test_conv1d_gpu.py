@@ -349,6 +349,67 @@ def test_conv_wgrad_pingpong_full_size_vs_lockstep(cuda):
   torch.testing.assert_close(b, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,T,Cin,Cout", [(3, 420, 256, 512), (2, 333, 320, 640), (1, 1111, 1024, 1024),
+                                         (4, 200, 128, 264), (5, 97, 520, 136)])
+@pytest.mark.parametrize("split", [1, 3, -1])
+def test_conv_wgrad1x1_pingpong_kernel(cuda, B, T, Cin, Cout, split):
+  """conv1d_wgrad1x1_pp_kernel (K = 1: the Dense weight gradient, 256 x 256 tile) forced, with Cin /
+  Cout tails, ragged lengths incl. an empty sample, a row-strided X view, the reduction unsplit,
+  cut 3 ways and by the cost model: vs the fp64 product of the same bf16 values (fp32 summation
+  order is the only noise: rtol 2e-3), accumulate on top of a previous dW, bitwise run-to-run
+  reproducibility (no atomics), tickets back at zero."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(B * 131 + T + Cout)
+  xw = _bf(torch.randn(B, T, Cin + 64, generator=g))
+  x = xw[:, :, 32:32 + Cin]                                 # channel slice of a wider tensor
+  dy = _bf(torch.randn(B, T, Cout, generator=g))
+  lens = torch.randint(T // 4, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  if B > 2:
+    lens[1] = 0
+  mask = (torch.arange(T)[None, :] < lens[:, None]).double()[:, :, None]
+  ref = torch.einsum("btc,bti->ci", dy.double() * mask, x.double()).float()[None]   # [1,Cout,Cin]
+  base = torch.randn(1, Cout, Cin, generator=g)
+  xd = xw.to(cuda)[:, :, 32:32 + Cin]
+  L = _lib.lib()
+  L.os2s_conv1d_wgrad_set_variant(2, split)
+  try:
+    o1 = capi.conv1d_wgrad(xd, dy.to(cuda), 1, pad_left=0, in_len=lens.to(cuda))
+    o2 = capi.conv1d_wgrad(xd, dy.to(cuda), 1, pad_left=0, in_len=lens.to(cuda))
+    o3 = base.clone().to(cuda)
+    capi.conv1d_wgrad(xd, dy.to(cuda), 1, pad_left=0, in_len=lens.to(cuda), out=o3, accumulate=True)
+    torch.cuda.synchronize()
+  finally:
+    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+  scale = float(ref.pow(2).mean().sqrt()) + 1e-6
+  torch.testing.assert_close(o1.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
+  assert torch.equal(o1, o2)
+  torch.testing.assert_close(o3.cpu(), ref + base, rtol=2e-3, atol=2e-3 * scale)
+  assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0
+
+
+def test_conv_wgrad1x1_pingpong_dense_size_vs_lockstep(cuda):
+  """Transformer-big Dense weight gradients (8300 packed tokens; 1024 -> 1024 / 4096 / 3072 and the
+  tied-softmax 1024 -> 32768) by the cost model's split: the ping-pong kernel vs the oracle-checked
+  lockstep kernel without batch split (fp32 summation order only)."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(11)
+  N = 8300
+  L = _lib.lib()
+  for Cin, Cout in ((1024, 1024), (1024, 4096), (4096, 1024), (1024, 3072), (1024, 32768)):
+    x = _bf(torch.randn(1, N, Cin, generator=g)).to(cuda)
+    dy = _bf(torch.randn(1, N, Cout, generator=g)).to(cuda)
+    try:
+      L.os2s_conv1d_wgrad_set_variant(0, -1)
+      ref = capi.conv1d_wgrad(x, dy, 1, pad_left=0)
+      L.os2s_conv1d_wgrad_set_variant(2, -1)
+      a = capi.conv1d_wgrad(x, dy, 1, pad_left=0)
+      torch.cuda.synchronize()
+    finally:
+      L.os2s_conv1d_wgrad_set_variant(-1, -1)
+    torch.testing.assert_close(a, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2])
 def test_conv1x1_grouped_equals_single_launches(cuda, variant):
   """os2s_conv1x1_fwd_grouped (the dense-residual branches of a block end in one launch; their data
