@@ -168,6 +168,17 @@ int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* grou
 int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W, void* C,
                  long long ldc, int M, int N, int K, const float* bias, int act, float keep_prob,
                  unsigned long long seed, const uint16_t* residual, int accumulate, int out_f32);
+/* The same with a caller-owned workspace (os2s_conv1d_workspace_bytes(), the contract of
+ * os2s_conv1d_fwd_ws: tickets zero on entry and on exit, one workspace per stream): the tiles of
+ * the last partial round of workgroups are cut along K and reduced deterministically by the last
+ * arriver when the cost model says so (few output tiles x a long reduction: the data gradient of
+ * a vocabulary projection). Same result up to fp32 summation order. */
+int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W, void* C,
+                    long long ldc, int M, int N, int K, const float* bias, int act, float keep_prob,
+                    unsigned long long seed, const uint16_t* residual, int accumulate, int out_f32,
+                    void* workspace, size_t workspace_bytes);
+/* test / experiment hook: f > 0 forces the split factor, 0 disables the split, < 0 = cost model */
+void os2s_gemm_nt_set_split(int f);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,
                     float* stats, int B, int Tin, int Cin, int Cout, int K,
@@ -544,17 +555,8 @@ int os2s_tf_beam_step(os2s_stream_t stream, const void* logits, int logits_f32, 
  * (pass the beam status so that a finished search stops permuting its caches). */
 int os2s_gather_rows(os2s_stream_t stream, const void* src, const int32_t* idx, long long rows,
                      long long row_bytes, const int32_t* enable, void* dst);
-/* Plain library GEMM through hipBLASLt (the fused ops stay on the hand-written kernels):
- * C[M,N] (row-major; bf16, or fp32 when c_f32) = op(A)[M,K] . op(B)[K,N] + beta * C, bf16
- * inputs, fp32 accumulation. A is stored [M,K] (a_is_T = 0) or [K,M] (1), row stride lda; B is
- * stored [K,N] (b_is_T = 0) or [N,K] (1), row stride ldb. Replaces the tf.layers.Dense matmuls of
- * the Transformer blocks and their data / weight gradients (x W^T: B = W [N,K], b_is_T = 1;
- * dx = dz W: b_is_T = 0; dW += dy^T x: A = dy, a_is_T = 1, c_f32 = 1, beta = 1). */
-int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_T, long long lda,
-                   const uint16_t* B, int b_is_T, long long ldb, void* C, int c_f32,
-                   long long ldc, int M, int N, int K, float beta);
 /* In place on bf16 y [rows, C]: y = residual + dropout(act(y + bias)) — the epilogue of a Dense
- * layer whose matmul ran in os2s_matmul_lt (same semantics and dropout stream as the fused
+ * layer whose matmul ran as a bare GEMM (same semantics and dropout stream as the fused
  * epilogue of os2s_conv1d_fwd_ex with K = 1; act 1 = ReLU). bias / residual may be NULL. */
 int os2s_dense_epilogue(os2s_stream_t stream, uint16_t* y, const float* bias, long long rows, int C,
                         int act, float keep_prob, unsigned long long seed, const uint16_t* residual);

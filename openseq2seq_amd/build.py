@@ -73,7 +73,7 @@ def build_hip(force: bool = False, verbose: bool = False, only=None) -> str:
       list(ex.map(cc, jobs))
   if jobs or _newer(LIB_PATH, objs):
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH]
-         + objs + ["-L/opt/rocm/lib", "-lhipblaslt", "-Wl,-rpath,/opt/rocm/lib"])
+         + objs + ["-Wl,-rpath,/opt/rocm/lib"])
   return LIB_PATH
 
 

@@ -546,8 +546,8 @@ def _lt_unsupported(e):
 
 def gemm(x2d, w, **kw):
   """x2d [N,Cin] bf16, w [Cout,Cin] bf16 -> [N,Cout]. A bare matmul (no bias / activation /
-  dropout / residual / fp32 output) runs in hipBLASLt (os2s_matmul_lt); everything with a fused
-  epilogue is the K=1 case of the in-tree conv1d_fwd kernel."""
+  dropout / residual / fp32 output) with enough rows runs on the 256 x 256 ping-pong tile
+  (os2s_gemm_nt); everything else is the K=1 case of the in-tree conv1d_fwd kernel."""
   plain = (all(kw.get(k) is None for k in ("bias", "residual", "stats", "in_len", "out_len"))
            and not kw.get("act", 0) and not kw.get("out_f32", False) and not kw.get("time_major", False)
            and kw.get("keep_prob", 1.0) >= 1.0)
@@ -587,18 +587,39 @@ def gemm_nt(a, w, out=None, bias=None, act=0, keep_prob=1.0, seed=0, residual=No
     out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
   assert out.stride(1) == 1 and tuple(out.shape) == (M, N)
   assert residual is None or (residual.stride(1) == 1 and residual.stride(0) == out.stride(0))
-  f = _fn("os2s_gemm_nt", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
-                          c_void_p, c_int, c_float, c_uint64, c_void_p, c_int, c_int))
+  ws = conv1d_workspace(a.device)
+  f = _fn("os2s_gemm_nt_ws", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                             c_void_p, c_int, c_float, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t))
   _lib.check(f(_stream(), c_void_p(a.data_ptr()), a.stride(0), c_void_p(w.data_ptr()),
                c_void_p(out.data_ptr()), out.stride(0), M, N, K, _ptr(bias, torch.float32, True),
                int(act), float(keep_prob), int(seed) & (2**64 - 1),
                c_void_p(residual.data_ptr()) if residual is not None else c_void_p(0),
-               int(bool(accumulate)), int(out.dtype == torch.float32)), "os2s_gemm_nt")
+               int(bool(accumulate)), int(out.dtype == torch.float32), _ptr(ws), ws.numel()), "os2s_gemm_nt_ws")
   return out
 
 
+_lt_lib = None
+
+
+def _lt():
+  """The hipBLASLt comparison library (tools/lt, built by tools/lt/build.sh): A/B runs only."""
+  global _lt_lib
+  if _lt_lib is None:
+    import ctypes
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lt", "libos2s_lt.so")
+    if not os.path.exists(path):
+      raise _lib.Os2sError("OS2S_GEMM=lt / matmul_lt need the comparison library: run tools/lt/build.sh "
+                           "(the product library does not link hipBLASLt)")
+    _lt_lib = ctypes.CDLL(path)
+    _lt_lib.os2s_lt_matmul.restype = c_int
+    _lt_lib.os2s_lt_matmul.argtypes = [c_void_p, c_void_p, c_int, c_ll, c_void_p, c_int, c_ll, c_void_p, c_int,
+                                       c_ll, c_int, c_int, c_int, c_float]
+  return _lt_lib
+
+
 def matmul_lt(a, b, a_is_t=False, b_is_t=False, out=None, out_f32=False, beta=0.0):
-  """out[M,N] = op(a) @ op(b) (+ beta * out) via hipBLASLt; a, b bf16 2-D (row stride free)."""
+  """out[M,N] = op(a) @ op(b) (+ beta * out) via hipBLASLt (comparison back end, tools/lt); a, b
+  bf16 2-D (row stride free)."""
   M, K = (a.shape[1], a.shape[0]) if a_is_t else (a.shape[0], a.shape[1])
   K2, N = (b.shape[1], b.shape[0]) if b_is_t else (b.shape[0], b.shape[1])
   assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -606,11 +627,10 @@ def matmul_lt(a, b, a_is_t=False, b_is_t=False, out=None, out_f32=False, beta=0.
     assert beta == 0.0
     out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
   assert out.stride(1) == 1 and tuple(out.shape) == (M, N)
-  f = _fn("os2s_matmul_lt", (c_void_p, c_void_p, c_int, c_ll, c_void_p, c_int, c_ll, c_void_p, c_int, c_ll,
-                            c_int, c_int, c_int, c_float))
-  _lib.check(f(_stream(), c_void_p(a.data_ptr()), int(a_is_t), a.stride(0), c_void_p(b.data_ptr()), int(b_is_t),
-               b.stride(0), c_void_p(out.data_ptr()), int(out.dtype == torch.float32), out.stride(0), M, N, K,
-               float(beta)), "os2s_matmul_lt")
+  _lib.check(_lt().os2s_lt_matmul(_stream(), c_void_p(a.data_ptr()), int(a_is_t), a.stride(0),
+                                  c_void_p(b.data_ptr()), int(b_is_t), b.stride(0), c_void_p(out.data_ptr()),
+                                  int(out.dtype == torch.float32), out.stride(0), M, N, K, float(beta)),
+             "os2s_lt_matmul")
   return out
 
 

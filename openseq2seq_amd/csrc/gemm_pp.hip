@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "conv1d_common.hpp"
+#include "os2s_split_reduce.hpp"
 
 namespace os2s {
 
@@ -42,9 +43,13 @@ __device__ __forceinline__ void gpp_barrier() {
 // 128 rows this wave's GROUP owns (first row, bytes that may be read from there: rows past it are
 // out of the descriptor's range and read as zeros); everything else comes from p: x_st = row
 // stride of A, Cin = reduction length (multiple of 64, nchunks = Cin / 64), w = W [Cout, Cin].
+// The tile covers the 64-deep steps c_beg .. c_beg + nsteps - 1 of the reduction; a piece of a split
+// unit (sp.f > 1) publishes its fp32 partial tile and only the last arriver runs the epilogue.
+struct GppSplit { float* slab0; int* ticket; int piece, f; };
 __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half, long long a_bytes, int n0,
                                          const int (&wb)[2], const int (&wt0)[2], const int (&wmid)[2],
-                                         char* smem, unsigned long long* stamps = nullptr) {
+                                         char* smem, int c_beg, int nsteps, const GppSplit& sp,
+                                         unsigned long long* stamps = nullptr) {
   constexpr int BM = 128, BN = 256, NWIN = 2, WM = 2, WN = 4;
   constexpr int MI = 4, NI = 2;
   constexpr int TILE = 256 * 128;                        // one operand tile: 256 rows x 64 k (bf16)
@@ -101,7 +106,6 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[in][im][e] = 0.f;
 
-  const int nsteps = p.nchunks;                          // 64-deep steps
   {
     const int l31 = lane & 31, lhi = lane >> 5;
     // fragment offsets inside a tile: 16-B slot (kk*2 + lhi) ^ swizzle(row)
@@ -115,11 +119,11 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
     // only step 0 has to land before the loop starts (a CU keeps ~16 KB of LDS-DMA in flight: the
     // 128 KB of two steps were 8-10 k cycles of pipeline fill); the tiles of step 1 are drained by
     // the counted wait of LOAD(1) like those of every later step
-    stage_a(0, 0);
-    stage_w(0, 0);
+    stage_a(c_beg, 0);
+    stage_w(c_beg, 0);
     if (nsteps > 1) {
-      stage_a(1, 1);
-      stage_w(1, 1);
+      stage_a(c_beg + 1, 1);
+      stage_w(c_beg + 1, 1);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -148,7 +152,7 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
       {
         int a2 = ai + 2;
         a2 = a2 >= 3 ? a2 - 3 : a2;
-        if (more) stage_a(s + 2, a2);
+        if (more) stage_a(c_beg + s + 2, a2);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       gpp_barrier();
@@ -171,7 +175,7 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
       // W tile of step s+1 (issued a step ago) is read right after the next barrier pair
       if (more) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        stage_w(s + 2, PB);
+        stage_w(c_beg + s + 2, PB);
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -196,6 +200,10 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
   }
   __syncthreads();
   if (stamps && tid == 0) stamps[3] = __builtin_readcyclecounter();
+  if (sp.f > 1) {
+    auto at = [&](int v) -> f32x16& { return acc[v >> 2][v & 3]; };
+    if (!split_publish_and_reduce(at, sp.slab0, sp.ticket, sp.piece, sp.f, smem, tid)) return;
+  }
   conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
   if (stamps) {
     __syncthreads();
@@ -205,33 +213,43 @@ __device__ __forceinline__ void gpp_tile(const ConvArgs& p, const bf16_t* a_half
 
 // ConvArgs is used as the argument block so that the fused epilogue is literally the convolution's:
 // B = 1, Tout = M rows, Cin = K, Cout = N, x = A (row stride x_st), w = W [N, K] contiguous.
-// MT = number of 128-row windows, MT8 = 256-row blocks per XCD in the main part, NT = 256-column tiles.
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm, int main_grid, int rem) {
+// MT = number of 128-row windows, MT8 = 256-row blocks per XCD in the main part, NT = 256-column
+// tiles. Units are ranked 0 .. U-1; the units at rank >= nfull (the last partial round of
+// workgroups, chosen on the host by the cost model of os2s_split_reduce.hpp) are cut f ways along
+// K: a vocabulary-sized reduction over few output tiles (the data gradient of a 32 k softmax into
+// a 512-wide layer: 50 tiles x 512 steps) otherwise runs on a fifth of the chip.
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm, int rem, int nfull, int f) {
   constexpr int BM = 128, BN = 256, NWIN = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wid >> 2;
   const int bid = blockIdx.x;
+  int rank = bid, piece = 0, npiece = 1;
+  if (bid >= nfull) {
+    const int i = bid - nfull;
+    rank = nfull + i / f;
+    piece = i - (i / f) * f;
+    npiece = f;
+  }
+  const int u_main = 8 * p.MT8 * p.NT;
   int m_blk, n_idx;
-  if (bid < main_grid) {
+  if (rank < u_main) {
     // ---- main part, 8 * MT8 row blocks: per XCD, groups of gm row blocks sweep the n-tiles together
     // (rows of A stay in that L2, every weight panel is shared by gm workgroups) -------------------
-    const int xcd = bid & 7, loc = bid >> 3;
+    const int xcd = rank & 7, loc = rank >> 3;
     const int mg = loc / (p.NT * gm), rr = loc - mg * (p.NT * gm);
-    n_idx = rr / gm;
-    const int mi = rr - n_idx * gm;
-    if (mg * gm + mi >= p.MT8) return;
-    m_blk = (mg * gm + mi) * 8 + xcd;
+    const int left = p.MT8 - mg * gm, gl = left < gm ? left : gm;   // blocks in this group
+    n_idx = rr / gl;
+    m_blk = (mg * gm + (rr - n_idx * gl)) * 8 + xcd;
   } else {
     // ---- the last rem < 8 row blocks: their tiles go round the XCDs one by one (given to XCD 0..rem-1
     // as whole row blocks, 8300 rows = 33 blocks put 5 blocks on XCD 0 and 4 on the others: the
     // 32768-column vocabulary GEMM ran 20 rounds of tiles on XCD 0 and 16 elsewhere) -----------------
-    const int t = bid - main_grid;
+    const int t = rank - u_main;
     n_idx = t / rem;
     m_blk = p.MT8 * 8 + (t - n_idx * rem);
   }
   const int m_first = m_blk * NWIN;
-  if (m_first >= p.MT) return;
   const int n0 = n_idx * BN;
   int wb[NWIN], wt0[NWIN], wmid[NWIN];
 #pragma unroll
@@ -241,7 +259,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm, int
     wmid[w] = (m_first + w < p.MT) ? m_first + w : -1;
   }
   const int m0 = m_first * BM + grp * BM;                // first row of this group's half
-  gpp_tile(p, p.x + (long long)m0 * p.x_st, (long long)(p.Tout - m0) * p.x_st * 2, n0, wb, wt0, wmid, smem);
+  const int c_beg = __builtin_amdgcn_readfirstlane(piece * p.nchunks / npiece);
+  const int c_end = __builtin_amdgcn_readfirstlane((piece + 1) * p.nchunks / npiece);
+  GppSplit sp;
+  sp.f = npiece; sp.piece = piece;
+  sp.slab0 = npiece > 1 ? p.ws_slabs + (size_t)(rank - nfull) * f * kSplitSlabFloats : nullptr;
+  sp.ticket = npiece > 1 ? p.ws_cnt + (rank - nfull) : nullptr;
+  gpp_tile(p, p.x + (long long)m0 * p.x_st, (long long)(p.Tout - m0) * p.x_st * 2, n0, wb, wt0, wmid, smem,
+           c_beg, c_end - c_beg, sp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,8 +386,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(ConvArgs p, ConvGrou
   }
   const int b_own = grp ? wb[1] : wb[0], t_own = grp ? wt0[1] : wt0[0], len_own = grp ? wlen[1] : wlen[0];
   if (stamps && tid == 0) { stamps[1] = __builtin_readcyclecounter(); stamps[5] = (unsigned long long)p.nchunks; }
+  GppSplit sp;
+  sp.f = 1; sp.piece = 0; sp.slab0 = nullptr; sp.ticket = nullptr;
   gpp_tile(p, p.x + (long long)b_own * p.x_sb + (long long)t_own * p.x_st,
-           (long long)(len_own - t_own) * p.x_st * 2, n_idx * BN, wb, wt0, wmid, smem, stamps);
+           (long long)(len_own - t_own) * p.x_st * 2, n_idx * BN, wb, wt0, wmid, smem, 0, p.nchunks, sp, stamps);
 }
 
 // Host side of conv1x1_pp_kernel. `a` carries the batch geometry (B, Tin = Tout = T, in_len, out_len)
@@ -399,13 +426,16 @@ int launch_conv1x1_pp(hipStream_t stream, ConvArgs a, ConvGroupTable gt) {
 
 }  // namespace os2s
 
+static int g_gemm_split = -1;
+
 // C[M,N] = A[M,K] . W[N,K]^T with the fused epilogue C = residual + dropout(act(. + bias)),
 // optional accumulation into C (bf16) and fp32 output. lda / ldc / residual row stride in
-// elements; W is contiguous [N, K].
-extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
-                            void* C, long long ldc, int M, int N, int K, const float* bias, int act,
-                            float keep_prob, unsigned long long seed, const uint16_t* residual,
-                            int accumulate, int out_f32) {
+// elements; W is contiguous [N, K]. With a workspace (os2s_conv1d_workspace_bytes(), zero tickets,
+// one per stream) the last partial round of tiles is cut along K when the cost model says so.
+extern "C" int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
+                               void* C, long long ldc, int M, int N, int K, const float* bias, int act,
+                               float keep_prob, unsigned long long seed, const uint16_t* residual,
+                               int accumulate, int out_f32, void* workspace, size_t workspace_bytes) {
   using namespace os2s;
   OS2S_REQUIRE(A && W && C && M >= 1 && N >= 1 && K >= 64 && K % 64 == 0);
   OS2S_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N);
@@ -430,21 +460,57 @@ extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long l
   const int mblocks = ceil_div(a.MT, 2);
   const int full8 = mblocks / 8, rem = mblocks % 8;
   const int gm = full8 < 4 ? (full8 > 0 ? full8 : 1) : 4;
-  const int mgroups = ceil_div(full8, gm);
   a.MT8 = full8;
-  const int main_grid = 8 * mgroups * gm * a.NT;
   const size_t main_bytes = (size_t)5 * 256 * 128;    // A ring of 3 + W ring of 2 = 160 KB
-  constexpr size_t kOP = 256 * 2 + 16;
   const size_t epi_bytes = conv_epilogue_lds_bytes<128, 256, 2, 512>();
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
+  static int ncu = 256;
   std::call_once(once, [] {
     attr_rc = hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n;
   });
   if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
-  const int grid = main_grid + rem * a.NT;
-  OS2S_LAUNCH(gemm_pp_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, a, gm, main_grid, rem > 0 ? rem : 1);
+  a.ncu = ncu;
+  // ---- tail split (decided here: nothing about the launch is only known on the device) ---------
+  const int U = mblocks * a.NT;
+  const int r = U % ncu;
+  int f = 1;
+  const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+  if (r > 0 && workspace && workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
+    a.ws_cnt = reinterpret_cast<int*>(workspace);
+    a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+    size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
+    const size_t cap = (size_t)3 * ncu;
+    a.ws_nslabs = (int)(n < cap ? n : cap);
+    int fmax = a.nchunks / 8;                           // >= 8 steps per piece
+    fmax = fmax > 16 ? 16 : fmax;
+    // a round of whole units: ~1.05 us per 64-deep step + ~10 us of fill and epilogue
+    if (g_gemm_split > 0) {
+      f = g_gemm_split < fmax ? g_gemm_split : (fmax > 1 ? fmax : 1);
+      while (f > 1 && r * f > a.ws_nslabs) --f;
+    } else if (g_gemm_split < 0 && fmax > 1) {
+      f = split_factor(r, ncu, 1.05f * a.nchunks + 10.f, fmax, a.ws_nslabs);
+    }
+  }
+  const int nfull = f > 1 ? U - r : U;
+  const int grid = nfull + (f > 1 ? r * f : 0);
+  OS2S_LAUNCH(gemm_pp_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, a, gm, rem > 0 ? rem : 1, nfull, f);
   return OS2S_OK;
 }
+
+extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
+                            void* C, long long ldc, int M, int N, int K, const float* bias, int act,
+                            float keep_prob, unsigned long long seed, const uint16_t* residual,
+                            int accumulate, int out_f32) {
+  return os2s_gemm_nt_ws(stream, A, lda, W, C, ldc, M, N, K, bias, act, keep_prob, seed, residual, accumulate,
+                         out_f32, nullptr, 0);
+}
+
+// test / experiment hook: > 0 forces the tail split factor, 0 disables the split, < 0 = cost model
+extern "C" void os2s_gemm_nt_set_split(int f) { g_gemm_split = f; }

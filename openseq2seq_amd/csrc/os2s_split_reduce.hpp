@@ -82,7 +82,7 @@ __device__ __forceinline__ bool split_publish_and_reduce(At&& at, float* slab0, 
 // after the epilogue work of round 2): a split unit adds ~20 us (pipeline fill, partial-tile store
 // + release, reducer epilogue), ~1.5 us per partial tile the reducer reads back and 0.17 us per
 // piece of aggregate workspace traffic.
-__device__ __forceinline__ int split_factor(int r, int G, float round_us, int fmax, int max_pieces) {
+__host__ __device__ __forceinline__ int split_factor(int r, int G, float round_us, int fmax, int max_pieces) {
   int f = 1;
   float best = round_us;
   for (int ff = 2; ff <= fmax; ++ff) {

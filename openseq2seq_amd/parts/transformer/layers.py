@@ -17,10 +17,10 @@ from ..cnns.conv_blocks import Act, on_side_stream
 
 
 SKINNY_MAX_ROWS = 512
-LT_FUSED_DENSE = True
-# GEMM back end of the Dense / tied-softmax layers: 'lt' = hipBLASLt for bare matmuls (+ one
-# elementwise pass for the epilogue), 'pp' = the hand-written MFMA GEMM with fused epilogues
-# (csrc/gemm_pp.hip) for forward and data gradient, the in-tree weight-gradient kernel for dW
+# GEMM back end of the Dense / tied-softmax layers: 'pp' (default) = the hand-written MFMA GEMM
+# with fused epilogues (csrc/gemm_pp.hip) for forward and data gradient and the in-tree
+# weight-gradient kernels for dW; 'lt' = hipBLASLt for the matmuls + one elementwise pass for the
+# epilogue (comparison runs; needs tools/lt/build.sh)
 import os as _os
 GEMM_BACKEND = _os.environ.get("OS2S_GEMM", "pp")
 # Dense weight gradients on the side stream (as the conv families do): most Dense GEMMs of a
@@ -85,22 +85,16 @@ class Dense(object):
       # decoding step: a few hundred rows — latency-bound kernel (csrc/gemm_skinny.hip)
       return Act(capi.gemm_skinny(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
                                   relu=(act == 1), residual=residual.data if residual is not None else None))
-    plain = act == 0 and keep >= 1.0 and residual is None and self.bias is None
-    if GEMM_BACKEND == "pp" and self.cin % 64 == 0:
-      y = capi.gemm_nt(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
-                       act=act, keep_prob=keep, seed=seed,
-                       residual=residual.data if residual is not None else None)
-    elif plain:
+    bias = self.bias.master if self.bias is not None else None
+    res = residual.data if residual is not None else None
+    if GEMM_BACKEND == "lt":       # comparison runs: vendor matmul + one elementwise epilogue pass
       y = capi.matmul_lt(x.data, self.w, b_is_t=True)
-    elif max(self.cin, self.cout) > min(self.cin, self.cout) and LT_FUSED_DENSE:
-      y = capi.matmul_lt(x.data, self.w, b_is_t=True)
-      capi.dense_epilogue(y, bias=self.bias.master if self.bias is not None else None, act=act,
-                          keep_prob=keep, seed=seed,
-                          residual=residual.data if residual is not None else None)
+      if not (act == 0 and keep >= 1.0 and residual is None and self.bias is None):
+        capi.dense_epilogue(y, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
+    elif self.cin % 64 == 0:
+      y = capi.gemm_nt(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
     else:
-      y = capi.gemm(x.data, self.w, bias=self.bias.master if self.bias is not None else None,
-                    act=act, keep_prob=keep, seed=seed,
-                    residual=residual.data if residual is not None else None)
+      y = capi.gemm(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
     out = Act(y)
     if tape is None:
       return out
@@ -119,24 +113,21 @@ class Dense(object):
       # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs
       # (kept on the main stream: on a side stream it wins 10 % over 20 steps but LOSES 11 % once
       # the GPU sits at its power limit — 26.6 vs 24.0 ms/step over 300 steps)
-      if GEMM_BACKEND == "pp":
-        if DENSE_WGRAD_STREAM:
-          with on_side_stream(dz.device, x.data, dz):
-            capi.conv1d_wgrad(x.data.view(1, -1, lin.cin), dz.view(1, -1, lin.cout), 1, pad_left=0,
-                              out=lin.kernel.grad, accumulate=True)
-        else:
-          capi.conv1d_wgrad(x.data.view(1, -1, lin.cin), dz.view(1, -1, lin.cout), 1, pad_left=0,
-                            out=lin.kernel.grad, accumulate=True)
-      else:
+      if GEMM_BACKEND == "lt":
         capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
+      elif DENSE_WGRAD_STREAM:
+        with on_side_stream(dz.device, x.data, dz):
+          capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
+      else:
+        capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
       if lin.bias is not None:
         _colsum_into(dz, lin.bias)
       if x.requires_grad:
         g = x.grad_buffer()
-        if GEMM_BACKEND == "pp" and lin.cout % 64 == 0:
-          capi.gemm_nt(dz, lin.kernel.wt16.view(lin.cin, lin.cout), out=g, accumulate=x.grad_init)
-        else:
+        if GEMM_BACKEND == "lt":
           capi.matmul_lt(dz, lin.w, out=g, beta=1.0 if x.grad_init else 0.0)
+        else:
+          capi.gemm(dz, lin.kernel.wt16.view(lin.cin, lin.cout), out=g, accumulate=x.grad_init)
         x.grad_init = True
       if residual is not None:
         residual.res_grad = dy      # consumed by the pre-norm LayerNorm backward of `residual`
@@ -286,10 +277,10 @@ class SharedEmbedding(object):
     """logits = x E^T  (bf16 [N, V])."""
     if tape is None and x.data.shape[0] <= SKINNY_MAX_ROWS and SKINNY_LOGITS:
       return Act(capi.gemm_skinny(x.data, self.table))
-    if GEMM_BACKEND == "pp" and self.D % 64 == 0:
-      y = capi.gemm_nt(x.data, self.table)
-    else:
+    if GEMM_BACKEND == "lt":
       y = capi.matmul_lt(x.data, self.table, b_is_t=True)
+    else:
+      y = capi.gemm(x.data, self.table)
     out = Act(y)
     if tape is not None:
       emb = self
@@ -298,13 +289,12 @@ class SharedEmbedding(object):
         dy = out.grad
         assert dy is not None
         g = x.grad_buffer()
-        if GEMM_BACKEND == "pp" and emb.V % 64 == 0:
-          capi.conv1d_wgrad(x.data.view(1, -1, emb.D), dy.view(1, -1, emb.V), 1, pad_left=0,
-                            out=emb.weights.grad, accumulate=True)
-          capi.gemm_nt(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
-        else:
+        if GEMM_BACKEND == "lt":
           capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
           capi.matmul_lt(dy, emb.table, out=g, beta=1.0 if x.grad_init else 0.0)
+        else:
+          capi.gemm_wgrad(x.data, dy, emb.weights.grad.view(emb.V, emb.D), accumulate=True)
+          capi.gemm(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
         x.grad_init = True
         out.grad = None
 

@@ -54,3 +54,37 @@ def test_gemm_nt_epilogue_accumulate_and_strided_a(cuda):
   acc = base.clone()
   capi.gemm_nt(a, w, out=acc, accumulate=True)
   torch.testing.assert_close(acc.float(), base.float() + a.float() @ w.float().t(), rtol=1e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(1500, 512, 4096), (6400, 512, 8192), (300, 264, 2048), (8300, 1024, 1024)])
+@pytest.mark.parametrize("split", [0, 3, 8, -1])
+def test_gemm_nt_tail_split(cuda, M, N, K, split):
+  """The last partial round of 256 x 256 tiles cut along K (forced 3 / 8 ways, off, cost model):
+  fp32 output equal to the unsplit result up to summation order (rtol 1e-4 of the largest value),
+  bf16 output with the fused epilogue within one rounding step of the unsplit one, bitwise
+  run-to-run reproducibility, tickets back at zero. Shapes: few tiles x a long reduction (the
+  vocabulary data gradient of the NMT config), ragged N, and a many-tile GEMM where r = U mod 256
+  tiles of the second round are cut."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(M + N + K)
+  a = _bf(torch.randn(M, K, generator=g)).to(cuda)
+  w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(cuda)
+  bias = torch.randn(N, generator=g).to(cuda)
+  L = _lib.lib()
+  try:
+    L.os2s_gemm_nt_set_split(0)
+    ref32 = capi.gemm_nt(a, w, out_f32=True)
+    ref16 = capi.gemm_nt(a, w, bias=bias, act=1)
+    L.os2s_gemm_nt_set_split(split)
+    y32 = capi.gemm_nt(a, w, out_f32=True)
+    y32b = capi.gemm_nt(a, w, out_f32=True)
+    y16 = capi.gemm_nt(a, w, bias=bias, act=1)
+    torch.cuda.synchronize()
+  finally:
+    L.os2s_gemm_nt_set_split(-1)
+  torch.testing.assert_close(y32, ref32, rtol=1e-4, atol=1e-4 * float(ref32.abs().max()))
+  assert torch.equal(y32, y32b)
+  torch.testing.assert_close(y16.float(), ref16.float(), rtol=1e-2, atol=1e-2)
+  full = a.float() @ w.float().t()
+  torch.testing.assert_close(y32, full, rtol=2e-3, atol=2e-3 * float(full.pow(2).mean().sqrt()))
+  assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0

@@ -196,37 +196,43 @@ def test_attention_fwd_long(cuda, causal, cross):
     oq += lq[b]; ok += lk[b]
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 1024, 512), (4096, 3072, 1024), (77, 40, 72)])
-def test_matmul_lt(cuda, M, N, K):
-  """os2s_matmul_lt (hipBLASLt) in the three roles of a Dense layer vs fp32 references on the
-  same bf16 inputs: forward x W^T, data gradient dz W, weight gradient dW += dy^T x (fp32 out,
-  beta 1). bf16 outputs: rtol 1e-2; fp32 output: 2e-3 of the rms."""
+@pytest.mark.parametrize("M,N,K", [(300, 1024, 512), (4096, 3072, 1024), (8300, 1024, 4096), (777, 520, 192)])
+def test_bare_matmuls_in_tree(cuda, M, N, K):
+  """The three roles of a Dense layer as bare matmuls on the in-tree kernels (capi.gemm ->
+  os2s_gemm_nt, capi.gemm_wgrad -> conv1d_wgrad: ping-pong 256 x 256 tiles, lockstep below
+  their thresholds) vs fp32 references on the same bf16 inputs: forward x W^T, data gradient
+  dz W (+ accumulate into an existing bf16 buffer), weight gradient dW += dy^T x (fp32 out), a
+  column-slice view as input. bf16 outputs: rtol 1e-2; fp32 output: 2e-3 of the rms."""
   from openseq2seq_amd import capi
   g = torch.Generator().manual_seed(M + N + K)
   x = _bf(torch.randn(M, K, generator=g)).to(cuda)
   w = _bf(torch.randn(N, K, generator=g) / K ** 0.5).to(cuda)
   dz = _bf(torch.randn(M, N, generator=g)).to(cuda)
-  y = capi.matmul_lt(x, w, b_is_t=True)
+  y = capi.gemm(x, w)
   ref = x.float() @ w.float().t()
   torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=2e-2)
-  dx = capi.matmul_lt(dz, w)
+  wt = w.t().contiguous()
+  dx = capi.gemm(dz, wt)
   ref = dz.float() @ w.float()
   torch.testing.assert_close(dx.float(), ref, rtol=1e-2, atol=2e-2 * float(ref.std()))
-  # accumulate into an existing bf16 buffer
-  dx2 = capi.matmul_lt(dz, w, out=dx.clone(), beta=1.0)
+  dx2 = capi.gemm(dz, wt, out=dx.clone(), accumulate=True)
   torch.testing.assert_close(dx2.float(), 2 * ref, rtol=2e-2, atol=4e-2 * float(ref.std()))
   base = torch.randn(N, K, generator=g).to(cuda)
-  dw = capi.matmul_lt(dz, x, a_is_t=True, out=base.clone(), beta=1.0)
+  dw = base.clone()
+  capi.gemm_wgrad(x, dz, dw, accumulate=True)
   ref = base + dz.float().t() @ x.float()
   torch.testing.assert_close(dw, ref, rtol=2e-3, atol=2e-3 * float(ref.std()))
-  # strided views (column slices of fused projections)
   wide = _bf(torch.randn(M, 2 * K, generator=g)).to(cuda)
-  y2 = capi.matmul_lt(wide[:, K:], w, b_is_t=True)
+  y2 = capi.gemm(wide[:, K:], w)
   torch.testing.assert_close(y2.float(), wide[:, K:].float() @ w.float().t(), rtol=1e-2, atol=2e-2)
+  dw2 = torch.zeros(N, K, device=cuda)
+  capi.gemm_wgrad(wide[:, K:], dz, dw2, accumulate=False)
+  ref = dz.float().t() @ wide[:, K:].float()
+  torch.testing.assert_close(dw2, ref, rtol=2e-3, atol=2e-3 * float(ref.std()))
 
 
 def test_dense_epilogue_matches_fused_gemm(cuda):
-  """os2s_matmul_lt + os2s_dense_epilogue == the fused in-tree GEMM epilogue (bias, ReLU, dropout
+  """bare os2s_gemm_nt + os2s_dense_epilogue == the fused in-tree GEMM epilogue (bias, ReLU, dropout
   with the same (seed, element) stream, residual): identical dropout pattern, values to bf16
   rounding of the intermediate (atol 3e-2)."""
   from openseq2seq_amd import capi
@@ -238,7 +244,7 @@ def test_dense_epilogue_matches_fused_gemm(cuda):
   r = _bf(torch.randn(M, N, generator=g)).to(cuda)
   for act, keep, res in ((1, 0.7, None), (0, 0.9, r), (0, 1.0, r), (1, 1.0, None)):
     fused = capi.gemm(x, w, bias=b, act=act, keep_prob=keep, seed=11, residual=res)
-    y = capi.matmul_lt(x, w, b_is_t=True)
+    y = capi.gemm_nt(x, w)
     capi.dense_epilogue(y, bias=b, act=act, keep_prob=keep, seed=11, residual=res)
     torch.testing.assert_close(y.float(), fused.float(), atol=3e-2, rtol=2e-2)
     if keep < 1.0 and act == 0:      # dropped elements are exactly the residual (or 0)

@@ -1,13 +1,9 @@
-// Plain library GEMMs through hipBLASLt.
+// hipBLASLt comparison back end — NOT part of the product library. Since round 2 every matmul of
+// the models runs on the in-tree MFMA kernels (os2s_gemm_nt, conv1d_wgrad1x1_pp_kernel, the conv /
+// recurrent kernels); this wrapper is kept for A/B measurements only (OS2S_GEMM=lt, tools/bench_*):
+// tools/lt/build.sh builds tools/lt/libos2s_lt.so, which openseq2seq_amd.capi.matmul_lt loads on
+// demand. libos2s_hip.so does not link the vendor library.
 //
-// The hand-written MFMA kernels of this library carry the fused ops (implicit-GEMM conv with
-// window reuse + BN statistics, attention, the decoding-step GEMMs, recurrent steps). A bare
-// C = op(A) . op(B) (+ beta C) with tokens x hidden shapes — the q/k/v, vocabulary and
-// feed-forward projections of the Transformer (tf.layers.Dense calls in
-// open_seq2seq/parts/transformer/{attention_layer,ffn_layer,embedding_layer}.py), their data
-// gradients and their weight gradients — is exactly what the vendor library is tuned for
-// (measured on MI355X, bf16, M = 16384: 1.0-1.5 PFLOP/s vs 0.63-0.92 for the in-tree 1x1-conv
-// GEMM, whose 128/256-row tiles meet the L2->LDS delivery limit first), so those go here.
 // Row-major in, row-major out; descriptors + heuristics are cached per problem.
 #include <hipblaslt/hipblaslt.h>
 
@@ -15,9 +11,13 @@
 #include <map>
 #include <mutex>
 
-#include "os2s_common.hpp"
+#include "../../openseq2seq_amd/csrc/os2s_common.hpp"
+
+#include <cstdio>
 
 namespace {
+
+void lt_note(int status, const char* where) { fprintf(stderr, "[os2s_lt] %s: status %d\n", where, status); }
 
 struct LtPlan {
   hipblasLtMatmulDesc_t desc = nullptr;
@@ -52,7 +52,7 @@ std::map<std::array<long long, 10>, LtPlan> g_plans;
 
 // C[M,N] (row-major, bf16 or fp32) = op(A)[M,K] . op(B)[K,N] + beta * C, bf16 inputs, fp32
 // accumulation. A is stored [M,K] (a_is_T = 0) or [K,M] (1); B is stored [K,N] (0) or [N,K] (1).
-extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_T, long long lda,
+extern "C" int os2s_lt_matmul(os2s_stream_t stream, const uint16_t* A, int a_is_T, long long lda,
                               const uint16_t* B, int b_is_T, long long ldb, void* C, int c_f32,
                               long long ldc, int M, int N, int K, float beta) {
   OS2S_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && lda >= 1 && ldb >= 1 && ldc >= N);
@@ -89,7 +89,7 @@ extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_
                                                                pref, kCand, res, &found);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
-      os2s_record_hip_error((int)st, "hipblasLtMatmulAlgoGetHeuristic");
+      lt_note((int)st, "hipblasLtMatmulAlgoGetHeuristic");
       return OS2S_ERR_UNSUPPORTED;
     }
     // The heuristic's first choice is often not the fastest for tall reductions into small
@@ -133,7 +133,7 @@ extern "C" int os2s_matmul_lt(os2s_stream_t stream, const uint16_t* A, int a_is_
   const hipblasStatus_t st = hipblasLtMatmul(g_handle, pl.desc, &alpha, B, pl.la, A, pl.lb, &beta, C, pl.lc, C,
                                              pl.lc, &pl.algo, g_ws, pl.ws, (hipStream_t)stream);
   if (st != HIPBLAS_STATUS_SUCCESS) {
-    os2s_record_hip_error((int)st, "hipblasLtMatmul");
+    lt_note((int)st, "hipblasLtMatmul");
     return OS2S_ERR_LAUNCH;
   }
   return OS2S_OK;
