@@ -169,29 +169,65 @@ struct RnnBwdArgs {
   RnnDirBwd d[2];
 };
 
-template <int G>
+// One workgroup = ROWS hidden units x 32 samples. Every load of a wave's share of the reduction
+// is issued before its first MFMA (rnn_tile.hpp; round 1 ran five dependent load rounds over the
+// 2400-deep reduction of the DeepSpeech2 GRU: 10.5 us per launch against 6.7 us forward).
+// ROWS = 8 (rows 8..31 of the MFMA tile are padding) when the 32-row grid would leave most of
+// the chip idle (H = 800, B = 32: 25 workgroups per direction -> 100); ROWS = 32 otherwise — every
+// workgroup reads the whole [32, G*H] gate-gradient block of its batch tile, so a finer row
+// split multiplies that traffic.
+template <int G, int ROWS>
 __global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_bwd_kernel(RnnBwdArgs pa) {
-  __shared__ float red[kRnnWaves * 16 * 64];
+  __shared__ float red[kRnnWaves * (ROWS == 8 ? 4 : 16) * 64];
   const RnnDirBwd& p = pa.d[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * ROWS, b0 = blockIdx.y * 32;
   const int H = pa.H, GH = G * pa.H;
+  // the epilogue operands of the (unit, sample) pairs of waves 0 .. ROWS/8 - 1 are fetched BEFORE
+  // the GEMM so that their round trip overlaps the weight stream instead of following it
+  const int b = b0 + l31, j = j0 + 8 * wave + 4 * lhi;
+  const bool evalid = wave < ROWS / 8 && b < pa.B && j < H;
+  int t = -1;
+  if (evalid) {
+    const int len = pa.lens ? min(max(pa.lens[b], 0), pa.T) : pa.T;
+    t = time_of(pa.step, len, p.reverse);
+  }
+  const bool act = evalid && t >= 0;
+  const int tp = p.reverse ? t + 1 : t - 1;    // previous time index in processing order (s-1)
+  const bool has_prev = pa.step > 0;
+  const long long row = (long long)b * pa.T + (act ? t : 0);
+  f32x4 carry = {0.f, 0.f, 0.f, 0.f}, dcarry = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f},
+        cprev = {0.f, 0.f, 0.f, 0.f};
+  u32x2 dyv = {0u, 0u}, hv = {0u, 0u}, gv[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+  if (act) {
+    if (!pa.first) carry = *reinterpret_cast<const f32x4*>(p.dh_carry + (long long)b * H + j);
+    dyv = *reinterpret_cast<const u32x2*>(p.dy + row * p.lddy + j);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      gv[g] = *reinterpret_cast<const u32x2*>(p.gates + row * (4 * H) + (long long)g * H + j);
+    if (pa.cell == kGruCudnn) {
+      if (has_prev) hv = *reinterpret_cast<const u32x2*>(p.y + ((long long)b * pa.T + tp) * p.ldy + j);
+    } else {
+      if (!pa.first) dcarry = *reinterpret_cast<const f32x4*>(p.dc_carry + (long long)b * H + j);
+      cv = *reinterpret_cast<const f32x4*>(p.c_seq + row * H + j);
+      if (has_prev) cprev = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * pa.T + tp) * H + j);
+    }
+  }
   float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
   if (!pa.first) {
-    f32x16 accw[1];
+    f32x16 accw;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accw[0][e] = 0.f;
-    tile_gemm_splitk<1, kRnnWaves, 4>(p.whT, GH, 0, j0, H, p.dg_next, GH, b0, pa.B, GH, accw);
-    tile_reduce_quarters<1, kRnnWaves>(accw, red, acc);
+    for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+    const bf16_t* wrow = (l31 < ROWS && j0 + l31 < H) ? p.whT + (long long)(j0 + l31) * GH : nullptr;
+    const int brow = b0 + l31;
+    const bf16_t* irow = brow < pa.B ? p.dg_next + (long long)brow * GH : nullptr;
+    // G = 3, H = 800: 150 k-slices = 19 per wave in one round; G = 4, H = 1024: two rounds of 16
+    tile_gemm_prefetch<kRnnWaves, G == 3 ? 19 : 16>(wrow, irow, GH, accw, p.whT);
+    if (ROWS == 8) tile_reduce_rows8<kRnnWaves>(accw, red, acc[0]);
+    else tile_reduce_rows<kRnnWaves>(accw, red, acc[0]);
   }
-  if (wave >= 4) return;
-  const int b = b0 + l31;
-  if (b >= pa.B) return;
-  const int len = pa.lens ? min(max(pa.lens[b], 0), pa.T) : pa.T;
-  const int t = time_of(pa.step, len, p.reverse);
+  if (!evalid) return;
   {
-    const int j = j0 + 8 * wave + 4 * lhi;
-    if (j >= H) return;
     bf16_t* dgc = p.dg_cur + (long long)b * GH;
     if (t < 0) {
       // inactive sample: its dg_next is zero (nothing was active later either) and the
@@ -203,29 +239,17 @@ __global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_bwd_kernel(RnnBwdArgs
       }
       return;
     }
-    f32x4 carry = {0.f, 0.f, 0.f, 0.f};
-    if (!pa.first) carry = *reinterpret_cast<const f32x4*>(p.dh_carry + (long long)b * H + j);
-    const u32x2 dyv = *reinterpret_cast<const u32x2*>(p.dy + ((long long)b * pa.T + t) * p.lddy + j);
     float dh[4] = {bflo(dyv[0]) + acc[0][0] + carry[0], bfhi(dyv[0]) + acc[0][1] + carry[1],
                    bflo(dyv[1]) + acc[0][2] + carry[2], bfhi(dyv[1]) + acc[0][3] + carry[3]};
     float sv[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const u32x2 v = *reinterpret_cast<const u32x2*>(p.gates + ((long long)b * pa.T + t) * (4 * H) +
-                                                      (long long)g * H + j);
-      sv[g][0] = bflo(v[0]); sv[g][1] = bfhi(v[0]); sv[g][2] = bflo(v[1]); sv[g][3] = bfhi(v[1]);
+      sv[g][0] = bflo(gv[g][0]); sv[g][1] = bfhi(gv[g][0]); sv[g][2] = bflo(gv[g][1]); sv[g][3] = bfhi(gv[g][1]);
     }
-    // previous time index in processing order (s-1): t-1 forward, t+1 reverse
-    const int tp = p.reverse ? t + 1 : t - 1;
-    const bool has_prev = pa.step > 0;
     float dpre[G][4];
     f32x4 ncarry;
     if (pa.cell == kGruCudnn) {
-      float hprev[4] = {0.f, 0.f, 0.f, 0.f};
-      if (has_prev) {
-        const u32x2 hv = *reinterpret_cast<const u32x2*>(p.y + ((long long)b * pa.T + tp) * p.ldy + j);
-        hprev[0] = bflo(hv[0]); hprev[1] = bfhi(hv[0]); hprev[2] = bflo(hv[1]); hprev[3] = bfhi(hv[1]);
-      }
+      const float hprev[4] = {bflo(hv[0]), bfhi(hv[0]), bflo(hv[1]), bfhi(hv[1])};   // zero at step 0
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float rg = sv[0][e], zg = sv[1][e], ng = sv[2][e], hn = sv[3][e];
@@ -240,11 +264,6 @@ __global__ __launch_bounds__(64 * kRnnWaves) void rnn_step_bwd_kernel(RnnBwdArgs
         sv[3][e] = dnpre * rg;                        // d(Rn h + bRn)   (recurrent side)
       }
     } else {
-      f32x4 dcarry = {0.f, 0.f, 0.f, 0.f};
-      if (!pa.first) dcarry = *reinterpret_cast<const f32x4*>(p.dc_carry + (long long)b * H + j);
-      const f32x4 cv = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * pa.T + t) * H + j);
-      f32x4 cprev = {0.f, 0.f, 0.f, 0.f};
-      if (has_prev) cprev = *reinterpret_cast<const f32x4*>(p.c_seq + ((long long)b * pa.T + tp) * H + j);
       f32x4 ndc;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -389,7 +408,8 @@ extern "C" int os2s_rnn_layer_bwd_multi(os2s_stream_t stream_, int cell, int ndi
       return OS2S_ERR_LAUNCH;
   }
   if (ndir == 1) a.d[1] = a.d[0];
-  dim3 grid(ceil_div(H, 32), ceil_div(B, 32), ndir);
+  const bool rows8 = ceil_div(H, 32) * ceil_div(B, 32) * ndir < 128;
+  dim3 grid(ceil_div(H, rows8 ? 8 : 32), ceil_div(B, 32), ndir);
   for (int s = T - 1; s >= 0; --s) {
     a.step = s;
     a.first = (s == T - 1);
@@ -398,8 +418,10 @@ extern "C" int os2s_rnn_layer_bwd_multi(os2s_stream_t stream_, int cell, int ndi
       a.d[d].dg_next = dg[d][par];
       a.d[d].dg_cur = dg[d][par ^ 1];
     }
-    if (G == 3) { OS2S_LAUNCH(rnn_step_bwd_kernel<3>, grid, dim3(64 * kRnnWaves), 0, stream, a); }
-    else { OS2S_LAUNCH(rnn_step_bwd_kernel<4>, grid, dim3(64 * kRnnWaves), 0, stream, a); }
+    if (G == 3 && rows8) { OS2S_LAUNCH((rnn_step_bwd_kernel<3, 8>), grid, dim3(64 * kRnnWaves), 0, stream, a); }
+    else if (G == 3) { OS2S_LAUNCH((rnn_step_bwd_kernel<3, 32>), grid, dim3(64 * kRnnWaves), 0, stream, a); }
+    else if (rows8) { OS2S_LAUNCH((rnn_step_bwd_kernel<4, 8>), grid, dim3(64 * kRnnWaves), 0, stream, a); }
+    else { OS2S_LAUNCH((rnn_step_bwd_kernel<4, 32>), grid, dim3(64 * kRnnWaves), 0, stream, a); }
   }
   return OS2S_OK;
 }

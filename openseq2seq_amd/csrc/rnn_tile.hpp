@@ -170,6 +170,25 @@ __device__ __forceinline__ void tile_reduce_rows(const f32x16& acc, float* red, 
   }
 }
 
+// Sum the first EIGHT rows of NW partial tiles (a tile with 8 real rows: accumulator elements
+// 0..3 are rows 4*(lane>>5) + e): wave 0 receives out[e] = sum_w acc_w[e]. `red`: NW*4*64 floats.
+template <int NW>
+__device__ __forceinline__ void tile_reduce_rows8(const f32x16& acc, float* red, float (&out)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[(wave * 4 + e) * 64 + lane] = acc[e];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) s += red[(w2 * 4 + e) * 64 + lane];
+      out[e] = s;
+    }
+  }
+}
+
 // Same with the WEIGHT operand stored as OCP e4m3 (1 byte per element, one fp32 scale per row
 // applied by the caller to the finished dot product): 8 bytes per lane and k-slice instead of 16
 // — the step kernels stream the whole weight matrix once per time step, so halving its bytes

@@ -20,12 +20,16 @@ def _cmp(got, ref, name, cos_min=0.99, rel_max=0.1):
 @pytest.mark.parametrize("cell", ["gru_cudnn", "lstm_cudnn", "lstm_tf"])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("use_lens", [True, False])
-def test_rnn_direction(cuda, cell, reverse, use_lens):
+@pytest.mark.parametrize("shape", [(5, 23, 64, 96), (130, 5, 64, 1024)])
+def test_rnn_direction(cuda, cell, reverse, use_lens, shape):
+  """One recurrent direction fwd + bwd vs the fp32 oracle. The second shape (1024 units, 130
+  samples) takes the 32-rows-per-workgroup backward step kernel and a reduction longer than one
+  round of loads; the first the 8-row one."""
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.parts.rnns.rnn_layers import RNNDirection
   from openseq2seq_amd.parts.cnns.conv_blocks import Act, Tape
   torch.manual_seed(0)
-  B, T, In, H = 5, 23, 64, 96
+  B, T, In, H = shape
   store = FlatParams(cuda)
   layer = RNNDirection(store, "rnn", cell, [In], H, reverse=reverse, forget_bias=1.0)
   store.finalize()
@@ -34,7 +38,10 @@ def test_rnn_direction(cuda, cell, reverse, use_lens):
     if p.kind == "vector":
       p.master.copy_((torch.randn(p.shape, generator=g) * 0.1).to(cuda))
   x = (torch.randn(B, T, In, generator=g)).to(torch.bfloat16)
-  lens = torch.tensor([23, 7, 15, 1, 20], dtype=torch.int32) if use_lens else None
+  lens = None
+  if use_lens:
+    lens = torch.tensor([23, 7, 15, 1, 20], dtype=torch.int32) if B == 5 else \
+        torch.randint(1, T + 1, (B,), generator=g).to(torch.int32)
   dy = torch.randn(B, T, H, generator=g).to(torch.bfloat16)
   xa = Act(x.to(cuda), None)
   tape = Tape()
