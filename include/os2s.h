@@ -437,6 +437,13 @@ int os2s_layernorm_bwd(os2s_stream_t stream, const uint16_t* dy, const uint16_t*
 int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out,
                      int mode, float keep_prob, unsigned long long seed, long long n,
                      uint16_t* d);
+/* The same on a [rows, C] matrix, with the column sums of d (the gradient of the Dense layer's
+ * bias) from the same pass: partial[os2s_dropout_bwd_colsum_num_parts(rows)][2][C] fp32, plane 0 =
+ * per-workgroup column sums (plane 1 zero) — reduce with os2s_bn_bwd_finalize(q = 1). */
+int os2s_dropout_bwd_colsum_num_parts(long long rows);
+int os2s_dropout_bwd_colsum(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out, int mode,
+                            float keep_prob, unsigned long long seed, long long rows, int C,
+                            uint16_t* d, float* partial);
 int os2s_add_bf16(os2s_stream_t stream, const uint16_t* a, const uint16_t* b, long long n,
                   uint16_t* out);
 /* Attention.call "loung" mode (parts/transformer/attention_layer.py:104-220): per

@@ -743,6 +743,22 @@ def dropout_bwd(dout, keep_prob, seed=0, out=None):
   return d
 
 
+def dropout_bwd_colsum(dout2d, keep_prob, seed=0, out=None):
+  """dropout_bwd on a [rows, C] matrix + partial column sums of the result ([nparts, 2, C] fp32,
+  plane 0; reduce with bn_bwd_finalize(q=1)): returns (d, partial)."""
+  rows, C = dout2d.shape
+  assert dout2d.is_contiguous()
+  d = torch.empty_like(dout2d)
+  n = int(_fn("os2s_dropout_bwd_colsum_num_parts", (c_ll,))(rows))
+  partial = torch.empty((n, 2, C), dtype=torch.float32, device=dout2d.device)
+  f = _fn("os2s_dropout_bwd_colsum", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll, c_int,
+                                      c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(dout2d, torch.bfloat16), _ptr(out, torch.bfloat16, True),
+               0 if out is None else 1, float(keep_prob), int(seed) & (2**64 - 1), rows, C, _ptr(d),
+               _ptr(partial)), "os2s_dropout_bwd_colsum")
+  return d, partial
+
+
 def add_bf16(a, b, out=None):
   out = torch.empty_like(a) if out is None else out
   f = _fn("os2s_add_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))

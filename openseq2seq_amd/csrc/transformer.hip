@@ -249,6 +249,66 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restri
   }
 }
 
+// The same on a [rows, C] matrix, plus the column sums of d (= the gradient of the layer's bias,
+// tf.layers.Dense(use_bias=True) in ffn_layer.py:51-85) from the same pass: a workgroup owns
+// kDropColRows rows x up to 2048 columns, a thread 8 columns of every (256 / G)-th row, and writes
+// one partial row of sums per workgroup into partial[nparts][2][C] (plane 0; plane 1 is zero —
+// the layout os2s_bn_bwd_finalize reduces). Before: a separate pass over d (os2s_bn_stats).
+constexpr int kDropColRows = 64;
+__global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const bf16_t* __restrict__ dout,
+                                                                 const bf16_t* __restrict__ out, int mode,
+                                                                 float keep_prob, unsigned long long seed,
+                                                                 long long rows, int C, int G,
+                                                                 bf16_t* __restrict__ d,
+                                                                 float* __restrict__ partial) {
+  __shared__ float sh[256 * 8];
+  const float ik = 1.f / keep_prob;
+  const int c8n = C >> 3;
+  const int cg = blockIdx.y * G + (int)(threadIdx.x % G), rp = threadIdx.x / G, nrp = 256 / G;
+  const long long r0 = (long long)blockIdx.x * kDropColRows;
+  const long long r1 = r0 + kDropColRows < rows ? r0 + kDropColRows : rows;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cg < c8n && rp < nrp) {
+    for (long long r = r0 + rp; r < r1; r += nrp) {
+      const long long i = r * c8n + cg;
+      const u32x4 t = reinterpret_cast<const u32x4*>(dout)[i];
+      float g[8] = {bflo(t[0]), bfhi(t[0]), bflo(t[1]), bfhi(t[1]),
+                    bflo(t[2]), bfhi(t[2]), bflo(t[3]), bfhi(t[3])};
+      if (mode == 0) {
+        const uint32_t keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((keep >> e) & 1u) ? g[e] * ik : 0.f;
+      } else {
+        const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
+        const float ov[8] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1]),
+                             bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ov[e] > 0.f ? g[e] * ik : 0.f;
+      }
+      u32x4 rr;
+      rr[0] = pack2bf(g[0], g[1]); rr[1] = pack2bf(g[2], g[3]);
+      rr[2] = pack2bf(g[4], g[5]); rr[3] = pack2bf(g[6], g[7]);
+      reinterpret_cast<u32x4*>(d)[i] = rr;
+      // the sums are those of the ROUNDED values the weight-gradient GEMM will read
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(rr[e]); acc[2 * e + 1] += bfhi(rr[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  if (rp == 0 && cg < c8n) {
+    float* const p0 = partial + ((long long)blockIdx.x * 2) * C + cg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+      for (int q = 0; q < nrp; ++q) s += sh[(q * G + (int)(threadIdx.x % G)) * 8 + e];
+      p0[e] = s;
+      p0[C + e] = 0.f;
+    }
+  }
+}
+
 // y = residual + dropout(act(y + bias)) in place on bf16 [rows, C]: the epilogue of a Dense
 // layer whose matmul ran in the vendor GEMM (same dropout stream as the fused conv epilogue:
 // element index / 8 -> dropout_bits8). One HBM pass; C % 8 == 0.
@@ -528,6 +588,23 @@ extern "C" int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, cons
   if (n == 0) return OS2S_OK;
   OS2S_LAUNCH(dropout_bwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, dout,
               out, mode, keep_prob, seed, n / 8, d);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_dropout_bwd_colsum_num_parts(long long rows) {
+  return (int)((rows + os2s::kDropColRows - 1) / os2s::kDropColRows);
+}
+
+extern "C" int os2s_dropout_bwd_colsum(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out,
+                                       int mode, float keep_prob, unsigned long long seed, long long rows,
+                                       int C, uint16_t* d, float* partial) {
+  OS2S_REQUIRE(dout && d && partial && rows >= 1 && C >= 8 && C % 8 == 0 && (mode == 0 || (mode == 1 && out)));
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
+  int G = C / 8 < 256 ? C / 8 : 256;
+  while (256 % G) --G;                      // G divides 256: whole rows of threads
+  dim3 grid((unsigned)os2s_dropout_bwd_colsum_num_parts(rows), (unsigned)ceil_div(C / 8, G));
+  OS2S_LAUNCH(dropout_bwd_colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, out, mode, keep_prob,
+              seed, rows, C, G, d, partial);
   return OS2S_OK;
 }
 

@@ -104,10 +104,18 @@ class Dense(object):
     def backward():
       dy = out.grad
       assert dy is not None, "no gradient reached " + lin.kernel.name
+      bias_part = None          # partial column sums of dz when the same pass can produce them
+      fuse = lin.bias is not None and dy.is_contiguous()
       if act == 1:
-        dz = capi.dropout_bwd(dy, keep, out=y)         # (y > 0) / keep
+        if fuse:
+          dz, bias_part = capi.dropout_bwd_colsum(dy, keep, out=y)
+        else:
+          dz = capi.dropout_bwd(dy, keep, out=y)         # (y > 0) / keep
       elif keep < 1.0:
-        dz = capi.dropout_bwd(dy, keep, seed=seed)     # recomputed hash mask / keep
+        if fuse:
+          dz, bias_part = capi.dropout_bwd_colsum(dy, keep, seed=seed)
+        else:
+          dz = capi.dropout_bwd(dy, keep, seed=seed)     # recomputed hash mask / keep
       else:
         dz = dy
       # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs
@@ -120,7 +128,10 @@ class Dense(object):
           capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
       else:
         capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
-      if lin.bias is not None:
+      if bias_part is not None:
+        scratch = torch.empty(2, lin.cout, dtype=torch.float32, device=dz.device)
+        capi.bn_bwd_finalize(bias_part, 1, 1, None, lin.bias.grad, True, scratch[0], scratch[1])
+      elif lin.bias is not None:
         _colsum_into(dz, lin.bias)
       if x.requires_grad:
         g = x.grad_buffer()

@@ -253,3 +253,24 @@ def test_dense_epilogue_matches_fused_gemm(cuda):
       assert float(((y.float() == base) != (fused.float() == base)).float().mean()) < 1e-3
       frac = float((y.float() == base).float().mean())
       assert abs(frac - (1 - keep)) < 0.02
+
+
+@pytest.mark.parametrize("rows,C", [(8300, 4096), (777, 1024), (130, 800), (64, 8)])
+def test_dropout_bwd_colsum(cuda, rows, C):
+  """os2s_dropout_bwd_colsum == os2s_dropout_bwd (bit-identical d, both modes) and its partial
+  column sums reduce to the fp32 column sums of the ROUNDED d (what the separate os2s_bn_stats
+  pass computed): rtol 1e-5 of the column's absolute sum."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(rows + C)
+  dy = _bf(torch.randn(rows, C, generator=g)).to(cuda)
+  y = _bf(torch.relu(torch.randn(rows, C, generator=g))).to(cuda)
+  for kw in (dict(seed=17), dict(out=y)):
+    ref = capi.dropout_bwd(dy, 0.8, **kw)
+    d, part = capi.dropout_bwd_colsum(dy, 0.8, **kw)
+    assert torch.equal(d, ref)
+    acc = torch.full((C,), 3.0, device=cuda)
+    scratch = torch.empty(2, C, device=cuda)
+    capi.bn_bwd_finalize(part, 1, 1, None, acc, True, scratch[0], scratch[1])
+    want = 3.0 + ref.float().sum(0)
+    tol = 1e-5 * ref.float().abs().sum(0) + 1e-4
+    assert bool(((acc - want).abs() <= tol).all())
