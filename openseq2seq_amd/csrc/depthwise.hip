@@ -237,9 +237,189 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stride-1, dilation-1 kernels (every QuartzNet block: K = 33 .. 75). With 2*K FLOP per element
+// the op is VALU-bound, not HBM-bound (K = 75, C = 512: 2 GFLOP per launch against 55 MB), and the
+// first kernels above were bound by LDS bytes per FMA and by one wave per SIMD (fp32 tiles of
+// 58-95 KB). Here:
+//   * tiles live in LDS as bf16 (136-byte rows: the 16-row offset between the time groups of a
+//     wave lands on the other half of the banks) — 64-78 KB per workgroup, two workgroups per CU;
+//   * a thread owns 4 channels x 16 outputs (forward) or 4 channels x 16 taps (weight gradient):
+//     64 accumulators and a sliding 16-row register window of the input, so one new 8-byte row
+//     (+ one weight row / one dy row) feeds 64 FMAs — 0.25-0.4 LDS bytes per FMA instead of 1-2;
+//   * the FMAs are v_pk_fma_f32 over channel pairs (the fp32 vector peak is the packed rate).
+// ---------------------------------------------------------------------------------------------
+constexpr int kD16BT = 256;      // time steps per tile
+constexpr int kD16Pitch = 136;   // LDS bytes per 64-channel bf16 row of the x tile
+
+// rows [0, nrows) of the x tile: LDS row r <-> input time t0 - padL + r, channels c0 .. c0+63
+__device__ __forceinline__ void d16_stage_x(const DwArgs& p, int b, int t0, int c0, char* xs, int nrows, int len_b) {
+  const bf16_t* xb = p.x + (long long)b * p.Tin * p.C;
+  const int tin0 = t0 - p.padL;
+  for (int q = threadIdx.x; q < nrows * 8; q += 256) {
+    const int r = q >> 3, cg = q & 7;
+    const int tin = tin0 + r, ch = c0 + cg * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (tin >= 0 && tin < len_b && ch < p.C) v = *reinterpret_cast<const u32x4*>(xb + (long long)tin * p.C + ch);
+    u32x2* d = reinterpret_cast<u32x2*>(xs + r * kD16Pitch + cg * 16);
+    d[0] = u32x2{v[0], v[1]};
+    d[1] = u32x2{v[2], v[3]};
+  }
+}
+
+__device__ __forceinline__ void d16_row(const char* ptr, f32x2 (&dst)[2]) {
+  const u32x2 v = *reinterpret_cast<const u32x2*>(ptr);
+  dst[0] = f32x2{bflo(v[0]), bfhi(v[0])};
+  dst[1] = f32x2{bflo(v[1]), bfhi(v[1])};
+}
+
+__global__ __launch_bounds__(256, 2) void depthwise_fwd16_kernel(DwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  const int R = kD16BT + p.K - 1;
+  char* const xs = smc;                                              // [R][136 B] bf16
+  float* const ws = reinterpret_cast<float*>(smc + ((R * kD16Pitch + 15) & ~15));   // [K][64] fp32
+  const int ntt = (p.Tout + kD16BT - 1) / kD16BT;
+  const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * kD16BT, c0 = blockIdx.y * kDwBC;
+  int len_b = p.Tin;
+  if (p.in_len) len_b = min(max(p.in_len[b], 0), p.Tin);
+  if (p.out_len && t0 >= p.out_len[b]) return;        // never-read output tile
+  if (t0 - p.padL >= len_b) {
+    // the whole input window lies past the sequence end: the outputs are exact zeros
+    const int rows = min(kD16BT, p.Tout - t0), c8n = min(kDwBC, p.C - c0) >> 3;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int q = threadIdx.x; q < rows * c8n; q += 256) {
+      const int r = q / c8n, cg8 = q - r * c8n;
+      *reinterpret_cast<u32x4*>(p.y + ((long long)b * p.Tout + t0 + r) * p.C + c0 + cg8 * 8) = z;
+    }
+    return;
+  }
+  d16_stage_x(p, b, t0, c0, xs, R, len_b);
+  for (int q = threadIdx.x; q < p.K * kDwBC; q += 256) {
+    const int k = q / kDwBC, c = q - k * kDwBC;
+    ws[q] = (c0 + c < p.C) ? p.w[(long long)(p.flip ? p.K - 1 - k : k) * p.C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  const int cg = threadIdx.x & 15, tg = threadIdx.x >> 4;            // 16 channel quads x 16 time groups
+  const int tt0 = tg * 16;
+  if (c0 + cg * 4 >= p.C || t0 + tt0 >= p.Tout) return;
+  f32x2 a[16][2], xw[16][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a[j][0] = f32x2{0.f, 0.f}; a[j][1] = f32x2{0.f, 0.f}; }
+  const char* const xr = xs + tt0 * kD16Pitch + cg * 8;
+#pragma unroll
+  for (int sl = 0; sl < 15; ++sl) d16_row(xr + sl * kD16Pitch, xw[sl]);
+  // window slot of output j at tap k = kb + kk is (j + kk) & 15 — static after unrolling
+  for (int kb = 0; kb < p.K; kb += 16) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = kb + kk;
+      if (k < p.K) {
+        d16_row(xr + (k + 15) * kD16Pitch, xw[(15 + kk) & 15]);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + k * kDwBC + cg * 4);
+        const f32x2 w0 = {wv[0], wv[1]}, w1 = {wv[2], wv[3]};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          a[j][0] = __builtin_elementwise_fma(xw[(j + kk) & 15][0], w0, a[j][0]);
+          a[j][1] = __builtin_elementwise_fma(xw[(j + kk) & 15][1], w1, a[j][1]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int t = t0 + tt0 + j;
+    if (t >= p.Tout) break;
+    u32x2 o;
+    o[0] = pack2bf(a[j][0][0], a[j][0][1]);
+    o[1] = pack2bf(a[j][1][0], a[j][1][1]);
+    *reinterpret_cast<u32x2*>(p.y + ((long long)b * p.Tout + t) * p.C + c0 + cg * 4) = o;
+  }
+}
+
+// dw[k,c] += sum_{b,t} dy[b,t,c] x[b, t + k - padL, c]. A workgroup walks (sample, 256-step) tiles of
+// its 64 channels with a grid stride and keeps the sums in registers: thread = (16-tap group, channel
+// quad, time segment); one LDS reduction over the segments and ONE atomic per (tap, channel) and
+// workgroup at the end (the first kernel issued them per 128-step tile).
+__global__ __launch_bounds__(256, 2) void depthwise_wgrad16_kernel(DwArgs p, int ngrp, int nseg) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  const int XR = kD16BT + 16 * ngrp;                                 // x rows staged per tile
+  char* const xs = smc;                                              // [XR][136 B] bf16
+  char* const ds = smc + XR * kD16Pitch;                             // [256][128 B] bf16 dy tile
+  const int ntt = (p.Tout + kD16BT - 1) / kD16BT;
+  const int c0 = blockIdx.y * kDwBC;
+  const int ncell = ngrp * 16;
+  const int cell = threadIdx.x % ncell, seg = threadIdx.x / ncell;
+  const int kg = cell >> 4, cg = cell & 15, k0 = kg * 16;
+  const bool active = seg < nseg && c0 + cg * 4 < p.C;
+  const int ta = seg * kD16BT / nseg, tb = (seg + 1) * kD16BT / nseg;
+  f32x2 a[16][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { a[j][0] = f32x2{0.f, 0.f}; a[j][1] = f32x2{0.f, 0.f}; }
+  for (int tile = blockIdx.x; tile < p.B * ntt; tile += gridDim.x) {
+    const int b = tile / ntt, t0 = (tile - b * ntt) * kD16BT;
+    int len_b = p.Tin;
+    if (p.in_len) len_b = min(max(p.in_len[b], 0), p.Tin);
+    if (t0 - p.padL >= len_b) continue;                              // the whole X window is padding
+    d16_stage_x(p, b, t0, c0, xs, XR, len_b);
+    const bf16_t* dyb = p.dy + (long long)b * p.Tout * p.C;
+    for (int q = threadIdx.x; q < kD16BT * 8; q += 256) {
+      const int r = q >> 3, cg8 = q & 7;
+      const int t = t0 + r, ch = c0 + cg8 * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t < p.Tout && ch < p.C) v = *reinterpret_cast<const u32x4*>(dyb + (long long)t * p.C + ch);
+      *reinterpret_cast<u32x4*>(ds + r * 128 + cg8 * 16) = v;
+    }
+    __syncthreads();
+    if (active) {
+      f32x2 xw[16][2];
+      const char* const xr = xs + (ta + k0) * kD16Pitch + cg * 8;
+      const char* const dr = ds + ta * 128 + cg * 8;
+#pragma unroll
+      for (int sl = 0; sl < 15; ++sl) d16_row(xr + sl * kD16Pitch, xw[sl]);
+      // window slot of tap j at step ti is (j + ti) & 15 — static after unrolling
+      for (int i0 = 0; i0 < tb - ta; i0 += 16) {
+#pragma unroll
+        for (int ti = 0; ti < 16; ++ti) {
+          const int i = i0 + ti;
+          if (i < tb - ta) {
+            d16_row(xr + (i + 15) * kD16Pitch, xw[(15 + ti) & 15]);
+            f32x2 dv[2];
+            d16_row(dr + i * 128, dv);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              a[j][0] = __builtin_elementwise_fma(xw[(j + ti) & 15][0], dv[0], a[j][0]);
+              a[j][1] = __builtin_elementwise_fma(xw[(j + ti) & 15][1], dv[1], a[j][1]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                                                 // the tiles are overwritten next
+  }
+  // combine the time segments through LDS: ONE atomic per (tap, channel) and workgroup
+  float* const red = reinterpret_cast<float*>(smc);                  // [nseg][ncell][16 taps][4 ch]
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      *reinterpret_cast<f32x4*>(red + ((seg * ncell + cell) * 16 + j) * 4) = f32x4{a[j][0][0], a[j][0][1], a[j][1][0], a[j][1][1]};
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < ncell * 64; q += 256) {
+    const int cl = q >> 6, je = q & 63, j = je >> 2, e = je & 3;
+    const int k = (cl >> 4) * 16 + j, ch = c0 + (cl & 15) * 4 + e;
+    if (k >= p.K || ch >= p.C) continue;
+    float v = 0.f;
+    for (int sg = 0; sg < nseg; ++sg) v += red[(sg * ncell + cl) * 64 + je];
+    if (v != 0.f) __hip_atomic_fetch_add(p.dw + (long long)k * p.C + ch, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 }  // namespace os2s
 
 using namespace os2s;
+
+static int g_dw_variant = -1;   // test / experiment hook: 0 = the generic kernels only
+extern "C" void os2s_depthwise_set_variant(int v) { g_dw_variant = v; }
 
 static int dw_fill(DwArgs& a, int B, int Tin, int Tout, int C, int K, int stride, int dil, int padL) {
   OS2S_REQUIRE(B >= 1 && Tin >= 1 && Tout >= 1 && C >= 8 && C % 8 == 0 && K >= 1 && stride >= 1 && dil >= 1);
@@ -258,6 +438,20 @@ extern "C" int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x
   if (rc != OS2S_OK) return rc;
   a.x = (const bf16_t*)x; a.w = w; a.y = (bf16_t*)y; a.in_len = in_len; a.out_len = out_len;
   a.flip = flip_taps;
+  if (stride == 1 && dil == 1 && g_dw_variant != 0) {
+    const size_t lds16 = (((size_t)(kD16BT + K - 1) * kD16Pitch + 15) & ~(size_t)15) + (size_t)K * kDwBC * sizeof(float);
+    if (lds16 <= 80 * 1024) {
+      static bool attr16 = false;
+      if (!attr16) {
+        if (hipFuncSetAttribute((const void*)depthwise_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+          return OS2S_ERR_LAUNCH;
+        attr16 = true;
+      }
+      dim3 grid16(B * ceil_div(Tout, kD16BT), ceil_div(C, kDwBC));
+      OS2S_LAUNCH(depthwise_fwd16_kernel, grid16, dim3(256), lds16, (hipStream_t)stream, a);
+      return OS2S_OK;
+    }
+  }
   const size_t lds = ((size_t)a.R * kDwP + (size_t)K * kDwBC) * sizeof(float);
   if (lds > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   if (lds > 64 * 1024 &&
@@ -276,6 +470,26 @@ extern "C" int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t*
   const int rc = dw_fill(a, B, Tin, Tout, C, K, stride, dil, padL);
   if (rc != OS2S_OK) return rc;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.in_len = in_len;
+  if (stride == 1 && dil == 1 && g_dw_variant != 0) {
+    const int ngrp = ceil_div(K, 16), ncell = ngrp * 16;
+    int nseg = 256 / ncell;
+    nseg = nseg > 8 ? 8 : nseg;
+    const size_t tiles = (size_t)(kD16BT + 16 * ngrp) * kD16Pitch + (size_t)kD16BT * 128;
+    const size_t redb = (size_t)nseg * ncell * 64 * sizeof(float);
+    const size_t lds16 = tiles > redb ? tiles : redb;
+    if (nseg >= 1 && lds16 <= 80 * 1024) {
+      static bool attr16 = false;
+      if (!attr16) {
+        if (hipFuncSetAttribute((const void*)depthwise_wgrad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+          return OS2S_ERR_LAUNCH;
+        attr16 = true;
+      }
+      const int ntiles = B * ceil_div(Tout, kD16BT);
+      dim3 grid16(ntiles < 64 ? ntiles : 64, ceil_div(C, kDwBC));
+      OS2S_LAUNCH(depthwise_wgrad16_kernel, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg);
+      return OS2S_OK;
+    }
+  }
   const size_t lds = ((size_t)a.R + kDwBT) * kDwP * sizeof(float);
   if (lds > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
   if (lds > 64 * 1024 &&

@@ -25,12 +25,17 @@ LAYERS = [
 ]
 
 
-@pytest.mark.parametrize("K,stride,dil", [(33, 1, 1), (11, 2, 1), (87, 1, 2), (1, 1, 1)])
-def test_depthwise_kernels(cuda, K, stride, dil):
+@pytest.mark.parametrize("K,stride,dil", [(33, 1, 1), (11, 2, 1), (87, 1, 2), (1, 1, 1), (75, 1, 1), (16, 1, 1)])
+@pytest.mark.parametrize("shape", [(3, 200, 72), (4, 700, 200)])
+def test_depthwise_kernels(cuda, K, stride, dil, shape):
+  """Depthwise forward / flipped-tap data gradient / weight gradient vs conv1d(groups=C) of the
+  same bf16 inputs. stride 1, dilation 1 takes the register-window kernels (K = 1, 16, 33, 75: one
+  to five 16-tap groups, a partial last group; T = 700: three 256-step tiles per sample, one of
+  them partial; C = 72 / 200: a partial 64-channel block), the rest the generic kernels."""
   from openseq2seq_amd import capi
   g = torch.Generator().manual_seed(K)
-  B, T, C = 3, 200, 72
-  lens = torch.tensor([200, 131, 57], dtype=torch.int32)
+  B, T, C = shape
+  lens = torch.tensor([T, (2 * T) // 3 + 1, T // 4 + 7] + [T // 2] * (B - 3), dtype=torch.int32)
   x = torch.randn(B, T, C, generator=g).to(torch.bfloat16)
   x = x * (torch.arange(T)[None, :, None] < lens[:, None, None])      # inputs are stored masked
   w = torch.randn(K, C, generator=g) * 0.3
