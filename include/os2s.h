@@ -770,6 +770,8 @@ int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const flo
 int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* dy,
                                 float* dw, const int32_t* in_len, int B, int Tin, int Tout, int C,
                                 int K, int stride, int dil, int padL);
+/* test / experiment hook: 0 = the generic depthwise kernels only, < 0 = by shape */
+void os2s_depthwise_set_variant(int v);
 
 /* ------------------------------------------------------------------------
  * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:

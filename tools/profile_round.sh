@@ -8,6 +8,8 @@
 #                                         --pmc passes, gfx950 correction) — bench.py reads the newest one
 #   <tag>_pmc_mfma_busy.json              SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE per
 #                                         kernel (conv fwd+dgrad ping-pong, lockstep, wgrad)
+#   <tag>_transformer_kernel_stats(.serial).csv, <tag>_transformer_pmc_mfma_busy.json, <tag>_gpu_idle_gaps.txt,
+#   <tag>_{quartznet,ds2,tacotron,nmt}_kernel_stats.csv (5 steps each), <tag>_mfma_issue_probe.txt
 # Usage on the GPU box: bash tools/profile_round.sh r02
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -70,4 +72,42 @@ json.dump(busy, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_launch"]) for k, v in per.items()}))
 print(json.dumps({k: v.get("mfma_duty_cycle") for k, v in busy["per_kernel"].items()}))
 PY
-ls -la $OUT/*.json $OUT/*.csv
+# ---- the other configurations: kernel stats of 8 steps each (serial streams: every kernel alone) ----
+T="python bench.py --only-transformer --steps 5 --warmup 3"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tks -o tr -- $T > $OUT/tks.log 2>&1
+cp $OUT/tks/tr_kernel_stats.csv $OUT/${TAG}_transformer_kernel_stats.csv
+python tools/trace_gaps.py $OUT/tks/tr_kernel_trace.csv > $OUT/${TAG}_gpu_idle_gaps.txt 2>&1
+python tools/trace_gaps.py $OUT/ks/jasper_kernel_trace.csv >> $OUT/${TAG}_gpu_idle_gaps.txt 2>&1
+OS2S_DENSE_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tkss -o tr -- $T > $OUT/tkss.log 2>&1
+cp $OUT/tkss/tr_kernel_stats.csv $OUT/${TAG}_transformer_kernel_stats_serial.csv
+OS2S_DENSE_WGRAD_STREAM=0 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT/tm -o c -- python bench.py --only-transformer --steps 2 --warmup 1 > $OUT/tm.log 2>&1
+python - <<PY
+import csv, glob, json, collections
+FAM = [("gemm_pp_kernel", "Dense forward / data gradient, 256x256 ping-pong tile"),
+       ("conv1d_wgrad1x1_pp_kernel", "Dense weight gradient, 256x256 ping-pong tile"),
+       ("conv1d_wgrad_kernel", "Dense weight gradient, lockstep tile (1024 x 1024 outputs)"),
+       ("attn_bwd_kernel", "attention backward"), ("attn_fwd_kernel", "attention forward")]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for f in glob.glob("$OUT/tm/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = next((k for k, _ in FAM if k in r["Kernel_Name"]), None)
+        if k is None: continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+busy = {"command": "OS2S_DENSE_WGRAD_STREAM=0 python bench.py --only-transformer --steps 2 --warmup 1",
+        "note": "per-launch means; mfma_duty_cycle = SQ_VALU_MFMA_BUSY_CYCLES / (128 x GRBM_GUI_ACTIVE)", "per_kernel": {}}
+for k, desc in FAM:
+    if k not in agg: continue
+    e = {c: agg[k][c] / cnt[(k, c)] for c in agg[k]}
+    e["launches"] = cnt[(k, "SQ_VALU_MFMA_BUSY_CYCLES")]
+    if e.get("GRBM_GUI_ACTIVE"): e["mfma_duty_cycle"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * e["GRBM_GUI_ACTIVE"])
+    e["what"] = desc
+    busy["per_kernel"][k] = e
+json.dump(busy, open("$OUT/${TAG}_transformer_pmc_mfma_busy.json", "w"), indent=1)
+print(json.dumps({k: v.get("mfma_duty_cycle") for k, v in busy["per_kernel"].items()}))
+PY
+for m in quartznet ds2 tacotron nmt; do
+  OS2S_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/o_$m -o k -- python bench.py --only-$m --steps 3 --warmup 2 > $OUT/o_$m.log 2>&1
+  cp $OUT/o_$m/k_kernel_stats.csv $OUT/${TAG}_${m}_kernel_stats.csv
+done
+[ -x tools/probe_mfma ] && ./tools/probe_mfma > $OUT/${TAG}_mfma_issue_probe.txt 2>&1
+ls -la $OUT/*.json $OUT/*.csv $OUT/*.txt
