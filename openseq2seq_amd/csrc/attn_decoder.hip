@@ -760,41 +760,60 @@ struct AdCellBwd {
   unsigned long long out_seed;
 };
 
-// dh = dropout'(dy_ext + dgA . WA^T + dq . Wq) + dgB . WB^T, then the LSTM gate derivatives
+// dh = dropout'(dy_ext + dgA . WA^T + dq . Wq) + dgB . WB^T, then the LSTM gate derivatives.
+// One workgroup = kCellBwdRows hidden units x 32 samples: with 32-row tiles a 1024-unit layer was
+// 32 workgroups (an eighth of the chip), each streaming two 256 KB weight slices next to the two
+// [32, 4H] gate-gradient blocks every workgroup reads anyway; 8-row tiles give 128 workgroups and
+// 64 KB slices (rows 8..31 of the MFMA tile are padding). Both products are accumulated before
+// ONE reduction through LDS.
+constexpr int kCellBwdRows = 8;
+constexpr int kCellBwdCols = 32;   // samples per workgroup. (8 samples per workgroup — a quarter of the
+                                   // gate-gradient bytes per CU, 4x the workgroups re-reading the weight
+                                   // slices — was slower: 29.8 vs 26.4 us; the step is five dependent
+                                   // rounds of loads, not bytes per CU.)
 __global__ __launch_bounds__(64 * kBwdWaves) void ad_cell_bwd_kernel(AdCellBwd p) {
   __shared__ float red[kBwdWaves * 8 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * kCellBwdRows, b0 = blockIdx.y * kCellBwdCols;
   const int H = p.H;
-  const bool vrow = j0 + l31 < H;
+  const bool vrow = l31 < kCellBwdRows && j0 + l31 < H;
   const int brow = b0 + l31;
-  const bool vcol = brow < p.B;
-  float accM[4] = {0.f, 0.f, 0.f, 0.f}, accB[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.KA > 0 || p.KQ > 0) {
-    f32x16 accw;
+  const bool vcol = l31 < kCellBwdCols && brow < p.B;
+  f32x16 accwM, accwB;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) accw[e] = 0.f;
-    if (p.KA > 0)
-      tile_gemm_prefetch<kBwdWaves, 8>(vrow ? p.wAT + (long long)(j0 + l31) * p.wAT_ld : nullptr,
-                                        vcol ? p.dgA + (long long)brow * p.dgA_ld : nullptr, p.KA, accw, p.wAT);
-    if (p.KQ > 0)
-      tile_gemm_prefetch<kBwdWaves, 2>(vrow ? p.wqT + (long long)(j0 + l31) * p.KQ : nullptr,
-                                       vcol ? p.dq + (long long)brow * p.dq_ld : nullptr, p.KQ, accw, p.wqT);
-    tile_reduce_quarters16(accw, red, accM);
-  }
-  if (!p.last && p.KB > 0) {
-    f32x16 accw;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accw[e] = 0.f;
+  for (int e = 0; e < 16; ++e) { accwM[e] = 0.f; accwB[e] = 0.f; }
+  if (p.KA > 0)
+    tile_gemm_prefetch<kBwdWaves, 8>(vrow ? p.wAT + (long long)(j0 + l31) * p.wAT_ld : nullptr,
+                                      vcol ? p.dgA + (long long)brow * p.dgA_ld : nullptr, p.KA, accwM, p.wAT);
+  if (p.KQ > 0)
+    tile_gemm_prefetch<kBwdWaves, 2>(vrow ? p.wqT + (long long)(j0 + l31) * p.KQ : nullptr,
+                                     vcol ? p.dq + (long long)brow * p.dq_ld : nullptr, p.KQ, accwM, p.wqT);
+  if (!p.last && p.KB > 0)
     tile_gemm_prefetch<kBwdWaves, 8>(vrow ? p.wBT + (long long)(j0 + l31) * p.wBT_ld : nullptr,
-                                      vcol ? p.dgB + (long long)brow * p.dgB_ld : nullptr, p.KB, accw, p.wBT);
-    tile_reduce_quarters16(accw, red, accB);
+                                      vcol ? p.dgB + (long long)brow * p.dgB_ld : nullptr, p.KB, accwB, p.wBT);
+  // rows 0..7 of the tile = accumulator elements 0..3 (row 4*(lane>>5) + e): 8 floats per lane and wave
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[(wave * 8 + e) * 64 + lane] = accwM[e];
+    red[(wave * 8 + 4 + e) * 64 + lane] = accwB[e];
   }
-  if (wave >= 4) return;
+  __syncthreads();
+  if (wave >= 1) return;
+  float accM[4], accB[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float sm = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < kBwdWaves; ++w2) {
+      sm += red[(w2 * 8 + e) * 64 + lane];
+      sb += red[(w2 * 8 + 4 + e) * 64 + lane];
+    }
+    accM[e] = sm; accB[e] = sb;
+  }
   const int b = b0 + l31;
-  if (b >= p.B) return;
+  if (l31 >= kCellBwdCols || b >= p.B) return;
   if (p.lens && p.t >= p.lens[b]) return;
-  const int j = j0 + 8 * wave + 4 * lhi;
+  const int j = j0 + 4 * lhi;
   if (j >= H) return;
   const long long row = (long long)b * p.T + p.t;
   float dyv[4] = {accM[0], accM[1], accM[2], accM[3]};
@@ -1128,7 +1147,7 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
   at.dq_seq = (bf16_t*)gr->dq_seq; at.dhq = dhq; at.dnv_acc = dnv_acc; at.dbd_acc = dbd_acc;
   at.dwck_acc = dwck_acc;
   const long long GH = 4LL * H;
-  dim3 cgrid(ceil_div(H, 32), ceil_div(B, 32));
+  dim3 cgrid(ceil_div(H, kCellBwdRows), ceil_div(B, kCellBwdCols));
   for (int t = T - 1; t >= 0; --t) {
     const int last = (t == T - 1);
     if (!last) {

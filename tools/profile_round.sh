@@ -15,8 +15,6 @@ TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
-timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
-tail -c 600 $OUT/${TAG}_bench_default.json; echo
 J="python bench.py --no-transformer --no-other-configs --no-cpu-baseline --no-kernel-timing"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o jasper -- $J --steps 8 --warmup 3 > $OUT/ks.log 2>&1
 cp $OUT/ks/jasper_kernel_stats.csv $OUT/${TAG}_jasper_kernel_stats.csv
@@ -72,6 +70,11 @@ json.dump(busy, open("$OUT/${TAG}_pmc_mfma_busy.json", "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_launch"]) for k, v in per.items()}))
 print(json.dumps({k: v.get("mfma_duty_cycle") for k, v in busy["per_kernel"].items()}))
 PY
+# ---- the driver's command, AFTER the PMC pass: bench.py reads roofline.traffic from the newest
+#      profiles/*_pmc_bench_traffic.json, which must be the one committed next to its line ----
+cp $OUT/${TAG}_pmc_bench_traffic.json profiles/${TAG}_pmc_bench_traffic.json
+timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+tail -c 600 $OUT/${TAG}_bench_default.json; echo
 # ---- the other configurations: kernel stats of 8 steps each (serial streams: every kernel alone) ----
 T="python bench.py --only-transformer --steps 5 --warmup 3"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tks -o tr -- $T > $OUT/tks.log 2>&1
