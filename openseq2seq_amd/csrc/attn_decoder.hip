@@ -484,21 +484,23 @@ __device__ __forceinline__ void tile_reduce_quarters16(const f32x16& acc, float*
   }
 }
 
+// 8 output rows per workgroup (rows 8..31 of the MFMA tile are padding): M = 512 attention
+// inputs are 64 workgroups instead of 16.
 __global__ __launch_bounds__(64 * kBwdWaves) void ad_dattn_kernel(AdDattn p) {
-  __shared__ float red[kBwdWaves * 8 * 64];
+  __shared__ float red[kBwdWaves * 4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
-  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
   f32x16 accw;
 #pragma unroll
   for (int e = 0; e < 16; ++e) accw[e] = 0.f;
-  const bf16_t* wrow = p.wT + (long long)min(j0 + l31, p.M - 1) * p.K;
+  const bf16_t* wrow = (l31 < 8 && j0 + l31 < p.M) ? p.wT + (long long)(j0 + l31) * p.K : nullptr;
   const int brow = b0 + l31;
   const bf16_t* irow = brow < p.B ? p.dg + (long long)brow * p.ld : nullptr;
   tile_gemm_prefetch<kBwdWaves, 8>(wrow, irow, p.K, accw, p.wT);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  tile_reduce_quarters16(accw, red, acc);
-  if (wave >= 4) return;
-  const int b = b0 + l31, j = j0 + 8 * wave + 4 * lhi;
+  float acc[4];
+  tile_reduce_rows8<kBwdWaves>(accw, red, acc);
+  if (wave >= 1) return;
+  const int b = b0 + l31, j = j0 + 4 * lhi;
   if (b >= p.B || j >= p.M) return;
   f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
   *reinterpret_cast<f32x4*>(p.out + (long long)b * p.M + j) = o;
@@ -1154,7 +1156,7 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
       AdDattn g;
       g.B = B; g.M = M; g.K = (int)GH; g.wT = (const bf16_t*)gr->wcatT[0];
       g.dg = (const bf16_t*)gr->dg[0] + (long long)(t + 1) * GH; g.ld = (long long)T * GH; g.out = dattn;
-      OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 32), ceil_div(B, 32)), dim3(64 * kBwdWaves), 0, stream, g);
+      OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 8), ceil_div(B, 32)), dim3(64 * kBwdWaves), 0, stream, g);
     }
     at.t = t; at.last = last;
     if (d->score_mode == 2) { OS2S_LAUNCH(ad_attn_bwd_kernel<true>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
