@@ -273,9 +273,14 @@ __device__ __forceinline__ void d16_row(const char* ptr, f32x2 (&dst)[2]) {
   dst[1] = f32x2{bflo(v[1]), bfhi(v[1])};
 }
 
+// Dilation D (stride 1): outputs whose (t - t0) has the same residue mod D only touch LDS rows of
+// that residue — y[t0 + q + D u] = sum_k x_row[q + D (u + k)] w[k] is a dilation-1 convolution on
+// the sub-sequence of residue q. A thread therefore owns 16 outputs of ONE residue class (time
+// group tg -> class tg % D, 16-output block tg / D) and walks the rows with a step of D.
+template <int D>
 __global__ __launch_bounds__(256, 2) void depthwise_fwd16_kernel(DwArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
-  const int R = kD16BT + p.K - 1;
+  const int R = kD16BT + (p.K - 1) * D;
   char* const xs = smc;                                              // [R][136 B] bf16
   float* const ws = reinterpret_cast<float*>(smc + ((R * kD16Pitch + 15) & ~15));   // [K][64] fp32
   const int ntt = (p.Tout + kD16BT - 1) / kD16BT;
@@ -300,21 +305,22 @@ __global__ __launch_bounds__(256, 2) void depthwise_fwd16_kernel(DwArgs p) {
   }
   __syncthreads();
   const int cg = threadIdx.x & 15, tg = threadIdx.x >> 4;            // 16 channel quads x 16 time groups
-  const int tt0 = tg * 16;
+  const int tt0 = (tg % D) + D * 16 * (tg / D);                      // first output of the thread (tile-relative)
   if (c0 + cg * 4 >= p.C || t0 + tt0 >= p.Tout) return;
   f32x2 a[16][2], xw[16][2];
 #pragma unroll
   for (int j = 0; j < 16; ++j) { a[j][0] = f32x2{0.f, 0.f}; a[j][1] = f32x2{0.f, 0.f}; }
+  constexpr int rstep = D * kD16Pitch;                               // LDS bytes between rows of the class
   const char* const xr = xs + tt0 * kD16Pitch + cg * 8;
 #pragma unroll
-  for (int sl = 0; sl < 15; ++sl) d16_row(xr + sl * kD16Pitch, xw[sl]);
+  for (int sl = 0; sl < 15; ++sl) d16_row(xr + sl * rstep, xw[sl]);
   // window slot of output j at tap k = kb + kk is (j + kk) & 15 — static after unrolling
   for (int kb = 0; kb < p.K; kb += 16) {
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
       const int k = kb + kk;
       if (k < p.K) {
-        d16_row(xr + (k + 15) * kD16Pitch, xw[(15 + kk) & 15]);
+        d16_row(xr + (k + 15) * rstep, xw[(15 + kk) & 15]);
         const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + k * kDwBC + cg * 4);
         const f32x2 w0 = {wv[0], wv[1]}, w1 = {wv[2], wv[3]};
 #pragma unroll
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void depthwise_fwd16_kernel(DwArgs p) {
   }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int t = t0 + tt0 + j;
+    const int t = t0 + tt0 + D * j;
     if (t >= p.Tout) break;
     u32x2 o;
     o[0] = pack2bf(a[j][0][0], a[j][0][1]);
@@ -340,9 +346,13 @@ __global__ __launch_bounds__(256, 2) void depthwise_fwd16_kernel(DwArgs p) {
 // its 64 channels with a grid stride and keeps the sums in registers: thread = (16-tap group, channel
 // quad, time segment); one LDS reduction over the segments and ONE atomic per (tap, channel) and
 // workgroup at the end (the first kernel issued them per 128-step tile).
+// Dilation D: a time segment is (residue class of t mod D, time range); within it consecutive
+// steps are D apart and the x rows of tap j are D (k0 + j) further on — the dilation-1 walk with a
+// row step of D. nseg is a multiple of D.
+template <int D>
 __global__ __launch_bounds__(256, 2) void depthwise_wgrad16_kernel(DwArgs p, int ngrp, int nseg) {
   extern __shared__ __attribute__((aligned(16))) char smc[];
-  const int XR = kD16BT + 16 * ngrp;                                 // x rows staged per tile
+  const int XR = kD16BT + 16 * ngrp * D;                             // x rows staged per tile
   char* const xs = smc;                                              // [XR][136 B] bf16
   char* const ds = smc + XR * kD16Pitch;                             // [256][128 B] bf16 dy tile
   const int ntt = (p.Tout + kD16BT - 1) / kD16BT;
@@ -351,7 +361,9 @@ __global__ __launch_bounds__(256, 2) void depthwise_wgrad16_kernel(DwArgs p, int
   const int cell = threadIdx.x % ncell, seg = threadIdx.x / ncell;
   const int kg = cell >> 4, cg = cell & 15, k0 = kg * 16;
   const bool active = seg < nseg && c0 + cg * 4 < p.C;
-  const int ta = seg * kD16BT / nseg, tb = (seg + 1) * kD16BT / nseg;
+  const int nts = nseg / D, par = seg % D, tsg = seg / D;            // time ranges, residue class, range
+  const int ta = tsg * kD16BT / nts + par, tb = (tsg + 1) * kD16BT / nts;
+  const int nst = tb > ta ? (tb - ta + D - 1) / D : 0;               // steps of this thread per tile
   f32x2 a[16][2];
 #pragma unroll
   for (int j = 0; j < 16; ++j) { a[j][0] = f32x2{0.f, 0.f}; a[j][1] = f32x2{0.f, 0.f}; }
@@ -372,19 +384,20 @@ __global__ __launch_bounds__(256, 2) void depthwise_wgrad16_kernel(DwArgs p, int
     __syncthreads();
     if (active) {
       f32x2 xw[16][2];
-      const char* const xr = xs + (ta + k0) * kD16Pitch + cg * 8;
+      constexpr int rstep = D * kD16Pitch;
+      const char* const xr = xs + (ta + k0 * D) * kD16Pitch + cg * 8;
       const char* const dr = ds + ta * 128 + cg * 8;
 #pragma unroll
-      for (int sl = 0; sl < 15; ++sl) d16_row(xr + sl * kD16Pitch, xw[sl]);
+      for (int sl = 0; sl < 15; ++sl) d16_row(xr + sl * rstep, xw[sl]);
       // window slot of tap j at step ti is (j + ti) & 15 — static after unrolling
-      for (int i0 = 0; i0 < tb - ta; i0 += 16) {
+      for (int i0 = 0; i0 < nst; i0 += 16) {
 #pragma unroll
         for (int ti = 0; ti < 16; ++ti) {
           const int i = i0 + ti;
-          if (i < tb - ta) {
-            d16_row(xr + (i + 15) * kD16Pitch, xw[(15 + ti) & 15]);
+          if (i < nst) {
+            d16_row(xr + (i + 15) * rstep, xw[(15 + ti) & 15]);
             f32x2 dv[2];
-            d16_row(dr + i * 128, dv);
+            d16_row(dr + i * D * 128, dv);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
               a[j][0] = __builtin_elementwise_fma(xw[(j + ti) & 15][0], dv[0], a[j][0]);
@@ -438,17 +451,21 @@ extern "C" int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x
   if (rc != OS2S_OK) return rc;
   a.x = (const bf16_t*)x; a.w = w; a.y = (bf16_t*)y; a.in_len = in_len; a.out_len = out_len;
   a.flip = flip_taps;
-  if (stride == 1 && dil == 1 && g_dw_variant != 0) {
-    const size_t lds16 = (((size_t)(kD16BT + K - 1) * kD16Pitch + 15) & ~(size_t)15) + (size_t)K * kDwBC * sizeof(float);
-    if (lds16 <= 80 * 1024) {
+  if (stride == 1 && (dil == 1 || dil == 2 || dil == 4) && g_dw_variant != 0) {
+    const size_t lds16 = (((size_t)(kD16BT + (K - 1) * dil) * kD16Pitch + 15) & ~(size_t)15) + (size_t)K * kDwBC * sizeof(float);
+    if (lds16 <= 160 * 1024) {             // <= 80 KB: two workgroups per CU (every dilation-1 QuartzNet layer)
       static bool attr16 = false;
       if (!attr16) {
-        if (hipFuncSetAttribute((const void*)depthwise_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)depthwise_fwd16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)depthwise_fwd16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)depthwise_fwd16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
           return OS2S_ERR_LAUNCH;
         attr16 = true;
       }
       dim3 grid16(B * ceil_div(Tout, kD16BT), ceil_div(C, kDwBC));
-      OS2S_LAUNCH(depthwise_fwd16_kernel, grid16, dim3(256), lds16, (hipStream_t)stream, a);
+      if (dil == 1) { OS2S_LAUNCH(depthwise_fwd16_kernel<1>, grid16, dim3(256), lds16, (hipStream_t)stream, a); }
+      else if (dil == 2) { OS2S_LAUNCH(depthwise_fwd16_kernel<2>, grid16, dim3(256), lds16, (hipStream_t)stream, a); }
+      else { OS2S_LAUNCH(depthwise_fwd16_kernel<4>, grid16, dim3(256), lds16, (hipStream_t)stream, a); }
       return OS2S_OK;
     }
   }
@@ -470,23 +487,28 @@ extern "C" int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t*
   const int rc = dw_fill(a, B, Tin, Tout, C, K, stride, dil, padL);
   if (rc != OS2S_OK) return rc;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.in_len = in_len;
-  if (stride == 1 && dil == 1 && g_dw_variant != 0) {
+  if (stride == 1 && (dil == 1 || dil == 2 || dil == 4) && g_dw_variant != 0) {
     const int ngrp = ceil_div(K, 16), ncell = ngrp * 16;
     int nseg = 256 / ncell;
     nseg = nseg > 8 ? 8 : nseg;
-    const size_t tiles = (size_t)(kD16BT + 16 * ngrp) * kD16Pitch + (size_t)kD16BT * 128;
-    const size_t redb = (size_t)nseg * ncell * 64 * sizeof(float);
+    nseg = (nseg / dil) * dil;             // whole residue classes
+    const size_t tiles = (size_t)(kD16BT + 16 * ngrp * dil) * kD16Pitch + (size_t)kD16BT * 128;
+    const size_t redb = (size_t)(nseg > 0 ? nseg : 1) * ncell * 64 * sizeof(float);
     const size_t lds16 = tiles > redb ? tiles : redb;
-    if (nseg >= 1 && lds16 <= 80 * 1024) {
+    if (nseg >= 1 && lds16 <= 160 * 1024) {
       static bool attr16 = false;
       if (!attr16) {
-        if (hipFuncSetAttribute((const void*)depthwise_wgrad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)depthwise_wgrad16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)depthwise_wgrad16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)depthwise_wgrad16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
           return OS2S_ERR_LAUNCH;
         attr16 = true;
       }
       const int ntiles = B * ceil_div(Tout, kD16BT);
       dim3 grid16(ntiles < 64 ? ntiles : 64, ceil_div(C, kDwBC));
-      OS2S_LAUNCH(depthwise_wgrad16_kernel, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg);
+      if (dil == 1) { OS2S_LAUNCH(depthwise_wgrad16_kernel<1>, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg); }
+      else if (dil == 2) { OS2S_LAUNCH(depthwise_wgrad16_kernel<2>, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg); }
+      else { OS2S_LAUNCH(depthwise_wgrad16_kernel<4>, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg); }
       return OS2S_OK;
     }
   }

@@ -25,13 +25,15 @@ LAYERS = [
 ]
 
 
-@pytest.mark.parametrize("K,stride,dil", [(33, 1, 1), (11, 2, 1), (87, 1, 2), (1, 1, 1), (75, 1, 1), (16, 1, 1)])
+@pytest.mark.parametrize("K,stride,dil", [(33, 1, 1), (11, 2, 1), (87, 1, 2), (1, 1, 1), (75, 1, 1), (16, 1, 1),
+                                          (39, 1, 2), (20, 1, 4)])
 @pytest.mark.parametrize("shape", [(3, 200, 72), (4, 700, 200)])
 def test_depthwise_kernels(cuda, K, stride, dil, shape):
   """Depthwise forward / flipped-tap data gradient / weight gradient vs conv1d(groups=C) of the
-  same bf16 inputs. stride 1, dilation 1 takes the register-window kernels (K = 1, 16, 33, 75: one
-  to five 16-tap groups, a partial last group; T = 700: three 256-step tiles per sample, one of
-  them partial; C = 72 / 200: a partial 64-channel block), the rest the generic kernels."""
+  same bf16 inputs. Stride 1 with dilation 1 / 2 / 4 takes the register-window kernels (K = 1, 16,
+  33, 75: one to five 16-tap groups, a partial last group; dilation = residue classes of the rows;
+  T = 700: three 256-step tiles per sample, one of them partial; C = 72 / 200: a partial 64-channel
+  block), stride 2 the generic kernels."""
   from openseq2seq_amd import capi
   g = torch.Generator().manual_seed(K)
   B, T, C = shape
