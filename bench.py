@@ -210,6 +210,21 @@ class ConvTimer(object):
         dense += r[2]
         n += 1
     self.dense_flops = dense
+    # the same split by the kernel a launch dispatches to (the tile choice is a fixed function of the
+    # shape, conv1d_igemm.hip: ping-pong kernel for stride 1, >= 320 output channels, Cin a multiple
+    # of 64 and K long enough to spread the X prefetch — every K >= 11 layer of the Jasper configs;
+    # the lockstep tiles — 256-channel layers, stride 2, K = 1, grouped 1x1 — otherwise)
+    self.by_kernel = {}
+    for r in self.records:
+      if r[4]:
+        continue
+      cin, cout, k, stride = r[5]
+      name = ("conv1d_pp_kernel" if (cin > 0 and stride == 1 and k >= 8 and cout >= 320 and cin % 64 == 0)
+              else "conv1d_igemm_kernel + conv1d_igemm_grouped_kernel (lockstep tiles)")
+      e = self.by_kernel.setdefault(name, [0, 0.0, 0.0])
+      e[0] += 1
+      e[1] += r[0].elapsed_time(r[1])
+      e[2] += r[2] * self._live_fraction(r[3], cache)
     if os.environ.get("OS2S_BENCH_CONV_TABLE"):      # per-shape breakdown of the timed launches
       tab = {}
       for r in self.records:
@@ -653,6 +668,14 @@ def main():
         "launches_timed": ("every 4th forward-pass launch (the kernel alone on the GPU)" if timer.overlap
                            else "every 4th forward / data-gradient launch"),
         "all_launches_per_step": (timer.all_n + timer.untimed) / max(args.steps, 1),
+        "by_kernel": {name: {"launches": c, "avg_launch_ms": t / max(c, 1),
+                             "achieved": f / (t * 1e-3) / 1e12 if t > 0 else 0.0,
+                             "frac": (f / (t * 1e-3) / 1e12 if t > 0 else 0.0) / BF16_DENSE_PEAK_TFLOPS,
+                             "share_of_timed_ms": t / max(ms, 1e-9)}
+                      for name, (c, t, f) in timer.by_kernel.items()},
+        "sustained_mfma_peak_note": "a loop of nothing but v_mfma_f32_32x32x16_bf16 on every SIMD reaches "
+                                    "1.93-2.07 PFLOP/s on this chip (1.9 GHz under MFMA load; "
+                                    "profiles/r02_mfma_issue_probe.txt); `peak` is the 2.4 GHz data-sheet figure",
         "note": "achieved = FLOPs of the executed (non-skipped) time tiles / HIP-event time; "
                 "tiles whose input window is all padding are exact zeros and are not multiplied. "
                 "The data-gradient launches of the same kernel run concurrently with the "
