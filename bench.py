@@ -701,7 +701,7 @@ def main():
     others = {}
     for key in ("nmt", "ds2", "tacotron", "quartznet"):
       try:
-        others[key] = bench_simple(simple[key], 3, 2, hvd, dev, rank, world)
+        others[key] = bench_simple(simple[key], 6, 3, hvd, dev, rank, world)
       except Exception as e:   # never lose the headline line to a secondary measurement
         others[key] = {"error": repr(e)}
     try:
