@@ -438,7 +438,8 @@ int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, const uint16_t*
                      int mode, float keep_prob, unsigned long long seed, long long n,
                      uint16_t* d);
 /* The same on a [rows, C] matrix, with the column sums of d (the gradient of the Dense layer's
- * bias) from the same pass: partial[os2s_dropout_bwd_colsum_num_parts(rows)][2][C] fp32, plane 0 =
+ * bias: tf.layers.Dense(use_bias=True) of FeedFowardNetwork, parts/transformer/ffn_layer.py:51-85)
+ * from the same pass: partial[os2s_dropout_bwd_colsum_num_parts(rows)][2][C] fp32, plane 0 =
  * per-workgroup column sums (plane 1 zero) — reduce with os2s_bn_bwd_finalize(q = 1). */
 int os2s_dropout_bwd_colsum_num_parts(long long rows);
 int os2s_dropout_bwd_colsum(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out, int mode,
