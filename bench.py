@@ -73,17 +73,9 @@ def parse():
 
 def spawn_ranks(n):
   """`python bench.py --gpus N` without a launcher: re-execute this script as N ranks of ONE node
-  under torch.distributed.run (one process per GPU, RCCL over xGMI; rendezvous on 127.0.0.1 — the
-  reference relies on an external `mpirun -np N`, run.py:43-49). Returns the launcher's exit code."""
-  import socket
-  import subprocess
-  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-         "--master-addr", "127.0.0.1", "--master-port", str(port),
-         os.path.abspath(__file__)] + sys.argv[1:]
-  return subprocess.call(cmd)
+  (openseq2seq_amd/utils/distributed.py:spawn_ranks). Returns the launcher's exit code."""
+  from openseq2seq_amd.utils.distributed import spawn_ranks as _spawn
+  return _spawn(n, __file__, sys.argv[1:])
 
 
 class ConvTimer(object):

@@ -74,6 +74,20 @@ class Model(object):
     self._mode = mode
     self._hvd = hvd
     p = self._params
+    # tower mode (models/model.py:293-303, 386-427): `use_horovod False, num_gpus N` means N
+    # replicas and a global batch of N * batch_size_per_gpu. Replicas are ranks here, so the
+    # process group has to have exactly N of them (run.py / bench.py launch them); training a
+    # tower config on fewer GPUs than it names is refused, never silent.
+    self._towers = 1
+    if not p['use_horovod']:
+      self._towers = dist_utils.configured_towers(p)
+      world = hvd.size() if hvd is not None else 1
+      if self._towers != world and mode in ("train", "eval"):
+        raise ValueError(
+            "config asks for %d replicas (use_horovod False, num_gpus/gpu_ids) but this process "
+            "group has %d rank(s): launch through run.py (it starts the ranks itself) or "
+            "`python -m torch.distributed.run --nproc-per-node %d`" % (self._towers, world,
+                                                                      self._towers))
     p.setdefault('dtype', 'mixed')
     p.setdefault('iter_size', 1)
     p.setdefault('loss_scaling', 1.0)
@@ -111,7 +125,9 @@ class Model(object):
 
   @property
   def num_gpus(self):
-    return 1
+    """Replicas the job trains on (model.py:293-303): the tower count of the config without
+    Horovod — each one is a rank of this process group — and 1 per rank under Horovod."""
+    return self._towers
 
   @property
   def store(self):

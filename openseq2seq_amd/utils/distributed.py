@@ -49,6 +49,62 @@ def init_from_env(backend=None):
   return HvdAdapter()
 
 
+def configured_towers(config):
+  """Number of model replicas a config asks for WITHOUT Horovod: `gpu_ids` wins over `num_gpus`
+  (models/model.py:293-303; the reference raises when neither is given, a single replica is the
+  default here)."""
+  if 'gpu_ids' in config:
+    return max(len(config['gpu_ids']), 1)
+  return max(int(config.get('num_gpus', 1)), 1)
+
+
+def plan_workers(config, environ=None):
+  """How many ranks a config means and whether this process still has to launch them.
+
+  The reference has two data-parallel modes (models/model.py:386-427): Horovod (`use_horovod
+  True`: the ranks come from `mpirun -np N`, `num_gpus` is ignored) and tower mode (`use_horovod
+  False, num_gpus N`: ONE process builds N replicas with shared variables, loss = mean over
+  replicas, data layer i of N per replica). Here both are one process per GPU over RCCL, so
+  tower mode with N > 1 means N ranks: if no launcher provided them (`WORLD_SIZE` unset) the
+  caller re-executes itself under torch.distributed.run (`spawn` True); a launcher whose world
+  size contradicts `num_gpus` is an error — a tower config never silently trains on fewer
+  replicas than it names.
+
+  Returns (world, spawn)."""
+  env = os.environ if environ is None else environ
+  launched = "WORLD_SIZE" in env
+  world_env = int(env.get("WORLD_SIZE", "1"))
+  if config.get('use_horovod', False):
+    return world_env, False
+  n = configured_towers(config)
+  if n == 1:
+    if launched and world_env > 1:
+      raise ValueError("use_horovod is False and the config names one GPU, but the launcher "
+                       "started %d ranks: set use_horovod True (or num_gpus %d)" % (world_env, world_env))
+    return 1, False
+  if not launched:
+    return n, True
+  if world_env != n:
+    raise ValueError("config asks for num_gpus=%d replicas but the launcher started %d rank(s) "
+                     "(WORLD_SIZE=%s)" % (n, world_env, env.get("WORLD_SIZE")))
+  return n, False
+
+
+def spawn_ranks(n, script, argv):
+  """Re-execute `script argv` as n ranks of ONE node under torch.distributed.run (one process per
+  GPU, RCCL over xGMI; rendezvous on 127.0.0.1 — the reference relies on an external
+  `mpirun -np N`, run.py:43-49, or on in-process towers). Returns the launcher's exit code."""
+  import socket
+  import subprocess
+  import sys
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script)] + list(argv)
+  return subprocess.call(cmd)
+
+
 def broadcast_parameters(store, extra_tensors=(), root=0):
   """Rank-0 values for every variable (masters + non-trainable state)."""
   dist.broadcast(store.master, src=root)

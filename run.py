@@ -9,6 +9,7 @@ utils/funcs.py:172-218 (objects/sec accounting); checkpoints are written under t
 variable names (openseq2seq_amd/utils/checkpoint.py)."""
 from __future__ import print_function
 
+import os
 import sys
 import time
 
@@ -111,9 +112,38 @@ def infer(model, args, rank):
     deco_print("Finished inference: %d batches -> %s" % (len(results), args.infer_output_file))
 
 
+def launch_dry_run(base_config, hvd):
+  """OS2S_LAUNCH_DRY_RUN=1: stop after the process group exists and report what the job would
+  train on (no model, no GPU work) — the check that a tower config gets all its replicas."""
+  import json
+  world = hvd.size() if hvd else 1
+  seen = torch.ones(1)
+  if world > 1:
+    torch.distributed.all_reduce(seen)
+  if (hvd.rank() if hvd else 0) == 0:
+    print(json.dumps({"world_size": world, "ranks_seen": int(seen.item()),
+                      "use_horovod": bool(base_config.get('use_horovod', False)),
+                      "batch_size_per_gpu": base_config['batch_size_per_gpu'],
+                      "global_batch": base_config['batch_size_per_gpu'] * world,
+                      "backend": torch.distributed.get_backend() if world > 1 else "none"}))
+  if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
   args, base_config, base_model, config_module = get_base_config(sys.argv[1:])
-  hvd = dist_utils.init_from_env() if base_config.get('use_horovod', False) else None
+  # Horovod mode: the ranks come from the launcher. Tower mode (`use_horovod False, num_gpus N`,
+  # models/model.py:386-427): N replicas = N ranks, started here when no launcher did
+  world, spawn = dist_utils.plan_workers(base_config)
+  if spawn:
+    deco_print("num_gpus=%d without Horovod: starting %d ranks (one process per GPU, RCCL)"
+               % (world, world))
+    sys.exit(dist_utils.spawn_ranks(world, __file__, sys.argv[1:]))
+  hvd = dist_utils.init_from_env() if world > 1 else None
+  if os.environ.get("OS2S_LAUNCH_DRY_RUN", "") == "1":
+    launch_dry_run(base_config, hvd)
+    return
   model = create_model(args, base_config, config_module, base_model, hvd)
   rank = hvd.rank() if hvd else 0
   if args.mode == "eval":

@@ -122,3 +122,99 @@ def test_tape_watermark_waits_for_out_of_order_and_shared_variables():
   t2.record(lambda: ran.append("x"), [emb])
   t2.backward()
   assert ran[-1] == "x"
+
+
+# ---- tower mode: `use_horovod False, num_gpus N` (models/model.py:386-427) -------------------
+
+REF_DS2 = "/root/reference/example_configs/speech2text/ds2_large_8gpus.py"
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+  env = dict(os.environ)
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+            "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+    env.pop(k, None)
+  env.update(extra)
+  return env
+
+
+def test_plan_workers_rules():
+  from openseq2seq_amd.utils.distributed import plan_workers
+  # Horovod mode: the launcher decides, num_gpus is ignored (as in the reference)
+  assert plan_workers({"use_horovod": True, "num_gpus": 8}, {}) == (1, False)
+  assert plan_workers({"use_horovod": True}, {"WORLD_SIZE": "4"}) == (4, False)
+  # tower mode: N replicas = N ranks; start them when nobody did
+  assert plan_workers({"use_horovod": False, "num_gpus": 8}, {}) == (8, True)
+  assert plan_workers({"use_horovod": False, "gpu_ids": [0, 1, 2], "num_gpus": 8}, {}) == (3, True)
+  assert plan_workers({"use_horovod": False, "num_gpus": 2}, {"WORLD_SIZE": "2"}) == (2, False)
+  assert plan_workers({"use_horovod": False, "num_gpus": 1}, {}) == (1, False)
+  assert plan_workers({"use_horovod": False}, {}) == (1, False)
+  with pytest.raises(ValueError):      # a launcher that contradicts the config is refused
+    plan_workers({"use_horovod": False, "num_gpus": 8}, {"WORLD_SIZE": "2"})
+  with pytest.raises(ValueError):
+    plan_workers({"use_horovod": False, "num_gpus": 1}, {"WORLD_SIZE": "2"})
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_DS2), reason="reference checkout not present")
+def test_tower_config_starts_its_ranks():
+  """The reference's ds2_large_8gpus.py (use_horovod False, num_gpus 8, batch_size_per_gpu 16)
+  with num_gpus overridden to 2: run.py starts 2 ranks itself (gloo here), every rank joins, the
+  global batch is 32. It never runs the config on one replica."""
+  import json
+  import subprocess
+  import sys
+  r = subprocess.run([sys.executable, os.path.join(_REPO, "run.py"), "--config_file=" + REF_DS2,
+                      "--mode=train", "--num_gpus=2"],
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                     env=_clean_env(OS2S_LAUNCH_DRY_RUN="1"))
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d["world_size"] == 2 and d["ranks_seen"] == 2 and d["global_batch"] == 32
+  assert d["use_horovod"] is False and d["backend"] in ("gloo", "nccl")
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_DS2), reason="reference checkout not present")
+def test_tower_config_refuses_a_smaller_world():
+  import subprocess
+  import sys
+  r = subprocess.run([sys.executable, os.path.join(_REPO, "run.py"), "--config_file=" + REF_DS2,
+                      "--mode=train"],                        # num_gpus 8 as written
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                     env=_clean_env(OS2S_LAUNCH_DRY_RUN="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+  assert r.returncode != 0 and "num_gpus=8" in r.stderr
+
+
+def test_model_refuses_fewer_replicas_than_the_config_names():
+  """Model.__init__ itself (not only run.py) refuses `num_gpus 8` on a one-rank process group;
+  Model.num_gpus reports the replica count (model.py:293-303)."""
+  from openseq2seq_amd.models.model import Model
+
+  class M(Model):
+    def _build_forward_pass_objects(self, store):
+      pass
+
+    def _forward_backward(self, batch, tape):
+      pass
+
+    def _get_num_objects_per_step(self, batch):
+      return 0
+
+  base = {"use_horovod": False, "batch_size_per_gpu": 16, "data_layer": None}
+  dev = torch.device("cpu")
+  with pytest.raises(ValueError, match="8 replicas"):
+    M(dict(base, num_gpus=8), mode="train", device=dev)
+  assert M(dict(base, num_gpus=1), mode="train", device=dev).num_gpus == 1
+
+  class Hvd(object):
+    def rank(self):
+      return 1
+
+    def size(self):
+      return 2
+
+  m = M(dict(base, num_gpus=2), mode="train", hvd=Hvd(), device=dev)
+  assert m.num_gpus == 2
+  assert M(dict(base, use_horovod=True, num_gpus=8), mode="train", hvd=Hvd(), device=dev).num_gpus == 1
