@@ -709,7 +709,7 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
 // os2s_conv1d_set_variant(v >= 0) forces a tile for experiments and tests:
 //   0 = 128x128, X window double-buffered   3 = 128x128, X window single-buffered when K >= 8
 //   5 = 256x256 lockstep                   10 = ping-pong
-// experiment knob read once from the environment (A/B runs on one box: tools/r2_probe31.sh)
+// experiment knob read once from the environment (A/B runs on one box: tools/bench_conv_split.py)
 static int env_int(const char* name, int dflt) {
   static std::mutex mu;
   static std::map<std::string, int> cache;

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void psf_absmax_kernel(const void* __restrict_
                                                         const int32_t* __restrict__ n_samples,
                                                         float* __restrict__ gain) {
   __shared__ float red[4];
-  const int b = blockIdx.x, n = n_samples[b];
+  const int b = blockIdx.x;
+  const int n = (int)min((long long)n_samples[b], sig_stride);   // never past the row (as logmel.hip)
   float m = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
     const float v = is_i16 ? (float)reinterpret_cast<const int16_t*>(signal)[(long long)b * sig_stride + i]
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void psf_logpowspec_kernel(
   float* sn = sm + 2 * n_win;    // [n_win]
   __shared__ double red[2][4];
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-  const int n = n_samples[b];
+  const int n = (int)min((long long)n_samples[b], sig_stride);   // never past the row
   int frames = n <= n_win ? 1 : 1 + (n - n_win + n_step - 1) / n_step;
   if (pad_to > 0 && frames % pad_to) frames += pad_to - frames % pad_to;
   if (t == 0 && tid == 0) frames_out[b] = frames;

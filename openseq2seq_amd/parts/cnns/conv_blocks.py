@@ -434,6 +434,11 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     capi.bn_bwd_finalize_multi(partial, rows, [br.gamma.grad for br in branches],
                                [br.beta.grad for br in branches], True, c1, c2)
     grouped = []        # plain 1x1 residual branches: their data gradients go out in one launch
+    # (one launch = one (B, T) and one length vector: the predicate of the forward grouping)
+    plain = [j for j in range(1, len(branches)) if _is_plain_1x1(branches[j])]
+    can_group = len(branches) > 2 and len(plain) >= 2 and \
+        len({tuple(inputs[j].data.shape[:2]) for j in plain}) == 1 and \
+        len({id(inputs[j].lens) for j in plain}) == 1
     for j, (br, inp, f) in enumerate(zip(branches, inputs, fw)):
       dy = torch.empty_like(f["y"])
       # a plain convolution's gradients read dy at most (K-1)*dilation rows past the sequence end
@@ -442,7 +447,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
       capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1[j], c2[j], dy,
                         out_len=lens if ragged else None, margin=(br.k - 1) * br.dil)
       f["y"] = None
-      if j > 0 and _is_plain_1x1(br) and len(branches) > 2:
+      if can_group and j in plain:
         br.backward_weights(inp, dy, f)
         if inp.requires_grad:
           grouped.append((br, inp, dy))

@@ -91,7 +91,7 @@ class Dense(object):
       y = capi.matmul_lt(x.data, self.w, b_is_t=True)
       if not (act == 0 and keep >= 1.0 and residual is None and self.bias is None):
         capi.dense_epilogue(y, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
-    elif self.cin % 64 == 0:
+    elif self.cin % 64 == 0 and act in (0, 1) and self.cout % 8 == 0:   # what gemm_pp.hip accepts
       y = capi.gemm_nt(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
     else:
       y = capi.gemm(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
@@ -118,9 +118,10 @@ class Dense(object):
           dz = capi.dropout_bwd(dy, keep, seed=seed)     # recomputed hash mask / keep
       else:
         dz = dy
-      # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs
-      # (kept on the main stream: on a side stream it wins 10 % over 20 steps but LOSES 11 % once
-      # the GPU sits at its power limit — 26.6 vs 24.0 ms/step over 300 steps)
+      # dW += dz^T x (fp32) and dx (+)= dz W: plain GEMMs. The weight gradient goes to the side
+      # stream by default (OS2S_DENSE_WGRAD_STREAM): with the in-tree kernels it fills the half of
+      # the chip a 132-tile data-gradient GEMM leaves idle, 22.1 -> 20.3 ms/step over 20 AND over
+      # 300 steps (with the round-1 vendor GEMMs the same move lost 11 % at the power limit)
       if GEMM_BACKEND == "lt":
         capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
       elif DENSE_WGRAD_STREAM:

@@ -17,8 +17,11 @@ reference's variable name, in the reference's layout:
   anything else   as is (conv2d kernels are already [KT, KF, Cin, Cout]; recurrent kernels keep the
                   device gate order — see DESIGN.md)
 
-In mixed precision the fp32 master values are written under BOTH the plain name and the
-master-copy name, so either restore path of helpers.py finds them. Optimizer slots, the
+In mixed precision a half-precision variable is written as DT_HALF (float16) under its plain
+name and as fp32 under the master-copy name — the dtypes a reference fp16 graph holds, so a
+plain tf.train.Saver restore and the casting restore of helpers.py both accept the file;
+import prefers the fp32 twin. The byte format has never been compared with a file written by
+TensorFlow itself (none ships with the reference): "TF-V2-shaped, unverified". Optimizer slots, the
 global step and the loss-scaler state are stored under 'OS2S/...' keys (own format).
 """
 from __future__ import absolute_import, division, print_function
@@ -84,10 +87,11 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
       return out
 
   def get(n):
-    if n in tf_arrays:
-      return np.asarray(tf_arrays[n], np.float32)
+    # the fp32 master twin first (exact), the (possibly half-precision) plain name otherwise
     if MASTER_PREFIX + n in tf_arrays:
       return np.asarray(tf_arrays[MASTER_PREFIX + n], np.float32)
+    if n in tf_arrays:
+      return np.asarray(tf_arrays[n], np.float32)
     return None
   if name.endswith("/qkv/kernel") or name.endswith("/kv/kernel"):
     base = name[:name.rindex("/", 0, len(name) - len("/kernel"))]
@@ -111,16 +115,22 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
 
 
 def model_variables(model):
-  """{reference name: fp32 array in TF layout} for every variable of the model."""
+  """{reference name: array in TF layout} for every variable of the model; dtypes as a
+  reference checkpoint of the same precision mode holds them."""
   store = model.store
   out = {}
   mixed = model.params.get("dtype", "mixed") == "mixed"
   for p in store.params:
     arr = p.master.detach().cpu().numpy()
     for tf_name, tf_arr in export_param(p.name, p.shape, p.kind, arr, getattr(p, "logical_out", None)):
-      out[tf_name] = tf_arr
-      if mixed and p.kind != "vector":      # only half-precision variables have master copies
+      if mixed and p.kind != "vector":
+        # a mixed-precision graph of the reference holds this variable as DT_HALF and its fp32
+        # twin under the master-copy name (optimizers/mp_wrapper.py:55-82): a plain
+        # tf.train.Saver restore checks the dtype, so the plain name carries float16
+        out[tf_name] = tf_arr.astype(np.float16)
         out[MASTER_PREFIX + tf_name] = tf_arr
+      else:
+        out[tf_name] = tf_arr
   for name, t in store.state.items():
     out[name] = t.detach().cpu().numpy().copy()
   return out
