@@ -33,6 +33,44 @@ def _r(x, emulate, fwd=True, bwd=True):
   return _Round.apply(x, fwd, bwd) if emulate else x
 
 
+def tdnn_layer(feats, layer_res, blk, name, weights, out_mask=None, activation="relu", bn_eps=1e-3,
+               keep_mask=None, keep_prob=1.0, emulate_bf16=False):
+  """ONE conv_bn_actv / conv_bn_res_bn_actv call (parts/cnns/conv_blocks.py:61-232) + the
+  encoder's dropout and output mask (tdnn_encoder.py:248-256): act(BN(conv(feats)) + sum_i
+  BN_i(conv1x1_i(layer_res[i]))) -> dropout -> mask. `feats` / `layer_res` are already masked
+  (the encoder masks every conv input); `layer_res` is empty unless this is the last repeat of a
+  residual block; `name` = 'convIJ'. Also the unit of the layer-by-layer device tests, which feed
+  both sides the same inputs."""
+  K, s = blk["kernel_size"][0], blk["stride"][0]
+  d = blk.get("dilation", [1])[0]
+  dense = blk.get("residual_dense", False)
+  em = emulate_bf16
+  # conv outputs are stored in bf16; their gradients (BN backward) too
+  sep = blk.get("type", "conv1d") == "sep_conv1d"
+  if sep:
+    y = _r(cnn.sep_conv1d_tf(feats, weights[name + "/depthwise_kernel"],
+                             weights[name + "/pointwise_kernel"], s, d, blk["padding"]), em)
+  else:
+    y = _r(cnn.conv1d_tf(feats, weights[name + "/kernel"], s, d, blk["padding"]), em)
+  tot = cnn.batch_norm_train(y, weights[name + "/bn/gamma"], weights[name + "/bn/beta"], bn_eps)[0]
+  for i, r in enumerate(layer_res):
+    rn = (name + "/res_%d" % i) if dense else (name + "/res")
+    bn = (name + "/res_bn_%d" % i) if dense else (name + "/res_bn")
+    if sep:   # residual branches use the block's layer type with k = 1 (conv_blocks.py:66,79-85)
+      ry = _r(cnn.sep_conv1d_tf(r, weights[rn + "/depthwise_kernel"],
+                                weights[rn + "/pointwise_kernel"], 1, 1, "SAME"), em)
+    else:
+      ry = _r(cnn.conv1d_tf(r, weights[rn + "/kernel"], 1, 1, "SAME"), em)
+    tot = tot + cnn.batch_norm_train(ry, weights[bn + "/gamma"], weights[bn + "/beta"], bn_eps)[0]
+  tot = _r(tot, em, fwd=False, bwd=True)      # dz is stored in bf16
+  out = cnn.act_fn(tot, activation)
+  if keep_mask is not None:
+    out = out * keep_mask.float() / keep_prob
+  if out_mask is not None:
+    out = out * out_mask   # idempotent w.r.t. the reference's later multiply
+  return _r(out, em)                           # block outputs / their grads: bf16
+
+
 def tdnn_encode(x, src_len, convnet_layers, weights, activation="relu", use_conv_mask=True,
                 bn_eps=1e-3, keep_masks=None, keep_probs=None, emulate_bf16=False):
   """x [B,T,F] fp32; weights: dict name -> tensor in TF layouts
@@ -69,34 +107,11 @@ def tdnn_encode(x, src_len, convnet_layers, weights, activation="relu", use_conv
         feats = feats * mask
       if use_conv_mask and (blk["padding"] == "VALID" or s > 1):
         mask = cnn.seq_mask(src_len, T)
-      em = emulate_bf16
-      # conv outputs are stored in bf16; their gradients (BN backward) too
-      sep = blk.get("type", "conv1d") == "sep_conv1d"
-      if sep:
-        y = _r(cnn.sep_conv1d_tf(feats, weights[name + "/depthwise_kernel"],
-                                 weights[name + "/pointwise_kernel"], s, d, blk["padding"]), em)
-      else:
-        y = _r(cnn.conv1d_tf(feats, weights[name + "/kernel"], s, d, blk["padding"]), em)
-      tot = cnn.batch_norm_train(y, weights[name + "/bn/gamma"], weights[name + "/bn/beta"],
-                                 bn_eps)[0]
-      if residual and ir == blk["repeat"] - 1:
-        for i, r in enumerate(layer_res):
-          rn = (name + "/res_%d" % i) if dense else (name + "/res")
-          bn = (name + "/res_bn_%d" % i) if dense else (name + "/res_bn")
-          if sep:   # residual branches use the block's layer type with k = 1 (conv_blocks.py:66,79-85)
-            ry = _r(cnn.sep_conv1d_tf(r, weights[rn + "/depthwise_kernel"],
-                                      weights[rn + "/pointwise_kernel"], 1, 1, "SAME"), em)
-          else:
-            ry = _r(cnn.conv1d_tf(r, weights[rn + "/kernel"], 1, 1, "SAME"), em)
-          tot = tot + cnn.batch_norm_train(ry, weights[bn + "/gamma"], weights[bn + "/beta"],
-                                           bn_eps)[0]
-      tot = _r(tot, em, fwd=False, bwd=True)      # dz is stored in bf16
-      feats = cnn.act_fn(tot, activation)
-      if keep_masks is not None and keep_masks[li] is not None:
-        feats = feats * keep_masks[li].float() / keep_probs[li]
-      if use_conv_mask and not (ib == len(convnet_layers) - 1 and ir == blk["repeat"] - 1):
-        feats = feats * mask   # idempotent w.r.t. the reference's later multiply
-      feats = _r(feats, em)                        # block outputs / their grads: bf16
+      last = ib == len(convnet_layers) - 1 and ir == blk["repeat"] - 1
+      feats = tdnn_layer(feats, layer_res if (residual and ir == blk["repeat"] - 1) else [], blk, name,
+                         weights, mask if (use_conv_mask and not last) else None, activation, bn_eps,
+                         keep_masks[li] if keep_masks is not None else None,
+                         keep_probs[li] if keep_probs is not None else 1.0, emulate_bf16)
       li += 1
   return feats, src_len
 

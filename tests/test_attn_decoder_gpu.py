@@ -36,7 +36,16 @@ CASES = {
     "tacotron_k5": (4, 9, 70, 2, 96, 128, 128, 2, 5, 8, False, 1.0, 0.9, False),
     "luong": (5, 8, 12, 1, 128, 256, 128, 3, 0, 0, False, 0.8, 1.0, True),
     "luong_2layer": (3, 6, 9, 2, 128, 64, 128, 3, 0, 0, False, 1.0, 0.9, False),
+    # the Tacotron2-GST decoder cell at the sizes of example_configs/text2speech/tacotron_gst.py:
+    # 152-170 — two LSTM layers of 1024 units, memory = encoder 512 + style embedding 512,
+    # attention layer 128 with bias, location filters 32 x 32 — over S = 200 source positions and
+    # 50 decoder steps (the 16-wave cell / backward tiles and the S > 128 attention paths the bench
+    # runs). Recurrent weights 0.35/sqrt(K) and a soft attention vector as in test_fp8_weights_gpu:
+    # at unit scale the recurrence + attention feedback is chaotic and tests the dynamics instead
+    "tacotron_full": (8, 50, 200, 2, 1024, 1024, 128, 2, 32, 32, True, 1.0, 0.9, False),
 }
+W_SCALE = {"tacotron_full": 0.35}      # recurrent weight scale (x 1/sqrt(K)); default 1.0
+V_SCALE = {"tacotron_full": 0.2}       # attention vector scale; default 1.0
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -46,11 +55,11 @@ def test_attn_decoder_fwd_bwd(cuda, case):
   g = torch.Generator().manual_seed(sum(map(ord, case)))
   rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
   kc = [M + H, 2 * H]
-  wcat = [_bf(rn(4 * H, kc[l], sc=1.0 / math.sqrt(kc[l]))) for l in range(L)]
+  wcat = [_bf(rn(4 * H, kc[l], sc=W_SCALE.get(case, 1.0) / math.sqrt(kc[l]))) for l in range(L)]
   bias = [None] + [rn(4 * H, sc=0.1) for _ in range(L - 1)]
   wq = _bf(rn(U, H, sc=1.0 / math.sqrt(H))) if mode != 3 else torch.eye(U).to(torch.bfloat16)
   wmem = _bf(rn(U, M, sc=1.0 / math.sqrt(M)))
-  v = rn(U, sc=1.0)
+  v = rn(U, sc=V_SCALE.get(case, 1.0))
   gsc = torch.tensor([1.3]) if mode == 1 else None
   bb = rn(U, sc=0.1) if (mode == 1 or use_bias) else None
   conv_w = rn(K, F, sc=0.5) if mode == 2 else None

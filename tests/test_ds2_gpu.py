@@ -1,7 +1,17 @@
-"""GPU parity of the DeepSpeech2 encoder path (scaled down: F=32, two conv2d+BN+ReLU
-layers with the reference's strides [2,2]/[1,2], 2-layer bidirectional cuDNN-form GRU,
-dense+ReLU) + FC-CTC: outputs, loss and all parameter gradients vs the CPU fp32 oracle.
-Dropout off for parity. Tolerances as in test_jasper_e2e_gpu (bf16 storage)."""
+"""GPU parity of the DeepSpeech2 encoder path + FC-CTC: outputs, loss and all parameter
+gradients vs the CPU fp32 oracle (oracle/ds2.py; recurrent layers = torch.nn.GRU in cuDNN form).
+Dropout off for parity.
+
+Two sizes:
+  * scaled down (F=32, 2-layer bidirectional GRU-64, dense 128) — tolerances as in
+    test_jasper_e2e_gpu (bf16 storage);
+  * the BASELINE configuration itself, example_configs/speech2text/ds2_large_8gpus.py:53-72:
+    F=160, conv2d [11,41]/[2,2] and [11,21]/[1,2] with 32 channels (-> 40*32 = 1280 features per
+    frame), FIVE bidirectional cuDNN-form GRU layers of 800 units, dense 1600, at a small ragged
+    batch — the shapes the bench runs (H=800 reductions of the 8-/32-row step tiles, the 1280- and
+    1600-wide input-projection GEMMs, the Toeplitz expansion at F=160) that no scaled test reaches.
+Tolerances (stated per case below): logits rel-L2, CTC loss rtol, per-parameter gradient cosine
+and rel-L2 against the fp32 oracle evaluated on the SAME bf16-rounded weights."""
 import pytest
 import torch
 
@@ -11,7 +21,7 @@ CONV = [{"kernel_size": [11, 41], "stride": [2, 2], "num_channels": 32, "padding
         {"kernel_size": [11, 21], "stride": [1, 2], "num_channels": 32, "padding": "SAME"}]
 
 
-def test_ds2_small_fwd_bwd(cuda):
+def _ds2_fwd_bwd(cuda, Fr, H, NH, n_layers, lens_list, n_labels, tol):
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders.ds2_encoder import DeepSpeech2Encoder
   from openseq2seq_amd.decoders.fc_decoders import FullyConnectedCTCDecoder
@@ -19,9 +29,8 @@ def test_ds2_small_fwd_bwd(cuda):
   from openseq2seq_amd.parts.cnns.conv_blocks import Tape
   from oracle import ds2 as ods, tdnn as otdnn
   torch.manual_seed(0)
-  Fr, H, NH = 32, 64, 128
   store = FlatParams(cuda)
-  enc = DeepSpeech2Encoder({"conv_layers": CONV, "num_rnn_layers": 2, "rnn_cell_dim": H,
+  enc = DeepSpeech2Encoder({"conv_layers": CONV, "num_rnn_layers": n_layers, "rnn_cell_dim": H,
                             "use_cudnn_rnn": True, "rnn_type": "cudnn_gru",
                             "rnn_unidirectional": False, "row_conv": False, "n_hidden": NH,
                             "dropout_keep_prob": 1.0, "activation_fn": "relu",
@@ -32,11 +41,11 @@ def test_ds2_small_fwd_bwd(cuda):
   lossf = CTCLoss({"dtype": "mixed"}, None)
   store.finalize()
   g = torch.Generator().manual_seed(1)
-  B, T = 3, 60
+  B, T = len(lens_list), max(lens_list)
   x = torch.randn(B, T, Fr, generator=g).to(torch.bfloat16)
-  lens = torch.tensor([60, 44, 31], dtype=torch.int32)
-  labels = torch.randint(0, 28, (B, 8), generator=g).to(torch.int32)
-  label_len = torch.tensor([8, 5, 3], dtype=torch.int32)
+  lens = torch.tensor(lens_list, dtype=torch.int32)
+  labels = torch.randint(0, 28, (B, max(n_labels)), generator=g).to(torch.int32)
+  label_len = torch.tensor(n_labels, dtype=torch.int32)
   tape = Tape()
   store.zero_grads()
   e = enc.encode({"source_tensors": [x.to(cuda), lens.to(cuda)], "tape": tape, "seed": 1})
@@ -44,7 +53,7 @@ def test_ds2_small_fwd_bwd(cuda):
   L = lossf.compute_loss({"decoder_output": d, "target_tensors": [labels.to(cuda), label_len.to(cuda)]})
   tape.backward()
   torch.cuda.synchronize()
-  assert e["src_length"].cpu().tolist() == [30, 22, 16]
+  assert e["src_length"].cpu().tolist() == [(n + 1) // 2 for n in lens_list]
   # ---- oracle -------------------------------------------------------------------
   W, leaves = {}, {}
   for i in (1, 2):
@@ -58,7 +67,7 @@ def test_ds2_small_fwd_bwd(cuda):
     leaves[n + "/bn/gamma"] = W["conv%d/bn/gamma" % i]
     leaves[n + "/bn/beta"] = W["conv%d/bn/beta" % i]
   width = enc.convs[-1].Fo * 32
-  gru = torch.nn.GRU(width, H, num_layers=2, batch_first=True, bidirectional=True)
+  gru = torch.nn.GRU(width, H, num_layers=n_layers, batch_first=True, bidirectional=True)
   with torch.no_grad():
     for l, dirs in enumerate(enc.rnn.layers):
       for dd, layer in enumerate(dirs):
@@ -69,6 +78,8 @@ def test_ds2_small_fwd_bwd(cuda):
         getattr(gru, "bias_hh" + sfx).copy_(layer.bh.master.cpu())
         leaves[layer.wx[0].name] = getattr(gru, "weight_ih" + sfx)
         leaves[layer.wh.name] = getattr(gru, "weight_hh" + sfx)
+        leaves[layer.bx.name] = getattr(gru, "bias_ih" + sfx)
+        leaves[layer.bh.name] = getattr(gru, "bias_hh" + sfx)
   fcw = enc.fc.kernel.w16.float().cpu()[0].t().contiguous().requires_grad_(True)
   fcb = enc.fc.bias.master.cpu().clone().requires_grad_(True)
   leaves[enc.fc.kernel.name], leaves[enc.fc.bias.name] = fcw, fcb
@@ -79,8 +90,8 @@ def test_ds2_small_fwd_bwd(cuda):
   loss.backward()
   lg = d["logits"].cpu()
   rel = float((lg - logits.detach()).norm() / logits.detach().norm())
-  assert rel < 3e-2, rel
-  torch.testing.assert_close(L.cpu()[0], loss.detach(), rtol=2e-2, atol=2e-2)
+  assert rel < tol["logits"], rel
+  torch.testing.assert_close(L.cpu()[0], loss.detach(), rtol=tol["loss"], atol=tol["loss"])
   worst = (1.0, "")
   for name, leaf in leaves.items():
     got = store.by_name(name).grad.cpu()
@@ -92,8 +103,24 @@ def test_ds2_small_fwd_bwd(cuda):
     cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
     relerr = float((got - ref).norm() / (ref.norm() + 1e-12))
     worst = min(worst, (cos, name))
-    assert cos > 0.98 and relerr < 0.2, (name, cos, relerr)
+    assert cos > tol["cos"] and relerr < tol["rel"], (name, cos, relerr)
   print("worst cosine", worst, "logits rel", rel)
+  return rel, worst
+
+
+
+def test_ds2_small_fwd_bwd(cuda):
+  _ds2_fwd_bwd(cuda, Fr=32, H=64, NH=128, n_layers=2, lens_list=[60, 44, 31], n_labels=[8, 5, 3],
+               tol=dict(logits=3e-2, loss=2e-2, cos=0.98, rel=0.2))
+
+
+def test_ds2_large_full_size_fwd_bwd(cuda):
+  """ds2_large_8gpus.py:53-72 at its real widths (see the module docstring): B=4 ragged,
+  T = 96 / 77 / 50 / 33 input frames. Tolerances: logits rel-L2 1e-2 (measured 3.6e-3), loss 1e-2,
+  every parameter gradient cosine > 0.995 (measured worst 0.9989) and rel-L2 < 0.1 against the fp32
+  oracle (bf16 storage noise through five recurrent layers)."""
+  _ds2_fwd_bwd(cuda, Fr=160, H=800, NH=1600, n_layers=5, lens_list=[96, 77, 50, 33],
+               n_labels=[12, 9, 6, 3], tol=dict(logits=1e-2, loss=1e-2, cos=0.995, rel=0.1))
 
 
 def test_row_conv_layer_and_unidirectional_encoder(cuda):

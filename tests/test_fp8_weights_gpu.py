@@ -48,9 +48,14 @@ def test_quantize_rows_e4m3_bit_exact(cuda):
   assert float((deq - w.float()).abs().max() / w.float().abs().max()) < 2.0 ** -4
 
 
-def test_decoder_loop_fp8_weights_240_steps(cuda):
+@pytest.mark.parametrize("size", ["h128_240_steps", "tacotron_gst_full_size"])
+def test_decoder_loop_fp8_weights_240_steps(cuda, size):
+  """h128_240_steps: H = M = 128 over 240 steps. tacotron_gst_full_size: the decoder cell of
+  tacotron_gst.py:152-170 (H = M = 1024, U = 128, 32 x 32 location filters) over S = 200 source
+  positions and 60 steps — the weight streams the fp8 path was built for (2 x 4096 x 2048 bytes)."""
   from openseq2seq_amd import capi
-  B, T, S, L, H, M, U, K, F = 4, 240, 40, 2, 128, 128, 128, 32, 32
+  B, T, S, L, H, M, U, K, F = (4, 240, 40, 2, 128, 128, 128, 32, 32) if size == "h128_240_steps" \
+      else (4, 60, 200, 2, 1024, 1024, 128, 32, 32)
   g = torch.Generator().manual_seed(5)
   rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
   kc = [M + H, 2 * H]
@@ -62,7 +67,7 @@ def test_decoder_loop_fp8_weights_240_steps(cuda):
   conv_w, conv_b, dense_w = rn(K, F, sc=0.5), rn(F, sc=0.1), rn(F, U, sc=0.3)
   gx0 = _bf(rn(B, T, 4 * H, sc=0.7))
   memory = _bf(rn(B, S, M))
-  src_len = torch.tensor([S, 31, 17, 25], dtype=torch.int32)
+  src_len = torch.tensor([S, (31 * S) // 40, (17 * S) // 40, (25 * S) // 40], dtype=torch.int32)
   values_h, _ = oad.prepare_memory(memory.float(), src_len)
   values = _bf(values_h)
   keys = _bf(values.float() @ wmem.float().t())
@@ -96,7 +101,7 @@ def test_decoder_loop_fp8_weights_240_steps(cuda):
   # (b) what the quantisation costs against the unquantised fp32 model over the 240 steps
   r_quant = rel(y, full["y"])
   a_quant = float((al - full["align"]).abs().max())
-  print("fp8 weights, 240 steps: outputs rel-L2 vs quantised-model oracle %.3e, vs unquantised oracle %.3e "
+  print("fp8 weights, %s:" % size, " outputs rel-L2 vs quantised-model oracle %.3e, vs unquantised oracle %.3e "
         "(oracle vs oracle %.3e); max alignment error %.3e"
         % (rel(y, ref["y"]), r_quant, rel(ref["y"], full["y"]), a_quant))
   assert r_quant <= 3e-2, r_quant

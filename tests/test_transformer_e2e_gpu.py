@@ -1,7 +1,10 @@
-"""GPU end-to-end parity of the Transformer NMT training path (scaled down:
-d_model 512, 8 heads, filter 1024, 2+2 layers, V=1000): loss and parameter gradients vs
+"""GPU end-to-end parity of the Transformer NMT training path: loss and parameter gradients vs
 the CPU fp32 oracle (oracle/transformer.py, padded [B,L] exactly like the reference) —
-the device path runs on PACKED tokens. Dropout is 0 for parity (mask-sharing tests of
+the device path runs on PACKED tokens. Two sizes: scaled down (d_model 512, 8 heads, filter 1024,
+2+2 layers, V=1000) and the BASELINE configuration itself (example_configs/text2text/en-de/
+transformer-big.py:19-83: d_model 1024, 16 heads, filter 4096, 6+6 layers, shared 32768-entry
+embedding/softmax, max_length 56) at B=32 — the 1024/3072/4096/32768-column GEMM shapes, the
+16-head attention kernels and the 32768-column smoothed cross-entropy the bench runs. Dropout is 0 for parity (mask-sharing tests of
 the dropout streams live in tests/test_transformer_kernels_gpu.py). Tolerances: bf16
 storage through ~30 GEMMs: loss rtol 2e-2; gradients cosine >= 0.98, rel-L2 <= 0.2."""
 import numpy as np
@@ -10,10 +13,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-D, H, F, V, NL = 512, 8, 1024, 1000, 2
+SMALL = (512, 8, 1024, 1000, 2)          # D, H, F, V, NL
+BIG = (1024, 16, 4096, 32768, 6)         # transformer-big.py:19-83
 
 
-def _build(cuda, dropout=0.0):
+def _build(cuda, dropout=0.0, dims=SMALL):
+  D, H, F, V, NL = dims
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders.transformer_encoder import TransformerEncoder
   from openseq2seq_amd.decoders.transformer_decoder import TransformerDecoder
@@ -36,7 +41,7 @@ def _build(cuda, dropout=0.0):
   return store, enc, dec, loss
 
 
-def _batch(cuda, B=4, Lmax=20, seed=1):
+def _batch(cuda, B=4, Lmax=20, seed=1, V=SMALL[3]):
   from openseq2seq_amd.parts.transformer import packing
   rng = np.random.RandomState(seed)
 
@@ -56,7 +61,8 @@ def _batch(cuda, B=4, Lmax=20, seed=1):
   return batch, src, sl, tgt, tl
 
 
-def _oracle_params(store):
+def _oracle_params(store, dims=SMALL):
+  D, H, F, V, NL = dims
   """Device parameters (bf16 compute copies for matrices) -> oracle dict with autograd."""
   def w(name):   # Dense kernel [1,Cout,Cin] -> [Cin,Cout]
     return store.by_name(name + "/kernel").w16.float().cpu()[0].t().contiguous().requires_grad_(True)
@@ -114,12 +120,13 @@ def _oracle_params(store):
   return PE, PD, leaves
 
 
-def test_transformer_small_fwd_bwd(cuda):
+def _fwd_bwd(cuda, dims, B, Lmax, tol):
+  D, H, F, V, NL = dims
   from openseq2seq_amd.parts.cnns.conv_blocks import Tape
   from openseq2seq_amd.parts.transformer.layers import SeedSeq
   from oracle import transformer as ot
-  store, enc, dec, lossf = _build(cuda)
-  batch, src, sl, tgt, tl = _batch(cuda)
+  store, enc, dec, lossf = _build(cuda, dims=dims)
+  batch, src, sl, tgt, tl = _batch(cuda, B=B, Lmax=Lmax, V=V)
   tape = Tape()
   store.zero_grads()
   e = enc.encode({'source_tensors': batch['source_tensors'], 'tape': tape, 'seeds': SeedSeq(1),
@@ -130,18 +137,18 @@ def test_transformer_small_fwd_bwd(cuda):
   tape.backward()
   torch.cuda.synchronize()
   # ---- oracle on the padded batch ---------------------------------------------
-  PE, PD, leaves = _oracle_params(store)
+  PE, PD, leaves = _oracle_params(store, dims)
   s_ids, t_ids = torch.from_numpy(src).long(), torch.from_numpy(tgt).long()
   enc_out, bias = ot.encoder(s_ids, PE, H)
   logits = ot.decoder_pass(t_ids, enc_out, bias, PD, H)
   loss = ot.padded_xent_smoothing(logits, t_ids, 0.1)
   loss.backward()
-  torch.testing.assert_close(L.cpu()[0], loss.detach(), rtol=2e-2, atol=2e-2)
+  torch.testing.assert_close(L.cpu()[0], loss.detach(), rtol=tol["loss"], atol=tol["loss"])
   # packed logits == padded logits at the non-pad positions
   lg = d["logits"].float().cpu()
   ref_rows = torch.cat([logits[b, :tl[b]] for b in range(len(tl))], 0).detach()
   rel = float((lg - ref_rows).norm() / ref_rows.norm())
-  assert rel < 3e-2, rel
+  assert rel < tol["logits"], rel
   worst = (1.0, "")
   for name, leaf in leaves.items():
     p = store.by_name(name if name.endswith(("scale", "bias", "weights")) or name.endswith("/kernel")
@@ -155,9 +162,21 @@ def test_transformer_small_fwd_bwd(cuda):
     cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
     relerr = float((got - ref).norm() / (ref.norm() + 1e-12))
     worst = min(worst, (cos, name))
-    assert cos > 0.98, (name, cos, relerr)
-    assert relerr < 0.2, (name, cos, relerr)
+    assert cos > tol["cos"], (name, cos, relerr)
+    assert relerr < tol["rel"], (name, cos, relerr)
   print("worst cosine", worst, "logits rel", rel)
+
+
+def test_transformer_small_fwd_bwd(cuda):
+  _fwd_bwd(cuda, SMALL, B=4, Lmax=20, tol=dict(loss=2e-2, logits=3e-2, cos=0.98, rel=0.2))
+
+
+def test_transformer_big_full_size_fwd_bwd(cuda):
+  """transformer-big.py:19-83 at its real widths, B=32 sentences of 3..56 tokens (~950 source and
+  ~950 target tokens). Tolerances: loss 1e-2, logits rel-L2 2e-2 (measured 7.9e-3), every parameter
+  gradient cosine > 0.995 (measured worst 0.9995) and rel-L2 < 0.1 vs the fp32 oracle on the same
+  bf16-rounded weights (bf16 storage through ~90 GEMMs)."""
+  _fwd_bwd(cuda, BIG, B=32, Lmax=56, tol=dict(loss=1e-2, logits=2e-2, cos=0.995, rel=0.1))
 
 
 def test_transformer_small_trains(cuda):
@@ -168,7 +187,7 @@ def test_transformer_small_trains(cuda):
   store, enc, dec, lossf = _build(cuda, dropout=0.1)
   op = optimize_loss(store, "LazyAdam", dict(beta1=0.9, beta2=0.997, epsilon=1e-9),
                      lr_policies.transformer_policy,
-                     dict(learning_rate=2.0, warmup_steps=40, d_model=D), loss_scaling="Backoff")
+                     dict(learning_rate=2.0, warmup_steps=40, d_model=SMALL[0]), loss_scaling="Backoff")
   batch, *_ = _batch(cuda, B=8, Lmax=24, seed=5)
   losses = []
   for step in range(40):
