@@ -37,7 +37,7 @@ def _cos(a, b):
   return float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
 
 
-def test_jasper10x5_every_layer_teacher_forced(cuda):
+def test_jasper10x5_every_layer_teacher_forced(cuda, monkeypatch):
   from openseq2seq_amd.configs.jasper import jasper_convnet_layers
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
@@ -69,6 +69,14 @@ def test_jasper10x5_every_layer_teacher_forced(cuda):
   x = Act(x0.to(cuda), lens0.to(cuda), requires_grad=False)
   src_len = lens0.clone()
   res_agg, layer_res = [], []
+  lens_dev, grouped_seen = None, []
+  from openseq2seq_amd import capi
+  orig_grouped = capi.conv1x1_fwd_grouped
+
+  def counting_grouped(items, **kw):
+    grouped_seen.append(len(items))
+    return orig_grouped(items, **kw)
+  monkeypatch.setattr(capi, "conv1x1_fwd_grouped", counting_grouped)
   worst = {"out": (0.0, ""), "dx": (0.0, ""), "dw": (0.0, ""), "dbn": (0.0, "")}
   worst_fp32 = 0.0
   for li, L in enumerate(enc._layers):
@@ -85,7 +93,8 @@ def test_jasper10x5_every_layer_teacher_forced(cuda):
     xin = Act(x.data, x.lens, requires_grad=li > 0)   # the feature tensor needs no gradient
     rin = [Act(r.data, r.lens, requires_grad=True) for r in layer_res] if L["res"] else []
     tape = Tape()
-    lens_dev = src_len.to(cuda)
+    if s > 1 or li == 0:        # ONE length tensor per resolution, as the encoder has: the grouped
+      lens_dev = src_len.to(cuda)  # 1x1 launches require the branches to share their length vector
     out = conv_bn_res_bn_actv(main, L["res"], xin, rin, lens_dev, "relu", True, tape, keep_prob=1.0,
                               seed=li, mask_output=not last)
     dy = torch.randn(out.data.shape, generator=g).to(torch.bfloat16)
@@ -145,5 +154,8 @@ def test_jasper10x5_every_layer_teacher_forced(cuda):
         worst["dbn"] = max(worst["dbn"], (r, tag + " " + n))
         assert r <= 1e-2, ("d(gamma/beta)", tag, n, r, c)
     x = Act(out.data, None if last else lens_dev, requires_grad=False)
+  # the grouped 1x1 launches really ran: forward + data gradient at every block end with >= 2
+  # dense-residual inputs (blocks 3..11: 2..10 branches)
+  assert sorted(grouped_seen) == sorted(list(range(2, 11)) * 2), grouped_seen
   print("jasper10x5 layer by layer (rel-L2, device vs bf16-storage oracle): worst", worst,
         "| worst output vs plain fp32 oracle %.3e" % worst_fp32)
