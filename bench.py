@@ -33,6 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def parse():
@@ -65,6 +66,9 @@ def parse():
   ap.add_argument("--only-transformer", action="store_true",
                   help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
+  ap.add_argument("--one-rank-group", action="store_true",
+                  help="N=1 only: run the data-parallel path (RCCL process group, bucketed all-reduce on "
+                       "the side stream, comm diagnostics) on a one-rank group")
   ap.add_argument("--launcher-dry-run", action="store_true",
                   help="exercise only the multi-rank launcher and the timing collectives (no GPU "
                        "work: runs on CPU over gloo); prints the JSON line with value null")
@@ -234,6 +238,112 @@ class ConvTimer(object):
     return ms, fl, n
 
 
+class StepBreakdown(object):
+  """Per-family kernel time of the REST of the train step, measured live but OUTSIDE the timed
+  region: after the timed steps, `steps` more steps run with the weight-gradient side stream off
+  (OS2S_WGRAD_STREAM=0: every kernel alone on the GPU) and a HIP-event pair around every launch of
+  the conv weight-gradient kernels (executed FLOPs vs the MFMA peak), the BatchNorm kernels and the
+  optimizer (algorithmic bytes vs the HBM peak). The event pairs cost a few microseconds each, so
+  these figures are lower bounds of the kernels' own rates; profiles/ holds the rocprofv3 view."""
+
+  def __init__(self, capi):
+    self.capi = capi
+    self.rec = {}       # family -> [launches, [event pairs], work]
+    self.saved = {}
+
+  def _bracket(self, family, work, call):
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = call()
+    e1.record()
+    r = self.rec.setdefault(family, [0, [], 0.0])
+    r[0] += 1
+    r[1].append((e0, e1))
+    r[2] += work
+    return out
+
+  @staticmethod
+  def _live(lens, T, cache, quantum=1, margin=0):
+    if lens is None:
+      return 1.0
+    key = (lens.data_ptr(), T, quantum, margin)
+    if key not in cache:
+      l = (lens.cpu().to(torch.int64) + margin).clamp(max=T)
+      l = ((l + quantum - 1) // quantum * quantum).clamp(max=T)
+      cache[key] = float(l.sum()) / float(l.numel() * T)
+    return cache[key]
+
+  def install(self):
+    capi, bd, cache = self.capi, self, {}
+    for name in ("conv1d_wgrad", "bn_act_fwd", "bn_act_bwd_reduce", "bn_bwd_apply", "opt_step"):
+      self.saved[name] = getattr(capi, name)
+    o = self.saved
+
+    def wgrad(x, dy, K, **kw):
+      B, Tin, Cin = x.shape
+      _, Tout, Cout = dy.shape
+      fl = 2.0 * B * Tout * Cin * Cout * K * bd._live(kw.get("in_len"), Tin, cache, quantum=64)
+      return bd._bracket("conv1d weight gradient (conv1d_wgrad_pp_kernel + lockstep conv1d_wgrad_kernel)",
+                         fl, lambda: o["conv1d_wgrad"](x, dy, K, **kw))
+
+    def bn_fwd(ys, scales, shifts, out, out_len, act, keep_prob, seed):
+      B, T, C = out.shape
+      by = B * T * C * 2.0 * (len(ys) * bd._live(out_len, T, cache) + 1.0)
+      return bd._bracket("batchnorm", by, lambda: o["bn_act_fwd"](ys, scales, shifts, out, out_len, act,
+                                                                  keep_prob, seed))
+
+    def bn_red(dout, out, ys, means, rstds, dz, partial, out_len, act, keep_prob, seed):
+      B, T, C = out.shape
+      by = B * T * C * 2.0 * ((2 + len(ys)) * bd._live(out_len, T, cache) + 1.0)
+      return bd._bracket("batchnorm", by, lambda: o["bn_act_bwd_reduce"](
+          dout, out, ys, means, rstds, dz, partial, out_len, act, keep_prob, seed))
+
+    def bn_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0):
+      T = dz.shape[1] if dz.dim() == 3 else 1
+      by = dz.numel() * 2.0 * (2.0 * bd._live(out_len, T, cache, margin=margin) + 1.0)
+      return bd._bracket("batchnorm", by, lambda: o["bn_bwd_apply"](dz, y, gamma, mean, rstd, c1, c2, dy,
+                                                                    out_len=out_len, margin=margin))
+
+    def opt(cfg, state, grads, weights, *a, **kw):
+      # per parameter: gradient + master + moment read (12 B), master + moment + bf16 copy written (10 B)
+      return bd._bracket("optimizer", 22.0 * weights.numel(),
+                         lambda: o["opt_step"](cfg, state, grads, weights, *a, **kw))
+
+    capi.conv1d_wgrad, capi.bn_act_fwd, capi.bn_act_bwd_reduce = wgrad, bn_fwd, bn_red
+    capi.bn_bwd_apply, capi.opt_step = bn_apply, opt
+
+  def remove(self):
+    for name, fn in self.saved.items():
+      setattr(self.capi, name, fn)
+
+  def run(self, model, batch, steps=2):
+    prev = os.environ.get("OS2S_WGRAD_STREAM")
+    os.environ["OS2S_WGRAD_STREAM"] = "0"
+    self.install()
+    try:
+      for _ in range(steps):
+        model.train_step(batch)
+      torch.cuda.synchronize()
+    finally:
+      self.remove()
+      if prev is None:
+        os.environ.pop("OS2S_WGRAD_STREAM", None)
+      else:
+        os.environ["OS2S_WGRAD_STREAM"] = prev
+    out = {}
+    for fam, (n, evs, work) in self.rec.items():
+      ms = sum(a.elapsed_time(b) for a, b in evs)
+      hbm = not fam.startswith("conv1d")
+      rate = work / (ms * 1e-3) / (1e9 if hbm else 1e12) if ms > 0 else 0.0
+      peak = HBM_PEAK_GBS if hbm else BF16_DENSE_PEAK_TFLOPS
+      out[fam] = {"bound": "hbm" if hbm else "mfma", "launches_per_step": n / float(steps),
+                  "ms_per_step": ms / steps, "avg_launch_ms": ms / max(n, 1), "achieved": rate,
+                  "unit": "GB/s" if hbm else "TFLOP/s", "peak": peak, "frac": rate / peak,
+                  "measured": "serial pass after the timed region (side stream off), HIP events per launch"}
+    return out
+
+
 def tensorflow_probe():
   """SURVEY 8d plan (1): the reference's own TF1 CPU path as the baseline when TensorFlow is
   importable on the bench host. It is not part of this image (and /root/reference does not travel
@@ -248,9 +358,11 @@ def tensorflow_probe():
 
 def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
   """Oracle training step (fp32 torch-CPU + NumPy NovoGrad/LARC/Backoff: oracle/tdnn.py,
-  oracle/optim.py) on a bounded SUB-BATCH OF THE SAME synthetic batch the GPU was timed on: its
-  shortest utterance (features, length and labels as in the batch). 3 warm-up steps, then >= 5
-  timed steps (as many as fit the time budget)."""
+  oracle/optim.py) on a bounded SUB-BATCH OF THE SAME synthetic batch the GPU was timed on: FOUR
+  utterances at the 0, 1/3, 2/3 and 1 quantiles of its length distribution (features, lengths and
+  labels as in the batch, padded to the longest of the four, so BatchNorm is a batch statistic and
+  the padding / masking work of a ragged step is in the number). 3 warm-up steps, then >= 5 timed
+  steps (as many as fit the time budget)."""
   from oracle import tdnn as otdnn, optim as oopt
   from openseq2seq_amd.configs.jasper import jasper_convnet_layers
   torch.manual_seed(0)
@@ -286,7 +398,9 @@ def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
                           larc_params=dict(larc_eta=0.001), scaler=oopt.BackoffScaler())
   feats, frames = [t.cpu() for t in batch["source_tensors"]]
   tgt, tlen = [t.cpu() for t in batch["target_tensors"]]
-  pick = torch.argsort(frames)[:1]
+  order = torch.argsort(frames)
+  nb = int(order.numel())
+  pick = order[sorted({0, (nb - 1) // 3, (2 * (nb - 1)) // 3, nb - 1})]
   lens = frames[pick].to(torch.int64)
   T = int(-(-int(lens.max()) // 8) * 8)
   x = feats[pick, :T].float()
@@ -317,9 +431,10 @@ def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
   dt = (time.time() - t0) / nt
   nframes = int(lens.sum())
   out = {"value": nframes / dt, "unit": "frames/sec", "cores": nthreads, "kind": "port",
-         "sample": "Jasper10x5 oracle train step (fp32 torch-CPU + NumPy NovoGrad) on the shortest "
-                   "utterance of the bench batch (%d frames, padded to %d), 3 warm-up + %d "
-                   "timed steps, %.2f s/step" % (int(lens[0]), T, nt, dt)}
+         "sample": "Jasper10x5 oracle train step (fp32 torch-CPU + NumPy NovoGrad) on %d utterances of "
+                   "the bench batch at the 0, 1/3, 2/3, 1 quantiles of its lengths (%s frames, padded "
+                   "to %d), 3 warm-up + %d timed steps, %.2f s/step"
+                   % (int(lens.numel()), "/".join(str(int(v)) for v in lens), T, nt, dt)}
   out.update(tensorflow_probe())
   return out
 
@@ -536,6 +651,13 @@ def main():
     sys.exit(spawn_ranks(args.gpus))      # one process per GPU; this process only waits for them
   from openseq2seq_amd.utils import distributed as dist_utils
   hvd = dist_utils.init_from_env()
+  if args.one_rank_group and hvd is None:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ["OS2S_FORCE_REDUCER"] = "1"
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    hvd = dist_utils.HvdAdapter()
   rank = hvd.rank() if hvd else 0
   world = hvd.size() if hvd else 1
   if args.gpus != world:
@@ -601,12 +723,35 @@ def main():
     model.train_step(batch)
   barrier()
   timer.enabled = not args.no_kernel_timing and rank == 0
+  reducer = getattr(model, "_reducer", None)
+  if reducer is not None:
+    reducer.timing = True           # a few event records per step (one pair per 128 MB bucket)
   t0 = time.perf_counter()
   for _ in range(args.steps):
     loss = model.train_step(batch)
   barrier()
   dt = time.perf_counter() - t0
   timer.enabled = False
+  comm = None
+  if reducer is not None:
+    reducer.timing = False
+    comm = reducer.pop_timing()
+    if comm is not None:
+      comm["backend"] = torch.distributed.get_backend()
+      comm["exposed_share_of_step"] = comm["exposed_ms_per_step"] / (1000.0 * dt / args.steps)
+      if rank == 0:
+        print("bench.py: world %d (%s), %d all-reduce bucket(s)/step = %.1f MB in %.2f ms "
+              "(bus %.0f GB/s), exposed (not hidden by backward) %.2f ms/step of %.2f"
+              % (comm["world_size"], comm["backend"], len(comm["bucket_ms"]),
+                 comm["allreduce_bytes_per_step"] / 1e6, comm["allreduce_ms_per_step"],
+                 comm["bus_GBps"] or 0.0, comm["exposed_ms_per_step"], 1000.0 * dt / args.steps),
+              file=sys.stderr)
+  breakdown = None
+  if not args.no_kernel_timing and rank == 0 and world == 1:
+    try:       # untimed: the other kernel families of the step, each alone on the GPU
+      breakdown = StepBreakdown(capi).run(model, batch, steps=2)
+    except Exception as e:
+      breakdown = {"error": repr(e)}
 
   tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
   frames = torch.tensor([float(batch['num_frames'])], dtype=torch.float64, device=dev)
@@ -644,6 +789,8 @@ def main():
           "skipped_steps": st["num_skipped"],
       },
   }
+  if comm is not None:
+    out["comm"] = comm
   if not args.no_kernel_timing:
     ms, fl, n = timer.summary()
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -660,11 +807,17 @@ def main():
         "launches_timed": ("every 4th forward-pass launch (the kernel alone on the GPU)" if timer.overlap
                            else "every 4th forward / data-gradient launch"),
         "all_launches_per_step": (timer.all_n + timer.untimed) / max(args.steps, 1),
+        # the WHOLE step against the same peak: FLOPs of the real (unpadded) frames of the batch /
+        # wall time per step — convolutions at `frac`, weight gradients, BatchNorm, optimizer, CTC
+        # and every bubble between them
+        "whole_step_achieved": 0.9975e-3 * float(frames.item()) * args.steps / dt,
+        "whole_step_frac": 0.9975e-3 * float(frames.item()) * args.steps / dt / (BF16_DENSE_PEAK_TFLOPS * world),
         "by_kernel": {name: {"launches": c, "avg_launch_ms": t / max(c, 1),
                              "achieved": f / (t * 1e-3) / 1e12 if t > 0 else 0.0,
                              "frac": (f / (t * 1e-3) / 1e12 if t > 0 else 0.0) / BF16_DENSE_PEAK_TFLOPS,
                              "share_of_timed_ms": t / max(ms, 1e-9)}
                       for name, (c, t, f) in timer.by_kernel.items()},
+        "rest_of_step": breakdown,
         "sustained_mfma_peak_note": "a loop of nothing but v_mfma_f32_32x32x16_bf16 on every SIMD reaches "
                                     "1.93-2.07 PFLOP/s on this chip (1.9 GHz under MFMA load; "
                                     "profiles/r02_mfma_issue_probe.txt); `peak` is the 2.4 GHz data-sheet figure",

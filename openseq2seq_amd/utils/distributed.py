@@ -136,6 +136,16 @@ class GradientReducer(object):
     # i.e. that variables really become final in the order mark_done() assumes
     self.check = os.environ.get("OS2S_CHECK_REDUCER", "") == "1" and world_size == 1
     self._snap = []
+    # OS2S_ALLREDUCE_DTYPE=bf16: the payload crosses xGMI as bf16 (half the bytes: 0.67 GB instead
+    # of 1.33 GB per Jasper step); the loss-scaled fp32 gradients are rounded to bf16 before the
+    # sum and the sum itself is rounded once more — NOT bit-compatible with the fp32 reduction
+    # (relative error <= 2^-8 per element), off by default
+    self.wire_dtype = torch.bfloat16 if os.environ.get("OS2S_ALLREDUCE_DTYPE", "fp32") == "bf16" \
+        else torch.float32
+    # timing=True: HIP events around every bucket's all-reduce on the side stream + the time the
+    # compute stream sits in finish() waiting for it (bench.py --gpus N reads `pop_timing()`)
+    self.timing = False
+    self._events, self._exposed = [], []
     self.reset()
 
   def reset(self):
@@ -147,7 +157,7 @@ class GradientReducer(object):
     if self.stream is None:
       if self.check:
         self._snap.append((s, e, g[s:e].clone()))
-      dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
+      self._all_reduce(g[s:e])
       return
     from ..parts.cnns.conv_blocks import side_streams
     ev = torch.cuda.Event()
@@ -158,7 +168,21 @@ class GradientReducer(object):
     with torch.cuda.stream(self.stream):
       if self.check:
         self._snap.append((s, e, g[s:e].clone()))
-      dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM)
+      if self.timing:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(self.stream)
+      self._all_reduce(g[s:e])
+      if self.timing:
+        e1.record(self.stream)
+        self._events.append((e0, e1, (e - s) * (2 if self.wire_dtype == torch.bfloat16 else 4)))
+
+  def _all_reduce(self, view):
+    if self.wire_dtype == torch.float32:
+      dist.all_reduce(view, op=dist.ReduceOp.SUM)
+      return
+    wire = view.to(self.wire_dtype)
+    dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+    view.copy_(wire)
 
   def mark_done(self, offset):
     """All gradients at flat offsets >= `offset` are final."""
@@ -172,7 +196,13 @@ class GradientReducer(object):
   def finish(self):
     self.mark_done(0)
     if self.stream is not None:
+      if self.timing:     # how long the compute stream waits here = communication NOT hidden by backward
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record(torch.cuda.current_stream())
       torch.cuda.current_stream().wait_stream(self.stream)
+      if self.timing:
+        w1.record(torch.cuda.current_stream())
+        self._exposed.append((w0, w1))
     if self.check:
       for s, e, snap in self._snap:
         if not torch.equal(snap, self.store.grads[s:e]):
@@ -182,6 +212,33 @@ class GradientReducer(object):
                              % (s, e, bad, names))
       self._snap = []
     self.reset()
+
+  def pop_timing(self):
+    """Per-bucket all-reduce durations and the exposed (non-overlapped) wait, in ms, since the last
+    call; synchronises. {"buckets": [{"bytes", "ms", "GBps"}...] averaged per step, "steps",
+    "allreduce_ms_per_step", "exposed_ms_per_step", "bus_GBps"} — bus bandwidth = the ring
+    all-reduce convention 2 (N-1)/N x bytes / time, what one xGMI link has to carry."""
+    if self.stream is None or not self._exposed:
+      return None
+    torch.cuda.synchronize()
+    steps = len(self._exposed)
+    nb = len(self.bounds)
+    per = [[0.0, 0] for _ in range(nb)]
+    for i, (e0, e1, nbytes) in enumerate(self._events):
+      per[i % nb][0] += e0.elapsed_time(e1)
+      per[i % nb][1] = nbytes
+    total_ms = sum(p[0] for p in per) / steps
+    total_bytes = sum(p[1] for p in per)
+    exposed = sum(a.elapsed_time(b) for a, b in self._exposed) / steps
+    f = 2.0 * (self.world - 1) / max(self.world, 1)
+    out = {"steps": steps, "world_size": self.world, "wire_dtype": str(self.wire_dtype).replace("torch.", ""),
+           "bucket_bytes": [p[1] for p in per],
+           "bucket_ms": [p[0] / steps for p in per],
+           "allreduce_bytes_per_step": total_bytes, "allreduce_ms_per_step": total_ms,
+           "exposed_ms_per_step": exposed,
+           "bus_GBps": f * total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else None}
+    self._events, self._exposed = [], []
+    return out
 
   def all_reduce(self):
     """Non-overlapped form (everything after backward)."""

@@ -69,6 +69,15 @@ def _worker(rank, world, port, q):
   ok_sum = ok_sum and red.next_bucket == 0
   red.finish()
   ok_sum = ok_sum and bool(torch.allclose(st.grads, base * 3)) and red.next_bucket == 2
+  # OS2S_ALLREDUCE_DTYPE=bf16: half the bytes on the wire, sums within bf16 rounding (2^-8 relative)
+  os.environ["OS2S_ALLREDUCE_DTYPE"] = "bf16"
+  red16 = du.GradientReducer(st, world, bucket_bytes=4096 * 4 * 2)
+  del os.environ["OS2S_ALLREDUCE_DTYPE"]
+  st.grads.copy_(base * (rank + 1))
+  red16.all_reduce()
+  ok_sum = ok_sum and red16.wire_dtype == torch.bfloat16 and red.wire_dtype == torch.float32
+  ok_sum = ok_sum and bool(torch.allclose(st.grads, base * 3, rtol=2 ** -7, atol=1e-6))
+  ok_sum = ok_sum and not bool(torch.equal(st.grads, base * 3))      # it really went through bf16
   objs = du.gather_objects({"rank": rank, "n": rank * 10})
   ok_gather = (objs is None) if rank != 0 else ([o["n"] for o in objs] == [0, 10])
   q.put((rank, ok_bcast, ok_sum, ok_gather))
