@@ -276,7 +276,8 @@ class StepBreakdown(object):
 
   def install(self):
     capi, bd, cache = self.capi, self, {}
-    for name in ("conv1d_wgrad", "bn_act_fwd", "bn_act_bwd_reduce", "bn_bwd_apply", "opt_step"):
+    for name in ("conv1d_wgrad", "conv1x1_wgrad_grouped", "bn_act_fwd", "bn_act_bwd_reduce", "bn_bwd_apply",
+                 "opt_step"):
       self.saved[name] = getattr(capi, name)
     o = self.saved
 
@@ -286,6 +287,13 @@ class StepBreakdown(object):
       fl = 2.0 * B * Tout * Cin * Cout * K * bd._live(kw.get("in_len"), Tin, cache, quantum=64)
       return bd._bracket("conv1d weight gradient (conv1d_wgrad_pp_kernel + lockstep conv1d_wgrad_kernel)",
                          fl, lambda: o["conv1d_wgrad"](x, dy, K, **kw))
+
+    def wgrad_grouped(items, in_len=None):
+      B, T, _ = items[0]["x"].shape
+      fl = sum(2.0 * B * T * it["x"].shape[2] * it["dy"].shape[2] for it in items) * \
+          bd._live(in_len, T, cache, quantum=64)
+      return bd._bracket("conv1d weight gradient, K = 1 residual branches grouped per block end "
+                         "(conv1d_wgrad_grouped_kernel)", fl, lambda: o["conv1x1_wgrad_grouped"](items, in_len=in_len))
 
     def bn_fwd(ys, scales, shifts, out, out_len, act, keep_prob, seed):
       B, T, C = out.shape
@@ -311,6 +319,7 @@ class StepBreakdown(object):
                          lambda: o["opt_step"](cfg, state, grads, weights, *a, **kw))
 
     capi.conv1d_wgrad, capi.bn_act_fwd, capi.bn_act_bwd_reduce = wgrad, bn_fwd, bn_red
+    capi.conv1x1_wgrad_grouped = wgrad_grouped
     capi.bn_bwd_apply, capi.opt_step = bn_apply, opt
 
   def remove(self):

@@ -159,6 +159,21 @@ typedef struct {
 } os2s_conv_group_t;
 int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* groups, int ngroups,
                              const int32_t* in_len, const int32_t* out_len, int B, int T);
+/* The weight gradients of the same branches in ONE launch: for up to 16 groups over one ragged
+ * batch (B, T, in_len), dw_i[co][ci] += sum_(b,t) dy_i[b,t,co] * x_i[b,t,ci] (fp32, accumulated:
+ * the gradient of tf.layers.conv1d(kernel_size=1) w.r.t. its kernel, parts/cnns/conv_blocks.py:78-85,
+ * once per residual input). One launch per branch held 12-36 output tiles and cut the reduction
+ * 14-40 ways with fp32 atomics; a block's branches together are 50-216 tiles. `groups` is a HOST
+ * array (copied into the launch); x rows may be a channel slice (x_row_stride >= Cin). */
+typedef struct {
+  const uint16_t* x;        /* [B, T, Cin]  bf16, row stride x_row_stride elements */
+  const uint16_t* dy;       /* [B, T, Cout] bf16 */
+  float* dw;                /* [1, Cout, Cin] fp32, accumulated into */
+  long long x_row_stride;
+  int Cin, Cout;
+} os2s_wgrad_group_t;
+int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
+                               const int32_t* in_len, int B, int T);
 /* Plain GEMM, hand-written for the gfx950 matrix cores (csrc/gemm_pp.hip):
  *   C[M,N] (+)= A[M,K] . W[N,K]^T, C = residual + dropout(act(. + bias)) as in os2s_conv1d_fwd_ex.
  * Replaces tf.layers.Dense of the Transformer (parts/transformer/attention_layer.py:54-62,125-127,

@@ -203,6 +203,32 @@ def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
 
+class _WgradGroup(_lib.ctypes.Structure):
+  _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("x_row_stride", c_ll),
+              ("Cin", c_int), ("Cout", c_int)]
+
+
+def conv1x1_wgrad_grouped(items, in_len=None):
+  """items: list of dict(x [B,T,Cin] bf16 (may be a channel slice), dy [B,T,Cout] bf16,
+  dw [1,Cout,Cin] fp32 accumulated into): the K = 1 weight gradients of up to 16 branches over the
+  same (B, T, in_len) in one launch."""
+  n = len(items)
+  assert 1 <= n <= 16
+  B, T, _ = items[0]["x"].shape
+  arr = (_WgradGroup * n)()
+  for i, it in enumerate(items):
+    x, dy, dw = it["x"], it["dy"], it["dw"]
+    assert x.shape[:2] == (B, T) and dy.shape[:2] == (B, T) and x.dtype == torch.bfloat16
+    assert x.stride(2) == 1 and x.stride(0) == T * x.stride(1) and dy.is_contiguous()
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.shape[2] * x.shape[2]
+    g = arr[i]
+    g.x, g.dy, g.dw = c_void_p(x.data_ptr()), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32)
+    g.x_row_stride, g.Cin, g.Cout = x.stride(1), x.shape[2], dy.shape[2]
+  f = _fn("os2s_conv1x1_wgrad_grouped",
+          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int))
+  _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T), "os2s_conv1x1_wgrad_grouped")
+
+
 def _ptr_array(tensors, dtype):
   arr = (c_void_p * len(tensors))()
   for i, t in enumerate(tensors):

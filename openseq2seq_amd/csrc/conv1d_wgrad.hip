@@ -65,22 +65,15 @@ __device__ __forceinline__ bf16x4 lds_tr(const char* p) {
 // COT = output-channel extent of the block tile (128: 4 waves, 2 workgroups/CU;
 // 256: 8 waves, 1 workgroup/CU, 0.74x the L2->LDS bytes per FLOP — the 128 tile runs at the
 // 64 B/clk/CU L2 port limit on the big layers).
+// One (co tile, ci tile, reduction split) unit x tap group of the lockstep kernel.
 template <int TAPS, int COT>
-__global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_lockstep_unit(const WgradArgs& p, const int unit, const int tp, char* smem) {
   constexpr int BT = 64;  // reduction rows per step
   constexpr int NW = COT / 32, NTHR = NW * 64, NSUB = COT / 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;  // wave tile 64 (co) x 64 (ci)
   const int ysub = wm >> 1, wmi = wm & 1;  // 128-channel dY sub-image, 64-row half inside it
-
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, loc = bid >> 3;
-  const int unit = (loc / p.NTP) * 8 + xcd;
-  const int tp = loc - (loc / p.NTP) * p.NTP;
-  const int nunits = p.NCO * p.NCI * p.NSPLIT;
-  if (unit >= nunits) return;
   const int split = unit / (p.NCO * p.NCI);
   const int rem = unit - split * (p.NCO * p.NCI);
   const int co0 = (rem / p.NCI) * COT, ci0 = (rem % p.NCI) * 128;
@@ -259,6 +252,54 @@ __global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_ke
         }
     }
   }
+}
+
+template <int TAPS, int COT>
+__global__ __launch_bounds__(COT * 2, (COT == 128) ? 2 : 1) void conv1d_wgrad_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int unit = (loc / p.NTP) * 8 + xcd;
+  const int tp = loc - (loc / p.NTP) * p.NTP;
+  if (unit >= p.NCO * p.NCI * p.NSPLIT) return;
+  wgrad_lockstep_unit<TAPS, COT>(p, unit, tp, smem);
+}
+
+// Up to kMaxWgradGroups independent K = 1 weight gradients over the same ragged batch (B, T,
+// in_len) in ONE grid: the dense-residual 1x1 branches of a Jasper block end (conv_blocks.py:78-85:
+// up to 10 branches of 2-36 output tiles each). One launch per branch put 12-36 tiles on 256 CUs
+// and cut the reduction 14-40 ways to fill the chip, every piece ending in fp32 atomics on the
+// same dW; together the branches of a block are 50-216 tiles, so the reduction is cut a few ways
+// at most (not at all for the wide blocks: one owner per dW element, deterministic).
+constexpr int kMaxWgradGroups = 16;
+struct WgradGroup {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;
+  long long x_ld;
+  int Cin, Cout, NCI, unit_begin;
+};
+struct WgradGroupTable {
+  int ngroups, total_units;
+  WgradGroup g[kMaxWgradGroups];
+};
+
+__global__ __launch_bounds__(256, 2) void conv1d_wgrad_grouped_kernel(WgradArgs p, WgradGroupTable gt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  if (bid >= gt.total_units) return;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxWgradGroups; ++i)
+    if (i < gt.ngroups && bid >= gt.g[i].unit_begin) gi = i;
+  WgradGroup g = gt.g[0];
+#pragma unroll
+  for (int i = 1; i < kMaxWgradGroups; ++i)
+    if (i == gi) g = gt.g[i];
+  p.x = g.x; p.dy = g.dy; p.dw = g.dw; p.x_ld = g.x_ld;
+  p.Cin = g.Cin; p.Cout = g.Cout;
+  p.NCO = (g.Cout + 127) / 128; p.NCI = g.NCI;
+  wgrad_lockstep_unit<1, 128>(p, bid - g.unit_begin, 0, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1218,5 +1259,63 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
     else
       OS2S_LAUNCH((conv1d_wgrad_kernel<2, 128>), dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
   }
+  return OS2S_OK;
+}
+
+
+// dW_i[co][ci] += sum_(b,t) dY_i[b,t,co] * X_i[b,t,ci] for up to 16 (X_i, dY_i, dW_i) over one ragged
+// batch, in one launch (the K = 1 weight gradients of the dense-residual branches of a block end).
+// dW_i are fp32 and are ACCUMULATED into (fp32 atomics: with one reduction split — whenever the
+// groups together hold >= 256 output tiles — every element receives exactly one add).
+extern "C" int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
+                                          const int32_t* in_len, int B, int T) {
+  using namespace os2s;
+  OS2S_REQUIRE(groups && ngroups >= 1 && ngroups <= kMaxWgradGroups && B >= 0 && T >= 1);
+  if (B == 0) return OS2S_OK;
+  WgradGroupTable gt;
+  gt.ngroups = ngroups;
+  int tiles = 0;
+  for (int i = 0; i < ngroups; ++i) {
+    const os2s_wgrad_group_t& s = groups[i];
+    OS2S_REQUIRE(s.x && s.dy && s.dw && s.Cin >= 8 && s.Cout >= 8 && s.Cin % 8 == 0 && s.Cout % 8 == 0);
+    OS2S_REQUIRE(s.x_row_stride >= s.Cin && s.x_row_stride % 8 == 0);
+    tiles += ceil_div(s.Cout, 128) * ceil_div(s.Cin, 128);
+  }
+  const int total_steps = B * ceil_div(T, 64);
+  // ~2 workgroups per CU (the kernel shares the GPU with the data-gradient chain); >= 8 steps each
+  int nsplit = ceil_div(512, tiles);
+  const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;
+  if (nsplit > max_split) nsplit = max_split;
+  if (tiles >= 256 || nsplit < 1) nsplit = 1;
+  WgradArgs a;
+  a.x = nullptr; a.dy = nullptr; a.dw = nullptr; a.in_len = in_len;
+  a.B = B; a.Tin = T; a.Tout = T; a.Cin = 0; a.Cout = 0; a.K = 1;
+  a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = 0; a.accumulate = 1;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
+  a.dbg = nullptr; a.dbg_mode = 0;
+  a.NCO = 0; a.NCI = 0; a.NTP = 1;
+  a.steps_per_split = ceil_div(total_steps, nsplit);
+  a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
+  a.use_atomic = 1;
+  a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;
+  int units = 0;
+  for (int i = 0; i < kMaxWgradGroups; ++i) {
+    const os2s_wgrad_group_t& s = groups[i < ngroups ? i : 0];
+    WgradGroup& g = gt.g[i];
+    g.x = s.x; g.dy = s.dy; g.dw = s.dw; g.x_ld = s.x_row_stride;
+    g.Cin = s.Cin; g.Cout = s.Cout; g.NCI = ceil_div(s.Cin, 128);
+    g.unit_begin = units;
+    if (i < ngroups) units += ceil_div(s.Cout, 128) * g.NCI * a.NSPLIT;
+  }
+  gt.total_units = units;
+  const size_t smem = (size_t)2 * 64 * 2 * 128 + (size_t)2 * a.xrows_pad * 256;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1d_wgrad_grouped_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  OS2S_LAUNCH(conv1d_wgrad_grouped_kernel, dim3(units), dim3(256), smem, (hipStream_t)stream, a, gt);
   return OS2S_OK;
 }

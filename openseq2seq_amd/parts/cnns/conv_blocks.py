@@ -33,6 +33,10 @@ def act_id(fn):
 _SIDE_STREAMS = {}
 
 
+# A/B knob: 0 = one K = 1 weight-gradient launch per residual branch (round 2), default = grouped
+GROUP_WGRAD = os.environ.get("OS2S_GROUP_WGRAD", "1") != "0"
+
+
 def _side_stream(device):
   """Side stream for work that may overlap the main stream inside one backward closure
   (OS2S_WGRAD_STREAM=0 keeps everything on one stream)."""
@@ -41,7 +45,10 @@ def _side_stream(device):
   key = (device.index, torch.cuda.current_stream().cuda_stream)
   st = _SIDE_STREAMS.get(key)
   if st is None:
-    st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    # OS2S_SIDE_PRIO (experiment): stream priority of the side stream (HIP: lower number = higher
+    # priority; the main stream has 0)
+    prio = int(os.environ.get("OS2S_SIDE_PRIO", "0"))
+    st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=prio)
   return st
 
 
@@ -434,6 +441,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     capi.bn_bwd_finalize_multi(partial, rows, [br.gamma.grad for br in branches],
                                [br.beta.grad for br in branches], True, c1, c2)
     grouped = []        # plain 1x1 residual branches: their data gradients go out in one launch
+    wgrouped = []       # ... and so do their weight gradients
     # (one launch = one (B, T) and one length vector: the predicate of the forward grouping)
     plain = [j for j in range(1, len(branches)) if _is_plain_1x1(branches[j])]
     can_group = len(branches) > 2 and len(plain) >= 2 and \
@@ -448,11 +456,21 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
                         out_len=lens if ragged else None, margin=(br.k - 1) * br.dil)
       f["y"] = None
       if can_group and j in plain:
-        br.backward_weights(inp, dy, f)
+        if GROUP_WGRAD:
+          wgrouped.append((br, inp, dy))
+        else:
+          br.backward_weights(inp, dy, f)
         if inp.requires_grad:
           grouped.append((br, inp, dy))
       else:
         br.backward_branch(inp, dy, f)
+    if wgrouped:
+      # the K = 1 weight gradients of all branches in one launch, on the side stream like every
+      # parameter gradient (ConvBN.backward_branch)
+      with on_side_stream(dz.device, *([w[1].data for w in wgrouped] + [w[2] for w in wgrouped])):
+        for i0 in range(0, len(wgrouped), 16):
+          capi.conv1x1_wgrad_grouped([dict(x=inp.data, dy=dy, dw=br.kernel.grad)
+                                      for br, inp, dy in wgrouped[i0:i0 + 16]], in_len=wgrouped[0][1].lens)
     if grouped:
       items = []
       for br, inp, dy in grouped:

@@ -473,3 +473,60 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
   live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])[:, :, None]
   assert torch.equal(torch.where(live, single, torch.zeros((), dtype=single.dtype, device=cuda)),
                      torch.where(live, single_ref, torch.zeros((), dtype=single.dtype, device=cuda)))
+
+
+@pytest.mark.parametrize("case", ["block_768", "narrow_split", "sliced_input"])
+def test_conv1x1_wgrad_grouped_equals_single_launches(cuda, case):
+  """os2s_conv1x1_wgrad_grouped (the K = 1 weight gradients of the dense-residual branches of a
+  block end in one launch) against one os2s_conv1d_wgrad per branch and against the fp32 matmul:
+  ragged lengths with dead 64-row chunks, channel tails, accumulation into non-zero dW, an input
+  that is a channel slice of a wider tensor.
+    block_768: the branches of the last Jasper block (+ 2 more) at a small T — 288 output tiles
+      (>= 256), so the reduction is not split: every dW element receives ONE add -> bit-identical
+      from run to run,
+      and equal to the single launches up to fp32 summation order (rtol 1e-4);
+    narrow_split: few small groups -> the reduction is split and combined with fp32 atomics."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(33)
+  if case == "block_768":
+    B, T, lens = 4, 330, [330, 201, 64, 17]
+    shapes = [(256, 768)] * 3 + [(384, 768)] * 2 + [(512, 768)] * 2 + [(640, 768)] * 2 + [(768, 768)] * 3
+  elif case == "narrow_split":
+    B, T, lens = 5, 500, [500, 350, 129, 64, 1]
+    shapes = [(256, 256), (72, 200), (128, 136)]
+  else:
+    B, T, lens = 3, 200, [200, 90, 33]
+    shapes = [(128, 256), (192, 256)]
+  lens = torch.tensor(lens, dtype=torch.int32, device=cuda)
+  mask = (torch.arange(T, device=cuda)[None, :] < lens[:, None])[:, :, None]
+  items, refs, singles = [], [], []
+  wide = _bf(torch.randn(B, T, 512, generator=g)).to(cuda) * mask if case == "sliced_input" else None
+  off = 0
+  for cin, cout in shapes:
+    if wide is not None:
+      x = wide[:, :, off:off + cin]
+      off += cin
+    else:
+      x = (_bf(torch.randn(B, T, cin, generator=g)).to(cuda) * mask).contiguous()   # masked conv inputs
+    dy = _bf(torch.randn(B, T, cout, generator=g)).to(cuda)
+    base = torch.randn(1, cout, cin, generator=g).to(cuda)
+    items.append(dict(x=x, dy=dy, dw=base.clone()))
+    ref = base.double() + torch.einsum("btc,bti->ci", dy.double(), x.double())[None]
+    refs.append(ref.float())
+    s = base.clone()
+    capi.conv1d_wgrad(x, dy, 1, pad_left=0, in_len=lens, out=s, accumulate=True)
+    singles.append(s)
+  capi.conv1x1_wgrad_grouped(items, in_len=lens)
+  torch.cuda.synchronize()
+  for it, ref, s in zip(items, refs, singles):
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(it["dw"], ref, rtol=1e-4, atol=1e-4 * scale)
+    torch.testing.assert_close(it["dw"], s, rtol=1e-4, atol=1e-4 * scale)
+  if case == "block_768":       # one owner per element: run-to-run bit-identical
+    again = [dict(it, dw=torch.zeros_like(it["dw"])) for it in items]
+    again2 = [dict(it, dw=torch.zeros_like(it["dw"])) for it in items]
+    capi.conv1x1_wgrad_grouped(again, in_len=lens)
+    capi.conv1x1_wgrad_grouped(again2, in_len=lens)
+    torch.cuda.synchronize()
+    for a, b in zip(again, again2):
+      assert torch.equal(a["dw"], b["dw"])
