@@ -115,7 +115,9 @@ class ConvTimer(object):
     self.overlap = os.environ.get("OS2S_WGRAD_STREAM", "1") != "0"
 
     def wrapped(x, w, **kw):
-      if not timer.enabled or (timer.in_backward and timer.overlap):
+      # launches that share the GPU with side-stream work are not the kernel alone: backward
+      # (weight gradients) and the forward launches next to early residual branches
+      if not timer.enabled or (timer.in_backward and timer.overlap) or conv_blocks.forward_side_busy():
         timer.untimed += int(timer.enabled)
         return timer.orig(x, w, **kw)
       # an event pair costs a few microseconds of dispatch bubble on the stream: bracket every
@@ -149,7 +151,7 @@ class ConvTimer(object):
     orig_grouped = self.capi.conv1x1_fwd_grouped
 
     def wrapped_grouped(items, in_len=None, out_len=None):
-      if not timer.enabled or (timer.in_backward and timer.overlap):
+      if not timer.enabled or (timer.in_backward and timer.overlap) or conv_blocks.forward_side_busy():
         timer.untimed += int(timer.enabled)
         return orig_grouped(items, in_len=in_len, out_len=out_len)
       timer.seen += 1
@@ -813,7 +815,8 @@ def main():
         "timed_launch_time_share_of_step": timer.all_ms / (1000.0 * dt),
         "executed_flop_fraction": fl / max(timer.dense_flops, 1.0),
         "dense_equivalent_tflops": timer.dense_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-        "launches_timed": ("every 4th forward-pass launch (the kernel alone on the GPU)" if timer.overlap
+        "launches_timed": ("every 4th forward-pass launch that has the GPU to itself (not the launches next to "
+                           "the early residual branches of the side stream)" if timer.overlap
                            else "every 4th forward / data-gradient launch"),
         "all_launches_per_step": (timer.all_n + timer.untimed) / max(args.steps, 1),
         # the WHOLE step against the same peak: FLOPs of the real (unpadded) frames of the batch /

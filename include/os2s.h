@@ -192,6 +192,16 @@ int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long long lda, cons
                     long long ldc, int M, int N, int K, const float* bias, int act, float keep_prob,
                     unsigned long long seed, const uint16_t* residual, int accumulate, int out_f32,
                     void* workspace, size_t workspace_bytes);
+/* The data gradient of a Dense layer whose input is the output of a ReLU + dropout layer
+ * (parts/transformer/ffn_layer.py:51-85: output_layer(dropout(relu(filter_layer(x))))), with that
+ * layer's activation / dropout backward fused into the epilogue:
+ *   C[M,N] = (A[M,K] . W[N,K]^T) * (mask_ref[m,n] > 0 ? mask_scale : 0)        (bf16)
+ * mask_ref = the saved forward output of the ReLU + dropout layer (row stride ldc), mask_scale =
+ * 1 / keep_prob. stats (or NULL): [ceil(M/128), 2, N] fp32 per-128-row-window column sums / sums of
+ * squares of C — the partial sums of that layer's bias gradient. Workspace as os2s_gemm_nt_ws. */
+int os2s_gemm_nt_mask_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W, void* C,
+                         long long ldc, int M, int N, int K, const uint16_t* mask_ref, float mask_scale,
+                         float* stats, void* workspace, size_t workspace_bytes);
 /* test / experiment hook: f > 0 forces the split factor, 0 disables the split, < 0 = cost model */
 void os2s_gemm_nt_set_split(int f);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,

@@ -624,6 +624,28 @@ def gemm_nt(a, w, out=None, bias=None, act=0, keep_prob=1.0, seed=0, residual=No
   return out
 
 
+def gemm_nt_mask(a, w, mask_ref, mask_scale, out=None, want_colsum=False):
+  """out[M,N] = (a[M,K] @ w[N,K]^T) * (mask_ref > 0 ? mask_scale : 0) (os2s_gemm_nt_mask_ws): a data
+  gradient with the ReLU + dropout backward of the producing layer in its epilogue. Returns
+  (out, partials [ceil(M/128), 2, N] or None) — partials[:, 0] are column sums of `out`."""
+  M, K = a.shape
+  N, K2 = w.shape
+  assert K == K2 and a.stride(1) == 1 and w.is_contiguous() and K % 64 == 0 and N % 8 == 0
+  if out is None:
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+  assert out.stride(1) == 1 and tuple(out.shape) == (M, N) and tuple(mask_ref.shape) == (M, N)
+  assert mask_ref.stride(1) == 1 and mask_ref.stride(0) == out.stride(0) and mask_ref.dtype == torch.bfloat16
+  part = torch.empty(((M + 127) // 128, 2, N), dtype=torch.float32, device=a.device) if want_colsum else None
+  ws = conv1d_workspace(a.device)
+  f = _fn("os2s_gemm_nt_mask_ws", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                                  c_void_p, c_float, c_void_p, c_void_p, c_size_t))
+  _lib.check(f(_stream(), c_void_p(a.data_ptr()), a.stride(0), c_void_p(w.data_ptr()),
+               c_void_p(out.data_ptr()), out.stride(0), M, N, K, c_void_p(mask_ref.data_ptr()),
+               float(mask_scale), _ptr(part, torch.float32, True), _ptr(ws), ws.numel()),
+             "os2s_gemm_nt_mask_ws")
+  return out, part
+
+
 _lt_lib = None
 
 

@@ -24,6 +24,12 @@ struct ConvArgs {
   float keep_prob;              // 1 = no dropout
   unsigned long long seed;
   const bf16_t* residual;       // same layout/strides as y (bf16 output only) or null
+  // backward of act + dropout fused into the data-gradient GEMM that produces dy (gemm_pp.hip,
+  // os2s_gemm_nt_mask_ws): y = (mask_ref > 0) ? acc * mask_scale : 0, mask_ref = the SAVED forward
+  // output relu(.)-then-dropout of the layer (same layout/strides as y); `stats` then holds the
+  // column sums of the masked gradient (= the bias gradient partials). Null = off.
+  const bf16_t* mask_ref;
+  float mask_scale;
   // ping-pong kernel only: split-unit workspace (fp32 partial tiles + one ticket per split unit)
   float* ws_slabs;
   int* ws_cnt;
@@ -209,12 +215,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
       const long long off = (long long)(t0 + row) * p.y_st + n0 + c8 * 8;
       if (p.residual) ro[i] = *reinterpret_cast<const u32x4*>(p.residual + (long long)b * p.y_sb + off);
       if (p.accumulate) ao[i] = *reinterpret_cast<const u32x4*>(yb + off);
+      if (p.mask_ref) ro[i] = *reinterpret_cast<const u32x4*>(p.mask_ref + (long long)b * p.y_sb + off);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = tid + i * NTHR;
       const int row = q / (BN / 8), c8 = q - row * (BN / 8);
-      if (p.residual) {
+      if (p.mask_ref) {          // (never together with residual / accumulate: checked on the host)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[i][e] = pack2bf(bflo(ro[i][e]) > 0.f ? bflo(v[i][e]) * p.mask_scale : 0.f,
+                            bfhi(ro[i][e]) > 0.f ? bfhi(v[i][e]) * p.mask_scale : 0.f);
+        if (p.stats) *reinterpret_cast<u32x4*>(const_cast<char*>(otw) + row * OP + c8 * 16) = v[i];
+      } else if (p.residual) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           v[i][e] = pack2bf(bflo(v[i][e]) + bflo(ro[i][e]), bfhi(v[i][e]) + bfhi(ro[i][e]));
@@ -234,7 +247,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
       if (row < valid_rows && gc < p.Cout) {
         u32x4 x = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
         bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
-        if (p.residual) {
+        if (p.mask_ref) {
+          const u32x4 o = *reinterpret_cast<const u32x4*>(
+              p.mask_ref + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            x[e] = pack2bf(bflo(o[e]) > 0.f ? bflo(x[e]) * p.mask_scale : 0.f,
+                           bfhi(o[e]) > 0.f ? bfhi(x[e]) * p.mask_scale : 0.f);
+          if (p.stats) *reinterpret_cast<u32x4*>(const_cast<char*>(otw) + row * OP + c8 * 16) = x;
+        } else if (p.residual) {
           const u32x4 o = *reinterpret_cast<const u32x4*>(
               p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
 #pragma unroll
@@ -252,6 +273,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
   }
 
   OS2S_EPI_STAMP();
+  if (p.stats && p.mask_ref) __syncthreads();   // the masked values were written back to the LDS tile
   if (p.stats) {
     constexpr int CP = BN / 2;       // column pairs
     constexpr int RG = (NTHR / CP) > 0 ? (NTHR / CP) : 1;    // row groups

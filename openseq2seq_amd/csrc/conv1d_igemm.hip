@@ -770,6 +770,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
   a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
+  a.mask_ref = nullptr; a.mask_scale = 1.f;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256;
   a.force_split = g_conv_split;
   a.dbg = g_conv_dbg; a.dbg_fixed_w = g_conv_fixed_w;
@@ -859,6 +860,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   a.stride = 1; a.dil = 1; a.padL = 0;
   a.x_sb = 0; a.x_st = 0; a.y_sb = 0; a.y_st = 0;
   a.out_f32 = 0; a.accumulate = 0; a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
+  a.mask_ref = nullptr; a.mask_scale = 1.f;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
   a.dbg = g_conv_dbg; a.dbg_fixed_w = 0;     // experiment hook (conv1x1_pp_kernel phase stamps)
   a.mtiles_per_b = ceil_div(T, BM);

@@ -432,10 +432,11 @@ static int g_gemm_split = -1;
 // optional accumulation into C (bf16) and fp32 output. lda / ldc / residual row stride in
 // elements; W is contiguous [N, K]. With a workspace (os2s_conv1d_workspace_bytes(), zero tickets,
 // one per stream) the last partial round of tiles is cut along K when the cost model says so.
-extern "C" int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
-                               void* C, long long ldc, int M, int N, int K, const float* bias, int act,
-                               float keep_prob, unsigned long long seed, const uint16_t* residual,
-                               int accumulate, int out_f32, void* workspace, size_t workspace_bytes) {
+static int gemm_nt_impl(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
+                        void* C, long long ldc, int M, int N, int K, const float* bias, int act,
+                        float keep_prob, unsigned long long seed, const uint16_t* residual,
+                        int accumulate, int out_f32, void* workspace, size_t workspace_bytes,
+                        const uint16_t* mask_ref, float mask_scale, float* stats) {
   using namespace os2s;
   OS2S_REQUIRE(A && W && C && M >= 1 && N >= 1 && K >= 64 && K % 64 == 0);
   OS2S_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N);
@@ -450,6 +451,9 @@ extern "C" int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long lon
   a.x_sb = 0; a.x_st = lda; a.y_sb = 0; a.y_st = ldc;
   a.out_f32 = out_f32; a.accumulate = accumulate; a.act = act; a.keep_prob = keep_prob; a.seed = seed;
   a.residual = residual;
+  a.mask_ref = mask_ref; a.mask_scale = mask_scale; a.stats = stats;
+  if (mask_ref) OS2S_REQUIRE(!residual && !accumulate && !out_f32 && act == 0 && keep_prob == 1.f && !bias);
+  if (stats) OS2S_REQUIRE(!out_f32);
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
   a.dbg = nullptr; a.dbg_fixed_w = 0;
   a.mtiles_per_b = ceil_div(M, 128);
@@ -502,6 +506,28 @@ extern "C" int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long lon
   const int grid = nfull + (f > 1 ? r * f : 0);
   OS2S_LAUNCH(gemm_pp_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, a, gm, rem > 0 ? rem : 1, nfull, f);
   return OS2S_OK;
+}
+
+extern "C" int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
+                               void* C, long long ldc, int M, int N, int K, const float* bias, int act,
+                               float keep_prob, unsigned long long seed, const uint16_t* residual,
+                               int accumulate, int out_f32, void* workspace, size_t workspace_bytes) {
+  return gemm_nt_impl(stream, A, lda, W, C, ldc, M, N, K, bias, act, keep_prob, seed, residual, accumulate,
+                      out_f32, workspace, workspace_bytes, nullptr, 1.f, nullptr);
+}
+
+// C[M,N] = (A[M,K] . W[N,K]^T) * (mask_ref > 0 ? mask_scale : 0), bf16: the data gradient of a Dense
+// layer whose INPUT is the output of a ReLU + dropout layer (ffn_layer.py:51-85), with that layer's
+// activation / dropout backward applied in the epilogue — mask_ref is its saved forward output
+// (zero where the ReLU or the dropout mask was off), mask_scale = 1 / keep_prob. stats (or null):
+// [ceil(M/128), 2, N] per-window column sums (and sums of squares) of C = the partials of the bias
+// gradient of that layer.
+extern "C" int os2s_gemm_nt_mask_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,
+                                    void* C, long long ldc, int M, int N, int K, const uint16_t* mask_ref,
+                                    float mask_scale, float* stats, void* workspace, size_t workspace_bytes) {
+  OS2S_REQUIRE(mask_ref != nullptr);
+  return gemm_nt_impl(stream, A, lda, W, C, ldc, M, N, K, nullptr, 0, 1.f, 0ull, nullptr, 0, 0, workspace,
+                      workspace_bytes, mask_ref, mask_scale, stats);
 }
 
 extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W,

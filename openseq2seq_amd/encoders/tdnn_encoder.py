@@ -11,8 +11,15 @@ from __future__ import absolute_import, division, print_function
 import torch
 
 from .encoder import Encoder
+import os
+
 from ..parts.cnns.conv_blocks import (Act, ConvBN, SepConvBN, conv_bn_res_bn_actv, xavier_normal_conv,
-                                      glorot_uniform_conv)
+                                      glorot_uniform_conv, launch_residual_early)
+
+# which layer of a residual block starts the block end's residual branches on the side stream
+# (-1 = never: they run in front of the block's last BatchNorm, as in round 2). 2 leaves the first
+# two convolutions of every block alone on the GPU (bench.py times those)
+RES_EARLY_REP = int(os.environ.get("OS2S_RES_EARLY", "-1"))
 
 
 class TDNNEncoder(Encoder):
@@ -110,6 +117,7 @@ class TDNNEncoder(Encoder):
     x = Act(source_sequence, lens, requires_grad=False)
     residual_aggregation = []
     layer_res = []
+    pending_res = None
     nl = len(self._layers)
     for li, L in enumerate(self._layers):
       blk, main = L['cfg'], L['main']
@@ -130,9 +138,20 @@ class TDNNEncoder(Encoder):
       keep = blk.get('dropout_keep_prob', default_keep) if training else 1.0
       res_in = layer_res if L['res'] else []
       last = (li == nl - 1)
+      # the block end's residual branches read the block inputs only: start them RES_EARLY_REP
+      # layers into the block, on the side stream (conv_blocks.launch_residual_early)
+      if blk.get('residual', False) and blk['repeat'] > 1 and s == 1 and \
+         L['rep'] == min(RES_EARLY_REP, blk['repeat'] - 2) and RES_EARLY_REP >= 0:
+        end = self._layers[li + blk['repeat'] - 1 - L['rep']]
+        if end['res'] and len(end['res']) >= 2:
+          pending_res = launch_residual_early(end['res'], layer_res, training)
+      res_fw = None
+      if L['res']:
+        res_fw, pending_res = pending_res, None
       x = conv_bn_res_bn_actv(main, L['res'], x, res_in, src_length if use_mask else None,
                               act_fn, training, tape, keep_prob=keep,
                               seed=seed0 * 1000003 + li, mask_output=(use_mask and not last),
                               drop_block_prob=self.params.get('drop_block_prob', 0.0),
-                              drop_block=(self.params.get('drop_block_index', -1) == L['block']))
+                              drop_block=(self.params.get('drop_block_index', -1) == L['block']),
+                              res_fw=res_fw)
     return {'outputs': x.data, 'src_length': src_length, 'outputs_act': x}

@@ -12,6 +12,8 @@ data-gradient convolution consumes (see include/os2s.h, os2s_conv1d_fwd).
 import struct
 
 import numpy as np
+import os
+
 import torch
 
 from .. import capi
@@ -126,6 +128,9 @@ class FlatParams(object):
     # copy): consumers that keep derived copies (fp8 weight copies) compare this counter
     self.version = getattr(self, "version", 0) + 1
     if self._wt_tiles:
+      # (only backward reads the transposed copies, but refreshing the copies on the side stream, under the first convolutions of the next forward
+      # pass, gains nothing: 39.3 / 40.0 vs 39.8 / 40.1 ms per Jasper step on one box — a ping-pong
+      # convolution owns whole CUs, every workgroup of another kernel displaces one of its tiles)
       capi.conv_weight_dgrad_copy(self.w16, self.wt16, self._wt_descs.view(-1, 32),
                                   self._wt_tiles)
 

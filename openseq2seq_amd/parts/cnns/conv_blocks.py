@@ -64,10 +64,12 @@ class on_side_stream(object):
     self.side = _side_stream(device)
     self.operands = operands
     self.ctx = None
+    self.main = None
 
   def __enter__(self):
     if self.side is not None:
-      self.side.wait_stream(torch.cuda.current_stream())
+      self.main = torch.cuda.current_stream()
+      self.side.wait_stream(self.main)
       self.ctx = torch.cuda.stream(self.side)
       self.ctx.__enter__()
     return self
@@ -79,6 +81,15 @@ class on_side_stream(object):
         if t is not None:
           t.record_stream(self.side)
     return False
+
+  def hand_over(self, *tensors):
+    """Tensors ALLOCATED inside the body (side-stream allocations) that the main stream consumes
+    after it has joined: their memory must not be recycled for later side-stream allocations while
+    main-stream kernels still use them."""
+    if self.side is not None:
+      for t in tensors:
+        if t is not None:
+          t.record_stream(self.main)
 
 
 def side_streams():
@@ -110,6 +121,9 @@ class Tape(object):
     self.ops.append((fn, params))
 
   def backward(self):
+    # work parked on the side stream since the last join (the data-gradient weight copies refreshed
+    # after the optimizer step, FlatParams.refresh_dgrad_copies) must have landed
+    join_side_streams()
     if self.on_done is None:
       for fn, _ in reversed(self.ops):
         fn()
@@ -140,15 +154,24 @@ class Tape(object):
 
 class Act(object):
   """An activation tensor + its valid lengths + (optionally) its gradient."""
-  __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad", "res_grad")
+  __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad", "res_grad", "mask_scale",
+               "grad_masked", "bias_part")
 
   def __init__(self, data, lens=None, requires_grad=True):
     self.data, self.lens = data, lens
     self.grad, self.grad_init = None, False
     self.requires_grad = requires_grad
     self.res_grad = None   # gradient arriving through a residual connection (pre-norm blocks)
+    # set by a ReLU (+ dropout) Dense layer on its OUTPUT: the consumer's data-gradient GEMM may
+    # apply (data > 0) * mask_scale in its epilogue (and leave the bias-gradient partials in
+    # bias_part); it then sets grad_masked and the producer skips its own activation backward
+    self.mask_scale = None
+    self.grad_masked = False
+    self.bias_part = None
 
   def grad_buffer(self):
+    # a gradient that already carries its producer's activation backward takes no more addends
+    assert not self.grad_masked, "a second consumer wrote to an activation whose gradient was finalised"
     if self.grad is None:
       self.grad = torch.empty_like(self.data)
       self.grad_init = False
@@ -385,7 +408,7 @@ class DepthwiseBN(ConvBN):
 
 def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_fn,
                         training, tape, keep_prob=1.0, seed=0, mask_output=True,
-                        drop_block_prob=0.0, drop_block=False):
+                        drop_block_prob=0.0, drop_block=False, res_fw=None):
   """act(BN(conv(x)) + sum_i BN_i(conv1x1_i(res_i))) -> dropout -> mask.
 
   main: ConvBN; res_branches: list of ConvBN (1x1) matching res_inputs (list of Act).
@@ -400,7 +423,14 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
   act = act_id(activation_fn)
   branches = [main] + list(res_branches)
   inputs = [x] + list(res_inputs)
-  fw = [main.conv_bn_stats(x, training)] + grouped_conv1x1_bn_stats(res_branches, res_inputs, training)
+  fw_main = main.conv_bn_stats(x, training)
+  if res_fw is not None:         # launched earlier on the side stream (launch_residual_early)
+    join_side_streams()
+    global _FWD_SIDE_BUSY
+    _FWD_SIDE_BUSY = False
+    fw = [fw_main] + res_fw
+  else:
+    fw = [fw_main] + grouped_conv1x1_bn_stats(res_branches, res_inputs, training)
   dropped = False
   if res_branches and drop_block_prob > 0:
     if training:
@@ -480,6 +510,33 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
 
   tape.record(backward, [p for br in [main] + list(res_branches) for p in br.trainable()])
   return result
+
+
+_FWD_SIDE_BUSY = False
+
+
+def forward_side_busy():
+  """True while residual branches launched early are (possibly) still running next to the main
+  stream's forward kernels (bench.py does not time those launches: not alone on the GPU)."""
+  return _FWD_SIDE_BUSY
+
+
+def launch_residual_early(res_branches, res_inputs, training):
+  """The 1x1 residual branches of a block END (conv + BatchNorm statistics of every dense-residual
+  input, conv_blocks.py:78-100) depend only on the block INPUTS, so they can run while the block's
+  own layers do: enqueued on the side stream, they use the CUs a 142-284-tile convolution leaves
+  idle (an HBM-bound grouped launch next to MFMA-bound ones). Returns what
+  grouped_conv1x1_bn_stats returns, for conv_bn_res_bn_actv(..., res_fw=...) which joins the side
+  stream before its BatchNorm sum; None when there is no side stream (OS2S_WGRAD_STREAM=0)."""
+  if not res_branches or _side_stream(res_inputs[0].data.device) is None:
+    return None
+  global _FWD_SIDE_BUSY
+  _FWD_SIDE_BUSY = True
+  with on_side_stream(res_inputs[0].data.device, *[r.data for r in res_inputs]) as ctx:
+    fw = grouped_conv1x1_bn_stats(res_branches, res_inputs, training)
+    for f in fw:
+      ctx.hand_over(*[v for v in f.values() if torch.is_tensor(v)])
+  return fw
 
 
 def _is_plain_1x1(br):

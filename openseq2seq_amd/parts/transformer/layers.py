@@ -28,6 +28,9 @@ GEMM_BACKEND = _os.environ.get("OS2S_GEMM", "pp")
 # gradient fills the other half of the chip. 22.1 -> 20.3 ms/step, sustained over 300 steps
 # (OS2S_DENSE_WGRAD_STREAM=0 keeps them on the main stream)
 DENSE_WGRAD_STREAM = _os.environ.get("OS2S_DENSE_WGRAD_STREAM", "1") == "1"
+# the ReLU + dropout backward of a Dense layer fused into the data-gradient GEMM of its consumer
+# (os2s_gemm_nt_mask_ws); OS2S_FUSE_RELU_BWD=0 = the separate dropout_bwd_colsum pass of round 2
+FUSE_RELU_BWD = _os.environ.get("OS2S_FUSE_RELU_BWD", "1") == "1"
 SKINNY_LOGITS = False    # [256 x 32768 x 1024]: the LDS-tiled kernel wins (60 vs 139 us)
 
 
@@ -53,6 +56,7 @@ def _colsum_into(dy2d, bias_param):
 def _accumulate_grad(x, dx):
   if not x.requires_grad:
     return
+  assert not x.grad_masked, "a second consumer wrote to an activation whose gradient was finalised"
   if x.grad_init and x.grad is not None:
     capi.add_bf16(x.grad, dx, out=x.grad)
   else:
@@ -100,13 +104,19 @@ class Dense(object):
       return out
     lin = self
     assert not (act == 1 and residual is not None)
+    if act == 1 and FUSE_RELU_BWD and GEMM_BACKEND != "lt" and y.is_contiguous():
+      out.mask_scale = 1.0 / keep       # y = dropout(relu(.)): zero exactly where the gradient is
 
     def backward():
       dy = out.grad
       assert dy is not None, "no gradient reached " + lin.kernel.name
       bias_part = None          # partial column sums of dz when the same pass can produce them
       fuse = lin.bias is not None and dy.is_contiguous()
-      if act == 1:
+      if act == 1 and out.grad_masked:
+        # the consumer's data-gradient GEMM applied (y > 0) / keep in its epilogue
+        dz, bias_part = dy, out.bias_part
+        out.bias_part = None
+      elif act == 1:
         if fuse:
           dz, bias_part = capi.dropout_bwd_colsum(dy, keep, out=y)
         else:
@@ -138,6 +148,13 @@ class Dense(object):
         g = x.grad_buffer()
         if GEMM_BACKEND == "lt":
           capi.matmul_lt(dz, lin.w, out=g, beta=1.0 if x.grad_init else 0.0)
+        elif x.mask_scale is not None and not x.grad_init and lin.cout % 64 == 0 and lin.cin % 8 == 0 and \
+            dz.stride(1) == 1 and g.is_contiguous():
+          # x = dropout(relu(.)) of the layer below, this is the only consumer: its activation
+          # backward (and the bias-gradient partials) ride in this GEMM's epilogue
+          _, x.bias_part = capi.gemm_nt_mask(dz, lin.kernel.wt16.view(lin.cin, lin.cout), x.data, x.mask_scale,
+                                             out=g, want_colsum=True)
+          x.grad_masked = True
         else:
           capi.gemm(dz, lin.kernel.wt16.view(lin.cin, lin.cout), out=g, accumulate=x.grad_init)
         x.grad_init = True

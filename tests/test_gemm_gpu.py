@@ -88,3 +88,46 @@ def test_gemm_nt_tail_split(cuda, M, N, K, split):
   full = a.float() @ w.float().t()
   torch.testing.assert_close(y32, full, rtol=2e-3, atol=2e-3 * float(full.pow(2).mean().sqrt()))
   assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K,split", [(8300, 4096, 1024, -1), (700, 1024, 512, -1), (515, 264, 2048, 3),
+                                         (129, 4096, 128, -1)])
+def test_gemm_nt_mask_epilogue(cuda, M, N, K, split):
+  """os2s_gemm_nt_mask_ws: the data gradient with the ReLU + dropout backward of the producing layer
+  in the epilogue, out = (a @ w^T) * (ref > 0) / keep, plus the per-window column sums of `out`
+  (the bias-gradient partials) — against the two-pass computation: the plain GEMM (bf16 output)
+  followed by os2s_dropout_bwd_colsum. The masked output must be BIT-IDENTICAL to the two passes
+  wherever the tile is not K-split (same accumulation order, one bf16 rounding less: the product is
+  scaled in fp32 before it is rounded — compared at 1 bf16 ulp); column sums rtol 2e-3 of the
+  column's absolute sum. M = 8300, N = 4096 is the Transformer-big FFN shape; ragged M and N edges;
+  a forced tail split."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(M + N)
+  keep = 0.9
+  a = _bf(torch.randn(M, K, generator=g)).to(cuda)
+  w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(cuda)
+  h = torch.randn(M, N, generator=g)
+  ref_out = _bf(torch.relu(h) * (torch.rand(M, N, generator=g) < keep).float() / keep).to(cuda)   # saved y
+  L = _lib.lib()
+  try:
+    L.os2s_gemm_nt_set_split(split)
+    out, part = capi.gemm_nt_mask(a, w, ref_out, 1.0 / keep, want_colsum=True)
+    out2, none = capi.gemm_nt_mask(a, w, ref_out, 1.0 / keep)
+  finally:
+    L.os2s_gemm_nt_set_split(-1)
+  torch.cuda.synchronize()
+  assert none is None and torch.equal(out, out2)
+  prod = a.float() @ w.float().t()
+  want = torch.where(ref_out > 0, prod / keep, torch.zeros_like(prod))
+  scale = float(want.pow(2).mean().sqrt())
+  torch.testing.assert_close(out.float(), want, rtol=1e-2, atol=1e-2 * scale)
+  assert bool((out[ref_out <= 0] == 0).all())              # exact zeros where the mask is off
+  # the column sums are sums of the bf16 values that were stored
+  sums = part[:, 0].sum(0)
+  want_sums = out.float().sum(0)
+  torch.testing.assert_close(sums, want_sums, rtol=2e-3, atol=2e-3 * float(out.float().abs().sum(0).max()))
+  assert tuple(part.shape) == ((M + 127) // 128, 2, N)
+  # two-pass path of round 2 for comparison: plain GEMM, then the elementwise backward
+  dy = capi.gemm_nt(a, w)
+  dz, _ = capi.dropout_bwd_colsum(dy, keep, out=ref_out)
+  torch.testing.assert_close(out.float(), dz.float(), rtol=2e-2, atol=2e-2 * scale)

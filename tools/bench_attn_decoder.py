@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "tacotron"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 if which == "tacotron":
-  B, S, L, H, M, U, mode, K, F = 32, 200, 2, 1024, 512, 128, 2, 32, 32
+  B, S, L, H, M, U, mode, K, F = 32, 200, 2, 1024, 1024, 128, 2, 32, 32   # tacotron_gst.py: encoder 512 + style 512
 else:
   B, S, L, H, M, U, mode, K, F = 128, 50, 1, 512, 1024, 512, 1, 0, 0
 g = torch.Generator().manual_seed(0)
