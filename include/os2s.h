@@ -174,6 +174,13 @@ typedef struct {
 } os2s_wgrad_group_t;
 int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
                                const int32_t* in_len, int B, int T);
+/* The weight gradients of up to 16 Dense layers over the same M rows (a packed token batch) in one
+ * launch of the K = 1 ping-pong kernel: dw_i[Cout_i, Cin_i] (+)= dy_i[M, Cout_i]^T x_i[M, Cin_i], fp32,
+ * deterministic (no atomics). tf.layers.Dense kernels of the Transformer whose outputs are too small
+ * to fill the chip alone (1024 x 1024: attention_layer.py:54-62, 219). Cin, Cout >= 128. Workspace:
+ * os2s_conv1d_workspace_bytes(), the contract of os2s_conv1d_fwd_ws. */
+int os2s_gemm_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
+                            long long M, int accumulate, void* workspace, size_t workspace_bytes);
 /* Plain GEMM, hand-written for the gfx950 matrix cores (csrc/gemm_pp.hip):
  *   C[M,N] (+)= A[M,K] . W[N,K]^T, C = residual + dropout(act(. + bias)) as in os2s_conv1d_fwd_ex.
  * Replaces tf.layers.Dense of the Transformer (parts/transformer/attention_layer.py:54-62,125-127,

@@ -229,6 +229,32 @@ def conv1x1_wgrad_grouped(items, in_len=None):
   _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T), "os2s_conv1x1_wgrad_grouped")
 
 
+def gemm_wgrad_grouped(items, accumulate=True):
+  """items: list of dict(x [M,Cin] bf16, dy [M,Cout] bf16, dw [Cout,Cin] fp32): the Dense weight
+  gradients dw (+)= dy^T x of up to 16 layers over the same M rows in one launch
+  (os2s_gemm_wgrad_grouped: ping-pong tiles, deterministic)."""
+  n = len(items)
+  assert 1 <= n <= 16
+  M = items[0]["x"].shape[0]
+  arr = (_WgradGroup * n)()
+  keep = []
+  for g, it in zip(arr, items):
+    x, dy, dw = it["x"], it["dy"], it["dw"]
+    if dy.stride(1) != 1 or dy.stride(0) != dy.shape[1]:
+      dy = dy.contiguous()
+    if x.stride(1) != 1 or x.stride(0) % 8:
+      x = x.contiguous()
+    keep += [x, dy]
+    assert x.shape[0] == M and dy.shape[0] == M and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape[-2:]) == (dy.shape[1], x.shape[1])
+    g.x, g.dy, g.dw = c_void_p(x.data_ptr()), c_void_p(dy.data_ptr()), _ptr(dw, torch.float32)
+    g.x_row_stride, g.Cin, g.Cout = x.stride(0), x.shape[1], dy.shape[1]
+  ws = conv1d_workspace(items[0]["x"].device)
+  f = _fn("os2s_gemm_wgrad_grouped",
+          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_ll, c_int, c_void_p, c_size_t))
+  _lib.check(f(_stream(), arr, n, M, int(bool(accumulate)), _ptr(ws), ws.numel()), "os2s_gemm_wgrad_grouped")
+
+
 def _ptr_array(tensors, dtype):
   arr = (c_void_p * len(tensors))()
   for i, t in enumerate(tensors):
@@ -763,8 +789,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, save=True):
   return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
-  """Returns dx (= dres + LN'(dy)); accumulates dgamma/dbeta."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer_param_grads=False):
+  """Returns dx (= dres + LN'(dy)); accumulates dgamma/dbeta — or, with defer_param_grads, returns
+  (dx, finish) where finish() reduces the partials into dgamma/dbeta (the caller may run it on
+  another stream: nothing in the rest of backward reads a parameter gradient)."""
   N, D = x.shape
   dx = torch.empty_like(x)
   nparts = int(_fn("os2s_layernorm_bwd_num_parts", (c_ll,))(N))
@@ -775,8 +803,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
                _ptr(gamma, torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
                _ptr(dres, torch.bfloat16, True), N, D, _ptr(dx), _ptr(partial)),
              "os2s_layernorm_bwd")
-  scratch = torch.empty((2, D), dtype=torch.float32, device=x.device)
-  bn_bwd_finalize(partial, 1, 1, dgamma, dbeta, True, scratch[0], scratch[1])
+  def finish():
+    scratch = torch.empty((2, D), dtype=torch.float32, device=x.device)
+    bn_bwd_finalize(partial, 1, 1, dgamma, dbeta, True, scratch[0], scratch[1])
+  if defer_param_grads:
+    return dx, finish, partial
+  finish()
   return dx
 
 

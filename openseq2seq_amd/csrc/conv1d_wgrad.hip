@@ -717,7 +717,11 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
 // 130 steps), so the units of the last partial round are cut up to 16 ways along the reduction
 // and reduced by the last arriver (os2s_split_reduce.hpp): deterministic, no atomics.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void conv1d_wgrad1x1_pp_kernel(WgradArgs p) {
+// gt.ngroups > 0: up to kMaxWgradGroups independent problems over the same rows (B, T, in_len) in
+// one grid — units are ranked over all groups (group g owns ranks [unit_begin, unit_begin + NCO*NCI)),
+// p.NCO * p.NCI = the total: three 1024 x 1024 Dense weight gradients are 48 tiles cut 5 ways instead
+// of three launches of 16 tiles cut 16 ways (or the lockstep kernel with its atomics).
+__global__ __launch_bounds__(512, 2) void conv1d_wgrad1x1_pp_kernel(WgradArgs p, WgradGroupTable gt) {
   constexpr int BT = 64;
   constexpr int TILE = BT * 256 * 2;                       // [64 rows][256 ch] bf16 = 32 KB
   constexpr int HALF = TILE / 2;                           // one [64][128] sub-image
@@ -772,8 +776,22 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad1x1_pp_kernel(WgradArgs p)
     piece = i - (i / f) * f;
     npiece = f;
   }
+  int grank = rank;                                       // rank inside its group
+  if (gt.ngroups > 0) {
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxWgradGroups; ++i)
+      if (i < gt.ngroups && rank >= gt.g[i].unit_begin) gi = i;
+    WgradGroup g = gt.g[0];
+#pragma unroll
+    for (int i = 1; i < kMaxWgradGroups; ++i)
+      if (i == gi) g = gt.g[i];
+    p.x = g.x; p.dy = g.dy; p.dw = g.dw; p.x_ld = g.x_ld;
+    p.Cin = g.Cin; p.Cout = g.Cout; p.NCI = g.NCI;
+    grank = rank - g.unit_begin;
+  }
   // the ci tiles of one co tile are adjacent ranks: they stream the same dY columns together
-  const int co0 = (rank / p.NCI) * 256, ci0 = (rank % p.NCI) * 256;
+  const int co0 = (grank / p.NCI) * 256, ci0 = (grank % p.NCI) * 256;
   const int sps = (total_live + npiece - 1) / npiece;
   const int s_begin = __builtin_amdgcn_readfirstlane(min(piece * sps, total_live));
   const int s_end = __builtin_amdgcn_readfirstlane(min(total_live, s_begin + sps));
@@ -1200,8 +1218,10 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
     const int U = a.NCO * a.NCI;
     const int r = U % ncu1;
     const int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
+    WgradGroupTable none;
+    none.ngroups = 0; none.total_units = 0;
     OS2S_LAUNCH(conv1d_wgrad1x1_pp_kernel, dim3(U + pieces), dim3(512), (size_t)160 * 1024,
-                (hipStream_t)stream, a);
+                (hipStream_t)stream, a, none);
     return OS2S_OK;
   }
 
@@ -1317,5 +1337,68 @@ extern "C" int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad
   });
   if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
   OS2S_LAUNCH(conv1d_wgrad_grouped_kernel, dim3(units), dim3(256), smem, (hipStream_t)stream, a, gt);
+  return OS2S_OK;
+}
+
+
+// The Dense weight gradients dw_i[Cout_i, Cin_i] (+)= dy_i^T x_i of up to 16 layers that see the
+// same rows (one packed token batch [M, .]) in ONE launch of the K = 1 ping-pong kernel
+// (conv1d_wgrad1x1_pp_kernel): deterministic (one owner per dW element, split reductions summed in
+// piece order), no atomics. For the small outputs — the 1024 x 1024 projections of the Transformer:
+// 16 tiles each — that a launch of their own cannot spread over the chip.
+extern "C" int os2s_gemm_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
+                                       long long M, int accumulate, void* workspace, size_t workspace_bytes) {
+  using namespace os2s;
+  OS2S_REQUIRE(groups && ngroups >= 1 && ngroups <= kMaxWgradGroups && M >= 1 && M < (1ll << 30));
+  WgradGroupTable gt;
+  gt.ngroups = ngroups;
+  int units = 0;
+  for (int i = 0; i < kMaxWgradGroups; ++i) {
+    const os2s_wgrad_group_t& s = groups[i < ngroups ? i : 0];
+    OS2S_REQUIRE(s.x && s.dy && s.dw && s.Cin >= 128 && s.Cout >= 128 && s.Cin % 8 == 0 && s.Cout % 8 == 0);
+    OS2S_REQUIRE(s.x_row_stride >= s.Cin && s.x_row_stride % 8 == 0);
+    OS2S_REQUIRE(s.x_row_stride * 2 * 64 < (1ll << 30) && (long long)s.Cout * 2 * 64 < (1ll << 30));
+    WgradGroup& g = gt.g[i];
+    g.x = s.x; g.dy = s.dy; g.dw = s.dw; g.x_ld = s.x_row_stride;
+    g.Cin = s.Cin; g.Cout = s.Cout; g.NCI = ceil_div(s.Cin, 256);
+    g.unit_begin = units;
+    if (i < ngroups) units += ceil_div(s.Cout, 256) * g.NCI;
+  }
+  gt.total_units = units;
+  WgradArgs a;
+  a.x = gt.g[0].x; a.dy = gt.g[0].dy; a.dw = gt.g[0].dw; a.in_len = nullptr;
+  a.B = 1; a.Tin = (int)M; a.Tout = (int)M; a.Cin = gt.g[0].Cin; a.Cout = gt.g[0].Cout; a.K = 1;
+  a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = gt.g[0].x_ld;
+  a.accumulate = accumulate ? 1 : 0;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
+  a.dbg = nullptr; a.dbg_mode = 0;
+  a.NCO = units; a.NCI = 1; a.NTP = 1;                   // U = NCO * NCI = all units of all groups
+  a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
+  a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  static int ncu = 256;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1d_wgrad1x1_pp_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n;
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  a.ncu = ncu;
+  const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+  if (workspace && workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
+    a.ws_cnt = reinterpret_cast<int*>(workspace);
+    a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+    size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
+    const size_t cap = (size_t)3 * ncu;
+    a.ws_nslabs = (int)(n < cap ? n : cap);
+  }
+  const int r = units % ncu;
+  const int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
+  OS2S_LAUNCH(conv1d_wgrad1x1_pp_kernel, dim3(units + pieces), dim3(512), (size_t)160 * 1024,
+              (hipStream_t)stream, a, gt);
   return OS2S_OK;
 }

@@ -11,6 +11,7 @@
 //   * dropout / relu-dropout backward helpers;
 //   * PaddedCrossEntropyLossWithSmoothing (losses/sequence_loss.py:257-309) fused with
 //     its gradient: one read of the [N, V] logits, one write of dlogits.
+#include <cstdlib>
 #include "os2s_common.hpp"
 
 namespace os2s {
@@ -557,6 +558,8 @@ extern "C" int os2s_layernorm_fwd(os2s_stream_t stream, const uint16_t* x, const
   return OS2S_OK;
 }
 
+// rows per workgroup of the LayerNorm backward (8 / 16 / 32 measured equal on a Transformer-big step:
+// the step is bound by the sum of kernel times, not by this kernel's latency)
 static const int kLnRowsPerBlock = 32;
 extern "C" int os2s_layernorm_bwd_num_parts(long long N) { return ceil_div(N, kLnRowsPerBlock); }
 

@@ -121,35 +121,78 @@ class Tape(object):
     self.ops.append((fn, params))
 
   def backward(self):
-    # work parked on the side stream since the last join (the data-gradient weight copies refreshed
-    # after the optimizer step, FlatParams.refresh_dgrad_copies) must have landed
+    # work parked on the side stream since the last join must have landed
     join_side_streams()
-    if self.on_done is None:
-      for fn, _ in reversed(self.ops):
-        fn()
-      self.ops = []
-      join_side_streams()
-      return
-    pending, by_id = {}, {}
-    for _, params in self.ops:
-      for p in params:
-        pending[id(p)] = pending.get(id(p), 0) + 1
-        by_id[id(p)] = p
-    order = sorted(by_id.values(), key=lambda p: -p.offset)
-    ptr = 0
-    for fn, params in reversed(self.ops):
-      fn()
-      if params:
-        for p in params:
-          pending[id(p)] -= 1
-        moved = False
-        while ptr < len(order) and pending[id(order[ptr])] == 0:
-          ptr += 1
-          moved = True
-        if moved:
-          self.on_done(order[ptr - 1].offset)
+    global _CUR_TAPE
+    _CUR_TAPE, self._deferred, self._pending = self, [], None
+    try:
+      if self.on_done is None:
+        for fn, _ in reversed(self.ops):
+          fn()
+        self.flush_deferred()
+      else:
+        pending, by_id = {}, {}
+        for _, params in self.ops:
+          for p in params:
+            pending[id(p)] = pending.get(id(p), 0) + 1
+            by_id[id(p)] = p
+        self._pending = pending
+        order = sorted(by_id.values(), key=lambda p: -p.offset)
+        ptr = 0
+
+        def advance():
+          nonlocal ptr
+          moved = False
+          while ptr < len(order) and pending[id(order[ptr])] == 0:
+            ptr += 1
+            moved = True
+          if moved:
+            self.on_done(order[ptr - 1].offset)
+
+        for fn, params in reversed(self.ops):
+          fn()
+          if params:
+            for p in params:
+              pending[id(p)] -= 1
+            advance()
+        if self._deferred:
+          self.flush_deferred()
+          advance()
+    finally:
+      _CUR_TAPE = None
     self.ops = []
     join_side_streams()
+
+  # ---- deferred (grouped) weight gradients -----------------------------------------------------
+  def defer_wgrad(self, param, item, group=3):
+    """A Dense weight gradient too small to fill the chip alone is held back until `group` of them
+    can go out in one launch (capi.gemm_wgrad_grouped). Until then `param` does not count as final
+    for the gradient reducer."""
+    self._deferred.append((param, item))
+    if self._pending is not None and id(param) in self._pending:
+      self._pending[id(param)] += 1
+    if len(self._deferred) >= group:
+      self.flush_deferred()
+
+  def flush_deferred(self):
+    if not self._deferred:
+      return
+    items = [it for _, it in self._deferred]
+    with on_side_stream(items[0]["x"].device, *([it["x"] for it in items] + [it["dy"] for it in items])):
+      capi.gemm_wgrad_grouped(items, accumulate=True)
+    if self._pending is not None:
+      for p, _ in self._deferred:
+        if id(p) in self._pending:
+          self._pending[id(p)] -= 1
+    self._deferred = []
+
+
+_CUR_TAPE = None
+
+
+def current_tape():
+  """The tape whose backward pass is running (None outside Tape.backward)."""
+  return _CUR_TAPE
 
 
 class Act(object):

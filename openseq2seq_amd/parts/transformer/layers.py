@@ -13,7 +13,7 @@ import math
 import torch
 
 from ... import capi
-from ..cnns.conv_blocks import Act, on_side_stream
+from ..cnns.conv_blocks import Act, on_side_stream, current_tape
 
 
 SKINNY_MAX_ROWS = 512
@@ -31,6 +31,18 @@ DENSE_WGRAD_STREAM = _os.environ.get("OS2S_DENSE_WGRAD_STREAM", "1") == "1"
 # the ReLU + dropout backward of a Dense layer fused into the data-gradient GEMM of its consumer
 # (os2s_gemm_nt_mask_ws); OS2S_FUSE_RELU_BWD=0 = the separate dropout_bwd_colsum pass of round 2
 FUSE_RELU_BWD = _os.environ.get("OS2S_FUSE_RELU_BWD", "1") == "1"
+# Dense weight gradients with fewer than 32 output tiles of 256 x 256 (the 1024 x 1024 projections)
+# are collected three at a time into one ping-pong launch (OS2S_GROUP_SMALL_WGRAD=0: one lockstep
+# launch with fp32 atomics each, as in round 2)
+GROUP_SMALL_WGRAD = _os.environ.get("OS2S_GROUP_SMALL_WGRAD", "1") == "1"
+
+
+def _small_wgrad(lin, dz):
+  units = ((lin.cout + 255) // 256) * ((lin.cin + 255) // 256)
+  return units < 32 and lin.cout >= 128 and lin.cin >= 128 and dz.shape[0] >= 2048 and \
+      lin.cout % 8 == 0 and lin.cin % 8 == 0
+
+
 SKINNY_LOGITS = False    # [256 x 32768 x 1024]: the LDS-tiled kernel wins (60 vs 139 us)
 
 
@@ -134,16 +146,21 @@ class Dense(object):
       # 300 steps (with the round-1 vendor GEMMs the same move lost 11 % at the power limit)
       if GEMM_BACKEND == "lt":
         capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
+      elif DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _small_wgrad(lin, dz) and current_tape() is not None:
+        # 16 output tiles: three of these go out as ONE launch (Tape.defer_wgrad)
+        current_tape().defer_wgrad(lin.kernel, dict(x=x.data, dy=dz, dw=lin.kernel.grad.view(lin.cout, lin.cin)))
       elif DENSE_WGRAD_STREAM:
         with on_side_stream(dz.device, x.data, dz):
           capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
       else:
         capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
       if bias_part is not None:
-        scratch = torch.empty(2, lin.cout, dtype=torch.float32, device=dz.device)
-        capi.bn_bwd_finalize(bias_part, 1, 1, None, lin.bias.grad, True, scratch[0], scratch[1])
+        with on_side_stream(dz.device, bias_part):        # parameter gradient: off the main chain
+          scratch = torch.empty(2, lin.cout, dtype=torch.float32, device=dz.device)
+          capi.bn_bwd_finalize(bias_part, 1, 1, None, lin.bias.grad, True, scratch[0], scratch[1])
       elif lin.bias is not None:
-        _colsum_into(dz, lin.bias)
+        with on_side_stream(dz.device, dz):
+          _colsum_into(dz, lin.bias)
       if x.requires_grad:
         g = x.grad_buffer()
         if GEMM_BACKEND == "lt":
@@ -187,8 +204,10 @@ class LayerNorm(object):
       dy = out.grad
       assert dy is not None
       dres, x.res_grad = x.res_grad, None
-      dx = capi.layernorm_bwd(dy, x.data, ln.scale.master, mean, rstd, dres, ln.scale.grad,
-                              ln.bias.grad)
+      dx, finish, partial = capi.layernorm_bwd(dy, x.data, ln.scale.master, mean, rstd, dres, ln.scale.grad,
+                                               ln.bias.grad, defer_param_grads=True)
+      with on_side_stream(dx.device, partial):      # scale / bias gradients: off the main chain
+        finish()
       _accumulate_grad(x, dx)
       out.grad = None
 
@@ -295,8 +314,12 @@ class SharedEmbedding(object):
 
       def backward():
         if out.grad is not None:
-          capi.embed_bwd(ids, out.grad, emb.weights.grad.view(emb.V, emb.D), emb.D ** 0.5, keep,
-                         seed)
+          # a parameter gradient: side stream, like every other (all three writers of the shared
+          # table — the softmax weight gradient and both embedding scatters — sit on that ONE stream,
+          # in order: the scatter's atomics must not interleave with the GEMM's read-modify-write)
+          with on_side_stream(out.grad.device, ids, out.grad):
+            capi.embed_bwd(ids, out.grad, emb.weights.grad.view(emb.V, emb.D), emb.D ** 0.5, keep,
+                           seed)
         out.grad = None
 
       tape.record(backward, [emb.weights] if final_use else ())
@@ -322,7 +345,8 @@ class SharedEmbedding(object):
           capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
           capi.matmul_lt(dy, emb.table, out=g, beta=1.0 if x.grad_init else 0.0)
         else:
-          capi.gemm_wgrad(x.data, dy, emb.weights.grad.view(emb.V, emb.D), accumulate=True)
+          with on_side_stream(dy.device, x.data, dy):
+            capi.gemm_wgrad(x.data, dy, emb.weights.grad.view(emb.V, emb.D), accumulate=True)
           capi.gemm(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
         x.grad_init = True
         out.grad = None

@@ -131,3 +131,33 @@ def test_gemm_nt_mask_epilogue(cuda, M, N, K, split):
   dy = capi.gemm_nt(a, w)
   dz, _ = capi.dropout_bwd_colsum(dy, keep, out=ref_out)
   torch.testing.assert_close(out.float(), dz.float(), rtol=2e-2, atol=2e-2 * scale)
+
+
+def test_gemm_wgrad_grouped(cuda):
+  """os2s_gemm_wgrad_grouped: three 1024 x 1024 Dense weight gradients (+ a ragged-edge one) over
+  the same 8300 packed rows in one launch of the K = 1 ping-pong kernel, accumulating into non-zero
+  dW: equal to the fp32 matmul (rtol 2e-3 of the largest entry) and to the single launches, and
+  bit-identical from run to run (no atomics)."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(5)
+  M = 8300
+  shapes = [(1024, 1024), (1024, 1024), (1024, 1024), (520, 264)]
+  items, refs = [], []
+  for cin, cout in shapes:
+    x = _bf(torch.randn(M, cin, generator=g)).to(cuda)
+    dy = _bf(torch.randn(M, cout, generator=g)).to(cuda)
+    base = torch.randn(cout, cin, generator=g).to(cuda)
+    items.append(dict(x=x, dy=dy, dw=base.clone()))
+    refs.append(base + dy.float().t() @ x.float())
+  capi.gemm_wgrad_grouped(items)
+  again = [dict(it, dw=torch.zeros_like(it["dw"])) for it in items]
+  again2 = [dict(it, dw=torch.zeros_like(it["dw"])) for it in items]
+  capi.gemm_wgrad_grouped(again)
+  capi.gemm_wgrad_grouped(again2)
+  torch.cuda.synchronize()
+  for it, ref, a, b in zip(items, refs, again, again2):
+    torch.testing.assert_close(it["dw"], ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    assert torch.equal(a["dw"], b["dw"])
+    single = torch.zeros_like(a["dw"])
+    capi.gemm_wgrad(it["x"], it["dy"], single, accumulate=True)
+    torch.testing.assert_close(a["dw"], single, rtol=2e-3, atol=2e-3 * float(single.abs().max()))
