@@ -724,7 +724,8 @@ typedef struct os2s_attn_decoder {
   const uint16_t* wq;           /* bf16 [U, H] */
   const float* v; const float* g; const float* b;                 /* [U], [1], [U] */
   const float* conv_w; const float* conv_b; const float* dense_w; /* [K,F], [F], [F,U] */
-  float* loc_ws;                /* mode 2: fp32 scratch [(K+1)*U] (folded location filter) */
+  float* loc_ws;                /* mode 2: fp32 scratch, os2s_attn_decoder_loc_ws_floats(B, S, U, loc_k) floats:
+                                 * the folded location filter [(K+1)*U] + partial scores [B, 4, S] */
   /* inputs */
   const uint16_t* gx0;          /* bf16 [B, T, 4H] */
   const uint16_t* keys;         /* bf16 [B, S, U] */
@@ -766,6 +767,8 @@ typedef struct os2s_attn_decoder_grads {
 int os2s_quantize_rows_e4m3(os2s_stream_t stream, const uint16_t* w, int rows, int K, uint8_t* q,
                             float* scale);
 int os2s_attn_decoder_fwd(os2s_stream_t stream, const os2s_attn_decoder_t* d);
+/* floats of os2s_attn_decoder_t.loc_ws (location-sensitive mode) */
+size_t os2s_attn_decoder_loc_ws_floats(int B, int S, int U, int loc_k);
 size_t os2s_attn_decoder_bwd_workspace_bytes(const os2s_attn_decoder_t* d);
 int os2s_attn_decoder_bwd(os2s_stream_t stream, const os2s_attn_decoder_t* d,
                           const os2s_attn_decoder_grads_t* grads, void* workspace,

@@ -1230,7 +1230,7 @@ class AttnDecoder(object):
     self.c_seq = [z((B, T, H), f32) for l in range(L)]
     self.gates = [z((B, T, 4 * H), bf) if save else None for l in range(L)]
     self.cum_seq = z((B, T + 1, S), f32) if mode == SCORE_LOCATION else None
-    self.loc_ws = z(((loc_k + 1) * U,), f32) if mode == SCORE_LOCATION else None
+    self.loc_ws = z(((loc_k + 1) * U + B * 4 * S,), f32) if mode == SCORE_LOCATION else None   # os2s_attn_decoder_loc_ws_floats
     self.align_seq = z((B, T, S), f32)
     self.q_seq = z((B, T, U), f32)
     self.y_top = y_top if y_top is not None else z((B, T, H), bf)

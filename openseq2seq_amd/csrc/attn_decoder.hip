@@ -23,6 +23,7 @@
 //   backward      : d(attention input) GEMM, attention backward per sample (recomputes the
 //                   tanh terms; accumulates dkeys, per-sample parameter partials), cell
 //                   backward (two fused transposed GEMMs + gate derivatives).
+#include <cstdlib>
 #include "os2s_common.hpp"
 #include "rnn_tile.hpp"
 
@@ -745,6 +746,451 @@ __global__ __launch_bounds__(kAttnThreads) void ad_attn_bwd_kernel(AdAttn p) {
   // d(query input) = dq . Wq runs on the matrix cores inside the top cell's backward kernel
 }
 
+// ------------------------------------------------------------------ location-sensitive attention, split
+// The one-workgroup-per-sample kernels above spend their time in VALU work on ONE compute unit
+// (scores: 200 positions x 128 units x (32 location taps + tanh); their gradient: three times that)
+// and in memory round trips nothing overlaps (Wq: 256 KB per sample, values: 410 KB per sample, both
+// L2-cold after the cell kernels streamed 32 MB of weights). For the location-sensitive mode
+// (U == 128) a step is therefore cut over kLocParts x B workgroups by UNITS and over kLocCtxParts x B
+// by context columns / source positions:
+//   forward : ad_loc_scores_kernel   (part, b): q and the partial scores of 32 units, all positions
+//             ad_loc_context_kernel  (cols, b): sum of the partial scores, masked softmax, alignments /
+//                                               cumulative alignments, context columns
+//   backward: ad_loc_dalign_kernel   (rows, b): total context gradient, d(alignment) of a range of positions
+//             ad_loc_score_bwd_kernel(part, b): softmax backward, score gradient of 32 units
+// A unit's quantities (q, dq, dnv, dWck column, dpre column) have ONE owner; what is summed over
+// units crosses workgroups through small global buffers written by their owners and summed by the
+// next kernel in a fixed order (partial scores [B, parts, S]; partial state gradients [B, parts, S]):
+// no atomics on global memory, no spinning.
+constexpr int kLocParts = 4;        // unit parts (32 units each)
+constexpr int kLocUnits = 32;
+constexpr int kLocStreams = 16;     // position streams per workgroup: a half wave = the 32 units of a stream
+constexpr int kLocCtxParts = 8;
+
+// sum over the 32 lanes of a half wave; valid in lanes 16..31 of each half
+__device__ __forceinline__ float half_sum_dpp(float x) {
+  x += dpp_mov<0xB1, 0xf>(0.f, x);    // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E, 0xf>(0.f, x);    // quad_perm [2,3,0,1]
+  x += dpp_mov<0x124, 0xf>(0.f, x);   // row_ror:4
+  x += dpp_mov<0x128, 0xf>(0.f, x);   // row_ror:8
+  x += dpp_mov<0x142, 0xa>(0.f, x);   // row_bcast:15 into rows 1, 3
+  return x;
+}
+
+struct AdLoc {
+  float* e_part;      // [B, kLocParts, S] partial scores (forward)
+  float* dal;         // [B, S] d(alignment) incl. the carried state gradient (backward)
+  float* dcum_part;   // [B, kLocParts, S] this step's state-gradient contributions per unit part
+};
+
+__host__ __device__ inline size_t loc_fwd_lds_floats(int H, int S) {
+  return (size_t)H + 3 * kLocUnits + (S + kLocKMax) + (size_t)S * kLocUnits / 2 + 64;
+}
+
+__global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_kernel(AdAttn p, AdLoc x) {
+  extern __shared__ float lds_raw[];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.tgt_len && p.t >= p.tgt_len[b]) return;
+  const int H = p.H, U = p.U, S = p.S, K = p.loc_k;
+  float* hq = lds_raw;
+  float* q = hq + H;
+  float* nv = q + kLocUnits;
+  float* bs = nv + kLocUnits;
+  float* cum = bs + kLocUnits;                                   // [S + kLocKMax], zero padded
+  uint16_t* keys = reinterpret_cast<uint16_t*>(cum + S + kLocKMax);   // [S][32] bf16
+  const int slen = min(max(p.src_len[b], 0), S);
+  const int u0 = part * kLocUnits;
+  const long long row = (long long)b * p.T + p.t;
+  // query input, this part's key columns (64 B per position), padded cumulative alignments
+  const bf16_t* yq = p.yq + (long long)b * p.yq_bs + (long long)p.t * p.yq_ts;
+  for (int h8 = tid; h8 < H / 8; h8 += kAttnThreads) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(yq + h8 * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hq[h8 * 8 + 2 * e] = bflo(v[e]); hq[h8 * 8 + 2 * e + 1] = bfhi(v[e]); }
+  }
+  {
+    const bf16_t* kb = p.keys + (long long)b * S * U + u0;
+    for (int i = tid; i < slen * 4; i += kAttnThreads) {
+      const int sp = i >> 2, c = i & 3;
+      *reinterpret_cast<u32x4*>(keys + sp * kLocUnits + c * 8) =
+          *reinterpret_cast<const u32x4*>(kb + (long long)sp * U + c * 8);
+    }
+    const int padl = (K - 1) / 2;
+    const float* cs = p.cum_seq + ((long long)b * (p.T + 1) + p.t) * S;
+    for (int i = tid; i < S + kLocKMax; i += kAttnThreads) {
+      const int sp = i - padl;
+      cum[i] = (sp >= 0 && sp < S) ? cs[sp] : 0.f;
+    }
+  }
+  if (tid < kLocUnits) {
+    const int u = u0 + tid;
+    nv[tid] = p.v[u];
+    bs[tid] = ((p.use_bias && p.bias) ? p.bias[u] : 0.f) + p.wck[(long long)K * U + u];
+  }
+  __syncthreads();
+  // q[u] = hq . Wq[u, :] for the 32 units of the part: 4 units per wave, all loads in flight together
+  {
+    constexpr int UB = kLocUnits / kAttnWaves;
+    float acc[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) acc[i] = 0.f;
+    for (int h = lane * 8; h < H; h += 1024) {
+      u32x4 wv[UB][2];
+#pragma unroll
+      for (int i = 0; i < UB; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          wv[i][hh] = *reinterpret_cast<const u32x4*>(p.wq + (long long)(u0 + wave * UB + i) * H +
+                                                      min(h + 512 * hh, H - 8));
+#pragma unroll
+      for (int i = 0; i < UB; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          if (h + 512 * hh < H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[i] += bflo(wv[i][hh][e]) * hq[h + 512 * hh + 2 * e] + bfhi(wv[i][hh][e]) * hq[h + 512 * hh + 2 * e + 1];
+          }
+    }
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      const float sq = wave_sum_dpp(acc[i]);
+      if (lane == 0) {
+        q[wave * UB + i] = sq;
+        p.q_seq[row * U + u0 + wave * UB + i] = sq;
+      }
+    }
+  }
+  __syncthreads();
+  // partial scores: a half wave = the 32 units of one stream of positions; 32-entry register window
+  // over the padded cumulative alignments (slot (j + k) & 31 holds cum[s + k] at the j-th step of a
+  // 32-step block: one new LDS read per position)
+  const int ul = lane & 31, st = wave * 2 + (lane >> 5);
+  float wk[kLocKMax];
+#pragma unroll
+  for (int k = 0; k < kLocKMax; ++k) wk[k] = k < K ? p.wck[(long long)k * U + u0 + ul] : 0.f;
+  const int chunk = (slen + kLocStreams - 1) / kLocStreams;
+  const int c0 = st * chunk, c1 = min(c0 + chunk, slen);
+  const float qb = q[ul] + bs[ul], nv0 = nv[ul];
+  float* eo = x.e_part + ((long long)b * kLocParts + part) * S;
+  float cw[kLocKMax];
+#pragma unroll
+  for (int k = 0; k < kLocKMax; ++k) cw[k] = cum[min(c0, S) + k];
+  for (int i0 = 0; i0 < chunk; i0 += kLocKMax) {        // uniform trip count: the streams stay in step
+#pragma unroll
+    for (int j = 0; j < kLocKMax; ++j) {
+      const int sp = c0 + i0 + j;
+      if (i0 + j < chunk) {
+        float x0 = qb;
+        if (sp < c1) x0 += bf2f(keys[sp * kLocUnits + ul]);
+#pragma unroll
+        for (int k = 0; k < kLocKMax; ++k) x0 += cw[(j + k) & 31] * wk[k];
+        float pr = half_sum_dpp(nv0 * tanh_fast(x0));
+        if (ul == 31 && sp < c1) eo[sp] = pr;
+        cw[j & 31] = sp < S ? cum[sp + kLocKMax] : 0.f;
+      }
+    }
+  }
+}
+
+// sum of the partial scores -> masked softmax -> alignments (+ cumulative) -> context columns
+__global__ __launch_bounds__(256) void ad_loc_context_kernel(AdAttn p, AdLoc x, int ncg, int nsp) {
+  extern __shared__ float lds_raw[];
+  const int cpart = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  if (p.tgt_len && p.t >= p.tgt_len[b]) return;
+  const int M = p.M, S = p.S;
+  float* e = lds_raw;                  // [S]
+  float* red = e + S;                  // [8]
+  float* part = red + 8;               // [nsp][ncg * 8]
+  const int slen = min(max(p.src_len[b], 0), S);
+  const float* ep = x.e_part + (long long)b * kLocParts * S;
+  float mx = -INFINITY;
+  for (int sp = tid; sp < slen; sp += 256) {
+    float v = ep[sp];
+#pragma unroll
+    for (int q = 1; q < kLocParts; ++q) v += ep[q * S + sp];
+    e[sp] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max_dpp(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int sp = tid; sp < slen; sp += 256) {
+    const float ex = __expf(e[sp] - mx);
+    e[sp] = ex;
+    sum += ex;
+  }
+  sum = wave_sum_dpp(sum);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const float inv = slen > 0 ? 1.f / sum : 0.f;
+  const long long row = (long long)b * p.T + p.t;
+  for (int sp = tid; sp < S; sp += 256) {
+    const float a = sp < slen ? e[sp] * inv : 0.f;
+    e[sp] = a;
+    if (cpart == 0) {
+      p.align_seq[row * S + sp] = a;
+      const long long ci = ((long long)b * (p.T + 1) + p.t) * S + sp;
+      p.cum_seq[ci + S] = p.cum_seq[ci] + a;
+    }
+  }
+  __syncthreads();
+  // context columns [cpart * ncg * 8, + ncg * 8): thread = (8-column group, slice of the positions)
+  const int MQ = ncg * 8, m0 = cpart * MQ;
+  const int cg = tid % ncg, sq = tid / ncg;
+  if (sq < nsp) {
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t* vp = p.values + (long long)b * S * M + m0 + cg * 8;
+#pragma unroll 8
+    for (int sp = sq; sp < slen; sp += nsp) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(vp + (long long)sp * M);
+      const float a = e[sp];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a8[2 * k] += a * bflo(v[k]); a8[2 * k + 1] += a * bfhi(v[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[sq * MQ + cg * 8 + k] = a8[k];
+  }
+  __syncthreads();
+  if (tid < ncg) {
+    float c8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      c8[k] = 0.f;
+      for (int q = 0; q < nsp; ++q) c8[k] += part[q * MQ + tid * 8 + k];
+    }
+    const int m8 = (m0 >> 3) + tid;
+    bf16_t* ctx = p.ctx + (long long)b * p.ctx_bs + (long long)p.t * p.ctx_ts;
+    bf16_t* cat = p.cat0 + ((long long)b * (p.T + 1) + p.t + 1) * p.Kc0;
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack2bf(c8[2 * k], c8[2 * k + 1]);
+    *reinterpret_cast<u32x4*>(ctx + m8 * 8) = o;
+    if (p.attn_in_keep < 1.f) {
+      const unsigned long long idx8 = (((unsigned long long)b * (p.T + 1) + p.t + 1) * M) / 8 + m8;
+      const uint32_t bits = dropout_bits8(p.attn_in_seed, idx8, p.attn_in_keep);
+      const float ik = 1.f / p.attn_in_keep;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c8[k] = ((bits >> k) & 1u) ? c8[k] * ik : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = pack2bf(c8[2 * k], c8[2 * k + 1]);
+    }
+    *reinterpret_cast<u32x4*>(cat + m8 * 8) = o;
+  }
+}
+
+// total context gradient of the step (every workgroup of a sample computes it; part 0 stores it) and
+// d(alignment)[s] = dctx . values[b, s, :] + carried state gradient, for a range of positions. The
+// state-gradient carry dcum[b, s] is owned here: dcum += the previous backward step's per-part
+// contributions, summed in part order.
+__global__ __launch_bounds__(256) void ad_loc_dalign_kernel(AdAttn p, AdLoc x) {
+  extern __shared__ float lds_raw[];
+  const int rp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.tgt_len && p.t >= p.tgt_len[b]) return;
+  const int M = p.M, S = p.S;
+  float* dctx = lds_raw;   // [M]
+  const int slen = min(max(p.src_len[b], 0), S);
+  const long long row = (long long)b * p.T + p.t;
+  const bf16_t* ext = p.dctx_ext ? p.dctx_ext + (long long)b * p.dctx_bs + (long long)p.t * p.dctx_ts : nullptr;
+  for (int m8 = tid; m8 < M / 8; m8 += 256) {
+    float c8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ext) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(ext + m8 * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { c8[2 * e] = bflo(v[e]); c8[2 * e + 1] = bfhi(v[e]); }
+    }
+    if (!p.last) {
+      const float* da = p.dattn + (long long)b * M + m8 * 8;
+      uint32_t bits = 0xffu;
+      float ik = 1.f;
+      if (p.attn_in_keep < 1.f) {
+        const unsigned long long idx8 = (((unsigned long long)b * (p.T + 1) + p.t + 1) * M) / 8 + m8;
+        bits = dropout_bits8(p.attn_in_seed, idx8, p.attn_in_keep);
+        ik = 1.f / p.attn_in_keep;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if ((bits >> e) & 1u) c8[e] += da[e] * ik;
+    }
+    if (rp == 0) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = pack2bf(c8[2 * e], c8[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(p.dctx_seq + row * M + m8 * 8) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dctx[m8 * 8 + e] = c8[e];
+  }
+  __syncthreads();
+  const int chunk = (S + kLocCtxParts - 1) / kLocCtxParts;
+  const int c0 = rp * chunk, c1 = min(c0 + chunk, S);
+  // the state-gradient carry of this range (all S: positions past slen still receive contributions
+  // through the filter's halo, they are never read back into a live alignment)
+  float* carry = dctx + M;   // [chunk]
+  for (int sp = c0 + tid; sp < c1; sp += 256) {
+    float d = p.dcum[(long long)b * S + sp];
+    const float* dp = x.dcum_part + (long long)b * kLocParts * S + sp;
+#pragma unroll
+    for (int q = 0; q < kLocParts; ++q) d += dp[q * S];
+    p.dcum[(long long)b * S + sp] = d;
+    carry[sp - c0] = d;
+  }
+  __syncthreads();
+  const int e1 = min(c1, slen);
+#pragma unroll 4
+  for (int sp = c0 + wave; sp < e1; sp += 4) {
+    float pr = 0.f;
+    const bf16_t* vp = p.values + ((long long)b * S + sp) * M;
+    for (int m = lane * 8; m < M; m += 512) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(vp + m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pr += bflo(v[e]) * dctx[m + 2 * e] + bfhi(v[e]) * dctx[m + 2 * e + 1];
+    }
+    pr = wave_sum_dpp(pr);
+    if (lane == 0) x.dal[(long long)b * S + sp] = pr + carry[sp - c0];
+  }
+}
+
+__host__ __device__ inline size_t loc_bwd_lds_floats(int S, int K) {
+  // q, nv, bs | e, dal, de | cum (padded) | dcum_l (padded) | dwk_l | dqp, dnvp | red | keys
+  return (size_t)3 * kLocUnits + 3 * S + (S + kLocKMax) + (S + 2 * kLocKMax) + (size_t)K * kLocUnits +
+         2 * (size_t)kLocStreams * kLocUnits + 64 + (size_t)S * kLocUnits / 2;
+}
+
+__global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p, AdLoc x) {
+  extern __shared__ float lds_raw[];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.tgt_len && p.t >= p.tgt_len[b]) return;
+  const int U = p.U, S = p.S, K = p.loc_k;
+  float* q = lds_raw;
+  float* nv = q + kLocUnits;
+  float* bs = nv + kLocUnits;
+  float* e = bs + kLocUnits;                 // [S] alignments
+  float* dal = e + S;                        // [S]
+  float* de = dal + S;                       // [S]
+  float* cum = de + S;                       // [S + kLocKMax]
+  float* dcum_l = cum + S + kLocKMax;        // [S + 2 kLocKMax]: index = position + kLocKMax
+  float* dwk_l = dcum_l + S + 2 * kLocKMax;  // [K][32]
+  float* dqp = dwk_l + K * kLocUnits;        // [streams][32]
+  float* dnvp = dqp + kLocStreams * kLocUnits;
+  float* red = dnvp + kLocStreams * kLocUnits;
+  uint16_t* keys = reinterpret_cast<uint16_t*>(red + 64);
+  const int slen = min(max(p.src_len[b], 0), S);
+  const int u0 = part * kLocUnits;
+  const long long row = (long long)b * p.T + p.t;
+  {
+    const bf16_t* kb = p.keys + (long long)b * S * U + u0;
+    for (int i = tid; i < slen * 4; i += kAttnThreads) {
+      const int sp = i >> 2, c = i & 3;
+      *reinterpret_cast<u32x4*>(keys + sp * kLocUnits + c * 8) =
+          *reinterpret_cast<const u32x4*>(kb + (long long)sp * U + c * 8);
+    }
+    const int padl = (K - 1) / 2;
+    const float* cs = p.cum_seq + ((long long)b * (p.T + 1) + p.t) * S;
+    for (int i = tid; i < S + kLocKMax; i += kAttnThreads) {
+      const int sp = i - padl;
+      cum[i] = (sp >= 0 && sp < S) ? cs[sp] : 0.f;
+    }
+    for (int sp = tid; sp < S; sp += kAttnThreads) {
+      e[sp] = p.align_seq[row * S + sp];
+      dal[sp] = sp < slen ? x.dal[(long long)b * S + sp] : 0.f;
+    }
+    for (int i = tid; i < S + 2 * kLocKMax; i += kAttnThreads) dcum_l[i] = 0.f;
+    for (int i = tid; i < K * kLocUnits; i += kAttnThreads) dwk_l[i] = 0.f;
+  }
+  if (tid < kLocUnits) {
+    const int u = u0 + tid;
+    q[tid] = p.q_seq[row * U + u];
+    nv[tid] = p.v[u];
+    bs[tid] = ((p.use_bias && p.bias) ? p.bias[u] : 0.f) + p.wck[(long long)K * U + u];
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int sp = tid; sp < slen; sp += kAttnThreads) dot += e[sp] * dal[sp];
+  dot = block_sum(dot, red);
+  for (int sp = tid; sp < S; sp += kAttnThreads) de[sp] = sp < slen ? e[sp] * (dal[sp] - dot) : 0.f;
+  __syncthreads();
+  // score gradient of this part's 32 units: three 32-entry register windows slide with s (slot
+  // (j + k) & 31 at the j-th step of a block): cw = padded cumulative alignments, gw = partial state
+  // gradient sum_k' dpre[s', u] Wck[k', u] (lane-local along s; the sum over the 32 units once per
+  // emitted position), dwk = the filter-gradient column of the unit
+  const int padl = (K - 1) / 2;
+  const int ul = lane & 31, st = wave * 2 + (lane >> 5), u = u0 + ul;
+  const int chunk = (slen + kLocStreams - 1) / kLocStreams;
+  const int c0 = st * chunk, c1 = min(c0 + chunk, slen);
+  float dq0 = 0.f, dn0 = 0.f;
+  {
+    float wk[kLocKMax], dwk[kLocKMax], cw[kLocKMax], gw[kLocKMax];
+#pragma unroll
+    for (int k = 0; k < kLocKMax; ++k) {
+      dwk[k] = 0.f;
+      gw[k] = 0.f;
+      wk[k] = k < K ? p.wck[(long long)k * U + u] : 0.f;
+      cw[k] = cum[min(c0, S) + k];
+    }
+    const float nv0 = nv[ul], qb = q[ul] + bs[ul];
+    bf16_t* dps = p.dpre_seq + (row * S) * U + u;
+    // chunk + kLocKMax steps: the last kLocKMax only emit the remaining window slots. The branch
+    // around the arithmetic is WAVE-uniform (the lower stream of the wave still has a position; the
+    // upper stream runs with a zero score gradient once it is past its range): a per-lane branch here
+    // made the compiler spill the four register windows (3.7 KB of scratch per lane)
+    const int c0a = __builtin_amdgcn_readfirstlane(wave * 2 * chunk);
+    for (int i0 = 0; i0 < chunk + kLocKMax; i0 += kLocKMax) {
+#pragma unroll
+      for (int j = 0; j < kLocKMax; ++j) {
+        const int i = i0 + j, sp = c0 + i;
+        {   // (whole 32-step blocks: the steps past chunk + kLocKMax emit zero slots — a second branch
+            //  level around this body made the compiler spill the register windows: 3.6 KB of scratch)
+          if (i < chunk && c0a + i < slen) {
+            const bool on = sp < c1;
+            float x0 = (on ? bf2f(keys[sp * kLocUnits + ul]) : 0.f) + qb;
+#pragma unroll
+            for (int k = 0; k < kLocKMax; ++k) x0 += cw[(j + k) & 31] * wk[k];
+            const float t0 = tanh_fast(x0);
+            const float des = on ? de[sp] : 0.f;
+            const float d0 = des * nv0 * (1.f - t0 * t0);
+            dq0 += d0;
+            dn0 += des * t0;
+            if (on) dps[(long long)sp * U] = f2bf(d0);
+#pragma unroll
+            for (int k = 0; k < kLocKMax; ++k) {
+              dwk[k] += cw[(j + k) & 31] * d0;
+              gw[(j + k) & 31] += d0 * wk[k];
+            }
+          }
+          // slot j is complete: the state gradient at position sp - padl (of this stream's range)
+          const float gsum = half_sum_dpp(gw[j & 31]);
+          gw[j & 31] = 0.f;
+          const int s2 = sp - padl;
+          if (ul == 31 && s2 >= -kLocKMax && s2 < S + kLocKMax) atomicAdd(&dcum_l[s2 + kLocKMax], gsum);
+          cw[j & 31] = sp < S ? cum[min(sp, S) + kLocKMax] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kLocKMax; ++k)
+      if (k < K) atomicAdd(&dwk_l[k * kLocUnits + ul], dwk[k]);
+  }
+  dqp[st * kLocUnits + ul] = dq0;
+  dnvp[st * kLocUnits + ul] = dn0;
+  __syncthreads();
+  if (tid < kLocUnits) {
+    float dq = 0.f, dn = 0.f;
+#pragma unroll
+    for (int w = 0; w < kLocStreams; ++w) { dq += dqp[w * kLocUnits + tid]; dn += dnvp[w * kLocUnits + tid]; }
+    p.dq_seq[row * U + u0 + tid] = f2bf(dq);
+    p.dnv_acc[(long long)b * U + u0 + tid] += dn;
+    p.dbd_acc[(long long)b * U + u0 + tid] += dq;
+  }
+  float* dpo = x.dcum_part + ((long long)b * kLocParts + part) * S;
+  for (int sp = tid; sp < S; sp += kAttnThreads) dpo[sp] = dcum_l[sp + kLocKMax];
+  float* dwa = p.dwck_acc + (long long)b * K * U;
+  for (int i = tid; i < K * kLocUnits; i += kAttnThreads)
+    dwa[(i / kLocUnits) * U + u0 + (i % kLocUnits)] += dwk_l[i];
+}
+
 // ------------------------------------------------------------------ cell backward
 struct AdCellBwd {
   int B, T, H, t, last, KA, KB, KQ;
@@ -1036,6 +1482,18 @@ static size_t attn_lds_bytes(const os2s_attn_decoder_t* d, bool bwd) {
   return attn_lds_floats(d->H, d->M, d->U, d->S, d->score_mode, d->loc_k, bwd) * sizeof(float);
 }
 
+// the split location-attention kernels (OS2S_ATTN_SPLIT=0: the one-workgroup-per-sample kernels)
+static bool loc_split(const os2s_attn_decoder_t* d) {
+  static const int mode = [] { const char* e = getenv("OS2S_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+  return mode != 0 && d->score_mode == 2 && d->U == kLocParts * kLocUnits && d->M % 8 == 0 &&
+         loc_fwd_lds_floats(d->H, d->S) * sizeof(float) <= 64 * 1024 &&
+         loc_bwd_lds_floats(d->S, d->loc_k) * sizeof(float) <= 64 * 1024;
+}
+
+extern "C" size_t os2s_attn_decoder_loc_ws_floats(int B, int S, int U, int loc_k) {
+  return (size_t)(loc_k + 1) * U + (size_t)B * kLocParts * S;
+}
+
 static int ad_check(const os2s_attn_decoder_t* d) {
   OS2S_REQUIRE(d && d->B >= 1 && d->T >= 1 && d->S >= 1 && (d->L == 1 || d->L == 2));
   OS2S_REQUIRE(d->H % 8 == 0 && d->M % 8 == 0 && d->U % 128 == 0 && d->U <= 512);
@@ -1088,6 +1546,18 @@ extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_deco
     OS2S_LAUNCH(ad_fold_location_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, d->conv_w,
                 d->conv_b, d->dense_w, d->loc_k, d->loc_f, d->U, d->loc_ws);
   }
+  // location-sensitive attention: the step is cut over kLocParts x B / ctx_parts x B workgroups
+  const bool split = loc_split(d);
+  AdLoc lx;
+  lx.e_part = split ? d->loc_ws + (size_t)(d->loc_k + 1) * d->U : nullptr;
+  lx.dal = nullptr; lx.dcum_part = nullptr;
+  int ctx_parts = kLocCtxParts;
+  while (ctx_parts > 1 && M % (8 * ctx_parts)) ctx_parts >>= 1;
+  const int ncg = M / (8 * ctx_parts);
+  const int nsp = 256 / ncg < 32 ? 256 / ncg : 32;
+  const size_t lds_s = loc_fwd_lds_floats(H, d->S) * sizeof(float);
+  const size_t lds_c = ((size_t)d->S + 8 + (size_t)nsp * ncg * 8) * sizeof(float);
+  if (split && ncg > 256) return OS2S_ERR_UNSUPPORTED;
   dim3 cgrid(ceil_div(H, 8), ceil_div(B, 32));
   for (int t = d->t_begin; t < d->t_end; ++t) {
     for (int l = 0; l < L; ++l) {
@@ -1106,7 +1576,12 @@ extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_deco
       OS2S_LAUNCH(ad_cell_fwd_kernel, cgrid, dim3(64 * kAdWaves), 0, stream, c);
     }
     at.t = t;
-    OS2S_LAUNCH(ad_attn_fwd_kernel, dim3(B), dim3(kAttnThreads), lds, stream, at);
+    if (split) {
+      OS2S_LAUNCH(ad_loc_scores_kernel, dim3(kLocParts, B), dim3(kAttnThreads), lds_s, stream, at, lx);
+      OS2S_LAUNCH(ad_loc_context_kernel, dim3(ctx_parts, B), dim3(256), lds_c, stream, at, lx, ncg, nsp);
+    } else {
+      OS2S_LAUNCH(ad_attn_fwd_kernel, dim3(B), dim3(kAttnThreads), lds, stream, at);
+    }
   }
   return OS2S_OK;
 }
@@ -1116,6 +1591,7 @@ extern "C" size_t os2s_attn_decoder_bwd_workspace_bytes(const os2s_attn_decoder_
   const size_t B = d->B;
   size_t n = B * d->M + B * d->H + 2 * B * d->H + B * d->S + B * d->U;
   if (d->score_mode == 2) n += B * d->U + B * d->loc_k * d->U + (size_t)(d->loc_k + 1) * d->U;
+  if (d->score_mode == 2) n += B * d->S + B * kLocParts * d->S;     // split kernels: dal, dcum_part
   return n * sizeof(float) + 1024;
 }
 
@@ -1152,6 +1628,15 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
     dwck_acc = ws; ws += (size_t)B * K * U;
     unfold_tmp = ws; ws += (size_t)(K + 1) * U;
   }
+  const bool split = loc_split(d);
+  AdLoc lx;
+  lx.e_part = nullptr; lx.dal = nullptr; lx.dcum_part = nullptr;
+  if (d->score_mode == 2) {
+    lx.dal = ws; ws += (size_t)B * S;
+    lx.dcum_part = ws; ws += (size_t)B * kLocParts * S;
+  }
+  const size_t lds_da = ((size_t)M + ceil_div(S, kLocCtxParts)) * sizeof(float);
+  const size_t lds_sb = loc_bwd_lds_floats(S, K) * sizeof(float);
   // gate gradients of finished steps are zero; dkeys accumulates
   for (int l = 0; l < L; ++l)
     if (hipMemsetAsync(gr->dg[l], 0, (size_t)B * T * 4 * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
@@ -1175,7 +1660,10 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
       OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 8), ceil_div(B, 32)), dim3(64 * kBwdWaves), 0, stream, g);
     }
     at.t = t; at.last = last;
-    if (d->score_mode == 2) { OS2S_LAUNCH(ad_attn_bwd_kernel<true>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
+    if (split) {
+      OS2S_LAUNCH(ad_loc_dalign_kernel, dim3(kLocCtxParts, B), dim3(256), lds_da, stream, at, lx);
+      OS2S_LAUNCH(ad_loc_score_bwd_kernel, dim3(kLocParts, B), dim3(kAttnThreads), lds_sb, stream, at, lx);
+    } else if (d->score_mode == 2) { OS2S_LAUNCH(ad_attn_bwd_kernel<true>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
     else { OS2S_LAUNCH(ad_attn_bwd_kernel<false>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
     for (int l = L - 1; l >= 0; --l) {
       AdCellBwd c;
