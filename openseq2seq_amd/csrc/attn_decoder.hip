@@ -155,7 +155,7 @@ constexpr int kAttnWaves = kAttnThreads / 64;
 // workgroup 0, read by os2s_debug_attn_phases / tools/bench_attn_decoder.py
 #ifdef OS2S_ATTN_PHASE_TIMERS
 __device__ long long g_attn_dbg[2][16];
-#define AD_TICK(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_attn_dbg[k][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define AD_TICK(k, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_attn_dbg[k][i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define AD_TICK(k, i) do { } while (0)
 #endif
@@ -1054,9 +1054,9 @@ __global__ __launch_bounds__(256) void ad_loc_dalign_kernel(AdAttn p, AdLoc x) {
 }
 
 __host__ __device__ inline size_t loc_bwd_lds_floats(int S, int K) {
-  // q, nv, bs | e, dal, de | cum (padded) | dcum_l (padded) | dwk_l | dqp, dnvp | red | keys
-  return (size_t)3 * kLocUnits + 3 * S + (S + kLocKMax) + (S + 2 * kLocKMax) + (size_t)K * kLocUnits +
-         2 * (size_t)kLocStreams * kLocUnits + 64 + (size_t)S * kLocUnits / 2;
+  // q, nv, bs | e, dal, de | cum (padded) | dcum_l (padded) | dwk_l per stream | dqp, dnvp | red | keys
+  return (size_t)3 * kLocUnits + 3 * S + (S + kLocKMax) + (S + 2 * kLocKMax) +
+         (size_t)kLocStreams * K * kLocUnits + 2 * (size_t)kLocStreams * kLocUnits + 64 + (size_t)S * kLocUnits / 2;
 }
 
 __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p, AdLoc x) {
@@ -1072,14 +1072,15 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
   float* de = dal + S;                       // [S]
   float* cum = de + S;                       // [S + kLocKMax]
   float* dcum_l = cum + S + kLocKMax;        // [S + 2 kLocKMax]: index = position + kLocKMax
-  float* dwk_l = dcum_l + S + 2 * kLocKMax;  // [K][32]
-  float* dqp = dwk_l + K * kLocUnits;        // [streams][32]
+  float* dwk_l = dcum_l + S + 2 * kLocKMax;  // [streams][K][32]: every stream's filter-gradient columns
+  float* dqp = dwk_l + kLocStreams * K * kLocUnits;   // [streams][32]
   float* dnvp = dqp + kLocStreams * kLocUnits;
   float* red = dnvp + kLocStreams * kLocUnits;
   uint16_t* keys = reinterpret_cast<uint16_t*>(red + 64);
   const int slen = min(max(p.src_len[b], 0), S);
   const int u0 = part * kLocUnits;
   const long long row = (long long)b * p.T + p.t;
+  AD_TICK(1, 0);
   {
     const bf16_t* kb = p.keys + (long long)b * S * U + u0;
     for (int i = tid; i < slen * 4; i += kAttnThreads) {
@@ -1098,7 +1099,6 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
       dal[sp] = sp < slen ? x.dal[(long long)b * S + sp] : 0.f;
     }
     for (int i = tid; i < S + 2 * kLocKMax; i += kAttnThreads) dcum_l[i] = 0.f;
-    for (int i = tid; i < K * kLocUnits; i += kAttnThreads) dwk_l[i] = 0.f;
   }
   if (tid < kLocUnits) {
     const int u = u0 + tid;
@@ -1107,11 +1107,13 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
     bs[tid] = ((p.use_bias && p.bias) ? p.bias[u] : 0.f) + p.wck[(long long)K * U + u];
   }
   __syncthreads();
+  AD_TICK(1, 1);
   float dot = 0.f;
   for (int sp = tid; sp < slen; sp += kAttnThreads) dot += e[sp] * dal[sp];
   dot = block_sum(dot, red);
   for (int sp = tid; sp < S; sp += kAttnThreads) de[sp] = sp < slen ? e[sp] * (dal[sp] - dot) : 0.f;
   __syncthreads();
+  AD_TICK(1, 2);
   // score gradient of this part's 32 units: three 32-entry register windows slide with s (slot
   // (j + k) & 31 at the j-th step of a block): cw = padded cumulative alignments, gw = partial state
   // gradient sum_k' dpre[s', u] Wck[k', u] (lane-local along s; the sum over the 32 units once per
@@ -1171,11 +1173,13 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
     }
 #pragma unroll
     for (int k = 0; k < kLocKMax; ++k)
-      if (k < K) atomicAdd(&dwk_l[k * kLocUnits + ul], dwk[k]);
+      if (k < K) dwk_l[(st * K + k) * kLocUnits + ul] = dwk[k];     // summed over the streams below, in order
   }
+  AD_TICK(1, 3);
   dqp[st * kLocUnits + ul] = dq0;
   dnvp[st * kLocUnits + ul] = dn0;
   __syncthreads();
+  AD_TICK(1, 4);
   if (tid < kLocUnits) {
     float dq = 0.f, dn = 0.f;
 #pragma unroll
@@ -1187,8 +1191,14 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
   float* dpo = x.dcum_part + ((long long)b * kLocParts + part) * S;
   for (int sp = tid; sp < S; sp += kAttnThreads) dpo[sp] = dcum_l[sp + kLocKMax];
   float* dwa = p.dwck_acc + (long long)b * K * U;
-  for (int i = tid; i < K * kLocUnits; i += kAttnThreads)
-    dwa[(i / kLocUnits) * U + u0 + (i % kLocUnits)] += dwk_l[i];
+  for (int i = tid; i < K * kLocUnits; i += kAttnThreads) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < kLocStreams; ++w) a += dwk_l[w * K * kLocUnits + i];
+    dwa[(i / kLocUnits) * U + u0 + (i % kLocUnits)] += a;
+  }
+  AD_TICK(1, 5);
+  AD_TICK(1, 6);
 }
 
 // ------------------------------------------------------------------ cell backward
@@ -1487,7 +1497,7 @@ static bool loc_split(const os2s_attn_decoder_t* d) {
   static const int mode = [] { const char* e = getenv("OS2S_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
   return mode != 0 && d->score_mode == 2 && d->U == kLocParts * kLocUnits && d->M % 8 == 0 &&
          loc_fwd_lds_floats(d->H, d->S) * sizeof(float) <= 64 * 1024 &&
-         loc_bwd_lds_floats(d->S, d->loc_k) * sizeof(float) <= 64 * 1024;
+         loc_bwd_lds_floats(d->S, d->loc_k) * sizeof(float) <= 160 * 1024;
 }
 
 extern "C" size_t os2s_attn_decoder_loc_ws_floats(int B, int S, int U, int loc_k) {
@@ -1637,6 +1647,9 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
   }
   const size_t lds_da = ((size_t)M + ceil_div(S, kLocCtxParts)) * sizeof(float);
   const size_t lds_sb = loc_bwd_lds_floats(S, K) * sizeof(float);
+  if (split && lds_sb > 64 * 1024 &&
+      hipFuncSetAttribute((const void*)ad_loc_score_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sb) != hipSuccess)
+    return OS2S_ERR_LAUNCH;
   // gate gradients of finished steps are zero; dkeys accumulates
   for (int l = 0; l < L; ++l)
     if (hipMemsetAsync(gr->dg[l], 0, (size_t)B * T * 4 * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
