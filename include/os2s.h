@@ -647,6 +647,14 @@ int os2s_decode_cross_attention(os2s_stream_t stream, const uint16_t* q, long lo
  * sums with the GEMM/wgrad entry points.
  * ---------------------------------------------------------------------- */
 size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
+/* cuDNN-form GRU layers with B <= 32, H <= 1024 run their whole forward recurrence in ONE persistent
+ * launch (csrc/rnn_xcd.hip: a direction per XCD, weights stationary in registers, the hidden state
+ * exchanged through that XCD's L2) instead of one launch per time step; os2s_rnn_fwd_workspace_bytes
+ * includes its exchange buffers. os2s_gru_xcd_set_mode: 0 = per-step launches, 1 = persistent kernel,
+ * -1 = environment OS2S_GRU_XCD (default on). A launch that gives up (unexpected workgroup placement,
+ * a wait that times out) makes a LATER os2s_rnn_layer_fwd_multi call return OS2S_ERR_LAUNCH. */
+void os2s_gru_xcd_set_mode(int mode);
+size_t os2s_gru_xcd_workspace_bytes(int B, int H);
 int os2s_rnn_layer_fwd(os2s_stream_t stream, int cell, const uint16_t* gx, const uint16_t* wh,
                        const float* bh, const int32_t* lens, int B, int T, int H, int reverse,
                        float forget_bias, uint16_t* y, long long ldy, uint16_t* gates,

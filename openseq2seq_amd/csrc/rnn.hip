@@ -307,9 +307,17 @@ using namespace os2s;
 
 static int rnn_gates(int cell) { return cell == kGruCudnn ? 3 : 4; }
 
-// workspace per direction: h16[2][B,H] bf16 + h32[B,H] + c32[B,H] fp32
+// rnn_xcd.hip: the persistent, XCD-local forward pass of a cuDNN-form GRU layer
+extern "C" size_t os2s_gru_xcd_workspace_bytes(int B, int H);
+bool gru_xcd_supported(int B, int T, int H, int ndir);
+int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* dirs, float* const* h32,
+                       void* const* xws, int* flags, const int32_t* lens, int B, int T, int H);
+
+// workspace per direction: h16[2][B,H] bf16 + h32[B,H] + c32[B,H] fp32 (+ the exchange buffer and the
+// flags of the persistent GRU kernel)
+static size_t rnn_fwd_state_bytes(int B, int H) { return (size_t)B * H * (2 * 2 + 4 + 4) + 256; }
 extern "C" size_t os2s_rnn_fwd_workspace_bytes(int B, int H) {
-  return (size_t)B * H * (2 * 2 + 4 + 4) + 256;
+  return rnn_fwd_state_bytes(B, H) + os2s_gru_xcd_workspace_bytes(B, H) + 256;
 }
 
 extern "C" int os2s_rnn_layer_fwd_multi(os2s_stream_t stream_, int cell, int ndir,
@@ -342,6 +350,18 @@ extern "C" int os2s_rnn_layer_fwd_multi(os2s_stream_t stream_, int cell, int ndi
       if (hipMemset2DAsync(s.y, (size_t)s.ldy * 2, 0, (size_t)H * 2, (size_t)B * T, stream) != hipSuccess)
         return OS2S_ERR_LAUNCH;
     }
+  }
+  if (cell == kGruCudnn && gru_xcd_supported(B, T, H, ndir)) {
+    // ONE launch for all T steps: weights stationary in registers, hidden state exchanged through the
+    // L2 of the XCD a direction lives on (rnn_xcd.hip)
+    float* h32p[2];
+    void* xws[2];
+    for (int d = 0; d < ndir; ++d) {
+      h32p[d] = a.d[d].h32;
+      xws[d] = (char*)workspace + per_dir * d + rnn_fwd_state_bytes(B, H);
+    }
+    int* flags = (int*)((char*)workspace + per_dir * 0 + rnn_fwd_state_bytes(B, H) + os2s_gru_xcd_workspace_bytes(B, H));
+    return launch_gru_xcd_fwd(stream, ndir, dirs, h32p, xws, flags, lens, B, T, H);
   }
   if (ndir == 1) a.d[1] = a.d[0];
   dim3 grid(ceil_div(H, 8), ceil_div(B, 32), ndir);
