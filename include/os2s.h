@@ -655,6 +655,7 @@ size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
  * a wait that times out) makes a LATER os2s_rnn_layer_fwd_multi call return OS2S_ERR_LAUNCH. */
 void os2s_gru_xcd_set_mode(int mode);
 size_t os2s_gru_xcd_workspace_bytes(int B, int H);
+size_t os2s_gru_xcd_bwd_workspace_bytes(int B, int H);   /* backward-through-time twin (B <= 16) */
 int os2s_rnn_layer_fwd(os2s_stream_t stream, int cell, const uint16_t* gx, const uint16_t* wh,
                        const float* bh, const int32_t* lens, int B, int T, int H, int reverse,
                        float forget_bias, uint16_t* y, long long ldy, uint16_t* gates,

@@ -312,6 +312,10 @@ extern "C" size_t os2s_gru_xcd_workspace_bytes(int B, int H);
 bool gru_xcd_supported(int B, int T, int H, int ndir);
 int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* dirs, float* const* h32,
                        void* const* xws, int* flags, const int32_t* lens, int B, int T, int H);
+extern "C" size_t os2s_gru_xcd_bwd_workspace_bytes(int B, int H);
+bool gru_xcd_bwd_supported(int B, int T, int H, int ndir);
+int launch_gru_xcd_bwd(hipStream_t stream, int ndir, const os2s_rnn_dir_bwd_t* dirs, void* const* xws, int* flags,
+                       const int32_t* lens, int B, int T, int H);
 
 // workspace per direction: h16[2][B,H] bf16 + h32[B,H] + c32[B,H] fp32 (+ the exchange buffer and the
 // flags of the persistent GRU kernel)
@@ -389,9 +393,11 @@ extern "C" int os2s_rnn_layer_fwd(os2s_stream_t stream_, int cell, const uint16_
                                   workspace_bytes);
 }
 
-// workspace per direction: dg[2][B,G*H] bf16 + dh_carry[B,H] + dc_carry[B,H] fp32
+// workspace per direction: dg[2][B,G*H] bf16 + dh_carry[B,H] + dc_carry[B,H] fp32 (+ the exchange
+// buffer and the flags of the persistent GRU kernel)
+static size_t rnn_bwd_state_bytes(int B, int H) { return (size_t)B * H * (2 * 4 * 2 + 4 + 4) + 256; }
 extern "C" size_t os2s_rnn_bwd_workspace_bytes(int B, int H) {
-  return (size_t)B * H * (2 * 4 * 2 + 4 + 4) + 256;
+  return rnn_bwd_state_bytes(B, H) + os2s_gru_xcd_bwd_workspace_bytes(B, H) + 256;
 }
 
 extern "C" int os2s_rnn_layer_bwd_multi(os2s_stream_t stream_, int cell, int ndir,
@@ -426,6 +432,12 @@ extern "C" int os2s_rnn_layer_bwd_multi(os2s_stream_t stream_, int cell, int ndi
     if (hipMemsetAsync(s.dgx, 0, (size_t)B * T * G * H * 2, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
     if (s.dgr && hipMemsetAsync(s.dgr, 0, (size_t)B * T * G * H * 2, stream) != hipSuccess)
       return OS2S_ERR_LAUNCH;
+  }
+  if (cell == kGruCudnn && gru_xcd_bwd_supported(B, T, H, ndir)) {
+    void* xws[2];
+    for (int d = 0; d < ndir; ++d) xws[d] = (char*)workspace + per_dir * d + rnn_bwd_state_bytes(B, H);
+    int* flags = (int*)((char*)workspace + rnn_bwd_state_bytes(B, H) + os2s_gru_xcd_bwd_workspace_bytes(B, H));
+    return launch_gru_xcd_bwd(stream, ndir, dirs, xws, flags, lens, B, T, H);
   }
   if (ndir == 1) a.d[1] = a.d[0];
   const bool rows8 = ceil_div(H, 32) * ceil_div(B, 32) * ndir < 128;

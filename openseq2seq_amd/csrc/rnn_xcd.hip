@@ -6,8 +6,8 @@
 // ramp of a 100-workgroup grid — 7.2 us per step, 4 000 steps per train step. Here ONE launch runs
 // all T steps of both directions:
 //
-//   * a direction lives on ONE XCD: its 32 compute units are 32 workgroups (blockIdx b runs on XCD
-//     b % 8 — observed placement, checked against HW_REG_XCC_ID; a mismatch aborts the launch), so the
+//   * a direction lives on ONE XCD: its 32 compute units are 32 workgroups (256 workgroups of one per CU;
+//     a workgroup reads HW_REG_XCC_ID and takes the next free slot of that XCD's direction), so the
 //     per-step exchange of the hidden state goes through that XCD's own L2 — plain 8-byte stores,
 //     L1-bypassing loads, no agent-scope fence, nothing crosses the fabric;
 //   * weights are STATIONARY IN REGISTERS: a workgroup owns H/32 hidden units = 3H/32 rows of R
@@ -66,13 +66,21 @@ __device__ __forceinline__ float tanh_fast_(float x) { return 1.f - 2.f / (1.f +
 template <int NB, int RT>
 __global__ __launch_bounds__(kXcdThreads) void gru_xcd_fwd_kernel(GruXcdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bid = blockIdx.x, dir = bid & 7, cu = bid >> 3;
-  if (dir >= a.ndir) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // role = (XCD this workgroup runs on, arrival order on that XCD): 256 workgroups of one per CU put 32
+  // on every XCD whatever the dispatch order (blockIdx b mostly lands on XCD b % 8, not always)
+  int dir, cu;
   {
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    if ((xcc & 7) != dir) {              // the placement this kernel is built on does not hold
+    dir = xcc & 7;
+    if (dir >= a.ndir) return;
+    int* const slot = reinterpret_cast<int*>(smem);
+    if (tid == 0) *slot = __hip_atomic_fetch_add(a.flags + 8 + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    cu = *slot;
+    __syncthreads();
+    if (cu >= kXcdCus) {                 // more than one workgroup per CU: not the residency this is built on
       if (tid == 0) __hip_atomic_store(a.flags, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
@@ -305,9 +313,225 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_fwd_kernel(GruXcdArgs a) 
   }
 #ifdef OS2S_GRU_XCD_TIMERS
   XCD_TICK(4);
-  if (bid == 8 * 5 && tid == 0)       // workgroup 5 of direction 0: cycles per step of each phase
+  if (dir == 0 && cu == 5 && tid == 0)   // workgroup 5 of direction 0: cycles per step of each phase
     for (int i = 0; i < 5; ++i) a.flags[2 + i] = (int)(tph[i] / T);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward through time, same scheme. A workgroup owns upc hidden units j: the rows j of Wh^T
+// [H, 3H] stay in registers (2 row tiles x ceil(3H/32)/8 k-steps per wave), the recurrent-side gate
+// gradients of the later step dg_{s+1} [B, 3H] are gathered from the exchange buffer into LDS,
+// dh_s = dy + dg_{s+1} . Wh + carry, then the gate derivatives of its (unit, sample) pairs
+// (rnn.hip:rnn_step_bwd_kernel, cuDNN GRU) and the publication of its 3 * upc rows of dg_s.
+// B <= 16 (the [16][3H] image of dg is 77 KB of LDS at H = 800).
+// ---------------------------------------------------------------------------------------------
+constexpr int kXcdKSB = 12;          // k-steps of 32 per wave: 8 x 12 x 32 = 3072 >= 3H
+
+struct GruXcdDirB {
+  const bf16_t* whT;       // [H, 3H]
+  const bf16_t* dy; long long lddy;
+  const bf16_t* y; long long ldy;     // forward outputs (h_{t-1})
+  const bf16_t* gates;     // [B, T, 4H] saved r, z, n, (R_n h + b_Rn)
+  bf16_t* dgx;             // [B, T, 3H]
+  bf16_t* dgr;             // [B, T, 3H] or null
+  unsigned long long* xbuf;
+  int reverse;
+};
+struct GruXcdArgsB {
+  int B, T, H, ndir;
+  const int32_t* lens;
+  int* flags;
+  GruXcdDirB d[2];
+};
+
+__global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // role = (XCD this workgroup runs on, arrival order on that XCD): 256 workgroups of one per CU put 32
+  // on every XCD whatever the dispatch order (blockIdx b mostly lands on XCD b % 8, not always)
+  int dir, cu;
+  {
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dir = xcc & 7;
+    if (dir >= a.ndir) return;
+    int* const slot = reinterpret_cast<int*>(smem);
+    if (tid == 0) *slot = __hip_atomic_fetch_add(a.flags + 8 + dir, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    cu = *slot;
+    __syncthreads();
+    if (cu >= kXcdCus) {                 // more than one workgroup per CU: not the residency this is built on
+      if (tid == 0) __hip_atomic_store(a.flags, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  const GruXcdDirB& p = a.d[dir];
+  const int B = a.B, T = a.T, H = a.H, GH = 3 * H;
+  constexpr int BP = 16;
+  const int upc = (H + kXcdCus - 1) / kXcdCus;
+  const int u0 = cu * upc;
+  const int nu = max(0, min(upc, H - u0));
+  const int NK = (GH + 31) / 32;                    // k-steps of the 3H-deep reduction
+  const int DS = NK * 32 * 2 + 16;                  // LDS row stride of dg (bytes)
+  const int nval = 3 * upc * BP;                    // values a workgroup publishes per step
+  const int gpc = (nval + 6) / 7;
+  const int ngran = kXcdCus * gpc;
+  const unsigned gpc_inv = (unsigned)((0x100000000ull + gpc - 1) / gpc);
+  constexpr int PR = 32 + 4;                        // pitch of the partial-sum image (2 row tiles)
+  // LDS: dg [BP][DS] | partial sums [8 waves][BP][PR] f32 | carry [upc][BP] f32 | pub [gpc * 7 + 1] bf16
+  char* const dg_l = smem;
+  float* const part = reinterpret_cast<float*>(smem + BP * DS);
+  float* const carry = part + 8 * BP * PR;
+  bf16_t* const pub = reinterpret_cast<bf16_t*>(carry + upc * BP);
+
+  bf16x8 af[kXcdKSB][2];
+  {
+    const int rrow = lane & 15, kq = (lane >> 4) * 8;
+#pragma unroll
+    for (int ks = 0; ks < kXcdKSB; ++ks) {
+      const int k = (wave + 8 * ks) * 32 + kq;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int u = rt * 16 + rrow;
+        bf16x8 v = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+        if (u < nu && k < GH) v = *reinterpret_cast<const bf16x8*>(p.whT + (long long)(u0 + u) * GH + k);
+        af[ks][rt] = v;
+      }
+    }
+  }
+  // this thread's (unit, sample) pair (upc * BP <= 512: one pair per thread)
+  const int pb = tid / upc, pu = tid - pb * upc;
+  const bool mine = tid < upc * BP && pu < nu && pb < B;
+  const int len = mine ? (a.lens ? min(max(a.lens[pb], 0), T) : T) : -1;
+  for (int i = tid; i < upc * BP; i += kXcdThreads) carry[i] = 0.f;
+  for (int i = tid; i < gpc * 7 + 1; i += kXcdThreads) pub[i] = 0;
+  for (int i = tid; i < BP * DS / 4; i += kXcdThreads) reinterpret_cast<uint32_t*>(dg_l)[i] = 0u;
+  __syncthreads();
+
+  int failed = 0;
+  for (int it = 0; it < T; ++it) {
+    const int s = T - 1 - it;
+    // ---- (0) operands of this thread's pair at loop step s ----------------------------------------
+    int t = -1;
+    float dyv = 0.f, sv0 = 0.f, sv1 = 0.f, sv2 = 0.f, sv3 = 0.f, hprev = 0.f;
+    if (s < len) {
+      t = p.reverse ? len - 1 - s : s;
+      const long long row = (long long)pb * T + t;
+      const int j = u0 + pu;
+      dyv = bf2f(p.dy[row * p.lddy + j]);
+      const bf16_t* gp = p.gates + row * (4 * H) + j;
+      sv0 = bf2f(gp[0]); sv1 = bf2f(gp[H]); sv2 = bf2f(gp[2 * H]); sv3 = bf2f(gp[3 * H]);
+      if (s > 0) hprev = bf2f(p.y[((long long)pb * T + (p.reverse ? t + 1 : t - 1)) * p.ldy + j]);
+    }
+    // ---- (1) gather dg_{s+1}: granule = {16-bit tag, 7 bf16}, values v = sample + BP * (gate * upc + unit)
+    if (it > 0) {
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.xbuf + (size_t)((it - 1) & 1) * ngran * 2), 0, ngran * 16, 0x00020000);
+      const unsigned want = (unsigned)it & 0xffffu;
+      int polls = 0;
+#pragma unroll 1
+      for (int g0 = 0; g0 < ngran; g0 += kXcdGC * kXcdThreads) {
+        unsigned pending = 0;
+#pragma unroll
+        for (int i = 0; i < kXcdGC; ++i)
+          if (g0 + tid + i * kXcdThreads < ngran) pending |= 1u << i;
+        while (pending && !failed) {
+          u32x4 g[kXcdGC];
+#pragma unroll
+          for (int i = 0; i < kXcdGC; ++i)
+            if (pending & (1u << i))
+              g[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (g0 + tid + i * kXcdThreads) * 16, 0, 16);
+#pragma unroll
+          for (int i = 0; i < kXcdGC; ++i)
+            if ((pending & (1u << i)) && (g[i][0] & 0xffffu) == want) {
+              const int gi = g0 + tid + i * kXcdThreads;
+              const int c = (int)__umulhi((unsigned)gi, gpc_inv);
+              const int j0 = (gi - c * gpc) * 7;
+#pragma unroll
+              for (int v = 0; v < 7; ++v) {
+                const int j = j0 + v, r = j / BP;            // r = gate * upc + unit
+                const int gg = r >= 2 * upc ? 2 : (r >= upc ? 1 : 0);
+                const unsigned w16 = (g[i][(v + 1) >> 1] >> (16 * ((v + 1) & 1))) & 0xffffu;
+                const int k = gg * H + c * upc + (r - gg * upc);
+                if (j < nval && c * upc + (r - gg * upc) < H)
+                  *reinterpret_cast<bf16_t*>(dg_l + (j & (BP - 1)) * DS + k * 2) = (bf16_t)w16;
+              }
+              pending &= ~(1u << i);
+            }
+          if (pending) {
+            if (++polls > (1 << 17) ||
+                ((polls & 63) == 0 && __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+              failed = 1;
+            else
+              __builtin_amdgcn_s_sleep(1);
+          }
+        }
+      }
+    }
+    if (__syncthreads_or(failed)) {
+      if (tid == 0) __hip_atomic_store(a.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // ---- (2) dg_{s+1} . Wh for this workgroup's units -----------------------------------------------
+    if (it > 0) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const int col = lane & 15, kq = (lane >> 4) * 8;
+#pragma unroll
+      for (int ks = 0; ks < kXcdKSB; ++ks) {
+        const int kstep = wave + 8 * ks;
+        if (kstep < NK) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(dg_l + col * DS + (kstep * 32 + kq) * 2);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bfr, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bfr, acc[1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        *reinterpret_cast<f32x4*>(part + ((size_t)wave * BP + col) * PR + rt * 16 + 4 * (lane >> 4)) = acc[rt];
+    }
+    __syncthreads();
+    // ---- (3) gate derivatives of this thread's pair (rnn.hip: cuDNN GRU) ------------------------------
+    if (tid < upc * BP) {
+      float dr_ = 0.f, dz_ = 0.f, dn_ = 0.f, drn_ = 0.f;
+      if (t >= 0) {
+        float dh = dyv + carry[pb + BP * pu];
+        if (it > 0) {
+#pragma unroll
+          for (int w = 0; w < 8; ++w) dh += part[((size_t)w * BP + pb) * PR + pu];
+        }
+        const float rg = sv0, zg = sv1, ng = sv2, hn = sv3;
+        const float dn = dh * (1.f - zg);
+        const float dz = dh * (hprev - ng);
+        const float dnpre = dn * (1.f - ng * ng);
+        dr_ = dnpre * hn * rg * (1.f - rg);
+        dz_ = dz * zg * (1.f - zg);
+        dn_ = dnpre;
+        drn_ = dnpre * rg;
+        carry[pb + BP * pu] = dh * zg;
+        const long long o = ((long long)pb * T + t) * GH + u0 + pu;
+        p.dgx[o] = f2bf(dr_); p.dgx[o + H] = f2bf(dz_); p.dgx[o + 2 * H] = f2bf(dn_);
+        if (p.dgr) { p.dgr[o] = f2bf(dr_); p.dgr[o + H] = f2bf(dz_); p.dgr[o + 2 * H] = f2bf(drn_); }
+      }
+      // recurrent-side gradients for the next (earlier) step: zeros for a sample past its length
+      pub[pb + BP * pu] = f2bf(dr_);
+      pub[pb + BP * (upc + pu)] = f2bf(dz_);
+      pub[pb + BP * (2 * upc + pu)] = f2bf(drn_);
+    }
+    __syncthreads();
+    // ---- (4) publish ---------------------------------------------------------------------------------
+    if (it + 1 < T) {
+      char* xo = reinterpret_cast<char*>(p.xbuf) + ((size_t)(it & 1) * ngran + (size_t)cu * gpc) * 16;
+      for (int e = tid; e < gpc; e += kXcdThreads) {
+        const bf16_t* hp = pub + e * 7;
+        u32x4 g;
+        g[0] = ((unsigned)(it + 1) & 0xffffu) | ((unsigned)hp[0] << 16);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) g[1 + v] = (unsigned)hp[1 + 2 * v] | ((unsigned)hp[2 + 2 * v] << 16);
+        st_plain_b128(xo + (size_t)e * 16, g);
+      }
+    }
+  }
 }
 
 }  // namespace os2s
@@ -360,6 +584,9 @@ int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* d
     *host_flag = 0;
   }
   if (*host_flag != 0) {   // an EARLIER launch gave up (placement mismatch / timeout): its results are invalid
+    fprintf(stderr, "os2s: a persistent GRU launch gave up (%s); its outputs are invalid. "
+                    "OS2S_GRU_XCD=0 selects the launch-per-step path\n",
+            *host_flag == 2 ? "workgroups were not placed on the expected XCDs" : "a wait timed out");
     *host_flag = 0;
     return OS2S_ERR_LAUNCH;
   }
@@ -400,5 +627,49 @@ int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* d
             hf[2], hf[3], hf[4], hf[5], hf[6]);
   }
 #endif
+  return OS2S_OK;
+}
+
+
+extern "C" size_t os2s_gru_xcd_bwd_workspace_bytes(int B, int H) {
+  const int upc = (H + 31) / 32, gpc = (3 * upc * 16 + 6) / 7;
+  (void)B;
+  return (size_t)2 * 32 * gpc * 16 + 256;
+}
+
+static size_t gru_xcd_bwd_lds_bytes(int H) {
+  const int upc = (H + kXcdCus - 1) / kXcdCus, NK = (3 * H + 31) / 32, gpc = (3 * upc * 16 + 6) / 7;
+  return (size_t)16 * (NK * 64 + 16) + (size_t)8 * 16 * 36 * 4 + (size_t)upc * 16 * 4 + (size_t)(gpc * 7 + 1) * 2 + 64;
+}
+
+bool gru_xcd_bwd_supported(int B, int T, int H, int ndir) {
+  // default OFF: at the DeepSpeech2 size the gather of dg [B, 3H] (88 KB per workgroup and step) makes
+  // the persistent backward step slower than the launch per step (10.96 vs 9.06 us); OS2S_GRU_XCD_BWD=1
+  static const int on = [] { const char* e = getenv("OS2S_GRU_XCD_BWD"); return e ? atoi(e) : 0; }();
+  if (!on) return false;
+  if (!gru_xcd_supported(B, T, H, ndir) || B > 16) return false;
+  const int upc = (H + kXcdCus - 1) / kXcdCus;
+  if (upc > 32 || upc * 16 > kXcdThreads || (3 * H + 31) / 32 > 8 * kXcdKSB) return false;
+  return gru_xcd_bwd_lds_bytes(H) <= 160 * 1024;
+}
+
+int launch_gru_xcd_bwd(hipStream_t stream, int ndir, const os2s_rnn_dir_bwd_t* dirs, void* const* xws, int* flags,
+                       const int32_t* lens, int B, int T, int H) {
+  GruXcdArgsB a;
+  a.B = B; a.T = T; a.H = H; a.ndir = ndir; a.lens = lens; a.flags = flags;
+  for (int d = 0; d < ndir; ++d) {
+    const os2s_rnn_dir_bwd_t& s = dirs[d];
+    GruXcdDirB& k = a.d[d];
+    k.whT = (const bf16_t*)s.whT; k.dy = (const bf16_t*)s.dy; k.lddy = s.lddy; k.y = (const bf16_t*)s.y; k.ldy = s.ldy;
+    k.gates = (const bf16_t*)s.gates; k.dgx = (bf16_t*)s.dgx; k.dgr = (bf16_t*)s.dgr; k.reverse = s.reverse;
+    k.xbuf = (unsigned long long*)xws[d];
+    if (hipMemsetAsync(xws[d], 0, os2s_gru_xcd_bwd_workspace_bytes(B, H), stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+  }
+  if (ndir == 1) a.d[1] = a.d[0];
+  if (hipMemsetAsync(flags, 0, 64, stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+  const size_t lds = gru_xcd_bwd_lds_bytes(H);
+  if (hipFuncSetAttribute((const void*)gru_xcd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return OS2S_ERR_LAUNCH;
+  OS2S_LAUNCH(gru_xcd_bwd_kernel, dim3(8 * kXcdCus), dim3(kXcdThreads), lds, stream, a);
   return OS2S_OK;
 }

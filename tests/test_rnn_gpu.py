@@ -159,3 +159,24 @@ def test_gru_persistent_xcd_kernel_equals_step_launches(cuda, B, T, H):
       assert torch.equal(b, live(again[d][i])), (d, name)   # run-to-run bit-identical (live rows)
     # rows past the sequence ends stay zero
     assert float((res[1][d][0].float() * (~m)).abs().max()) == 0.0
+  # ---- backward through time on the saved activations of the persistent forward (B <= 16: the
+  #      persistent backward kernel; B = 32 compares the step path with itself) -----------------------
+  dys = [bf(torch.randn(B, T, H, generator=g)) for _ in range(2)]
+  bw = {}
+  try:
+    for mode in (0, 1):
+      L.os2s_gru_xcd_set_mode(mode)
+      bw[mode] = capi.rnn_layer_bwd_multi(
+          capi.CELL_GRU_CUDNN,
+          [dict(whT=dirs[d]["wh"].t().contiguous(), dy=dys[d], y=res[1][d][0], gates=res[1][d][1],
+                reverse=bool(d)) for d in range(2)], lens.to(cuda), H)
+      torch.cuda.synchronize()
+  finally:
+    L.os2s_gru_xcd_set_mode(-1)
+  for d in range(2):
+    for i, name in ((0, "dgx"), (1, "dgr")):
+      a, b = bw[0][d][i].float(), bw[1][d][i].float()
+      assert bool(torch.isfinite(b).all()), (d, name)
+      assert float((a * (~m)).abs().max()) == 0.0 and float((b * (~m)).abs().max()) == 0.0
+      rel = float((a - b).norm() / (a.norm() + 1e-20))
+      assert rel <= 1e-2, (d, name, rel)       # bf16 gate gradients through T steps, two summation orders

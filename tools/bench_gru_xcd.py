@@ -39,3 +39,24 @@ for d in range(2):
     a, b = res[0][d][i].float(), res[1][d][i].float()
     print("dir %d %-5s max|diff| %.3e  rel-L2 %.3e" % (d, name, float((a - b).abs().max()),
                                                       float((a - b).norm() / (a.norm() + 1e-20))))
+
+# backward through time
+dys = [bf(torch.randn(B, T, H, generator=g)) for _ in range(2)]
+bw = {}
+for mode in (0, 1):
+  L.os2s_gru_xcd_set_mode(mode)
+  mk = lambda: [dict(whT=dirs[d]["wh"].t().contiguous(), dy=dys[d], y=res[1][d][0], gates=res[1][d][1], reverse=bool(d))
+                for d in range(2)]
+  args = mk()
+  bw[mode] = capi.rnn_layer_bwd_multi(capi.CELL_GRU_CUDNN, args, lens.to(dev), H)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(3):
+    bw[mode] = capi.rnn_layer_bwd_multi(capi.CELL_GRU_CUDNN, args, lens.to(dev), H)
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / 3
+  print("backward mode %d: %.3f ms per layer = %.2f us per step" % (mode, dt * 1e3, dt * 1e6 / T))
+L.os2s_gru_xcd_set_mode(-1)
+for d in range(2):
+  a, b = bw[0][d][0].float(), bw[1][d][0].float()
+  print("dir %d dgx rel-L2 %.3e" % (d, float((a - b).norm() / (a.norm() + 1e-20))))
