@@ -319,14 +319,17 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_fwd_kernel(GruXcdArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward through time, same scheme. A workgroup owns upc hidden units j: the rows j of Wh^T
-// [H, 3H] stay in registers (2 row tiles x ceil(3H/32)/8 k-steps per wave), the recurrent-side gate
-// gradients of the later step dg_{s+1} [B, 3H] are gathered from the exchange buffer into LDS,
-// dh_s = dy + dg_{s+1} . Wh + carry, then the gate derivatives of its (unit, sample) pairs
-// (rnn.hip:rnn_step_bwd_kernel, cuDNN GRU) and the publication of its 3 * upc rows of dg_s.
-// B <= 16 (the [16][3H] image of dg is 77 KB of LDS at H = 800).
+// Backward through time. dh_s = dy + carry + dg_{s+1} . Wh has a 3H-deep reduction; gathering dg
+// [B, 3H] on every workgroup (88 KB per step at H = 800) made a first version of this kernel slower
+// than the launch per step (10.96 vs 9.06 us). Here the product is cut along its REDUCTION instead: a
+// workgroup keeps the gate gradients of its OWN upc units (it computed them itself one step earlier),
+// multiplies them with its 3 * upc rows of Wh — held in registers as columns of Wh^T, [H x 96] — into a
+// partial dh for ALL H units, and hands each other workgroup the [upc x B] block of that partial that
+// belongs to its units (bf16, 7 values + tag per 16-byte granule). A step gathers 32 such blocks
+// (30 KB, the forward pass's volume), sums them in a fixed order (no atomics) and does the gate
+// derivatives of rnn.hip:rnn_step_bwd_kernel. B <= 16.
 // ---------------------------------------------------------------------------------------------
-constexpr int kXcdKSB = 12;          // k-steps of 32 per wave: 8 x 12 x 32 = 3072 >= 3H
+constexpr int kXcdBT = 7;            // row tiles (16 units of dh) per wave: 8 x 7 x 16 = 896 >= H
 
 struct GruXcdDirB {
   const bf16_t* whT;       // [H, 3H]
@@ -335,7 +338,7 @@ struct GruXcdDirB {
   const bf16_t* gates;     // [B, T, 4H] saved r, z, n, (R_n h + b_Rn)
   bf16_t* dgx;             // [B, T, 3H]
   bf16_t* dgr;             // [B, T, 3H] or null
-  unsigned long long* xbuf;
+  unsigned long long* xbuf;   // granules [2 slots][32 consumers][32 producers][gpp] x 16 bytes
   int reverse;
 };
 struct GruXcdArgsB {
@@ -348,8 +351,6 @@ struct GruXcdArgsB {
 __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // role = (XCD this workgroup runs on, arrival order on that XCD): 256 workgroups of one per CU put 32
-  // on every XCD whatever the dispatch order (blockIdx b mostly lands on XCD b % 8, not always)
   int dir, cu;
   {
     int xcc;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a)
     __syncthreads();
     cu = *slot;
     __syncthreads();
-    if (cu >= kXcdCus) {                 // more than one workgroup per CU: not the residency this is built on
+    if (cu >= kXcdCus) {
       if (tid == 0) __hip_atomic_store(a.flags, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
@@ -369,44 +370,49 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a)
   const GruXcdDirB& p = a.d[dir];
   const int B = a.B, T = a.T, H = a.H, GH = 3 * H;
   constexpr int BP = 16;
-  const int upc = (H + kXcdCus - 1) / kXcdCus;
+  const int upc = (H + kXcdCus - 1) / kXcdCus;      // <= 32
   const int u0 = cu * upc;
   const int nu = max(0, min(upc, H - u0));
-  const int NK = (GH + 31) / 32;                    // k-steps of the 3H-deep reduction
-  const int DS = NK * 32 * 2 + 16;                  // LDS row stride of dg (bytes)
-  const int nval = 3 * upc * BP;                    // values a workgroup publishes per step
-  const int gpc = (nval + 6) / 7;
-  const int ngran = kXcdCus * gpc;
-  const unsigned gpc_inv = (unsigned)((0x100000000ull + gpc - 1) / gpc);
-  constexpr int PR = 32 + 4;                        // pitch of the partial-sum image (2 row tiles)
-  // LDS: dg [BP][DS] | partial sums [8 waves][BP][PR] f32 | carry [upc][BP] f32 | pub [gpc * 7 + 1] bf16
-  char* const dg_l = smem;
-  float* const part = reinterpret_cast<float*>(smem + BP * DS);
-  float* const carry = part + 8 * BP * PR;
-  bf16_t* const pub = reinterpret_cast<bf16_t*>(carry + upc * BP);
+  const int nval = upc * BP;                        // values of one (producer, consumer) block
+  const int gpp = (nval + 6) / 7;                   // granules of a block
+  const int VP = gpp * 7 + 2;                       // pitch (bf16) of a block image in LDS
+  const int ngran = kXcdCus * gpp;                  // granules a workgroup gathers / publishes per step
+  const unsigned gpp_inv = (unsigned)((0x100000000ull + gpp - 1) / gpp);
+  constexpr int DS = 96 * 2 + 16;                   // row stride (bytes) of the own gate gradients [BP][96]
+  // LDS: stage [32 producers][VP] bf16 | out [32 consumers][VP] bf16 | dgo [BP][DS] | carry [upc][BP] f32
+  bf16_t* const stage = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* const outi = stage + kXcdCus * VP;
+  char* const dgo = reinterpret_cast<char*>(outi + kXcdCus * VP + 8);
+  float* const carry = reinterpret_cast<float*>(dgo + BP * DS);
 
-  bf16x8 af[kXcdKSB][2];
+  // ---- Wh^T columns of this workgroup's gate rows -> registers: A[j][k'], k' = 32 gate + unit -------
+  bf16x8 af[kXcdBT][3];
   {
     const int rrow = lane & 15, kq = (lane >> 4) * 8;
 #pragma unroll
-    for (int ks = 0; ks < kXcdKSB; ++ks) {
-      const int k = (wave + 8 * ks) * 32 + kq;
+    for (int rt = 0; rt < kXcdBT; ++rt) {
+      const int j = (wave + 8 * rt) * 16 + rrow;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int u = rt * 16 + rrow;
-        bf16x8 v = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-        if (u < nu && k < GH) v = *reinterpret_cast<const bf16x8*>(p.whT + (long long)(u0 + u) * GH + k);
-        af[ks][rt] = v;
+      for (int ks = 0; ks < 3; ++ks) {               // k-step = gate
+        unsigned short e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int u = kq + i;
+          e[i] = (j < H && u < nu) ? p.whT[(long long)j * GH + (long long)ks * H + u0 + u] : (unsigned short)0;
+        }
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)e[2 * i] | ((unsigned)e[2 * i + 1] << 16);
+        af[rt][ks] = __builtin_bit_cast(bf16x8, w);
       }
     }
   }
-  // this thread's (unit, sample) pair (upc * BP <= 512: one pair per thread)
-  const int pb = tid / upc, pu = tid - pb * upc;
+  const int pb = tid / upc, pu = tid - pb * upc;     // this thread's (unit, sample) pair (upc * BP <= 512)
   const bool mine = tid < upc * BP && pu < nu && pb < B;
   const int len = mine ? (a.lens ? min(max(a.lens[pb], 0), T) : T) : -1;
   for (int i = tid; i < upc * BP; i += kXcdThreads) carry[i] = 0.f;
-  for (int i = tid; i < gpc * 7 + 1; i += kXcdThreads) pub[i] = 0;
-  for (int i = tid; i < BP * DS / 4; i += kXcdThreads) reinterpret_cast<uint32_t*>(dg_l)[i] = 0u;
+  for (int i = tid; i < 2 * kXcdCus * VP + 8; i += kXcdThreads) stage[i] = 0;
+  for (int i = tid; i < BP * DS / 4; i += kXcdThreads) reinterpret_cast<uint32_t*>(dgo)[i] = 0u;
   __syncthreads();
 
   int failed = 0;
@@ -424,10 +430,10 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a)
       sv0 = bf2f(gp[0]); sv1 = bf2f(gp[H]); sv2 = bf2f(gp[2 * H]); sv3 = bf2f(gp[3 * H]);
       if (s > 0) hprev = bf2f(p.y[((long long)pb * T + (p.reverse ? t + 1 : t - 1)) * p.ldy + j]);
     }
-    // ---- (1) gather dg_{s+1}: granule = {16-bit tag, 7 bf16}, values v = sample + BP * (gate * upc + unit)
+    // ---- (1) gather the 32 partial blocks of dg_{s+1} . Wh for this workgroup's units ----------------
     if (it > 0) {
       const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.xbuf + (size_t)((it - 1) & 1) * ngran * 2), 0, ngran * 16, 0x00020000);
+          (void*)(p.xbuf + ((size_t)((it - 1) & 1) * kXcdCus + cu) * ngran * 2), 0, ngran * 16, 0x00020000);
       const unsigned want = (unsigned)it & 0xffffu;
       int polls = 0;
 #pragma unroll 1
@@ -446,17 +452,11 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a)
           for (int i = 0; i < kXcdGC; ++i)
             if ((pending & (1u << i)) && (g[i][0] & 0xffffu) == want) {
               const int gi = g0 + tid + i * kXcdThreads;
-              const int c = (int)__umulhi((unsigned)gi, gpc_inv);
-              const int j0 = (gi - c * gpc) * 7;
+              const int pr = (int)__umulhi((unsigned)gi, gpp_inv);        // producer
+              bf16_t* const dst = stage + pr * VP + (gi - pr * gpp) * 7;
 #pragma unroll
-              for (int v = 0; v < 7; ++v) {
-                const int j = j0 + v, r = j / BP;            // r = gate * upc + unit
-                const int gg = r >= 2 * upc ? 2 : (r >= upc ? 1 : 0);
-                const unsigned w16 = (g[i][(v + 1) >> 1] >> (16 * ((v + 1) & 1))) & 0xffffu;
-                const int k = gg * H + c * upc + (r - gg * upc);
-                if (j < nval && c * upc + (r - gg * upc) < H)
-                  *reinterpret_cast<bf16_t*>(dg_l + (j & (BP - 1)) * DS + k * 2) = (bf16_t)w16;
-              }
+              for (int v = 0; v < 7; ++v)
+                dst[v] = (bf16_t)((g[i][(v + 1) >> 1] >> (16 * ((v + 1) & 1))) & 0xffffu);
               pending &= ~(1u << i);
             }
           if (pending) {
@@ -473,32 +473,15 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a)
       if (tid == 0) __hip_atomic_store(a.flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    // ---- (2) dg_{s+1} . Wh for this workgroup's units -----------------------------------------------
-    if (it > 0) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      const int col = lane & 15, kq = (lane >> 4) * 8;
-#pragma unroll
-      for (int ks = 0; ks < kXcdKSB; ++ks) {
-        const int kstep = wave + 8 * ks;
-        if (kstep < NK) {
-          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(dg_l + col * DS + (kstep * 32 + kq) * 2);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bfr, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bfr, acc[1], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-        *reinterpret_cast<f32x4*>(part + ((size_t)wave * BP + col) * PR + rt * 16 + 4 * (lane >> 4)) = acc[rt];
-    }
-    __syncthreads();
-    // ---- (3) gate derivatives of this thread's pair (rnn.hip: cuDNN GRU) ------------------------------
+    // ---- (2) gate derivatives of this thread's pair (rnn.hip: cuDNN GRU) ------------------------------
     if (tid < upc * BP) {
-      float dr_ = 0.f, dz_ = 0.f, dn_ = 0.f, drn_ = 0.f;
+      float dr_ = 0.f, dz_ = 0.f, drn_ = 0.f;
       if (t >= 0) {
         float dh = dyv + carry[pb + BP * pu];
         if (it > 0) {
-#pragma unroll
-          for (int w = 0; w < 8; ++w) dh += part[((size_t)w * BP + pb) * PR + pu];
+          const bf16_t* sp = stage + pu * BP + pb;            // value index = unit * BP + sample
+#pragma unroll 8
+          for (int q = 0; q < kXcdCus; ++q) dh += bf2f(sp[q * VP]);
         }
         const float rg = sv0, zg = sv1, ng = sv2, hn = sv3;
         const float dn = dh * (1.f - zg);
@@ -506,29 +489,59 @@ __global__ __launch_bounds__(kXcdThreads) void gru_xcd_bwd_kernel(GruXcdArgsB a)
         const float dnpre = dn * (1.f - ng * ng);
         dr_ = dnpre * hn * rg * (1.f - rg);
         dz_ = dz * zg * (1.f - zg);
-        dn_ = dnpre;
         drn_ = dnpre * rg;
         carry[pb + BP * pu] = dh * zg;
         const long long o = ((long long)pb * T + t) * GH + u0 + pu;
-        p.dgx[o] = f2bf(dr_); p.dgx[o + H] = f2bf(dz_); p.dgx[o + 2 * H] = f2bf(dn_);
+        p.dgx[o] = f2bf(dr_); p.dgx[o + H] = f2bf(dz_); p.dgx[o + 2 * H] = f2bf(dnpre);
         if (p.dgr) { p.dgr[o] = f2bf(dr_); p.dgr[o + H] = f2bf(dz_); p.dgr[o + 2 * H] = f2bf(drn_); }
       }
-      // recurrent-side gradients for the next (earlier) step: zeros for a sample past its length
-      pub[pb + BP * pu] = f2bf(dr_);
-      pub[pb + BP * (upc + pu)] = f2bf(dz_);
-      pub[pb + BP * (2 * upc + pu)] = f2bf(drn_);
+      // recurrent-side gradients of the own units, the B operand of the next product (zeros for a
+      // sample past its length)
+      bf16_t* dq = reinterpret_cast<bf16_t*>(dgo + pb * DS) + pu;
+      dq[0] = f2bf(dr_); dq[32] = f2bf(dz_); dq[64] = f2bf(drn_);
     }
     __syncthreads();
-    // ---- (4) publish ---------------------------------------------------------------------------------
     if (it + 1 < T) {
-      char* xo = reinterpret_cast<char*>(p.xbuf) + ((size_t)(it & 1) * ngran + (size_t)cu * gpc) * 16;
-      for (int e = tid; e < gpc; e += kXcdThreads) {
-        const bf16_t* hp = pub + e * 7;
-        u32x4 g;
-        g[0] = ((unsigned)(it + 1) & 0xffffu) | ((unsigned)hp[0] << 16);
+      // ---- (3) partial dh for ALL units: Wh^T[:, own rows] x dg_own -> bf16 image by consumer ------------
+      {
+        const int col = lane & 15, kq = (lane >> 4) * 8;
+        bf16x8 bfr[3];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) g[1 + v] = (unsigned)hp[1 + 2 * v] | ((unsigned)hp[2 + 2 * v] << 16);
-        st_plain_b128(xo + (size_t)e * 16, g);
+        for (int ks = 0; ks < 3; ++ks)
+          bfr[ks] = *reinterpret_cast<const bf16x8*>(dgo + col * DS + (ks * 32 + kq) * 2);
+#pragma unroll
+        for (int rt = 0; rt < kXcdBT; ++rt) {
+          const int j0 = (wave + 8 * rt) * 16;
+          if (j0 < H) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][ks], bfr[ks], acc, 0, 0, 0);
+            // C layout: sample = lane & 15, units j0 + 4 (lane >> 4) + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int j = j0 + 4 * (lane >> 4) + i;
+              if (j < H) {
+                const int cc = j / upc;
+                outi[cc * VP + (j - cc * upc) * BP + col] = f2bf(acc[i]);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- (4) publish: block (consumer cc, producer cu) = gpp granules ------------------------------------
+      {
+        char* const xo = reinterpret_cast<char*>(p.xbuf) + (size_t)(it & 1) * kXcdCus * ngran * 16;
+        for (int e = tid; e < ngran; e += kXcdThreads) {
+          const int cc = (int)__umulhi((unsigned)e, gpp_inv), ge = e - cc * gpp;
+          const bf16_t* hp = outi + cc * VP + ge * 7;
+          u32x4 g;
+          g[0] = ((unsigned)(it + 1) & 0xffffu) | ((unsigned)hp[0] << 16);
+#pragma unroll
+          for (int v = 0; v < 3; ++v) g[1 + v] = (unsigned)hp[1 + 2 * v] | ((unsigned)hp[2 + 2 * v] << 16);
+          st_plain_b128(xo + ((size_t)cc * ngran + (size_t)cu * gpp + ge) * 16, g);
+        }
       }
     }
   }
@@ -632,24 +645,22 @@ int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* d
 
 
 extern "C" size_t os2s_gru_xcd_bwd_workspace_bytes(int B, int H) {
-  const int upc = (H + 31) / 32, gpc = (3 * upc * 16 + 6) / 7;
+  const int upc = (H + 31) / 32, gpp = (upc * 16 + 6) / 7;
   (void)B;
-  return (size_t)2 * 32 * gpc * 16 + 256;
+  return (size_t)2 * 32 * 32 * gpp * 16 + 256;
 }
 
 static size_t gru_xcd_bwd_lds_bytes(int H) {
-  const int upc = (H + kXcdCus - 1) / kXcdCus, NK = (3 * H + 31) / 32, gpc = (3 * upc * 16 + 6) / 7;
-  return (size_t)16 * (NK * 64 + 16) + (size_t)8 * 16 * 36 * 4 + (size_t)upc * 16 * 4 + (size_t)(gpc * 7 + 1) * 2 + 64;
+  const int upc = (H + kXcdCus - 1) / kXcdCus, gpp = (upc * 16 + 6) / 7, VP = gpp * 7 + 2;
+  return (size_t)2 * kXcdCus * VP * 2 + 16 + (size_t)16 * (96 * 2 + 16) + (size_t)upc * 16 * 4 + 64;
 }
 
 bool gru_xcd_bwd_supported(int B, int T, int H, int ndir) {
-  // default OFF: at the DeepSpeech2 size the gather of dg [B, 3H] (88 KB per workgroup and step) makes
-  // the persistent backward step slower than the launch per step (10.96 vs 9.06 us); OS2S_GRU_XCD_BWD=1
-  static const int on = [] { const char* e = getenv("OS2S_GRU_XCD_BWD"); return e ? atoi(e) : 0; }();
+  static const int on = [] { const char* e = getenv("OS2S_GRU_XCD_BWD"); return e ? atoi(e) : 1; }();
   if (!on) return false;
   if (!gru_xcd_supported(B, T, H, ndir) || B > 16) return false;
   const int upc = (H + kXcdCus - 1) / kXcdCus;
-  if (upc > 32 || upc * 16 > kXcdThreads || (3 * H + 31) / 32 > 8 * kXcdKSB) return false;
+  if (upc > 32 || upc * 16 > kXcdThreads || H > 8 * kXcdBT * 16) return false;
   return gru_xcd_bwd_lds_bytes(H) <= 160 * 1024;
 }
 
