@@ -309,7 +309,11 @@ def test_checkpoint_roundtrip_transformer_layout(cuda, tmp_path):
   assert base + "/qkv/kernel" not in ck
   assert ck["ForwardPass/embedding_and_softmax/weights"].shape == (96, 512)
   qkv = m1.store.by_name(base + "/qkv/kernel").master.cpu().numpy()
-  assert np.array_equal(ck[base + "/k/kernel"], qkv[0, 512:1024].T)
+  # mixed precision: the plain name holds DT_HALF (what a reference fp16 graph stores), the fp32 value
+  # lives under the master-copy name (mp_wrapper.py:55-82)
+  assert ck[base + "/k/kernel"].dtype == np.float16
+  assert np.array_equal(ck[base + "/k/kernel"], qkv[0, 512:1024].T.astype(np.float16))
+  assert np.array_equal(ck[checkpoint.MASTER_PREFIX + base + "/k/kernel"], qkv[0, 512:1024].T)
   m2 = cls(params, mode="train", hvd=None, device=cuda)
   m2.compile()
   m2.store.master.mul_(0.5)             # same seed => same init: make it differ before the restore
