@@ -309,11 +309,11 @@ class StepBreakdown(object):
       return bd._bracket("batchnorm", by, lambda: o["bn_act_bwd_reduce"](
           dout, out, ys, means, rstds, dz, partial, out_len, act, keep_prob, seed))
 
-    def bn_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0):
+    def bn_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0, **kw):
       T = dz.shape[1] if dz.dim() == 3 else 1
       by = dz.numel() * 2.0 * (2.0 * bd._live(out_len, T, cache, margin=margin) + 1.0)
       return bd._bracket("batchnorm", by, lambda: o["bn_bwd_apply"](dz, y, gamma, mean, rstd, c1, c2, dy,
-                                                                    out_len=out_len, margin=margin))
+                                                                    out_len=out_len, margin=margin, **kw))
 
     def opt(cfg, state, grads, weights, *a, **kw):
       # per parameter: gradient + master + moment read (12 B), master + moment + bf16 copy written (10 B)

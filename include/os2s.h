@@ -123,6 +123,23 @@ int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
  * may overlap must not share one. Without a workspace (os2s_conv1d_fwd_ex / os2s_conv1d_fwd)
  * results are identical up to fp32 summation order, only the load balance differs.
  * The tile choice is a fixed function of the problem shape; no timing, no hidden state. */
+/* Data gradient of a convolution whose input is the output of a conv + BatchNorm + ReLU (+ dropout)
+ * layer (parts/cnns/conv_blocks.py:170-232), as the LAST contribution to that output's gradient, with
+ * the activation backward and the partial sums of that layer's BatchNorm backward in the epilogue:
+ *   dx (+)= conv(dy, wT) [stride 1];  dz = (mask_ref > 0) ? dx * mask_scale : 0, written to dx;
+ *   stats[window, 0, c] = sum_rows dz,  stats[window, 1, c] = sum_rows dz * stat_ref   (ZERO on entry)
+ * mask_ref = the layer's saved output [B, Tout, Cout], stat_ref = its convolution output (same layout),
+ * mask_scale = 1 / keep_prob; wT = the tap-flipped transposed weights [K, Cout, Cin]; out_len as in
+ * os2s_conv1d_fwd_ws. Replaces the reduction pass os2s_bn_act_bwd_reduce for single-input BatchNorm
+ * layers; os2s_bn_bwd_finalize_raw turns the partials into dgamma / dbeta / c1 / c2. */
+int os2s_conv1d_dgrad_bnact_ws(os2s_stream_t stream, const uint16_t* dy, const uint16_t* wT, void* dx,
+                               float* stats, int B, int Tin, int Cin, int Cout, int K, int dil, int padL,
+                               int Tout, int accumulate, const int32_t* out_len, const uint16_t* mask_ref,
+                               float mask_scale, const uint16_t* stat_ref, void* workspace,
+                               size_t workspace_bytes);
+int os2s_bn_bwd_finalize_raw(os2s_stream_t stream, const float* partial, int nparts, int C, long long count,
+                             const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                             int accumulate, float* c1, float* c2);
 size_t os2s_conv1d_workspace_bytes(void);
 int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* w, void* y,
                        const int32_t* in_len, const float* bias, float* stats, int B,
@@ -309,6 +326,12 @@ int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* 
  * for the data- and weight-gradient convolutions of a K-tap layer (dy is not zero there: the batch
  * statistics run over padded frames too). out_len NULL = every row. */
 int os2s_bn_bwd_apply_ragged(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                             const float* gamma, const float* mean, const float* rstd,
+                             const float* c1, const float* c2, uint16_t* dy,
+                             const int32_t* out_len, int margin, int B, int T, int C);
+/* ... with a dz that is defined only for rows t < out_len[b] (written by os2s_conv1d_dgrad_bnact_ws,
+ * which skips the rest) and is taken as zero beyond, unread */
+int os2s_bn_bwd_apply_ragged_dz(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
                              const float* gamma, const float* mean, const float* rstd,
                              const float* c1, const float* c2, uint16_t* dy,
                              const int32_t* out_len, int margin, int B, int T, int C);

@@ -143,6 +143,40 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
   return out
 
 
+def conv1d_dgrad_bnact(dy, wt, dx, *, dil, pad_left, accumulate, out_len, mask_ref, mask_scale, stat_ref):
+  """dx (+)= conv(dy, wt) (stride 1), then dz = (mask_ref > 0) ? dx * mask_scale : 0 written to dx;
+  returns the BatchNorm-backward partials [num_mtiles(B, T), 2, C] = (sum dz, sum dz * stat_ref) per
+  128-row window (os2s_conv1d_dgrad_bnact_ws). dy [B,Tin,Cin] bf16, wt [K,Cout,Cin] bf16 (tap-flipped
+  transposed weights), dx / mask_ref / stat_ref [B,Tout,Cout] bf16 contiguous."""
+  B, Tin, Cin = dy.shape
+  K, Cout, _ = wt.shape
+  Tout = dx.shape[1]
+  assert tuple(dx.shape) == (B, Tout, Cout) == tuple(mask_ref.shape) == tuple(stat_ref.shape)
+  assert dx.is_contiguous() and mask_ref.is_contiguous() and stat_ref.is_contiguous() and dy.is_contiguous()
+  stats = torch.zeros((conv1d_num_mtiles(B, Tout), 2, Cout), dtype=torch.float32, device=dy.device)
+  ws = conv1d_workspace(dy.device)
+  f = _fn("os2s_conv1d_dgrad_bnact_ws",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+           c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t))
+  _lib.check(f(_stream(), _ptr(dy, torch.bfloat16), _ptr(wt, torch.bfloat16), _ptr(dx, torch.bfloat16),
+               _ptr(stats, torch.float32), B, Tin, Cin, Cout, K, int(dil), int(pad_left), Tout,
+               int(bool(accumulate)), _ptr(out_len, torch.int32, True), _ptr(mask_ref, torch.bfloat16),
+               float(mask_scale), _ptr(stat_ref, torch.bfloat16), _ptr(ws), ws.numel()),
+             "os2s_conv1d_dgrad_bnact_ws")
+  return stats
+
+
+def bn_bwd_finalize_raw(partial, count, mean, rstd, dgamma, dbeta, accumulate, c1, c2):
+  """dgamma / dbeta / c1 / c2 from raw partials [nparts, 2, C] = (sum dz, sum dz * y)."""
+  nparts, two, C = partial.shape
+  assert two == 2
+  f = _fn("os2s_bn_bwd_finalize_raw", (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(partial, torch.float32), nparts, C, int(count), _ptr(mean, torch.float32),
+               _ptr(rstd, torch.float32), _ptr(dgamma, torch.float32, True), _ptr(dbeta, torch.float32, True),
+               int(accumulate), _ptr(c1, torch.float32), _ptr(c2, torch.float32)), "os2s_bn_bwd_finalize_raw")
+
+
 class _ConvGroup(_lib.ctypes.Structure):
   _fields_ = [("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("stats", c_void_p),
               ("Cin", c_int), ("Cout", c_int), ("accumulate", c_int)]
@@ -346,14 +380,14 @@ def bn_bwd_finalize_multi(partial, count, dgammas, dbetas, accumulate, c1, c2):
              "os2s_bn_bwd_finalize_multi")
 
 
-def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0):
+def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0, dz_to_len=False):
   """out_len / margin (dz [B,T,C]): rows t >= out_len[b] + margin are written as zeros unread —
   margin = (K-1)*dilation of the convolution whose gradients consume dy."""
   C = dz.shape[-1]
   rows = dz.numel() // C
   if out_len is not None:
     B, T = dz.shape[0], dz.shape[1]
-    f = _fn("os2s_bn_bwd_apply_ragged",
+    f = _fn("os2s_bn_bwd_apply_ragged_dz" if dz_to_len else "os2s_bn_bwd_apply_ragged",
             (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
              c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int))
     _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(y, torch.bfloat16),
@@ -362,6 +396,7 @@ def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0):
                  _ptr(dy, torch.bfloat16), _ptr(out_len, torch.int32), int(margin), B, T, C),
                "os2s_bn_bwd_apply_ragged")
     return dy
+  assert not dz_to_len
   f = _fn("os2s_bn_bwd_apply",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_void_p, c_void_p, c_ll, c_int))

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ c1,
     const float* __restrict__ c2, bf16_t* __restrict__ dy, const int32_t* __restrict__ out_len,
-    int margin, int B, int T, int C, int gmax, int trows) {
+    int margin, int B, int T, int C, int gmax, int trows, int dz_to_len) {
   const int C8 = C >> 3;
   const TileMap tm(C8, gmax);
   if (!tm.cvalid) return;
@@ -598,9 +598,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       rw[u] = base + (long long)u * RL;
       ok[u] = rw[u] < r1;
       lv[u] = ok[u] && cur.t < cur.len + margin;
+      // dz_to_len: dz is only DEFINED for rows before the sequence end (it was written by a data-
+      // gradient launch that skips the rest, os2s_conv1d_dgrad_bnact_ws) and is zero beyond
+      const bool dzl = lv[u] && (!dz_to_len || cur.t < cur.len);
       if (ok[u]) cur.advance(RL, rows);
       if (lv[u]) {
-        d[u] = *reinterpret_cast<const u32x4*>(dz + rw[u] * C + c0);
+        d[u] = u32x4{0u, 0u, 0u, 0u};
+        if (dzl) d[u] = *reinterpret_cast<const u32x4*>(dz + rw[u] * C + c0);
         yv[u] = *reinterpret_cast<const u32x4*>(y + rw[u] * C + c0);
       }
     }
@@ -758,6 +762,47 @@ extern "C" int os2s_bn_bwd_finalize(os2s_stream_t stream, const float* partial, 
   return OS2S_OK;
 }
 
+// The same from RAW partials [nparts, 2, C] = (sum dz, sum dz * y) per part (the data-gradient epilogue of
+// os2s_conv1d_dgrad_bnact_ws): sum dz * xhat = rstd * (sum dz * y - mean * sum dz).
+namespace os2s {
+__global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_raw_kernel(
+    const float* __restrict__ partial, int nparts, int C, double count, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double sh_d[kFinLanes][64], sh_x[kFinLanes][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double sd = 0.0, sx = 0.0;
+  if (c < C)
+    for (int i = pl; i < nparts; i += kFinLanes) {
+      sd += (double)partial[((long long)i * 2 + 0) * C + c];
+      sx += (double)partial[((long long)i * 2 + 1) * C + c];
+    }
+  sh_d[pl][cl] = sd;
+  sh_x[pl][cl] = sx;
+  __syncthreads();
+  if (pl != 0 || c >= C) return;
+  sd = 0.0; sx = 0.0;
+#pragma unroll
+  for (int l = 0; l < kFinLanes; ++l) { sd += sh_d[l][cl]; sx += sh_x[l][cl]; }
+  sx = (double)rstd[c] * (sx - (double)mean[c] * sd);
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sd;
+  c1[c] = (float)(sd / count);
+  c2[c] = (float)(sx / count);
+}
+}  // namespace os2s
+
+extern "C" int os2s_bn_bwd_finalize_raw(os2s_stream_t stream, const float* partial, int nparts, int C,
+                                        long long count, const float* mean, const float* rstd, float* dgamma,
+                                        float* dbeta, int accumulate, float* c1, float* c2) {
+  using namespace os2s;
+  OS2S_REQUIRE(partial && mean && rstd && c1 && c2 && nparts >= 1 && C >= 1 && count >= 1);
+  OS2S_LAUNCH(bn_bwd_finalize_raw_kernel, dim3(ceil_div(C, 64)), dim3(64 * kFinLanes), 0, (hipStream_t)stream,
+              partial, nparts, C, (double)count, mean, rstd, dgamma, dbeta, accumulate, c1, c2);
+  return OS2S_OK;
+}
+
 extern "C" int os2s_bn_bwd_finalize_multi(os2s_stream_t stream, const float* partial, int nparts,
                                           int J, int C, long long count, float* const* dgamma,
                                           float* const* dbeta, int accumulate, float* c1,
@@ -774,11 +819,11 @@ extern "C" int os2s_bn_bwd_finalize_multi(os2s_stream_t stream, const float* par
 static int bn_bwd_apply_launch(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
                                const float* gamma, const float* mean, const float* rstd,
                                const float* c1, const float* c2, uint16_t* dy,
-                               const int32_t* out_len, int margin, int B, int T, int C) {
+                               const int32_t* out_len, int margin, int B, int T, int C, int dz_to_len = 0) {
   const int gmax = g_tiling[2][0], trows = g_tiling[2][1];
   dim3 grid(ceil_div((long long)B * T, trows), tile_cblocks(C / 8, gmax));
   OS2S_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, y, gamma, mean,
-              rstd, c1, c2, dy, out_len, margin, B, T, C, gmax, trows);
+              rstd, c1, c2, dy, out_len, margin, B, T, C, gmax, trows, dz_to_len);
   return OS2S_OK;
 }
 
@@ -790,6 +835,17 @@ extern "C" int os2s_bn_bwd_apply_ragged(os2s_stream_t stream, const uint16_t* dz
   OS2S_REQUIRE(margin >= 0);
   if ((long long)B * T == 0) return OS2S_OK;
   return bn_bwd_apply_launch(stream, dz, y, gamma, mean, rstd, c1, c2, dy, out_len, margin, B, T, C);
+}
+
+// the same for a dz that is defined only up to the sequence ends (zero beyond, never read there)
+extern "C" int os2s_bn_bwd_apply_ragged_dz(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,
+                                           const float* gamma, const float* mean, const float* rstd,
+                                           const float* c1, const float* c2, uint16_t* dy,
+                                           const int32_t* out_len, int margin, int B, int T, int C) {
+  OS2S_REQUIRE(dz && y && mean && rstd && c1 && c2 && dy && out_len && C % 8 == 0 && B >= 0 && T >= 0);
+  OS2S_REQUIRE(margin >= 0);
+  if ((long long)B * T == 0) return OS2S_OK;
+  return bn_bwd_apply_launch(stream, dz, y, gamma, mean, rstd, c1, c2, dy, out_len, margin, B, T, C, 1);
 }
 
 extern "C" int os2s_bn_bwd_apply(os2s_stream_t stream, const uint16_t* dz, const uint16_t* y,

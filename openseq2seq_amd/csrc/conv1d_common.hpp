@@ -30,6 +30,11 @@ struct ConvArgs {
   // column sums of the masked gradient (= the bias gradient partials). Null = off.
   const bf16_t* mask_ref;
   float mask_scale;
+  // with mask_ref: stats[.., 1, c] = sum over the window's rows of y[row, c] * stat_ref[row, c]
+  // instead of the sum of squares (stat_ref in the layout of y) — the BatchNorm backward partials
+  // sum(dz), sum(dz * conv_out) of the PRODUCING layer when this launch is the data gradient that
+  // finalises its output gradient (os2s_conv1d_dgrad_bnact_ws). Null = sums of squares.
+  const bf16_t* stat_ref;
   // ping-pong kernel only: split-unit workspace (fp32 partial tiles + one ticket per split unit)
   float* ws_slabs;
   int* ws_cnt;
@@ -221,13 +226,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
     for (int i = 0; i < NQ; ++i) {
       const int q = tid + i * NTHR;
       const int row = q / (BN / 8), c8 = q - row * (BN / 8);
-      if (p.mask_ref) {          // (never together with residual / accumulate: checked on the host)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[i][e] = pack2bf(bflo(ro[i][e]) > 0.f ? bflo(v[i][e]) * p.mask_scale : 0.f,
-                            bfhi(ro[i][e]) > 0.f ? bfhi(v[i][e]) * p.mask_scale : 0.f);
-        if (p.stats) *reinterpret_cast<u32x4*>(const_cast<char*>(otw) + row * OP + c8 * 16) = v[i];
-      } else if (p.residual) {
+      if (p.residual && !p.mask_ref) {      // (mask_ref excludes residual: checked on the host)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           v[i][e] = pack2bf(bflo(v[i][e]) + bflo(ro[i][e]), bfhi(v[i][e]) + bfhi(ro[i][e]));
@@ -236,6 +235,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           v[i][e] = pack2bf(bflo(v[i][e]) + bflo(ao[i][e]), bfhi(v[i][e]) + bfhi(ao[i][e]));
+      }
+      if (p.mask_ref) {          // activation (+ dropout) backward of the producing layer on the SUM
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[i][e] = pack2bf(bflo(ro[i][e]) > 0.f ? bflo(v[i][e]) * p.mask_scale : 0.f,
+                            bfhi(ro[i][e]) > 0.f ? bfhi(v[i][e]) * p.mask_scale : 0.f);
+        if (p.stats) *reinterpret_cast<u32x4*>(const_cast<char*>(otw) + row * OP + c8 * 16) = v[i];
       }
       *reinterpret_cast<u32x4*>(yb + (long long)(t0 + row) * p.y_st + n0 + c8 * 8) = v[i];
     }
@@ -247,15 +253,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
       if (row < valid_rows && gc < p.Cout) {
         u32x4 x = *reinterpret_cast<const u32x4*>(otw + row * OP + c8 * 16);
         bf16_t* dst = yb + (long long)(t0 + row) * p.y_st + gc;
-        if (p.mask_ref) {
-          const u32x4 o = *reinterpret_cast<const u32x4*>(
-              p.mask_ref + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            x[e] = pack2bf(bflo(o[e]) > 0.f ? bflo(x[e]) * p.mask_scale : 0.f,
-                           bfhi(o[e]) > 0.f ? bfhi(x[e]) * p.mask_scale : 0.f);
-          if (p.stats) *reinterpret_cast<u32x4*>(const_cast<char*>(otw) + row * OP + c8 * 16) = x;
-        } else if (p.residual) {
+        if (p.residual && !p.mask_ref) {
           const u32x4 o = *reinterpret_cast<const u32x4*>(
               p.residual + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
 #pragma unroll
@@ -265,6 +263,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
           const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = pack2bf(bflo(x[e]) + bflo(o[e]), bfhi(x[e]) + bfhi(o[e]));
+        }
+        if (p.mask_ref) {
+          const u32x4 o = *reinterpret_cast<const u32x4*>(
+              p.mask_ref + (long long)b * p.y_sb + (long long)(t0 + row) * p.y_st + gc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            x[e] = pack2bf(bflo(o[e]) > 0.f ? bflo(x[e]) * p.mask_scale : 0.f,
+                           bfhi(o[e]) > 0.f ? bfhi(x[e]) * p.mask_scale : 0.f);
+          if (p.stats) *reinterpret_cast<u32x4*>(const_cast<char*>(otw) + row * OP + c8 * 16) = x;
         }
         *reinterpret_cast<u32x4*>(dst) = x;
       }
@@ -295,11 +302,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
           const int row = rg + i * RG;
           vv[i] = row < valid_rows ? *reinterpret_cast<const uint32_t*>(otw + row * OP + cp * 4) : 0u;
         }
+        if (p.stat_ref) {
+          // second statistic = sum of (value x reference): the reference pair of this thread's columns,
+          // 4 bytes per row (a wave reads 256 contiguous bytes of a row)
+          const bool cok = n0 + cp * 2 < p.Cout;
+          const bf16_t* const rp = p.stat_ref + (long long)wb[w] * p.y_sb + (long long)wt0[w] * p.y_st + n0 + cp * 2;
+          uint32_t rr[RPT];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-          const float a = bflo(vv[i]), bb = bfhi(vv[i]);
-          s0 += a; q0 += a * a;
-          s1 += bb; q1 += bb * bb;
+          for (int i = 0; i < RPT; ++i) {
+            const int row = rg + i * RG;
+            rr[i] = (cok && row < valid_rows) ? *reinterpret_cast<const uint32_t*>(rp + (long long)row * p.y_st) : 0u;
+          }
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) {
+            const float a = bflo(vv[i]), bb = bfhi(vv[i]);
+            s0 += a; q0 += a * bflo(rr[i]);
+            s1 += bb; q1 += bb * bfhi(rr[i]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) {
+            const float a = bflo(vv[i]), bb = bfhi(vv[i]);
+            s0 += a; q0 += a * a;
+            s1 += bb; q1 += bb * bb;
+          }
         }
         float* sc = reinterpret_cast<float*>(smem + EW * BM * OP) + (size_t)(w - w0) * RG * BN * 2;
         sc[(rg * BN + cp * 2 + 0) * 2 + 0] = s0;

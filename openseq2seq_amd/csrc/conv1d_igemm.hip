@@ -751,8 +751,11 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
                            int Tout, long long y_stride_b, long long y_stride_t, int out_f32,
                            int accumulate, int act, float keep_prob, unsigned long long seed,
                            const uint16_t* residual, const int32_t* out_len, void* workspace,
-                           size_t workspace_bytes) {
+                           size_t workspace_bytes, const uint16_t* mask_ref = nullptr, float mask_scale = 1.f,
+                           const uint16_t* stat_ref = nullptr) {
   using namespace os2s;
+  if (mask_ref) OS2S_REQUIRE(!residual && !out_f32 && act == 0 && keep_prob == 1.f && !bias);
+  if (stat_ref) OS2S_REQUIRE(mask_ref && stats);
   OS2S_REQUIRE(act == 0 || act == 1);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
   if (out_f32) OS2S_REQUIRE(act == 0 && keep_prob == 1.f && residual == nullptr);
@@ -770,7 +773,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
   a.y_sb = y_stride_b; a.y_st = y_stride_t;
   a.out_f32 = out_f32; a.accumulate = accumulate;
   a.act = act; a.keep_prob = keep_prob; a.seed = seed; a.residual = residual;
-  a.mask_ref = nullptr; a.mask_scale = 1.f;
+  a.mask_ref = mask_ref; a.mask_scale = mask_scale; a.stat_ref = stat_ref;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256;
   a.force_split = g_conv_split;
   a.dbg = g_conv_dbg; a.dbg_fixed_w = g_conv_fixed_w;
@@ -822,6 +825,25 @@ extern "C" int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const
                          seed, residual, out_len, workspace, workspace_bytes);
 }
 
+// The data gradient of a convolution whose INPUT is the output of a conv + BatchNorm + ReLU (+ dropout)
+// layer (parts/cnns/conv_blocks.py:170-232), as the LAST contribution to that output's gradient:
+//   dx (+)= conv(dy, flipped transposed weights);  dz = (mask_ref > 0) ? dx * mask_scale : 0  -> dx
+//   stats[window, 0, c] = sum_rows dz,  stats[window, 1, c] = sum_rows dz * stat_ref
+// mask_ref = that layer's saved output (zero where the ReLU or the dropout mask was off), mask_scale =
+// 1 / keep_prob, stat_ref = its convolution output: the partial sums of its BatchNorm backward come out of
+// this launch and its own reduction pass (os2s_bn_act_bwd_reduce) is not needed. stats must be ZERO on
+// entry (windows past out_len are not visited). Layouts of mask_ref / stat_ref: as dx.
+extern "C" int os2s_conv1d_dgrad_bnact_ws(os2s_stream_t stream, const uint16_t* dy, const uint16_t* wT, void* dx,
+                                          float* stats, int B, int Tin, int Cin, int Cout, int K, int dil,
+                                          int padL, int Tout, int accumulate, const int32_t* out_len,
+                                          const uint16_t* mask_ref, float mask_scale, const uint16_t* stat_ref,
+                                          void* workspace, size_t workspace_bytes) {
+  OS2S_REQUIRE(mask_ref && stat_ref && stats);
+  return conv1d_fwd_impl(stream, dy, wT, dx, nullptr, nullptr, stats, B, Tin, Cin, Cout, K, 1, dil, padL, Tout,
+                         (long long)Tout * Cout, Cout, 0, accumulate, 0, 1.f, 0ull, nullptr, out_len, workspace,
+                         workspace_bytes, mask_ref, mask_scale, stat_ref);
+}
+
 extern "C" int os2s_conv1d_fwd_ex(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                                   void* y, const int32_t* in_len, const float* bias,
                                   float* stats, int B, int Tin, int Cin, int Cout, int K,
@@ -860,7 +882,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   a.stride = 1; a.dil = 1; a.padL = 0;
   a.x_sb = 0; a.x_st = 0; a.y_sb = 0; a.y_st = 0;
   a.out_f32 = 0; a.accumulate = 0; a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
-  a.mask_ref = nullptr; a.mask_scale = 1.f;
+  a.mask_ref = nullptr; a.mask_scale = 1.f; a.stat_ref = nullptr;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
   a.dbg = g_conv_dbg; a.dbg_fixed_w = 0;     // experiment hook (conv1x1_pp_kernel phase stamps)
   a.mtiles_per_b = ceil_div(T, BM);

@@ -451,7 +451,7 @@ static int gemm_nt_impl(os2s_stream_t stream, const uint16_t* A, long long lda, 
   a.x_sb = 0; a.x_st = lda; a.y_sb = 0; a.y_st = ldc;
   a.out_f32 = out_f32; a.accumulate = accumulate; a.act = act; a.keep_prob = keep_prob; a.seed = seed;
   a.residual = residual;
-  a.mask_ref = mask_ref; a.mask_scale = mask_scale; a.stats = stats;
+  a.mask_ref = mask_ref; a.mask_scale = mask_scale; a.stats = stats; a.stat_ref = nullptr;
   if (mask_ref) OS2S_REQUIRE(!residual && !accumulate && !out_f32 && act == 0 && keep_prob == 1.f && !bias);
   if (stats) OS2S_REQUIRE(!out_f32);
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;

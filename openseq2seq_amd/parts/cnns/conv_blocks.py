@@ -33,6 +33,10 @@ def act_id(fn):
 _SIDE_STREAMS = {}
 
 
+# A/B knob: 0 = every conv + BatchNorm + ReLU layer runs its own BatchNorm-backward reduction pass
+# (round 2); default = the pass is folded into the data-gradient launch that finalises the layer's
+# output gradient (capi.conv1d_dgrad_bnact)
+FUSE_BN_BWD = os.environ.get("OS2S_FUSE_BN_BWD", "1") != "0"
 # A/B knob: 0 = one K = 1 weight-gradient launch per residual branch (round 2), default = grouped
 GROUP_WGRAD = os.environ.get("OS2S_GROUP_WGRAD", "1") != "0"
 
@@ -198,7 +202,7 @@ def current_tape():
 class Act(object):
   """An activation tensor + its valid lengths + (optionally) its gradient."""
   __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad", "res_grad", "mask_scale",
-               "grad_masked", "bias_part")
+               "grad_masked", "bias_part", "bn_y", "bn_scale")
 
   def __init__(self, data, lens=None, requires_grad=True):
     self.data, self.lens = data, lens
@@ -211,6 +215,12 @@ class Act(object):
     self.mask_scale = None
     self.grad_masked = False
     self.bias_part = None
+    # set by conv_bn_actv on the output of a single-input conv + BatchNorm + ReLU (+ dropout) layer: the
+    # convolution output y. The data gradient of the NEXT layer's main convolution — the last
+    # contribution to this activation's gradient — then applies the ReLU / dropout backward and leaves
+    # the BatchNorm-backward partials (sum dz, sum dz * y) in bias_part (capi.conv1d_dgrad_bnact)
+    self.bn_y = None
+    self.bn_scale = 1.0
 
   def grad_buffer(self):
     # a gradient that already carries its producer's activation backward takes no more addends
@@ -301,21 +311,32 @@ class ConvBN(object):
                         pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
                         accumulate=True)
 
-  def backward_branch(self, inp, dy, f):
+  def backward_branch(self, inp, dy, f, final=False):
     """Weight and data gradients of the convolution given dy = d(conv output). Nothing in the
     rest of backward depends on the weight gradient, so it runs on a side stream: its
     workgroups fill the CUs the data-gradient kernels leave idle in their last, partial round of
     tiles, and it overlaps the HBM-bound BatchNorm backward kernels of the layers below. The
     main stream re-joins at the end of `Tape.backward`; the gradient reducer waits for the side
-    stream on its own stream."""
+    stream on its own stream. final: this is the LAST contribution to inp's gradient (the main
+    branch of the layer that follows inp's producer: every other consumer of inp is a residual
+    branch of a LATER block end, whose backward has already run)."""
     self.backward_weights(inp, dy, f)
     if inp.requires_grad:
       if self.stride != 1:
         raise NotImplementedError("data-gradient of a strided conv")
       g = inp.grad_buffer()
       tin = inp.data.shape[1]
-      capi.conv1d_fwd(dy, self.kernel.wt16, dil=self.dil,
-                      pad_left=(self.k - 1) * self.dil - f["pad_left"], tout=tin, out=g,
+      pl = (self.k - 1) * self.dil - f["pad_left"]
+      if final and FUSE_BN_BWD and inp.bn_y is not None and dy.is_contiguous() and g.is_contiguous():
+        # the producer's ReLU / dropout backward and its BatchNorm-backward partial sums ride in this
+        # launch's epilogue: its own reduction pass (bn_act_bwd_reduce) is skipped
+        inp.bias_part = capi.conv1d_dgrad_bnact(dy, self.kernel.wt16, g, dil=self.dil, pad_left=pl,
+                                                accumulate=inp.grad_init, out_len=inp.lens,
+                                                mask_ref=inp.data, mask_scale=inp.bn_scale, stat_ref=inp.bn_y)
+        inp.grad_init = True
+        inp.grad_masked = True
+        return
+      capi.conv1d_fwd(dy, self.kernel.wt16, dil=self.dil, pad_left=pl, tout=tin, out=g,
                       accumulate=inp.grad_init, out_len=inp.lens)
       inp.grad_init = True
 
@@ -494,6 +515,11 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
   result = Act(out, out_lens if mask_output else None)
   if not (training and tape is not None):
     return result
+  if FUSE_BN_BWD and len(fw) == 1 and act == 1 and type(main) is ConvBN and not dropped and \
+     (lens is None or main.stride == 1):
+    # single-input conv + BatchNorm + ReLU (+ dropout): out is zero exactly where the gradient is
+    result.bn_y = fw[0]["y"]
+    result.bn_scale = 1.0 / (keep_prob if training else 1.0)
 
   def backward():
     dout = result.grad
@@ -502,17 +528,27 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     assert dout is not None, "no gradient reached " + main.name
     rows = B * tout
     J = len(branches)
-    dz = torch.empty_like(out)
-    partial = torch.empty((capi.bn_act_bwd_num_parts(rows), 1 + J, C), dtype=torch.float32,
-                          device=out.device)
-    capi.bn_act_bwd_reduce(dout, out, [f["y"] for f in fw], [f["mean"] for f in fw],
-                           [f["rstd"] for f in fw], dz, partial, lens, act, keep_prob, seed)
-    result.grad = None
-    # dgamma / dbeta / the two means of every branch in ONE launch
     c1 = torch.empty((J, C), dtype=torch.float32, device=out.device)
     c2 = torch.empty((J, C), dtype=torch.float32, device=out.device)
-    capi.bn_bwd_finalize_multi(partial, rows, [br.gamma.grad for br in branches],
-                               [br.beta.grad for br in branches], True, c1, c2)
+    dz_to_len = False
+    if result.grad_masked:
+      # the data gradient that finalised `dout` already applied the ReLU / dropout backward and left
+      # (sum dz, sum dz * y) per 128-row window: no reduction pass (ConvBN.backward_branch, final=True)
+      dz, partial = dout, result.bias_part
+      result.bias_part = None
+      capi.bn_bwd_finalize_raw(partial, rows, fw[0]["mean"], fw[0]["rstd"], branches[0].gamma.grad,
+                               branches[0].beta.grad, True, c1[0], c2[0])
+      dz_to_len = lens is not None       # rows past the sequence ends were not written: zero, unread
+    else:
+      dz = torch.empty_like(out)
+      partial = torch.empty((capi.bn_act_bwd_num_parts(rows), 1 + J, C), dtype=torch.float32,
+                            device=out.device)
+      capi.bn_act_bwd_reduce(dout, out, [f["y"] for f in fw], [f["mean"] for f in fw],
+                             [f["rstd"] for f in fw], dz, partial, lens, act, keep_prob, seed)
+      # dgamma / dbeta / the two means of every branch in ONE launch
+      capi.bn_bwd_finalize_multi(partial, rows, [br.gamma.grad for br in branches],
+                                 [br.beta.grad for br in branches], True, c1, c2)
+    result.grad = None
     grouped = []        # plain 1x1 residual branches: their data gradients go out in one launch
     wgrouped = []       # ... and so do their weight gradients
     # (one launch = one (B, T) and one length vector: the predicate of the forward grouping)
@@ -526,7 +562,8 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
       # (wgrad pairs it with the masked input, dgrad only produces live rows): the rest is not computed
       ragged = lens is not None and type(br) is ConvBN and br.stride == 1
       capi.bn_bwd_apply(dz, f["y"], br.gamma.master, f["mean"], f["rstd"], c1[j], c2[j], dy,
-                        out_len=lens if ragged else None, margin=(br.k - 1) * br.dil)
+                        out_len=lens if ragged else None, margin=(br.k - 1) * br.dil,
+                        dz_to_len=dz_to_len and ragged)
       f["y"] = None
       if can_group and j in plain:
         if GROUP_WGRAD:
@@ -535,6 +572,8 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
           br.backward_weights(inp, dy, f)
         if inp.requires_grad:
           grouped.append((br, inp, dy))
+      elif j == 0 and type(br) is ConvBN:
+        br.backward_branch(inp, dy, f, final=True)     # the last contribution to its input's gradient
       else:
         br.backward_branch(inp, dy, f)
     if wgrouped:
