@@ -62,6 +62,22 @@ __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_fwd_kernel(AdCellFwd p)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int j0 = blockIdx.x * 8, b0 = blockIdx.y * 32;
   const int H = p.H;
+  // the epilogue operands of this lane's (unit, sample) are fetched BEFORE the weight stream so that
+  // their round trip overlaps it instead of following the reduction (as rnn.hip does)
+  const int eb = b0 + l31, ej = j0 + wave + 4 * lhi;
+  const bool elive = wave < 4 && eb < p.B && ej < H && !(p.lens && p.t >= p.lens[eb]);
+  float e_gx[4] = {0.f, 0.f, 0.f, 0.f}, e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_sc[4] = {1.f, 1.f, 1.f, 1.f};
+  float e_cprev = 0.f;
+  if (elive) {
+    const long long erow = (long long)eb * p.T + p.t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (p.w8) e_sc[g] = p.w8_scale[g * H + ej];
+      if (p.gx) e_gx[g] = bf2f(p.gx[erow * (4 * H) + (long long)g * H + ej]);
+      if (p.bias) e_bias[g] = p.bias[g * H + ej];
+    }
+    if (p.t > 0) e_cprev = p.c_seq[(erow - 1) * H + ej];
+  }
   f32x16 accw;
 #pragma unroll
   for (int e = 0; e < 16; ++e) accw[e] = 0.f;
@@ -86,12 +102,8 @@ __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_fwd_kernel(AdCellFwd p)
   if (j >= H) return;
   const long long row = (long long)b * p.T + p.t;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (p.w8) pre[g] *= p.w8_scale[g * H + j];       // per-row scale of the e4m3 weights
-    if (p.gx) pre[g] += bf2f(p.gx[row * (4 * H) + (long long)g * H + j]);
-    if (p.bias) pre[g] += p.bias[g * H + j];
-  }
-  const float cprev = p.t > 0 ? p.c_seq[(row - 1) * H + j] : 0.f;
+  for (int g = 0; g < 4; ++g) pre[g] = pre[g] * e_sc[g] + e_gx[g] + e_bias[g];   // (scale: e4m3 weight rows)
+  const float cprev = e_cprev;
   const float ig = sigmoidf_(pre[0]), gg = tanhf(pre[1]);
   const float fg = sigmoidf_(pre[2] + p.forget_bias), og = sigmoidf_(pre[3]);
   const float cn = cprev * fg + ig * gg;
@@ -1225,7 +1237,10 @@ struct AdCellBwd {
 // 64 KB slices (rows 8..31 of the MFMA tile are padding). Both products are accumulated before
 // ONE reduction through LDS.
 constexpr int kCellBwdRows = 8;
-constexpr int kCellBwdCols = 32;   // samples per workgroup. (8 samples per workgroup — a quarter of the
+constexpr int kCellBwdCols = 32;   // samples per workgroup. (Fetching wave 0's epilogue operands before the
+                                   // products — in registers: spills at the 128-register budget of 16 waves; by
+                                   // LDS-DMA: no spill — left the step at 95 us either way: not kept.)
+                                   // (8 samples per workgroup — a quarter of the
                                    // gate-gradient bytes per CU, 4x the workgroups re-reading the weight
                                    // slices — was slower: 29.8 vs 26.4 us; the step is five dependent
                                    // rounds of loads, not bytes per CU.)
