@@ -115,26 +115,31 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
 // translation unit; device code is not linked across TUs).
 static __device__ __attribute__((aligned(256))) uint32_t g_zero_page[64];
 
+// 4 keep/drop decisions (elements idx4*4 .. idx4*4 + 3) from the mixing state
+// z0 = idx4 * kDropGolden + seed: one 64-bit mix -> four 16-bit uniforms, keep iff u16 < thr
+// (thr = keep * 65536). Callers that walk idx4 in constant steps add step * kDropGolden to z0
+// instead of redoing the first multiply.
+constexpr unsigned long long kDropGolden = 0x9E3779B97F4A7C15ull;
+__device__ __forceinline__ uint32_t dropout_bits4_z(unsigned long long z, uint32_t thr) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t u = (uint32_t)(z >> (16 * e)) & 0xffffu;
+    bits |= (u < thr ? 1u : 0u) << e;
+  }
+  return bits;
+}
 // 8 keep/drop decisions for the 8 channels starting at element index idx8*8:
-// two 64-bit mixes -> eight 16-bit uniforms, keep iff u16 < keep*65536.
+// two 64-bit mixes (idx4 = idx8*2, idx8*2 + 1) -> eight 16-bit uniforms, keep iff u16 < keep*65536.
 __device__ __forceinline__ uint32_t dropout_bits8(unsigned long long seed,
                                                   unsigned long long idx8,
                                                   float keep_prob) {
   const uint32_t thr = (uint32_t)(keep_prob * 65536.0f);
-  uint32_t bits = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    unsigned long long z = (idx8 * 2 + h) * 0x9E3779B97F4A7C15ull + seed;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t u = (uint32_t)(z >> (16 * e)) & 0xffffu;
-      bits |= (u < thr ? 1u : 0u) << (h * 4 + e);
-    }
-  }
-  return bits;
+  const unsigned long long z0 = (idx8 * 2) * kDropGolden + seed;
+  return dropout_bits4_z(z0, thr) | (dropout_bits4_z(z0 + kDropGolden, thr) << 4);
 }
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

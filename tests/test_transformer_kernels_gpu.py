@@ -29,13 +29,18 @@ def _cu(lens, dev):
 
 @pytest.mark.parametrize("causal,cross", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("keep", [1.0, 0.9])
-def test_attention_fwd_bwd(cuda, causal, cross, keep):
+@pytest.mark.parametrize("lens", [([64, 17, 1, 33, 56], [40, 64, 9, 2, 56]),
+                                  ([32, 16, 48, 31, 49], [16, 32, 33, 64, 15])])
+def test_attention_fwd_bwd(cuda, causal, cross, keep, lens):
+  """Lengths on both sides of the 16- and 32-row block edges: the kernels skip whole 32 x 32 blocks
+  (and 16-row reduction steps) past a sequence's length or above the causal diagonal; outputs are
+  allocated with torch.empty so a skipped store shows."""
   from openseq2seq_amd import capi
   g = torch.Generator().manual_seed(7 + causal + 2 * cross)
   B, H, dh = 5, 3, 64
   D = H * dh
-  lq = [64, 17, 1, 33, 56]
-  lk = [40, 64, 9, 2, 56] if cross else lq
+  lq = lens[0]
+  lk = lens[1] if cross else lq
   q = _bf(torch.randn(sum(lq), D, generator=g))
   k = _bf(torch.randn(sum(lk), D, generator=g))
   v = _bf(torch.randn(sum(lk), D, generator=g))
@@ -63,6 +68,8 @@ def test_attention_fwd_bwd(cuda, causal, cross, keep):
     if causal:
       S = S + ot.get_decoder_self_attention_bias(lq[b])[0, 0][:, :lk[b]]
     P = torch.softmax(S, -1)
+    lse_ref = torch.logsumexp(S.detach(), -1).transpose(0, 1)         # [lq, H]
+    torch.testing.assert_close(lse[oq:oq + lq[b]].cpu(), lse_ref, rtol=2e-3, atol=2e-3)
     if keep < 1.0:
       # the device mask: element ((b*H+h)*64 + q)*64 + key
       n = B * H * 64 * 64
