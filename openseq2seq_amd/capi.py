@@ -143,6 +143,49 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
   return out
 
 
+class _ZeroArena(object):
+  """fp32 scratch that must read as zeros when handed out (per-window statistic partials that dead
+  windows never write): ONE fill per backward pass instead of one 7 us fill launch per layer. take()
+  falls back to torch.zeros until reset() has seen the pass's total demand once."""
+
+  def __init__(self):
+    self.buf, self.cursor, self.demand = None, 0, 0
+
+  def reset(self):
+    if self.demand == 0 and self.buf is None:
+      return
+    if self.buf is None or self.demand > self.buf.numel():
+      self.buf = torch.zeros(self.demand, dtype=torch.float32, device=self._device) if self.demand else None
+    elif self.cursor:
+      self.buf[:self.cursor].zero_()
+    self.cursor, self.demand = 0, 0
+
+  def take(self, shape, device):
+    n = 1
+    for d in shape:
+      n *= int(d)
+    n = (n + 63) & ~63
+    self.demand += n
+    self._device = device
+    if self.buf is None or self.buf.device != device or self.cursor + n > self.buf.numel():
+      return torch.zeros(shape, dtype=torch.float32, device=device)
+    out = self.buf[self.cursor:self.cursor + n]
+    self.cursor += n
+    m = 1
+    for d in shape:
+      m *= int(d)
+    return out[:m].view(shape)
+
+
+_zero_arena = _ZeroArena()
+
+
+def zero_arena_reset():
+  """Start of a backward pass (Tape.backward): every slice handed out so far is dead (the pass that
+  used them joined its side streams), re-zero what was used."""
+  _zero_arena.reset()
+
+
 def conv1d_dgrad_bnact(dy, wt, dx, *, dil, pad_left, accumulate, out_len, mask_ref, mask_scale, stat_ref):
   """dx (+)= conv(dy, wt) (stride 1), then dz = (mask_ref > 0) ? dx * mask_scale : 0 written to dx;
   returns the BatchNorm-backward partials [num_mtiles(B, T), 2, C] = (sum dz, sum dz * stat_ref) per
@@ -153,7 +196,7 @@ def conv1d_dgrad_bnact(dy, wt, dx, *, dil, pad_left, accumulate, out_len, mask_r
   Tout = dx.shape[1]
   assert tuple(dx.shape) == (B, Tout, Cout) == tuple(mask_ref.shape) == tuple(stat_ref.shape)
   assert dx.is_contiguous() and mask_ref.is_contiguous() and stat_ref.is_contiguous() and dy.is_contiguous()
-  stats = torch.zeros((conv1d_num_mtiles(B, Tout), 2, Cout), dtype=torch.float32, device=dy.device)
+  stats = _zero_arena.take((conv1d_num_mtiles(B, Tout), 2, Cout), dy.device)
   ws = conv1d_workspace(dy.device)
   f = _fn("os2s_conv1d_dgrad_bnact_ws",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -18,6 +18,7 @@
 //      beta_t(s) - logp_t(l'_s) - ll) (a posterior, <= 1) the per-class sums are
 //      a dense one-hot product over the extended label — deterministic, no
 //      atomics:  dlogit[t,v] = softmax_t(v) - sum_{s: l'_s = v} e_s.
+#include <cstdlib>
 #include "os2s_common.hpp"
 
 namespace os2s {
@@ -59,7 +60,7 @@ constexpr int kTC = 32;  // time steps of log-probs prefetched per chunk
 __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
     const float* __restrict__ logp, const int32_t* __restrict__ labels, int Lmax,
     const int32_t* __restrict__ label_len, const int32_t* __restrict__ in_len, int T,
-    int B, int V, int blank, int Smax, float* __restrict__ alpha,
+    int B, int V, int blank, int Smax, int Sld, float* __restrict__ alpha,
     float* __restrict__ beta, double* __restrict__ coff_a, double* __restrict__ coff_b,
     double* __restrict__ loglik, int32_t* __restrict__ valid) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
     if (dir == 0 && threadIdx.x == 0) { loglik[b] = 0.0; valid[b] = 0; }
     return;
   }
-  float* outp = (dir == 0 ? alpha : beta) + (long long)b * T * Smax;
+  float* outp = (dir == 0 ? alpha : beta) + (long long)b * T * Sld;      // rows of Sld floats (Sld % 16 == 0)
   double* coff = (dir == 0 ? coff_a : coff_b) + (long long)b * T;
   // The stored rows are alpha_t(s) - C_t with C_t a running normaliser kept in
   // double: fp32 alphas that grow like -3.4*t lose ~1e-4 absolute per step.
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
         }
         if (v < kNegInf) v = kNegInf;
         cur[s] = v;
-        outp[(long long)t * Smax + s] = v;
+        outp[(long long)t * Sld + s] = v;
       }
       if (threadIdx.x == 0) coff[t] = C;
       __syncthreads();
@@ -164,13 +165,196 @@ __global__ __launch_bounds__(256) void ctc_alpha_beta_kernel(
   }
 }
 
+// The same recursion with ONE WAVE per (sample, direction) and no barrier at all: lane i owns the
+// KS consecutive states i*KS .. i*KS + KS - 1 in registers, so prev[s - 1] / prev[s - 2] are register
+// renames except at the lane edge (two DPP wave shifts per time step), blank and label states
+// alternate with the register index (KS even: two-term / three-term logsumexp decided at compile
+// time), the row maximum is a DPP reduction, and the log-prob chunks are double-buffered in LDS by
+// the wave itself. The 256-thread kernel above pays a workgroup barrier per time step
+// (0.84 us x 835 frames at the Jasper shape); this one ~0.4 us. S <= 64 * KS.
+// No "all terms are -inf" case to guard: the sentinel is the FINITE -1e30, whose fp32 spacing is 7.6e22, so
+// -1e30 + log(3) and -1e30 + log_prob are -1e30 again — a dead state stays exactly at the sentinel.
+__device__ __forceinline__ float lse2m(float a, float b) {       // max + log(1 + exp(min - max))
+  const float mx = fmaxf(a, b), mn = fminf(a, b);
+  return mx + 0.6931471805599453f * __log2f(1.f + __builtin_amdgcn_exp2f((mn - mx) * 1.4426950408889634f));
+}
+__device__ __forceinline__ float lse3m(float a, float b, float c) {
+  const float mx = fmaxf(a, fmaxf(b, c));
+  const float md = __builtin_amdgcn_fmed3f(a, b, c), mn = fminf(a, fminf(b, c));
+  return mx + 0.6931471805599453f * __log2f(1.f + __builtin_amdgcn_exp2f((md - mx) * 1.4426950408889634f) +
+                                            __builtin_amdgcn_exp2f((mn - mx) * 1.4426950408889634f));
+}
+// lane i <- lane i - 1 (lane 0 <- fill) / lane i <- lane i + 1 (lane 63 <- fill)
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <int KS>
+__global__ __launch_bounds__(64) void ctc_alpha_beta_wave_kernel(
+    const float* __restrict__ logp, const int32_t* __restrict__ labels, int Lmax,
+    const int32_t* __restrict__ label_len, const int32_t* __restrict__ in_len, int T,
+    int B, int V, int blank, int Smax, int Sld, float* __restrict__ alpha,
+    float* __restrict__ beta, double* __restrict__ coff_a, double* __restrict__ coff_b,
+    double* __restrict__ loglik, int32_t* __restrict__ valid) {
+  static_assert(KS % 4 == 0, "blank / label states alternate with the register index; 16-byte row pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* const lp = reinterpret_cast<float*>(smem_raw);          // [2][kTC][V]
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x >> 1, dir = blockIdx.x & 1;
+  int L = label_len[b];
+  L = L < 0 ? 0 : (L > Lmax ? Lmax : L);
+  int Tb = in_len[b];
+  Tb = Tb < 0 ? 0 : (Tb > T ? T : Tb);
+  const int S = 2 * L + 1;
+  const int32_t* labb = labels + (long long)b * Lmax;
+  // odd registers: label (s >> 1); jump2[k]: the skip transition into (alpha) / out of (beta) state s
+  int lab[KS / 2];
+  bool jump2[KS / 2];
+  int rep = 0;
+#pragma unroll
+  for (int h = 0; h < KS / 2; ++h) {
+    const int s = lane * KS + 2 * h + 1, li = s >> 1;
+    const bool in = s < S;
+    const int l = in ? labb[li] : blank;
+    lab[h] = l;
+    const bool same_prev = in && s >= 3 && labb[li - 1] == l;
+    rep += (int)__popcll(__ballot(same_prev));
+    if (dir == 0) jump2[h] = in && s >= 3 && l != blank && !same_prev;
+    else jump2[h] = in && s + 2 < S && l != blank && labb[li + 1] != l;
+  }
+  const bool ok = (Tb > 0) && (L + rep <= Tb);
+  if (!ok) {
+    if (dir == 0 && lane == 0) { loglik[b] = 0.0; valid[b] = 0; }
+    return;
+  }
+  float* outp = (dir == 0 ? alpha : beta) + (long long)b * T * Sld;      // rows of Sld floats (Sld % 16 == 0)
+  double* coff = (dir == 0 ? coff_a : coff_b) + (long long)b * T;
+  const float* lpb = logp + (long long)b * T * V;
+  double C = 0.0;
+  float a[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) a[k] = kNegInf;
+
+  constexpr int kLoads = 16;                  // 64 * 16 >= kTC * V for V <= 32
+  const int nchunk = (Tb + kTC - 1) / kTC;
+  float pre[kLoads];
+  auto fetch = [&](int c0) {
+    const int n = min(kTC, Tb - c0);
+#pragma unroll
+    for (int r = 0; r < kLoads; ++r) {
+      const int i = lane + 64 * r;
+      const int j = i / V, v = i - j * V;
+      const int t = dir == 0 ? (c0 + j) : (Tb - 1 - (c0 + j));
+      pre[r] = i < n * V ? lpb[(long long)t * V + v] : 0.f;
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < kLoads; ++r) {
+      const int i = lane + 64 * r;
+      if (i < kTC * V) lp[buf * kTC * V + i] = pre[r];
+    }
+  };
+  fetch(0);
+  park(0);
+  for (int c = 0; c < nchunk; ++c) {
+    const int c0 = c * kTC, n = min(kTC, Tb - c0);
+    if (c + 1 < nchunk) fetch(c0 + kTC);       // in flight under this chunk's steps
+    const float* lpc = lp + (c & 1) * kTC * V;
+    for (int j = 0; j < n; ++j) {
+      const int step = c0 + j;
+      const int t = dir == 0 ? step : (Tb - 1 - step);
+      const float* lpr = lpc + j * V;
+      const float pb = lpr[blank];
+      float pl[KS / 2];
+#pragma unroll
+      for (int h = 0; h < KS / 2; ++h) pl[h] = lpr[lab[h]];
+      float v[KS];
+      if (step == 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const int s = lane * KS + k;
+          const bool start = dir == 0 ? s <= 1 : (s >= S - 2 && s < S);
+          v[k] = start ? ((k & 1) ? pl[k >> 1] : pb) : kNegInf;
+        }
+      } else if (dir == 0) {
+        // prev[s - 1] / prev[s - 2]: registers k - 1 / k - 2, or the previous lane's last register
+        const float e1 = wave_shr1(a[KS - 1], kNegInf);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const float a1 = k >= 1 ? a[k - 1] : e1;
+          if (k & 1) {
+            const float a2 = k >= 3 ? a[k - 2] : e1;         // k = 1: state s - 2 is the previous lane's KS - 1
+            v[k] = lse3m(a[k], a1, jump2[k >> 1] ? a2 : kNegInf) + pl[k >> 1];
+          } else {
+            v[k] = lse2m(a[k], a1) + pb;
+          }
+        }
+      } else {
+        const float e1 = wave_shl1(a[0], kNegInf), e2 = wave_shl1(a[1], kNegInf);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const float a1 = k + 1 < KS ? a[k + 1] : e1;
+          if (k & 1) {
+            const float a2 = k + 2 < KS ? a[k + 2] : e2;     // k = KS - 1: state s + 2 is the next lane's register 1
+            v[k] = lse3m(a[k], a1, jump2[k >> 1] ? a2 : kNegInf) + pl[k >> 1];
+          } else {
+            v[k] = lse2m(a[k], a1) + pb;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KS; ++k) a[k] = lane * KS + k < S ? v[k] : kNegInf;
+      if (lane * KS < Sld) {       // whole 16-byte groups: a row is padded to Sld (entries >= S are never read)
+        float* const orow = outp + (long long)t * Sld + lane * KS;
+#pragma unroll
+        for (int k4 = 0; k4 < KS / 4; ++k4)
+          *reinterpret_cast<f32x4*>(orow + 4 * k4) = f32x4{a[4 * k4], a[4 * k4 + 1], a[4 * k4 + 2], a[4 * k4 + 3]};
+      }
+      if (lane == 0) coff[t] = C;
+      if ((step & 7) == 7 && step + 1 < Tb) {
+        float m = kNegInf;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) m = fmaxf(m, a[k]);
+        m = wave_max_dpp(m);
+        if (m > kNegInf * 0.5f) {
+#pragma unroll
+          for (int k = 0; k < KS; ++k) a[k] = a[k] > kNegInf * 0.5f ? a[k] - m : kNegInf;
+          C += (double)m;
+        }
+      }
+    }
+    if (c + 1 < nchunk) park((c + 1) & 1);
+  }
+  if (dir == 0) {
+    // states S - 1 and S - 2 live in lanes (S - 1) / KS and (S - 2) / KS
+    float last1 = kNegInf, last2 = kNegInf;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int s = lane * KS + k;
+      if (s == S - 1) last1 = a[k];
+      if (s == S - 2) last2 = a[k];
+    }
+    last1 = wave_max_dpp(last1);
+    last2 = wave_max_dpp(last2);
+    if (lane == 0) {
+      const float l2 = S >= 2 ? lse2(last1, last2) : last1;
+      loglik[b] = C + (double)l2;
+      valid[b] = (l2 > kNegInf * 0.5f && isfinite(l2)) ? 1 : 0;
+    }
+  }
+}
+
 constexpr int kGR = 8;  // time rows per gradient block
 
 // grid = (ceil(T/kGR), B). thread -> (row r = tid/32, class lane v = tid%32 (+32k))
 __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ logp, const int32_t* __restrict__ labels, int Lmax,
     const int32_t* __restrict__ label_len, const int32_t* __restrict__ in_len, int T,
-    int B, int V, int blank, int Smax, const float* __restrict__ alpha,
+    int B, int V, int blank, int Smax, int Sld, const float* __restrict__ alpha,
     const float* __restrict__ beta, const double* __restrict__ coff_a,
     const double* __restrict__ coff_b, const double* __restrict__ loglik,
     const int32_t* __restrict__ valid, float grad_scale_host,
@@ -200,8 +384,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
       const int tt = t0 + rr;
       if (tt < Tb) {
         const float off = (float)(coff_a[(long long)b * T + tt] + coff_b[(long long)b * T + tt] - ll);
-        const float* al = alpha + ((long long)b * T + tt) * Smax;
-        const float* be = beta + ((long long)b * T + tt) * Smax;
+        const float* al = alpha + ((long long)b * T + tt) * Sld;
+        const float* be = beta + ((long long)b * T + tt) * Sld;
         const float* lpr = logp + ((long long)b * T + tt) * V;
         for (int s = threadIdx.x; s < S; s += 256) {
           const float x = (al[s] + be[s] - lpr[lab[s]]) + off;
@@ -253,12 +437,17 @@ __global__ void ctc_finish_kernel(const double* __restrict__ loglik,
 
 using namespace os2s;
 
+// workspace sections, each a multiple of 256 bytes; alpha / beta rows are padded to Sld = 16-float
+// multiples so that the one-wave kernel stores whole 16-byte groups
+static inline size_t ctc_round256(size_t n) { return (n + 255) & ~(size_t)255; }
+static inline int ctc_row_floats(int Lmax) { return (2 * Lmax + 1 + 15) & ~15; }
+
 extern "C" size_t os2s_ctc_loss_workspace_bytes(int T, int B, int V, int Lmax) {
-  const size_t Smax = 2 * (size_t)Lmax + 1;
-  size_t n = (size_t)B * T * V * 4;        // logp
-  n += 2 * (size_t)B * T * Smax * 4;       // alpha, beta
-  n += 2 * (size_t)B * T * 8;              // running normalisers (double)
-  n += (size_t)B * 16;                     // loglik (double), valid
+  const size_t Sld = (size_t)ctc_row_floats(Lmax);
+  size_t n = ctc_round256((size_t)B * T * V * 4);          // logp
+  n += 2 * ctc_round256((size_t)B * T * Sld * 4);          // alpha, beta
+  n += 2 * ctc_round256((size_t)B * T * 8);                // running normalisers (double)
+  n += ctc_round256((size_t)B * 16);                       // loglik (double), valid
   return n + 256;
 }
 
@@ -274,13 +463,13 @@ extern "C" int os2s_ctc_loss(os2s_stream_t stream_, const float* logits,
   if (dlogits_bf16) OS2S_REQUIRE(Vpad >= V && Vpad % 8 == 0);
   if (workspace_bytes < os2s_ctc_loss_workspace_bytes(T, B, V, Lmax)) return OS2S_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  const int Smax = 2 * Lmax + 1;
-  char* ws = (char*)workspace;
-  float* logp = (float*)ws; ws += (size_t)B * T * V * 4;
-  float* alpha = (float*)ws; ws += (size_t)B * T * Smax * 4;
-  float* beta = (float*)ws; ws += (size_t)B * T * Smax * 4;
-  double* coff_a = (double*)ws; ws += (size_t)B * T * 8;
-  double* coff_b = (double*)ws; ws += (size_t)B * T * 8;
+  const int Smax = 2 * Lmax + 1, Sld = ctc_row_floats(Lmax);
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float* logp = (float*)ws; ws += ctc_round256((size_t)B * T * V * 4);
+  float* alpha = (float*)ws; ws += ctc_round256((size_t)B * T * Sld * 4);
+  float* beta = (float*)ws; ws += ctc_round256((size_t)B * T * Sld * 4);
+  double* coff_a = (double*)ws; ws += ctc_round256((size_t)B * T * 8);
+  double* coff_b = (double*)ws; ws += ctc_round256((size_t)B * T * 8);
   double* ll = (double*)ws; ws += (size_t)B * 8;
   int32_t* valid = (int32_t*)ws;
 
@@ -289,11 +478,25 @@ extern "C" int os2s_ctc_loss(os2s_stream_t stream_, const float* logits,
   const size_t smem_ab = (size_t)Smax * 4 * 3 + (size_t)kTC * V * 4;
   const size_t smem_g = (size_t)Smax * 4 * (1 + kGR);
   if (smem_ab > 64 * 1024 || smem_g > 64 * 1024) return OS2S_ERR_UNSUPPORTED;
-  OS2S_LAUNCH(ctc_alpha_beta_kernel, dim3(2 * B), dim3(256), smem_ab, stream, logp, labels,
-              Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, coff_a, coff_b, ll, valid);
+  // one wave per (sample, direction) when the extended label fits 64 lanes x KS registers
+  static const bool wave_path = !(getenv("OS2S_CTC_WAVE") && atoi(getenv("OS2S_CTC_WAVE")) == 0);
+  const size_t smem_w = (size_t)2 * kTC * V * 4;
+  if (wave_path && V <= 32 && Smax <= 64 * 4) {
+    OS2S_LAUNCH(ctc_alpha_beta_wave_kernel<4>, dim3(2 * B), dim3(64), smem_w, stream, logp, labels,
+                Lmax, label_len, in_len, T, B, V, blank, Smax, Sld, alpha, beta, coff_a, coff_b, ll, valid);
+  } else if (wave_path && V <= 32 && Smax <= 64 * 8) {
+    OS2S_LAUNCH(ctc_alpha_beta_wave_kernel<8>, dim3(2 * B), dim3(64), smem_w, stream, logp, labels,
+                Lmax, label_len, in_len, T, B, V, blank, Smax, Sld, alpha, beta, coff_a, coff_b, ll, valid);
+  } else if (wave_path && V <= 32 && Smax <= 64 * 16) {
+    OS2S_LAUNCH(ctc_alpha_beta_wave_kernel<16>, dim3(2 * B), dim3(64), smem_w, stream, logp, labels,
+                Lmax, label_len, in_len, T, B, V, blank, Smax, Sld, alpha, beta, coff_a, coff_b, ll, valid);
+  } else {
+    OS2S_LAUNCH(ctc_alpha_beta_kernel, dim3(2 * B), dim3(256), smem_ab, stream, logp, labels,
+                Lmax, label_len, in_len, T, B, V, blank, Smax, Sld, alpha, beta, coff_a, coff_b, ll, valid);
+  }
   if (dlogits || dlogits_bf16) {
     OS2S_LAUNCH(ctc_grad_kernel, dim3(ceil_div(T, kGR), B), dim3(256), smem_g, stream, logp,
-                labels, Lmax, label_len, in_len, T, B, V, blank, Smax, alpha, beta, coff_a, coff_b,
+                labels, Lmax, label_len, in_len, T, B, V, blank, Smax, Sld, alpha, beta, coff_a, coff_b,
                 ll, valid, grad_scale, grad_scale_dev, dlogits, dlogits_bf16, Vpad);
   }
   OS2S_LAUNCH(ctc_finish_kernel, dim3(1), dim3(64), 0, stream, ll, valid, B, loss_per_sample,

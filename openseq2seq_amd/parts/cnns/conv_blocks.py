@@ -127,6 +127,7 @@ class Tape(object):
   def backward(self):
     # work parked on the side stream since the last join must have landed
     join_side_streams()
+    capi.zero_arena_reset()       # the previous pass's statistic partials are dead: one fill for this pass
     global _CUR_TAPE
     _CUR_TAPE, self._deferred, self._pending = self, [], None
     try:
