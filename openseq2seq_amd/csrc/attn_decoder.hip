@@ -57,6 +57,8 @@ struct AdCellFwd {
 // One workgroup = 8 hidden units x 32 samples: the 32 tile rows are (gate, unit) pairs
 // (row = 8*gate + unit), so H/8 workgroups stream disjoint 32-row slices of the weights and
 // after the split-K reduction a lane owns all four gates of one (unit, sample).
+// (20 slices per wave so that the Tacotron2 decoder LSTM, Kc = 2560, needs one round of loads instead
+// of a second, mostly empty one: 46.1 vs 46.4 us per forward step — not kept.)
 __global__ __launch_bounds__(64 * kAdWaves) void ad_cell_fwd_kernel(AdCellFwd p) {
   __shared__ float red[kAdWaves * 16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -517,6 +519,96 @@ __global__ __launch_bounds__(64 * kBwdWaves) void ad_dattn_kernel(AdDattn p) {
   if (b >= p.B || j >= p.M) return;
   f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
   *reinterpret_cast<f32x4*>(p.out + (long long)b * p.M + j) = o;
+}
+
+// The same product cut kDaSplit ways along the reduction, one FULL 32-row tile per workgroup and ONE
+// round of loads per wave; the pieces of a tile meet through a ticket exactly as in
+// ad_cell_bwd_split_kernel (deterministic: the last arriver sums the slabs in piece order).
+// M = 512, K = 4096: 16 x 8 = 128 workgroups of one round instead of 64 of two.
+constexpr int kDaSplit = 8;
+constexpr int kDaWaves = 8;
+constexpr int kDaSlices = 4;
+constexpr int kDaSlabFloats = 16 * 64;
+
+struct AdDattnSplit {
+  AdDattn g;
+  float* part;   // [M/32][B/32][kDaSplit][kDaSlabFloats]
+  int* ticket;   // [M/32][B/32], zero before and after every launch
+};
+
+__global__ __launch_bounds__(64 * kDaWaves) void ad_dattn_split_kernel(AdDattnSplit ps) {
+  const AdDattn& p = ps.g;
+  __shared__ float red[kDaWaves * 16 * 64];       // 32 KB
+  __shared__ int s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = blockIdx.x, kq = blockIdx.y, bb = blockIdx.z;
+  const int j0 = mb * 32, b0 = bb * 32;
+  const bool vrow = j0 + l31 < p.M;
+  const int brow = b0 + l31;
+  const bool vcol = brow < p.B;
+  const bf16_t* const wr = p.wT + (long long)(vrow ? j0 + l31 : 0) * p.K;
+  const bf16_t* const gr = p.dg + (long long)(vcol ? brow : 0) * p.ld;
+  const int nit = (p.K + 15) >> 4, nper = (nit + kDaSplit - 1) / kDaSplit;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (int base = 0; base < nper; base += kDaWaves * kDaSlices) {
+    u32x4 wa[kDaSlices], ga[kDaSlices];
+#pragma unroll
+    for (int i = 0; i < kDaSlices; ++i) {
+      const int s = kq * nper + base + wave + kDaWaves * i;
+      const int ko = min(s * 16 + lhi * 8, p.K - 8);
+      wa[i] = *reinterpret_cast<const u32x4*>(wr + ko);
+      ga[i] = *reinterpret_cast<const u32x4*>(gr + ko);
+    }
+#pragma unroll
+    for (int i = 0; i < kDaSlices; ++i) {
+      const int sl = base + wave + kDaWaves * i, s = kq * nper + sl;
+      const bool kv = sl < nper && s < nit && s * 16 + lhi * 8 < p.K;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (kv && vrow) ? wa[i] : zero),
+                                                    __builtin_bit_cast(bf16x8, (kv && vcol) ? ga[i] : zero), acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  float* const slab0 = ps.part + ((size_t)(mb * gridDim.z + bb) * kDaSplit) * kDaSlabFloats;
+#pragma unroll
+  for (int q = 0; q < kDaSlabFloats / (64 * kDaWaves); ++q) {
+    const int o = tid + 64 * kDaWaves * q;
+    float s = 0.f;
+#pragma unroll
+    for (int w2 = 0; w2 < kDaWaves; ++w2) s += red[w2 * 16 * 64 + o];
+    slab0[(size_t)kq * kDaSlabFloats + o] = s;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* const ticket = ps.ticket + mb * gridDim.z + bb;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_ticket = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_ticket != kDaSplit - 1) return;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // wave g < 4: rows 8g + 4*lhi + e of the tile (accumulator registers 4g + e), column = sample l31
+  if (wave >= 4 || !vcol) return;
+  const int j = j0 + 8 * wave + 4 * lhi;
+  if (j >= p.M) return;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  for (int pc = 0; pc < kDaSplit; ++pc) {
+    const float* const sl = slab0 + (size_t)pc * kDaSlabFloats;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += sl[(4 * wave + e) * 64 + lane];
+  }
+  *reinterpret_cast<f32x4*>(p.out + (long long)brow * p.M + j) = o;
 }
 
 // ------------------------------------------------------------------ attention backward
@@ -1814,6 +1906,8 @@ extern "C" size_t os2s_attn_decoder_bwd_workspace_bytes(const os2s_attn_decoder_
   // cell backward cut along the reduction: partial tiles + tickets per (32 units, 32 samples)
   const size_t nblk = (size_t)ceil_div(d->H, 32) * ceil_div(d->B, 32);
   n += nblk * kCbSplit * kCbSlabFloats + nblk + 64;
+  const size_t nda = (size_t)ceil_div(d->M, 32) * ceil_div(d->B, 32);        // d(attention input), same scheme
+  n += nda * kDaSplit * kDaSlabFloats + nda + 64;
   return n * sizeof(float) + 1024;
 }
 
@@ -1871,6 +1965,9 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
   float* const cb_part = ws; ws += ncb * kCbSplit * kCbSlabFloats;
   int* const cb_ticket = reinterpret_cast<int*>(ws); ws += ncb;
   const bool csplit = cell_split(d);
+  const size_t nda = (size_t)ceil_div(M, 32) * ceil_div(B, 32);
+  float* const da_part = ws; ws += nda * kDaSplit * kDaSlabFloats;
+  int* const da_ticket = reinterpret_cast<int*>(ws); ws += nda;
   const size_t lds_da = ((size_t)M + ceil_div(S, kLocCtxParts)) * sizeof(float);
   const size_t lds_sb = loc_bwd_lds_floats(S, K) * sizeof(float);
   if (split && lds_sb > 64 * 1024 &&
@@ -1896,7 +1993,14 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
       AdDattn g;
       g.B = B; g.M = M; g.K = (int)GH; g.wT = (const bf16_t*)gr->wcatT[0];
       g.dg = (const bf16_t*)gr->dg[0] + (long long)(t + 1) * GH; g.ld = (long long)T * GH; g.out = dattn;
-      OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 8), ceil_div(B, 32)), dim3(64 * kBwdWaves), 0, stream, g);
+      if (csplit && M % 4 == 0) {
+        AdDattnSplit gs;
+        gs.g = g; gs.part = da_part; gs.ticket = da_ticket;
+        OS2S_LAUNCH(ad_dattn_split_kernel, dim3(ceil_div(M, 32), kDaSplit, ceil_div(B, 32)), dim3(64 * kDaWaves), 0,
+                    stream, gs);
+      } else {
+        OS2S_LAUNCH(ad_dattn_kernel, dim3(ceil_div(M, 8), ceil_div(B, 32)), dim3(64 * kBwdWaves), 0, stream, g);
+      }
     }
     at.t = t; at.last = last;
     if (split) {
