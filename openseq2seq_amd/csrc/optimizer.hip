@@ -398,6 +398,37 @@ __global__ __launch_bounds__(256) void conv_weight_dgrad_copy_kernel(
   const int co0 = (r / tci) * 64, ci0 = (r % tci) * 64;
   const bf16_t* src = w16 + d.src_off + (long long)k * d.Cout * d.Cin;
   bf16_t* dst = wt16 + d.dst_off + (long long)(d.K - 1 - k) * d.Cin * d.Cout;
+  // 16-byte pieces on both sides when the rows allow it (every conv / dense layer of the models: channel
+  // counts are multiples of 8): 2-byte accesses moved 2.6 TB/s, a quarter of the instructions were
+  // address arithmetic per element
+  const bool vec = (d.Cin % 8 == 0) && (d.Cout % 8 == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) % 16 == 0);
+  if (vec) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int piece = it * 256 + threadIdx.x;
+      const int a = piece >> 3, b8 = piece & 7;          // a: co, 8 consecutive ci
+      const int co = co0 + a, ci = ci0 + b8 * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (co < d.Cout && ci < d.Cin) v = *reinterpret_cast<const u32x4*>(src + (long long)co * d.Cin + ci);
+      uint32_t* t32 = reinterpret_cast<uint32_t*>(&tile[a][b8 * 8]);     // 132-byte rows: 4-byte aligned
+      t32[0] = v[0]; t32[1] = v[1]; t32[2] = v[2]; t32[3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int piece = it * 256 + threadIdx.x;
+      const int a = piece >> 3, b8 = piece & 7;          // a: ci, 8 consecutive co
+      const int ci = ci0 + a, co = co0 + b8 * 8;
+      if (ci < d.Cin && co < d.Cout) {
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = (uint32_t)tile[b8 * 8 + 2 * e][a] | ((uint32_t)tile[b8 * 8 + 2 * e + 1][a] << 16);
+        *reinterpret_cast<u32x4*>(dst + (long long)ci * d.Cout + co) = v;
+      }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int a = i >> 6, b = i & 63;   // a: co, b: ci (contiguous)
     const int co = co0 + a, ci = ci0 + b;

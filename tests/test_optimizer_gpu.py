@@ -163,3 +163,27 @@ def test_iter_size_algebra_kat(cuda):
     np.testing.assert_allclose(p.master.cpu().numpy(), v - 0.1 * true_g * 4, atol=1e-6)
   with pytest.raises(ValueError):
     optimize_loss(store, "SGD", {}, lr_policies.fixed_lr, dict(learning_rate=0.1), iter_size=2)
+
+
+def test_conv_weight_dgrad_copies_every_shape_class(cuda):
+  """wT[k'][ci][co] = w[K-1-k'][co][ci], bit-exact, for the 16-byte-piece path (channel counts that are
+  multiples of 8: whole 64 x 64 tiles, ragged tiles, a single tile) and for the element path (a channel
+  count that is not a multiple of 8), in one batched launch as the optimizer step issues it."""
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  rng = np.random.RandomState(3)
+  shapes = [(3, 128, 64), (5, 136, 72), (1, 8, 1024), (2, 29, 64), (11, 40, 24), (1, 1024, 8), (4, 200, 264)]
+  store = FlatParams(cuda)
+  for i, s in enumerate(shapes):
+    store.add("w%d" % i, s, (rng.randn(*s)).astype(np.float32), kind="conv")
+  store.finalize()
+  torch.cuda.synchronize()
+  for p in store.params:
+    want = p.w16.float().cpu().flip(0).permute(0, 2, 1)
+    torch.testing.assert_close(p.wt16.float().cpu(), want, rtol=0, atol=0)
+  # and again after the weights change (the refresh every optimizer step ends with)
+  store.master.mul_(-0.5)
+  store.refresh_compute_copies()
+  torch.cuda.synchronize()
+  for p in store.params:
+    want = p.w16.float().cpu().flip(0).permute(0, 2, 1)
+    torch.testing.assert_close(p.wt16.float().cpu(), want, rtol=0, atol=0)
