@@ -675,12 +675,15 @@ def _lt_unsupported(e):
 
 
 def gemm(x2d, w, **kw):
-  """x2d [N,Cin] bf16, w [Cout,Cin] bf16 -> [N,Cout]. A bare matmul (no bias / activation /
+  """x2d [N,Cin] bf16, w [Cout,Cin] bf16 -> [N,Cout]. A matmul with at most an fp32 bias (no activation /
   dropout / residual / fp32 output) with enough rows runs on the 256 x 256 ping-pong tile
   (os2s_gemm_nt); everything else is the K=1 case of the in-tree conv1d_fwd kernel."""
-  plain = (all(kw.get(k) is None for k in ("bias", "residual", "stats", "in_len", "out_len"))
+  plain = (all(kw.get(k) is None for k in ("residual", "stats", "in_len", "out_len"))
            and not kw.get("act", 0) and not kw.get("out_f32", False) and not kw.get("time_major", False)
            and kw.get("keep_prob", 1.0) >= 1.0)
+  bias = kw.get("bias", None)
+  if bias is not None and (USE_LT or bias.dtype != torch.float32):
+    plain = False           # the ping-pong kernel adds an fp32 bias in its epilogue; the library route has none
   if plain and x2d.shape[0] >= LT_MIN_ROWS and x2d.stride(1) == 1 and w.stride(1) == 1:
     out_t = kw.get("out", None)
     if USE_LT:
@@ -691,7 +694,7 @@ def gemm(x2d, w, **kw):
           raise
     elif (x2d.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous() and x2d.stride(0) % 8 == 0
           and (out_t is None or (out_t.stride(1) == 1 and out_t.stride(0) % 8 == 0))):
-      return gemm_nt(x2d, w, out=out_t, accumulate=bool(kw.get("accumulate", False)))
+      return gemm_nt(x2d, w, out=out_t, bias=bias, accumulate=bool(kw.get("accumulate", False)))
   out = kw.pop("out", None)
   N, Cin = x2d.shape
   Cout = w.shape[0]
