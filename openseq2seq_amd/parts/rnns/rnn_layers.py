@@ -9,6 +9,7 @@ no concat is materialised), the recurrence is os2s_rnn_layer_fwd/bwd, and the we
 gradients are GEMMs over the saved gate gradients (h_{t-1} enters as a time-shifted
 operand of the wgrad kernel)."""
 import math
+import os
 
 import torch
 
@@ -18,6 +19,10 @@ from ..transformer.layers import _colsum_into
 
 CELLS = {"gru_cudnn": capi.CELL_GRU_CUDNN, "lstm_cudnn": capi.CELL_LSTM_CUDNN,
          "lstm_tf": capi.CELL_LSTM_TF}
+
+
+# rows (B x T) from which the recurrent weight gradient goes through the ping-pong TN GEMM
+SHIFTED_WH_MIN_ROWS = int(os.environ.get("OS2S_RNN_WH_GEMM_ROWS", "4096"))
 
 
 class RNNDirection(object):
@@ -68,8 +73,22 @@ class RNNDirection(object):
     if self.bh is not None:
       _colsum_into(dgr.view(B * T, GH), self.bh)
     # dWh += dgr^T . h_{t-1}: h_{t-1} is y shifted by one step in processing order
-    capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if self.reverse else 1), in_len=lens,
-                      out=self.wh.grad, accumulate=True)
+    if B * T >= SHIFTED_WH_MIN_ROWS and H % 8 == 0 and T > 1:
+      # as a plain TN GEMM over a shifted copy of y (the 256 x 256 ping-pong weight-gradient kernel:
+      # 165 -> ~90 us per DeepSpeech2 layer and direction) instead of the shifted-window K = 1 convolution
+      # gradient on the lockstep tile. Rows at or past a sample's length carry zero gate gradients, and
+      # y is zero there (the step kernels never write a finished sample), so the copy needs no mask.
+      ysh = torch.empty((B, T, H), dtype=y.dtype, device=y.device)
+      if self.reverse:
+        ysh[:, :-1] = y[:, 1:]
+        ysh[:, -1] = 0
+      else:
+        ysh[:, 1:] = y[:, :-1]
+        ysh[:, 0] = 0
+      capi.gemm_wgrad(ysh.view(B * T, H), dgr.view(B * T, GH), self.wh.grad.view(GH, H), accumulate=True)
+    else:
+      capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if self.reverse else 1), in_len=lens,
+                        out=self.wh.grad, accumulate=True)
 
   def forward(self, xs, lens, tape, y_view=None, dy_view_fn=None):
     """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H].

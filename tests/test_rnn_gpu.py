@@ -180,3 +180,37 @@ def test_gru_persistent_xcd_kernel_equals_step_launches(cuda, B, T, H):
       assert float((a * (~m)).abs().max()) == 0.0 and float((b * (~m)).abs().max()) == 0.0
       rel = float((a - b).norm() / (a.norm() + 1e-20))
       assert rel <= 1e-2, (d, name, rel)       # bf16 gate gradients through T steps, two summation orders
+
+
+@pytest.mark.parametrize("cell", ["gru_cudnn", "lstm_tf"])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("use_lens", [True, False])
+def test_recurrent_weight_gradient_gemm_path_equals_shifted_window_path(cuda, monkeypatch, cell, reverse, use_lens):
+  """dWh = sum_t dgr_t^T h_{t-1} two ways: the shifted-window K = 1 convolution gradient (small
+  batches) and the plain TN GEMM over a time-shifted copy of y (B x T >= 4096 rows: DeepSpeech2).
+  Same products, different summation order: rel-L2 <= 1e-3; ragged lengths and both directions
+  (the first processed step of a reversed sample must see h = 0, not the next sample's rows)."""
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.parts.rnns import rnn_layers
+  from openseq2seq_amd.parts.cnns.conv_blocks import Act, Tape
+  B, T, In, H = 6, 40, 64, 128
+  g = torch.Generator().manual_seed(5)
+  x = torch.randn(B, T, In, generator=g).to(torch.bfloat16).to(cuda)
+  dy = torch.randn(B, T, H, generator=g).to(torch.bfloat16).to(cuda)
+  lens = torch.tensor([40, 17, 33, 1, 40, 8], dtype=torch.int32).to(cuda) if use_lens else None
+  grads = []
+  for min_rows in (1, 10 ** 9):
+    monkeypatch.setattr(rnn_layers, "SHIFTED_WH_MIN_ROWS", min_rows)
+    torch.manual_seed(0)
+    store = FlatParams(cuda)
+    layer = rnn_layers.RNNDirection(store, "rnn", cell, [In], H, reverse=reverse, forget_bias=1.0)
+    store.finalize()
+    tape = Tape()
+    store.zero_grads()
+    out = layer.forward([Act(x, None)], lens, tape)
+    out.grad = dy.clone()
+    tape.backward()
+    torch.cuda.synchronize()
+    grads.append(layer.wh.grad.float().cpu().clone())
+  rel = float((grads[0] - grads[1]).norm() / grads[1].norm())
+  assert float(grads[1].abs().max()) > 0 and rel <= 1e-3, rel

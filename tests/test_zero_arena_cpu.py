@@ -1,0 +1,31 @@
+"""capi._ZeroArena (the per-backward-pass zeroed scratch for BatchNorm-backward statistic partials):
+every slice handed out reads as zeros, slices of one pass never overlap, and reset() re-zeroes what the
+previous pass dirtied. Host logic only (CPU tensors)."""
+import torch
+
+
+def test_zero_arena_hands_out_disjoint_zeroed_slices():
+  from openseq2seq_amd.capi import _ZeroArena
+  dev = torch.device("cpu")
+  arena = _ZeroArena()
+  arena.reset()                                   # nothing known yet: a no-op
+  shapes = [(7, 2, 24), (3, 2, 1024), (1, 2, 8)]
+  first = [arena.take(s, dev) for s in shapes]    # before the first reset: plain zero tensors
+  assert arena.buf is None and all(float(t.abs().sum()) == 0.0 and tuple(t.shape) == s for t, s in zip(first, shapes))
+  arena.reset()                                   # sized to the demand of that pass
+  assert arena.buf is not None and arena.buf.numel() >= sum(t.numel() for t in first)
+  for rounds in range(2):
+    got = [arena.take(s, dev) for s in shapes]
+    for t, s in zip(got, shapes):
+      assert tuple(t.shape) == s and float(t.abs().sum()) == 0.0
+      assert t.data_ptr() >= arena.buf.data_ptr() and t.data_ptr() < arena.buf.data_ptr() + arena.buf.numel() * 4
+    spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * 4) for t in got)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))     # disjoint
+    for t in got:
+      t.fill_(3.0)                                                  # a pass writes its partials
+    arena.reset()
+  # a pass that needs more than the buffer holds falls back to fresh zeros and grows the buffer next time
+  big = arena.take((64, 2, 4096), dev)
+  assert float(big.abs().sum()) == 0.0
+  arena.reset()
+  assert arena.buf.numel() >= big.numel()
