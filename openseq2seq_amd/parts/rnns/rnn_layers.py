@@ -14,7 +14,7 @@ import os
 import torch
 
 from ... import capi
-from ..cnns.conv_blocks import Act
+from ..cnns.conv_blocks import Act, on_side_stream
 from ..transformer.layers import _colsum_into
 
 CELLS = {"gru_cudnn": capi.CELL_GRU_CUDNN, "lstm_cudnn": capi.CELL_LSTM_CUDNN,
@@ -63,32 +63,38 @@ class RNNDirection(object):
     B, T, _ = xs[0].data.shape
     H, GH = self.H, self.G * self.H
     d2 = dgx.view(B * T, GH)
+    # the data gradients first, on the main stream (the layer below waits for them) ...
     for x, w in zip(xs, self.wx):
-      capi.gemm_wgrad(x.data.reshape(B * T, -1), d2, w.grad.view(GH, -1), accumulate=True)
       if x.requires_grad:
         g = x.grad_buffer()
         capi.gemm(d2, w.wt16.view(-1, GH), out=g.view(B * T, -1), accumulate=x.grad_init)
         x.grad_init = True
-    _colsum_into(d2, self.bx)
-    if self.bh is not None:
-      _colsum_into(dgr.view(B * T, GH), self.bh)
-    # dWh += dgr^T . h_{t-1}: h_{t-1} is y shifted by one step in processing order
-    if B * T >= SHIFTED_WH_MIN_ROWS and H % 8 == 0 and T > 1:
-      # as a plain TN GEMM over a shifted copy of y (the 256 x 256 ping-pong weight-gradient kernel:
-      # 165 -> ~90 us per DeepSpeech2 layer and direction) instead of the shifted-window K = 1 convolution
-      # gradient on the lockstep tile. Rows at or past a sample's length carry zero gate gradients, and
-      # y is zero there (the step kernels never write a finished sample), so the copy needs no mask.
-      ysh = torch.empty((B, T, H), dtype=y.dtype, device=y.device)
-      if self.reverse:
-        ysh[:, :-1] = y[:, 1:]
-        ysh[:, -1] = 0
+    # ... the parameter gradients on the side stream: nothing in the rest of backward reads them, and
+    # during the next layer's recurrence (ONE persistent launch on two XCDs for a DeepSpeech2 GRU layer)
+    # six XCDs have nothing else to do
+    with on_side_stream(dgx.device, dgx, dgr, y, *[x.data for x in xs]):
+      for x, w in zip(xs, self.wx):
+        capi.gemm_wgrad(x.data.reshape(B * T, -1), d2, w.grad.view(GH, -1), accumulate=True)
+      _colsum_into(d2, self.bx)
+      if self.bh is not None:
+        _colsum_into(dgr.view(B * T, GH), self.bh)
+      # dWh += dgr^T . h_{t-1}: h_{t-1} is y shifted by one step in processing order
+      if B * T >= SHIFTED_WH_MIN_ROWS and H % 8 == 0 and T > 1:
+        # as a plain TN GEMM over a shifted copy of y (the 256 x 256 ping-pong weight-gradient kernel:
+        # 165 -> ~90 us per DeepSpeech2 layer and direction) instead of the shifted-window K = 1 convolution
+        # gradient on the lockstep tile. Rows at or past a sample's length carry zero gate gradients, and
+        # y is zero there (the step kernels never write a finished sample), so the copy needs no mask.
+        ysh = torch.empty((B, T, H), dtype=y.dtype, device=y.device)
+        if self.reverse:
+          ysh[:, :-1] = y[:, 1:]
+          ysh[:, -1] = 0
+        else:
+          ysh[:, 1:] = y[:, :-1]
+          ysh[:, 0] = 0
+        capi.gemm_wgrad(ysh.view(B * T, H), dgr.view(B * T, GH), self.wh.grad.view(GH, H), accumulate=True)
       else:
-        ysh[:, 1:] = y[:, :-1]
-        ysh[:, 0] = 0
-      capi.gemm_wgrad(ysh.view(B * T, H), dgr.view(B * T, GH), self.wh.grad.view(GH, H), accumulate=True)
-    else:
-      capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if self.reverse else 1), in_len=lens,
-                        out=self.wh.grad, accumulate=True)
+        capi.conv1d_wgrad(y, dgr, 1, pad_left=(-1 if self.reverse else 1), in_len=lens,
+                          out=self.wh.grad, accumulate=True)
 
   def forward(self, xs, lens, tape, y_view=None, dy_view_fn=None):
     """xs: list of Act [B,T,In_i]; lens int32 [B] or None. Returns Act [B,T,H].
