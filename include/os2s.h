@@ -44,6 +44,12 @@ int os2s_abi_version(void);
 const char* os2s_strerror(int code);
 /* Detail of the last failed kernel launch on this thread (HIP error string). */
 const char* os2s_last_error_detail(void);
+/* Deterministic mode (default: environment OS2S_DETERMINISTIC, else off): a debugging aid. The kernels that
+ * accumulate parameter gradients with fp32 atomics from several workgroups (narrow / K = 1 / stride-2 conv
+ * and depthwise weight gradients, the embedding gradient, the style-token attention gradient) are
+ * launched in a single-contributor geometry instead: slower, bit-identical run to run. */
+int os2s_deterministic(void);
+void os2s_set_deterministic(int on);
 
 /* ------------------------------------------------------------------------
  * CTC greedy (best-path) decode.

@@ -93,6 +93,17 @@ def conv1d_num_mtiles(B, tout):
 _conv_ws = {}
 
 
+def set_deterministic(on):
+  """Deterministic mode of the library (os2s_set_deterministic; default = environment
+  OS2S_DETERMINISTIC): parameter-gradient kernels that use fp32 atomics across workgroups run in a
+  single-contributor launch geometry — slower, bit-identical run to run."""
+  _fn("os2s_set_deterministic", (c_int,), None)(int(bool(on)))
+
+
+def deterministic():
+  return bool(_fn("os2s_deterministic", (), c_int)())
+
+
 def conv1d_workspace(device):
   """Caller-owned workspace of os2s_conv1d_fwd_ws (tickets zeroed once): one per (device,
   stream) — launches that may overlap must not share one."""

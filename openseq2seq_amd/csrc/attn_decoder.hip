@@ -1157,10 +1157,16 @@ __global__ __launch_bounds__(256) void ad_loc_dalign_kernel(AdAttn p, AdLoc x) {
   }
 }
 
+// state-gradient slots a stream emits: its chunk of positions + one filter width, in whole 32-step blocks
+__host__ __device__ inline int loc_bwd_slab_pitch(int S) {
+  const int chunk = (S + kLocStreams - 1) / kLocStreams;
+  return ((chunk + kLocKMax + kLocKMax - 1) / kLocKMax) * kLocKMax;
+}
 __host__ __device__ inline size_t loc_bwd_lds_floats(int S, int K) {
-  // q, nv, bs | e, dal, de | cum (padded) | dcum_l (padded) | dwk_l per stream | dqp, dnvp | red | keys
+  // q, nv, bs | e, dal, de | cum (padded) | dcum_l (padded) | dwk_l per stream | dqp, dnvp | red | keys | dslab
   return (size_t)3 * kLocUnits + 3 * S + (S + kLocKMax) + (S + 2 * kLocKMax) +
-         (size_t)kLocStreams * K * kLocUnits + 2 * (size_t)kLocStreams * kLocUnits + 64 + (size_t)S * kLocUnits / 2;
+         (size_t)kLocStreams * K * kLocUnits + 2 * (size_t)kLocStreams * kLocUnits + 64 + (size_t)S * kLocUnits / 2 +
+         (size_t)kLocStreams * loc_bwd_slab_pitch(S);
 }
 
 __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p, AdLoc x) {
@@ -1181,6 +1187,11 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
   float* dnvp = dqp + kLocStreams * kLocUnits;
   float* red = dnvp + kLocStreams * kLocUnits;
   uint16_t* keys = reinterpret_cast<uint16_t*>(red + 64);
+  // [streams][pitch]: the state-gradient slots of every stream, summed over the streams in order below
+  // (an LDS float atomic per slot let up to four streams race on one position: last-bit differences
+  // from run to run)
+  float* dslab = red + 64 + (size_t)S * kLocUnits / 2;
+  const int spitch = loc_bwd_slab_pitch(S);
   const int slen = min(max(p.src_len[b], 0), S);
   const int u0 = part * kLocUnits;
   const long long row = (long long)b * p.T + p.t;
@@ -1202,7 +1213,6 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
       e[sp] = p.align_seq[row * S + sp];
       dal[sp] = sp < slen ? x.dal[(long long)b * S + sp] : 0.f;
     }
-    for (int i = tid; i < S + 2 * kLocKMax; i += kAttnThreads) dcum_l[i] = 0.f;
   }
   if (tid < kLocUnits) {
     const int u = u0 + tid;
@@ -1269,8 +1279,7 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
           // slot j is complete: the state gradient at position sp - padl (of this stream's range)
           const float gsum = half_sum_dpp(gw[j & 31]);
           gw[j & 31] = 0.f;
-          const int s2 = sp - padl;
-          if (ul == 31 && s2 >= -kLocKMax && s2 < S + kLocKMax) atomicAdd(&dcum_l[s2 + kLocKMax], gsum);
+          if (ul == 31 && i < spitch) dslab[st * spitch + i] = gsum;      // position c0 + i - padl
           cw[j & 31] = sp < S ? cum[min(sp, S) + kLocKMax] : 0.f;
         }
       }
@@ -1293,7 +1302,18 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_kernel(AdAttn p
     p.dbd_acc[(long long)b * U + u0 + tid] += dq;
   }
   float* dpo = x.dcum_part + ((long long)b * kLocParts + part) * S;
-  for (int sp = tid; sp < S; sp += kAttnThreads) dpo[sp] = dcum_l[sp + kLocKMax];
+  {
+    // position sp was slot sp + padl - w * chunk of stream w (slots 0 .. nemit - 1 were written by every stream)
+    const int nemit = ((chunk + 2 * kLocKMax - 1) / kLocKMax) * kLocKMax;
+    for (int sp = tid; sp < S; sp += kAttnThreads) {
+      float a = 0.f;
+      for (int w = 0; w < kLocStreams; ++w) {
+        const int i = sp + padl - w * chunk;
+        if (i >= 0 && i < nemit) a += dslab[w * spitch + i];
+      }
+      dpo[sp] = a;
+    }
+  }
   float* dwa = p.dwck_acc + (long long)b * K * U;
   for (int i = tid; i < K * kLocUnits; i += kAttnThreads) {
     float a = 0.f;

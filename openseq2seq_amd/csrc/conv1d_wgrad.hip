@@ -1244,6 +1244,7 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
     const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;   // >= 8 steps per block
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
+    if (os2s_deterministic()) nsplit = 1;     // one add per dW element
   }
   a.steps_per_split = ceil_div(total_steps, nsplit);
   a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
@@ -1306,7 +1307,7 @@ extern "C" int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad
   int nsplit = ceil_div(512, tiles);
   const int max_split = total_steps / 8 > 0 ? total_steps / 8 : 1;
   if (nsplit > max_split) nsplit = max_split;
-  if (tiles >= 256 || nsplit < 1) nsplit = 1;
+  if (tiles >= 256 || nsplit < 1 || os2s_deterministic()) nsplit = 1;
   WgradArgs a;
   a.x = nullptr; a.dy = nullptr; a.dw = nullptr; a.in_len = in_len;
   a.B = B; a.Tin = T; a.Tout = T; a.Cin = 0; a.Cout = 0; a.K = 1;

@@ -21,6 +21,7 @@ struct DwArgs {
   const bf16_t* x; const float* w; bf16_t* y; const bf16_t* dy; float* dw;
   const int32_t* in_len; const int32_t* out_len;
   int B, Tin, Tout, C, K, stride, dil, padL, flip, R;
+  int tile0;      // generic weight gradient: first (sample, time tile) of this launch (deterministic mode: one per launch)
 };
 
 __device__ __forceinline__ void dw_stage_x(const DwArgs& p, int b, int t0, int c0, float* xs, int len_b) {
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256) void depthwise_wgrad_kernel(DwArgs p) {
   float* xs = sm;                       // [R][64]
   float* ds = sm + p.R * kDwP;          // [128][pitch] dy tile
   const int ntt = (p.Tout + kDwBT - 1) / kDwBT;
-  const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * kDwBT, c0 = blockIdx.y * kDwBC;
+  const int tile = blockIdx.x + p.tile0;
+  const int b = tile / ntt, t0 = (tile - b * ntt) * kDwBT, c0 = blockIdx.y * kDwBC;
   int len_b = p.Tin;
   if (p.in_len) len_b = min(max(p.in_len[b], 0), p.Tin);
   if (t0 * p.stride - p.padL >= len_b) return;          // the whole X window is padding: zero
@@ -505,7 +507,8 @@ extern "C" int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t*
         attr16 = true;
       }
       const int ntiles = B * ceil_div(Tout, kD16BT);
-      dim3 grid16(ntiles < 64 ? ntiles : 64, ceil_div(C, kDwBC));
+      // deterministic mode: ONE workgroup per channel block walks every tile (one add per dw element)
+      dim3 grid16(os2s_deterministic() ? 1 : (ntiles < 64 ? ntiles : 64), ceil_div(C, kDwBC));
       if (dil == 1) { OS2S_LAUNCH(depthwise_wgrad16_kernel<1>, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg); }
       else if (dil == 2) { OS2S_LAUNCH(depthwise_wgrad16_kernel<2>, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg); }
       else { OS2S_LAUNCH(depthwise_wgrad16_kernel<4>, grid16, dim3(256), lds16, (hipStream_t)stream, a, ngrp, nseg); }
@@ -518,6 +521,13 @@ extern "C" int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t*
       hipFuncSetAttribute((const void*)depthwise_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
     return OS2S_ERR_LAUNCH;
   dim3 grid(B * ceil_div(Tout, kDwBT), ceil_div(C, kDwBC));
+  if (os2s_deterministic()) {     // one (sample, time tile) per launch: the adds of a dw element arrive in tile order
+    const int ntiles = (int)grid.x;
+    grid.x = 1;
+    for (a.tile0 = 0; a.tile0 < ntiles; ++a.tile0)
+      OS2S_LAUNCH(depthwise_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    return OS2S_OK;
+  }
   OS2S_LAUNCH(depthwise_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
   return OS2S_OK;
 }

@@ -171,10 +171,14 @@ __global__ __launch_bounds__(64) void gst_attn_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(64) void gst_attn_bwd_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
     const bf16_t* __restrict__ v, const float* __restrict__ att_v, const float* __restrict__ w,
-    int heads, int N, bf16_t* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+    int B, int heads, int N, bf16_t* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
     float* __restrict__ datt_v) {
-  const int b = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+  // grid (B, heads) — or (1, 1) in deterministic mode: then every address gets its adds from ONE thread,
+  // in (head, sample) order
+  const int d = threadIdx.x;
   const int D = heads * 64;
+  for (int h = blockIdx.y; h < heads; h += gridDim.y)
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
   const long long off = (long long)h * 64 + d;
   const float qv = bf2f(q[(long long)b * D + off]), av = att_v[d], dov = bf2f(dout[(long long)b * D + off]);
   float dw[64];
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(64) void gst_attn_bwd_kernel(
   }
   dq[(long long)b * D + off] = f2bf(dqa);
   __hip_atomic_fetch_add(datt_v + d, dava, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace os2s
@@ -249,8 +254,9 @@ extern "C" int os2s_gst_attention_bwd(os2s_stream_t stream, const uint16_t* dout
                                       const float* w, int B, int heads, int N, uint16_t* dq, float* dk,
                                       float* dv, float* datt_v) {
   OS2S_REQUIRE(dout && q && k && v && att_v && w && dq && dk && dv && datt_v && N >= 1 && N <= 64);
-  OS2S_LAUNCH(gst_attn_bwd_kernel, dim3(B, heads), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dout,
-              (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, att_v, w, heads, N, (bf16_t*)dq, dk,
+  const dim3 grid = os2s_deterministic() ? dim3(1, 1) : dim3(B, heads);
+  OS2S_LAUNCH(gst_attn_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dout,
+              (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, att_v, w, B, heads, N, (bf16_t*)dq, dk,
               dv, datt_v);
   return OS2S_OK;
 }

@@ -1,6 +1,7 @@
 // Library-level entry points of the C ABI.
 #include "os2s_common.hpp"
 #include <cstdio>
+#include <cstdlib>
 
 extern "C" int os2s_abi_version(void) { return 1; }
 
@@ -24,3 +25,18 @@ extern "C" void os2s_record_hip_error(int hip_error, const char* where) {
 }
 
 extern "C" const char* os2s_last_error_detail(void) { return g_last_err; }
+
+// Deterministic mode (debugging aid): every kernel whose fp32 atomics make parameter gradients depend
+// on the arrival order of workgroups is launched in a geometry with ONE contributor per address
+// (narrow / K = 1 / stride-2 conv weight gradients: no reduction split; depthwise weight gradients: one
+// workgroup per channel block / one tile per launch; embedding gradient: one thread per column chunk
+// walking the tokens in order; style-token attention: one workgroup). Slower; bit-identical run to run.
+static int g_deterministic = -1;
+extern "C" int os2s_deterministic(void) {
+  if (g_deterministic < 0) {
+    const char* e = getenv("OS2S_DETERMINISTIC");
+    g_deterministic = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_deterministic;
+}
+extern "C" void os2s_set_deterministic(int on) { g_deterministic = on ? 1 : 0; }

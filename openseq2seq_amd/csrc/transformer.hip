@@ -94,6 +94,37 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
   }
 }
 
+// Deterministic mode: one thread per 8-column chunk walks the tokens in order — every element of dE gets
+// its adds from ONE thread in token order (no atomics; ~1 us per token: a debugging aid).
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(
+    const int32_t* __restrict__ ids, const bf16_t* __restrict__ dout, int V, int D, long long N,
+    float emb_scale, float keep_prob, unsigned long long seed, float* __restrict__ dtable,
+    int plain) {
+  const int D8 = D >> 3;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= D8) return;
+  const float ik = 1.f / keep_prob;
+  const int c0 = col * 8;
+  for (long long n = 0; n < N; ++n) {
+    int id = ids[n];
+    if (id > V - 1 || id < 0) id = 0;
+    if (id == 0 && !plain) continue;
+    const long long i = n * D8 + col;
+    const u32x4 t = *reinterpret_cast<const u32x4*>(dout + n * D + c0);
+    float g[8] = {bflo(t[0]), bfhi(t[0]), bflo(t[1]), bfhi(t[1]),
+                  bflo(t[2]), bfhi(t[2]), bflo(t[3]), bfhi(t[3])};
+    uint32_t keep = 0xffu;
+    if (keep_prob < 1.f) keep = dropout_bits8(seed, (unsigned long long)i, keep_prob);
+    float* const row = dtable + (long long)id * D + c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = g[e] * emb_scale;
+      if (keep_prob < 1.f) x = ((keep >> e) & 1u) ? x * ik : 0.f;
+      if (x != 0.f) row[e] += x;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // LayerNorm: one wave per row
 // ---------------------------------------------------------------------------
@@ -535,6 +566,11 @@ extern "C" int os2s_embed_bwd(os2s_stream_t stream, const int32_t* ids, const ui
                               int plain_lookup) {
   OS2S_REQUIRE(ids && dout && dtable && D % 8 == 0 && N >= 0);
   if (N == 0) return OS2S_OK;
+  if (os2s_deterministic()) {
+    OS2S_LAUNCH(embed_bwd_det_kernel, dim3(ceil_div(D / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                ids, dout, V, D, N, emb_scale, keep_prob, seed, dtable, plain_lookup);
+    return OS2S_OK;
+  }
   OS2S_LAUNCH(embed_bwd_kernel, dim3(ew_blocks(N * (D / 8))), dim3(256), 0, (hipStream_t)stream,
               ids, dout, V, D, N, emb_scale, keep_prob, seed, dtable, plain_lookup);
   return OS2S_OK;
