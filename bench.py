@@ -881,4 +881,8 @@ def main():
 
 
 if __name__ == "__main__":
-  main()
+  try:
+    main()
+  finally:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+      torch.distributed.destroy_process_group()      # RCCL communicators released before interpreter exit
