@@ -292,6 +292,14 @@ int os2s_bn_finalize(os2s_stream_t stream, const float* partial, int nparts, int
                      float eps, float momentum, int training, float* moving_mean,
                      float* moving_var, float* mean_out, float* rstd_out,
                      float* scale_out, float* shift_out);
+/* The same for J <= 16 BatchNorms of one geometry (nparts, C, count) in one launch: the 1x1 residual
+ * branches of a conv_bn_res_bn_actv block end (conv_blocks.py:134-168 builds one BatchNorm per branch).
+ * Every argument that is a pointer above is an array of J pointers here (the arrays live on the host). */
+int os2s_bn_finalize_multi(os2s_stream_t stream, int J, const float* const* partial, int nparts, int C,
+                           long long count, const float* const* gamma, const float* const* beta, float eps,
+                           float momentum, int training, float* const* moving_mean,
+                           float* const* moving_var, float* const* mean_out, float* const* rstd_out,
+                           float* const* scale_out, float* const* shift_out);
 /* stand-alone statistics partials for producers other than os2s_conv1d_fwd */
 int os2s_bn_stats_num_parts(long long rows);
 int os2s_bn_stats(os2s_stream_t stream, const uint16_t* y, long long rows, int C,

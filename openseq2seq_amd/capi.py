@@ -366,6 +366,31 @@ def bn_finalize(partial, count, gamma, beta, eps, momentum, training, moving_mea
              "os2s_bn_finalize")
 
 
+def bn_finalize_multi(items, count, eps, momentum, training):
+  """items: list (<= 16) of dict(partial, gamma, beta, moving_mean, moving_var, mean_out, rstd_out,
+  scale_out, shift_out) of one geometry — os2s_bn_finalize for all of them in one launch."""
+  J = len(items)
+  C = items[0]["scale_out"].numel()
+  nparts = 0 if items[0]["partial"] is None else items[0]["partial"].shape[0]
+  keys = ("partial", "gamma", "beta", "moving_mean", "moving_var", "mean_out", "rstd_out", "scale_out", "shift_out")
+  arrs = {}
+  for k in keys:
+    a = (c_void_p * J)()
+    for j, it in enumerate(items):
+      t = it.get(k)
+      assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+      if k == "partial" and t is not None:
+        assert t.shape[0] == nparts and t.shape[2] == C
+      a[j] = None if t is None else t.data_ptr()
+    arrs[k] = a
+  P = _lib.ctypes.POINTER(c_void_p)
+  f = _fn("os2s_bn_finalize_multi", (c_void_p, c_int, P, c_int, c_int, c_ll, P, P, c_float, c_float, c_int,
+                                     P, P, P, P, P, P))
+  _lib.check(f(_stream(), J, arrs["partial"], nparts, C, int(count), arrs["gamma"], arrs["beta"], float(eps),
+               float(momentum), int(training), arrs["moving_mean"], arrs["moving_var"], arrs["mean_out"],
+               arrs["rstd_out"], arrs["scale_out"], arrs["shift_out"]), "os2s_bn_finalize_multi")
+
+
 def bn_stats(y2d):
   rows, C = y2d.shape
   n = int(_fn("os2s_bn_stats_num_parts", (c_ll,))(rows))

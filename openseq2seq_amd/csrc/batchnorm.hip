@@ -26,7 +26,7 @@ constexpr int kMaxBnInputs = 12;
 // ---------------------------------------------------------------------------
 constexpr int kFinLanes = 16;     // partial-row lanes per channel (x 64 channels = 1024 threads)
 
-__global__ __launch_bounds__(64 * kFinLanes) void bn_finalize_kernel(
+__device__ __forceinline__ void bn_finalize_body(
     const float* __restrict__ partial, int nparts, int C, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     float momentum, int training, float* __restrict__ moving_mean,
@@ -84,6 +84,32 @@ __global__ __launch_bounds__(64 * kFinLanes) void bn_finalize_kernel(
   if (rstd_out) rstd_out[c] = rstd;
   scale_out[c] = g * rstd;
   shift_out[c] = b - mean * g * rstd;
+}
+
+__global__ __launch_bounds__(64 * kFinLanes) void bn_finalize_kernel(
+    const float* __restrict__ partial, int nparts, int C, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    float momentum, int training, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, float* __restrict__ scale_out,
+    float* __restrict__ shift_out) {
+  bn_finalize_body(partial, nparts, C, count, gamma, beta, eps, momentum, training, moving_mean, moving_var,
+                   mean_out, rstd_out, scale_out, shift_out);
+}
+
+// The same for up to 16 BatchNorms of one geometry (nparts, C, count) in ONE launch (blockIdx.y = the
+// BatchNorm): the 1x1 residual branches of a block end (up to 11 finalize launches of ~5.6 us each).
+constexpr int kBnFinMaxJ = 16;
+struct BnFinFwdMulti {
+  const float* partial[kBnFinMaxJ]; const float* gamma[kBnFinMaxJ]; const float* beta[kBnFinMaxJ];
+  float* moving_mean[kBnFinMaxJ]; float* moving_var[kBnFinMaxJ]; float* mean_out[kBnFinMaxJ];
+  float* rstd_out[kBnFinMaxJ]; float* scale_out[kBnFinMaxJ]; float* shift_out[kBnFinMaxJ];
+};
+__global__ __launch_bounds__(64 * kFinLanes) void bn_finalize_fwd_multi_kernel(
+    BnFinFwdMulti t, int nparts, int C, double count, float eps, float momentum, int training) {
+  const int j = blockIdx.y;
+  bn_finalize_body(t.partial[j], nparts, C, count, t.gamma[j], t.beta[j], eps, momentum, training,
+                   t.moving_mean[j], t.moving_var[j], t.mean_out[j], t.rstd_out[j], t.scale_out[j], t.shift_out[j]);
 }
 
 // ---------------------------------------------------------------------------
@@ -660,6 +686,35 @@ extern "C" int os2s_bn_finalize(os2s_stream_t stream, const float* partial, int 
               (hipStream_t)stream, partial, nparts, C, (double)count, gamma, beta, eps,
               momentum, training, moving_mean, moving_var, mean_out, rstd_out, scale_out,
               shift_out);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_bn_finalize_multi(os2s_stream_t stream, int J, const float* const* partial, int nparts,
+                                      int C, long long count, const float* const* gamma,
+                                      const float* const* beta, float eps, float momentum, int training,
+                                      float* const* moving_mean, float* const* moving_var,
+                                      float* const* mean_out, float* const* rstd_out,
+                                      float* const* scale_out, float* const* shift_out) {
+  OS2S_REQUIRE(J >= 1 && J <= kBnFinMaxJ && C >= 1 && scale_out && shift_out);
+  if (training) OS2S_REQUIRE(partial && nparts >= 1 && count >= 1);
+  else OS2S_REQUIRE(moving_mean && moving_var);
+  BnFinFwdMulti t = {};
+  for (int j = 0; j < J; ++j) {
+    OS2S_REQUIRE(scale_out[j] && shift_out[j]);
+    if (training) OS2S_REQUIRE(partial[j]);
+    else OS2S_REQUIRE(moving_mean[j] && moving_var[j]);
+    t.partial[j] = partial ? partial[j] : nullptr;
+    t.gamma[j] = gamma ? gamma[j] : nullptr;
+    t.beta[j] = beta ? beta[j] : nullptr;
+    t.moving_mean[j] = moving_mean ? moving_mean[j] : nullptr;
+    t.moving_var[j] = moving_var ? moving_var[j] : nullptr;
+    t.mean_out[j] = mean_out ? mean_out[j] : nullptr;
+    t.rstd_out[j] = rstd_out ? rstd_out[j] : nullptr;
+    t.scale_out[j] = scale_out[j];
+    t.shift_out[j] = shift_out[j];
+  }
+  OS2S_LAUNCH(bn_finalize_fwd_multi_kernel, dim3(ceil_div(C, 64), J), dim3(64 * kFinLanes), 0,
+              (hipStream_t)stream, t, nparts, C, (double)count, eps, momentum, training);
   return OS2S_OK;
 }
 

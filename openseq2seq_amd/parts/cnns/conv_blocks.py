@@ -289,8 +289,8 @@ class ConvBN(object):
                         pad_left=pl, tout=tout, in_len=x.lens, stats=stats)
     return self.bn_from_stats(y, stats, B, tout, training, pl)
 
-  def bn_from_stats(self, y, stats, B, tout, training, pl=0):
-    """BatchNorm scale / shift (and the moving-statistics update) from the conv's fused partials."""
+  def bn_outputs(self, y, training, tout, pl=0):
+    """The record conv_bn_stats returns, with freshly allocated scale / shift (/ mean / rstd) vectors."""
     dev, C = y.device, self.cout
     sc = torch.empty(C, dtype=torch.float32, device=dev)
     sh = torch.empty(C, dtype=torch.float32, device=dev)
@@ -298,10 +298,15 @@ class ConvBN(object):
     if training:
       mean = torch.empty(C, dtype=torch.float32, device=dev)
       rstd = torch.empty(C, dtype=torch.float32, device=dev)
-    capi.bn_finalize(stats, B * tout, self.gamma.master, self.beta.master, self.eps,
-                     self.momentum, training, self.moving_mean, self.moving_var, mean, rstd,
-                     sc, sh)
     return dict(y=y, scale=sc, shift=sh, mean=mean, rstd=rstd, tout=tout, pad_left=pl)
+
+  def bn_from_stats(self, y, stats, B, tout, training, pl=0):
+    """BatchNorm scale / shift (and the moving-statistics update) from the conv's fused partials."""
+    d = self.bn_outputs(y, training, tout, pl)
+    capi.bn_finalize(stats, B * tout, self.gamma.master, self.beta.master, self.eps,
+                     self.momentum, training, self.moving_mean, self.moving_var, d["mean"], d["rstd"],
+                     d["scale"], d["shift"])
+    return d
 
   def trainable(self):
     return [self.kernel, self.gamma, self.beta]
@@ -646,10 +651,26 @@ def grouped_conv1x1_bn_stats(branches, inputs, training):
     items.append(dict(x=x.data, w=br.kernel.w16, y=y, stats=stats))
     out[i] = (y, stats)
   capi.conv1x1_fwd_grouped(items, in_len=inputs[plain[0]].lens)
+  # the BatchNorm finalizes of the grouped branches in ONE launch too (same Cout, same window count)
+  B, T = inputs[plain[0]].data.shape[:2]
+  same = len({branches[i].cout for i in plain}) == 1 and len(plain) <= 16 and \
+      len({(branches[i].eps, branches[i].momentum) for i in plain}) == 1
+  if same:
+    fin = []
+    for i in plain:
+      br = branches[i]
+      y, stats = out[i]
+      d = br.bn_outputs(y, training, T)
+      fin.append(dict(partial=stats, gamma=br.gamma.master, beta=br.beta.master, moving_mean=br.moving_mean,
+                      moving_var=br.moving_var, mean_out=d["mean"], rstd_out=d["rstd"], scale_out=d["scale"],
+                      shift_out=d["shift"]))
+      out[i] = d
+    br0 = branches[plain[0]]
+    capi.bn_finalize_multi(fin, B * T, br0.eps, br0.momentum, training)
   for i, br in enumerate(branches):
     if out[i] is None:
       out[i] = br.conv_bn_stats(inputs[i], training)
-    else:
+    elif not same:
       y, stats = out[i]
       out[i] = br.bn_from_stats(y, stats, inputs[i].data.shape[0], inputs[i].data.shape[1], training)
   return out
