@@ -41,10 +41,20 @@ FUSE_BN_BWD = os.environ.get("OS2S_FUSE_BN_BWD", "1") != "0"
 GROUP_WGRAD = os.environ.get("OS2S_GROUP_WGRAD", "1") != "0"
 
 
+_SIDE_STREAM_ENABLED = True
+
+
+def set_side_stream_enabled(on):
+  """Per-model switch (config key `os2s_side_stream`, set at the start of every train step): with False
+  every `on_side_stream` body runs on the current stream."""
+  global _SIDE_STREAM_ENABLED
+  _SIDE_STREAM_ENABLED = bool(on)
+
+
 def _side_stream(device):
   """Side stream for work that may overlap the main stream inside one backward closure
-  (OS2S_WGRAD_STREAM=0 keeps everything on one stream)."""
-  if os.environ.get("OS2S_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
+  (OS2S_WGRAD_STREAM=0 or the model's `os2s_side_stream: False` keeps everything on one stream)."""
+  if not _SIDE_STREAM_ENABLED or os.environ.get("OS2S_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
     return None
   key = (device.index, torch.cuda.current_stream().cuda_stream)
   st = _SIDE_STREAMS.get(key)
