@@ -689,8 +689,13 @@ size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
  * exchanged through that XCD's L2) instead of one launch per time step; os2s_rnn_fwd_workspace_bytes
  * includes its exchange buffers. os2s_gru_xcd_set_mode: 0 = per-step launches, 1 = persistent kernel,
  * -1 = environment OS2S_GRU_XCD (default on). A launch that gives up (unexpected workgroup placement,
- * a wait that times out) makes a LATER os2s_rnn_layer_fwd_multi call return OS2S_ERR_LAUNCH. */
+ * a wait that times out) leaves its outputs partially written: its abort code is latched, behind every
+ * persistent forward AND backward launch, into a sticky host-visible word no launch clears. From then on
+ * every persistent launch returns OS2S_ERR_LAUNCH and os2s_gru_xcd_status() returns the code (1 = timeout,
+ * 2 = placement, 3 = both; 0 = fine so far) — call it after a stream synchronisation, once per step
+ * (the host layer does, where it reads the optimizer state); clear != 0 resets the word. */
 void os2s_gru_xcd_set_mode(int mode);
+int os2s_gru_xcd_status(int clear);
 size_t os2s_gru_xcd_workspace_bytes(int B, int H);
 size_t os2s_gru_xcd_bwd_workspace_bytes(int B, int H);   /* backward-through-time twin (B <= 16) */
 int os2s_rnn_layer_fwd(os2s_stream_t stream, int cell, const uint16_t* gx, const uint16_t* wh,

@@ -581,7 +581,20 @@ def opt_read_state(state):
   raw = bytes(state.cpu().numpy().tobytes())
   fmt = "<" + "".join(c for _, c in OPT_STATE_FIELDS)
   vals = struct.unpack(fmt, raw[:struct.calcsize(fmt)])
+  gru_xcd_check()            # the step's sync point: a persistent GRU launch that gave up shows here
   return dict(zip([n for n, _ in OPT_STATE_FIELDS], vals))
+
+
+def gru_xcd_check(clear=False):
+  """Raises if a persistent GRU launch (csrc/rnn_xcd.hip, forward or backward) has given up since the
+  word was last cleared: its outputs — and every gradient computed from them — are invalid. The abort
+  word is sticky and host-visible (os2s_gru_xcd_status); definite after a stream synchronisation,
+  otherwise it reports launches that have already finished."""
+  f = _fn("os2s_gru_xcd_status", (c_int,))
+  st = f(int(bool(clear)))
+  if st:
+    raise _lib.Os2sError("a persistent GRU launch gave up (code %d: 1 = poll timeout, 2 = workgroup placement); "
+                         "the step's results are invalid. OS2S_GRU_XCD=0 selects the launch-per-step path" % st)
 
 
 def opt_step(cfg, state, grads, weights, m1, m2, w16, chunk_tensor, tensor_chunk_begin,
@@ -700,14 +713,7 @@ def spec_augment(feats, masks):
 # --------------------------------------------------------------------------
 # Transformer kernels (packed token-major tensors)
 # --------------------------------------------------------------------------
-LT_MIN_ROWS = 256     # plain matmuls with at least this many rows go to the big-tile GEMMs
-# Back end of the bare matmuls (no fused epilogue): 'pp' (default) = the in-tree ping-pong MFMA
-# kernels (os2s_gemm_nt / conv1d_wgrad1x1_pp_kernel), 'lt' = hipBLASLt (kept for A/B runs)
-USE_LT = os.environ.get("OS2S_GEMM", "pp") == "lt"
-
-
-def _lt_unsupported(e):
-  return "unsupported" in str(e).lower()
+BIG_TILE_MIN_ROWS = 256     # plain matmuls with at least this many rows go to the 256 x 256 ping-pong tile
 
 
 def gemm(x2d, w, **kw):
@@ -718,17 +724,11 @@ def gemm(x2d, w, **kw):
            and not kw.get("act", 0) and not kw.get("out_f32", False) and not kw.get("time_major", False)
            and kw.get("keep_prob", 1.0) >= 1.0)
   bias = kw.get("bias", None)
-  if bias is not None and (USE_LT or bias.dtype != torch.float32):
-    plain = False           # the ping-pong kernel adds an fp32 bias in its epilogue; the library route has none
-  if plain and x2d.shape[0] >= LT_MIN_ROWS and x2d.stride(1) == 1 and w.stride(1) == 1:
+  if bias is not None and bias.dtype != torch.float32:
+    plain = False           # the ping-pong kernel adds an fp32 bias in its epilogue
+  if plain and x2d.shape[0] >= BIG_TILE_MIN_ROWS and x2d.stride(1) == 1 and w.stride(1) == 1:
     out_t = kw.get("out", None)
-    if USE_LT:
-      try:
-        return matmul_lt(x2d, w, b_is_t=True, out=out_t, beta=1.0 if kw.get("accumulate", False) else 0.0)
-      except _lib.Os2sError as e:
-        if not _lt_unsupported(e):
-          raise
-    elif (x2d.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous() and x2d.stride(0) % 8 == 0
+    if (x2d.shape[1] % 64 == 0 and w.shape[0] % 8 == 0 and w.is_contiguous() and x2d.stride(0) % 8 == 0
           and (out_t is None or (out_t.stride(1) == 1 and out_t.stride(0) % 8 == 0))):
       return gemm_nt(x2d, w, out=out_t, bias=bias, accumulate=bool(kw.get("accumulate", False)))
   out = kw.pop("out", None)
@@ -789,42 +789,6 @@ def gemm_nt_mask(a, w, mask_ref, mask_scale, out=None, want_colsum=False):
   return out, part
 
 
-_lt_lib = None
-
-
-def _lt():
-  """The hipBLASLt comparison library (tools/lt, built by tools/lt/build.sh): A/B runs only."""
-  global _lt_lib
-  if _lt_lib is None:
-    import ctypes
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lt", "libos2s_lt.so")
-    if not os.path.exists(path):
-      raise _lib.Os2sError("OS2S_GEMM=lt / matmul_lt need the comparison library: run tools/lt/build.sh "
-                           "(the product library does not link hipBLASLt)")
-    _lt_lib = ctypes.CDLL(path)
-    _lt_lib.os2s_lt_matmul.restype = c_int
-    _lt_lib.os2s_lt_matmul.argtypes = [c_void_p, c_void_p, c_int, c_ll, c_void_p, c_int, c_ll, c_void_p, c_int,
-                                       c_ll, c_int, c_int, c_int, c_float]
-  return _lt_lib
-
-
-def matmul_lt(a, b, a_is_t=False, b_is_t=False, out=None, out_f32=False, beta=0.0):
-  """out[M,N] = op(a) @ op(b) (+ beta * out) via hipBLASLt (comparison back end, tools/lt); a, b
-  bf16 2-D (row stride free)."""
-  M, K = (a.shape[1], a.shape[0]) if a_is_t else (a.shape[0], a.shape[1])
-  K2, N = (b.shape[1], b.shape[0]) if b_is_t else (b.shape[0], b.shape[1])
-  assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
-  if out is None:
-    assert beta == 0.0
-    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
-  assert out.stride(1) == 1 and tuple(out.shape) == (M, N)
-  _lib.check(_lt().os2s_lt_matmul(_stream(), c_void_p(a.data_ptr()), int(a_is_t), a.stride(0),
-                                  c_void_p(b.data_ptr()), int(b_is_t), b.stride(0), c_void_p(out.data_ptr()),
-                                  int(out.dtype == torch.float32), out.stride(0), M, N, K, float(beta)),
-             "os2s_lt_matmul")
-  return out
-
-
 def dense_epilogue(y, bias=None, act=0, keep_prob=1.0, seed=0, residual=None):
   """In place: y = residual + dropout(act(y + bias)) on bf16 [rows, C]."""
   rows, C = y.shape
@@ -855,13 +819,6 @@ def gemm_wgrad(x2d, dy2d, out, accumulate=True):
   """dW [Cout,Cin] (+)= dy^T x (fp32)."""
   N, Cin = x2d.shape
   Cout = dy2d.shape[1]
-  if USE_LT and N >= LT_MIN_ROWS and x2d.stride(1) == 1 and dy2d.stride(1) == 1 and out.stride(1) == 1:
-    try:
-      matmul_lt(dy2d, x2d, a_is_t=True, out=out, beta=1.0 if accumulate else 0.0)
-      return
-    except _lib.Os2sError as e:
-      if not _lt_unsupported(e):
-        raise
   if dy2d.stride(1) != 1 or dy2d.stride(0) != Cout:
     dy2d = dy2d.contiguous()
   if x2d.stride(1) != 1 or x2d.stride(0) % 8:

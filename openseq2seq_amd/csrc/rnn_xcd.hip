@@ -586,23 +586,64 @@ bool gru_xcd_supported(int B, int T, int H, int ndir) {
   return true;
 }
 
+// ---- sticky abort word -------------------------------------------------------------------------------
+// A launch that gives up (poll timeout / placement mismatch) leaves partially written outputs. Its abort
+// code is latched by a one-thread kernel behind EVERY persistent launch (forward and backward) into a pinned,
+// device-mapped host word that no launch ever clears: the next persistent launch of either direction and
+// os2s_gru_xcd_status() (called by the host layer at its per-step sync point) fail loudly.
+static int* g_sticky_host = nullptr;
+static int* g_sticky_dev = nullptr;
+
+static bool gru_xcd_sticky_init() {
+  if (g_sticky_host) return true;
+  int* h = nullptr;
+  if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) != hipSuccess) return false;
+  *h = 0;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { hipHostFree(h); return false; }
+  g_sticky_dev = (int*)d;
+  g_sticky_host = h;
+  return true;
+}
+
+__global__ void gru_xcd_latch_kernel(const int* __restrict__ flags, int* __restrict__ sticky) {
+  const int f = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (f != 0) __hip_atomic_fetch_or(sticky, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int gru_xcd_latch(hipStream_t stream, const int* flags) {
+  if (!gru_xcd_sticky_init()) return OS2S_ERR_LAUNCH;
+  OS2S_LAUNCH(gru_xcd_latch_kernel, dim3(1), dim3(1), 0, stream, flags, g_sticky_dev);
+  return OS2S_OK;
+}
+
+static int gru_xcd_check_sticky() {
+  if (!gru_xcd_sticky_init()) return OS2S_ERR_LAUNCH;
+  const int f = *(volatile int*)g_sticky_host;
+  if (f == 0) return OS2S_OK;
+  fprintf(stderr, "os2s: a persistent GRU launch gave up (%s%s); its outputs are invalid. "
+                  "OS2S_GRU_XCD=0 selects the launch-per-step path\n",
+          (f & 2) ? "workgroups were not placed on the expected XCDs" : "",
+          (f & 1) ? ((f & 2) ? " / a wait timed out" : "a wait timed out") : "");
+  return OS2S_ERR_LAUNCH;
+}
+
+// 0 = no persistent GRU launch has given up so far (as far as the host can see without synchronising: call
+// it after a stream synchronisation for a definite answer); otherwise the OR of the abort codes (1 = poll
+// timeout, 2 = placement mismatch). clear != 0 resets the word (after the caller has discarded the step).
+extern "C" int os2s_gru_xcd_status(int clear) {
+  if (!g_sticky_host) return 0;            // no persistent launch has run in this process
+  const int f = *(volatile int*)g_sticky_host;
+  if (clear) *(volatile int*)g_sticky_host = 0;
+  return f;
+}
+
 // one launch for all T steps of ndir directions. gx/wh/bh/y/gates/reverse per direction as in
 // os2s_rnn_dir_fwd_t; h32[d] = fp32 state [B, H] (in: initial, out: final); xws[d] = exchange buffer of
 // os2s_gru_xcd_workspace_bytes() bytes (zeroed here); flags = 64 zeroed bytes shared by the launch.
 int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* dirs, float* const* h32,
                        void* const* xws, int* flags, const int32_t* lens, int B, int T, int H) {
-  static int* host_flag = nullptr;                       // pinned mirror of the last launches' abort flag
-  if (!host_flag) {
-    if (hipHostMalloc((void**)&host_flag, 64, hipHostMallocDefault) != hipSuccess) return OS2S_ERR_LAUNCH;
-    *host_flag = 0;
-  }
-  if (*host_flag != 0) {   // an EARLIER launch gave up (placement mismatch / timeout): its results are invalid
-    fprintf(stderr, "os2s: a persistent GRU launch gave up (%s); its outputs are invalid. "
-                    "OS2S_GRU_XCD=0 selects the launch-per-step path\n",
-            *host_flag == 2 ? "workgroups were not placed on the expected XCDs" : "a wait timed out");
-    *host_flag = 0;
-    return OS2S_ERR_LAUNCH;
-  }
+  if (int rc = gru_xcd_check_sticky()) return rc;
   GruXcdArgs a;
   a.B = B; a.T = T; a.H = H; a.ndir = ndir; a.lens = lens; a.flags = flags;
   const int BP = B <= 16 ? 16 : 32;
@@ -629,8 +670,7 @@ int launch_gru_xcd_fwd(hipStream_t stream, int ndir, const os2s_rnn_dir_fwd_t* d
   else if (BP == 16) { OS2S_LAUNCH((gru_xcd_fwd_kernel<1, 6>), grid, blk, lds, stream, a); }
   else if (RT == 5) { OS2S_LAUNCH((gru_xcd_fwd_kernel<2, 5>), grid, blk, lds, stream, a); }
   else { OS2S_LAUNCH((gru_xcd_fwd_kernel<2, 6>), grid, blk, lds, stream, a); }
-  if (hipMemcpyAsync(host_flag, flags, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess)
-    return OS2S_ERR_LAUNCH;
+  if (int rc = gru_xcd_latch(stream, flags)) return rc;
 #ifdef OS2S_GRU_XCD_TIMERS
   {
     int hf[8];
@@ -666,6 +706,7 @@ bool gru_xcd_bwd_supported(int B, int T, int H, int ndir) {
 
 int launch_gru_xcd_bwd(hipStream_t stream, int ndir, const os2s_rnn_dir_bwd_t* dirs, void* const* xws, int* flags,
                        const int32_t* lens, int B, int T, int H) {
+  if (int rc = gru_xcd_check_sticky()) return rc;
   GruXcdArgsB a;
   a.B = B; a.T = T; a.H = H; a.ndir = ndir; a.lens = lens; a.flags = flags;
   for (int d = 0; d < ndir; ++d) {
@@ -682,5 +723,5 @@ int launch_gru_xcd_bwd(hipStream_t stream, int ndir, const os2s_rnn_dir_bwd_t* d
   if (hipFuncSetAttribute((const void*)gru_xcd_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return OS2S_ERR_LAUNCH;
   OS2S_LAUNCH(gru_xcd_bwd_kernel, dim3(8 * kXcdCus), dim3(kXcdThreads), lds, stream, a);
-  return OS2S_OK;
+  return gru_xcd_latch(stream, flags);
 }

@@ -19,6 +19,7 @@ import time
 import six
 import torch
 
+from .. import capi
 from ..optimizers.flat_params import FlatParams
 from ..optimizers.optimizers import optimize_loss
 from ..parts.cnns.conv_blocks import Tape, set_side_stream_enabled
@@ -223,21 +224,27 @@ class Model(object):
   def train_step(self, batch):
     assert self._compiled and self._mode == "train"
     p = self._params
-    set_side_stream_enabled(p.get('os2s_side_stream', True))
-    iter_size = p.get('iter_size', 1)
-    micro = self._step_count % iter_size
-    if micro == 0:
-      self._store.zero_grads()
-    last_micro = (micro == iter_size - 1)
-    overlap = self._reducer is not None and last_micro
-    tape = Tape(on_done=self._reducer.mark_done if overlap else None)
-    loss = self._forward_backward(batch, tape)
-    tape.backward()
-    self._step_count += 1
-    if last_micro:
-      if self._reducer is not None:
-        self._reducer.finish()
-      self._train_op.run()
+    capi.gru_xcd_check()        # sticky abort word of the persistent GRU kernels (no sync: earlier steps)
+    # the side-stream switch is this model's, for the duration of its step only (a second model in the
+    # process — an eval twin, a test's bare Tape — keeps the setting it had)
+    prev = set_side_stream_enabled(p.get('os2s_side_stream', True))
+    try:
+      iter_size = p.get('iter_size', 1)
+      micro = self._step_count % iter_size
+      if micro == 0:
+        self._store.zero_grads()
+      last_micro = (micro == iter_size - 1)
+      overlap = self._reducer is not None and last_micro
+      tape = Tape(on_done=self._reducer.mark_done if overlap else None)
+      loss = self._forward_backward(batch, tape)
+      tape.backward()
+      self._step_count += 1
+      if last_micro:
+        if self._reducer is not None:
+          self._reducer.finish()
+        self._train_op.run()
+    finally:
+      set_side_stream_enabled(prev)
     return loss
 
   def copy_weights_from(self, other):

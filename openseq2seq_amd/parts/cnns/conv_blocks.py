@@ -46,9 +46,11 @@ _SIDE_STREAM_ENABLED = True
 
 def set_side_stream_enabled(on):
   """Per-model switch (config key `os2s_side_stream`, set at the start of every train step): with False
-  every `on_side_stream` body runs on the current stream."""
+  every `on_side_stream` body runs on the current stream. Returns the previous setting (the caller
+  restores it when its step is over)."""
   global _SIDE_STREAM_ENABLED
-  _SIDE_STREAM_ENABLED = bool(on)
+  prev, _SIDE_STREAM_ENABLED = _SIDE_STREAM_ENABLED, bool(on)
+  return prev
 
 
 def _side_stream(device):
@@ -183,6 +185,11 @@ class Tape(object):
     """A Dense weight gradient too small to fill the chip alone is held back until `group` of them
     can go out in one launch (capi.gemm_wgrad_grouped). Until then `param` does not count as final
     for the gradient reducer."""
+    # one grouped launch has ONE row count (os2s_gemm_wgrad_grouped takes a single M): a layer fed by
+    # another number of packed rows (the enc-dec attention's k/v projection of the SOURCE tokens among
+    # target-row layers) starts a new group
+    if self._deferred and self._deferred[0][1]["x"].shape[0] != item["x"].shape[0]:
+      self.flush_deferred()
     self._deferred.append((param, item))
     if self._pending is not None and id(param) in self._pending:
       self._pending[id(param)] += 1
@@ -588,8 +595,10 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
           br.backward_weights(inp, dy, f)
         if inp.requires_grad:
           grouped.append((br, inp, dy))
-      elif j == 0 and type(br) is ConvBN:
-        br.backward_branch(inp, dy, f, final=True)     # the last contribution to its input's gradient
+      elif j == 0 and br is main and type(br) is ConvBN:
+        # the last contribution to its input's gradient (with the block dropped, branches[0] is a
+        # RESIDUAL branch whose input still has later-running consumers: never final)
+        br.backward_branch(inp, dy, f, final=True)
       else:
         br.backward_branch(inp, dy, f)
     if wgrouped:

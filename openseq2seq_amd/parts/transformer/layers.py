@@ -17,12 +17,7 @@ from ..cnns.conv_blocks import Act, on_side_stream, current_tape
 
 
 SKINNY_MAX_ROWS = 512
-# GEMM back end of the Dense / tied-softmax layers: 'pp' (default) = the hand-written MFMA GEMM
-# with fused epilogues (csrc/gemm_pp.hip) for forward and data gradient and the in-tree
-# weight-gradient kernels for dW; 'lt' = hipBLASLt for the matmuls + one elementwise pass for the
-# epilogue (comparison runs; needs tools/lt/build.sh)
 import os as _os
-GEMM_BACKEND = _os.environ.get("OS2S_GEMM", "pp")
 # Dense weight gradients on the side stream (as the conv families do): most Dense GEMMs of a
 # Transformer-big step are 132 tiles on 256 CUs (8300 tokens x 1024 columns), the split weight
 # gradient fills the other half of the chip. 22.1 -> 20.3 ms/step, sustained over 300 steps
@@ -103,11 +98,7 @@ class Dense(object):
                                   relu=(act == 1), residual=residual.data if residual is not None else None))
     bias = self.bias.master if self.bias is not None else None
     res = residual.data if residual is not None else None
-    if GEMM_BACKEND == "lt":       # comparison runs: vendor matmul + one elementwise epilogue pass
-      y = capi.matmul_lt(x.data, self.w, b_is_t=True)
-      if not (act == 0 and keep >= 1.0 and residual is None and self.bias is None):
-        capi.dense_epilogue(y, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
-    elif self.cin % 64 == 0 and act in (0, 1) and self.cout % 8 == 0:   # what gemm_pp.hip accepts
+    if self.cin % 64 == 0 and act in (0, 1) and self.cout % 8 == 0:   # what gemm_pp.hip accepts
       y = capi.gemm_nt(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
     else:
       y = capi.gemm(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
@@ -116,7 +107,7 @@ class Dense(object):
       return out
     lin = self
     assert not (act == 1 and residual is not None)
-    if act == 1 and FUSE_RELU_BWD and GEMM_BACKEND != "lt" and y.is_contiguous():
+    if act == 1 and FUSE_RELU_BWD and y.is_contiguous():
       out.mask_scale = 1.0 / keep       # y = dropout(relu(.)): zero exactly where the gradient is
 
     def backward():
@@ -144,9 +135,7 @@ class Dense(object):
       # stream by default (OS2S_DENSE_WGRAD_STREAM): with the in-tree kernels it fills the half of
       # the chip a 132-tile data-gradient GEMM leaves idle, 22.1 -> 20.3 ms/step over 20 AND over
       # 300 steps (with the round-1 vendor GEMMs the same move lost 11 % at the power limit)
-      if GEMM_BACKEND == "lt":
-        capi.matmul_lt(dz, x.data, a_is_t=True, out=lin.kernel.grad.view(lin.cout, lin.cin), beta=1.0)
-      elif DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _small_wgrad(lin, dz) and current_tape() is not None:
+      if DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _small_wgrad(lin, dz) and current_tape() is not None:
         # 16 output tiles: three of these go out as ONE launch (Tape.defer_wgrad)
         current_tape().defer_wgrad(lin.kernel, dict(x=x.data, dy=dz, dw=lin.kernel.grad.view(lin.cout, lin.cin)))
       elif DENSE_WGRAD_STREAM:
@@ -154,7 +143,7 @@ class Dense(object):
           capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
       else:
         capi.gemm_wgrad(x.data, dz, lin.kernel.grad.view(lin.cout, lin.cin), accumulate=True)
-      if bias_part is not None:
+      if bias_part is not None and lin.bias is not None:
         with on_side_stream(dz.device, bias_part):        # parameter gradient: off the main chain
           scratch = torch.empty(2, lin.cout, dtype=torch.float32, device=dz.device)
           capi.bn_bwd_finalize(bias_part, 1, 1, None, lin.bias.grad, True, scratch[0], scratch[1])
@@ -163,9 +152,7 @@ class Dense(object):
           _colsum_into(dz, lin.bias)
       if x.requires_grad:
         g = x.grad_buffer()
-        if GEMM_BACKEND == "lt":
-          capi.matmul_lt(dz, lin.w, out=g, beta=1.0 if x.grad_init else 0.0)
-        elif x.mask_scale is not None and not x.grad_init and lin.cout % 64 == 0 and lin.cin % 8 == 0 and \
+        if x.mask_scale is not None and not x.grad_init and lin.cout % 64 == 0 and lin.cin % 8 == 0 and \
             dz.stride(1) == 1 and g.is_contiguous():
           # x = dropout(relu(.)) of the layer below, this is the only consumer: its activation
           # backward (and the bias-gradient partials) ride in this GEMM's epilogue
@@ -329,11 +316,7 @@ class SharedEmbedding(object):
     """logits = x E^T  (bf16 [N, V])."""
     if tape is None and x.data.shape[0] <= SKINNY_MAX_ROWS and SKINNY_LOGITS:
       return Act(capi.gemm_skinny(x.data, self.table))
-    if GEMM_BACKEND == "lt":
-      y = capi.matmul_lt(x.data, self.table, b_is_t=True)
-    else:
-      y = capi.gemm(x.data, self.table)
-    out = Act(y)
+    out = Act(capi.gemm(x.data, self.table))
     if tape is not None:
       emb = self
 
@@ -341,13 +324,9 @@ class SharedEmbedding(object):
         dy = out.grad
         assert dy is not None
         g = x.grad_buffer()
-        if GEMM_BACKEND == "lt":
-          capi.matmul_lt(dy, x.data, a_is_t=True, out=emb.weights.grad.view(emb.V, emb.D), beta=1.0)
-          capi.matmul_lt(dy, emb.table, out=g, beta=1.0 if x.grad_init else 0.0)
-        else:
-          with on_side_stream(dy.device, x.data, dy):
-            capi.gemm_wgrad(x.data, dy, emb.weights.grad.view(emb.V, emb.D), accumulate=True)
-          capi.gemm(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
+        with on_side_stream(dy.device, x.data, dy):
+          capi.gemm_wgrad(x.data, dy, emb.weights.grad.view(emb.V, emb.D), accumulate=True)
+        capi.gemm(dy, emb.weights.wt16.view(emb.D, emb.V), out=g, accumulate=x.grad_init)
         x.grad_init = True
         out.grad = None
 

@@ -5,6 +5,9 @@ import os
 import sys
 
 import torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lt"))
+import lt_backend  # noqa: E402  (hipBLASLt comparison harness, tools only)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openseq2seq_amd import capi  # noqa: E402
@@ -49,7 +52,7 @@ def main():
     t4 = timeit(lambda: capi.gemm_skinny(inp, w))
     del os.environ["OS2S_SKINNY_VARIANT"]
     t5 = timeit(lambda: capi.gemm_skinny(inp, w))
-    t2 = timeit(lambda: capi.matmul_lt(inp, w, b_is_t=True))
+    t2 = timeit(lambda: lt_backend.matmul_lt(inp, w, b_is_t=True))
     print("gemm %-18s reg %6.1f  lds64 %6.1f  lds32 %6.1f  wide %6.1f  auto %6.1f  hipBLASLt %6.1f us  (W %.1f MB)"
           % (name, t, t1, t3, t4, t5, t2, n * k * 2 / 1e6), flush=True)
   Tmax, step = 106, 50

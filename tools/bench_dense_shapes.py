@@ -7,6 +7,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lt"))
+import lt_backend  # noqa: E402  (hipBLASLt comparison harness, tools only)
 from openseq2seq_amd import capi, _lib
 
 dev = torch.device("cuda:0")
@@ -44,7 +47,7 @@ for N, K in [(1024, 1024), (3072, 1024), (1024, 3072), (2048, 1024), (1024, 2048
   w = (torch.randn(N, K, device=dev) * 0.03).to(torch.bfloat16)
   y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
   t1 = timeit(lambda: capi.gemm_nt(a, w, out=y))
-  t2 = nan_on_error(lambda: capi.matmul_lt(a, w, b_is_t=True, out=y))
+  t2 = nan_on_error(lambda: lt_backend.matmul_lt(a, w, b_is_t=True, out=y))
   fl = 2.0 * M * N * K
   print("N %5d K %5d: gemm_nt %.3f ms %5.0f TF/s | hipBLASLt %.3f ms %5.0f TF/s" % (
       N, K, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9), flush=True)
@@ -61,7 +64,7 @@ for Cin, Cout in [(1024, 1024), (1024, 3072), (1024, 2048), (1024, 4096), (4096,
       res[name] = timeit(lambda: capi.conv1d_wgrad(x, dy, 1, pad_left=0, out=dw, accumulate=True))
     finally:
       L.os2s_conv1d_wgrad_set_variant(-1, -1)
-  res["lt"] = nan_on_error(lambda: capi.matmul_lt(dy[0], x[0], a_is_t=True, out=dw[0], beta=1.0))
+  res["lt"] = nan_on_error(lambda: lt_backend.matmul_lt(dy[0], x[0], a_is_t=True, out=dw[0], beta=1.0))
   fl = 2.0 * M * Cin * Cout
   print("Cin %5d Cout %5d: " % (Cin, Cout) + " | ".join(
       "%s %.3f ms %5.0f TF/s" % (k, v, fl / v / 1e9) for k, v in res.items()), flush=True)

@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lt"))
+import lt_backend  # noqa: E402  (hipBLASLt comparison harness, tools only)
 from openseq2seq_amd import capi
 dev = torch.device("cuda:0")
 def timeit(fn, n=10):
@@ -22,7 +25,7 @@ for M, N, K in [(16384, 1024, 1024), (16384, 3072, 1024), (16384, 4096, 1024), (
   y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
   t1 = timeit(lambda: capi.gemm_nt(a, w, out=y))
   try:
-    t2 = timeit(lambda: capi.matmul_lt(a, w, b_is_t=True, out=y))
+    t2 = timeit(lambda: lt_backend.matmul_lt(a, w, b_is_t=True, out=y))
   except Exception as e:
     t2 = float("nan")
   fl = 2.0 * M * N * K

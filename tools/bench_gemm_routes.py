@@ -6,6 +6,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lt"))
+import lt_backend  # noqa: E402  (hipBLASLt comparison harness, tools only)
 from openseq2seq_amd import capi
 
 dev = torch.device("cuda:0")
@@ -39,7 +42,7 @@ for M, N, K in [(6400, 2048, 512), (6400, 2048, 1024), (6400, 2048, 1536), (6400
     res["gemm_nt"] = timeit(lambda: capi.gemm_nt(a, w, out=y))
   res["conv_k1"] = timeit(lambda: capi.conv1d_fwd(a.view(1, M, K), w.view(1, N, K), pad_left=0, tout=M, out=y.view(1, M, N)))
   try:
-    res["lt"] = timeit(lambda: capi.matmul_lt(a, w, b_is_t=True, out=y))
+    res["lt"] = timeit(lambda: lt_backend.matmul_lt(a, w, b_is_t=True, out=y))
   except Exception:
     pass
   fl = 2.0 * M * N * K
