@@ -385,11 +385,13 @@ int os2s_ctc_loss(os2s_stream_t stream, const float* logits, const int32_t* in_l
  * Adam, and the lr policies (lr_policies.py) evaluated at the device-resident
  * global step. Tensors start at multiples of os2s_opt_chunk_elems() elements.
  * ---------------------------------------------------------------------- */
+#define OS2S_LR_MAX_BOUNDARIES 16
 typedef struct {
   int optimizer;               /* 0 SGD, 1 Momentum, 2 NovoGrad, 3 Adam */
   float beta1, beta2, epsilon, weight_decay;
   int grad_averaging;          /* NovoGrad: g *= (1-beta1) */
-  int lr_policy;               /* 0 fixed, 1 poly_decay, 2 exp_decay, 3 transformer_policy, 4 cosine_decay */
+  int lr_policy;               /* 0 fixed, 1 poly_decay, 2 exp_decay, 3 transformer_policy, 4 cosine_decay,
+                                * 5 piecewise_constant (lr_policies.py:30-57), 6 inv_poly_decay (:203-245) */
   float learning_rate, min_lr, power, decay_rate, max_lr, coefficient;
   long long decay_steps, begin_decay_at, warmup_steps;
   int use_staircase_decay, d_model, has_max_lr;
@@ -402,6 +404,11 @@ typedef struct {
   long long step_window;
   float log_max, lm_beta1, lm_beta2, overflow_std_dev;
   int world_size;              /* gradients in the buffer are sums over ranks */
+  /* piecewise_constant: lr = learning_rate * pw_rates[i], i = number of boundaries < global_step
+   * (tf.train.piecewise_constant: the value changes AFTER a boundary step); pw_rates[0] = 1. */
+  int pw_count;                /* number of boundaries, <= OS2S_LR_MAX_BOUNDARIES */
+  long long pw_boundaries[16];
+  float pw_rates[17];
   int novograd_ema;            /* 0 (reference): v_t = |g_t|^2 every step — the reference graph
                                 * never assigns nvgrad2_ema* (novograd.py:107-113: the tf.cond result
                                 * only replaces the Python list entry), so beta2 is dead there;
@@ -874,6 +881,17 @@ int os2s_tts_loss(os2s_stream_t stream, const uint16_t* pred, long long ld_pred,
                   const float* target, long long ld_target, const int32_t* lens, int B, int T,
                   int F, int mode, float weight, const float* grad_scale_dev, float* partial,
                   float* loss, uint16_t* dpred);
+/* The same terms when prediction and target have different row counts per sample (eval / infer: the
+ * free-running decoder stops on its own stop token; text2speech_loss.py:80-131): both are padded to
+ * T = max(T_pred, T_target) — predictions with zeros, targets with target_pad (0 for spectrogram
+ * rows, 1 for the stop token, :100-101) — and the mask is sequence_mask(lens, T), so a live target row
+ * the decoder never produced is compared with zeros. pred rows (b,t) at pred + (b*T_pred+t)*ld_pred,
+ * target rows at target + (b*T_target+t)*ld_target; dpred (layout of pred) gets no rows past T_pred;
+ * partial: [os2s_tts_loss_num_parts(B, max(T_pred, T_target))]. */
+int os2s_tts_loss_padded(os2s_stream_t stream, const uint16_t* pred, long long ld_pred, int T_pred,
+                         const float* target, long long ld_target, int T_target, float target_pad,
+                         const int32_t* lens, int B, int F, int mode, float weight,
+                         const float* grad_scale_dev, float* partial, float* loss, uint16_t* dpred);
 /* tf.exp on the magnitude branch (decoders/tacotron2_decoder.py:541-542) and its gradient
  * helper y = a * b; out[b,c] (+)= sum_t x[b,t,c] (gradient of a vector tiled over time:
  * the style embedding, encoders/tacotron2_encoder.py:168-172). n % 8 == 0. */

@@ -546,7 +546,8 @@ class OptConfig(_lib.ctypes.Structure):
       ("scaler", c_int), ("scale_min", c_float), ("scale_max", c_float),
       ("step_factor", c_float), ("step_window", c_ll), ("log_max", c_float),
       ("lm_beta1", c_float), ("lm_beta2", c_float), ("overflow_std_dev", c_float),
-      ("world_size", c_int), ("novograd_ema", c_int),
+      ("world_size", c_int), ("pw_count", c_int), ("pw_boundaries", c_ll * 16), ("pw_rates", c_float * 17),
+      ("novograd_ema", c_int),
   ]
 
 
@@ -1406,23 +1407,25 @@ class AttnDecoder(object):
 LOSS_MSE, LOSS_L1, LOSS_SIGMOID_XENT = 0, 1, 2
 
 
-def tts_loss(pred, target, lens, F, mode, weight, loss, grad_scale_dev=None, want_grad=True):
-  """pred bf16 [B,T,ld>=F], target fp32 [B,T,ld_t>=F] (both may be column-slice views);
-  loss fp32 [1] is accumulated. Returns dpred (same shape/strides as a fresh [B,T,ld] tensor;
-  columns >= F untouched/zero) or None."""
-  B, T = pred.shape[0], pred.shape[1]
-  assert pred.stride(2) == 1 and pred.stride(0) == T * pred.stride(1)
-  assert target.stride(2) == 1 and target.stride(0) == T * target.stride(1)
+def tts_loss(pred, target, lens, F, mode, weight, loss, grad_scale_dev=None, want_grad=True, target_pad=0.0):
+  """pred bf16 [B,Tp,ld>=F], target fp32 [B,Tt,ld_t>=F] (both may be column-slice views);
+  loss fp32 [1] is accumulated. Tp != Tt: both sides padded to max(Tp, Tt) as the reference does
+  (predictions with zeros, targets with target_pad; os2s_tts_loss_padded). Returns dpred (same
+  shape/strides as a fresh [B,Tp,ld] tensor; columns >= F untouched/zero) or None."""
+  B, Tp, Tt = pred.shape[0], pred.shape[1], target.shape[1]
+  assert target.shape[0] == B
+  assert pred.stride(2) == 1 and pred.stride(0) == Tp * pred.stride(1)
+  assert target.stride(2) == 1 and target.stride(0) == Tt * target.stride(1)
   dev = pred.device
-  nparts = int(_fn("os2s_tts_loss_num_parts", (c_int, c_int))(B, T))
+  nparts = int(_fn("os2s_tts_loss_num_parts", (c_int, c_int))(B, max(Tp, Tt)))
   partial = torch.empty(nparts, dtype=torch.float32, device=dev)
-  dpred = torch.zeros((B, T, pred.stride(1)), dtype=torch.bfloat16, device=dev) if want_grad else None
-  f = _fn("os2s_tts_loss", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int,
-                            c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p))
-  _lib.check(f(_stream(), c_void_p(pred.data_ptr()), pred.stride(1), c_void_p(target.data_ptr()),
-               target.stride(1), _ptr(lens, torch.int32, True), B, T, F, mode, float(weight),
+  dpred = torch.zeros((B, Tp, pred.stride(1)), dtype=torch.bfloat16, device=dev) if want_grad else None
+  f = _fn("os2s_tts_loss_padded", (c_void_p, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_float, c_void_p,
+                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), c_void_p(pred.data_ptr()), pred.stride(1), Tp, c_void_p(target.data_ptr()),
+               target.stride(1), Tt, float(target_pad), _ptr(lens, torch.int32, True), B, F, mode, float(weight),
                _ptr(grad_scale_dev, torch.float32, True), _ptr(partial), _ptr(loss, torch.float32),
-               _ptr(dpred, None, True)), "os2s_tts_loss")
+               _ptr(dpred, None, True)), "os2s_tts_loss_padded")
   return dpred
 
 

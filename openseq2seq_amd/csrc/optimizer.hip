@@ -78,6 +78,18 @@ __device__ float lr_policy_value(const os2s_opt_config_t& c, long long step) {
       const float cosd = 0.5f * (1.f + cosf(3.14159265358979323846f * (float)s / (float)c.decay_steps));
       return lr * ((1.f - c.min_lr) * cosd + c.min_lr);
     }
+    case 5: {  // piecewise_constant (lr_policies.py:30-57 + tf.train.piecewise_constant: x <= b[0] -> v[0],
+               // b[i-1] < x <= b[i] -> v[i], x > b[-1] -> v[-1])
+      int i = 0;
+      while (i < c.pw_count && step > c.pw_boundaries[i]) ++i;
+      return lr * c.pw_rates[i];
+    }
+    case 6: {  // inv_poly_decay (lr_policies.py:203-245): lr / (1 + scale * step)^power,
+               // scale = ((lr / min_lr)^(1/power) - 1) / decay_steps, min_lr clamped to [1e-8, lr]
+      const float mn = fminf(fmaxf(c.min_lr, 1e-8f), lr);
+      const float scale = (powf(lr / mn, 1.f / c.power) - 1.f) / (float)c.decay_steps;
+      return lr / powf(1.f + scale * fs, c.power);
+    }
     default:
       return lr;
   }

@@ -12,13 +12,17 @@ namespace os2s {
 
 constexpr int kTtsRowsPerBlock = 16;
 
-// mode 0: (p-t)^2, 1: |p-t|, 2: sigmoid cross entropy with logits p and labels t
+// mode 0: (p-t)^2, 1: |p-t|, 2: sigmoid cross entropy with logits p and labels t.
+// Prediction and target may have different row counts per sample (Tp / Tt): both are padded to
+// T = max(Tp, Tt) as text2speech_loss.py:80-117 does — predictions with zeros, targets with target_pad
+// (0 for spectrogram rows, 1 for the stop token) — and the mask is sequence_mask(lens, T).
 __global__ __launch_bounds__(256) void tts_loss_kernel(
-    const bf16_t* __restrict__ pred, long long ld_p, const float* __restrict__ target,
-    long long ld_t, const int32_t* __restrict__ lens, int B, int T, int F, int mode, float weight,
-    const float* __restrict__ grad_scale_dev, float* __restrict__ partial,
+    const bf16_t* __restrict__ pred, long long ld_p, int Tp, const float* __restrict__ target,
+    long long ld_t, int Tt, float target_pad, const int32_t* __restrict__ lens, int B, int F, int mode,
+    float weight, const float* __restrict__ grad_scale_dev, float* __restrict__ partial,
     bf16_t* __restrict__ dpred) {
   __shared__ float red[4];
+  const int T = max(Tp, Tt);
   long long cnt = 0;
   for (int b = 0; b < B; ++b) cnt += lens ? min(max(lens[b], 0), T) : T;
   const float inv_n = cnt > 0 ? 1.f / ((float)cnt * (float)F) : 0.f;
@@ -30,10 +34,12 @@ __global__ __launch_bounds__(256) void tts_loss_kernel(
     if (row >= (long long)B * T) break;
     const int b = (int)(row / T), t = (int)(row - (long long)b * T);
     const bool live = !lens || t < lens[b];
+    const bool has_p = t < Tp, has_t = t < Tt;
+    const long long prow = ((long long)b * Tp + t) * ld_p, trow = ((long long)b * Tt + t) * ld_t;
     for (int f = threadIdx.x; f < F; f += 256) {
       float g = 0.f;
       if (live) {
-        const float p = bf2f(pred[row * ld_p + f]), y = target[row * ld_t + f];
+        const float p = has_p ? bf2f(pred[prow + f]) : 0.f, y = has_t ? target[trow + f] : target_pad;
         if (mode == 0) { const float d = p - y; sum += d * d; g = 2.f * d; }
         else if (mode == 1) { const float d = p - y; sum += fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
         else {
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256) void tts_loss_kernel(
           g = 1.f / (1.f + __expf(-p)) - y;
         }
       }
-      if (dpred) dpred[row * ld_p + f] = f2bf(g * gs);
+      if (dpred && has_p) dpred[prow + f] = f2bf(g * gs);
     }
   }
   sum = wave_sum(sum);
@@ -136,19 +142,29 @@ extern "C" int os2s_tts_loss_num_parts(int B, int T) {
   return ceil_div((long long)B * T, kTtsRowsPerBlock);
 }
 
+extern "C" int os2s_tts_loss_padded(os2s_stream_t stream_, const uint16_t* pred, long long ld_pred, int T_pred,
+                                    const float* target, long long ld_target, int T_target, float target_pad,
+                                    const int32_t* lens, int B, int F, int mode, float weight,
+                                    const float* grad_scale_dev, float* partial, float* loss, uint16_t* dpred) {
+  OS2S_REQUIRE(pred && target && partial && loss && B >= 1 && T_pred >= 1 && T_target >= 1 && F >= 1 &&
+               mode >= 0 && mode <= 2);
+  OS2S_REQUIRE(ld_pred >= F && ld_target >= F);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int T = std::max(T_pred, T_target);
+  const int nparts = os2s_tts_loss_num_parts(B, T);
+  OS2S_LAUNCH(tts_loss_kernel, dim3(nparts), dim3(256), 0, stream, (const bf16_t*)pred, ld_pred, T_pred, target,
+              ld_target, T_target, target_pad, lens, B, F, mode, weight, grad_scale_dev, partial, (bf16_t*)dpred);
+  OS2S_LAUNCH(tts_loss_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, nparts, lens, B, T, F,
+              weight, loss);
+  return OS2S_OK;
+}
+
 extern "C" int os2s_tts_loss(os2s_stream_t stream_, const uint16_t* pred, long long ld_pred,
                              const float* target, long long ld_target, const int32_t* lens, int B,
                              int T, int F, int mode, float weight, const float* grad_scale_dev,
                              float* partial, float* loss, uint16_t* dpred) {
-  OS2S_REQUIRE(pred && target && partial && loss && B >= 1 && T >= 1 && F >= 1 && mode >= 0 && mode <= 2);
-  OS2S_REQUIRE(ld_pred >= F && ld_target >= F);
-  hipStream_t stream = (hipStream_t)stream_;
-  const int nparts = os2s_tts_loss_num_parts(B, T);
-  OS2S_LAUNCH(tts_loss_kernel, dim3(nparts), dim3(256), 0, stream, (const bf16_t*)pred, ld_pred, target,
-              ld_target, lens, B, T, F, mode, weight, grad_scale_dev, partial, (bf16_t*)dpred);
-  OS2S_LAUNCH(tts_loss_finalize_kernel, dim3(1), dim3(256), 0, stream, partial, nparts, lens, B, T, F,
-              weight, loss);
-  return OS2S_OK;
+  return os2s_tts_loss_padded(stream_, pred, ld_pred, T, target, ld_target, T, 0.f, lens, B, F, mode, weight,
+                              grad_scale_dev, partial, loss, dpred);
 }
 
 static int ew_grid(long long n8) { return (int)std::min<long long>((n8 + 255) / 256, 4096); }

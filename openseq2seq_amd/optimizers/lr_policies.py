@@ -72,7 +72,8 @@ def inv_poly_decay(global_step, learning_rate, decay_steps, min_lr, power=1.0,
 
 
 _DEVICE_IDS = {"fixed_lr": 0, "poly_decay": 1, "exp_decay": 2, "transformer_policy": 3,
-               "cosine_decay": 4}
+               "cosine_decay": 4, "piecewise_constant": 5, "inv_poly_decay": 6}
+MAX_BOUNDARIES = 16      # OS2S_LR_MAX_BOUNDARIES
 
 
 def device_policy(policy_fn, params):
@@ -91,4 +92,16 @@ def device_policy(policy_fn, params):
              d_model=int(p.get("d_model", 1)), coefficient=float(p.get("coefficient", 1.0)),
              has_max_lr=int(p.get("max_lr") is not None),
              max_lr=float(p.get("max_lr") or 0.0))
+  if name == "piecewise_constant":
+    bounds = list(p["boundaries"])
+    if p.get("steps_per_epoch") is not None:
+      bounds = [p["steps_per_epoch"] * e for e in bounds]
+    rates = [1.0] + list(p["decay_rates"])
+    if len(bounds) > MAX_BOUNDARIES or len(rates) != len(bounds) + 1:
+      raise ValueError("piecewise_constant: at most %d boundaries, one decay rate per boundary" % MAX_BOUNDARIES)
+    out["pw_count"] = len(bounds)
+    out["pw_boundaries"] = [int(b) for b in bounds]
+    out["pw_rates"] = [float(r) for r in rates]
+  if name == "inv_poly_decay" and float(p.get("power", 1.0)) <= 0.0:
+    raise ValueError("Inv poly decay requires power >  0.")
   return out

@@ -67,7 +67,12 @@ def build_opt_config(optimizer, optimizer_params, learning_rate_decay_fn,
     cfg.beta1, cfg.beta2 = op.get("beta1", 0.9), op.get("beta2", 0.999)
     cfg.epsilon = op.get("epsilon", 1e-8)
   for k, v in lr_policies.device_policy(learning_rate_decay_fn, lr_policy_params).items():
-    setattr(cfg, k, v)
+    if isinstance(v, list):            # fixed-size arrays of the config struct (piecewise_constant)
+      arr = getattr(cfg, k)
+      for i, e in enumerate(v):
+        arr[i] = e
+    else:
+      setattr(cfg, k, v)
   if larc_params is not None:
     check_params(larc_params, {'larc_eta': float},
                  {'larc_mode': ['clip', 'scale'], 'min_update': float, 'epsilon': float})

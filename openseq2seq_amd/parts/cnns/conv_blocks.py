@@ -596,9 +596,11 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
         if inp.requires_grad:
           grouped.append((br, inp, dy))
       elif j == 0 and br is main and type(br) is ConvBN:
-        # the last contribution to its input's gradient (with the block dropped, branches[0] is a
-        # RESIDUAL branch whose input still has later-running consumers: never final)
-        br.backward_branch(inp, dy, f, final=True)
+        # the last contribution to its input's gradient — unless the same activation also feeds a
+        # residual branch of THIS call (a residual block with repeat = 1), which runs after it.
+        # (With the block dropped, branches[0] is a RESIDUAL branch whose input still has
+        # later-running consumers: never final.)
+        br.backward_branch(inp, dy, f, final=all(r is not inp for r in inputs[1:]))
       else:
         br.backward_branch(inp, dy, f)
     if wgrouped:

@@ -71,6 +71,28 @@ def transformer_policy(global_step, learning_rate, d_model, warmup_steps, max_lr
   return min(max_lr, new_lr) if max_lr is not None else new_lr
 
 
+def piecewise_constant(global_step, learning_rate, boundaries, decay_rates, steps_per_epoch=None):
+  """lr_policies.py:30-57 over tf.train.piecewise_constant(x, boundaries, values): values[0] for
+  x <= boundaries[0], values[i] for boundaries[i-1] < x <= boundaries[i], values[-1] beyond."""
+  if steps_per_epoch is not None:
+    boundaries = [steps_per_epoch * e for e in boundaries]
+  vals = [learning_rate * d for d in [1.0] + list(decay_rates)]
+  for i, b in enumerate(boundaries):
+    if global_step <= b:
+      return vals[i]
+  return vals[-1]
+
+
+def inv_poly_decay(global_step, learning_rate, decay_steps, min_lr, power=1.0, begin_decay_at=0,
+                   warmup_steps=0):
+  """lr_policies.py:203-245: lr / (1 + scale * t)^power with scale chosen so that lr(decay_steps) =
+  min_lr (clamped to [1e-8, learning_rate]); begin_decay_at / warmup_steps are accepted and unused,
+  as in the reference."""
+  min_lr = min(max(min_lr, 1e-8), learning_rate)
+  scale = (math.pow(learning_rate / min_lr, 1.0 / power) - 1.0) / decay_steps
+  return learning_rate / math.pow(1.0 + scale * global_step, power)
+
+
 # ---------------------------------------------------------------------------
 # loss scalers (automatic_loss_scaler.py)
 # ---------------------------------------------------------------------------

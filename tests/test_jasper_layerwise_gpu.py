@@ -159,3 +159,211 @@ def test_jasper10x5_every_layer_teacher_forced(cuda, monkeypatch):
   assert sorted(grouped_seen) == sorted(list(range(2, 11)) * 2), grouped_seen
   print("jasper10x5 layer by layer (rel-L2, device vs bf16-storage oracle): worst", worst,
         "| worst output vs plain fp32 oracle %.3e" % worst_fp32)
+
+
+def _oracle_weights(store, prefix, names):
+  w = {}
+  for n in names:
+    p = store.by_name(prefix + n)
+    w[n] = (p.w16.float().cpu().permute(0, 2, 1).contiguous() if p.kind == "conv"
+            else p.master.cpu().clone()).requires_grad_(True)
+  return w
+
+
+def _layer_names(name, nres):
+  names = [name + "/kernel", name + "/bn/gamma", name + "/bn/beta"]
+  for i in range(nres):
+    names += [name + "/res_%d/kernel" % i, name + "/res_bn_%d/gamma" % i, name + "/res_bn_%d/beta" % i]
+  return names
+
+
+def test_jasper10x5_layer_pairs_fused_bn_backward(cuda, monkeypatch):
+  """The BatchNorm-backward reduction of a single-input conv + BN + ReLU layer rides in the epilogue of
+  the NEXT layer's data gradient (capi.conv1d_dgrad_bnact -> os2s_conv1d_dgrad_bnact_ws, finished by
+  os2s_bn_bwd_finalize_raw; parts/cnns/conv_blocks.py ConvBN.backward_branch(final=True)): 41 of the
+  53 layers of Jasper 10x5. That path only exists when layer L+1 consumes layer L's REAL output Act
+  (it carries bn_y), so the one-layer test above never takes it. Here every consecutive pair
+  (L, L+1) with L a plain conv_bn_actv layer — repeats 1-4 of the ten blocks, i.e. 384 ... 896 channels on
+  the 256 x 256 ping-pong tile, K = 13 ... 29, and the dilated 896-channel layer in front of the 1 x 1
+  1024-channel one — runs as a two-layer device graph on a ragged batch against the composition of two
+  oracle layers (oracle/tdnn.py:tdnn_layer with bf16-storage emulation), teacher-forced with the tensors
+  the device network produced. Asserted per pair: the fused call happened; layer L's d(gamma), d(beta),
+  d(kernel) and d(input) and layer L+1's parameter gradients within the one-layer test's bounds
+  (6e-3 / 1e-2 rel-L2). The accumulate = True flavour of the fused epilogue (layer L's output has a second,
+  earlier-finishing consumer) is test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers."""
+  from openseq2seq_amd import capi
+  from openseq2seq_amd.configs.jasper import jasper_convnet_layers
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
+  from openseq2seq_amd.parts.cnns.conv_blocks import Act, Tape, conv_bn_res_bn_actv
+  from oracle import cnn, tdnn
+  torch.manual_seed(0)
+  cfg_layers = [dict(l, dropout_keep_prob=1.0) for l in jasper_convnet_layers()]
+  store = FlatParams(cuda)
+  enc = TDNNEncoder({"convnet_layers": cfg_layers, "dropout_keep_prob": 1.0, "activation_fn": "relu",
+                     "use_conv_mask": True, "dtype": "mixed"}, None, mode="train").build(store, 64)
+  store.finalize()
+  g = torch.Generator().manual_seed(5)
+  B, T = 4, 600
+  lens0 = torch.tensor([600, 452, 300, 130], dtype=torch.int32)
+  x0 = torch.randn(B, T, 64, generator=g).to(torch.bfloat16)
+  prefix = "ForwardPass/w2l_encoder/"
+  nl = len(enc._layers)
+  fused_calls = []
+  orig = capi.conv1d_dgrad_bnact
+
+  def counting(dy, wt, g_, **kw):
+    fused_calls.append((tuple(dy.shape), tuple(g_.shape), bool(kw.get("accumulate", False))))
+    return orig(dy, wt, g_, **kw)
+  monkeypatch.setattr(capi, "conv1d_dgrad_bnact", counting)
+
+  # ---- device chain: realistic inputs for every layer (post-ReLU, masked, bf16) ------------------
+  x = Act(x0.to(cuda), lens0.to(cuda), requires_grad=False)
+  src_len = lens0.clone()
+  res_agg, layer_res, lens_dev = [], [], None
+  layer_in = []          # per layer: (input Act data, input lens, residual datas, out lens (host), lens_dev)
+  for li, L in enumerate(enc._layers):
+    blk = L["cfg"]
+    if L["rep"] == 0 and blk.get("residual", False):
+      res_agg.append(x)
+      layer_res = list(res_agg)
+    s = blk["stride"][0]
+    src_len = (src_len + s - 1) // s
+    if s > 1 or li == 0:
+      lens_dev = src_len.to(cuda)
+    last = li == nl - 1
+    rin = [Act(r.data, r.lens, requires_grad=False) for r in layer_res] if L["res"] else []
+    layer_in.append(dict(x=x, res=list(layer_res) if L["res"] else [], src_len=src_len.clone(), lens_dev=lens_dev))
+    out = conv_bn_res_bn_actv(L["main"], L["res"], Act(x.data, x.lens, requires_grad=False), rin, lens_dev,
+                              "relu", True, None, keep_prob=1.0, seed=li, mask_output=not last)
+    x = Act(out.data, None if last else lens_dev, requires_grad=False)
+  torch.cuda.synchronize()
+
+  pairs = [li for li, L in enumerate(enc._layers[:-1])
+           if li > 0 and not L["res"] and L["main"].stride == 1 and enc._layers[li + 1]["main"].stride == 1]
+  assert len(pairs) == 41, len(pairs)
+  worst = {"dbn": (0.0, ""), "dw": (0.0, ""), "dx": (0.0, ""), "out": (0.0, "")}
+  for li in pairs:
+    La, Lb = enc._layers[li], enc._layers[li + 1]
+    ia, ib = layer_in[li], layer_in[li + 1]
+    last_b = li + 1 == nl - 1
+    na = "conv%d%d" % (La["block"] + 1, La["rep"] + 1)
+    nb = "conv%d%d" % (Lb["block"] + 1, Lb["rep"] + 1)
+    # ---- device: two layers on ONE tape, layer b consumes layer a's real output -----------------
+    store.zero_grads()
+    n_before = len(fused_calls)
+    xin = Act(ia["x"].data, ia["x"].lens, requires_grad=True)
+    rin = [Act(r.data, r.lens, requires_grad=True) for r in ib["res"]]
+    tape = Tape()
+    ya = conv_bn_res_bn_actv(La["main"], [], xin, [], ia["lens_dev"], "relu", True, tape, keep_prob=1.0, seed=li)
+    assert ya.bn_y is not None, na
+    yb = conv_bn_res_bn_actv(Lb["main"], Lb["res"], ya, rin, ib["lens_dev"], "relu", True, tape, keep_prob=1.0,
+                             seed=li + 1, mask_output=not last_b)
+    dy = torch.randn(yb.data.shape, generator=g).to(torch.bfloat16)
+    yb.grad = dy.to(cuda)
+    tape.backward()
+    torch.cuda.synchronize()
+    assert len(fused_calls) == n_before + 1, (na, nb, fused_calls[n_before:])
+    assert fused_calls[-1][1] == tuple(ya.data.shape) and fused_calls[-1][2] is False
+    # ---- oracle: the same two layers composed --------------------------------------------------
+    names_a, names_b = _layer_names(na, 0), _layer_names(nb, len(Lb["res"]))
+    w = _oracle_weights(store, prefix, names_a + names_b)
+    Ta = ia["x"].data.shape[1]
+    in_len = ia["x"].lens.cpu()
+    in_mask = cnn.seq_mask(in_len, Ta)
+    mask_a = cnn.seq_mask(ia["src_len"], ya.data.shape[1])
+    mask_b = cnn.seq_mask(ib["src_len"], yb.data.shape[1])
+    xo = ia["x"].data.float().cpu().requires_grad_(True)
+    ro = [r.data.float().cpu().requires_grad_(True) for r in ib["res"]]
+    oa = tdnn.tdnn_layer(xo * in_mask, [], La["cfg"], na, w, mask_a, "relu", 1e-3, None, 1.0, True)
+    ob = tdnn.tdnn_layer(oa * mask_a, [r * mask_b for r in ro], Lb["cfg"], nb, w, None if last_b else mask_b,
+                         "relu", 1e-3, None, 1.0, True)
+    (ob * dy.float()).sum().backward()
+    tag = "%s -> %s (layers %d, %d: %d->%d K=%d d=%d, then %d->%d K=%d d=%d, %d residual branches)" % (
+        na, nb, li, li + 1, La["main"].cin, La["main"].cout, La["main"].k, La["main"].dil, Lb["main"].cin,
+        Lb["main"].cout, Lb["main"].k, Lb["main"].dil, len(Lb["res"]))
+    live_b = mask_b.bool().expand_as(ob) if not last_b else torch.ones_like(ob, dtype=torch.bool)
+    r = _rel(yb.data.float().cpu()[live_b], ob.detach()[live_b])
+    worst["out"] = max(worst["out"], (r, tag))
+    assert r <= 2e-3, ("output", tag, r)
+    live_in = in_mask.bool().expand_as(xo)
+    gx = xin.grad.float().cpu()
+    r, c = _rel(gx[live_in], xo.grad[live_in]), _cos(gx[live_in], xo.grad[live_in])
+    worst["dx"] = max(worst["dx"], (r, tag))
+    assert r <= 6e-3 and c >= 0.9999, ("d(input of layer L)", tag, r, c)
+    for n in names_a + names_b:
+      p = store.by_name(prefix + n)
+      ref = w[n].grad.permute(0, 2, 1) if p.kind == "conv" else w[n].grad
+      gp = p.grad.float().cpu()
+      r, c = _rel(gp, ref), _cos(gp, ref)
+      if p.kind == "conv":
+        worst["dw"] = max(worst["dw"], (r, tag + " " + n))
+        assert r <= 6e-3 and c >= 0.9999, ("d(kernel)", tag, n, r, c)
+      else:
+        worst["dbn"] = max(worst["dbn"], (r, tag + " " + n))
+        assert r <= 1e-2, ("d(gamma/beta)", tag, n, r, c)
+  print("jasper10x5 layer pairs through the fused dgrad + BatchNorm-backward epilogue (rel-L2 vs bf16-storage "
+        "oracle): worst", worst)
+
+
+@pytest.mark.parametrize("C,K,dil", [(640, 21, 1), (768, 13, 2), (384, 13, 1)])
+def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, monkeypatch, C, K, dil):
+  """accumulate = True in the fused epilogue: layer A (plain conv + BN + ReLU, stride 1) feeds a residual
+  block of two repeats — its first repeat's main convolution AND the block end's 1 x 1 residual branch.
+  The residual branch's data gradient reaches A's output gradient first (the block end runs first in
+  backward); the first repeat's data gradient is the LAST contribution and adds
+  (dgrad) onto it before the ReLU mask and the BatchNorm partial sums are taken (`accumulate=inp.grad_init`).
+  Checked against three composed oracle layers at ping-pong widths, ragged."""
+  from openseq2seq_amd import capi
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+  from oracle import cnn, tdnn
+  torch.manual_seed(3)
+  layers = [
+      {"type": "conv1d", "repeat": 1, "kernel_size": [K], "stride": [1], "num_channels": C, "padding": "SAME",
+       "dilation": [dil], "dropout_keep_prob": 1.0},
+      {"type": "conv1d", "repeat": 2, "kernel_size": [K], "stride": [1], "num_channels": C, "padding": "SAME",
+       "dilation": [dil], "dropout_keep_prob": 1.0, "residual": True, "residual_dense": True},
+  ]
+  store = FlatParams(cuda)
+  enc = TDNNEncoder({"convnet_layers": layers, "dropout_keep_prob": 1.0, "activation_fn": "relu",
+                     "use_conv_mask": True, "dtype": "mixed"}, None, mode="train").build(store, C)
+  store.finalize()
+  g = torch.Generator().manual_seed(9)
+  B, T = 5, 330
+  lens = torch.tensor([330, 257, 256, 129, 40], dtype=torch.int32)
+  x0 = (torch.randn(B, T, C, generator=g) * cnn.seq_mask(lens, T)).to(torch.bfloat16)
+  calls = []
+  orig = capi.conv1d_dgrad_bnact
+
+  def counting(dy, wt, g_, **kw):
+    calls.append(bool(kw.get("accumulate", False)))
+    return orig(dy, wt, g_, **kw)
+  monkeypatch.setattr(capi, "conv1d_dgrad_bnact", counting)
+  store.zero_grads()
+  tape = Tape()
+  e = enc.encode({"source_tensors": [x0.to(cuda), lens.to(cuda)], "tape": tape, "seed": 3})
+  out = e["outputs_act"]
+  dy = torch.randn(out.data.shape, generator=g).to(torch.bfloat16)
+  out.grad = dy.to(cuda)
+  tape.backward()
+  torch.cuda.synchronize()
+  # two fused calls: block end -> repeat 1's output (fresh), repeat 1 -> layer A's output (accumulating)
+  assert calls == [False, True], calls
+  prefix = "ForwardPass/w2l_encoder/"
+  names = _layer_names("conv11", 0) + _layer_names("conv21", 0) + _layer_names("conv22", 1)
+  w = _oracle_weights(store, prefix, names)
+  m = cnn.seq_mask(lens, T)
+  xo = x0.float().requires_grad_(True)
+  a = tdnn.tdnn_layer(xo * m, [], layers[0], "conv11", w, m, "relu", 1e-3, None, 1.0, True)
+  r1 = tdnn.tdnn_layer(a * m, [], layers[1], "conv21", w, m, "relu", 1e-3, None, 1.0, True)
+  r2 = tdnn.tdnn_layer(r1 * m, [a * m], layers[1], "conv22", w, None, "relu", 1e-3, None, 1.0, True)
+  (r2 * dy.float()).sum().backward()
+  assert _rel(out.data.float().cpu(), r2.detach()) <= 2e-3
+  for n in names:
+    p = store.by_name(prefix + n)
+    ref = w[n].grad.permute(0, 2, 1) if p.kind == "conv" else w[n].grad
+    gp = p.grad.float().cpu()
+    r, c = _rel(gp, ref), _cos(gp, ref)
+    assert r <= (6e-3 if p.kind == "conv" else 1e-2) and c >= 0.9999, (n, r, c)

@@ -187,3 +187,36 @@ def test_conv_weight_dgrad_copies_every_shape_class(cuda):
   for p in store.params:
     want = p.w16.float().cpu().flip(0).permute(0, 2, 1)
     torch.testing.assert_close(p.wt16.float().cpu(), want, rtol=0, atol=0)
+
+
+def test_lr_policies_cosine_piecewise_inv_poly_on_device(cuda):
+  """The three lr policies the earlier tests never ran on the GPU (device ids 4, 5, 6 of
+  os2s_opt_config_t.lr_policy: lr_policies.py:134-170, :30-57, :203-245): weights after 12 Momentum
+  steps follow the oracle, and the lr the kernel latched at every step equals the host formula
+  (warm-up, begin_decay_at, boundary steps themselves, the far end of the schedule)."""
+  cases = [
+      ("cosine_decay", dict(learning_rate=0.05, decay_steps=9, min_lr=0.1, begin_decay_at=2, warmup_steps=2)),
+      ("cosine_decay", dict(learning_rate=0.05, decay_steps=5)),
+      ("piecewise_constant", dict(learning_rate=0.04, boundaries=[2, 3, 7], decay_rates=[0.5, 0.1, 0.02])),
+      ("piecewise_constant", dict(learning_rate=0.04, boundaries=[1, 2], decay_rates=[0.3, 0.05], steps_per_epoch=3)),
+      ("inv_poly_decay", dict(learning_rate=0.03, decay_steps=10, min_lr=1e-4, power=0.75)),
+      ("inv_poly_decay", dict(learning_rate=0.03, decay_steps=4, min_lr=0.0, power=2.0)),
+  ]
+  from openseq2seq_amd.optimizers import lr_policies
+  for lr_fn, lr_params in cases:
+    st = _run(cuda, "Momentum", dict(momentum=0.9), lr_fn, lr_params, loss_scaling=1.0, nsteps=12, inf_step=-1)
+    assert st["global_step"] == 12
+    # the lr of the LAST applied step (global step 11 at the time of the update)
+    want = getattr(oopt, lr_fn)(11, **lr_params)
+    assert abs(st["lr"] - want) <= 2e-6 * max(abs(want), 1e-6) + 1e-12, (lr_fn, lr_params, st["lr"], want)
+    # product-side host function == oracle at every step of the schedule
+    for step in range(0, 40):
+      a, b = getattr(lr_policies, lr_fn)(step, **lr_params), getattr(oopt, lr_fn)(step, **lr_params)
+      assert abs(a - b) <= 1e-12 + 1e-9 * abs(b), (lr_fn, step, a, b)
+
+
+def test_piecewise_constant_rejects_too_many_boundaries(cuda):
+  from openseq2seq_amd.optimizers import lr_policies
+  with pytest.raises(ValueError):
+    lr_policies.device_policy(lr_policies.piecewise_constant,
+                              dict(learning_rate=0.1, boundaries=list(range(1, 19)), decay_rates=[0.5] * 18))

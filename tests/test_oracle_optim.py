@@ -67,3 +67,27 @@ def test_novograd_second_moment_follows_the_reference_graph_as_written():
                           lr_fn=lambda s: 1.0)
   ema.step(g1); ema.step(g2)
   assert float(ema.ema[0]) == 13.0
+
+
+def test_piecewise_constant_and_inv_poly_closed_forms():
+  """lr_policies.py:30-57 / :203-245. tf.train.piecewise_constant switches AFTER a boundary step
+  (x <= b uses the earlier value); inv_poly_decay hits learning_rate at step 0 and min_lr at decay_steps."""
+  from oracle import optim as o
+  pw = dict(learning_rate=0.1, boundaries=[3, 5], decay_rates=[0.5, 0.25])
+  got = [o.piecewise_constant(s, **pw) for s in range(8)]
+  assert got == [0.1, 0.1, 0.1, 0.1, 0.05, 0.05, 0.025, 0.025], got
+  ep = dict(learning_rate=1.0, boundaries=[1, 2], decay_rates=[0.1, 0.01], steps_per_epoch=10)
+  assert o.piecewise_constant(10, **ep) == 1.0 and o.piecewise_constant(11, **ep) == 0.1
+  assert o.piecewise_constant(20, **ep) == 0.1 and o.piecewise_constant(21, **ep) == 0.01
+  ip = dict(learning_rate=0.03, decay_steps=100, min_lr=1e-4, power=0.5)
+  assert abs(o.inv_poly_decay(0, **ip) - 0.03) < 1e-12
+  assert abs(o.inv_poly_decay(100, **ip) - 1e-4) < 1e-12
+  assert o.inv_poly_decay(50, **ip) < o.inv_poly_decay(49, **ip)
+  # min_lr is clamped into [1e-8, learning_rate]
+  assert abs(o.inv_poly_decay(100, 0.03, 100, 0.0, 1.0) - 1e-8) < 1e-15
+  assert abs(o.inv_poly_decay(100, 0.03, 100, 1.0, 1.0) - 0.03) < 1e-12
+  # the product's host-side policies are the same functions of the step
+  from openseq2seq_amd.optimizers import lr_policies as lp
+  for s in range(0, 130, 7):
+    assert abs(lp.inv_poly_decay(s, **ip) - o.inv_poly_decay(s, **ip)) < 1e-15
+    assert lp.piecewise_constant(s, **ep) == o.piecewise_constant(s, **ep)
