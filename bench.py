@@ -58,6 +58,9 @@ def parse():
                   help="QuartzNet 15x5 (separable convolutions) train step only: frames/sec")
   ap.add_argument("--only-tacotron", action="store_true",
                   help="Tacotron2 (tacotron_gst.py shapes) train step only: mel frames/sec")
+  ap.add_argument("--only-tacotron-decode", action="store_true",
+                  help="Tacotron2-GST free-running decode (BASELINE configs[4]) only: mel frames/sec, us per step")
+  ap.add_argument("--decode-steps", type=int, default=1000)
   ap.add_argument("--no-style", action="store_true", help="Tacotron2 without the GST style encoder")
   ap.add_argument("--no-fp8", action="store_true",
                   help="Tacotron2 with bf16 decoder weights (default: e4m3 copies, BASELINE configs[4])")
@@ -355,6 +358,153 @@ class StepBreakdown(object):
     return out
 
 
+class FamilyBrackets(object):
+  """HIP-event pairs around every call of some capi entry points during `steps` extra train steps with the
+  side stream off (every kernel alone on the GPU): what the roofline blocks of the other configurations
+  are computed from. spec: {capi function name: (family label, work(args, kwargs) -> number)}."""
+
+  def __init__(self, capi, spec):
+    self.capi, self.spec, self.rec, self.saved = capi, spec, {}, {}
+
+  def run(self, model, batch, steps=2):
+    capi = self.capi
+    prev = os.environ.get("OS2S_WGRAD_STREAM")
+    os.environ["OS2S_WGRAD_STREAM"] = "0"
+    for name, (fam, work) in self.spec.items():
+      orig = getattr(capi, name)
+      self.saved[name] = orig
+
+      def wrapped(*a, _orig=orig, _fam=fam, _work=work, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = _orig(*a, **kw)
+        e1.record()
+        r = self.rec.setdefault(_fam, [0, [], 0.0])
+        r[0] += 1
+        r[1].append((e0, e1))
+        r[2] += float(_work(a, kw))
+        return out
+      setattr(capi, name, wrapped)
+    try:
+      for _ in range(steps):
+        model.train_step(batch)
+      torch.cuda.synchronize()
+    finally:
+      for name, fn in self.saved.items():
+        setattr(capi, name, fn)
+      if prev is None:
+        os.environ.pop("OS2S_WGRAD_STREAM", None)
+      else:
+        os.environ["OS2S_WGRAD_STREAM"] = prev
+    out = {}
+    for fam, (n, evs, work) in self.rec.items():
+      ms = sum(a.elapsed_time(b) for a, b in evs)
+      out[fam] = {"launches_per_step": n / float(steps), "ms_per_step": ms / steps, "work_per_step": work / steps}
+    return out
+
+
+def _roofline(bound, kernel, achieved, how, traffic=None, **extra):
+  peak = HBM_PEAK_GBS if bound == "hbm" else BF16_DENSE_PEAK_TFLOPS
+  d = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": peak,
+       "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "how": how}
+  d.update(extra)
+  return d
+
+
+def other_config_roofline(key, model, batch, res):
+  """The roofline block of one `other_configs` entry: what bounds the configuration's
+  dominant kernel family, measured in a serial pass after the timed steps."""
+  from openseq2seq_amd import capi
+  if key == "ds2":
+    # the recurrence: one persistent launch per GRU layer and pass (csrc/rnn_xcd.hip) or one launch per step
+    def steps_of(a, kw):
+      dirs = a[1]
+      t = dirs[0]["gx"] if "gx" in dirs[0] else dirs[0]["dy"]
+      return t.shape[1]           # sequential steps of the call (both directions advance together)
+    fb = FamilyBrackets(capi, {"rnn_layer_fwd_multi": ("recurrence forward", steps_of),
+                               "rnn_layer_bwd_multi": ("recurrence backward", steps_of)}).run(model, batch)
+    enc = model.get_encoder()
+    H = enc.params["rnn_cell_dim"]
+    B = batch["source_tensors"][0].shape[0]
+    f, b = fb.get("recurrence forward"), fb.get("recurrence backward")
+    us_f = 1e3 * f["ms_per_step"] / max(f["work_per_step"], 1) if f else None
+    us_b = 1e3 * b["ms_per_step"] / max(b["work_per_step"], 1) if b else None
+    rec_ms = (f["ms_per_step"] if f else 0.0) + (b["ms_per_step"] if b else 0.0)
+    # per sequential step and direction: recurrent product 2 * B * 3H * H FLOP forward, twice that backward
+    flop = 2.0 * 2 * B * 3 * H * H * ((f["work_per_step"] if f else 0) + 2 * (b["work_per_step"] if b else 0))
+    return _roofline(
+        "mfma", "gru_xcd_fwd_kernel / gru_xcd_bwd_kernel (persistent, one XCD per direction)",
+        flop / (rec_ms * 1e-3) / 1e12 if rec_ms else 0.0,
+        "recurrent-product FLOPs of the bracketed launches / their time (serial pass). The recurrence is bound "
+        "by its per-step exchange, not by the matrix pipe: see us_per_step",
+        us_per_step_forward=us_f, us_per_step_backward=us_b, recurrence_ms_per_train_step=rec_ms,
+        share_of_step=rec_ms / res["ms_per_step"],
+        exchange_bytes_per_step_per_direction=B * H * 2,
+        exchange="all-gather (forward) / reduce-scatter (backward) of the bf16 state among the 32 workgroups of one "
+                 "XCD through that XCD's L2, 16-byte tagged granules; the guide prices a 16-32 KB all-gather at "
+                 "2.4-4.2 us (MI355X_MICROARCH.md, row allgather)",
+        )
+  if key == "quartznet":
+    def dw_bytes(a, kw):
+      x = a[0]
+      return 2.0 * x.numel() * 2          # read x, write y (bf16); the [K, C] filter is noise
+    fb = FamilyBrackets(capi, {"depthwise_conv1d_fwd": ("depthwise forward / data gradient", dw_bytes),
+                               "depthwise_conv1d_wgrad": ("depthwise weight gradient", dw_bytes)}).run(model, batch)
+    ms = sum(v["ms_per_step"] for v in fb.values())
+    by = sum(v["work_per_step"] for v in fb.values())
+    return _roofline("hbm", "depthwise_fwd / depthwise_wgrad register-window kernels (csrc/depthwise.hip)",
+                     by / (ms * 1e-3) / 1e9 if ms else 0.0,
+                     "algorithmic bytes (input + output, bf16) of the bracketed depthwise launches / their time; the "
+                     "kernels are VALU-bound (2 K FLOP per element, K = 33 ... 87), so this is far below the HBM peak "
+                     "by construction", depthwise_ms_per_train_step=ms, share_of_step=ms / res["ms_per_step"],
+                     families=fb)
+  if key in ("nmt", "tacotron"):
+    # sequential decoder loops: price the loop launches
+    def steps_fwd(a, kw):
+      self_ = a[0]
+      t0 = a[1] if len(a) > 1 else kw.get("t_begin", 0)
+      t1 = a[2] if len(a) > 2 else kw.get("t_end")
+      return (self_.dims["T"] if t1 is None else t1) - t0
+    saved_f, saved_b = capi.AttnDecoder.forward, capi.AttnDecoder.backward
+    rec = {"f": [0.0, [], 0], "b": [0.0, [], 0]}
+
+    def fwd(self_, *a, **kw):
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(); out = saved_f(self_, *a, **kw); e1.record()
+      rec["f"][1].append((e0, e1)); rec["f"][2] += steps_fwd((self_,) + a, kw)
+      return out
+
+    def bwd(self_, *a, **kw):
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(); out = saved_b(self_, *a, **kw); e1.record()
+      rec["b"][1].append((e0, e1)); rec["b"][2] += self_.dims["T"]
+      return out
+    capi.AttnDecoder.forward, capi.AttnDecoder.backward = fwd, bwd
+    try:
+      for _ in range(2):
+        model.train_step(batch)
+      torch.cuda.synchronize()
+    finally:
+      capi.AttnDecoder.forward, capi.AttnDecoder.backward = saved_f, saved_b
+    msf = sum(a.elapsed_time(b) for a, b in rec["f"][1]) / 2
+    msb = sum(a.elapsed_time(b) for a, b in rec["b"][1]) / 2
+    nf, nb = rec["f"][2] / 2.0, rec["b"][2] / 2.0
+    dec = model.get_decoder()
+    cell = dec.cell
+    # bytes a decoder step must stream: the recurrent weight matrices of the loop (bf16, or e4m3 forward)
+    wbytes = sum(w.numel for w in cell.wcat) * (1.0 if getattr(cell, "fp8_weights", False) else 2.0)
+    us_f = 1e3 * msf / max(nf, 1)
+    return _roofline("hbm", "attention-decoder loop (ad_cell_fwd / ad_loc_* / ad_attn_* kernels, csrc/attn_decoder.hip)",
+                     wbytes / (us_f * 1e-6) / 1e9 if us_f else 0.0,
+                     "recurrent weight bytes a forward decoder step streams / its measured time; the loop is a chain of "
+                     "dependent launches (latency-bound), the weights are re-read from L2 / MALL every step",
+                     us_per_decoder_step_forward=us_f, us_per_decoder_step_backward=1e3 * msb / max(nb, 1),
+                     decoder_steps_per_train_step=nf, loop_ms_per_train_step=msf + msb,
+                     share_of_step=(msf + msb) / res["ms_per_step"], weight_bytes_per_step=wbytes)
+  return None
+
+
+
 def tensorflow_probe():
   """SURVEY 8d plan (1): the reference's own TF1 CPU path as the baseline when TensorFlow is
   importable on the bench host. It is not part of this image (and /root/reference does not travel
@@ -556,7 +706,7 @@ def bench_transformer(args, hvd, dev, rank, world):
   return res
 
 
-def bench_simple(spec, steps, warmup, hvd, dev, rank, world):
+def bench_simple(spec, steps, warmup, hvd, dev, rank, world, roofline_key=None):
   """One model of BASELINE.json's other configs: K timed train steps on a synthetic batch."""
   import importlib
   mod, fn, kw, metric, count_key, unit = spec
@@ -576,6 +726,11 @@ def bench_simple(spec, steps, warmup, hvd, dev, rank, world):
          "dtype": "fp8-weights" if kw.get("fp8_weights") else "bf16",
          "ms_per_step": 1000 * dt / steps, "n_gpus": world, "steps": steps,
          "params_M": model.store.num_trainable() / 1e6, "loss": float(loss.cpu()[0])}
+  if roofline_key is not None:
+    try:
+      res["roofline"] = other_config_roofline(roofline_key, model, batch, res)
+    except Exception as e:      # a diagnostic must not lose the measurement
+      res["roofline"] = {"error": repr(e)}
   del model
   torch.cuda.empty_cache()
   return res
@@ -605,6 +760,71 @@ def bench_transformer_infer(dev, batch=64, reps=2):
          "value": batch * beam * steps / best, "unit": "positions/sec",
          "ms_per_decode_step": 1000 * best / steps, "decode_steps": steps, "sentences": batch,
          "beam_size": beam, "ms_per_batch": 1000 * best}
+  del model
+  torch.cuda.empty_cache()
+  return res
+
+
+def bench_tacotron_decode(dev, style=True, fp8=True, batch=32, steps=1000, reps=2):
+  """BASELINE.json configs[4] as it is named: Tacotron2-GST free-running DECODE with fp8 weights (eval / infer
+  mode of tacotron_gst.py: TacotronHelper, parts/tacotron/tacotron_helper.py:138-226). B = 32 utterances, text
+  lengths U[20, 200], random-init weights. The reference decodes until every stop token has fired or 10 x
+  max(src_len) steps; random weights make the stop token meaningless, so the loop is run for a FIXED number of
+  steps (mask_decoder_sequence off: the full per-step work, including the stop projection and the device-side
+  bookkeeping, still runs). Timed: the whole infer call — encoder + style tokens, memory keys, the step loop,
+  post-net, magnitude branch — with the batch resident in HBM; us_per_step comes from the difference of two run
+  lengths (it excludes everything outside the loop)."""
+  from openseq2seq_amd.configs.tacotron import tacotron_gst_config
+  model_cls, params = tacotron_gst_config(batch_size_per_gpu=batch, style=style, fp8_weights=fp8)
+  params["decoder_params"]["mask_decoder_sequence"] = False
+  model = model_cls(params, mode="infer", hvd=None, device=dev)
+  model.compile()
+  data = model.get_data_layer().synthetic_batch(dev, seed=4321)
+
+  def run(n):
+    best = None
+    for _ in range(reps + 1):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      out = model.infer_batch(data, max_decoder_steps=n)
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      best = dt if best is None else min(best, dt)
+    return best, out
+
+  t_full, out = run(steps)
+  t_half, _ = run(steps // 2)
+  us = 1e6 * (t_full - t_half) / (steps - steps // 2)
+  dec = model.get_decoder()
+  cell = dec.cell
+  src_len = data["source_tensors"][1].float()
+  S = int(data["source_tensors"][0].shape[1])
+  live = float(src_len.sum())
+  H, M, U, P, nm = cell.H, cell.M, cell.U, dec.prenet[0].cout, dec.n_mel
+  wb = 1.0 if fp8 else 2.0
+  by = {"lstm_weights": wb * (4 * H * (P + M + H) + 4 * H * 2 * H) + (4.0 * 8 * H if fp8 else 0.0),
+        "query_frame_prenet_weights": 2.0 * (U * H + nm * H + P * nm + P * P),
+        "memory_values_live_rows": 2.0 * live * M, "memory_keys_live_rows": 2.0 * live * U,
+        "frame_projection_of_values_live_rows": 4.0 * live * nm,
+        "state_vectors": 2.0 * batch * (P + M + H + 2 * H) * 2 + 4.0 * batch * (2 * H + 3 * S)}
+  total = sum(by.values())
+  fused = out.get("decoder_steps") == steps
+  res = {"metric": "mel-frames/sec Tacotron2-GST free-running decode (%s decoder weights)" % ("fp8 e4m3" if fp8 else "bf16"),
+         "value": batch * steps / t_full, "unit": "frames/sec", "dtype": "fp8-weights" if fp8 else "bf16",
+         "ms_per_batch": 1e3 * t_full, "decoder_steps": steps, "utterances": batch, "us_per_step": us,
+         "launches_per_step": 4, "host_syncs_per_step": 1.0 / (2 * dec.POLL_STEPS),
+         "workload": "tacotron_gst.py infer: B=%d, text U[20,200] (padded S=%d), %d free-running steps, "
+                     "encoder + GST + post-net + magnitude branch included in ms_per_batch" % (batch, S, steps),
+         "roofline": _roofline(
+             "hbm", "one decoder step = ti_lstm_kernel x 2 + ti_scores_kernel + ti_context_kernel (csrc/tacotron_infer.hpp)",
+             total / (us * 1e-6) / 1e9 if us > 0 else 0.0,
+             "algorithmic bytes one step must read (recurrent weights once, live memory rows once, state vectors) / "
+             "measured time per step. ~%.0f MB per step: it is re-read every step and fits the 256 MB MALL (and most "
+             "of the per-XCD slices of the weight stream fit the 4 MB L2s), so after the first step little of it is "
+             "HBM traffic: 'achieved' is an effective (algorithmic) rate against the HBM peak, as for every re-read "
+             "working set" % (total / 1e6),
+             bytes_per_step=by, bytes_per_step_total=total, floor_us_at_hbm_peak=total / (HBM_PEAK_GBS * 1e3),
+             weights="streamed every step (e4m3: 17.8 MB; L2 / MALL resident across steps, not register-stationary)")}
   del model
   torch.cuda.empty_cache()
   return res
@@ -699,13 +919,18 @@ def main():
   for key, flag in (("quartznet", args.only_quartznet), ("tacotron", args.only_tacotron),
                     ("ds2", args.only_ds2), ("nmt", args.only_nmt)):
     if flag:
-      res = bench_simple(simple[key], args.steps, args.warmup, hvd, dev, rank, world)
+      res = bench_simple(simple[key], args.steps, args.warmup, hvd, dev, rank, world, roofline_key=key)
       if rank == 0:
         print(json.dumps(res))
       return
   if args.only_transformer_infer:
     if rank == 0:
       print(json.dumps(bench_transformer_infer(dev)))
+    return
+  if args.only_tacotron_decode:
+    if rank == 0:
+      print(json.dumps(bench_tacotron_decode(dev, style=not args.no_style, fp8=not args.no_fp8,
+                                             batch=args.batch, steps=args.decode_steps)))
     return
   if args.only_transformer:
     tr = bench_transformer(args, hvd, dev, rank, world)
@@ -858,13 +1083,17 @@ def main():
     others = {}
     for key in ("nmt", "ds2", "tacotron", "quartznet"):
       try:
-        others[key] = bench_simple(simple[key], 6, 3, hvd, dev, rank, world)
+        others[key] = bench_simple(simple[key], 6, 3, hvd, dev, rank, world, roofline_key=key)
       except Exception as e:   # never lose the headline line to a secondary measurement
         others[key] = {"error": repr(e)}
     try:
       others["transformer_beam_search"] = bench_transformer_infer(dev)
     except Exception as e:
       others["transformer_beam_search"] = {"error": repr(e)}
+    try:
+      others["tacotron_decode"] = bench_tacotron_decode(dev)
+    except Exception as e:
+      others["tacotron_decode"] = {"error": repr(e)}
     out["other_configs"] = others
   if world == 1:
     try:

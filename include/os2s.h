@@ -819,6 +819,52 @@ typedef struct os2s_attn_decoder_grads {
   float* dv; float* dg_scalar; float* dconv_w; float* dconv_b; float* ddense_w;
 } os2s_attn_decoder_grads_t;
 
+/* ------------------------------------------------------------------------
+ * Free-running Tacotron2 decoding: Tacotron2Decoder._decode in eval / infer mode
+ * (decoders/tacotron2_decoder.py:378-428) = dynamic_decode(TacotronDecoder(TacotronHelper),
+ * impute_finished = False, maximum_iterations = 10 * max(src_len)); per step
+ * (parts/tacotron/tacotron_decoder.py:153-190, tacotron_helper.py:138-226):
+ *   x_t = prenet(frame_{t-1})  (2 x Dense + ReLU + dropout(prenet_keep), on in every mode; frame_{-1} = 0)
+ *   LSTM stack on [x_t, attention_{t-1}] -> location-sensitive attention (query = top cell output)
+ *   frame_t = W_out [h_top, attention_t] + b;  stop_t = W_stop frame_t + b
+ *   finished |= stop_t > 0  (round(sigmoid) with mask_decoder_sequence); ends when every sample finished.
+ * `loop` is the attention cell exactly as os2s_attn_decoder_fwd takes it (score_mode 2, parameters, keys /
+ * values / src_len, zeroed sequence buffers, T = step capacity; gx0 is not read: the layer-0 input
+ * projection is the first P columns of w0x; tgt_len must be NULL, attn_in_keep = out_keep = 1).
+ * One step is four launches with no host interaction; the stop decision is device-resident:
+ *   state int32 [4 + 2B], zeroed by the caller: [1] = number of steps after which every sample had
+ *   finished (0 while running; launches enqueued past that point return at once), [2] finished count,
+ *   [4, 4+B) finished flags, [4+B, 4+2B) sequence lengths (the step that raised the stop token counts).
+ * So the caller may enqueue any number of steps ahead and poll state[1] at its own interval.
+ * Outputs: mel bf16 [B, T, n_mel] (decoder frames), stop fp32 [B, T] (logits), loop->align_seq,
+ * loop->y_top / ctx rows. os2s_tacotron_infer_steps with t_begin == 0 also prepares step 0.
+ * Returns OS2S_ERR_UNSUPPORTED for shapes the step kernels are not built for (B > 32, H / M / P not
+ * multiples of 64, n_mel > 128, ...): drive os2s_attn_decoder_fwd step by step then.
+ * ---------------------------------------------------------------------- */
+typedef struct os2s_tacotron_infer {
+  const os2s_attn_decoder_t* loop;
+  int P, n_mel;                    /* pre-net units, frame size */
+  int mask_decoder_sequence;
+  float prenet_keep; unsigned long long prenet_seed[2];
+  /* layer 0 with the pre-net columns in front: [4H, P + M + H] = [kernel rows of the inputs | attention | state];
+   * exactly one of w0x (bf16) / w0x8 (e4m3 + per-row scales; then loop->wcat8[1] serves layer 1) */
+  const uint16_t* w0x; const uint8_t* w0x8; const float* w0x8_scale;
+  const float* bias0;              /* [4H] */
+  const uint16_t* wp1; const float* bp1;   /* pre-net layer 1: bf16 [P, n_mel], fp32 [P] */
+  const uint16_t* wp2; const float* bp2;   /* pre-net layer 2: bf16 [P, P], fp32 [P] */
+  const uint16_t* wout_h;          /* bf16 [n_mel, H]: output-projection columns of the cell output */
+  const float* pv;                 /* fp32 [B, S, n_mel] = values W_out[:, H:]^T (one caller GEMM per batch) */
+  const float* bout;               /* [n_mel] */
+  const uint16_t* wstop; const float* bstop;   /* bf16 [n_mel], fp32 [1] */
+  uint16_t* x_seq;                 /* bf16 [B, T+1, P]: pre-net outputs, row t = input of step t */
+  uint16_t* mel;                   /* bf16 [B, T, n_mel] */
+  float* stop;                     /* fp32 [B, T] */
+  int32_t* state;                  /* int32 [os2s_tacotron_infer_state_ints(B)] */
+} os2s_tacotron_infer_t;
+size_t os2s_tacotron_infer_state_ints(int B);
+int os2s_tacotron_infer_supported(const os2s_tacotron_infer_t* x);
+int os2s_tacotron_infer_steps(os2s_stream_t stream, const os2s_tacotron_infer_t* x, int t_begin, int t_end);
+
 /* fp8 weight storage (BASELINE.json configs[4]: Tacotron2 decode with fp8 weights; the reference has
  * no fp8 — models/model.py:88 — so the policy is this library's): q[r,k] = e4m3(w[r,k] / scale[r]),
  * scale[r] = max_k |w[r,k]| / 448, OCP e4m3fn. w bf16 [rows, K], K % 8 == 0. */

@@ -1401,6 +1401,70 @@ class AttnDecoder(object):
     return out
 
 
+class _TacotronInfer(_lib.ctypes.Structure):
+  """ctypes mirror of os2s_tacotron_infer_t (include/os2s.h)."""
+  _fields_ = [("loop", c_void_p), ("P", c_int), ("n_mel", c_int), ("mask_decoder_sequence", c_int),
+              ("prenet_keep", c_float), ("prenet_seed", c_ull * 2),
+              ("w0x", c_void_p), ("w0x8", c_void_p), ("w0x8_scale", c_void_p), ("bias0", c_void_p),
+              ("wp1", c_void_p), ("bp1", c_void_p), ("wp2", c_void_p), ("bp2", c_void_p),
+              ("wout_h", c_void_p), ("pv", c_void_p), ("bout", c_void_p), ("wstop", c_void_p), ("bstop", c_void_p),
+              ("x_seq", c_void_p), ("mel", c_void_p), ("stop", c_void_p), ("state", c_void_p)]
+
+
+class TacotronInfer(object):
+  """Free-running Tacotron2 decoding on the device (os2s_tacotron_infer_steps): owns the frame / stop /
+  pre-net / state buffers next to an AttnDecoder's sequence buffers. `w`: dict of the tensors of
+  os2s_tacotron_infer_t (w0x bf16 [4H, P+M+H] or w0x8 = (uint8, scales), bias0, wp1, bp1, wp2, bp2,
+  wout_h, pv, bout, wstop, bstop). Steps are enqueued without host interaction; `done_steps()` reads
+  the device-resident stop decision (synchronises)."""
+
+  def __init__(self, loop, P, n_mel, w, mask_decoder_sequence=True, prenet_keep=0.5, prenet_seeds=(0, 0)):
+    self.loop, self.P, self.n_mel, self.w = loop, P, n_mel, w
+    self.mask, self.keep, self.seeds = bool(mask_decoder_sequence), float(prenet_keep), tuple(prenet_seeds)
+    B, T = loop.dims["B"], loop.dims["T"]
+    dev = loop.align_seq.device
+    self.x_seq = torch.zeros((B, T + 1, P), dtype=torch.bfloat16, device=dev)
+    self.mel = torch.zeros((B, T, n_mel), dtype=torch.bfloat16, device=dev)
+    self.stop = torch.zeros((B, T), dtype=torch.float32, device=dev)
+    n = int(_fn("os2s_tacotron_infer_state_ints", (c_int,), c_size_t)(B))
+    self.state = torch.zeros((n,), dtype=torch.int32, device=dev)
+    self._keep_alive = None
+
+  def _desc(self):
+    d = self.loop._desc(0, self.loop.dims["T"])
+    x, w = _TacotronInfer(), self.w
+    x.loop = _lib.ctypes.addressof(d)
+    x.P, x.n_mel, x.mask_decoder_sequence = self.P, self.n_mel, int(self.mask)
+    x.prenet_keep = self.keep
+    x.prenet_seed[0], x.prenet_seed[1] = (int(v) & (2**64 - 1) for v in self.seeds)
+    if w.get("w0x8") is not None:
+      x.w0x, x.w0x8, x.w0x8_scale = None, _addr(w["w0x8"][0]), _addr(w["w0x8"][1])
+    else:
+      x.w0x, x.w0x8, x.w0x8_scale = _addr(w["w0x"]), None, None
+    for k in ("bias0", "wp1", "bp1", "wp2", "bp2", "wout_h", "pv", "bout", "wstop", "bstop"):
+      setattr(x, k, _addr(w[k]))
+    x.x_seq, x.mel, x.stop, x.state = _addr(self.x_seq), _addr(self.mel), _addr(self.stop), _addr(self.state)
+    self._keep_alive = d
+    return x
+
+  def supported(self):
+    return bool(_fn("os2s_tacotron_infer_supported", (c_void_p,))(_lib.ctypes.byref(self._desc())))
+
+  def steps(self, t_begin, t_end):
+    x = self._desc()
+    f = _fn("os2s_tacotron_infer_steps", (c_void_p, c_void_p, c_int, c_int))
+    _lib.check(f(_stream(), _lib.ctypes.byref(x), int(t_begin), int(t_end)), "os2s_tacotron_infer_steps")
+
+  def done_steps(self):
+    """0 while samples are still running, else the number of steps after which all had finished."""
+    return int(self.state[1].item())
+
+  @property
+  def lengths(self):
+    B = self.loop.dims["B"]
+    return self.state[4 + B:4 + 2 * B]
+
+
 # --------------------------------------------------------------------------
 # text-to-speech loss terms and small element-wise ops
 # --------------------------------------------------------------------------

@@ -23,6 +23,7 @@
 //   backward      : d(attention input) GEMM, attention backward per sample (recomputes the
 //                   tanh terms; accumulates dkeys, per-sample parameter partials), cell
 //                   backward (two fused transposed GEMMs + gate derivatives).
+#include <algorithm>
 #include <cstdlib>
 #include "os2s_common.hpp"
 #include "rnn_tile.hpp"
@@ -891,7 +892,7 @@ __host__ __device__ inline size_t loc_fwd_lds_floats(int H, int S) {
   return (size_t)H + 3 * kLocUnits + (S + kLocKMax) + (size_t)S * kLocUnits / 2 + 64;
 }
 
-__global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_kernel(AdAttn p, AdLoc x) {
+__device__ __forceinline__ void ad_loc_scores_body(const AdAttn& p, const AdLoc& x) {
   extern __shared__ float lds_raw[];
   const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (p.tgt_len && p.t >= p.tgt_len[b]) return;
@@ -995,6 +996,13 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_kernel(AdAttn p, A
       }
     }
   }
+}
+
+__global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_kernel(AdAttn p, AdLoc x) { ad_loc_scores_body(p, x); }
+// the same behind the free-running decoder's stop flag (tacotron_infer.hpp: state[1] != 0 = decoding has ended)
+__global__ __launch_bounds__(kAttnThreads) void ti_scores_kernel(AdAttn p, AdLoc x, const int32_t* __restrict__ state) {
+  if (state[1] != 0) return;
+  ad_loc_scores_body(p, x);
 }
 
 // sum of the partial scores -> masked softmax -> alignments (+ cumulative) -> context columns
@@ -2115,3 +2123,5 @@ extern "C" int os2s_quantize_rows_e4m3(os2s_stream_t stream, const uint16_t* w, 
               rows, K, q, scale);
   return OS2S_OK;
 }
+
+#include "tacotron_infer.hpp"

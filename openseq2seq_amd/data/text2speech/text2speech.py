@@ -71,6 +71,13 @@ class Text2SpeechDataLayer(DataLayer):
       return naf['mel'], naf['magnitude']
     return (naf, 0) if self.params['output_type'] == 'mel' else (0, naf)
 
+  def iterate_batches(self, device, seed=0, drop_remainder=None, num_batches=2):
+    """eval / infer passes (run.py). The csv + wav reader of the reference's TTS data layer
+    (data/text2speech/text2speech.py:150-420) is outside SURVEY 8f's file-reading row (ASR only): the
+    pass runs over `num_batches` synthetic batches of the configured shapes."""
+    for i in range(num_batches):
+      yield self.synthetic_batch(device, seed + i)
+
   def synthetic_batch(self, device, seed, fixed_text=None, fixed_frames=None):
     p = self.params
     B = p['batch_size']

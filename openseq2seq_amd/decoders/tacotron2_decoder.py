@@ -14,6 +14,8 @@ through the pre-net; stops when every sample's sigmoid(stop token) rounds to 1 o
 10 x max source length steps."""
 from __future__ import absolute_import, division, print_function
 
+import os
+
 import torch
 
 from .decoder import Decoder
@@ -136,7 +138,7 @@ class Tacotron2Decoder(Decoder):
     src_len = enc['src_length']
     training = self._mode == "train"
     if not training:
-      return self._free_running(enc_act, src_len)
+      return self._free_running(enc_act, src_len, input_dict.get('max_decoder_steps'))
     p = self.params
     tape = input_dict.get('tape')
     seeds = enc.get('seeds') or SeedSeq(37)
@@ -221,55 +223,135 @@ class Tacotron2Decoder(Decoder):
     }
 
   # ---------------------------------------------------------------- inference
-  def _free_running(self, enc_act, src_len):
+  POLL_STEPS = 32      # host looks at the device-resident stop decision every POLL_STEPS steps
+
+  def _infer_weights(self, fp8):
+    """Inference copies the fused step kernels read (csrc/tacotron_infer.hpp), rebuilt when the bf16
+    weights changed: layer 0 with the pre-net columns in front of the attention / state columns
+    ([kernel_inputs | kernel_attention_state], optionally e4m3 with per-row scales) and the output
+    projection split into its cell-output and context column blocks."""
+    cell = self.cell
+    store = getattr(cell.wcat[0], "store", None)
+    ver = getattr(store, "version", None) if store is not None else None
+    c = getattr(self, "_infer_cache", None)
+    if c is not None and ver is not None and c["ver"] == ver and c["fp8"] == fp8:
+      return c["w"]
+    H, GH = self.H, 4 * self.H
+    w0x = torch.cat([cell.w_in.w16.view(GH, -1), cell.wcat[0].w16.view(GH, -1)], dim=1).contiguous()
+    w = {"w0x": w0x, "w0x8": capi.quantize_rows_e4m3(w0x) if fp8 else None,
+         "bias0": cell.bias[0].master,
+         "wp1": self.prenet[0].w.contiguous(), "bp1": self.prenet[0].bias.master,
+         "wp2": self.prenet[1].w.contiguous(), "bp2": self.prenet[1].bias.master,
+         "wout_h": self.out_proj.w[:, :H].contiguous(), "wout_c": self.out_proj.w[:, H:].contiguous(),
+         "bout": self.out_proj.bias.master,
+         "wstop": self.stop_proj.w[0].contiguous(), "bstop": self.stop_proj.bias.master[:1].contiguous()}
+    self._infer_cache = {"ver": ver, "fp8": fp8, "w": w}
+    return w
+
+  def _free_running(self, enc_act, src_len, max_steps=None):
+    """TacotronHelper decoding (tacotron_helper.py:138-226, tacotron2_decoder.py:378-428): at most
+    10 x max(src_len) steps (`max_steps` overrides: benchmarks), until every sample's stop token has
+    fired. Returns the reference's outputs plus `acts` (what Text2SpeechLoss reads: eval-mode loss)."""
     p = self.params
     B, S, M = enc_act.data.shape
     dev = enc_act.data.device
-    nm, H, GH = self.n_mel, self.H, 4 * self.H
-    T = 10 * int(src_len.max().item())
+    nm, H = self.n_mel, self.H
+    T = int(max_steps) if max_steps else 10 * int(src_len.max().item())
     seeds = SeedSeq(41)
     both = torch.zeros((B, T, H + M), dtype=torch.bfloat16, device=dev)
     cell = self.cell
     loop = cell._new_loop(B, T, S, dev, False, 1.0, 1.0, seeds, y_top=both[:, :, :H], ctx=both[:, :, H:])
     keys = cell.memory(enc_act, None)
-    gx0 = torch.zeros((B, T, GH), dtype=torch.bfloat16, device=dev)
-    loop.set_inputs(gx0, keys, enc_act.data, src_len, None)
-    frame = torch.zeros((B, nm), dtype=torch.bfloat16, device=dev)
-    mels = torch.zeros((B, T, nm), dtype=torch.bfloat16, device=dev)
-    stops = torch.zeros((B, T, 1), dtype=torch.bfloat16, device=dev)
-    finished = torch.zeros((B,), dtype=torch.bool, device=dev)
-    lengths = torch.zeros((B,), dtype=torch.int32, device=dev)
-    steps = 0
     mask_seq = p.get('mask_decoder_sequence', True)
-    for t in range(T):
-      x = Act(frame, requires_grad=False)
-      for d in self.prenet:          # pre-net dropout stays on at inference (:63)
-        x = d.forward(x, None, act=1, keep=PRENET_KEEP, seed=seeds.next())
-      gx0[:, t] = capi.gemm(x.data, cell.w_in.w16.view(GH, -1), bias=cell.bias[0].master)
-      loop.forward(t, t + 1)
-      mel_t = capi.gemm(both[:, t].contiguous(), self.out_proj.w, bias=self.out_proj.bias.master)
-      stop_t = capi.gemm(mel_t, self.stop_proj.w, bias=self.stop_proj.bias.master)[:, :1]
-      mels[:, t], stops[:, t] = mel_t, stop_t
-      lengths += (~finished).to(torch.int32)
-      if mask_seq:
-        finished = finished | (torch.sigmoid(stop_t[:, 0].float()) > 0.5)
-      frame = mel_t
-      steps = t + 1
-      if bool(finished.all()):
-        break
+    prenet_seeds = (seeds.next(), seeds.next())
+    fused = None
+    if len(self.prenet) == 2 and os.environ.get("OS2S_TACOTRON_FUSED_DECODE", "1") != "0":
+      w = dict(self._infer_weights(bool(getattr(cell, "fp8_weights", False))))
+      values2d = enc_act.data.reshape(B * S, M)
+      # PV = values W_out[:, H:]^T: the context half of the frame projection, once per batch
+      w["pv"] = capi.gemm(values2d, w["wout_c"], out_f32=True).view(B, S, nm)
+      loop.set_inputs(torch.zeros(8, dtype=torch.bfloat16, device=dev), keys, enc_act.data, src_len, None)
+      fused = capi.TacotronInfer(loop, self.prenet[0].cout, nm, w, mask_seq, PRENET_KEEP, prenet_seeds)
+      if not fused.supported():
+        fused = None
+    if fused is not None:
+      steps, mels, stops, lengths = self._decode_fused(fused, T)
+    else:
+      steps, mels, stops, lengths = self._decode_stepwise(loop, keys, enc_act, src_len, both, T, mask_seq,
+                                                          prenet_seeds)
     mel = Act(mels[:, :steps].contiguous())
     top = mel
     for cl, layer in zip(p['postnet_conv_layers'], self.postnet):
       top = conv_bn_actv(layer, top, None, cl['activation_fn'], False, None, mask_output=False)
-    post = capi.add_bf16(mel.data, top.data)
+    post = Act(capi.add_bf16(mel.data, top.data))
     mag = None
     if self._both:
-      m = conv_bn_actv(self.mag[0], Act(post), None, "relu", False, None, mask_output=False)
+      m = conv_bn_actv(self.mag[0], post, None, "relu", False, None, mask_output=False)
       m = conv_bn_actv(self.mag[1], m, None, "relu", False, None, mask_output=False)
       md = capi.exp_fwd(m.data) if self.exp_mag else m.data
-      mag = capi.gemm(md.view(-1, 512), self.mag_proj.w16.view(self.n_mag_pad, 512)) \
-          .view(B, steps, self.n_mag_pad)[:, :, :self.n_mag]
-    st = stops[:, :steps]
-    return {'outputs': [mel.data, post, loop.align_seq[:, :steps], torch.sigmoid(st.float()),
-                        lengths, mag],
-            'stop_token_prediction': st, 'n_feats': (self.n_mel, self.n_mag)}
+      mag = Act(capi.gemm(md.view(-1, 512), self.mag_proj.w16.view(self.n_mag_pad, 512))
+                .view(B, steps, self.n_mag_pad))
+    st = stops[:, :steps].contiguous().view(B, steps, 1)
+    stop8 = torch.zeros((B, steps, 8), dtype=torch.bfloat16, device=dev)     # the training pass's padded layout
+    stop8[:, :, :1] = st.to(torch.bfloat16)
+    return {'outputs': [mel.data, post.data, loop.align_seq[:, :steps], torch.sigmoid(st.float()),
+                        lengths, mag.data[:, :, :self.n_mag] if mag is not None else None],
+            'stop_token_prediction': st, 'n_feats': (self.n_mel, self.n_mag),
+            'acts': {'mel': mel, 'post': post, 'stop': Act(stop8), 'mag': mag},
+            'decoder_steps': steps}
+
+  def _decode_fused(self, fused, T):
+    """Four launches per step, enqueued POLL_STEPS at a time; the stop decision is taken on the device
+    (kernels enqueued past it return at once), the host reads it one chunk behind the enqueue front so the
+    GPU never waits for the host. The result does not depend on POLL_STEPS."""
+    done, t0 = 0, 0
+    while t0 < T and not done:
+      t1 = min(T, t0 + self.POLL_STEPS)
+      fused.steps(t0, t1)
+      t0 = t1
+      if t0 < T:                       # keep one chunk in flight while the host looks
+        t1 = min(T, t0 + self.POLL_STEPS)
+        fused.steps(t0, t1)
+        t0 = t1
+      done = fused.done_steps()
+    steps = done if done else T
+    return steps, fused.mel, fused.stop, fused.lengths.clone()
+
+  def _decode_stepwise(self, loop, keys, enc_act, src_len, both, T, mask_seq, prenet_seeds):
+    """Generic path (shapes the fused step kernels are not built for): one os2s_attn_decoder_fwd call and
+    a few GEMM launches per step; the finished test stays on the device, the host polls it every
+    POLL_STEPS steps."""
+    B = enc_act.data.shape[0]
+    dev = enc_act.data.device
+    nm, GH = self.n_mel, 4 * self.H
+    cell = self.cell
+    gx0 = torch.zeros((B, T, GH), dtype=torch.bfloat16, device=dev)
+    loop.set_inputs(gx0, keys, enc_act.data, src_len, None)
+    frame = torch.zeros((B, nm), dtype=torch.bfloat16, device=dev)
+    mels = torch.zeros((B, T, nm), dtype=torch.bfloat16, device=dev)
+    stops = torch.zeros((B, T), dtype=torch.float32, device=dev)
+    finished = torch.zeros((B,), dtype=torch.bool, device=dev)
+    lengths = torch.zeros((B,), dtype=torch.int32, device=dev)
+    all_done_at = torch.zeros((), dtype=torch.int32, device=dev)    # first step count with everyone finished
+    steps = T
+    for t in range(T):
+      x = Act(frame, requires_grad=False)
+      for li, d in enumerate(self.prenet):          # pre-net dropout stays on at inference (:63)
+        x = d.forward(x, None, act=1, keep=PRENET_KEEP, seed=prenet_seeds[li % 2] * 1000003 + t)
+      gx0[:, t] = capi.gemm(x.data, cell.w_in.w16.view(GH, -1), bias=cell.bias[0].master)
+      loop.forward(t, t + 1)
+      mel_t = capi.gemm(both[:, t].contiguous(), self.out_proj.w, bias=self.out_proj.bias.master)
+      stop_t = capi.gemm(mel_t, self.stop_proj.w, bias=self.stop_proj.bias.master)[:, 0].float()
+      mels[:, t], stops[:, t] = mel_t, stop_t
+      running = ~finished
+      lengths += (running & (all_done_at == 0)).to(torch.int32)
+      if mask_seq:
+        finished = finished | (stop_t > 0)          # round(sigmoid(s)) == 1
+        all_done_at = torch.where((all_done_at == 0) & finished.all(),
+                                  torch.full_like(all_done_at, t + 1), all_done_at)
+      frame = mel_t
+      if mask_seq and (t + 1) % self.POLL_STEPS == 0 and int(all_done_at.item()):
+        break
+    if mask_seq and int(all_done_at.item()):
+      steps = int(all_done_at.item())
+    return steps, mels, stops, lengths

@@ -69,17 +69,111 @@ def decoder(P, enc_out, src_len, spec_mel, postnet_acts, bn_eps=1e-5, exp_mag=Tr
   return dict(mel=mel, post=post, stop=stop, mag=mag, align=r["align"])
 
 
-def text2speech_loss(out, spec, stop_token, spec_len, n_mel, n_mag, l1=False):
-  """Masked MSE (SUM_BY_NONZERO_WEIGHTS over the broadcast mask) + masked stop xent."""
-  B, T, _ = spec.shape
-  mask = cnn.seq_mask(spec_len, T)
+def text2speech_loss(out, spec, stop_token, spec_len, n_mel, n_mag, l1=False, use_mask=True,
+                     mel_weight=1.0, mag_weight=1.0, stop_token_weight=1.0, scale=None):
+  """losses/text2speech_loss.py:35-209. Predictions (out["mel"], out["post"], out["stop"] logits
+  [B,Tp,1], out["mag"]) and targets (spec [B,Tt,n_mel(+n_mag)], stop_token [B,Tt]) are first padded
+  to max_length = max(Tp, Tt) (:80-117): predictions and the spectrogram with zeros, the stop-token
+  TARGET with ones. Then masked (mask = sequence_mask(spec_len, max_length)) MSE / L1 with
+  tf.losses' SUM_BY_NONZERO_WEIGHTS reduction (sum(w * err) / #non-zero broadcast weights) plus the
+  masked stop-token sigmoid cross entropy / sum(mask) (:139-176), or their plain means without a
+  mask (:177-195); weights and scale as :197-209."""
+  B, Tt, _ = spec.shape
+  Tp = out["mel"].shape[1]
+  T = max(Tp, Tt)
+
+  def pad_t(x, value=0.0):
+    return x if x.shape[1] == T else F.pad(x, (0, 0, 0, T - x.shape[1]), value=value)
+
+  mel, post, stop = pad_t(out["mel"]), pad_t(out["post"]), pad_t(out["stop"])
+  spec = pad_t(spec)
+  stop_t = pad_t(stop_token[..., None].float(), 1.0)
+  mag = pad_t(out["mag"]) if out.get("mag") is not None else None
+  mask = cnn.seq_mask(spec_len, T) if use_mask else torch.ones(B, T, 1)
 
   def reg(pred, tgt):
     err = (pred - tgt).abs() if l1 else (pred - tgt) ** 2
+    if not use_mask:
+      return err.mean()
     return (err * mask).sum() / (mask.sum() * pred.shape[-1])
 
-  loss = reg(out["mel"], spec[..., :n_mel]) + reg(out["post"], spec[..., :n_mel])
-  if out.get("mag") is not None:
-    loss = loss + reg(out["mag"], spec[..., n_mel:n_mel + n_mag])
-  xe = F.binary_cross_entropy_with_logits(out["stop"], stop_token[..., None], reduction="none")
-  return loss + (xe * mask).sum() / mask.sum()
+  loss = mel_weight * (reg(mel, spec[..., :n_mel]) + reg(post, spec[..., :n_mel]))
+  if mag is not None:
+    loss = loss + mag_weight * reg(mag, spec[..., n_mel:n_mel + n_mag])
+  xe = F.binary_cross_entropy_with_logits(stop, stop_t, reduction="none")
+  stop_loss = (xe * mask).sum() / mask.sum() if use_mask else xe.mean()
+  loss = loss + stop_token_weight * stop_loss
+  return loss * scale if scale else loss
+
+
+def decoder_infer(P, enc_out, src_len, max_steps=None, prenet_masks=None, mask_decoder_sequence=True,
+                  round_frames_bf16=True):
+  """Free-running decoding: Tacotron2Decoder._decode in eval / infer mode
+  (decoders/tacotron2_decoder.py:378-428) = dynamic_decode(TacotronDecoder(helper=TacotronHelper),
+  impute_finished=False, maximum_iterations=10 * max(src_len)); TacotronDecoder.step
+  (parts/tacotron/tacotron_decoder.py:153-190): cell on prenet(inputs) -> spec projection -> stop
+  projection -> helper.next_inputs (tacotron_helper.py:195-226): finished = round(sigmoid(stop)),
+  next input = the projected frame. dynamic_decode: sequence_lengths[b] = first step count at which b
+  was finished (the finishing step counts); the loop stops once every sample has finished.
+
+  P as for `decoder` (prenet, cell incl. w_in / b0, out_w, out_b, stop_w, stop_b). prenet_masks:
+  per pre-net layer a [T, B, units] keep mask already scaled by 1/keep (the always-on dropout), or None.
+  round_frames_bf16: frames, stop logits and pre-net outputs are bf16 tensors on the device; rounding
+  them here keeps a long free-running trajectory comparable.
+  Returns dict(mel [B,steps,n_mel], stop [B,steps] logits, align [B,steps,S], lengths [B], steps)."""
+  rb = (lambda x: x.to(torch.bfloat16).float()) if round_frames_bf16 else (lambda x: x)
+  B, S, M = enc_out.shape
+  c = P["cell"]
+  L = len(c["wcat"])
+  H = c["wq"].shape[1]
+  T = int(max_steps) if max_steps else 10 * int(torch.as_tensor(src_len).max())
+  values, mask = oad.prepare_memory(enc_out, src_len)
+  keys = values @ c["wmem"].t()
+  h = [enc_out.new_zeros(B, H) for _ in range(L)]
+  cs = [enc_out.new_zeros(B, H) for _ in range(L)]
+  attn = enc_out.new_zeros(B, M)
+  cum = enc_out.new_zeros(B, S)
+  frame = enc_out.new_zeros(B, P["out_w"].shape[0])
+  finished = torch.zeros(B, dtype=torch.bool)
+  lengths = torch.zeros(B, dtype=torch.int32)
+  mels, stops, aligns = [], [], []
+  steps = T
+  for t in range(T):
+    x = frame
+    for i, (w, b) in enumerate(P["prenet"]):
+      x = torch.relu(x @ w.t() + b)
+      if prenet_masks is not None:
+        x = x * prenet_masks[i][t]
+      x = rb(x)
+    gx0 = x @ c["w_in"].t() + c["b0"]
+    xin = None
+    for l in range(L):
+      if l == 0:
+        hn, cn = oad.lstm_cell(torch.cat([attn, h[0]], -1), cs[0], c["wcat"][0], gx0, 1.0)
+      else:
+        hn, cn = oad.lstm_cell(torch.cat([xin, h[l]], -1), cs[l], c["wcat"][l], c["bias"][l], 1.0)
+      hn = rb(hn)                    # the state rows the next GEMMs read are bf16
+      h[l], cs[l] = hn, cn
+      xin = hn
+    q = xin @ c["wq"].t()
+    pre = keys + q[:, None, :] + oad.location_features(cum, c["conv_w"], c["conv_b"], c["dense_w"])
+    if c.get("b") is not None:
+      pre = pre + c["b"]
+    al = oad.masked_softmax((c["v"] * torch.tanh(pre)).sum(-1), mask)
+    attn_full = (al[:, :, None] * values).sum(1)
+    cum = cum + al
+    mel = rb(torch.cat([xin, attn_full], -1) @ P["out_w"].t() + P["out_b"])
+    stop = rb(mel @ P["stop_w"].t() + P["stop_b"])[:, 0]
+    attn = rb(attn_full)
+    mels.append(mel)
+    stops.append(stop)
+    aligns.append(al)
+    lengths = lengths + (~finished).to(torch.int32)
+    if mask_decoder_sequence:
+      finished = finished | (torch.sigmoid(stop) > 0.5)      # tf.round: half to even, 0.5 -> 0
+    frame = mel
+    if bool(finished.all()):
+      steps = t + 1
+      break
+  return dict(mel=torch.stack(mels, 1), stop=torch.stack(stops, 1), align=torch.stack(aligns, 1),
+              lengths=lengths, steps=steps)

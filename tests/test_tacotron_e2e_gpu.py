@@ -27,6 +27,23 @@ def _cmp(got, ref, name, cos_min=0.98, rel_max=0.2):
   return None if (cos > cos_min and rel < rel_max) else (name, round(cos, 4), round(rel, 4))
 
 
+SMALL = dict(V=40, E=64, Henc=32, H=64, NM=16, NG=24, pre=64, convs=None, post=None, style=None,
+             B=3, S=12, T=24, text_len=[12, 7, 10], spec_len=[24, 16, 8])
+# the reference's tacotron_gst.py at its own widths (example_configs/text2speech/tacotron_gst.py:95-200):
+# embedding 512, 3 x conv 512 k5, BiLSTM 256, style encoder 6 x conv2d 3x3 stride 2 (32, 32, 64, 64, 128,
+# 128 channels) + GRU 128 + 32 tokens x 8 heads (512), pre-net 2 x 256, 2 x LSTM 1024, attention 128,
+# post-net 4 x 512 k5 tanh + 1 linear, mel 80 + magnitude 401 (n_fft 800)
+FULL_CONVS = [{"kernel_size": [5], "stride": [1], "num_channels": 512, "padding": "SAME"}] * 3
+FULL_POST = [{"kernel_size": [5], "stride": [1], "num_channels": 512, "padding": "SAME", "activation_fn": "tanh"}] * 4 + \
+            [{"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
+FULL_STYLE = {"conv_layers": [{"kernel_size": [3, 3], "stride": [2, 2], "num_channels": c, "padding": "SAME"}
+                              for c in (32, 32, 64, 64, 128, 128)],
+              "num_rnn_layers": 1, "rnn_cell_dim": 128, "rnn_unidirectional": True, "rnn_type": "GRUCell",
+              "emb_size": 512, "attention_layer_size": 512, "num_tokens": 32, "num_heads": 8}
+FULL = dict(V=94, E=512, Henc=256, H=1024, NM=80, NG=401, pre=256, convs=FULL_CONVS, post=FULL_POST,
+            style=FULL_STYLE, B=4, S=60, T=80, text_len=[60, 41, 22, 53], spec_len=[80, 57, 33, 70])
+
+
 STYLE = {"conv_layers": [{"kernel_size": [3, 3], "stride": [2, 2], "num_channels": 16, "padding": "SAME"}] * 2,
          "num_rnn_layers": 1, "rnn_cell_dim": 32, "rnn_unidirectional": True, "rnn_type": "GRUCell",
          "emb_size": 64, "attention_layer_size": 64, "num_tokens": 10, "num_heads": 1}
@@ -34,6 +51,19 @@ STYLE = {"conv_layers": [{"kernel_size": [3, 3], "stride": [2, 2], "num_channels
 
 @pytest.mark.parametrize("style", [False, True])
 def test_tacotron2_small_fwd_bwd(cuda, monkeypatch, style):
+  _tacotron_fwd_bwd(cuda, monkeypatch, style, SMALL)
+
+
+def test_tacotron2_gst_config_width_fwd_bwd(cuda, monkeypatch):
+  """Tacotron2-GST at the widths of example_configs/text2speech/tacotron_gst.py:95-200 (encoder 3 x conv512 +
+  BiLSTM-256, style encoder 6 conv2d / GRU-128 / 32 tokens x 8 heads, pre-net 256, decoder 2 x LSTM-1024 with
+  location-sensitive attention, post-net 5 x 512, mel 80 + magnitude 401, Text2SpeechLoss) on B = 4, S = 60,
+  T = 80 ragged: outputs, loss and every parameter gradient vs the CPU fp32 oracle. Same bounds as the
+  scaled-down test (outputs rel-L2 <= 3e-2, loss 3e-2, gradients cosine >= 0.98 / rel-L2 <= 0.2)."""
+  _tacotron_fwd_bwd(cuda, monkeypatch, True, FULL)
+
+
+def _tacotron_fwd_bwd(cuda, monkeypatch, style, D):
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders import Tacotron2Encoder
   from openseq2seq_amd.decoders import Tacotron2Decoder
@@ -44,22 +74,24 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch, style):
   from oracle import tacotron as otac
   monkeypatch.setattr(t2d, "PRENET_KEEP", 1.0)
   torch.manual_seed(0)
-  V, E, Henc, H, NM, NG = 40, 64, 32, 64, 16, 24
+  V, E, Henc, H, NM, NG = D["V"], D["E"], D["Henc"], D["H"], D["NM"], D["NG"]
+  convs, post_layers = D["convs"] or CONVS, D["post"] or POST
+  style_p = D["style"] or STYLE
   store = FlatParams(cuda)
   ep = {"cnn_dropout_prob": 0.0, "rnn_dropout_prob": 0.0, "src_emb_size": E,
-        "conv_layers": CONVS, "activation_fn": "relu", "num_rnn_layers": 1,
+        "conv_layers": convs, "activation_fn": "relu", "num_rnn_layers": 1,
         "rnn_cell_dim": Henc, "use_cudnn_rnn": True, "rnn_type": "CudnnLSTM",
         "rnn_unidirectional": False, "dtype": "mixed"}
   if style:
-    ep.update({"style_embedding_enable": True, "style_embedding_params": STYLE})
+    ep.update({"style_embedding_enable": True, "style_embedding_params": style_p})
   enc = Tacotron2Encoder(ep, None, mode="train")
   enc.build(store, src_vocab_size=V, num_style_features=NM)
   dec = Tacotron2Decoder({"attention_layer_size": 128, "attention_type": "location",
                           "attention_bias": True, "decoder_cell_units": H,
                           "decoder_cell_type": "LSTMCell", "decoder_layers": 2, "dropout_prob": 0.0,
-                          "enable_prenet": True, "prenet_layers": 2, "prenet_units": 64,
+                          "enable_prenet": True, "prenet_layers": 2, "prenet_units": D["pre"],
                           "enable_postnet": True, "postnet_keep_dropout_prob": 1.0,
-                          "postnet_conv_layers": POST, "dtype": "mixed"}, None, mode="train")
+                          "postnet_conv_layers": post_layers, "dtype": "mixed"}, None, mode="train")
   dec.build(store, memory_dim=enc.output_dim, num_audio_features={"mel": NM, "magnitude": NG},
             exp_mag=True)
   lossf = Text2SpeechLoss({"use_mask": True, "dtype": "mixed"}, None)
@@ -69,10 +101,10 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch, style):
     if p.kind == "vector" and p.numel > 1 and "gamma" not in p.name:
       p.master.add_((torch.randn(p.shape, generator=g) * 0.1).to(cuda))
   store.refresh_compute_copies()
-  B, S, T = 3, 12, 24
+  B, S, T = D["B"], D["S"], D["T"]
   text = torch.randint(3, V, (B, S), generator=g).to(torch.int32)
-  text_len = torch.tensor([12, 7, 10], dtype=torch.int32)
-  spec_len = torch.tensor([24, 16, 8], dtype=torch.int32)
+  text_len = torch.tensor(D["text_len"], dtype=torch.int32)
+  spec_len = torch.tensor(D["spec_len"], dtype=torch.int32)
   spec = torch.cat([torch.randn(B, T, NM, generator=g) - 1.0,
                     torch.exp(torch.randn(B, T, NG, generator=g) - 2.0)], -1)
   spec = spec.to(torch.bfloat16).float()      # the teacher-forced inputs are bf16 on the device
@@ -106,7 +138,7 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch, style):
     return (leaf(c.kernel), leaf(c.gamma, None, False), leaf(c.beta, None, False))
 
   EP = {"emb": leaf(enc.embedding.table), "convs": [convbn(c) for c in enc.convs]}
-  lstm = torch.nn.LSTM(64, Henc, batch_first=True, bidirectional=True)
+  lstm = torch.nn.LSTM(convs[-1]["num_channels"], Henc, batch_first=True, bidirectional=True)
   with torch.no_grad():
     for dd, layer in enumerate(enc.rnn[0]):
       sfx = "_l0" + ("_reverse" if dd else "")
@@ -144,9 +176,9 @@ def test_tacotron2_small_fwd_bwd(cuda, monkeypatch, style):
       leaves[p.name] = (t, None)
       return t
     SP = style_oracle_params(enc.style, leaf2)
-    style_vec = ogst.style_encoder(SP, spec[..., :NM], spec_len, STYLE["conv_layers"], 1)
+    style_vec = ogst.style_encoder(SP, spec[..., :NM], spec_len, style_p["conv_layers"], style_p["num_heads"])
   enc_out = otac.encoder(EP, text, lstm, style=style_vec)
-  out = otac.decoder(DP, enc_out, text_len, spec[..., :NM], ["tanh", "tanh", None])
+  out = otac.decoder(DP, enc_out, text_len, spec[..., :NM], [cl["activation_fn"] for cl in post_layers])
   ref = otac.text2speech_loss(out, spec, stop, spec_len, NM, NG)
   ref.backward()
   def close(got, want, name, rel_max=0.03, abs_max=0.15):
