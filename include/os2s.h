@@ -839,7 +839,7 @@ typedef struct os2s_attn_decoder_grads {
  * Outputs: mel bf16 [B, T, n_mel] (decoder frames), stop fp32 [B, T] (logits), loop->align_seq,
  * loop->y_top / ctx rows. os2s_tacotron_infer_steps with t_begin == 0 also prepares step 0.
  * Returns OS2S_ERR_UNSUPPORTED for shapes the step kernels are not built for (B > 32, H / M / P not
- * multiples of 64, n_mel > 128, ...): drive os2s_attn_decoder_fwd step by step then.
+ * multiples of 64, H > 1024, P > 256, n_mel > 128, ...): drive os2s_attn_decoder_fwd step by step then.
  * ---------------------------------------------------------------------- */
 typedef struct os2s_tacotron_infer {
   const os2s_attn_decoder_t* loop;
@@ -856,6 +856,7 @@ typedef struct os2s_tacotron_infer {
   const float* pv;                 /* fp32 [B, S, n_mel] = values W_out[:, H:]^T (one caller GEMM per batch) */
   const float* bout;               /* [n_mel] */
   const uint16_t* wstop; const float* bstop;   /* bf16 [n_mel], fp32 [1] */
+  float* mh;                       /* fp32 [B, n_mel] scratch (the cell-output half of the frame of the step) */
   uint16_t* x_seq;                 /* bf16 [B, T+1, P]: pre-net outputs, row t = input of step t */
   uint16_t* mel;                   /* bf16 [B, T, n_mel] */
   float* stop;                     /* fp32 [B, T] */

@@ -1408,7 +1408,7 @@ class _TacotronInfer(_lib.ctypes.Structure):
               ("w0x", c_void_p), ("w0x8", c_void_p), ("w0x8_scale", c_void_p), ("bias0", c_void_p),
               ("wp1", c_void_p), ("bp1", c_void_p), ("wp2", c_void_p), ("bp2", c_void_p),
               ("wout_h", c_void_p), ("pv", c_void_p), ("bout", c_void_p), ("wstop", c_void_p), ("bstop", c_void_p),
-              ("x_seq", c_void_p), ("mel", c_void_p), ("stop", c_void_p), ("state", c_void_p)]
+              ("mh", c_void_p), ("x_seq", c_void_p), ("mel", c_void_p), ("stop", c_void_p), ("state", c_void_p)]
 
 
 class TacotronInfer(object):
@@ -1426,6 +1426,7 @@ class TacotronInfer(object):
     self.x_seq = torch.zeros((B, T + 1, P), dtype=torch.bfloat16, device=dev)
     self.mel = torch.zeros((B, T, n_mel), dtype=torch.bfloat16, device=dev)
     self.stop = torch.zeros((B, T), dtype=torch.float32, device=dev)
+    self.mh = torch.zeros((B, n_mel), dtype=torch.float32, device=dev)
     n = int(_fn("os2s_tacotron_infer_state_ints", (c_int,), c_size_t)(B))
     self.state = torch.zeros((n,), dtype=torch.int32, device=dev)
     self._keep_alive = None
@@ -1444,6 +1445,7 @@ class TacotronInfer(object):
     for k in ("bias0", "wp1", "bp1", "wp2", "bp2", "wout_h", "pv", "bout", "wstop", "bstop"):
       setattr(x, k, _addr(w[k]))
     x.x_seq, x.mel, x.stop, x.state = _addr(self.x_seq), _addr(self.mel), _addr(self.stop), _addr(self.state)
+    x.mh = _addr(self.mh)
     self._keep_alive = d
     return x
 

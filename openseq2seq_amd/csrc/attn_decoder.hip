@@ -906,6 +906,17 @@ __device__ __forceinline__ void ad_loc_scores_body(const AdAttn& p, const AdLoc&
   const int slen = min(max(p.src_len[b], 0), S);
   const int u0 = part * kLocUnits;
   const long long row = (long long)b * p.T + p.t;
+  // this wave's rows of Wq do not depend on anything staged below: requested first, so that their round trip
+  // overlaps the staging (and its barrier) instead of following it
+  constexpr int UB = kLocUnits / kAttnWaves;
+  u32x4 wv0[UB][2];
+#pragma unroll
+  for (int i = 0; i < UB; ++i)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+      wv0[i][hh] = *reinterpret_cast<const u32x4*>(p.wq + (long long)(u0 + wave * UB + i) * H +
+                                                   min(lane * 8 + 512 * hh, H - 8));
+  __builtin_amdgcn_sched_barrier(0);
   // query input, this part's key columns (64 B per position), padded cumulative alignments
   const bf16_t* yq = p.yq + (long long)b * p.yq_bs + (long long)p.t * p.yq_ts;
   for (int h8 = tid; h8 < H / 8; h8 += kAttnThreads) {
@@ -933,9 +944,8 @@ __device__ __forceinline__ void ad_loc_scores_body(const AdAttn& p, const AdLoc&
     bs[tid] = ((p.use_bias && p.bias) ? p.bias[u] : 0.f) + p.wck[(long long)K * U + u];
   }
   __syncthreads();
-  // q[u] = hq . Wq[u, :] for the 32 units of the part: 4 units per wave, all loads in flight together
+  // q[u] = hq . Wq[u, :] for the 32 units of the part: 4 units per wave
   {
-    constexpr int UB = kLocUnits / kAttnWaves;
     float acc[UB];
 #pragma unroll
     for (int i = 0; i < UB; ++i) acc[i] = 0.f;
@@ -945,8 +955,9 @@ __device__ __forceinline__ void ad_loc_scores_body(const AdAttn& p, const AdLoc&
       for (int i = 0; i < UB; ++i)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
-          wv[i][hh] = *reinterpret_cast<const u32x4*>(p.wq + (long long)(u0 + wave * UB + i) * H +
-                                                      min(h + 512 * hh, H - 8));
+          wv[i][hh] = h == lane * 8 ? wv0[i][hh]
+                                    : *reinterpret_cast<const u32x4*>(p.wq + (long long)(u0 + wave * UB + i) * H +
+                                                                      min(h + 512 * hh, H - 8));
 #pragma unroll
       for (int i = 0; i < UB; ++i)
 #pragma unroll
@@ -999,12 +1010,6 @@ __device__ __forceinline__ void ad_loc_scores_body(const AdAttn& p, const AdLoc&
 }
 
 __global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_kernel(AdAttn p, AdLoc x) { ad_loc_scores_body(p, x); }
-// the same behind the free-running decoder's stop flag (tacotron_infer.hpp: state[1] != 0 = decoding has ended)
-__global__ __launch_bounds__(kAttnThreads) void ti_scores_kernel(AdAttn p, AdLoc x, const int32_t* __restrict__ state) {
-  if (state[1] != 0) return;
-  ad_loc_scores_body(p, x);
-}
-
 // sum of the partial scores -> masked softmax -> alignments (+ cumulative) -> context columns
 __global__ __launch_bounds__(256) void ad_loc_context_kernel(AdAttn p, AdLoc x, int ncg, int nsp) {
   extern __shared__ float lds_raw[];
