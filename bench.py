@@ -805,7 +805,7 @@ def bench_tacotron_decode(dev, style=True, fp8=True, batch=32, steps=1000, reps=
   by = {"lstm_weights": wb * (4 * H * (P + M + H) + 4 * H * 2 * H) + (4.0 * 8 * H if fp8 else 0.0),
         "query_frame_prenet_weights": 2.0 * (U * H + nm * H + P * nm + P * P),
         "memory_values_live_rows": 2.0 * live * M, "memory_keys_live_rows": 2.0 * live * U,
-        "frame_projection_of_values_live_rows": 4.0 * live * nm,
+        "frame_projection_of_values_live_rows": 2.0 * live * nm,
         "state_vectors": 2.0 * batch * (P + M + H + 2 * H) * 2 + 4.0 * batch * (2 * H + 3 * S)}
   total = sum(by.values())
   fused = out.get("decoder_steps") == steps

@@ -853,7 +853,10 @@ typedef struct os2s_tacotron_infer {
   const uint16_t* wp1; const float* bp1;   /* pre-net layer 1: bf16 [P, n_mel], fp32 [P] */
   const uint16_t* wp2; const float* bp2;   /* pre-net layer 2: bf16 [P, P], fp32 [P] */
   const uint16_t* wout_h;          /* bf16 [n_mel, H]: output-projection columns of the cell output */
-  const float* pv;                 /* fp32 [B, S, n_mel] = values W_out[:, H:]^T (one caller GEMM per batch) */
+  /* transposed operands of the two attention-weighted sums, positions contiguous, rows padded with zeros to
+   * Sp = S rounded up to 32 (caller GEMM + transposes, once per batch): */
+  const uint16_t* pv_t;            /* bf16 [B, n_mel rounded up to 16, Sp] = (values W_out[:, H:]^T)^T */
+  const uint16_t* values_t;        /* bf16 [B, M, Sp] = values^T */
   const float* bout;               /* [n_mel] */
   const uint16_t* wstop; const float* bstop;   /* bf16 [n_mel], fp32 [1] */
   float* mh;                       /* fp32 [B, n_mel] scratch (the cell-output half of the frame of the step) */

@@ -1407,7 +1407,7 @@ class _TacotronInfer(_lib.ctypes.Structure):
               ("prenet_keep", c_float), ("prenet_seed", c_ull * 2),
               ("w0x", c_void_p), ("w0x8", c_void_p), ("w0x8_scale", c_void_p), ("bias0", c_void_p),
               ("wp1", c_void_p), ("bp1", c_void_p), ("wp2", c_void_p), ("bp2", c_void_p),
-              ("wout_h", c_void_p), ("pv", c_void_p), ("bout", c_void_p), ("wstop", c_void_p), ("bstop", c_void_p),
+              ("wout_h", c_void_p), ("pv_t", c_void_p), ("values_t", c_void_p), ("bout", c_void_p), ("wstop", c_void_p), ("bstop", c_void_p),
               ("mh", c_void_p), ("x_seq", c_void_p), ("mel", c_void_p), ("stop", c_void_p), ("state", c_void_p)]
 
 
@@ -1415,7 +1415,7 @@ class TacotronInfer(object):
   """Free-running Tacotron2 decoding on the device (os2s_tacotron_infer_steps): owns the frame / stop /
   pre-net / state buffers next to an AttnDecoder's sequence buffers. `w`: dict of the tensors of
   os2s_tacotron_infer_t (w0x bf16 [4H, P+M+H] or w0x8 = (uint8, scales), bias0, wp1, bp1, wp2, bp2,
-  wout_h, pv, bout, wstop, bstop). Steps are enqueued without host interaction; `done_steps()` reads
+  wout_h, pv_t, values_t, bout, wstop, bstop). Steps are enqueued without host interaction; `done_steps()` reads
   the device-resident stop decision (synchronises)."""
 
   def __init__(self, loop, P, n_mel, w, mask_decoder_sequence=True, prenet_keep=0.5, prenet_seeds=(0, 0)):
@@ -1442,7 +1442,7 @@ class TacotronInfer(object):
       x.w0x, x.w0x8, x.w0x8_scale = None, _addr(w["w0x8"][0]), _addr(w["w0x8"][1])
     else:
       x.w0x, x.w0x8, x.w0x8_scale = _addr(w["w0x"]), None, None
-    for k in ("bias0", "wp1", "bp1", "wp2", "bp2", "wout_h", "pv", "bout", "wstop", "bstop"):
+    for k in ("bias0", "wp1", "bp1", "wp2", "bp2", "wout_h", "pv_t", "values_t", "bout", "wstop", "bstop"):
       setattr(x, k, _addr(w[k]))
     x.x_seq, x.mel, x.stop, x.state = _addr(self.x_seq), _addr(self.mel), _addr(self.stop), _addr(self.state)
     x.mh = _addr(self.mh)

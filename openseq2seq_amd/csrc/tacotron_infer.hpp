@@ -34,8 +34,14 @@
 
 namespace os2s {
 
-constexpr int kTiWaves = 8;          // waves per LSTM workgroup (reduction split)
-constexpr int kTiCpw = 5;            // 64-wide k chunks per wave and round (K <= 2560 in one round)
+// waves per LSTM workgroup (the reduction split) x 64-wide k chunks per wave and round: 8 x 5 or 16 x 3 (K <= 2560 /
+// 3072 in one round of requests)
+
+#ifdef OS2S_TI_NT_WEIGHTS
+#define TI_WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define TI_WLOAD(p) (*(p))
+#endif
 
 struct TiLstm {
   int B, H, K, Ka;                   // K = Ka + Kb input columns
@@ -55,7 +61,7 @@ struct TiLstm {
 // rows of a 16-row tile: r = 4 * unit + gate, so that after the MFMA (acc[i] = row 4 * (lane >> 4) + i,
 // column lane & 15) a lane holds the four gates of ONE (unit, sample). MT row tiles (4 * MT units) x NT
 // 16-sample column tiles per workgroup.
-template <bool FP8, int MT, int NT>
+template <bool FP8, int MT, int NT, int kTiWaves, int kTiCpw>
 __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
   __shared__ float red[kTiWaves * MT * NT * 4 * 64];
   const int done = p.state[1];         // consumed after the loads are in flight
@@ -119,10 +125,10 @@ __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
       const int k = c * 64 + q * 16;                  // this lane's 16 consecutive k of the chunk
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if (FP8) wa[i][mt] = *reinterpret_cast<const u32x4*>(w8[mt] + k);
+        if (FP8) wa[i][mt] = TI_WLOAD(reinterpret_cast<const u32x4*>(w8[mt] + k));
         else {
-          wa[i][mt] = *reinterpret_cast<const u32x4*>(w16[mt] + k);
-          wb[i][mt] = *reinterpret_cast<const u32x4*>(w16[mt] + k + 8);
+          wa[i][mt] = TI_WLOAD(reinterpret_cast<const u32x4*>(w16[mt] + k));
+          wb[i][mt] = TI_WLOAD(reinterpret_cast<const u32x4*>(w16[mt] + k + 8));
         }
       }
 #pragma unroll
@@ -186,14 +192,36 @@ __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
     for (int w = 0; w < kTiWaves; ++w) s += red[(((w * MT + e_mt) * NT + e_nt) * 4 + g) * 64 + lane];
     pre[g] = s * e_sc[g] + e_bias[g];
   }
-  const float ig = sigmoidf_(pre[0]), gg = tanhf(pre[1]);
+  // (tanh through one exp + one reciprocal: the library tanhf is several hundred bytes of code per call, and the
+  // code a step kernel executes IS its latency, see "score launch" below; |error| ~1e-7 against bf16 outputs)
+  const float ig = sigmoidf_(pre[0]), gg = tanh_fast(pre[1]);
   const float fg = sigmoidf_(pre[2] + p.forget_bias), og = sigmoidf_(pre[3]);
   const float cn = e_c * fg + ig * gg;
-  const bf16_t hn = f2bf(tanhf(cn) * og);
+  const bf16_t hn = f2bf(tanh_fast(cn) * og);
   p.c_out[(long long)e_b * p.ldc_out + e_j] = cn;
   if (p.h1) p.h1[(long long)e_b * p.ldh1 + e_j] = hn;
   if (p.h2) p.h2[(long long)e_b * p.ldh2 + e_j] = hn;
 }
+
+typedef __attribute__((ext_vector_type(2))) __bf16 ti_bf2;
+__device__ __forceinline__ float ti_dot2(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ti_bf2, a), __builtin_bit_cast(ti_bf2, b), c, false);
+}
+__device__ __forceinline__ float ti_dot8(const u32x4& a, const u32x4& b, float c) {
+  c = ti_dot2(a[0], b[0], c);
+  c = ti_dot2(a[1], b[1], c);
+  c = ti_dot2(a[2], b[2], c);
+  return ti_dot2(a[3], b[3], c);
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_mov<0xB1, 0xf>(0.f, x);    // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E, 0xf>(0.f, x);    // quad_perm [2,3,0,1]
+  x += dpp_mov<0x124, 0xf>(0.f, x);   // row_ror:4
+  x += dpp_mov<0x128, 0xf>(0.f, x);   // row_ror:8
+  return x;
+}
+
 
 // ---- context + frame ----------------------------------------------------------------------------------
 struct TiTail {
@@ -204,7 +232,8 @@ struct TiTail {
   const bf16_t* wp1; const float* bp1; // [P, n_mel], [P]
   const bf16_t* wp2; const float* bp2; // [P, P], [P]
   const bf16_t* wout_h;                // [n_mel, H]
-  const float* pv;                     // [B, S, n_mel]
+  const bf16_t* pv_t;                  // [B, n_mel16, Sp] bf16: (values W_out[:, H:]^T)^T, positions contiguous
+  const bf16_t* values_t;              // [B, M, Sp] bf16: values^T
   const float* bout;                   // [n_mel]
   const bf16_t* wstop; const float* bstop;   // [n_mel], [1]
   float* mh;                           // [B, n_mel] scratch: W_out[:, :H] h1 of the step (ti_scores_kernel -> ti_context_kernel)
@@ -218,221 +247,25 @@ struct TiTail {
 constexpr int kTiCtxThreads = 512;
 constexpr int kTiW2Rows = 16;          // W2 rows per thread (P <= 256: P * P / 8 sixteen-byte pieces over 512 threads)
 constexpr int kTiW1Pieces = 8;         // W1 pieces per thread
-constexpr int kTiPvLoads = 8;          // PV rows per thread and round
+constexpr int kTiKs = 8;               // 32-position steps whose operands are requested up front (S <= 256)
 
-__host__ __device__ inline size_t ti_tail_lds_floats(int S, int P, int n_mel) {
-  // e [S] + red [32] + fr [n_mel] + x1 [P] + partials: max(G * n_mel, P * (P / 8 + 1), P * 8)
-  const size_t G = kTiCtxThreads / (n_mel / 4);
-  size_t part = G * n_mel;
-  if ((size_t)P * (P / 8 + 1) > part) part = (size_t)P * (P / 8 + 1);
+__host__ __device__ inline int ti_spad(int S) { return (S + 31) & ~31; }      // row pitch of values_t / pv_t
+
+__host__ __device__ inline size_t ti_ctx_lds_floats(int S, int P, int n_mel) {
+  // e [Sp] + red [32] + hi / lo alignments (bf16, max(Sp, 256) each) + frame [n_mel] + x1 [P] + mc [n_mel + 16] +
+  // partials max(P * (P / 8 + 1), P * 8)
+  const size_t Sp = ti_spad(S), Sa = Sp > 256 ? Sp : 256;
+  size_t part = (size_t)P * (P / 8 + 1);
   if ((size_t)P * 8 > part) part = (size_t)P * 8;
-  return (size_t)S + 4 + 32 + n_mel + P + part + 64;
+  return Sp + 32 + Sa + n_mel + P + n_mel + 16 + part + 64;
 }
 
-// The frame part of a sample: one workgroup, ONE dependent chain (alignments -> frame -> stop token -> pre-net
-// layer 1 -> layer 2), so everything that does not depend on the chain is requested first: both pre-net
-// matrices (168 KB) and this sample's rows of PV sit in registers before the softmax starts.
-__device__ __forceinline__ void ti_tail(const AdAttn& p, const AdLoc& x, const TiTail& q, float* lds) {
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int S = p.S, P = q.P, nm = q.n_mel, B = p.B, T = p.T;
-  float* e = lds;                      // [S]
-  float* red = e + ((S + 3) & ~3);     // [32]
-  float* fr = red + 32;                // [nm] the frame, bf16-rounded
-  float* x1 = fr + nm;                 // [P]
-  float* part = x1 + P;                // partial sums of the stage at hand
-  const int t_next = q.first ? 0 : p.t + 1;
-  const int slen = q.first ? 0 : min(max(p.src_len[b], 0), S);
-  // ---- requests ---------------------------------------------------------------------------------------
-  // W2 [P, P]: thread = (piece pc of a row, row group rg); rows rg, rg + RG, ...
-  const int pcs2 = P >> 3, RG = kTiCtxThreads / pcs2;
-  const int pc2 = tid % pcs2, rg = tid / pcs2;
-  u32x4 w2[kTiW2Rows];
-#pragma unroll
-  for (int i = 0; i < kTiW2Rows; ++i) {
-    const int j = min(rg + i * RG, P - 1);
-    w2[i] = *reinterpret_cast<const u32x4*>(q.wp2 + (long long)j * P + pc2 * 8);
-  }
-  // W1 [P, nm]: TPR threads per row, each pieces pc, pc + TPR, ...
-  const int pcs1 = nm >> 3, TPR = kTiCtxThreads / P;          // P <= 256: TPR >= 2
-  const int j1 = tid / TPR, s1 = tid % TPR;
-  u32x4 w1[kTiW1Pieces];
-#pragma unroll
-  for (int i = 0; i < kTiW1Pieces; ++i) {
-    const int pc = min(s1 + i * TPR, pcs1 - 1);
-    w1[i] = *reinterpret_cast<const u32x4*>(q.wp1 + (long long)min(j1, P - 1) * nm + pc * 8);
-  }
-  // PV rows of this sample: thread = (quad of frame columns m4, position group sg); positions sg, sg + G, ...
-  const int nm4 = nm >> 2, G = kTiCtxThreads / nm4;
-  const int m4 = tid % nm4, sg = tid / nm4;
-  f32x4 pvr[kTiPvLoads];
-  const float* pvb = q.pv + (long long)b * S * nm + m4 * 4;
-#pragma unroll
-  for (int i = 0; i < kTiPvLoads; ++i) {
-    const int sp = min(sg + i * G, S - 1);
-    pvr[i] = *reinterpret_cast<const f32x4*>(pvb + (long long)sp * nm);
-  }
-  float mh = 0.f, bo = 0.f;
-  if (!q.first && tid < nm) { mh = q.mh[(long long)b * nm + tid]; bo = q.bout[tid]; }
-  __builtin_amdgcn_sched_barrier(0);
-  if (q.first) {
-    for (int k = tid; k < nm; k += kTiCtxThreads) fr[k] = 0.f;
-    __syncthreads();
-  } else {
-    // ---- alignments ---------------------------------------------------------------------------------------
-    const float* ep = x.e_part + (long long)b * kLocParts * S;
-    float mx = -INFINITY;
-    for (int sp = tid; sp < slen; sp += kTiCtxThreads) {
-      float v = ep[sp];
-#pragma unroll
-      for (int k = 1; k < kLocParts; ++k) v += ep[k * S + sp];
-      e[sp] = v;
-      mx = fmaxf(mx, v);
-    }
-    mx = wave_max_dpp(mx);
-    if (lane == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = red[0];
-#pragma unroll
-    for (int w = 1; w < kTiCtxThreads / 64; ++w) mx = fmaxf(mx, red[w]);
-    float sum = 0.f;
-    for (int sp = tid; sp < slen; sp += kTiCtxThreads) {
-      const float ex = __expf(e[sp] - mx);
-      e[sp] = ex;
-      sum += ex;
-    }
-    sum = wave_sum_dpp(sum);
-    if (lane == 0) red[8 + (tid >> 6)] = sum;
-    __syncthreads();
-    sum = 0.f;
-#pragma unroll
-    for (int w = 0; w < kTiCtxThreads / 64; ++w) sum += red[8 + w];
-    const float inv = slen > 0 ? 1.f / sum : 0.f;
-    // ---- context half of the frame: sum_s a[s] PV[s, :] ------------------------------------------------------
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (sg < G) {
-#pragma unroll
-      for (int i = 0; i < kTiPvLoads; ++i) {
-        const int sp = sg + i * G;
-        const float a = sp < slen ? e[sp] * inv : 0.f;
-        acc += a * pvr[i];
-      }
-      for (int sp = sg + kTiPvLoads * G; sp < slen; sp += G) {       // S > 8 G: the rest, not prefetched
-        const f32x4 v = *reinterpret_cast<const f32x4*>(pvb + (long long)sp * nm);
-        acc += (e[sp] * inv) * v;
-      }
-      *reinterpret_cast<f32x4*>(part + sg * nm + m4 * 4) = acc;
-    }
-    __syncthreads();
-    if (tid < nm) {
-      float sacc = mh + bo;
-      for (int g2 = 0; g2 < G; ++g2) sacc += part[g2 * nm + tid];
-      const bf16_t fb = f2bf(sacc);
-      q.mel[((long long)b * T + p.t) * nm + tid] = fb;
-      fr[tid] = bf2f(fb);
-    }
-    __syncthreads();
-    // ---- stop token, finished / length bookkeeping (wave 0; the others go on) ----------------------------------
-    if (tid < 64) {
-      float sacc = 0.f;
-      for (int k = tid; k < nm; k += 64) sacc += bf2f(q.wstop[k]) * fr[k];
-      sacc = wave_sum_dpp(sacc);
-      if (tid == 0) {
-        sacc = bf2f(f2bf(sacc + q.bstop[0]));            // the stop projection's output tensor is bf16
-        q.stop[(long long)b * T + p.t] = sacc;
-        int32_t* fin = q.state + 4;
-        int32_t* len = q.state + 4 + B;
-        const int was = fin[b];
-        if (!was) len[b] = p.t + 1;                      // dynamic_decode: lengths count the step that finished
-        // round(sigmoid(s)) == 1  <=>  sigmoid(s) > 0.5  <=>  s > 0  (round half to even: 0.5 -> 0)
-        if (q.mask_seq && !was && sacc > 0.f) {
-          fin[b] = 1;
-          const int n = atomicAdd(&q.state[2], 1);
-          if (n == B - 1) q.state[1] = p.t + 1;          // visible to the next launch (kernel boundary)
-        }
-      }
-    }
-  }
-  if (t_next > T) return;
-  // ---- pre-net of the next step ---------------------------------------------------------------------------
-  const float ik = 1.f / q.keep;
-  {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < kTiW1Pieces; ++i) {
-      const int pc = s1 + i * TPR;
-      if (pc < pcs1) {
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2)
-          s += bflo(w1[i][k2]) * fr[pc * 8 + 2 * k2] + bfhi(w1[i][k2]) * fr[pc * 8 + 2 * k2 + 1];
-      }
-    }
-    if (j1 < P) part[j1 * 8 + s1] = s;                   // TPR <= 8
-  }
-  __syncthreads();
-  if (tid < P) {
-    float s = q.bp1[tid];
-    for (int i = 0; i < TPR; ++i) s += part[tid * 8 + i];
-    s = fmaxf(s, 0.f);
-    if (q.keep < 1.f) {
-      const unsigned long long idx = ((unsigned long long)t_next * B + b) * P + tid;
-      const uint32_t bits = dropout_bits8(q.seed[0], idx >> 3, q.keep);
-      s = ((bits >> (idx & 7)) & 1u) ? s * ik : 0.f;
-    }
-    x1[tid] = bf2f(f2bf(s));            // the layer's output is a bf16 tensor in the teacher-forced pass too
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < kTiW2Rows; ++i) {
-    const int j = rg + i * RG;
-    if (j < P && rg < RG) {
-      float s = 0.f;
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2)
-        s += bflo(w2[i][k2]) * x1[pc2 * 8 + 2 * k2] + bfhi(w2[i][k2]) * x1[pc2 * 8 + 2 * k2 + 1];
-      part[j * (pcs2 + 1) + pc2] = s;
-    }
-  }
-  __syncthreads();
-  if (tid < P) {
-    float s = q.bp2[tid];
-    for (int i = 0; i < pcs2; ++i) s += part[tid * (pcs2 + 1) + i];
-    s = fmaxf(s, 0.f);
-    if (q.keep < 1.f) {
-      const unsigned long long idx = ((unsigned long long)t_next * B + b) * P + tid;
-      const uint32_t bits = dropout_bits8(q.seed[1], idx >> 3, q.keep);
-      s = ((bits >> (idx & 7)) & 1u) ? s * ik : 0.f;
-    }
-    q.x_seq[((long long)b * (T + 1) + t_next) * P + tid] = f2bf(s);
-  }
-}
-
-// grid (ctx_parts + 1, B), 512 threads: parts < ctx_parts are the context columns (ad_loc_context_kernel's
-// arithmetic with twice the position slices); the last part is the frame
-__global__ __launch_bounds__(kTiCtxThreads) void ti_context_kernel(AdAttn p, AdLoc x, TiTail q, int ctx_parts,
-                                                                   int ncg, int nsp) {
-  extern __shared__ float lds_raw[];
-  const int cpart = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int M = p.M, S = p.S;
-  if (cpart == ctx_parts) {
-    if (!q.first && (q.state[1] != 0 || (q.dbg & 4))) return;
-    ti_tail(p, x, q, lds_raw);
-    return;
-  }
-  if (q.first || q.state[1] != 0 || (q.dbg & 8)) return;
-  float* e = lds_raw;                  // [S]
-  float* red = e + S;                  // [32]
-  float* part = red + 32;              // [nsp][ncg * 8]
-  const int slen = min(max(p.src_len[b], 0), S);
-  const long long row = (long long)b * p.T + p.t;
-  // this thread's rows of `values` do not depend on the alignments: requested before the softmax
-  const int MQ = ncg * 8, m0 = cpart * MQ;
-  const int cg = tid % ncg, sq = tid / ncg;
-  constexpr int kVr = 8;
-  u32x4 vr[kVr];
-  const bf16_t* vp = p.values + (long long)b * S * M + m0 + cg * 8;
-#pragma unroll
-  for (int i = 0; i < kVr; ++i) vr[i] = *reinterpret_cast<const u32x4*>(vp + (long long)min(sq + i * nsp, S - 1) * M);
-  __builtin_amdgcn_sched_barrier(0);
+// Softmax over the summed partial scores -> alignments: e[s] (fp32, zero past the length) and their bf16 hi / lo
+// halves ah / al (zero up to max(Sp, 256): the A operand of the weighted sums below). Every part of a sample
+// computes them; `store` (part 0) writes the alignment row and advances the cumulative alignments.
+__device__ __forceinline__ void ti_alignments(const AdAttn& p, const AdLoc& x, int b, int slen, float* e, float* red,
+                                              uint16_t* ah, uint16_t* al, bool store) {
+  const int tid = threadIdx.x, S = p.S, Sa = max(ti_spad(S), 256);
   const float* ep = x.e_part + (long long)b * kLocParts * S;
   float mx = -INFINITY;
   for (int sp = tid; sp < slen; sp += kTiCtxThreads) {
@@ -461,96 +294,433 @@ __global__ __launch_bounds__(kTiCtxThreads) void ti_context_kernel(AdAttn p, AdL
 #pragma unroll
   for (int w = 0; w < kTiCtxThreads / 64; ++w) sum += red[8 + w];
   const float inv = slen > 0 ? 1.f / sum : 0.f;
-  for (int sp = tid; sp < S; sp += kTiCtxThreads) {
+  const long long row = (long long)b * p.T + p.t;
+  for (int sp = tid; sp < Sa; sp += kTiCtxThreads) {
     const float a = sp < slen ? e[sp] * inv : 0.f;
-    e[sp] = a;
-    if (cpart == 0) {
+    const bf16_t hi = f2bf(a);
+    ah[sp] = hi;
+    al[sp] = f2bf(a - bf2f(hi));
+    if (store && sp < S) {
       p.align_seq[row * S + sp] = a;
       const long long ci = ((long long)b * (p.T + 1) + p.t) * S + sp;
       p.cum_seq[ci + S] = p.cum_seq[ci] + a;
     }
   }
   __syncthreads();
-  if (sq < nsp) {
-    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < kVr; ++i) {
-      const int sp = sq + i * nsp;
-      const float a = sp < slen ? e[sp] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { a8[2 * k] += a * bflo(vr[i][k]); a8[2 * k + 1] += a * bfhi(vr[i][k]); }
-    }
-    for (int sp = sq + kVr * nsp; sp < slen; sp += nsp) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(vp + (long long)sp * M);
-      const float a = e[sp];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { a8[2 * k] += a * bflo(v[k]); a8[2 * k + 1] += a * bfhi(v[k]); }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) part[sq * MQ + cg * 8 + k] = a8[k];
-  }
-  __syncthreads();
-  if (tid < ncg) {
-    float c8[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      c8[k] = 0.f;
-      for (int s2 = 0; s2 < nsp; ++s2) c8[k] += part[s2 * MQ + tid * 8 + k];
-    }
-    const int m8 = (m0 >> 3) + tid;
-    u32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = pack2bf(c8[2 * k], c8[2 * k + 1]);
-    *reinterpret_cast<u32x4*>(p.ctx + (long long)b * p.ctx_bs + (long long)p.t * p.ctx_ts + m8 * 8) = o;
-    *reinterpret_cast<u32x4*>(p.cat0 + ((long long)b * (p.T + 1) + p.t + 1) * p.Kc0 + m8 * 8) = o;
-  }
 }
 
-// W_out[:, :H] h1 of the step -> mh [B, n_mel]: it only needs the cell output, so it rides in the score launch as a
-// fifth part per sample (a wave per output row round, every load in flight at once)
-__device__ __forceinline__ void ti_frame_hpart(const AdAttn& p, const TiTail& q) {
-  extern __shared__ float lds_raw[];
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = p.H, nm = q.n_mel;
-  float* hq = lds_raw;
-  const bf16_t* yq = p.yq + (long long)b * p.yq_bs + (long long)p.t * p.yq_ts;
-  // rows wave, wave + 8, ...: kTiHRows rows per wave, H / 8 pieces per row over 64 lanes (H <= 1024: 2 per lane)
-  constexpr int kRows = 16, kPc = 2;
-  u32x4 wv[kRows][kPc];
+// out[n] = sum_s a[s] mat_t[row0 + n][s] for the 16 rows of one tile of a TRANSPOSED operand (bf16 [rows, Sp],
+// positions contiguous): the alignments are the A operand of a 16x16x32 MFMA (every A row the same, bf16 hi + lo),
+// 16 positions-contiguous bytes per lane are the B operand. Result for column n = lane & 15 in every lane.
+// breq: this lane's operands of the first kTiKs position steps, requested by the caller before the softmax.
+__device__ __forceinline__ float ti_weighted_sum(const bf16_t* __restrict__ mrow, int Sp, const u32x4 (&breq)[kTiKs],
+                                                 const uint16_t* ah, const uint16_t* al) {
+  const int kb = (threadIdx.x & 63) >> 4;
+  const int nks = Sp >> 5;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < kRows; ++i)
-#pragma unroll
-    for (int c = 0; c < kPc; ++c)
-      wv[i][c] = *reinterpret_cast<const u32x4*>(q.wout_h + (long long)min(wave + i * kAttnWaves, nm - 1) * H +
-                                                 min((lane + 64 * c) * 8, H - 8));
-  for (int h8 = tid; h8 < H / 8; h8 += kAttnThreads) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(yq + h8 * 8);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { hq[h8 * 8 + 2 * k] = bflo(v[k]); hq[h8 * 8 + 2 * k + 1] = bfhi(v[k]); }
+  for (int ks = 0; ks < kTiKs; ++ks) {
+    // steps past nks re-read the last step's operand against zero alignments (ah / al are zero up to 256)
+    const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(ah + ks * 32 + kb * 8);
+    const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(al + ks * 32 + kb * 8);
+    const bf16x8 bv = __builtin_bit_cast(bf16x8, breq[ks]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bv, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, bv, acc, 0, 0, 0);
   }
-  __syncthreads();
+#pragma unroll 1
+  for (int ks = kTiKs; ks < nks; ++ks) {           // S > 256: the rest, not requested ahead
+    const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(ah + ks * 32 + kb * 8);
+    const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(al + ks * 32 + kb * 8);
+    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(mrow + ks * 32 + kb * 8);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bv, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, bv, acc, 0, 0, 0);
+  }
+  return acc[0];                                   // rows are identical: row 4 * kb
+}
+
+__device__ __forceinline__ void ti_request_rows(const bf16_t* __restrict__ mrow, int Sp, u32x4 (&breq)[kTiKs]) {
+  const int kb = (threadIdx.x & 63) >> 4;
+  const int nks = Sp >> 5;
 #pragma unroll
-  for (int i = 0; i < kRows; ++i) {
-    float s = 0.f;
+  for (int ks = 0; ks < kTiKs; ++ks)
+    breq[ks] = *reinterpret_cast<const u32x4*>(mrow + min(ks, nks - 1) * 32 + kb * 8);
+}
+
+// The frame part of a sample: one workgroup, ONE dependent chain (alignments -> frame -> stop token -> pre-net
+// layer 1 -> layer 2), so everything that does not depend on the chain is requested first: both pre-net
+// matrices (168 KB) and this sample's rows of PV^T sit in registers before the softmax starts.
+__device__ __forceinline__ void ti_tail(const AdAttn& p, const AdLoc& x, const TiTail& q, float* lds) {
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = p.S, P = q.P, nm = q.n_mel, B = p.B, T = p.T;
+  const int Sp = ti_spad(S), Sa = max(Sp, 256), nm16 = (nm + 15) & ~15;
+  float* e = lds;                      // [Sp]
+  float* red = e + Sp;                 // [32]
+  uint16_t* ah = reinterpret_cast<uint16_t*>(red + 32);    // [Sa] bf16
+  uint16_t* al = ah + Sa;                                  // [Sa]
+  uint32_t* frp = reinterpret_cast<uint32_t*>(al + Sa);    // [nm / 2] the frame as packed bf16 pairs (nm floats reserved)
+  uint32_t* x1p = frp + nm;            // [P / 2] pre-net layer-1 output, packed bf16 (P floats reserved)
+  float* mc = reinterpret_cast<float*>(x1p + P);            // [nm16] context half of the frame
+  float* part = mc + nm + 16;          // partial sums of the pre-net stages
+  uint16_t* fr16 = reinterpret_cast<uint16_t*>(frp);
+  uint16_t* x116 = reinterpret_cast<uint16_t*>(x1p);
+  const int t_next = q.first ? 0 : p.t + 1;
+  const int slen = q.first ? 0 : min(max(p.src_len[b], 0), S);
+  // ---- requests ---------------------------------------------------------------------------------------
+  // W2 [P, P]: thread = (piece pc of a row, row group rg); rows rg, rg + RG, ...
+  const int pcs2 = P >> 3, RG = kTiCtxThreads / pcs2;
+  const int pc2 = tid % pcs2, rg = tid / pcs2;
+  u32x4 w2[kTiW2Rows];
 #pragma unroll
-    for (int c = 0; c < kPc; ++c) {
-      const int k = (lane + 64 * c) * 8;
-      if (k < H) {
+  for (int i = 0; i < kTiW2Rows; ++i) {
+    const int j = min(rg + i * RG, P - 1);
+    w2[i] = *reinterpret_cast<const u32x4*>(q.wp2 + (long long)j * P + pc2 * 8);
+  }
+  // W1 [P, nm]: TPR threads per row, each pieces pc, pc + TPR, ...
+  const int pcs1 = nm >> 3, TPR = kTiCtxThreads / P;          // P <= 256: TPR >= 2
+  const int j1 = tid / TPR, s1 = tid % TPR;
+  u32x4 w1[kTiW1Pieces];
 #pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) s += bflo(wv[i][c][k2]) * hq[k + 2 * k2] + bfhi(wv[i][c][k2]) * hq[k + 2 * k2 + 1];
+  for (int i = 0; i < kTiW1Pieces; ++i) {
+    const int pc = min(s1 + i * TPR, pcs1 - 1);
+    w1[i] = *reinterpret_cast<const u32x4*>(q.wp1 + (long long)min(j1, P - 1) * nm + pc * 8);
+  }
+  // PV^T rows of this sample: wave w < nm16 / 16 owns frame columns 16 w ... (the other waves re-read tile 0)
+  const int ct = wave < nm16 / 16 ? wave : 0;
+  const bf16_t* pvrow = q.pv_t + ((long long)b * nm16 + ct * 16 + (lane & 15)) * Sp;
+  u32x4 breq[kTiKs];
+  ti_request_rows(pvrow, Sp, breq);
+  float mh = 0.f, bo = 0.f;
+  if (!q.first && tid < nm) { mh = q.mh[(long long)b * nm + tid]; bo = q.bout[tid]; }
+  __builtin_amdgcn_sched_barrier(0);
+  if (q.first) {
+    for (int k = tid; k < nm; k += kTiCtxThreads) fr16[k] = 0;
+    __syncthreads();
+  } else {
+    ti_alignments(p, x, b, slen, e, red, ah, al, false);
+    // ---- context half of the frame: sum_s a[s] PV[s, :] ------------------------------------------------------
+    const float cs = ti_weighted_sum(pvrow, Sp, breq, ah, al);
+    if (wave < nm16 / 16 && lane < 16) mc[wave * 16 + lane] = cs;
+    __syncthreads();
+    if (tid < nm) {
+      const bf16_t fb = f2bf(mh + bo + mc[tid]);
+      q.mel[((long long)b * T + p.t) * nm + tid] = fb;
+      fr16[tid] = fb;
+    }
+    __syncthreads();
+    // ---- stop token, finished / length bookkeeping (wave 0; the others go on) ----------------------------------
+    if (tid < 64) {
+      float sacc = 0.f;
+      for (int k = tid; k < nm / 2; k += 64) sacc = ti_dot2(reinterpret_cast<const uint32_t*>(q.wstop)[k], frp[k], sacc);
+      sacc = wave_sum_dpp(sacc);
+      if (tid == 0) {
+        sacc = bf2f(f2bf(sacc + q.bstop[0]));            // the stop projection's output tensor is bf16
+        q.stop[(long long)b * T + p.t] = sacc;
+        int32_t* fin = q.state + 4;
+        int32_t* len = q.state + 4 + B;
+        const int was = fin[b];
+        if (!was) len[b] = p.t + 1;                      // dynamic_decode: lengths count the step that finished
+        // round(sigmoid(s)) == 1  <=>  sigmoid(s) > 0.5  <=>  s > 0  (round half to even: 0.5 -> 0)
+        if (q.mask_seq && !was && sacc > 0.f) {
+          fin[b] = 1;
+          const int n = atomicAdd(&q.state[2], 1);
+          if (n == B - 1) q.state[1] = p.t + 1;          // visible to the next launch (kernel boundary)
+        }
       }
     }
-    s = wave_sum_dpp(s);
-    const int m = wave + i * kAttnWaves;
-    if (lane == 0 && m < nm) q.mh[(long long)b * nm + m] = s;
+  }
+  if (t_next > T) return;
+  // ---- pre-net of the next step ---------------------------------------------------------------------------
+  const float ik = 1.f / q.keep;
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kTiW1Pieces; ++i) {
+      const int pc = min(s1 + i * TPR, pcs1 - 1);
+      const float d = ti_dot8(w1[i], *reinterpret_cast<const u32x4*>(frp + pc * 4), 0.f);
+      s += s1 + i * TPR < pcs1 ? d : 0.f;
+    }
+    if (j1 < P) part[j1 * 8 + s1] = s;                   // TPR <= 8
+  }
+  __syncthreads();
+  if (tid < P) {
+    float s = q.bp1[tid];
+    for (int i = 0; i < TPR; ++i) s += part[tid * 8 + i];
+    s = fmaxf(s, 0.f);
+    if (q.keep < 1.f) {
+      const unsigned long long idx = ((unsigned long long)t_next * B + b) * P + tid;
+      const uint32_t bits = dropout_bits8(q.seed[0], idx >> 3, q.keep);
+      s = ((bits >> (idx & 7)) & 1u) ? s * ik : 0.f;
+    }
+    x116[tid] = f2bf(s);                // the layer's output is a bf16 tensor in the teacher-forced pass too
+  }
+  __syncthreads();
+  {
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x1p + pc2 * 4);
+#pragma unroll
+    for (int i = 0; i < kTiW2Rows; ++i) {
+      const int j = rg + i * RG;
+      const float d = ti_dot8(w2[i], xv, 0.f);
+      if (j < P && rg < RG) part[j * (pcs2 + 1) + pc2] = d;
+    }
+  }
+  __syncthreads();
+  if (tid < P) {
+    float s = q.bp2[tid];
+    for (int i = 0; i < pcs2; ++i) s += part[tid * (pcs2 + 1) + i];
+    s = fmaxf(s, 0.f);
+    if (q.keep < 1.f) {
+      const unsigned long long idx = ((unsigned long long)t_next * B + b) * P + tid;
+      const uint32_t bits = dropout_bits8(q.seed[1], idx >> 3, q.keep);
+      s = ((bits >> (idx & 7)) & 1u) ? s * ik : 0.f;
+    }
+    q.x_seq[((long long)b * (T + 1) + t_next) * P + tid] = f2bf(s);
   }
 }
 
-// grid (kLocParts + 1, B): the location-sensitive scores (attn_decoder.hip) + the cell-output half of the frame
+// grid (ctx_parts + 1, B), 512 threads: part c < ctx_parts = context columns [c * MQ, (c + 1) * MQ) (a 16-column
+// tile per wave: attention_t[m] = sum_s a[s] values^T[m][s] on the matrix cores); the last part is the frame
+__global__ __launch_bounds__(kTiCtxThreads) void ti_context_kernel(AdAttn p, AdLoc x, TiTail q, int ctx_parts,
+                                                                   int MQ) {
+  extern __shared__ float lds_raw[];
+  const int cpart = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = p.M, S = p.S;
+  if (cpart == ctx_parts) {
+    if (!q.first && (q.state[1] != 0 || (q.dbg & 4))) return;
+    ti_tail(p, x, q, lds_raw);
+    return;
+  }
+  if (q.first || q.state[1] != 0 || (q.dbg & 8)) return;
+  const int Sp = ti_spad(S), Sa = max(Sp, 256);
+  float* e = lds_raw;                  // [Sp]
+  float* red = e + Sp;                 // [32]
+  uint16_t* ah = reinterpret_cast<uint16_t*>(red + 32);
+  uint16_t* al = ah + Sa;
+  const int slen = min(max(p.src_len[b], 0), S);
+  const int ntile = MQ >> 4;           // 16-column tiles of this part: wave w owns tiles w and w + 8 (requested up
+  const int m0 = cpart * MQ;           // front), further ones (M > 2048 / parts) in a rolled loop
+  constexpr int NW = kTiCtxThreads / 64;
+  const int cta = wave < ntile ? wave : 0, ctb = wave + NW < ntile ? wave + NW : cta;
+  const bf16_t* vbase = q.values_t + ((long long)b * M + m0 + (lane & 15)) * Sp;
+  u32x4 breq_a[kTiKs], breq_b[kTiKs];
+  ti_request_rows(vbase + (long long)cta * 16 * Sp, Sp, breq_a);
+  ti_request_rows(vbase + (long long)ctb * 16 * Sp, Sp, breq_b);
+  __builtin_amdgcn_sched_barrier(0);
+  ti_alignments(p, x, b, slen, e, red, ah, al, cpart == 0);
+  bf16_t* ctx = p.ctx + (long long)b * p.ctx_bs + (long long)p.t * p.ctx_ts;
+  bf16_t* cat = p.cat0 + ((long long)b * (p.T + 1) + p.t + 1) * p.Kc0;
+  {
+    const float ca = ti_weighted_sum(vbase + (long long)cta * 16 * Sp, Sp, breq_a, ah, al);
+    const float cb = ti_weighted_sum(vbase + (long long)ctb * 16 * Sp, Sp, breq_b, ah, al);
+    if (lane < 16) {
+      if (wave < ntile) { const bf16_t v = f2bf(ca); ctx[m0 + wave * 16 + lane] = v; cat[m0 + wave * 16 + lane] = v; }
+      if (wave + NW < ntile) {
+        const bf16_t v = f2bf(cb);
+        ctx[m0 + (wave + NW) * 16 + lane] = v;
+        cat[m0 + (wave + NW) * 16 + lane] = v;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int ct = wave + 2 * NW; ct < ntile; ct += NW) {
+    const bf16_t* vr = vbase + (long long)ct * 16 * Sp;
+    u32x4 br[kTiKs];
+    ti_request_rows(vr, Sp, br);
+    const float c = ti_weighted_sum(vr, Sp, br, ah, al);
+    if (lane < 16) {
+      const bf16_t v = f2bf(c);
+      ctx[m0 + ct * 16 + lane] = v;
+      cat[m0 + ct * 16 + lane] = v;
+    }
+  }
+}
+
+// ---- score launch -----------------------------------------------------------------------------------------
+// What a step kernel costs is mostly the CODE it executes once: the instruction cache is cold at every dispatch
+// and straight-line code streams in at roughly 64 B per 0.1 us (a 10 KB unrolled block measured 18 us by
+// itself, tools/README.md "OS2S_TI_DEBUG"). So the inference kernels are written for few instruction bytes on
+// the critical path: packed bf16 dot products (v_dot2c_f32_bf16, one instruction per pair) instead of
+// unpack + FMA, rolled loops, and the location term on the matrix cores instead of a 32 x 32 unrolled FMA
+// window.
+__host__ __device__ inline size_t ti_scores_lds_floats(int S) {
+  const size_t Sp = ((size_t)S + 15) & ~(size_t)15;
+  return 64 + (Sp + 48) + Sp * kLocUnits / 2 + 64;     // q/bias, padded cumulative alignments, key columns (bf16)
+}
+
+// W_out[:, :H] h1 of the step -> mh [B, n_mel] (the half of the frame that only needs the cell output): a wave
+// per output row round, the row pieces and the cell output straight from global memory in packed bf16
+__device__ __forceinline__ void ti_frame_hpart(const AdAttn& p, const TiTail& q) {
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, nm = q.n_mel;
+  const bf16_t* yq = p.yq + (long long)b * p.yq_bs + (long long)p.t * p.yq_ts;
+  constexpr int kRows = 16;            // rows wave, wave + 8, ...: n_mel <= 128; H <= 1024: 2 pieces per lane
+  const int k0 = min(lane * 8, H - 8), k1 = min(lane * 8 + 512, H - 8);
+  const u32x4 h0 = *reinterpret_cast<const u32x4*>(yq + k0);
+  u32x4 h1v = *reinterpret_cast<const u32x4*>(yq + k1);
+  u32x4 w0[kRows], w1[kRows];
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) {
+    const bf16_t* wr = q.wout_h + (long long)min(wave + i * kAttnWaves, nm - 1) * H;
+    w0[i] = *reinterpret_cast<const u32x4*>(wr + k0);
+    w1[i] = *reinterpret_cast<const u32x4*>(wr + k1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  const u32x4 h0m = lane * 8 < H ? h0 : zero;
+  h1v = lane * 8 + 512 < H ? h1v : zero;
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) {
+    float sacc = ti_dot8(w0[i], h0m, 0.f);
+    sacc = ti_dot8(w1[i], h1v, sacc);
+    sacc = wave_sum_dpp(sacc);
+    const int m = wave + i * kAttnWaves;
+    if (lane == 0 && m < nm) q.mh[(long long)b * nm + m] = sacc;
+  }
+}
+
+// location-sensitive scores of one unit part (32 units) of one sample:
+//   e_part[s] = sum_u v[u] tanh(keys[s,u] + q[u] + bias[u] + sum_k cum[s + k - padl] Wck[k,u])
+// The location term is a [S x 32 taps] x [32 taps x 32 units] product on the matrix cores: A = the Toeplitz rows
+// of the (zero padded) cumulative alignments, B = the folded location filter, both split into bf16 hi + lo
+// (three MFMAs per tile: the cumulative alignments grow with the step count and a single bf16 would lose them).
+__device__ __forceinline__ void ti_scores_part(const AdAttn& p, const AdLoc& x, float* lds) {
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, U = p.U, S = p.S, K = p.loc_k;
+  const int Sp = (S + 15) & ~15;
+  float* qb = lds;                                   // [32] q + bias + folded location bias
+  float* nv = qb + kLocUnits;                        // [32]
+  float* cum = nv + kLocUnits;                       // [Sp + 48] cum[i] = cumulative[i - padl], zero padded
+  uint16_t* keys = reinterpret_cast<uint16_t*>(cum + Sp + 48);   // [Sp][32] bf16
+  const int slen = min(max(p.src_len[b], 0), S);
+  const int u0 = part * kLocUnits;
+  const long long row = (long long)b * p.T + p.t;
+  // ---- requests: this wave's rows of Wq + the cell output (packed bf16, no staging) ---------------------------
+  constexpr int UB = kLocUnits / kAttnWaves;         // 4 units per wave
+  const bf16_t* yq = p.yq + (long long)b * p.yq_bs + (long long)p.t * p.yq_ts;
+  const int k0 = min(lane * 8, H - 8), k1 = min(lane * 8 + 512, H - 8);
+  const u32x4 h0 = *reinterpret_cast<const u32x4*>(yq + k0);
+  u32x4 h1v = *reinterpret_cast<const u32x4*>(yq + k1);
+  u32x4 wq0[UB], wq1[UB];
+#pragma unroll
+  for (int i = 0; i < UB; ++i) {
+    const bf16_t* wr = p.wq + (long long)(u0 + wave * UB + i) * H;
+    wq0[i] = *reinterpret_cast<const u32x4*>(wr + k0);
+    wq1[i] = *reinterpret_cast<const u32x4*>(wr + k1);
+  }
+  // the folded location filter as the MFMA B operand: column n = lane & 15 (+ 16), taps (lane >> 4) * 8 ... + 8
+  const int r16 = lane & 15, kb = lane >> 4;
+  float wf[2][8];
+#pragma unroll
+  for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kb * 8 + j;
+      wf[ut][j] = p.wck[(long long)min(k, K - 1) * U + u0 + ut * 16 + r16];
+    }
+  // staging: padded cumulative alignments, this part's key columns
+  {
+    const int padl = (K - 1) / 2;
+    const float* cs = p.cum_seq + ((long long)b * (p.T + 1) + p.t) * S;
+    for (int i = tid; i < Sp + 48; i += kAttnThreads) {
+      const int sp = i - padl;
+      cum[i] = (sp >= 0 && sp < S) ? cs[sp] : 0.f;
+    }
+    const bf16_t* kp = p.keys + (long long)b * S * U + u0;
+    for (int i = tid; i < slen * 4; i += kAttnThreads) {
+      const int sp = i >> 2, c = i & 3;
+      *reinterpret_cast<u32x4*>(keys + sp * kLocUnits + c * 8) = *reinterpret_cast<const u32x4*>(kp + (long long)sp * U + c * 8);
+    }
+  }
+  float e_b = 0.f, e_v = 0.f;
+  if (tid < kLocUnits) {
+    const int u = u0 + tid;
+    e_v = p.v[u];
+    e_b = ((p.use_bias && p.bias) ? p.bias[u] : 0.f) + p.wck[(long long)K * U + u];
+  }
+  // ---- q of this wave's four units ------------------------------------------------------------------------
+  {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    const u32x4 h0m = lane * 8 < H ? h0 : zero;
+    h1v = lane * 8 + 512 < H ? h1v : zero;
+    float qv[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      float sacc = ti_dot8(wq0[i], h0m, 0.f);
+      sacc = ti_dot8(wq1[i], h1v, sacc);
+      qv[i] = wave_sum_dpp(sacc);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        qb[wave * UB + i] = qv[i];
+        p.q_seq[row * U + u0 + wave * UB + i] = qv[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < kLocUnits) { qb[tid] += e_b; nv[tid] = e_v; }
+  // B operand registers: hi / lo halves of the filter taps (taps >= K are zero)
+  bf16x8 bh[2], bl[2];
+#pragma unroll
+  for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = kb * 8 + j < K ? wf[ut][j] : 0.f;
+      const __bf16 hi = (__bf16)w;
+      bh[ut][j] = hi;
+      bl[ut][j] = (__bf16)(w - (float)hi);
+    }
+  __syncthreads();
+  const float q0 = qb[r16], q1 = qb[16 + r16], v0 = nv[r16], v1 = nv[16 + r16];
+  float* eo = x.e_part + ((long long)b * kLocParts + part) * S;
+  const int ntiles = (slen + 15) >> 4;
+#pragma unroll 1
+  for (int pt = wave; pt < ntiles; pt += kAttnWaves) {
+    // A operand: row = position pt * 16 + (lane & 15), taps kb * 8 ... + 8 -> cum[pos + tap]
+    const float* cp = cum + pt * 16 + r16 + kb * 8;
+    bf16x8 ah, al;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float c = cp[j];
+      const __bf16 hi = (__bf16)c;
+      ah[j] = hi;
+      al[j] = (__bf16)(c - (float)hi);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[1], acc1, 0, 0, 0);
+    // accumulator element i: position pt * 16 + 4 * (lane >> 4) + i, unit (lane & 15) (+ 16)
+    float pr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sp = pt * 16 + 4 * kb + i;
+      const uint16_t* kr = keys + sp * kLocUnits + r16;
+      const float x0 = acc0[i] + q0 + (sp < slen ? bf2f(kr[0]) : 0.f);
+      const float x1 = acc1[i] + q1 + (sp < slen ? bf2f(kr[16]) : 0.f);
+      pr[i] = row16_sum(v0 * tanh_fast(x0) + v1 * tanh_fast(x1));
+    }
+    if (r16 == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sp = pt * 16 + 4 * kb + i;
+        if (sp < slen) eo[sp] = pr[i];
+      }
+    }
+  }
+}
+
+// grid (kLocParts + 1, B): the location-sensitive scores + the cell-output half of the frame
 __global__ __launch_bounds__(kAttnThreads) void ti_scores_kernel(AdAttn p, AdLoc x, TiTail q) {
+  extern __shared__ float lds_raw[];
   if (q.state[1] != 0) return;
   if (blockIdx.x == kLocParts) { if (!(q.dbg & 1)) ti_frame_hpart(p, q); }
-  else if (!(q.dbg & 2)) ad_loc_scores_body(p, x);
+  else if (!(q.dbg & 2)) ti_scores_part(p, x, lds_raw);
 }
 
 }  // namespace os2s
@@ -564,7 +734,7 @@ static int ti_check(const os2s_tacotron_infer_t* x) {
   const os2s_attn_decoder_t* d = x->loop;
   const int rc = ad_check(d);
   if (rc != OS2S_OK) return rc;
-  OS2S_REQUIRE(x->P >= 8 && x->n_mel >= 8 && x->x_seq && x->mel && x->stop && x->state && x->pv && x->wout_h);
+  OS2S_REQUIRE(x->P >= 8 && x->n_mel >= 8 && x->x_seq && x->mel && x->stop && x->state && x->pv_t && x->values_t && x->wout_h);
   OS2S_REQUIRE(x->wp1 && x->bp1 && x->wp2 && x->bp2 && x->bout && x->wstop && x->bstop && x->bias0);
   OS2S_REQUIRE((x->w0x != nullptr) != (x->w0x8 != nullptr));
   if (x->w0x8) OS2S_REQUIRE(x->w0x8_scale && (d->L == 1 || (d->wcat8[1] && d->wcat8_scale[1])));
@@ -574,34 +744,60 @@ static int ti_check(const os2s_tacotron_infer_t* x) {
       x->n_mel > 128 || x->P > 1024 || d->attn_in_keep < 1.f || d->out_keep < 1.f || d->tgt_len)
     return OS2S_ERR_UNSUPPORTED;
   if (x->P > 256 || x->n_mel / 8 > kTiW1Pieces * (kTiCtxThreads / x->P) || x->n_mel > 16 * kAttnWaves ||
-      d->H > 1024 || !x->mh)
+      d->H > 1024 || !x->mh || d->loc_k > 32 || ti_scores_lds_floats(d->S) * sizeof(float) > 64 * 1024)
     return OS2S_ERR_UNSUPPORTED;
-  if (ti_tail_lds_floats(d->S, x->P, x->n_mel) * sizeof(float) > 64 * 1024) return OS2S_ERR_UNSUPPORTED;
+  if (ti_ctx_lds_floats(d->S, x->P, x->n_mel) * sizeof(float) > 64 * 1024 || d->M % 16) return OS2S_ERR_UNSUPPORTED;
   return OS2S_OK;
 }
 
 extern "C" int os2s_tacotron_infer_supported(const os2s_tacotron_infer_t* x) { return ti_check(x) == OS2S_OK; }
 
 // units per workgroup: 4 (16 gate rows: H / 4 workgroups) or 8 (32 rows: half the workgroups, half the reads of the
-// state rows); OS2S_TI_ROWS = 16 | 32 overrides the default (experiments)
+// state rows); OS2S_TI_ROWS = 16 | 32 and OS2S_TI_WAVES = 8 | 16 override the defaults (experiments)
 static int ti_rows() {
   static const int v = [] { const char* e = getenv("OS2S_TI_ROWS"); return e ? atoi(e) : 16; }();
   return v == 32 ? 32 : 16;
 }
+// waves x chunk slots per wave of the 16-row kernel: by default the smallest number of slots that covers K with 8
+// or 9 waves (every slot of requests costs about a microsecond: 8 x 5 -> 8 x 4 measured 9.7 -> 8.7 us on the
+// K = 2048 layer; K = 2304 = 36 chunks takes 9 waves x 4). OS2S_TI_GEOM = "<waves>x<slots>" overrides (experiments).
+static void ti_geom(int K, int* nw, int* cpw) {
+  static const int env = [] {
+    const char* e = getenv("OS2S_TI_GEOM");
+    int a = 0, b = 0;
+    return (e && sscanf(e, "%dx%d", &a, &b) == 2) ? a * 100 + b : 0;
+  }();
+  if (env) { *nw = env / 100; *cpw = env % 100; return; }
+  const int nchunks = K >> 6;
+  if (nchunks <= 32) { *nw = 8; *cpw = 4; }
+  else if (nchunks <= 36) { *nw = 9; *cpw = 4; }
+  else { *nw = 8; *cpw = 5; }
+}
 
-template <bool FP8>
-static int ti_launch_lstm(hipStream_t stream, const TiLstm& c) {
-  const dim3 blk(64 * kTiWaves);
+template <bool FP8, int NT>
+static int ti_launch_lstm_nt(hipStream_t stream, const TiLstm& c) {
   if (ti_rows() == 32 && c.H % 8 == 0) {
-    const dim3 grid(ceil_div(c.H, 8));
-    if (c.B <= 16) { OS2S_LAUNCH((ti_lstm_kernel<FP8, 2, 1>), grid, blk, 0, stream, c); }
-    else { OS2S_LAUNCH((ti_lstm_kernel<FP8, 2, 2>), grid, blk, 0, stream, c); }
+    OS2S_LAUNCH((ti_lstm_kernel<FP8, 2, NT, 8, 5>), dim3(ceil_div(c.H, 8)), dim3(512), 0, stream, c);
     return OS2S_OK;
   }
   const dim3 grid(ceil_div(c.H, 4));
-  if (c.B <= 16) { OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, 1>), grid, blk, 0, stream, c); }
-  else { OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, 2>), grid, blk, 0, stream, c); }
+  int nw, cpw;
+  ti_geom(c.K, &nw, &cpw);
+  switch (nw * 100 + cpw) {
+    case 804: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 8, 4>), grid, dim3(512), 0, stream, c); break;
+    case 904: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 9, 4>), grid, dim3(576), 0, stream, c); break;
+    case 1203: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 12, 3>), grid, dim3(768), 0, stream, c); break;
+    case 1103: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 11, 3>), grid, dim3(704), 0, stream, c); break;
+    case 1603: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 16, 3>), grid, dim3(1024), 0, stream, c); break;
+    case 1602: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 16, 2>), grid, dim3(1024), 0, stream, c); break;
+    default: OS2S_LAUNCH((ti_lstm_kernel<FP8, 1, NT, 8, 5>), grid, dim3(512), 0, stream, c); break;
+  }
   return OS2S_OK;
+}
+
+template <bool FP8>
+static int ti_launch_lstm(hipStream_t stream, const TiLstm& c) {
+  return c.B <= 16 ? ti_launch_lstm_nt<FP8, 1>(stream, c) : ti_launch_lstm_nt<FP8, 2>(stream, c);
 }
 
 extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacotron_infer_t* x, int t_begin,
@@ -617,20 +813,22 @@ extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacot
   AdLoc lx;
   lx.e_part = d->loc_ws + (size_t)(d->loc_k + 1) * d->U;
   lx.dal = nullptr; lx.dcum_part = nullptr;
-  int ctx_parts = kLocCtxParts;
-  while (ctx_parts > 1 && M % (8 * ctx_parts)) ctx_parts >>= 1;
-  const int ncg = M / (8 * ctx_parts);
-  const int nsp = kTiCtxThreads / ncg < 32 ? kTiCtxThreads / ncg : 32;
-  if (ncg > 256) return OS2S_ERR_UNSUPPORTED;
-  const size_t lds_s = loc_fwd_lds_floats(H, d->S) * sizeof(float);
-  const size_t lds_c = std::max(((size_t)d->S + 32 + (size_t)nsp * ncg * 8) * sizeof(float),
-                                ti_tail_lds_floats(d->S, P, x->n_mel) * sizeof(float));
+  // context columns per part: 16-column MFMA tiles, up to two per wave with their operands requested up front.
+  // (parts + 1) * B workgroups should not exceed the CUs: two workgroups on one CU measured 12 us for the launch
+  // against 7.6 / 9.1 for the context / frame parts alone. OS2S_TI_CTX_PARTS overrides (experiments).
+  static const int parts_env = [] { const char* e = getenv("OS2S_TI_CTX_PARTS"); return e ? atoi(e) : 0; }();
+  int ctx_parts = parts_env > 0 ? parts_env : (B > 28 ? 4 : kLocCtxParts);
+  while (ctx_parts > 1 && M % (16 * ctx_parts)) ctx_parts >>= 1;
+  const int MQ = M / ctx_parts;
+  const size_t lds_s = ti_scores_lds_floats(d->S) * sizeof(float);
+  const size_t lds_c = ti_ctx_lds_floats(d->S, P, x->n_mel) * sizeof(float);
   TiTail q;
   q.P = P; q.n_mel = x->n_mel; q.mask_seq = x->mask_decoder_sequence; q.first = 0;
   { static const int dbg = [] { const char* e = getenv("OS2S_TI_DEBUG"); return e ? atoi(e) : 0; }(); q.dbg = dbg; }
   q.keep = x->prenet_keep; q.seed[0] = x->prenet_seed[0]; q.seed[1] = x->prenet_seed[1];
   q.wp1 = (const bf16_t*)x->wp1; q.bp1 = x->bp1; q.wp2 = (const bf16_t*)x->wp2; q.bp2 = x->bp2;
-  q.wout_h = (const bf16_t*)x->wout_h; q.pv = x->pv; q.bout = x->bout;
+  q.wout_h = (const bf16_t*)x->wout_h; q.pv_t = (const bf16_t*)x->pv_t; q.values_t = (const bf16_t*)x->values_t;
+  q.bout = x->bout;
   q.wstop = (const bf16_t*)x->wstop; q.bstop = x->bstop; q.mh = x->mh;
   q.x_seq = (bf16_t*)x->x_seq; q.mel = (bf16_t*)x->mel; q.stop = x->stop; q.state = x->state;
   if (t_begin == 0) {
@@ -640,8 +838,7 @@ extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacot
     TiTail q0 = q;
     q0.first = 1;
     at.t = 0;
-    OS2S_LAUNCH(ti_context_kernel, dim3(ctx_parts + 1, B), dim3(kTiCtxThreads), lds_c, stream, at, lx, q0, ctx_parts,
-                ncg, nsp);
+    OS2S_LAUNCH(ti_context_kernel, dim3(ctx_parts + 1, B), dim3(kTiCtxThreads), lds_c, stream, at, lx, q0, ctx_parts, MQ);
   }
   const bool fp8 = x->w0x8 != nullptr;
   for (int t = t_begin; t < t_end; ++t) {
@@ -672,8 +869,7 @@ extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacot
     }
     at.t = t;
     OS2S_LAUNCH(ti_scores_kernel, dim3(kLocParts + 1, B), dim3(kAttnThreads), lds_s, stream, at, lx, q);
-    OS2S_LAUNCH(ti_context_kernel, dim3(ctx_parts + 1, B), dim3(kTiCtxThreads), lds_c, stream, at, lx, q, ctx_parts,
-                ncg, nsp);
+    OS2S_LAUNCH(ti_context_kernel, dim3(ctx_parts + 1, B), dim3(kTiCtxThreads), lds_c, stream, at, lx, q, ctx_parts, MQ);
   }
   return OS2S_OK;
 }

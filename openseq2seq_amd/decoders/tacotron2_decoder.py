@@ -268,8 +268,15 @@ class Tacotron2Decoder(Decoder):
     if len(self.prenet) == 2 and os.environ.get("OS2S_TACOTRON_FUSED_DECODE", "1") != "0":
       w = dict(self._infer_weights(bool(getattr(cell, "fp8_weights", False))))
       values2d = enc_act.data.reshape(B * S, M)
-      # PV = values W_out[:, H:]^T: the context half of the frame projection, once per batch
-      w["pv"] = capi.gemm(values2d, w["wout_c"], out_f32=True).view(B, S, nm)
+      # once per batch: PV = values W_out[:, H:]^T (the context half of the frame projection commutes with the
+      # attention sum) and the transposed copies the step kernels' weighted sums read (positions contiguous,
+      # rows zero-padded to a multiple of 32)
+      Sp, nm16 = (S + 31) // 32 * 32, (nm + 15) // 16 * 16
+      pv = capi.gemm(values2d, w["wout_c"], out_f32=True).view(B, S, nm)
+      w["pv_t"] = torch.zeros((B, nm16, Sp), dtype=torch.bfloat16, device=dev)
+      w["pv_t"][:, :nm, :S] = pv.transpose(1, 2)
+      w["values_t"] = torch.zeros((B, M, Sp), dtype=torch.bfloat16, device=dev)
+      w["values_t"][:, :, :S] = enc_act.data.transpose(1, 2)
       loop.set_inputs(torch.zeros(8, dtype=torch.bfloat16, device=dev), keys, enc_act.data, src_len, None)
       fused = capi.TacotronInfer(loop, self.prenet[0].cout, nm, w, mask_seq, PRENET_KEEP, prenet_seeds)
       if not fused.supported():

@@ -171,15 +171,23 @@ def test_fused_decode_stop_token_and_lengths(cuda, monkeypatch):
       if bool(fin.all()):
         return t + 1, ln
     return None, ln
+  # (random weights give each sample a smooth logit trajectory: a rising one crosses zero once, at a step that
+  # differs between samples — the sign of the projection is chosen so that it rises)
+  b0 = float(dec.stop_proj.bias.master[0])
   best = None
-  for shift in torch.linspace(-float(probe.max()), -float(probe.min()), 400).tolist():
-    st, ln = rule(probe + shift)
-    if st is not None and 3 <= st <= 36 and len(set(ln.tolist())) >= 2:
-      margin = float((probe[:, :st] + shift).abs().min())
-      if best is None or margin > best[0]:
-        best = (margin, shift)
-  assert best is not None, "no stop bias gives a staggered finish"
+  for sign in (1.0, -1.0):
+    traj = sign * (probe - b0) + b0
+    for shift in torch.linspace(-float(traj.max()), -float(traj.min()), 400).tolist():
+      st, ln = rule(traj + shift)
+      if st is not None and 2 <= st <= 38 and len(set(ln.tolist())) >= 2:
+        margin = float((traj[:, :st] + shift).abs().min())
+        if best is None or margin > best[0]:
+          best = (margin, shift, sign)
+  assert best is not None, ("no stop projection gives a staggered finish", probe[:, :8])
   shift = best[1]
+  if best[2] < 0:
+    with torch.no_grad():
+      dec.stop_proj.kernel.master.mul_(-1.0)
   with torch.no_grad():
     dec.stop_proj.bias.master.add_(shift)
   store.refresh_compute_copies()
