@@ -600,6 +600,60 @@ def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
   return out
 
 
+def cpu_baseline_nmt(batch, vocab=32768, sentences=16, budget_s=20.0):
+  """BASELINE.json configs[0] (en-de-nmt-small, CPU fp32, world_size 1) as a timed CPU leg: the oracle port of the
+  model (oracle/nmt.py: 2 x bi-LSTM-512 encoder, GNMT-v2 attention decoder, 32 k softmax, BasicSequenceLoss) +
+  torch Adam, forward + backward + update on the first `sentences` sentence pairs of the synthetic batch the GPU
+  leg ran (a bounded sample: the full batch of 128 is about 8 x the work). TensorFlow — the reference's own CPU
+  path — is not importable on the bench host (tensorflow_probe)."""
+  from oracle import nmt as onmt
+  torch.manual_seed(0)
+  n = sentences
+  src, sl = batch['source_tensors'][0][:n].cpu(), batch['source_tensors'][1][:n].cpu()
+  tgt, tl = batch['target_tensors'][0][:n].cpu(), batch['target_tensors'][1][:n].cpu()
+  src, tgt = src[:, :int(sl.max())], tgt[:, :int(tl.max())]
+  H, E, U, M, V = 512, 512, 512, 1024, vocab
+  leaves = []
+
+  def w(*shape):
+    t = (torch.rand(*shape) * 2 - 1) * (6.0 / (shape[0] + shape[-1])) ** 0.5
+    t.requires_grad_(True)
+    leaves.append(t)
+    return t
+
+  def lstm(inp):
+    return dict(wx=w(4 * H, inp), wh=w(4 * H, H), b=w(4 * H))
+  P = {"emb": w(V, E), "fw": [lstm(E), lstm(H)], "bw": [lstm(E), lstm(H)]}
+  cell = dict(wcat=[w(4 * H, M + H)], bias=[None], wq=w(U, H), wmem=w(U, M), v=w(U), g=w(1), b=w(U),
+              w_in=w(4 * H, E), b0=w(4 * H))
+  D = {"demb": w(V, E), "cell": cell,
+       "upper": [dict(wx_h=w(4 * H, H), wx_a=w(4 * H, M), wh=w(4 * H, H), b=w(4 * H))], "proj": w(V, H)}
+  opt = torch.optim.Adam(leaves, lr=1e-3)
+  torch.set_num_threads(os.cpu_count() or 1)
+
+  def step():
+    opt.zero_grad()
+    enc = onmt.encoder(P, src, sl)
+    logits = onmt.decoder_logits(D, enc, sl, tgt, tl, "gnmt_v2")
+    loss = onmt.basic_sequence_loss(logits, tgt, tl, n)
+    loss.backward()
+    opt.step()
+    return float(loss.detach())
+  step()
+  t0 = time.perf_counter()
+  k = 0
+  while k < 3 or (time.perf_counter() - t0 < budget_s and k < 10):
+    step()
+    k += 1
+  dt = (time.perf_counter() - t0) / k
+  toks = float(sl.sum() + tl.sum())
+  probe = tensorflow_probe()
+  return {"value": toks / dt, "unit": "tokens/sec", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "en-de-nmt-small oracle train step (oracle/nmt.py fp32 torch-CPU + torch Adam) on the first %d "
+                    "sentence pairs of the GPU leg's batch (%d tokens), %d timed steps of %.2f s" % (n, toks, k, dt),
+          "tensorflow": probe.get("tensorflow"), "reason": probe.get("reason")}
+
+
 def bench_frontend(dev, batch_size, seed=1234, reps=20):
   """The log-mel front end (get_speech_features_librosa, speech_utils.py:322-441) as
   its own timed stage: int16 PCM of the bench batch's durations resident in HBM -> normalised
@@ -706,7 +760,7 @@ def bench_transformer(args, hvd, dev, rank, world):
   return res
 
 
-def bench_simple(spec, steps, warmup, hvd, dev, rank, world, roofline_key=None):
+def bench_simple(spec, steps, warmup, hvd, dev, rank, world, roofline_key=None, cpu_leg=False):
   """One model of BASELINE.json's other configs: K timed train steps on a synthetic batch."""
   import importlib
   mod, fn, kw, metric, count_key, unit = spec
@@ -731,6 +785,11 @@ def bench_simple(spec, steps, warmup, hvd, dev, rank, world, roofline_key=None):
       res["roofline"] = other_config_roofline(roofline_key, model, batch, res)
     except Exception as e:      # a diagnostic must not lose the measurement
       res["roofline"] = {"error": repr(e)}
+  if roofline_key == "nmt" and cpu_leg:
+    try:
+      res["cpu_baseline"] = cpu_baseline_nmt(batch)
+    except Exception as e:
+      res["cpu_baseline"] = {"value": None, "unit": "tokens/sec", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
   del model
   torch.cuda.empty_cache()
   return res
@@ -919,7 +978,8 @@ def main():
   for key, flag in (("quartznet", args.only_quartznet), ("tacotron", args.only_tacotron),
                     ("ds2", args.only_ds2), ("nmt", args.only_nmt)):
     if flag:
-      res = bench_simple(simple[key], args.steps, args.warmup, hvd, dev, rank, world, roofline_key=key)
+      res = bench_simple(simple[key], args.steps, args.warmup, hvd, dev, rank, world, roofline_key=key,
+                         cpu_leg=not args.no_cpu_baseline)
       if rank == 0:
         print(json.dumps(res))
       return
@@ -1055,9 +1115,6 @@ def main():
                              "share_of_timed_ms": t / max(ms, 1e-9)}
                       for name, (c, t, f) in timer.by_kernel.items()},
         "rest_of_step": breakdown,
-        "sustained_mfma_peak_note": "a loop of nothing but v_mfma_f32_32x32x16_bf16 on every SIMD reaches "
-                                    "1.93-2.07 PFLOP/s on this chip (1.9 GHz under MFMA load; "
-                                    "profiles/r02_mfma_issue_probe.txt); `peak` is the 2.4 GHz data-sheet figure",
         "note": "achieved = FLOPs of the executed (non-skipped) time tiles / HIP-event time; "
                 "tiles whose input window is all padding are exact zeros and are not multiplied. "
                 "The data-gradient launches of the same kernel run concurrently with the "
@@ -1083,7 +1140,8 @@ def main():
     others = {}
     for key in ("nmt", "ds2", "tacotron", "quartznet"):
       try:
-        others[key] = bench_simple(simple[key], 6, 3, hvd, dev, rank, world, roofline_key=key)
+        others[key] = bench_simple(simple[key], 6, 3, hvd, dev, rank, world, roofline_key=key,
+                                   cpu_leg=not args.no_cpu_baseline)
       except Exception as e:   # never lose the headline line to a secondary measurement
         others[key] = {"error": repr(e)}
     try:
