@@ -66,6 +66,7 @@ def parse():
                   help="Tacotron2 with bf16 decoder weights (default: e4m3 copies, BASELINE configs[4])")
   ap.add_argument("--only-ds2", action="store_true",
                   help="run only the DeepSpeech2-large train step (BASELINE configs[2])")
+  ap.add_argument("--only-frontend", action="store_true", help="profiling aid: the log-mel front end only")
   ap.add_argument("--only-transformer", action="store_true",
                   help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
@@ -693,11 +694,13 @@ def bench_frontend(dev, batch_size, seed=1234, reps=20):
     return ms, nframes, int(bs * feats.shape[1]), algo
 
   ms, nframes, padded, algo = run(batch_size)
+  traffic, traffic_src = committed_pmc_traffic("frontend")
   out = {"metric": "audio-frames/sec log-mel front end (int16 PCM -> normalised bf16 features)",
          "value": nframes / (ms * 1e-3), "unit": "frames/sec", "ms_per_batch": ms,
          "frames_per_batch": nframes, "padded_frames": padded,
          "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": 8000.0,
-                      "unit": "GB/s", "frac": algo / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                      "unit": "GB/s", "frac": algo / (ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
+                      "traffic_source": traffic_src, "traffic_unit": "HBM bytes per batch (all launches of the stage)",
                       "algorithmic_bytes": algo,
                       "note": "launch-bound at the bench batch (3 launches, 31 MB); see `saturated`"}}
   try:
@@ -751,7 +754,9 @@ def bench_transformer(args, hvd, dev, rank, world):
       "roofline": {"bound": "mfma", "kernel": "whole train step (the in-tree MFMA GEMMs dominate: gemm_pp_kernel, "
                              "conv1d_wgrad1x1_pp_kernel; no vendor GEMM in the product library)",
                    "achieved": 0.629e-3 * tps, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                   "frac": 0.629e-3 * tps / BF16_DENSE_PEAK_TFLOPS, "traffic": None},
+                   "frac": 0.629e-3 * tps / BF16_DENSE_PEAK_TFLOPS, "traffic": committed_pmc_traffic("transformer")[0],
+                   "traffic_source": committed_pmc_traffic("transformer")[1],
+                   "traffic_unit": "HBM bytes per gemm_pp_kernel launch (FETCH_SIZE x 2 + WRITE_SIZE, committed PMC pass)"},
       "params_M": model.store.num_trainable() / 1e6,
       "loss": float(loss.cpu()[0]), "skipped_steps": st["num_skipped"],
   }
@@ -889,14 +894,15 @@ def bench_tacotron_decode(dev, style=True, fp8=True, batch=32, steps=1000, reps=
   return res
 
 
-def committed_pmc_traffic():
-  """HBM bytes per launch of the dominant kernel from the committed PMC pass of this workload
-  (tools/pmc_bench_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction
-  applied). Counters cannot be collected inside the timed run, so the JSON line carries the
-  number of the newest profiles/*_pmc_bench_traffic.json, or null if there is none."""
+def committed_pmc_traffic(kind="bench"):
+  """HBM bytes per launch of a configuration's dominant kernel from the committed PMC pass of the same command
+  (tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied). Counters cannot
+  be collected inside the timed run, so the JSON line carries the number of the newest
+  profiles/*_pmc_<kind>_traffic.json (kind: bench = Jasper conv kernels, transformer = gemm_pp_kernel,
+  frontend = the log-mel kernels per batch), or null if there is none."""
   import glob
   here = os.path.dirname(os.path.abspath(__file__))
-  files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_bench_traffic.json")))
+  files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_%s_traffic.json" % kind)))
   if not files:
     return None, None
   try:
@@ -986,6 +992,10 @@ def main():
   if args.only_transformer_infer:
     if rank == 0:
       print(json.dumps(bench_transformer_infer(dev)))
+    return
+  if args.only_frontend:
+    if rank == 0:
+      print(json.dumps(bench_frontend(dev, args.batch)))
     return
   if args.only_tacotron_decode:
     if rank == 0:
