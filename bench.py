@@ -67,6 +67,7 @@ def parse():
   ap.add_argument("--only-ds2", action="store_true",
                   help="run only the DeepSpeech2-large train step (BASELINE configs[2])")
   ap.add_argument("--only-frontend", action="store_true", help="profiling aid: the log-mel front end only")
+  ap.add_argument("--cpu-nmt-leg", default=None, help=argparse.SUPPRESS)     # child process of cpu_baseline_nmt_guarded
   ap.add_argument("--only-transformer", action="store_true",
                   help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
@@ -630,7 +631,9 @@ def cpu_baseline_nmt(batch, vocab=32768, sentences=16, budget_s=20.0):
   D = {"demb": w(V, E), "cell": cell,
        "upper": [dict(wx_h=w(4 * H, H), wx_a=w(4 * H, M), wh=w(4 * H, H), b=w(4 * H))], "proj": w(V, H)}
   opt = torch.optim.Adam(leaves, lr=1e-3)
-  torch.set_num_threads(os.cpu_count() or 1)
+  # hundreds of small sequential ops per step: more threads than this only add barrier time (with every core of a
+  # 2-socket host the step did not finish in 10 minutes)
+  torch.set_num_threads(min(os.cpu_count() or 1, 16))
 
   def step():
     opt.zero_grad()
@@ -653,6 +656,27 @@ def cpu_baseline_nmt(batch, vocab=32768, sentences=16, budget_s=20.0):
           "sample": "en-de-nmt-small oracle train step (oracle/nmt.py fp32 torch-CPU + torch Adam) on the first %d "
                     "sentence pairs of the GPU leg's batch (%d tokens), %d timed steps of %.2f s" % (n, toks, k, dt),
           "tensorflow": probe.get("tensorflow"), "reason": probe.get("reason")}
+
+
+def cpu_baseline_nmt_guarded(batch, limit_s=120):
+  """cpu_baseline_nmt in a child process with a hard time limit: a CPU leg must never cost the bench line."""
+  import subprocess
+  import tempfile
+  fail = lambda why: {"value": None, "unit": "tokens/sec", "cores": 0, "kind": "port", "sample": "failed: " + why}
+  try:
+    with tempfile.TemporaryDirectory() as d:
+      f = os.path.join(d, "batch.pt")
+      torch.save({"source_tensors": [t[:16].cpu() for t in batch["source_tensors"][:2]],
+                  "target_tensors": [t[:16].cpu() for t in batch["target_tensors"][:2]]}, f)
+      env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+      r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-nmt-leg", f], capture_output=True, text=True,
+                         timeout=limit_s, env=env)
+      lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+      return json.loads(lines[-1]) if lines else fail("no output (rc %d): %s" % (r.returncode, r.stderr[-200:]))
+  except subprocess.TimeoutExpired:
+    return fail("time limit of %d s" % limit_s)
+  except Exception as e:
+    return fail(repr(e))
 
 
 def bench_frontend(dev, batch_size, seed=1234, reps=20):
@@ -791,10 +815,7 @@ def bench_simple(spec, steps, warmup, hvd, dev, rank, world, roofline_key=None, 
     except Exception as e:      # a diagnostic must not lose the measurement
       res["roofline"] = {"error": repr(e)}
   if roofline_key == "nmt" and cpu_leg:
-    try:
-      res["cpu_baseline"] = cpu_baseline_nmt(batch)
-    except Exception as e:
-      res["cpu_baseline"] = {"value": None, "unit": "tokens/sec", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    res["cpu_baseline"] = cpu_baseline_nmt_guarded(batch)
   del model
   torch.cuda.empty_cache()
   return res
@@ -943,6 +964,9 @@ def launcher_dry_run(args, hvd, rank, world):
 
 def main():
   args = parse()
+  if args.cpu_nmt_leg:
+    print(json.dumps(cpu_baseline_nmt(torch.load(args.cpu_nmt_leg))))
+    return
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(spawn_ranks(args.gpus))      # one process per GPU; this process only waits for them
   from openseq2seq_amd.utils import distributed as dist_utils
