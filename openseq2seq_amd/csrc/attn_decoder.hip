@@ -1874,6 +1874,11 @@ static void ad_fill_attn(const os2s_attn_decoder_t* d, AdAttn& a) {
   a.dwck_acc = nullptr; a.last = 0; a.dctx_bs = a.dctx_ts = 0;
 }
 
+namespace os2s { struct TiLstm; }
+static bool ad_fast_cells(const os2s_attn_decoder_t* d);
+static int ad_launch_fast_cell(hipStream_t stream, const os2s_attn_decoder_t* d, int l, int t);
+static int ad_launch_fast_scores(hipStream_t stream, const os2s::AdAttn& at, const os2s::AdLoc& lx, const os2s_attn_decoder_t* d);
+
 extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_decoder_t* d) {
   const int rc = ad_check(d);
   if (rc != OS2S_OK) return rc;
@@ -1903,8 +1908,14 @@ extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_deco
   const size_t lds_c = ((size_t)d->S + 8 + (size_t)nsp * ncg * 8) * sizeof(float);
   if (split && ncg > 256) return OS2S_ERR_UNSUPPORTED;
   dim3 cgrid(ceil_div(H, 8), ceil_div(B, 32));
+  const bool fast = split && ad_fast_cells(d);
   for (int t = d->t_begin; t < d->t_end; ++t) {
     for (int l = 0; l < L; ++l) {
+      if (fast) {
+        const int r2 = ad_launch_fast_cell(stream, d, l, t);
+        if (r2 != OS2S_OK) return r2;
+        continue;
+      }
       AdCellFwd c;
       c.B = B; c.T = T; c.H = H; c.t = t; c.forget_bias = d->forget_bias; c.lens = d->tgt_len;
       c.Kc = l == 0 ? M + H : 2 * H;
@@ -1921,7 +1932,12 @@ extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_deco
     }
     at.t = t;
     if (split) {
-      OS2S_LAUNCH(ad_loc_scores_kernel, dim3(kLocParts, B), dim3(kAttnThreads), lds_s, stream, at, lx);
+      if (fast) {
+        const int r2 = ad_launch_fast_scores(stream, at, lx, d);
+        if (r2 != OS2S_OK) return r2;
+      } else {
+        OS2S_LAUNCH(ad_loc_scores_kernel, dim3(kLocParts, B), dim3(kAttnThreads), lds_s, stream, at, lx);
+      }
       OS2S_LAUNCH(ad_loc_context_kernel, dim3(ctx_parts, B), dim3(256), lds_c, stream, at, lx, ncg, nsp);
     } else {
       OS2S_LAUNCH(ad_attn_fwd_kernel, dim3(B), dim3(kAttnThreads), lds, stream, at);

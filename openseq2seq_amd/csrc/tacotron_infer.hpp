@@ -54,8 +54,12 @@ struct TiLstm {
   const float* c_prev; long long ldc_prev;   // row b at c_prev + b * ldc_prev, or null (zeros)
   float* c_out; long long ldc_out;
   bf16_t* h1; long long ldh1;        // h destinations (row b at h + b * ld; either may be null)
-  bf16_t* h2; long long ldh2;
-  const int32_t* state;              // state[1] != 0: decoding has ended
+  bf16_t* h2; long long ldh2;        //   h2 takes the output dropout (training: the cell's OUTPUT, not its state)
+  const int32_t* state;              // state[1] != 0: decoding has ended (null: no stop flag — the training pass)
+  // training pass (os2s_attn_decoder_fwd): input projection of the step, saved gates, output dropout
+  const bf16_t* gx; long long ldgx;  // row b: gx + b * ldgx, [4H] (or null)
+  bf16_t* gates; long long ldgates;  // row b: gates + b * ldgates, [4H] = i, f, g, o activations (or null)
+  float out_keep; unsigned long long out_seed; long long drop_t, drop_T;   // element index ((b * T + t) * H + j)
 };
 
 // rows of a 16-row tile: r = 4 * unit + gate, so that after the MFMA (acc[i] = row 4 * (lane >> 4) + i,
@@ -64,7 +68,7 @@ struct TiLstm {
 template <bool FP8, int MT, int NT, int kTiWaves, int kTiCpw>
 __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
   __shared__ float red[kTiWaves * MT * NT * 4 * 64];
-  const int done = p.state[1];         // consumed after the loads are in flight
+  const int done = p.state ? p.state[1] : 0;     // consumed after the loads are in flight
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // an SGPR: the chunk tests below are scalar
   const int r = lane & 15, q = lane >> 4;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
   const int e_mt = wave / NT, e_nt = wave % NT, e_u = 4 * e_mt + (lane >> 4), e_n = lane & 15;
   const int e_b = e_nt * 16 + e_n, e_j = j0 + e_u;
   const bool e_live = wave < MT * NT && e_b < p.B && e_j < H;
-  float e_sc[4], e_bias[4], e_c;
+  float e_sc[4], e_bias[4], e_c, e_gx[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const int cj = min(e_j, H - 1), cb = min(e_b, p.B - 1);
     const float* scp = FP8 ? p.scale : p.c_out;            // any readable fp32 array of >= 4H elements
@@ -84,6 +88,10 @@ __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
     for (int g = 0; g < 4; ++g) {
       e_sc[g] = scp[g * H + cj];
       e_bias[g] = bip[g * H + cj];
+    }
+    if (p.gx) {                                              // uniform branch; its loads join the same round
+#pragma unroll
+      for (int g = 0; g < 4; ++g) e_gx[g] = bf2f(p.gx[(long long)cb * p.ldgx + g * H + cj]);
     }
     e_c = (p.c_prev ? p.c_prev : p.c_out)[(long long)cb * (p.c_prev ? p.ldc_prev : p.ldc_out) + cj];
 #pragma unroll
@@ -190,17 +198,26 @@ __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < kTiWaves; ++w) s += red[(((w * MT + e_mt) * NT + e_nt) * 4 + g) * 64 + lane];
-    pre[g] = s * e_sc[g] + e_bias[g];
+    pre[g] = s * e_sc[g] + e_bias[g] + e_gx[g];
   }
   // (tanh through one exp + one reciprocal: the library tanhf is several hundred bytes of code per call, and the
   // code a step kernel executes IS its latency, see "score launch" below; |error| ~1e-7 against bf16 outputs)
   const float ig = sigmoidf_(pre[0]), gg = tanh_fast(pre[1]);
   const float fg = sigmoidf_(pre[2] + p.forget_bias), og = sigmoidf_(pre[3]);
   const float cn = e_c * fg + ig * gg;
-  const bf16_t hn = f2bf(tanh_fast(cn) * og);
+  float hv = tanh_fast(cn) * og;
   p.c_out[(long long)e_b * p.ldc_out + e_j] = cn;
-  if (p.h1) p.h1[(long long)e_b * p.ldh1 + e_j] = hn;
-  if (p.h2) p.h2[(long long)e_b * p.ldh2 + e_j] = hn;
+  if (p.gates) {
+    bf16_t* gp = p.gates + (long long)e_b * p.ldgates + e_j;
+    gp[0] = f2bf(ig); gp[H] = f2bf(fg); gp[2 * H] = f2bf(gg); gp[3 * H] = f2bf(og);
+  }
+  if (p.h1) p.h1[(long long)e_b * p.ldh1 + e_j] = f2bf(hv);
+  if (p.out_keep < 1.f) {
+    const unsigned long long idx = ((unsigned long long)e_b * p.drop_T + p.drop_t) * H + e_j;
+    const uint32_t bits = dropout_bits8(p.out_seed, idx >> 3, p.out_keep);
+    hv = ((bits >> (e_j & 7)) & 1u) ? hv / p.out_keep : 0.f;
+  }
+  if (p.h2) p.h2[(long long)e_b * p.ldh2 + e_j] = f2bf(hv);
 }
 
 typedef __attribute__((ext_vector_type(2))) __bf16 ti_bf2;
@@ -800,6 +817,13 @@ static int ti_launch_lstm(hipStream_t stream, const TiLstm& c) {
   return c.B <= 16 ? ti_launch_lstm_nt<FP8, 1>(stream, c) : ti_launch_lstm_nt<FP8, 2>(stream, c);
 }
 
+// the training pass's cell launch (os2s_attn_decoder_fwd) on the same kernel: returns false when the shape is not
+// covered (the caller keeps ad_cell_fwd_kernel)
+static bool ti_cell_supported(int B, int H, int Kc) { return B <= 32 && H % 4 == 0 && Kc % 64 == 0; }
+static int ti_launch_cell(hipStream_t stream, const TiLstm& c, bool fp8) {
+  return fp8 ? ti_launch_lstm<true>(stream, c) : ti_launch_lstm<false>(stream, c);
+}
+
 extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacotron_infer_t* x, int t_begin,
                                          int t_end) {
   const int rc = ti_check(x);
@@ -845,6 +869,7 @@ extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacot
     for (int l = 0; l < L; ++l) {
       TiLstm c;
       c.B = B; c.H = H; c.forget_bias = d->forget_bias; c.state = x->state;
+      c.gx = nullptr; c.ldgx = 0; c.gates = nullptr; c.ldgates = 0; c.out_keep = 1.f; c.out_seed = 0; c.drop_t = 0; c.drop_T = 0;
       if (l == 0) {
         c.K = P + M + H; c.Ka = P;
         c.in_a = (const bf16_t*)x->x_seq + (long long)t * P; c.lda = (long long)(T + 1) * P;
@@ -871,5 +896,56 @@ extern "C" int os2s_tacotron_infer_steps(os2s_stream_t stream_, const os2s_tacot
     OS2S_LAUNCH(ti_scores_kernel, dim3(kLocParts + 1, B), dim3(kAttnThreads), lds_s, stream, at, lx, q);
     OS2S_LAUNCH(ti_context_kernel, dim3(ctx_parts + 1, B), dim3(kTiCtxThreads), lds_c, stream, at, lx, q, ctx_parts, MQ);
   }
+  return OS2S_OK;
+}
+
+// ---- the training pass on the small-code kernels -------------------------------------------------------------
+// os2s_attn_decoder_fwd (location-sensitive mode, no per-sample target lengths, B <= 32) launches ti_lstm_kernel
+// for the cells (+ input projection of the step, saved gates, output dropout) and ti_scores_part for the scores:
+// 13.3 -> ~8.7 us per cell launch and 10.4 -> ~6.5 us per score launch of a Tacotron2 decoder step. OS2S_AD_FAST=0
+// keeps the round-3 kernels.
+namespace os2s {
+__global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_mfma_kernel(AdAttn p, AdLoc x) {
+  extern __shared__ float lds_raw[];
+  ti_scores_part(p, x, lds_raw);
+}
+}  // namespace os2s
+
+static bool ad_fast_cells(const os2s_attn_decoder_t* d) {
+  static const int on = [] { const char* e = getenv("OS2S_AD_FAST"); return e ? atoi(e) : 1; }();
+  if (!on || d->tgt_len || d->score_mode != 2 || d->B > 32 || d->H > 1024 || d->H % 64 || d->M % 64 || d->loc_k > 32)
+    return false;
+  if (ti_scores_lds_floats(d->S) * sizeof(float) > 64 * 1024) return false;
+  for (int l = 0; l < d->L; ++l)
+    if (!ti_cell_supported(d->B, d->H, l == 0 ? d->M + d->H : 2 * d->H)) return false;
+  return true;
+}
+
+static int ad_launch_fast_cell(hipStream_t stream, const os2s_attn_decoder_t* d, int l, int t) {
+  const int B = d->B, T = d->T, H = d->H, M = d->M, L = d->L;
+  const int Kc = l == 0 ? M + H : 2 * H;
+  TiLstm c;
+  c.B = B; c.H = H; c.K = Kc; c.Ka = 0; c.in_a = nullptr; c.lda = 0;
+  c.in_b = (const bf16_t*)d->cat[l] + (long long)t * Kc; c.ldb = (long long)(T + 1) * Kc;
+  const bool fp8 = d->wcat8[l] != nullptr;
+  if (fp8 && !d->wcat8_scale[l]) return OS2S_ERR_INVALID_ARG;
+  c.w = fp8 ? (const void*)d->wcat8[l] : (const void*)d->wcat[l]; c.scale = d->wcat8_scale[l]; c.bias = d->bias[l];
+  c.forget_bias = d->forget_bias;
+  c.c_prev = t > 0 ? d->c_seq[l] + (long long)(t - 1) * H : nullptr; c.ldc_prev = (long long)T * H;
+  c.c_out = d->c_seq[l] + (long long)t * H; c.ldc_out = (long long)T * H;
+  c.h1 = (bf16_t*)d->cat[l] + (long long)(t + 1) * Kc + (l == 0 ? M : H); c.ldh1 = (long long)(T + 1) * Kc;
+  if (l == L - 1) { c.h2 = (bf16_t*)d->y_top + (long long)t * d->y_top_ts; c.ldh2 = d->y_top_bs; }
+  else { c.h2 = (bf16_t*)d->cat[l + 1] + (long long)t * 2 * H; c.ldh2 = (long long)(T + 1) * 2 * H; }
+  c.state = nullptr;
+  c.gx = l == 0 ? (const bf16_t*)d->gx0 + (long long)t * 4 * H : nullptr; c.ldgx = (long long)T * 4 * H;
+  c.gates = d->gates[l] ? (bf16_t*)d->gates[l] + (long long)t * 4 * H : nullptr; c.ldgates = (long long)T * 4 * H;
+  c.out_keep = d->out_keep; c.out_seed = d->out_seed[l]; c.drop_t = t; c.drop_T = T;
+  return ti_launch_cell(stream, c, fp8);
+}
+
+static int ad_launch_fast_scores(hipStream_t stream, const os2s::AdAttn& at, const os2s::AdLoc& lx,
+                                 const os2s_attn_decoder_t* d) {
+  const size_t lds = ti_scores_lds_floats(d->S) * sizeof(float);
+  OS2S_LAUNCH(ad_loc_scores_mfma_kernel, dim3(kLocParts, d->B), dim3(kAttnThreads), lds, stream, at, lx);
   return OS2S_OK;
 }
