@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64 * kTiWaves) void ti_lstm_kernel(TiLstm p) {
   float e_sc[4], e_bias[4], e_c, e_gx[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const int cj = min(e_j, H - 1), cb = min(e_b, p.B - 1);
-    const float* scp = FP8 ? p.scale : p.c_out;            // any readable fp32 array of >= 4H elements
+    // (placeholders for absent operands: any readable 16 H bytes — the weight matrix itself)
+    const float* scp = FP8 ? p.scale : reinterpret_cast<const float*>(p.w);
     const float* bip = p.bias ? p.bias : scp;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

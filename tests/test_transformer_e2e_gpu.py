@@ -179,6 +179,28 @@ def test_transformer_big_full_size_fwd_bwd(cuda):
   _fwd_bwd(cuda, BIG, B=32, Lmax=56, tol=dict(loss=1e-2, logits=2e-2, cos=0.995, rel=0.1))
 
 
+def test_transformer_base_width_groups_weight_gradients_by_row_count(cuda, monkeypatch):
+  """d_model 512 (transformer-base width) with >= 2048 source AND >= 2048 target tokens of different counts: every
+  512-wide Dense weight gradient is 'small' (< 32 output tiles), so Tape.defer_wgrad collects them — including the
+  enc-dec attention's k/v projection, whose rows are the SOURCE tokens, among target-row layers. One grouped launch
+  has one row count (os2s_gemm_wgrad_grouped takes a single M): groups must be cut where the row count changes
+  (before the fix this configuration asserted in the first backward pass). Parity vs the oracle as
+  in the small test; asserts both row counts went through grouped launches and no group mixed them."""
+  from openseq2seq_amd import capi
+  groups = []
+  orig = capi.gemm_wgrad_grouped
+
+  def recording(items, **kw):
+    groups.append([int(it["x"].shape[0]) for it in items])
+    return orig(items, **kw)
+  monkeypatch.setattr(capi, "gemm_wgrad_grouped", recording)
+  _fwd_bwd(cuda, SMALL, B=160, Lmax=28, tol=dict(loss=2e-2, logits=3e-2, cos=0.98, rel=0.2))
+  assert groups, "no grouped weight-gradient launch ran"
+  assert all(len(set(g)) == 1 for g in groups), groups
+  rows = {g[0] for g in groups}
+  assert len(rows) == 2 and min(rows) >= 2048, rows
+
+
 def test_transformer_small_trains(cuda):
   from openseq2seq_amd.parts.cnns.conv_blocks import Tape
   from openseq2seq_amd.parts.transformer.layers import SeedSeq
