@@ -1878,6 +1878,8 @@ namespace os2s { struct TiLstm; }
 static bool ad_fast_cells(const os2s_attn_decoder_t* d);
 static int ad_launch_fast_cell(hipStream_t stream, const os2s_attn_decoder_t* d, int l, int t);
 static int ad_launch_fast_scores(hipStream_t stream, const os2s::AdAttn& at, const os2s::AdLoc& lx, const os2s_attn_decoder_t* d);
+static bool ad_fast_score_bwd(const os2s_attn_decoder_t* d);
+static int ad_launch_fast_score_bwd(hipStream_t stream, const os2s::AdAttn& at, const os2s::AdLoc& lx, const os2s_attn_decoder_t* d);
 
 extern "C" int os2s_attn_decoder_fwd(os2s_stream_t stream_, const os2s_attn_decoder_t* d) {
   const int rc = ad_check(d);
@@ -2036,6 +2038,7 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
   at.dwck_acc = dwck_acc;
   const long long GH = 4LL * H;
   dim3 cgrid(ceil_div(H, kCellBwdRows), ceil_div(B, kCellBwdCols));
+  const bool fast_sb = split && ad_fast_score_bwd(d);
   for (int t = T - 1; t >= 0; --t) {
     const int last = (t == T - 1);
     if (!last) {
@@ -2054,7 +2057,12 @@ extern "C" int os2s_attn_decoder_bwd(os2s_stream_t stream_, const os2s_attn_deco
     at.t = t; at.last = last;
     if (split) {
       OS2S_LAUNCH(ad_loc_dalign_kernel, dim3(kLocCtxParts, B), dim3(256), lds_da, stream, at, lx);
-      OS2S_LAUNCH(ad_loc_score_bwd_kernel, dim3(kLocParts, B), dim3(kAttnThreads), lds_sb, stream, at, lx);
+      if (fast_sb) {
+        const int r2 = ad_launch_fast_score_bwd(stream, at, lx, d);
+        if (r2 != OS2S_OK) return r2;
+      } else {
+        OS2S_LAUNCH(ad_loc_score_bwd_kernel, dim3(kLocParts, B), dim3(kAttnThreads), lds_sb, stream, at, lx);
+      }
     } else if (d->score_mode == 2) { OS2S_LAUNCH(ad_attn_bwd_kernel<true>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
     else { OS2S_LAUNCH(ad_attn_bwd_kernel<false>, dim3(B), dim3(kAttnThreads), lds, stream, at); }
     for (int l = L - 1; l >= 0; --l) {

@@ -912,6 +912,227 @@ __global__ __launch_bounds__(kAttnThreads) void ad_loc_scores_mfma_kernel(AdAttn
 }
 }  // namespace os2s
 
+// ---- score gradient of the location-sensitive attention on the matrix cores ------------------------------------
+// ad_loc_score_bwd_kernel's arithmetic (softmax backward, score gradient of one 32-unit part of one sample) with its
+// 36 KB of unrolled register-window code replaced by four small MFMA products:
+//   x[s,u]     = keys + q + bias + sum_k cum[s+k-p] Wck[k,u]            (as the forward: A = Toeplitz rows of cum)
+//   d0[s,u]    = de[s] v[u] (1 - tanh^2 x)                               -> dpre_seq (bf16), dq = sum_s d0, dv += sum_s de tanh x
+//   dWck[k,u] += sum_s cum[s+k-p] d0[s,u]        A = Toeplitz COLUMNS of cum (taps x positions), B = d0^T[u][s]
+//   G[s,k]     = sum_u d0[s,u] Wck[k,u]          A = d0[s][u], B = Wck;   dcum[c] = sum_k G[c + p - k][k]
+// every operand bf16 hi + lo (three MFMAs per product). Waves 0-3 own the four 16x16 tiles of dWck over all
+// positions, waves 4-7 the position tiles of G: no cross-wave sums, fixed summation order (deterministic).
+namespace os2s {
+constexpr int kSbD0sPitch = 40;                      // bf16 elements per position row of d0[s][u]
+__host__ __device__ inline size_t ad_score_bwd_mfma_lds_floats(int S) {
+  const size_t Sp = ((size_t)S + 31) & ~(size_t)31;
+  return 64 + (Sp + 48) + 3 * Sp + Sp * kLocUnits / 2 + Sp * kSbD0sPitch + (size_t)kLocUnits * (Sp + 8) +
+         Sp * 33 + 2 * (size_t)kAttnWaves * 4 * kLocUnits + 64;
+}
+
+__global__ __launch_bounds__(kAttnThreads) void ad_loc_score_bwd_mfma_kernel(AdAttn p, AdLoc x) {
+  extern __shared__ float lds_raw[];
+  const int part = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int U = p.U, S = p.S, K = p.loc_k;
+  const int Sp = (S + 31) & ~31, TP = Sp + 8;
+  float* qb = lds_raw;                               // [32]
+  float* nv = qb + kLocUnits;                        // [32]
+  float* cum = nv + kLocUnits;                       // [Sp + 48] zero padded, cum[i] = cumulative[i - padl]
+  float* de = cum + Sp + 48;                         // [Sp] softmax-backward of the alignments, zero past the length
+  float* ea = de + Sp;                               // [Sp] alignments   (scratch of the preamble)
+  float* da = ea + Sp;                               // [Sp] d(alignment)
+  uint16_t* keys = reinterpret_cast<uint16_t*>(da + Sp);                    // [Sp][32] bf16
+  uint16_t* d0s_hi = keys + (size_t)Sp * kLocUnits;                         // [Sp][40] bf16: d0[s][u]
+  uint16_t* d0s_lo = d0s_hi + (size_t)Sp * kSbD0sPitch;
+  uint16_t* d0t_hi = d0s_lo + (size_t)Sp * kSbD0sPitch;                     // [32][Sp + 8] bf16: d0^T[u][s]
+  uint16_t* d0t_lo = d0t_hi + (size_t)kLocUnits * TP;
+  float* G = reinterpret_cast<float*>(d0t_lo + (size_t)kLocUnits * TP);     // [Sp][33]
+  float* pq = G + (size_t)Sp * 33;                   // [waves][4][32] partial dq
+  float* pn = pq + kAttnWaves * 4 * kLocUnits;       // [waves][4][32] partial dv terms
+  float* red = pn + kAttnWaves * 4 * kLocUnits;      // [64]
+  const int slen = min(max(p.src_len[b], 0), S);
+  const int u0 = part * kLocUnits;
+  const long long row = (long long)b * p.T + p.t;
+  const int padl = (K - 1) / 2;
+  const int r16 = lane & 15, kb = lane >> 4;
+  // the folded location filter: forward B operand (taps x units) ...
+  float wf[2][8];
+#pragma unroll
+  for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[ut][j] = p.wck[(long long)min(kb * 8 + j, K - 1) * U + u0 + ut * 16 + r16];
+  // ... and as the B operand of G (units x taps): tap = nt * 16 + r16, units kb * 8 ... + 8 (contiguous)
+  float wg[2][8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float* wr = p.wck + (long long)min(nt * 16 + r16, K - 1) * U + u0 + kb * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(wr), c = *reinterpret_cast<const f32x4*>(wr + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wg[nt][j] = a[j]; wg[nt][4 + j] = c[j]; }
+  }
+  {
+    const float* cs = p.cum_seq + ((long long)b * (p.T + 1) + p.t) * S;
+    for (int i = tid; i < Sp + 48; i += kAttnThreads) {
+      const int sp = i - padl;
+      cum[i] = (sp >= 0 && sp < S) ? cs[sp] : 0.f;
+    }
+    const bf16_t* kp = p.keys + (long long)b * S * U + u0;
+    for (int i = tid; i < slen * 4; i += kAttnThreads) {
+      const int sp = i >> 2, c = i & 3;
+      *reinterpret_cast<u32x4*>(keys + sp * kLocUnits + c * 8) = *reinterpret_cast<const u32x4*>(kp + (long long)sp * U + c * 8);
+    }
+    for (int sp = tid; sp < Sp; sp += kAttnThreads) {
+      ea[sp] = sp < slen ? p.align_seq[row * S + sp] : 0.f;
+      da[sp] = sp < slen ? x.dal[(long long)b * S + sp] : 0.f;
+    }
+  }
+  if (tid < kLocUnits) {
+    const int u = u0 + tid;
+    qb[tid] = p.q_seq[row * U + u] + ((p.use_bias && p.bias) ? p.bias[u] : 0.f) + p.wck[(long long)K * U + u];
+    nv[tid] = p.v[u];
+  }
+  __syncthreads();
+  // softmax backward: de[s] = a[s] (dal[s] - sum_s' a[s'] dal[s'])
+  float dot = 0.f;
+  for (int sp = tid; sp < slen; sp += kAttnThreads) dot += ea[sp] * da[sp];
+  dot = block_sum(dot, red);
+  for (int sp = tid; sp < Sp; sp += kAttnThreads) de[sp] = sp < slen ? ea[sp] * (da[sp] - dot) : 0.f;
+  bf16x8 bh[2], bl[2];
+#pragma unroll
+  for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = kb * 8 + j < K ? wf[ut][j] : 0.f;
+      const __bf16 hi = (__bf16)w;
+      bh[ut][j] = hi;
+      bl[ut][j] = (__bf16)(w - (float)hi);
+    }
+  __syncthreads();
+  // ---- phase A: score gradient of every 16-position tile (all tiles up to Sp: dead ones write zeros) ----------
+  const float q0 = qb[r16], q1 = qb[16 + r16], v0 = nv[r16], v1 = nv[16 + r16];
+  float dq0 = 0.f, dq1 = 0.f, dn0 = 0.f, dn1 = 0.f;
+  bf16_t* dps = p.dpre_seq + (row * S) * U + u0;
+#pragma unroll 1
+  for (int pt = wave; pt < Sp / 16; pt += kAttnWaves) {
+    const float* cp = cum + pt * 16 + r16 + kb * 8;
+    bf16x8 ah, al;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float c = cp[j];
+      const __bf16 hi = (__bf16)c;
+      ah[j] = hi;
+      al[j] = (__bf16)(c - (float)hi);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[1], acc1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sp = pt * 16 + 4 * kb + i;
+      const bool on = sp < slen;
+      const uint16_t* kr = keys + sp * kLocUnits + r16;
+      const float t0 = tanh_fast(acc0[i] + q0 + (on ? bf2f(kr[0]) : 0.f));
+      const float t1 = tanh_fast(acc1[i] + q1 + (on ? bf2f(kr[16]) : 0.f));
+      const float des = de[sp];
+      const float d0 = des * v0 * (1.f - t0 * t0), d1 = des * v1 * (1.f - t1 * t1);
+      dq0 += d0; dq1 += d1;
+      dn0 += des * t0; dn1 += des * t1;
+      const bf16_t h0 = f2bf(d0), h1 = f2bf(d1);
+      const bf16_t l0 = f2bf(d0 - bf2f(h0)), l1 = f2bf(d1 - bf2f(h1));
+      if (on) {
+        dps[(long long)sp * U + r16] = h0;
+        dps[(long long)sp * U + 16 + r16] = h1;
+      }
+      d0s_hi[sp * kSbD0sPitch + r16] = h0; d0s_hi[sp * kSbD0sPitch + 16 + r16] = h1;
+      d0s_lo[sp * kSbD0sPitch + r16] = l0; d0s_lo[sp * kSbD0sPitch + 16 + r16] = l1;
+      d0t_hi[r16 * TP + sp] = h0; d0t_hi[(16 + r16) * TP + sp] = h1;
+      d0t_lo[r16 * TP + sp] = l0; d0t_lo[(16 + r16) * TP + sp] = l1;
+    }
+  }
+  pq[(wave * 4 + kb) * kLocUnits + r16] = dq0; pq[(wave * 4 + kb) * kLocUnits + 16 + r16] = dq1;
+  pn[(wave * 4 + kb) * kLocUnits + r16] = dn0; pn[(wave * 4 + kb) * kLocUnits + 16 + r16] = dn1;
+  __syncthreads();
+  if (wave < 4) {
+    // ---- phase B: dWck tile (taps mt * 16 ..., units nt * 16 ...) over all positions ---------------------------
+    const int mt = wave >> 1, nt = wave & 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < Sp / 32; ++ks) {
+      const float* cp = cum + ks * 32 + kb * 8 + mt * 16 + r16;      // row = tap, 8 consecutive positions
+      bf16x8 ah, al;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = cp[j];
+        const __bf16 hi = (__bf16)c;
+        ah[j] = hi;
+        al[j] = (__bf16)(c - (float)hi);
+      }
+      const bf16x8 th = *reinterpret_cast<const bf16x8*>(d0t_hi + (nt * 16 + r16) * TP + ks * 32 + kb * 8);
+      const bf16x8 tl = *reinterpret_cast<const bf16x8*>(d0t_lo + (nt * 16 + r16) * TP + ks * 32 + kb * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, th, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, th, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, tl, acc, 0, 0, 0);
+    }
+    float* dwa = p.dwck_acc + (long long)b * K * U + u0 + nt * 16 + r16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = mt * 16 + 4 * kb + i;
+      if (k < K) dwa[(long long)k * U] += acc[i];
+    }
+  } else {
+    // ---- phase C: G[s, k] = sum_u d0[s, u] Wck[k, u] for the position tiles of this wave ---------------------------
+    bf16x8 gh[2], gl[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float w = nt * 16 + r16 < K ? wg[nt][j] : 0.f;
+        const __bf16 hi = (__bf16)w;
+        gh[nt][j] = hi;
+        gl[nt][j] = (__bf16)(w - (float)hi);
+      }
+#pragma unroll 1
+    for (int pt = wave - 4; pt < Sp / 16; pt += 4) {
+      const bf16x8 sh = *reinterpret_cast<const bf16x8*>(d0s_hi + (pt * 16 + r16) * kSbD0sPitch + kb * 8);
+      const bf16x8 sl = *reinterpret_cast<const bf16x8*>(d0s_lo + (pt * 16 + r16) * kSbD0sPitch + kb * 8);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, gh[nt], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, gh[nt], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, gl[nt], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G[(pt * 16 + 4 * kb + i) * 33 + nt * 16 + r16] = acc[i];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase D: state gradient along the anti-diagonals of G; dq / dv sums in a fixed order ------------------------
+  float* dpo = x.dcum_part + ((long long)b * kLocParts + part) * S;
+  for (int c = tid; c < S; c += kAttnThreads) {
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int sp = c + padl - k;
+      if (sp >= 0 && sp < Sp) a += G[sp * 33 + k];
+    }
+    dpo[c] = a;
+  }
+  if (tid < kLocUnits) {
+    float dq = 0.f, dn = 0.f;
+    for (int w = 0; w < kAttnWaves * 4; ++w) { dq += pq[w * kLocUnits + tid]; dn += pn[w * kLocUnits + tid]; }
+    p.dq_seq[row * U + u0 + tid] = f2bf(dq);
+    p.dnv_acc[(long long)b * U + u0 + tid] += dn;
+    p.dbd_acc[(long long)b * U + u0 + tid] += dq;
+  }
+}
+}  // namespace os2s
+
+static bool ad_fast_score_bwd(const os2s_attn_decoder_t* d);
+
 static bool ad_fast_cells(const os2s_attn_decoder_t* d) {
   static const int on = [] { const char* e = getenv("OS2S_AD_FAST"); return e ? atoi(e) : 1; }();
   if (!on || d->tgt_len || d->score_mode != 2 || d->B > 32 || d->H > 1024 || d->H % 64 || d->M % 64 || d->loc_k > 32)
@@ -948,5 +1169,23 @@ static int ad_launch_fast_scores(hipStream_t stream, const os2s::AdAttn& at, con
                                  const os2s_attn_decoder_t* d) {
   const size_t lds = ti_scores_lds_floats(d->S) * sizeof(float);
   OS2S_LAUNCH(ad_loc_scores_mfma_kernel, dim3(kLocParts, d->B), dim3(kAttnThreads), lds, stream, at, lx);
+  return OS2S_OK;
+}
+
+// the backward pass's score-gradient launch on the MFMA kernel (same conditions as the forward fast path)
+static bool ad_fast_score_bwd(const os2s_attn_decoder_t* d) {
+  return ad_fast_cells(d) && ad_score_bwd_mfma_lds_floats(d->S) * sizeof(float) <= 160 * 1024 && d->U % 4 == 0;
+}
+static int ad_launch_fast_score_bwd(hipStream_t stream, const os2s::AdAttn& at, const os2s::AdLoc& lx,
+                                    const os2s_attn_decoder_t* d) {
+  const size_t lds = ad_score_bwd_mfma_lds_floats(d->S) * sizeof(float);
+  static size_t attr_for = 0;
+  if (lds > 64 * 1024 && lds > attr_for) {
+    if (hipFuncSetAttribute((const void*)ad_loc_score_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return OS2S_ERR_LAUNCH;
+    attr_for = lds;
+  }
+  OS2S_LAUNCH(ad_loc_score_bwd_mfma_kernel, dim3(kLocParts, d->B), dim3(kAttnThreads), lds, stream, at, lx);
   return OS2S_OK;
 }
