@@ -1,5 +1,6 @@
-// Free-running Tacotron2 decoding (eval / infer), gfx950. Included at the end of attn_decoder.hip: it reuses
-// that translation unit's location-sensitive score kernel.
+// Free-running Tacotron2 decoding (eval / infer) and the small-code kernels of the location-sensitive decoder's
+// training pass, gfx950. Included at the end of attn_decoder.hip (one translation unit: the training driver
+// launches these kernels, and they share its argument structs).
 //
 // Reference: Tacotron2Decoder._decode in eval / infer mode (open_seq2seq/decoders/tacotron2_decoder.py:378-428)
 // = tf.contrib.seq2seq.dynamic_decode(TacotronDecoder(helper = TacotronHelper), impute_finished = False,
@@ -17,16 +18,17 @@
 //   ti_lstm_kernel (layer 0)   gates = [x_t | attention_{t-1} | h0_{t-1}] . W0x^T — the pre-net columns are part of
 //                              the streamed matrix (no separate input-projection GEMM); 16 gate rows (4 units) x
 //                              all samples per workgroup = H/4 workgroups, MFMA 16x16x32 with the reduction cut
-//                              over 8 waves, EVERY load of a wave (weights as e4m3 or bf16, inputs straight from
+//                              over 8 or 9 waves, EVERY load of a wave (weights as e4m3 or bf16, inputs straight from
 //                              the row-major state rows — no LDS staging) in flight before its first MFMA
 //   ti_lstm_kernel (layer 1)
-//   ti_scores_kernel           query projection + partial scores (attn_decoder.hip), 4 unit parts x B, and as a fifth
-//                              part per sample W_out[:, :H] h1 (the half of the frame that only needs the cell output)
-//   ti_context_kernel          softmax, alignments, context columns (8 parts x B) and, as a ninth part per sample,
-//                              the frame: W_out[:, :H] h1 + sum_s a[s] PV[s] + b with PV = values W_out[:, H:]^T
-//                              computed ONCE per batch (the context half of the projection commutes with the
-//                              attention sum), stop token, finished / length bookkeeping, and the pre-net of the
-//                              NEXT step
+//   ti_scores_kernel           query projection + partial scores (location filter on the matrix cores), 4 unit parts
+//                              x B, and as a fifth part per sample W_out[:, :H] h1 (the half of the frame that only
+//                              needs the cell output)
+//   ti_context_kernel          softmax, alignments, context columns (4 or 8 parts x B: MFMA weighted sums over the
+//                              transposed memory) and, as one more part per sample, the frame: W_out[:, :H] h1 +
+//                              sum_s a[s] PV[s] + b with PV = values W_out[:, H:]^T computed ONCE per batch (the
+//                              context half of the projection commutes with the attention sum), stop token,
+//                              finished / length bookkeeping, and the pre-net of the NEXT step
 // The stop decision stays on the device: the launch that sees the last sample finish writes the step count to
 // state[1]; every later launch returns at once, so the host may enqueue steps ahead and poll every N steps —
 // the result does not depend on N.
@@ -34,8 +36,9 @@
 
 namespace os2s {
 
-// waves per LSTM workgroup (the reduction split) x 64-wide k chunks per wave and round: 8 x 5 or 16 x 3 (K <= 2560 /
-// 3072 in one round of requests)
+// ti_lstm_kernel's template geometry: waves per workgroup (the reduction split) x 64-wide k chunks ("request slots")
+// per wave and round; ti_geom() picks 8 x 4, 9 x 4 or 8 x 5 by K.
+// OS2S_TI_NT_WEIGHTS (build flag, experiment): non-temporal weight loads — measured no change.
 
 #ifdef OS2S_TI_NT_WEIGHTS
 #define TI_WLOAD(p) __builtin_nontemporal_load(p)
