@@ -563,348 +563,8 @@ __global__ __launch_bounds__(kTiCtxThreads) void ti_context_kernel(AdAttn p, AdL
 // for 4 cycles — the 2 600 instructions of the round-3 score kernel's unrolled unpack + FMA window are its 10.5 us
 // (a 10 KB unrolled block measured 18 us by itself, OS2S_TI_DEBUG; a cold instruction cache was ruled out with
 // tools/probe_icache.hip). So the inference kernels are written for few issued instructions: packed bf16 dot
-// products (v_dot2c_f32_bf16, one instruction per pair) instead of unpack + FMA, rolled loops, and the location
-// term on the matrix cores instead of a 32 x 32 unrolled FMA window.
-typedef __attribute__((ext_vector_type(2))) __bf16 ti_bf2;
-__device__ __forceinline__ float ti_dot2(uint32_t a, uint32_t b, float c) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ti_bf2, a), __builtin_bit_cast(ti_bf2, b), c, false);
-}
-__device__ __forceinline__ float ti_dot8(const u32x4& a, const u32x4& b, float c) {
-  c = ti_dot2(a[0], b[0], c);
-  c = ti_dot2(a[1], b[1], c);
-  c = ti_dot2(a[2], b[2], c);
-  return ti_dot2(a[3], b[3], c);
-}
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ float row16_sum(float x) {
-  x += dpp_mov<0xB1, 0xf>(0.f, x);    // quad_perm [1,0,3,2]
-  x += dpp_mov<0x4E, 0xf>(0.f, x);    // quad_perm [2,3,0,1]
-  x += dpp_mov<0x124, 0xf>(0.f, x);   // row_ror:4
-  x += dpp_mov<0x128, 0xf>(0.f, x);   // row_ror:8
-  return x;
-}
-
-
-// ---- context + frame ----------------------------------------------------------------------------------
-struct TiTail {
-  int P, n_mel, mask_seq, first;       // first = 1: only the pre-net of step 0 (frame = 0) runs
-  int dbg;                             // profiling aid (OS2S_TI_DEBUG): bit 0 / 1 skip the frame / score parts of the score
-                                       // launch, bit 2 / 3 the frame / context parts of the context launch (WRONG results)
-  float keep; unsigned long long seed[2];
-  const bf16_t* wp1; const float* bp1; // [P, n_mel], [P]
-  const bf16_t* wp2; const float* bp2; // [P, P], [P]
-  const bf16_t* wout_h;                // [n_mel, H]
-  const bf16_t* pv_t;                  // [B, n_mel16, Sp] bf16: (values W_out[:, H:]^T)^T, positions contiguous
-  const bf16_t* values_t;              // [B, M, Sp] bf16: values^T
-  const float* bout;                   // [n_mel]
-  const bf16_t* wstop; const float* bstop;   // [n_mel], [1]
-  float* mh;                           // [B, n_mel] scratch: W_out[:, :H] h1 of the step (ti_scores_kernel -> ti_context_kernel)
-  bf16_t* x_seq;                       // [B, T+1, P]
-  bf16_t* mel;                         // [B, T, n_mel]
-  float* stop;                         // [B, T]
-  int32_t* state;                      // [0] unused, [1] steps at which everything had finished (0 = running),
-                                       // [2] finished samples, [3] unused, [4 .. 4+B) finished, [4+B .. 4+2B) lengths
-};
-
-constexpr int kTiCtxThreads = 512;
-constexpr int kTiW2Rows = 16;          // W2 rows per thread (P <= 256: P * P / 8 sixteen-byte pieces over 512 threads)
-constexpr int kTiW1Pieces = 8;         // W1 pieces per thread
-constexpr int kTiKs = 8;               // 32-position steps whose operands are requested up front (S <= 256)
-
-__host__ __device__ inline int ti_spad(int S) { return (S + 31) & ~31; }      // row pitch of values_t / pv_t
-
-__host__ __device__ inline size_t ti_ctx_lds_floats(int S, int P, int n_mel) {
-  // e [Sp] + red [32] + hi / lo alignments (bf16, max(Sp, 256) each) + frame [n_mel] + x1 [P] + mc [n_mel + 16] +
-  // partials max(P * (P / 8 + 1), P * 8)
-  const size_t Sp = ti_spad(S), Sa = Sp > 256 ? Sp : 256;
-  size_t part = (size_t)P * (P / 8 + 1);
-  if ((size_t)P * 8 > part) part = (size_t)P * 8;
-  return Sp + 32 + Sa + n_mel + P + n_mel + 16 + part + 64;
-}
-
-// Softmax over the summed partial scores -> alignments: e[s] (fp32, zero past the length) and their bf16 hi / lo
-// halves ah / al (zero up to max(Sp, 256): the A operand of the weighted sums below). Every part of a sample
-// computes them; `store` (part 0) writes the alignment row and advances the cumulative alignments.
-__device__ __forceinline__ void ti_alignments(const AdAttn& p, const AdLoc& x, int b, int slen, float* e, float* red,
-                                              uint16_t* ah, uint16_t* al, bool store) {
-  const int tid = threadIdx.x, S = p.S, Sa = max(ti_spad(S), 256);
-  const float* ep = x.e_part + (long long)b * kLocParts * S;
-  float mx = -INFINITY;
-  for (int sp = tid; sp < slen; sp += kTiCtxThreads) {
-    float v = ep[sp];
-#pragma unroll
-    for (int k = 1; k < kLocParts; ++k) v += ep[k * S + sp];
-    e[sp] = v;
-    mx = fmaxf(mx, v);
-  }
-  mx = wave_max_dpp(mx);
-  if ((tid & 63) == 0) red[tid >> 6] = mx;
-  __syncthreads();
-  mx = red[0];
-#pragma unroll
-  for (int w = 1; w < kTiCtxThreads / 64; ++w) mx = fmaxf(mx, red[w]);
-  float sum = 0.f;
-  for (int sp = tid; sp < slen; sp += kTiCtxThreads) {
-    const float ex = __expf(e[sp] - mx);
-    e[sp] = ex;
-    sum += ex;
-  }
-  sum = wave_sum_dpp(sum);
-  if ((tid & 63) == 0) red[8 + (tid >> 6)] = sum;
-  __syncthreads();
-  sum = 0.f;
-#pragma unroll
-  for (int w = 0; w < kTiCtxThreads / 64; ++w) sum += red[8 + w];
-  const float inv = slen > 0 ? 1.f / sum : 0.f;
-  const long long row = (long long)b * p.T + p.t;
-  for (int sp = tid; sp < Sa; sp += kTiCtxThreads) {
-    const float a = sp < slen ? e[sp] * inv : 0.f;
-    const bf16_t hi = f2bf(a);
-    ah[sp] = hi;
-    al[sp] = f2bf(a - bf2f(hi));
-    if (store && sp < S) {
-      p.align_seq[row * S + sp] = a;
-      const long long ci = ((long long)b * (p.T + 1) + p.t) * S + sp;
-      p.cum_seq[ci + S] = p.cum_seq[ci] + a;
-    }
-  }
-  __syncthreads();
-}
-
-// out[n] = sum_s a[s] mat_t[row0 + n][s] for the 16 rows of one tile of a TRANSPOSED operand (bf16 [rows, Sp],
-// positions contiguous): the alignments are the A operand of a 16x16x32 MFMA (every A row the same, bf16 hi + lo),
-// 16 positions-contiguous bytes per lane are the B operand. Result for column n = lane & 15 in every lane.
-// breq: this lane's operands of the first kTiKs position steps, requested by the caller before the softmax.
-__device__ __forceinline__ float ti_weighted_sum(const bf16_t* __restrict__ mrow, int Sp, const u32x4 (&breq)[kTiKs],
-                                                 const uint16_t* ah, const uint16_t* al) {
-  const int kb = (threadIdx.x & 63) >> 4;
-  const int nks = Sp >> 5;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < kTiKs; ++ks) {
-    // steps past nks re-read the last step's operand against zero alignments (ah / al are zero up to 256)
-    const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(ah + ks * 32 + kb * 8);
-    const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(al + ks * 32 + kb * 8);
-    const bf16x8 bv = __builtin_bit_cast(bf16x8, breq[ks]);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bv, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, bv, acc, 0, 0, 0);
-  }
-#pragma unroll 1
-  for (int ks = kTiKs; ks < nks; ++ks) {           // S > 256: the rest, not requested ahead
-    const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(ah + ks * 32 + kb * 8);
-    const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(al + ks * 32 + kb * 8);
-    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(mrow + ks * 32 + kb * 8);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bv, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, bv, acc, 0, 0, 0);
-  }
-  return acc[0];                                   // rows are identical: row 4 * kb
-}
-
-__device__ __forceinline__ void ti_request_rows(const bf16_t* __restrict__ mrow, int Sp, u32x4 (&breq)[kTiKs]) {
-  const int kb = (threadIdx.x & 63) >> 4;
-  const int nks = Sp >> 5;
-#pragma unroll
-  for (int ks = 0; ks < kTiKs; ++ks)
-    breq[ks] = *reinterpret_cast<const u32x4*>(mrow + min(ks, nks - 1) * 32 + kb * 8);
-}
-
-// The frame part of a sample: one workgroup, ONE dependent chain (alignments -> frame -> stop token -> pre-net
-// layer 1 -> layer 2), so everything that does not depend on the chain is requested first: both pre-net
-// matrices (168 KB) and this sample's rows of PV^T sit in registers before the softmax starts.
-__device__ __forceinline__ void ti_tail(const AdAttn& p, const AdLoc& x, const TiTail& q, float* lds) {
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int S = p.S, P = q.P, nm = q.n_mel, B = p.B, T = p.T;
-  const int Sp = ti_spad(S), Sa = max(Sp, 256), nm16 = (nm + 15) & ~15;
-  float* e = lds;                      // [Sp]
-  float* red = e + Sp;                 // [32]
-  uint16_t* ah = reinterpret_cast<uint16_t*>(red + 32);    // [Sa] bf16
-  uint16_t* al = ah + Sa;                                  // [Sa]
-  uint32_t* frp = reinterpret_cast<uint32_t*>(al + Sa);    // [nm / 2] the frame as packed bf16 pairs (nm floats reserved)
-  uint32_t* x1p = frp + nm;            // [P / 2] pre-net layer-1 output, packed bf16 (P floats reserved)
-  float* mc = reinterpret_cast<float*>(x1p + P);            // [nm16] context half of the frame
-  float* part = mc + nm + 16;          // partial sums of the pre-net stages
-  uint16_t* fr16 = reinterpret_cast<uint16_t*>(frp);
-  uint16_t* x116 = reinterpret_cast<uint16_t*>(x1p);
-  const int t_next = q.first ? 0 : p.t + 1;
-  const int slen = q.first ? 0 : min(max(p.src_len[b], 0), S);
-  // ---- requests ---------------------------------------------------------------------------------------
-  // W2 [P, P]: thread = (piece pc of a row, row group rg); rows rg, rg + RG, ...
-  const int pcs2 = P >> 3, RG = kTiCtxThreads / pcs2;
-  const int pc2 = tid % pcs2, rg = tid / pcs2;
-  u32x4 w2[kTiW2Rows];
-#pragma unroll
-  for (int i = 0; i < kTiW2Rows; ++i) {
-    const int j = min(rg + i * RG, P - 1);
-    w2[i] = *reinterpret_cast<const u32x4*>(q.wp2 + (long long)j * P + pc2 * 8);
-  }
-  // W1 [P, nm]: TPR threads per row, each pieces pc, pc + TPR, ...
-  const int pcs1 = nm >> 3, TPR = kTiCtxThreads / P;          // P <= 256: TPR >= 2
-  const int j1 = tid / TPR, s1 = tid % TPR;
-  u32x4 w1[kTiW1Pieces];
-#pragma unroll
-  for (int i = 0; i < kTiW1Pieces; ++i) {
-    const int pc = min(s1 + i * TPR, pcs1 - 1);
-    w1[i] = *reinterpret_cast<const u32x4*>(q.wp1 + (long long)min(j1, P - 1) * nm + pc * 8);
-  }
-  // PV^T rows of this sample: wave w < nm16 / 16 owns frame columns 16 w ... (the other waves re-read tile 0)
-  const int ct = wave < nm16 / 16 ? wave : 0;
-  const bf16_t* pvrow = q.pv_t + ((long long)b * nm16 + ct * 16 + (lane & 15)) * Sp;
-  u32x4 breq[kTiKs];
-  ti_request_rows(pvrow, Sp, breq);
-  float mh = 0.f, bo = 0.f;
-  if (!q.first && tid < nm) { mh = q.mh[(long long)b * nm + tid]; bo = q.bout[tid]; }
-  __builtin_amdgcn_sched_barrier(0);
-  if (q.first) {
-    for (int k = tid; k < nm; k += kTiCtxThreads) fr16[k] = 0;
-    __syncthreads();
-  } else {
-    ti_alignments(p, x, b, slen, e, red, ah, al, false);
-    // ---- context half of the frame: sum_s a[s] PV[s, :] ------------------------------------------------------
-    const float cs = ti_weighted_sum(pvrow, Sp, breq, ah, al);
-    if (wave < nm16 / 16 && lane < 16) mc[wave * 16 + lane] = cs;
-    __syncthreads();
-    if (tid < nm) {
-      const bf16_t fb = f2bf(mh + bo + mc[tid]);
-      q.mel[((long long)b * T + p.t) * nm + tid] = fb;
-      fr16[tid] = fb;
-    }
-    __syncthreads();
-    // ---- stop token, finished / length bookkeeping (wave 0; the others go on) ----------------------------------
-    if (tid < 64) {
-      float sacc = 0.f;
-      for (int k = tid; k < nm / 2; k += 64) sacc = ti_dot2(reinterpret_cast<const uint32_t*>(q.wstop)[k], frp[k], sacc);
-      sacc = wave_sum_dpp(sacc);
-      if (tid == 0) {
-        sacc = bf2f(f2bf(sacc + q.bstop[0]));            // the stop projection's output tensor is bf16
-        q.stop[(long long)b * T + p.t] = sacc;
-        int32_t* fin = q.state + 4;
-        int32_t* len = q.state + 4 + B;
-        const int was = fin[b];
-        if (!was) len[b] = p.t + 1;                      // dynamic_decode: lengths count the step that finished
-        // round(sigmoid(s)) == 1  <=>  sigmoid(s) > 0.5  <=>  s > 0  (round half to even: 0.5 -> 0)
-        if (q.mask_seq && !was && sacc > 0.f) {
-          fin[b] = 1;
-          const int n = atomicAdd(&q.state[2], 1);
-          if (n == B - 1) q.state[1] = p.t + 1;          // visible to the next launch (kernel boundary)
-        }
-      }
-    }
-  }
-  if (t_next > T) return;
-  // ---- pre-net of the next step ---------------------------------------------------------------------------
-  const float ik = 1.f / q.keep;
-  {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < kTiW1Pieces; ++i) {
-      const int pc = min(s1 + i * TPR, pcs1 - 1);
-      const float d = ti_dot8(w1[i], *reinterpret_cast<const u32x4*>(frp + pc * 4), 0.f);
-      s += s1 + i * TPR < pcs1 ? d : 0.f;
-    }
-    if (j1 < P) part[j1 * 8 + s1] = s;                   // TPR <= 8
-  }
-  __syncthreads();
-  if (tid < P) {
-    float s = q.bp1[tid];
-    for (int i = 0; i < TPR; ++i) s += part[tid * 8 + i];
-    s = fmaxf(s, 0.f);
-    if (q.keep < 1.f) {
-      const unsigned long long idx = ((unsigned long long)t_next * B + b) * P + tid;
-      const uint32_t bits = dropout_bits8(q.seed[0], idx >> 3, q.keep);
-      s = ((bits >> (idx & 7)) & 1u) ? s * ik : 0.f;
-    }
-    x116[tid] = f2bf(s);                // the layer's output is a bf16 tensor in the teacher-forced pass too
-  }
-  __syncthreads();
-  {
-    const u32x4 xv = *reinterpret_cast<const u32x4*>(x1p + pc2 * 4);
-#pragma unroll
-    for (int i = 0; i < kTiW2Rows; ++i) {
-      const int j = rg + i * RG;
-      const float d = ti_dot8(w2[i], xv, 0.f);
-      if (j < P && rg < RG) part[j * (pcs2 + 1) + pc2] = d;
-    }
-  }
-  __syncthreads();
-  if (tid < P) {
-    float s = q.bp2[tid];
-    for (int i = 0; i < pcs2; ++i) s += part[tid * (pcs2 + 1) + i];
-    s = fmaxf(s, 0.f);
-    if (q.keep < 1.f) {
-      const unsigned long long idx = ((unsigned long long)t_next * B + b) * P + tid;
-      const uint32_t bits = dropout_bits8(q.seed[1], idx >> 3, q.keep);
-      s = ((bits >> (idx & 7)) & 1u) ? s * ik : 0.f;
-    }
-    q.x_seq[((long long)b * (T + 1) + t_next) * P + tid] = f2bf(s);
-  }
-}
-
-// grid (ctx_parts + 1, B), 512 threads: part c < ctx_parts = context columns [c * MQ, (c + 1) * MQ) (a 16-column
-// tile per wave: attention_t[m] = sum_s a[s] values^T[m][s] on the matrix cores); the last part is the frame
-__global__ __launch_bounds__(kTiCtxThreads) void ti_context_kernel(AdAttn p, AdLoc x, TiTail q, int ctx_parts,
-                                                                   int MQ) {
-  extern __shared__ float lds_raw[];
-  const int cpart = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int M = p.M, S = p.S;
-  if (cpart == ctx_parts) {
-    if (!q.first && (q.state[1] != 0 || (q.dbg & 4))) return;
-    ti_tail(p, x, q, lds_raw);
-    return;
-  }
-  if (q.first || q.state[1] != 0 || (q.dbg & 8)) return;
-  const int Sp = ti_spad(S), Sa = max(Sp, 256);
-  float* e = lds_raw;                  // [Sp]
-  float* red = e + Sp;                 // [32]
-  uint16_t* ah = reinterpret_cast<uint16_t*>(red + 32);
-  uint16_t* al = ah + Sa;
-  const int slen = min(max(p.src_len[b], 0), S);
-  const int ntile = MQ >> 4;           // 16-column tiles of this part: wave w owns tiles w and w + 8 (requested up
-  const int m0 = cpart * MQ;           // front), further ones (M > 2048 / parts) in a rolled loop
-  constexpr int NW = kTiCtxThreads / 64;
-  const int cta = wave < ntile ? wave : 0, ctb = wave + NW < ntile ? wave + NW : cta;
-  const bf16_t* vbase = q.values_t + ((long long)b * M + m0 + (lane & 15)) * Sp;
-  u32x4 breq_a[kTiKs], breq_b[kTiKs];
-  ti_request_rows(vbase + (long long)cta * 16 * Sp, Sp, breq_a);
-  ti_request_rows(vbase + (long long)ctb * 16 * Sp, Sp, breq_b);
-  __builtin_amdgcn_sched_barrier(0);
-  ti_alignments(p, x, b, slen, e, red, ah, al, cpart == 0);
-  bf16_t* ctx = p.ctx + (long long)b * p.ctx_bs + (long long)p.t * p.ctx_ts;
-  bf16_t* cat = p.cat0 + ((long long)b * (p.T + 1) + p.t + 1) * p.Kc0;
-  {
-    const float ca = ti_weighted_sum(vbase + (long long)cta * 16 * Sp, Sp, breq_a, ah, al);
-    const float cb = ti_weighted_sum(vbase + (long long)ctb * 16 * Sp, Sp, breq_b, ah, al);
-    if (lane < 16) {
-      if (wave < ntile) { const bf16_t v = f2bf(ca); ctx[m0 + wave * 16 + lane] = v; cat[m0 + wave * 16 + lane] = v; }
-      if (wave + NW < ntile) {
-        const bf16_t v = f2bf(cb);
-        ctx[m0 + (wave + NW) * 16 + lane] = v;
-        cat[m0 + (wave + NW) * 16 + lane] = v;
-      }
-    }
-  }
-#pragma unroll 1
-  for (int ct = wave + 2 * NW; ct < ntile; ct += NW) {
-    const bf16_t* vr = vbase + (long long)ct * 16 * Sp;
-    u32x4 br[kTiKs];
-    ti_request_rows(vr, Sp, br);
-    const float c = ti_weighted_sum(vr, Sp, br, ah, al);
-    if (lane < 16) {
-      const bf16_t v = f2bf(c);
-      ctx[m0 + ct * 16 + lane] = v;
-      cat[m0 + ct * 16 + lane] = v;
-    }
-  }
-}
-
-// ---- score launch -----------------------------------------------------------------------------------------
-// What a step kernel costs is mostly the CODE it executes once: the instruction cache is cold at every dispatch
-// and straight-line code streams in at roughly 64 B per 0.1 us (a 10 KB unrolled block measured 18 us by
-// itself, tools/README.md "OS2S_TI_DEBUG"). So the inference kernels are written for few instruction bytes on
-// the critical path: packed bf16 dot products (v_dot2c_f32_bf16, one instruction per pair) instead of
-// unpack + FMA, rolled loops, and the location term on the matrix cores instead of a 32 x 32 unrolled FMA
-// window.
+// products (v_dot2c_f32_bf16, one instruction per pair; ti_dot2 / ti_dot8 above) instead of unpack + FMA, rolled
+// loops, and the location term on the matrix cores instead of a 32 x 32 unrolled FMA window.
 __host__ __device__ inline size_t ti_scores_lds_floats(int S) {
   const size_t Sp = ((size_t)S + 15) & ~(size_t)15;
   return 64 + (Sp + 48) + Sp * kLocUnits / 2 + 64;     // q/bias, padded cumulative alignments, key columns (bf16)
