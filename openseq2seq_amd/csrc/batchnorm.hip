@@ -187,12 +187,25 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // Thread layout of the row-walking kernels below: a workgroup covers trows consecutive rows of
 // the flattened [B*T, C] tensor x G 8-channel groups (g_tiling below: 32 groups = 512 contiguous
 // bytes per row and 32 / 64 rows per workgroup measured best; the kernels are bound by how many
-// wavefronts are in flight, not by the segment width); thread -> group g = tid % G, fixed for
-// the thread's whole walk so the
-// per-channel constants live in registers, and row lane rl = tid / G. Rows are walked kTileU at a
-// time so that every thread keeps >= 4 independent 16-B loads per tensor in flight; (b, t) of a
-// row is tracked incrementally (no per-row division).
+// bytes are in flight, not by the segment width); thread -> group g = tid % G, fixed for
+// the thread's whole walk so the per-channel constants live in registers, and row lane rl = tid / G.
+//
+// Round 4, the two backward kernels (bn_act_bwd_reduce, bn_bwd_apply): no branch stands around a
+// memory instruction. The first version tracked (b, t) of a row with an incremental cursor and
+// loaded `if (live) ...`; hipcc compiled that into one exec-masked basic block per row, each ending
+// in s_waitcnt vmcnt(0) — a thread had two 16-byte loads in flight, not eight. Now (1) the workgroup
+// classifies its rows once (one division per ROW, by the first trows threads, into LDS: BlockRows),
+// (2) every tensor is read and written through a buffer descriptor that covers exactly the
+// workgroup's rows, with the byte offset of a row that must not be touched replaced by an
+// out-of-range one: such a load returns zeros without a memory request and such a store is
+// dropped, (3) all loads of a thread's rows are issued back to back before the first use.
+// tools/bench_bn_sweep.py, Jasper shapes, same box: apply 18.7 / 27.2 / 31.6 -> 17.8 / 24.1 / 29.5 us
+// (512 / 768 / 1024 channels), reduce 28.4 / 38.0 / 45.5 -> 28.5 / 35.8 / 40.8 — 5-10 %, not the 2x
+// the instruction stream suggested: at ~4 TB/s of mixed read / write streams over ~40 MB tensors
+// these 20-40 us kernels are bound by the memory system, not by loads in flight per thread.
 constexpr int kTileU = 4;
+constexpr int kMaxTileRows = 1024;   // os2s_bn_set_tiling's upper bound on rows per workgroup
+constexpr int kOobOffset = 0x7fffffff;
 
 struct TileMap {
   int G, RL, g, rl, cg;
@@ -212,6 +225,56 @@ static inline int tile_cblocks(int C8, int gmax) { return ceil_div(C8, C8 < gmax
 // defaults from tools/bench_bn_sweep.py on MI355X (Jasper shapes, working set rotated out of the MALL)
 static int g_tiling[3][2] = {{32, 32}, {32, 64}, {32, 64}};
 
+// Row classes of a workgroup's block of rows [r0, r0 + n): bit 0 = t < len[b] + margin, bit 1 = t < len[b]
+// (len = T without a length vector). Ends with a barrier: call it before any thread leaves.
+struct BlockRows {
+  long long r0;
+  int n;
+  __device__ __forceinline__ void init(unsigned char* flag, long long rows, int trows, int T,
+                                       const int32_t* lens, int margin) {
+    r0 = (long long)blockIdx.x * trows;
+    const long long left = rows - r0;
+    n = (int)(left < trows ? left : trows);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const long long r = r0 + i;
+      const int b = (int)((unsigned long long)r / (unsigned)T);
+      const int t = (int)(r - (long long)b * T);
+      const int len = lens ? lens[b] : T;
+      flag[i] = (unsigned char)((t < len + margin ? 1 : 0) | (t < len ? 2 : 0));
+    }
+    __syncthreads();
+  }
+};
+
+// Descriptor over the n rows of C bf16 channels that start at row r0 of a [rows, C] tensor
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t block_rsrc(const void* base, long long r0, int n, int C) {
+  const unsigned long long a = (unsigned long long)base + (unsigned long long)r0 * (unsigned)C * 2ull;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int bytes = __builtin_amdgcn_readfirstlane(n * C * 2);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 row_load(__amdgpu_buffer_rsrc_t rs, int off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+}
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&o)[8]) {
+  o[0] = bflo(v[0]); o[1] = bfhi(v[0]); o[2] = bflo(v[1]); o[3] = bfhi(v[1]);
+  o[4] = bflo(v[2]); o[5] = bfhi(v[2]); o[6] = bflo(v[3]); o[7] = bfhi(v[3]);
+}
+
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+  u32x4 o;
+  o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
+  o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
+  return o;
+}
+
+// The forward apply keeps the incremental (b, t) cursor: one tensor in, one out, four loads in flight
+// were enough (the BlockRows version measured the same at 64 rows and slower at 32).
 struct RowCursor {
   long long row;
   int b, t, T, len;
@@ -232,18 +295,6 @@ struct RowCursor {
     }
   }
 };
-
-__device__ __forceinline__ void unpack8(const u32x4& v, float (&o)[8]) {
-  o[0] = bflo(v[0]); o[1] = bfhi(v[0]); o[2] = bflo(v[1]); o[3] = bfhi(v[1]);
-  o[4] = bflo(v[2]); o[5] = bfhi(v[2]); o[6] = bflo(v[3]); o[7] = bfhi(v[3]);
-}
-
-__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
-  u32x4 o;
-  o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-  o[2] = pack2bf(v[4], v[5]); o[3] = pack2bf(v[6], v[7]);
-  return o;
-}
 
 template <bool SINGLE>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs p, int gmax, int trows) {
@@ -361,16 +412,22 @@ struct BnBwdReduceArgs {
 
 // U = rows in flight per thread: 4 for the single-input instantiation, fewer for the residual block
 // ends (their per-input accumulators already take 32 / 96 registers; with U = 4 the 12-input
-// instantiation ran at one wave per SIMD)
+// instantiation ran at one wave per SIMD). The inputs are read JB at a time so that every
+// instantiation has 4 loads of y in flight, the first JB together with dout / out.
 template <int J_MAX, int kTileU>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs p, int gmax) {
+  constexpr int U = kTileU;
+  constexpr int JB = 4 / U;
+  static_assert(JB >= 1 && J_MAX % JB == 0, "inputs are read in whole groups");
   __shared__ float red[256 * 8];
+  __shared__ unsigned char flag[kMaxTileRows];
   const int C8 = p.C >> 3;
   const int trows = p.rows_per_block;
   const TileMap tm(C8, gmax);
   const int g = tm.g, rl = tm.rl, cg = tm.cg, RL = tm.RL, G = tm.G;
   const bool cvalid = tm.cvalid;
   const int c0 = cg * 8;
+  const int rowb = p.C * 2;
   const float inv_keep = 1.f / p.keep_prob;
   float sd[8];
   float sx[J_MAX][8];
@@ -380,54 +437,74 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
   for (int j = 0; j < J_MAX; ++j)
 #pragma unroll
     for (int e = 0; e < 8; ++e) sx[j][e] = 0.f;
+  BlockRows br;
+  br.init(flag, (long long)p.B * p.T, trows, p.T, p.out_len, 0);
   if (cvalid) {
-    const long long rows = (long long)p.B * p.T;
-    const long long r0 = (long long)blockIdx.x * trows;
-    const long long r1 = min(rows, r0 + trows);
-    RowCursor cur;
-    if (r0 + rl < r1) cur.init(r0 + rl, p.T, p.out_len);
-    for (long long base = r0 + rl; base < r1; base += (long long)kTileU * RL) {
-      long long rw[kTileU];
-      bool ok[kTileU], lv[kTileU];
-      u32x4 d[kTileU], o[kTileU];
-      float dr[kTileU][8];
+    const __amdgpu_buffer_rsrc_t dors = block_rsrc(p.dout, br.r0, br.n, p.C);
+    const __amdgpu_buffer_rsrc_t outrs = block_rsrc(p.out, br.r0, br.n, p.C);
+    const __amdgpu_buffer_rsrc_t dzrs = block_rsrc(p.dz, br.r0, br.n, p.C);
+    for (int i0 = rl; i0 < br.n; i0 += U * RL) {
+      int off[U], ld[U];
+      bool lv[U];
+      u32x4 d[U], o[U], y[JB][U];
+      float dr[U][8];
 #pragma unroll
-      for (int u = 0; u < kTileU; ++u) {
-        rw[u] = base + (long long)u * RL;
-        ok[u] = rw[u] < r1;
-        lv[u] = ok[u] && cur.live();
-        if (ok[u]) cur.advance(RL, rows);
-        if (lv[u]) {
-          d[u] = *reinterpret_cast<const u32x4*>(p.dout + rw[u] * p.C + c0);
-          o[u] = *reinterpret_cast<const u32x4*>(p.out + rw[u] * p.C + c0);
-        }
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * RL;
+        const bool in = i < br.n;
+        lv[u] = in && (flag[in ? i : 0] & 2);
+        off[u] = in ? i * rowb + c0 * 2 : kOobOffset;
+        ld[u] = lv[u] ? off[u] : kOobOffset;
       }
 #pragma unroll
-      for (int u = 0; u < kTileU; ++u) {
-        if (!ok[u]) continue;
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if (lv[u]) {
-          float dv[8], ov[8], dzv[8];
-          unpack8(d[u], dv);
-          unpack8(o[u], ov);
-          uint32_t keep = 0xffu;
-          if (p.keep_prob < 1.f)
-            keep = dropout_bits8(p.seed, (unsigned long long)(rw[u] * C8 + cg), p.keep_prob);
+      for (int u = 0; u < U; ++u) {
+        d[u] = row_load(dors, ld[u]);
+        o[u] = row_load(outrs, ld[u]);
+      }
+      auto load_inputs = [&](int jc) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float gsc = 1.f;
-            if (p.keep_prob < 1.f) gsc = ((keep >> e) & 1u) ? inv_keep : 0.f;
-            float dact = 1.f;
-            if (p.act == 1) dact = ov[e] > 0.f ? 1.f : 0.f;
-            else if (p.act == 2) {
-              const float th = ov[e] * p.keep_prob;  // tanh(z) of a kept element
-              dact = 1.f - th * th;
-            }
-            dzv[e] = dv[e] * gsc * dact;
-          }
-          w = pack8(dzv);
+        for (int jj = 0; jj < JB; ++jj) {
+          // inputs past p.J: whatever the argument block holds there is never dereferenced
+          const __amdgpu_buffer_rsrc_t yrs = block_rsrc(p.y[jc + jj], br.r0, br.n, p.C);
+#pragma unroll
+          for (int u = 0; u < U; ++u) y[jj][u] = row_load(yrs, jc + jj < p.J ? ld[u] : kOobOffset);
         }
-        *reinterpret_cast<u32x4*>(p.dz + rw[u] * p.C + c0) = w;
+      };
+      auto sum_inputs = [&](int jc) {
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            float yv[8];
+            unpack8(y[jj][u], yv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sx[jc + jj][e] += dr[u][e] * yv[e];
+          }
+      };
+      load_inputs(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float dv[8], ov[8], dzv[8];
+        unpack8(d[u], dv);
+        unpack8(o[u], ov);
+        uint32_t keep = 0xffu;
+        if (p.keep_prob < 1.f)
+          keep = dropout_bits8(p.seed, (unsigned long long)((br.r0 + i0 + u * RL) * C8 + cg), p.keep_prob);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float gsc = 1.f;
+          if (p.keep_prob < 1.f) gsc = ((keep >> e) & 1u) ? inv_keep : 0.f;
+          float dact = 1.f;
+          if (p.act == 1) dact = ov[e] > 0.f ? 1.f : 0.f;
+          else if (p.act == 2) {
+            const float th = ov[e] * p.keep_prob;  // tanh(z) of a kept element
+            dact = 1.f - th * th;
+          }
+          dzv[e] = dv[e] * gsc * dact;
+        }
+        // rows at or past out_len[b] read as zeros above, so dz is zero there
+        const u32x4 w = pack8(dzv);
+        row_store(dzrs, off[u], w);
         // the sums use the bf16-rounded dz, i.e. exactly what pass 2 re-reads
         unpack8(w, dr[u]);
 #pragma unroll
@@ -435,21 +512,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
       }
       // only sum(dz * y) is accumulated per row: sum(dz * xhat) = rstd * (sum(dz * y) -
       // mean * sum(dz)) is formed once per thread below (no per-row mean / rstd loads)
+      sum_inputs(0);
 #pragma unroll
-      for (int j = 0; j < J_MAX; ++j)
-        if (j < p.J) {
-          u32x4 y[kTileU];
-#pragma unroll
-          for (int u = 0; u < kTileU; ++u)
-            if (lv[u]) y[u] = *reinterpret_cast<const u32x4*>(p.y[j] + rw[u] * p.C + c0);
-#pragma unroll
-          for (int u = 0; u < kTileU; ++u)
-            if (lv[u]) {
-              float yv[8];
-              unpack8(y[u], yv);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) sx[j][e] += dr[u][e] * yv[e];
-            }
+      for (int jc = JB; jc < J_MAX; jc += JB)
+        if (jc < p.J) {
+          load_inputs(jc);
+          sum_inputs(jc);
         }
     }
   }
@@ -581,18 +649,24 @@ __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_multi_kernel(
 
 // Backward pass 2 for input j: dy = gamma*rstd*(dz - c1 - xhat*c2)
 //   = A*dz + Bq*y + Cc with per-channel A, Bq, Cc held in registers; a thread owns
-// 8 channels and walks rows (4 rows = 8 x 16-B loads in flight).
+// 8 channels and 8 rows of the workgroup's block: 16 x 16-B loads in flight, all issued before the
+// first use (64 rows x 32 groups per workgroup: the walk is one straight pass).
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dz, const bf16_t* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ c1,
     const float* __restrict__ c2, bf16_t* __restrict__ dy, const int32_t* __restrict__ out_len,
     int margin, int B, int T, int C, int gmax, int trows, int dz_to_len) {
+  constexpr int U = 2 * kTileU;
+  __shared__ unsigned char flag[kMaxTileRows];
   const int C8 = C >> 3;
   const TileMap tm(C8, gmax);
+  BlockRows br;
+  br.init(flag, (long long)B * T, trows, T, out_len, margin);
   if (!tm.cvalid) return;
   const int rl = tm.rl, cg = tm.cg, RL = tm.RL;
   const int c0 = cg * 8;
+  const int rowb = C * 2;
   float A[8], Bq[8], Cc[8];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -610,47 +684,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       Cc[4 * h + e] = gm * rs * (me4[e] * rs * b4[e] - a4[e]);
     }
   }
-  const long long rows = (long long)B * T;
-  const long long r0 = (long long)blockIdx.x * trows;
-  const long long r1 = min(rows, r0 + trows);
-  RowCursor cur;
-  if (r0 + rl < r1) cur.init(r0 + rl, T, out_len);
-  for (long long base = r0 + rl; base < r1; base += (long long)kTileU * RL) {
-    long long rw[kTileU];
-    bool ok[kTileU], lv[kTileU];
-    u32x4 d[kTileU], yv[kTileU];
+  const __amdgpu_buffer_rsrc_t dzrs = block_rsrc(dz, br.r0, br.n, C);
+  const __amdgpu_buffer_rsrc_t yrs = block_rsrc(y, br.r0, br.n, C);
+  const __amdgpu_buffer_rsrc_t dyrs = block_rsrc(dy, br.r0, br.n, C);
+  // dz_to_len: dz is only DEFINED for rows before the sequence end (it was written by a data-
+  // gradient launch that skips the rest, os2s_conv1d_dgrad_bnact_ws) and is zero beyond
+  const unsigned dz_bit = dz_to_len ? 2u : 1u;
+  for (int i0 = rl; i0 < br.n; i0 += U * RL) {
+    int off[U];
+    bool lv[U];
+    u32x4 d[U], yv[U];
 #pragma unroll
-    for (int u = 0; u < kTileU; ++u) {
-      rw[u] = base + (long long)u * RL;
-      ok[u] = rw[u] < r1;
-      lv[u] = ok[u] && cur.t < cur.len + margin;
-      // dz_to_len: dz is only DEFINED for rows before the sequence end (it was written by a data-
-      // gradient launch that skips the rest, os2s_conv1d_dgrad_bnact_ws) and is zero beyond
-      const bool dzl = lv[u] && (!dz_to_len || cur.t < cur.len);
-      if (ok[u]) cur.advance(RL, rows);
-      if (lv[u]) {
-        d[u] = u32x4{0u, 0u, 0u, 0u};
-        if (dzl) d[u] = *reinterpret_cast<const u32x4*>(dz + rw[u] * C + c0);
-        yv[u] = *reinterpret_cast<const u32x4*>(y + rw[u] * C + c0);
-      }
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * RL;
+      const bool in = i < br.n;
+      const unsigned f = in ? flag[i] : 0u;
+      lv[u] = (f & 1u) != 0u;
+      off[u] = in ? i * rowb + c0 * 2 : kOobOffset;
+      d[u] = row_load(dzrs, (f & dz_bit) ? off[u] : kOobOffset);
+      yv[u] = row_load(yrs, lv[u] ? off[u] : kOobOffset);
     }
 #pragma unroll
-    for (int u = 0; u < kTileU; ++u) {
-      if (!ok[u]) continue;
+    for (int u = 0; u < U; ++u) {
       // rows at or past out_len[b] + margin are written as zeros WITHOUT reading dz / y: the caller
       // states with `margin` how far past the sequence end its consumers look (the data- and
       // weight-gradient convolutions reach (K-1)*dilation rows into the padding; dy is NOT zero
       // there: -gamma*rstd*(c1 + xhat*c2) flows back through the batch statistics)
-      u32x4 o = {0u, 0u, 0u, 0u};
-      if (lv[u]) {
+      u32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = A[2 * e] * bflo(d[u][e]) + Bq[2 * e] * bflo(yv[u][e]) + Cc[2 * e];
-          const float hi = A[2 * e + 1] * bfhi(d[u][e]) + Bq[2 * e + 1] * bfhi(yv[u][e]) + Cc[2 * e + 1];
-          o[e] = pack2bf(lo, hi);
-        }
+      for (int e = 0; e < 4; ++e) {
+        const float lo = A[2 * e] * bflo(d[u][e]) + Bq[2 * e] * bflo(yv[u][e]) + Cc[2 * e];
+        const float hi = A[2 * e + 1] * bfhi(d[u][e]) + Bq[2 * e + 1] * bfhi(yv[u][e]) + Cc[2 * e + 1];
+        o[e] = pack2bf(lo, hi) & (lv[u] ? 0xffffffffu : 0u);   // a mask, not a branch
       }
-      *reinterpret_cast<u32x4*>(dy + rw[u] * C + c0) = o;
+      row_store(dyrs, off[u], o);
     }
   }
 }
