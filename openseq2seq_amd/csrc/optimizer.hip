@@ -303,6 +303,11 @@ __global__ __launch_bounds__(256) void mt_finalize_kernel(
 }
 
 // ---- pass 3: apply -----------------------------------------------------------
+// One chunk per workgroup, 16 elements per thread. The optimizer is a template parameter and every
+// load of the thread (4 x {grad, weight, moments}) is issued before the first use: with the
+// optimizer as a run-time switch hipcc emitted load - s_waitcnt vmcnt(0) - switch - store per 4
+// elements, i.e. 3 loads in flight per thread and a branch per element.
+template <int OPT>
 __global__ __launch_bounds__(256) void mt_apply_kernel(
     const float* __restrict__ grads, float* __restrict__ weights, float* __restrict__ m1,
     float* __restrict__ m2, bf16_t* __restrict__ w16, const int32_t* __restrict__ chunk_tensor,
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(256) void mt_apply_kernel(
     const float* __restrict__ tensor_wd_mask, os2s_opt_config_t cfg,
     const OptDeviceState* __restrict__ st) {
   if (st->skip) return;
+  constexpr int N = kChunk / 4 / 256;
   const int c = blockIdx.x;
   const int ti = chunk_tensor[c];
   // st->loss_scale was already updated by the finalize pass; the gradients in
@@ -319,46 +325,51 @@ __global__ __launch_bounds__(256) void mt_apply_kernel(
   const float mult = tensor_mult[ti];
   const float lr = st->lr;
   const float wd = cfg.weight_decay * (tensor_wd_mask ? tensor_wd_mask[ti] : 1.f);
+  const float ga = cfg.grad_averaging ? (1.f - cfg.beta1) : 1.f;
   float adam_lr = lr;
-  if (cfg.optimizer == 3) {
+  if (OPT == 3) {
     const float t = (float)(st->global_step);  // already incremented: t = step+1
     adam_lr = lr * sqrtf(1.f - powf(cfg.beta2, t)) / (1.f - powf(cfg.beta1, t));
   }
-  const long long base = (long long)c * kChunk;
+  const long long base = (long long)c * kChunk + (long long)threadIdx.x * 4;
+  f32x4 g[N], w[N], m[N], v[N];
 #pragma unroll
-  for (int i = 0; i < kChunk / 4 / 256; ++i) {
-    const long long off = base + (long long)(i * 256 + threadIdx.x) * 4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(grads + off);
-    f32x4 w = *reinterpret_cast<const f32x4*>(weights + off);
-    f32x4 m = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-    if (cfg.optimizer != 0) m = *reinterpret_cast<const f32x4*>(m1 + off);
-    if (cfg.optimizer == 3) v = *reinterpret_cast<const f32x4*>(m2 + off);
+  for (int i = 0; i < N; ++i) {
+    const long long off = base + (long long)i * 1024;
+    g[i] = *reinterpret_cast<const f32x4*>(grads + off);
+    w[i] = *reinterpret_cast<const f32x4*>(weights + off);
+    if (OPT != 0) m[i] = *reinterpret_cast<const f32x4*>(m1 + off);
+    if (OPT == 3) v[i] = *reinterpret_cast<const f32x4*>(m2 + off);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const long long off = base + (long long)i * 1024;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float ge = (g[e] * inv + l2 * w[e]) * mult;
-      switch (cfg.optimizer) {
-        case 0: w[e] -= lr * ge; break;
-        case 1: m[e] = cfg.beta1 * m[e] + ge; w[e] -= lr * m[e]; break;
-        case 2:
-          ge += wd * w[e];
-          if (cfg.grad_averaging) ge *= (1.f - cfg.beta1);
-          m[e] = cfg.beta1 * m[e] + ge;
-          w[e] -= lr * m[e];
-          break;
-        default:
-          m[e] = cfg.beta1 * m[e] + (1.f - cfg.beta1) * ge;
-          v[e] = cfg.beta2 * v[e] + (1.f - cfg.beta2) * ge * ge;
-          w[e] -= adam_lr * m[e] / (sqrtf(v[e]) + cfg.epsilon);
-          break;
+      float ge = (g[i][e] * inv + l2 * w[i][e]) * mult;
+      if (OPT == 0) {
+        w[i][e] -= lr * ge;
+      } else if (OPT == 1) {
+        m[i][e] = cfg.beta1 * m[i][e] + ge;
+        w[i][e] -= lr * m[i][e];
+      } else if (OPT == 2) {
+        ge += wd * w[i][e];
+        ge *= ga;
+        m[i][e] = cfg.beta1 * m[i][e] + ge;
+        w[i][e] -= lr * m[i][e];
+      } else {
+        m[i][e] = cfg.beta1 * m[i][e] + (1.f - cfg.beta1) * ge;
+        v[i][e] = cfg.beta2 * v[i][e] + (1.f - cfg.beta2) * ge * ge;
+        w[i][e] -= adam_lr * m[i][e] / (sqrtf(v[i][e]) + cfg.epsilon);
       }
     }
-    *reinterpret_cast<f32x4*>(weights + off) = w;
-    if (cfg.optimizer != 0) *reinterpret_cast<f32x4*>(m1 + off) = m;
-    if (cfg.optimizer == 3) *reinterpret_cast<f32x4*>(m2 + off) = v;
+    *reinterpret_cast<f32x4*>(weights + off) = w[i];
+    if (OPT != 0) *reinterpret_cast<f32x4*>(m1 + off) = m[i];
+    if (OPT == 3) *reinterpret_cast<f32x4*>(m2 + off) = v[i];
     if (w16) {
       u32x2 o;
-      o[0] = pack2bf(w[0], w[1]);
-      o[1] = pack2bf(w[2], w[3]);
+      o[0] = pack2bf(w[i][0], w[i][1]);
+      o[1] = pack2bf(w[i][2], w[i][3]);
       *reinterpret_cast<u32x2*>(w16 + off) = o;
     }
   }
@@ -492,8 +503,16 @@ extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg
               tensor_chunk_begin, tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult);
   OS2S_LAUNCH(mt_finalize_kernel, dim3(1), dim3(256), 0, stream, ntensors, *cfg, st,
               tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult, tensor_v);
-  OS2S_LAUNCH(mt_apply_kernel, dim3(nchunks), dim3(256), 0, stream, grads, weights, m1, m2,
-              w16, chunk_tensor, tensor_l2, tensor_mult, tensor_wd_mask, *cfg, st);
+#define OS2S_APPLY(OPT)                                                                          \
+  OS2S_LAUNCH(mt_apply_kernel<OPT>, dim3(nchunks), dim3(256), 0, stream, grads, weights, m1, m2, \
+              w16, chunk_tensor, tensor_l2, tensor_mult, tensor_wd_mask, *cfg, st)
+  switch (cfg->optimizer) {
+    case 0: OS2S_APPLY(0); break;
+    case 1: OS2S_APPLY(1); break;
+    case 2: OS2S_APPLY(2); break;
+    default: OS2S_APPLY(3); break;
+  }
+#undef OS2S_APPLY
   return OS2S_OK;
 }
 
