@@ -565,6 +565,35 @@ struct BnFinMulti {
   float* dbeta[kMaxBnInputs];
 };
 
+// Sum of rows q0 and q1 of the partials [nparts, nq, C] over the parts i = pl, pl + kFinLanes, ... for
+// channel c, in fp64 and in a fixed order. Eight parts (16 loads) are in flight per thread and the
+// tail is read with clamped indices and zeroed by a select: these kernels are a latency chain over
+// nparts / kFinLanes loads (the two-at-a-time loop took 9 round trips for 263 parts, 11-13 us per
+// launch, ~50 launches per step).
+__device__ __forceinline__ void fin_sum_pair(const float* __restrict__ partial, int nparts, int nq, int q0,
+                                             int q1, int C, int c, int pl, double& s0, double& s1) {
+  const long long stride = (long long)nq * C;
+  const float* const p0 = partial + (long long)q0 * C + c;
+  const float* const p1 = partial + (long long)q1 * C + c;
+  for (int i = pl; i < nparts; i += 8 * kFinLanes) {
+    float a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ik = i + k * kFinLanes;
+      const long long o = (long long)(ik < nparts ? ik : nparts - 1) * stride;
+      a[k] = p0[o];
+      b[k] = p1[o];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i + k * kFinLanes >= nparts) { a[k] = 0.f; b[k] = 0.f; }
+    s0 += (((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3])) +
+          (((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]));
+    s1 += (((double)b[0] + (double)b[1]) + ((double)b[2] + (double)b[3])) +
+          (((double)b[4] + (double)b[5]) + ((double)b[6] + (double)b[7]));
+  }
+}
+
 // All inputs of a block end in ONE launch (blockIdx.y = input): c1 / c2 are [J, C].
 __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_multi_kernel(
     const float* __restrict__ partial, int nparts, int nq, int C, double count, BnFinMulti ptrs,
@@ -578,21 +607,7 @@ __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_kernel(
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double sd = 0.0, sx = 0.0;
-  if (c < C) {
-    int i = pl;
-    for (; i + kFinLanes < nparts; i += 2 * kFinLanes) {
-      const float a0 = partial[((long long)i * nq + 0) * C + c];
-      const float b0 = partial[((long long)i * nq + q) * C + c];
-      const float a1 = partial[((long long)(i + kFinLanes) * nq + 0) * C + c];
-      const float b1 = partial[((long long)(i + kFinLanes) * nq + q) * C + c];
-      sd += (double)a0 + (double)a1;
-      sx += (double)b0 + (double)b1;
-    }
-    for (; i < nparts; i += kFinLanes) {
-      sd += (double)partial[((long long)i * nq + 0) * C + c];
-      sx += (double)partial[((long long)i * nq + q) * C + c];
-    }
-  }
+  if (c < C) fin_sum_pair(partial, nparts, nq, 0, q, C, c, pl, sd, sx);
   sh_d[pl][cl] = sd;
   sh_x[pl][cl] = sx;
   __syncthreads();
@@ -618,21 +633,7 @@ __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_multi_kernel(
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double sd = 0.0, sx = 0.0;
-  if (c < C) {
-    int i = pl;
-    for (; i + kFinLanes < nparts; i += 2 * kFinLanes) {
-      const float a0 = partial[((long long)i * nq + 0) * C + c];
-      const float b0 = partial[((long long)i * nq + q) * C + c];
-      const float a1 = partial[((long long)(i + kFinLanes) * nq + 0) * C + c];
-      const float b1 = partial[((long long)(i + kFinLanes) * nq + q) * C + c];
-      sd += (double)a0 + (double)a1;
-      sx += (double)b0 + (double)b1;
-    }
-    for (; i < nparts; i += kFinLanes) {
-      sd += (double)partial[((long long)i * nq + 0) * C + c];
-      sx += (double)partial[((long long)i * nq + q) * C + c];
-    }
-  }
+  if (c < C) fin_sum_pair(partial, nparts, nq, 0, q, C, c, pl, sd, sx);
   sh_d[pl][cl] = sd;
   sh_x[pl][cl] = sx;
   __syncthreads();
@@ -895,11 +896,7 @@ __global__ __launch_bounds__(64 * kFinLanes) void bn_bwd_finalize_raw_kernel(
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double sd = 0.0, sx = 0.0;
-  if (c < C)
-    for (int i = pl; i < nparts; i += kFinLanes) {
-      sd += (double)partial[((long long)i * 2 + 0) * C + c];
-      sx += (double)partial[((long long)i * 2 + 1) * C + c];
-    }
+  if (c < C) fin_sum_pair(partial, nparts, 2, 0, 1, C, c, pl, sd, sx);
   sh_d[pl][cl] = sd;
   sh_x[pl][cl] = sx;
   __syncthreads();

@@ -173,34 +173,78 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 
 // dx = dres + rstd * (g*dy - mean_D(g*dy) - xhat * mean_D(g*dy*xhat));
 // per-block partial sums of dbeta = sum dy, dgamma = sum dy*xhat -> partial[blk][2][D]
+//
+// One wave per row, kLnWaves rows of a workgroup's block at a time. A row is two dependent steps (two
+// wave reductions between its loads and its stores), so the kernel is a latency chain per wave:
+// the first version (4 waves x 8 rows, loads of a row issued after the stores of the previous one,
+// the residual gradient loaded after the reductions) ran at 1.1 TB/s. Now every load of row i + kLnWaves
+// (dy, x, dres, mean, rstd) is issued before row i is reduced — through buffer descriptors over the
+// block's rows, so the prefetch past the last row needs no branch: it is out of range, returns zeros
+// and costs no memory request — and a workgroup has 8 waves.
+constexpr int kLnWaves = 8;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ln_rows_rsrc(const void* base, long long r0, int n, int D) {
+  const unsigned long long a = (unsigned long long)base + (unsigned long long)r0 * (unsigned)D * 2ull;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int bytes = __builtin_amdgcn_readfirstlane(base ? n * D * 2 : 0);   // null tensor: everything is out of range
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
 template <int VPL>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+struct LnRow {
+  u32x4 a[VPL], t[VPL], r[VPL];
+  float mu, rs;
+};
+
+template <int VPL>
+__global__ __launch_bounds__(64 * kLnWaves) void layernorm_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd,
     const bf16_t* __restrict__ dres, long long N, int rows_per_block, bf16_t* __restrict__ dx,
     float* __restrict__ partial) {
   constexpr int D = 64 * 8 * VPL;
-  __shared__ float red[4][D];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr int kOob = 0x7fffffff;
+  __shared__ float red[kLnWaves][D];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float gb[VPL][8], gg[VPL][8], gm[VPL][8];
 #pragma unroll
-  for (int u = 0; u < VPL; ++u)
+  for (int u = 0; u < VPL; ++u) {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + (u * 64 + lane) * 8);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + (u * 64 + lane) * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gb[u][e] = 0.f; gg[u][e] = 0.f;
-      gm[u][e] = gamma[(u * 64 + lane) * 8 + e];
-    }
+    for (int e = 0; e < 4; ++e) { gm[u][e] = g0[e]; gm[u][4 + e] = g1[e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gb[u][e] = 0.f; gg[u][e] = 0.f; }
+  }
   const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r1 = min(N, r0 + rows_per_block);
-  for (long long row = r0 + wid; row < r1; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
+  const long long left = N - r0;
+  const int n = (int)(left < rows_per_block ? left : rows_per_block);
+  const __amdgpu_buffer_rsrc_t dyr = ln_rows_rsrc(dy, r0, n, D);
+  const __amdgpu_buffer_rsrc_t xr = ln_rows_rsrc(x, r0, n, D);
+  const __amdgpu_buffer_rsrc_t drr = ln_rows_rsrc(dres, r0, n, D);
+  const __amdgpu_buffer_rsrc_t dxr = ln_rows_rsrc(dx, r0, n, D);
+  auto fetch = [&](int i, LnRow<VPL>& R) {
+    const bool in = i < n;
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+      const int off = in ? i * (D * 2) + (u * 64 + lane) * 16 : kOob;
+      R.a[u] = __builtin_amdgcn_raw_buffer_load_b128(dyr, off, 0, 0);
+      R.t[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+      R.r[u] = __builtin_amdgcn_raw_buffer_load_b128(drr, off, 0, 0);
+    }
+    const long long gr = r0 + (in ? i : 0);
+    R.mu = mean[gr];
+    R.rs = rstd[gr];
+  };
+  auto process = [&](int i, const LnRow<VPL>& cur) {
+    const float mu = cur.mu, rs = cur.rs;
     float dyv[VPL][8], xh[VPL][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
-      const int c0 = (u * 64 + lane) * 8;
-      const u32x4 a = *reinterpret_cast<const u32x4*>(dy + row * D + c0);
-      const u32x4 t = *reinterpret_cast<const u32x4*>(x + row * D + c0);
+      const u32x4 a = cur.a[u], t = cur.t[u];
       dyv[u][0] = bflo(a[0]); dyv[u][1] = bfhi(a[0]); dyv[u][2] = bflo(a[1]); dyv[u][3] = bfhi(a[1]);
       dyv[u][4] = bflo(a[2]); dyv[u][5] = bfhi(a[2]); dyv[u][6] = bflo(a[3]); dyv[u][7] = bfhi(a[3]);
       xh[u][0] = bflo(t[0]); xh[u][1] = bfhi(t[0]); xh[u][2] = bflo(t[1]); xh[u][3] = bfhi(t[1]);
@@ -215,26 +259,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         s2 += gd * xh[u][e];
       }
     }
-    s1 = wave_sum(s1) * (1.f / D);
-    s2 = wave_sum(s2) * (1.f / D);
+    s1 = wave_sum_dpp(s1) * (1.f / D);
+    s2 = wave_sum_dpp(s2) * (1.f / D);
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
-      const int c0 = (u * 64 + lane) * 8;
       float r[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] = rs * (gm[u][e] * dyv[u][e] - s1 - xh[u][e] * s2);
-      if (dres) {
-        const u32x4 t = *reinterpret_cast<const u32x4*>(dres + row * D + c0);
-        r[0] += bflo(t[0]); r[1] += bfhi(t[0]); r[2] += bflo(t[1]); r[3] += bfhi(t[1]);
-        r[4] += bflo(t[2]); r[5] += bfhi(t[2]); r[6] += bflo(t[3]); r[7] += bfhi(t[3]);
-      }
+      const u32x4 t = cur.r[u];            // zeros without a residual gradient
+      r[0] += bflo(t[0]); r[1] += bfhi(t[0]); r[2] += bflo(t[1]); r[3] += bfhi(t[1]);
+      r[4] += bflo(t[2]); r[5] += bfhi(t[2]); r[6] += bflo(t[3]); r[7] += bfhi(t[3]);
       u32x4 o;
       o[0] = pack2bf(r[0], r[1]); o[1] = pack2bf(r[2], r[3]);
       o[2] = pack2bf(r[4], r[5]); o[3] = pack2bf(r[6], r[7]);
-      *reinterpret_cast<u32x4*>(dx + row * D + c0) = o;
+      __builtin_amdgcn_raw_buffer_store_b128(o, dxr, i * (D * 2) + (u * 64 + lane) * 16, 0, 0);
     }
+  };
+  // two row buffers, used alternately (a register copy `cur = next` would have to wait for the prefetch);
+  // sched_barrier: the prefetch is issued where it stands, not where hipcc would sink it to
+  LnRow<VPL> ra, rb;
+  fetch(wid, ra);
+  for (int i = wid; i < n; i += 2 * kLnWaves) {
+    fetch(i + kLnWaves, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    process(i, ra);
+    if (i + kLnWaves >= n) break;
+    fetch(i + 2 * kLnWaves, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    process(i + kLnWaves, rb);
   }
-  // block reduce the parameter-gradient partials over the 4 waves
+  // block reduce the parameter-gradient partials over the waves (fixed order)
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
@@ -243,9 +297,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       for (int e = 0; e < 8; ++e)
         red[wid][(u * 64 + lane) * 8 + e] = pass == 0 ? gb[u][e] : gg[u][e];
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256)
-      partial[((long long)blockIdx.x * 2 + pass) * D + c] =
-          (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < D; c += 64 * kLnWaves) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < kLnWaves; ++w) acc += red[w][c];
+      partial[((long long)blockIdx.x * 2 + pass) * D + c] = acc;
+    }
   }
 }
 
@@ -609,10 +666,10 @@ extern "C" int os2s_layernorm_bwd(os2s_stream_t stream, const uint16_t* dy, cons
   if (N == 0) return OS2S_OK;
   dim3 grid(ceil_div(N, kLnRowsPerBlock));
   if (D == 1024) {
-    OS2S_LAUNCH(layernorm_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean,
+    OS2S_LAUNCH(layernorm_bwd_kernel<2>, grid, dim3(64 * kLnWaves), 0, (hipStream_t)stream, dy, x, gamma, mean,
                 rstd, dres, N, kLnRowsPerBlock, dx, partial);
   } else if (D == 512) {
-    OS2S_LAUNCH(layernorm_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean,
+    OS2S_LAUNCH(layernorm_bwd_kernel<1>, grid, dim3(64 * kLnWaves), 0, (hipStream_t)stream, dy, x, gamma, mean,
                 rstd, dres, N, kLnRowsPerBlock, dx, partial);
   } else {
     return OS2S_ERR_UNSUPPORTED;
