@@ -138,9 +138,13 @@ class Tape(object):
 
   def backward(self):
     # work parked on the side stream since the last join must have landed
+    global _CUR_TAPE
+    # one backward pass at a time: the zeroed scratch of the BatchNorm-backward partials (capi._zero_arena)
+    # and the side streams are per process, a pass started inside another one would re-zero live partials
+    if _CUR_TAPE is not None:
+      raise RuntimeError("Tape.backward() called while another backward pass is running")
     join_side_streams()
     capi.zero_arena_reset()       # the previous pass's statistic partials are dead: one fill for this pass
-    global _CUR_TAPE
     _CUR_TAPE, self._deferred, self._pending = self, [], None
     try:
       if self.on_done is None:

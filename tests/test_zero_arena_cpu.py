@@ -29,3 +29,27 @@ def test_zero_arena_hands_out_disjoint_zeroed_slices():
   assert float(big.abs().sum()) == 0.0
   arena.reset()
   assert arena.buf.numel() >= big.numel()
+
+
+def test_tape_backward_refuses_to_nest():
+  """The zeroed scratch is per process: a backward pass started from inside another one must fail loudly
+  instead of re-zeroing the outer pass's partials."""
+  import pytest
+  from openseq2seq_amd.parts.cnns import conv_blocks as cb
+  from openseq2seq_amd import capi
+  calls = []
+  saved = (cb.join_side_streams, capi.zero_arena_reset)
+  cb.join_side_streams = lambda: None
+  capi.zero_arena_reset = lambda: calls.append("reset")
+  try:
+    inner = cb.Tape()
+    inner.record(lambda: calls.append("inner"))
+    outer = cb.Tape()
+    outer.record(lambda: inner.backward())
+    with pytest.raises(RuntimeError, match="another backward pass"):
+      outer.backward()
+    assert cb.current_tape() is None and calls == ["reset"]      # the outer pass cleaned up, the inner never ran
+    inner.backward()                                             # sequential passes are fine
+    assert calls == ["reset", "reset", "inner"]
+  finally:
+    cb.join_side_streams, capi.zero_arena_reset = saved
