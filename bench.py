@@ -71,6 +71,9 @@ def parse():
   ap.add_argument("--only-transformer", action="store_true",
                   help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
+  ap.add_argument("--pp-cost", default=None,
+                  help="A/B aid: 'c256,c2x128,c3x128' = microseconds per step of the three ping-pong convolution "
+                       "tiles in the device-side tile choice (os2s_conv1d_set_pp_cost; 1e6 removes a tile)")
   ap.add_argument("--one-rank-group", action="store_true",
                   help="N=1 only: run the data-parallel path (RCCL process group, bucketed all-reduce on "
                        "the side stream, comm diagnostics) on a one-rank group")
@@ -988,6 +991,13 @@ def main():
     return
   dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
+  if args.pp_cost:
+    import ctypes
+    from openseq2seq_amd import _lib
+    c = [float(v) for v in args.pp_cost.split(",")]
+    f = _lib.lib().os2s_conv1d_set_pp_cost
+    f.argtypes, f.restype = [ctypes.c_float] * 3, None
+    f(*c)
   if rank == 0 and world > 1:
     print("bench.py: %d ranks, backend %s (RCCL), one process per GPU" % (
         world, torch.distributed.get_backend()), file=sys.stderr)

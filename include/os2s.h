@@ -156,8 +156,13 @@ int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
                        size_t workspace_bytes);
 /* experiment / test hook: force a tile. -1 (default) = by shape; 0 = 128x128 tile, X window
  * double-buffered; 3 = 128x128, X window single-buffered when K >= 8 (3 workgroups per CU);
- * 5 = 256x256 lockstep tile; 10 = ping-pong kernel (256x256, balanced over live windows) */
+ * 5 = 256x256 lockstep tile; 10 = ping-pong kernels (balanced over live windows), tile chosen on the
+ * device from the live-window count: 2 windows x 256 columns, or 2 / 3 windows x 128 columns;
+ * 12 / 13 / 14 = ping-pong with the 2 x 128 / 3 x 128 / 2 x 256 tile forced */
 void os2s_conv1d_set_variant(int v);
+/* fitted microseconds per 64-deep step of the three ping-pong tiles (2 x 256, 2 x 128, 3 x 128
+ * windows x columns) — the constants of the device-side tile choice; values <= 0 keep the default */
+void os2s_conv1d_set_pp_cost(float c256, float c2x128, float c3x128);
 /* experiment / test hook for the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers):
  * 0 (default) and 1 = lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows
  * whenever its envelope allows (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as

@@ -42,6 +42,12 @@ struct ConvArgs {
   int force_split;              // experiment hook: > 0 forces the tail split factor
   unsigned long long* dbg;      // experiment hook: slot time stamps [4 wg][2 waves][48 steps][9]
   int dbg_fixed_w;              // experiment hook: every step reads the weight tile of step 0
+  // ping-pong convolution only: tile shape of the launch. -1 = chosen on the device from the live-window
+  // count (pp_choose_tile), 0 = two windows x 256 columns, 2 / 3 = two / three windows x 128 columns.
+  // pp_ok2 / pp_ok3: the narrow tiles fit this layer (LDS, K), pp_cost = fitted microseconds per
+  // 64-deep step of the three tiles (the device-side choice is a pure function of these and in_len).
+  int pp_tile = 0, pp_ok2 = 0, pp_ok3 = 0;
+  float pp_c256 = 1.18f, pp_c2 = 0.62f, pp_c3 = 0.80f;
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
@@ -90,6 +96,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
   constexpr int NW = WM * WN, NTHR = NW * 64;
   constexpr int WTM = (BM * NWIN) / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
   const int wm = wid / WN, wn = wid % WN;
+  // STRADDLE: the rows of a wave cross a window boundary (three windows over four row groups of the
+  // 128-column ping-pong tile): window, sample and time are then taken per 32-row fragment
+  constexpr bool STRADDLE = (BM % WTM) != 0;
+  static_assert(!STRADDLE || (size_t)NWIN * BM * (BN * 2 + 16) <= kEpiSplitBytes,
+                "a straddling wave layout needs all windows staged in one pass");
   const int my_win = (wm * WTM) / BM;
   const int row_in_win = (wm * WTM) % BM;
   const int my_b = (NWIN == 1 || my_win == 0) ? wb[0] : wb[NWIN - 1];
@@ -99,6 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
   const int l31 = lane & 31, lhi = lane >> 5;
   if (p.out_f32) {
     // small/rare path (FC logits): scattered fp32 stores straight from registers
+    // (not reachable with a straddling layout: the ping-pong launchers refuse out_f32)
     const int b = my_b, t0 = my_t0;
     const int valid_rows = (my_mid >= 0) ? min(BM, p.Tout - t0) : 0;
     float* const yb = reinterpret_cast<float*>(p.y) + (long long)b * p.y_sb;
@@ -187,7 +199,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
       }
     }
   };
-  if (my_win >= w0 && my_win < w0 + EW) {
+  if constexpr (STRADDLE) {
+    // (b, t0) of a row are per fragment here; the launchers keep dropout off these tiles (pp_ok3)
+    stage_tile(std::false_type{});
+  } else if (my_win >= w0 && my_win < w0 + EW) {
     if (__builtin_amdgcn_readfirstlane(p.keep_prob < 1.f ? 1 : 0)) stage_tile(std::true_type{});
     else stage_tile(std::false_type{});
   }

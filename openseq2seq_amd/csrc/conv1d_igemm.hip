@@ -33,6 +33,7 @@
 #include "os2s_common.hpp"
 #include "conv1d_common.hpp"
 #include "os2s_split_reduce.hpp"
+#include <algorithm>
 #include <array>
 #include <type_traits>
 #include <map>
@@ -292,17 +293,93 @@ __device__ __forceinline__ void pp_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// DBG: per-slot s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py)
-template <bool DBG>
-__global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
-  constexpr int BM = 128, BN = kPpBN, NWIN = 2, WM = 2, WN = 4;
-  constexpr int MI = 4, NI = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid >> 2, wn = wid & 3;
+// Store-only role of the ping-pong launches (forward calls): workgroup z of the tail of the grid writes
+// the zero rows (or the residual rows) and the zero BatchNorm partials of kPpZeroWin dead windows.
+__device__ __forceinline__ void pp_zero_role(const ConvArgs& p, const int nw, const int z, const int tid) {
+  constexpr int BM = 128;
+  if (p.out_len || p.out_f32 || z >= (p.MT + kPpZeroWin - 1) / kPpZeroWin) return;
+  for (int m = z * kPpZeroWin; m < (z + 1) * kPpZeroWin && m < p.MT; ++m) {
+    const int b = m / p.mtiles_per_b, j = m - b * p.mtiles_per_b;
+    if (j < __shfl(nw, b, 64)) continue;
+    const int t0 = j * BM, rows = min(BM, p.Tout - t0);
+    if (!p.accumulate) {
+      bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
+      const int c8n = p.Cout >> 3;
+      const u32x4 zv = {0u, 0u, 0u, 0u};
+      for (int e = tid; e < rows * c8n; e += 512) {
+        const int row = e / c8n, c8 = e - row * c8n;
+        u32x4 v = zv;
+        if (p.residual)
+          v = *reinterpret_cast<const u32x4*>(p.residual + (long long)b * p.y_sb +
+                                              (long long)(t0 + row) * p.y_st + c8 * 8);
+        *reinterpret_cast<u32x4*>(yb + (long long)(t0 + row) * p.y_st + c8 * 8) = v;
+      }
+    }
+    if (p.stats)
+      for (int e = tid; e < 2 * p.Cout; e += 512) p.stats[(long long)m * 2 * p.Cout + e] = 0.f;
+  }
+}
 
-  // ---- live windows per sample, inclusive scan over the batch (one value per lane) ----------
+// Tail-split factor of the 256-column tile (same decision in every workgroup: pure function of the launch)
+__device__ __forceinline__ int pp256_split(const ConvArgs& p, const int U, const int S) {
+  const int G = p.ncu;
+  const int q = U / G, r = U - q * G;
+  int f = 1;
+  if (p.force_split > 0 && p.ws_slabs) {
+    f = p.force_split;
+    while (f > 1 && (f > p.nchunks || r * f > p.ws_nslabs)) --f;
+    if (r == 0) f = 1;
+  } else if (r > 0 && p.ws_slabs) {
+    // a round of whole units takes S steps x 1.18 us (tools/bench_conv_split.py)
+    f = split_factor(r, G, p.pp_c256 * S, p.nchunks < 8 ? p.nchunks : 8, p.ws_nslabs);
+  }
+  return f;
+}
+
+// Tile shape of a ping-pong launch, chosen on the device (the live-window count L of a ragged batch is
+// only known there) from a fixed cost model — every workgroup evaluates the same pure function of the
+// launch arguments and in_len / out_len. Candidates: 0 = two windows x 256 columns (tail of the
+// launch split along the input channels), 2 / 3 = two / three windows x 128 columns (ppn_body).
+// The model is rounds x steps x microseconds per step of the tile (+ the fitted tail-split terms):
+// what decides is how many equal units a layer gives — Jasper's 384 / 512 / 640-channel layers on the
+// bench batch are 146 / 146 / 219 units of 256 columns on 256 CUs, but 219 / 196 / 245 narrow ones.
+__device__ __forceinline__ int pp_choose_tile(const ConvArgs& p, const int L) {
+  if (p.pp_tile >= 0) return p.pp_tile;
+  const int G = p.ncu, S = p.nchunks * p.K;
+  float best;
+  {
+    const int U = ((L + 1) >> 1) * p.NT;
+    const int q = U / G, r = U - q * G;
+    const float round_us = p.pp_c256 * S + 12.f;
+    best = q * round_us;
+    if (r > 0) {
+      const int f = pp256_split(p, U, S);
+      best += f > 1 ? (float)((r * f + G - 1) / G) * round_us / f + 20.f + 1.5f * f + 0.17f * (r * f) : round_us;
+    }
+  }
+  int tile = 0;
+  const int NT128 = (p.Cout + 127) >> 7;
+  if (p.pp_ok2) {
+    const int U = ((L + 1) >> 1) * NT128;
+    const float t = (float)((U + G - 1) / G) * (p.pp_c2 * S + 9.f);
+    if (t < 0.97f * best) { best = t; tile = 2; }
+  }
+  if (p.pp_ok3) {
+    const int U = ((L + 2) / 3) * NT128;
+    const float t = (float)((U + G - 1) / G) * (p.pp_c3 * S + 10.f);
+    if (t < 0.97f * best) { best = t; tile = 3; }
+  }
+  return tile;
+}
+
+template <bool DBG>
+__device__ __forceinline__ void pp256_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem);
+template <int NWIN>
+__device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem);
+
+// live windows per sample (one value per lane), inclusive scan over the batch in `scan`
+__device__ __forceinline__ int pp_live_windows(const ConvArgs& p, const int lane, int& scan) {
+  constexpr int BM = 128;
   int nw = 0;
   if (lane < p.B) {
     if (p.out_len) {
@@ -320,55 +397,58 @@ __global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
     }
     nw = nw < p.mtiles_per_b ? nw : p.mtiles_per_b;
   }
-  int scan = nw;
+  scan = nw;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const int t = __shfl_up(scan, o, 64);
     if (lane >= o) scan += t;
   }
+  return nw;
+}
+
+// The two ping-pong kernels of a launch whose tile is chosen on the device (pp_tile < 0) are enqueued
+// back to back; every workgroup of both evaluates pp_choose_tile and the kernel that was not chosen
+// exits at once (one global load + a wave scan: ~2 us per launch pair). They are separate kernels, not
+// one kernel with three bodies: fused, the register allocator re-read kernel arguments inside the
+// main loops (s_load + s_waitcnt lgkmcnt(0) in every LOAD slot of the 256-column body).
+// DBG: per-slot s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py)
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int scan;
+  const int nw = pp_live_windows(p, threadIdx.x & 63, scan);
   const int L = __builtin_amdgcn_readlane(scan, 63);
+  if (__builtin_amdgcn_readfirstlane(pp_choose_tile(p, L)) != 0) return;
+  pp256_body<DBG>(p, L, scan, nw, smem);
+}
+
+__global__ __launch_bounds__(512, 2) void conv1d_ppn_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int scan;
+  const int nw = pp_live_windows(p, threadIdx.x & 63, scan);
+  const int L = __builtin_amdgcn_readlane(scan, 63);
+  const int tile = __builtin_amdgcn_readfirstlane(pp_choose_tile(p, L));
+  if (tile == 2) ppn_body<2>(p, L, scan, nw, smem);
+  else if (tile == 3) ppn_body<3>(p, L, scan, nw, smem);
+}
+
+template <bool DBG>
+__device__ __forceinline__ void pp256_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem) {
+  constexpr int BM = 128, BN = kPpBN, NWIN = 2, WM = 2, WN = 4;
+  constexpr int MI = 4, NI = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wn = wid & 3;
   const int P = (L + 1) >> 1, U = P * p.NT, G = p.ncu;
   const int S = p.nchunks * p.K;
-
-  // ---- tail split factor (same decision in every workgroup: pure function of the launch) -----
-  const int q = U / G, r = U - q * G;
-  int f = 1;
-  if (p.force_split > 0 && p.ws_slabs) {
-    f = p.force_split;
-    while (f > 1 && (f > p.nchunks || r * f > p.ws_nslabs)) --f;
-    if (r == 0) f = 1;
-  } else if (r > 0 && p.ws_slabs) {
-    // a round of whole units takes S steps x 1.18 us (tools/bench_conv_split.py)
-    f = split_factor(r, G, 1.18f * S, p.nchunks < 8 ? p.nchunks : 8, p.ws_nslabs);
-  }
+  const int r = U - (U / G) * G;
+  const int f = pp256_split(p, U, S);
   const int nfull = f > 1 ? U - r : U;
   const int nwork = nfull + (f > 1 ? r * f : 0);
   const int bid = blockIdx.x;
 
   if (bid >= nwork) {
-    // ---- store-only role: zero rows + zero BN partials of the dead windows (forward calls)
-    const int z = (int)gridDim.x - 1 - bid;
-    if (p.out_len || p.out_f32 || z >= (p.MT + kPpZeroWin - 1) / kPpZeroWin) return;
-    for (int m = z * kPpZeroWin; m < (z + 1) * kPpZeroWin && m < p.MT; ++m) {
-      const int b = m / p.mtiles_per_b, j = m - b * p.mtiles_per_b;
-      if (j < __shfl(nw, b, 64)) continue;
-      const int t0 = j * BM, rows = min(BM, p.Tout - t0);
-      if (!p.accumulate) {
-        bf16_t* const yb = reinterpret_cast<bf16_t*>(p.y) + (long long)b * p.y_sb;
-        const int c8n = p.Cout >> 3;
-        const u32x4 zv = {0u, 0u, 0u, 0u};
-        for (int e = tid; e < rows * c8n; e += 512) {
-          const int row = e / c8n, c8 = e - row * c8n;
-          u32x4 v = zv;
-          if (p.residual)
-            v = *reinterpret_cast<const u32x4*>(p.residual + (long long)b * p.y_sb +
-                                                (long long)(t0 + row) * p.y_st + c8 * 8);
-          *reinterpret_cast<u32x4*>(yb + (long long)(t0 + row) * p.y_st + c8 * 8) = v;
-        }
-      }
-      if (p.stats)
-        for (int e = tid; e < 2 * p.Cout; e += 512) p.stats[(long long)m * 2 * p.Cout + e] = 0.f;
-    }
+    pp_zero_role(p, nw, (int)gridDim.x - 1 - bid, tid);
     return;
   }
 
@@ -608,6 +688,245 @@ __global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
   conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow ping-pong tile: NWIN (2 or 3) live 128-row windows x 128 output channels per workgroup.
+//
+// Why it exists: the unit of the 256-column tile is (window pair, 256 columns) — a ragged Jasper batch
+// of ~146 live windows gives 146 units for the 384 / 512-channel layers and 219 for the 640 / 768-channel
+// ones on 256 CUs, and the 384 / 640 / 896-channel layers pay for half a tile of dead columns. Pieces of
+// a reduction split cost a 256 KB fp32 partial tile each (measured: slower, DESIGN round 3). The narrow
+// tiles own DISJOINT outputs instead: 3 windows x 128 columns = 0.75 of a unit (196 / 245 units for
+// 512 / 640 channels), 2 x 128 = 0.5 (219 units for 384 channels, 511 = two full rounds for 896).
+//
+// Wave layout: 8 waves = 4 row groups (wr) x 2 column halves (wc); wave (wr, wc) owns the 32-row
+// fragments wr*NWIN .. wr*NWIN + NWIN-1 of the 4*NWIN fragments of the tile (a fragment lies in ONE
+// window; with three windows a wave straddles two) x 64 columns: NWIN x 2 accumulator tiles, 96 / 64
+// registers. Waves 0-3 (row groups 0, 1) are group A, waves 4-7 group B; wave w and w + 4 share a SIMD.
+//
+// Two slots per 64-deep step (the 256-column kernel has four): in one slot a wave fetches ALL fragments
+// of its next step (8 weight + 4*NWIN window reads), drains the LDS-DMA it issued one step ago, issues
+// the DMA of the step two ahead; in the other it issues its 8*NWIN MFMAs (768 / 512 matrix-pipe
+// cycles) while its SIMD partner loads. The weight tile [128 x 64] is read by both groups one slot
+// apart and refilled two steps ahead: ring of THREE (16 KB each). X windows: double-buffered per
+// 64-channel chunk as in the 256-column kernel, one instruction per wave and step during the first
+// taps of the previous chunk. A window image is R = 128 + (K-1)*dil rows; when R is 4 mod 8 the last
+// 8-row DMA instruction of a window runs with lanes 32-63 masked off, so three windows of K = 21
+// (148 rows) fit next to the weight ring (162 816 of the 163 840 bytes).
+// No reduction split: these tiles are chosen when they give whole rounds of equal units.
+// ---------------------------------------------------------------------------------------------
+template <int NWIN>
+__device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem) {
+  constexpr int BM = 128, BN = 128, WM = 4, WN = 2, MI = NWIN, NI = 2;
+  constexpr int WTILE = BN * 128;                     // one weight tile: 128 rows x 64 k (bf16)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wr = wid >> 1, wc = wid & 1;
+  const int P = (L + NWIN - 1) / NWIN;
+  const int NT = (p.Cout + BN - 1) / BN;
+  const int nwork = P * NT;
+  const int bid = blockIdx.x;
+  if (bid >= nwork) {
+    pp_zero_role(p, nw, (int)gridDim.x - 1 - bid, tid);
+    return;
+  }
+  // ---- unit rank -> (window group, n-tile): consecutive workgroups (= the XCDs round-robin) hold
+  // different window groups, the n-tiles of one group follow each other on one XCD ---------------
+  int xcd, loc;
+  {
+    const int P8 = (P + 7) >> 3, rem = P - 8 * (P8 - 1), base = (P8 - 1) * NT * 8;
+    if (bid < base) { xcd = bid & 7; loc = bid >> 3; }
+    else { const int i = bid - base; loc = (P8 - 1) * NT + i / rem; xcd = i - (i / rem) * rem; }
+  }
+  const int wgrp = (loc / NT) * 8 + xcd;
+  const int n_idx = loc - (loc / NT) * NT;
+  const int n0 = n_idx * BN;
+  int wb[NWIN], wt0[NWIN], wmid[NWIN];
+  // per-window buffer descriptor and first-row offset of the X staging. Always indexed by a
+  // COMPILE-TIME window number (stage_x is instantiated per window): a runtime index would put the
+  // arrays into scratch and the descriptor into a waterfall loop
+  __amdgpu_buffer_rsrc_t xrs[NWIN];
+  int xrow0[NWIN];
+#pragma unroll
+  for (int w = 0; w < NWIN; ++w) {
+    const int i = NWIN * wgrp + w;
+    const bool live = i < L;
+    const int b = live ? __builtin_popcountll(__ballot(scan <= i)) : 0;
+    const int before = b > 0 ? __shfl(scan, b - 1, 64) : 0;
+    wb[w] = b;
+    wt0[w] = live ? (i - before) * BM : 0;
+    int len_b = p.Tin;
+    if (p.in_len) {
+      const int l = p.in_len[b];
+      len_b = l < 0 ? 0 : (l < p.Tin ? l : p.Tin);
+    }
+    wmid[w] = live ? b * p.mtiles_per_b + (i - before) : -1;
+    const bf16_t* xb = p.x + (long long)b * p.x_sb;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)xb);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)xb >> 32));
+    // dead slot: num_records = 0, every row reads as zero
+    const int bytes = __builtin_amdgcn_readfirstlane((live ? len_b : 0) * (int)p.x_st * 2);
+    xrs[w] = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+    xrow0[w] = __builtin_amdgcn_readfirstlane((wt0[w] - p.padL) * (int)p.x_st * 2);   // stride 1
+  }
+
+  // ---- LDS: X windows [2 chunks][NWIN][win_bytes] | weight ring [3][16 KB] ---------------------
+  const int rbw = (p.R + 7) >> 3;                     // 8-row DMA instructions per window
+  const bool half = (p.R & 7) != 0 && (p.R & 7) <= 4; // the last one covers 4 rows only
+  const int win_bytes = (half ? rbw * 8 - 4 : rbw * 8) * 128;
+  const int xbuf_bytes = NWIN * win_bytes;
+  char* const xbuf0 = smem;
+  char* const wbuf0 = smem + 2 * xbuf_bytes;
+  const int npw = (rbw + 7) >> 3;                     // X instructions per wave per window and chunk
+  const int nxi = NWIN * npw;                         // ... per wave and chunk (launcher: K > nxi)
+
+  // X DMA: instruction n = m * NWIN + w of a chunk issued by wave wid covers row group rb = wid + 8 m of
+  // window w (8 rows x 128 B); per-lane byte offset inside the group: row (lane >> 3), 16-B slot
+  // jj ^ swizzle(row), swizzle term (row >> 1) & 7 flips bit 2 for odd rb. Rows before the sequence
+  // start give a negative (= huge unsigned) offset, rows past in_len lie past num_records: zeros.
+  const int xlane = (lane >> 3) * (int)p.x_st * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  const int xgrp_bytes = __builtin_amdgcn_readfirstlane(8 * (int)p.x_st * 2);
+  auto stage_xw = [&](auto WIN, int c, int m) {
+    constexpr int w = decltype(WIN)::value;
+    const int rb = wid + 8 * m;
+    if (rb >= rbw) return;                            // wave-uniform
+    char* const dst = xbuf0 + (c & 1) * xbuf_bytes + w * win_bytes + rb * 1024;
+    const int vo = (xlane ^ ((rb & 1) << 6)) + xrow0[w] + rb * xgrp_bytes;
+    const int soff = __builtin_amdgcn_readfirstlane(c * 128);
+    if (half && rb == rbw - 1) {
+      if (lane < 32)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[w], (__attribute__((address_space(3))) void*)dst, 16, vo, soff, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[w], (__attribute__((address_space(3))) void*)dst, 16, vo, soff, 0, 0);
+    }
+  };
+  auto stage_x = [&](int c, int n) {                  // n = 0 .. nxi-1
+    const int m = n / NWIN, w = n - m * NWIN;
+    if (w == 0) stage_xw(std::integral_constant<int, 0>{}, c, m);
+    else if (w == 1) stage_xw(std::integral_constant<int, 1>{}, c, m);
+    else if constexpr (NWIN > 2) stage_xw(std::integral_constant<int, 2>{}, c, m);
+  };
+  // weight tile rows handled by this lane (2 DMA instructions of 8 rows per wave and step)
+  // the weight descriptor is rebuilt per step from three values parked in VGPRs (opaque to the
+  // compiler): left to itself it re-reads p.w from the kernel-argument segment in every LOAD slot
+  // (SGPRs are short here) and the s_waitcnt lgkmcnt(0) behind that s_load also waits for the 20
+  // fragment reads just issued, before the first DMA instruction of the slot can go out
+  unsigned wlo_v = (unsigned)(unsigned long long)p.w, whi_v = (unsigned)((unsigned long long)p.w >> 32);
+  unsigned wbytes_v = (unsigned)((long long)p.K * p.Cout * p.Cin * 2);
+  asm volatile("" : "+v"(wlo_v), "+v"(whi_v), "+v"(wbytes_v));
+  int wsrc[2];
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    const int row = (pi * 8 + wid) * 8 + (lane >> 3), jj = lane & 7;
+    const int j = jj ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < p.Cout ? n : p.Cout - 1;
+    wsrc[pi] = (n * p.Cin + j * 8) * 2;
+  }
+  const int w_kstride = __builtin_amdgcn_readfirstlane(p.Cout * p.Cin * 2);
+  auto stage_w = [&](int c, int k, int buf) {
+    const int soff = __builtin_amdgcn_readfirstlane(k * w_kstride + c * 128);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)__builtin_amdgcn_readfirstlane(whi_v) << 32) | __builtin_amdgcn_readfirstlane(wlo_v)),
+        0, (int)__builtin_amdgcn_readfirstlane(wbytes_v), 0x00020000);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(wbuf0 + buf * WTILE + (pi * 8 + wid) * 1024), 16,
+          wsrc[pi], soff, 0, 0);
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int im = 0; im < MI; ++im)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[in][im][e] = 0.f;
+
+  const int nsteps = p.nchunks * p.K;
+  {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int n = 0; n < nxi; ++n) stage_x(0, n);
+    stage_w(0, 0, 0);
+    if (nsteps > 1) stage_w(p.K > 1 ? 0 : 1, p.K > 1 ? 1 : 0, 1);
+    // weight fragment offsets: row = wc*64 + in*32 + l31 of the tile, fixed for the kernel
+    int woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      woff[kk] = (wc * 64 + l31) * 128 + (((kk * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4);
+    // X fragment im = rows (wr*MI + im)*32 .. +31 of the tile: window (f >> 2), rows (f & 3)*32 of it
+    int ximg[MI];
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      const int f = wr * MI + im;
+      ximg[im] = (f >> 2) * win_bytes + ((f & 3) * 32) * 128;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp) pp_barrier();                            // group B runs one slot behind group A
+
+    int c = 0, k = 0;     // step s
+    int cw = 0, kw = 0;   // step s + 2
+    for (int i = 0; i < 2; ++i) { if (++kw == p.K) { kw = 0; ++cw; } }
+    // LDS byte addresses of this lane's X fragments of the CURRENT step (refreshed at the end of LOAD)
+    const char* xad[MI][4];
+    auto set_xad = [&](int cc, int kk_tap) {
+      const int r0 = l31 + kk_tap * p.dil;            // row inside the 32-row fragment's window image
+      const int m = (r0 >> 1) & 7;                    // ((f&3)*32 + r0) >> 1 & 7 == (r0 >> 1) & 7
+      const char* const xrow = xbuf0 + (cc & 1) * xbuf_bytes + r0 * 128;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int sw = ((kk * 2 + lhi) ^ m) << 4;
+#pragma unroll
+        for (int im = 0; im < MI; ++im) xad[im][kk] = xrow + ximg[im] + sw;
+      }
+    };
+    set_xad(0, 0);
+    auto step = [&](auto WBUF, int s) {
+      constexpr int WB = decltype(WBUF)::value;
+      const char* const ws = wbuf0 + WB * WTILE;
+      bf16x8 wf[NI][4], xf[MI][4];
+      // ---- LOAD(s): every fragment of the step
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+          wf[in][kk] = *reinterpret_cast<const bf16x8*>(ws + woff[kk] + in * 4096);
+#pragma unroll
+        for (int im = 0; im < MI; ++im)
+          xf[im][kk] = *reinterpret_cast<const bf16x8*>(xad[im][kk]);
+      }
+      // drain what this wave issued in LOAD(s-1) (a whole step of flight time), then issue the weight
+      // tile of step s+2 (its ring slot was last read in the other group's LOAD(s-1)) and one X
+      // instruction of the next chunk; the barrier at the end of this slot publishes the drained tiles
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (s + 2 < nsteps) stage_w(cw, kw, (WB + 2) % 3);
+      if (k < nxi && c + 1 < p.nchunks) stage_x(c + 1, k);
+      if (++k == p.K) { k = 0; ++c; }
+      if (++kw == p.K) { kw = 0; ++cw; }
+      set_xad(c, k);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_barrier();
+      // ---- COMPUTE(s): nothing but MFMAs
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int in = 0; in < NI; ++in)
+#pragma unroll
+          for (int im = 0; im < MI; ++im)
+            acc[in][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in][kk], xf[im][kk], acc[in][im], 0, 0, 0);
+      pp_barrier();
+    };
+    for (int s = 0; s < nsteps; s += 3) {
+      step(std::integral_constant<int, 0>{}, s);
+      if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+      if (s + 2 < nsteps) step(std::integral_constant<int, 2>{}, s + 2);
+    }
+    if (!grp) pp_barrier();
+  }
+  conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
+}
+
 constexpr int kConvBM = 128, kConvBN = 128;
 
 template <int BM, int BN, int WM, int WN, int NWIN, bool XSINGLE = false>
@@ -641,7 +960,19 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
 // (stride 1, Cin a multiple of 64, K long enough to spread the X prefetch, B <= 64, LDS budget).
 // workspace = [1024 int32 tickets, zero on entry and on exit][fp32 partial tiles]; without one
 // the tail of the launch is not split.
-static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size_t workspace_bytes) {
+static float g_pp_cost[3] = {1.18f, 0.62f, 0.80f};   // fitted us per 64-deep step: 2x256, 2x128, 3x128 tile
+
+// LDS bytes of the narrow tile's main loop (ppn_body): X windows double-buffered + weight ring of 3
+static size_t ppn_main_bytes(int nwin, int R) {
+  const int rbw = (R + 7) / 8;
+  const bool half = (R & 7) != 0 && (R & 7) <= 4;
+  const size_t win = (size_t)(half ? rbw * 8 - 4 : rbw * 8) * 128;
+  return 2 * nwin * win + (size_t)3 * 128 * 128;
+}
+
+// tile: -1 = chosen on the device (pp_choose_tile), 0 / 2 / 3 = forced (2 / 3 fall back to 0 when the
+// narrow tile does not fit the layer)
+static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size_t workspace_bytes, int tile) {
   constexpr int BM = 128, BN = kPpBN, NWIN = 2, NTHR = 512;
   if (a.stride != 1 || a.Cin % 64 != 0 || a.out_f32 || a.B > 64) return OS2S_ERR_UNSUPPORTED;
   a.mtiles_per_b = ceil_div(a.Tout, BM);
@@ -655,10 +986,27 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   if (a.K <= nxi) return OS2S_ERR_UNSUPPORTED;
   const bool dbg = a.dbg != nullptr || a.dbg_fixed_w;
   const size_t main_bytes = (size_t)4 * a.Rpad * 128 + (size_t)2 * BN * 128 + 1024 + (dbg ? 2 * 48 * 9 * 8 : 0);
-  constexpr size_t kOP = BN * 2 + 16;
   const size_t epi_bytes = conv_epilogue_lds_bytes<BM, BN, NWIN, NTHR>();
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
   if (smem > 160 * 1024) return OS2S_ERR_UNSUPPORTED;
+  // ---- narrow tiles (ppn_body): K must spread the X prefetch of a chunk, LDS must hold the images;
+  // no dropout in the epilogue of the three-window tile (conv_epilogue, STRADDLE)
+  const int npw = (ceil_div(a.R, 8) + 7) / 8;
+  size_t smem_n = 0;
+  a.pp_ok2 = a.pp_ok3 = 0;
+  if (!dbg && a.Cout >= 128 && tile != 0) {
+    const size_t m2 = ppn_main_bytes(2, a.R), e2 = conv_epilogue_lds_bytes<BM, 128, 2, NTHR>();
+    const size_t m3 = ppn_main_bytes(3, a.R), e3 = conv_epilogue_lds_bytes<BM, 128, 3, NTHR>();
+    // (a cost of 1e6 or more takes a narrow tile out of the candidates: A/B runs)
+    if (tile != 3 && a.K > 2 * npw && m2 <= 160 * 1024 && e2 <= 160 * 1024 && (tile == 2 || g_pp_cost[1] < 1e6f)) a.pp_ok2 = 1;
+    if (tile != 2 && a.K > 3 * npw && m3 <= 160 * 1024 && e3 <= 160 * 1024 && a.keep_prob >= 1.f &&
+        (tile == 3 || g_pp_cost[2] < 1e6f)) a.pp_ok3 = 1;
+    if (a.pp_ok2) smem_n = std::max(smem_n, std::max(m2, e2));
+    if (a.pp_ok3) smem_n = std::max(smem_n, std::max(m3, e3));
+  }
+  if ((tile == 2 && !a.pp_ok2) || (tile == 3 && !a.pp_ok3)) tile = 0;
+  a.pp_tile = tile;
+  a.pp_c256 = g_pp_cost[0]; a.pp_c2 = g_pp_cost[1]; a.pp_c3 = g_pp_cost[2];
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   static int ncu = 256;
@@ -667,6 +1015,9 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_rc == hipSuccess)
       attr_rc = hipFuncSetAttribute((const void*)conv1d_pp_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc == hipSuccess)
+      attr_rc = hipFuncSetAttribute((const void*)conv1d_ppn_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -684,16 +1035,21 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
     const size_t cap = (size_t)3 * ncu;
     a.ws_nslabs = (int)(n < cap ? n : cap);
   }
-  // upper bound of the grid (the live-window count is only known on the device): every unit of
-  // the padded batch + the pieces of a split tail + the store-only workgroups; surplus
-  // workgroups exit at once
-  const int umax = ceil_div(a.MT, NWIN) * a.NT;
+  // upper bound of each grid (the live-window count — and with it the tile — is only known on the
+  // device): every unit of the padded batch + the pieces of a split tail + the store-only workgroups;
+  // surplus workgroups exit at once
   const int nzero = a.out_len ? 0 : ceil_div(a.MT, kPpZeroWin);
-  const int grid = umax + a.ws_nslabs + nzero;
-  if (dbg) {
-    OS2S_LAUNCH(conv1d_pp_kernel<true>, dim3(grid), dim3(NTHR), smem, stream, a);
-  } else {
-    OS2S_LAUNCH(conv1d_pp_kernel<false>, dim3(grid), dim3(NTHR), smem, stream, a);
+  if (tile <= 0) {
+    const int grid = ceil_div(a.MT, NWIN) * a.NT + a.ws_nslabs + nzero;
+    if (dbg) {
+      OS2S_LAUNCH(conv1d_pp_kernel<true>, dim3(grid), dim3(NTHR), smem, stream, a);
+    } else {
+      OS2S_LAUNCH(conv1d_pp_kernel<false>, dim3(grid), dim3(NTHR), smem, stream, a);
+    }
+  }
+  if (tile != 0 && (a.pp_ok2 || a.pp_ok3)) {
+    const int grid = ceil_div(a.MT, 2) * ceil_div(a.Cout, 128) + nzero;
+    OS2S_LAUNCH(conv1d_ppn_kernel, dim3(grid), dim3(NTHR), smem_n, stream, a);
   }
   return OS2S_OK;
 }
@@ -708,7 +1064,8 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
 //     rows to fill the chip, else the 128 x 128 tile (single-buffered X window for K >= 8).
 // os2s_conv1d_set_variant(v >= 0) forces a tile for experiments and tests:
 //   0 = 128x128, X window double-buffered   3 = 128x128, X window single-buffered when K >= 8
-//   5 = 256x256 lockstep                   10 = ping-pong
+//   5 = 256x256 lockstep                   10 = ping-pong (tile chosen on the device)
+//   12 / 13 = ping-pong, 2 / 3 windows x 128 columns   14 = ping-pong, 2 windows x 256 columns
 // experiment knob read once from the environment (A/B runs on one box: tools/bench_conv_split.py)
 static int env_int(const char* name, int dflt) {
   static std::mutex mu;
@@ -727,6 +1084,13 @@ static unsigned long long* g_conv_dbg = nullptr;
 static int g_conv_fixed_w = 0;
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
 extern "C" void os2s_conv1d_set_split(int f) { g_conv_split = f; }
+// fitted microseconds per 64-deep step of the three ping-pong tiles (2 x 256, 2 x 128, 3 x 128): the
+// constants of the device-side tile choice (tools/bench_conv_shapes.py refits them)
+extern "C" void os2s_conv1d_set_pp_cost(float c256, float c2x128, float c3x128) {
+  if (c256 > 0.f) os2s::g_pp_cost[0] = c256;
+  if (c2x128 > 0.f) os2s::g_pp_cost[1] = c2x128;
+  if (c3x128 > 0.f) os2s::g_pp_cost[2] = c3x128;
+}
 // experiment hook (tools/pp_timeline.py): device buffer of 4*2*48*9 uint64 slot time stamps;
 // fixed_w = every step streams the weight tile of step 0 (always an L2 hit)
 extern "C" void os2s_conv1d_set_debug(void* stamps, int fixed_w) {
@@ -795,9 +1159,10 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
     if (rc != OS2S_ERR_UNSUPPORTED) return rc;
   }
   if (v == 11) v = 10;
-  if (v == 10) {
-    // the dense-residual / accumulate epilogue variants are all supported by the ping-pong kernel
-    const int rc = launch_conv_pp(st, a, workspace, workspace_bytes);
+  if (v == 10 || (v >= 12 && v <= 14)) {
+    // the dense-residual / accumulate epilogue variants are all supported by the ping-pong kernel;
+    // 10: tile chosen on the device, 12 / 13: two / three windows x 128 columns, 14: two windows x 256
+    const int rc = launch_conv_pp(st, a, workspace, workspace_bytes, v == 10 ? -1 : (v == 14 ? 0 : v - 10));
     if (rc != OS2S_ERR_UNSUPPORTED) return rc;
     v = K >= 8 ? 3 : 0;
     if (g_conv_variant < 0 && Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;

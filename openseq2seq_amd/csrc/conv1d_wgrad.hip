@@ -501,6 +501,10 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
     }
   };
 
+  // taps past K (the last tap quad of K = 4n + 1 ... 4n + 3: every Jasper layer has K = 4n + 1) are
+  // not computed: their fragment reads and MFMAs are skipped (wave-uniform), the wave keeps its DMA
+  // duties and its barriers. A quad with one live tap then costs about a third less than a full one.
+  const bool live0 = k0 + 2 * grp < p.K, live1 = k0 + 2 * grp + 1 < p.K;
   f32x16 acc[2][2][2];                                     // [tap of the pair][i][j]
 #pragma unroll
   for (int e = 0; e < 2; ++e)
@@ -555,38 +559,44 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
       // ---- LOAD(2s): also the table entry of step s+2 (consumed in the odd slot)
       int ent_v;
       asm volatile("ds_read_b32 %0, %1" : "=v"(ent_v) : "v"(tab0 + (s + 2 < nsteps ? s + 2 : s) * 4) : "memory");
+      if (live0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        yf[i][0] = lds_frag<0>(ys + ya[i]); yf[i][1] = lds_frag<1>(ys + ya[i]);
-        yf[i][2] = lds_frag<2>(ys + ya[i]); yf[i][3] = lds_frag<3>(ys + ya[i]);
-      }
+        for (int i = 0; i < 2; ++i) {
+          yf[i][0] = lds_frag<0>(ys + ya[i]); yf[i][1] = lds_frag<1>(ys + ya[i]);
+          yf[i][2] = lds_frag<2>(ys + ya[i]); yf[i][3] = lds_frag<3>(ys + ya[i]);
+        }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        xf[j][0] = lds_frag<0>(xs + xa[0][j]); xf[j][1] = lds_frag<1>(xs + xa[0][j]);
-        xf[j][2] = lds_frag<2>(xs + xa[0][j]); xf[j][3] = lds_frag<3>(xs + xa[0][j]);
+        for (int j = 0; j < 2; ++j) {
+          xf[j][0] = lds_frag<0>(xs + xa[0][j]); xf[j][1] = lds_frag<1>(xs + xa[0][j]);
+          xf[j][2] = lds_frag<2>(xs + xa[0][j]); xf[j][3] = lds_frag<3>(xs + xa[0][j]);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       stamp(s, 0);
       wpp_barrier();
       stamp(s, 1);
       // ---- COMPUTE(2s)
+      if (live0) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[0][i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+              acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[0][i][j], 0, 0, 0);
+      }
       stamp(s, 2);
       wpp_barrier();
       stamp(s, 3);
       // ---- LOAD(2s+1): X fragments of the second tap; then drain the DMA issued one step ago
       //      and issue step s+2 (X slot (s+2) % 3 was last read one step ago, the dY slot in the
       //      even slots of this step)
+      if (live1) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        xf[j][0] = lds_frag<0>(xs + xa[1][j]); xf[j][1] = lds_frag<1>(xs + xa[1][j]);
-        xf[j][2] = lds_frag<2>(xs + xa[1][j]); xf[j][3] = lds_frag<3>(xs + xa[1][j]);
+        for (int j = 0; j < 2; ++j) {
+          xf[j][0] = lds_frag<0>(xs + xa[1][j]); xf[j][1] = lds_frag<1>(xs + xa[1][j]);
+          xf[j][2] = lds_frag<2>(xs + xa[1][j]); xf[j][3] = lds_frag<3>(xs + xa[1][j]);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(s, 4); }
@@ -602,13 +612,15 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
       wpp_barrier();
       stamp(s, 7);
       // ---- COMPUTE(2s+1)
+      if (live1) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[1][i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j)
+              acc[1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[1][i][j], 0, 0, 0);
+      }
       stamp(s, 8);
       wpp_barrier();
       stamp(s, 9);

@@ -193,10 +193,14 @@ PP_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pp", [10, 12, 13, 14])
 @pytest.mark.parametrize("use_ws", [True, False])
 @pytest.mark.parametrize("B,T,Cin,Cout,K,d", PP_CASES)
-def test_conv_pingpong_kernel(cuda, use_ws, B, T, Cin, Cout, K, d):
-  """The ping-pong kernel (conv1d_pp_kernel) forced on Jasper-shaped layers with ragged lengths
+def test_conv_pingpong_kernel(cuda, pp, use_ws, B, T, Cin, Cout, K, d):
+  """pp = os2s_conv1d_set_variant: 10 = tile chosen on the device, 12 / 13 = the narrow tiles (2 / 3 live
+  windows x 128 columns, conv1d_ppn_kernel; a layer they do not fit falls back to 14), 14 = 2 windows x 256
+  columns.
+  The ping-pong kernel (conv1d_pp_kernel) forced on Jasper-shaped layers with ragged lengths
   (dead windows, odd live-window counts), with a workspace (the tail of the launch is split over
   the input channels and reduced by the last arriver) and without: forward + BN partial sums
   (dead windows must read as zero rows / zero partials) vs the fp32 oracle, and the
@@ -220,7 +224,7 @@ def test_conv_pingpong_kernel(cuda, use_ws, B, T, Cin, Cout, K, d):
   wT = w_dev.flip(0).permute(0, 2, 1).contiguous()
   _, pl = capi.same_padding(T, K, 1, d)
   dym = _bf(dy.float() * mask)
-  _lib.lib().os2s_conv1d_set_variant(10)
+  _lib.lib().os2s_conv1d_set_variant(pp)
   try:
     y = torch.full((B, T, Cout), 5.0, dtype=torch.bfloat16, device=cuda)
     capi.conv1d_fwd(x.to(cuda), w_dev.to(cuda), dil=d, in_len=lens.to(cuda), stats=stats, out=y,
@@ -284,6 +288,47 @@ def test_conv_pingpong_full_size_vs_lockstep_tile(cuda, ragged):
   a, b = outs["pp_ws"][0].float(), outs["tile"][0].float()
   assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max())
   torch.testing.assert_close(outs["pp_ws"][1].sum(0), outs["tile"][1].sum(0), rtol=1e-3, atol=1e-1)
+
+
+@pytest.mark.parametrize("C,K", [(384, 13), (512, 17), (640, 21), (768, 25)])
+def test_conv_narrow_pingpong_tiles_full_size_bit_identical(cuda, C, K):
+  """The narrow ping-pong tiles (2 / 3 live windows x 128 columns: conv1d_ppn_kernel) at the Jasper block
+  shapes, B = 32, ragged: they own disjoint outputs and accumulate in the (chunk, tap) order of the
+  oracle-checked 128x128 tile, so outputs AND BatchNorm partial sums are BIT-IDENTICAL to it — for every
+  live window count modulo 2 and 3 (the last window group of a launch is partly dead), for the
+  148-row window image of K = 21 whose last DMA instruction is half masked, and for the layer the
+  three-window tile does not fit (K = 25: falls back to the 256-column tile). Also the tile chosen on
+  the device (variant 10) and the data-gradient call with out_len."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(C + K)
+  B, T = 32, 840
+  x = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  w = _bf(torch.randn(K, C, C, generator=g) * (1.0 / (K * C) ** 0.5)).to(cuda)
+  nm = capi.conv1d_num_mtiles(B, T)
+  for trial in range(3):
+    lens = torch.randint(100, T + 1, (B,), generator=g).to(torch.int32)
+    lens[3] = T
+    lens[5] = 1 + trial          # a sample of one window with a single live row
+    lens = lens.to(cuda)
+    outs = {}
+    try:
+      for name, v in (("tile", 3), ("n2", 12), ("n3", 13), ("auto", 10)):
+        _lib.lib().os2s_conv1d_set_variant(v)
+        st = torch.full((nm, 2, C), float("nan"), device=cuda)
+        y = torch.full((B, T, C), 3.0, dtype=torch.bfloat16, device=cuda)
+        capi.conv1d_fwd(x, w, in_len=lens, stats=st, out=y)
+        dx = torch.full((B, T, C), 7.0, dtype=torch.bfloat16, device=cuda)
+        capi.conv1d_fwd(x, w, pad_left=(K - 1) // 2, tout=T, in_len=lens, out_len=lens, out=dx)
+        torch.cuda.synchronize()
+        outs[name] = (y, st, dx)
+    finally:
+      _lib.lib().os2s_conv1d_set_variant(-1)
+    live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])[:, :, None]
+    for name in ("n2", "n3", "auto"):
+      assert torch.equal(outs[name][0], outs["tile"][0]), (name, trial)
+      assert torch.equal(outs[name][1], outs["tile"][1]), (name, trial)
+      # data gradient: rows below out_len (rows past it are don't-care)
+      assert torch.equal(outs[name][2] * live, outs["tile"][2] * live), (name, trial)
 
 
 @pytest.mark.parametrize("B,T,Cin,Cout,K,d", [(3, 420, 256, 512, 17, 1), (2, 333, 320, 640, 21, 1),

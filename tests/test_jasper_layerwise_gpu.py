@@ -321,9 +321,12 @@ def test_jasper10x5_layer_pairs_fused_bn_backward(cuda, monkeypatch):
 GRAD_TOL_3LAYER = 8e-3
 
 
+@pytest.mark.parametrize("pp", [-1, 12, 13])
 @pytest.mark.parametrize("C,K,dil", [(640, 21, 1), (768, 13, 2), (384, 13, 1)])
-def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, monkeypatch, C, K, dil):
-  """accumulate = True in the fused epilogue: layer A (plain conv + BN + ReLU, stride 1) feeds a residual
+def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, monkeypatch, C, K, dil, pp):
+  """pp: os2s_conv1d_set_variant for the whole pass (-1 = default, 12 / 13 = the narrow ping-pong tiles of
+  2 / 3 windows x 128 columns wherever a layer fits them — the fused epilogue on the straddling wave layout).
+  accumulate = True in the fused epilogue: layer A (plain conv + BN + ReLU, stride 1) feeds a residual
   block of two repeats — its first repeat's main convolution AND the block end's 1 x 1 residual branch.
   The residual branch's data gradient reaches A's output gradient first (the block end runs first in
   backward); the first repeat's data gradient is the LAST contribution and adds
@@ -367,12 +370,17 @@ def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, 
   monkeypatch.setattr(te, "conv_bn_res_bn_actv", recording_block)
   store.zero_grads()
   tape = Tape()
-  e = enc.encode({"source_tensors": [x0.to(cuda), lens.to(cuda)], "tape": tape, "seed": 3})
-  out = e["outputs_act"]
-  dy = torch.randn(out.data.shape, generator=g).to(torch.bfloat16)
-  out.grad = dy.to(cuda)
-  tape.backward()
-  torch.cuda.synchronize()
+  from openseq2seq_amd import _lib
+  _lib.lib().os2s_conv1d_set_variant(pp)
+  try:
+    e = enc.encode({"source_tensors": [x0.to(cuda), lens.to(cuda)], "tape": tape, "seed": 3})
+    out = e["outputs_act"]
+    dy = torch.randn(out.data.shape, generator=g).to(torch.bfloat16)
+    out.grad = dy.to(cuda)
+    tape.backward()
+    torch.cuda.synchronize()
+  finally:
+    _lib.lib().os2s_conv1d_set_variant(-1)
   # two fused calls: block end -> repeat 1's output (fresh), repeat 1 -> layer A's output (accumulating)
   from openseq2seq_amd.parts.cnns import conv_blocks
   assert calls == ([False, True] if conv_blocks.FUSE_BN_BWD else []), calls
