@@ -72,7 +72,7 @@ def parse():
                   help="profiling aid: run only the Transformer-big measurement")
   ap.add_argument("--no-kernel-timing", action="store_true")
   ap.add_argument("--pp-cost", default=None,
-                  help="A/B aid: 'c256,c2x128,c3x128' = microseconds per step of the three ping-pong convolution "
+                  help="A/B aid: 'c256,c2x128,c3x128[,dgrad_penalty[,prio]]' (os2s_set_option conv1d.pp_*) = microseconds per step of the three ping-pong convolution "
                        "tiles in the device-side tile choice (os2s_conv1d_set_pp_cost; 1e6 removes a tile)")
   ap.add_argument("--one-rank-group", action="store_true",
                   help="N=1 only: run the data-parallel path (RCCL process group, bucketed all-reduce on "
@@ -994,10 +994,12 @@ def main():
   if args.pp_cost:
     import ctypes
     from openseq2seq_amd import _lib
-    c = [float(v) for v in args.pp_cost.split(",")]
-    f = _lib.lib().os2s_conv1d_set_pp_cost
-    f.argtypes, f.restype = [ctypes.c_float] * 3, None
-    f(*c)
+    f = _lib.lib().os2s_set_option
+    f.argtypes, f.restype = [ctypes.c_char_p, ctypes.c_double], ctypes.c_int
+    names = ["conv1d.pp_cost_256", "conv1d.pp_cost_2x128", "conv1d.pp_cost_3x128", "conv1d.pp_dgrad_penalty",
+             "conv1d.pp_prio"]
+    for n, v in zip(names, args.pp_cost.split(",")):
+      assert f(n.encode(), float(v)) == 0
   if rank == 0 and world > 1:
     print("bench.py: %d ranks, backend %s (RCCL), one process per GPU" % (
         world, torch.distributed.get_backend()), file=sys.stderr)

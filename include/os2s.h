@@ -160,9 +160,15 @@ int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
  * device from the live-window count: 2 windows x 256 columns, or 2 / 3 windows x 128 columns;
  * 12 / 13 / 14 = ping-pong with the 2 x 128 / 3 x 128 / 2 x 256 tile forced */
 void os2s_conv1d_set_variant(int v);
-/* fitted microseconds per 64-deep step of the three ping-pong tiles (2 x 256, 2 x 128, 3 x 128
- * windows x columns) — the constants of the device-side tile choice; values <= 0 keep the default */
-void os2s_conv1d_set_pp_cost(float c256, float c2x128, float c3x128);
+/* Named tuning options (test / measurement aid; nothing in the library reads the environment for them):
+ *   conv1d.pp_cost_256, conv1d.pp_cost_2x128, conv1d.pp_cost_3x128: fitted microseconds per 64-deep step
+ *     of the three ping-pong convolution tiles — the constants of the device-side tile choice; a cost
+ *     >= 1e6 removes a narrow tile from the candidates
+ *   conv1d.pp_dgrad_penalty: factor on the narrow tiles' cost in data-gradient launches (out_len given:
+ *     they share the chip with the weight-gradient stream)
+ *   conv1d.pp_prio: 1 = the loading wave of a narrow-tile slot runs at s_setprio 2
+ * Returns 0, or -1 for an unknown name. */
+int os2s_set_option(const char* name, double value);
 /* experiment / test hook for the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers):
  * 0 (default) and 1 = lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows
  * whenever its envelope allows (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as

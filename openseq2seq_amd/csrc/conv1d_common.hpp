@@ -47,7 +47,9 @@ struct ConvArgs {
   // pp_ok2 / pp_ok3: the narrow tiles fit this layer (LDS, K), pp_cost = fitted microseconds per
   // 64-deep step of the three tiles (the device-side choice is a pure function of these and in_len).
   int pp_tile = 0, pp_ok2 = 0, pp_ok3 = 0;
-  float pp_c256 = 1.18f, pp_c2 = 0.62f, pp_c3 = 0.80f;
+  float pp_c256 = 1.19f, pp_c2 = 0.90f, pp_c3 = 1.06f;
+  int pp_prio = 0;              // experiment: the loading wave of a ping-pong slot runs at s_setprio 2
+  float pp_dgrad_pen = 1.f;     // factor on the narrow tiles' cost in data-gradient launches (out_len given)
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {

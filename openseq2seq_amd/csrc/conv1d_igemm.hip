@@ -34,6 +34,7 @@
 #include "conv1d_common.hpp"
 #include "os2s_split_reduce.hpp"
 #include <algorithm>
+#include <string>
 #include <array>
 #include <type_traits>
 #include <map>
@@ -359,14 +360,17 @@ __device__ __forceinline__ int pp_choose_tile(const ConvArgs& p, const int L) {
   }
   int tile = 0;
   const int NT128 = (p.Cout + 127) >> 7;
+  // data-gradient launches share the chip with the weight-gradient stream: what counts there is CU time,
+  // not the length of the launch alone — the narrow tiles' cost carries a penalty factor
+  const float pen = p.out_len ? p.pp_dgrad_pen : 1.f;
   if (p.pp_ok2) {
     const int U = ((L + 1) >> 1) * NT128;
-    const float t = (float)((U + G - 1) / G) * (p.pp_c2 * S + 9.f);
+    const float t = pen * (float)((U + G - 1) / G) * (p.pp_c2 * S + 9.f);
     if (t < 0.97f * best) { best = t; tile = 2; }
   }
   if (p.pp_ok3) {
     const int U = ((L + 2) / 3) * NT128;
-    const float t = (float)((U + G - 1) / G) * (p.pp_c3 * S + 10.f);
+    const float t = pen * (float)((U + G - 1) / G) * (p.pp_c3 * S + 10.f);
     if (t < 0.97f * best) { best = t; tile = 3; }
   }
   return tile;
@@ -374,7 +378,7 @@ __device__ __forceinline__ int pp_choose_tile(const ConvArgs& p, const int L) {
 
 template <bool DBG>
 __device__ __forceinline__ void pp256_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem);
-template <int NWIN>
+template <int NWIN, bool DBG>
 __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem);
 
 // live windows per sample (one value per lane), inclusive scan over the batch in `scan`
@@ -422,14 +426,15 @@ __global__ __launch_bounds__(512, 2) void conv1d_pp_kernel(ConvArgs p) {
   pp256_body<DBG>(p, L, scan, nw, smem);
 }
 
+template <bool DBG>
 __global__ __launch_bounds__(512, 2) void conv1d_ppn_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int scan;
   const int nw = pp_live_windows(p, threadIdx.x & 63, scan);
   const int L = __builtin_amdgcn_readlane(scan, 63);
   const int tile = __builtin_amdgcn_readfirstlane(pp_choose_tile(p, L));
-  if (tile == 2) ppn_body<2>(p, L, scan, nw, smem);
-  else if (tile == 3) ppn_body<3>(p, L, scan, nw, smem);
+  if (tile == 2) ppn_body<2, DBG>(p, L, scan, nw, smem);
+  else if (tile == 3) ppn_body<3, DBG>(p, L, scan, nw, smem);
 }
 
 template <bool DBG>
@@ -714,7 +719,8 @@ __device__ __forceinline__ void pp256_body(const ConvArgs& p, const int L, const
 // (148 rows) fit next to the weight ring (162 816 of the 163 840 bytes).
 // No reduction split: these tiles are chosen when they give whole rounds of equal units.
 // ---------------------------------------------------------------------------------------------
-template <int NWIN>
+constexpr int kPpnDbgSteps = 24;                     // DBG: recorded steps (9 stamps each, waves 0 and 4)
+template <int NWIN, bool DBG>
 __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const int scan, const int nw, char* smem) {
   constexpr int BM = 128, BN = 128, WM = 4, WN = 2, MI = NWIN, NI = 2;
   constexpr int WTILE = BN * 128;                     // one weight tile: 128 rows x 64 k (bf16)
@@ -744,8 +750,10 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
   // per-window buffer descriptor and first-row offset of the X staging. Always indexed by a
   // COMPILE-TIME window number (stage_x is instantiated per window): a runtime index would put the
   // arrays into scratch and the descriptor into a waterfall loop
-  __amdgpu_buffer_rsrc_t xrs[NWIN];
-  int xrow0[NWIN];
+  // per-window words of the X buffer descriptors (base, bytes) and first-row offsets, as NAMED scalars: the
+  // descriptor of an instruction is assembled from arithmetic selects of these (see prep_x)
+  unsigned xlo0 = 0, xlo1 = 0, xlo2 = 0, xhi0 = 0, xhi1 = 0, xhi2 = 0;
+  int xby0 = 0, xby1 = 0, xby2 = 0, xr0a = 0, xr0b = 0, xr0c = 0;
 #pragma unroll
   for (int w = 0; w < NWIN; ++w) {
     const int i = NWIN * wgrp + w;
@@ -765,8 +773,10 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)xb >> 32));
     // dead slot: num_records = 0, every row reads as zero
     const int bytes = __builtin_amdgcn_readfirstlane((live ? len_b : 0) * (int)p.x_st * 2);
-    xrs[w] = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-    xrow0[w] = __builtin_amdgcn_readfirstlane((wt0[w] - p.padL) * (int)p.x_st * 2);   // stride 1
+    const int row0 = __builtin_amdgcn_readfirstlane((wt0[w] - p.padL) * (int)p.x_st * 2);   // stride 1
+    if (w == 0) { xlo0 = lo; xhi0 = hi; xby0 = bytes; xr0a = row0; }
+    if (w == 1) { xlo1 = lo; xhi1 = hi; xby1 = bytes; xr0b = row0; }
+    if (w == 2) { xlo2 = lo; xhi2 = hi; xby2 = bytes; xr0c = row0; }
   }
 
   // ---- LDS: X windows [2 chunks][NWIN][win_bytes] | weight ring [3][16 KB] ---------------------
@@ -785,26 +795,41 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
   // start give a negative (= huge unsigned) offset, rows past in_len lie past num_records: zeros.
   const int xlane = (lane >> 3) * (int)p.x_st * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
   const int xgrp_bytes = __builtin_amdgcn_readfirstlane(8 * (int)p.x_st * 2);
-  auto stage_xw = [&](auto WIN, int c, int m) {
-    constexpr int w = decltype(WIN)::value;
+  // An X instruction is PREPARED (window, row group, LDS destination, per-lane offset, half mask) in
+  // one place and ISSUED in another: in the main loop the preparation rides between the MFMAs of the
+  // wave's COMPUTE slot, the LOAD slot only carries s_mov m0 + buffer_load (see the slot budget below).
+  // Plain scalars, no struct / array: hipcc turns those into scratch accesses whose vmcnt wait in the
+  // COMPUTE slot would also wait for the LDS-DMA in flight.
+  int x_dst = 0, x_soff = 0, x_vo = 0, x_by = 0;
+  unsigned x_lo = 0, x_hi = 0;
+  bool x_keep = false;                                // per lane: this lane takes part in the instruction
+  auto prep_x = [&](int c, int n, bool on) __attribute__((always_inline)) {   // n = 0 .. nxi-1: window n % NWIN, row group wid + 8 (n / NWIN)
+    const int m = n / NWIN;
+    const int w = n - m * NWIN;
     const int rb = wid + 8 * m;
-    if (rb >= rbw) return;                            // wave-uniform
-    char* const dst = xbuf0 + (c & 1) * xbuf_bytes + w * win_bytes + rb * 1024;
-    const int vo = (xlane ^ ((rb & 1) << 6)) + xrow0[w] + rb * xgrp_bytes;
-    const int soff = __builtin_amdgcn_readfirstlane(c * 128);
-    if (half && rb == rbw - 1) {
-      if (lane < 32)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[w], (__attribute__((address_space(3))) void*)dst, 16, vo, soff, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[w], (__attribute__((address_space(3))) void*)dst, 16, vo, soff, 0, 0);
-    }
+    // the last 8-row group of a 4-mod-8 window image is written by lanes 0-31 only
+    x_keep = on && rb < rbw && !(half && rb == rbw - 1 && lane >= 32);
+    x_dst = (c & 1) * xbuf_bytes + w * win_bytes + rb * 1024;
+    x_soff = c * 128;
+    // (arithmetic, not a select of the captured variables: hipcc turns that into a select of their
+    // ADDRESSES and keeps the whole closure in scratch)
+    const int s0 = w == 0, s1 = w == 1, s2 = w >= 2;
+    x_lo = xlo0 * s0 + xlo1 * s1 + xlo2 * s2;
+    x_hi = xhi0 * s0 + xhi1 * s1 + xhi2 * s2;
+    x_by = xby0 * s0 + xby1 * s1 + xby2 * s2;
+    const int r0 = xr0a * s0 + xr0b * s1 + xr0c * s2;
+    x_vo = (xlane ^ ((rb & 1) << 6)) + r0 + rb * xgrp_bytes;
   };
-  auto stage_x = [&](int c, int n) {                  // n = 0 .. nxi-1
-    const int m = n / NWIN, w = n - m * NWIN;
-    if (w == 0) stage_xw(std::integral_constant<int, 0>{}, c, m);
-    else if (w == 1) stage_xw(std::integral_constant<int, 1>{}, c, m);
-    else if constexpr (NWIN > 2) stage_xw(std::integral_constant<int, 2>{}, c, m);
+  auto issue_x = [&]() __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(x_hi) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(x_lo)),
+        0, __builtin_amdgcn_readfirstlane(x_by), 0x00020000);
+    if (x_keep)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(xbuf0 + x_dst), 16, x_vo,
+                                               __builtin_amdgcn_readfirstlane(x_soff), 0, 0);
   };
+  auto stage_x = [&](int c, int n) __attribute__((always_inline)) { prep_x(c, n, true); issue_x(); };
   // weight tile rows handled by this lane (2 DMA instructions of 8 rows per wave and step)
   // the weight descriptor is rebuilt per step from three values parked in VGPRs (opaque to the
   // compiler): left to itself it re-reads p.w from the kernel-argument segment in every LOAD slot
@@ -823,17 +848,22 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
     wsrc[pi] = (n * p.Cin + j * 8) * 2;
   }
   const int w_kstride = __builtin_amdgcn_readfirstlane(p.Cout * p.Cin * 2);
-  auto stage_w = [&](int c, int k, int buf) {
-    const int soff = __builtin_amdgcn_readfirstlane(k * w_kstride + c * 128);
+  auto stage_w_at = [&](int soff_in, int buf) __attribute__((always_inline)) {
+    const int soff = __builtin_amdgcn_readfirstlane(soff_in);
+    // (readfirstlane returns int: without the unsigned casts a low word with bit 31 set sign-extends
+    // over the high word of the base address)
+    const unsigned wlo = (unsigned)__builtin_amdgcn_readfirstlane(wlo_v);
+    const unsigned whi = (unsigned)__builtin_amdgcn_readfirstlane(whi_v);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(((unsigned long long)__builtin_amdgcn_readfirstlane(whi_v) << 32) | __builtin_amdgcn_readfirstlane(wlo_v)),
-        0, (int)__builtin_amdgcn_readfirstlane(wbytes_v), 0x00020000);
+        (void*)(((unsigned long long)whi << 32) | (unsigned long long)wlo), 0,
+        (int)__builtin_amdgcn_readfirstlane(wbytes_v), 0x00020000);
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           wrs, (__attribute__((address_space(3))) void*)(wbuf0 + buf * WTILE + (pi * 8 + wid) * 1024), 16,
           wsrc[pi], soff, 0, 0);
   };
+  auto stage_w = [&](int c, int k, int buf) __attribute__((always_inline)) { stage_w_at(k * w_kstride + c * 128, buf); };
 
   f32x16 acc[NI][MI];
 #pragma unroll
@@ -870,7 +900,7 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
     for (int i = 0; i < 2; ++i) { if (++kw == p.K) { kw = 0; ++cw; } }
     // LDS byte addresses of this lane's X fragments of the CURRENT step (refreshed at the end of LOAD)
     const char* xad[MI][4];
-    auto set_xad = [&](int cc, int kk_tap) {
+    auto set_xad = [&](int cc, int kk_tap) __attribute__((always_inline)) {
       const int r0 = l31 + kk_tap * p.dil;            // row inside the 32-row fragment's window image
       const int m = (r0 >> 1) & 7;                    // ((f&3)*32 + r0) >> 1 & 7 == (r0 >> 1) & 7
       const char* const xrow = xbuf0 + (cc & 1) * xbuf_bytes + r0 * 128;
@@ -882,32 +912,77 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
       }
     };
     set_xad(0, 0);
-    auto step = [&](auto WBUF, int s) {
+    // DBG: s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py): 0 first read batch
+    // issued, 1 DMA drained, 2 DMA issued, 3 second read batch issued, 4 arithmetic done, 5 reads
+    // landed, 6 barrier passed (MFMAs start), 7 MFMAs issued, 8 barrier passed
+    unsigned long long* const tl = reinterpret_cast<unsigned long long*>(wbuf0 + 3 * WTILE);
+    const bool rec = DBG && p.dbg && bid < 4 && lane == 0 && (wid & 3) == 0;
+    auto stamp = [&](int s, int i) __attribute__((always_inline)) {
+      if (DBG && rec && s >= 8 && s < 8 + kPpnDbgSteps) tl[(grp * kPpnDbgSteps + s - 8) * 9 + i] = __builtin_readcyclecounter();
+    };
+    // Slot budget. While a wave's SIMD partner issues its MFMAs back to back, the loading wave gets
+    // roughly one instruction out per MFMA (ppn timeline, tools/ppn_timeline.py): a LOAD slot of ~100
+    // instructions (20 fragment reads, DMA issue with its address arithmetic, the (c, k) counters, 12
+    // fragment addresses of the next step) ran 920-1060 cycles next to 768 cycles of MFMAs. So the LOAD
+    // slot carries only what must be there — the reads, the drain, s_mov m0 + buffer_load per DMA — and
+    // everything that PREPARES the next LOAD slot (counters, DMA operands, fragment addresses) is issued
+    // by the computing wave between its own MFMAs (5 issue slots per 32-cycle MFMA are free there).
+    // pp_prio: the loading wave raises its priority for the slot (its few instructions go out at once).
+    int w_soff = kw * w_kstride + cw * 128;           // weight DMA of the NEXT load slot (step s + 2)
+    prep_x(1, 0, 1 < p.nchunks);                      // X DMA of the next load slot
+    auto step = [&](auto WBUF, int s) __attribute__((always_inline)) {
       constexpr int WB = decltype(WBUF)::value;
       const char* const ws = wbuf0 + WB * WTILE;
       bf16x8 wf[NI][4], xf[MI][4];
-      // ---- LOAD(s): every fragment of the step
+      if (DBG) {                                      // (the timing-only modes skip the reads)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-        for (int in = 0; in < NI; ++in)
-          wf[in][kk] = *reinterpret_cast<const bf16x8*>(ws + woff[kk] + in * 4096);
+          for (int in = 0; in < NI; ++in) wf[in][kk] = bf16x8{};
 #pragma unroll
-        for (int im = 0; im < MI; ++im)
-          xf[im][kk] = *reinterpret_cast<const bf16x8*>(xad[im][kk]);
+          for (int im = 0; im < MI; ++im) xf[im][kk] = bf16x8{};
+        }
       }
+      // ---- LOAD(s)
+      if (p.pp_prio) __builtin_amdgcn_s_setprio(2);
+      const bool rd = !(DBG && (p.dbg_fixed_w & 4)) || s < 2;
+      if (rd) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int in = 0; in < NI; ++in)
+            wf[in][kk] = *reinterpret_cast<const bf16x8*>(ws + woff[kk] + in * 4096);
+          xf[0][kk] = *reinterpret_cast<const bf16x8*>(xad[0][kk]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(s, 0);
       // drain what this wave issued in LOAD(s-1) (a whole step of flight time), then issue the weight
       // tile of step s+2 (its ring slot was last read in the other group's LOAD(s-1)) and one X
       // instruction of the next chunk; the barrier at the end of this slot publishes the drained tiles
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (s + 2 < nsteps) stage_w(cw, kw, (WB + 2) % 3);
-      if (k < nxi && c + 1 < p.nchunks) stage_x(c + 1, k);
-      if (++k == p.K) { k = 0; ++c; }
-      if (++kw == p.K) { kw = 0; ++cw; }
-      set_xad(c, k);
+      stamp(s, 1);
+      if (!(DBG && (p.dbg_fixed_w & 2))) {
+        if (s + 2 < nsteps) stage_w_at(w_soff, (WB + 2) % 3);
+        issue_x();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(s, 2);
+      if (rd) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int im = 1; im < MI; ++im)
+            xf[im][kk] = *reinterpret_cast<const bf16x8*>(xad[im][kk]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stamp(s, 3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(s, 5);
+      if (p.pp_prio) __builtin_amdgcn_s_setprio(0);
       pp_barrier();
-      // ---- COMPUTE(s): nothing but MFMAs
+      stamp(s, 6);
+      // ---- COMPUTE(s): the MFMAs, and between them the preparation of LOAD(s+1)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -915,7 +990,22 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
 #pragma unroll
           for (int im = 0; im < MI; ++im)
             acc[in][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[in][kk], xf[im][kk], acc[in][im], 0, 0, 0);
+      if (++k == p.K) { k = 0; ++c; }
+      if (++kw == p.K) { kw = 0; ++cw; }
+      w_soff = kw * w_kstride + cw * 128;
+      prep_x(c + 1, k, k < nxi && c + 1 < p.nchunks);
+      set_xad(c, k);
+      // one MFMA, then up to two vector and three scalar instructions of the preparation, and so on
+#pragma unroll
+      for (int i = 0; i < MI * NI * 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+      }
+      if (DBG) __builtin_amdgcn_sched_barrier(0);
+      stamp(s, 7);
       pp_barrier();
+      stamp(s, 8);
     };
     for (int s = 0; s < nsteps; s += 3) {
       step(std::integral_constant<int, 0>{}, s);
@@ -923,6 +1013,10 @@ __device__ __forceinline__ void ppn_body(const ConvArgs& p, const int L, const i
       if (s + 2 < nsteps) step(std::integral_constant<int, 2>{}, s + 2);
     }
     if (!grp) pp_barrier();
+    if (DBG && p.dbg && bid < 4) {
+      __syncthreads();
+      for (int i = tid; i < 2 * kPpnDbgSteps * 9; i += 512) p.dbg[bid * 2 * kPpnDbgSteps * 9 + i] = tl[i];
+    }
   }
   conv_epilogue<BM, BN, WM, WN, NWIN>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
 }
@@ -960,7 +1054,13 @@ static int launch_conv(hipStream_t stream, ConvArgs& a) {
 // (stride 1, Cin a multiple of 64, K long enough to spread the X prefetch, B <= 64, LDS budget).
 // workspace = [1024 int32 tickets, zero on entry and on exit][fp32 partial tiles]; without one
 // the tail of the launch is not split.
-static float g_pp_cost[3] = {1.18f, 0.62f, 0.80f};   // fitted us per 64-deep step: 2x256, 2x128, 3x128 tile
+static int g_pp_prio = 0;
+// fitted us per 64-deep step of the 2x256, 2x128, 3x128 tile (tools/bench_conv_shapes.py on the bench batch:
+// 0.261 / 0.232 ms for 640 channels K = 21, 0.091 / 0.066 for 384 K = 13, 0.611 / 0.724 for 896 K = 29) and the
+// data-gradient penalty: >= 100 keeps the narrow tiles out of data-gradient launches altogether — next to the
+// weight-gradient stream what counts is CU time, and a narrow tile needs 10-19 % MORE of it per output
+// (measured: Jasper step 40.6 -> 42.0 ms with the narrow tiles in backward, 39.16 -> 39.05 forward only)
+static float g_pp_cost[4] = {1.19f, 0.90f, 1.06f, 1000.f};
 
 // LDS bytes of the narrow tile's main loop (ppn_body): X windows double-buffered + weight ring of 3
 static size_t ppn_main_bytes(int nwin, int R) {
@@ -984,7 +1084,10 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   a.Rpad = ceil_div(a.R, 8) * 8;
   const int nxi = (a.Rpad / 8 + 3) / 4;
   if (a.K <= nxi) return OS2S_ERR_UNSUPPORTED;
-  const bool dbg = a.dbg != nullptr || a.dbg_fixed_w;
+  const bool dbg_any = a.dbg != nullptr || a.dbg_fixed_w;
+  const bool dbg_n = dbg_any && (tile == 2 || tile == 3);     // stamps of the narrow tile (forced)
+  const bool dbg = dbg_any && !dbg_n;
+  const size_t dbg_n_bytes = dbg_n ? (size_t)2 * kPpnDbgSteps * 9 * 8 : 0;
   const size_t main_bytes = (size_t)4 * a.Rpad * 128 + (size_t)2 * BN * 128 + 1024 + (dbg ? 2 * 48 * 9 * 8 : 0);
   const size_t epi_bytes = conv_epilogue_lds_bytes<BM, BN, NWIN, NTHR>();
   const size_t smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
@@ -994,9 +1097,10 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   const int npw = (ceil_div(a.R, 8) + 7) / 8;
   size_t smem_n = 0;
   a.pp_ok2 = a.pp_ok3 = 0;
-  if (!dbg && a.Cout >= 128 && tile != 0) {
-    const size_t m2 = ppn_main_bytes(2, a.R), e2 = conv_epilogue_lds_bytes<BM, 128, 2, NTHR>();
-    const size_t m3 = ppn_main_bytes(3, a.R), e3 = conv_epilogue_lds_bytes<BM, 128, 3, NTHR>();
+  const bool no_narrow = tile < 0 && a.out_len != nullptr && g_pp_cost[3] >= 100.f;
+  if (!dbg && a.Cout >= 128 && tile != 0 && !no_narrow) {
+    const size_t m2 = ppn_main_bytes(2, a.R) + dbg_n_bytes, e2 = conv_epilogue_lds_bytes<BM, 128, 2, NTHR>();
+    const size_t m3 = ppn_main_bytes(3, a.R) + dbg_n_bytes, e3 = conv_epilogue_lds_bytes<BM, 128, 3, NTHR>();
     // (a cost of 1e6 or more takes a narrow tile out of the candidates: A/B runs)
     if (tile != 3 && a.K > 2 * npw && m2 <= 160 * 1024 && e2 <= 160 * 1024 && (tile == 2 || g_pp_cost[1] < 1e6f)) a.pp_ok2 = 1;
     if (tile != 2 && a.K > 3 * npw && m3 <= 160 * 1024 && e3 <= 160 * 1024 && a.keep_prob >= 1.f &&
@@ -1006,7 +1110,8 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   }
   if ((tile == 2 && !a.pp_ok2) || (tile == 3 && !a.pp_ok3)) tile = 0;
   a.pp_tile = tile;
-  a.pp_c256 = g_pp_cost[0]; a.pp_c2 = g_pp_cost[1]; a.pp_c3 = g_pp_cost[2];
+  a.pp_c256 = g_pp_cost[0]; a.pp_c2 = g_pp_cost[1]; a.pp_c3 = g_pp_cost[2]; a.pp_dgrad_pen = g_pp_cost[3];
+  a.pp_prio = g_pp_prio;
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   static int ncu = 256;
@@ -1017,7 +1122,10 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
       attr_rc = hipFuncSetAttribute((const void*)conv1d_pp_kernel<true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_rc == hipSuccess)
-      attr_rc = hipFuncSetAttribute((const void*)conv1d_ppn_kernel,
+      attr_rc = hipFuncSetAttribute((const void*)conv1d_ppn_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_rc == hipSuccess)
+      attr_rc = hipFuncSetAttribute((const void*)conv1d_ppn_kernel<true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
@@ -1049,7 +1157,11 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
   }
   if (tile != 0 && (a.pp_ok2 || a.pp_ok3)) {
     const int grid = ceil_div(a.MT, 2) * ceil_div(a.Cout, 128) + nzero;
-    OS2S_LAUNCH(conv1d_ppn_kernel, dim3(grid), dim3(NTHR), smem_n, stream, a);
+    if (dbg_n) {
+      OS2S_LAUNCH(conv1d_ppn_kernel<true>, dim3(grid), dim3(NTHR), smem_n, stream, a);
+    } else {
+      OS2S_LAUNCH(conv1d_ppn_kernel<false>, dim3(grid), dim3(NTHR), smem_n, stream, a);
+    }
   }
   return OS2S_OK;
 }
@@ -1084,15 +1196,27 @@ static unsigned long long* g_conv_dbg = nullptr;
 static int g_conv_fixed_w = 0;
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
 extern "C" void os2s_conv1d_set_split(int f) { g_conv_split = f; }
-// fitted microseconds per 64-deep step of the three ping-pong tiles (2 x 256, 2 x 128, 3 x 128): the
-// constants of the device-side tile choice (tools/bench_conv_shapes.py refits them)
-extern "C" void os2s_conv1d_set_pp_cost(float c256, float c2x128, float c3x128) {
-  if (c256 > 0.f) os2s::g_pp_cost[0] = c256;
-  if (c2x128 > 0.f) os2s::g_pp_cost[1] = c2x128;
-  if (c3x128 > 0.f) os2s::g_pp_cost[2] = c3x128;
+// Named tuning options of the convolution launchers (one entry point instead of one exported setter
+// per knob; nothing here is read from the environment or per launch):
+//   conv1d.pp_cost_256 / .pp_cost_2x128 / .pp_cost_3x128   fitted microseconds per 64-deep step of the three
+//       ping-pong tiles — the constants of the device-side tile choice (tools/bench_conv_shapes.py refits
+//       them); a cost >= 1e6 removes a narrow tile from the candidates
+//   conv1d.pp_dgrad_penalty   factor on the narrow tiles' cost in data-gradient launches (out_len given)
+//   conv1d.pp_prio            1: the loading wave of a narrow-tile slot runs at s_setprio 2
+// Returns 0, or -1 for an unknown name.
+extern "C" int os2s_set_option(const char* name, double value) {
+  if (!name) return -1;
+  const std::string k(name);
+  if (k == "conv1d.pp_cost_256") { os2s::g_pp_cost[0] = (float)value; return 0; }
+  if (k == "conv1d.pp_cost_2x128") { os2s::g_pp_cost[1] = (float)value; return 0; }
+  if (k == "conv1d.pp_cost_3x128") { os2s::g_pp_cost[2] = (float)value; return 0; }
+  if (k == "conv1d.pp_dgrad_penalty") { os2s::g_pp_cost[3] = (float)value; return 0; }
+  if (k == "conv1d.pp_prio") { os2s::g_pp_prio = (int)value; return 0; }
+  return -1;
 }
-// experiment hook (tools/pp_timeline.py): device buffer of 4*2*48*9 uint64 slot time stamps;
-// fixed_w = every step streams the weight tile of step 0 (always an L2 hit)
+// experiment hook (tools/pp_timeline.py, tools/ppn_timeline.py): device buffer of slot time stamps;
+// fixed_w (256-column tile) = every step streams the weight tile of step 0 (always an L2 hit); narrow
+// tiles: bit 1 = no DMA issue in the loop, bit 2 = no fragment reads in the loop (timing only)
 extern "C" void os2s_conv1d_set_debug(void* stamps, int fixed_w) {
   g_conv_dbg = (unsigned long long*)stamps;
   g_conv_fixed_w = fixed_w;

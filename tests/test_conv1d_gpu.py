@@ -274,7 +274,9 @@ def test_conv_pingpong_full_size_vs_lockstep_tile(cuda, ragged):
   nm = capi.conv1d_num_mtiles(B, T)
   outs = {}
   try:
-    for name, v, ws in (("tile", 3, False), ("pp", 10, False), ("pp_ws", 10, True), ("pp_ws2", 10, True)):
+    # 14 = the 256-column ping-pong tile (10 lets the device choose: a narrow tile reduces the
+    # BatchNorm partials in another fp32 grouping, see test_conv_narrow_pingpong_tiles_full_size_bit_identical)
+    for name, v, ws in (("tile", 3, False), ("pp", 14, False), ("pp_ws", 14, True), ("pp_ws2", 14, True)):
       _lib.lib().os2s_conv1d_set_variant(v)
       st = torch.full((nm, 2, C), float("nan"), device=cuda)
       y = capi.conv1d_fwd(x, w, in_len=lens, stats=st, use_workspace=ws)
@@ -294,7 +296,8 @@ def test_conv_pingpong_full_size_vs_lockstep_tile(cuda, ragged):
 def test_conv_narrow_pingpong_tiles_full_size_bit_identical(cuda, C, K):
   """The narrow ping-pong tiles (2 / 3 live windows x 128 columns: conv1d_ppn_kernel) at the Jasper block
   shapes, B = 32, ragged: they own disjoint outputs and accumulate in the (chunk, tap) order of the
-  oracle-checked 128x128 tile, so outputs AND BatchNorm partial sums are BIT-IDENTICAL to it — for every
+  oracle-checked 128x128 tile, so outputs are BIT-IDENTICAL to it (BatchNorm partial sums: equal up to the
+  fp32 grouping of a window's rows) — for every
   live window count modulo 2 and 3 (the last window group of a launch is partly dead), for the
   148-row window image of K = 21 whose last DMA instruction is half masked, and for the layer the
   three-window tile does not fit (K = 25: falls back to the 256-column tile). Also the tile chosen on
@@ -325,8 +328,16 @@ def test_conv_narrow_pingpong_tiles_full_size_bit_identical(cuda, C, K):
       _lib.lib().os2s_conv1d_set_variant(-1)
     live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])[:, :, None]
     for name in ("n2", "n3", "auto"):
-      assert torch.equal(outs[name][0], outs["tile"][0]), (name, trial)
-      assert torch.equal(outs[name][1], outs["tile"][1]), (name, trial)
+      if name == "auto" or (name == "n3" and K > 21):    # (K = 25: the three-window tile does not fit)
+        # the device may pick the 256-column tile with a split tail: fp32 summation order of the split
+        # units differs (bf16 outputs within 1 ulp = 2^-8 relative)
+        a, b = outs[name][0].float(), outs["tile"][0].float()
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(b.abs().max()), (name, trial)
+      else:
+        assert torch.equal(outs[name][0], outs["tile"][0]), (name, trial)
+      # BatchNorm partials: the narrow tiles sum a window's 128 rows in 8 row groups of 16 (512 threads
+      # over 64 column pairs), the 128x128 tile in 4 groups of 32: same values, other fp32 grouping
+      torch.testing.assert_close(outs[name][1], outs["tile"][1], rtol=2e-5, atol=1e-3)
       # data gradient: rows below out_len (rows past it are don't-care)
       assert torch.equal(outs[name][2] * live, outs["tile"][2] * live), (name, trial)
 

@@ -7,6 +7,8 @@ import numpy as np
 import torch
 from openseq2seq_amd import capi, _lib
 dev = torch.device("cuda:0")
+_lib.lib().os2s_set_option.argtypes = [_lib.ctypes.c_char_p, _lib.ctypes.c_double]
+_lib.lib().os2s_set_option(b"conv1d.pp_prio", float(os.environ.get("OS2S_PP_PRIO", "0")))
 B, T = 32, 840
 shapes = [(256, 256, 11), (256, 384, 13), (384, 384, 13), (384, 512, 17), (512, 512, 17), (512, 640, 21),
           (640, 640, 21), (640, 768, 25), (768, 768, 25), (768, 896, 29)]
