@@ -887,18 +887,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer_param_gra
   return dx
 
 
-def dropout_bwd(dout, keep_prob, seed=0, out=None):
-  """mode 0 (hash mask) when out is None, mode 1 (relu+dropout via saved output) otherwise."""
+def dropout_bwd(dout, keep_prob, seed=0, out=None, capped=False):
+  """mode 0 (hash mask) when out is None, mode 1 (relu+dropout via saved output) otherwise; capped: mode 2,
+  the saved output is dropout(min(relu(.), 20)) — no gradient at the cap either."""
   d = torch.empty_like(dout)
   f = _fn("os2s_dropout_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll,
                                c_void_p))
   _lib.check(f(_stream(), _ptr(dout, torch.bfloat16), _ptr(out, torch.bfloat16, True),
-               0 if out is None else 1, float(keep_prob), int(seed) & (2**64 - 1),
+               0 if out is None else (2 if capped else 1), float(keep_prob), int(seed) & (2**64 - 1),
                dout.numel(), _ptr(d)), "os2s_dropout_bwd")
   return d
 
 
-def dropout_bwd_colsum(dout2d, keep_prob, seed=0, out=None):
+def dropout_bwd_colsum(dout2d, keep_prob, seed=0, out=None, capped=False):
   """dropout_bwd on a [rows, C] matrix + partial column sums of the result ([nparts, 2, C] fp32,
   plane 0; reduce with bn_bwd_finalize(q=1)): returns (d, partial)."""
   rows, C = dout2d.shape
@@ -909,8 +910,8 @@ def dropout_bwd_colsum(dout2d, keep_prob, seed=0, out=None):
   f = _fn("os2s_dropout_bwd_colsum", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll, c_int,
                                       c_void_p, c_void_p))
   _lib.check(f(_stream(), _ptr(dout2d, torch.bfloat16), _ptr(out, torch.bfloat16, True),
-               0 if out is None else 1, float(keep_prob), int(seed) & (2**64 - 1), rows, C, _ptr(d),
-               _ptr(partial)), "os2s_dropout_bwd_colsum")
+               0 if out is None else (2 if capped else 1), float(keep_prob), int(seed) & (2**64 - 1), rows, C,
+               _ptr(d), _ptr(partial)), "os2s_dropout_bwd_colsum")
   return d, partial
 
 

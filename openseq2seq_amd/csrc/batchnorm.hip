@@ -173,14 +173,17 @@ struct BnActArgs {
   bf16_t* out;
   const int32_t* out_len;  // [B] or null: rows t >= out_len[b] are zeroed
   int B, T, C;
-  int act;                 // 0 none, 1 relu, 2 tanh
+  int act;                 // 0 none, 1 relu, 2 tanh, 3 relu capped at 20 (min(relu(x), 20): the clipped
+                           // ReLU of the reference's DeepSpeech2 / Wave2Letter configs)
   float keep_prob;         // 1.0 = no dropout
   unsigned long long seed;
 };
 
+constexpr float kReluCap = 20.f;
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return v > 0.f ? v : 0.f;
   if (act == 2) return tanhf(v);
+  if (act == 3) return fminf(fmaxf(v, 0.f), kReluCap);
   return v;
 }
 
@@ -429,6 +432,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
   const int c0 = cg * 8;
   const int rowb = p.C * 2;
   const float inv_keep = 1.f / p.keep_prob;
+  // a capped output as stored: bf16(20 / keep) (values at or above it took no gradient)
+  const float cap_out = bflo(pack2bf(kReluCap * inv_keep, 0.f));
   float sd[8];
   float sx[J_MAX][8];
 #pragma unroll
@@ -496,6 +501,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(BnBwdReduceArgs 
           if (p.keep_prob < 1.f) gsc = ((keep >> e) & 1u) ? inv_keep : 0.f;
           float dact = 1.f;
           if (p.act == 1) dact = ov[e] > 0.f ? 1.f : 0.f;
+          else if (p.act == 3) dact = (ov[e] > 0.f && ov[e] < cap_out) ? 1.f : 0.f;
           else if (p.act == 2) {
             const float th = ov[e] * p.keep_prob;  // tanh(z) of a kept element
             dact = 1.f - th * th;

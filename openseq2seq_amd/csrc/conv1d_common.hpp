@@ -20,7 +20,7 @@ struct ConvArgs {
   int out_f32, accumulate;
   int mtiles_per_b, MT, MT8, NT, nchunks, R, Rpad;
   // fused epilogue: y = residual + dropout(act(acc + bias))
-  int act;                      // 0 none, 1 relu
+  int act;                      // 0 none, 1 relu, 3 relu capped at 20
   float keep_prob;              // 1 = no dropout
   unsigned long long seed;
   const bf16_t* residual;       // same layout/strides as y (bf16 output only) or null
@@ -182,6 +182,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p,
         }
         if (p.act == 1) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        } else if (p.act == 3) {      // min(relu(x), 20)
+          v0 = fminf(fmaxf(v0, 0.f), 20.f); v1 = fminf(fmaxf(v1, 0.f), 20.f);
+          v2 = fminf(fmaxf(v2, 0.f), 20.f); v3 = fminf(fmaxf(v3, 0.f), 20.f);
         }
         if constexpr (decltype(DROP)::value) {
           // same (seed, element index / 8) convention as the elementwise kernels

@@ -1244,7 +1244,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
   using namespace os2s;
   if (mask_ref) OS2S_REQUIRE(!residual && !out_f32 && act == 0 && keep_prob == 1.f && !bias);
   if (stat_ref) OS2S_REQUIRE(mask_ref && stats);
-  OS2S_REQUIRE(act == 0 || act == 1);
+  OS2S_REQUIRE(act == 0 || act == 1 || act == 3);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
   if (out_f32) OS2S_REQUIRE(act == 0 && keep_prob == 1.f && residual == nullptr);
   OS2S_REQUIRE(x && w && y);

@@ -440,7 +440,7 @@ static int gemm_nt_impl(os2s_stream_t stream, const uint16_t* A, long long lda, 
   using namespace os2s;
   OS2S_REQUIRE(A && W && C && M >= 1 && N >= 1 && K >= 64 && K % 64 == 0);
   OS2S_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N);
-  OS2S_REQUIRE(act == 0 || act == 1);
+  OS2S_REQUIRE(act == 0 || act == 1 || act == 3);
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
   if (out_f32) OS2S_REQUIRE(act == 0 && keep_prob == 1.f && residual == nullptr);
   if (!out_f32) OS2S_REQUIRE(N % 8 == 0 && ldc % 8 == 0);

@@ -309,7 +309,8 @@ __global__ __launch_bounds__(64 * kLnWaves) void layernorm_bwd_kernel(
 // ---------------------------------------------------------------------------
 // dropout backward helpers
 // ---------------------------------------------------------------------------
-// mode 0: d = dout * keepmask/keep (mask from the hash);  mode 1: d = dout * (out > 0)/keep
+// mode 0: d = dout * keepmask/keep (mask from the hash);  mode 1: d = dout * (out > 0)/keep;
+// mode 2: d = dout * (0 < out < bf16(20/keep))/keep — out = dropout(min(relu(.), 20)), the clipped ReLU
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restrict__ dout,
                                                           const bf16_t* __restrict__ out, int mode,
                                                           float keep_prob, unsigned long long seed,
@@ -328,8 +329,9 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const bf16_t* __restri
       const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
       const float ov[8] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1]),
                            bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+      const float cap = mode == 2 ? bflo(pack2bf(20.f * ik, 0.f)) : __builtin_inff();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = ov[e] > 0.f ? g[e] * ik : 0.f;
+      for (int e = 0; e < 8; ++e) g[e] = (ov[e] > 0.f && ov[e] < cap) ? g[e] * ik : 0.f;
     }
     u32x4 r;
     r[0] = pack2bf(g[0], g[1]); r[1] = pack2bf(g[2], g[3]);
@@ -371,8 +373,9 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const bf16_t* _
         const u32x4 o = reinterpret_cast<const u32x4*>(out)[i];
         const float ov[8] = {bflo(o[0]), bfhi(o[0]), bflo(o[1]), bfhi(o[1]),
                              bflo(o[2]), bfhi(o[2]), bflo(o[3]), bfhi(o[3])};
+        const float cap = mode == 2 ? bflo(pack2bf(20.f * ik, 0.f)) : __builtin_inff();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ov[e] > 0.f ? g[e] * ik : 0.f;
+        for (int e = 0; e < 8; ++e) g[e] = (ov[e] > 0.f && ov[e] < cap) ? g[e] * ik : 0.f;
       }
       u32x4 rr;
       rr[0] = pack2bf(g[0], g[1]); rr[1] = pack2bf(g[2], g[3]);
@@ -680,7 +683,7 @@ extern "C" int os2s_layernorm_bwd(os2s_stream_t stream, const uint16_t* dy, cons
 extern "C" int os2s_dropout_bwd(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out,
                                 int mode, float keep_prob, unsigned long long seed, long long n,
                                 uint16_t* d) {
-  OS2S_REQUIRE(dout && d && n >= 0 && n % 8 == 0 && (mode == 0 || (mode == 1 && out)));
+  OS2S_REQUIRE(dout && d && n >= 0 && n % 8 == 0 && (mode == 0 || ((mode == 1 || mode == 2) && out)));
   if (n == 0) return OS2S_OK;
   OS2S_LAUNCH(dropout_bwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, dout,
               out, mode, keep_prob, seed, n / 8, d);
@@ -694,7 +697,7 @@ extern "C" int os2s_dropout_bwd_colsum_num_parts(long long rows) {
 extern "C" int os2s_dropout_bwd_colsum(os2s_stream_t stream, const uint16_t* dout, const uint16_t* out,
                                        int mode, float keep_prob, unsigned long long seed, long long rows,
                                        int C, uint16_t* d, float* partial) {
-  OS2S_REQUIRE(dout && d && partial && rows >= 1 && C >= 8 && C % 8 == 0 && (mode == 0 || (mode == 1 && out)));
+  OS2S_REQUIRE(dout && d && partial && rows >= 1 && C >= 8 && C % 8 == 0 && (mode == 0 || ((mode == 1 || mode == 2) && out)));
   OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f);
   int G = C / 8 < 256 ? C / 8 : 256;
   while (256 % G) --G;                      // G divides 256: whole rows of threads

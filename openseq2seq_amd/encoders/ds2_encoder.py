@@ -214,7 +214,11 @@ class DeepSpeech2Encoder(Encoder):
         x2.grad = None
 
       tape.record(backward)
-    y = self.fc.forward(x2, tape if training else None, act=1, keep=keep, seed=seeds.next())
+    # the hidden layer takes the encoder's activation (ds2_encoder.py:381-388: the clipped ReLU of the configs)
+    fc_act = act_id(self.params['activation_fn'])
+    if fc_act not in (0, 1, 3):
+      raise NotImplementedError("activation of the DeepSpeech2 hidden layer")
+    y = self.fc.forward(x2, tape if training else None, act=fc_act, keep=keep, seed=seeds.next())
     out = Act(y.data.view(B, T, -1), None)
     if training and tape is not None:
       def backward2(out=out, y=y):

@@ -169,6 +169,17 @@ class Model(object):
         func_params = {}
       if 'decay_steps' in func_params and 'decay_steps' not in lr_params:
         lr_params['decay_steps'] = self._last_step()
+        # model.py:484-490: the decay starts no earlier than the warm-up ends, and runs over what is left
+        if 'begin_decay_at' in func_params:
+          if 'warmup_steps' in func_params:
+            lr_params['begin_decay_at'] = max(lr_params.get('begin_decay_at', 0),
+                                              lr_params.get('warmup_steps', 0))
+          lr_params['decay_steps'] -= lr_params.get('begin_decay_at', 0)
+      # model.py:492-494: policies stated in epochs (piecewise_constant boundaries) get the epoch length
+      if 'steps_per_epoch' in func_params and 'steps_per_epoch' not in lr_params and 'num_epochs' in p:
+        spe = self.steps_in_epoch
+        if spe is not None:
+          lr_params['steps_per_epoch'] = spe
       self._train_op = optimize_loss(
           self._store, p['optimizer'], p.get('optimizer_params', {}), p['lr_policy'],
           lr_params, dtype=p['dtype'], clip_gradients=p.get('max_grad_norm', None),
@@ -198,6 +209,20 @@ class Model(object):
       except Exception:
         pass
     return default
+
+  @property
+  def steps_in_epoch(self):
+    """models/model.py:340-344: dataset size // (batch_size_per_gpu * workers * iter_size); None when the data
+    layer cannot tell its size (synthetic batches)."""
+    p = self._params
+    if self._data_layer is None:
+      return None
+    try:
+      n = self._data_layer.get_size_in_samples()
+    except Exception:
+      return None
+    world = self._hvd.size() if self._hvd is not None else 1
+    return n // (p['batch_size_per_gpu'] * world * p.get('iter_size', 1))
 
   @property
   def last_step(self):

@@ -98,6 +98,12 @@ class Speech2Text(EncoderDecoderModel):
     dl = self.get_data_layer()
     idx2char = dl.params['idx2char']
     dec = self.forward(batch)
+    # the eval graph's loss (the reference's eval_losses, models/speech2text_test.py:46-47)
+    self._last_eval_loss = None
+    if getattr(self, "_loss_computator", None) is not None and 'target_tensors' in batch:
+      self._last_eval_loss = self._loss_computator.compute_loss({
+          'decoder_output': dec, 'target_tensors': batch['target_tensors'], 'loss_scale_dev': None,
+          'vpad': self._decoder.Vpad})
     ids, lens = self._decoded(dec)
     pred = dense_to_chars(ids.cpu().numpy(), lens.cpu().numpy(), idx2char)
     tgt, tgt_len = batch['target_tensors']
@@ -151,13 +157,17 @@ class Speech2Text(EncoderDecoderModel):
   def evaluate(self, device=None, max_batches=None):
     """One pass over the eval data layer's files (run.py eval / train_eval): 'Eval WER'."""
     dl = self.get_data_layer()
-    results = []
+    results, losses = [], []
     for n, batch in enumerate(dl.iterate_batches(device or self._device, drop_remainder=False)):
       if max_batches is not None and n >= max_batches:
         break
       results.append(self.evaluate_batch(batch))
+      if self._last_eval_loss is not None:
+        losses.append(self._last_eval_loss)
     out = self.finalize_evaluation(results)
     out["samples_batches"] = len(results)
+    if losses:
+      out["Eval loss"] = float(sum(float(l.cpu()[0]) for l in losses) / len(losses))
     return out
 
   def _get_num_objects_per_step(self, batch):

@@ -16,15 +16,45 @@ import torch
 
 from ... import capi
 
-ACT_IDS = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+ACT_IDS = {None: 0, "none": 0, "relu": 1, "tanh": 2, "relu20": 3}
+
+
+class _Probe(object):
+  """Stand-in argument for probing a config's activation lambda under the tensorflow token module
+  (compat/tensorflow_shim.py): its functions return tokens that record their arguments."""
+  __name__ = "x"
+
+
+def _probe_activation(fn):
+  """`lambda x: tf.minimum(tf.nn.relu(x), 20.0)` — the clipped ReLU of the reference's DeepSpeech2 /
+  Wave2Letter configs (ds2_toy_config.py:79, test_speech_configs/*.py) — is recognised by calling it on a
+  probe: the token module returns minimum(relu(x), 20.0) as a tree of tokens. Returns an id or None."""
+  try:
+    r = fn(_Probe())
+  except Exception:
+    return None
+  if getattr(r, "__name__", "") != "minimum" or len(getattr(r, "args", ())) != 2:
+    return None
+  a, b = r.args
+  if isinstance(a, (int, float)):
+    a, b = b, a
+  inner = getattr(a, "__name__", "")
+  if inner == "relu" and isinstance(b, (int, float)) and float(b) == 20.0 and \
+     len(getattr(a, "args", ())) == 1 and isinstance(a.args[0], _Probe):
+    return ACT_IDS["relu20"]
+  return None
 
 
 def act_id(fn):
-  """Maps config tokens (tf.nn.relu, tf.nn.tanh, None, names) to kernel ids."""
+  """Maps config tokens (tf.nn.relu, tf.nn.tanh, None, names, the clipped-ReLU lambda) to kernel ids."""
   if fn is None:
     return 0
   name = fn if isinstance(fn, str) else getattr(fn, "__name__", str(fn))
   name = name.lower()
+  if name not in ACT_IDS and callable(fn):
+    pid = _probe_activation(fn)
+    if pid is not None:
+      return pid
   if name not in ACT_IDS:
     raise NotImplementedError("activation %r" % (fn,))
   return ACT_IDS[name]

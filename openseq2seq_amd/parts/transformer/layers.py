@@ -98,7 +98,7 @@ class Dense(object):
                                   relu=(act == 1), residual=residual.data if residual is not None else None))
     bias = self.bias.master if self.bias is not None else None
     res = residual.data if residual is not None else None
-    if self.cin % 64 == 0 and act in (0, 1) and self.cout % 8 == 0:   # what gemm_pp.hip accepts
+    if self.cin % 64 == 0 and act in (0, 1, 3) and self.cout % 8 == 0:   # what gemm_pp.hip accepts
       y = capi.gemm_nt(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
     else:
       y = capi.gemm(x.data, self.w, bias=bias, act=act, keep_prob=keep, seed=seed, residual=res)
@@ -106,7 +106,7 @@ class Dense(object):
     if tape is None:
       return out
     lin = self
-    assert not (act == 1 and residual is not None)
+    assert not (act in (1, 3) and residual is not None)
     if act == 1 and FUSE_RELU_BWD and y.is_contiguous():
       out.mask_scale = 1.0 / keep       # y = dropout(relu(.)): zero exactly where the gradient is
 
@@ -119,11 +119,12 @@ class Dense(object):
         # the consumer's data-gradient GEMM applied (y > 0) / keep in its epilogue
         dz, bias_part = dy, out.bias_part
         out.bias_part = None
-      elif act == 1:
+      elif act in (1, 3):
+        # act 3 = min(relu(.), 20): no gradient where the stored output sits at the cap either
         if fuse:
-          dz, bias_part = capi.dropout_bwd_colsum(dy, keep, out=y)
+          dz, bias_part = capi.dropout_bwd_colsum(dy, keep, out=y, capped=(act == 3))
         else:
-          dz = capi.dropout_bwd(dy, keep, out=y)         # (y > 0) / keep
+          dz = capi.dropout_bwd(dy, keep, out=y, capped=(act == 3))     # (y > 0) / keep
       elif keep < 1.0:
         if fuse:
           dz, bias_part = capi.dropout_bwd_colsum(dy, keep, seed=seed)

@@ -114,6 +114,19 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
   return a
 
 
+def _half_in_reference(p):
+  """Is this variable DT_HALF with an fp32 master twin in a mixed-precision graph of the reference? Everything
+  the mixed-precision wrapper sees (optimizers/mp_wrapper.py:55-82) — kernels AND the biases of dense / recurrent
+  layers — except the variables the reference creates as fp32 explicitly: BatchNorm gamma / beta, the row
+  convolution (encoders/ds2_encoder.py:54-57) and the LayerNorm scale / bias of the Transformer
+  (parts/transformer/common.py:48-53). The reference's own count for its toy models: 7 of 14 (DeepSpeech2),
+  6 of 14 (Wave2Letter) — models/speech2text_{ds2,w2l}_test.py."""
+  if p.kind != "vector":
+    return True
+  n = p.name
+  return (n.endswith("/bias") or n.endswith("/bias_h")) and "/bn/" not in n and "/row_conv/" not in n
+
+
 def model_variables(model):
   """{reference name: array in TF layout} for every variable of the model; dtypes as a
   reference checkpoint of the same precision mode holds them."""
@@ -123,7 +136,7 @@ def model_variables(model):
   for p in store.params:
     arr = p.master.detach().cpu().numpy()
     for tf_name, tf_arr in export_param(p.name, p.shape, p.kind, arr, getattr(p, "logical_out", None)):
-      if mixed and p.kind != "vector":
+      if mixed and _half_in_reference(p):
         # a mixed-precision graph of the reference holds this variable as DT_HALF and its fp32
         # twin under the master-copy name (optimizers/mp_wrapper.py:55-82): a plain
         # tf.train.Saver restore checks the dtype, so the plain name carries float16

@@ -118,6 +118,10 @@ def act_fn(x, act):
     return torch.relu(x)
   if act in ("tanh", 2):
     return torch.tanh(x)
+  if act in ("relu20", 3):
+    # the clipped ReLU of the reference's DeepSpeech2 / Wave2Letter configs:
+    # activation_fn = lambda x: tf.minimum(tf.nn.relu(x), 20.0)  (example_configs/speech2text/ds2_toy_config.py:79)
+    return torch.clamp(torch.relu(x), max=20.0)
   raise ValueError(act)
 
 

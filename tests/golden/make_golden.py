@@ -9,6 +9,12 @@ reference checkout (only runnable where /root/reference exists).
   ctc_test_lm.trie     <- ctc_decoder_with_lm/ctc-test-lm.trie   (1.1 KB letter trie, data)
   toy_data_lm.binary   <- open_seq2seq/test_utils/toy_speech_data/toy_data-lm.binary (7.6 KB KenLM
                           trigram model in the probing layout, data)
+  ../../open_seq2seq/test_utils/toy_speech_data/{toy_data.csv, wav_files/*.wav}
+                       <- the reference's toy speech corpus (8 WSJ utterances, 1.6 MB, data): the input of
+                          its ASR acceptance tests (models/speech2text_test.py, scripts/run_all_tests.sh:71-83).
+                          Kept at the path the reference's configs name, relative to the repository root, so
+                          that `python run.py --config_file=open_seq2seq/test_utils/test_speech_configs/...`
+                          runs as in the reference (tests/test_speech_acceptance_gpu.py).
 """
 import json
 import os
@@ -54,6 +60,14 @@ def main():
   os.chmod(os.path.join(OUT, "toy_data_lm.binary"), 0o644)
   with open(os.path.join(OUT, "ctc_test_meta.json"), "w") as f:
     json.dump(meta, f, indent=1)
+  toy_src = os.path.join(REF, "open_seq2seq", "test_utils", "toy_speech_data")
+  toy_dst = os.path.join(os.path.dirname(os.path.dirname(OUT)), "open_seq2seq", "test_utils", "toy_speech_data")
+  os.makedirs(os.path.join(toy_dst, "wav_files"), exist_ok=True)
+  shutil.copyfile(os.path.join(toy_src, "toy_data.csv"), os.path.join(toy_dst, "toy_data.csv"))
+  os.chmod(os.path.join(toy_dst, "toy_data.csv"), 0o644)
+  for w in sorted(os.listdir(os.path.join(toy_src, "wav_files"))):
+    shutil.copyfile(os.path.join(toy_src, "wav_files", w), os.path.join(toy_dst, "wav_files", w))
+    os.chmod(os.path.join(toy_dst, "wav_files", w), 0o644)
   print("wrote", OUT)
 
 

@@ -81,3 +81,37 @@ def test_baseline_configs_load_unchanged():
                                   "--mode=infer"])
   assert mod["infer_params"]["decoder"] is D.BeamSearchRNNDecoderWithAttention
   assert mod["infer_params"]["decoder_params"]["beam_width"] == 10
+
+
+def test_toy_speech_test_configs_equal_the_reference():
+  """open_seq2seq/test_utils/test_speech_configs/*.py of THIS repository restate the reference's acceptance
+  configurations (DS2 / W2L convergence tests, block-dropout runs): same dictionaries, value for value (the
+  clipped-ReLU lambda is compared by what it resolves to)."""
+  from openseq2seq_amd.utils.utils import get_base_config
+  from openseq2seq_amd.parts.cnns.conv_blocks import act_id
+  repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+  def norm(x):
+    if isinstance(x, dict):
+      return {k: norm(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+      return [norm(v) for v in x]
+    if callable(x) and getattr(x, "__name__", "") == "<lambda>":
+      return "activation id %d" % act_id(x)
+    if callable(x) or hasattr(x, "__name__"):
+      return getattr(x, "__name__", str(x))
+    return x
+
+  cwd = os.getcwd()
+  os.chdir(repo)
+  try:
+    for n in ("ds2", "w2l", "jasper_res_blockout"):
+      rel = "open_seq2seq/test_utils/test_speech_configs/%s_test_config.py" % n
+      ours = get_base_config(["--config_file=" + rel, "--mode=train"])
+      ref = get_base_config(["--config_file=" + os.path.join("/root/reference", rel), "--mode=train"])
+      assert norm(ours[1]) == norm(ref[1]), n
+      for key in ("train_params", "eval_params"):
+        assert norm(ours[3][key]) == norm(ref[3][key]), (n, key)
+      assert norm(ours[1])["encoder_params"]["activation_fn"] == "activation id 3"      # min(relu(x), 20)
+  finally:
+    os.chdir(cwd)
