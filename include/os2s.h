@@ -479,6 +479,17 @@ int os2s_psf_spectrogram(os2s_stream_t stream, const void* signal, int sample_is
                          const int32_t* n_samples, int B, long long Nmax, int n_win, int n_step,
                          int pad_to, int num_features, int Tpad, uint16_t* out_bf16, float* out_f32,
                          int32_t* out_len, void* workspace, size_t workspace_bytes);
+/* 'logfbank' features of the python_speech_features backend (get_speech_features_psf,
+ * open_seq2seq/data/speech2text/speech_utils.py:517-535 -> psf.logfbank(nfft = 512, lowfreq = 0,
+ * highfreq = sr / 2, preemph = 0.97): int16 normalisation, pre-emphasis, rectangular frames, |rfft|^2 / nfft,
+ * the filter table fb [nfilt][nfft/2 + 1] (device, fp32: python_speech_features.get_filterbanks), ln, then
+ * (x - mean) / std over the utterance incl. the pad_to frames). Workspace:
+ * os2s_psf_spectrogram_workspace_bytes(B, Tpad, nfilt). The toy Wave2Letter / TDNN configurations of the
+ * reference's acceptance tests use this path. */
+int os2s_psf_logfbank(os2s_stream_t stream, const void* signal, int sample_is_int16, const int32_t* n_samples,
+                      int B, long long Nmax, int n_win, int n_step, int pad_to, int nfilt, int nfft,
+                      const float* fb, int Tpad, uint16_t* out_bf16, float* out_f32, int32_t* out_len,
+                      void* workspace, size_t workspace_bytes);
 size_t os2s_logmel_workspace_bytes(int B, int Tmax, int n_mels);
 int os2s_logmel(os2s_stream_t stream, const void* signal, const int32_t* n_samples,
                 int sample_is_int16, int B, long long Nmax, int n_fft, int hop,

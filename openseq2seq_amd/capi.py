@@ -683,6 +683,28 @@ def psf_spectrogram(signal, n_samples, *, n_win, n_step, pad_to, num_features, t
   return out, olen, out32
 
 
+def psf_logfbank(signal, n_samples, fb, *, n_win, n_step, pad_to, nfft, tpad, want_f32=False):
+  """signal [B,Nmax] float32|int16, fb [nfilt, nfft/2+1] fp32 -> (features bf16 [B,tpad,nfilt], frames int32 [B],
+  f32|None): the psf backend's 'logfbank' features (os2s_psf_logfbank)."""
+  B, Nmax = signal.shape
+  dev = signal.device
+  is_i16 = signal.dtype == torch.int16
+  assert is_i16 or signal.dtype == torch.float32
+  nfilt = fb.shape[0]
+  assert fb.is_contiguous() and fb.shape[1] == nfft // 2 + 1
+  nbytes = int(_fn("os2s_psf_spectrogram_workspace_bytes", (c_int, c_int, c_int), c_size_t)(B, tpad, nfilt))
+  ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+  out = torch.empty((B, tpad, nfilt), dtype=torch.bfloat16, device=dev)
+  out32 = torch.empty((B, tpad, nfilt), dtype=torch.float32, device=dev) if want_f32 else None
+  olen = torch.empty((B,), dtype=torch.int32, device=dev)
+  f = _fn("os2s_psf_logfbank", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int,
+                               c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+  _lib.check(f(_stream(), _ptr(signal), int(is_i16), _ptr(n_samples, torch.int32), B, Nmax, n_win, n_step,
+               pad_to, nfilt, nfft, _ptr(fb, torch.float32), tpad, _ptr(out), _ptr(out32, None, True),
+               _ptr(olen), _ptr(ws), nbytes), "os2s_psf_logfbank")
+  return out, olen, out32
+
+
 def augment_signal(signal, n_in, n_out, ratio, noise_amp, interp_win, num_table, nout_max, seed=0,
                    fixed_gain=-1.0):
   """signal [B,Nmax] int16|float32 -> normalised, speed-perturbed, noised fp32 [B,nout_max]."""

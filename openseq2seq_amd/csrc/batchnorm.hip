@@ -814,7 +814,7 @@ extern "C" int os2s_bn_act_fwd(os2s_stream_t stream, int J, const uint16_t* cons
                                int C, int act, float keep_prob,
                                unsigned long long seed) {
   OS2S_REQUIRE(J >= 1 && J <= kMaxBnInputs && out && C % 8 == 0 && C >= 8);
-  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f && act >= 0 && act <= 2);
+  OS2S_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f && act >= 0 && act <= 3);
   if ((long long)B * T == 0) return OS2S_OK;
   BnActArgs a;
   for (int j = 0; j < J; ++j) {

@@ -62,7 +62,7 @@ class LogMelFrontEnd(object):
     self.sample_freq = sr
     if params.get('backend', 'psf') != 'librosa' or params.get('input_type') != 'logfbank':
       raise NotImplementedError("GPU front ends: backend='librosa' + input_type='logfbank' (the Jasper "
-                                "configs) and backend='psf' + input_type='spectrogram' (DeepSpeech2)")
+                                "configs), backend='psf' + input_type='spectrogram' (DeepSpeech2) or 'logfbank'")
     self.n_mels = params['num_audio_features']
     window_size = params.get('window_size', 20e-3)
     window_stride = params.get('window_stride', 10e-3)
@@ -147,11 +147,58 @@ class PsfSpectrogramFrontEnd(object):
                                 tpad=self.frames(nmax), want_f32=want_f32)
 
 
+def psf_filterbanks(nfilt, nfft, samplerate, lowfreq=0.0, highfreq=None):
+  """python_speech_features.get_filterbanks (0.6): nfilt triangular filters on the HTK mel scale
+  (2595 log10(1 + f / 700)), corner bins floor((nfft + 1) * hz / samplerate), unnormalised: [nfilt, nfft/2 + 1]."""
+  highfreq = highfreq or samplerate / 2.0
+  hz2mel = lambda hz: 2595.0 * np.log10(1.0 + hz / 700.0)
+  mel2hz = lambda mel: 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+  melpoints = np.linspace(hz2mel(lowfreq), hz2mel(highfreq), nfilt + 2)
+  bins = np.floor((nfft + 1) * mel2hz(melpoints) / samplerate)
+  fb = np.zeros([nfilt, nfft // 2 + 1])
+  for j in range(nfilt):
+    for i in range(int(bins[j]), int(bins[j + 1])):
+      fb[j, i] = (i - bins[j]) / (bins[j + 1] - bins[j])
+    for i in range(int(bins[j + 1]), int(bins[j + 2])):
+      fb[j, i] = (bins[j + 2] - i) / (bins[j + 2] - bins[j + 1])
+  return fb
+
+
+class PsfLogfbankFrontEnd(PsfSpectrogramFrontEnd):
+  """Launcher for the 'logfbank' features of the python_speech_features backend (get_speech_features_psf,
+  speech_utils.py:517-535: psf.logfbank with nfft = 512, preemph = 0.97; the toy Wave2Letter / TDNN test
+  configurations). Framing and padding as the spectrogram path."""
+
+  def __init__(self, params, device):
+    self.device = device
+    sr = params.get('sample_freq', 16000)
+    self.sample_freq = sr
+    if params.get('backend', 'psf') != 'psf' or params.get('input_type') != 'logfbank':
+      raise NotImplementedError("PsfLogfbankFrontEnd implements backend='psf', input_type='logfbank'")
+    self.num_features = params['num_audio_features']
+    self.win_length = int(sr * params.get('window_size', 20e-3))
+    self.hop = int(sr * params.get('window_stride', 10e-3))
+    self.pad_to = params.get('pad_to', 8)
+    self.gain = None
+    self.nfft = 512
+    if self.win_length > self.nfft:
+      raise NotImplementedError("psf.logfbank truncates frames longer than nfft = 512 (window_size > 32 ms)")
+    fb = psf_filterbanks(self.num_features, self.nfft, sr, 0.0, sr / 2.0)
+    self.fb = torch.from_numpy(np.ascontiguousarray(fb, np.float32)).to(device)
+
+  def __call__(self, signal, n_samples, max_samples=None, seed=0, want_f32=False):
+    nmax = int(max_samples) if max_samples is not None else signal.shape[1]
+    return capi.psf_logfbank(signal, n_samples, self.fb, n_win=self.win_length, n_step=self.hop,
+                             pad_to=self.pad_to, nfft=self.nfft, tpad=self.frames(nmax), want_f32=want_f32)
+
+
 def make_front_end(params, device):
   """The GPU front end of a Speech2TextDataLayer configuration: log-mel (librosa backend, the
   Jasper / wav2letter configs) or psf spectrogram (the DeepSpeech2 configs)."""
   if params.get('backend', 'psf') == 'psf' and params.get('input_type') == 'spectrogram':
     return PsfSpectrogramFrontEnd(params, device)
+  if params.get('backend', 'psf') == 'psf' and params.get('input_type') == 'logfbank':
+    return PsfLogfbankFrontEnd(params, device)
   return LogMelFrontEnd(params, device)
 
 

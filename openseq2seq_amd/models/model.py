@@ -231,7 +231,10 @@ class Model(object):
     return self._last_step()
 
   def _extra_state_tensors(self):
-    return []
+    """Non-trainable state that travels with the variables (rank-0 broadcast, train -> eval copy): every
+    tensor registered with the store under its reference name (BatchNorm moving statistics of ALL layers —
+    the row convolution of DeepSpeech2 included), in registration order (same build code => same order)."""
+    return list(self._store.state.values()) if self._store is not None else []
 
   @abc.abstractmethod
   def _build_forward_pass_objects(self, store):

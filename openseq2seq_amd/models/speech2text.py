@@ -173,14 +173,3 @@ class Speech2Text(EncoderDecoderModel):
   def _get_num_objects_per_step(self, batch):
     """speech2text.py:356-360: number of INPUT feature frames in the batch."""
     return batch['source_tensors'][1].sum()
-
-  def _extra_state_tensors(self):
-    """Non-trainable state broadcast with the variables (BatchNorm moving statistics)."""
-    out = []
-    enc = self._encoder
-    for L in getattr(enc, "_layers", None) or []:
-      for br in [L['main']] + L['res']:
-        out += [br.moving_mean, br.moving_var]
-    for c in getattr(enc, "convs", None) or []:
-      out += [c.moving_mean, c.moving_var]
-    return out

@@ -173,3 +173,60 @@ def get_speech_features_psf_spectrogram(signal, sample_freq, num_features, pad_t
   mean = np.mean(features)
   std_dev = np.std(features)
   return ((features - mean) / std_dev).astype(np.float32), audio_duration
+
+
+# ---- python_speech_features 0.6: logfbank (published algorithm restated; the package is not in the
+# reference tree — requirements.txt names it) -------------------------------------------------------------
+#   preemphasis(signal, coeff): append(signal[0], signal[1:] - coeff * signal[:-1])
+#   fbank: frames = framesig(signal, winlen*sr, winstep*sr, winfunc = ones)   (rectangular)
+#          pspec  = |rfft(frames, nfft)|^2 / nfft;  feat = pspec . get_filterbanks(nfilt, nfft, sr, low, high)^T
+#          feat == 0 -> float eps;  logfbank = log(feat)
+#   get_filterbanks: HTK mel scale 2595 log10(1 + f / 700), corner bins floor((nfft + 1) * hz / sr),
+#          rising / falling unnormalised triangles
+# PARITY STATUS: "parity unpinned" for the values (the reference's speech_utils_test.py pins shapes, mean ~ 0 and
+# std ~ 1 for this backend); cross-checked in tests/test_oracle_speech_features.py against a direct O(N^2) DFT.
+def psf_get_filterbanks(nfilt, nfft, samplerate, lowfreq=0.0, highfreq=None):
+  highfreq = highfreq or samplerate / 2.0
+  lowmel = 2595.0 * np.log10(1.0 + lowfreq / 700.0)
+  highmel = 2595.0 * np.log10(1.0 + highfreq / 700.0)
+  melpoints = np.linspace(lowmel, highmel, nfilt + 2)
+  bins = np.floor((nfft + 1) * (700.0 * (10.0 ** (melpoints / 2595.0) - 1.0)) / samplerate)
+  fbank = np.zeros([nfilt, nfft // 2 + 1])
+  for j in range(nfilt):
+    for i in range(int(bins[j]), int(bins[j + 1])):
+      fbank[j, i] = (i - bins[j]) / (bins[j + 1] - bins[j])
+    for i in range(int(bins[j + 1]), int(bins[j + 2])):
+      fbank[j, i] = (bins[j + 2] - i) / (bins[j + 2] - bins[j + 1])
+  return fbank
+
+
+def psf_logfbank(signal, samplerate, winlen, winstep, nfilt, nfft, lowfreq, highfreq, preemph):
+  signal = np.asarray(signal, np.float64)
+  signal = np.append(signal[0], signal[1:] - preemph * signal[:-1])
+  frames = psf_framesig(signal, int(round(winlen * samplerate)), int(round(winstep * samplerate)),
+                        lambda n: np.ones((n,)))
+  pspec = np.square(np.abs(np.fft.rfft(frames, nfft))) / nfft
+  feat = np.dot(pspec, psf_get_filterbanks(nfilt, nfft, samplerate, lowfreq, highfreq).T)
+  feat = np.where(feat == 0, np.finfo(float).eps, feat)
+  return np.log(feat)
+
+
+def get_speech_features_psf_logfbank(signal, sample_freq, num_features, pad_to=8, window_size=20e-3,
+                                     window_stride=10e-3):
+  """speech_utils.py:473-535, features_type='logfbank' (no augmentation): returns
+  (features float32 [frames, num_features], audio_duration)."""
+  signal = (normalize_signal(np.asarray(signal).astype(np.float32)) * 32767.0).astype(np.int16)
+  audio_duration = len(signal) * 1.0 / sample_freq
+  n_window_size = int(sample_freq * window_size)
+  n_window_stride = int(sample_freq * window_stride)
+  length = 1 + int(math.ceil((1.0 * signal.shape[0] - n_window_size) / n_window_stride))
+  if pad_to > 0 and length % pad_to != 0:
+    pad_size = (pad_to - length % pad_to) * n_window_stride
+    signal = np.pad(signal, (0, pad_size), mode='constant')
+  features = psf_logfbank(signal, sample_freq, window_size, window_stride, num_features, 512, 0,
+                          sample_freq / 2, 0.97)
+  if pad_to > 0:
+    assert features.shape[0] % pad_to == 0
+  mean = np.mean(features)
+  std_dev = np.std(features)
+  return ((features - mean) / std_dev).astype(np.float32), audio_duration

@@ -102,3 +102,41 @@ def test_psf_spectrogram_int16_and_padding_rows():
   # frame `real` still overlaps the last 37 samples; the rows after it are all-zero frames and
   # hold one constant (the floor), far below every other row
   assert np.ptp(fa[real + 1:]) == 0.0 and fa[real + 1:].max() < fa[:real + 1].min()
+
+
+def test_psf_logfbank_reference_relations_and_direct_dft():
+  """The psf 'logfbank' branch (speech_utils.py:517-535): shapes / whitening as the reference's
+  speech_utils_test.py pins them for this backend; the filter table and the spectrum against their
+  definitions (a direct O(N^2) DFT of the pre-emphasised rectangular frames)."""
+  for n, pad_to, F in [(16000, 8, 40), (23456, 8, 64), (5000, 16, 26), (48000, 0, 40)]:
+    feats, dur = sf.get_speech_features_psf_logfbank(_speechlike(n, n), 16000, F, pad_to=pad_to)
+    frames = 1 + int(np.ceil((n - 320) / 160.0))
+    if pad_to:
+      frames = -(-frames // pad_to) * pad_to
+    assert feats.shape == (frames, F)
+    assert abs(feats.mean()) < 1e-3 and abs(feats.std() - 1.0) < 1e-3
+  fb = sf.psf_get_filterbanks(40, 512, 16000, 0, 8000)
+  assert fb.shape == (40, 257) and fb.min() >= 0 and fb.max() <= 1.0
+  assert np.all(fb.sum(1) > 0)                                   # every triangle has support
+  peaks = fb.argmax(1)
+  assert np.all(np.diff(peaks) > 0)                              # centres rise with the filter index
+  x = (_speechlike(3000, 7) * 8000).astype(np.int16).astype(np.float64)
+  y = np.append(x[0], x[1:] - 0.97 * x[:-1])
+  got = sf.psf_logfbank(x, 16000, 0.02, 0.01, 40, 512, 0, 8000, 0.97)
+  nfr = 1 + int(np.ceil((3000 - 320) / 160.0))
+  pad = np.concatenate([y, np.zeros((nfr - 1) * 160 + 320 - 3000)])
+  fr = np.stack([pad[i * 160:i * 160 + 320] for i in range(nfr)])
+  dft = fr @ np.exp(-2j * np.pi * np.outer(np.arange(320), np.arange(257)) / 512)
+  want = np.log(np.maximum((np.abs(dft) ** 2 / 512) @ fb.T, np.finfo(float).eps))
+  np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+
+
+def test_psf_logfbank_padding_rows():
+  """pad_to rows: the first padding sample is -0.97 x[n-1] (pre-emphasis runs over the padded signal), rows
+  past it are ln(eps) before the whitening — one constant, below every real row."""
+  x = _speechlike(16000 + 37, 5)
+  xi = (x / np.abs(x).max() * 20000).astype(np.int16)
+  fa, _ = sf.get_speech_features_psf_logfbank(xi, 16000, 40, pad_to=8)
+  real = 1 + int(np.ceil((len(xi) - 320) / 160.0))
+  assert fa.shape[0] % 8 == 0 and real < fa.shape[0]
+  assert np.ptp(fa[real + 1:]) == 0.0 and fa[real + 1:].max() < fa[:real + 1].min()
