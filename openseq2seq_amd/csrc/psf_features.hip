@@ -170,9 +170,19 @@ __global__ __launch_bounds__(256) void psf_logfbank_kernel(
                              : reinterpret_cast<const float*>(signal)[(long long)b * sig_stride + j];
     return truncf((raw / d) * 32767.0f);                      // astype(np.int16): toward zero
   };
+  // the reference pads the SIGNAL (by whole strides, to the pad_to frame count) before psf.logfbank runs its
+  // pre-emphasis over it; framesig then zero-pads the pre-emphasised signal to complete the last frame. So
+  // y[n] = -0.97 s16[n-1] exists only when that signal padding happened (plen > n), and y[j] = 0 past plen.
+  long long plen = n;
+  {
+    const int length = n <= n_win ? 1 : 1 + (n - n_win + n_step - 1) / n_step;   // 1 + ceil((n - n_win) / n_step)
+    // (python: 1 + int(ceil((n - n_win) / n_step)) is <= 1 for n <= n_win: ceil of a non-positive quotient;
+    // for n < n_win - n_step it is <= 0 — such clips (< 10 ms) do not occur: frames >= 1 is kept)
+    if (pad_to > 0 && length % pad_to) plen = (long long)n + (long long)(pad_to - length % pad_to) * n_step;
+  }
   for (int i = tid; i < n_win; i += 256) {
     const long long j = (long long)t * n_step + i;
-    x[i] = j == 0 ? s16(0) : s16(j) - 0.97f * s16(j - 1);
+    x[i] = j >= plen ? 0.f : (j == 0 ? s16(0) : s16(j) - 0.97f * s16(j - 1));
   }
   for (int i = tid; i < nfft; i += 256) {
     float s, c;
