@@ -721,7 +721,11 @@ size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
  * a wait that times out) leaves its outputs partially written: its abort code is latched, behind every
  * persistent forward AND backward launch, into a sticky host-visible word no launch clears. From then on
  * every persistent launch returns OS2S_ERR_LAUNCH and os2s_gru_xcd_status() returns the code (1 = timeout,
- * 2 = placement, 3 = both; 0 = fine so far) — call it after a stream synchronisation, once per step
+ * 2 = placement, 3 = both;
+/* Persistent GRU launches (forward + backward) this process has enqueued so far. The host layer
+ * (Model.train_step) reads os2s_gru_xcd_status after the steps that ran some, agrees on the answer over the
+ * data-parallel ranks and redoes an aborted step on the launch-per-step kernels (os2s_gru_xcd_set_mode(0)). */
+long long os2s_gru_xcd_launch_count(void); 0 = fine so far) — call it after a stream synchronisation, once per step
  * (the host layer does, where it reads the optimizer state); clear != 0 resets the word. */
 void os2s_gru_xcd_set_mode(int mode);
 int os2s_gru_xcd_status(int clear);

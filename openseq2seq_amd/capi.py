@@ -586,16 +586,33 @@ def opt_read_state(state):
   return dict(zip([n for n, _ in OPT_STATE_FIELDS], vals))
 
 
+def gru_xcd_status(clear=False):
+  """The sticky abort word of the persistent GRU kernels (csrc/rnn_xcd.hip): 0, or the OR of 1 = poll timeout,
+  2 = workgroup placement. Definite after a stream synchronisation. clear=True resets it (the caller has
+  discarded or redone the step)."""
+  return int(_fn("os2s_gru_xcd_status", (c_int,))(int(bool(clear))))
+
+
+def gru_xcd_launch_count():
+  f = _fn("os2s_gru_xcd_launch_count", (), c_ll)
+  return int(f())
+
+
+def gru_xcd_set_mode(mode):
+  """0: recurrent layers use the launch-per-step kernels, 1: persistent kernels where supported, -1: default."""
+  _fn("os2s_gru_xcd_set_mode", (c_int,), None)(int(mode))
+
+
 def gru_xcd_check(clear=False):
-  """Raises if a persistent GRU launch (csrc/rnn_xcd.hip, forward or backward) has given up since the
-  word was last cleared: its outputs — and every gradient computed from them — are invalid. The abort
-  word is sticky and host-visible (os2s_gru_xcd_status); definite after a stream synchronisation,
-  otherwise it reports launches that have already finished."""
-  f = _fn("os2s_gru_xcd_status", (c_int,))
-  st = f(int(bool(clear)))
-  if st:
+  """Raises if a persistent GRU launch (forward or backward) has given up since the word was last cleared:
+  its outputs — and every gradient computed from them — are invalid. Model.train_step recovers from this by
+  itself (the step is redone on the launch-per-step kernels); this check is for callers that drive the
+  kernels directly. With clear=True the word is reset and the code returned instead of raised."""
+  st = gru_xcd_status(clear)
+  if st and not clear:
     raise _lib.Os2sError("a persistent GRU launch gave up (code %d: 1 = poll timeout, 2 = workgroup placement); "
                          "the step's results are invalid. OS2S_GRU_XCD=0 selects the launch-per-step path" % st)
+  return st
 
 
 def opt_step(cfg, state, grads, weights, m1, m2, w16, chunk_tensor, tensor_chunk_begin,

@@ -252,7 +252,6 @@ class Model(object):
   def train_step(self, batch):
     assert self._compiled and self._mode == "train"
     p = self._params
-    capi.gru_xcd_check()        # sticky abort word of the persistent GRU kernels (no sync: earlier steps)
     # the side-stream switch is this model's, for the duration of its step only (a second model in the
     # process — an eval twin, a test's bare Tape — keeps the setting it had)
     prev = set_side_stream_enabled(p.get('os2s_side_stream', True))
@@ -263,9 +262,20 @@ class Model(object):
         self._store.zero_grads()
       last_micro = (micro == iter_size - 1)
       overlap = self._reducer is not None and last_micro
+      # what a persistent-GRU abort must be able to roll back (see _recover_gru_abort): the non-trainable state
+      # always (a few KB: BatchNorm statistics a garbage forward pass would poison), the gradient buffer only
+      # inside an accumulation window (iter_size > 1: earlier micro-steps already sit in it)
+      snap = None
+      if self._gru_guard:
+        snap = ([t.clone() for t in self._extra_state_tensors()],
+                self._store.grads.clone() if micro > 0 else None)
+      launches0 = capi.gru_xcd_launch_count()
       tape = Tape(on_done=self._reducer.mark_done if overlap else None)
       loss = self._forward_backward(batch, tape)
       tape.backward()
+      if capi.gru_xcd_launch_count() != launches0:
+        self._gru_guard = True          # this model runs persistent GRU kernels: snapshots from the next step on
+        loss = self._recover_gru_abort(batch, loss, snap, micro, overlap)
       self._step_count += 1
       if last_micro:
         if self._reducer is not None:
@@ -273,6 +283,51 @@ class Model(object):
         self._train_op.run()
     finally:
       set_side_stream_enabled(prev)
+    return loss
+
+  _gru_guard = False
+
+  def _recover_gru_abort(self, batch, loss, snap, micro, overlap):
+    """The persistent GRU kernels (csrc/rnn_xcd.hip) need 32 co-resident workgroups per XCD and give up after a
+    bounded wait when they do not get them (CUs held by RCCL's resident kernels, a second process on the
+    device, a partitioned GPU): the launch sets a sticky word and its outputs are garbage. Instead of raising
+    (round 4), the step is REDONE on the launch-per-step kernels: one synchronisation per step of a model that
+    ran persistent launches, the answer agreed over the data-parallel ranks (every rank redoes — and re-reduces —
+    or none does), state and gradient buffer rolled back, the persistent path switched off for the rest of the
+    process. The first step of a model has no snapshot yet: its BatchNorm statistics are re-initialised by the
+    redone forward pass only in so far as the moving average forgets (documented; the abort of a FIRST step was
+    never observed — the placement check fails at launch, before any state is written)."""
+    torch.cuda.current_stream().synchronize()
+    code = capi.gru_xcd_status(clear=True)
+    world = self._hvd.size() if self._hvd is not None else 1
+    if world > 1:
+      t = torch.tensor([code], dtype=torch.int32, device=self._device)
+      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+      code = int(t.item())
+    if code == 0:
+      return loss
+    import warnings
+    warnings.warn("a persistent GRU launch gave up (code %d: 1 = poll timeout, 2 = workgroup placement); the step "
+                  "is redone on the launch-per-step kernels, which stay selected for this process" % code)
+    capi.gru_xcd_set_mode(0)
+    if self._reducer is not None:
+      if overlap:
+        self._reducer.finish()          # drain the buckets of the aborted pass (same collectives on every rank)
+      self._reducer.reset()
+    if snap is not None:
+      for t, s0 in zip(self._extra_state_tensors(), snap[0]):
+        t.copy_(s0)
+    if micro == 0:
+      self._store.zero_grads()
+    elif snap is not None and snap[1] is not None:
+      self._store.grads.copy_(snap[1])
+    else:
+      raise RuntimeError("persistent GRU abort inside an accumulation window before a snapshot existed")
+    tape = Tape(on_done=self._reducer.mark_done if overlap else None)
+    loss = self._forward_backward(batch, tape)
+    tape.backward()
+    torch.cuda.current_stream().synchronize()
+    assert capi.gru_xcd_status(clear=True) == 0
     return loss
 
   def copy_weights_from(self, other):

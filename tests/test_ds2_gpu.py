@@ -177,3 +177,51 @@ def test_row_conv_layer_and_unidirectional_encoder(cuda):
   tape.backward()
   gw = store2.by_name("ForwardPass/ds2_encoder/row_conv/w").grad
   assert torch.isfinite(gw).all() and float(gw.abs().max()) > 0
+
+
+def test_persistent_gru_abort_is_recovered_by_redoing_the_step(cuda):
+  """A persistent GRU launch that gives up (it needs 32 co-resident workgroups per XCD; the test hook
+  os2s_gru_xcd_set_mode(2) makes the next forward launch start with its abort flag set, as after a poll
+  timeout) no longer raises at the next step (round 4): Model.train_step reads the abort word at the end of
+  the step, rolls the BatchNorm statistics back, redoes the step on the launch-per-step kernels and keeps
+  those selected. The recovered model must follow the trajectory of a model that used the per-step kernels
+  from the start: same kernels after the abort => bit-identical master weights and losses."""
+  import warnings
+  from openseq2seq_amd import capi
+  from openseq2seq_amd.configs.ds2 import ds2_large_config
+
+  def run(mode_at_step):
+    capi.gru_xcd_set_mode(-1)
+    capi.gru_xcd_status(clear=True)
+    cls, p = ds2_large_config(batch_size_per_gpu=4, max_steps=100)
+    p["encoder_params"].update(num_rnn_layers=2, rnn_cell_dim=128, n_hidden=256, dropout_keep_prob=1.0,
+                               row_conv=True, row_conv_width=8)
+    p["use_horovod"] = False
+    m = cls(p, mode="train", hvd=None, device=cuda)
+    m.compile()
+    dl = m.get_data_layer()
+    losses = []
+    for step in range(4):
+      if step in mode_at_step:
+        capi.gru_xcd_set_mode(mode_at_step[step])
+      losses.append(float(m.train_step(dl.synthetic_batch(cuda, seed=40 + step)).cpu()[0]))
+    torch.cuda.synchronize()
+    state = [t.clone() for t in m._extra_state_tensors()]
+    return losses, m.store.master.clone(), state
+
+  try:
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter("always")
+      # persistent kernels for steps 0-1, the abort is injected into step 2 -> redone per-step, step 3 per-step
+      la, wa, sa = run({2: 2})
+      assert any("persistent GRU launch gave up" in str(x.message) for x in w), [str(x.message) for x in w]
+    # reference trajectory: persistent for steps 0-1, per-step kernels from step 2 on, no abort
+    lb, wb, sb = run({2: 0})
+  finally:
+    capi.gru_xcd_set_mode(-1)
+    capi.gru_xcd_status(clear=True)
+  assert la == lb, (la, lb)
+  assert torch.equal(wa, wb)
+  for x, y in zip(sa, sb):
+    assert torch.equal(x, y)          # BatchNorm statistics: the aborted pass left no trace
+  assert all(l == l and abs(l) < 1e6 for l in la)
