@@ -717,16 +717,16 @@ size_t os2s_rnn_fwd_workspace_bytes(int B, int H);
  * launch (csrc/rnn_xcd.hip: a direction per XCD, weights stationary in registers, the hidden state
  * exchanged through that XCD's L2) instead of one launch per time step; os2s_rnn_fwd_workspace_bytes
  * includes its exchange buffers. os2s_gru_xcd_set_mode: 0 = per-step launches, 1 = persistent kernel,
- * -1 = environment OS2S_GRU_XCD (default on). A launch that gives up (unexpected workgroup placement,
- * a wait that times out) leaves its outputs partially written: its abort code is latched, behind every
- * persistent forward AND backward launch, into a sticky host-visible word no launch clears. From then on
- * every persistent launch returns OS2S_ERR_LAUNCH and os2s_gru_xcd_status() returns the code (1 = timeout,
- * 2 = placement, 3 = both;
-/* Persistent GRU launches (forward + backward) this process has enqueued so far. The host layer
- * (Model.train_step) reads os2s_gru_xcd_status after the steps that ran some, agrees on the answer over the
- * data-parallel ranks and redoes an aborted step on the launch-per-step kernels (os2s_gru_xcd_set_mode(0)). */
-long long os2s_gru_xcd_launch_count(void); 0 = fine so far) — call it after a stream synchronisation, once per step
- * (the host layer does, where it reads the optimizer state); clear != 0 resets the word. */
+ * -1 = environment OS2S_GRU_XCD (default on), 2 (test hook) = on, and the next forward launch starts with
+ * its abort flag set. A launch that gives up (unexpected workgroup placement, a wait that times out) leaves
+ * its outputs partially written: its abort code is latched, behind every persistent forward AND backward
+ * launch, into a sticky host-visible word no launch clears; os2s_gru_xcd_status() returns it (1 = timeout,
+ * 2 = placement, 3 = both; 0 = fine so far) — definite after a stream synchronisation; clear != 0 resets the
+ * word. Launches do not fail on a set word: in a data-parallel job every rank must enqueue the same collectives,
+ * so the step runs to its end and the host layer (Model.train_step) reads the word after every step that ran
+ * persistent launches (os2s_gru_xcd_launch_count), agrees on the answer over the ranks and redoes an aborted
+ * step on the launch-per-step kernels (os2s_gru_xcd_set_mode(0)). */
+long long os2s_gru_xcd_launch_count(void);
 void os2s_gru_xcd_set_mode(int mode);
 int os2s_gru_xcd_status(int clear);
 size_t os2s_gru_xcd_workspace_bytes(int B, int H);
