@@ -185,7 +185,8 @@ def test_persistent_gru_abort_is_recovered_by_redoing_the_step(cuda):
   timeout) no longer raises at the next step (round 4): Model.train_step reads the abort word at the end of
   the step, rolls the BatchNorm statistics back, redoes the step on the launch-per-step kernels and keeps
   those selected. The recovered model must follow the trajectory of a model that used the per-step kernels
-  from the start: same kernels after the abort => bit-identical master weights and losses."""
+  from the start: same kernels after the abort => bit-identical master weights and losses (deterministic
+  mode: the default launches use fp32 atomics in a few weight-gradient kernels, last-bit differences run to run)."""
   import warnings
   from openseq2seq_amd import capi
   from openseq2seq_amd.configs.ds2 import ds2_large_config
@@ -209,6 +210,8 @@ def test_persistent_gru_abort_is_recovered_by_redoing_the_step(cuda):
     state = [t.clone() for t in m._extra_state_tensors()]
     return losses, m.store.master.clone(), state
 
+  det = capi.deterministic()
+  capi.set_deterministic(True)
   try:
     with warnings.catch_warnings(record=True) as w:
       warnings.simplefilter("always")
@@ -218,6 +221,7 @@ def test_persistent_gru_abort_is_recovered_by_redoing_the_step(cuda):
     # reference trajectory: persistent for steps 0-1, per-step kernels from step 2 on, no abort
     lb, wb, sb = run({2: 0})
   finally:
+    capi.set_deterministic(det)
     capi.gru_xcd_set_mode(-1)
     capi.gru_xcd_status(clear=True)
   assert la == lb, (la, lb)

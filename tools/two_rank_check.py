@@ -55,7 +55,7 @@ def small_models():
   cls, p = ds2_large_config(batch_size_per_gpu=4, max_steps=100)
   p["encoder_params"].update(num_rnn_layers=2, rnn_cell_dim=128, n_hidden=256)
   yield "ds2-small", cls, p
-  cls, p = transformer_config(d_model=256, num_layers=2, num_heads=4, batch_size_per_gpu=16, vocab_size=1024,
+  cls, p = transformer_config(d_model=512, num_layers=2, num_heads=8, batch_size_per_gpu=16, vocab_size=1024,
                               max_length=24, max_steps=1000)
   yield "transformer-small", cls, p
 
