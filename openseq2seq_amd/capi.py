@@ -1501,6 +1501,21 @@ class TacotronInfer(object):
     """0 while samples are still running, else the number of steps after which all had finished."""
     return int(self.state[1].item())
 
+  def poll_async(self):
+    """Snapshot of the stop word AS OF the work enqueued so far, without draining the stream: an async copy
+    of state[1] into pinned memory + an event. `poll_wait(handle)` waits for that event only — kernels enqueued
+    after the call keep the GPU busy while the host looks."""
+    if getattr(self, "_pin", None) is None:
+      self._pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+    self._pin.copy_(self.state[1:2], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    return ev
+
+  def poll_wait(self, ev):
+    ev.synchronize()
+    return int(self._pin[0])
+
   @property
   def lengths(self):
     B = self.loop.dims["B"]

@@ -507,12 +507,18 @@ __global__ __launch_bounds__(kTiCtxThreads) void ti_context_kernel(AdAttn p, AdL
   const int cpart = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int M = p.M, S = p.S;
+  // "decoding has ended" for THIS launch means: ended at an EARLIER step (state[1] = t' + 1 <= t). The tail
+  // workgroup of the last sample to finish writes state[1] = t + 1 during this very launch; a workgroup that
+  // is scheduled after that write (more workgroups than CUs, a partitioned GPU, a co-running stream) must not
+  // take it as a reason to skip step t — the host counts step t, its rows have to be complete.
+  const int ended = q.state[1];
+  const bool over = ended != 0 && ended <= p.t;
   if (cpart == ctx_parts) {
-    if (!q.first && (q.state[1] != 0 || (q.dbg & 4))) return;
+    if (!q.first && (over || (q.dbg & 4))) return;
     ti_tail(p, x, q, lds_raw);
     return;
   }
-  if (q.first || q.state[1] != 0 || (q.dbg & 8)) return;
+  if (q.first || over || (q.dbg & 8)) return;
   const int Sp = ti_spad(S), Sa = max(Sp, 256);
   float* e = lds_raw;                  // [Sp]
   float* red = e + Sp;                 // [32]

@@ -305,22 +305,27 @@ class Tacotron2Decoder(Decoder):
                         lengths, mag.data[:, :, :self.n_mag] if mag is not None else None],
             'stop_token_prediction': st, 'n_feats': (self.n_mel, self.n_mag),
             'acts': {'mel': mel, 'post': post, 'stop': Act(stop8), 'mag': mag},
-            'decoder_steps': steps}
+            'decoder_steps': steps, 'fused': fused is not None}
 
   def _decode_fused(self, fused, T):
     """Four launches per step, enqueued POLL_STEPS at a time; the stop decision is taken on the device
     (kernels enqueued past it return at once), the host reads it one chunk behind the enqueue front so the
     GPU never waits for the host. The result does not depend on POLL_STEPS."""
+    # chunk k is enqueued, then an async snapshot of the stop word is taken BEHIND it (pinned copy + event),
+    # then chunk k + 1 goes out, and only then does the host wait for the snapshot of chunk k: the GPU always
+    # has a chunk queued while the host looks (state[1].item() drained the whole stream, chunk k + 1 included)
     done, t0 = 0, 0
+    pending = None
     while t0 < T and not done:
       t1 = min(T, t0 + self.POLL_STEPS)
       fused.steps(t0, t1)
       t0 = t1
-      if t0 < T:                       # keep one chunk in flight while the host looks
-        t1 = min(T, t0 + self.POLL_STEPS)
-        fused.steps(t0, t1)
-        t0 = t1
-      done = fused.done_steps()
+      ev = fused.poll_async()
+      if pending is not None:
+        done = fused.poll_wait(pending)
+      pending = ev
+    if not done and pending is not None:
+      done = fused.poll_wait(pending)
     steps = done if done else T
     return steps, fused.mel, fused.stop, fused.lengths.clone()
 
