@@ -754,37 +754,8 @@ def bench_transformer(args, hvd, dev, rank, world):
       torch.distributed.barrier()
     torch.cuda.synchronize()
 
-  # A step starts from PCM resident in HBM (north_star puts the log-mel front end on the path): int16 audio of
-  # the batch's durations -> os2s_logmel -> features -> train step, all inside the timed region. The synthetic
-  # batch above fixes the durations / labels; its N(0,1) feature tensor is replaced by the front end's output.
-  step_from_pcm = None
-  if not args.fixed_frames:
-    try:
-      import numpy as np
-      from openseq2seq_amd.data.speech2text.speech_utils import make_front_end
-      fe = make_front_end(dl.params, dev)
-      sr = dl.params.get('sample_freq', 16000)
-      dur = np.random.RandomState(1234 + rank).uniform(2.0, dl.params.get('max_duration', 16.7), size=args.batch)
-      ns = (dur * sr).astype(np.int32)
-      nmax = int(ns.max())
-      pcm = torch.randint(-20000, 20000, (args.batch, nmax), dtype=torch.int16, device=dev)
-      n_samples = torch.from_numpy(ns).to(dev)
-      feats, frames_dev, _ = fe(pcm, n_samples, max_samples=nmax, seed=0)
-      if tuple(feats.shape) == tuple(batch['source_tensors'][0].shape) and \
-         torch.equal(frames_dev.cpu(), batch['source_tensors'][1].cpu()):
-        def step_from_pcm(i):
-          f, fr, _ = fe(pcm, n_samples, max_samples=nmax, seed=i)
-          batch['source_tensors'] = [f, fr]
-          return model.train_step(batch)
-    except Exception as e:      # never lose the headline to the front-end plumbing: fall back, and say so
-      print("bench.py: front end not in the timed step (%r)" % (e,), file=sys.stderr)
-      step_from_pcm = None
-
-  def one_step(i):
-    return step_from_pcm(i) if step_from_pcm is not None else model.train_step(batch)
-
-  for i in range(args.warmup):
-    one_step(i)
+  for _ in range(args.warmup):
+    model.train_step(batch)
   barrier()
   t0 = time.perf_counter()
   for _ in range(args.steps):
