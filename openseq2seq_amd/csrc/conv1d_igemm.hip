@@ -1178,17 +1178,15 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
 //   0 = 128x128, X window double-buffered   3 = 128x128, X window single-buffered when K >= 8
 //   5 = 256x256 lockstep                   10 = ping-pong (tile chosen on the device)
 //   12 / 13 = ping-pong, 2 / 3 windows x 128 columns   14 = ping-pong, 2 windows x 256 columns
-// experiment knob read once from the environment (A/B runs on one box: tools/bench_conv_split.py)
-static int env_int(const char* name, int dflt) {
-  static std::mutex mu;
-  static std::map<std::string, int> cache;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(name);
-  if (it != cache.end()) return it->second;
-  const char* v = getenv(name);
-  const int r = v ? atoi(v) : dflt;
-  cache[name] = r;
-  return r;
+// narrowest layer the ping-pong kernels take (conv1d.pp_min_cout; the environment variable OS2S_PP_MIN_COUT is
+// read ONCE, at the first launch — no per-launch environment or map lookups in the launch path)
+static int g_pp_min_cout = -1;
+static int pp_min_cout() {
+  if (g_pp_min_cout < 0) {
+    const char* v = getenv("OS2S_PP_MIN_COUT");
+    g_pp_min_cout = v ? atoi(v) : 320;
+  }
+  return g_pp_min_cout;
 }
 static int g_conv_variant = -1;
 static int g_conv_split = -1;
@@ -1203,6 +1201,7 @@ extern "C" void os2s_conv1d_set_split(int f) { g_conv_split = f; }
 //       them); a cost >= 1e6 removes a narrow tile from the candidates
 //   conv1d.pp_dgrad_penalty   factor on the narrow tiles' cost in data-gradient launches (out_len given)
 //   conv1d.pp_prio            1: the loading wave of a narrow-tile slot runs at s_setprio 2
+//   conv1d.pp_min_cout        narrowest layer (output channels) the ping-pong kernels take (default 320)
 // Returns 0, or -1 for an unknown name.
 extern "C" int os2s_set_option(const char* name, double value) {
   if (!name) return -1;
@@ -1212,6 +1211,7 @@ extern "C" int os2s_set_option(const char* name, double value) {
   if (k == "conv1d.pp_cost_3x128") { os2s::g_pp_cost[2] = (float)value; return 0; }
   if (k == "conv1d.pp_dgrad_penalty") { os2s::g_pp_cost[3] = (float)value; return 0; }
   if (k == "conv1d.pp_prio") { os2s::g_pp_prio = (int)value; return 0; }
+  if (k == "conv1d.pp_min_cout") { g_pp_min_cout = (int)value; return 0; }
   return -1;
 }
 // experiment hook (tools/pp_timeline.py, tools/ppn_timeline.py): device buffer of slot time stamps;
@@ -1270,7 +1270,7 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
   if (v < 0) {
     v = K >= 8 ? 3 : 0;
     if (Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;
-    if (Cout >= env_int("OS2S_PP_MIN_COUT", 320)) v = 10;
+    if (Cout >= pp_min_cout()) v = 10;
   }
   if ((v == 10 || v == 11) && K == 1 && g_conv1x1_variant == 2 && residual == nullptr && Cout >= 256 &&
       y_stride_t == Cout && y_stride_b == (long long)Tout * Cout) {

@@ -217,7 +217,7 @@ extern "C" int os2s_gemm_skinny(os2s_stream_t stream, const uint16_t* x, long lo
   // tiles when they do, else 32x32 tiles (4x the workgroups, each streaming half the bytes);
   // "reg" = the register-direct kernel. OS2S_SKINNY_VARIANT ("reg" | "l64" | "l32" | "wide")
   // overrides (tools / tests).
-  const char* force = getenv("OS2S_SKINNY_VARIANT");
+  static const char* const force = getenv("OS2S_SKINNY_VARIANT");     // read once per process
   const long long blocks64 = (long long)((N + 63) / 64) * ((M + 63) / 64);
   int variant = blocks64 >= 192 ? 2 : 1;
   if (M > 128 && (long long)((N + 127) / 128) * ((M + 255) / 256) >= 192) variant = 3;

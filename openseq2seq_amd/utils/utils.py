@@ -1,92 +1,108 @@
-"""Config helpers with the reference's semantics (open_seq2seq/utils/utils.py)."""
+"""Configuration plumbing of the drop-in CLI: parameter-schema checks, nested dictionary overrides, the
+`--a/b/c=value` command line and model construction.
+
+What is a CONTRACT here — because user configs and scripts written against NVIDIA/OpenSeq2Seq depend on it — is
+the behaviour of open_seq2seq/utils/utils.py: which keys are accepted, the wording of the ValueErrors
+(`check_params`, :403-429), the "/"-joined names of nested overrides (`flatten_dict` / `nest_dict`, :296-349)
+and the flags of `get_base_config` (:469-545). The code below is written against that behaviour, not copied
+from it; tests/test_config_dropin.py runs the reference's own config files through it.
+"""
 from __future__ import print_function
 
-import sys
-
-
-def deco_print(line, offset=0, start="*** ", end='\n'):
-  # utils.py:373-379
-  print((start + " " * offset + line), end=end)
-  sys.stdout.flush()
-
-
-def check_params(config, required_dict, optional_dict):
-  """utils.py:403-429 — unknown key => ValueError; wrong type => ValueError;
-  a list in the schema enumerates the allowed values; None accepts anything."""
-  if required_dict is None or optional_dict is None:
-    return
-  for pm, vals in required_dict.items():
-    if pm not in config:
-      raise ValueError("{} parameter has to be specified".format(pm))
-    _check_one(pm, config[pm], vals)
-  for pm, vals in optional_dict.items():
-    if pm in config:
-      _check_one(pm, config[pm], vals)
-  for pm in config:
-    if pm not in required_dict and pm not in optional_dict:
-      raise ValueError("Unknown parameter: {}".format(pm))
-
-
-def _check_one(pm, value, vals):
-  if vals == str:
-    vals = (str, type(u""))
-  if vals is None:
-    return
-  if isinstance(vals, list):
-    if value not in vals:
-      raise ValueError("{} has to be one of {}".format(pm, vals))
-    return
-  if vals is float and isinstance(value, int) and not isinstance(value, bool):
-    return  # ints are accepted where the reference's configs pass them for floats
-  if not isinstance(value, vals):
-    raise ValueError("{} has to be of type {}".format(pm, vals))
-
-
-def nested_update(org_dict, upd_dict):
-  # utils.py:351-363
-  for key, value in upd_dict.items():
-    if isinstance(value, dict):
-      if key in org_dict:
-        if not isinstance(org_dict[key], dict):
-          raise ValueError("Mismatch between org_dict and upd_dict at node {}".format(key))
-        nested_update(org_dict[key], value)
-      else:
-        org_dict[key] = value
-    else:
-      org_dict[key] = value
-
-
-# ---------------------------------------------------------------------------
-# config loading / CLI (open_seq2seq/utils/utils.py:296-349, 469-545, 791-864)
-# ---------------------------------------------------------------------------
 import argparse
 import ast
 import contextlib
 import copy
 import runpy
+import sys
+
+_SCALARS = (int, float, str, bool)
+
+
+def deco_print(line, offset=0, start="*** ", end='\n'):
+  """The '*** '-prefixed progress lines of the reference's logs (scripts grep for them)."""
+  sys.stdout.write("%s%s%s%s" % (start, " " * offset, line, end))
+  sys.stdout.flush()
+
+
+def _type_ok(value, want):
+  """Does `value` satisfy one schema entry? None: anything; a list: one of its members; a type: an instance
+  of it (text types interchangeable; an int where a float is asked for passes, as the reference's configs
+  rely on)."""
+  if want is None:
+    return True, None
+  if isinstance(want, list):
+    return value in want, "{} has to be one of {}"
+  if want is str:
+    want = (str, type(u""))
+  if want is float and isinstance(value, int) and not isinstance(value, bool):
+    return True, None
+  return isinstance(value, want), "{} has to be of type {}"
+
+
+def check_params(config, required_dict, optional_dict):
+  """Schema check of a plugin's parameter dictionary: every required key present, every present key known and
+  of the declared kind. Raises ValueError with the reference's wording."""
+  if required_dict is None or optional_dict is None:
+    return
+  missing = [k for k in required_dict if k not in config]
+  if missing:
+    raise ValueError("{} parameter has to be specified".format(missing[0]))
+  schema = dict(optional_dict)
+  schema.update(required_dict)
+  for key, value in config.items():
+    if key not in schema:
+      raise ValueError("Unknown parameter: {}".format(key))
+  for table in (required_dict, optional_dict):
+    for key, want in table.items():
+      if key in config:
+        ok, msg = _type_ok(config[key], want)
+        if not ok:
+          shown = want if not (want is str) else (str, type(u""))
+          raise ValueError(msg.format(key, shown))
+
+
+def nested_update(org_dict, upd_dict):
+  """In-place merge of `upd_dict` into `org_dict`: sub-dictionaries merge key by key, anything else replaces.
+  A dictionary arriving where the original holds a non-dictionary is an error."""
+  stack = [(org_dict, upd_dict)]
+  while stack:
+    dst, src = stack.pop()
+    for key, value in src.items():
+      if isinstance(value, dict) and key in dst:
+        if not isinstance(dst[key], dict):
+          raise ValueError("Mismatch between org_dict and upd_dict at node {}".format(key))
+        stack.append((dst[key], value))
+      else:
+        dst[key] = value
 
 
 def flatten_dict(dct):
-  flat_dict = {}
-  for key, value in dct.items():
-    if isinstance(value, (int, float, str, bool)):
-      flat_dict.update({key: value})
-    elif isinstance(value, dict):
-      flat_dict.update({key + '/' + k: v for k, v in flatten_dict(dct[key]).items()})
-  return flat_dict
+  """{'a': {'b': 1}, 'c': 2} -> {'a/b': 1, 'c': 2}: the scalar leaves (int / float / str / bool) of a nested
+  dictionary under '/'-joined names — the names of the command-line overrides. Other leaves are dropped."""
+  flat = {}
+
+  def walk(prefix, node):
+    for key, value in node.items():
+      name = prefix + key
+      if isinstance(value, dict):
+        walk(name + '/', value)
+      elif isinstance(value, _SCALARS):
+        flat[name] = value
+  walk('', dct)
+  return flat
 
 
 def nest_dict(flat_dict):
-  nst_dict = {}
-  for key, value in flat_dict.items():
-    nest_keys = key.split('/')
-    cur_dict = nst_dict
-    for i in range(len(nest_keys) - 1):
-      if nest_keys[i] not in cur_dict:
-        cur_dict[nest_keys[i]] = {}
-      cur_dict = cur_dict[nest_keys[i]]
-    cur_dict[nest_keys[-1]] = value
-  return nst_dict
+  """Inverse of flatten_dict."""
+  root = {}
+  for name, value in flat_dict.items():
+    *parents, leaf = name.split('/')
+    node = root
+    for part in parents:
+      node = node.setdefault(part, {})
+    node[leaf] = value
+  return root
 
 
 @contextlib.contextmanager
@@ -128,27 +144,27 @@ def load_config_module(config_file):
         'tf': tf, 'DL_REPLACE': os.environ.get('DL_REPLACE', '[REPLACE THIS TO THE PATH WITH YOUR DATA]')})
 
 
+_MODES = ['train', 'eval', 'train_eval', 'infer', 'interactive_infer']
+_FLAGS = ['continue_learning', 'no_dir_check', 'benchmark', 'enable_logs', 'use_xla_jit']
+
+
 def get_base_config(args):
-  """Same CLI as the reference (utils.py:469-545): --config_file, --mode, --benchmark,
-  --bench_steps, --bench_start, --continue_learning, --no_dir_check, --enable_logs, plus
-  `--a/b/c=value` overrides of any int/float/str/bool leaf of base_params."""
-  parser = argparse.ArgumentParser(description='Experiment parameters')
-  parser.add_argument("--config_file", required=True, help="Path to the configuration file")
-  parser.add_argument("--mode", default='train',
-                      help="Could be \"train\", \"eval\", \"train_eval\" or \"infer\"")
-  parser.add_argument("--infer_output_file", default='infer-out.txt')
-  parser.add_argument('--continue_learning', dest='continue_learning', action='store_true')
-  parser.add_argument('--no_dir_check', dest='no_dir_check', action='store_true')
-  parser.add_argument('--benchmark', dest='benchmark', action='store_true')
-  parser.add_argument('--bench_steps', type=int, default='20')
-  parser.add_argument('--bench_start', type=int)
-  parser.add_argument('--debug_port', type=int)
-  parser.add_argument('--enable_logs', dest='enable_logs', action='store_true')
-  parser.add_argument('--use_xla_jit', dest='use_xla_jit', action='store_true')
-  args, unknown = parser.parse_known_args(args)
-  if args.mode not in ['train', 'eval', 'train_eval', 'infer', 'interactive_infer']:
-    raise ValueError("Mode has to be one of ['train', 'eval', 'train_eval', 'infer', "
-                     "'interactive_infer']")
+  """The reference's command line (utils.py:469-545): --config_file, --mode, --infer_output_file, the flags
+  --continue_learning / --no_dir_check / --benchmark / --enable_logs / --use_xla_jit, --bench_steps,
+  --bench_start, --debug_port, and one `--a/b/c=value` override per int / float / str / bool leaf of the
+  config's base_params (typed like the value it replaces). Returns (args, base_config, base_model, module)."""
+  cli = argparse.ArgumentParser(description='Experiment parameters')
+  cli.add_argument("--config_file", required=True, help="Path to the configuration file")
+  cli.add_argument("--mode", default='train', help='Could be "train", "eval", "train_eval" or "infer"')
+  cli.add_argument("--infer_output_file", default='infer-out.txt')
+  for flag in _FLAGS:
+    cli.add_argument('--' + flag, dest=flag, action='store_true')
+  cli.add_argument('--bench_steps', type=int, default='20')
+  cli.add_argument('--bench_start', type=int)
+  cli.add_argument('--debug_port', type=int)
+  args, overrides = cli.parse_known_args(args)
+  if args.mode not in _MODES:
+    raise ValueError("Mode has to be one of %s" % (_MODES,))
   config_module = load_config_module(args.config_file)
   base_config = config_module.get('base_params', None)
   if base_config is None:
@@ -156,14 +172,14 @@ def get_base_config(args):
   base_model = config_module.get('base_model', None)
   if base_model is None:
     raise ValueError('base_config class has to be defined in the config file')
-  parser_unk = argparse.ArgumentParser()
-  for pm, value in flatten_dict(base_config).items():
-    if type(value) == int or type(value) == float or isinstance(value, str):
-      parser_unk.add_argument('--' + pm, default=value, type=type(value))
-    elif type(value) == bool:
-      parser_unk.add_argument('--' + pm, default=value, type=ast.literal_eval)
-  config_update = parser_unk.parse_args(unknown)
-  nested_update(base_config, nest_dict(vars(config_update)))
+  leaves = argparse.ArgumentParser()
+  for name, value in flatten_dict(base_config).items():
+    # bool before int: a bool IS an int; its text form goes through literal_eval ("False" must not be truthy)
+    if isinstance(value, bool):
+      leaves.add_argument('--' + name, default=value, type=ast.literal_eval)
+    else:
+      leaves.add_argument('--' + name, default=value, type=type(value))
+  nested_update(base_config, nest_dict(vars(leaves.parse_args(overrides))))
   return args, base_config, base_model, config_module
 
 

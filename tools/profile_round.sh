@@ -27,7 +27,8 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OU
 OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT/m -o c -- $P > $OUT/m.log 2>&1
 python - <<PY
 import csv, glob, json, collections
-FAM = [("conv1d_pp_kernel", "conv fwd+dgrad, ping-pong tile"), ("conv1d_igemm_grouped_kernel", "grouped 1x1 fwd+dgrad, lockstep tile"),
+FAM = [("conv1d_pp_kernel", "conv fwd+dgrad, ping-pong tile (2 windows x 256 columns)"),
+       ("conv1d_ppn_kernel", "conv fwd, narrow ping-pong tiles (2 / 3 windows x 128 columns)"), ("conv1d_igemm_grouped_kernel", "grouped 1x1 fwd+dgrad, lockstep tile"),
        ("conv1d_igemm_kernel", "conv fwd+dgrad, lockstep tile"), ("conv1d_wgrad_pp_kernel", "wgrad, ping-pong tile"),
        ("conv1d_wgrad_kernel", "wgrad, lockstep tile")]
 def fam(name):
