@@ -13,8 +13,8 @@ import torch
 from .encoder import Encoder
 import os
 
-from ..parts.cnns.conv_blocks import (Act, ConvBN, SepConvBN, conv_bn_res_bn_actv, xavier_normal_conv,
-                                      glorot_uniform_conv, launch_residual_early)
+from ..parts.cnns.conv_blocks import (Act, ConvBN, ConvOnly, SepConvBN, conv_actv, conv_bn_res_bn_actv,
+                                      xavier_normal_conv, glorot_uniform_conv, launch_residual_early)
 
 # which layer of a residual block starts the block end's residual branches on the side stream
 # (-1 = never: they run in front of the block's last BatchNorm, as in round 2). 2 leaves the first
@@ -47,8 +47,13 @@ class TDNNEncoder(Encoder):
 
   def __init__(self, params, model, name="w2l_encoder", mode='train'):
     super(TDNNEncoder, self).__init__(params, model, name, mode)
-    if self.params.get('normalization', 'batch_norm') != 'batch_norm':
-      raise NotImplementedError("only normalization='batch_norm' has HIP kernels so far")
+    # normalization None = conv_actv (conv_blocks.py:17-58): convolution + activation, BatchNorm only at the
+    # residual block ends, which go through conv_bn_res_bn_actv whatever the setting (tdnn_encoder.py:216-233).
+    # 'layer_norm' (tf.contrib.layers.layer_norm: statistics over time AND channels of a sample) and
+    # 'instance_norm' (over time, per sample and channel) have no kernels: no example config uses them
+    if self.params.get('normalization', 'batch_norm') not in ('batch_norm', None):
+      raise NotImplementedError("normalization %r: only 'batch_norm' and None have HIP kernels"
+                                % (self.params.get('normalization'),))
     if self.params.get('data_format', 'channels_last') != 'channels_last':
       raise NotImplementedError("HIP path is channels_last (the reference's default)")
     self._layers = None
@@ -83,9 +88,16 @@ class TDNNEncoder(Encoder):
           res_in = [cin]
       for ir in range(blk['repeat']):
         lname = "%s/conv%d%d" % (scope, ib + 1, ir + 1)
-        main = Layer(store, lname, lname + "/bn", cin, blk['num_channels'],
-                      blk['kernel_size'][0], blk['stride'][0], blk['dilation'][0] if
-                      'dilation' in blk else 1, blk['padding'], mom, eps, l2, initializer)
+        block_end = residual and ir == blk['repeat'] - 1
+        if p.get('normalization', 'batch_norm') is None and not block_end:
+          if Layer is not ConvBN:
+            raise NotImplementedError("normalization=None with sep_conv1d layers")
+          main = ConvOnly(store, lname, cin, blk['num_channels'], blk['kernel_size'][0], blk['stride'][0],
+                          blk['dilation'][0] if 'dilation' in blk else 1, blk['padding'], l2, initializer)
+        else:
+          main = Layer(store, lname, lname + "/bn", cin, blk['num_channels'],
+                       blk['kernel_size'][0], blk['stride'][0], blk['dilation'][0] if
+                       'dilation' in blk else 1, blk['padding'], mom, eps, l2, initializer)
         res = []
         if residual and ir == blk['repeat'] - 1:
           for i, rc in enumerate(res_in):
@@ -148,6 +160,10 @@ class TDNNEncoder(Encoder):
       res_fw = None
       if L['res']:
         res_fw, pending_res = pending_res, None
+      if isinstance(main, ConvOnly):
+        x = conv_actv(main, x, src_length if use_mask else None, act_fn, training, tape, keep_prob=keep,
+                      seed=seed0 * 1000003 + li, mask_output=(use_mask and not last))
+        continue
       x = conv_bn_res_bn_actv(main, L['res'], x, res_in, src_length if use_mask else None,
                               act_fn, training, tape, keep_prob=keep,
                               seed=seed0 * 1000003 + li, mask_output=(use_mask and not last),

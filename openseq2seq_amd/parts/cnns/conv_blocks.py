@@ -731,6 +731,56 @@ def grouped_conv1x1_bn_stats(branches, inputs, training):
   return out
 
 
+class ConvOnly(ConvBN):
+  """tf.layers.conv1d(use_bias=False) alone — the layer of conv_actv (conv_blocks.py:17-58), TDNNEncoder with
+  normalization=None: one variable, '<name>/kernel'."""
+
+  def __init__(self, store, name, cin, cout, k, stride=1, dilation=1, padding="SAME", l2=0.0,
+               initializer=xavier_normal_conv):
+    self.name, self.cin, self.cout, self.k = name, cin, cout, k
+    self.stride, self.dil, self.padding = stride, dilation, padding
+    self.kernel = store.add(name + "/kernel", (k, cout, cin), initializer, kind="conv", l2=l2)
+
+  def trainable(self):
+    return [self.kernel]
+
+
+def conv_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, seed=0, mask_output=True):
+  """act(conv(x)) -> dropout -> mask: conv_actv (conv_blocks.py:17-58) + the encoder's tf.nn.dropout and mask
+  (tdnn_encoder.py:204-205, 255). Runs on the BatchNorm + activation kernels with the identity transform
+  (scale 1, shift 0): one tested pass produces activation, dropout and the masked store, and its backward twin
+  produces dz; the convolution's output takes the place of BatchNorm's input."""
+  act = act_id(activation_fn)
+  B, Tin, _ = x.data.shape
+  tout, pl = layer.out_geometry(Tin)
+  dev = x.data.device
+  C = layer.cout
+  y = capi.conv1d_fwd(x.data, layer.kernel.w16, stride=layer.stride, dil=layer.dil, pad_left=pl, tout=tout,
+                      in_len=x.lens)
+  one, zero = torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev)
+  out = torch.empty((B, tout, C), dtype=torch.bfloat16, device=dev)
+  lens = out_lens if mask_output else None
+  keep = keep_prob if training else 1.0
+  capi.bn_act_fwd([y], [one], [zero], out, lens, act, keep, seed)
+  result = Act(out, lens)
+  if not (training and tape is not None):
+    return result
+
+  def backward():
+    dout = result.grad
+    assert dout is not None, "no gradient reached " + layer.name
+    dz = torch.empty_like(out)
+    partial = torch.empty((capi.bn_act_bwd_num_parts(B * tout), 2, C), dtype=torch.float32, device=dev)
+    # identity "BatchNorm": mean 0, rstd 1 — only dz = dout * act'(out) * dropout' is used, the partial sums
+    # of the BatchNorm parameters are ignored
+    capi.bn_act_bwd_reduce(dout, out, [y], [zero], [one], dz, partial, lens, act, keep, seed)
+    result.grad = None
+    layer.backward_branch(x, dz, dict(pad_left=pl), final=False)
+
+  tape.record(backward, layer.trainable())
+  return result
+
+
 def conv_bn_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, seed=0,
                  mask_output=True):
   return conv_bn_res_bn_actv(layer, [], x, [], out_lens, activation_fn, training, tape,

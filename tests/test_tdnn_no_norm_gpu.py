@@ -1,0 +1,89 @@
+"""TDNNEncoder with normalization=None (conv_actv, open_seq2seq/parts/cnns/conv_blocks.py:17-58: convolution +
+activation, dropout and the sequence mask from the encoder loop, tdnn_encoder.py:204-205, 255; BatchNorm only at
+the residual block ends, :216-233) against a direct fp32 restatement on the same bf16-rounded weights, with the
+device's bf16 storage points emulated (convolution output, layer output). Tolerances as the layer-wise Jasper
+test: outputs 2e-3, kernel gradients 6e-3 relative L2."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+  return x.to(torch.bfloat16).float()
+
+
+def _rel(a, b):
+  return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@pytest.mark.parametrize("act", ["relu", "relu20"])
+def test_tdnn_without_normalization(cuda, act):
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
+  from openseq2seq_amd.parts.cnns.conv_blocks import ConvOnly, Tape
+  from oracle import cnn
+  torch.manual_seed(0)
+  layers = [
+      {"type": "conv1d", "repeat": 1, "kernel_size": [11], "stride": [2], "num_channels": 128, "padding": "SAME",
+       "dilation": [1]},
+      {"type": "conv1d", "repeat": 2, "kernel_size": [7], "stride": [1], "num_channels": 192, "padding": "SAME",
+       "dilation": [1]},
+      {"type": "conv1d", "repeat": 1, "kernel_size": [1], "stride": [1], "num_channels": 256, "padding": "SAME",
+       "dilation": [1]},
+  ]
+  fn = "relu" if act == "relu" else (lambda x: _Tok("minimum", _Tok("relu", x), 20.0))
+  store = FlatParams(cuda)
+  enc = TDNNEncoder({"convnet_layers": layers, "dropout_keep_prob": 1.0, "activation_fn": fn,
+                     "normalization": None, "use_conv_mask": True, "dtype": "mixed"}, None, mode="train").build(store, 64)
+  store.finalize()
+  assert all(isinstance(L["main"], ConvOnly) for L in enc._layers)
+  assert [p.name.split("/")[-1] for p in store.params] == ["kernel"] * 4        # no BatchNorm variables
+  g = torch.Generator().manual_seed(1)
+  B, T = 3, 210
+  lens0 = torch.tensor([210, 133, 64], dtype=torch.int32)
+  # inputs scaled so that the clipped ReLU actually clips in the deeper layers
+  x0 = (torch.randn(B, T, 64, generator=g) * (6.0 if act == "relu20" else 1.0)).to(torch.bfloat16)
+  store.zero_grads()
+  tape = Tape()
+  e = enc.encode({"source_tensors": [x0.to(cuda), lens0.to(cuda)], "tape": tape, "seed": 3})
+  out = e["outputs_act"]
+  dy = torch.randn(out.data.shape, generator=g).to(torch.bfloat16)
+  out.grad = dy.to(cuda)
+  tape.backward()
+  torch.cuda.synchronize()
+  # ---- restatement -----------------------------------------------------------------------------------------
+  ws = [p.master.float().cpu().to(torch.bfloat16).float().permute(0, 2, 1).contiguous().requires_grad_(True)
+        for p in store.params]                                       # device [K, Cout, Cin] -> TF [K, Cin, Cout]
+  x = x0.float()
+  lens = lens0.clone()
+  specs = [(2, 11), (1, 7), (1, 7), (1, 1)]
+  capped = 0
+  for i, ((stride, k), w) in enumerate(zip(specs, ws)):
+    x = x * cnn.seq_mask(lens, x.shape[1])                           # mask before every conv input
+    y = cnn.conv1d_tf(x, w, stride, 1, "SAME")
+    y = y + (_bf(y) - y).detach()                                    # bf16 storage of the conv output
+    if stride > 1:
+      lens = (lens + stride - 1) // stride
+    a = torch.relu(y)
+    if act == "relu20":
+      capped += int((a > 20).sum())
+      a = torch.clamp(a, max=20.0)
+    if i < len(specs) - 1:
+      a = a * cnn.seq_mask(lens, a.shape[1])
+    x = a + (_bf(a) - a).detach()
+  assert _rel(out.data.float().cpu(), x.detach()) <= 2e-3
+  if act == "relu20":
+    assert capped > 100, capped
+  assert torch.equal(e["src_length"].cpu(), lens)
+  (x * dy.float()).sum().backward()
+  for p, w in zip(store.params, ws):
+    got = p.grad.float().cpu().permute(0, 2, 1)
+    assert _rel(got, w.grad) <= 6e-3, (p.name, _rel(got, w.grad))
+
+
+class _Tok(object):
+  """what the tensorflow token module returns for tf.minimum(tf.nn.relu(x), 20.0)"""
+
+  def __init__(self, name, *args):
+    self.__name__, self.args = name, args
