@@ -83,6 +83,29 @@ def parse():
   return ap.parse_args()
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+  """The contract is ONE JSON line on stdout. RCCL and the ROCm runtime print through C stdio ('Librccl path : ...'
+  on the first communicator), and that buffer is flushed at process exit — AFTER Python's own print, on every
+  rank. So each rank keeps a private duplicate of the original stdout for the JSON line and points fd 1 at
+  stderr for everything else (C and Python alike)."""
+  global _JSON_FD
+  if _JSON_FD is None:
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(obj):
+  sys.stdout.flush()
+  data = (json.dumps(obj) + "\n").encode()
+  fd = _JSON_FD if _JSON_FD is not None else 1
+  while data:
+    data = data[os.write(fd, data):]
+
+
 def spawn_ranks(n):
   """`python bench.py --gpus N` without a launcher: re-execute this script as N ranks of ONE node
   (openseq2seq_amd/utils/distributed.py:spawn_ranks). Returns the launcher's exit code."""
@@ -584,7 +607,7 @@ def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
     with torch.no_grad():
       for t, nw in zip(tensors, opt.w):
         t.copy_(torch.from_numpy(nw))
-    return float(loss)
+    return float(loss.detach())
 
   t_w = time.time()
   for _ in range(3):
@@ -959,23 +982,24 @@ def launcher_dry_run(args, hvd, rank, world):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dist.all_reduce(units, op=dist.ReduceOp.SUM)
   if rank == 0:
-    print(json.dumps({"metric": "launcher dry run (no GPU work)", "value": None, "unit": "frames/sec",
+    emit({"metric": "launcher dry run (no GPU work)", "value": None, "unit": "frames/sec",
                       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": 1000.0 * float(tmax.item()), "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                       "config": {"workload": "launcher dry run", "global_batch": args.batch * world,
                                  "parallelism": "dp%d" % world,
                                  "backend": dist.get_backend() if world > 1 else "none",
-                                 "units_sum_over_ranks": float(units.item())}}))
+                                 "units_sum_over_ranks": float(units.item())}})
 
 
 def main():
   args = parse()
   if args.cpu_nmt_leg:
-    print(json.dumps(cpu_baseline_nmt(torch.load(args.cpu_nmt_leg))))
+    emit(cpu_baseline_nmt(torch.load(args.cpu_nmt_leg)))
     return
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(spawn_ranks(args.gpus))      # one process per GPU; this process only waits for them
+  claim_stdout()
   from openseq2seq_amd.utils import distributed as dist_utils
   hvd = dist_utils.init_from_env()
   if args.one_rank_group and hvd is None:
@@ -1027,25 +1051,25 @@ def main():
       res = bench_simple(simple[key], args.steps, args.warmup, hvd, dev, rank, world, roofline_key=key,
                          cpu_leg=not args.no_cpu_baseline)
       if rank == 0:
-        print(json.dumps(res))
+        emit(res)
       return
   if args.only_transformer_infer:
     if rank == 0:
-      print(json.dumps(bench_transformer_infer(dev)))
+      emit(bench_transformer_infer(dev))
     return
   if args.only_frontend:
     if rank == 0:
-      print(json.dumps(bench_frontend(dev, args.batch)))
+      emit(bench_frontend(dev, args.batch))
     return
   if args.only_tacotron_decode:
     if rank == 0:
-      print(json.dumps(bench_tacotron_decode(dev, style=not args.no_style, fp8=not args.no_fp8,
-                                             batch=args.batch, steps=args.decode_steps)))
+      emit(bench_tacotron_decode(dev, style=not args.no_style, fp8=not args.no_fp8,
+                                             batch=args.batch, steps=args.decode_steps))
     return
   if args.only_transformer:
     tr = bench_transformer(args, hvd, dev, rank, world)
     if rank == 0:
-      print(json.dumps(tr))
+      emit(tr)
     return
   from openseq2seq_amd import capi
   from openseq2seq_amd.configs.jasper import jasper10x5_config
@@ -1274,7 +1298,7 @@ def main():
     except Exception as e:  # the baseline must never break the bench line
       out["cpu_baseline"] = {"value": None, "unit": "frames/sec", "cores": 0, "kind": "port",
                              "sample": "failed: %r" % (e,)}
-  print(json.dumps(out))
+  emit(out)
 
 
 if __name__ == "__main__":

@@ -20,8 +20,9 @@
 //     tag = step + 1, written by ONE store (MI355X_MICROARCH.md "handoff" rows); two buffer slots
 //     suffice because nobody can publish h_{t+1} before everybody has read h_{t-1};
 //   * every wait is bounded: a workgroup that does not see its granules within ~2^17 polls raises
-//     the abort flag and leaves, every other workgroup follows; the caller sees OS2S_ERR_LAUNCH on
-//     a later call and can fall back to the per-step path (OS2S_GRU_XCD=0).
+//     the abort flag and leaves, every other workgroup follows; the code is latched into the sticky
+//     word os2s_gru_xcd_status() returns and the host layer redoes the step on the per-step path
+//     (Model.train_step; launches themselves do not fail on a set word — see "sticky abort word").
 #include <cstdio>
 #include <cstdlib>
 

@@ -43,7 +43,7 @@ def test_tdnn_without_normalization(cuda, act):
   B, T = 3, 210
   lens0 = torch.tensor([210, 133, 64], dtype=torch.int32)
   # inputs scaled so that the clipped ReLU actually clips in the deeper layers
-  x0 = (torch.randn(B, T, 64, generator=g) * (6.0 if act == "relu20" else 1.0)).to(torch.bfloat16)
+  x0 = (torch.randn(B, T, 64, generator=g) * (25.0 if act == "relu20" else 1.0)).to(torch.bfloat16)
   store.zero_grads()
   tape = Tape()
   e = enc.encode({"source_tensors": [x0.to(cuda), lens0.to(cuda)], "tape": tape, "seed": 3})

@@ -38,13 +38,25 @@ def main():
   ap.add_argument("--steps", type=int, default=12)
   ap.add_argument("--warmup", type=int, default=4)
   ap.add_argument("--thieves", default="0,16,32,48,64,96")
+  ap.add_argument("--model", default="jasper", choices=["jasper", "ds2", "transformer"],
+                  help="round 5: the same experiment on DeepSpeech2-large (whose persistent GRU launches need 32 "
+                       "co-resident workgroups per XCD: a held CU makes them give up and the step is redone on the "
+                       "launch-per-step kernels) and on Transformer-big")
   args = ap.parse_args()
   lib = build()
-  from openseq2seq_amd.configs.jasper import jasper10x5_config
+  from openseq2seq_amd import capi
   from openseq2seq_amd.parts.cnns import conv_blocks
   dev = torch.device("cuda", 0)
   torch.cuda.set_device(dev)
-  model_cls, params = jasper10x5_config(batch_size_per_gpu=32, use_horovod=True)
+  if args.model == "jasper":
+    from openseq2seq_amd.configs.jasper import jasper10x5_config
+    model_cls, params = jasper10x5_config(batch_size_per_gpu=32, use_horovod=True)
+  elif args.model == "ds2":
+    from openseq2seq_amd.configs.ds2 import ds2_large_config
+    model_cls, params = ds2_large_config()
+  else:
+    from openseq2seq_amd.configs.transformer import transformer_config
+    model_cls, params = transformer_config()
   model = model_cls(params, mode="train", hvd=None, device=dev)
   model.compile()
   batch = model.get_data_layer().synthetic_batch(dev, seed=1234)
@@ -70,10 +82,18 @@ def main():
     return orig_backward(self)
   conv_blocks.Tape.backward = backward
 
+  fell_back = {}
+
   def run(n, mode):
     state["n"], state["mode"] = n, mode
-    for _ in range(args.warmup):
-      model.train_step(batch)
+    capi.gru_xcd_set_mode(-1)       # a setting that made the persistent GRU give up must not decide the next one
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+      warnings.simplefilter("always")
+      for _ in range(args.warmup):
+        model.train_step(batch)
+    if args.model == "ds2":
+      fell_back["%s/%d" % (mode, n)] = any("persistent GRU" in str(w.message) for w in caught)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -83,13 +103,15 @@ def main():
 
   base = run(0, "off")
   state["bwd_us"] = 1000.0 * base * 0.62          # backward is ~62 % of the step (trace_phases)
-  out = {"baseline_ms": base, "backward_us_assumed": state["bwd_us"], "full": {}, "bursts": {}, "distinct_cus_held": {}}
+  out = {"model": args.model, "baseline_ms": base, "backward_us_assumed": state["bwd_us"], "full": {}, "bursts": {}, "distinct_cus_held": {}}
   for n in [int(v) for v in args.thieves.split(",") if int(v) > 0]:
     where.fill_(-1)
     out["full"][n] = run(n, "full")
     out["distinct_cus_held"][n] = len(set(where[:n].cpu().tolist()))
     out["bursts"][n] = run(n, "bursts")
   out["baseline_again_ms"] = run(0, "off")
+  if args.model == "ds2":
+    out["gru_fell_back_to_step_launches"] = fell_back
   print(json.dumps(out))
 
 
