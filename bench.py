@@ -74,6 +74,9 @@ def parse():
   ap.add_argument("--pp-cost", default=None,
                   help="A/B aid: 'c256,c2x128,c3x128[,dgrad_penalty[,prio]]' (os2s_set_option conv1d.pp_*) = microseconds per step of the three ping-pong convolution "
                        "tiles in the device-side tile choice (os2s_conv1d_set_pp_cost; 1e6 removes a tile)")
+  ap.add_argument("--no-host-lens", action="store_true",
+                  help="A/B: drop the batch's host copy of the sequence lengths (the convolution launcher then "
+                       "enqueues both ping-pong kernels and the device chooses)")
   ap.add_argument("--one-rank-group", action="store_true",
                   help="N=1 only: run the data-parallel path (RCCL process group, bucketed all-reduce on "
                        "the side stream, comm diagnostics) on a one-rank group")
@@ -1083,6 +1086,9 @@ def main():
   dl = model.get_data_layer()
   batch = dl.synthetic_batch(dev, seed=1234 + rank,
                              fixed_frames=args.fixed_frames if args.fixed_frames > 0 else None)
+
+  if args.no_host_lens:
+    batch.pop('source_lengths_host', None)
 
   def barrier():
     if world > 1:

@@ -160,6 +160,14 @@ int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
  * device from the live-window count: 2 windows x 256 columns, or 2 / 3 windows x 128 columns;
  * 12 / 13 / 14 = ping-pong with the 2 x 128 / 3 x 128 / 2 x 256 tile forced */
 void os2s_conv1d_set_variant(int v);
+/* Optional hint: a HOST copy of the int32 sequence lengths that the forward launches which follow receive
+ * as in_len (lens == NULL or B <= 0 withdraws it). The tile of a ping-pong launch depends on the number of live
+ * 128-row windows of the ragged batch; without the hint that number is only known on the device, both
+ * ping-pong kernels are enqueued and the one not chosen exits (~8 us per launch); with it the same cost
+ * model is evaluated at launch time and one kernel is enqueued. The hint only selects among tiles that are
+ * all exact for any data: lengths that differ from the device's cost speed, never results. Process-wide
+ * state, like the variant hook: set it around the launches of one batch (the encoder does). Returns OS2S_OK. */
+int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
 /* Named tuning options (test / measurement aid; nothing in the library reads the environment for them):
  *   conv1d.pp_cost_256, conv1d.pp_cost_2x128, conv1d.pp_cost_3x128: fitted microseconds per 64-deep step
  *     of the three ping-pong convolution tiles — the constants of the device-side tile choice; a cost

@@ -104,6 +104,19 @@ def deterministic():
   return bool(_fn("os2s_deterministic", (), c_int)())
 
 
+def conv1d_set_host_lens(lens):
+  """Hands the launcher a HOST copy (sequence of ints / numpy int32) of the lengths the following forward
+  convolutions receive as in_len, or withdraws it (None). See include/os2s.h: a hint that saves the second
+  (null) launch of the device-side tile choice; it cannot change results."""
+  import ctypes
+  f = _fn("os2s_conv1d_set_host_lens", (c_void_p, c_int))
+  if lens is None:
+    _lib.check(f(None, 0), "os2s_conv1d_set_host_lens")
+    return
+  arr = (ctypes.c_int32 * len(lens))(*[int(v) for v in lens])
+  _lib.check(f(ctypes.cast(arr, c_void_p), len(lens)), "os2s_conv1d_set_host_lens")
+
+
 def conv1d_workspace(device):
   """Caller-owned workspace of os2s_conv1d_fwd_ws (tickets zeroed once): one per (device,
   stream) — launches that may overlap must not share one."""

@@ -39,6 +39,7 @@
 #include <type_traits>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace os2s {
 
@@ -322,7 +323,7 @@ __device__ __forceinline__ void pp_zero_role(const ConvArgs& p, const int nw, co
 }
 
 // Tail-split factor of the 256-column tile (same decision in every workgroup: pure function of the launch)
-__device__ __forceinline__ int pp256_split(const ConvArgs& p, const int U, const int S) {
+__host__ __device__ __forceinline__ int pp256_split(const ConvArgs& p, const int U, const int S) {
   const int G = p.ncu;
   const int q = U / G, r = U - q * G;
   int f = 1;
@@ -344,7 +345,7 @@ __device__ __forceinline__ int pp256_split(const ConvArgs& p, const int U, const
 // The model is rounds x steps x microseconds per step of the tile (+ the fitted tail-split terms):
 // what decides is how many equal units a layer gives — Jasper's 384 / 512 / 640-channel layers on the
 // bench batch are 146 / 146 / 219 units of 256 columns on 256 CUs, but 219 / 196 / 245 narrow ones.
-__device__ __forceinline__ int pp_choose_tile(const ConvArgs& p, const int L) {
+__host__ __device__ __forceinline__ int pp_choose_tile(const ConvArgs& p, const int L) {
   if (p.pp_tile >= 0) return p.pp_tile;
   const int G = p.ncu, S = p.nchunks * p.K;
   float best;
@@ -412,7 +413,11 @@ __device__ __forceinline__ int pp_live_windows(const ConvArgs& p, const int lane
 
 // The two ping-pong kernels of a launch whose tile is chosen on the device (pp_tile < 0) are enqueued
 // back to back; every workgroup of both evaluates pp_choose_tile and the kernel that was not chosen
-// exits at once (one global load + a wave scan: ~2 us per launch pair). They are separate kernels, not
+// exits at once (one global load + a wave scan per workgroup, but a grid of several hundred of them:
+// 7.5 - 8.7 us per null launch in profiles/r05_jasper_kernel_stats.csv, 0.35 ms of a Jasper step — which
+// is why a caller that holds the sequence lengths on the host hands them over, os2s_conv1d_set_host_lens:
+// the same function is then evaluated at launch time and only the chosen kernel is enqueued). They are
+// separate kernels, not
 // one kernel with three bodies: fused, the register allocator re-read kernel arguments inside the
 // main loops (s_load + s_waitcnt lgkmcnt(0) in every LOAD slot of the 256-column body).
 // DBG: per-slot s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py)
@@ -1061,6 +1066,9 @@ static int g_pp_prio = 0;
 // weight-gradient stream what counts is CU time, and a narrow tile needs 10-19 % MORE of it per output
 // (measured: Jasper step 40.6 -> 42.0 ms with the narrow tiles in backward, 39.16 -> 39.05 forward only)
 static float g_pp_cost[4] = {1.19f, 0.90f, 1.06f, 1000.f};
+// host copy of the sequence lengths of the forward launches that follow (os2s_conv1d_set_host_lens)
+static std::vector<int32_t> g_host_lens;
+static bool g_host_lens_set = false;
 
 // LDS bytes of the narrow tile's main loop (ppn_body): X windows double-buffered + weight ring of 3
 static size_t ppn_main_bytes(int nwin, int R) {
@@ -1143,9 +1151,22 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
     const size_t cap = (size_t)3 * ncu;
     a.ws_nslabs = (int)(n < cap ? n : cap);
   }
-  // upper bound of each grid (the live-window count — and with it the tile — is only known on the
-  // device): every unit of the padded batch + the pieces of a split tail + the store-only workgroups;
-  // surplus workgroups exit at once
+  // a forward launch whose lengths the host knows (no mask at all, or the caller's host copy): the tile
+  // choice is evaluated here — the same pure function the device evaluates — and ONE kernel is enqueued
+  if (tile < 0 && !a.out_len && (a.pp_ok2 || a.pp_ok3) &&
+      (a.in_len == nullptr || (g_host_lens_set && (int)g_host_lens.size() == a.B))) {
+    int L = 0;
+    for (int b = 0; b < a.B; ++b) {
+      int len = a.Tin;
+      if (a.in_len) len = std::min(std::max(g_host_lens[b], 0), a.Tin);
+      const int nw = len > 0 ? (len + a.padL + BM - 1) / BM : 0;
+      L += std::min(nw, a.mtiles_per_b);
+    }
+    tile = a.pp_tile = pp_choose_tile(a, L);
+  }
+  // upper bound of each grid (the live-window count — and with it the tile, unless the host knew the
+  // lengths — is only known on the device): every unit of the padded batch + the pieces of a split tail +
+  // the store-only workgroups; surplus workgroups exit at once
   const int nzero = a.out_len ? 0 : ceil_div(a.MT, kPpZeroWin);
   if (tile <= 0) {
     const int grid = ceil_div(a.MT, NWIN) * a.NT + a.ws_nslabs + nzero;
@@ -1193,6 +1214,16 @@ static int g_conv_split = -1;
 static unsigned long long* g_conv_dbg = nullptr;
 static int g_conv_fixed_w = 0;
 extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
+extern "C" int os2s_conv1d_set_host_lens(const int32_t* lens, int B) {
+  if (lens == nullptr || B <= 0) {
+    os2s::g_host_lens_set = false;
+    os2s::g_host_lens.clear();
+    return OS2S_OK;
+  }
+  os2s::g_host_lens.assign(lens, lens + B);
+  os2s::g_host_lens_set = true;
+  return OS2S_OK;
+}
 extern "C" void os2s_conv1d_set_split(int f) { g_conv_split = f; }
 // Named tuning options of the convolution launchers (one entry point instead of one exported setter
 // per knob; nothing here is read from the environment or per launch):

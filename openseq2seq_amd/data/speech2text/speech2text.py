@@ -256,6 +256,10 @@ class Speech2TextDataLayer(DataLayer):
     batch = {'source_tensors': [feats, frames], 'num_frames': int(sum(self.frames_for_samples(n) for n in n_out)),
              'padded_frames': int(B * feats.shape[1]),
              'source_ids': torch.tensor([e['index'] for e in exs], dtype=torch.int32, device=device)}
+    if not self._psf():
+      # the frame counts as the host computes them (= `frames`, tests/test_speech_data_gpu.py): a hint for the
+      # convolution launcher, see TDNNEncoder._encode
+      batch['source_lengths_host'] = np.array([self.frames_for_samples(n) for n in n_out], np.int32)
     if exs[0]['target'] is not None:
       tl = np.array([len(e['target']) for e in exs], np.int32)
       tgt = np.zeros((B, max(int(tl.max()), 1)), np.int32)       # target_pad_value = 0 (:136)
@@ -356,6 +360,7 @@ class Speech2TextDataLayer(DataLayer):
       feats[b, frames[b]:] = 0
     return {
         'source_tensors': [feats.to(device), torch.from_numpy(frames).to(device)],
+        'source_lengths_host': frames.astype(np.int32).copy(),      # the same lengths, kept on the host
         'target_tensors': [torch.from_numpy(tgt).to(device), torch.from_numpy(tlen).to(device)],
         'num_frames': int(frames.sum()), 'padded_frames': int(B * T),
     }

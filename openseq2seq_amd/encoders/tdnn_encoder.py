@@ -11,6 +11,7 @@ from __future__ import absolute_import, division, print_function
 import torch
 
 from .encoder import Encoder
+from .. import capi
 import os
 
 from ..parts.cnns.conv_blocks import (Act, ConvBN, ConvOnly, SepConvBN, conv_actv, conv_bn_res_bn_actv,
@@ -127,11 +128,28 @@ class TDNNEncoder(Encoder):
     lens = src_length if use_mask else None
     # the data layer hands over already-padded features; mask the first conv input
     x = Act(source_sequence, lens, requires_grad=False)
+    # a host copy of the lengths, when the data layer kept one ('source_lengths_host'): the convolution
+    # launcher then chooses its tile at launch time instead of enqueueing both candidates
+    # (capi.conv1d_set_host_lens — a hint, it cannot change results); followed through the strides below
+    host_len = input_dict.get('source_lengths_host') if use_mask else None
+    if host_len is not None:
+      host_len = [int(v) for v in host_len]
+    try:
+      return self._encode_layers(x, src_length, host_len, tape, seed0, training, use_mask, act_fn, default_keep)
+    finally:
+      if host_len is not None:
+        capi.conv1d_set_host_lens(None)
+
+  def _encode_layers(self, x, src_length, host_len, tape, seed0, training, use_mask, act_fn, default_keep):
     residual_aggregation = []
     layer_res = []
     pending_res = None
+    hint_stale = host_len is not None
     nl = len(self._layers)
     for li, L in enumerate(self._layers):
+      if hint_stale:
+        capi.conv1d_set_host_lens(host_len)       # = the in_len of this layer's convolution
+        hint_stale = False
       blk, main = L['cfg'], L['main']
       if L['rep'] == 0 and blk.get('residual', False):
         if blk.get('residual_dense', False):
@@ -142,8 +160,12 @@ class TDNNEncoder(Encoder):
       s = blk['stride'][0]
       if blk['padding'] == "VALID":
         new_len = torch.div(src_length - blk['kernel_size'][0], s, rounding_mode='floor') + 1
+        if host_len is not None:
+          host_len, hint_stale = [(v - blk['kernel_size'][0]) // s + 1 for v in host_len], True
       elif s > 1:
         new_len = torch.div(src_length + s - 1, s, rounding_mode='floor')
+        if host_len is not None:
+          host_len, hint_stale = [(v + s - 1) // s for v in host_len], True
       else:
         new_len = src_length
       src_length = new_len

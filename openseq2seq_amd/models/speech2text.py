@@ -72,7 +72,8 @@ class Speech2Text(EncoderDecoderModel):
     """batch: dict(source_tensors=[feats bf16 [B,T,F], src_len int32 [B]],
                    target_tensors=[tgt int32 [B,L], tgt_len int32 [B]])."""
     enc = self._encoder.encode({'source_tensors': batch['source_tensors'], 'tape': tape,
-                                'seed': self._seed * 7919 + self._step_count})
+                                'seed': self._seed * 7919 + self._step_count,
+                                'source_lengths_host': batch.get('source_lengths_host')})
     dec = self._decoder.decode({'encoder_output': enc, 'tape': tape})
     scale_dev = self._train_op.loss_scale_view if self._train_op is not None else None
     loss = self._loss_computator.compute_loss({
@@ -83,7 +84,8 @@ class Speech2Text(EncoderDecoderModel):
 
   def forward(self, batch):
     """eval / infer forward pass: returns decoder output dict."""
-    enc = self._encoder.encode({'source_tensors': batch['source_tensors']})
+    enc = self._encoder.encode({'source_tensors': batch['source_tensors'],
+                                'source_lengths_host': batch.get('source_lengths_host')})
     return self._decoder.decode({'encoder_output': enc})
 
   def _decoded(self, dec):

@@ -346,6 +346,41 @@ def test_conv_narrow_pingpong_tiles_full_size_bit_identical(cuda, C, K):
         assert torch.equal(outs[name][2] * live, outs["tile"][2] * live), (name, trial)
 
 
+@pytest.mark.parametrize("C,K", [(384, 13), (512, 17), (640, 21)])
+def test_conv_host_length_hint_cannot_change_results(cuda, C, K):
+  """os2s_conv1d_set_host_lens: with a host copy of the lengths the launcher evaluates the tile choice
+  itself and enqueues one kernel. Whatever the hint says — the true lengths, lengths that are all wrong, a
+  vector of the wrong size (ignored) — the output equals the oracle-checked 128x128 tile's within the 1 ulp
+  a split 256-column tail may differ by, and the true hint gives the BITS of the device-side choice."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(5 * C + K)
+  B, T = 32, 840
+  x = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  w = _bf(torch.randn(K, C, C, generator=g) * (1.0 / (K * C) ** 0.5)).to(cuda)
+  lens_h = torch.randint(100, T + 1, (B,), generator=g).to(torch.int32)
+  lens = lens_h.to(cuda)
+
+  def run(variant, hint):
+    _lib.lib().os2s_conv1d_set_variant(variant)
+    capi.conv1d_set_host_lens(hint)
+    try:
+      y = torch.full((B, T, C), 3.0, dtype=torch.bfloat16, device=cuda)
+      capi.conv1d_fwd(x, w, in_len=lens, out=y)
+      torch.cuda.synchronize()
+      return y
+    finally:
+      capi.conv1d_set_host_lens(None)
+      _lib.lib().os2s_conv1d_set_variant(-1)
+
+  ref = run(3, None)
+  dev_choice = run(-1, None)
+  hinted = run(-1, lens_h.tolist())
+  assert torch.equal(hinted, dev_choice)
+  for hint in ([T] * B, [1] * B, [T // 3] * B, lens_h.tolist()[:5]):
+    y = run(-1, hint)
+    assert float((y.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+
+
 @pytest.mark.parametrize("B,T,Cin,Cout,K,d", [(3, 420, 256, 512, 17, 1), (2, 333, 320, 640, 21, 1),
                                               (2, 300, 768, 896, 29, 2), (4, 200, 128, 256, 2, 1),
                                               (2, 150, 192, 200, 5, 1)])

@@ -119,6 +119,8 @@ def test_data_layer_batches_vs_oracle(cuda, tmp_path):
     feats, frames = batch['source_tensors']
     tgt, tl = batch['target_tensors']
     assert feats.shape[1] % 16 == 0
+    # the host copy of the lengths (the convolution launcher's tile hint) is the device's lengths
+    assert batch['source_lengths_host'].tolist() == frames.cpu().tolist()
     for b in range(feats.shape[0]):
       path, _, txt = rows[int(batch['source_ids'][b])]
       _, sig = wavfile.read(path)
