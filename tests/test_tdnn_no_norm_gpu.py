@@ -83,7 +83,11 @@ def test_tdnn_without_normalization(cuda, act):
   (x * dy.float()).sum().backward()
   for p, w in zip(store.params, ws):
     got = p.grad.float().cpu().permute(0, 2, 1)
-    assert _rel(got, w.grad) <= 6e-3, (p.name, _rel(got, w.grad))
+    # relu20: four hard-capped layers on inputs that differ by single bf16 ulps between the two sides move a few
+    # pre-activations across the cap, each flip a full-size gradient (1.3e-2 measured; a wrong cap convention
+    # measures 6e-2, and the kernel's own backward is pinned tightly in test_batchnorm_gpu's relu20 cases)
+    bound = 6e-3 if act == "relu" else 2e-2
+    assert _rel(got, w.grad) <= bound, (p.name, _rel(got, w.grad))
 
 
 class _Tok(object):
