@@ -353,6 +353,11 @@ __device__ __forceinline__ void wpp_barrier() {
 }
 
 constexpr int kWppTaps = 4;
+// descriptor words + X row offset of one staged step (conv1d_wgrad_pp_kernel: prep / issue)
+struct WppStaged {
+  unsigned ylo, yhi, ynr, xlo, xhi, xnr;
+  int xro;
+};
 
 // DBG: per-slot s_memtime stamps of waves 0 and 4 of workgroups 0..3 (tools/pp_timeline.py)
 template <bool DBG>
@@ -469,36 +474,56 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   const int ycol_bytes = __builtin_amdgcn_readfirstlane(p.Cout * 2);
   const int xcol_bytes = __builtin_amdgcn_readfirstlane((int)p.x_ld * 2);
   const unsigned long long xsample_bytes = (unsigned long long)p.Tin * (unsigned long long)p.x_ld * 2ull;
-  // stage the tiles of the step described by table entry `ent`
-  auto stage = [&](int ent, int ybuf_idx, int xbuf_idx) {
+  // Staging the tiles of the step described by table entry `ent` is two things: `prep` — the two buffer
+  // descriptors and the row offset of the X window, ~30 scalar instructions — and `issue`, the five LDS-DMA
+  // instructions themselves. In the loop `prep` for step s+2 runs INSIDE the COMPUTE slot of step s, between
+  // its MFMAs (round 5: tools/pp_timeline.py showed the LOAD slot that carried both at 908 cycles against 598
+  // of the COMPUTE slot it is paired with — the partner waited 300 cycles per step at the barrier).
+  // (the words are pinned to scalar registers where they are computed — an empty asm — or the compiler sinks
+  // the whole computation back to its first use in the LOAD slot)
+  auto prep = [&](int ent) __attribute__((always_inline)) -> WppStaged {
     const int b = ent & 0xff, t0 = ((ent >> 8) & 0xff) * BT, len_b = (int)((unsigned)ent >> 16);
+    WppStaged st;
     // dY rows t0.. of sample b; num_records up to the sample end (rows >= Tout read as zeros)
     const unsigned long long yb = dy_base + (unsigned long long)(unsigned)(b * p.Tout + t0) * (unsigned)ycol_bytes;
+    st.ylo = (unsigned)yb; st.yhi = (unsigned)(yb >> 32);
+    st.ynr = (unsigned)((p.Tout - t0) * ycol_bytes);
+    // X rows of sample b, num_records = in_len rows: rows < 0 (a negative offset) and rows >=
+    // in_len read as zeros
+    const unsigned long long xb = x_base + (unsigned long long)(unsigned)b * xsample_bytes;
+    st.xlo = (unsigned)xb; st.xhi = (unsigned)(xb >> 32);
+    st.xnr = (unsigned)(len_b * xcol_bytes);
+    st.xro = (t0 + k0 * p.dil - p.padL) * xcol_bytes;
+#if defined(__HIP_DEVICE_COMPILE__)      // ("s" is a scalar-register constraint of the device pass only)
+    asm volatile("" : "+s"(st.ylo), "+s"(st.yhi), "+s"(st.ynr), "+s"(st.xlo), "+s"(st.xhi), "+s"(st.xnr), "+s"(st.xro));
+#endif
+    return st;
+  };
+  auto issue = [&](const WppStaged& st, int ybuf_idx, int xbuf_idx) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)yb, 0, (p.Tout - t0) * ycol_bytes, 0x00020000);
+        (void*)(((unsigned long long)st.yhi << 32) | st.ylo), 0, (int)st.ynr, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)st.xhi << 32) | st.xlo), 0, (int)st.xnr, 0x00020000);
     char* const yd = ybuf0 + ybuf_idx * YBUF;
     if (!(DBG && (p.dbg_mode & 1)))
 #pragma unroll
     for (int it = 0; it < 2; ++it)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           yrs, (__attribute__((address_space(3))) void*)(yd + (it * 8 + wid) * 1024), 16, yv[it], 0, 0, 0);
-    // X rows of sample b, num_records = in_len rows: rows < 0 (a negative offset) and rows >=
-    // in_len read as zeros
-    const unsigned long long xb = x_base + (unsigned long long)(unsigned)b * xsample_bytes;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)xb, 0, len_b * xcol_bytes, 0x00020000);
-    const int xro = (t0 + k0 * p.dil - p.padL) * xcol_bytes;
     char* const xd = xbuf0 + xbuf_idx * xbuf_bytes;
     if (!(DBG && (p.dbg_mode & 2))) {
 #pragma unroll
       for (int n = 0; n < 2; ++n)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             xrs, (__attribute__((address_space(3))) void*)(xd + (n * 8 + wid) * 1024), 16,
-            xv[n] + xro, 0, 0, 0);
+            xv[n] + st.xro, 0, 0, 0);
       if (x3)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            xrs, (__attribute__((address_space(3))) void*)(xd + (16 + wid) * 1024), 16, xv[2] + xro, 0, 0, 0);
+            xrs, (__attribute__((address_space(3))) void*)(xd + (16 + wid) * 1024), 16, xv[2] + st.xro, 0, 0, 0);
     }
+  };
+  auto stage = [&](int ent, int ybuf_idx, int xbuf_idx) __attribute__((always_inline)) {
+    issue(prep(ent), ybuf_idx, xbuf_idx);
   };
 
   // taps past K (the last tap quad of K = 4n + 1 ... 4n + 3: every Jasper layer has K = 4n + 1) are
@@ -575,7 +600,9 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
       stamp(s, 0);
       wpp_barrier();
       stamp(s, 1);
-      // ---- COMPUTE(2s)
+      // ---- COMPUTE(2s): the MFMAs and, between them, the descriptors of step s+2 (its table entry landed
+      //      with the lgkmcnt(0) that closed the LOAD slot)
+      WppStaged nxt;
       if (live0) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -584,7 +611,18 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[i][kk], xf[j][kk], acc[0][i][j], 0, 0, 0);
+        nxt = prep(__builtin_amdgcn_readfirstlane(ent_v));
+        // one MFMA, then up to three scalar / one vector instruction of the preparation, and so on
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+      } else {
+        nxt = prep(__builtin_amdgcn_readfirstlane(ent_v));
       }
+      if (DBG) __builtin_amdgcn_sched_barrier(0);
       stamp(s, 2);
       wpp_barrier();
       stamp(s, 3);
@@ -603,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
       {
         int x2 = xi + 2;
         x2 = x2 >= 3 ? x2 - 3 : x2;
-        if (s + 2 < nsteps) stage(__builtin_amdgcn_readfirstlane(ent_v), s & 1, x2);
+        if (s + 2 < nsteps) issue(nxt, s & 1, x2);
         xi = xi + 1 >= 3 ? 0 : xi + 1;
       }
       stamp(s, 5);
