@@ -27,6 +27,33 @@ from ..utils import distributed as dist_utils
 from ..utils.utils import check_params
 
 
+def resolve_lr_params(lr_policy, lr_policy_params, last_step, steps_in_epoch, has_num_epochs):
+  """The defaults Model.compile adds to `lr_policy_params` before the policy is built (models/model.py:479-495),
+  by the policy function's signature: `decay_steps` = the last step of the run when the policy has the parameter
+  and the config does not set it — then also `begin_decay_at` = max(begin_decay_at, warmup_steps) and
+  `decay_steps` reduced by it (the decay starts no earlier than the warm-up ends and runs over what is left);
+  `steps_per_epoch` = the epoch length when the run is configured in epochs (piecewise_constant boundaries are
+  given in epochs then). `last_step` / `steps_in_epoch`: callables, evaluated only when needed. Returns a new
+  dict."""
+  import inspect
+  lr_params = dict(lr_policy_params)
+  try:
+    func_params = inspect.signature(lr_policy).parameters
+  except (TypeError, ValueError):
+    func_params = {}
+  if 'decay_steps' in func_params and 'decay_steps' not in lr_params:
+    lr_params['decay_steps'] = last_step()
+    if 'begin_decay_at' in func_params:
+      if 'warmup_steps' in func_params:
+        lr_params['begin_decay_at'] = max(lr_params.get('begin_decay_at', 0), lr_params.get('warmup_steps', 0))
+      lr_params['decay_steps'] -= lr_params.get('begin_decay_at', 0)
+  if 'steps_per_epoch' in func_params and 'steps_per_epoch' not in lr_params and has_num_epochs:
+    spe = steps_in_epoch()
+    if spe is not None:
+      lr_params['steps_per_epoch'] = spe
+  return lr_params
+
+
 @six.add_metaclass(abc.ABCMeta)
 class Model(object):
   @staticmethod
@@ -160,26 +187,8 @@ class Model(object):
       p = self._params
       if 'lr_policy' not in p:
         raise ValueError("lr_policy has to be specified for train mode")
-      lr_params = dict(p.get('lr_policy_params', {}))
-      # model.py:492-499: decay_steps defaults to the total number of steps
-      import inspect
-      try:
-        func_params = inspect.signature(p['lr_policy']).parameters
-      except (TypeError, ValueError):
-        func_params = {}
-      if 'decay_steps' in func_params and 'decay_steps' not in lr_params:
-        lr_params['decay_steps'] = self._last_step()
-        # model.py:484-490: the decay starts no earlier than the warm-up ends, and runs over what is left
-        if 'begin_decay_at' in func_params:
-          if 'warmup_steps' in func_params:
-            lr_params['begin_decay_at'] = max(lr_params.get('begin_decay_at', 0),
-                                              lr_params.get('warmup_steps', 0))
-          lr_params['decay_steps'] -= lr_params.get('begin_decay_at', 0)
-      # model.py:492-494: policies stated in epochs (piecewise_constant boundaries) get the epoch length
-      if 'steps_per_epoch' in func_params and 'steps_per_epoch' not in lr_params and 'num_epochs' in p:
-        spe = self.steps_in_epoch
-        if spe is not None:
-          lr_params['steps_per_epoch'] = spe
+      lr_params = resolve_lr_params(p['lr_policy'], p.get('lr_policy_params', {}), self._last_step,
+                                    lambda: self.steps_in_epoch, 'num_epochs' in p)
       self._train_op = optimize_loss(
           self._store, p['optimizer'], p.get('optimizer_params', {}), p['lr_policy'],
           lr_params, dtype=p['dtype'], clip_gradients=p.get('max_grad_norm', None),
