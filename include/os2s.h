@@ -1114,6 +1114,29 @@ int os2s_ctc_dict_beam_search(const float* probs, long long ld_t, long long ld_b
                               const void* scorer, int n_threads, int32_t* out_ids,
                               int32_t* out_len, float* out_score);
 
+/* ------------------------------------------------------------------------
+ * Per-sample normalisations of the TDNN encoder (csrc/sample_norm.hip): tf.contrib.layers.layer_norm and
+ * tf.contrib.layers.instance_norm as conv_ln_actv / conv_in_actv apply them to a channels-last convolution
+ * output (open_seq2seq/parts/cnns/conv_blocks.py:234-309; selected by TDNNEncoder's `normalization`
+ * 'layer_norm' / 'instance_norm', encoders/tdnn_encoder.py:144-156).
+ *   x, z, dz, dx  [B, T, C] bf16 (C even); gamma, beta, dgamma, dbeta [C] fp32; mean, rstd [B, C] fp32
+ *   mode 0 = instance norm: statistics per (sample, channel) over the T frames of the padded tensor
+ *            (the reference normalises the padded tensor), epsilon 1e-6 in the reference
+ *   mode 1 = layer norm with the defaults the reference leaves in place (begin_norm_axis = 1,
+ *            begin_params_axis = -1): statistics per sample over all T x C values, epsilon 1e-12
+ * fwd: z = gamma * (x - mean) * rstd + beta, mean / rstd saved for bwd. bwd: dx, and dgamma / dbeta
+ * ACCUMULATED (+=). partial: os2s_sample_norm_partial_floats(B, C) floats; scratch (bwd): 4 * B * C floats.
+ * Deterministic (fixed-order reductions). Activation, dropout and the sequence mask are the caller's next
+ * pass (os2s_bn_act_fwd with scale 1 / shift 0).
+ * ---------------------------------------------------------------------- */
+size_t os2s_sample_norm_partial_floats(int B, int C);
+int os2s_sample_norm_fwd(os2s_stream_t stream, const uint16_t* x, const float* gamma, const float* beta,
+                         int B, int T, int C, int mode, float eps, uint16_t* z, float* mean, float* rstd,
+                         float* partial);
+int os2s_sample_norm_bwd(os2s_stream_t stream, const uint16_t* dz, const uint16_t* x, const float* gamma,
+                         const float* mean, const float* rstd, int B, int T, int C, int mode, uint16_t* dx,
+                         float* dgamma, float* dbeta, float* partial, float* scratch);
+
 #ifdef __cplusplus
 }
 #endif

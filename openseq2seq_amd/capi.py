@@ -413,6 +413,43 @@ def bn_stats(y2d):
   return partial
 
 
+def sample_norm_fwd(x, gamma, beta, mode, eps):
+  """Per-sample normalisation of a [B, T, C] bf16 tensor (csrc/sample_norm.hip): mode 0 = instance norm (per
+  sample and channel over T), 1 = layer norm over (T, C). Returns (z bf16, mean [B, C], rstd [B, C])."""
+  B, T, C = x.shape
+  assert x.is_contiguous() and x.dtype == torch.bfloat16
+  dev = x.device
+  z = torch.empty_like(x)
+  mean = torch.empty((B, C), dtype=torch.float32, device=dev)
+  rstd = torch.empty((B, C), dtype=torch.float32, device=dev)
+  nf = int(_fn("os2s_sample_norm_partial_floats", (c_int, c_int), c_size_t)(B, C))
+  part = torch.empty(nf, dtype=torch.float32, device=dev)
+  f = _fn("os2s_sample_norm_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(gamma, torch.float32), _ptr(beta, torch.float32), B, T, C,
+               int(mode), float(eps), _ptr(z, torch.bfloat16), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
+               _ptr(part, torch.float32)), "os2s_sample_norm_fwd")
+  return z, mean, rstd
+
+
+def sample_norm_bwd(dz, x, gamma, mean, rstd, mode, dgamma, dbeta):
+  """Gradient of sample_norm_fwd: returns dx (bf16); dgamma / dbeta (fp32 [C]) are accumulated into."""
+  B, T, C = x.shape
+  assert x.is_contiguous() and dz.is_contiguous()
+  dev = x.device
+  dx = torch.empty_like(x)
+  nf = int(_fn("os2s_sample_norm_partial_floats", (c_int, c_int), c_size_t)(B, C))
+  part = torch.empty(nf, dtype=torch.float32, device=dev)
+  scratch = torch.empty(4 * B * C, dtype=torch.float32, device=dev)
+  f = _fn("os2s_sample_norm_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(x, torch.bfloat16), _ptr(gamma, torch.float32),
+               _ptr(mean, torch.float32), _ptr(rstd, torch.float32), B, T, C, int(mode), _ptr(dx, torch.bfloat16),
+               _ptr(dgamma, torch.float32), _ptr(dbeta, torch.float32), _ptr(part, torch.float32),
+               _ptr(scratch, torch.float32)), "os2s_sample_norm_bwd")
+  return dx
+
+
 def bn_act_fwd(ys, scales, shifts, out, out_len, act, keep_prob, seed):
   B, T, C = out.shape
   J = len(ys)

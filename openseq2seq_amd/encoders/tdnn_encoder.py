@@ -14,7 +14,7 @@ from .encoder import Encoder
 from .. import capi
 import os
 
-from ..parts.cnns.conv_blocks import (Act, ConvBN, ConvOnly, SepConvBN, conv_actv, conv_bn_res_bn_actv,
+from ..parts.cnns.conv_blocks import (Act, ConvBN, ConvOnly, ConvSampleNorm, SepConvBN, conv_actv, conv_bn_res_bn_actv,
                                       xavier_normal_conv, glorot_uniform_conv, launch_residual_early)
 
 # which layer of a residual block starts the block end's residual branches on the side stream
@@ -50,11 +50,12 @@ class TDNNEncoder(Encoder):
     super(TDNNEncoder, self).__init__(params, model, name, mode)
     # normalization None = conv_actv (conv_blocks.py:17-58): convolution + activation, BatchNorm only at the
     # residual block ends, which go through conv_bn_res_bn_actv whatever the setting (tdnn_encoder.py:216-233).
-    # 'layer_norm' (tf.contrib.layers.layer_norm: statistics over time AND channels of a sample) and
-    # 'instance_norm' (over time, per sample and channel) have no kernels: no example config uses them
-    if self.params.get('normalization', 'batch_norm') not in ('batch_norm', None):
-      raise NotImplementedError("normalization %r: only 'batch_norm' and None have HIP kernels"
-                                % (self.params.get('normalization'),))
+    # 'layer_norm' / 'instance_norm' = conv_ln_actv / conv_in_actv (conv_blocks.py:234-309) on
+    # csrc/sample_norm.hip. With those two the reference passes NO bn_momentum / bn_epsilon to a residual block
+    # end (normalization_params stays empty, tdnn_encoder.py:144-156) and conv_bn_res_bn_actv fails on its
+    # missing arguments: residual blocks are refused here as well
+    if self.params.get('normalization', 'batch_norm') not in ('batch_norm', None, 'layer_norm', 'instance_norm'):
+      raise ValueError("Incorrect normalization")
     if self.params.get('data_format', 'channels_last') != 'channels_last':
       raise NotImplementedError("HIP path is channels_last (the reference's default)")
     self._layers = None
@@ -90,7 +91,19 @@ class TDNNEncoder(Encoder):
       for ir in range(blk['repeat']):
         lname = "%s/conv%d%d" % (scope, ib + 1, ir + 1)
         block_end = residual and ir == blk['repeat'] - 1
-        if p.get('normalization', 'batch_norm') is None and not block_end:
+        norm = p.get('normalization', 'batch_norm')
+        if norm in ('layer_norm', 'instance_norm'):
+          if block_end:
+            raise ValueError("normalization %r with residual blocks: the reference calls conv_bn_res_bn_actv "
+                             "without bn_momentum / bn_epsilon there (tdnn_encoder.py:144-156, 216-233)" % norm)
+          if Layer is not ConvBN:
+            raise NotImplementedError("normalization=%r with sep_conv1d layers" % norm)
+          scope_name = ConvSampleNorm.MODES[norm][2]
+          n_norm = sum(isinstance(L['main'], ConvSampleNorm) for L in layers)
+          main = ConvSampleNorm(store, lname, "%s/%s%s" % (scope, scope_name, "_%d" % n_norm if n_norm else ""),
+                                norm, cin, blk['num_channels'], blk['kernel_size'][0], blk['stride'][0],
+                                blk['dilation'][0] if 'dilation' in blk else 1, blk['padding'], l2, initializer)
+        elif norm is None and not block_end:
           if Layer is not ConvBN:
             raise NotImplementedError("normalization=None with sep_conv1d layers")
           main = ConvOnly(store, lname, cin, blk['num_channels'], blk['kernel_size'][0], blk['stride'][0],

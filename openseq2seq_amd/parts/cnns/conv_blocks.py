@@ -745,6 +745,27 @@ class ConvOnly(ConvBN):
     return [self.kernel]
 
 
+class ConvSampleNorm(ConvOnly):
+  """The layer of conv_ln_actv / conv_in_actv (conv_blocks.py:234-309): tf.layers.conv1d(use_bias=False)
+  followed by tf.contrib.layers.layer_norm (mode 1: per sample over all T x C values of the padded tensor,
+  epsilon 1e-12, begin_norm_axis = 1 / begin_params_axis = -1 as the reference leaves them) or
+  tf.contrib.layers.instance_norm (mode 0: per sample and channel over T, epsilon 1e-6). Variables:
+  '<name>/kernel' and gamma / beta [C] under the scope tf.contrib gives them — 'LayerNorm' / 'InstanceNorm',
+  uniquified '_1', '_2', ... in creation order, directly under the encoder's scope (the reference opens no
+  per-layer scope around them)."""
+  MODES = {"instance_norm": (0, 1e-6, "InstanceNorm"), "layer_norm": (1, 1e-12, "LayerNorm")}
+
+  def __init__(self, store, name, norm_scope, kind, cin, cout, k, stride=1, dilation=1, padding="SAME", l2=0.0,
+               initializer=xavier_normal_conv):
+    super(ConvSampleNorm, self).__init__(store, name, cin, cout, k, stride, dilation, padding, l2, initializer)
+    self.mode, self.eps, _ = self.MODES[kind]
+    self.gamma = store.add(norm_scope + "/gamma", (cout,), torch.ones(cout), kind="vector")
+    self.beta = store.add(norm_scope + "/beta", (cout,), torch.zeros(cout), kind="vector")
+
+  def trainable(self):
+    return [self.kernel, self.gamma, self.beta]
+
+
 def conv_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, seed=0, mask_output=True):
   """act(conv(x)) -> dropout -> mask: conv_actv (conv_blocks.py:17-58) + the encoder's tf.nn.dropout and mask
   (tdnn_encoder.py:204-205, 255). Runs on the BatchNorm + activation kernels with the identity transform
@@ -757,11 +778,17 @@ def conv_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, 
   C = layer.cout
   y = capi.conv1d_fwd(x.data, layer.kernel.w16, stride=layer.stride, dil=layer.dil, pad_left=pl, tout=tout,
                       in_len=x.lens)
+  # conv_ln_actv / conv_in_actv: the per-sample normalisation sits between the convolution and the activation
+  norm = isinstance(layer, ConvSampleNorm)
+  if norm:
+    z, mean, rstd = capi.sample_norm_fwd(y, layer.gamma.master, layer.beta.master, layer.mode, layer.eps)
+  else:
+    z = y
   one, zero = torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev)
   out = torch.empty((B, tout, C), dtype=torch.bfloat16, device=dev)
   lens = out_lens if mask_output else None
   keep = keep_prob if training else 1.0
-  capi.bn_act_fwd([y], [one], [zero], out, lens, act, keep, seed)
+  capi.bn_act_fwd([z], [one], [zero], out, lens, act, keep, seed)
   result = Act(out, lens)
   if not (training and tape is not None):
     return result
@@ -773,8 +800,13 @@ def conv_actv(layer, x, out_lens, activation_fn, training, tape, keep_prob=1.0, 
     partial = torch.empty((capi.bn_act_bwd_num_parts(B * tout), 2, C), dtype=torch.float32, device=dev)
     # identity "BatchNorm": mean 0, rstd 1 — only dz = dout * act'(out) * dropout' is used, the partial sums
     # of the BatchNorm parameters are ignored
-    capi.bn_act_bwd_reduce(dout, out, [y], [zero], [one], dz, partial, lens, act, keep, seed)
+    capi.bn_act_bwd_reduce(dout, out, [z], [zero], [one], dz, partial, lens, act, keep, seed)
     result.grad = None
+    if norm:
+      # the statistics run over the PADDED tensor (as the reference's): the gradient reaches rows past the
+      # sequence end too, and from there the kernel taps that still see live input rows
+      dz = capi.sample_norm_bwd(dz, y, layer.gamma.master, mean, rstd, layer.mode, layer.gamma.grad,
+                                layer.beta.grad)
     layer.backward_branch(x, dz, dict(pad_left=pl), final=False)
 
   tape.record(backward, layer.trainable())

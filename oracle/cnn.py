@@ -111,6 +111,27 @@ def batch_norm_eval(y, gamma, beta, eps, moving_mean, moving_var):
   return (y - moving_mean) * torch.rsqrt(moving_var + eps) * gamma + beta
 
 
+def layer_norm_tf(y, gamma, beta, eps=1e-12):
+  """tf.contrib.layers.layer_norm(inputs=conv) as conv_ln_actv calls it (conv_blocks.py:262-264; TensorFlow 1.x
+  contrib, a dependency that is not vendored in the reference — "parity unpinned" against TensorFlow itself; its
+  published algorithm, tensorflow/contrib/layers/python/layers/layers.py `layer_norm`): begin_norm_axis = 1 —
+  moments over ALL axes but the batch axis, here the T x C values of a sample (padded frames included) —,
+  begin_params_axis = -1 — gamma / beta of shape [C] —, tf.nn.batch_normalization with variance_epsilon 1e-12.
+  y [B, T, C] fp32 (differentiable)."""
+  mean = y.mean(dim=(1, 2), keepdim=True)
+  var = ((y - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+  return (y - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def instance_norm_tf(y, gamma, beta, eps=1e-6):
+  """tf.contrib.layers.instance_norm(inputs=conv, data_format="NHWC") as conv_in_actv calls it
+  (conv_blocks.py:298-301; same unvendored dependency): moments per sample and channel over the remaining
+  (time) axis of the padded tensor, gamma / beta of shape [C], epsilon 1e-6. y [B, T, C] fp32."""
+  mean = y.mean(dim=1, keepdim=True)
+  var = ((y - mean) ** 2).mean(dim=1, keepdim=True)
+  return (y - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
 def act_fn(x, act):
   if act in (None, "none", 0):
     return x
