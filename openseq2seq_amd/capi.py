@@ -201,13 +201,32 @@ class _ZeroArena(object):
     return out[:m].view(shape)
 
 
-_zero_arena = _ZeroArena()
+# One arena per NESTING DEPTH of Tape.backward: a backward pass started from inside a closure of another one
+# (depth 1, 2, ...) takes its zeroed scratch from its own arena and cannot re-zero the partials the outer pass
+# still has in flight. Arenas persist across steps (they learn a pass's demand once).
+_zero_arenas = [_ZeroArena()]
+_zero_arena = _zero_arenas[0]
+
+
+def zero_arena_enter(depth):
+  """Start of a backward pass at nesting depth `depth` (Tape.backward): selects that depth's arena; every
+  slice it handed out so far is dead (the pass that used them joined its side streams), re-zero what was
+  used."""
+  global _zero_arena
+  while len(_zero_arenas) <= depth:
+    _zero_arenas.append(_ZeroArena())
+  _zero_arena = _zero_arenas[depth]
+  _zero_arena.reset()
+
+
+def zero_arena_leave(depth):
+  """End of the pass at `depth`: the enclosing pass (if any) gets its arena back, untouched."""
+  global _zero_arena
+  _zero_arena = _zero_arenas[max(depth - 1, 0)]
 
 
 def zero_arena_reset():
-  """Start of a backward pass (Tape.backward): every slice handed out so far is dead (the pass that
-  used them joined its side streams), re-zero what was used."""
-  _zero_arena.reset()
+  zero_arena_enter(0)
 
 
 def conv1d_dgrad_bnact(dy, wt, dx, *, dil, pad_left, accumulate, out_len, mask_ref, mask_scale, stat_ref):

@@ -167,15 +167,14 @@ class Tape(object):
     self.ops.append((fn, params))
 
   def backward(self):
-    # work parked on the side stream since the last join must have landed
-    global _CUR_TAPE
-    # one backward pass at a time: the zeroed scratch of the BatchNorm-backward partials (capi._zero_arena)
-    # and the side streams are per process, a pass started inside another one would re-zero live partials
-    if _CUR_TAPE is not None:
-      raise RuntimeError("Tape.backward() called while another backward pass is running")
+    # Re-entrant: a closure may run another tape's backward pass (a nested pass gets the zeroed scratch arena
+    # of its own depth — capi.zero_arena_enter — and its own deferred-gradient list; `current_tape()` is the
+    # innermost pass). Work parked on the side streams since the last join must have landed first.
+    depth = len(_TAPE_STACK)
     join_side_streams()
-    capi.zero_arena_reset()       # the previous pass's statistic partials are dead: one fill for this pass
-    _CUR_TAPE, self._deferred, self._pending = self, [], None
+    capi.zero_arena_enter(depth)   # the previous pass's statistic partials at this depth are dead: one fill
+    _TAPE_STACK.append(self)
+    self._deferred, self._pending = [], None
     try:
       if self.on_done is None:
         for fn, _ in reversed(self.ops):
@@ -210,7 +209,8 @@ class Tape(object):
           self.flush_deferred()
           advance()
     finally:
-      _CUR_TAPE = None
+      _TAPE_STACK.pop()
+      capi.zero_arena_leave(depth)
     self.ops = []
     join_side_streams()
 
@@ -243,12 +243,12 @@ class Tape(object):
     self._deferred = []
 
 
-_CUR_TAPE = None
+_TAPE_STACK = []
 
 
 def current_tape():
-  """The tape whose backward pass is running (None outside Tape.backward)."""
-  return _CUR_TAPE
+  """The tape whose backward pass is running — the innermost one (None outside Tape.backward)."""
+  return _TAPE_STACK[-1] if _TAPE_STACK else None
 
 
 class Act(object):

@@ -31,25 +31,58 @@ def test_zero_arena_hands_out_disjoint_zeroed_slices():
   assert arena.buf.numel() >= big.numel()
 
 
-def test_tape_backward_refuses_to_nest():
-  """The zeroed scratch is per process: a backward pass started from inside another one must fail loudly
-  instead of re-zeroing the outer pass's partials."""
-  import pytest
+def test_tape_backward_nests_with_an_arena_per_depth():
+  """Tape.backward is re-entrant (product hygiene): a pass started from inside a closure of
+  another one takes its zeroed scratch from the arena of ITS depth — the outer pass's partials stay as they
+  are — and current_tape() is the innermost pass."""
   from openseq2seq_amd.parts.cnns import conv_blocks as cb
   from openseq2seq_amd import capi
-  calls = []
-  saved = (cb.join_side_streams, capi.zero_arena_reset)
+  dev = torch.device("cpu")
+  saved = cb.join_side_streams
   cb.join_side_streams = lambda: None
-  capi.zero_arena_reset = lambda: calls.append("reset")
+  seen = []
   try:
-    inner = cb.Tape()
-    inner.record(lambda: calls.append("inner"))
-    outer = cb.Tape()
-    outer.record(lambda: inner.backward())
-    with pytest.raises(RuntimeError, match="another backward pass"):
+    for rounds in range(3):          # round 0 teaches the arenas their demand, later rounds hand out arena slices
+      held = {}
+      inner = cb.Tape()
+
+      def inner_op():
+        seen.append(("inner", cb.current_tape() is inner))
+        t = capi._zero_arena.take((4, 2, 16), dev)
+        assert float(t.abs().sum()) == 0.0
+        t.fill_(7.0)
+        held["inner"] = t
+      inner.record(inner_op)
+      outer = cb.Tape()
+
+      def outer_first():            # runs LAST (reverse order): the partials written before the nested pass survive
+        seen.append(("outer_first", cb.current_tape() is outer))
+        assert float(held["outer"].sum()) == 5.0 * held["outer"].numel()
+        if rounds:
+          a = held["outer"].data_ptr()
+          b = held["inner"].data_ptr()
+          assert abs(a - b) >= held["outer"].numel() * 4 or capi._zero_arenas[0].buf is not capi._zero_arenas[1].buf
+
+      def outer_last():             # runs FIRST: takes scratch, writes it, then a nested pass runs
+        t = capi._zero_arena.take((6, 2, 16), dev)
+        assert float(t.abs().sum()) == 0.0
+        t.fill_(5.0)
+        held["outer"] = t
+        inner.backward()
+        assert cb.current_tape() is outer and capi._zero_arena is capi._zero_arenas[0]
+      outer.record(outer_first)
+      outer.record(outer_last)
       outer.backward()
-    assert cb.current_tape() is None and calls == ["reset"]      # the outer pass cleaned up, the inner never ran
-    inner.backward()                                             # sequential passes are fine
-    assert calls == ["reset", "reset", "inner"]
+      assert cb.current_tape() is None and capi._zero_arena is capi._zero_arenas[0]
+    assert len(capi._zero_arenas) >= 2 and capi._zero_arenas[1].buf is not None
+    assert all(ok for _, ok in seen) and len(seen) == 6
+    # a failing closure unwinds the stack
+    bad = cb.Tape()
+    bad.record(lambda: 1 / 0)
+    try:
+      bad.backward()
+    except ZeroDivisionError:
+      pass
+    assert cb.current_tape() is None and capi._zero_arena is capi._zero_arenas[0]
   finally:
-    cb.join_side_streams, capi.zero_arena_reset = saved
+    cb.join_side_streams = saved
