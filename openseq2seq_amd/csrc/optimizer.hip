@@ -98,6 +98,9 @@ __device__ float lr_policy_value(const os2s_opt_config_t& c, long long step) {
 // ---- pass 1: per-chunk statistics of the effective gradient ----------------
 // g_eff = g * inv_scale + l2[tensor] * w      (mp_wrapper.py:79-95)
 // partial[c] = {sum g_eff^2, sum w^2, max |g_eff|, nan flag}
+// NEED_W = false: no tensor has an l2 term and LARC is off — the weights are not read at all (a third of
+// this pass's 2.7 GB for Transformer-big; round 5)
+template <bool NEED_W>
 __global__ __launch_bounds__(256) void mt_grad_stats_kernel(
     const float* __restrict__ grads, const float* __restrict__ weights,
     const int32_t* __restrict__ chunk_tensor, const float* __restrict__ tensor_l2,
@@ -113,10 +116,11 @@ __global__ __launch_bounds__(256) void mt_grad_stats_kernel(
 #pragma unroll
   for (int i = 0; i < kChunk / 4 / 256; ++i) {
     const f32x4 g = g4[i * 256 + threadIdx.x];
-    const f32x4 w = w4[i * 256 + threadIdx.x];
+    f32x4 w = {0.f, 0.f, 0.f, 0.f};
+    if (NEED_W) w = w4[i * 256 + threadIdx.x];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float ge = g[e] * inv + l2 * w[e];
+      const float ge = NEED_W ? g[e] * inv + l2 * w[e] : g[e] * inv;
       sg += ge * ge;
       sw += w[e] * w[e];
       mx = fmaxf(mx, fabsf(ge));   // fmaxf drops NaN -> tracked separately
@@ -336,7 +340,9 @@ __global__ __launch_bounds__(256) void mt_apply_kernel(
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const long long off = base + (long long)i * 1024;
-    g[i] = *reinterpret_cast<const f32x4*>(grads + off);
+    // the gradient is dead after this pass and the bf16 copy is next read a step later: nontemporal (the
+    // pattern alone, tools/probe_streams.hip: 5.89 -> 6.14 TB/s)
+    g[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grads + off));
     w[i] = *reinterpret_cast<const f32x4*>(weights + off);
     if (OPT != 0) m[i] = *reinterpret_cast<const f32x4*>(m1 + off);
     if (OPT == 3) v[i] = *reinterpret_cast<const f32x4*>(m2 + off);
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void mt_apply_kernel(
       u32x2 o;
       o[0] = pack2bf(w[i][0], w[i][1]);
       o[1] = pack2bf(w[i][2], w[i][3]);
-      *reinterpret_cast<u32x2*>(w16 + off) = o;
+      __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(w16 + off));
     }
   }
 }
@@ -497,8 +503,13 @@ extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg
   hipStream_t stream = (hipStream_t)stream_;
   OptDeviceState* st = (OptDeviceState*)state;
   OS2S_LAUNCH(opt_latch_scale_kernel, dim3(1), dim3(1), 0, stream, st);
-  OS2S_LAUNCH(mt_grad_stats_kernel, dim3(nchunks), dim3(256), 0, stream, grads, weights,
-              chunk_tensor, tensor_l2, st, cfg->world_size, partial);
+  if (tensor_l2 != nullptr || cfg->use_larc) {
+    OS2S_LAUNCH(mt_grad_stats_kernel<true>, dim3(nchunks), dim3(256), 0, stream, grads, weights,
+                chunk_tensor, tensor_l2, st, cfg->world_size, partial);
+  } else {
+    OS2S_LAUNCH(mt_grad_stats_kernel<false>, dim3(nchunks), dim3(256), 0, stream, grads, weights,
+                chunk_tensor, tensor_l2, st, cfg->world_size, partial);
+  }
   OS2S_LAUNCH(mt_tensor_reduce_kernel, dim3(ntensors), dim3(256), 0, stream, partial,
               tensor_chunk_begin, tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult);
   OS2S_LAUNCH(mt_finalize_kernel, dim3(1), dim3(256), 0, stream, ntensors, *cfg, st,

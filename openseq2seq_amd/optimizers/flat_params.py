@@ -89,6 +89,9 @@ class FlatParams(object):
     self.chunk_tensor = torch.from_numpy(chunk_tensor).to(dev)
     self.tensor_chunk_begin = torch.tensor(begins, dtype=torch.int32, device=dev)
     self.tensor_l2 = torch.tensor([p.l2 for p in self.params], dtype=torch.float32, device=dev)
+    # no tensor has an l2 term: the optimizer's statistics pass does not read the weights at all (the host
+    # knows; a caller that writes into tensor_l2 afterwards sets this flag too)
+    self.l2_active = any(float(p.l2) != 0.0 for p in self.params)
     self.partial = torch.zeros(off // ch * 4, dtype=torch.float32, device=dev)
     self.t_gnorm2 = torch.zeros(nt, dtype=torch.float32, device=dev)
     self.t_wnorm2 = torch.zeros(nt, dtype=torch.float32, device=dev)

@@ -114,7 +114,7 @@ class TrainOp(object):
   def run(self):
     s = self.store
     capi.opt_step(self.cfg, self.state, s.grads, s.master, s.m1, s.m2, s.w16,
-                  s.chunk_tensor, s.tensor_chunk_begin, s.tensor_l2, None, s.partial,
+                  s.chunk_tensor, s.tensor_chunk_begin, s.tensor_l2 if s.l2_active else None, None, s.partial,
                   s.t_gnorm2, s.t_wnorm2, s.t_amax, s.t_mult, s.t_v)
     s.refresh_dgrad_copies()
 

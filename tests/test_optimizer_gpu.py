@@ -35,6 +35,7 @@ def _run(cuda, optimizer, opt_params, lr_fn, lr_params, larc=None, clip=None,
   _LAST["store"] = store
   if l2:
     store.tensor_l2.copy_(torch.tensor(l2))
+    store.l2_active = True
   op = optimize_loss(store, optimizer, opt_params, getattr(lr_policies, lr_fn), lr_params,
                      larc_params=larc, clip_gradients=clip, loss_scaling=loss_scaling,
                      world_size=world)
