@@ -251,7 +251,8 @@ class ConvTimer(object):
       if r[4]:
         continue
       cin, cout, k, stride = r[5]
-      name = ("conv1d_pp_kernel" if (cin > 0 and stride == 1 and k >= 8 and cout >= 320 and cin % 64 == 0)
+      name = ("conv1d_pp_kernel / conv1d_ppn_kernel (ping-pong tiles: 2 x 256, 2 x 128, 3 x 128 by the cost model)"
+              if (cin > 0 and stride == 1 and k >= 8 and cout >= 320 and cin % 64 == 0)
               else "conv1d_igemm_kernel + conv1d_igemm_grouped_kernel (lockstep tiles)")
       e = self.by_kernel.setdefault(name, [0, 0.0, 0.0])
       e[0] += 1
@@ -1230,7 +1231,7 @@ def main():
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic, traffic_src = committed_pmc_traffic()
     out["roofline"] = {
-        "bound": "mfma", "kernel": "conv1d implicit GEMM (conv1d_pp_kernel + conv1d_igemm_kernel tiles, incl. grouped 1x1)",
+        "bound": "mfma", "kernel": "conv1d implicit GEMM (conv1d_pp_kernel + conv1d_ppn_kernel + conv1d_igemm_kernel tiles, incl. grouped 1x1)",
         "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "timed_launches_per_step": n / max(args.steps, 1),
