@@ -216,6 +216,14 @@ typedef struct {
 } os2s_wgrad_group_t;
 int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
                                const int32_t* in_len, int B, int T);
+/* The same with the conv workspace (os2s_conv1d_workspace_bytes, one per stream): when every group is at
+ * least 128 x 128 channels and the batch has >= 2048 rows the launch runs on the K = 1 ping-pong TN-GEMM
+ * kernel — 256 x 256 tiles, reduction over the live 64-row chunks only, the tail of the launch cut along
+ * the reduction and summed by the last arriver: no atomics, bit-identical run to run — otherwise it is
+ * os2s_conv1x1_wgrad_grouped. */
+int os2s_conv1x1_wgrad_grouped_ws(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
+                                  const int32_t* in_len, int B, int T, void* workspace,
+                                  size_t workspace_bytes);
 /* The weight gradients of up to 16 Dense layers over the same M rows (a packed token batch) in one
  * launch of the K = 1 ping-pong kernel: dw_i[Cout_i, Cin_i] (+)= dy_i[M, Cout_i]^T x_i[M, Cin_i], fp32,
  * deterministic (no atomics). tf.layers.Dense kernels of the Transformer whose outputs are too small

@@ -328,7 +328,7 @@ class _WgradGroup(_lib.ctypes.Structure):
               ("Cin", c_int), ("Cout", c_int)]
 
 
-def conv1x1_wgrad_grouped(items, in_len=None):
+def conv1x1_wgrad_grouped(items, in_len=None, pingpong=True):
   """items: list of dict(x [B,T,Cin] bf16 (may be a channel slice), dy [B,T,Cout] bf16,
   dw [1,Cout,Cin] fp32 accumulated into): the K = 1 weight gradients of up to 16 branches over the
   same (B, T, in_len) in one launch."""
@@ -344,9 +344,17 @@ def conv1x1_wgrad_grouped(items, in_len=None):
     g = arr[i]
     g.x, g.dy, g.dw = c_void_p(x.data_ptr()), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32)
     g.x_row_stride, g.Cin, g.Cout = x.stride(1), x.shape[2], dy.shape[2]
-  f = _fn("os2s_conv1x1_wgrad_grouped",
-          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int))
-  _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T), "os2s_conv1x1_wgrad_grouped")
+  if not pingpong:
+    f = _fn("os2s_conv1x1_wgrad_grouped",
+            (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int))
+    _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T), "os2s_conv1x1_wgrad_grouped")
+    return
+  # wide branches of a big batch: the K = 1 ping-pong TN-GEMM kernel (deterministic), else the lockstep kernel
+  ws = conv1d_workspace(items[0]["x"].device)
+  f = _fn("os2s_conv1x1_wgrad_grouped_ws",
+          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int, c_void_p, c_size_t))
+  _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T, _ptr(ws), ws.numel()),
+             "os2s_conv1x1_wgrad_grouped_ws")
 
 
 def gemm_wgrad_grouped(items, accumulate=True):

@@ -1392,6 +1392,77 @@ extern "C" int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad
 }
 
 
+// The same grouped K = 1 weight gradients on the ping-pong TN-GEMM kernel (conv1d_wgrad1x1_pp_kernel with its
+// group table; round 5): the residual branches of a Jasper block end are 3 x 1 ... 3 x 3 tiles of 256 x 256 each
+// — far too few for a launch of their own, 50 - 60 together, cut along the reduction by the tail split —, the
+// reduction runs over the live 64-row chunks of the ragged batch only, one owner writes each dW element (no
+// atomics: deterministic). The lockstep grouped kernel above reached 0.105 of the MFMA peak on these launches.
+// Falls back to it when a group is narrower than 128 channels or the batch has fewer than 2048 rows.
+extern "C" int os2s_conv1x1_wgrad_grouped_ws(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
+                                             const int32_t* in_len, int B, int T, void* workspace,
+                                             size_t workspace_bytes) {
+  using namespace os2s;
+  OS2S_REQUIRE(groups && ngroups >= 1 && ngroups <= kMaxWgradGroups && B >= 0 && T >= 1);
+  if (B == 0) return OS2S_OK;
+  bool pp = B <= 64 && (long long)B * T >= 2048 && workspace != nullptr;
+  for (int i = 0; i < ngroups && pp; ++i) {
+    const os2s_wgrad_group_t& s = groups[i];
+    OS2S_REQUIRE(s.x && s.dy && s.dw && s.Cin >= 8 && s.Cout >= 8 && s.Cin % 8 == 0 && s.Cout % 8 == 0);
+    OS2S_REQUIRE(s.x_row_stride >= s.Cin && s.x_row_stride % 8 == 0);
+    pp = s.Cin >= 128 && s.Cout >= 128 && s.x_row_stride * 2 * 64 < (1ll << 30) &&
+         (long long)s.Cout * 2 * 64 < (1ll << 30);
+  }
+  if (!pp) return os2s_conv1x1_wgrad_grouped(stream, groups, ngroups, in_len, B, T);
+  WgradGroupTable gt;
+  gt.ngroups = ngroups;
+  int units = 0;
+  for (int i = 0; i < kMaxWgradGroups; ++i) {
+    const os2s_wgrad_group_t& s = groups[i < ngroups ? i : 0];
+    WgradGroup& g = gt.g[i];
+    g.x = s.x; g.dy = s.dy; g.dw = s.dw; g.x_ld = s.x_row_stride;
+    g.Cin = s.Cin; g.Cout = s.Cout; g.NCI = ceil_div(s.Cin, 256);
+    g.unit_begin = units;
+    if (i < ngroups) units += ceil_div(s.Cout, 256) * g.NCI;
+  }
+  gt.total_units = units;
+  WgradArgs a;
+  a.x = gt.g[0].x; a.dy = gt.g[0].dy; a.dw = gt.g[0].dw; a.in_len = in_len;
+  a.B = B; a.Tin = T; a.Tout = T; a.Cin = gt.g[0].Cin; a.Cout = gt.g[0].Cout; a.K = 1;
+  a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = gt.g[0].x_ld;
+  a.accumulate = 1;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
+  a.dbg = nullptr; a.dbg_mode = 0;
+  a.NCO = units; a.NCI = 1; a.NTP = 1;                   // U = NCO * NCI = all units of all groups
+  a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
+  a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  static int ncu = 256;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute((const void*)conv1d_wgrad1x1_pp_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      ncu = n;
+  });
+  if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+  a.ncu = ncu;
+  const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+  if (workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
+    a.ws_cnt = reinterpret_cast<int*>(workspace);
+    a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+    size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
+    const size_t cap = (size_t)3 * ncu;
+    a.ws_nslabs = (int)(n < cap ? n : cap);
+  }
+  const int r = units % ncu;
+  const int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
+  OS2S_LAUNCH(conv1d_wgrad1x1_pp_kernel, dim3(units + pieces), dim3(512), (size_t)160 * 1024,
+              (hipStream_t)stream, a, gt);
+  return OS2S_OK;
+}
+
 // The Dense weight gradients dw_i[Cout_i, Cin_i] (+)= dy_i^T x_i of up to 16 layers that see the
 // same rows (one packed token batch [M, .]) in ONE launch of the K = 1 ping-pong kernel
 // (conv1d_wgrad1x1_pp_kernel): deterministic (one owner per dW element, split reductions summed in

@@ -69,6 +69,8 @@ _SIDE_STREAMS = {}
 FUSE_BN_BWD = os.environ.get("OS2S_FUSE_BN_BWD", "1") != "0"
 # A/B knob: 0 = one K = 1 weight-gradient launch per residual branch (round 2), default = grouped
 GROUP_WGRAD = os.environ.get("OS2S_GROUP_WGRAD", "1") != "0"
+# A/B knob: 0 = the grouped K = 1 weight gradients stay on the lockstep kernel with its atomics (round 2 - 4)
+GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
@@ -643,7 +645,8 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
       with on_side_stream(dz.device, *([w[1].data for w in wgrouped] + [w[2] for w in wgrouped])):
         for i0 in range(0, len(wgrouped), 16):
           capi.conv1x1_wgrad_grouped([dict(x=inp.data, dy=dy, dw=br.kernel.grad)
-                                      for br, inp, dy in wgrouped[i0:i0 + 16]], in_len=wgrouped[0][1].lens)
+                                      for br, inp, dy in wgrouped[i0:i0 + 16]], in_len=wgrouped[0][1].lens,
+                                     pingpong=GROUP_WGRAD_PP)
     if grouped:
       items = []
       for br, inp, dy in grouped:

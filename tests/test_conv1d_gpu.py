@@ -570,7 +570,7 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
                      torch.where(live, single_ref, torch.zeros((), dtype=single.dtype, device=cuda)))
 
 
-@pytest.mark.parametrize("case", ["block_768", "narrow_split", "sliced_input"])
+@pytest.mark.parametrize("case", ["block_768", "narrow_split", "sliced_input", "block_768_big", "sliced_big"])
 def test_conv1x1_wgrad_grouped_equals_single_launches(cuda, case):
   """os2s_conv1x1_wgrad_grouped (the K = 1 weight gradients of the dense-residual branches of a
   block end in one launch) against one os2s_conv1d_wgrad per branch and against the fp32 matmul:
@@ -580,7 +580,11 @@ def test_conv1x1_wgrad_grouped_equals_single_launches(cuda, case):
       (>= 256), so the reduction is not split: every dW element receives ONE add -> bit-identical
       from run to run,
       and equal to the single launches up to fp32 summation order (rtol 1e-4);
-    narrow_split: few small groups -> the reduction is split and combined with fp32 atomics."""
+    narrow_split: few small groups -> the reduction is split and combined with fp32 atomics;
+    block_768_big / sliced_big (round 5): >= 2048 rows and every group >= 128 x 128 channels -> the launch runs
+      on the K = 1 ping-pong TN-GEMM kernel (os2s_conv1x1_wgrad_grouped_ws): 57 / 3 tiles of 256 x 256 cut
+      along the live 64-row chunks, one owner per dW element -> bit-identical from run to run, also with
+      pingpong=False (the lockstep kernel) inside the same tolerances."""
   from openseq2seq_amd import capi
   g = torch.Generator().manual_seed(33)
   if case == "block_768":
@@ -589,13 +593,19 @@ def test_conv1x1_wgrad_grouped_equals_single_launches(cuda, case):
   elif case == "narrow_split":
     B, T, lens = 5, 500, [500, 350, 129, 64, 1]
     shapes = [(256, 256), (72, 200), (128, 136)]
+  elif case == "block_768_big":
+    B, T, lens = 8, 400, [400, 330, 201, 64, 17, 400, 1, 129]
+    shapes = [(256, 768)] * 3 + [(384, 768)] * 2 + [(512, 768)] * 2 + [(640, 768)] * 2 + [(768, 768)] * 3
+  elif case == "sliced_big":
+    B, T, lens = 6, 400, [400, 90, 33, 400, 257, 128]
+    shapes = [(128, 256), (192, 256), (192, 384)]
   else:
     B, T, lens = 3, 200, [200, 90, 33]
     shapes = [(128, 256), (192, 256)]
   lens = torch.tensor(lens, dtype=torch.int32, device=cuda)
   mask = (torch.arange(T, device=cuda)[None, :] < lens[:, None])[:, :, None]
   items, refs, singles = [], [], []
-  wide = _bf(torch.randn(B, T, 512, generator=g)).to(cuda) * mask if case == "sliced_input" else None
+  wide = _bf(torch.randn(B, T, 512, generator=g)).to(cuda) * mask if case.startswith("sliced") else None
   off = 0
   for cin, cout in shapes:
     if wide is not None:
@@ -617,7 +627,14 @@ def test_conv1x1_wgrad_grouped_equals_single_launches(cuda, case):
     scale = float(ref.abs().max())
     torch.testing.assert_close(it["dw"], ref, rtol=1e-4, atol=1e-4 * scale)
     torch.testing.assert_close(it["dw"], s, rtol=1e-4, atol=1e-4 * scale)
-  if case == "block_768":       # one owner per element: run-to-run bit-identical
+  if case.endswith("_big"):     # the lockstep kernel on the same problem: same tolerances
+    lock = [dict(it, dw=b.clone()) for it, b in zip(items, [r - torch.einsum("btc,bti->ci", it["dy"].double(),
+            it["x"].double())[None].float().to(cuda) for it, r in zip(items, [r.to(cuda) for r in refs])])]
+    capi.conv1x1_wgrad_grouped(lock, in_len=lens, pingpong=False)
+    torch.cuda.synchronize()
+    for it, ref in zip(lock, refs):
+      torch.testing.assert_close(it["dw"], ref.to(cuda), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+  if case in ("block_768", "block_768_big", "sliced_big"):       # one owner per element: run-to-run bit-identical
     again = [dict(it, dw=torch.zeros_like(it["dw"])) for it in items]
     again2 = [dict(it, dw=torch.zeros_like(it["dw"])) for it in items]
     capi.conv1x1_wgrad_grouped(again, in_len=lens)
