@@ -69,6 +69,10 @@ _SIDE_STREAMS = {}
 FUSE_BN_BWD = os.environ.get("OS2S_FUSE_BN_BWD", "1") != "0"
 # A/B knob: 0 = one K = 1 weight-gradient launch per residual branch (round 2), default = grouped
 GROUP_WGRAD = os.environ.get("OS2S_GROUP_WGRAD", "1") != "0"
+# A/B knobs: the pointwise (K = 1) kernel gradients of separable-conv layers collected N per launch of the ping-pong
+# TN-GEMM kernel (0 = one lockstep launch each, round 1 - 4)
+GROUP_POINTWISE_WGRAD = os.environ.get("OS2S_GROUP_POINTWISE_WGRAD", "1") != "0"
+POINTWISE_WGRAD_GROUP = int(os.environ.get("OS2S_POINTWISE_WGRAD_GROUP", "5"))
 # A/B knob: 0 = the grouped K = 1 weight gradients stay on the lockstep kernel with its atomics (round 2 - 4)
 GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 
@@ -455,8 +459,21 @@ class SepConvBN(ConvBN):
 
   def backward_branch(self, inp, dy, f):
     z = f["z"]
-    with on_side_stream(dy.device, z, dy):          # parameter gradients: see ConvBN.backward_branch
-      capi.conv1d_wgrad(z, dy, 1, pad_left=0, out=self.kernel.grad, accumulate=True)
+    rows = z.shape[0] * z.shape[1]
+    units = ((self.cout + 255) // 256) * ((self.cin + 255) // 256)
+    if GROUP_POINTWISE_WGRAD and current_tape() is not None and units < 32 and self.cin >= 128 and \
+       self.cout >= 128 and rows >= 2048 and self.cin % 8 == 0 and self.cout % 8 == 0 and \
+       z.is_contiguous() and dy.is_contiguous():
+      # the pointwise kernel gradient is a TN GEMM over the B * T rows with 1 ... 16 output tiles of 256 x 256:
+      # alone it runs on the lockstep kernel with the batch split over fp32 atomics (42 us for 3.5 GFLOP);
+      # several of them — consecutive layers see the same rows — go out as ONE launch of the ping-pong
+      # TN-GEMM kernel (Tape.defer_wgrad, as the Transformer's 1024 x 1024 projections do): deterministic
+      current_tape().defer_wgrad(self.kernel, dict(x=z.view(rows, self.cin), dy=dy.view(rows, self.cout),
+                                                   dw=self.kernel.grad.view(self.cout, self.cin)),
+                                 group=POINTWISE_WGRAD_GROUP)
+    else:
+      with on_side_stream(dy.device, z, dy):          # parameter gradients: see ConvBN.backward_branch
+        capi.conv1d_wgrad(z, dy, 1, pad_left=0, out=self.kernel.grad, accumulate=True)
     dz = capi.conv1d_fwd(dy, self.kernel.wt16, pad_left=0, tout=z.shape[1])
     f["z"] = None
     with on_side_stream(dy.device, inp.data, dz):
