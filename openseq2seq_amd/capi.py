@@ -13,7 +13,16 @@ from . import _lib
 from ._lib import c_void_p, c_int, c_int64, c_size_t, c_float, c_uint64
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+  """The current HIP stream of the current device as a raw handle. torch.cuda.current_stream() builds a Stream
+  object through three Python layers (7 us a call, 850 calls = 6 ms of host time per Jasper step); the two C
+  entry points underneath it return the same handle in well under a microsecond."""
+  if _raw_stream is not None and _cur_device is not None:
+    return c_void_p(_raw_stream(_cur_device()))
   return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -120,7 +129,10 @@ def conv1d_set_host_lens(lens):
 def conv1d_workspace(device):
   """Caller-owned workspace of os2s_conv1d_fwd_ws (tickets zeroed once): one per (device,
   stream) — launches that may overlap must not share one."""
-  key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+  if _raw_stream is not None and device.index is not None:
+    key = (device.index, _raw_stream(device.index))
+  else:
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
   ws = _conv_ws.get(key)
   if ws is None:
     n = int(_fn("os2s_conv1d_workspace_bytes", (), c_size_t)())

@@ -94,7 +94,7 @@ def _side_stream(device):
   (OS2S_WGRAD_STREAM=0 or the model's `os2s_side_stream: False` keeps everything on one stream)."""
   if not _SIDE_STREAM_ENABLED or os.environ.get("OS2S_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
     return None
-  key = (device.index, torch.cuda.current_stream().cuda_stream)
+  key = (device.index, capi._stream().value)
   st = _SIDE_STREAMS.get(key)
   if st is None:
     # OS2S_SIDE_PRIO (experiment): stream priority of the side stream (HIP: lower number = higher
