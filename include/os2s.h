@@ -1145,6 +1145,13 @@ int os2s_sample_norm_bwd(os2s_stream_t stream, const uint16_t* dz, const uint16_
                          const float* mean, const float* rstd, int B, int T, int C, int mode, uint16_t* dx,
                          float* dgamma, float* dbeta, float* partial, float* scratch);
 
+/* y[b, t * stride, :] = x[b, t, :] with every other row of y [B, Tup, C] zero (Tup >= (T - 1) * stride + 1, C a
+ * multiple of 8): the zero-upsampled output gradient of a STRIDED tf.layers.conv1d past the first layer
+ * (parts/cnns/conv_blocks.py:195-206 with strides > 1) — its data gradient is the stride-1 data gradient of
+ * the upsampled tensor (os2s_conv1d_fwd on the tap-flipped weights). */
+int os2s_upsample_rows_bf16(os2s_stream_t stream, const uint16_t* x, int B, int T, int C, int stride, int Tup,
+                            uint16_t* y);
+
 #ifdef __cplusplus
 }
 #endif

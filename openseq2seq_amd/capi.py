@@ -113,6 +113,17 @@ def deterministic():
   return bool(_fn("os2s_deterministic", (), c_int)())
 
 
+def upsample_rows(x, stride, tup):
+  """[B, T, C] bf16 -> [B, tup, C] with x's rows at the multiples of `stride` and zeros between
+  (os2s_upsample_rows_bf16: the output gradient of a strided convolution, made stride-1)."""
+  B, T, C = x.shape
+  y = torch.empty((B, tup, C), dtype=torch.bfloat16, device=x.device)
+  f = _fn("os2s_upsample_rows_bf16", (c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p))
+  _lib.check(f(_stream(), _ptr(x, torch.bfloat16), B, T, C, int(stride), int(tup), _ptr(y, torch.bfloat16)),
+             "os2s_upsample_rows_bf16")
+  return y
+
+
 def conv1d_set_host_lens(lens):
   """Hands the launcher a HOST copy (sequence of ints / numpy int32) of the lengths the following forward
   convolutions receive as in_len, or withdraws it (None). See include/os2s.h: a hint that saves the second

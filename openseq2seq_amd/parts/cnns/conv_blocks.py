@@ -385,11 +385,18 @@ class ConvBN(object):
     branch of a LATER block end, whose backward has already run)."""
     self.backward_weights(inp, dy, f)
     if inp.requires_grad:
-      if self.stride != 1:
-        raise NotImplementedError("data-gradient of a strided conv")
       g = inp.grad_buffer()
       tin = inp.data.shape[1]
       pl = (self.k - 1) * self.dil - f["pad_left"]
+      if self.stride != 1:
+        # a strided layer past the first one: dx[t] = sum_k dy_up[t - k dil + padL] w[k] with the output gradient
+        # zero-upsampled to the input's resolution — the stride-1 data gradient of dy_up (stride x the work of
+        # a dedicated kernel; no configuration of the reference strides anywhere but in its first layer)
+        dy = capi.upsample_rows(dy.contiguous(), self.stride, (dy.shape[1] - 1) * self.stride + 1)
+        capi.conv1d_fwd(dy, self.kernel.wt16, dil=self.dil, pad_left=pl, tout=tin, out=g,
+                        accumulate=inp.grad_init, out_len=inp.lens)
+        inp.grad_init = True
+        return
       if final and FUSE_BN_BWD and inp.bn_y is not None and dy.is_contiguous() and g.is_contiguous():
         # the producer's ReLU / dropout backward and its BatchNorm-backward partial sums ride in this
         # launch's epilogue: its own reduction pass (bn_act_bwd_reduce) is skipped
@@ -480,8 +487,8 @@ class SepConvBN(ConvBN):
       capi.depthwise_conv1d_wgrad(inp.data, dz, self.depthwise.grad, stride=self.stride, dil=self.dil,
                                   pad_left=f["pad_left"], in_len=inp.lens)
     if inp.requires_grad:
-      if self.stride != 1:
-        raise NotImplementedError("data-gradient of a strided separable conv")
+      if self.stride != 1:      # as ConvBN.backward_branch: the stride-1 data gradient of the zero-upsampled dz
+        dz = capi.upsample_rows(dz.contiguous(), self.stride, (dz.shape[1] - 1) * self.stride + 1)
       tin = inp.data.shape[1]
       dx = capi.depthwise_conv1d_fwd(dz, self.depthwise.master, dil=self.dil,
                                      pad_left=(self.k - 1) * self.dil - f["pad_left"], tout=tin,

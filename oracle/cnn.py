@@ -41,11 +41,14 @@ def conv1d_tf(x, w_tf, stride=1, dil=1, padding="SAME", mask_len=None):
   return y.permute(0, 2, 1).contiguous()
 
 
-def sep_conv1d_tf(x, depthwise, pointwise, stride=1, dil=1, padding="SAME"):
+def sep_conv1d_tf(x, depthwise, pointwise, stride=1, dil=1, padding="SAME", between=None):
   """tf.layers.separable_conv1d(use_bias=False, depth_multiplier=1) (layer type
   'sep_conv1d', conv_blocks.py:11-16): depthwise [K, Cin] (TF depthwise_kernel [K, Cin, 1])
   applied per channel with the block's stride / dilation / padding, then the pointwise
-  kernel [1, Cin, Cout]."""
+  kernel [1, Cin, Cout]. `between`: optional function applied to the depthwise output before the pointwise
+  product (identity in exact arithmetic) — the device stores that tensor, and the gradient flowing back
+  through it, in bf16; oracle/tdnn.py passes its storage-rounding node here when it emulates the device's
+  storage points."""
   x = torch.as_tensor(x, dtype=torch.float32)
   B, T, C = x.shape
   K = depthwise.shape[0]
@@ -54,6 +57,8 @@ def sep_conv1d_tf(x, depthwise, pointwise, stride=1, dil=1, padding="SAME"):
     _, pl, pr = same_pad(T, K, stride, dil)
     xc = F.pad(xc, (pl, pr))
   z = F.conv1d(xc, depthwise.t()[:, None, :].contiguous(), stride=stride, dilation=dil, groups=C)
+  if between is not None:
+    z = between(z)
   y = F.conv1d(z, pointwise.permute(2, 1, 0).contiguous())
   return y.permute(0, 2, 1).contiguous()
 

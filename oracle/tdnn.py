@@ -49,7 +49,8 @@ def tdnn_layer(feats, layer_res, blk, name, weights, out_mask=None, activation="
   sep = blk.get("type", "conv1d") == "sep_conv1d"
   if sep:
     y = _r(cnn.sep_conv1d_tf(feats, weights[name + "/depthwise_kernel"],
-                             weights[name + "/pointwise_kernel"], s, d, blk["padding"]), em)
+                             weights[name + "/pointwise_kernel"], s, d, blk["padding"],
+                             between=(lambda z: _r(z, em))), em)
   else:
     y = _r(cnn.conv1d_tf(feats, weights[name + "/kernel"], s, d, blk["padding"]), em)
   tot = cnn.batch_norm_train(y, weights[name + "/bn/gamma"], weights[name + "/bn/beta"], bn_eps)[0]
@@ -58,7 +59,7 @@ def tdnn_layer(feats, layer_res, blk, name, weights, out_mask=None, activation="
     bn = (name + "/res_bn_%d" % i) if dense else (name + "/res_bn")
     if sep:   # residual branches use the block's layer type with k = 1 (conv_blocks.py:66,79-85)
       ry = _r(cnn.sep_conv1d_tf(r, weights[rn + "/depthwise_kernel"],
-                                weights[rn + "/pointwise_kernel"], 1, 1, "SAME"), em)
+                                weights[rn + "/pointwise_kernel"], 1, 1, "SAME", between=(lambda z: _r(z, em))), em)
     else:
       ry = _r(cnn.conv1d_tf(r, weights[rn + "/kernel"], 1, 1, "SAME"), em)
     tot = tot + cnn.batch_norm_train(ry, weights[bn + "/gamma"], weights[bn + "/beta"], bn_eps)[0]
