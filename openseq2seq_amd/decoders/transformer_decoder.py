@@ -44,6 +44,10 @@ class TransformerDecoder(Decoder):
     p = self.params
     D = p["hidden_size"]
     scope = "ForwardPass/" + self._name
+    # the encoder-decoder key / value kernels of all layers, created next to each other (L.FusedCrossKV)
+    kvs = [L.Dense(store, "%s/layer_%d/encdec_attention/attention/kv" % (scope, n), D, 2 * D, False)
+           for n in range(p["num_hidden_layers"])]
+    self.cross_kv = L.FusedCrossKV(store, kvs)
     for n in range(p["num_hidden_layers"]):
       ls = "%s/layer_%d" % (scope, n)
       self.layers.append(dict(
@@ -52,7 +56,7 @@ class TransformerDecoder(Decoder):
                                         p["num_heads"], True),
           ln2=L.LayerNorm(store, ls + "/encdec_attention/layer_normalization", D),
           cross=L.MultiHeadAttention(store, ls + "/encdec_attention/attention", D,
-                                     p["num_heads"], False),
+                                     p["num_heads"], False, kv=kvs[n]),
           ln3=L.LayerNorm(store, ls + "/ffn/layer_normalization", D),
           ffn=L.FeedForward(store, ls + "/ffn/feed_foward_network", D, p["filter_size"])))
     self.output_normalization = L.LayerNorm(store, scope + "/layer_normalization", D)
@@ -79,13 +83,17 @@ class TransformerDecoder(Decoder):
     enc_out = enc['outputs_act']
     x = emb.embed(pt["ids"], pt["pos"], tape, post_keep, seeds.next())
     max_cross = max(pt["max_len"], ps["max_len"])
-    for lyr in self.layers:
+    kv_all = self.cross_kv.forward(enc_out, tape) if self.cross_kv.usable() else None
+    for li, lyr in enumerate(self.layers):
       y = lyr["ln1"].forward(x, tape)
       x = lyr["self_att"].forward(y, y, pt["cu"], pt["cu"], pt["max_len"], True, tape, seeds,
                                   att_keep, post_keep, residual=x)
       y = lyr["ln2"].forward(x, tape)
+      if li == 0 and kv_all is not None:
+        self.cross_kv.join()
       x = lyr["cross"].forward(y, enc_out, pt["cu"], ps["cu"], max_cross, False, tape, seeds,
-                               att_keep, post_keep, residual=x)
+                               att_keep, post_keep, residual=x,
+                               kv_pre=(kv_all, li) if kv_all is not None else None)
       y = lyr["ln3"].forward(x, tape)
       x = lyr["ffn"].forward(y, tape, seeds, relu_keep, post_keep, residual=x)
     out = self.output_normalization.forward(x, tape)

@@ -209,7 +209,7 @@ class MultiHeadAttention(object):
   query projection and a fused [2D, D] key/value projection. (The reference keeps q, k, v
   as three Dense kernels; fusing only changes how the same numbers are laid out.)"""
 
-  def __init__(self, store, name, hidden, num_heads, self_attention):
+  def __init__(self, store, name, hidden, num_heads, self_attention, kv=None):
     self.D, self.H, self.self_att = hidden, num_heads, self_attention
     self.scale = (hidden // num_heads) ** -0.5
     if hidden // num_heads != 64:
@@ -218,16 +218,24 @@ class MultiHeadAttention(object):
       self.qkv = Dense(store, name + "/qkv", hidden, 3 * hidden, False)
     else:
       self.q = Dense(store, name + "/q", hidden, hidden, False)
-      self.kv = Dense(store, name + "/kv", hidden, 2 * hidden, False)
+      # (the decoder creates the key / value projections of all its layers next to each other — FusedCrossKV)
+      self.kv = kv if kv is not None else Dense(store, name + "/kv", hidden, 2 * hidden, False)
     self.out = Dense(store, name + "/output_transform", hidden, hidden, False)
 
-  def forward(self, x, y, cu_q, cu_k, max_len, causal, tape, seeds, att_keep, post_keep, residual):
+  def forward(self, x, y, cu_q, cu_k, max_len, causal, tape, seeds, att_keep, post_keep, residual, kv_pre=None):
     """x: queries source (Act [Nq,D]); y: keys/values source (Act [Nk,D]) — y is x for
-    self-attention. Returns residual + dropout(W_o attention)."""
+    self-attention. Returns residual + dropout(W_o attention). kv_pre = (Act [Nk, n * 2D], l): the key / value
+    projections of n layers computed by ONE GEMM (FusedCrossKV), this layer's are columns [l * 2D, (l + 1) * 2D)."""
     D, H = self.D, self.H
+    kv_all = None
     if self.self_att:
       qkv = self.qkv.forward(x, tape)
       qv, kv_, vv = qkv.data[:, :D], qkv.data[:, D:2 * D], qkv.data[:, 2 * D:]
+    elif kv_pre is not None:
+      q = self.q.forward(x, tape)
+      kv_all, lidx = kv_pre
+      kd = kv_all.data[:, lidx * 2 * D:(lidx + 1) * 2 * D]
+      qv, kv_, vv = q.data, kd[:, :D], kd[:, D:]
     else:
       q = self.q.forward(x, tape)
       kv = self.kv.forward(y, tape)
@@ -247,6 +255,13 @@ class MultiHeadAttention(object):
           capi.attention_bwd(qv, kv_, vv, d_o, lse, g[:, :D], g[:, D:2 * D], g[:, 2 * D:], cu_q,
                              cu_k, H, max_len, causal, att.scale, att_keep, seed)
           qkv.grad = g
+        elif kv_all is not None:
+          # this layer's columns of the fused gradient; FusedCrossKV's closure runs after every layer's
+          gq = torch.empty_like(q.data)
+          gkv = kv_all.grad_buffer()[:, lidx * 2 * D:(lidx + 1) * 2 * D]
+          capi.attention_bwd(qv, kv_, vv, d_o, lse, gq, gkv[:, :D], gkv[:, D:], cu_q, cu_k, H,
+                             max_len, causal, att.scale, att_keep, seed)
+          q.grad = gq
         else:
           gq = torch.empty_like(q.data)
           gkv = torch.empty_like(kv.data)
@@ -257,6 +272,74 @@ class MultiHeadAttention(object):
 
       tape.record(backward)
     return self.out.forward(oa, tape, keep=post_keep, seed=seeds.next(), residual=residual)
+
+
+# A/B knob: 0 = one key / value GEMM per decoder layer (rounds 1 - 4)
+FUSE_CROSS_KV = _os.environ.get("OS2S_FUSE_CROSS_KV", "1") == "1"
+FUSE_CROSS_KV_SIDE = _os.environ.get("OS2S_FUSE_CROSS_KV_SIDE", "1") == "1"
+
+
+class FusedCrossKV(object):
+  """The key / value projections of the encoder output for ALL decoder layers' encoder-decoder attention
+  (transformer_decoder.py:155-230: every layer projects the same encoder output with its own k, v kernels) as ONE
+  GEMM with N = n_layers * 2D columns — 1584 tiles instead of six launches of 264 for Transformer-big — and ONE
+  TN GEMM for the six kernel gradients. The kernels stay six variables under their reference names; they are created
+  next to each other, so their bf16 copies (and their gradients) ARE the rows of one [n * 2D, D] matrix. The data
+  gradient into the encoder output stays one GEMM per layer (the transposed weight copies are per kernel)."""
+
+  def __init__(self, store, kvs):
+    self.store, self.kvs = store, kvs
+    self.D = kvs[0].cin
+
+  def join(self):
+    """The current stream waits for the fused projection (no-op when it ran on the current stream)."""
+    if getattr(self, "_side", None) is not None:
+      torch.cuda.current_stream().wait_stream(self._side)
+      self._side = None
+
+  def usable(self):
+    ks = [d.kernel for d in self.kvs]
+    return FUSE_CROSS_KV and len(ks) > 1 and all(b.offset == a.offset + a.numel and b.numel == a.numel
+                                                 for a, b in zip(ks, ks[1:]))
+
+  def _rows(self, flat):
+    k0, n = self.kvs[0].kernel, len(self.kvs)
+    return flat[k0.offset:k0.offset + n * k0.numel].view(n * 2 * self.D, self.D)
+
+  def forward(self, enc_out, tape):
+    # on the side stream: nothing of the decoder needs the result before its first encoder-decoder attention, and
+    # the embedding + self-attention sublayer in front of it are 132-tile launches that leave half the chip idle
+    # (the decoder calls join() there)
+    self._side = None
+    if FUSE_CROSS_KV_SIDE:
+      with on_side_stream(enc_out.data.device, enc_out.data) as ctx:
+        y = capi.gemm_nt(enc_out.data, self._rows(self.store.w16))
+        ctx.hand_over(y)
+        self._side = ctx.side
+    else:
+      y = capi.gemm_nt(enc_out.data, self._rows(self.store.w16))
+    out = Act(y)
+    if tape is None:
+      return out
+    fused, D = self, self.D
+
+    def backward():
+      g = out.grad
+      assert g is not None, "no decoder layer wrote the fused key / value gradient"
+      with on_side_stream(g.device, enc_out.data, g):
+        capi.gemm_wgrad(enc_out.data, g, fused._rows(fused.store.grads), accumulate=True)
+      if enc_out.requires_grad:
+        ge = enc_out.grad_buffer()
+        for l, d in enumerate(fused.kvs):
+          gl = g[:, l * 2 * D:(l + 1) * 2 * D]
+          if g.shape[0] < capi.BIG_TILE_MIN_ROWS:     # the small-batch kernel wants contiguous rows
+            gl = gl.contiguous()
+          capi.gemm(gl, d.kernel.wt16.view(d.cin, d.cout), out=ge, accumulate=enc_out.grad_init)
+          enc_out.grad_init = True
+      out.grad = None
+
+    tape.record(backward, [d.kernel for d in self.kvs])
+    return out
 
 
 class FeedForward(object):
