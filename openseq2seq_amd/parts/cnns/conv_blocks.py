@@ -73,6 +73,8 @@ GROUP_WGRAD = os.environ.get("OS2S_GROUP_WGRAD", "1") != "0"
 # TN-GEMM kernel (0 = one lockstep launch each, round 1 - 4)
 GROUP_POINTWISE_WGRAD = os.environ.get("OS2S_GROUP_POINTWISE_WGRAD", "1") != "0"
 POINTWISE_WGRAD_GROUP = int(os.environ.get("OS2S_POINTWISE_WGRAD_GROUP", "5"))
+# how many small Dense weight gradients (Transformer: the 1024 x 1024 projections, 16 tiles each) share one launch
+SMALL_WGRAD_GROUP = int(os.environ.get("OS2S_SMALL_WGRAD_GROUP", "3"))
 # A/B knob: 0 = the grouped K = 1 weight gradients stay on the lockstep kernel with its atomics (round 2 - 4)
 GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 
@@ -221,7 +223,7 @@ class Tape(object):
     join_side_streams()
 
   # ---- deferred (grouped) weight gradients -----------------------------------------------------
-  def defer_wgrad(self, param, item, group=3):
+  def defer_wgrad(self, param, item, group=None):
     """A Dense weight gradient too small to fill the chip alone is held back until `group` of them
     can go out in one launch (capi.gemm_wgrad_grouped). Until then `param` does not count as final
     for the gradient reducer."""
@@ -233,7 +235,7 @@ class Tape(object):
     self._deferred.append((param, item))
     if self._pending is not None and id(param) in self._pending:
       self._pending[id(param)] += 1
-    if len(self._deferred) >= group:
+    if len(self._deferred) >= (group if group is not None else SMALL_WGRAD_GROUP):
       self.flush_deferred()
 
   def flush_deferred(self):
