@@ -154,12 +154,6 @@ int os2s_conv1d_fwd_ws(os2s_stream_t stream, const uint16_t* x, const uint16_t* 
                        int accumulate, int act, float keep_prob, unsigned long long seed,
                        const uint16_t* residual, const int32_t* out_len, void* workspace,
                        size_t workspace_bytes);
-/* experiment / test hook: force a tile. -1 (default) = by shape; 0 = 128x128 tile, X window
- * double-buffered; 3 = 128x128, X window single-buffered when K >= 8 (3 workgroups per CU);
- * 5 = 256x256 lockstep tile; 10 = ping-pong kernels (balanced over live windows), tile chosen on the
- * device from the live-window count: 2 windows x 256 columns, or 2 / 3 windows x 128 columns;
- * 12 / 13 / 14 = ping-pong with the 2 x 128 / 3 x 128 / 2 x 256 tile forced */
-void os2s_conv1d_set_variant(int v);
 /* Optional hint: a HOST copy of the int32 sequence lengths that the forward launches which follow receive
  * as in_len (lens == NULL or B <= 0 withdraws it). The tile of a ping-pong launch depends on the number of live
  * 128-row windows of the ragged batch; without the hint that number is only known on the device, both
@@ -168,24 +162,41 @@ void os2s_conv1d_set_variant(int v);
  * all exact for any data: lengths that differ from the device's cost speed, never results. Process-wide
  * state, like the variant hook: set it around the launches of one batch (the encoder does). Returns OS2S_OK. */
 int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
-/* Named tuning options (test / measurement aid; nothing in the library reads the environment for them):
+/* Named test / measurement options — the ONE entry point for every tuning knob and forced-variant switch of
+ * the library (nothing in the library reads the environment for them; values are process-wide and only
+ * select among launch geometries that are all exact for any data):
+ *   conv1d.variant: force a convolution tile. -1 (default) = by shape; 0 = 128x128 tile, X window
+ *     double-buffered; 3 = 128x128, X window single-buffered when K >= 8 (3 workgroups per CU); 5 = 256x256
+ *     lockstep tile; 10 = ping-pong kernels (balanced over live windows), tile chosen on the device from the
+ *     live-window count: 2 windows x 256 columns, or 2 / 3 windows x 128 columns; 12 / 13 / 14 = ping-pong
+ *     with the 2 x 128 / 3 x 128 / 2 x 256 tile forced
+ *   conv1d.split: f > 0 forces the tail split factor of the ping-pong kernel (-1 = cost model)
  *   conv1d.pp_cost_256, conv1d.pp_cost_2x128, conv1d.pp_cost_3x128: fitted microseconds per 64-deep step
  *     of the three ping-pong convolution tiles — the constants of the device-side tile choice; a cost
  *     >= 1e6 removes a narrow tile from the candidates
  *   conv1d.pp_dgrad_penalty: factor on the narrow tiles' cost in data-gradient launches (out_len given:
  *     they share the chip with the weight-gradient stream)
  *   conv1d.pp_prio: 1 = the loading wave of a narrow-tile slot runs at s_setprio 2
- * Returns 0, or -1 for an unknown name. */
+ *   conv1d.pp_min_cout: narrowest layer (output channels) the ping-pong kernels take (default 320)
+ *   conv1x1.variant: the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers): 0 (default) and 1 =
+ *     lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows whenever its envelope allows
+ *     (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as a measured alternative
+ *   conv1d_wgrad.variant: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, -1 = by shape;
+ *   conv1d_wgrad.split: > 0 forces the reduction split factor of the ping-pong kernels (-1 = cost model)
+ *   gemm_nt.split: f > 0 forces the tail split factor of os2s_gemm_nt*, 0 disables the split, < 0 = cost model
+ *   depthwise.variant: 0 = the generic depthwise kernels only, < 0 = by shape
+ *   bn.act_fwd.groups, bn.act_fwd.rows, bn.act_bwd_reduce.groups, bn.act_bwd_reduce.rows, bn.bwd_apply.groups,
+ *     bn.bwd_apply.rows: tiling of the three BatchNorm kernels (8-channel groups per workgroup 8 .. 256, rows
+ *     per workgroup 8 .. 1024; tools/bench_bn_sweep.py); the reduce tiling also sets what
+ *     os2s_bn_act_bwd_num_parts returns
+ * Returns 0, or -1 for an unknown name. os2s_option_name(i) enumerates the registered names (NULL past the
+ * last one). */
 int os2s_set_option(const char* name, double value);
-/* experiment / test hook for the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers):
- * 0 (default) and 1 = lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows
- * whenever its envelope allows (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as
- * a measured alternative */
-void os2s_conv1x1_set_variant(int v);
-/* experiment hook: f > 0 forces the tail split factor of the ping-pong kernel (-1 = cost model) */
-void os2s_conv1d_set_split(int f);
-/* experiment hook (tools/pp_timeline.py): per-slot time stamps of the ping-pong kernel */
-void os2s_conv1d_set_debug(void* stamps, int fixed_w);
+const char* os2s_option_name(int index);
+/* Profiling aid (tools/pp_timeline.py, ppn_timeline.py, conv1x1_phases.py): a device buffer the instrumented
+ * kernel `kernel` ("conv1d", "conv1d_wgrad") writes per-slot time stamps into (NULL withdraws it); `mode` is
+ * the kernel's own timing-experiment bit mask. Returns 0, or -1 for an unknown kernel name. */
+int os2s_set_debug_stamps(const char* kernel, void* stamps, int mode);
 /* Up to 16 independent 1x1 convolutions over the same batch geometry (B, T, lengths) in ONE
  * launch: y_i[b,t,:] (+)= x_i[b,t,:] . w_i^T, bf16 out, optional BatchNorm partials per group
  * (layout as os2s_conv1d_fwd). Replaces the dense-residual branches of conv_bn_res_bn_actv
@@ -259,8 +270,6 @@ int os2s_gemm_nt_ws(os2s_stream_t stream, const uint16_t* A, long long lda, cons
 int os2s_gemm_nt_mask_ws(os2s_stream_t stream, const uint16_t* A, long long lda, const uint16_t* W, void* C,
                          long long ldc, int M, int N, int K, const uint16_t* mask_ref, float mask_scale,
                          float* stats, void* workspace, size_t workspace_bytes);
-/* test / experiment hook: f > 0 forces the split factor, 0 disables the split, < 0 = cost model */
-void os2s_gemm_nt_set_split(int f);
 int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const uint16_t* w,
                     void* y, const int32_t* in_len, const float* bias,
                     float* stats, int B, int Tin, int Cin, int Cout, int K,
@@ -297,11 +306,6 @@ int os2s_conv1d_wgrad_ws(os2s_stream_t stream, const uint16_t* x, long long x_ro
                          const uint16_t* dy, float* dw, const int32_t* in_len, int B, int Tin,
                          int Cin, int Cout, int K, int stride, int dil, int padL, int Tout,
                          int accumulate, void* workspace, size_t workspace_bytes);
-/* experiment / test hook: variant 0 = lockstep kernel, 1 / -1 = by shape; split > 0 forces the
- * reduction split factor of the ping-pong kernel (-1 = cost model) */
-void os2s_conv1d_wgrad_set_variant(int variant, int split);
-/* experiment hook (tools/pp_timeline.py): per-slot time stamps of the ping-pong wgrad kernel */
-void os2s_conv1d_wgrad_set_debug(void* stamps, int mode);
 
 /* ------------------------------------------------------------------------
  * BatchNorm + residual sum + activation + dropout + sequence mask
@@ -956,8 +960,6 @@ int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const flo
 int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* dy,
                                 float* dw, const int32_t* in_len, int B, int Tin, int Tout, int C,
                                 int K, int stride, int dil, int padL);
-/* test / experiment hook: 0 = the generic depthwise kernels only, < 0 = by shape */
-void os2s_depthwise_set_variant(int v);
 
 /* ------------------------------------------------------------------------
  * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:

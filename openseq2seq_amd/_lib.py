@@ -62,3 +62,28 @@ def bind(name, argtypes, restype=c_int):
   f.argtypes = argtypes
   f.restype = restype
   return f
+
+
+def set_option(name, value):
+  """os2s_set_option: the library's named test / measurement options (include/os2s.h lists them)."""
+  f = bind("os2s_set_option", [ctypes.c_char_p, ctypes.c_double])
+  if f(name.encode(), float(value)) != 0:
+    raise Os2sError("os2s_set_option: unknown option %r" % (name,))
+
+
+def option_names():
+  f = bind("os2s_option_name", [c_int], ctypes.c_char_p)
+  out, i = [], 0
+  while True:
+    n = f(i)
+    if n is None:
+      return out
+    out.append(n.decode())
+    i += 1
+
+
+def set_debug_stamps(kernel, ptr, mode=0):
+  """os2s_set_debug_stamps: device buffer (address or None) an instrumented kernel writes time stamps into."""
+  f = bind("os2s_set_debug_stamps", [ctypes.c_char_p, c_void_p, c_int])
+  if f(kernel.encode(), c_void_p(int(ptr) if ptr else 0), int(mode)) != 0:
+    raise Os2sError("os2s_set_debug_stamps: unknown kernel %r" % (kernel,))

@@ -223,7 +223,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // the instruction stream suggested: at ~4 TB/s of mixed read / write streams over ~40 MB tensors
 // these 20-40 us kernels are bound by the memory system, not by loads in flight per thread.
 constexpr int kTileU = 4;
-constexpr int kMaxTileRows = 1024;   // os2s_bn_set_tiling's upper bound on rows per workgroup
+constexpr int kMaxTileRows = 1024;   // the tiling options' upper bound on rows per workgroup
 constexpr int kOobOffset = 0x7fffffff;
 
 struct TileMap {
@@ -851,15 +851,18 @@ extern "C" int os2s_bn_act_fwd(os2s_stream_t stream, int J, const uint16_t* cons
 
 
 
-// Benchmark / test hook: tiling of kernel `which` (0 bn_act_fwd, 1 bn_act_bwd_reduce, 2 bn_bwd_apply).
-// Not thread-safe; the reduce tiling also sets what os2s_bn_act_bwd_num_parts returns.
-extern "C" int os2s_bn_set_tiling(int which, int groups_per_block, int rows_per_block) {
-  OS2S_REQUIRE(which >= 0 && which < 3 && groups_per_block >= 8 && groups_per_block <= 256);
-  OS2S_REQUIRE(rows_per_block >= 8 && rows_per_block <= 1024);
-  g_tiling[which][0] = groups_per_block;
-  g_tiling[which][1] = rows_per_block;
-  return OS2S_OK;
-}
+// Benchmark options (os2s_set_option; tools/bench_bn_sweep.py): tiling of bn_act_fwd / bn_act_bwd_reduce /
+// bn_bwd_apply — bn.<kernel>.groups (8-channel groups per block, 8 .. 256) and bn.<kernel>.rows (rows per
+// block, 8 .. 1024; out-of-range values are ignored). Not thread-safe; the reduce tiling also sets what
+// os2s_bn_act_bwd_num_parts returns.
+static void bn_set_groups(int which, double v) { if (v >= 8 && v <= 256) g_tiling[which][0] = (int)v; }
+static void bn_set_rows(int which, double v) { if (v >= 8 && v <= kMaxTileRows) g_tiling[which][1] = (int)v; }
+static os2s::OptionReg r_bn0g("bn.act_fwd.groups", [](double v) { bn_set_groups(0, v); });
+static os2s::OptionReg r_bn0r("bn.act_fwd.rows", [](double v) { bn_set_rows(0, v); });
+static os2s::OptionReg r_bn1g("bn.act_bwd_reduce.groups", [](double v) { bn_set_groups(1, v); });
+static os2s::OptionReg r_bn1r("bn.act_bwd_reduce.rows", [](double v) { bn_set_rows(1, v); });
+static os2s::OptionReg r_bn2g("bn.bwd_apply.groups", [](double v) { bn_set_groups(2, v); });
+static os2s::OptionReg r_bn2r("bn.bwd_apply.rows", [](double v) { bn_set_rows(2, v); });
 
 extern "C" int os2s_bn_act_bwd_num_parts(long long rows) {
   return ceil_div(rows, g_tiling[1][1]);

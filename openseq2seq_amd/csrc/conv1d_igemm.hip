@@ -1195,7 +1195,7 @@ static int launch_conv_pp(hipStream_t stream, ConvArgs& a, void* workspace, size
 //     layers: a whole unit is shorter than the fixed costs of its workgroup, 0.057 vs 0.054 ms);
 //   * otherwise the lockstep kernel: 256 x 256 tile for wide 1x1 / short-K layers with enough
 //     rows to fill the chip, else the 128 x 128 tile (single-buffered X window for K >= 8).
-// os2s_conv1d_set_variant(v >= 0) forces a tile for experiments and tests:
+// os2s_set_option("conv1d.variant", v >= 0) forces a tile for experiments and tests:
 //   0 = 128x128, X window double-buffered   3 = 128x128, X window single-buffered when K >= 8
 //   5 = 256x256 lockstep                   10 = ping-pong (tile chosen on the device)
 //   12 / 13 = ping-pong, 2 / 3 windows x 128 columns   14 = ping-pong, 2 windows x 256 columns
@@ -1213,7 +1213,6 @@ static int g_conv_variant = -1;
 static int g_conv_split = -1;
 static unsigned long long* g_conv_dbg = nullptr;
 static int g_conv_fixed_w = 0;
-extern "C" void os2s_conv1d_set_variant(int v) { g_conv_variant = v; }
 extern "C" int os2s_conv1d_set_host_lens(const int32_t* lens, int B) {
   if (lens == nullptr || B <= 0) {
     os2s::g_host_lens_set = false;
@@ -1224,37 +1223,34 @@ extern "C" int os2s_conv1d_set_host_lens(const int32_t* lens, int B) {
   os2s::g_host_lens_set = true;
   return OS2S_OK;
 }
-extern "C" void os2s_conv1d_set_split(int f) { g_conv_split = f; }
-// Named tuning options of the convolution launchers (one entry point instead of one exported setter
-// per knob; nothing here is read from the environment or per launch):
+// Named options of the convolution launchers (os2s_set_option; nothing here is read per launch):
+//   conv1d.variant            >= 0 forces a tile (list above), -1 = by shape
+//   conv1d.split              > 0 forces the tail split factor of the ping-pong kernel, -1 = cost model
 //   conv1d.pp_cost_256 / .pp_cost_2x128 / .pp_cost_3x128   fitted microseconds per 64-deep step of the three
 //       ping-pong tiles — the constants of the device-side tile choice (tools/bench_conv_shapes.py refits
 //       them); a cost >= 1e6 removes a narrow tile from the candidates
 //   conv1d.pp_dgrad_penalty   factor on the narrow tiles' cost in data-gradient launches (out_len given)
 //   conv1d.pp_prio            1: the loading wave of a narrow-tile slot runs at s_setprio 2
 //   conv1d.pp_min_cout        narrowest layer (output channels) the ping-pong kernels take (default 320)
-// Returns 0, or -1 for an unknown name.
-extern "C" int os2s_set_option(const char* name, double value) {
-  if (!name) return -1;
-  const std::string k(name);
-  if (k == "conv1d.pp_cost_256") { os2s::g_pp_cost[0] = (float)value; return 0; }
-  if (k == "conv1d.pp_cost_2x128") { os2s::g_pp_cost[1] = (float)value; return 0; }
-  if (k == "conv1d.pp_cost_3x128") { os2s::g_pp_cost[2] = (float)value; return 0; }
-  if (k == "conv1d.pp_dgrad_penalty") { os2s::g_pp_cost[3] = (float)value; return 0; }
-  if (k == "conv1d.pp_prio") { os2s::g_pp_prio = (int)value; return 0; }
-  if (k == "conv1d.pp_min_cout") { g_pp_min_cout = (int)value; return 0; }
-  return -1;
-}
-// experiment hook (tools/pp_timeline.py, tools/ppn_timeline.py): device buffer of slot time stamps;
-// fixed_w (256-column tile) = every step streams the weight tile of step 0 (always an L2 hit); narrow
+//   conv1x1.variant           the 1x1 launches: 0 / 1 = lockstep 128x128 tile, 2 = 256x256 ping-pong tile
+static os2s::OptionReg r_variant("conv1d.variant", [](double v) { g_conv_variant = (int)v; });
+static os2s::OptionReg r_split("conv1d.split", [](double v) { g_conv_split = (int)v; });
+static os2s::OptionReg r_c256("conv1d.pp_cost_256", [](double v) { os2s::g_pp_cost[0] = (float)v; });
+static os2s::OptionReg r_c2("conv1d.pp_cost_2x128", [](double v) { os2s::g_pp_cost[1] = (float)v; });
+static os2s::OptionReg r_c3("conv1d.pp_cost_3x128", [](double v) { os2s::g_pp_cost[2] = (float)v; });
+static os2s::OptionReg r_pen("conv1d.pp_dgrad_penalty", [](double v) { os2s::g_pp_cost[3] = (float)v; });
+static os2s::OptionReg r_prio("conv1d.pp_prio", [](double v) { os2s::g_pp_prio = (int)v; });
+static os2s::OptionReg r_min("conv1d.pp_min_cout", [](double v) { g_pp_min_cout = (int)v; });
+// debug stamps "conv1d" (tools/pp_timeline.py, tools/ppn_timeline.py): device buffer of slot time stamps;
+// mode (256-column tile) = every step streams the weight tile of step 0 (always an L2 hit); narrow
 // tiles: bit 1 = no DMA issue in the loop, bit 2 = no fragment reads in the loop (timing only)
-extern "C" void os2s_conv1d_set_debug(void* stamps, int fixed_w) {
+static os2s::StampReg r_stamps("conv1d", [](void* stamps, int mode) {
   g_conv_dbg = (unsigned long long*)stamps;
-  g_conv_fixed_w = fixed_w;
-}
+  g_conv_fixed_w = mode;
+});
 
 static int g_conv1x1_variant = 0;
-extern "C" void os2s_conv1x1_set_variant(int v) { g_conv1x1_variant = v; }
+static os2s::OptionReg r_1x1("conv1x1.variant", [](double v) { g_conv1x1_variant = (int)v; });
 
 extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
   return B * os2s::ceil_div(Tout, os2s::kConvBM);
@@ -1423,7 +1419,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   }
   for (int i = ngroups; i < kMaxConvGroups; ++i) gt.g[i] = gt.g[0];
   gt.total_tiles = tiles;
-  // The 256 x 256 ping-pong tile (conv1x1_pp_kernel) is available behind os2s_conv1x1_set_variant(2)
+  // The 256 x 256 ping-pong tile (conv1x1_pp_kernel) is available behind os2s_set_option("conv1x1.variant", 2)
   // only: a 1x1 unit is 4-12 steps of matrix work followed by 128 KB of output, one workgroup per CU
   // cannot overlap the two (measured: epilogue 25 us of a 40 us unit; Jasper step +1 ms), while two
   // or three lockstep workgroups per CU do.

@@ -1120,14 +1120,15 @@ static int g_wgrad_variant = -1;   // experiment / test hook: 0 = lockstep kerne
 static int g_wgrad_split = -1;
 static unsigned long long* g_wgrad_dbg = nullptr;
 static int g_wgrad_dbg_mode = 0;
-extern "C" void os2s_conv1d_wgrad_set_debug(void* stamps, int mode) {
+// os2s_set_option: conv1d_wgrad.variant (0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, -1 = by shape),
+// conv1d_wgrad.split (> 0 forces the reduction split factor of the ping-pong kernels, -1 = cost model);
+// debug stamps "conv1d_wgrad" (tools/pp_timeline.py): per-slot time stamps of the ping-pong kernel
+static os2s::OptionReg r_wg_variant("conv1d_wgrad.variant", [](double v) { g_wgrad_variant = (int)v; });
+static os2s::OptionReg r_wg_split("conv1d_wgrad.split", [](double v) { g_wgrad_split = (int)v; });
+static os2s::StampReg r_wg_stamps("conv1d_wgrad", [](void* stamps, int mode) {
   g_wgrad_dbg = (unsigned long long*)stamps;
   g_wgrad_dbg_mode = mode;
-}
-extern "C" void os2s_conv1d_wgrad_set_variant(int v, int split) {
-  g_wgrad_variant = v;
-  g_wgrad_split = split;
-}
+});
 
 extern "C" int os2s_conv1d_wgrad_ws(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
                                     const uint16_t* dy, float* dw, const int32_t* in_len, int B,

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void depthwise_wgrad16_kernel(DwArgs p, int
 using namespace os2s;
 
 static int g_dw_variant = -1;   // test / experiment hook: 0 = the generic kernels only
-extern "C" void os2s_depthwise_set_variant(int v) { g_dw_variant = v; }
+static os2s::OptionReg r_dw_variant("depthwise.variant", [](double v) { g_dw_variant = (int)v; });
 
 static int dw_fill(DwArgs& a, int B, int Tin, int Tout, int C, int K, int stride, int dil, int padL) {
   OS2S_REQUIRE(B >= 1 && Tin >= 1 && Tout >= 1 && C >= 8 && C % 8 == 0 && K >= 1 && stride >= 1 && dil >= 1);

@@ -538,5 +538,5 @@ extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long l
                          out_f32, nullptr, 0);
 }
 
-// test / experiment hook: > 0 forces the tail split factor, 0 disables the split, < 0 = cost model
-extern "C" void os2s_gemm_nt_set_split(int f) { g_gemm_split = f; }
+// os2s_set_option("gemm_nt.split", f): > 0 forces the tail split factor, 0 disables the split, < 0 = cost model
+static os2s::OptionReg r_gemm_split("gemm_nt.split", [](double v) { g_gemm_split = (int)v; });

@@ -2,6 +2,8 @@
 #include "os2s_common.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 extern "C" int os2s_abi_version(void) { return 1; }
 
@@ -40,3 +42,29 @@ extern "C" int os2s_deterministic(void) {
   return g_deterministic;
 }
 extern "C" void os2s_set_deterministic(int on) { g_deterministic = on ? 1 : 0; }
+
+// ---- named options: one entry point for every test / measurement knob of the library ----
+namespace {
+template <typename F> struct Named { const char* name; F fn; };
+std::vector<Named<os2s::OptionSetter>>& option_table() { static std::vector<Named<os2s::OptionSetter>> t; return t; }
+std::vector<Named<os2s::StampSetter>>& stamp_table() { static std::vector<Named<os2s::StampSetter>> t; return t; }
+}  // namespace
+os2s::OptionReg::OptionReg(const char* name, OptionSetter fn) { option_table().push_back({name, fn}); }
+os2s::StampReg::StampReg(const char* name, StampSetter fn) { stamp_table().push_back({name, fn}); }
+
+extern "C" int os2s_set_option(const char* name, double value) {
+  if (!name) return -1;
+  for (const auto& o : option_table())
+    if (strcmp(o.name, name) == 0) { o.fn(value); return 0; }
+  return -1;
+}
+extern "C" const char* os2s_option_name(int index) {
+  const auto& t = option_table();
+  return index >= 0 && index < (int)t.size() ? t[(size_t)index].name : nullptr;
+}
+extern "C" int os2s_set_debug_stamps(const char* kernel, void* stamps, int mode) {
+  if (!kernel) return -1;
+  for (const auto& o : stamp_table())
+    if (strcmp(o.name, kernel) == 0) { o.fn(stamps, mode); return 0; }
+  return -1;
+}

@@ -28,6 +28,16 @@ extern "C" void os2s_record_hip_error(int hip_error, const char* where);
 
 namespace os2s {
 
+// Named test / measurement options behind the ONE entry point os2s_set_option (os2s_api.hip). A translation
+// unit registers its knobs next to the state they set: `static OptionReg r("conv1d.variant", [](double v) {...});`
+// (host-side only; the registry lives behind a function-local static so the order in which the translation
+// units are initialised does not matter). Nothing registered here is read from the environment.
+typedef void (*OptionSetter)(double value);
+struct OptionReg { OptionReg(const char* name, OptionSetter fn); };
+// debug time-stamp buffers of instrumented kernels (os2s_set_debug_stamps): fn(stamps, mode)
+typedef void (*StampSetter)(void* stamps, int mode);
+struct StampReg { StampReg(const char* name, StampSetter fn); };
+
 constexpr int kWave = 64;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -52,3 +52,34 @@ def test_missing_library_fails_loudly(monkeypatch):
   monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libos2s_hip.so")
   with pytest.raises(_lib.Os2sError):
     _lib.lib()
+
+
+def test_named_options_are_the_only_knobs():
+  """One entry point for every test / measurement knob (os2s_set_option): each name the tests, tools and
+  bench.py use is registered, each registered name is documented in the header, an unknown name is refused,
+  and the library exports no per-knob setter beside it (the product controls os2s_set_deterministic and
+  os2s_gru_xcd_set_mode, and the host-length hint, are entry points of their own)."""
+  import glob
+  import subprocess
+  from openseq2seq_amd import _lib
+  names = _lib.option_names()
+  assert len(names) == len(set(names)) >= 16
+  header = open(os.path.join(REPO, "include", "os2s.h")).read()
+  used = set()
+  for f in glob.glob(os.path.join(REPO, "tests", "*.py")) + glob.glob(os.path.join(REPO, "tools", "*.py")) + \
+      [os.path.join(REPO, "bench.py")]:
+    if os.path.basename(f) == "test_boundary.py":
+      continue
+    src = open(f).read()
+    used |= set(re.findall(r"set_option\(b?\"([a-z0-9_.]+)\"", src))
+    used |= set(re.findall(r"\"((?:conv1d|conv1x1|conv1d_wgrad|gemm_nt|depthwise)\.[a-z0-9_]+)\"", src))
+  assert used and not (used - set(names)), sorted(used - set(names))
+  for n in names:
+    assert n in header, n
+  f = _lib.bind("os2s_set_option", [ctypes.c_char_p, ctypes.c_double])
+  assert f(b"no.such.option", 1.0) == -1 and f(None, 1.0) == -1
+  g = _lib.bind("os2s_set_debug_stamps", [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int])
+  assert g(b"conv1d", None, 0) == 0 and g(b"conv1d_wgrad", None, 0) == 0 and g(b"nope", None, 0) == -1
+  out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+  setters = sorted(set(re.findall(r"\b(os2s_[a-z0-9_]*_set_(?:variant|split|debug|tiling))\b", out)))
+  assert setters == [], setters

@@ -167,7 +167,7 @@ def test_conv_fwd_tile_variants(cuda, variant, B, T, Cin, Cout, K, s, d):
   res = _bf(torch.randn(B, tout, Cout, generator=g))
   nm = capi.conv1d_num_mtiles(B, tout)
   stats = torch.full((nm, 2, Cout), float("nan"), device=cuda)
-  _lib.lib().os2s_conv1d_set_variant(variant)
+  _lib.set_option("conv1d.variant", variant)
   try:
     y = capi.conv1d_fwd(x.to(cuda), cnn.to_dev_layout(w_tf).to(cuda), stride=s, dil=d,
                         in_len=lens.to(cuda), stats=stats)
@@ -175,7 +175,7 @@ def test_conv_fwd_tile_variants(cuda, variant, B, T, Cin, Cout, K, s, d):
                          in_len=lens.to(cuda), act=1, residual=res.to(cuda))
     torch.cuda.synchronize()
   finally:
-    _lib.lib().os2s_conv1d_set_variant(-1)
+    _lib.set_option("conv1d.variant", -1)
   _check(y, ref)
   _check(y2, torch.relu(ref) + res.float(), extra=2.0)
   yr = y.float().cpu()
@@ -197,7 +197,7 @@ PP_CASES = [
 @pytest.mark.parametrize("use_ws", [True, False])
 @pytest.mark.parametrize("B,T,Cin,Cout,K,d", PP_CASES)
 def test_conv_pingpong_kernel(cuda, pp, use_ws, B, T, Cin, Cout, K, d):
-  """pp = os2s_conv1d_set_variant: 10 = tile chosen on the device, 12 / 13 = the narrow tiles (2 / 3 live
+  """pp = option conv1d.variant: 10 = tile chosen on the device, 12 / 13 = the narrow tiles (2 / 3 live
   windows x 128 columns, conv1d_ppn_kernel; a layer they do not fit falls back to 14), 14 = 2 windows x 256
   columns.
   The ping-pong kernel (conv1d_pp_kernel) forced on Jasper-shaped layers with ragged lengths
@@ -224,7 +224,7 @@ def test_conv_pingpong_kernel(cuda, pp, use_ws, B, T, Cin, Cout, K, d):
   wT = w_dev.flip(0).permute(0, 2, 1).contiguous()
   _, pl = capi.same_padding(T, K, 1, d)
   dym = _bf(dy.float() * mask)
-  _lib.lib().os2s_conv1d_set_variant(pp)
+  _lib.set_option("conv1d.variant", pp)
   try:
     y = torch.full((B, T, Cout), 5.0, dtype=torch.bfloat16, device=cuda)
     capi.conv1d_fwd(x.to(cuda), w_dev.to(cuda), dil=d, in_len=lens.to(cuda), stats=stats, out=y,
@@ -234,7 +234,7 @@ def test_conv_pingpong_kernel(cuda, pp, use_ws, B, T, Cin, Cout, K, d):
                     in_len=lens.to(cuda), out_len=lens.to(cuda), out=dx, use_workspace=use_ws)
     torch.cuda.synchronize()
   finally:
-    _lib.lib().os2s_conv1d_set_variant(-1)
+    _lib.set_option("conv1d.variant", -1)
   _check(y, ref.detach())
   yr = y.float().cpu()
   assert bool(torch.isfinite(stats).all())
@@ -277,13 +277,13 @@ def test_conv_pingpong_full_size_vs_lockstep_tile(cuda, ragged):
     # 14 = the 256-column ping-pong tile (10 lets the device choose: a narrow tile reduces the
     # BatchNorm partials in another fp32 grouping, see test_conv_narrow_pingpong_tiles_full_size_bit_identical)
     for name, v, ws in (("tile", 3, False), ("pp", 14, False), ("pp_ws", 14, True), ("pp_ws2", 14, True)):
-      _lib.lib().os2s_conv1d_set_variant(v)
+      _lib.set_option("conv1d.variant", v)
       st = torch.full((nm, 2, C), float("nan"), device=cuda)
       y = capi.conv1d_fwd(x, w, in_len=lens, stats=st, use_workspace=ws)
       torch.cuda.synchronize()
       outs[name] = (y, st)
   finally:
-    _lib.lib().os2s_conv1d_set_variant(-1)
+    _lib.set_option("conv1d.variant", -1)
   assert torch.equal(outs["pp"][0], outs["tile"][0])
   assert torch.equal(outs["pp"][1], outs["tile"][1])
   assert torch.equal(outs["pp_ws"][0], outs["pp_ws2"][0]) and torch.equal(outs["pp_ws"][1], outs["pp_ws2"][1])
@@ -316,7 +316,7 @@ def test_conv_narrow_pingpong_tiles_full_size_bit_identical(cuda, C, K):
     outs = {}
     try:
       for name, v in (("tile", 3), ("n2", 12), ("n3", 13), ("auto", 10)):
-        _lib.lib().os2s_conv1d_set_variant(v)
+        _lib.set_option("conv1d.variant", v)
         st = torch.full((nm, 2, C), float("nan"), device=cuda)
         y = torch.full((B, T, C), 3.0, dtype=torch.bfloat16, device=cuda)
         capi.conv1d_fwd(x, w, in_len=lens, stats=st, out=y)
@@ -325,7 +325,7 @@ def test_conv_narrow_pingpong_tiles_full_size_bit_identical(cuda, C, K):
         torch.cuda.synchronize()
         outs[name] = (y, st, dx)
     finally:
-      _lib.lib().os2s_conv1d_set_variant(-1)
+      _lib.set_option("conv1d.variant", -1)
     live = (torch.arange(T, device=cuda)[None, :] < lens[:, None])[:, :, None]
     for name in ("n2", "n3", "auto"):
       if name == "auto" or (name == "n3" and K > 21):    # (K = 25: the three-window tile does not fit)
@@ -361,7 +361,7 @@ def test_conv_host_length_hint_cannot_change_results(cuda, C, K):
   lens = lens_h.to(cuda)
 
   def run(variant, hint):
-    _lib.lib().os2s_conv1d_set_variant(variant)
+    _lib.set_option("conv1d.variant", variant)
     capi.conv1d_set_host_lens(hint)
     try:
       y = torch.full((B, T, C), 3.0, dtype=torch.bfloat16, device=cuda)
@@ -370,7 +370,7 @@ def test_conv_host_length_hint_cannot_change_results(cuda, C, K):
       return y
     finally:
       capi.conv1d_set_host_lens(None)
-      _lib.lib().os2s_conv1d_set_variant(-1)
+      _lib.set_option("conv1d.variant", -1)
 
   ref = run(3, None)
   dev_choice = run(-1, None)
@@ -403,7 +403,7 @@ def test_conv_wgrad_pingpong_kernel(cuda, B, T, Cin, Cout, K, d, split):
   ref = cnn.to_dev_layout(w_tf.grad)
   base = torch.randn(K, Cout, Cin, generator=g)
   L = _lib.lib()
-  L.os2s_conv1d_wgrad_set_variant(1, split)
+  _lib.set_option("conv1d_wgrad.variant", 1); _lib.set_option("conv1d_wgrad.split", split)
   try:
     o1 = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
     o2 = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
@@ -411,7 +411,7 @@ def test_conv_wgrad_pingpong_kernel(cuda, B, T, Cin, Cout, K, d, split):
     capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda), out=o3, accumulate=True)
     torch.cuda.synchronize()
   finally:
-    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
   scale = float(ref.pow(2).mean().sqrt()) + 1e-6
   torch.testing.assert_close(o1.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
   assert torch.equal(o1, o2)
@@ -431,15 +431,15 @@ def test_conv_wgrad_pingpong_full_size_vs_lockstep(cuda):
   lens = torch.randint(100, T + 1, (B,), generator=g).to(torch.int32).to(cuda)
   L = _lib.lib()
   try:
-    L.os2s_conv1d_wgrad_set_variant(0, -1)
+    _lib.set_option("conv1d_wgrad.variant", 0); _lib.set_option("conv1d_wgrad.split", -1)
     ref = capi.conv1d_wgrad(x, dy, K, in_len=lens)
-    L.os2s_conv1d_wgrad_set_variant(1, 1)
+    _lib.set_option("conv1d_wgrad.variant", 1); _lib.set_option("conv1d_wgrad.split", 1)
     a = capi.conv1d_wgrad(x, dy, K, in_len=lens)
-    L.os2s_conv1d_wgrad_set_variant(1, 4)
+    _lib.set_option("conv1d_wgrad.variant", 1); _lib.set_option("conv1d_wgrad.split", 4)
     b = capi.conv1d_wgrad(x, dy, K, in_len=lens)
     torch.cuda.synchronize()
   finally:
-    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
   assert torch.equal(a, ref)
   torch.testing.assert_close(b, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
@@ -467,7 +467,7 @@ def test_conv_wgrad1x1_pingpong_kernel(cuda, B, T, Cin, Cout, split):
   base = torch.randn(1, Cout, Cin, generator=g)
   xd = xw.to(cuda)[:, :, 32:32 + Cin]
   L = _lib.lib()
-  L.os2s_conv1d_wgrad_set_variant(2, split)
+  _lib.set_option("conv1d_wgrad.variant", 2); _lib.set_option("conv1d_wgrad.split", split)
   try:
     o1 = capi.conv1d_wgrad(xd, dy.to(cuda), 1, pad_left=0, in_len=lens.to(cuda))
     o2 = capi.conv1d_wgrad(xd, dy.to(cuda), 1, pad_left=0, in_len=lens.to(cuda))
@@ -475,7 +475,7 @@ def test_conv_wgrad1x1_pingpong_kernel(cuda, B, T, Cin, Cout, split):
     capi.conv1d_wgrad(xd, dy.to(cuda), 1, pad_left=0, in_len=lens.to(cuda), out=o3, accumulate=True)
     torch.cuda.synchronize()
   finally:
-    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
   scale = float(ref.pow(2).mean().sqrt()) + 1e-6
   torch.testing.assert_close(o1.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
   assert torch.equal(o1, o2)
@@ -495,13 +495,13 @@ def test_conv_wgrad1x1_pingpong_dense_size_vs_lockstep(cuda):
     x = _bf(torch.randn(1, N, Cin, generator=g)).to(cuda)
     dy = _bf(torch.randn(1, N, Cout, generator=g)).to(cuda)
     try:
-      L.os2s_conv1d_wgrad_set_variant(0, -1)
+      _lib.set_option("conv1d_wgrad.variant", 0); _lib.set_option("conv1d_wgrad.split", -1)
       ref = capi.conv1d_wgrad(x, dy, 1, pad_left=0)
-      L.os2s_conv1d_wgrad_set_variant(2, -1)
+      _lib.set_option("conv1d_wgrad.variant", 2); _lib.set_option("conv1d_wgrad.split", -1)
       a = capi.conv1d_wgrad(x, dy, 1, pad_left=0)
       torch.cuda.synchronize()
     finally:
-      L.os2s_conv1d_wgrad_set_variant(-1, -1)
+      _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
     torch.testing.assert_close(a, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
@@ -512,7 +512,7 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
   outputs BIT-IDENTICAL group by group, ragged lengths and dead windows included (same k order in
   every tile); BatchNorm partials identical for the lockstep tile and within fp32 summation-order
   noise (1e-5 relative to the window's largest partial) for the ping-pong tile, whose waves cover
-  the 128 rows of a window in a different order. variant = os2s_conv1x1_set_variant."""
+  the 128 rows of a window in a different order. variant = option conv1x1.variant."""
   from openseq2seq_amd import capi, _lib
   g = torch.Generator().manual_seed(21)
   B, T = 3, 300
@@ -523,8 +523,8 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
   items, ref = [], []
   items2, ref2 = [], []
   try:
-    L.os2s_conv1x1_set_variant(1)
-    L.os2s_conv1d_set_variant(0)
+    _lib.set_option("conv1x1.variant", 1)
+    _lib.set_option("conv1d.variant", 0)
     for cin, cout in shapes:
       x = _bf(torch.randn(B, T, cin, generator=g)).to(cuda)
       w = _bf(torch.randn(1, cout, cin, generator=g) * 0.05).to(cuda)
@@ -541,8 +541,8 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
       capi.conv1d_fwd(dy, wt, pad_left=0, tout=T, out=a, accumulate=True, out_len=lens)
       items2.append(dict(x=dy, w=wt, y=b, accumulate=True))
       ref2.append(a)
-    L.os2s_conv1d_set_variant(-1)
-    L.os2s_conv1x1_set_variant(variant)
+    _lib.set_option("conv1d.variant", -1)
+    _lib.set_option("conv1x1.variant", variant)
     capi.conv1x1_fwd_grouped(items, in_len=lens)
     # data-gradient form: accumulate into existing buffers, rows past out_len untouched
     capi.conv1x1_fwd_grouped(items2, out_len=lens)
@@ -550,13 +550,13 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
     xs, ws = items[2]["x"], items[2]["w"]
     bias = torch.randn(768, generator=g).to(cuda)
     single = capi.conv1d_fwd(xs, ws, pad_left=0, tout=T, in_len=lens, bias=bias, act=1)
-    L.os2s_conv1x1_set_variant(1)
-    L.os2s_conv1d_set_variant(0)
+    _lib.set_option("conv1x1.variant", 1)
+    _lib.set_option("conv1d.variant", 0)
     single_ref = capi.conv1d_fwd(xs, ws, pad_left=0, tout=T, in_len=lens, bias=bias, act=1)
     torch.cuda.synchronize()
   finally:
-    L.os2s_conv1d_set_variant(-1)
-    L.os2s_conv1x1_set_variant(0)
+    _lib.set_option("conv1d.variant", -1)
+    _lib.set_option("conv1x1.variant", 0)
   for it, (y, st) in zip(items, ref):
     assert torch.equal(it["y"], y)
     if variant == 1:

@@ -72,16 +72,16 @@ def test_gemm_nt_tail_split(cuda, M, N, K, split):
   bias = torch.randn(N, generator=g).to(cuda)
   L = _lib.lib()
   try:
-    L.os2s_gemm_nt_set_split(0)
+    _lib.set_option("gemm_nt.split", 0)
     ref32 = capi.gemm_nt(a, w, out_f32=True)
     ref16 = capi.gemm_nt(a, w, bias=bias, act=1)
-    L.os2s_gemm_nt_set_split(split)
+    _lib.set_option("gemm_nt.split", split)
     y32 = capi.gemm_nt(a, w, out_f32=True)
     y32b = capi.gemm_nt(a, w, out_f32=True)
     y16 = capi.gemm_nt(a, w, bias=bias, act=1)
     torch.cuda.synchronize()
   finally:
-    L.os2s_gemm_nt_set_split(-1)
+    _lib.set_option("gemm_nt.split", -1)
   torch.testing.assert_close(y32, ref32, rtol=1e-4, atol=1e-4 * float(ref32.abs().max()))
   assert torch.equal(y32, y32b)
   torch.testing.assert_close(y16.float(), ref16.float(), rtol=1e-2, atol=1e-2)
@@ -110,11 +110,11 @@ def test_gemm_nt_mask_epilogue(cuda, M, N, K, split):
   ref_out = _bf(torch.relu(h) * (torch.rand(M, N, generator=g) < keep).float() / keep).to(cuda)   # saved y
   L = _lib.lib()
   try:
-    L.os2s_gemm_nt_set_split(split)
+    _lib.set_option("gemm_nt.split", split)
     out, part = capi.gemm_nt_mask(a, w, ref_out, 1.0 / keep, want_colsum=True)
     out2, none = capi.gemm_nt_mask(a, w, ref_out, 1.0 / keep)
   finally:
-    L.os2s_gemm_nt_set_split(-1)
+    _lib.set_option("gemm_nt.split", -1)
   torch.cuda.synchronize()
   assert none is None and torch.equal(out, out2)
   prod = a.float() @ w.float().t()

@@ -324,7 +324,7 @@ GRAD_TOL_3LAYER = 8e-3
 @pytest.mark.parametrize("pp", [-1, 12, 13])
 @pytest.mark.parametrize("C,K,dil", [(640, 21, 1), (768, 13, 2), (384, 13, 1)])
 def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, monkeypatch, C, K, dil, pp):
-  """pp: os2s_conv1d_set_variant for the whole pass (-1 = default, 12 / 13 = the narrow ping-pong tiles of
+  """pp: option conv1d.variant for the whole pass (-1 = default, 12 / 13 = the narrow ping-pong tiles of
   2 / 3 windows x 128 columns wherever a layer fits them — the fused epilogue on the straddling wave layout).
   accumulate = True in the fused epilogue: layer A (plain conv + BN + ReLU, stride 1) feeds a residual
   block of two repeats — its first repeat's main convolution AND the block end's 1 x 1 residual branch.
@@ -371,7 +371,7 @@ def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, 
   store.zero_grads()
   tape = Tape()
   from openseq2seq_amd import _lib
-  _lib.lib().os2s_conv1d_set_variant(pp)
+  _lib.set_option("conv1d.variant", pp)
   try:
     e = enc.encode({"source_tensors": [x0.to(cuda), lens.to(cuda)], "tape": tape, "seed": 3})
     out = e["outputs_act"]
@@ -380,7 +380,7 @@ def test_fused_bn_backward_accumulates_into_a_gradient_with_two_consumers(cuda, 
     tape.backward()
     torch.cuda.synchronize()
   finally:
-    _lib.lib().os2s_conv1d_set_variant(-1)
+    _lib.set_option("conv1d.variant", -1)
   # two fused calls: block end -> repeat 1's output (fresh), repeat 1 -> layer A's output (accumulating)
   from openseq2seq_amd.parts.cnns import conv_blocks
   assert calls == ([False, True] if conv_blocks.FUSE_BN_BWD else []), calls

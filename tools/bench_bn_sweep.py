@@ -1,4 +1,4 @@
-"""Sweep of the BatchNorm kernels' tiling (os2s_bn_set_tiling) at Jasper shapes."""
+"""Sweep of the BatchNorm kernels' tiling (os2s_set_option bn.<kernel>.groups / .rows) at Jasper shapes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
@@ -12,7 +12,12 @@ rng = np.random.RandomState(0)
 lens = (rng.uniform(2.0, 16.7, B) * 50).astype(np.int32) + 1
 T = int(-(-lens.max() // 16) * 16)
 out_len = torch.from_numpy(lens).to(dev)
-set_tiling = _lib.bind("os2s_bn_set_tiling", [ctypes.c_int] * 3)
+_BN_KERNELS = ("act_fwd", "act_bwd_reduce", "bwd_apply")
+
+
+def set_tiling(which, groups, rows):
+  _lib.set_option("bn.%s.groups" % _BN_KERNELS[which], groups)
+  _lib.set_option("bn.%s.rows" % _BN_KERNELS[which], rows)
 
 
 def timeit(fn, n=20):
@@ -53,7 +58,7 @@ for C in (256, 512, 768, 1024):
     row = []
     for R in (16, 32, 64, 128):
       for w in range(3):
-        _lib.check(set_tiling(w, G, R))
+        set_tiling(w, G, R)
       def f_fwd():
         b = nxt(); capi.bn_act_fwd([b["y"]], [sc], [sh], b["out"], out_len, 1, 0.8, 7)
       def f_red():

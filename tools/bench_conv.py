@@ -7,7 +7,7 @@ from openseq2seq_amd import capi
 dev = torch.device("cuda:0")
 from openseq2seq_amd import _lib
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else -1
-_lib.lib().os2s_conv1d_set_variant(variant)
+_lib.set_option("conv1d.variant", variant)
 print("variant", variant)
 B, T = 32, 840
 shapes = [(256, 256, 11, 1), (384, 384, 13, 1), (512, 512, 17, 1), (640, 640, 21, 1),

@@ -39,11 +39,11 @@ for cin, cout, K in shapes:
   rag = torch.from_numpy(lens_np).to(dev)
   dil = 2 if K == 29 else 1
   for v in variants:
-    _lib.lib().os2s_conv1d_set_variant(v)
+    _lib.set_option("conv1d.variant", v)
     ms_d = timeit(lambda: capi.conv1d_fwd(x, w, out=y, dil=dil, stats=stats))
     ms_r = timeit(lambda: capi.conv1d_fwd(x, w, out=y, dil=dil, stats=stats, in_len=rag))
     fl = 2.0 * B * T * cin * cout * K
     res[(v, cin, cout, K)] = (ms_d, fl / ms_d / 1e9, ms_r, fl * live / ms_r / 1e9)
-  _lib.lib().os2s_conv1d_set_variant(-1)
+  _lib.set_option("conv1d.variant", -1)
   print("C %4d->%4d K %2d: " % (cin, cout, K) + "  ".join(
       "v%d %.3f ms %4.0f TF | rag %.3f ms %4.0f TF(live)" % ((v,) + res[(v, cin, cout, K)]) for v in variants), flush=True)

@@ -37,11 +37,11 @@ for cin, cout, K in shapes:
     nl = B * 7 if ln is None else int(sum(min(7, (int(v) + pl + 127) // 128) for v in ln))
     U = ((nl + 1) // 2) * ((cout + 255) // 256)
     out = []
-    L.os2s_conv1d_set_variant(3)
+    _lib.set_option("conv1d.variant", 3)
     out.append("tile128 %.3f" % timeit(lambda: capi.conv1d_fwd(x, w, out=y, dil=dil, stats=stats, in_len=lens)))
-    L.os2s_conv1d_set_variant(10)
+    _lib.set_option("conv1d.variant", 10)
     for f in (-1, 1, 2, 3, 4, 6, 8):
-      L.os2s_conv1d_set_split(f)
+      _lib.set_option("conv1d.split", f)
       out.append("f%d %.3f" % (f, timeit(lambda: capi.conv1d_fwd(x, w, out=y, dil=dil, stats=stats, in_len=lens))))
-    L.os2s_conv1d_set_split(-1); L.os2s_conv1d_set_variant(-1)
+    _lib.set_option("conv1d.split", -1); _lib.set_option("conv1d.variant", -1)
     print("C %4d->%4d K %2d %-10s live windows %3d units %3d (r %3d): %s" % (cin, cout, K, name, nl, U, U % 256, "  ".join(out)), flush=True)

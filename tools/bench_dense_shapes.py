@@ -59,11 +59,11 @@ for Cin, Cout in [(1024, 1024), (1024, 3072), (1024, 2048), (1024, 4096), (4096,
   dw = torch.zeros(1, Cout, Cin, device=dev)
   res = {}
   for name, var in (("lockstep", 0), ("pp1x1", 2)):
-    L.os2s_conv1d_wgrad_set_variant(var, -1)
+    _lib.set_option("conv1d_wgrad.variant", var); _lib.set_option("conv1d_wgrad.split", -1)
     try:
       res[name] = timeit(lambda: capi.conv1d_wgrad(x, dy, 1, pad_left=0, out=dw, accumulate=True))
     finally:
-      L.os2s_conv1d_wgrad_set_variant(-1, -1)
+      _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
   res["lt"] = nan_on_error(lambda: lt_backend.matmul_lt(dy[0], x[0], a_is_t=True, out=dw[0], beta=1.0))
   fl = 2.0 * M * Cin * Cout
   print("Cin %5d Cout %5d: " % (Cin, Cout) + " | ".join(
@@ -79,11 +79,11 @@ for Cin, Cout in [(256, 256), (256, 384), (384, 512), (512, 640), (640, 768), (7
   dw = torch.zeros(1, Cout, Cin, device=dev)
   res = {}
   for name, var in (("lockstep", 0), ("pp1x1", 2)):
-    L.os2s_conv1d_wgrad_set_variant(var, -1)
+    _lib.set_option("conv1d_wgrad.variant", var); _lib.set_option("conv1d_wgrad.split", -1)
     try:
       res[name] = timeit(lambda: capi.conv1d_wgrad(x, dy, 1, pad_left=0, in_len=lens, out=dw, accumulate=True))
     finally:
-      L.os2s_conv1d_wgrad_set_variant(-1, -1)
+      _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
   fl = 2.0 * float(lens.sum()) * Cin * Cout
   print("Cin %5d Cout %5d: " % (Cin, Cout) + " | ".join(
       "%s %.3f ms %5.0f TF/s" % (k, v, fl / v / 1e9) for k, v in res.items()), flush=True)

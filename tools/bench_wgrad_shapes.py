@@ -34,13 +34,13 @@ for cin, cout, K in shapes:
     live = 1.0 if ln is None else float(ln.sum()) / (B * T)
     fl = 2.0 * B * T * cin * cout * K * live
     out = []
-    L.os2s_conv1d_wgrad_set_variant(0, -1)
+    _lib.set_option("conv1d_wgrad.variant", 0); _lib.set_option("conv1d_wgrad.split", -1)
     t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
     out.append("lockstep %.3f ms %4.0f TF" % (t, fl / t / 1e9))
     for f in (-1, 1, 2, 3, 4, 6, 8, 12, 16):
-      L.os2s_conv1d_wgrad_set_variant(1, f)
+      _lib.set_option("conv1d_wgrad.variant", 1); _lib.set_option("conv1d_wgrad.split", f)
       t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
       out.append("f%d %.3f" % (f, t) + (" %4.0f TF" % (fl / t / 1e9) if f == -1 else ""))
-    L.os2s_conv1d_wgrad_set_variant(-1, -1)
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
     units = ((cout + 127) // 128) * ((cin + 127) // 128) * ((K + 3) // 4)
     print("C %4d->%4d K %2d %-6s units %3d: %s" % (cin, cout, K, name, units, "  ".join(out)), flush=True)

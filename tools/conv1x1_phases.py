@@ -1,4 +1,4 @@
-"""Phase breakdown of conv1x1_pp_kernel work units (stamps via os2s_conv1d_set_debug) for a Jasper
+"""Phase breakdown of conv1x1_pp_kernel work units (stamps via os2s_set_debug_stamps) for a Jasper
 block-end grouped launch: entry -> decoded -> pipeline filled -> main loop -> epilogue."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +14,6 @@ lens_np = (rng.uniform(2.0, 16.7, B) * 50).astype(np.int32) + 1
 T = int(-(-lens_np.max() // 16) * 16)
 lens = torch.from_numpy(lens_np).to(dev)
 L = _lib.lib()
-L.os2s_conv1d_set_debug.argtypes = [_lib.c_void_p, _lib.c_int]
 nm = capi.conv1d_num_mtiles(B, T)
 cins = [256, 256, 256, 384, 384, 512, 512, 640, 640, 768][10 - NG:]
 cout = 768
@@ -23,7 +22,7 @@ for variant in (1, 2):
   for cin in cins:
     items.append(dict(x=torch.randn(B, T, cin, device=dev).bfloat16(), w=(torch.randn(1, cout, cin, device=dev) * 0.05).bfloat16(),
                       y=torch.empty(B, T, cout, device=dev, dtype=torch.bfloat16), stats=torch.empty(nm, 2, cout, device=dev)))
-  L.os2s_conv1x1_set_variant(variant)
+  _lib.set_option("conv1x1.variant", variant)
   for _ in range(3):
     capi.conv1x1_fwd_grouped(items, in_len=lens)
   torch.cuda.synchronize()
@@ -36,11 +35,11 @@ for variant in (1, 2):
   if variant == 2:
     STRIDE = int(os.environ.get("PH_STRIDE", "8"))     # 24 with a -DOS2S_EPI_STAMPS build
     st = torch.zeros(2048 * STRIDE, dtype=torch.int64, device=dev)
-    L.os2s_conv1d_set_debug(_lib.c_void_p(st.data_ptr()), 0)
+    _lib.set_debug_stamps("conv1d", st.data_ptr(), 0)
     e0.record()
     capi.conv1x1_fwd_grouped(items, in_len=lens)
     e1.record(); torch.cuda.synchronize()
-    L.os2s_conv1d_set_debug(_lib.c_void_p(0), 0)
+    _lib.set_debug_stamps("conv1d", 0, 0)
     us = e0.elapsed_time(e1) * 1e3
     full = st.cpu().numpy().reshape(2048, STRIDE).astype(np.float64)
     t = full[:, :8]
@@ -64,4 +63,4 @@ for variant in (1, 2):
       m = t[(np.arange(len(ok))[ok] % 8) == x]
       print("  XCD %d: %d units, span %.0f ticks, sum of unit totals / 32 CUs = %.0f ticks"
             % (x, len(m), m[:, 4].max() - m[:, 0].min(), (m[:, 4] - m[:, 0]).sum() / 32))
-L.os2s_conv1x1_set_variant(0)
+_lib.set_option("conv1x1.variant", 0)

@@ -35,7 +35,7 @@ def run_case(name, B, T, Cin, Cout, K, dil, ragged, mode, variant):
   nm = capi.conv1d_num_mtiles(B, T)
   outs = {}
   for v in (3, variant):
-    _lib.lib().os2s_conv1d_set_variant(v)
+    _lib.set_option("conv1d.variant", v)
     st = torch.full((nm, 2, Cout), float("nan"), device=dev)
     y = torch.full((B, T, Cout), 3.0, dtype=torch.bfloat16, device=dev)
     if mode == "fwd":
@@ -44,7 +44,7 @@ def run_case(name, B, T, Cin, Cout, K, dil, ragged, mode, variant):
       capi.conv1d_fwd(x, w, dil=dil, pad_left=(K - 1) * dil // 2, tout=T, in_len=lens, out_len=lens, out=y)
     torch.cuda.synchronize()
     outs[v] = (y, st)
-  _lib.lib().os2s_conv1d_set_variant(-1)
+  _lib.set_option("conv1d.variant", -1)
   a, b = outs[3], outs[variant]
   if mode == "fwd":
     eq = bool(torch.equal(a[0], b[0])) and bool(torch.equal(a[1], b[1]))

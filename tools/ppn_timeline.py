@@ -8,7 +8,6 @@ import torch
 from openseq2seq_amd import capi, _lib
 dev = torch.device("cuda:0")
 L = _lib.lib()
-L.os2s_conv1d_set_debug.argtypes = [_lib.c_void_p, _lib.c_int]
 L.os2s_set_option.argtypes = [_lib.ctypes.c_char_p, _lib.ctypes.c_double]
 B, T, NS = 32, 840, 24
 # mode: 0 normal, 2 no DMA issue in the loop, 4 no fragment reads in the loop, 6 neither (barriers + MFMAs only)
@@ -21,16 +20,16 @@ for cin, cout, K, v, prio, mode in [(384, 384, 13, 12, 0, 0), (384, 384, 13, 12,
   w = (torch.randn(K, cout, cin, device=dev) * 0.02).to(torch.bfloat16)
   y = torch.empty(B, T, cout, device=dev, dtype=torch.bfloat16)
   st = torch.zeros(4 * 2 * NS * 9, dtype=torch.int64, device=dev)
-  L.os2s_conv1d_set_variant(v)
+  _lib.set_option("conv1d.variant", v)
   for _ in range(3): capi.conv1d_fwd(x, w, out=y)
   torch.cuda.synchronize()
-  L.os2s_conv1d_set_debug(_lib.c_void_p(st.data_ptr()), mode)
+  _lib.set_debug_stamps("conv1d", st.data_ptr(), mode)
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()
   capi.conv1d_fwd(x, w, out=y)
   e1.record(); torch.cuda.synchronize()
-  L.os2s_conv1d_set_debug(_lib.c_void_p(0), 0)
-  L.os2s_conv1d_set_variant(-1)
+  _lib.set_debug_stamps("conv1d", 0, 0)
+  _lib.set_option("conv1d.variant", -1)
   t = st.cpu().numpy().reshape(4, 2, NS, 9).astype(np.float64)
   print("C %d->%d K %d variant %d prio %d mode %d: launch %.3f ms" % (cin, cout, K, v, prio, mode, e0.elapsed_time(e1)))
   names = ["rd1", "vmcnt", "dma", "rd2", "valu", "lgkm", "bar", "MFMA", "bar"]
