@@ -1,0 +1,179 @@
+"""Fixture generator: runs the REFERENCE'S OWN PYTHON SOURCE (the files under /root/reference/open_seq2seq, where
+they lie) on seeded inputs and writes inputs, variables and outputs to tests/golden/ref_exec_*.npz.
+
+TensorFlow is not installed in this container, so `tensorflow` resolves to oracle/ref_shim/tf1 — a restatement
+of the TF 1.x LIBRARY primitives on torch CPU tensors (see its header). Everything above the primitives — the
+encoder / decoder / loss / lr-policy / loss-scaler logic — executes from the reference's files, unmodified.
+The parity tests (tests/test_ref_exec_*.py) then hold the oracle restatements (CPU) and the HIP path (GPU)
+against these fixtures; when /root/reference is present they also re-run this generator and check that it
+reproduces the committed files.
+
+    python tests/golden/make_ref_exec.py [--check] [name ...]
+
+Only importable pieces of the reference are loaded: its packages' __init__ files import every model family
+(cuDNN RNNs, librosa, horovod ...), so the package names are pre-seeded as empty namespace stubs that point at
+the reference's directories and the wanted modules are imported one by one.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("OS2S_REFERENCE", "/root/reference")
+PKG = os.path.join(REF, "open_seq2seq")
+
+
+def reference_available():
+  return os.path.isdir(PKG)
+
+
+def _install():
+  """tensorflow -> the shim; open_seq2seq.* -> namespace stubs over the reference's directories."""
+  sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
+  import tf1
+  tf = tf1.install()
+  for k in [k for k in sys.modules if k == "open_seq2seq" or k.startswith("open_seq2seq.")]:
+    del sys.modules[k]
+  subs = ["", "encoders", "decoders", "losses", "optimizers", "utils", "parts", "parts.transformer", "parts.cnns",
+          "parts.rnns", "data", "data.speech2text", "models"]
+  for s in subs:
+    name = "open_seq2seq" + ("." + s if s else "")
+    m = types.ModuleType(name)
+    m.__path__ = [os.path.join(PKG, *s.split("."))] if s else [PKG]
+    m.__package__ = name
+    sys.modules[name] = m
+    if s:
+      parent, _, leaf = name.rpartition(".")
+      setattr(sys.modules[parent], leaf, m)
+  # the data layer class the TDNN encoder imports for a type check only (its module needs librosa / pandas)
+  dl = types.ModuleType("open_seq2seq.data.speech2text.speech2text")
+  dl.Speech2TextDataLayer = type("Speech2TextDataLayer", (), {})
+  sys.modules[dl.__name__] = dl
+  import importlib
+  enc = importlib.import_module("open_seq2seq.encoders.encoder")
+  sys.modules["open_seq2seq.encoders"].Encoder = enc.Encoder
+  dec = importlib.import_module("open_seq2seq.decoders.decoder")
+  sys.modules["open_seq2seq.decoders"].Decoder = dec.Decoder
+  los = importlib.import_module("open_seq2seq.losses.loss")
+  sys.modules["open_seq2seq.losses"].Loss = los.Loss
+  return tf, importlib.import_module
+
+
+def _np(v):
+  return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Transformer: TransformerEncoder._encode -> TransformerDecoder.decode_pass -> PaddedCrossEntropyLossWithSmoothing
+# (encoders/transformer_encoder.py:78-170, decoders/transformer_decoder.py:96-230, parts/transformer/*.py,
+# losses/sequence_loss.py:233-309), train mode with every dropout probability 0, forward + all gradients.
+# ---------------------------------------------------------------------------------------------------------
+def transformer(seed=11):
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  TransformerEncoder = imp("open_seq2seq.encoders.transformer_encoder").TransformerEncoder
+  TransformerDecoder = imp("open_seq2seq.decoders.transformer_decoder").TransformerDecoder
+  Loss = imp("open_seq2seq.losses.sequence_loss").PaddedCrossEntropyLossWithSmoothing
+  rng = np.random.RandomState(seed)
+  B, S, T, V, D, H, F, NL = 3, 11, 9, 45, 32, 4, 64, 2
+  src_len = np.array([11, 7, 4], np.int32)
+  tgt_len = np.array([6, 9, 3], np.int32)
+  src = np.zeros((B, S), np.int32)
+  tgt = np.zeros((B, T), np.int32)
+  for b in range(B):
+    src[b, :src_len[b]] = rng.randint(2, V, size=src_len[b])
+    tgt[b, :tgt_len[b]] = rng.randint(2, V, size=tgt_len[b])
+  src[1, 2] = V + 5            # an id past the vocabulary: mapped to the pad symbol (embedding_layer.py:71-73)
+  enc_params = dict(encoder_layers=NL, hidden_size=D, num_heads=H, attention_dropout=0.0, filter_size=F,
+                    src_vocab_size=V, relu_dropout=0.0, layer_postprocess_dropout=0.0, remove_padding=True,
+                    pad_embeddings_2_eight=True, dtype=tf.float32)
+  dec_params = dict(EOS_ID=1, layer_postprocess_dropout=0.0, num_hidden_layers=NL, hidden_size=D, num_heads=H,
+                    attention_dropout=0.0, relu_dropout=0.0, filter_size=F, batch_size=B, tgt_vocab_size=V,
+                    beam_size=4, alpha=0.6, extra_decode_length=5, GO_SYMBOL=1, PAD_SYMBOL=0, END_SYMBOL=1,
+                    dtype=tf.float32)
+  loss_params = dict(batch_size=B, tgt_vocab_size=V, label_smoothing=0.1, pad_embeddings_2_eight=True,
+                     dtype=tf.float32)
+  with tf.variable_scope("ForwardPass"):
+    encoder = TransformerEncoder(enc_params, None, mode="train")
+    decoder = TransformerDecoder(dec_params, None, mode="train")
+    loss_fn = Loss(loss_params, None)
+    src_t, src_len_t = tf.constant(src), tf.constant(src_len)
+    tgt_t, tgt_len_t = tf.constant(tgt), tf.constant(tgt_len)
+    enc_out = encoder.encode({"source_tensors": [src_t, src_len_t]})
+    dec_out = decoder.decode({"encoder_output": enc_out, "target_tensors": [tgt_t, tgt_len_t]})
+    loss = loss_fn.compute_loss({"decoder_output": dec_out, "target_tensors": [tgt_t, tgt_len_t]})
+  tvars = tf.trainable_variables()
+  # non-trivial LayerNorm parameters (the initial 1 / 0 would hide a swapped scale / bias)
+  with tf.Session() as sess:
+    for v in tvars:
+      if "layer_norm" in v.name:
+        v.load(_np(v._var) + 0.1 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+    grads = tf.gradients(loss, tvars)
+    names = [v.name.split(":")[0] for v in tvars]
+    vals = sess.run({"enc": enc_out["outputs"], "bias": enc_out["inputs_attention_bias"], "logits": dec_out["logits"],
+                     "loss": loss, "grads": grads, "vars": list(tvars)})
+  out = {"src": src, "src_len": src_len, "tgt": tgt, "tgt_len": tgt_len, "enc_out": vals["enc"],
+         "enc_bias": vals["bias"], "logits": vals["logits"], "loss": np.float32(vals["loss"]),
+         "config": np.array([B, S, T, V, D, H, F, NL], np.int32), "label_smoothing": np.float32(0.1),
+         "var_names": np.array(names)}
+  for n, v, g in zip(names, vals["vars"], vals["grads"]):
+    out["var/" + n] = v.astype(np.float32)
+    out["grad/" + n] = g.astype(np.float32)
+  return out
+
+
+GENERATORS = {"transformer": transformer}
+
+
+def generate(name):
+  out = GENERATORS[name]()
+  return {k: np.asarray(v) for k, v in out.items()}
+
+
+def fixture_path(name):
+  return os.path.join(HERE, "ref_exec_%s.npz" % name)
+
+
+def compare(a, b, rtol=2e-5, atol=2e-6):
+  """Names that differ between two fixture dicts (float arrays within rtol / atol, everything else exact)."""
+  bad = [k for k in set(a) ^ set(b)]
+  for k in set(a) & set(b):
+    x, y = np.asarray(a[k]), np.asarray(b[k])
+    if x.shape != y.shape:
+      bad.append(k)
+    elif x.dtype.kind == "f":
+      if not np.allclose(x, y, rtol=rtol, atol=atol * max(1.0, float(np.abs(y).max()) if y.size else 1.0)):
+        bad.append(k)
+    elif not np.array_equal(x, y):
+      bad.append(k)
+  return sorted(bad)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("names", nargs="*", default=sorted(GENERATORS))
+  ap.add_argument("--check", action="store_true", help="regenerate and compare with the committed files")
+  args = ap.parse_args()
+  if not reference_available():
+    raise SystemExit("%s not found: fixtures can only be generated where the reference checkout is" % PKG)
+  rc = 0
+  for n in args.names:
+    out = generate(n)
+    if args.check:
+      bad = compare(out, dict(np.load(fixture_path(n))))
+      print("%s: %s" % (n, "reproduced" if not bad else "DIFFERS in %s" % bad))
+      rc |= bool(bad)
+    else:
+      np.savez_compressed(fixture_path(n), **out)
+      print("%s: %d arrays, %.1f KB -> %s" % (n, len(out), os.path.getsize(fixture_path(n)) / 1e3,
+                                             os.path.relpath(fixture_path(n), REPO)))
+  return rc
+
+
+if __name__ == "__main__":
+  sys.exit(main())
