@@ -72,7 +72,27 @@ def _np(v):
 # (encoders/transformer_encoder.py:78-170, decoders/transformer_decoder.py:96-230, parts/transformer/*.py,
 # losses/sequence_loss.py:233-309), train mode with every dropout probability 0, forward + all gradients.
 # ---------------------------------------------------------------------------------------------------------
-def transformer(seed=11):
+def seeded_array(name, shape, seed, scale=None):
+  """The value of variable `name` in the fixtures that do not store their variables: N(0, scale^2) from a seed
+  derived from the name (scale: 1 / sqrt(fan_in) for matrices, 0.1 around 1 / 0 for LayerNorm scale / bias and
+  for biases) — the generator and the tests call this same function."""
+  import zlib
+  rs = np.random.RandomState((zlib.crc32(name.encode()) + seed) % (2 ** 31))
+  x = rs.standard_normal(shape).astype(np.float32)
+  if len(shape) >= 2:
+    return x * np.float32(scale if scale is not None else 1.0 / np.sqrt(shape[-2] if "embedding" not in name else shape[-1]))
+  return (np.float32(1.0) if name.endswith(("scale", "gamma")) else np.float32(0.0)) + np.float32(0.1) * x
+
+
+def projection(name, g, seed):
+  """(norm, <g, r>) with r a seeded N(0,1) direction: two numbers that pin a gradient tensor without storing it."""
+  import zlib
+  r = np.random.RandomState((zlib.crc32(("proj/" + name).encode()) + seed) % (2 ** 31)).standard_normal(g.shape)
+  g = np.asarray(g, np.float64)
+  return np.array([np.linalg.norm(g), float((g * r).sum())], np.float64)
+
+
+def transformer(seed=11, dims=(3, 11, 9, 45, 32, 4, 64, 2), store_vars=True):
   tf, imp = _install()
   tf.reset_default_graph()
   tf.set_random_seed(seed)
@@ -80,7 +100,7 @@ def transformer(seed=11):
   TransformerDecoder = imp("open_seq2seq.decoders.transformer_decoder").TransformerDecoder
   Loss = imp("open_seq2seq.losses.sequence_loss").PaddedCrossEntropyLossWithSmoothing
   rng = np.random.RandomState(seed)
-  B, S, T, V, D, H, F, NL = 3, 11, 9, 45, 32, 4, 64, 2
+  B, S, T, V, D, H, F, NL = dims
   src_len = np.array([11, 7, 4], np.int32)
   tgt_len = np.array([6, 9, 3], np.int32)
   src = np.zeros((B, S), np.int32)
@@ -88,7 +108,8 @@ def transformer(seed=11):
   for b in range(B):
     src[b, :src_len[b]] = rng.randint(2, V, size=src_len[b])
     tgt[b, :tgt_len[b]] = rng.randint(2, V, size=tgt_len[b])
-  src[1, 2] = V + 5            # an id past the vocabulary: mapped to the pad symbol (embedding_layer.py:71-73)
+  if store_vars:
+    src[1, 2] = V + 5            # an id past the vocabulary: mapped to the pad symbol (embedding_layer.py:71-73)
   enc_params = dict(encoder_layers=NL, hidden_size=D, num_heads=H, attention_dropout=0.0, filter_size=F,
                     src_vocab_size=V, relu_dropout=0.0, layer_postprocess_dropout=0.0, remove_padding=True,
                     pad_embeddings_2_eight=True, dtype=tf.float32)
@@ -108,26 +129,38 @@ def transformer(seed=11):
     dec_out = decoder.decode({"encoder_output": enc_out, "target_tensors": [tgt_t, tgt_len_t]})
     loss = loss_fn.compute_loss({"decoder_output": dec_out, "target_tensors": [tgt_t, tgt_len_t]})
   tvars = tf.trainable_variables()
-  # non-trivial LayerNorm parameters (the initial 1 / 0 would hide a swapped scale / bias)
+  names = [v.name.split(":")[0] for v in tvars]
   with tf.Session() as sess:
-    for v in tvars:
-      if "layer_norm" in v.name:
+    for n, v in zip(names, tvars):
+      if not store_vars:
+        v.load(seeded_array(n, tuple(v._var.shape), seed))
+      elif "layer_norm" in v.name:      # LayerNorm parameters away from 1 / 0 (a swapped scale / bias would hide there)
         v.load(_np(v._var) + 0.1 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
     grads = tf.gradients(loss, tvars)
-    names = [v.name.split(":")[0] for v in tvars]
     vals = sess.run({"enc": enc_out["outputs"], "bias": enc_out["inputs_attention_bias"], "logits": dec_out["logits"],
                      "loss": loss, "grads": grads, "vars": list(tvars)})
   out = {"src": src, "src_len": src_len, "tgt": tgt, "tgt_len": tgt_len, "enc_out": vals["enc"],
          "enc_bias": vals["bias"], "logits": vals["logits"], "loss": np.float32(vals["loss"]),
          "config": np.array([B, S, T, V, D, H, F, NL], np.int32), "label_smoothing": np.float32(0.1),
-         "var_names": np.array(names)}
+         "var_names": np.array(names), "seed": np.int32(seed)}
   for n, v, g in zip(names, vals["vars"], vals["grads"]):
-    out["var/" + n] = v.astype(np.float32)
-    out["grad/" + n] = g.astype(np.float32)
+    if store_vars:
+      out["var/" + n] = v.astype(np.float32)
+      out["grad/" + n] = g.astype(np.float32)
+    else:
+      out["shape/" + n] = np.array(v.shape, np.int32)
+      out["gproj/" + n] = projection(n, g, seed)
   return out
 
 
-GENERATORS = {"transformer": transformer}
+def transformer_d512():
+  """The same graph at the narrowest widths the HIP kernels take (head dim 64, LayerNorm rows of 512 or 1024):
+  d_model 512, 8 heads, filter 1024, 2 + 2 layers, V 90 -> 96. Variables come from seeded_array (not stored),
+  gradients are stored as (norm, seeded projection) per variable."""
+  return transformer(seed=23, dims=(3, 11, 9, 90, 512, 8, 1024, 2), store_vars=False)
+
+
+GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512}
 
 
 def generate(name):

@@ -1,0 +1,94 @@
+"""The HIP Transformer path against the REFERENCE'S OWN CODE (no oracle in between).
+
+tests/golden/ref_exec_transformer_d512.npz = open_seq2seq's TransformerEncoder / TransformerDecoder /
+PaddedCrossEntropyLossWithSmoothing executed from their files (tests/golden/make_ref_exec.py) at the narrowest widths
+the device kernels take: d_model 512, 8 heads of 64, filter 1024, 2 + 2 layers, vocabulary 90 padded to 96, a ragged
+batch of 3. The device model is built from the same config, its variables are loaded BY THE REFERENCE'S NAMES through
+the checkpoint importer (utils/checkpoint.py: Dense kernels transposed, q / k / v fused), and one forward + backward
+pass on packed tokens must give the reference's logits, loss and variable gradients. Tolerances are the bf16 ones of
+tests/test_transformer_e2e_gpu.py (the device stores activations and weights in bf16, the fixture is fp32): logits
+rel-L2 3e-2, loss 2e-2, gradients: norm within 20 %, seeded projection within 4 x 0.2 x norm."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_exec_util as rx  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SHARED = "ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights"
+
+
+def test_device_transformer_reproduces_the_reference_code(cuda):
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.encoders.transformer_encoder import TransformerEncoder
+  from openseq2seq_amd.decoders.transformer_decoder import TransformerDecoder
+  from openseq2seq_amd.losses.sequence_loss import PaddedCrossEntropyLossWithSmoothing
+  from openseq2seq_amd.parts.cnns.conv_blocks import Tape
+  from openseq2seq_amd.parts.transformer.layers import SeedSeq
+  from openseq2seq_amd.parts.transformer import packing
+  from openseq2seq_amd.utils import checkpoint
+  d, names = rx.load("transformer_d512")
+  B, S, T, V, D, H, F, NL = [int(v) for v in d["config"]]
+  store = FlatParams(cuda)
+  enc = TransformerEncoder({"encoder_layers": NL, "hidden_size": D, "num_heads": H, "attention_dropout": 0.0,
+                            "filter_size": F, "src_vocab_size": V, "relu_dropout": 0.0,
+                            "layer_postprocess_dropout": 0.0, "remove_padding": True,
+                            "pad_embeddings_2_eight": True, "dtype": "mixed"}, None, mode="train").build(store)
+  dec = TransformerDecoder({"EOS_ID": 1, "layer_postprocess_dropout": 0.0, "num_hidden_layers": NL,
+                            "hidden_size": D, "num_heads": H, "attention_dropout": 0.0, "relu_dropout": 0.0,
+                            "filter_size": F, "batch_size": B, "tgt_vocab_size": V, "beam_size": 4, "alpha": 0.6,
+                            "extra_decode_length": 5, "dtype": "mixed"}, None, mode="train").build(store)
+  lossf = PaddedCrossEntropyLossWithSmoothing({"label_smoothing": float(d["label_smoothing"]), "tgt_vocab_size": V,
+                                               "batch_size": B, "pad_embeddings_2_eight": True,
+                                               "dtype": "mixed"}, None)
+  store.finalize(need_m2=False)
+  # ---- the reference's variables, by the reference's names -------------------------------------------------
+  tf_arrays = rx.variables(d, names)
+  tf_arrays["ForwardPass/embedding_and_softmax/weights"] = tf_arrays[SHARED]
+  used = set()
+  for p in store.params:
+    a = checkpoint.import_param(p.name, p.shape, p.kind, tf_arrays, getattr(p, "logical_out", None))
+    assert a is not None and tuple(a.shape) == tuple(p.shape), (p.name, None if a is None else a.shape, p.shape)
+    p.master.copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(cuda).view_as(p.master))
+    for tf_name, _ in checkpoint.export_param(p.name, p.shape, p.kind, a, getattr(p, "logical_out", None)):
+      used.add(tf_name)
+  assert used - {"ForwardPass/embedding_and_softmax/weights"} | {SHARED} == set(names), \
+      "the device model holds exactly the reference's variables"
+  store.refresh_compute_copies()
+  # ---- one forward + backward pass on the packed batch --------------------------------------------------------
+  src, sl, tgt, tl = d["src"], d["src_len"], d["tgt"], d["tgt_len"]
+  batch = {'source_tensors': [torch.from_numpy(src).to(cuda), torch.from_numpy(sl).to(cuda)],
+           'target_tensors': [torch.from_numpy(tgt).to(cuda), torch.from_numpy(tl).to(cuda)],
+           'packed_source': packing.to_device(packing.pack_ids(src, sl), cuda),
+           'packed_target': packing.to_device(packing.pack_ids(tgt, tl, shift_right=True), cuda)}
+  tape = Tape()
+  store.zero_grads()
+  e = enc.encode({'source_tensors': batch['source_tensors'], 'tape': tape, 'seeds': SeedSeq(1),
+                  'packed_source': batch['packed_source']})
+  dd = dec.decode({'encoder_output': e, 'target_tensors': batch['target_tensors'], 'tape': tape,
+                   'packed_target': batch['packed_target']})
+  L = lossf.compute_loss({'decoder_output': dd, 'target_tensors': batch['target_tensors']})
+  tape.backward()
+  torch.cuda.synchronize()
+  # ---- against the reference's numbers ----------------------------------------------------------------------------
+  ref_loss = float(d["loss"])
+  assert abs(float(L.cpu()[0]) - ref_loss) <= 2e-2 * abs(ref_loss), (float(L.cpu()[0]), ref_loss)
+  lg = dd["logits"].float().cpu().numpy()
+  ref_rows = np.concatenate([d["logits"][b, :tl[b]] for b in range(B)], 0)
+  assert lg.shape == ref_rows.shape, (lg.shape, ref_rows.shape)
+  r = rx.rel(lg, ref_rows)
+  assert r < 3e-2, r
+  worst = 0.0
+  for p in store.params:
+    g = p.grad.detach().float().cpu().numpy()
+    for tf_name, tf_g in checkpoint.export_param(p.name, p.shape, p.kind, g, getattr(p, "logical_out", None)):
+      n = SHARED if tf_name == "ForwardPass/embedding_and_softmax/weights" else tf_name
+      worst = max(worst, rx.check_gradient(d, n, tf_g, 0.2))
+  print("device vs the reference's code: loss %.5f vs %.5f, logits rel-L2 %.2e, worst gradient projection error %.2e"
+        % (float(L.cpu()[0]), ref_loss, r, worst))
