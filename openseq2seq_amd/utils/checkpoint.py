@@ -37,7 +37,15 @@ LATEST_FILENAME = "checkpoint"
 
 
 def _is_dense(name):
-  return not re.search(r"/conv\d*[^/]*/kernel$|pointwise_kernel$", name)
+  """Is this [1, Cout, Cin] matrix a tf.layers.dense kernel ([Cin, Cout] in a checkpoint) rather than a K = 1
+  tf.layers.conv1d kernel ([1, Cin, Cout])? Convolution variables sit under a scope component named conv...
+  ('conv61/kernel', and the residual branches 'conv22/res_0/kernel', 'conv22/res/kernel' of
+  parts/cnns/conv_blocks.py:78-85 — until round 5 the branches were taken for dense kernels and written / read
+  with the wrong rank; found by running the reference's own TDNNEncoder, tests/test_ref_exec_tdnn_gpu.py)."""
+  parts = name.split("/")
+  if parts[-1] == "pointwise_kernel":
+    return False
+  return not any(re.match(r"conv(_|\d|$)", c) for c in parts[:-1])
 
 
 def export_param(name, shape, kind, arr, logical_out=None):
@@ -106,9 +114,9 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
   if name.endswith("embedding_and_softmax/weights"):
     return a[None]
   if kind == "conv":
-    if shape[0] == 1 and _is_dense(name):
+    if a.ndim == 2:                       # tf.layers.dense [Cin, Cout]
       return a.T[None]
-    return np.transpose(a, (0, 2, 1))
+    return np.transpose(a, (0, 2, 1))     # tf.layers.conv1d [K, Cin, Cout] (the array's own rank decides)
   if name.endswith("/depthwise_kernel"):
     return a[:, :, 0]
   return a

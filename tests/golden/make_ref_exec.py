@@ -160,7 +160,107 @@ def transformer_d512():
   return transformer(seed=23, dims=(3, 11, 9, 90, 512, 8, 1024, 2), store_vars=False)
 
 
-GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512}
+# ---------------------------------------------------------------------------------------------------------
+# Jasper / TDNN: TDNNEncoder._encode (encoders/tdnn_encoder.py:87-265) over conv_bn_actv / conv_bn_res_bn_actv
+# (parts/cnns/conv_blocks.py:61-232) -> FullyConnectedCTCDecoder (decoders/fc_decoders.py:105-250: dense +
+# time-major transpose + tf.nn.ctc_greedy_decoder), train mode (BatchNorm on batch statistics, moving averages
+# updated through UPDATE_OPS), dropout keep 1. tf.nn.ctc_loss is TensorFlow-internal: the gradients are those of
+# the surrogate loss sum(logits * R) with a seeded R (also stored), which exercises every variable.
+# ---------------------------------------------------------------------------------------------------------
+def jasper_layers(c, k):
+  """Jasper's layer pattern scaled down: stride-2 first layer, dense-residual blocks with repeat 2, a
+  dilation-2 layer, a 1x1 last layer (example_configs/speech2text/jasper10x5_LibriSpeech_nvgrad_masks.py:58-147)."""
+  def blk(rep, kk, ch, stride=1, dil=1, res=False):
+    d = {"type": "conv1d", "repeat": rep, "kernel_size": [kk], "stride": [stride], "num_channels": ch,
+         "padding": "SAME", "dilation": [dil], "dropout_keep_prob": 1.0}
+    if res:
+      d.update(residual=True, residual_dense=True)
+    return d
+  return [blk(1, k[0], c[0], stride=2), blk(2, k[0], c[0], res=True), blk(2, k[1], c[1], res=True),
+          blk(2, k[2], c[2], res=True), blk(1, k[3], c[3], dil=2), blk(1, 1, c[4])]
+
+
+def tdnn_input(seed, src_len, T, F):
+  """The feature batch of the TDNN fixtures (zeros past each length, as the data layer pads)."""
+  x = np.random.RandomState(seed + 1000).standard_normal((len(src_len), T, F)).astype(np.float32)
+  for b, n in enumerate(src_len):
+    x[b, int(n):] = 0.0
+  return x
+
+
+def tdnn(seed=5, F=16, chans=(8, 16, 16, 24, 24), kern=(5, 7, 9, 11), T=48, B=3, store_vars=True, V=29):
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  TDNNEncoder = imp("open_seq2seq.encoders.tdnn_encoder").TDNNEncoder
+  Decoder = imp("open_seq2seq.decoders.fc_decoders").FullyConnectedCTCDecoder
+  DataLayer = sys.modules["open_seq2seq.data.speech2text.speech2text"].Speech2TextDataLayer
+  rng = np.random.RandomState(seed)
+  src_len = np.array(([T, T - 13, T // 2 - 3] * B)[:B], np.int32)
+  src_len[3:] -= np.arange(B - 3, dtype=np.int32)[:max(B - 3, 0)] * 2 + 1
+  x = tdnn_input(seed, src_len, T, F)
+  layers = jasper_layers(chans, kern)
+
+  class _Model(object):                 # what the encoder asks its model for (encoder.py:86-112, tdnn_encoder.py:113-117)
+    params = {"dtype": tf.float32}
+
+    def get_data_layer(self):
+      dl = DataLayer()
+      dl.params = {"backend": "librosa", "pad_to": 16}
+      return dl
+  enc_params = dict(convnet_layers=layers, dropout_keep_prob=1.0, activation_fn=tf.nn.relu, data_format="channels_last",
+                    use_conv_mask=True, dtype=tf.float32)
+  dec_params = dict(tgt_vocab_size=V, dtype=tf.float32)
+  with tf.variable_scope("ForwardPass"):
+    encoder = TDNNEncoder(enc_params, _Model(), name="w2l_encoder", mode="train")
+    decoder = Decoder(dec_params, None, mode="train")
+    x_t, len_t = tf.constant(x), tf.constant(src_len)
+    enc_out = encoder.encode({"source_tensors": [x_t, len_t]})
+    dec_out = decoder.decode({"encoder_output": enc_out})
+  logits = dec_out["logits"]                      # [T', B, V], time major
+  R = rng.standard_normal(tuple(int(v) for v in logits.get_shape())).astype(np.float32)
+  loss = tf.reduce_sum(logits * tf.constant(R))
+  tvars = tf.trainable_variables()
+  names = [v.name.split(":")[0] for v in tvars]
+  moving = [v for v in tf.global_variables() if "moving_" in v.name]
+  with tf.Session() as sess:
+    for n, v in zip(names, tvars):
+      v.load(seeded_array(n, tuple(v._var.shape), seed) if not store_vars else
+             (seeded_array(n, tuple(v._var.shape), seed) if v._var.dim() == 1 else _np(v._var)))
+    grads = tf.gradients(loss, tvars)
+    decoded = dec_out["outputs"][0]
+    vals = sess.run({"enc": enc_out["outputs"], "len": enc_out["src_length"], "logits": logits, "loss": loss,
+                     "grads": grads, "vars": list(tvars), "ids": tf.sparse_tensor_to_dense(decoded, default_value=-1)})
+    sess.run(tf.get_collection(tf.GraphKeys.UPDATE_OPS))
+    mv = sess.run(list(moving))
+  out = {"src_len": src_len, "T": np.int32(T), "out_len": vals["len"].astype(np.int32),
+         "logits": vals["logits"], "R": R, "loss": np.float32(vals["loss"]), "greedy_ids": vals["ids"].astype(np.int32),
+         "var_names": np.array(names), "seed": np.int32(seed), "chans": np.array(chans, np.int32),
+         "kern": np.array(kern, np.int32), "F": np.int32(F), "V": np.int32(V),
+         "moving_names": np.array([v.name.split(":")[0] for v in moving])}
+  for v, a in zip(moving, mv):
+    out["moving/" + v.name.split(":")[0]] = a.astype(np.float32)
+  if store_vars:
+    out["enc_out"] = vals["enc"]
+  for n, v, g in zip(names, vals["vars"], vals["grads"]):
+    if store_vars:
+      out["var/" + n] = v.astype(np.float32)
+      out["grad/" + n] = g.astype(np.float32)
+    else:
+      out["shape/" + n] = np.array(v.shape, np.int32)
+      out["gproj/" + n] = projection(n, g, seed)
+  return out
+
+
+def tdnn_wide():
+  """The same graph at widths the HIP convolution kernels run at (channels in multiples of 64, 64 features):
+  variables from seeded_array, gradients as (norm, projection); B = 6 (288 rows per BatchNorm: the batch size of the
+  device's own end-to-end test); the encoder output is not stored (the logits are its 29-dimensional image)."""
+  return tdnn(seed=9, F=64, chans=(128, 192, 256, 320, 384), kern=(11, 13, 17, 29), T=96, B=6, store_vars=False)
+
+
+GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
+              "tdnn_wide": tdnn_wide}
 
 
 def generate(name):

@@ -40,6 +40,40 @@ def test_unpadded_layers_are_untouched():
   np.testing.assert_array_equal(ck.import_param(n, w.shape, "conv", {n: a}), w)
 
 
+def test_residual_branch_kernels_keep_the_conv1d_rank():
+  """The 1x1 residual branches of conv_bn_res_bn_actv are tf.layers.conv1d(res, filters, 1, name='<layer>/res_<i>')
+  (parts/cnns/conv_blocks.py:78-85): their checkpoint variable is [1, Cin, Cout], like any conv1d kernel, not the
+  [Cin, Cout] of a tf.layers.dense. The variable list of the reference's own TDNNEncoder
+  (tests/golden/ref_exec_tdnn.npz, produced by executing it) is the witness: every '.../kernel' under the encoder has
+  rank 3, the decoder's fully_connected/kernel rank 2 — and export_param / import_param must write and read exactly
+  those shapes."""
+  import os
+  d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec_tdnn.npz"))
+  seen_res = 0
+  for n in [str(v) for v in d["var_names"]]:
+    if not n.endswith("/kernel"):
+      continue
+    tf_arr = d["var/" + n]
+    if "/w2l_encoder/" in n:
+      assert tf_arr.ndim == 3, n
+      K, cin, cout = tf_arr.shape
+      dev = ck.import_param(n, (K, cout, cin), "conv", {n: tf_arr})
+      assert dev.shape == (K, cout, cin), (n, dev.shape)
+      np.testing.assert_array_equal(dev, np.transpose(tf_arr, (0, 2, 1)))
+      (n2, back), = ck.export_param(n, dev.shape, "conv", dev)
+      assert n2 == n and back.shape == tf_arr.shape, (n, back.shape, tf_arr.shape)
+      np.testing.assert_array_equal(back, tf_arr)
+      seen_res += "/res_" in n
+    else:
+      assert tf_arr.ndim == 2, n
+      cin, cout = tf_arr.shape
+      dev = ck.import_param(n, (1, cout, cin), "conv", {n: tf_arr})
+      np.testing.assert_array_equal(dev, tf_arr.T[None])
+      (n2, back), = ck.export_param(n, dev.shape, "conv", dev)
+      np.testing.assert_array_equal(back, tf_arr)
+  assert seen_res >= 6
+
+
 def test_mixed_precision_dtypes_match_a_reference_checkpoint():
   """A reference mixed-precision graph holds weight matrices as DT_HALF and their fp32 twins under
   Loss_Optimization/FP32-master-copy/ (mp_wrapper.py:55-82); BatchNorm vectors stay fp32 with no
