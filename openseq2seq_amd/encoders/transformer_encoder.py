@@ -36,8 +36,11 @@ class TransformerEncoder(Encoder):
     p = self.params
     D = p["hidden_size"]
     scope = "ForwardPass/" + self._name
+    # tf.layers.Layer scoping: EmbeddingSharedWeights is first CALLED inside the encoder's variable scope, so its
+    # variable is '<encoder scope>/embedding_shared_weights/embedding_and_softmax/weights' (embedding_layer.py:49-54;
+    # the name the reference's own code produces when it is executed: tests/golden/ref_exec_transformer.npz)
     self.embedding_softmax_layer = L.SharedEmbedding(
-        store, "ForwardPass", p["src_vocab_size"], D,
+        store, scope + "/embedding_shared_weights", p["src_vocab_size"], D,
         pad_vocab_to_eight=p.get('pad_embeddings_2_eight', False))
     for n in range(p['encoder_layers']):
       ls = "%s/layer_%d" % (scope, n)

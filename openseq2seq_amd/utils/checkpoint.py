@@ -109,6 +109,8 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
       return None
     return np.concatenate([m.T for m in mats], axis=0)[None]
   a = get(name)
+  if a is None and name.endswith("/embedding_shared_weights/embedding_and_softmax/weights"):
+    a = get("ForwardPass/embedding_and_softmax/weights")      # checkpoints this repository wrote before round 5
   if a is None:
     return None
   if name.endswith("embedding_and_softmax/weights"):

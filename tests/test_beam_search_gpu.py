@@ -194,7 +194,7 @@ def _tiny_transformer(cuda, V=200, D=512, H=8, NL=2, beam=4, extra=6):
                            mode="infer").build(store)
   store.finalize()
   # sharpen the output distribution so that beams are well separated
-  emb = store.by_name("ForwardPass/embedding_and_softmax/weights")
+  emb = store.by_name("ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights")
   emb.master.mul_(4.0)
   store.refresh_compute_copies()
   return store, enc, dec

@@ -108,3 +108,20 @@ def test_mixed_precision_dtypes_match_a_reference_checkpoint():
   M.params = {"dtype": "float32"}
   out32 = ck.model_variables(M())
   assert out32[k].dtype == np.float32 and ck.MASTER_PREFIX + k not in out32
+
+
+def test_shared_embedding_is_stored_under_the_reference_name():
+  """'ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights' — the name the
+  reference's code gives the variable when executed (first variable of tests/golden/ref_exec_transformer.npz);
+  checkpoints this repository wrote earlier ('ForwardPass/embedding_and_softmax/weights') still load."""
+  import os
+  d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec_transformer.npz"))
+  name = str(d["var_names"][0])
+  assert name == "ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights"
+  tab = d["var/" + name]
+  dev = ck.import_param(name, (1,) + tab.shape, "conv", {name: tab})
+  np.testing.assert_array_equal(dev[0], tab)
+  old = ck.import_param(name, (1,) + tab.shape, "conv", {"ForwardPass/embedding_and_softmax/weights": tab})
+  np.testing.assert_array_equal(old[0], tab)
+  (n2, back), = ck.export_param(name, dev.shape, "conv", dev)
+  assert n2 == name and back.shape == tab.shape

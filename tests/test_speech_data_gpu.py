@@ -309,7 +309,7 @@ def test_checkpoint_roundtrip_transformer_layout(cuda, tmp_path):
   for t in "qkv":
     assert ck["%s/%s/kernel" % (base, t)].shape == (512, 512)
   assert base + "/qkv/kernel" not in ck
-  assert ck["ForwardPass/embedding_and_softmax/weights"].shape == (96, 512)
+  assert ck["ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights"].shape == (96, 512)
   qkv = m1.store.by_name(base + "/qkv/kernel").master.cpu().numpy()
   # mixed precision: the plain name holds DT_HALF (what a reference fp16 graph stores), the fp32 value
   # lives under the master-copy name (mp_wrapper.py:55-82)

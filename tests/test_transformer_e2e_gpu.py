@@ -98,9 +98,9 @@ def _oracle_params(store, dims=SMALL):
     leaves[prefix + "/output_layer/kernel"], leaves[prefix + "/output_layer/bias"] = d["w2"], d["b2"]
     return d
 
-  emb = store.by_name("ForwardPass/embedding_and_softmax/weights").w16.float().cpu()[0] \
+  emb = store.by_name("ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights").w16.float().cpu()[0] \
       .clone().requires_grad_(True)
-  leaves["ForwardPass/embedding_and_softmax/weights"] = emb
+  leaves["ForwardPass/transformer_encoder/embedding_shared_weights/embedding_and_softmax/weights"] = emb
   e, dc = "ForwardPass/transformer_encoder", "ForwardPass/transformer_decoder"
   PE = {"emb": emb, "layers": [], "ln_out": ln(e + "/layer_normalization")}
   PD = {"emb": emb, "layers": [], "ln_out": ln(dc + "/layer_normalization")}
