@@ -807,6 +807,8 @@ class Session(object):
       memo[id(k)] = _t(v).to(k._value.dtype) if isinstance(k, Tensor) else v
 
     def ev(t):
+      if isinstance(t, Variable):       # a ref variable is read where it is used: after an assign that the
+        return t._var                   # reader's control dependencies ran first, it shows the new value
       key = id(t)
       if key not in memo:
         memo[key] = t._eval(ev)

@@ -259,8 +259,78 @@ def tdnn_wide():
   return tdnn(seed=9, F=64, chans=(128, 192, 256, 320, 384), kern=(11, 13, 17, 29), T=96, B=6, store_vars=False)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Optimizer side: the seven learning-rate policies (optimizers/lr_policies.py) evaluated at a list of global steps,
+# and the two loss scalers (optimizers/automatic_loss_scaler.py: BackoffScaler, LogMaxScaler) driven through a
+# scripted sequence of (has_nan, amax) events — update_op built ONCE and run per event, as a training loop does.
+# ---------------------------------------------------------------------------------------------------------
+LR_CASES = [
+    ("fixed_lr", dict(learning_rate=0.3)),
+    ("piecewise_constant", dict(learning_rate=0.1, boundaries=[40, 90, 200], decay_rates=[0.5, 0.1, 0.01])),
+    ("piecewise_constant", dict(learning_rate=0.1, boundaries=[2, 5], decay_rates=[0.1, 0.01], steps_per_epoch=30)),
+    ("exp_decay", dict(learning_rate=0.05, decay_steps=50, decay_rate=0.5, use_staircase_decay=True,
+                       begin_decay_at=20, min_lr=1e-3)),
+    ("exp_decay", dict(learning_rate=0.05, decay_steps=37, decay_rate=0.9, use_staircase_decay=False)),
+    ("poly_decay", dict(learning_rate=0.02, decay_steps=300, power=2.0, min_lr=1e-5)),
+    ("poly_decay", dict(learning_rate=0.02, decay_steps=200, power=0.5, begin_decay_at=60, min_lr=1e-4,
+                        warmup_steps=25)),
+    ("cosine_decay", dict(learning_rate=0.01, decay_steps=250, begin_decay_at=30, min_lr=0.05, warmup_steps=10)),
+    ("transformer_policy", dict(learning_rate=2.0, d_model=512, warmup_steps=80)),
+    ("transformer_policy", dict(learning_rate=1.0, d_model=1024, warmup_steps=40, max_lr=1e-3, coefficient=2.0)),
+    ("inv_poly_decay", dict(learning_rate=0.1, decay_steps=400, min_lr=1e-4, power=2.0)),
+]
+LR_STEPS = [0, 1, 2, 9, 10, 11, 19, 20, 24, 25, 26, 29, 30, 31, 39, 40, 41, 59, 60, 61, 79, 80, 81, 89, 90, 91, 149, 150,
+            151, 199, 200, 201, 260, 299, 300, 301, 399, 400, 1000]
+
+
+def scaler_events(seed=3, n=260):
+  """(has_nan, amax) per step: mostly finite maxima spread over decades, isolated and back-to-back overflows of both
+  kinds (NaN seen, Inf maximum), small step windows so that growth happens inside the trace."""
+  rs = np.random.RandomState(seed)
+  amax = np.exp2(rs.uniform(-6, 14, size=n)).astype(np.float32)
+  nan = np.zeros(n, np.bool_)
+  for i in (7, 8, 40, 41, 42, 100, 180):
+    nan[i] = True
+  for i in (20, 101, 150, 151):
+    amax[i] = np.inf
+  return nan, amax
+
+
+def optim():
+  tf, imp = _install()
+  tf.reset_default_graph()
+  pol = imp("open_seq2seq.optimizers.lr_policies")
+  als = imp("open_seq2seq.optimizers.automatic_loss_scaler")
+  out = {"lr_steps": np.array(LR_STEPS, np.int64)}
+  gs = tf.train.get_or_create_global_step()
+  with tf.Session() as sess:
+    for i, (name, params) in enumerate(LR_CASES):
+      lr = getattr(pol, name)(global_step=gs, **params)
+      vals = []
+      for st in LR_STEPS:
+        gs.load(np.int64(st))
+        vals.append(float(sess.run(lr)) if hasattr(lr, "_eval") else float(lr))
+      out["lr/%d/%s" % (i, name)] = np.array(vals, np.float64)
+    nan, amax = scaler_events()
+    out["ev_nan"], out["ev_amax"] = nan, amax
+    cases = [("backoff", dict(step_window=16)), ("backoff", dict(scale_min=8.0, scale_max=4096.0, step_factor=4.0,
+                                                              step_window=5)),
+             ("logmax", {}), ("logmax", dict(scale_max=2.0 ** 10, beta1=0.9, beta2=0.95, overflow_std_dev=2.0))]
+    for i, (algo, params) in enumerate(cases):
+      sc = als.AutomaticLossScaler(algorithm=algo, params=dict(params))
+      p_nan, p_amax = tf.placeholder(tf.bool, []), tf.placeholder(tf.float32, [])
+      up = sc.update_op(p_nan, p_amax)
+      trace = [float(sess.run(sc.loss_scale))]
+      for h, a in zip(nan, amax):
+        sess.run(up, {p_nan: bool(h), p_amax: np.float32(a)})
+        trace.append(float(sess.run(sc.loss_scale)))
+      out["scale/%d/%s" % (i, algo)] = np.array(trace, np.float32)
+      out["scale_params/%d" % i] = np.array(repr(sorted(params.items())))
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide}
+              "tdnn_wide": tdnn_wide, "optim": optim}
 
 
 def generate(name):
