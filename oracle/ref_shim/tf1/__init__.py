@@ -453,8 +453,8 @@ class Variable(Tensor):
       v = v.to(as_dtype(dtype).torch)
     self._var = v
     self.trainable = _PYBOOL(trainable)
-    if self.trainable and v.dtype.is_floating_point:
-      self._var.requires_grad_(True)
+    if v.dtype.is_floating_point:          # tf.gradients may be taken w.r.t. any variable (mp_wrapper.py:79-88 does,
+      self._var.requires_grad_(True)       # w.r.t. its non-trainable fp32 master copies)
     super(Variable, self).__init__(lambda: self._var, (), name=name, build_value=self._var)
     self._ctrl = []
     full = "/".join([s for s in (_scope().name, name or "Variable") if s])
@@ -482,7 +482,7 @@ class Variable(Tensor):
     v = v.detach().to(self._var.dtype).clone()
     if _tuple(v.shape) != _tuple(self._var.shape):
       v = v.reshape(self._var.shape)
-    if self.trainable and v.dtype.is_floating_point:
+    if v.dtype.is_floating_point:
       v.requires_grad_(True)
     self._var = v
     return v
@@ -2073,15 +2073,19 @@ class Optimizer(object):
 
   def __init__(self, use_locking=False, name="Optimizer"):
     self._name = name
+    self._use_locking = use_locking
     self._slots = {}
 
   def get_name(self):
     return self._name
 
+  LAST_COMPUTED = None      # (fixture generator's tap) the grads_and_vars of the latest compute_gradients call
+
   def compute_gradients(self, loss, var_list=None, gate_gradients=1, aggregation_method=None,
                         colocate_gradients_with_ops=False, grad_loss=None):
     vs = list(var_list) if var_list is not None else trainable_variables()
     gs = gradients(loss, vs, grad_ys=None if grad_loss is None else [grad_loss])
+    Optimizer.LAST_COMPUTED = list(zip(gs, vs))
     return list(zip(gs, vs))
 
   def _zeros_slot(self, var, slot_name, op_name=None):

@@ -53,6 +53,10 @@ def _install():
   dl = types.ModuleType("open_seq2seq.data.speech2text.speech2text")
   dl.Speech2TextDataLayer = type("Speech2TextDataLayer", (), {})
   sys.modules[dl.__name__] = dl
+  import collections
+  import collections.abc
+  if not hasattr(collections, "Sequence"):      # the reference predates Python 3.10 (optimizers.py:441)
+    collections.Sequence = collections.abc.Sequence
   import importlib
   enc = importlib.import_module("open_seq2seq.encoders.encoder")
   sys.modules["open_seq2seq.encoders"].Encoder = enc.Encoder
@@ -329,8 +333,104 @@ def optim():
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The train op: optimizers.optimize_loss (optimizers/optimizers.py:107-286) with dtype "mixed" — the
+# MixedPrecisionOptimizerWrapper (mp_wrapper.py: loss scaling, FP32 master copies, regularisation on the master
+# copy, un-scaling, skip on NaN / Inf, saturate_cast back to fp16), post_process_gradients (LARC / global-norm
+# clipping), the automatic loss scalers and the optimizer itself (NovoGrad from optimizers/novograd.py over the
+# restated tf.train.MomentumOptimizer; Adam; Momentum), built ONCE and run step after step on a toy model whose
+# fp16 gradients overflow at the initial loss scale. Recorded per step: the loss scale going in, the learning
+# rate, the scaled half-precision gradients the wrapper received, and every variable after the step.
+# ---------------------------------------------------------------------------------------------------------
+TRAIN_OP_CASES = {
+    "novograd_larc_backoff": dict(optimizer="NovoGrad", optimizer_params=dict(beta1=0.95, beta2=0.98, weight_decay=0.001),
+                                  larc_params=dict(larc_eta=0.001), loss_scaling="Backoff",
+                                  loss_scaling_params=dict(step_window=6), l2=0.0,
+                                  lr=("poly_decay", dict(learning_rate=0.02, decay_steps=40, power=2.0, min_lr=1e-5))),
+    "adam_backoff_l2": dict(optimizer="Adam", optimizer_params=dict(beta1=0.9, beta2=0.997, epsilon=1e-9),
+                            loss_scaling="Backoff", loss_scaling_params=dict(step_window=5), l2=1e-3,
+                            lr=("transformer_policy", dict(learning_rate=2.0, d_model=64, warmup_steps=8))),
+    "momentum_clip_logmax": dict(optimizer="Momentum", optimizer_params=dict(momentum=0.9), clip_gradients=0.5,
+                                 loss_scaling="LogMax", loss_scaling_params={}, l2=5e-4,
+                                 lr=("exp_decay", dict(learning_rate=0.05, decay_steps=10, decay_rate=0.7,
+                                                       use_staircase_decay=False))),
+}
+TRAIN_OP_VARS = [("w1", (6, 10), "float16", 3.0), ("w2", (10, 4), "float16", 9.0), ("bias", (4,), "float16", 1.0),
+                 ("gamma", (10,), "float32", 2.0)]
+
+
+def train_op_constants(seed=31):
+  """Per toy variable: initial value, A (linear term, magnitude `amp`: 9 x 2^14 overflows fp16) and B > 0 (curvature).
+  loss = sum_v sum(cast32(v) * A + 0.5 * cast32(v)^2 * B)."""
+  rs = np.random.RandomState(seed)
+  out = {}
+  for name, shape, dt, amp in TRAIN_OP_VARS:
+    out[name] = (rs.standard_normal(shape).astype(dt), (amp * rs.standard_normal(shape)).astype(np.float32),
+                 rs.uniform(0.5, 1.5, size=shape).astype(np.float32))
+  return out
+
+
+def train_op(steps=28):
+  out = {"steps": np.int32(steps)}
+  for case, cfg in TRAIN_OP_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    opt_mod = imp("open_seq2seq.optimizers.optimizers")
+    pol = imp("open_seq2seq.optimizers.lr_policies")
+    mpw = imp("open_seq2seq.optimizers.mp_wrapper")
+    optimizer = imp("open_seq2seq.optimizers.novograd").NovoGrad if cfg["optimizer"] == "NovoGrad" else cfg["optimizer"]
+    consts = train_op_constants()
+    reg = mpw.mp_regularizer_wrapper(tf.contrib.layers.l2_regularizer(cfg["l2"])) if cfg["l2"] else None
+    tvars, terms = [], []
+    with tf.variable_scope("ForwardPass"):
+      for name, shape, dt, amp in TRAIN_OP_VARS:
+        init, A, B = consts[name]
+        v = tf.get_variable(name, shape=list(shape), dtype=tf.as_dtype(dt), initializer=tf.constant(init),
+                            regularizer=reg if (dt == "float16" and len(shape) == 2) else None)
+        tvars.append(v)
+        v32 = tf.cast(v, tf.float32)
+        terms.append(tf.reduce_sum(v32 * tf.constant(A) + 0.5 * v32 * v32 * tf.constant(B)))
+    loss = tf.add_n(terms)
+    lr_name, lr_params = cfg["lr"]
+    train = opt_mod.optimize_loss(
+        loss=loss, optimizer=optimizer, optimizer_params=dict(cfg["optimizer_params"]),
+        learning_rate_decay_fn=lambda gs: getattr(pol, lr_name)(global_step=gs, **lr_params), dtype="mixed",
+        clip_gradients=cfg.get("clip_gradients"), larc_params=cfg.get("larc_params"),
+        loss_scaling=cfg["loss_scaling"], loss_scaling_params=dict(cfg["loss_scaling_params"]), on_horovod=False)
+    scaled = [g for g, _ in tf.train.Optimizer.LAST_COMPUTED]          # d(loss * scale) / d(variable), variable dtype
+    gs = tf.train.get_global_step()
+    masters = {v.name.split(":")[0]: v for v in tf.get_collection("FP32_MASTER_COPIES")}
+    scale_var = [v for v in tf.global_variables() if v.name.startswith("Loss_Optimization/Variable")]
+    # the scaler's variables in creation order: Backoff (iteration, last_overflow_iteration, scale), LogMax
+    # (iteration, scale, ...): the loss scale is the first float32 scalar among them
+    scale_var = [v for v in scale_var if v._var.dtype.is_floating_point and v._var.dim() == 0][0]
+    lr_t = getattr(pol, lr_name)(global_step=gs, **lr_params)
+    rec = {k: [] for k in ("scale_in", "lr", "global_step_after")}
+    for name, _, _, _ in TRAIN_OP_VARS:
+      rec["g/" + name], rec["w/" + name], rec["m/" + name] = [], [], []
+    with tf.Session() as sess:
+      for st in range(steps):
+        pre = sess.run({"scale": scale_var, "lr": lr_t, "g": scaled})
+        sess.run(train)
+        rec["scale_in"].append(pre["scale"])
+        rec["lr"].append(pre["lr"])
+        rec["global_step_after"].append(sess.run(gs))
+        for (name, _, dt, _), g, v in zip(TRAIN_OP_VARS, pre["g"], tvars):
+          rec["g/" + name].append(np.asarray(g, np.float32))
+          rec["w/" + name].append(np.asarray(sess.run(v), np.float32))
+          mk = [k for k in masters if k.endswith("/" + name)]
+          rec["m/" + name].append(np.asarray(sess.run(masters[mk[0]]), np.float32) if mk
+                                   else rec["w/" + name][-1])
+      out[case + "/scale_final"] = np.float32(sess.run(scale_var))
+    assert (len(masters) == 3), sorted(masters)
+    for k, v in rec.items():
+      out[case + "/" + k] = np.stack(v)
+    out[case + "/master_names"] = np.array(sorted(masters))
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op}
 
 
 def generate(name):
