@@ -1563,6 +1563,37 @@ def _ctc_greedy_decoder(inputs, sequence_length, merge_repeated=True):
   return [SparseTensor(parts[0], parts[1], parts[2])], parts[3]
 
 
+def _ctc_loss(labels, inputs, sequence_length, preprocess_collapse_repeated=False, ctc_merge_repeated=True,
+              ignore_longer_outputs_than_inputs=False, time_major=True):
+  """tf.nn.ctc_loss: labels SparseTensor [B, Lmax], inputs logits [T, B, V] (time major), blank = V - 1; per-sample
+  negative log likelihood [B]; with ignore_longer_outputs_than_inputs a sample whose label sequence cannot be
+  emitted in its input length gets loss 0 and no gradient (otherwise TensorFlow raises). Restated on
+  torch.nn.functional.ctc_loss (float64 log-softmax)."""
+  def f(idx, vals, shp, z, sl):
+    z = _t(z)
+    if not time_major:
+      z = z.transpose(0, 1)
+    T, B, V = z.shape
+    sl = _t(sl).long()
+    idx, vals = _t(idx).long(), _t(vals).long()
+    lab = [[] for _ in _range(B)]
+    for (b, j), c in zip(idx.tolist(), vals.tolist()):
+      lab[b].append(c)
+    lens = torch.tensor([len(l) for l in lab], dtype=torch.long)
+    L = int(max(1, lens.max()))
+    dense = torch.zeros((B, L), dtype=torch.long)
+    for b, l in enumerate(lab):
+      dense[b, :len(l)] = torch.tensor(l, dtype=torch.long)
+    need = torch.tensor([len(l) + sum(1 for a, c in zip(l, l[1:]) if a == c) for l in lab], dtype=torch.long)
+    feasible = need <= sl
+    if not ignore_longer_outputs_than_inputs and not _PYBOOL(feasible.all()):
+      raise ValueError("Not enough time for target transition sequence")
+    lp = torch.log_softmax(z.double(), dim=-1)
+    loss = torch.nn.functional.ctc_loss(lp, dense, sl, lens, blank=V - 1, reduction="none", zero_infinity=True)
+    return torch.where(feasible, loss, torch.zeros_like(loss)).to(z.dtype)
+  return Tensor(f, (labels.indices, labels.values, labels.dense_shape, inputs, sequence_length), name="ctc_loss")
+
+
 def sparse_tensor_to_dense(sp_input, default_value=0, validate_indices=True, name=None):
   def f(i, v, s):
     out = torch.full(_ishape(s), default_value, dtype=_t(v).dtype)
@@ -1578,7 +1609,7 @@ nn = types.SimpleNamespace(
     dropout=_dropout, sparse_softmax_cross_entropy_with_logits=_sparse_xent,
     softmax_cross_entropy_with_logits_v2=_soft_xent_v2, softmax_cross_entropy_with_logits=_soft_xent,
     moments=_moments, bias_add=_bias_add, l2_loss=lambda t, name=None: reduce_sum(square(t)) / 2.0,
-    ctc_greedy_decoder=_ctc_greedy_decoder, l2_normalize=lambda x, axis=None, epsilon=1e-12, name=None, dim=None:
+    ctc_greedy_decoder=_ctc_greedy_decoder, ctc_loss=_ctc_loss, l2_normalize=lambda x, axis=None, epsilon=1e-12, name=None, dim=None:
     x * rsqrt(maximum(reduce_sum(square(x), axis if axis is not None else dim, keepdims=True), epsilon)))
 
 

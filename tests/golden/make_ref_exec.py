@@ -198,6 +198,7 @@ def tdnn(seed=5, F=16, chans=(8, 16, 16, 24, 24), kern=(5, 7, 9, 11), T=48, B=3,
   tf.set_random_seed(seed)
   TDNNEncoder = imp("open_seq2seq.encoders.tdnn_encoder").TDNNEncoder
   Decoder = imp("open_seq2seq.decoders.fc_decoders").FullyConnectedCTCDecoder
+  CTCLoss = imp("open_seq2seq.losses.ctc_loss").CTCLoss
   DataLayer = sys.modules["open_seq2seq.data.speech2text.speech2text"].Speech2TextDataLayer
   rng = np.random.RandomState(seed)
   src_len = np.array(([T, T - 13, T // 2 - 3] * B)[:B], np.int32)
@@ -222,6 +223,16 @@ def tdnn(seed=5, F=16, chans=(8, 16, 16, 24, 24), kern=(5, 7, 9, 11), T=48, B=3,
     enc_out = encoder.encode({"source_tensors": [x_t, len_t]})
     dec_out = decoder.decode({"encoder_output": enc_out})
   logits = dec_out["logits"]                      # [T', B, V], time major
+  # CTCLoss (losses/ctc_loss.py:44-88: dense_to_sparse, tf.nn.ctc_loss(ignore_longer_outputs_than_inputs=True),
+  # mask_nans, mean over the WHOLE batch); the last sample's transcript is longer than its output: zero loss
+  out_frames = (src_len + 1) // 2
+  label_len = np.minimum(np.maximum(out_frames // 3, 2), 12).astype(np.int32)
+  label_len[-1] = out_frames[-1] + 3
+  labels = rng.randint(0, V - 1, size=(B, int(label_len.max()))).astype(np.int32)
+  with tf.variable_scope("ForwardPass"):
+    ctc = CTCLoss({}, None).compute_loss({"decoder_output": dec_out,
+                                          "target_tensors": [tf.constant(labels), tf.constant(label_len)]})
+  ctc_dlogits = tf.gradients(ctc, [logits])[0]
   R = rng.standard_normal(tuple(int(v) for v in logits.get_shape())).astype(np.float32)
   loss = tf.reduce_sum(logits * tf.constant(R))
   tvars = tf.trainable_variables()
@@ -234,14 +245,16 @@ def tdnn(seed=5, F=16, chans=(8, 16, 16, 24, 24), kern=(5, 7, 9, 11), T=48, B=3,
     grads = tf.gradients(loss, tvars)
     decoded = dec_out["outputs"][0]
     vals = sess.run({"enc": enc_out["outputs"], "len": enc_out["src_length"], "logits": logits, "loss": loss,
-                     "grads": grads, "vars": list(tvars), "ids": tf.sparse_tensor_to_dense(decoded, default_value=-1)})
+                     "grads": grads, "vars": list(tvars), "ids": tf.sparse_tensor_to_dense(decoded, default_value=-1),
+                     "ctc": ctc, "ctc_dlogits": ctc_dlogits})
     sess.run(tf.get_collection(tf.GraphKeys.UPDATE_OPS))
     mv = sess.run(list(moving))
   out = {"src_len": src_len, "T": np.int32(T), "out_len": vals["len"].astype(np.int32),
          "logits": vals["logits"], "R": R, "loss": np.float32(vals["loss"]), "greedy_ids": vals["ids"].astype(np.int32),
          "var_names": np.array(names), "seed": np.int32(seed), "chans": np.array(chans, np.int32),
          "kern": np.array(kern, np.int32), "F": np.int32(F), "V": np.int32(V),
-         "moving_names": np.array([v.name.split(":")[0] for v in moving])}
+         "moving_names": np.array([v.name.split(":")[0] for v in moving]), "labels": labels, "label_len": label_len,
+         "ctc_loss": np.float32(vals["ctc"]), "ctc_dlogits": vals["ctc_dlogits"].astype(np.float32)}
   for v, a in zip(moving, mv):
     out["moving/" + v.name.split(":")[0]] = a.astype(np.float32)
   if store_vars:

@@ -67,6 +67,27 @@ def test_oracle_reproduces_the_reference_tdnn(fixture):
 
 
 @pytest.mark.parametrize("fixture", ["tdnn", "tdnn_wide"])
+def test_oracle_ctc_loss_follows_the_reference_wrapper(fixture):
+  """CTCLoss._compute_loss (losses/ctc_loss.py:44-88) executed on the reference's logits: dense_to_sparse of the
+  label matrix, ignore_longer_outputs_than_inputs (the last sample's transcript does not fit: zero loss, zero
+  gradient), mask_nans, mean over the whole batch. tf.nn.ctc_loss itself is TensorFlow-internal — the stand-in and the
+  oracle both sit on torch's ctc_loss, so this pins the WRAPPER (what is averaged, what is zeroed), the values of the
+  recursion are pinned elsewhere (tests/test_oracle_ctc.py)."""
+  d, names = rx.load(fixture)
+  logits = torch.from_numpy(d["logits"]).requires_grad_(True)
+  out_len, labels, label_len = d["out_len"], d["labels"], d["label_len"]
+  assert label_len[-1] > out_len[-1]
+  # fc_ctc applies the FC layer itself: hand it the logits through an identity "layer"
+  lg, loss = tdnn.fc_ctc(logits.permute(1, 0, 2), out_len, torch.eye(logits.shape[2]), torch.zeros(logits.shape[2]),
+                         labels, label_len)
+  assert abs(float(loss.detach()) - float(d["ctc_loss"])) < 1e-5 * abs(float(d["ctc_loss"]))
+  loss.backward()
+  g = logits.grad.numpy()
+  assert rx.rel(g, d["ctc_dlogits"]) < 1e-5
+  assert np.abs(d["ctc_dlogits"][:, -1, :]).max() == 0.0, "the sample that does not fit contributes nothing"
+
+
+@pytest.mark.parametrize("fixture", ["tdnn", "tdnn_wide"])
 def test_oracle_moving_statistics_follow_the_reference(fixture):
   """UPDATE_OPS of tf.layers.batch_normalization on the 4-D (fused) path the reference forces with expand_dims
   (conv_blocks.py:139-156): moving = moving * momentum + batch * (1 - momentum), momentum 0.90, the batch variance

@@ -55,6 +55,15 @@ def test_device_tdnn_reproduces_the_reference_code(cuda):
   tape = Tape()
   e = enc.encode({"source_tensors": [x, lens], "tape": tape, "seed": 3})
   dd = dec.decode({"encoder_output": e, "tape": tape})
+  # CTCLoss on the device's logits vs the reference's CTCLoss on its own (one sample's transcript does not fit its
+  # output length: zero loss, as ignore_longer_outputs_than_inputs makes it) — then the surrogate gradient replaces
+  # the one the loss deposited
+  from openseq2seq_amd.losses.ctc_loss import CTCLoss
+  ctc = CTCLoss({"dtype": "mixed"}, None).compute_loss(
+      {"decoder_output": dd, "target_tensors": [torch.from_numpy(d["labels"]).to(cuda),
+                                                torch.from_numpy(d["label_len"]).to(cuda)]})
+  assert abs(float(ctc.cpu()[0]) - float(d["ctc_loss"])) < 2e-2 * abs(float(d["ctc_loss"])), (float(ctc.cpu()[0]),
+                                                                                             float(d["ctc_loss"]))
   Tq, B = d["logits"].shape[0], d["logits"].shape[1]
   dl = torch.zeros((B, Tq, dec.Vpad), dtype=torch.float32)
   dl[:, :, :V] = torch.from_numpy(d["R"]).permute(1, 0, 2)
@@ -104,7 +113,7 @@ def test_device_tdnn_reproduces_the_reference_code(cuda):
     for tf_name, tf_g in checkpoint.export_param(p.name, p.shape, p.kind, g, lo):
       ref = leaves[tf_name].grad.numpy()
       rx.check_gradient(d, tf_name, ref, 1e-4)
-      worst = max(worst, rx.check_gradient(d, tf_name, tf_g, 0.25))
+      worst = max(worst, rx.check_gradient(d, tf_name, tf_g, 0.3))
 
       def cosine(a, b):
         return float((a.astype(np.float64) * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
@@ -113,10 +122,12 @@ def test_device_tdnn_reproduces_the_reference_code(cuda):
       # vs the reference's fp32 numbers: measured worst 0.9797 / 0.204 on the first layer's gamma (nine BatchNorm
       # layers of 288 rows above it: a ReLU mask flipped by one bf16 ulp carries a full-size gradient error); vs the
       # bf16-storage emulation, whose masks flip with the device's: measured worst 0.9941 / 0.109 (first kernel)
-      assert cos > 0.97 and rx.rel(tf_g, ref) < 0.25, (tf_name, cos, rx.rel(tf_g, ref))
-      assert cos16 > 0.99 and rx.rel(tf_g, leaves16[tf_name].grad.numpy()) < 0.15, \
+      # (three runs: 0.9766 - 0.9797 and 0.9929 - 0.9941; the weight-gradient atomics differ in the last bit run to
+      # run and the masks amplify it — bounds with margin)
+      assert cos > 0.96 and rx.rel(tf_g, ref) < 0.3, (tf_name, cos, rx.rel(tf_g, ref))
+      assert cos16 > 0.985 and rx.rel(tf_g, leaves16[tf_name].grad.numpy()) < 0.2, \
           (tf_name, cos16, rx.rel(tf_g, leaves16[tf_name].grad.numpy()))
-  print("device vs the reference's code: encoder output %.2e, logits %.2e, argmax agreement %.3f, moving statistics "
+  print("device vs the reference's code: CTC loss %.4f vs %.4f, encoder output %.2e, logits %.2e, argmax agreement %.3f, moving statistics "
         "%.2e, worst gradient cosine %.4f (%s) [%.4f with bf16 storage emulated (%s)], worst projection error %.2e; "
-        "decoded %s" % (r_enc, r_log, agree, worst_mv, worst_cos[0], worst_cos[1], worst_cos16[0], worst_cos16[1],
+        "decoded %s" % (float(ctc.cpu()[0]), float(d["ctc_loss"]), r_enc, r_log, agree, worst_mv, worst_cos[0], worst_cos[1], worst_cos16[0], worst_cos16[1],
                         worst, type(ids).__name__))
