@@ -5,7 +5,12 @@ PARITY STATUS: the reference ships no test that pins conv / BN *values*
 ("parity unpinned"); TensorFlow is not installable here. The
 restatement follows the TF-1.13 semantics the reference calls into and is
 cross-checked against an independent direct-loop NumPy implementation
-(tests/test_oracle_cnn.py).
+(tests/test_oracle_cnn.py). Round 5: through oracle/tdnn.py these functions reproduce the
+reference's own conv_bn_actv / conv_bn_res_bn_actv, executed on a TF-primitive stand-in
+(tests/test_ref_exec_tdnn.py) — the padding and the BatchNorm conventions ("SAME" with the
+extra element at the end, biased variance to normalise, Bessel-corrected variance in the
+moving average of the 4-D fused path) are the stand-in's restatement of TF 1.13, written
+independently of this file.
 """
 import numpy as np
 import torch

@@ -14,7 +14,12 @@ optimizer path (open_seq2seq/optimizers).
 PARITY STATUS: the reference pins only two relations here
 (mp_wrapper_test.py:93-95 regulariser gradient 1e-8 under the MP wrapper;
 optimizers_test.py:56-80 iter_size algebra); both are reproduced in
-tests/test_oracle_optim.py. Everything else is "parity unpinned" (SURVEY §8c).
+tests/test_oracle_optim.py. Round 5: the lr policies, both loss scalers and RefOptimizer
+(mixed-precision wrapper + LARC / clipping + NovoGrad as written / Adam / Momentum) are pinned
+to the reference's OWN CODE, executed from its files on the TF-primitive stand-in
+oracle/ref_shim/tf1: tests/test_ref_exec_optim.py (policies 2e-6, Backoff trace exact),
+tests/test_ref_exec_train_op.py (28 steps with fp16 overflow: loss scale, skipped steps,
+master copies step by step).
 """
 import math
 

@@ -4,9 +4,13 @@ forward path with torch autograd supplying reference gradients.
 Follows open_seq2seq/encoders/tdnn_encoder.py:87-265 (mask before each conv,
 length bookkeeping, dense residuals, dropout per layer, no mask on the final
 output), parts/cnns/conv_blocks.py:61-232, decoders/fc_decoders.py:105-158 and
-losses/ctc_loss.py:44-88. PARITY STATUS: unpinned by the reference (no value
-tests for these) — the building blocks are cross-checked against
-independent implementations in tests/test_oracle_*.py.
+losses/ctc_loss.py:44-88. PARITY STATUS (round 5): pinned to the reference's OWN CODE —
+TDNNEncoder._encode, conv_bn_actv / conv_bn_res_bn_actv, FullyConnectedCTCDecoder and the
+CTCLoss wrapper executed from their files on the TF-primitive stand-in oracle/ref_shim/tf1
+(tests/golden/make_ref_exec.py); this module reproduces their outputs, lengths, logits,
+greedy ids (exact), BatchNorm moving statistics and all variable gradients (1e-6) on a
+Jasper-shaped stack (tests/test_ref_exec_tdnn.py). The CTC recursion itself (tf.nn.ctc_loss,
+TensorFlow-internal) stays pinned to torch.nn.functional.ctc_loss only.
 """
 import torch
 

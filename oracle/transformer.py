@@ -10,8 +10,13 @@ as the reference computes it:
   encoders/transformer_encoder.py:78-170, decoders/transformer_decoder.py:155-230
   losses/sequence_loss.py:257-309      PaddedCrossEntropyLossWithSmoothing
 Known-answer pins from the reference's own tests (parts/transformer/utils_test.py:27-61)
-are reproduced in tests/test_oracle_transformer.py; everything else is "parity
-unpinned" by the reference and cross-checked against torch.nn.functional.
+are reproduced in tests/test_oracle_transformer.py. PARITY STATUS (round 5): pinned to the
+reference's OWN CODE — TransformerEncoder / TransformerDecoder.decode_pass /
+PaddedCrossEntropyLossWithSmoothing executed from their files on the TF-primitive stand-in
+oracle/ref_shim/tf1 (tests/golden/make_ref_exec.py); this module reproduces their encoder
+output, logits, loss (1e-5) and all 65 variable gradients (1e-6) on the same inputs and
+variables (tests/test_ref_exec_transformer.py). The primitives under the reference (matmul,
+softmax, Dense ...) are restated there: "pinned modulo TF primitives".
 Dropout masks are passed in explicitly (keep masks), never drawn here.
 """
 import math
