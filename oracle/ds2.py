@@ -2,7 +2,11 @@
 (open_seq2seq/encoders/ds2_encoder.py:158-401) for the cuDNN-GRU configuration
 (example_configs/speech2text/ds2_large_8gpus.py:53-72): conv2d(SAME, TF asymmetric
 padding) + BN + ReLU, bidirectional multi-layer cuDNN-form GRU without sequence lengths,
-dense + ReLU (+ dropout mask). PARITY STATUS: unpinned by the reference."""
+dense + ReLU (+ dropout mask). PARITY STATUS (round 5): the encoder's WIRING is pinned to the
+reference's own code — DeepSpeech2Encoder._encode executed from its file on the TF-primitive stand-in
+oracle/ref_shim/tf1 (bidirectional and unidirectional + row_conv cases): outputs 1e-5, all gradients 1e-6
+(tests/test_ref_exec_ds2.py). The cuDNN GRU cell itself is a TensorFlow library object (torch.nn.GRU on
+both sides): its equations stay "parity unpinned" (cross-checked in tests/test_oracle_rnn.py)."""
 import torch
 import torch.nn.functional as F
 

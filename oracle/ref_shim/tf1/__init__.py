@@ -1594,6 +1594,23 @@ def _ctc_loss(labels, inputs, sequence_length, preprocess_collapse_repeated=Fals
   return Tensor(f, (labels.indices, labels.values, labels.dense_shape, inputs, sequence_length), name="ctc_loss")
 
 
+def _depthwise_conv2d(input, filter, strides, padding, rate=None, name=None, data_format=None):   # noqa: A002
+  """tf.nn.depthwise_conv2d: filter [KH, KW, Cin, mult], output channel = c * mult + m."""
+  nhwc = data_format in (None, "NHWC")
+
+  def f(x, w):
+    x, w = _t(x), _t(w)
+    w = w.to(x.dtype)
+    if nhwc:
+      x = x.permute(0, 3, 1, 2)
+    kh, kw, cin, mult = w.shape
+    wt = w.permute(2, 3, 0, 1).reshape(cin * mult, 1, kh, kw)
+    st = strides[1:3] if nhwc else strides[2:4]
+    y = _conv_nd(x, wt, [int(v) for v in st], padding, [1, 1] if rate is None else list(rate), 2, groups=cin)
+    return y.permute(0, 2, 3, 1) if nhwc else y
+  return Tensor(f, (input, filter), name="depthwise_conv2d")
+
+
 def sparse_tensor_to_dense(sp_input, default_value=0, validate_indices=True, name=None):
   def f(i, v, s):
     out = torch.full(_ishape(s), default_value, dtype=_t(v).dtype)
@@ -1609,7 +1626,7 @@ nn = types.SimpleNamespace(
     dropout=_dropout, sparse_softmax_cross_entropy_with_logits=_sparse_xent,
     softmax_cross_entropy_with_logits_v2=_soft_xent_v2, softmax_cross_entropy_with_logits=_soft_xent,
     moments=_moments, bias_add=_bias_add, l2_loss=lambda t, name=None: reduce_sum(square(t)) / 2.0,
-    ctc_greedy_decoder=_ctc_greedy_decoder, ctc_loss=_ctc_loss, l2_normalize=lambda x, axis=None, epsilon=1e-12, name=None, dim=None:
+    ctc_greedy_decoder=_ctc_greedy_decoder, ctc_loss=_ctc_loss, depthwise_conv2d=None, l2_normalize=lambda x, axis=None, epsilon=1e-12, name=None, dim=None:
     x * rsqrt(maximum(reduce_sum(square(x), axis if axis is not None else dim, keepdims=True), epsilon)))
 
 
@@ -1911,6 +1928,54 @@ layers = types.SimpleNamespace(
     dropout=lambda inputs, rate=0.5, noise_shape=None, seed=None, training=False, name=None:
     (_dropout(inputs, keep_prob=1.0 - rate, noise_shape=noise_shape) if training else identity(inputs)))
 
+class _CudnnRNN(Layer):
+  """tf.contrib.cudnn_rnn.CudnnGRU / CudnnLSTM: time-major input [T, B, I], NO sequence lengths (the whole padded
+  length is run), num_layers stacked, optionally bidirectional with the two directions concatenated after every
+  layer. Built on torch.nn.GRU / LSTM, which implement the same cuDNN cell equations; the parameters are exposed as
+  variables under torch's names (TensorFlow keeps one opaque buffer)."""
+  KIND = None
+
+  def __init__(self, num_layers, num_units, input_mode="linear_input", direction="unidirectional", dropout=0.0,
+               seed=None, dtype=None, kernel_initializer=None, bias_initializer=None, name=None):
+    super(_CudnnRNN, self).__init__(name=name)
+    self.num_layers, self.num_units = int(num_layers), int(num_units)
+    self.bidir = direction == "bidirectional"
+    self.dropout = float(dropout)
+
+  @property
+  def name(self):
+    return self._given_name or ("cudnn_" + self.KIND.lower())
+
+  def build(self, input_shape):
+    cls = {"GRU": torch.nn.GRU, "LSTM": torch.nn.LSTM}[self.KIND]
+    self._mod = cls(int(input_shape[-1]), self.num_units, num_layers=self.num_layers, bidirectional=self.bidir)
+    self._pnames = [n for n, _ in self._mod.named_parameters()]
+    k = 1.0 / math.sqrt(self.num_units)
+    self._pvars = [self.add_variable(n, list(p.shape), dtype=float32,
+                                     initializer=random_uniform_initializer(-k, k))
+                   for n, p in self._mod.named_parameters()]
+    self.built = True
+
+  def call(self, inputs, initial_state=None, training=True):
+    if self.dropout != 0.0:
+      raise NotImplementedError("inter-layer dropout of the cuDNN RNN is not restated (use dropout 0)")
+    names, mod = self._pnames, self._mod
+
+    def f(x, ps):
+      out, state = torch.func.functional_call(mod, {n: _t(p) for n, p in zip(names, ps)}, (_t(x),))
+      return out
+    out = Tensor(f, (inputs, list(self._pvars)), name=self.name)
+    return out, None
+
+
+class _CudnnGRU(_CudnnRNN):
+  KIND = "GRU"
+
+
+class _CudnnLSTM(_CudnnRNN):
+  KIND = "LSTM"
+
+
 keras = types.SimpleNamespace(
     initializers=types.SimpleNamespace(Zeros=zeros_initializer, Ones=ones_initializer,
                                        glorot_uniform=glorot_uniform_initializer,
@@ -2002,6 +2067,9 @@ contrib = types.SimpleNamespace(
                                      factor, mode.lower(), "uniform" if uniform else "normal")),
     opt=types.SimpleNamespace(), seq2seq=types.SimpleNamespace(), rnn=types.SimpleNamespace(),
     cudnn_rnn=types.SimpleNamespace(), framework=types.SimpleNamespace(nest=None))
+
+contrib.cudnn_rnn = types.SimpleNamespace(CudnnGRU=_CudnnGRU, CudnnLSTM=_CudnnLSTM)
+nn.depthwise_conv2d = _depthwise_conv2d
 
 losses = types.SimpleNamespace(
     get_regularization_losses=lambda scope=None: get_collection(GraphKeys.REGULARIZATION_LOSSES, scope),
@@ -2285,6 +2353,12 @@ def install():
   sub("tensorflow.python.util")
   sub("tensorflow.python.util.nest", flatten=_flatten, map_structure=lambda f, *s: _map_structure(f, *s),
       is_sequence=lambda x: isinstance(x, (list, tuple, dict)))
+  sub("tensorflow.contrib")
+  sub("tensorflow.contrib.cudnn_rnn", CudnnGRU=_CudnnGRU, CudnnLSTM=_CudnnLSTM)
+  sub("tensorflow.contrib.cudnn_rnn.python")
+  sub("tensorflow.contrib.cudnn_rnn.python.ops")
+  sub("tensorflow.contrib.cudnn_rnn.python.ops.cudnn_rnn_ops", CUDNN_RNN_UNIDIRECTION="unidirectional",
+      CUDNN_RNN_BIDIRECTION="bidirectional")
   sub("tensorflow.python.layers")
   sub("tensorflow.python.layers.base", Layer=Layer)
   sub("tensorflow.python.layers.core", Dense=Dense)

@@ -442,8 +442,59 @@ def train_op(steps=28):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# DeepSpeech2: DeepSpeech2Encoder._encode (encoders/ds2_encoder.py:158-401) — conv2d + BatchNorm + ReLU blocks
+# through conv_bn_actv('conv2d'), the [B, T, F, C] -> [T, B, F * C] hand-over to the cuDNN GRU (run over the whole
+# padded length: no sequence lengths), row convolution, dense + ReLU. Two cases: bidirectional (ds2_large_8gpus.py)
+# and unidirectional + row_conv. The cuDNN RNN is a TensorFlow library object: the stand-in builds it on
+# torch.nn.GRU (same cell equations) and exposes its parameters under torch's names.
+# ---------------------------------------------------------------------------------------------------------
+DS2_CASES = {
+    "bidir": dict(unidir=False, row_conv=False, layers=2),
+    "unidir_rowconv": dict(unidir=True, row_conv=True, layers=1),
+}
+DS2_CONV = [{"kernel_size": [5, 7], "stride": [2, 2], "num_channels": 6, "padding": "SAME"},
+            {"kernel_size": [5, 5], "stride": [1, 2], "num_channels": 8, "padding": "SAME"}]
+
+
+def ds2(seed=17, B=3, T=37, F=20, H=12, NH=16):
+  out = {"dims": np.array([B, T, F, H, NH], np.int32)}
+  for case, cfg in DS2_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    tf.set_random_seed(seed)
+    Enc = imp("open_seq2seq.encoders.ds2_encoder").DeepSpeech2Encoder
+    rng = np.random.RandomState(seed)
+    src_len = np.array([T, T - 9, T // 2], np.int32)
+    x = tdnn_input(seed, src_len, T, F)
+    params = dict(dropout_keep_prob=1.0, conv_layers=DS2_CONV, activation_fn=tf.nn.relu, num_rnn_layers=cfg["layers"],
+                  row_conv=cfg["row_conv"], row_conv_width=4, n_hidden=NH, use_cudnn_rnn=True, rnn_cell_dim=H,
+                  rnn_type="cudnn_gru", rnn_unidirectional=cfg["unidir"], bn_momentum=0.99, bn_epsilon=1e-3,
+                  dtype=tf.float32)
+    with tf.variable_scope("ForwardPass"):
+      enc = Enc(params, None, name="ds2_encoder", mode="train")
+      res = enc.encode({"source_tensors": [tf.constant(x), tf.constant(src_len)]})
+    outputs = res["outputs"]
+    R = rng.standard_normal(tuple(int(v) for v in outputs.get_shape())).astype(np.float32)
+    loss = tf.reduce_sum(outputs * tf.constant(R))
+    tvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in tvars]
+    with tf.Session() as sess:
+      for n, v in zip(names, tvars):
+        if v._var.dim() == 1 and "cudnn" not in n:       # BatchNorm / bias vectors away from 1 / 0
+          v.load(seeded_array(n, tuple(v._var.shape), seed))
+      vals = sess.run({"out": outputs, "len": res["src_length"], "grads": tf.gradients(loss, tvars),
+                       "vars": list(tvars)})
+    out.update({case + "/src_len": src_len, case + "/out": vals["out"], case + "/out_len": vals["len"].astype(np.int32),
+                case + "/R": R, case + "/var_names": np.array(names), case + "/seed": np.int32(seed)})
+    for n, v, g in zip(names, vals["vars"], vals["grads"]):
+      out["%s/var/%s" % (case, n)] = v.astype(np.float32)
+      out["%s/grad/%s" % (case, n)] = g.astype(np.float32)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2}
 
 
 def generate(name):
