@@ -1,7 +1,9 @@
 """Convergence test on the toy reversal corpus with the en-de-nmt-small architecture
 (BASELINE.json configs[0]) — the reference's own acceptance test for its RNN NMT path is of
-this kind (toy reversal task, BLEU > 0.9: SURVEY.md 4 / 8c). 600 steps of the full config
-(400 reach BLEU 0.89-0.95 depending on the initialisation draw)
+this kind (toy reversal task, BLEU > 0.9: SURVEY.md 4 / 8c). 1000 steps of the full config with a
+fixed random_seed (the config leaves it to the clock, as the reference's does: 400 steps reach BLEU
+0.89-0.95 and 600 steps 0.86-0.97 depending on the initialisation draw — one in-suite run of round 5
+drew 0.86)
 through run.py's train loop, then greedy decoding of the dev set."""
 import os
 import sys
@@ -23,10 +25,12 @@ def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch):
               data_path="toy_text_data", seed=0)
   cfg = os.path.join(REPO, "example_configs/text2text/toy-reversal/nmt-small-reversal.py")
   args, base_config, base_model, config_module = get_base_config(
-      ["--config_file=" + cfg, "--mode=train_eval", "--max_steps=600", "--print_loss_steps=100"])
+      ["--config_file=" + cfg, "--mode=train_eval", "--max_steps=1000", "--print_loss_steps=100"])
+  base_config["random_seed"] = 7        # (command-line overrides exist only for keys the config file has)
   model = create_model(args, base_config, config_module, base_model, None)
   run.train(model, args)
   res = run.run_eval(model, model.eval_model, 0)
+  print("nmt-small reversal: %r" % (res,))
   assert res["samples"] == 256
   assert res["bleu"] > 0.9, res
   # infer mode of the same config = BeamSearchRNNDecoderWithAttention (beam 10, GNMT length
