@@ -134,6 +134,28 @@ class TensorShape(object):
   def is_fully_defined(self):
     return self._dims is not None and all(d is not None for d in self._dims)
 
+  def is_compatible_with(self, other):
+    other = other if isinstance(other, TensorShape) else TensorShape(other)
+    if self._dims is None or other._dims is None:
+      return True
+    return len(self._dims) == len(other._dims) and all(a is None or b is None or int(a) == int(b)
+                                                       for a, b in zip(self._dims, other._dims))
+
+  def assert_is_compatible_with(self, other):
+    if not self.is_compatible_with(other):
+      raise ValueError("Shapes %s and %s are incompatible" % (self, other))
+
+  def merge_with(self, other):
+    self.assert_is_compatible_with(other)
+    return self
+
+  def concatenate(self, other):
+    other = other if isinstance(other, TensorShape) else TensorShape(other)
+    return TensorShape(list(self._dims) + list(other._dims))
+
+  def with_rank_at_least(self, rank):
+    return self
+
   def __len__(self):
     return len(self._dims)
 
@@ -270,6 +292,7 @@ class Tensor(object):
     return Tensor(f, (self, idx), name="strided_slice")
 
   __array_priority__ = 100
+  __array_ufunc__ = None          # numpy scalars / arrays defer to the reflected operators above
 
 
 def _binop(name, f):
@@ -1653,6 +1676,10 @@ class Layer(object):
   def name(self):
     return self._given_name or _snake(self.__class__.__name__)
 
+  @property
+  def _base_name(self):
+    return self.name
+
   def build(self, input_shape):
     self.built = True
 
@@ -1745,7 +1772,7 @@ class _Conv(Layer):
                dilation_rate=1, activation=None, use_bias=True, kernel_initializer=None, bias_initializer=None,
                kernel_regularizer=None, bias_regularizer=None, activity_regularizer=None, kernel_constraint=None,
                bias_constraint=None, trainable=True, name=None, **kwargs):
-    super(_Conv, self).__init__(trainable=trainable, name=name)
+    super(_Conv, self).__init__(trainable=trainable, name=name, dtype=kwargs.get("dtype"))
     tup = lambda v: _tuple(int(a) for a in (v if isinstance(v, (list, _tuple)) else [v] * self.ND))   # noqa: E731
     self.filters, self.k, self.s, self.d = int(filters), tup(kernel_size), tup(strides), tup(dilation_rate)
     self.padding, self.data_format, self.activation, self.use_bias = padding, data_format, activation, use_bias
@@ -2311,6 +2338,24 @@ app = types.SimpleNamespace(flags=types.SimpleNamespace(FLAGS=types.SimpleNamesp
 test = types.SimpleNamespace(TestCase=object, main=lambda: None, is_gpu_available=lambda *a, **k: False)
 gfile = types.SimpleNamespace()
 
+softmax, log_softmax, relu, dropout = _softmax, _log_softmax, nn.relu, _dropout
+assert_equal = lambda *a, **k: no_op()                   # noqa: E731  (tf.python.ops.check_ops)
+assert_positive = assert_greater = assert_less_equal = assert_rank = assert_equal
+with_same_shape = lambda old, new: new                   # noqa: E731  (contrib.framework tensor_util)
+
+from . import rnn as _rnn                                # noqa: E402  (the recurrent part of the stand-in)
+nn.rnn_cell = types.SimpleNamespace(
+    RNNCell=_rnn.RNNCell, LSTMCell=_rnn.LSTMCell, BasicLSTMCell=_rnn.BasicLSTMCell, MultiRNNCell=_rnn.MultiRNNCell,
+    LSTMStateTuple=_rnn.LSTMStateTuple, ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper)
+nn.dynamic_rnn, nn.bidirectional_dynamic_rnn = _rnn.dynamic_rnn, _rnn.bidirectional_dynamic_rnn
+nn.embedding_lookup = _rnn.embedding_lookup
+contrib.rnn = types.SimpleNamespace(MultiRNNCell=_rnn.MultiRNNCell, ResidualWrapper=_rnn.ResidualWrapper,
+                                    LSTMStateTuple=_rnn.LSTMStateTuple, DropoutWrapper=_rnn.DropoutWrapper,
+                                    LSTMCell=_rnn.LSTMCell, BasicLSTMCell=_rnn.BasicLSTMCell, RNNCell=_rnn.RNNCell)
+contrib.seq2seq = types.SimpleNamespace(
+    Decoder=_rnn.Decoder, Helper=_rnn.Helper, TrainingHelper=_rnn.TrainingHelper, BasicDecoder=_rnn.BasicDecoder,
+    BasicDecoderOutput=_rnn.BasicDecoderOutput, dynamic_decode=_rnn.dynamic_decode)
+
 slice = slice_          # noqa: A001  (the TF names; Python's own slice / range are not used below this line)
 range = range_          # noqa: A001
 tuple = tuple_          # noqa: A001
@@ -2335,24 +2380,39 @@ def install():
   sub("tensorflow.python.framework.ops", convert_to_tensor=convert_to_tensor, Tensor=Tensor,
       IndexedSlices=IndexedSlices, GraphKeys=GraphKeys, colocate_with=colocate_with,
       control_dependencies=control_dependencies, name_scope=name_scope, get_default_graph=get_default_graph)
-  sub("tensorflow.python.framework.dtypes", float32=float32, float16=float16, int32=int32, int64=int64)
+  sub("tensorflow.python.framework.dtypes", float32=float32, float16=float16, int32=int32, int64=int64, bool=bool,
+      as_dtype=as_dtype, DType=DType)
   sub("tensorflow.python.ops")
-  sub("tensorflow.python.ops.control_flow_ops", with_dependencies=lambda deps, out, name=None: _with_deps(deps, out),
-      group=group, cond=cond, no_op=no_op)
-  sub("tensorflow.python.ops.array_ops", identity=identity, reshape=reshape, zeros_like=zeros_like,
-      ones_like=ones_like, shape=shape, where=where, concat=concat, expand_dims=expand_dims)
-  sub("tensorflow.python.ops.math_ops", cast=cast, reduce_sum=reduce_sum, sqrt=sqrt, square=square, add=add,
-      multiply=multiply, maximum=maximum, minimum=minimum, equal=equal)
-  sub("tensorflow.python.ops.state_ops", assign=assign, assign_add=assign_add, assign_sub=assign_sub)
-  sub("tensorflow.python.ops.init_ops", Zeros=zeros_initializer, Ones=ones_initializer)
   sub("tensorflow.python.training")
   sub("tensorflow.python.training.optimizer", Optimizer=Optimizer)
   sub("tensorflow.python.training.training_ops")
   sub("tensorflow.python.client")
   sub("tensorflow.python.client.device_lib", list_local_devices=lambda: [])
   sub("tensorflow.python.util")
-  sub("tensorflow.python.util.nest", flatten=_flatten, map_structure=lambda f, *s: _map_structure(f, *s),
-      is_sequence=lambda x: isinstance(x, (list, tuple, dict)))
+  sub("tensorflow.python.util.nest", flatten=_rnn.flatten, map_structure=_rnn.map_structure,
+      is_sequence=_rnn.is_sequence, pack_sequence_as=_rnn.pack_sequence_as,
+      assert_same_structure=_rnn.assert_same_structure)
+  for opsmod in ("array_ops", "check_ops", "clip_ops", "functional_ops", "init_ops", "math_ops", "nn_ops",
+                 "random_ops", "control_flow_ops", "state_ops"):
+    mods["tensorflow.python.ops." + opsmod] = me         # one namespace: every op lives in this module
+  me.with_dependencies = lambda deps, out, name=None: _with_deps(deps, out)
+  me.Zeros, me.Ones = zeros_initializer, ones_initializer
+  sub("tensorflow.python.ops.variable_scope", get_variable=get_variable, variable_scope=variable_scope,
+      get_variable_scope=get_variable_scope, AUTO_REUSE=AUTO_REUSE, VariableScope=VariableScope)
+  sub("tensorflow.python.ops.rnn_cell_impl", RNNCell=_rnn.RNNCell, LayerRNNCell=_rnn.RNNCell,
+      assert_like_rnncell=_rnn.assert_like_rnncell, _zero_state_tensors=_rnn._zero_state_tensors,
+      LSTMStateTuple=_rnn.LSTMStateTuple, LSTMCell=_rnn.LSTMCell, MultiRNNCell=_rnn.MultiRNNCell)
+  sub("tensorflow.python.ops.rnn_cell", ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper,
+      LSTMCell=_rnn.LSTMCell, MultiRNNCell=_rnn.MultiRNNCell, RNNCell=_rnn.RNNCell)
+  sub("tensorflow.python.ops.tensor_array_ops", TensorArray=_rnn.TensorArray)
+  sub("tensorflow.python.framework.tensor_shape", TensorShape=TensorShape, Dimension=Dimension)
+  sub("tensorflow.python.layers.convolutional", Conv1D=Conv1D, Conv2D=Conv2D)
+  sub("tensorflow.contrib.framework")
+  sub("tensorflow.contrib.framework.python")
+  sub("tensorflow.contrib.framework.python.framework")
+  sub("tensorflow.contrib.framework.python.framework.tensor_util", with_same_shape=with_same_shape)
+  sub("tensorflow.contrib.rnn", **vars(contrib.rnn))
+  sub("tensorflow.contrib.seq2seq", **vars(contrib.seq2seq))
   sub("tensorflow.contrib")
   sub("tensorflow.contrib.cudnn_rnn", CudnnGRU=_CudnnGRU, CudnnLSTM=_CudnnLSTM)
   sub("tensorflow.contrib.cudnn_rnn.python")

@@ -53,6 +53,17 @@ def _install():
   dl = types.ModuleType("open_seq2seq.data.speech2text.speech2text")
   dl.Speech2TextDataLayer = type("Speech2TextDataLayer", (), {})
   sys.modules[dl.__name__] = dl
+  for name, attrs in (("open_seq2seq.parts.rnns.rnn_beam_search_decoder", ["BeamSearchDecoder"]),
+                      ("open_seq2seq.parts.rnns.weight_drop", ["WeightDropLayerNormBasicLSTMCell"]),
+                      ("open_seq2seq.parts.rnns.slstm", ["BasicSLSTMCell"]),
+                      ("open_seq2seq.parts.rnns.glstm", ["GLSTMCell"]),
+                      ("open_seq2seq.parts.rnns.zoneout", ["ZoneoutWrapper"])):
+    # imported by rnn_decoders.py / parts/rnns/utils.py at module level, not used by the configurations executed
+    # here; their own imports reach deep into TensorFlow's private modules
+    m = types.ModuleType(name)
+    for a in attrs:
+      setattr(m, a, type(a, (), {}))
+    sys.modules[name] = m
   import collections
   import collections.abc
   if not hasattr(collections, "Sequence"):      # the reference predates Python 3.10 (optimizers.py:441)
@@ -493,8 +504,73 @@ def ds2(seed=17, B=3, T=37, F=20, H=12, NH=16):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# RNN NMT decoder: RNNDecoderWithAttention._decode (decoders/rnn_decoders.py:147-321) in train mode — decoder
+# embedding, single_cell (parts/rnns/utils.py), BahdanauAttention(normalize=True) / AttentionWrapper
+# (parts/rnns/attention_wrapper.py), GNMTAttentionMultiCell + gnmt_residual_fn (parts/rnns/gnmt.py), the output
+# projection, TrainingHelper / BasicDecoder / dynamic_decode(impute_finished=True) — followed by BasicSequenceLoss
+# (losses/sequence_loss.py:10-114). The cell classes, dynamic_decode and the helpers are TensorFlow library code
+# (restated in oracle/ref_shim/tf1/rnn.py: one traced step, replayed); everything else runs from the reference.
+# ---------------------------------------------------------------------------------------------------------
+NMT_CASES = {
+    "gnmt_v2": dict(attention_type="gnmt_v2", skip=False, layers=2),
+    "gnmt": dict(attention_type="gnmt", skip=False, layers=2),
+    "gnmt_v2_skip": dict(attention_type="gnmt_v2", skip=True, layers=3),
+}
+NMT_DIMS = dict(B=3, S=7, T=6, V=24, E=12, H=14, M=16, U=10)
+
+
+def nmt_decoder(seed=41):
+  out = {"dims": np.array([NMT_DIMS[k] for k in ("B", "S", "T", "V", "E", "H", "M", "U")], np.int32)}
+  D = NMT_DIMS
+  for case, cfg in NMT_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    tf.set_random_seed(seed)
+    Dec = imp("open_seq2seq.decoders.rnn_decoders").RNNDecoderWithAttention
+    Loss = imp("open_seq2seq.losses.sequence_loss").BasicSequenceLoss
+    rng = np.random.RandomState(seed)
+    B, S, T, V, E, H, M, U = [D[k] for k in ("B", "S", "T", "V", "E", "H", "M", "U")]
+    src_len = np.array([7, 4, 5], np.int32)
+    tgt_len = np.array([6, 3, 5], np.int32)
+    tgt = rng.randint(3, V, size=(B, T)).astype(np.int32)
+    tgt[:, 0] = 1
+    for b in range(B):
+      tgt[b, tgt_len[b] - 1] = 2
+      tgt[b, tgt_len[b]:] = 0
+    enc = rng.standard_normal((B, S, M)).astype(np.float32)
+    params = dict(GO_SYMBOL=1, END_SYMBOL=2, tgt_vocab_size=V, tgt_emb_size=E, attention_layer_size=U,
+                  attention_type=cfg["attention_type"], core_cell=tf.nn.rnn_cell.LSTMCell,
+                  core_cell_params={"num_units": H, "forget_bias": 1.0}, decoder_layers=cfg["layers"],
+                  decoder_use_skip_connections=cfg["skip"], batch_size=B, decoder_dp_input_keep_prob=1.0,
+                  decoder_dp_output_keep_prob=1.0, dtype=tf.float32)
+    with tf.variable_scope("ForwardPass"):
+      enc_var = tf.get_variable("encoder_outputs", initializer=tf.constant(enc))
+      dec = Dec(params, None, mode="train")
+      res = dec.decode({"encoder_output": {"outputs": enc_var, "src_lengths": tf.constant(src_len)},
+                        "target_tensors": [tf.constant(tgt), tf.constant(tgt_len)]})
+      loss = Loss(dict(tgt_vocab_size=V, batch_size=B, offset_target_by_one=True, average_across_timestep=False,
+                       do_mask=True, dtype=tf.float32), None).compute_loss(
+          {"decoder_output": res, "target_tensors": [tf.constant(tgt), tf.constant(tgt_len)]})
+    tvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in tvars]
+    with tf.Session() as sess:
+      for n, v in zip(names, tvars):
+        if v._var.dim() == 1:                 # biases / attention vectors away from their 0 / constant initial values
+          v.load(_np(v._var) + 0.2 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+      vals = sess.run({"logits": res["logits"], "loss": loss, "lens": res["final_sequence_lengths"],
+                       "grads": tf.gradients(loss, tvars), "vars": list(tvars)})
+    out.update({case + "/src_len": src_len, case + "/tgt_len": tgt_len, case + "/tgt": tgt,
+                case + "/logits": vals["logits"], case + "/loss": np.float32(vals["loss"]),
+                case + "/final_sequence_lengths": vals["lens"].astype(np.int32), case + "/var_names": np.array(names)})
+    for n, v, g in zip(names, vals["vars"], vals["grads"]):
+      out["%s/var/%s" % (case, n)] = v.astype(np.float32)
+      out["%s/grad/%s" % (case, n)] = g.astype(np.float32)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder}
 
 
 def generate(name):
