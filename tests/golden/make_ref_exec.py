@@ -569,8 +569,53 @@ def nmt_decoder(seed=41):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# RNN NMT encoders: BidirectionalRNNEncoderWithEmbedding and GNMTLikeEncoderWithEmbedding
+# (encoders/rnn_encoders.py:221-305, 380-470): embedding, single_cell stacks, bidirectional_dynamic_rnn /
+# dynamic_rnn with sequence lengths, ResidualWrapper on the upper unidirectional layers.
+# ---------------------------------------------------------------------------------------------------------
+NMT_ENC_CASES = {"bidir": dict(cls="BidirectionalRNNEncoderWithEmbedding", layers=2),
+                 "gnmt_like": dict(cls="GNMTLikeEncoderWithEmbedding", layers=3)}
+
+
+def nmt_encoder(seed=43, B=3, S=7, V=20, E=10, H=12):
+  out = {"dims": np.array([B, S, V, E, H], np.int32)}
+  for case, cfg in NMT_ENC_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    tf.set_random_seed(seed)
+    Enc = getattr(imp("open_seq2seq.encoders.rnn_encoders"), cfg["cls"])
+    rng = np.random.RandomState(seed)
+    src_len = np.array([7, 3, 5], np.int32)
+    src = rng.randint(3, V, size=(B, S)).astype(np.int32)
+    for b in range(B):
+      src[b, src_len[b]:] = 0
+    params = dict(src_vocab_size=V, src_emb_size=E, core_cell=tf.nn.rnn_cell.LSTMCell,
+                  core_cell_params={"num_units": H, "forget_bias": 1.0}, encoder_layers=cfg["layers"],
+                  encoder_use_skip_connections=False, encoder_dp_input_keep_prob=1.0,
+                  encoder_dp_output_keep_prob=1.0, dtype=tf.float32)
+    with tf.variable_scope("ForwardPass"):
+      res = Enc(params, None, mode="train").encode({"source_tensors": [tf.constant(src), tf.constant(src_len)]})
+    outputs = res["outputs"]
+    R = rng.standard_normal(tuple(int(v) for v in outputs.get_shape())).astype(np.float32)
+    loss = tf.reduce_sum(outputs * tf.constant(R))
+    tvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in tvars]
+    with tf.Session() as sess:
+      for n, v in zip(names, tvars):
+        if v._var.dim() == 1:
+          v.load(0.2 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+      vals = sess.run({"out": outputs, "grads": tf.gradients(loss, tvars), "vars": list(tvars)})
+    out.update({case + "/src": src, case + "/src_len": src_len, case + "/out": vals["out"], case + "/R": R,
+                case + "/var_names": np.array(names)})
+    for n, v, g in zip(names, vals["vars"], vals["grads"]):
+      out["%s/var/%s" % (case, n)] = v.astype(np.float32)
+      out["%s/grad/%s" % (case, n)] = g.astype(np.float32)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder}
 
 
 def generate(name):

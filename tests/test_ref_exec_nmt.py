@@ -67,8 +67,46 @@ def test_oracle_reproduces_the_reference_nmt_decoder(case):
   print("%s: worst gradient rel-L2 vs the reference's code %.2e" % (case, worst))
 
 
+@pytest.mark.parametrize("case", sorted(rx.gen.NMT_ENC_CASES))
+def test_oracle_reproduces_the_reference_nmt_encoders(case):
+  """BidirectionalRNNEncoderWithEmbedding / GNMTLikeEncoderWithEmbedding (encoders/rnn_encoders.py:221-305, 380-470)
+  executed from the reference's file: embedding lookup, stacks of single_cell LSTM cells, bidirectional_dynamic_rnn with
+  sequence lengths (outputs zero past each length, the backward direction reversed within each length), the
+  unidirectional upper layers with ResidualWrapper from the second one on. Outputs 1e-5, gradients 1e-4."""
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_nmt_encoder.npz")))
+  B, S, V, E, H = [int(v) for v in d["dims"]]
+  names = [str(n) for n in d[case + "/var_names"]]
+  leaf = {n: torch.from_numpy(d["%s/var/%s" % (case, n)].copy()).requires_grad_(True) for n in names}
+
+  def lyr(prefix, cin):
+    k = leaf[prefix + "/kernel"].t()                      # [4H, In + H]
+    return {"wx": k[:, :cin], "wh": k[:, cin:], "b": leaf[prefix + "/bias"]}
+  ids, lens = torch.from_numpy(d[case + "/src"]), torch.from_numpy(d[case + "/src_len"])
+  if case == "bidir":
+    sc = "ForwardPass/bidir_rnn_encoder_with_emb/"
+    P = {"emb": leaf[sc + "EncoderEmbeddingMatrix"]}
+    for key in ("fw", "bw"):
+      P[key] = [lyr(sc + "bidirectional_rnn/%s/multi_rnn_cell/cell_%d/lstm_cell" % (key, i), E if i == 0 else H)
+                for i in range(2)]
+    out = onmt.encoder(P, ids, lens)
+  else:
+    sc = "ForwardPass/gnmt_encoder_with_emb/"
+    P = {"emb": leaf[sc + "EncoderEmbeddingMatrix"],
+         "l1fw": lyr(sc + "bidirectional_rnn/fw/lstm_cell", E), "l1bw": lyr(sc + "bidirectional_rnn/bw/lstm_cell", E),
+         "uni": [lyr(sc + "rnn/multi_rnn_cell/cell_%d/lstm_cell" % i, 2 * H if i == 0 else H) for i in range(2)]}
+    out = onmt.gnmt_like_encoder(P, ids, lens)
+  assert rx.rel(out.detach().numpy(), d[case + "/out"]) < 1e-5
+  (out * torch.from_numpy(d[case + "/R"])).sum().backward()
+  worst = 0.0
+  for n in names:
+    r = rx.rel(leaf[n].grad.numpy(), d["%s/grad/%s" % (case, n)])
+    worst = max(worst, r)
+    assert r < 1e-4, (n, r)
+  print("%s encoder: worst gradient rel-L2 vs the reference's code %.2e" % (case, worst))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
-  r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check", "nmt_decoder"],
-                     capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0 and "reproduced" in r.stdout, r.stdout + r.stderr
+  r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check", "nmt_decoder",
+                      "nmt_encoder"], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 2, r.stdout + r.stderr
