@@ -1492,6 +1492,9 @@ def _log_softmax(logits, axis=None, name=None, dim=None):
   return Tensor(lambda v: torch.log_softmax(_t(v), dim=int(ax)), (logits,), name="log_softmax")
 
 
+DROPOUT_TAP = None      # fixture generator's tap: when a list, every evaluated dropout appends its scaled keep mask
+
+
 def _dropout(x, keep_prob=None, noise_shape=None, seed=None, name=None, rate=None):
   kp = keep_prob if keep_prob is not None else (None if rate is None else 1.0 - rate)
   if not isinstance(kp, Tensor) and float(kp) == 1.0:
@@ -1502,6 +1505,8 @@ def _dropout(x, keep_prob=None, noise_shape=None, seed=None, name=None, rate=Non
     k = float(_t(k))
     shp = list(v.shape) if noise_shape is None else _ishape(noise_shape)
     mask = (torch.rand(shp, generator=_RNG, dtype=torch.float32) + k).floor().to(v.dtype)
+    if DROPOUT_TAP is not None:
+      DROPOUT_TAP.append(mask / k)
     return v / k * mask
   return Tensor(f, (x, kp), name="dropout")
 
@@ -2413,6 +2418,11 @@ def install():
   sub("tensorflow.contrib.framework.python.framework.tensor_util", with_same_shape=with_same_shape)
   sub("tensorflow.contrib.rnn", **vars(contrib.rnn))
   sub("tensorflow.contrib.seq2seq", **vars(contrib.seq2seq))
+  sub("tensorflow.contrib.seq2seq.python")
+  sub("tensorflow.contrib.seq2seq.python.ops")
+  sub("tensorflow.contrib.seq2seq.python.ops.decoder", Decoder=_rnn.Decoder, dynamic_decode=_rnn.dynamic_decode,
+      _transpose_batch_time=_rnn._transpose_batch_time)
+  sub("tensorflow.contrib.seq2seq.python.ops.helper", Helper=_rnn.Helper, TrainingHelper=_rnn.TrainingHelper)
   sub("tensorflow.contrib")
   sub("tensorflow.contrib.cudnn_rnn", CudnnGRU=_CudnnGRU, CudnnLSTM=_CudnnLSTM)
   sub("tensorflow.contrib.cudnn_rnn.python")

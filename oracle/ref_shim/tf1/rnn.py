@@ -170,11 +170,13 @@ class _LoopShared(object):
     return self._memo[1]
 
 
-def _outputs_of(compute, deps, n):
-  """n tensors backed by one `compute(ev) -> list of n torch values` (evaluated eagerly once for the build values)."""
+def _outputs_of(compute, deps, n, like=None):
+  """n tensors backed by one `compute(ev) -> list of n torch values` (evaluated eagerly once for the build values);
+  an output whose counterpart in `like` is a TensorArray is one too."""
   shared = _LoopShared(compute, deps)
   build = shared.values(_BUILD_EV)
-  return [_LoopOut(shared, i, build[i]) for i in _range(n)]
+  like = like or [None] * n
+  return [(_TALoopOut if isinstance(like[i], _TAMethods) else _LoopOut)(shared, i, build[i]) for i in _range(n)]
 
 
 def _BUILD_EV(t):
@@ -344,7 +346,8 @@ class DropoutWrapper(RNNCell):
 
 def _slots_like(structure):
   flat = flatten(structure)
-  slots = [_Slot(_t(v._value if isinstance(v, Tensor) else v)) for v in flat]
+  slots = [(_TASlot if isinstance(v, _TAMethods) else _Slot)(_t(v._value if isinstance(v, Tensor) else v))
+           for v in flat]
   return pack_sequence_as(structure, slots), slots
 
 
@@ -385,7 +388,7 @@ def dynamic_rnn(cell, inputs, sequence_length=None, initial_state=None, dtype=No
     return [torch.stack(v, 1 if not time_major else 0) for v in outs] + st
   deps = [x] + [s for s in init_flat if isinstance(s, Tensor)] + \
       ([sequence_length] if isinstance(sequence_length, Tensor) else []) + flat_out + flat_new
-  res = _outputs_of(compute, deps, n_out + n_state)
+  res = _outputs_of(compute, deps, n_out + n_state, like=flat_out + flat_new)
   return pack_sequence_as(out, res[:n_out]), pack_sequence_as(new_state, res[n_out:])
 
 
@@ -529,7 +532,7 @@ def dynamic_decode(decoder, output_time_major=False, impute_finished=False, maxi
     return stacked + st + [lens]
   deps = [z for z in [i_fin] + i_in + i_st + [maximum_iterations] if isinstance(z, Tensor)] + \
       out_flat + ns_flat + ni_flat + [finished]
-  res = _outputs_of(compute, deps, n_o + n_s + 1)
+  res = _outputs_of(compute, deps, n_o + n_s + 1, like=out_flat + ns_flat + [None])
   final_outputs = pack_sequence_as(outputs, res[:n_o])
   final_state = pack_sequence_as(next_state, res[n_o:n_o + n_s])
   lengths = res[-1]
@@ -537,9 +540,57 @@ def dynamic_decode(decoder, output_time_major=False, impute_finished=False, maxi
   return final_outputs, final_state, lengths
 
 
-class TensorArray(object):
-  def __init__(self, dtype, size=0, dynamic_size=False, **kwargs):
-    raise NotImplementedError("TensorArray (alignment_history=True) is not restated: run with alignment_history off")
+class _TAMethods(object):
+  """tf.TensorArray over the node machinery: the array IS a tensor node holding the stacked elements [n, ...]; write
+  returns a new array (functional, as TensorFlow's flow semantics are), so it can be a loop variable."""
+
+  def write(self, index, value, name=None):
+    def f(cur, i, v):
+      cur, i, v = _t(cur), int(_t(i)), _t(v)
+      if cur.numel() == 0 and cur.dim() == 1:
+        if i != 0:
+          raise IndexError("TensorArray.write past the end of an empty array")
+        return v.unsqueeze(0)
+      if i == cur.shape[0]:
+        return torch.cat([cur, v.unsqueeze(0).to(cur.dtype)], 0)
+      out = cur.clone()
+      out[i] = v
+      return out
+    return TATensor(f, (self, index, value), name="ta_write")
+
+  def read(self, index, name=None):
+    return Tensor(lambda cur, i: _t(cur)[int(_t(i))], (self, index), name="ta_read")
+
+  def stack(self, name=None):
+    return identity(self)
+
+  def unstack(self, value, name=None):
+    return TATensor(lambda v: _t(v), (value,), name="ta_unstack")
+
+  def size(self, name=None):
+    return Tensor(lambda cur: torch.tensor(0 if (_t(cur).dim() == 1 and _t(cur).numel() == 0) else _t(cur).shape[0],
+                                           dtype=torch.int32), (self,), name="ta_size")
+
+
+class TATensor(_TAMethods, Tensor):
+  pass
+
+
+class _TASlot(_TAMethods, _Slot):
+  pass
+
+
+class _TALoopOut(_TAMethods, _LoopOut):
+  pass
+
+
+def TensorArray(dtype, size=0, dynamic_size=False, clear_after_read=None, element_shape=None, **kwargs):   # noqa: N802
+  td = as_dtype(dtype).torch
+  return TATensor(lambda: torch.zeros(0, dtype=td), (), name="tensor_array")
+
+
+def _transpose_batch_time(x):
+  return Tensor(lambda v: _t(v).transpose(0, 1), (x,), name="transpose_batch_time")
 
 
 def embedding_lookup(params, ids, partition_strategy="mod", name=None, validate_indices=True, max_norm=None):

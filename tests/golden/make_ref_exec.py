@@ -614,8 +614,99 @@ def nmt_encoder(seed=43, B=3, S=7, V=20, E=10, H=12):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Tacotron 2 decoder: Tacotron2Decoder._decode in train mode (decoders/tacotron2_decoder.py:257-567) — pre-net with
+# its always-on dropout, single_cell LSTM stack inside AttentionWrapper(output_attention="both",
+# alignment_history=True) over LocationSensitiveAttention (parts/rnns/attention_wrapper.py:641-878: Chorowski
+# location layer on the CUMULATIVE alignments, optional attention bias), TacotronDecoder + TacotronTrainingHelper
+# (parts/tacotron/*.py) under dynamic_decode(impute_finished=False), output / stop-token projections, the five-layer
+# post-net through conv_bn_actv, the magnitude branch of "both" mode. The pre-net's dropout masks are random in the
+# reference: the stand-in's dropout records them (tf1.DROPOUT_TAP) and they are part of the fixture.
+# ---------------------------------------------------------------------------------------------------------
+TACO_DIMS = dict(B=3, S=9, T=7, M=12, H=16, U=10, P=8, NMEL=8, NMAG=12, K=5, F=6)
+
+
+def tacotron_decoder(seed=47):
+  out = {"dims": np.array([TACO_DIMS[k] for k in ("B", "S", "T", "M", "H", "U", "P", "NMEL", "NMAG", "K", "F")],
+                          np.int32)}
+  D = TACO_DIMS
+  for case, bias in (("location", False), ("location_bias", True)):
+    tf, imp = _install()
+    tf.reset_default_graph()
+    tf.set_random_seed(seed)
+    Dec = imp("open_seq2seq.decoders.tacotron2_decoder").Tacotron2Decoder
+    rng = np.random.RandomState(seed)
+    B, S, T, M, H, U, P, NMEL, NMAG, K, F = [D[k] for k in ("B", "S", "T", "M", "H", "U", "P", "NMEL", "NMAG", "K", "F")]
+    src_len = np.array([9, 5, 7], np.int32)
+    spec_len = np.array([7, 4, 6], np.int32)
+    enc = rng.standard_normal((B, S, M)).astype(np.float32)
+    spec = rng.standard_normal((B, T, NMEL + NMAG)).astype(np.float32)
+
+    class _DL(object):
+      params = {"num_audio_features": {"mel": NMEL, "magnitude": NMAG}, "output_type": "both"}
+      _exp_mag = True
+
+    class _Model(object):
+      params = {"dtype": tf.float32}
+
+      def get_data_layer(self):
+        return _DL()
+    postnet = [{"kernel_size": [5], "stride": [1], "num_channels": 10, "padding": "SAME", "activation_fn": tf.nn.tanh},
+               {"kernel_size": [5], "stride": [1], "num_channels": 10, "padding": "SAME", "activation_fn": tf.nn.tanh},
+               {"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
+    params = dict(attention_layer_size=U, attention_type="location", attention_bias=bias, decoder_cell_units=H,
+                  decoder_cell_type=tf.nn.rnn_cell.LSTMCell, decoder_layers=2, enable_prenet=True, prenet_layers=2,
+                  prenet_units=P, enable_postnet=True, postnet_conv_layers=postnet, postnet_keep_dropout_prob=1.0,
+                  postnet_bn_momentum=0.1, postnet_bn_epsilon=1e-5, mask_decoder_sequence=True, zoneout_prob=0.0,
+                  dropout_prob=0.0, dtype=tf.float32)
+    with tf.variable_scope("ForwardPass"):
+      enc_var = tf.get_variable("encoder_outputs", initializer=tf.constant(enc))
+      dec = Dec(params, _Model(), mode="train")
+      # the location layer's sizes are fixed to 32 x 32 in the reference unless location_attention_params is given,
+      # which _build_attention does not pass on: the fixture runs at the reference's 32 taps / 32 filters
+      res = dec.decode({"encoder_output": {"outputs": enc_var, "src_length": tf.constant(src_len)},
+                        "target_tensors": [tf.constant(spec), tf.constant(np.zeros((B, T), np.float32)),
+                                           tf.constant(spec_len)]})
+    dec_out, post, align, stop_sig, seq_lens, mag = res["outputs"]
+    stop_logits = res["stop_token_prediction"]
+    Rs = [rng.standard_normal(tuple(int(v) for v in t.get_shape())).astype(np.float32) for t in (dec_out, post, stop_logits, mag)]
+    loss = tf.add_n([tf.reduce_sum(t * tf.constant(r)) for t, r in zip((dec_out, post, stop_logits, mag), Rs)])
+    tvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in tvars]
+    with tf.Session() as sess:
+      big = {n for n, v in zip(names, tvars) if v._var.numel() > 4096}   # the magnitude branch's fixed 256 / 512 widths
+      for n, v in zip(names, tvars):
+        if n in big:
+          v.load(seeded_array(n, tuple(v._var.shape), seed))
+        elif v._var.dim() == 1:
+          v.load(_np(v._var) + 0.2 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+      tf1 = tf
+      tf1.DROPOUT_TAP = []
+      vals = sess.run({"mel": dec_out, "post": post, "align": align, "stop": stop_logits, "lens": seq_lens, "mag": mag,
+                       "loss": loss, "grads": tf.gradients(loss, tvars), "vars": list(tvars)})
+      masks = [_np(m) for m in tf1.DROPOUT_TAP]
+      tf1.DROPOUT_TAP = None
+    assert len(masks) == 2 * T, len(masks)
+    out.update({case + "/src_len": src_len, case + "/spec_len": spec_len, case + "/spec": spec,
+                case + "/mel": vals["mel"], case + "/post": vals["post"], case + "/align": vals["align"],
+                case + "/stop": vals["stop"], case + "/mag": vals["mag"], case + "/lens": vals["lens"].astype(np.int32),
+                case + "/loss": np.float32(vals["loss"]), case + "/var_names": np.array(names),
+                case + "/prenet_mask0": np.stack(masks[0::2], 1), case + "/prenet_mask1": np.stack(masks[1::2], 1)})
+    out[case + "/seed"] = np.int32(seed)
+    for i, r in enumerate(Rs):
+      out["%s/R%d" % (case, i)] = r
+    for n, v, g in zip(names, vals["vars"], vals["grads"]):
+      if n in big:                       # regenerated from the seed by the tests; gradient as (norm, projection)
+        out["%s/shape/%s" % (case, n)] = np.array(v.shape, np.int32)
+        out["%s/gproj/%s" % (case, n)] = projection(n, g, seed)
+      else:
+        out["%s/var/%s" % (case, n)] = v.astype(np.float32)
+        out["%s/grad/%s" % (case, n)] = g.astype(np.float32)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder}
 
 
 def generate(name):

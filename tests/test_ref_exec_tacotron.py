@@ -1,0 +1,95 @@
+"""The Tacotron 2 decoder oracle against the REFERENCE'S OWN CODE.
+
+tests/golden/ref_exec_tacotron_decoder.npz = open_seq2seq's Tacotron2Decoder._decode in train mode
+(decoders/tacotron2_decoder.py:257-567) executed from the reference's files by tests/golden/make_ref_exec.py:
+pre-net (two Dense + ReLU layers with their always-on dropout — the masks the run drew are part of the fixture),
+two LSTM cells inside AttentionWrapper(output_attention="both", alignment_history=True) over
+LocationSensitiveAttention (parts/rnns/attention_wrapper.py:641-878: query layer, k=1 memory layer, Chorowski location
+layer — 32 taps x 32 filters over the CUMULATIVE alignments — score bias on / off, scores masked to -inf past the
+source lengths), TacotronDecoder / TacotronTrainingHelper (parts/tacotron/*.py) under dynamic_decode, output and
+stop-token projections, the post-net through conv_bn_actv (BatchNorm on batch statistics, tanh / linear), the magnitude
+branch (two conv + BN + ReLU layers of 256 / 512 channels, exp, 1x1 projection). The LSTM cell class and dynamic_decode
+are TensorFlow library code (oracle/ref_shim/tf1/rnn.py). oracle/tacotron.py:decoder must reproduce the mel frames, the
+post-net output, stop logits, magnitude frames, alignments (1e-5) and the gradient of every variable incl. the encoder
+outputs (1e-4) under the surrogate loss sum(outputs * R)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import ref_exec_util as rx  # noqa: E402
+from oracle import tacotron as otaco  # noqa: E402
+
+SC = "ForwardPass/tacotron_2_decoder/"
+AW = SC + "decoder/attention_wrapper/"
+
+
+@pytest.mark.parametrize("case", ["location", "location_bias"])
+def test_oracle_reproduces_the_reference_tacotron_decoder(case):
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_tacotron_decoder.npz")))
+  B, S, T, M, H, U, P_, NMEL, NMAG, K, F = [int(v) for v in d["dims"]]
+  names = [str(n) for n in d[case + "/var_names"]]
+  seed = int(d[case + "/seed"])
+  leaf = {}
+  for n in names:
+    k = "%s/var/%s" % (case, n)
+    a = d[k] if k in d else rx.gen.seeded_array(n, tuple(int(v) for v in d["%s/shape/%s" % (case, n)]), seed)
+    leaf[n] = torch.from_numpy(np.array(a, np.float32)).requires_grad_(True)
+
+  def conv(prefix):          # TF [K, Cin, Cout] -> the oracle's [K, Cout, Cin]
+    return (leaf[prefix + "/kernel"].permute(0, 2, 1), leaf[prefix + "/bn/gamma"], leaf[prefix + "/bn/beta"])
+  k0 = leaf[AW + "multi_rnn_cell/cell_0/lstm_cell/kernel"].t()          # [4H, P + M + H]: pre-net | attention | h
+  cell = {"w_in": k0[:, :P_], "b0": leaf[AW + "multi_rnn_cell/cell_0/lstm_cell/bias"],
+          "wcat": [k0[:, P_:], leaf[AW + "multi_rnn_cell/cell_1/lstm_cell/kernel"].t()],
+          "bias": [None, leaf[AW + "multi_rnn_cell/cell_1/lstm_cell/bias"]],
+          "wq": leaf[AW + "location_attention/query_layer/kernel"].t(),
+          "wmem": leaf[SC + "AttentionMechanism/memory_layer/kernel"][0].t(),
+          "v": leaf[AW + "location_attention/attention_v"],
+          "b": leaf.get(AW + "location_attention/attention_bias"),
+          "conv_w": leaf[AW + "location_attention/location_conv/kernel"][:, 0, :],
+          "conv_b": leaf[AW + "location_attention/location_conv/bias"],
+          "dense_w": leaf[AW + "location_attention/location_dense/kernel"][0]}
+  assert (cell["b"] is not None) == (case == "location_bias")
+  P = {"prenet": [(leaf[SC + "decoder/prenet_%d/kernel" % i].t(), leaf[SC + "decoder/prenet_%d/bias" % i])
+                  for i in (1, 2)],
+       "cell": cell, "out_w": leaf[SC + "decoder/output_proj/kernel"].t(), "out_b": leaf[SC + "decoder/output_proj/bias"],
+       "stop_w": leaf[SC + "decoder/stop_token_proj/kernel"].t(), "stop_b": leaf[SC + "decoder/stop_token_proj/bias"],
+       "postnet": [conv(SC + "conv%d" % i) for i in (1, 2, 3)],
+       "mag": {"c0": conv(SC + "conv_0"), "c1": conv(SC + "conv_1"), "proj": leaf[SC + "post_net_proj/kernel"][0].t()}}
+  spec = torch.from_numpy(d[case + "/spec"])
+  masks = [torch.from_numpy(d[case + "/prenet_mask0"]), torch.from_numpy(d[case + "/prenet_mask1"])]
+  assert set(np.unique(d[case + "/prenet_mask0"]).tolist()) <= {0.0, 2.0}       # keep 0.5: kept values doubled
+  out = otaco.decoder(P, leaf["ForwardPass/encoder_outputs"], torch.from_numpy(d[case + "/src_len"]),
+                      spec[:, :, :NMEL], ["tanh", "tanh", None], bn_eps=1e-5, exp_mag=True, prenet_masks=masks)
+  # mask_decoder_sequence: a sample is finished once time + 1 >= its spectrogram length; impute_finished=False, so
+  # every sample keeps running until the longest one ends
+  assert d[case + "/lens"].tolist() == d[case + "/spec_len"].tolist()
+  for key, ref in (("mel", "mel"), ("post", "post"), ("stop", "stop"), ("mag", "mag"), ("align", "align")):
+    r = rx.rel(out[key].detach().numpy(), d["%s/%s" % (case, ref)])
+    assert r < 1e-5, (key, r)
+  # scores are masked to -inf past the source lengths: those alignments are exact zeros in the reference's output
+  for b in range(B):
+    assert np.abs(d[case + "/align"][b, :, int(d[case + "/src_len"][b]):]).max(initial=0.0) == 0.0
+  loss = sum((out[k] * torch.from_numpy(d["%s/R%d" % (case, i)])).sum()
+             for i, k in enumerate(("mel", "post", "stop", "mag")))
+  assert abs(float(loss.detach()) - float(d[case + "/loss"])) < 1e-4 * max(1.0, abs(float(d[case + "/loss"])))
+  loss.backward()
+  worst = 0.0
+  dd = {k[len(case) + 1:]: v for k, v in d.items() if k.startswith(case + "/")}
+  dd["seed"] = d[case + "/seed"]
+  for n in names:
+    worst = max(worst, rx.check_gradient(dd, n, leaf[n].grad.numpy(), 1e-4))
+  print("%s: worst gradient error vs the reference's code %.2e" % (case, worst))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
+def test_generator_reproduces_the_committed_fixture():
+  r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check",
+                      "tacotron_decoder"], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and "reproduced" in r.stdout, r.stdout + r.stderr
