@@ -2132,6 +2132,44 @@ def _losses_softmax_xent(onehot_labels, logits, weights=1.0, label_smoothing=0, 
 
 losses.softmax_cross_entropy = _losses_softmax_xent
 
+
+def _weighted_loss(per_element, weights, reduction):
+  """tf.losses.compute_weighted_loss, default reduction SUM_BY_NONZERO_WEIGHTS: sum(losses * weights) divided by
+  the number of elements whose (broadcast) weight is non-zero; 0 when there is none."""
+  def f(l, w):
+    l = _t(l).to(torch.float32)
+    w = _t(w, like=l).to(torch.float32)
+    wl = l * w
+    if reduction == "none":
+      return wl
+    if reduction == "weighted_sum":
+      return wl.sum()
+    present = (torch.broadcast_to(w, l.shape) != 0).to(torch.float32).sum()
+    return torch.where(present > 0, wl.sum() / torch.clamp(present, min=1.0), torch.zeros(()))
+  return Tensor(f, (per_element, weights), name="weighted_loss")
+
+
+def _mean_squared_error(labels, predictions, weights=1.0, scope=None, loss_collection=None,
+                        reduction="weighted_sum_by_nonzero_weights"):
+  return _weighted_loss(squared_difference(cast(predictions, float32), cast(labels, float32)), weights, reduction)
+
+
+def _absolute_difference(labels, predictions, weights=1.0, scope=None, loss_collection=None,
+                         reduction="weighted_sum_by_nonzero_weights"):
+  return _weighted_loss(abs(cast(predictions, float32) - cast(labels, float32)), weights, reduction)
+
+
+losses.mean_squared_error, losses.absolute_difference = _mean_squared_error, _absolute_difference
+
+
+def _sigmoid_xent(_sentinel=None, labels=None, logits=None, name=None):
+  """max(x, 0) - x z + log(1 + exp(-|x|))"""
+  return Tensor(lambda z, x: torch.clamp(_t(x), min=0) - _t(x) * _t(z).to(_t(x).dtype) +
+                torch.log1p(torch.exp(-_t(x).abs())), (labels, logits), name="sigmoid_cross_entropy_with_logits")
+
+
+nn.sigmoid_cross_entropy_with_logits = _sigmoid_xent
+
 # ----------------------------------------------------------------------------------------------- tf.train
 
 _GLOBAL_STEP = []

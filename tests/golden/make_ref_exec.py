@@ -705,8 +705,58 @@ def tacotron_decoder(seed=47):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Text2SpeechLoss (losses/text2speech_loss.py:35-209) on synthetic predictions: "both" mode, predictions shorter and
+# longer than the targets (the pad-to-common-length branch), mask on / off, l1 / l2, weights and scale.
+# ---------------------------------------------------------------------------------------------------------
+T2S_CASES = {
+    "masked_l2_pred_longer": dict(Tp=9, Tt=7, use_mask=True, l1_norm=False),
+    "masked_l1_pred_shorter": dict(Tp=5, Tt=8, use_mask=True, l1_norm=True, mel_weight=0.7, mag_weight=1.3,
+                                   stop_token_weight=2.0, scale=0.5),
+    "unmasked_l2_equal": dict(Tp=6, Tt=6, use_mask=False, l1_norm=False),
+}
+
+
+def t2s_loss(seed=53, B=3, NMEL=5, NMAG=7):
+  out = {"dims": np.array([B, NMEL, NMAG], np.int32)}
+  for case, cfg in T2S_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    Loss = imp("open_seq2seq.losses.text2speech_loss").Text2SpeechLoss
+    rng = np.random.RandomState(seed)
+    Tp, Tt = cfg["Tp"], cfg["Tt"]
+    mel, post = [rng.standard_normal((B, Tp, NMEL)).astype(np.float32) for _ in range(2)]
+    stop = rng.standard_normal((B, Tp, 1)).astype(np.float32)
+    mag = rng.standard_normal((B, Tp, NMAG)).astype(np.float32)
+    spec = rng.standard_normal((B, Tt, NMEL + NMAG)).astype(np.float32)
+    spec_len = np.array([Tt, max(Tt - 3, 1), max(Tt - 1, 1)], np.int32)
+    stop_t = (np.arange(Tt)[None, :] >= (spec_len[:, None] - 1)).astype(np.float32)
+
+    class _DL(object):
+      params = {"num_audio_features": {"mel": NMEL, "magnitude": NMAG}, "output_type": "both"}
+
+    class _Model(object):
+      def get_data_layer(self):
+        return _DL()
+
+      def get_tf_dtype(self):
+        return tf.float32
+    params = {k: v for k, v in cfg.items() if k not in ("Tp", "Tt")}
+    vs = [tf.Variable(a) for a in (mel, post, stop, mag)]
+    loss = Loss(params, _Model()).compute_loss(
+        {"decoder_output": {"outputs": [vs[0], vs[1], None, None, None, vs[3]], "stop_token_prediction": vs[2]},
+         "target_tensors": [tf.constant(spec), tf.constant(stop_t), tf.constant(spec_len)]})
+    with tf.Session() as sess:
+      vals = sess.run({"loss": loss, "grads": tf.gradients(loss, vs)})
+    out.update({case + "/mel": mel, case + "/post": post, case + "/stop": stop, case + "/mag": mag, case + "/spec": spec,
+                case + "/spec_len": spec_len, case + "/stop_target": stop_t, case + "/loss": np.float32(vals["loss"])})
+    for k, g in zip(("mel", "post", "stop", "mag"), vals["grads"]):
+      out["%s/grad/%s" % (case, k)] = g.astype(np.float32)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss}
 
 
 def generate(name):

@@ -88,8 +88,30 @@ def test_oracle_reproduces_the_reference_tacotron_decoder(case):
   print("%s: worst gradient error vs the reference's code %.2e" % (case, worst))
 
 
+@pytest.mark.parametrize("case", sorted(rx.gen.T2S_CASES))
+def test_oracle_reproduces_the_reference_text2speech_loss(case):
+  """Text2SpeechLoss._compute_loss (losses/text2speech_loss.py:35-209) executed from the reference's file on synthetic
+  predictions in "both" mode: predictions longer / shorter than the targets (zeros appended to predictions and
+  spectrogram, ONES to the stop-token target), masked MSE / L1 with tf.losses' SUM_BY_NONZERO_WEIGHTS reduction,
+  masked stop-token cross entropy, the unmasked means, weights and scale. Loss 1e-6, gradients w.r.t. all four
+  prediction tensors 1e-5."""
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_t2s_loss.npz")))
+  cfg = rx.gen.T2S_CASES[case]
+  B, NMEL, NMAG = [int(v) for v in d["dims"]]
+  out = {k: torch.from_numpy(d["%s/%s" % (case, k)].copy()).requires_grad_(True) for k in ("mel", "post", "stop", "mag")}
+  loss = otaco.text2speech_loss(out, torch.from_numpy(d[case + "/spec"]), torch.from_numpy(d[case + "/stop_target"]),
+                                torch.from_numpy(d[case + "/spec_len"]), NMEL, NMAG, l1=cfg.get("l1_norm", False),
+                                use_mask=cfg["use_mask"], mel_weight=cfg.get("mel_weight", 1.0),
+                                mag_weight=cfg.get("mag_weight", 1.0),
+                                stop_token_weight=cfg.get("stop_token_weight", 1.0), scale=cfg.get("scale"))
+  assert abs(float(loss.detach()) - float(d[case + "/loss"])) < 1e-6 * max(1.0, abs(float(d[case + "/loss"])))
+  loss.backward()
+  for k in out:
+    assert rx.rel(out[k].grad.numpy(), d["%s/grad/%s" % (case, k)]) < 1e-5, k
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check",
-                      "tacotron_decoder"], capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0 and "reproduced" in r.stdout, r.stdout + r.stderr
+                      "tacotron_decoder", "t2s_loss"], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 2, r.stdout + r.stderr
