@@ -705,6 +705,78 @@ def tacotron_decoder(seed=47):
   return out
 
 
+def tacotron_infer(seed=59):
+  """Tacotron2Decoder._decode in eval mode (decoders/tacotron2_decoder.py:378-428): TacotronHelper feeds every
+  projected frame back through the pre-net, finished = round(sigmoid(stop logit)), the loop ends when every sample has
+  finished (or after 10 x max(src_len) steps); sequence lengths as dynamic_decode counts them. The stop projection's
+  bias and gain are searched (deterministically) until a sample finishes in the middle of the run while another one keeps
+  decoding (random LSTM trajectories settle quickly: most settings finish at step 1 or never)."""
+  D = TACO_DIMS
+  B, S, M, H, U, P, NMEL, NMAG = [D[k] for k in ("B", "S", "M", "H", "U", "P", "NMEL", "NMAG")]
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  Dec = imp("open_seq2seq.decoders.tacotron2_decoder").Tacotron2Decoder
+  rng = np.random.RandomState(seed)
+  src_len = np.array([3, 2, 3], np.int32)                       # limit = 10 * 3 = 30 steps
+  S = 3
+  enc = rng.standard_normal((B, S, M)).astype(np.float32)
+
+  class _DL(object):
+    params = {"num_audio_features": NMEL, "output_type": "mel"}
+
+  class _Model(object):
+    params = {"dtype": tf.float32}
+
+    def get_data_layer(self):
+      return _DL()
+  postnet = [{"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
+  params = dict(attention_layer_size=U, attention_type="location", attention_bias=True, decoder_cell_units=H,
+                decoder_cell_type=tf.nn.rnn_cell.LSTMCell, decoder_layers=2, enable_prenet=True, prenet_layers=2,
+                prenet_units=P, enable_postnet=True, postnet_conv_layers=postnet, postnet_keep_dropout_prob=1.0,
+                mask_decoder_sequence=True, zoneout_prob=0.0, dropout_prob=0.0, dtype=tf.float32)
+  with tf.variable_scope("ForwardPass"):
+    dec = Dec(params, _Model(), mode="eval")
+    res = dec.decode({"encoder_output": {"outputs": tf.constant(enc), "src_length": tf.constant(src_len)}})
+  dec_out, post, align, stop_sig, seq_lens, _ = res["outputs"]
+  gvars = tf.trainable_variables()
+  names = [v.name.split(":")[0] for v in gvars]
+  stop_b = [v for v in gvars if v.name.endswith("stop_token_proj/bias:0")][0]
+  stop_k = [v for v in gvars if v.name.endswith("stop_token_proj/kernel:0")][0]
+  out_k = [v for v in gvars if v.name.endswith("output_proj/kernel:0")][0]
+  with tf.Session() as sess:
+    for n, v in zip(names, gvars):
+      if v._var.dim() == 1:
+        v.load(_np(v._var) + 0.2 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+    stop_k0, out_k0 = _np(stop_k._var).copy(), _np(out_k._var).copy()
+    chosen = None
+    for bias, gain in [(b, g) for g in (3.0, 10.0, 30.0) for b in np.linspace(-3.0, 3.0, 61)]:
+      stop_b.load(np.array([bias], np.float32))
+      stop_k.load(gain * stop_k0)
+      out_k.load(2.0 * out_k0)
+      tf._RNG.manual_seed(seed)
+      tf.DROPOUT_TAP = []
+      vals = sess.run({"mel": dec_out, "align": align, "stop": res["stop_token_prediction"], "lens": seq_lens,
+                       "vars": list(gvars)})
+      masks = [_np(m) for m in tf.DROPOUT_TAP]
+      tf.DROPOUT_TAP = None
+      lens = vals["lens"]
+      mid = [int(v) for v in lens if 3 <= v <= 28]
+      if len(set(lens.tolist())) >= 2 and mid:
+        chosen = (float(bias), float(gain))
+        break
+  assert chosen is not None, "no stop bias / gain lets a sample finish in the middle of the run"
+  steps = vals["mel"].shape[1]
+  assert len(masks) == 2 * steps, (len(masks), steps)
+  out = {"dims": np.array([B, S, M, H, U, P, NMEL], np.int32), "src_len": src_len, "enc": enc, "mel": vals["mel"],
+         "align": vals["align"], "stop": vals["stop"], "lens": vals["lens"].astype(np.int32),
+         "steps": np.int32(steps), "var_names": np.array(names),
+         "prenet_mask0": np.stack(masks[0::2], 0), "prenet_mask1": np.stack(masks[1::2], 0)}
+  for n, v in zip(names, vals["vars"]):
+    out["var/" + n] = v.astype(np.float32)
+  return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Text2SpeechLoss (losses/text2speech_loss.py:35-209) on synthetic predictions: "both" mode, predictions shorter and
 # longer than the targets (the pad-to-common-length branch), mask on / off, l1 / l2, weights and scale.
@@ -756,7 +828,7 @@ def t2s_loss(seed=53, B=3, NMEL=5, NMAG=7):
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer}
 
 
 def generate(name):

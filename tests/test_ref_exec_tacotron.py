@@ -88,6 +88,41 @@ def test_oracle_reproduces_the_reference_tacotron_decoder(case):
   print("%s: worst gradient error vs the reference's code %.2e" % (case, worst))
 
 
+def test_oracle_reproduces_the_reference_free_running_decode():
+  """Tacotron2Decoder._decode in eval mode (decoders/tacotron2_decoder.py:378-428; TacotronHelper,
+  parts/tacotron/tacotron_helper.py:138-226) executed from the reference's files: every projected frame goes back
+  through the pre-net (dropout on, masks recorded), finished = round(sigmoid(stop logit)) accumulates, the loop runs
+  until every sample has finished or 10 x max(src_len) steps; one sample finishes at step 28 of 30 and the others run
+  into the limit. oracle/tacotron.py:decoder_infer (the restatement the device's fused decode kernels are tested
+  against) must give the same frames, stop logits, alignments (1e-4 over 30 free-running steps), the same step count
+  and the same per-sample lengths."""
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_tacotron_infer.npz")))
+  B, S, M, H, U, P_, NMEL = [int(v) for v in d["dims"]]
+  leaf = {str(n): torch.from_numpy(d["var/" + str(n)].copy()) for n in d["var_names"]}
+  k0 = leaf[AW + "multi_rnn_cell/cell_0/lstm_cell/kernel"].t()
+  cell = {"w_in": k0[:, :P_], "b0": leaf[AW + "multi_rnn_cell/cell_0/lstm_cell/bias"],
+          "wcat": [k0[:, P_:], leaf[AW + "multi_rnn_cell/cell_1/lstm_cell/kernel"].t()],
+          "bias": [None, leaf[AW + "multi_rnn_cell/cell_1/lstm_cell/bias"]],
+          "wq": leaf[AW + "location_attention/query_layer/kernel"].t(),
+          "wmem": leaf[SC + "AttentionMechanism/memory_layer/kernel"][0].t(),
+          "v": leaf[AW + "location_attention/attention_v"], "b": leaf[AW + "location_attention/attention_bias"],
+          "conv_w": leaf[AW + "location_attention/location_conv/kernel"][:, 0, :],
+          "conv_b": leaf[AW + "location_attention/location_conv/bias"],
+          "dense_w": leaf[AW + "location_attention/location_dense/kernel"][0]}
+  P = {"prenet": [(leaf[SC + "decoder/prenet_%d/kernel" % i].t(), leaf[SC + "decoder/prenet_%d/bias" % i])
+                  for i in (1, 2)],
+       "cell": cell, "out_w": leaf[SC + "decoder/output_proj/kernel"].t(), "out_b": leaf[SC + "decoder/output_proj/bias"],
+       "stop_w": leaf[SC + "decoder/stop_token_proj/kernel"].t(), "stop_b": leaf[SC + "decoder/stop_token_proj/bias"]}
+  masks = [torch.from_numpy(d["prenet_mask0"]), torch.from_numpy(d["prenet_mask1"])]
+  out = otaco.decoder_infer(P, torch.from_numpy(d["enc"]), torch.from_numpy(d["src_len"]), prenet_masks=masks,
+                            round_frames_bf16=False)
+  assert int(out["steps"]) == int(d["steps"]) == 30
+  assert [int(v) for v in out["lengths"]] == d["lens"].tolist() == [28, 30, 30]
+  assert rx.rel(out["mel"].numpy(), d["mel"]) < 1e-4
+  assert rx.rel(out["stop"].numpy(), d["stop"][:, :, 0]) < 1e-4
+  assert rx.rel(out["align"].numpy(), d["align"]) < 1e-4
+
+
 @pytest.mark.parametrize("case", sorted(rx.gen.T2S_CASES))
 def test_oracle_reproduces_the_reference_text2speech_loss(case):
   """Text2SpeechLoss._compute_loss (losses/text2speech_loss.py:35-209) executed from the reference's file on synthetic
@@ -113,5 +148,6 @@ def test_oracle_reproduces_the_reference_text2speech_loss(case):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check",
-                      "tacotron_decoder", "t2s_loss"], capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0 and r.stdout.count("reproduced") == 2, r.stdout + r.stderr
+                      "tacotron_decoder", "t2s_loss", "tacotron_infer"], capture_output=True, text=True,
+                     timeout=900)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 3, r.stdout + r.stderr
