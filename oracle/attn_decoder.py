@@ -13,9 +13,15 @@ Parameter tensors use the DEVICE layout of openseq2seq_amd (weights [out, in], g
 i, j, f, o as tf.nn.rnn_cell.LSTMCell, forget_bias inside the sigmoid); dropout masks are
 passed in explicitly (already scaled by 1/keep) so GPU and oracle share them.
 
-PARITY STATUS: unpinned by the reference (no value tests for any attention mechanism,
-SURVEY.md 8c). The normalised Bahdanau score and the masked softmax are cross-checked
-against closed forms in tests/test_oracle_attn_decoder.py."""
+PARITY STATUS (round 5): pinned to the reference's OWN CODE — parts/rnns/attention_wrapper.py
+(AttentionWrapper, BahdanauAttention normalised, LocationSensitiveAttention with the Chorowski
+location layer, memory preparation, score masking), parts/rnns/gnmt.py, decoders/rnn_decoders.py
+and decoders/tacotron2_decoder.py executed from their files on the TF-primitive stand-in
+oracle/ref_shim/tf1 (its rnn.py restates the LSTM cell class and dynamic_decode as one traced step);
+through oracle/nmt.py and oracle/tacotron.py this loop reproduces their outputs (1e-5) and all
+gradients (3e-6): tests/test_ref_exec_nmt.py, tests/test_ref_exec_tacotron.py. The LSTM cell
+equations themselves are TensorFlow library code (i, j, f, o; forget_bias inside the sigmoid):
+restated on both sides."""
 import math
 
 import torch

@@ -4,8 +4,11 @@
 (decoders/rnn_decoders.py:147-321, parts/rnns/gnmt.py:32-79) -> BasicSequenceLoss
 (losses/sequence_loss.py:53-114). Dropout is off (keep probabilities 1.0); the dropout
 plumbing of the kernels is pinned separately in tests/test_attn_decoder_gpu.py.
-PARITY STATUS: unpinned by the reference (no value tests). The sub-blocks are
-cross-checked in tests/test_oracle_rnn.py and tests/test_oracle_attn_decoder.py."""
+PARITY STATUS (round 5): pinned to the reference's OWN CODE — both encoders,
+RNNDecoderWithAttention (gnmt / gnmt_v2 / skip connections) and BasicSequenceLoss executed from their
+files on the TF-primitive stand-in oracle/ref_shim/tf1: outputs / logits / loss 1e-5, all gradients
+6e-7 (tests/test_ref_exec_nmt.py). tf.nn.rnn_cell.LSTMCell, dynamic_rnn and dynamic_decode are
+TensorFlow library code, restated in oracle/ref_shim/tf1/rnn.py."""
 import torch
 import torch.nn.functional as F
 

@@ -5,7 +5,12 @@ Tacotron2Decoder._decode in train mode (decoders/tacotron2_decoder.py:257-567; P
 LocationSensitiveAttention parts/rnns/attention_wrapper.py:641-878) and Text2SpeechLoss
 (losses/text2speech_loss.py:35-209). Weights use the device layout ([out, in] / conv
 [K, Cout, Cin]); dropout masks are passed explicitly (None = off).
-PARITY STATUS: unpinned by the reference (no value tests for this model)."""
+PARITY STATUS (round 5): decoder, free-running decoder_infer and text2speech_loss are pinned to the
+reference's OWN CODE — Tacotron2Decoder._decode (train and eval mode), TacotronDecoder / helpers,
+LocationSensitiveAttention and Text2SpeechLoss executed from their files on the TF-primitive stand-in
+oracle/ref_shim/tf1 with the pre-net's dropout masks recorded: outputs 1e-5, gradients 3e-6, 30
+free-running steps 1e-4 with the same lengths (tests/test_ref_exec_tacotron.py). The encoder (cuDNN
+LSTM, global style tokens) is not executed: "parity unpinned"."""
 import torch
 import torch.nn.functional as F
 
