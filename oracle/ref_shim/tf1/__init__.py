@@ -1722,6 +1722,8 @@ class Layer(object):
 
   @property
   def variables(self):
+    if self.scope_name is None:
+      return []
     p = self.scope_name + "/"
     return [v for v in global_variables() if v.name.startswith(p)]
 
@@ -1729,6 +1731,8 @@ class Layer(object):
 
   @property
   def trainable_variables(self):
+    if self.scope_name is None:           # not called yet: TensorFlow returns the (empty) list of built weights
+      return []
     p = self.scope_name + "/"
     return [v for v in trainable_variables() if v.name.startswith(p)]
 
@@ -2389,7 +2393,7 @@ with_same_shape = lambda old, new: new                   # noqa: E731  (contrib.
 from . import rnn as _rnn                                # noqa: E402  (the recurrent part of the stand-in)
 nn.rnn_cell = types.SimpleNamespace(
     RNNCell=_rnn.RNNCell, LSTMCell=_rnn.LSTMCell, BasicLSTMCell=_rnn.BasicLSTMCell, MultiRNNCell=_rnn.MultiRNNCell,
-    LSTMStateTuple=_rnn.LSTMStateTuple, ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper)
+    GRUCell=_rnn.GRUCell, LSTMStateTuple=_rnn.LSTMStateTuple, ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper)
 nn.dynamic_rnn, nn.bidirectional_dynamic_rnn = _rnn.dynamic_rnn, _rnn.bidirectional_dynamic_rnn
 nn.embedding_lookup = _rnn.embedding_lookup
 contrib.rnn = types.SimpleNamespace(MultiRNNCell=_rnn.MultiRNNCell, ResidualWrapper=_rnn.ResidualWrapper,

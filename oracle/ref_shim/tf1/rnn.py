@@ -278,6 +278,40 @@ class BasicLSTMCell(LSTMCell):
     return self._given_name or "basic_lstm_cell"
 
 
+class GRUCell(RNNCell):
+  """tf.nn.rnn_cell.GRUCell: gates/kernel [in + H, 2H] (r | u, bias initialised to ones), candidate/kernel [in + H, H];
+  r, u = sigmoid([x, h] Wg + bg); c = tanh([x, r * h] Wc + bc); h' = u h + (1 - u) c (the reset gate is applied BEFORE
+  the candidate product — unlike the cuDNN form)."""
+
+  def __init__(self, num_units, activation=None, reuse=None, kernel_initializer=None, bias_initializer=None,
+               name=None, dtype=None, **kwargs):
+    super(GRUCell, self).__init__(name=name, dtype=dtype)
+    self._num_units = int(num_units)
+
+  @property
+  def name(self):
+    return self._given_name or "gru_cell"
+
+  state_size = property(lambda self: self._num_units)
+  output_size = property(lambda self: self._num_units)
+
+  def build(self, input_shape):
+    from . import ones_initializer
+    cin, H = int(input_shape[-1]), self._num_units
+    self._gk = self.add_variable("gates/kernel", [cin + H, 2 * H])
+    self._gb = self.add_variable("gates/bias", [2 * H], initializer=ones_initializer())
+    self._ck = self.add_variable("candidate/kernel", [cin + H, H])
+    self._cb = self.add_variable("candidate/bias", [H], initializer=zeros_initializer())
+    self.built = True
+
+  def call(self, inputs, state):
+    ru = sigmoid(matmul(concat([inputs, state], 1), self._gk) + self._gb)
+    r, u = split(ru, 2, axis=1)
+    c = tanh(matmul(concat([inputs, r * state], 1), self._ck) + self._cb)
+    new_h = u * state + (1 - u) * c
+    return new_h, new_h
+
+
 class MultiRNNCell(RNNCell):
   def __init__(self, cells, state_is_tuple=True):
     super(MultiRNNCell, self).__init__()

@@ -705,6 +705,73 @@ def tacotron_decoder(seed=47):
   return out
 
 
+TACO_ENC = dict(B=3, S=9, V=30, E=10, C=12, H=7, NS=16, TS=21, SC1=4, SC2=6, SH=9, NTOK=5, TOKE=8, ATT=8, HEADS=2)
+TACO_STYLE_CONV = [{"kernel_size": [3, 3], "stride": [2, 2], "num_channels": 4, "padding": "SAME"},
+                   {"kernel_size": [3, 3], "stride": [2, 2], "num_channels": 6, "padding": "SAME"}]
+
+
+def tacotron_encoder(seed=61):
+  """Tacotron2Encoder._encode with global style tokens (encoders/tacotron2_encoder.py:104-505): embedding, three
+  conv_bn_actv layers, the cuDNN bidirectional LSTM over the whole padded length, and _embed_style — conv2d + BatchNorm
+  + ReLU blocks over the style spectrogram, tf.nn.rnn_cell.GRUCell under dynamic_rnn (final state at each sample's
+  length), Dense(128, tanh), the reference's multi-head Attention in "bahdanau" mode over tanh(style tokens) — tiled
+  over time and concatenated. Train mode, dropout probabilities 0."""
+  D = TACO_ENC
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  Enc = imp("open_seq2seq.encoders.tacotron2_encoder").Tacotron2Encoder
+  rng = np.random.RandomState(seed)
+  B, S, V, E, C, H, NS, TS = [D[k] for k in ("B", "S", "V", "E", "C", "H", "NS", "TS")]
+  text_len = np.array([9, 6, 4], np.int32)
+  text = rng.randint(1, V, size=(B, S)).astype(np.int32)
+  for b in range(B):
+    text[b, text_len[b]:] = 0
+  style_len = np.array([21, 13, 17], np.int32)
+  style = rng.standard_normal((B, TS, NS)).astype(np.float32)
+  for b in range(B):
+    style[b, style_len[b]:] = 0.0
+
+  class _DL(object):
+    params = {"src_vocab_size": V, "style_input": "wav"}
+
+  class _Model(object):
+    params = {"dtype": tf.float32}
+
+    def get_data_layer(self):
+      return _DL()
+  conv = [{"kernel_size": [5], "stride": [1], "num_channels": C, "padding": "SAME"} for _ in range(3)]
+  params = dict(src_emb_size=E, conv_layers=conv, activation_fn=tf.nn.relu, num_rnn_layers=1, rnn_cell_dim=H,
+                rnn_type=tf.contrib.cudnn_rnn.CudnnLSTM, use_cudnn_rnn=True, rnn_unidirectional=False,
+                cnn_dropout_prob=0.0, rnn_dropout_prob=0.0, zoneout_prob=0.0, data_format="channels_last",
+                style_embedding_enable=True,
+                style_embedding_params=dict(conv_layers=TACO_STYLE_CONV, num_rnn_layers=1, rnn_cell_dim=D["SH"],
+                                            rnn_unidirectional=True, rnn_type=tf.nn.rnn_cell.GRUCell,
+                                            emb_size=D["TOKE"], attention_layer_size=D["ATT"], num_tokens=D["NTOK"],
+                                            num_heads=D["HEADS"]),
+                dtype=tf.float32)
+  with tf.variable_scope("ForwardPass"):
+    res = Enc(params, _Model(), mode="train").encode(
+        {"source_tensors": [tf.constant(text), tf.constant(text_len), tf.constant(style), tf.constant(style_len)]})
+  outputs = res["outputs"]
+  R = rng.standard_normal(tuple(int(v) for v in outputs.get_shape())).astype(np.float32)
+  loss = tf.reduce_sum(outputs * tf.constant(R))
+  gvars = [v for v in tf.global_variables() if "moving_" not in v.name and "global_step" not in v.name]
+  names = [v.name.split(":")[0] for v in gvars]
+  with tf.Session() as sess:
+    for n, v in zip(names, gvars):
+      if v._var.dim() == 1 and "cudnn" not in n:
+        v.load(_np(v._var) + 0.2 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+    vals = sess.run({"out": outputs, "len": res["src_length"], "grads": tf.gradients(loss, gvars), "vars": list(gvars)})
+  out = {"dims": np.array([D[k] for k in sorted(D)], np.int32), "dim_names": np.array(sorted(D)), "text": text,
+         "text_len": text_len, "style": style, "style_len": style_len, "out": vals["out"],
+         "out_len": vals["len"].astype(np.int32), "R": R, "var_names": np.array(names)}
+  for n, v, g in zip(names, vals["vars"], vals["grads"]):
+    out["var/" + n] = v.astype(np.float32)
+    out["grad/" + n] = g.astype(np.float32)
+  return out
+
+
 def tacotron_infer(seed=59):
   """Tacotron2Decoder._decode in eval mode (decoders/tacotron2_decoder.py:378-428): TacotronHelper feeds every
   projected frame back through the pre-net, finished = round(sigmoid(stop logit)), the loop ends when every sample has
@@ -828,7 +895,7 @@ def t2s_loss(seed=53, B=3, NMEL=5, NMAG=7):
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder}
 
 
 def generate(name):

@@ -88,6 +88,54 @@ def test_oracle_reproduces_the_reference_tacotron_decoder(case):
   print("%s: worst gradient error vs the reference's code %.2e" % (case, worst))
 
 
+def test_oracle_reproduces_the_reference_tacotron_encoder_with_style_tokens():
+  """Tacotron2Encoder._encode + _embed_style (encoders/tacotron2_encoder.py:104-505) executed from the reference's
+  file: embedding, three conv + BatchNorm + ReLU layers, the cuDNN bidirectional LSTM over the whole padded length
+  (torch.nn.LSTM on both sides: its wiring is what is pinned), and the global-style-token branch — two conv2d blocks
+  over the style spectrogram, the [B, T, F, C] flattening by tf.unstack / concat, tf.nn.rnn_cell.GRUCell under
+  dynamic_rnn with the shrunken lengths (final state), Dense(128, tanh), the reference's multi-head Attention in
+  "bahdanau" mode over tanh(token_embeddings) — tiled over time and concatenated to the encoder output.
+  oracle/tacotron.py:encoder + oracle/gst.py:style_encoder: outputs 1e-5, gradients of all 36 variables 1e-4."""
+  from oracle import gst as ogst
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_tacotron_encoder.npz")))
+  D = {str(k): int(v) for k, v in zip(d["dim_names"], d["dims"])}
+  names = [str(n) for n in d["var_names"]]
+  leaf = {n: torch.from_numpy(d["var/" + n].copy()).requires_grad_(True) for n in names}
+  E_ = "ForwardPass/tacotron2_encoder/"
+  ST = E_ + "style_encoder/"
+  PS = {"convs": [(leaf[ST + "conv%d/kernel" % i], leaf[ST + "conv%d/bn/gamma" % i], leaf[ST + "conv%d/bn/beta" % i])
+                  for i in (1, 2)],
+        "wg": leaf[ST + "rnn/multi_rnn_cell/cell_0/gru_cell/gates/kernel"],
+        "bg": leaf[ST + "rnn/multi_rnn_cell/cell_0/gru_cell/gates/bias"],
+        "wc": leaf[ST + "rnn/multi_rnn_cell/cell_0/gru_cell/candidate/kernel"],
+        "bc": leaf[ST + "rnn/multi_rnn_cell/cell_0/gru_cell/candidate/bias"],
+        "ref_w": leaf[ST + "reference_activation/kernel"], "ref_b": leaf[ST + "reference_activation/bias"],
+        "tokens": leaf[ST + "token_embeddings"], "wq": leaf[ST + "attention/q/kernel"],
+        "wk": leaf[ST + "attention/k/kernel"], "wv": leaf[ST + "attention/v/kernel"],
+        "wo": leaf[ST + "attention/output_transform/kernel"], "att_v": leaf[ST + "attention/attention_v"]}
+  style = ogst.style_encoder(PS, torch.from_numpy(d["style"]), torch.from_numpy(d["style_len"]),
+                             rx.gen.TACO_STYLE_CONV, D["HEADS"])
+  lstm = torch.nn.LSTM(D["C"], D["H"], num_layers=1, bidirectional=True, batch_first=True)
+  pn = [n for n, _ in lstm.named_parameters()]
+
+  class L(object):
+    def __call__(self, x):
+      return torch.func.functional_call(lstm, {n: leaf[E_ + n] for n in pn}, (x,))
+  P = {"emb": leaf[E_ + "EncoderEmbeddingMatrix"],
+       "convs": [(leaf[E_ + "conv%d/kernel" % i].permute(0, 2, 1), leaf[E_ + "conv%d/bn/gamma" % i],
+                  leaf[E_ + "conv%d/bn/beta" % i]) for i in (1, 2, 3)]}
+  out = otaco.encoder(P, torch.from_numpy(d["text"]), L(), bn_eps=1e-5, style=style)
+  assert d["out_len"].tolist() == d["text_len"].tolist()
+  assert rx.rel(out.detach().numpy(), d["out"]) < 1e-5
+  (out * torch.from_numpy(d["R"])).sum().backward()
+  worst = 0.0
+  for n in names:
+    r = rx.rel(leaf[n].grad.numpy(), d["grad/" + n])
+    worst = max(worst, r)
+    assert r < 1e-4, (n, r)
+  print("tacotron encoder + style tokens: worst gradient rel-L2 vs the reference's code %.2e" % worst)
+
+
 def test_oracle_reproduces_the_reference_free_running_decode():
   """Tacotron2Decoder._decode in eval mode (decoders/tacotron2_decoder.py:378-428; TacotronHelper,
   parts/tacotron/tacotron_helper.py:138-226) executed from the reference's files: every projected frame goes back
@@ -148,6 +196,6 @@ def test_oracle_reproduces_the_reference_text2speech_loss(case):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check",
-                      "tacotron_decoder", "t2s_loss", "tacotron_infer"], capture_output=True, text=True,
-                     timeout=900)
-  assert r.returncode == 0 and r.stdout.count("reproduced") == 3, r.stdout + r.stderr
+                      "tacotron_decoder", "t2s_loss", "tacotron_infer", "tacotron_encoder"], capture_output=True,
+                     text=True, timeout=900)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 4, r.stdout + r.stderr
