@@ -3,8 +3,10 @@ Tacotron2Encoder._embed_style (open_seq2seq/encoders/tacotron2_encoder.py:341-50
 conv2d(3x3, stride 2, SAME) + BN + ReLU stack, tf.nn.rnn_cell.GRUCell under
 dynamic_rnn(sequence_length) (final state), Dense(128, tanh), multi-head attention in
 "bahdanau" mode over tanh(style tokens) (parts/transformer/attention_layer.py:104-196).
-PARITY STATUS: unpinned by the reference; the GRUCell restatement is
-cross-checked against a direct per-step formula in tests/test_oracle_gst.py."""
+PARITY STATUS (round 5): pinned to the reference's OWN CODE — Tacotron2Encoder._embed_style executed from
+its file on the TF-primitive stand-in oracle/ref_shim/tf1 (tf.nn.rnn_cell.GRUCell is TF library code,
+restated there): style embedding and all gradients 7e-7 (tests/test_ref_exec_tacotron.py). The GRUCell
+restatement is also cross-checked against a direct per-step formula in tests/test_oracle_gst.py."""
 import torch
 
 from . import cnn

@@ -9,8 +9,9 @@ PARITY STATUS (round 5): decoder, free-running decoder_infer and text2speech_los
 reference's OWN CODE — Tacotron2Decoder._decode (train and eval mode), TacotronDecoder / helpers,
 LocationSensitiveAttention and Text2SpeechLoss executed from their files on the TF-primitive stand-in
 oracle/ref_shim/tf1 with the pre-net's dropout masks recorded: outputs 1e-5, gradients 3e-6, 30
-free-running steps 1e-4 with the same lengths (tests/test_ref_exec_tacotron.py). The encoder (cuDNN
-LSTM, global style tokens) is not executed: "parity unpinned"."""
+free-running steps 1e-4 with the same lengths; the encoder with global style tokens likewise (outputs
+1e-5, gradients 7e-7; the cuDNN LSTM is torch.nn.LSTM on both sides: its wiring is what is pinned) —
+tests/test_ref_exec_tacotron.py."""
 import torch
 import torch.nn.functional as F
 
