@@ -600,17 +600,23 @@ def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
   label_len = tlen[pick].to(torch.int64)
   labels = tgt[pick, :int(label_len.max())].to(torch.int64)
 
+  split = {"model": 0.0, "optimizer": 0.0}
+
   def step():
+    t_a = time.time()
     for t in tensors:
       t.grad = None
     out, olen = otdnn.tdnn_encode(x, lens, layers, w)
     _, loss = otdnn.fc_ctc(out, olen, fcw, fcb, labels, label_len)
     scale = float(opt.loss_scale)
     (loss * scale).backward()
+    t_b = time.time()
     opt.step([t.grad.numpy() for t in tensors])
     with torch.no_grad():
       for t, nw in zip(tensors, opt.w):
         t.copy_(torch.from_numpy(nw))
+    split["model"] += t_b - t_a
+    split["optimizer"] += time.time() - t_b         # batch-independent: 333 M parameters through NumPy
     return float(loss.detach())
 
   t_w = time.time()
@@ -618,12 +624,17 @@ def cpu_baseline(batch, vocab_size=29, budget_s=30.0):
     step()
   per = (time.time() - t_w) / 3
   nt = max(5, min(12, int(max(budget_s - 3 * per, 0.0) / max(per, 1e-3))))
+  split["model"] = split["optimizer"] = 0.0
   t0 = time.time()
   for _ in range(nt):
     step()
   dt = (time.time() - t0) / nt
   nframes = int(lens.sum())
   out = {"value": nframes / dt, "unit": "frames/sec", "cores": nthreads, "kind": "port",
+         # the step's two halves: forward + backward scale with the frames, the NumPy optimizer pass over the
+         # 333 M parameters does not — at the bench batch (32 utterances) the second term is amortised 8 x further
+         "seconds_per_step": {"forward_backward": split["model"] / nt, "optimizer": split["optimizer"] / nt},
+         "frames_per_sec_forward_backward_only": nframes / max(split["model"] / nt, 1e-9),
          "sample": "Jasper10x5 oracle train step (fp32 torch-CPU + NumPy NovoGrad) on %d utterances of "
                    "the bench batch at the 0, 1/3, 2/3, 1 quantiles of its lengths (%s frames, padded "
                    "to %d), 3 warm-up + %d timed steps, %.2f s/step"
