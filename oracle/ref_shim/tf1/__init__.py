@@ -386,10 +386,27 @@ def convert_to_tensor(value, dtype=None, name=None, preferred_dtype=None):
   return Tensor(lambda v: _t(v, dtype=td), (value,), name=name or "const")
 
 
-constant = lambda value, dtype=None, shape=None, name="Const", verify_shape=False: (     # noqa: E731
-    convert_to_tensor(value, dtype, name) if shape is None else
-    Tensor(lambda v: _t(v, dtype=as_dtype(dtype).torch if dtype else None).expand(*_ishape(shape)).clone(),
-           (value,), name=name))
+_OP_NAMES = {}
+
+
+def _unique_op_name(base):
+  """TensorFlow's op naming inside the current name scope: base, base_1, base_2 ... (mp_wrapper_test.py:91 asserts
+  the name of a constant; only constants — and the reduction-axes constants reduce_* create — are named this way
+  here, every other node keeps its internal name)."""
+  key = "/".join(_NAME + [base])
+  n = _OP_NAMES.get(key, 0)
+  _OP_NAMES[key] = n + 1
+  return key if n == 0 else "%s_%d" % (key, n)
+
+
+def constant(value, dtype=None, shape=None, name="Const", verify_shape=False):
+  if shape is None:
+    t = convert_to_tensor(value, dtype, name)
+  else:
+    t = Tensor(lambda v: _t(v, dtype=as_dtype(dtype).torch if dtype else None).expand(*_ishape(shape)).clone(),
+               (value,), name=name)
+  t.name = _unique_op_name(name or "Const") + ":0"
+  return t
 
 
 def _ishape(shape):
@@ -408,8 +425,11 @@ class Graph(object):
     self.collections = {}
     self.seed = 0
 
+  @contextlib.contextmanager
   def as_default(self):
-    return contextlib.nullcontext(self)
+    """A fresh tf.Graph() made the default: the stand-in keeps ONE graph's state, so entering starts it over."""
+    reset_default_graph()
+    yield self
 
   def get_collection(self, name, scope=None):
     return get_collection(name, scope)
@@ -880,6 +900,7 @@ def reset_default_graph():
   global _GRAPH
   _GRAPH = Graph()
   _VARS.clear()
+  _OP_NAMES.clear()
   _VAR_NAMES.clear()
   _DEFAULT_NAMES.clear()
   _SCOPES[:] = [VariableScope("")]
@@ -1257,6 +1278,8 @@ def _reduce(name, fn):
   def op(input_tensor, axis=None, keepdims=None, name=None, reduction_indices=None, keep_dims=None):
     ax = axis if axis is not None else reduction_indices
     kd = _PYBOOL(keepdims if keepdims is not None else (keep_dims or False))
+    if ax is None:
+      _unique_op_name("Const")          # TensorFlow materialises range(rank) as a Const op for a full reduction
 
     def f(v, a):
       v = _t(v)
@@ -1639,6 +1662,12 @@ def _depthwise_conv2d(input, filter, strides, padding, rate=None, name=None, dat
   return Tensor(f, (input, filter), name="depthwise_conv2d")
 
 
+def _top_k(input, k=1, sorted=True, name=None):          # noqa: A002
+  vals = Tensor(lambda v, kk: torch.topk(_t(v), int(_t(kk)), dim=-1).values, (input, k), name="top_k")
+  idx = Tensor(lambda v, kk: torch.topk(_t(v), int(_t(kk)), dim=-1).indices.to(torch.int32), (input, k), name="top_k")
+  return vals, idx
+
+
 def sparse_tensor_to_dense(sp_input, default_value=0, validate_indices=True, name=None):
   def f(i, v, s):
     out = torch.full(_ishape(s), default_value, dtype=_t(v).dtype)
@@ -1654,7 +1683,7 @@ nn = types.SimpleNamespace(
     dropout=_dropout, sparse_softmax_cross_entropy_with_logits=_sparse_xent,
     softmax_cross_entropy_with_logits_v2=_soft_xent_v2, softmax_cross_entropy_with_logits=_soft_xent,
     moments=_moments, bias_add=_bias_add, l2_loss=lambda t, name=None: reduce_sum(square(t)) / 2.0,
-    ctc_greedy_decoder=_ctc_greedy_decoder, ctc_loss=_ctc_loss, depthwise_conv2d=None, l2_normalize=lambda x, axis=None, epsilon=1e-12, name=None, dim=None:
+    ctc_greedy_decoder=_ctc_greedy_decoder, ctc_loss=_ctc_loss, top_k=_top_k, depthwise_conv2d=None, l2_normalize=lambda x, axis=None, epsilon=1e-12, name=None, dim=None:
     x * rsqrt(maximum(reduce_sum(square(x), axis if axis is not None else dim, keepdims=True), epsilon)))
 
 
@@ -1692,6 +1721,8 @@ class Layer(object):
     return inputs
 
   def add_variable(self, name, shape, dtype=None, initializer=None, regularizer=None, trainable=True, **kw):
+    if dtype is None:       # tf.layers: a layer's variables take the layer's dtype = the dtype of its first input
+      dtype = self.dtype if self.dtype is not None else getattr(self, "_input_dtype", None)
     return get_variable(name, shape, dtype=dtype, initializer=initializer, regularizer=regularizer,
                         trainable=trainable and self.trainable)
 
@@ -1709,6 +1740,8 @@ class Layer(object):
   def _run(self, inputs, args, kwargs):
     if not self.built:
       first = inputs[0] if isinstance(inputs, (list, _tuple)) else inputs
+      if isinstance(first, Tensor) and first.dtype.is_floating:
+        self._input_dtype = first.dtype
       with variable_scope(_scope(), reuse=AUTO_REUSE):
         self.build(first.get_shape() if isinstance(first, Tensor) else None)
       self.built = True
@@ -2382,7 +2415,33 @@ contrib.opt.LazyAdamOptimizer = AdamOptimizer       # dense gradients: LazyAdam 
 
 learn = types.SimpleNamespace()
 app = types.SimpleNamespace(flags=types.SimpleNamespace(FLAGS=types.SimpleNamespace()), run=lambda *a, **k: None)
-test = types.SimpleNamespace(TestCase=object, main=lambda: None, is_gpu_available=lambda *a, **k: False)
+import unittest as _unittest
+
+
+class _TestCase(_unittest.TestCase):
+  """tf.test.TestCase: unittest + test_session + the array assertions (what the reference's *_test.py files use)."""
+
+  def setUp(self):
+    reset_default_graph()
+
+  def test_session(self, graph=None, config=None, use_gpu=False, force_gpu=False):
+    return Session()
+
+  session = test_session
+  cached_session = test_session
+
+  def assertAllEqual(self, a, b, msg=None):             # noqa: N802
+    np.testing.assert_array_equal(np.asarray(a), np.asarray(b), err_msg=msg or "")
+
+  def assertAllClose(self, a, b, rtol=1e-6, atol=1e-6, msg=None):      # noqa: N802
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=rtol, atol=atol, err_msg=msg or "")
+
+  def assertAllCloseAccordingToType(self, a, b, **kw):    # noqa: N802
+    self.assertAllClose(a, b)
+
+
+test = types.SimpleNamespace(TestCase=_TestCase, main=lambda *a, **k: _unittest.main(*a, **k),
+                             is_gpu_available=lambda *a, **k: False)
 gfile = types.SimpleNamespace()
 
 softmax, log_softmax, relu, dropout = _softmax, _log_softmax, nn.relu, _dropout
