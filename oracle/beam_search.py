@@ -8,7 +8,10 @@ the same gather-based formulation the reference builds as a tf.while_loop:
   helpers :421-541 (_log_prob_from_logits, _length_normalization, _expand_to_beam_size,
   _flatten/_unflatten_beam_dim, _gather_beams, _gather_topk_beams).
 
-Pinned to the reference's own known answers (beam_search_test.py: expand / flatten /
+PARITY STATUS (round 5): the whole search is pinned to the reference's OWN CODE — sequence_beam_search executed
+from its file on the TF-primitive stand-in oracle/ref_shim/tf1 (tf.while_loop restated as a traced loop): ids exact,
+scores 1e-5 in three regimes (tests/test_ref_exec_beam_search.py). Also
+pinned to the reference's own known answers (beam_search_test.py: expand / flatten /
 unflatten shapes, _gather_beams and _gather_topk_beams values) in
 tests/test_oracle_beam_search.py. tf.nn.top_k semantics: descending values, the LOWER index
 wins between equal values (a stable argsort of the negated values restates that). All score

@@ -209,10 +209,28 @@ class Tensor(object):
     Tensor._count += 1
     self._id = Tensor._count
     self.name = ("/".join(_NAME + [name or "op"])) + "_%d:0" % self._id
+    self._alt = None
     if build_value is not _MISSING:
       self._value = build_value
     else:
       self._value = self._compute(lambda t: t._value)
+      self._shadow()
+
+  def _shadow(self):
+    """Static-shape inference for loop bodies: a loop variable whose shape invariant leaves a dimension open carries
+    a second build value that is one longer there (`_alt`); every op evaluated on such inputs is evaluated on the
+    shadow values too, and a dimension in which the two results differ is reported as unknown (None) by .shape — as
+    TensorFlow reports it inside tf.while_loop, which is what makes the reference fall back to tf.shape()."""
+    found = []
+    _walk((self._args, self._kwargs), lambda t: found.append(t) or t)
+    if not any(t._alt is not None for t in found):
+      return
+    try:
+      alt = self._compute(lambda t: t._alt if t._alt is not None else t._value)
+    except Exception:      # the shadow is advisory: an op that cannot take the longer operand keeps a static shape
+      return
+    if isinstance(alt, torch.Tensor) and isinstance(self._value, torch.Tensor):
+      self._alt = alt
 
   def _compute(self, get):
     return self._fn(*_walk(self._args, get), **_walk(self._kwargs, get))
@@ -229,7 +247,16 @@ class Tensor(object):
 
   @property
   def shape(self):
-    return TensorShape(list(self._value.shape))
+    st = getattr(self, "_static_shape", None)
+    if st is not None:
+      return st
+    dims = list(self._value.shape)
+    alt = getattr(self, "_alt", None)
+    if alt is not None:
+      if alt.dim() != len(dims):
+        return TensorShape(None)
+      dims = [d if d == a else None for d, a in zip(dims, alt.shape)]
+    return TensorShape(dims)
 
   def get_shape(self):
     return self.shape
@@ -1198,9 +1225,14 @@ def scatter_nd(indices, updates, shape, name=None):       # noqa: A002
 def where(condition, x=None, y=None, name=None):
   if x is None and y is None:
     return Tensor(lambda c: torch.nonzero(_t(c)), (condition,), name="where")
-  return Tensor(lambda c, a, b: torch.where(_t(c), _t(a, like=_t(b) if isinstance(b, torch.Tensor) else None),
-                                            _t(b, like=_t(a) if isinstance(a, torch.Tensor) else None)),
-                (condition, x, y), name="select")
+  def sel(c, a, b):
+    c = _t(c)
+    a = _t(a, like=_t(b) if isinstance(b, torch.Tensor) else None)
+    b = _t(b, like=a)
+    if c.dim() == 1 and a.dim() > 1:          # tf.where with a vector condition selects whole ROWS of x / y
+      c = c.reshape([-1] + [1] * (a.dim() - 1))
+    return torch.where(c, a, b)
+  return Tensor(sel, (condition, x, y), name="select")
 
 
 def sequence_mask(lengths, maxlen=None, dtype=bool, name=None):
@@ -1314,6 +1346,7 @@ reduce_min = _reduce("reduce_min", _amin)
 reduce_any = _reduce("reduce_any", lambda v, a, kd: v.to(torch.int32).sum(dim=a, keepdim=kd) > 0)
 reduce_all = _reduce("reduce_all", lambda v, a, kd: (~v).to(torch.int32).sum(dim=a, keepdim=kd) == 0)
 reduce_prod = _reduce("reduce_prod", lambda v, a, kd: _prod(v, a, kd))
+reduce_logsumexp = _reduce("reduce_logsumexp", lambda v, a, kd: torch.logsumexp(v, dim=a, keepdim=kd))
 
 
 def _prod(v, a, kd):
@@ -2455,6 +2488,7 @@ nn.rnn_cell = types.SimpleNamespace(
     GRUCell=_rnn.GRUCell, LSTMStateTuple=_rnn.LSTMStateTuple, ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper)
 nn.dynamic_rnn, nn.bidirectional_dynamic_rnn = _rnn.dynamic_rnn, _rnn.bidirectional_dynamic_rnn
 nn.embedding_lookup = _rnn.embedding_lookup
+while_loop = _rnn.while_loop
 contrib.rnn = types.SimpleNamespace(MultiRNNCell=_rnn.MultiRNNCell, ResidualWrapper=_rnn.ResidualWrapper,
                                     LSTMStateTuple=_rnn.LSTMStateTuple, DropoutWrapper=_rnn.DropoutWrapper,
                                     LSTMCell=_rnn.LSTMCell, BasicLSTMCell=_rnn.BasicLSTMCell, RNNCell=_rnn.RNNCell)

@@ -627,5 +627,47 @@ def _transpose_batch_time(x):
   return Tensor(lambda v: _t(v).transpose(0, 1), (x,), name="transpose_batch_time")
 
 
+def while_loop(cond, body, loop_vars, shape_invariants=None, parallel_iterations=10, back_prop=True,
+               swap_memory=False, name=None, maximum_iterations=None, return_same_structure=False):
+  """tf.while_loop: cond and body are CALLED ONCE on loop-variable slots (that is how TensorFlow builds the loop) and
+  the two recorded graphs are replayed while cond holds; loop variables may change shape between iterations (the
+  shape_invariants of the caller say the same)."""
+  single = not isinstance(loop_vars, (list, _tuple))
+  lv = [loop_vars] if single else list(loop_vars)
+  slots_struct, slots = _slots_like(lv)
+  if shape_invariants is not None:
+    inv = flatten([shape_invariants] if single else list(shape_invariants))
+    for sl, sh in zip(slots, inv):
+      if isinstance(sh, TensorShape) and sh.dims is not None and any(d is None for d in sh.dims):
+        v = sl._value
+        if len(sh.dims) == v.dim():
+          pad = []
+          for d in reversed(sh.dims):            # one longer wherever the invariant leaves the dimension open
+            pad += [0, 1 if d is None else 0]
+          sl._alt = torch.nn.functional.pad(v, pad)
+          sl._static_shape = sh
+  c = cond(*slots_struct)
+  out = body(*slots_struct)
+  if not isinstance(out, (list, _tuple)):
+    out = [out]
+  out_flat = flatten(list(out))
+  if len(out_flat) != len(slots):
+    raise ValueError("while_loop: body returned %d tensors for %d loop variables" % (len(out_flat), len(slots)))
+  tc, tb = Traced(slots, [c]), Traced(slots, out_flat)
+  init_flat = flatten(lv)
+
+  def compute(ev):
+    vals = [ev(z) if isinstance(z, Tensor) else _t(z) for z in init_flat]
+    it = 0
+    while _PYBOOL(tc.run(ev, vals)[0]) and (maximum_iterations is None or it < int(maximum_iterations)):
+      vals = tb.run(ev, vals)
+      it += 1
+    return vals
+  deps = [z for z in init_flat if isinstance(z, Tensor)] + [c] + [o for o in out_flat if isinstance(o, Tensor)]
+  res = _outputs_of(compute, deps, len(slots), like=out_flat)
+  packed = pack_sequence_as(lv, res)
+  return packed[0] if single else packed
+
+
 def embedding_lookup(params, ids, partition_strategy="mod", name=None, validate_indices=True, max_norm=None):
   return Tensor(lambda p, i: _t(p)[_t(i).long()], (params, ids), name="embedding_lookup")

@@ -894,8 +894,50 @@ def t2s_loss(seed=53, B=3, NMEL=5, NMAG=7):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Transformer beam search: parts/transformer/beam_search.py:sequence_beam_search (the tf.while_loop over
+# _continue_search / _search_step with its alive / finished bookkeeping, length normalisation, 2 x beam candidates)
+# driven by a TABLE symbols_to_logits_fn: logits = table[step][last id] + cache["bias"] — the cache entry travels
+# through the search's expand / flatten / gather plumbing like the decoder's K / V tensors do.
+# ---------------------------------------------------------------------------------------------------------
+BEAM_CASES = {
+    "finishes": dict(B=3, V=9, beam=4, alpha=0.6, L=7, eos=1, eos_boost=1.5, seed=71),
+    "never_finishes": dict(B=2, V=7, beam=3, alpha=1.0, L=5, eos=1, eos_boost=-30.0, seed=73),
+    "early_stop": dict(B=2, V=8, beam=2, alpha=0.0, L=9, eos=1, eos_boost=6.0, seed=79),
+}
+
+
+def beam_tables(cfg):
+  rs = np.random.RandomState(cfg["seed"])
+  table = rs.standard_normal((cfg["L"] + 1, cfg["V"], cfg["V"])).astype(np.float32)
+  table[:, :, cfg["eos"]] += np.float32(cfg["eos_boost"])
+  bias = (0.5 * rs.standard_normal((cfg["B"], cfg["V"]))).astype(np.float32)
+  return table, bias
+
+
+def beam_search():
+  out = {}
+  for case, cfg in BEAM_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    bs = imp("open_seq2seq.parts.transformer.beam_search")
+    table, bias = beam_tables(cfg)
+    tab = tf.constant(table)
+
+    def fn(ids, i, cache):
+      last = ids[:, -1]
+      logits = tf.gather(tf.gather(tab, i), last) + cache["bias"]
+      return logits, cache
+    ids, scores = bs.sequence_beam_search(fn, tf.zeros([cfg["B"]], dtype=tf.int32), {"bias": tf.constant(bias)},
+                                          cfg["V"], cfg["beam"], cfg["alpha"], cfg["L"], cfg["eos"])
+    with tf.Session() as sess:
+      v = sess.run({"ids": ids, "scores": scores})
+    out[case + "/ids"], out[case + "/scores"] = v["ids"].astype(np.int32), v["scores"].astype(np.float32)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search}
 
 
 def generate(name):
