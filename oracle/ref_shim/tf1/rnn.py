@@ -641,11 +641,16 @@ def while_loop(cond, body, loop_vars, shape_invariants=None, parallel_iterations
       if isinstance(sh, TensorShape) and sh.dims is not None and any(d is None for d in sh.dims):
         v = sl._value
         if len(sh.dims) == v.dim():
-          pad = []
-          for d in reversed(sh.dims):            # one longer wherever the invariant leaves the dimension open
-            pad += [0, 1 if d is None else 0]
-          sl._alt = torch.nn.functional.pad(v, pad)
-          sl._static_shape = sh
+          # one longer in the LAST open dimension (never the leading one): the dimension that grows from one
+          # iteration to the next in the loops the reference writes (decoded length, cache length). Open leading
+          # dimensions (batch, beam) are tied across loop variables and do not change inside a loop: lengthening
+          # them independently per variable would make the shadow values inconsistent with each other
+          open_dims = [i for i, d in enumerate(sh.dims) if d is None and i > 0]
+          if open_dims:
+            pad = []
+            for i in reversed(_range(len(sh.dims))):
+              pad += [0, 1 if i == open_dims[-1] else 0]
+            sl._alt = torch.nn.functional.pad(v, pad)
   c = cond(*slots_struct)
   out = body(*slots_struct)
   if not isinstance(out, (list, _tuple)):

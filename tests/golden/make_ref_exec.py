@@ -168,6 +168,50 @@ def transformer(seed=11, dims=(3, 11, 9, 45, 32, 4, 64, 2), store_vars=True):
   return out
 
 
+def transformer_infer(seed=13, dims=(3, 8, 40, 32, 4, 64, 2), beam=3, extra=4):
+  """TransformerEncoder + TransformerDecoder.predict in infer mode (decoders/transformer_decoder.py:232-326): the
+  cached decode step (_get_symbols_to_logits_fn: embedding of the last id, timing signal row i, self-attention bias
+  slice, K / V cache concatenation inside the reference's Attention layers) under sequence_beam_search's tf.while_loop;
+  returns the top beam's ids. Variables are stored (no gradients)."""
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  TransformerEncoder = imp("open_seq2seq.encoders.transformer_encoder").TransformerEncoder
+  TransformerDecoder = imp("open_seq2seq.decoders.transformer_decoder").TransformerDecoder
+  rng = np.random.RandomState(seed)
+  B, S, V, D, H, F, NL = dims
+  src_len = np.array([8, 5, 3], np.int32)
+  src = np.zeros((B, S), np.int32)
+  for b in range(B):
+    src[b, :src_len[b]] = rng.randint(2, V, size=src_len[b])
+  enc_params = dict(encoder_layers=NL, hidden_size=D, num_heads=H, attention_dropout=0.1, filter_size=F,
+                    src_vocab_size=V, relu_dropout=0.1, layer_postprocess_dropout=0.1, remove_padding=True,
+                    dtype=tf.float32)
+  dec_params = dict(EOS_ID=1, layer_postprocess_dropout=0.1, num_hidden_layers=NL, hidden_size=D, num_heads=H,
+                    attention_dropout=0.1, relu_dropout=0.1, filter_size=F, batch_size=B, tgt_vocab_size=V,
+                    beam_size=beam, alpha=0.6, extra_decode_length=extra, GO_SYMBOL=1, PAD_SYMBOL=0, END_SYMBOL=1,
+                    dtype=tf.float32)
+  with tf.variable_scope("ForwardPass"):
+    encoder = TransformerEncoder(enc_params, None, mode="infer")
+    decoder = TransformerDecoder(dec_params, None, mode="infer")
+    enc_out = encoder.encode({"source_tensors": [tf.constant(src), tf.constant(src_len)]})
+    dec_out = decoder.decode({"encoder_output": enc_out})
+  gvars = tf.trainable_variables()
+  names = [v.name.split(":")[0] for v in gvars]
+  with tf.Session() as sess:
+    for n, v in zip(names, gvars):
+      if "layer_norm" in n:
+        v.load(_np(v._var) + 0.1 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+      elif n.endswith("embedding_and_softmax/weights"):
+        v.load(3.0 * _np(v._var))          # a sharper output distribution: well separated beams
+    vals = sess.run({"ids": dec_out["outputs"][0], "logits": dec_out["logits"], "vars": list(gvars)})
+  out = {"src": src, "src_len": src_len, "ids": vals["ids"].astype(np.int32), "logits": vals["logits"],
+         "config": np.array(list(dims) + [beam, extra], np.int32), "var_names": np.array(names)}
+  for n, v in zip(names, vals["vars"]):
+    out["var/" + n] = v.astype(np.float32)
+  return out
+
+
 def transformer_d512():
   """The same graph at the narrowest widths the HIP kernels take (head dim 64, LayerNorm rows of 512 or 1024):
   d_model 512, 8 heads, filter 1024, 2 + 2 layers, V 90 -> 96. Variables come from seeded_array (not stored),
@@ -937,7 +981,7 @@ def beam_search():
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer}
 
 
 def generate(name):

@@ -97,6 +97,33 @@ def test_oracle_reproduces_the_reference_transformer(fixture):
   print("worst gradient rel-L2 vs the reference's code: %.2e" % worst)
 
 
+def test_oracle_reproduces_the_reference_cached_beam_decode():
+  """TransformerDecoder.predict in infer mode (decoders/transformer_decoder.py:232-326) executed from the reference's
+  files: the cached decode step (embedding of the last id + timing-signal row i, the self-attention bias slice, K / V
+  caches concatenated inside the reference's Attention layers and gathered per surviving beam) under
+  sequence_beam_search's while loop. The oracle composition the device's beam-search test uses —
+  oracle/beam_search.py driving oracle/transformer.py's decoder_pass on the growing prefix (no cache: the cache is an
+  optimisation, the logits are the same function of the prefix) — must return the same top-beam ids, exactly."""
+  from oracle import beam_search as obs
+  d, names = rx.load("transformer_infer")
+  B, S, V, D, H, F, NL, beam, extra = [int(v) for v in d["config"]]
+  PE, PD, leaves = oracle_params(d, NL, names)
+  with torch.no_grad():
+    src = torch.from_numpy(d["src"]).long()
+    enc_out, bias = ot.encoder(src, PE, H)
+
+    def fn(ids, i, cache):
+      tgt = torch.from_numpy(np.concatenate([ids[:, 1:], np.zeros((ids.shape[0], 1), ids.dtype)], 1)).long()
+      logits = ot.decoder_pass(tgt, torch.from_numpy(cache["enc"]), torch.from_numpy(cache["bias"]), PD, H)
+      return logits[:, i, :].numpy(), cache
+    ids, scores = obs.sequence_beam_search(fn, np.zeros(B, np.int32), {"enc": enc_out.numpy(), "bias": bias.numpy()},
+                                           V, beam, 0.6, S + extra, 1)
+  top = ids[:, 0, 1:]
+  assert top.shape == d["ids"].shape, (top.shape, d["ids"].shape)
+  assert np.array_equal(top, d["ids"]), (top, d["ids"])
+  assert len({tuple(r) for r in d["ids"].tolist()}) == B, "three different hypotheses"
+
+
 def test_fixture_has_the_cases_that_matter():
   d, _ = load_fixture()
   B, S, T, V, D, H, F, NL = [int(v) for v in d["config"]]
@@ -111,5 +138,5 @@ def test_fixture_has_the_cases_that_matter():
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check", "transformer",
-                      "transformer_d512"], capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0 and r.stdout.count("reproduced") == 2, r.stdout + r.stderr
+                      "transformer_d512", "transformer_infer"], capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 3, r.stdout + r.stderr
