@@ -122,6 +122,10 @@ def test_oracle_reproduces_the_reference_cached_beam_decode():
   assert top.shape == d["ids"].shape, (top.shape, d["ids"].shape)
   assert np.array_equal(top, d["ids"]), (top, d["ids"])
   assert len({tuple(r) for r in d["ids"].tolist()}) == B, "three different hypotheses"
+  # predict() ends with decode_pass(top ids) (transformer_decoder.py:318-320): the logits it returns
+  with torch.no_grad():
+    lg = ot.decoder_pass(torch.from_numpy(d["ids"]).long(), enc_out, bias, PD, H)
+  assert rel(lg.numpy(), d["logits"]) < 1e-5
 
 
 def test_fixture_has_the_cases_that_matter():
