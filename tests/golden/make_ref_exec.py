@@ -96,7 +96,9 @@ def seeded_array(name, shape, seed, scale=None):
   x = rs.standard_normal(shape).astype(np.float32)
   if len(shape) >= 2:
     return x * np.float32(scale if scale is not None else 1.0 / np.sqrt(shape[-2] if "embedding" not in name else shape[-1]))
-  return (np.float32(1.0) if name.endswith(("scale", "gamma")) else np.float32(0.0)) + np.float32(0.1) * x
+  if name.endswith("attention_v"):        # a score vector of unit scale: attention that is not uniform
+    return x
+  return (np.float32(1.0) if name.endswith(("scale", "gamma", "attention_g")) else np.float32(0.0)) + np.float32(0.1) * x
 
 
 def projection(name, g, seed):
@@ -980,8 +982,65 @@ def beam_search():
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The whole RNN NMT model at widths the HIP kernels take (attention depth 128): BidirectionalRNNEncoderWithEmbedding ->
+# RNNDecoderWithAttention (gnmt_v2) -> BasicSequenceLoss, chained as models/encoder_decoder.py chains them. Variables
+# from seeded_array (not stored), gradients as (norm, projection).
+# ---------------------------------------------------------------------------------------------------------
+NMT_FULL = dict(B=4, S=11, T=9, V=30, E=64, H=64, U=128, layers=2)
+
+
+def nmt_full(seed=67):
+  D = NMT_FULL
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  Enc = imp("open_seq2seq.encoders.rnn_encoders").BidirectionalRNNEncoderWithEmbedding
+  Dec = imp("open_seq2seq.decoders.rnn_decoders").RNNDecoderWithAttention
+  Loss = imp("open_seq2seq.losses.sequence_loss").BasicSequenceLoss
+  rng = np.random.RandomState(seed)
+  B, S, T, V, E, H, U, NL = [D[k] for k in ("B", "S", "T", "V", "E", "H", "U", "layers")]
+  src_len = np.array([11, 6, 9, 3], np.int32)
+  tgt_len = np.array([9, 4, 7, 2], np.int32)
+  src = rng.randint(4, V, size=(B, S)).astype(np.int32)
+  tgt = rng.randint(4, V, size=(B, T)).astype(np.int32)
+  for b in range(B):
+    src[b, src_len[b]:] = 0
+    tgt[b, 0] = 2
+    tgt[b, tgt_len[b] - 1] = 1
+    tgt[b, tgt_len[b]:] = 0
+  cellp = {"num_units": H, "forget_bias": 1.0}
+  with tf.variable_scope("ForwardPass"):
+    enc = Enc(dict(src_vocab_size=V, src_emb_size=E, core_cell=tf.nn.rnn_cell.LSTMCell, core_cell_params=cellp,
+                   encoder_layers=NL, encoder_use_skip_connections=False, encoder_dp_input_keep_prob=1.0,
+                   encoder_dp_output_keep_prob=1.0, dtype=tf.float32), None, mode="train")
+    dec = Dec(dict(GO_SYMBOL=2, END_SYMBOL=1, tgt_vocab_size=V, tgt_emb_size=E, attention_layer_size=U,
+                   attention_type="gnmt_v2", core_cell=tf.nn.rnn_cell.LSTMCell, core_cell_params=dict(cellp),
+                   decoder_layers=NL, decoder_use_skip_connections=False, batch_size=B,
+                   decoder_dp_input_keep_prob=1.0, decoder_dp_output_keep_prob=1.0, dtype=tf.float32), None,
+              mode="train")
+    eo = enc.encode({"source_tensors": [tf.constant(src), tf.constant(src_len)]})
+    do = dec.decode({"encoder_output": eo, "target_tensors": [tf.constant(tgt), tf.constant(tgt_len)]})
+    loss = Loss(dict(tgt_vocab_size=V, batch_size=B, offset_target_by_one=True, average_across_timestep=False,
+                     do_mask=True, dtype=tf.float32), None).compute_loss(
+        {"decoder_output": do, "target_tensors": [tf.constant(tgt), tf.constant(tgt_len)]})
+  tvars = tf.trainable_variables()
+  names = [v.name.split(":")[0] for v in tvars]
+  with tf.Session() as sess:
+    for n, v in zip(names, tvars):
+      v.load(seeded_array(n, tuple(v._var.shape), seed))
+    vals = sess.run({"enc": eo["outputs"], "logits": do["logits"], "loss": loss, "grads": tf.gradients(loss, tvars)})
+  out = {"src": src, "src_len": src_len, "tgt": tgt, "tgt_len": tgt_len, "enc_out": vals["enc"].astype(np.float16),
+         "logits": vals["logits"], "loss": np.float32(vals["loss"]), "var_names": np.array(names),
+         "seed": np.int32(seed)}
+  for n, v, g in zip(names, tvars, vals["grads"]):
+    out["shape/" + n] = np.array(tuple(v._var.shape), np.int32)
+    out["gproj/" + n] = projection(n, g, seed)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full}
 
 
 def generate(name):
