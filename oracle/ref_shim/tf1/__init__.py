@@ -1549,11 +1549,13 @@ def _log_softmax(logits, axis=None, name=None, dim=None):
 
 
 DROPOUT_TAP = None      # fixture generator's tap: when a list, every evaluated dropout appends its scaled keep mask
+DROPOUT_OFF = False     # fixture generator's switch: dropout passes its input through (the deterministic part of a
+                        # graph whose dropout cannot be configured away: Tacotron's pre-net, rate 0.5 in every mode)
 
 
 def _dropout(x, keep_prob=None, noise_shape=None, seed=None, name=None, rate=None):
   kp = keep_prob if keep_prob is not None else (None if rate is None else 1.0 - rate)
-  if not isinstance(kp, Tensor) and float(kp) == 1.0:
+  if DROPOUT_OFF or (not isinstance(kp, Tensor) and float(kp) == 1.0):
     return identity(x)                # TF: keep_prob == 1 returns x itself
 
   def f(v, k):

@@ -96,8 +96,8 @@ def seeded_array(name, shape, seed, scale=None):
   x = rs.standard_normal(shape).astype(np.float32)
   if len(shape) >= 2:
     return x * np.float32(scale if scale is not None else 1.0 / np.sqrt(shape[-2] if "embedding" not in name else shape[-1]))
-  if name.endswith("attention_v"):        # a score vector of unit scale: attention that is not uniform
-    return x
+  if name.endswith("attention_v"):        # scores of a few units at depth 128: attention that is neither uniform nor
+    return np.float32(0.2) * x            # one-hot (a one-hot softmax flips under a bf16 ulp: nothing to compare)
   return (np.float32(1.0) if name.endswith(("scale", "gamma", "attention_g")) else np.float32(0.0)) + np.float32(0.1) * x
 
 
@@ -1039,8 +1039,89 @@ def nmt_full(seed=67):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The whole Tacotron 2 model at widths the HIP kernels take: Tacotron2Encoder (no style tokens) -> Tacotron2Decoder
+# ("both" mode, attention depth 128, attention bias) -> Text2SpeechLoss, train mode, the pre-net's dropout passed
+# through (tf1.DROPOUT_OFF: the device test runs with its pre-net dropout off as well). Variables from seeded_array,
+# gradients as (norm, projection).
+# ---------------------------------------------------------------------------------------------------------
+TACO_FULL = dict(B=3, S=12, T=24, V=40, E=64, Henc=32, H=64, NM=16, NG=24, pre=64, C=64, U=128,
+                 text_len=[12, 7, 10], spec_len=[24, 16, 8])
+
+
+def tacotron_full(seed=83):
+  D = TACO_FULL
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  tf.DROPOUT_OFF = True
+  try:
+    Enc = imp("open_seq2seq.encoders.tacotron2_encoder").Tacotron2Encoder
+    Dec = imp("open_seq2seq.decoders.tacotron2_decoder").Tacotron2Decoder
+    Loss = imp("open_seq2seq.losses.text2speech_loss").Text2SpeechLoss
+    rng = np.random.RandomState(seed)
+    B, S, T, V, E, NM, NG = [D[k] for k in ("B", "S", "T", "V", "E", "NM", "NG")]
+    text_len, spec_len = np.array(D["text_len"], np.int32), np.array(D["spec_len"], np.int32)
+    text = rng.randint(3, V, size=(B, S)).astype(np.int32)
+    spec = np.concatenate([rng.standard_normal((B, T, NM)) - 1.0, np.exp(rng.standard_normal((B, T, NG)) - 2.0)],
+                          -1).astype(np.float32)
+    spec = _np(__import__("torch").from_numpy(spec).to(__import__("torch").bfloat16).float())   # bf16 teacher frames
+    stop = (np.arange(T)[None, :] >= (spec_len[:, None] - 2)).astype(np.float32)
+
+    class _DL(object):
+      params = {"src_vocab_size": V, "num_audio_features": {"mel": NM, "magnitude": NG}, "output_type": "both"}
+      _exp_mag = True
+
+    class _Model(object):
+      params = {"dtype": tf.float32}
+
+      def get_data_layer(self):
+        return _DL()
+
+      def get_tf_dtype(self):
+        return tf.float32
+    conv = [{"kernel_size": [5], "stride": [1], "num_channels": D["C"], "padding": "SAME"} for _ in range(2)]
+    post = [{"kernel_size": [5], "stride": [1], "num_channels": D["C"], "padding": "SAME", "activation_fn": tf.nn.tanh},
+            {"kernel_size": [5], "stride": [1], "num_channels": D["C"], "padding": "SAME", "activation_fn": tf.nn.tanh},
+            {"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
+    with tf.variable_scope("ForwardPass"):
+      enc = Enc(dict(src_emb_size=E, conv_layers=conv, activation_fn=tf.nn.relu, num_rnn_layers=1,
+                     rnn_cell_dim=D["Henc"], rnn_type=tf.contrib.cudnn_rnn.CudnnLSTM, use_cudnn_rnn=True,
+                     rnn_unidirectional=False, cnn_dropout_prob=0.0, rnn_dropout_prob=0.0, zoneout_prob=0.0,
+                     data_format="channels_last", dtype=tf.float32), _Model(), mode="train")
+      dec = Dec(dict(attention_layer_size=D["U"], attention_type="location", attention_bias=True,
+                     decoder_cell_units=D["H"], decoder_cell_type=tf.nn.rnn_cell.LSTMCell, decoder_layers=2,
+                     enable_prenet=True, prenet_layers=2, prenet_units=D["pre"], enable_postnet=True,
+                     postnet_conv_layers=post, postnet_keep_dropout_prob=1.0, postnet_bn_momentum=0.1,
+                     postnet_bn_epsilon=1e-5, mask_decoder_sequence=True, zoneout_prob=0.0, dropout_prob=0.0,
+                     dtype=tf.float32), _Model(), mode="train")
+      tgt = [tf.constant(spec), tf.constant(stop), tf.constant(spec_len)]
+      eo = enc.encode({"source_tensors": [tf.constant(text), tf.constant(text_len)]})
+      do = dec.decode({"encoder_output": eo, "target_tensors": tgt})
+      loss = Loss(dict(use_mask=True), _Model()).compute_loss(
+          {"decoder_output": do, "target_tensors": tgt})
+    tvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in tvars]
+    mel, post_o, align, _, lens, mag = do["outputs"]
+    with tf.Session() as sess:
+      for n, v in zip(names, tvars):
+        v.load(seeded_array(n, tuple(v._var.shape), seed))
+      vals = sess.run({"enc": eo["outputs"], "mel": mel, "post": post_o, "stop": do["stop_token_prediction"],
+                       "mag": mag, "align": align, "loss": loss, "grads": tf.gradients(loss, tvars)})
+  finally:
+    tf.DROPOUT_OFF = False
+  out = {"text": text, "spec": spec, "stop_target": stop, "enc_out": vals["enc"].astype(np.float16),
+         "mel": vals["mel"], "post": vals["post"], "stop": vals["stop"], "mag": vals["mag"],
+         "align": vals["align"].astype(np.float16), "loss": np.float32(vals["loss"]), "var_names": np.array(names),
+         "seed": np.int32(seed)}
+  for n, v, g in zip(names, tvars, vals["grads"]):
+    out["shape/" + n] = np.array(tuple(v._var.shape), np.int32)
+    out["gproj/" + n] = projection(n, g, seed)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full}
 
 
 def generate(name):
