@@ -1120,8 +1120,53 @@ def tacotron_full(seed=83):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# DeepSpeech2 at widths the HIP kernels take (the device test's scaled-down case: 32 features, the configuration's own
+# conv2d kernels [11, 41] / [11, 21] with 32 channels, two bidirectional GRU-64 layers, dense 128) + the CTC decoder's
+# dense layer, surrogate loss sum(logits * R). Variables from seeded_array, gradients as (norm, projection).
+# ---------------------------------------------------------------------------------------------------------
+DS2_FULL = dict(B=3, T=48, F=32, H=64, NH=128, layers=2, V=29, lens=[48, 35, 22])
+DS2_FULL_CONV = [{"kernel_size": [11, 41], "stride": [2, 2], "num_channels": 32, "padding": "SAME"},
+                 {"kernel_size": [11, 21], "stride": [1, 2], "num_channels": 32, "padding": "SAME"}]
+
+
+def ds2_full(seed=89):
+  D = DS2_FULL
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  Enc = imp("open_seq2seq.encoders.ds2_encoder").DeepSpeech2Encoder
+  Dec = imp("open_seq2seq.decoders.fc_decoders").FullyConnectedCTCDecoder
+  rng = np.random.RandomState(seed)
+  B, T, F, H, NH, V = [D[k] for k in ("B", "T", "F", "H", "NH", "V")]
+  src_len = np.array(D["lens"], np.int32)
+  x = tdnn_input(seed, src_len, T, F)
+  with tf.variable_scope("ForwardPass"):
+    enc = Enc(dict(dropout_keep_prob=1.0, conv_layers=DS2_FULL_CONV, activation_fn=tf.nn.relu,
+                   num_rnn_layers=D["layers"], row_conv=False, n_hidden=NH, use_cudnn_rnn=True, rnn_cell_dim=H,
+                   rnn_type="cudnn_gru", rnn_unidirectional=False, bn_momentum=0.99, bn_epsilon=1e-3,
+                   dtype=tf.float32), None, name="ds2_encoder", mode="train")
+    eo = enc.encode({"source_tensors": [tf.constant(x), tf.constant(src_len)]})
+    do = Dec(dict(tgt_vocab_size=V, dtype=tf.float32), None, mode="train").decode({"encoder_output": eo})
+  logits = do["logits"]
+  R = rng.standard_normal(tuple(int(v) for v in logits.get_shape())).astype(np.float32)
+  loss = tf.reduce_sum(logits * tf.constant(R))
+  tvars = tf.trainable_variables()
+  names = [v.name.split(":")[0] for v in tvars]
+  with tf.Session() as sess:
+    for n, v in zip(names, tvars):
+      v.load(seeded_array(n, tuple(v._var.shape), seed))
+    vals = sess.run({"out": eo["outputs"], "len": eo["src_length"], "logits": logits, "grads": tf.gradients(loss, tvars)})
+  out = {"src_len": src_len, "out": vals["out"].astype(np.float16), "out_len": vals["len"].astype(np.int32),
+         "logits": vals["logits"], "R": R, "var_names": np.array(names), "seed": np.int32(seed)}
+  for n, v, g in zip(names, tvars, vals["grads"]):
+    out["shape/" + n] = np.array(tuple(v._var.shape), np.int32)
+    out["gproj/" + n] = projection(n, g, seed)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full}
 
 
 def generate(name):
