@@ -10,7 +10,12 @@ behaviour:
     zero-padded CENTRED to n_fft, frames = 1 + len(y)//hop, rfft of each frame;
   * librosa.filters.mel(sr, n_fft, n_mels, fmin=0, fmax=sr/2, htk=False, norm=1):
     Slaney mel scale + area normalisation, float32 result.
-PARITY STATUS: the reference's own test (speech_utils_test.py:45-85) pins only
+PARITY STATUS (round 5): the GLUE of all four paths (signal normalisation, pre-emphasis, FFT-size rule, log floors,
+slicing, padding to a multiple of pad_to, normalisation) is pinned to the reference's OWN get_speech_features,
+executed from its file with independent stand-ins for librosa / python_speech_features
+(oracle/ref_shim/audio_libs; tests/test_ref_exec_frontend.py: 3e-5 / 2e-5). The libraries' own arithmetic stays a
+restatement (now written twice, independently). Before that:
+the reference's own test (speech_utils_test.py:45-85) pins only
 shapes and mean~0/std~1 — no feature values — and only for the psf backend:
 "parity unpinned" for the values; the pieces are cross-checked against
 scipy.signal.stft and closed forms in tests/test_oracle_speech_features.py.

@@ -1165,8 +1165,73 @@ def ds2_full(seed=89):
   return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# ASR front end: get_speech_features (data/speech2text/speech_utils.py:274-535) executed from the reference's file with
+# stand-ins for librosa / python_speech_features (oracle/ref_shim/audio_libs): the librosa 'logfbank' path of the
+# Jasper configs (64 mel bands, n_fft 512, per-feature normalisation, dither with a seeded np.random), the librosa
+# 'spectrogram' path, and the psf 'spectrogram' (DeepSpeech2 configs, padded to a multiple of 8 frames) and 'logfbank'
+# (the toy Wave2Letter config) paths.
+# ---------------------------------------------------------------------------------------------------------
+FRONTEND_CASES = {
+    "jasper_logfbank": dict(backend="librosa", input_type="logfbank", num_audio_features=64, window_size=20e-3,
+                            window_stride=10e-3, window="hanning", dither=1e-5, num_fft=512, norm_per_feature=True),
+    "librosa_spectrogram": dict(backend="librosa", input_type="spectrogram", num_audio_features=96, window="hanning"),
+    "ds2_psf_spectrogram": dict(input_type="spectrogram", num_audio_features=160, pad_to=8),
+    "w2l_psf_logfbank": dict(backend="psf", input_type="logfbank", num_audio_features=40, pad_to=8),
+}
+
+
+TTS_CASES = {
+    "tts_both_power2": dict(num_features={"mel": 80, "magnitude": 401}, n_fft=800, mag_power=2,
+                            data_min={"mel": 1e-5, "magnitude": 1e-5}),
+    "tts_both_power1": dict(num_features={"mel": 40, "magnitude": 257}, n_fft=512, mag_power=1,
+                            data_min={"mel": 1e-2, "magnitude": 1e-3}),
+}
+
+
+def frontend_signal(seed=97, n=7013):
+  rs = np.random.RandomState(seed)
+  t = np.arange(n) / 16000.0
+  sig = 0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.1 * np.sin(2 * np.pi * 3100.0 * t * (1 + 0.2 * t)) + \
+      0.05 * rs.standard_normal(n)
+  return (sig * 20000).astype(np.int16)
+
+
+def frontend():
+  sys.path.insert(0, os.path.join(REPO, "oracle", "ref_shim"))
+  import audio_libs
+  audio_libs.install()
+  _install()
+  import importlib
+  for k in [k for k in sys.modules if k.startswith("open_seq2seq.data.speech2text.speech_utils")]:
+    del sys.modules[k]
+  su = importlib.import_module("open_seq2seq.data.speech2text.speech_utils")
+  assert "librosa" in su.BACKENDS
+  sig = frontend_signal()
+  out = {"signal": sig}
+  # the TTS features of the Tacotron configs (data/text2speech/speech_utils.py:98-182: periodic-Hann STFT at hop
+  # n_fft / 4, |D| ^ power, log(clip(., data_min)), HTK mel basis without normalisation, "both" = [mel, magnitude])
+  for k in [k for k in sys.modules if k.startswith("open_seq2seq.data.text2speech")]:
+    del sys.modules[k]
+  pkg = types.ModuleType("open_seq2seq.data.text2speech")
+  pkg.__path__ = [os.path.join(PKG, "data", "text2speech")]
+  sys.modules["open_seq2seq.data.text2speech"] = pkg
+  tts = importlib.import_module("open_seq2seq.data.text2speech.speech_utils")
+  fsig = sig.astype(np.float32) / 32768.0
+  for case, kw in TTS_CASES.items():
+    mel_f, mag_f = tts.get_speech_features(fsig, 22050, dict(kw["num_features"]), "both", kw["n_fft"], None,
+                                           kw["mag_power"], False, 0., 1., dict(kw["data_min"]))
+    out[case + "/mel"], out[case + "/mag"] = np.asarray(mel_f, np.float32), np.asarray(mag_f, np.float32)
+  for case, params in FRONTEND_CASES.items():
+    np.random.seed(1234)                     # the dither draw of the librosa path
+    feats, dur = su.get_speech_features(sig.copy(), 16000, dict(params))
+    out[case + "/features"] = np.asarray(feats, np.float32)
+    out[case + "/duration"] = np.float64(dur)
+  return out
+
+
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend}
 
 
 def generate(name):
