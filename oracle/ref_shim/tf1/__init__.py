@@ -118,6 +118,10 @@ class Dimension(int):
 
 class TensorShape(object):
   def __init__(self, dims):
+    if isinstance(dims, TensorShape):
+      dims = dims._dims
+    elif dims is not None and not hasattr(dims, "__iter__"):
+      dims = [dims]                               # TensorShape(5) is the shape [5]
     self._dims = None if dims is None else [None if d is None else Dimension(d) for d in dims]
 
   @property
@@ -920,7 +924,61 @@ class ConfigProto(object):
 
 def placeholder(dtype, shape=None, name=None):
   shp = [1 if d is None else int(d) for d in (shape or [])]
-  return Tensor(lambda: torch.zeros(shp, dtype=as_dtype(dtype).torch), (), name=name or "placeholder")
+  t = Tensor(lambda: torch.zeros(shp, dtype=as_dtype(dtype).torch), (), name=name or "placeholder")
+  t._fed = True
+  return t
+
+
+def constant_value(tensor, partial=False):
+  """tensor_util.constant_value: the NumPy value of a node that depends on no variable, placeholder, loop variable or
+  stateful op; None otherwise."""
+  if not isinstance(tensor, Tensor):
+    return np.asarray(tensor)
+  seen = {}
+
+  def const(t):
+    if id(t) in seen:
+      return seen[id(t)]
+    seen[id(t)] = False
+    ok = not (isinstance(t, Variable) or t._fn is None or t._stateful or getattr(t, "_fed", False)
+              or hasattr(t, "_deps"))
+    if ok:
+      found = []
+      _walk((t._args, t._kwargs), lambda a: found.append(a) or a)
+      ok = all(const(a) for a in found)
+    seen[id(t)] = ok
+    return ok
+  if not const(tensor):
+    return None
+  v = tensor._value
+  return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else None
+
+
+def tile_batch(t, multiplier, name=None):
+  """tf.contrib.seq2seq.tile_batch: every [B, ...] entry of the structure -> [B * multiplier, ...], each row repeated
+  `multiplier` times in place (b0, b0, ..., b1, b1, ...)."""
+  return _rnn.map_structure(
+      lambda x: Tensor(lambda v: torch.repeat_interleave(_t(v), int(multiplier), dim=0), (x,), name="tile_batch"), t)
+
+
+def gather_tree(step_ids, parent_ids, max_sequence_lengths, end_token, name=None):
+  """tf.contrib.seq2seq.gather_tree (the beam_search_ops kernel): [T, B, W] step ids and parent beams -> the full
+  sequence behind every final beam, read backwards from step min(T, max_sequence_lengths[b]) - 1; positions past that
+  length, and every position after a sequence's first end_token, hold end_token."""
+  def f(ids, par, lens, end):
+    ids, par, lens, end = _t(ids).long(), _t(par).long(), _t(lens).long(), int(_t(end))
+    T, B, W = ids.shape
+    out = torch.full((T, B, W), end, dtype=torch.long)
+    L = torch.clamp(lens, max=T)
+    cur = torch.arange(W).unsqueeze(0).expand(B, W).clone()      # the beam whose entry at step t is on the path
+    for t in _range(T - 1, -1, -1):
+      on = (t < L).unsqueeze(1).expand(B, W)
+      out[t] = torch.where(on, torch.gather(ids[t], 1, cur), out[t])
+      cur = torch.where(on, torch.gather(par[t], 1, cur), cur)
+    ended = torch.cumsum((out == end).long(), 0) - (out == end).long() > 0      # an end_token strictly earlier
+    out = torch.where(ended, torch.full_like(out, end), out)
+    return out.to(torch.int32)
+  return Tensor(f, (step_ids, parent_ids, max_sequence_lengths, end_token), name="gather_tree")
 
 
 def reset_default_graph():
@@ -1246,15 +1304,16 @@ def sequence_mask(lengths, maxlen=None, dtype=bool, name=None):
 
 
 def one_hot(indices, depth, on_value=None, off_value=None, axis=None, dtype=None, name=None):
-  td = as_dtype(dtype or float32).torch
+  if dtype is None:
+    dtype = next((v.dtype for v in (on_value, off_value) if isinstance(v, Tensor)), float32)
+  td = as_dtype(dtype).torch
 
   def f(i, d, on, off):
     i = _t(i).long()
-    oh = torch.nn.functional.one_hot(i.clamp(min=0), int(_t(d))).to(td)
-    oh = oh * (i >= 0).unsqueeze(-1).to(td)
-    on = 1.0 if on is None else _t(on).to(td)
-    off = 0.0 if off is None else _t(off).to(td)
-    return oh * on + (1 - oh) * off
+    hit = torch.nn.functional.one_hot(i.clamp(min=0), int(_t(d))).bool() & (i >= 0).unsqueeze(-1)
+    on = torch.ones((), dtype=td) if on is None else _t(on).to(td)
+    off = torch.zeros((), dtype=td) if off is None else _t(off).to(td)
+    return torch.where(hit, on, off)           # a select: an infinite off_value stays out of the on positions
   return Tensor(f, (indices, depth, on_value, off_value), name="one_hot")
 
 
@@ -1698,9 +1757,14 @@ def _depthwise_conv2d(input, filter, strides, padding, rate=None, name=None, dat
 
 
 def _top_k(input, k=1, sorted=True, name=None):          # noqa: A002
-  vals = Tensor(lambda v, kk: torch.topk(_t(v), int(_t(kk)), dim=-1).values, (input, k), name="top_k")
-  idx = Tensor(lambda v, kk: torch.topk(_t(v), int(_t(kk)), dim=-1).indices.to(torch.int32), (input, k), name="top_k")
-  return vals, idx
+  """tf.nn.top_k: descending, the LOWER index first among equal values (a stable sort)."""
+  def f(v, kk, which):
+    r = torch.sort(_t(v), dim=-1, descending=True, stable=True)
+    return r.values[..., :int(_t(kk))] if which == 0 else r.indices[..., :int(_t(kk))].to(torch.int32)
+  return Tensor(f, (input, k, 0), name="top_k"), Tensor(f, (input, k, 1), name="top_k")
+
+
+top_k = _top_k
 
 
 def sparse_tensor_to_dense(sp_input, default_value=0, validate_indices=True, name=None):
@@ -2489,14 +2553,15 @@ nn.rnn_cell = types.SimpleNamespace(
     RNNCell=_rnn.RNNCell, LSTMCell=_rnn.LSTMCell, BasicLSTMCell=_rnn.BasicLSTMCell, MultiRNNCell=_rnn.MultiRNNCell,
     GRUCell=_rnn.GRUCell, LSTMStateTuple=_rnn.LSTMStateTuple, ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper)
 nn.dynamic_rnn, nn.bidirectional_dynamic_rnn = _rnn.dynamic_rnn, _rnn.bidirectional_dynamic_rnn
-nn.embedding_lookup = _rnn.embedding_lookup
+nn.embedding_lookup = embedding_lookup = _rnn.embedding_lookup
 while_loop = _rnn.while_loop
 contrib.rnn = types.SimpleNamespace(MultiRNNCell=_rnn.MultiRNNCell, ResidualWrapper=_rnn.ResidualWrapper,
                                     LSTMStateTuple=_rnn.LSTMStateTuple, DropoutWrapper=_rnn.DropoutWrapper,
                                     LSTMCell=_rnn.LSTMCell, BasicLSTMCell=_rnn.BasicLSTMCell, RNNCell=_rnn.RNNCell)
 contrib.seq2seq = types.SimpleNamespace(
     Decoder=_rnn.Decoder, Helper=_rnn.Helper, TrainingHelper=_rnn.TrainingHelper, BasicDecoder=_rnn.BasicDecoder,
-    BasicDecoderOutput=_rnn.BasicDecoderOutput, dynamic_decode=_rnn.dynamic_decode)
+    BasicDecoderOutput=_rnn.BasicDecoderOutput, dynamic_decode=_rnn.dynamic_decode, tile_batch=tile_batch,
+    gather_tree=gather_tree)
 
 slice = slice_          # noqa: A001  (the TF names; Python's own slice / range are not used below this line)
 range = range_          # noqa: A001
@@ -2547,7 +2612,8 @@ def install():
   sub("tensorflow.python.ops.rnn_cell", ResidualWrapper=_rnn.ResidualWrapper, DropoutWrapper=_rnn.DropoutWrapper,
       LSTMCell=_rnn.LSTMCell, MultiRNNCell=_rnn.MultiRNNCell, RNNCell=_rnn.RNNCell)
   sub("tensorflow.python.ops.tensor_array_ops", TensorArray=_rnn.TensorArray)
-  sub("tensorflow.python.framework.tensor_shape", TensorShape=TensorShape, Dimension=Dimension)
+  sub("tensorflow.python.framework.tensor_shape", TensorShape=TensorShape, Dimension=Dimension,
+      as_shape=lambda s: s if isinstance(s, TensorShape) else TensorShape(s))
   sub("tensorflow.python.layers.convolutional", Conv1D=Conv1D, Conv2D=Conv2D)
   sub("tensorflow.contrib.framework")
   sub("tensorflow.contrib.framework.python")
@@ -2559,6 +2625,9 @@ def install():
   sub("tensorflow.contrib.seq2seq.python.ops")
   sub("tensorflow.contrib.seq2seq.python.ops.decoder", Decoder=_rnn.Decoder, dynamic_decode=_rnn.dynamic_decode,
       _transpose_batch_time=_rnn._transpose_batch_time)
+  sub("tensorflow.contrib.seq2seq.python.ops.beam_search_ops", gather_tree=gather_tree)
+  sub("tensorflow.python.framework.tensor_util", constant_value=constant_value)
+  mods["tensorflow.python.ops.embedding_ops"] = me
   sub("tensorflow.contrib.seq2seq.python.ops.helper", Helper=_rnn.Helper, TrainingHelper=_rnn.TrainingHelper)
   sub("tensorflow.contrib")
   sub("tensorflow.contrib.cudnn_rnn", CudnnGRU=_CudnnGRU, CudnnLSTM=_CudnnLSTM)

@@ -543,7 +543,7 @@ def dynamic_decode(decoder, output_time_major=False, impute_finished=False, maxi
     fin = val(i_fin).bool()
     inp, st = [val(z) for z in i_in], [val(z) for z in i_st]
     max_it = None if maximum_iterations is None else int(val(maximum_iterations))
-    lens = torch.zeros(fin.shape[0], dtype=torch.int32)
+    lens = torch.zeros(fin.shape, dtype=torch.int32)       # [B], or [B, beam_width] under a beam-search decoder
     outs = [[] for _ in _range(n_o)]
     t = 0
     while not _PYBOOL(fin.all()) and (max_it is None or t < max_it):
@@ -562,7 +562,7 @@ def dynamic_decode(decoder, output_time_major=False, impute_finished=False, maxi
         outs[k].append(o[k])
       fin, inp, st = next_fin, ni, ns
       t += 1
-    stacked = [torch.stack(v, 0 if output_time_major else 1) if v else torch.zeros(0) for v in outs]
+    stacked = [torch.stack(v, 0) if v else torch.zeros(0) for v in outs]            # time-major, as TF stacks them
     return stacked + st + [lens]
   deps = [z for z in [i_fin] + i_in + i_st + [maximum_iterations] if isinstance(z, Tensor)] + \
       out_flat + ns_flat + ni_flat + [finished]
@@ -571,6 +571,8 @@ def dynamic_decode(decoder, output_time_major=False, impute_finished=False, maxi
   final_state = pack_sequence_as(next_state, res[n_o:n_o + n_s])
   lengths = res[-1]
   final_outputs, final_state = decoder.finalize(final_outputs, final_state, lengths)
+  if not output_time_major:                    # after finalize, as in TensorFlow (gather_tree reads [T, B, W])
+    final_outputs = map_structure(_transpose_batch_time, final_outputs)
   return final_outputs, final_state, lengths
 
 
@@ -618,9 +620,15 @@ class _TALoopOut(_TAMethods, _LoopOut):
   pass
 
 
-def TensorArray(dtype, size=0, dynamic_size=False, clear_after_read=None, element_shape=None, **kwargs):   # noqa: N802
-  td = as_dtype(dtype).torch
-  return TATensor(lambda: torch.zeros(0, dtype=td), (), name="tensor_array")
+class _TAMeta(type):
+  def __instancecheck__(cls, obj):          # isinstance(x, tf.TensorArray) (rnn_beam_search_decoder.py:128)
+    return isinstance(obj, _TAMethods)
+
+
+class TensorArray(object, metaclass=_TAMeta):   # noqa: N801
+  def __new__(cls, dtype, size=0, dynamic_size=False, clear_after_read=None, element_shape=None, **kwargs):
+    td = as_dtype(dtype).torch
+    return TATensor(lambda: torch.zeros(0, dtype=td), (), name="tensor_array")
 
 
 def _transpose_batch_time(x):

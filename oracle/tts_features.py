@@ -11,8 +11,11 @@ restated from its documented behaviour:
   * librosa.magphase(D, power) -> |D| ** power;
   * librosa.filters.mel(sr, n_fft, n_mels, htk=True, norm=None): HTK mel scale, unit-peak
     triangles (the TTS call site, :160-172).
-PARITY STATUS: unpinned by the reference (no TTS feature value tests); the STFT is
-cross-checked against scipy.signal.stft in tests/test_oracle_tts_features.py."""
+PARITY STATUS (round 5): the reference's own get_speech_features ("both": mel + magnitude, two parameter sets) is
+executed from its file on independent stand-ins for librosa.stft / magphase / filters.mel
+(oracle/ref_shim/audio_libs) and this restatement matches it to 1e-4 (tests/test_ref_exec_frontend.py); librosa's own
+arithmetic stays a restatement (no value tests in the reference); the STFT is cross-checked against
+scipy.signal.stft in tests/test_oracle_tts_features.py."""
 import math
 
 import numpy as np

@@ -53,8 +53,7 @@ def _install():
   dl = types.ModuleType("open_seq2seq.data.speech2text.speech2text")
   dl.Speech2TextDataLayer = type("Speech2TextDataLayer", (), {})
   sys.modules[dl.__name__] = dl
-  for name, attrs in (("open_seq2seq.parts.rnns.rnn_beam_search_decoder", ["BeamSearchDecoder"]),
-                      ("open_seq2seq.parts.rnns.weight_drop", ["WeightDropLayerNormBasicLSTMCell"]),
+  for name, attrs in (("open_seq2seq.parts.rnns.weight_drop", ["WeightDropLayerNormBasicLSTMCell"]),
                       ("open_seq2seq.parts.rnns.slstm", ["BasicSLSTMCell"]),
                       ("open_seq2seq.parts.rnns.glstm", ["GLSTMCell"]),
                       ("open_seq2seq.parts.rnns.zoneout", ["ZoneoutWrapper"])):
@@ -68,6 +67,8 @@ def _install():
   import collections.abc
   if not hasattr(collections, "Sequence"):      # the reference predates Python 3.10 (optimizers.py:441)
     collections.Sequence = collections.abc.Sequence
+  if "Inf" not in np.__dict__:                  # ... and NumPy 2.0 (rnn_beam_search_decoder.py:324)
+    np.Inf = np.inf
   import importlib
   enc = importlib.import_module("open_seq2seq.encoders.encoder")
   sys.modules["open_seq2seq.encoders"].Encoder = enc.Encoder
@@ -1040,6 +1041,72 @@ def nmt_full(seed=67):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# Beam-search inference of the RNN NMT model: BidirectionalRNNEncoderWithEmbedding (infer) ->
+# BeamSearchRNNDecoderWithAttention (decoders/rnn_decoders.py:324-532) over the reference's OWN BeamSearchDecoder
+# (parts/rnns/rnn_beam_search_decoder.py: initialize / step / _beam_search_step / _mask_probs / _get_scores /
+# finalize) under dynamic_decode(maximum_iterations = 2 * max source length). tile_batch, gather_tree, top_k and
+# dynamic_decode are TensorFlow library code (oracle/ref_shim/tf1). Same dims, source batch and variable seed as
+# nmt_full; matrices scaled by `gain` so that hypotheses separate, END chosen among the symbols this random model emits.
+# ---------------------------------------------------------------------------------------------------------
+NMT_BEAM_CASES = {
+    "lp0_beam4": dict(beam=4, lp=0.0, END=4, att="gnmt_v2"),       # two rows finish (lengths 1..6), two run to the cap
+    "lp03_beam4": dict(beam=4, lp=0.3, END=18, att="gnmt_v2"),     # finished and live hypotheses compete by penalty
+    "lp06_beam3_gnmt": dict(beam=3, lp=0.6, END=19, att="gnmt"),
+}
+NMT_BEAM_GAIN = 2.5
+
+
+def nmt_beam_variable(name, shape, seed=67):
+  a = seeded_array(name, shape, seed)
+  return a * np.float32(NMT_BEAM_GAIN) if a.ndim == 2 else a
+
+
+def nmt_beam(seed=67):
+  D = NMT_FULL
+  B, S, T, V, E, H, U, NL = [D[k] for k in ("B", "S", "T", "V", "E", "H", "U", "layers")]
+  rng = np.random.RandomState(seed)
+  src_len = np.array([11, 6, 9, 3], np.int32)
+  src = rng.randint(4, V, size=(B, S)).astype(np.int32)
+  for b in range(B):
+    src[b, src_len[b]:] = 0
+  out = {"src": src, "src_len": src_len, "seed": np.int32(seed)}
+  for case, cfg in NMT_BEAM_CASES.items():
+    tf, imp = _install()
+    tf.reset_default_graph()
+    tf.set_random_seed(seed)
+    Enc = imp("open_seq2seq.encoders.rnn_encoders").BidirectionalRNNEncoderWithEmbedding
+    Dec = imp("open_seq2seq.decoders.rnn_decoders").BeamSearchRNNDecoderWithAttention
+    cellp = {"num_units": H, "forget_bias": 1.0}
+    with tf.variable_scope("ForwardPass"):
+      enc = Enc(dict(src_vocab_size=V, src_emb_size=E, core_cell=tf.nn.rnn_cell.LSTMCell, core_cell_params=cellp,
+                     encoder_layers=NL, encoder_use_skip_connections=False, encoder_dp_input_keep_prob=1.0,
+                     encoder_dp_output_keep_prob=1.0, dtype=tf.float32), None, mode="infer")
+      dec = Dec(dict(GO_SYMBOL=2, END_SYMBOL=cfg["END"], tgt_vocab_size=V, tgt_emb_size=E, attention_layer_size=U,
+                     attention_type=cfg["att"], core_cell=tf.nn.rnn_cell.LSTMCell, core_cell_params=dict(cellp),
+                     decoder_layers=NL, decoder_use_skip_connections=False, batch_size=B,
+                     decoder_dp_input_keep_prob=1.0, decoder_dp_output_keep_prob=1.0, dtype=tf.float32,
+                     beam_width=cfg["beam"], length_penalty=cfg["lp"]), None, mode="infer")
+      eo = enc.encode({"source_tensors": [tf.constant(src), tf.constant(src_len)]})
+      do = dec.decode({"encoder_output": eo})
+    tvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in tvars]
+    st = do["final_state"]
+    with tf.Session() as sess:
+      for n, v in zip(names, tvars):
+        v.load(nmt_beam_variable(n, tuple(v._var.shape), seed))
+      vals = sess.run({"top": do["logits"], "lengths": st.lengths, "log_probs": st.log_probs, "finished": st.finished,
+                       "seq_len": do["final_sequence_lengths"]})
+    out.update({case + "/top_ids": vals["top"].astype(np.int32), case + "/lengths": vals["lengths"].astype(np.int32),
+                case + "/log_probs": vals["log_probs"].astype(np.float32),
+                case + "/finished": vals["finished"].astype(np.bool_),
+                case + "/final_sequence_lengths": vals["seq_len"].astype(np.int32),
+                case + "/var_names": np.array(names)})
+    for n, v in zip(names, tvars):
+      out["%s/shape/%s" % (case, n)] = np.array(tuple(v._var.shape), np.int32)
+  return out
+
+
+# ---------------------------------------------------------------------------------------------------------
 # The whole Tacotron 2 model at widths the HIP kernels take: Tacotron2Encoder (no style tokens) -> Tacotron2Decoder
 # ("both" mode, attention depth 128, attention bias) -> Text2SpeechLoss, train mode, the pre-net's dropout passed
 # through (tf1.DROPOUT_OFF: the device test runs with its pre-net dropout off as well). Variables from seeded_array,
@@ -1231,7 +1298,7 @@ def frontend():
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam}
 
 
 def generate(name):
