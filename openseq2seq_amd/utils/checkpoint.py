@@ -14,8 +14,15 @@ reference's variable name, in the reference's layout:
   shared embedding device [1, V, D]            -> embedding_and_softmax/weights [V, D]
   depthwise       device [K, C]                -> separable_conv1d depthwise_kernel [K, C, 1]
   BatchNorm       gamma / beta / moving_mean / moving_variance  (fp32, as is)
-  anything else   as is (conv2d kernels are already [KT, KF, Cin, Cout]; recurrent kernels keep the
-                  device gate order — see DESIGN.md)
+  LSTM cell       device wx_0 [1, 4H, in0], wx_1 ..., wh [1, 4H, H] (or kernel_inputs +
+                  kernel_attention_state)      -> ONE lstm_cell/kernel [in0 + in1 + ... + H, 4H] per cell
+                  (rows: the cell's inputs in order, then h; gate order i, j, f, o on both sides), under the
+                  scope names the reference's GRAPH gives them (bidirectional_rnn/fw/..., rnn/...,
+                  decoder/multi_rnn_cell/cell_0_attention/gnmt_attention/..., AttentionMechanism/...):
+                  the RNN NMT encoders and RNNDecoderWithAttention (gnmt / gnmt_v2), names checked against
+                  the reference's executed graphs (tests/golden/ref_exec_nmt_*.npz)
+  anything else   as is (conv2d kernels are already [KT, KF, Cin, Cout]; the recurrent layers of
+                  DeepSpeech2 / Tacotron 2 keep the device names and gate order — see DESIGN.md)
 
 In mixed precision a half-precision variable is written as DT_HALF (float16) under its plain
 name and as fp32 under the master-copy name — the dtypes a reference fp16 graph holds, so a
@@ -124,6 +131,58 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
   return a
 
 
+# ---------------------------------------------------------------------------------------------------------
+# RNN NMT models: device scope names -> the names of the reference's graph. The reference BUILDS its cells under
+# 'FW' / 'BW' / 'Level1FW' / 'UniDirLevel' (encoders/rnn_encoders.py:276-282, 392-417) but the variables are created
+# when bidirectional_dynamic_rnn / dynamic_rnn / dynamic_decode first call the cells, under THEIR scopes.
+# ---------------------------------------------------------------------------------------------------------
+_RNN_SCOPES = [
+    (r"/bidir_rnn_encoder_with_emb/FW/", "/bidir_rnn_encoder_with_emb/bidirectional_rnn/fw/"),
+    (r"/bidir_rnn_encoder_with_emb/BW/", "/bidir_rnn_encoder_with_emb/bidirectional_rnn/bw/"),
+    (r"/gnmt_encoder_with_emb/Level1FW/", "/gnmt_encoder_with_emb/bidirectional_rnn/fw/"),
+    (r"/gnmt_encoder_with_emb/Level1BW/", "/gnmt_encoder_with_emb/bidirectional_rnn/bw/"),
+    (r"/gnmt_encoder_with_emb/UniDirLevel/", "/gnmt_encoder_with_emb/rnn/"),
+    (r"/rnn_decoder_with_attention/attention_cell/cell_0/",
+     "/rnn_decoder_with_attention/decoder/multi_rnn_cell/cell_0_attention/gnmt_attention/lstm_cell/"),
+    (r"/rnn_decoder_with_attention/attention_cell/attention/memory_layer/",
+     "/rnn_decoder_with_attention/AttentionMechanism/memory_layer/"),
+    (r"/rnn_decoder_with_attention/attention_cell/attention/",
+     "/rnn_decoder_with_attention/decoder/multi_rnn_cell/cell_0_attention/gnmt_attention/bahdanau_attention/"),
+    (r"/rnn_decoder_with_attention/multi_rnn_cell/", "/rnn_decoder_with_attention/decoder/multi_rnn_cell/"),
+    (r"/rnn_decoder_with_attention/dense/", "/rnn_decoder_with_attention/decoder/dense/"),
+]
+_LSTM_PART = re.compile(r"^(.*)/(wx_(\d+)|wh|kernel_inputs|kernel_attention_state)$")
+
+
+def reference_name(name):
+  """device parameter name -> (reference variable name, rank of this parameter among the row blocks of that
+  variable or None when the parameter IS the variable)."""
+  for pat, rep in _RNN_SCOPES:
+    if pat in name:
+      name = name.replace(pat, rep, 1)
+      break
+  else:
+    return name, None
+  m = _LSTM_PART.match(name)
+  if not m:
+    return name, None
+  part = m.group(2)
+  order = int(m.group(3)) if m.group(3) is not None else {"kernel_inputs": 0, "kernel_attention_state": 1,
+                                                           "wh": 1 << 20}[part]
+  return m.group(1) + "/kernel", order
+
+
+def lstm_kernel_groups(params):
+  """{reference kernel name: [device parameters, in row order]} for the LSTM cells stored as one kernel by the
+  reference and as several matrices here."""
+  groups = {}
+  for p in params:
+    ref, order = reference_name(p.name)
+    if order is not None:
+      groups.setdefault(ref, []).append((order, p))
+  return {k: [p for _, p in sorted(v, key=lambda t: t[0])] for k, v in groups.items()}
+
+
 def _half_in_reference(p):
   """Is this variable DT_HALF with an fp32 master twin in a mixed-precision graph of the reference? Everything
   the mixed-precision wrapper sees (optimizers/mp_wrapper.py:55-82) — kernels AND the biases of dense / recurrent
@@ -143,9 +202,22 @@ def model_variables(model):
   store = model.store
   out = {}
   mixed = model.params.get("dtype", "mixed") == "mixed"
+  groups = lstm_kernel_groups(store.params)
+  grouped = {p.name for ps in groups.values() for p in ps}
+  for ref, ps in groups.items():
+    # [1, 4H, in_k] blocks -> one [sum in_k, 4H] kernel, the cell's inputs first, h last
+    k = np.concatenate([p.master.detach().cpu().numpy()[0].T for p in ps], axis=0)
+    if mixed:
+      out[ref] = k.astype(np.float16)
+      out[MASTER_PREFIX + ref] = k
+    else:
+      out[ref] = k
   for p in store.params:
+    if p.name in grouped:
+      continue
     arr = p.master.detach().cpu().numpy()
-    for tf_name, tf_arr in export_param(p.name, p.shape, p.kind, arr, getattr(p, "logical_out", None)):
+    for tf_name, tf_arr in export_param(reference_name(p.name)[0], p.shape, p.kind, arr,
+                                        getattr(p, "logical_out", None)):
       if mixed and _half_in_reference(p):
         # a mixed-precision graph of the reference holds this variable as DT_HALF and its fp32
         # twin under the master-copy name (optimizers/mp_wrapper.py:55-82): a plain
@@ -225,8 +297,25 @@ def load(model, prefix, restore_optimizer=True, strict=True):
   data = open_checkpoint(prefix)
   store = model.store
   missing = []
+  split = {}
+  for ref, ps in lstm_kernel_groups(store.params).items():
+    k = None
+    for n in (MASTER_PREFIX + ref, ref):
+      if n in data:
+        k = np.asarray(data[n], np.float32)
+        break
+    if k is None or k.ndim != 2 or k.shape != (sum(p.shape[2] for p in ps), ps[0].shape[1]):
+      continue                      # falls through to the per-parameter lookup below (and its diagnostics)
+    row = 0
+    for p in ps:
+      split[p.name] = k[row:row + p.shape[2]].T[None]
+      row += p.shape[2]
   for p in store.params:
-    a = import_param(p.name, p.shape, p.kind, data, getattr(p, "logical_out", None))
+    a = split.get(p.name)
+    if a is None:
+      a = import_param(reference_name(p.name)[0], p.shape, p.kind, data, getattr(p, "logical_out", None))
+    if a is None and reference_name(p.name)[0] != p.name:     # files this repository wrote before the translation
+      a = import_param(p.name, p.shape, p.kind, data, getattr(p, "logical_out", None))
     if a is None or tuple(a.shape) != tuple(p.shape):
       missing.append(p.name)
       continue

@@ -7,8 +7,14 @@ length), outputs = final_outputs.predicted_ids[:, :, 0]).
 BeamSearchDecoder lives in TensorFlow (tensorflow/contrib/seq2seq/python/ops/beam_search_decoder.py,
 TF 1.x), which is neither vendored in /root/reference nor installable here: its published algorithm
 (_beam_search_step, _mask_probs, _get_scores / _length_penalty, gather_tree in finalize) is
-restated — this piece is "parity unpinned" by the reference and is cross-checked against
-exhaustive search (tests/test_oracle_rnn_beam_search.py).
+restated and cross-checked against exhaustive search (tests/test_oracle_rnn_beam_search.py).
+PARITY STATUS (round 5): the reference carries its OWN copy of that class
+(parts/rnns/rnn_beam_search_decoder.py — beams 1.. start "finished" with log-probability -inf instead of
+the time-0 special case below; the same search) and THAT file is executed, under the reference's
+BeamSearchRNNDecoderWithAttention, on the TF-primitive stand-in oracle/ref_shim/tf1: this restatement
+returns the same winner ids, and every beam's length, finished flag and log-probability (1e-5), on three
+cases (tests/test_ref_exec_nmt_beam.py). tile_batch, gather_tree, top_k and dynamic_decode are
+TensorFlow library code, restated in the stand-in.
 
 One step, state = (log_probs [B,W], finished [B,W], lengths [B,W]):
   step_log_probs = log_softmax(logits); finished beams put all mass on END (_mask_probs: END -> 0,
@@ -90,7 +96,7 @@ def gather_tree(step_ids, parent_ids, max_lengths, end_token):
 
 
 def beam_search(logits_fn, B, beam_width, vocab_size, start_token, end_token, length_penalty_weight,
-                maximum_iterations):
+                maximum_iterations, return_log_probs=False):
   """logits_fn(ids [B*W] int, time, parent_rows [B*W] | None) -> logits [B*W, V]. Returns
   (predicted_ids [B, T, W], lengths [B, W], scores [B, W])."""
   W = beam_width
@@ -116,4 +122,6 @@ def beam_search(logits_fn, B, beam_width, vocab_size, start_token, end_token, le
   par = np.stack(hist_par, 0)
   max_len = lengths.max(1)
   pred = gather_tree(step_ids, par, max_len, end_token)
+  if return_log_probs:        # + final_state.log_probs / .finished of every beam
+    return np.transpose(pred, (1, 0, 2)), lengths, scores, log_probs, finished
   return np.transpose(pred, (1, 0, 2)), lengths, scores

@@ -1046,19 +1046,30 @@ def nmt_full(seed=67):
 # (parts/rnns/rnn_beam_search_decoder.py: initialize / step / _beam_search_step / _mask_probs / _get_scores /
 # finalize) under dynamic_decode(maximum_iterations = 2 * max source length). tile_batch, gather_tree, top_k and
 # dynamic_decode are TensorFlow library code (oracle/ref_shim/tf1). Same dims, source batch and variable seed as
-# nmt_full; matrices scaled by `gain` so that hypotheses separate, END chosen among the symbols this random model emits.
+# nmt_full.
 # ---------------------------------------------------------------------------------------------------------
 NMT_BEAM_CASES = {
-    "lp0_beam4": dict(beam=4, lp=0.0, END=4, att="gnmt_v2"),       # two rows finish (lengths 1..6), two run to the cap
-    "lp03_beam4": dict(beam=4, lp=0.3, END=18, att="gnmt_v2"),     # finished and live hypotheses compete by penalty
-    "lp06_beam3_gnmt": dict(beam=3, lp=0.6, END=19, att="gnmt"),
+    # matrices scaled by `gain`; END among the symbols this random model emits. A random recurrent model is an
+    # ill-conditioned beam-search problem (near-ties at the beam boundary at most steps): the cases are the ones, of
+    # a scan over (gain, END, penalty), where most rows' winners survive perturbations of bf16 size — see `stable`
+    "lp0_beam4": dict(beam=4, lp=0.0, END=4, att="gnmt_v2", gain=2.5),     # two rows finish (lengths 4 and 1), two run to the cap
+    "lp06_beam4": dict(beam=4, lp=0.6, END=18, att="gnmt_v2", gain=8.0),   # winners of lengths 2, 3, 4, 13
+    "lp1_beam3_gnmt": dict(beam=3, lp=1.0, END=18, att="gnmt", gain=8.0),
 }
-NMT_BEAM_GAIN = 2.5
+NMT_BEAM_PERTURBATIONS = 6
 
 
-def nmt_beam_variable(name, shape, seed=67):
+def nmt_beam_variable(name, shape, seed, gain, perturbation=None):
+  """The variable values of the beam-search fixture; perturbation k: every matrix entry times 1 + 2^-7 u, u ~ U(-1, 1)
+  (four times the rounding error of a bf16 weight)."""
+  import zlib
   a = seeded_array(name, shape, seed)
-  return a * np.float32(NMT_BEAM_GAIN) if a.ndim == 2 else a
+  if a.ndim == 2:
+    a = a * np.float32(gain)
+    if perturbation is not None:
+      rs = np.random.RandomState((zlib.crc32(name.encode()) + 1000 * perturbation) % (2 ** 31))
+      a = a * (1 + np.float32(2.0 ** -7) * rs.uniform(-1, 1, a.shape).astype(np.float32))
+  return a
 
 
 def nmt_beam(seed=67):
@@ -1093,13 +1104,22 @@ def nmt_beam(seed=67):
     st = do["final_state"]
     with tf.Session() as sess:
       for n, v in zip(names, tvars):
-        v.load(nmt_beam_variable(n, tuple(v._var.shape), seed))
+        v.load(nmt_beam_variable(n, tuple(v._var.shape), seed, cfg["gain"]))
       vals = sess.run({"top": do["logits"], "lengths": st.lengths, "log_probs": st.log_probs, "finished": st.finished,
                        "seq_len": do["final_sequence_lengths"]})
+      # which rows' winners are properties of the model rather than of the last bit: the reference's own answer under
+      # perturbations of bf16 size (the device computes in bf16; it is held to the `stable` rows exactly)
+      stable = np.ones(B, np.bool_)
+      for k in range(NMT_BEAM_PERTURBATIONS):
+        for n, v in zip(names, tvars):
+          v.load(nmt_beam_variable(n, tuple(v._var.shape), seed, cfg["gain"], perturbation=k))
+        top_k = sess.run(do["logits"])
+        stable &= np.array([top_k.shape == vals["top"].shape and np.array_equal(top_k[b], vals["top"][b])
+                            for b in range(B)])
     out.update({case + "/top_ids": vals["top"].astype(np.int32), case + "/lengths": vals["lengths"].astype(np.int32),
                 case + "/log_probs": vals["log_probs"].astype(np.float32),
                 case + "/finished": vals["finished"].astype(np.bool_),
-                case + "/final_sequence_lengths": vals["seq_len"].astype(np.int32),
+                case + "/final_sequence_lengths": vals["seq_len"].astype(np.int32), case + "/stable": stable,
                 case + "/var_names": np.array(names)})
     for n, v in zip(names, tvars):
       out["%s/shape/%s" % (case, n)] = np.array(tuple(v._var.shape), np.int32)

@@ -125,3 +125,118 @@ def test_shared_embedding_is_stored_under_the_reference_name():
   np.testing.assert_array_equal(old[0], tab)
   (n2, back), = ck.export_param(name, dev.shape, "conv", dev)
   assert n2 == name and back.shape == tab.shape
+
+
+def _cpu_store(monkeypatch):
+  """A FlatParams whose finalize() only gives every parameter a seeded CPU master (no device buffers)."""
+  import torch
+  from openseq2seq_amd.optimizers import flat_params
+
+  def finalize(self, need_m2=False):
+    g = torch.Generator().manual_seed(5)
+    for p in self.params:
+      p.master = torch.randn(tuple(p.shape), generator=g)
+    self.finalized = True
+  monkeypatch.setattr(flat_params.FlatParams, "finalize", finalize)
+  monkeypatch.setattr(flat_params.FlatParams, "refresh_compute_copies", lambda self: None)
+  return flat_params.FlatParams(torch.device("cpu"))
+
+
+def _nmt_device_model(monkeypatch, encoder, V, E, H, U, enc_layers, dec_layers, att, dtype="float32", M=None):
+  from openseq2seq_amd import encoders, decoders
+  store = _cpu_store(monkeypatch)
+  cellp = {"num_units": H, "forget_bias": 1.0}
+  if encoder is not None:
+    getattr(encoders, encoder)(
+        {"src_vocab_size": V, "src_emb_size": E, "encoder_layers": enc_layers, "encoder_use_skip_connections": False,
+         "core_cell": "LSTMCell", "core_cell_params": cellp, "encoder_dp_input_keep_prob": 1.0, "dtype": "mixed"},
+        None, mode="train").build(store)
+  if dec_layers:
+    dec = decoders.RNNDecoderWithAttention(
+        {"GO_SYMBOL": 2, "END_SYMBOL": 1, "tgt_vocab_size": V, "tgt_emb_size": E, "attention_layer_size": U,
+         "attention_type": att, "core_cell": "LSTMCell", "core_cell_params": cellp, "decoder_layers": dec_layers,
+         "decoder_use_skip_connections": False, "decoder_dp_input_keep_prob": 1.0, "batch_size": 4, "dtype": "mixed"},
+        None, mode="train")
+    dec.build(store, memory_dim=M if M is not None else 2 * H)
+  store.finalize()
+
+  class M(object):
+    params = {"dtype": dtype}
+  M.store = store
+  return M()
+
+
+def test_rnn_nmt_checkpoints_carry_the_reference_graphs_variables(monkeypatch):
+  """The variable lists of the reference's EXECUTED graphs (tests/golden/ref_exec_nmt_*.npz: names and shapes of
+  tf.trainable_variables() after open_seq2seq's own encoders / RNNDecoderWithAttention ran) against what
+  utils/checkpoint.py writes for the device models of the same configuration: the same names, the same shapes —
+  an LSTM cell is ONE kernel [inputs + H, 4H] there and two or three matrices here — and reading the reference's
+  arrays back puts every row block where the GPU test (tests/test_ref_exec_nmt_gpu.py) puts it by hand."""
+  import os
+  here = os.path.dirname(os.path.abspath(__file__))
+  # bidirectional encoder + gnmt_v2 decoder at the dims of ref_exec_nmt_full
+  d = np.load(os.path.join(here, "golden", "ref_exec_nmt_full.npz"))
+  want = {str(n): tuple(int(v) for v in d["shape/" + str(n)]) for n in d["var_names"]}
+  m = _nmt_device_model(monkeypatch, "BidirectionalRNNEncoderWithEmbedding", 30, 64, 64, 128, 2, 2, "gnmt_v2")
+  got = {k: v.shape for k, v in ck.model_variables(m).items()}
+  assert got == want, sorted(set(got) ^ set(want))
+  # ... and the GNMT-like encoder (one bidirectional level + unidirectional levels) with a three-layer gnmt decoder
+  e = np.load(os.path.join(here, "golden", "ref_exec_nmt_encoder.npz"))
+  B, S, V, E, H = [int(v) for v in e["dims"]]
+  want = {str(n): e["gnmt_like/var/" + str(n)].shape for n in e["gnmt_like/var_names"]}
+  m2 = _nmt_device_model(monkeypatch, "GNMTLikeEncoderWithEmbedding", V, E, H, 16, 3, 0, None)
+  got = {k: v.shape for k, v in ck.model_variables(m2).items()}
+  assert got == want, sorted(set(got) ^ set(want))
+  dd = np.load(os.path.join(here, "golden", "ref_exec_nmt_decoder.npz"))
+  B, S, T, V, E, H, M, U = [int(v) for v in dd["dims"]]
+  case = "gnmt_v2_skip"
+  want = {str(n): dd["%s/var/%s" % (case, n)].shape for n in dd[case + "/var_names"]
+          if str(n) != "ForwardPass/encoder_outputs"}
+  m3 = _nmt_device_model(monkeypatch, None, V, E, H, U, 0, 3, "gnmt_v2", M=M)
+  got = {k: v.shape for k, v in ck.model_variables(m3).items()}
+  # the device pads the output layer to a multiple of 8 rows and writes the logical V
+  assert {k: v for k, v in got.items()} == want, sorted(set(got) ^ set(want))
+
+
+def test_rnn_nmt_checkpoint_round_trip_and_row_blocks(monkeypatch, tmp_path):
+  import torch
+  m = _nmt_device_model(monkeypatch, "BidirectionalRNNEncoderWithEmbedding", 30, 64, 64, 128, 2, 2, "gnmt_v2",
+                        dtype="mixed")
+  arrays = ck.model_variables(m)
+  k = "ForwardPass/rnn_decoder_with_attention/decoder/multi_rnn_cell/cell_1/lstm_cell/kernel"
+  assert arrays[k].dtype == np.float16 and arrays[ck.MASTER_PREFIX + k].dtype == np.float32
+  by = {p.name: p for p in m.store.params}
+  pre = "ForwardPass/rnn_decoder_with_attention/multi_rnn_cell/cell_1/lstm_cell/"
+  full = arrays[ck.MASTER_PREFIX + k]                       # [H + M + H, 4H]: layer below | attention | h
+  np.testing.assert_array_equal(full[:64].T, by[pre + "wx_0"].master[0].numpy())
+  np.testing.assert_array_equal(full[64:192].T, by[pre + "wx_1"].master[0].numpy())
+  np.testing.assert_array_equal(full[192:].T, by[pre + "wh"].master[0].numpy())
+  k0 = "ForwardPass/rnn_decoder_with_attention/decoder/multi_rnn_cell/cell_0_attention/gnmt_attention/lstm_cell/kernel"
+  c0 = "ForwardPass/rnn_decoder_with_attention/attention_cell/cell_0/"
+  np.testing.assert_array_equal(arrays[ck.MASTER_PREFIX + k0][:64].T, by[c0 + "kernel_inputs"].master[0].numpy())
+  np.testing.assert_array_equal(arrays[ck.MASTER_PREFIX + k0][64:].T, by[c0 + "kernel_attention_state"].master[0].numpy())
+  # through a TensorBundle file and back into a second model with different values
+  from openseq2seq_amd.utils import tensor_bundle
+  prefix = str(tmp_path / "model.ckpt-0")
+  tensor_bundle.write_bundle(prefix, arrays)
+  before = {p.name: p.master.clone() for p in m.store.params}
+  for p in m.store.params:
+    p.master = torch.zeros_like(p.master)
+  assert ck.load(m, prefix, restore_optimizer=False) == []
+  for p in m.store.params:
+    n = getattr(p, "logical_out", None) or p.master.shape[1 if p.master.dim() == 3 else 0]
+    a, b = (p.master[:, :n], before[p.name][:, :n]) if p.master.dim() == 3 else (p.master, before[p.name])
+    assert torch.equal(a, b), p.name              # the rows past the logical vocabulary come back as zeros
+  # a file this repository wrote before the translation (device names) still loads
+  legacy = {}
+  for p in m.store.params:
+    for n, a in ck.export_param(p.name, p.shape, p.kind, before[p.name].numpy(), getattr(p, "logical_out", None)):
+      legacy[n] = a
+  np.savez(str(tmp_path / "old.npz"), **legacy)
+  for p in m.store.params:
+    p.master = torch.zeros_like(p.master)
+  assert ck.load(m, str(tmp_path / "old.npz"), restore_optimizer=False) == []
+  for p in m.store.params:
+    n = getattr(p, "logical_out", None) or p.master.shape[1 if p.master.dim() == 3 else 0]
+    a, b = (p.master[:, :n], before[p.name][:, :n]) if p.master.dim() == 3 else (p.master, before[p.name])
+    assert torch.equal(a, b), p.name              # the rows past the logical vocabulary come back as zeros

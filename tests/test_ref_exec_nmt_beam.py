@@ -39,7 +39,8 @@ def oracle_params(d, case):
 
   def v(n):
     used.add(n)
-    return torch.from_numpy(rx.gen.nmt_beam_variable(n, tuple(int(x) for x in d["%s/shape/%s" % (case, n)]), seed))
+    return torch.from_numpy(rx.gen.nmt_beam_variable(n, tuple(int(x) for x in d["%s/shape/%s" % (case, n)]), seed,
+                                                     rx.gen.NMT_BEAM_CASES[case]["gain"]))
 
   def lyr(prefix, cin):
     k = v(prefix + "/kernel").t()
@@ -84,13 +85,13 @@ def oracle_beam_search(d, case):
       lg = onmt.decoder_logits(PD, enc_t, len_t, p, torch.full((B * W,), p.shape[1], dtype=torch.int32),
                                attention_type=cfg["att"], skip=False)
       return lg[:, -1].numpy()
-    return orb.beam_search(logits_fn, B, W, V, 2, cfg["END"], cfg["lp"], 2 * int(src_len.max()))
+    return orb.beam_search(logits_fn, B, W, V, 2, cfg["END"], cfg["lp"], 2 * int(src_len.max()), return_log_probs=True)
 
 
 @pytest.mark.parametrize("case", sorted(rx.gen.NMT_BEAM_CASES))
 def test_oracle_reproduces_the_reference_rnn_beam_search(case):
   d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_nmt_beam.npz")))
-  pred, lengths, scores = oracle_beam_search(d, case)
+  pred, lengths, scores, _, _ = oracle_beam_search(d, case)
   ref = d[case + "/top_ids"]
   assert pred.shape[:2] == ref.shape, (pred.shape, ref.shape)
   assert np.array_equal(pred[:, :, 0], ref), (pred[:, :, 0], ref)
@@ -104,13 +105,15 @@ def test_beam_log_probabilities_and_finished_flags(case):
   """final_state.log_probs / .finished of every beam (not only the top one)."""
   d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_nmt_beam.npz")))
   cfg = rx.gen.NMT_BEAM_CASES[case]
-  pred, lengths, scores = oracle_beam_search(d, case)
-  lp = scores * orb.length_penalty(lengths, cfg["lp"])      # the last step's scores = log_probs / penalty(lengths)
-  assert np.abs(lp - d[case + "/log_probs"]).max() < 1e-4 * np.abs(d[case + "/log_probs"]).max()
+  pred, lengths, scores, log_probs, finished = oracle_beam_search(d, case)
+  assert np.abs(log_probs - d[case + "/log_probs"]).max() < 1e-5 * np.abs(d[case + "/log_probs"]).max()
+  assert np.array_equal(finished, d[case + "/finished"])
+  # the scores of the last step are log_probs / penalty(lengths) for every beam that did not finish AT that step
+  # (an END candidate is scored one shorter than the length it ends with)
   T = pred.shape[1]
-  fin = np.array([[(pred[b, :lengths[b, w], w] == cfg["END"]).any() if lengths[b, w] <= T else False
-                   for w in range(cfg["beam"])] for b in range(pred.shape[0])])
-  assert np.array_equal(fin, d[case + "/finished"])
+  ended_last = (pred[:, T - 1, :] == cfg["END"]) & (lengths == T)
+  want = log_probs / orb.length_penalty(lengths, cfg["lp"])
+  assert np.abs(scores - want)[~ended_last].max() < 1e-5 * np.abs(want).max()
 
 
 def test_fixture_has_the_cases_that_matter():
@@ -119,7 +122,12 @@ def test_fixture_has_the_cases_that_matter():
   assert fin.all(1).any() and (~fin).all(1).any() and (fin.any(1) & ~fin.all(1)).any(), \
       "rows whose beams all finished, rows that ran to the cap, and a row with both kinds"
   assert len({int(v) for v in d["lp0_beam4/lengths"].reshape(-1)}) >= 5
-  assert not np.array_equal(d["lp0_beam4/top_ids"], d["lp03_beam4/top_ids"]), "the length penalty changes the winner"
+  stable = np.concatenate([d[c + "/stable"] for c in rx.gen.NMT_BEAM_CASES])
+  fin_top = np.concatenate([d[c + "/finished"][:, 0] for c in rx.gen.NMT_BEAM_CASES])
+  assert stable.sum() >= 6 and (stable & fin_top).sum() >= 4 and (stable & ~fin_top).sum() >= 1, \
+      "rows whose winner survives bf16-size perturbations of the variables: finished ones and ones that ran to the cap"
+  assert len({int(v) for c in rx.gen.NMT_BEAM_CASES for v in d[c + "/lengths"][:, 0]}) >= 6, "winners of six lengths"
+  assert not stable.all(), "and rows whose winner is decided by the last bits (near-ties at the beam boundary)"
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
