@@ -106,6 +106,7 @@ class Tacotron2Decoder(Decoder):
     self.out_proj = Dense(store, scope + "/output_proj", H + self.M, self.n_mel, True)
     self.stop_proj = Dense(store, scope + "/stop_token_proj", self.n_mel, 8, True)   # 1 unit, padded to 8
     self.out_proj.kernel.l2 = self.stop_proj.kernel.l2 = l2
+    self.stop_proj.kernel.logical_out = self.stop_proj.bias.logical_out = 1      # checkpoints carry the one unit
     mom, eps = p.get('postnet_bn_momentum', 0.1), p.get('postnet_bn_epsilon', 1e-5)
     self.postnet = []
     cin = self.n_mel
@@ -128,7 +129,8 @@ class Tacotron2Decoder(Decoder):
         w[:, self.n_mag:, :] = 0.0
         return w
 
-      self.mag_proj = store.add(scope + "/post_net_proj/kernel", (1, self.n_mag_pad, 512), init, kind="conv")
+      self.mag_proj = store.add(scope + "/post_net_proj/kernel", (1, self.n_mag_pad, 512), init, kind="conv",
+                                logical_out=self.n_mag)
     return self
 
   # ---------------------------------------------------------------- teacher-forced pass

@@ -19,10 +19,11 @@ reference's variable name, in the reference's layout:
                   (rows: the cell's inputs in order, then h; gate order i, j, f, o on both sides), under the
                   scope names the reference's GRAPH gives them (bidirectional_rnn/fw/..., rnn/...,
                   decoder/multi_rnn_cell/cell_0_attention/gnmt_attention/..., AttentionMechanism/...):
-                  the RNN NMT encoders and RNNDecoderWithAttention (gnmt / gnmt_v2), names checked against
-                  the reference's executed graphs (tests/golden/ref_exec_nmt_*.npz)
-  anything else   as is (conv2d kernels are already [KT, KF, Cin, Cout]; the recurrent layers of
-                  DeepSpeech2 / Tacotron 2 keep the device names and gate order — see DESIGN.md)
+                  the RNN NMT encoders, RNNDecoderWithAttention (gnmt / gnmt_v2) and Tacotron2Decoder, names
+                  checked against the reference's executed graphs (tests/golden/ref_exec_{nmt,tacotron}_*.npz)
+  anything else   as is (conv2d kernels are already [KT, KF, Cin, Cout]; the cuDNN layers — DeepSpeech2's
+                  recurrent layers, Tacotron 2's encoder LSTM — keep the device names and gate order: they are
+                  one opaque buffer in a TensorFlow checkpoint)
 
 In mixed precision a half-precision variable is written as DT_HALF (float16) under its plain
 name and as fp32 under the master-copy name — the dtypes a reference fp16 graph holds, so a
@@ -43,6 +44,13 @@ MASTER_PREFIX = "Loss_Optimization/FP32-master-copy/"
 LATEST_FILENAME = "checkpoint"
 
 
+# K = 1 tf.layers.conv1d layers of the Tacotron 2 decoder that sit under no conv... scope: the location-sensitive
+# attention's memory layer (parts/rnns/attention_wrapper.py: LocationSensitiveAttention, memory_layer = Conv1D) and
+# the magnitude head (decoders/tacotron2_decoder.py: post_net_proj) — rank 3 in tf.trainable_variables() of the
+# reference's executed graph (tests/golden/ref_exec_tacotron_full.npz)
+_TACOTRON_CONV1D = re.compile(r"/tacotron_2_decoder/(AttentionMechanism/memory_layer|post_net_proj)/kernel$")
+
+
 def _is_dense(name):
   """Is this [1, Cout, Cin] matrix a tf.layers.dense kernel ([Cin, Cout] in a checkpoint) rather than a K = 1
   tf.layers.conv1d kernel ([1, Cin, Cout])? Convolution variables sit under a scope component named conv...
@@ -51,6 +59,8 @@ def _is_dense(name):
   with the wrong rank; found by running the reference's own TDNNEncoder, tests/test_ref_exec_tdnn_gpu.py)."""
   parts = name.split("/")
   if parts[-1] == "pointwise_kernel":
+    return False
+  if _TACOTRON_CONV1D.search(name):
     return False
   return not any(re.match(r"conv(_|\d|$)", c) for c in parts[:-1])
 
@@ -79,6 +89,10 @@ def export_param(name, shape, kind, arr, logical_out=None):
     return [(name, np.transpose(arr, (0, 2, 1)).copy())]
   if name.endswith("/depthwise_kernel"):
     return [(name, arr[:, :, None].copy())]
+  if name.endswith("/location_conv/kernel") and arr.ndim == 2:       # [K, F] -> conv1d over the one alignment channel
+    return [(name, arr[:, None, :].copy())]
+  if name.endswith("/location_dense/kernel") and arr.ndim == 2:      # [F, U] -> the K = 1 conv1d the reference uses
+    return [(name, arr[None].copy())]
   return [(name, arr.copy())]
 
 
@@ -128,6 +142,8 @@ def import_param(name, shape, kind, tf_arrays, logical_out=None):
     return np.transpose(a, (0, 2, 1))     # tf.layers.conv1d [K, Cin, Cout] (the array's own rank decides)
   if name.endswith("/depthwise_kernel"):
     return a[:, :, 0]
+  if name.endswith(("/location_conv/kernel", "/location_dense/kernel")) and a.ndim == 3 and len(shape) == 2:
+    return a.reshape(shape) if a.size == int(np.prod(shape)) else a
   return a
 
 
@@ -150,7 +166,18 @@ _RNN_SCOPES = [
      "/rnn_decoder_with_attention/decoder/multi_rnn_cell/cell_0_attention/gnmt_attention/bahdanau_attention/"),
     (r"/rnn_decoder_with_attention/multi_rnn_cell/", "/rnn_decoder_with_attention/decoder/multi_rnn_cell/"),
     (r"/rnn_decoder_with_attention/dense/", "/rnn_decoder_with_attention/decoder/dense/"),
+    # Tacotron2Decoder (decoders/tacotron2_decoder.py: everything the decoder step touches lives under dynamic_decode's
+    # 'decoder' scope; the memory layer is created with the attention mechanism, outside it)
+    (r"/tacotron_2_decoder/attention_wrapper/attention/memory_layer/", "/tacotron_2_decoder/AttentionMechanism/memory_layer/"),
+    (r"/tacotron_2_decoder/attention_wrapper/attention/", "/tacotron_2_decoder/decoder/attention_wrapper/location_attention/"),
+    (r"/tacotron_2_decoder/attention_wrapper/cell_0/",
+     "/tacotron_2_decoder/decoder/attention_wrapper/multi_rnn_cell/cell_0/lstm_cell/"),
+    (r"/tacotron_2_decoder/attention_wrapper/cell_", "/tacotron_2_decoder/decoder/attention_wrapper/multi_rnn_cell/cell_"),
+    (r"/tacotron_2_decoder/prenet_", "/tacotron_2_decoder/decoder/prenet_"),
+    (r"/tacotron_2_decoder/output_proj/", "/tacotron_2_decoder/decoder/output_proj/"),
+    (r"/tacotron_2_decoder/stop_token_proj/", "/tacotron_2_decoder/decoder/stop_token_proj/"),
 ]
+_UPPER_CELL = re.compile(r"^(.*/tacotron_2_decoder/decoder/attention_wrapper/multi_rnn_cell/cell_[1-9]\d*)/(kernel|bias)$")
 _LSTM_PART = re.compile(r"^(.*)/(wx_(\d+)|wh|kernel_inputs|kernel_attention_state)$")
 
 
@@ -163,6 +190,9 @@ def reference_name(name):
       break
   else:
     return name, None
+  m = _UPPER_CELL.match(name)
+  if m:                                   # the upper decoder cells are one [1, 4H, 2H] matrix here: a rename
+    return "%s/lstm_cell/%s" % (m.group(1), m.group(2)), None
   m = _LSTM_PART.match(name)
   if not m:
     return name, None

@@ -240,3 +240,68 @@ def test_rnn_nmt_checkpoint_round_trip_and_row_blocks(monkeypatch, tmp_path):
     n = getattr(p, "logical_out", None) or p.master.shape[1 if p.master.dim() == 3 else 0]
     a, b = (p.master[:, :n], before[p.name][:, :n]) if p.master.dim() == 3 else (p.master, before[p.name])
     assert torch.equal(a, b), p.name              # the rows past the logical vocabulary come back as zeros
+
+
+def test_tacotron_decoder_checkpoints_carry_the_reference_graphs_variables(monkeypatch, tmp_path):
+  """The same for Tacotron 2: tf.trainable_variables() of the reference's executed Tacotron2Encoder + Tacotron2Decoder
+  + "both"-mode heads (tests/golden/ref_exec_tacotron_full.npz) against what utils/checkpoint.py writes for the device
+  model of that configuration — the decoder-step variables under dynamic_decode's 'decoder' scope, the attention cell's
+  kernel as one [prenet + attention + H, 4H] matrix, the K = 1 conv1d layers (location attention's memory layer and
+  location_dense, post_net_proj) and the location convolution [K, 1, F] at rank 3, the stop-token layer with its one
+  logical unit. Only the encoder's cuDNN LSTM differs: one opaque buffer in TensorFlow, own names here."""
+  import os
+  import torch
+  from openseq2seq_amd.encoders import Tacotron2Encoder
+  from openseq2seq_amd.decoders import Tacotron2Decoder
+  sys_path = os.path.dirname(os.path.abspath(__file__))
+  import sys
+  sys.path.insert(0, sys_path)
+  import ref_exec_util as rx
+  from test_tacotron_e2e_gpu import CONVS, POST
+  d = np.load(os.path.join(sys_path, "golden", "ref_exec_tacotron_full.npz"))
+  C = rx.gen.TACO_FULL
+  V, E, Henc, H, NM, NG, PRE, U = [C[k] for k in ("V", "E", "Henc", "H", "NM", "NG", "pre", "U")]
+  store = _cpu_store(monkeypatch)
+  enc = Tacotron2Encoder({"cnn_dropout_prob": 0.0, "rnn_dropout_prob": 0.0, "src_emb_size": E, "conv_layers": CONVS,
+                          "activation_fn": "relu", "num_rnn_layers": 1, "rnn_cell_dim": Henc, "use_cudnn_rnn": True,
+                          "rnn_type": "CudnnLSTM", "rnn_unidirectional": False, "dtype": "mixed"}, None, mode="train")
+  enc.build(store, src_vocab_size=V, num_style_features=NM)
+  dec = Tacotron2Decoder({"attention_layer_size": U, "attention_type": "location", "attention_bias": True,
+                          "decoder_cell_units": H, "decoder_cell_type": "LSTMCell", "decoder_layers": 2,
+                          "dropout_prob": 0.0, "enable_prenet": True, "prenet_layers": 2, "prenet_units": PRE,
+                          "enable_postnet": True, "postnet_keep_dropout_prob": 1.0, "postnet_conv_layers": POST,
+                          "dtype": "mixed"}, None, mode="train")
+  dec.build(store, memory_dim=enc.output_dim, num_audio_features={"mel": NM, "magnitude": NG}, exp_mag=True)
+  store.finalize()
+
+  class M(object):
+    params = {"dtype": "float32"}
+  M.store = store
+  m = M()
+  opaque = lambda n: "/tacotron2_encoder/weight_" in n or "/tacotron2_encoder/bias_" in n or "/cudnn_rnn/" in n  # noqa: E731
+  want = {str(n): tuple(int(v) for v in d["shape/" + str(n)]) for n in d["var_names"] if not opaque(str(n))}
+  arrays = ck.model_variables(m)
+  got = {k: v.shape for k, v in arrays.items() if not opaque(k) and "/bn/moving_" not in k}
+  assert got == want, (sorted(set(got) ^ set(want)), [(k, got[k], want[k]) for k in got if k in want and got[k] != want[k]])
+  # row blocks of the attention cell: prenet output | attention context | h
+  by = {p.name: p for p in store.params}
+  k0 = arrays["ForwardPass/tacotron_2_decoder/decoder/attention_wrapper/multi_rnn_cell/cell_0/lstm_cell/kernel"]
+  c0 = "ForwardPass/tacotron_2_decoder/attention_wrapper/cell_0/"
+  np.testing.assert_array_equal(k0[:PRE].T, by[c0 + "kernel_inputs"].master[0].numpy())
+  np.testing.assert_array_equal(k0[PRE:].T, by[c0 + "kernel_attention_state"].master[0].numpy())
+  # file round trip
+  from openseq2seq_amd.utils import tensor_bundle
+  prefix = str(tmp_path / "model.ckpt-0")
+  tensor_bundle.write_bundle(prefix, arrays)
+  before = {p.name: p.master.clone() for p in store.params}
+  for p in store.params:
+    p.master = torch.zeros_like(p.master)
+  assert ck.load(m, prefix, restore_optimizer=False) == []
+  for p in store.params:
+    n = getattr(p, "logical_out", None)
+    if n is None:
+      assert torch.equal(p.master, before[p.name]), p.name
+    elif p.master.dim() == 3:
+      assert torch.equal(p.master[:, :n], before[p.name][:, :n]) and not p.master[:, n:].any(), p.name
+    else:
+      assert torch.equal(p.master[:n], before[p.name][:n]) and not p.master[n:].any(), p.name
