@@ -83,6 +83,18 @@ def test_device_nmt_reproduces_the_reference_code(cuda):
   assert {p.name for p in store.params} == set(slices), sorted({p.name for p in store.params} ^ set(slices))
   assert {v[0] for v in slices.values()} == set(names), "every reference variable went into the device model"
   store.refresh_compute_copies()
+  # what utils/checkpoint.py would write for this model IS the reference's variable list, value for value: loading a
+  # reference checkpoint by name puts every array where the hand placement above put it
+  from openseq2seq_amd.utils import checkpoint
+
+  class _M(object):
+    params = {"dtype": "float32"}
+  _M.store = store
+  written = checkpoint.model_variables(_M())
+  opaque = lambda n: False           # cuDNN layers: one opaque buffer in TensorFlow
+  for n in names:
+    if not opaque(n):
+      assert written[n].shape == tuple(ref[n].shape) and np.array_equal(written[n], ref[n].numpy()), n
   # ---- one step ------------------------------------------------------------------------------------------------
   src, src_len = torch.from_numpy(d["src"]), torch.from_numpy(d["src_len"])
   tgt, tgt_len = torch.from_numpy(d["tgt"]), torch.from_numpy(d["tgt_len"])

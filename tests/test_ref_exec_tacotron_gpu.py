@@ -128,6 +128,18 @@ def test_device_tacotron_reproduces_the_reference_code(cuda, monkeypatch):
   assert {id(t[0]) for t in table} == {id(p) for p in store.params}, "every device parameter was filled"
   assert {t[1] for t in table} == set(names), "every reference variable went into the device model"
   store.refresh_compute_copies()
+  # what utils/checkpoint.py would write for this model IS the reference's variable list, value for value: loading a
+  # reference checkpoint by name puts every array where the hand placement above put it
+  from openseq2seq_amd.utils import checkpoint
+
+  class _M(object):
+    params = {"dtype": "float32"}
+  _M.store = store
+  written = checkpoint.model_variables(_M())
+  opaque = lambda n: "/tacotron2_encoder/weight_" in n or "/tacotron2_encoder/bias_" in n           # cuDNN layers: one opaque buffer in TensorFlow
+  for n in names:
+    if not opaque(n):
+      assert written[n].shape == tuple(ref[n].shape) and np.array_equal(written[n], ref[n].numpy()), n
   # ---- one training step on the device ----------------------------------------------------------------------------
   text, text_len = torch.from_numpy(d["text"]), torch.tensor(C["text_len"], dtype=torch.int32)
   spec, stop = torch.from_numpy(d["spec"]), torch.from_numpy(d["stop_target"])
