@@ -215,6 +215,72 @@ def transformer_infer(seed=13, dims=(3, 8, 40, 32, 4, 64, 2), beam=3, extra=4):
   return out
 
 
+TRANSFORMER_BEAM = dict(dims=(4, 11, 96, 512, 8, 1024, 2), beam=4, extra=4, seed=29, emb_gain=1.0, mat_gain=3.0, eos_gain=2.0, perturbations=6,
+                        src_len=[11, 7, 9, 4])
+
+
+def transformer_beam_variable(name, shape, seed, perturbation=None):
+  """The variable values of the d512 beam-search fixture: seeded_array, the shared embedding (= output layer) times
+  emb_gain for a sharper output distribution; perturbation k: every matrix entry times 1 + 2^-7 u, u ~ U(-1, 1)."""
+  import zlib
+  a = seeded_array(name, shape, seed)
+  if name.endswith("embedding_and_softmax/weights"):
+    a = a * np.float32(TRANSFORMER_BEAM["emb_gain"])
+    a[1] *= np.float32(TRANSFORMER_BEAM["eos_gain"])        # EOS: logits of a wider spread, sometimes the largest
+  elif a.ndim == 2:
+    a = a * np.float32(TRANSFORMER_BEAM["mat_gain"])
+  if a.ndim == 2 and perturbation is not None:
+    rs = np.random.RandomState((zlib.crc32(name.encode()) + 1000 * perturbation) % (2 ** 31))
+    a = a * (1 + np.float32(2.0 ** -7) * rs.uniform(-1, 1, a.shape).astype(np.float32))
+  return a
+
+
+def transformer_infer_d512():
+  """TransformerDecoder.predict (cached decode under sequence_beam_search) at the widths the HIP kernels take: the
+  device's beam search is held to these ids. As for the RNN beam search (nmt_beam), the reference is re-run with every
+  matrix perturbed by 2^-7 relative and the rows whose winner never changes are recorded (`stable`)."""
+  C = TRANSFORMER_BEAM
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(C["seed"])
+  TransformerEncoder = imp("open_seq2seq.encoders.transformer_encoder").TransformerEncoder
+  TransformerDecoder = imp("open_seq2seq.decoders.transformer_decoder").TransformerDecoder
+  rng = np.random.RandomState(C["seed"])
+  B, S, V, D, H, F, NL = C["dims"]
+  src_len = np.array(C["src_len"], np.int32)
+  src = np.zeros((B, S), np.int32)
+  for b in range(B):
+    src[b, :src_len[b]] = rng.randint(2, V, size=src_len[b])
+  enc_params = dict(encoder_layers=NL, hidden_size=D, num_heads=H, attention_dropout=0.1, filter_size=F,
+                    src_vocab_size=V, relu_dropout=0.1, layer_postprocess_dropout=0.1, remove_padding=True,
+                    dtype=tf.float32)          # V = 96: a vocabulary the data layer already padded to a multiple of 8
+  dec_params = dict(EOS_ID=1, layer_postprocess_dropout=0.1, num_hidden_layers=NL, hidden_size=D, num_heads=H,
+                    attention_dropout=0.1, relu_dropout=0.1, filter_size=F, batch_size=B, tgt_vocab_size=V,
+                    beam_size=C["beam"], alpha=0.6, extra_decode_length=C["extra"], GO_SYMBOL=1, PAD_SYMBOL=0,
+                    END_SYMBOL=1, dtype=tf.float32)
+  with tf.variable_scope("ForwardPass"):
+    encoder = TransformerEncoder(enc_params, None, mode="infer")
+    decoder = TransformerDecoder(dec_params, None, mode="infer")
+    enc_out = encoder.encode({"source_tensors": [tf.constant(src), tf.constant(src_len)]})
+    dec_out = decoder.decode({"encoder_output": enc_out})
+  gvars = tf.trainable_variables()
+  names = [v.name.split(":")[0] for v in gvars]
+  with tf.Session() as sess:
+    for n, v in zip(names, gvars):
+      v.load(transformer_beam_variable(n, tuple(v._var.shape), C["seed"]))
+    ids = sess.run(dec_out["outputs"][0]).astype(np.int32)
+    stable = np.ones(B, np.bool_)
+    for k in range(C["perturbations"]):
+      for n, v in zip(names, gvars):
+        v.load(transformer_beam_variable(n, tuple(v._var.shape), C["seed"], perturbation=k))
+      ids_k = sess.run(dec_out["outputs"][0])
+      stable &= np.array([ids_k.shape == ids.shape and np.array_equal(ids_k[b], ids[b]) for b in range(B)])
+  out = {"src": src, "src_len": src_len, "ids": ids, "stable": stable, "var_names": np.array(names)}
+  for n, v in zip(names, gvars):
+    out["shape/" + n] = np.array(tuple(v._var.shape), np.int32)
+  return out
+
+
 def transformer_d512():
   """The same graph at the narrowest widths the HIP kernels take (head dim 64, LayerNorm rows of 512 or 1024):
   d_model 512, 8 heads, filter 1024, 2 + 2 layers, V 90 -> 96. Variables come from seeded_array (not stored),
@@ -1318,7 +1384,7 @@ def frontend():
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam, "transformer_infer_d512": transformer_infer_d512}
 
 
 def generate(name):

@@ -29,10 +29,11 @@ def load_fixture(name="transformer"):
   return rx.load(name)
 
 
-def oracle_params(d, NL, names=None):
+def oracle_params(d, NL, names=None, arrays=None):
   """reference variable names -> the oracle's parameter dicts (autograd leaves, fp32)."""
   leaves = {}
-  arrays = rx.variables(d, names if names is not None else [str(n) for n in d["var_names"]])
+  if arrays is None:
+    arrays = rx.variables(d, names if names is not None else [str(n) for n in d["var_names"]])
 
   def v(name):
     t = torch.from_numpy(np.array(arrays[name], np.float32)).requires_grad_(True)
@@ -128,6 +129,40 @@ def test_oracle_reproduces_the_reference_cached_beam_decode():
   assert rel(lg.numpy(), d["logits"]) < 1e-5
 
 
+def beam_arrays(d):
+  C = rx.gen.TRANSFORMER_BEAM
+  return {str(n): rx.gen.transformer_beam_variable(str(n), tuple(int(v) for v in d["shape/" + str(n)]), C["seed"])
+          for n in d["var_names"]}
+
+
+def test_oracle_reproduces_the_reference_beam_decode_at_device_widths():
+  """The same at d_model 512, 8 heads, V 96, beam 4 (tests/golden/ref_exec_transformer_infer_d512.npz: the fixture
+  the HIP beam search is held to, tests/test_ref_exec_transformer_gpu.py): a row that ends with EOS and is zero-padded,
+  rows that run to the length cap; `stable` marks the rows whose winner the REFERENCE keeps under six perturbations
+  of every matrix by 2^-7 relative."""
+  from oracle import beam_search as obs
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_transformer_infer_d512.npz")))
+  C = rx.gen.TRANSFORMER_BEAM
+  B, S, V, D, H, F, NL = C["dims"]
+  names = [str(n) for n in d["var_names"]]
+  PE, PD, leaves = oracle_params(d, NL, names, arrays=beam_arrays(d))
+  assert sorted(leaves) == sorted(names)
+  with torch.no_grad():
+    src = torch.from_numpy(d["src"]).long()
+    enc_out, bias = ot.encoder(src, PE, H)
+
+    def fn(ids, i, cache):
+      tgt = torch.from_numpy(np.concatenate([ids[:, 1:], np.zeros((ids.shape[0], 1), ids.dtype)], 1)).long()
+      logits = ot.decoder_pass(tgt, torch.from_numpy(cache["enc"]), torch.from_numpy(cache["bias"]), PD, H)
+      return logits[:, i, :].numpy(), cache
+    ids, scores = obs.sequence_beam_search(fn, np.zeros(B, np.int32), {"enc": enc_out.numpy(), "bias": bias.numpy()},
+                                           V, C["beam"], 0.6, S + C["extra"], 1)
+  assert np.array_equal(ids[:, 0, 1:], d["ids"]), (ids[:, 0, 1:], d["ids"])
+  assert d["stable"].any() and not d["stable"].all()
+  ended = [(r == 1).any() for r in d["ids"]]
+  assert any(ended) and not all(ended), "a row that finishes (zero-padded after EOS) and rows that run to the cap"
+
+
 def test_fixture_has_the_cases_that_matter():
   d, _ = load_fixture()
   B, S, T, V, D, H, F, NL = [int(v) for v in d["config"]]
@@ -142,5 +177,6 @@ def test_fixture_has_the_cases_that_matter():
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check", "transformer",
-                      "transformer_d512", "transformer_infer"], capture_output=True, text=True, timeout=900)
-  assert r.returncode == 0 and r.stdout.count("reproduced") == 3, r.stdout + r.stderr
+                      "transformer_d512", "transformer_infer", "transformer_infer_d512"], capture_output=True,
+                     text=True, timeout=900)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 4, r.stdout + r.stderr
