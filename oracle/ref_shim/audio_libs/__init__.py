@@ -162,9 +162,38 @@ def logfbank(signal, samplerate=16000, winlen=0.025, winstep=0.01, nfilt=26, nff
   return np.log(feat)
 
 
+def lifter(cepstra, L=22):            # noqa: N803
+  if L > 0:
+    n = np.arange(cepstra.shape[1])
+    return (1 + (L / 2.0) * np.sin(np.pi * n / L)) * cepstra
+  return cepstra
+
+
+def mfcc(signal, samplerate=16000, winlen=0.025, winstep=0.01, numcep=13, nfilt=26, nfft=None, lowfreq=0,
+         highfreq=None, preemph=0.97, ceplifter=22, appendEnergy=True, winfunc=lambda x: np.ones((x,))):   # noqa: N803
+  """python_speech_features.mfcc: log filterbank energies -> DCT-II (orthonormal) -> the first numcep coefficients
+  -> sinusoidal lifter; with appendEnergy the first coefficient is the log of the frame energy."""
+  from scipy.fftpack import dct
+  feat, energy = fbank(signal, samplerate, winlen, winstep, nfilt, nfft or 512, lowfreq, highfreq, preemph, winfunc)
+  feat = dct(np.log(feat), type=2, axis=1, norm="ortho")[:, :numcep]
+  feat = lifter(feat, ceplifter)
+  if appendEnergy:
+    feat[:, 0] = np.log(energy)
+  return feat
+
+
+def resample(x, sr_orig, sr_new, axis=-1, filter="kaiser_best", **kwargs):   # noqa: A002
+  """resampy.resample's CONTRACT (output length int(n * sr_new / sr_orig), band-limited) through scipy's Fourier
+  resampler — not resampy's windowed-sinc interpolation, which oracle/augment.py restates: this stand-in only lets the
+  reference's augmentation code run (its own test checks lengths)."""
+  from scipy.signal import resample as fft_resample
+  n = int(x.shape[axis] * float(sr_new) / float(sr_orig))
+  return fft_resample(x, n, axis=axis).astype(x.dtype)
+
+
 def install():
-  """Registers `librosa`, `python_speech_features` (the stand-ins above) and empty `h5py` / `resampy` modules (imported
-  by speech_utils.py at module level, used only by the caching and speed-perturbation paths that are not executed)."""
+  """Registers `librosa`, `python_speech_features`, `resampy` (the stand-ins above) and an empty `h5py` module (imported
+  by speech_utils.py at module level, used only by the caching path that is not executed)."""
   lib = types.ModuleType("librosa")
   lib.core = types.ModuleType("librosa.core")
   lib.core.stft = stft
@@ -178,9 +207,11 @@ def install():
   for n, f in (("framesig", framesig), ("magspec", magspec), ("powspec", powspec), ("logpowspec", logpowspec),
                ("preemphasis", preemphasis)):
     setattr(psf.sigproc, n, f)
-  psf.get_filterbanks, psf.fbank, psf.logfbank = get_filterbanks, fbank, logfbank
+  psf.get_filterbanks, psf.fbank, psf.logfbank, psf.mfcc, psf.lifter = get_filterbanks, fbank, logfbank, mfcc, lifter
+  rsm = types.ModuleType("resampy")
+  rsm.resample = resample
   mods = {"librosa": lib, "librosa.core": lib.core, "librosa.filters": lib.filters, "librosa.feature": lib.feature,
           "python_speech_features": psf, "python_speech_features.sigproc": psf.sigproc,
-          "h5py": types.ModuleType("h5py"), "resampy": types.ModuleType("resampy")}
+          "h5py": types.ModuleType("h5py"), "resampy": rsm}
   sys.modules.update(mods)
   return mods

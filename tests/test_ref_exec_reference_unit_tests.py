@@ -7,7 +7,12 @@ plumbing incl. tf.nn.top_k + gather_nd), losses/sequence_loss_test.py (sparse vs
 combinations), optimizers/mp_wrapper_test.py (regulariser gradient 1e-8 under the mixed-precision wrapper incl. the
 'Const_1:0' op-name assertion, 2 x 6000 steps of least-squares convergence through optimize_loss in fp32 and mixed
 precision) and optimizers/optimizers_test.py (the iter_size accumulate / apply algebra of the Horovod branch, with a
-one-rank stand-in for horovod.tensorflow) and runs them with unittest. All 15 must pass."""
+one-rank stand-in for horovod.tensorflow) and — on the stand-ins for librosa / python_speech_features / resampy
+(oracle/ref_shim/audio_libs) — data/speech2text/speech_utils_test.py (108 feature extractions from the reference's toy
+wav files: shapes padded to a multiple of 8, mean 0 / std 1 to six places, the num_features assertion; 200 random speed
+perturbations within their length bounds; augmentation changes the features), and runs them with unittest; NumPy's
+generator is seeded before each test (two of the reference's augmentation assertions hold for most random draws, not
+for all). All 18 must pass."""
 import os
 import subprocess
 import sys
@@ -22,10 +27,11 @@ def test_reference_unit_tests_pass_on_the_stand_in():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "run_reference_unit_tests.py")],
                      capture_output=True, text=True, timeout=1200)
   lines = [l.split() for l in r.stdout.strip().splitlines() if "::" in l and "::test_session" not in l]
-  assert r.returncode == 0 and len(lines) == 15, r.stdout + r.stderr[-2000:]
+  assert r.returncode == 0 and len(lines) == 18, r.stdout + r.stderr[-2000:]
   bad = [l for l in lines if l[1] != "PASS"]
   assert not bad, bad
   names = {l[0] for l in lines}
   assert {"optimizers.mp_wrapper_test::test_regularization_mixed", "optimizers.optimizers_test::test_updates",
           "optimizers.mp_wrapper_test::test_convergence", "parts.transformer.beam_search_test::test_gather_topk_beams",
-          "losses.sequence_loss_test::test_compute_loss"} <= names
+          "losses.sequence_loss_test::test_compute_loss",
+          "data.speech2text.speech_utils_test::test_get_speech_features_from_file"} <= names
