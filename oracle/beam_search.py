@@ -10,7 +10,8 @@ the same gather-based formulation the reference builds as a tf.while_loop:
 
 PARITY STATUS (round 5): the whole search is pinned to the reference's OWN CODE — sequence_beam_search executed
 from its file on the TF-primitive stand-in oracle/ref_shim/tf1 (tf.while_loop restated as a traced loop): ids exact,
-scores 1e-5 in three regimes (tests/test_ref_exec_beam_search.py). Also
+scores 1e-5 in three regimes (tests/test_ref_exec_beam_search.py); driving oracle/transformer.py it returns the ids of
+the reference's TransformerDecoder.predict exactly, at d 32 and at d 512 (tests/test_ref_exec_transformer.py). Also
 pinned to the reference's own known answers (beam_search_test.py: expand / flatten /
 unflatten shapes, _gather_beams and _gather_topk_beams values) in
 tests/test_oracle_beam_search.py. tf.nn.top_k semantics: descending values, the LOWER index

@@ -7,7 +7,8 @@ plumbing of the kernels is pinned separately in tests/test_attn_decoder_gpu.py.
 PARITY STATUS (round 5): pinned to the reference's OWN CODE — both encoders,
 RNNDecoderWithAttention (gnmt / gnmt_v2 / skip connections) and BasicSequenceLoss executed from their
 files on the TF-primitive stand-in oracle/ref_shim/tf1: outputs / logits / loss 1e-5, all gradients
-6e-7 (tests/test_ref_exec_nmt.py). tf.nn.rnn_cell.LSTMCell, dynamic_rnn and dynamic_decode are
+6e-7 (tests/test_ref_exec_nmt.py); under oracle/rnn_beam_search.py the decoder returns what the reference's
+BeamSearchRNNDecoderWithAttention returns (tests/test_ref_exec_nmt_beam.py). tf.nn.rnn_cell.LSTMCell, dynamic_rnn and dynamic_decode are
 TensorFlow library code, restated in oracle/ref_shim/tf1/rnn.py."""
 import torch
 import torch.nn.functional as F
