@@ -197,6 +197,14 @@ const char* os2s_option_name(int index);
  * kernel `kernel` ("conv1d", "conv1d_wgrad") writes per-slot time stamps into (NULL withdraws it); `mode` is
  * the kernel's own timing-experiment bit mask. Returns 0, or -1 for an unknown kernel name. */
 int os2s_set_debug_stamps(const char* kernel, void* stamps, int mode);
+/* Shader-clock probe (bench.py `roofline.shader_clock_mhz`): enqueues, on a private non-blocking stream, ONE wave
+ * that spins for `spin_cycles` ticks of the shader clock counter and writes {shader cycles, ticks of the constant
+ * 100 MHz reference counter} to the device buffer `out_u64x2`; os2s_clock_probe_wait() blocks until it has
+ * finished. Run next to the work being measured it reports the clock the chip sustains under that load — the
+ * factor between the 2.5 PFLOP/s peak (quoted at 2.4 GHz) and what the matrix pipes can deliver there. No
+ * reference counterpart (measurement aid of SURVEY 8d). */
+int os2s_clock_probe(void* out_u64x2, unsigned long long spin_cycles);
+int os2s_clock_probe_wait(void);
 /* Up to 16 independent 1x1 convolutions over the same batch geometry (B, T, lengths) in ONE
  * launch: y_i[b,t,:] (+)= x_i[b,t,:] . w_i^T, bf16 out, optional BatchNorm partials per group
  * (layout as os2s_conv1d_fwd). Replaces the dense-residual branches of conv_bn_res_bn_actv

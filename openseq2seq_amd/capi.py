@@ -49,6 +49,23 @@ def abi_version():
   return _lib.lib().os2s_abi_version()
 
 
+def clock_probe_start(spin_cycles):
+  """Enqueue the one-wave shader-clock probe (os2s_clock_probe) next to whatever runs on the other streams;
+  returns the device buffer clock_probe_read() reads."""
+  out = torch.zeros((2,), dtype=torch.int64, device="cuda")
+  torch.cuda.current_stream().synchronize()      # the zero fill lands before the probe stream writes
+  f = _fn("os2s_clock_probe", (c_void_p, c_uint64))
+  _lib.check(f(_ptr(out), int(spin_cycles)), "os2s_clock_probe")
+  return out
+
+
+def clock_probe_read(out):
+  """MHz of the shader clock over the probe's run (100 MHz reference counter), or None if it did not run."""
+  _lib.check(_fn("os2s_clock_probe_wait", ())(), "os2s_clock_probe_wait")
+  cyc, ref = (int(v) for v in out.cpu())
+  return 100.0 * cyc / ref if ref > 0 else None
+
+
 # --------------------------------------------------------------------------
 # CTC greedy decode
 # --------------------------------------------------------------------------

@@ -68,3 +68,38 @@ extern "C" int os2s_set_debug_stamps(const char* kernel, void* stamps, int mode)
     if (strcmp(o.name, kernel) == 0) { o.fn(stamps, mode); return 0; }
   return -1;
 }
+
+// ---- shader-clock probe: what the matrix-pipe peak is a fraction OF on this box, under this load ----
+// One wave spins for `spin_cycles` ticks of the shader clock counter (s_memtime) and reports how many ticks of
+// the constant 100 MHz reference (s_memrealtime) went by: clock = 100 MHz x cycles / ref ticks. Launched on its
+// own stream NEXT TO the work being timed (one wave of 24 registers, no LDS: it fits beside any resident
+// workgroup), so it reads the clock the power manager grants under THAT load (MI355X_MICROARCH.md "DVFS
+// give-back": 1.9 - 1.95 GHz on random data under matrix load, 2.3 - 2.4 GHz on zero-filled operands).
+namespace {
+__global__ void __launch_bounds__(64) clock_probe_kernel(unsigned long long* out, unsigned long long spin_cycles) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long c0 = __builtin_readcyclecounter();
+  const unsigned long long r0 = wall_clock64();
+  unsigned long long c1 = c0;
+  while (c1 - c0 < spin_cycles) {
+    __builtin_amdgcn_s_sleep(32);
+    c1 = __builtin_readcyclecounter();
+  }
+  const unsigned long long r1 = wall_clock64();
+  out[0] = c1 - c0;
+  out[1] = r1 - r0;
+}
+hipStream_t g_probe_stream = nullptr;
+}  // namespace
+
+extern "C" int os2s_clock_probe(void* out_u64x2, unsigned long long spin_cycles) {
+  if (!out_u64x2 || spin_cycles > (1ull << 36)) return OS2S_ERR_INVALID_ARG;   // <= 30 s even at 2.4 GHz
+  if (!g_probe_stream && hipStreamCreateWithFlags(&g_probe_stream, hipStreamNonBlocking) != hipSuccess)
+    return OS2S_ERR_LAUNCH;
+  OS2S_LAUNCH(clock_probe_kernel, dim3(1), dim3(64), 0, g_probe_stream, (unsigned long long*)out_u64x2, spin_cycles);
+  return OS2S_OK;
+}
+extern "C" int os2s_clock_probe_wait(void) {
+  if (g_probe_stream && hipStreamSynchronize(g_probe_stream) != hipSuccess) return OS2S_ERR_LAUNCH;
+  return OS2S_OK;
+}

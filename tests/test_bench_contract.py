@@ -76,3 +76,99 @@ def test_bench_refuses_a_world_size_mismatch():
   r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launcher-dry-run"],
                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
   assert r.returncode != 0 and "--gpus 2" in r.stderr
+
+
+def _load_bench():
+  import importlib.util
+  spec = importlib.util.spec_from_file_location("os2s_bench_module", os.path.join(REPO, "bench.py"))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def test_step_breakdown_wrappers_accept_every_keyword_of_the_entry_points_they_wrap():
+  """Round 5 shipped a `rest_of_step` block that was {"error": TypeError(... 'pingpong')}: capi.conv1x1_wgrad_grouped
+  had grown a keyword its bench wrapper did not pass on. Every wrapper StepBreakdown / ConvTimer install is called
+  here with ALL parameters of the function it replaces (positional ones by position, keyword ones by name), on
+  stand-ins with the real signatures — a signature drift fails on CPU, not in the driver's record."""
+  import inspect
+  import types
+  import torch
+  bench = _load_bench()
+  from openseq2seq_amd import capi as real
+
+  x = torch.zeros((2, 8, 4))
+  lens = torch.tensor([8, 5], dtype=torch.int32)
+  by_name = {"x": x, "dy": x, "dz": x, "y": x, "out": x, "dout": x, "w": torch.zeros((3, 4, 4)), "K": 3,
+             "ys": [x], "scales": [x], "shifts": [x], "means": [x], "rstds": [x], "partial": x,
+             "items": [{"x": x, "dy": x, "w": torch.zeros((1, 4, 4))}], "in_len": lens, "out_len": lens,
+             "weights": torch.zeros(16), "grads": torch.zeros(16)}
+  names = ("conv1d_wgrad", "conv1x1_wgrad_grouped", "bn_act_fwd", "bn_act_bwd_reduce", "bn_bwd_apply", "opt_step",
+           "conv1x1_fwd_grouped")
+  seen = {}
+
+  def stand_in(name):
+    sig = inspect.signature(getattr(real, name))
+
+    def f(*a, **kw):
+      sig.bind(*a, **kw)                 # TypeError if the wrapper dropped or invented an argument
+      seen[name] = seen.get(name, 0) + 1
+      return x
+    f.__signature__ = sig
+    return f
+
+  fake = types.SimpleNamespace(**{n: stand_in(n) for n in names})
+  fake.same_padding = real.same_padding
+  bd = bench.StepBreakdown(fake)
+  bd._bracket = lambda family, work, call: call()
+  bd.install()
+  for n in names[:-1]:
+    sig = inspect.signature(getattr(real, n))
+    args, kwargs = [], {}
+    for p in sig.parameters.values():
+      if p.kind is p.VAR_POSITIONAL or p.kind is p.VAR_KEYWORD:
+        continue
+      v = by_name.get(p.name, p.default if p.default is not p.empty else 1)
+      if p.kind is p.KEYWORD_ONLY or p.default is not p.empty:
+        kwargs[p.name] = v
+      else:
+        args.append(v)
+    getattr(fake, n)(*args, **kwargs)
+    assert seen.get(n) == 1, n
+  bd.remove()
+
+
+def test_committed_line_breakdown_has_no_error_and_headline_is_last():
+  d, path = _latest()
+  r = d["roofline"]
+  if "rest_of_step_ok" in r:                  # lines written from round 6 on
+    assert r["rest_of_step_ok"] is True, (path, r.get("rest_of_step"))
+    assert isinstance(r["rest_of_step"], dict) and "error" not in r["rest_of_step"]
+    assert list(d.keys())[-1] == "headline"
+    h = d["headline"]
+    assert h["value"] == d["value"] and h["ms_per_step"] == d["ms_per_step"]
+    assert abs(h["roofline"]["frac"] - r["frac"]) < 1e-12
+    assert h["secondary"]["ms_per_step"] == d["secondary"]["ms_per_step"]
+    assert len(json.dumps(h)) < 2000          # fits the tail the driver keeps
+    assert r["sampled_frac"] >= r["frac"] * 0.8 and "frac_is" in r
+
+
+def test_with_headline_puts_both_metrics_in_the_tail():
+  bench = _load_bench()
+  out = {"metric": "m", "value": 1.0, "unit": "frames/sec", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 3.0,
+         "dtype": "bf16", "config": {"workload": "w"},
+         "roofline": {"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None,
+                      "note": "x" * 5000},
+         "secondary": {"value": 9.0, "unit": "tokens/sec", "ms_per_step": 4.0, "roofline": {"frac": 0.25}},
+         "other_configs": {"tacotron_decode": {"us_per_step": 30.0}, "ds2": {"ms_per_step": 50.0},
+                           "nmt": {"error": "boom"}},
+         "cpu_baseline": {"value": 2.0, "unit": "frames/sec", "cores": 4, "kind": "port", "sample": "s" * 3000}}
+  line = json.dumps(bench.with_headline(out))
+  tail = line[-2000:]
+  assert '"headline"' in tail
+  h = json.loads(line)["headline"]
+  assert h["secondary"] == {"value": 9.0, "unit": "tokens/sec", "ms_per_step": 4.0, "roofline_frac": 0.25}
+  assert h["tacotron_decode_us_per_step"] == 30.0 and h["other_ms_per_step"] == {"ds2": 50.0}
+  c = json.loads(line)["config"]
+  assert c["secondary_value"] == 9.0 and c["secondary_ms_per_step"] == 4.0 and c["secondary_roofline_frac"] == 0.25
+  assert c["tacotron_decode_us_per_step"] == 30.0 and c["ds2_ms_per_step"] == 50.0
