@@ -47,9 +47,19 @@ struct WgradArgs {
   float* ws_slabs;
   int* ws_cnt;
   int ws_nslabs, ncu, force_split;
+  int xcd_order;             // 1: consecutive ranks (the tap quads / ci tiles of one tile) share an XCD (wgrad_xcd_rank)
   unsigned long long* dbg;   // experiment hook: slot time stamps [4 wg][2 waves][48 steps][10]
   int dbg_mode;              // experiment hook (DBG kernel): 1 no dY DMA, 2 no X DMA, 4 frozen cursor
 };
+
+// Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"; a wrong guess costs speed,
+// never results). Consecutive ranks of the ping-pong / one-wave kernels are the tap quads (or ci tiles) of ONE
+// (co, ci) tile: they stream the same dY / X rows at the same time, so they belong behind the same L2. Bijective on
+// [0, n): XCD x owns the contiguous ranks [start(x), start(x + 1)).
+__device__ __forceinline__ int wgrad_xcd_rank(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 
 __device__ __forceinline__ void dma16w(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -407,8 +417,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   }
   const int nfull = f > 1 ? U - r : U;
   const int nwork = nfull + (f > 1 ? r * f : 0);
-  const int bid = blockIdx.x;
-  if (bid >= nwork) return;
+  if ((int)blockIdx.x >= nwork) return;
+  const int bid = p.xcd_order ? wgrad_xcd_rank(blockIdx.x, nwork) : (int)blockIdx.x;
   int rank = bid, piece = 0, npiece = 1;
   if (bid >= nfull) {
     const int i = bid - nfull;
@@ -739,6 +749,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   }
 }
 
+#include "conv1d_wgrad_sw.hpp"
+
 // ---------------------------------------------------------------------------------------------
 // Ping-pong weight gradient of the K = 1 convolution = the weight gradient of tf.layers.Dense
 // (Transformer projections, attention_layer.py:54-62 / ffn_layer.py:51-85 / embedding_layer.py:
@@ -817,8 +829,8 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad1x1_pp_kernel(WgradArgs p,
   }
   const int nfull = f > 1 ? U - r : U;
   const int nwork = nfull + (f > 1 ? r * f : 0);
-  const int bid = blockIdx.x;
-  if (bid >= nwork) return;
+  if ((int)blockIdx.x >= nwork) return;
+  const int bid = p.xcd_order ? wgrad_xcd_rank(blockIdx.x, nwork) : (int)blockIdx.x;
   int rank = bid, piece = 0, npiece = 1;
   if (bid >= nfull) {
     const int i = bid - nfull;
@@ -1116,8 +1128,10 @@ static bool wgrad1x1_pp_auto(int B, int T, int Cin, int Cout, bool have_ws) {
   const int units = os2s::ceil_div(Cout, 256) * os2s::ceil_div(Cin, 256);
   return have_ws && rows >= 2048 && units >= 32;
 }
-static int g_wgrad_variant = -1;   // experiment / test hook: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong
+static int g_wgrad_variant = -1;   // experiment / test hook: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, 3 = one wave per SIMD
 static int g_wgrad_split = -1;
+static int g_wgrad_sw_ablate = 0;  // conv1d_wgrad.sw_ablate: only read by builds with -DOS2S_SW_ABLATE
+static int g_wgrad_xcd = 1;        // conv1d_wgrad.xcd_order: 0 = rank = blockIdx.x (rounds 2 - 5), 1 = wgrad_xcd_rank
 static unsigned long long* g_wgrad_dbg = nullptr;
 static int g_wgrad_dbg_mode = 0;
 // os2s_set_option: conv1d_wgrad.variant (0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, -1 = by shape),
@@ -1125,6 +1139,8 @@ static int g_wgrad_dbg_mode = 0;
 // debug stamps "conv1d_wgrad" (tools/pp_timeline.py): per-slot time stamps of the ping-pong kernel
 static os2s::OptionReg r_wg_variant("conv1d_wgrad.variant", [](double v) { g_wgrad_variant = (int)v; });
 static os2s::OptionReg r_wg_split("conv1d_wgrad.split", [](double v) { g_wgrad_split = (int)v; });
+static os2s::OptionReg r_wg_abl("conv1d_wgrad.sw_ablate", [](double v) { g_wgrad_sw_ablate = (int)v; });
+static os2s::OptionReg r_wg_xcd("conv1d_wgrad.xcd_order", [](double v) { g_wgrad_xcd = v != 0 ? 1 : 0; });
 static os2s::StampReg r_wg_stamps("conv1d_wgrad", [](void* stamps, int mode) {
   g_wgrad_dbg = (unsigned long long*)stamps;
   g_wgrad_dbg_mode = mode;
@@ -1173,7 +1189,7 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
   a.stride = stride; a.dil = dil; a.padL = padL; a.x_ld = x_row_stride;
   a.accumulate = accumulate ? 1 : 0;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
-  a.dbg = g_wgrad_dbg; a.dbg_mode = g_wgrad_dbg_mode;
+  a.dbg = g_wgrad_dbg; a.dbg_mode = g_wgrad_dbg_mode; a.xcd_order = g_wgrad_xcd;
 
   // ---- ping-pong kernel ------------------------------------------------------------------
   const bool pp_shape = stride == 1 && K >= 2 && B <= 64 && Cout >= 128 && Cin >= 64 &&
@@ -1184,6 +1200,69 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
   // (co, ci, 4-tap) tiles of the ping-pong kernel; with the reduction split across workgroups even
   // the 256-channel layers (12 tiles) beat the lockstep kernel (0.076 vs 0.093 ms ragged)
   const int pp_units = ceil_div(Cout, 128) * ceil_div(Cin, 128) * ceil_div(K, kWppTaps);
+  // ---- one wave per SIMD, 16 accumulator blocks per wave (conv1d_wgrad_sw.hpp; round 6): the same units ----
+  const bool sw_shape = pp_shape && 63 + 3 * dil + 1 <= kSwXInstr * 16 &&     // the X window fits the 20 KB slot
+                        Cout % 128 == 0 && Cin % 128 == 0;                      // whole tiles only
+  // Opt-in (conv1d_wgrad.variant 3): measured against the ping-pong kernel on the 768 x 768 x 25 layer it needs 3 050
+  // cycles per 64-row step at 2.11 GHz where the ping-pong kernel needs 2 400 at 1.75 GHz — 0.648 vs 0.612 ms
+  // (profiles/r06_wgrad_sw_ablation.txt, DESIGN.md "Round-6 kernel work").
+  if (sw_shape && g_wgrad_variant == 3) {
+    a.NCO = ceil_div(Cout, 128);
+    a.NCI = ceil_div(Cin, 128);
+    a.NTP = ceil_div(K, kWppTaps);
+    a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
+    a.xrows = 63 + (kWppTaps - 1) * dil + 1;
+    a.xrows_pad = ceil_div(a.xrows, 4) * 4;
+    a.xbuf_bytes = kSwXBuf;
+    a.steptab_bytes = ceil_div(B * ceil_div(Tout, 64) * 4, 16) * 16;
+    const size_t smem = (size_t)kSwRing * (kSwYBuf + kSwXBuf) + a.steptab_bytes;
+    if (smem <= 160 * 1024) {
+      static std::once_flag once_sw;
+      static hipError_t attr_rc = hipSuccess;
+      static int ncu = 256;
+      std::call_once(once_sw, [] {
+        attr_rc = hipFuncSetAttribute((const void*)conv1d_wgrad_sw_kernel<0>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef OS2S_SW_ABLATE
+        for (const void* k : {(const void*)conv1d_wgrad_sw_kernel<1>, (const void*)conv1d_wgrad_sw_kernel<2>,
+                              (const void*)conv1d_wgrad_sw_kernel<4>, (const void*)conv1d_wgrad_sw_kernel<8>,
+                              (const void*)conv1d_wgrad_sw_kernel<3>, (const void*)conv1d_wgrad_sw_kernel<5>})
+          if (attr_rc == hipSuccess) attr_rc = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+          ncu = n;
+      });
+      if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
+      a.ncu = ncu;
+      const size_t slab_bytes = (size_t)kSplitSlabFloats * 4;
+      if (workspace && workspace_bytes >= kSplitTicketBytes + 2 * slab_bytes) {
+        a.ws_cnt = reinterpret_cast<int*>(workspace);
+        a.ws_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + kSplitTicketBytes);
+        size_t n = (workspace_bytes - kSplitTicketBytes) / slab_bytes;
+        const size_t cap = (size_t)3 * ncu;
+        a.ws_nslabs = (int)(n < cap ? n : cap);
+      }
+      const int U = a.NCO * a.NCI * a.NTP;
+      const int r = U % ncu;
+      const int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
+#ifdef OS2S_SW_ABLATE      // measurement build only (tools/sw_ablate.py): the stream with one ingredient removed
+      switch (g_wgrad_sw_ablate) {
+        case 1: OS2S_LAUNCH(conv1d_wgrad_sw_kernel<1>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a); return OS2S_OK;
+        case 2: OS2S_LAUNCH(conv1d_wgrad_sw_kernel<2>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a); return OS2S_OK;
+        case 3: OS2S_LAUNCH(conv1d_wgrad_sw_kernel<3>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a); return OS2S_OK;
+        case 4: OS2S_LAUNCH(conv1d_wgrad_sw_kernel<4>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a); return OS2S_OK;
+        case 5: OS2S_LAUNCH(conv1d_wgrad_sw_kernel<5>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a); return OS2S_OK;
+        case 8: OS2S_LAUNCH(conv1d_wgrad_sw_kernel<8>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a); return OS2S_OK;
+        default: break;
+      }
+#endif
+      OS2S_LAUNCH(conv1d_wgrad_sw_kernel<0>, dim3(U + pieces), dim3(256), smem, (hipStream_t)stream, a);
+      return OS2S_OK;
+    }
+  }
+
   if (pp_shape && g_wgrad_variant != 0 && (g_wgrad_variant == 1 || pp_units >= wgrad_pp_min_units())) {
     a.NCO = ceil_div(Cout, 128);
     a.NCI = ceil_div(Cin, 128);
@@ -1364,7 +1443,7 @@ extern "C" int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad
   a.B = B; a.Tin = T; a.Tout = T; a.Cin = 0; a.Cout = 0; a.K = 1;
   a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = 0; a.accumulate = 1;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
-  a.dbg = nullptr; a.dbg_mode = 0;
+  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd;
   a.NCO = 0; a.NCI = 0; a.NTP = 1;
   a.steps_per_split = ceil_div(total_steps, nsplit);
   a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
@@ -1432,7 +1511,7 @@ extern "C" int os2s_conv1x1_wgrad_grouped_ws(os2s_stream_t stream, const os2s_wg
   a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = gt.g[0].x_ld;
   a.accumulate = 1;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
-  a.dbg = nullptr; a.dbg_mode = 0;
+  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd;
   a.NCO = units; a.NCI = 1; a.NTP = 1;                   // U = NCO * NCI = all units of all groups
   a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
   a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;
@@ -1494,7 +1573,7 @@ extern "C" int os2s_gemm_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_gr
   a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = gt.g[0].x_ld;
   a.accumulate = accumulate ? 1 : 0;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
-  a.dbg = nullptr; a.dbg_mode = 0;
+  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd;
   a.NCO = units; a.NCI = 1; a.NTP = 1;                   // U = NCO * NCI = all units of all groups
   a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
   a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;

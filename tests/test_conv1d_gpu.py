@@ -444,6 +444,89 @@ def test_conv_wgrad_pingpong_full_size_vs_lockstep(cuda):
   torch.testing.assert_close(b, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,T,Cin,Cout,K,d", [(3, 420, 256, 512, 17, 1), (2, 333, 384, 640, 21, 1),
+                                              (2, 300, 768, 896, 29, 2), (4, 200, 128, 256, 2, 1),
+                                              (2, 150, 256, 128, 5, 1), (3, 260, 128, 128, 3, 1),
+                                              (2, 190, 256, 384, 13, 3), (2, 500, 128, 256, 11, 5),
+                                              (1, 64, 128, 128, 4, 1), (5, 130, 256, 256, 8, 2)])
+@pytest.mark.parametrize("split", [1, 3, -1])
+def test_conv_wgrad_one_wave_per_simd_kernel(cuda, B, T, Cin, Cout, K, d, split):
+  """conv1d_wgrad_sw_kernel forced (option conv1d_wgrad.variant 3: one wave per SIMD, 16 accumulator blocks per
+  wave, hand-written instruction stream) at every class of tap count (4n: no dead tap; 4n + 1 ... 4n + 3: waves whose
+  tap pair is half or wholly past K), dilation 1 ... 5 (the widest X window the 20 KB slot holds), one-step and
+  many-step reductions, ragged lengths with dead chunks; reduction unsplit, cut 3 ways and by the cost model: vs
+  autograd of the fp32 oracle (fp32 summation-order noise only: rtol 2e-3), accumulate on top of a previous dW,
+  run-to-run bitwise reproducibility (no atomics), tickets left at zero."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(B * 77 + T + K + Cout + 1)
+  x = _bf(torch.randn(B, T, Cin, generator=g))
+  w_tf = (torch.randn(K, Cin, Cout, generator=g) * 0.05).requires_grad_(True)
+  lens = torch.randint(T // 4, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  lens[-1] = max(1, T // 6)
+  y = cnn.conv1d_tf(x.float(), w_tf, 1, d, "SAME", mask_len=lens)
+  dy = _bf(torch.randn(y.shape, generator=g))
+  y.backward(dy.float())
+  ref = cnn.to_dev_layout(w_tf.grad)
+  base = torch.randn(K, Cout, Cin, generator=g)
+  _lib.set_option("conv1d_wgrad.variant", 3); _lib.set_option("conv1d_wgrad.split", split)
+  try:
+    o1 = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
+    o2 = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
+    o3 = base.clone().to(cuda)
+    capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda), out=o3, accumulate=True)
+    _lib.set_option("conv1d_wgrad.variant", 0); _lib.set_option("conv1d_wgrad.split", -1)
+    lock = capi.conv1d_wgrad(x.to(cuda), dy.to(cuda), K, dil=d, in_len=lens.to(cuda))
+    torch.cuda.synchronize()
+  finally:
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
+  scale = float(ref.pow(2).mean().sqrt()) + 1e-6
+  torch.testing.assert_close(o1.cpu(), ref, rtol=2e-3, atol=2e-3 * scale)
+  assert torch.equal(o1, o2)
+  torch.testing.assert_close(o3.cpu(), ref + base, rtol=2e-3, atol=2e-3 * scale)
+  assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0
+  if split == 1:      # unsplit: the live 64-row chunks are added in the order of the lockstep kernel
+    assert torch.equal(o1, lock)
+
+
+@pytest.mark.parametrize("C,K,d", [(768, 25, 1), (896, 29, 2), (512, 17, 1), (384, 13, 1), (1024, 1 + 4, 1)])
+def test_conv_wgrad_one_wave_per_simd_full_size_vs_lockstep(cuda, C, K, d):
+  """BASELINE-size layers (B = 32, T' = 840, ragged): the one-wave-per-SIMD kernel unsplit is BIT-IDENTICAL to
+  the oracle-checked lockstep kernel and to the ping-pong kernel; cut 4 ways it differs by fp32 summation order
+  only. Also the default launch (ping-pong kernel, cost-model split, XCD-ordered ranks): deterministic."""
+  from openseq2seq_amd import capi, _lib
+  g = torch.Generator().manual_seed(5 + C + K)
+  B, T = 32, 840
+  x = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  dy = _bf(torch.randn(B, T, C, generator=g)).to(cuda)
+  lens = torch.randint(100, T + 1, (B,), generator=g).to(torch.int32).to(cuda)
+  try:
+    _lib.set_option("conv1d_wgrad.variant", 0); _lib.set_option("conv1d_wgrad.split", -1)
+    ref = capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens)
+    _lib.set_option("conv1d_wgrad.variant", 1); _lib.set_option("conv1d_wgrad.split", 1)
+    pp = capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens)
+    _lib.set_option("conv1d_wgrad.variant", 3); _lib.set_option("conv1d_wgrad.split", 1)
+    a = capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens)
+    # (a register read in the shadow of the last MFMAs showed up as ONE wrong 32 x 32 block in one launch of ten)
+    again = [capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens) for _ in range(12)]
+    _lib.set_option("conv1d_wgrad.variant", 3); _lib.set_option("conv1d_wgrad.split", 4)
+    b = capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens)
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
+    c = capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens)
+    c2 = capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens)
+    torch.cuda.synchronize()
+  finally:
+    _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
+  assert torch.equal(pp, ref)
+  assert torch.equal(a, ref), (int((a != ref).sum()), float((a - ref).abs().max()))
+  for o in again:
+    assert torch.equal(o, ref), (int((o != ref).sum()), float((o - ref).abs().max()))
+  tol = 1e-4 * float(ref.abs().max())
+  torch.testing.assert_close(b, ref, rtol=1e-4, atol=tol)
+  torch.testing.assert_close(c, ref, rtol=1e-4, atol=tol)
+  assert torch.equal(c, c2)
+
+
 @pytest.mark.parametrize("B,T,Cin,Cout", [(3, 420, 256, 512), (2, 333, 320, 640), (1, 1111, 1024, 1024),
                                          (4, 200, 128, 264), (5, 97, 520, 136)])
 @pytest.mark.parametrize("split", [1, 3, -1])

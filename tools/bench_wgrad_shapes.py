@@ -37,10 +37,11 @@ for cin, cout, K in shapes:
     _lib.set_option("conv1d_wgrad.variant", 0); _lib.set_option("conv1d_wgrad.split", -1)
     t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
     out.append("lockstep %.3f ms %4.0f TF" % (t, fl / t / 1e9))
-    for f in (-1, 1, 2, 3, 4, 6, 8, 12, 16):
-      _lib.set_option("conv1d_wgrad.variant", 1); _lib.set_option("conv1d_wgrad.split", f)
-      t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
-      out.append("f%d %.3f" % (f, t) + (" %4.0f TF" % (fl / t / 1e9) if f == -1 else ""))
+    for variant, label in ((1, "pp"), (3, "sw")):      # ping-pong (2 waves / SIMD) vs one wave per SIMD (round 6)
+      for f in ((-1, 1, 2, 3, 4, 6, 8, 12, 16) if os.environ.get("OS2S_BENCH_SPLITS") else (-1, 1)):
+        _lib.set_option("conv1d_wgrad.variant", variant); _lib.set_option("conv1d_wgrad.split", f)
+        t = timeit(lambda: capi.conv1d_wgrad(x, dy, K, dil=dil, pad_left=pl, in_len=lens, out=dw, accumulate=True))
+        out.append("%s f%d %.3f" % (label, f, t) + (" %4.0f TF" % (fl / t / 1e9)))
     _lib.set_option("conv1d_wgrad.variant", -1); _lib.set_option("conv1d_wgrad.split", -1)
     units = ((cout + 127) // 128) * ((cin + 127) // 128) * ((K + 3) // 4)
     print("C %4d->%4d K %2d %-6s units %3d: %s" % (cin, cout, K, name, units, "  ".join(out)), flush=True)
