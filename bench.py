@@ -80,6 +80,15 @@ def parse():
   ap.add_argument("--one-rank-group", action="store_true",
                   help="N=1 only: run the data-parallel path (RCCL process group, bucketed all-reduce on "
                        "the side stream, comm diagnostics) on a one-rank group")
+  ap.add_argument("--bucket-mb", type=float, default=None,
+                  help="size of the gradient all-reduce buckets in MB of fp32 (default 128; OS2S_BUCKET_MB)")
+  ap.add_argument("--allreduce-dtype", choices=["fp32", "bf16"], default=None,
+                  help="what crosses the wire in the gradient all-reduce (default fp32; OS2S_ALLREDUCE_DTYPE)")
+  ap.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                  help="process-group backend for --gpus N (default: nccl = RCCL)")
+  ap.add_argument("--one-device", action="store_true",
+                  help="rehearsal of --gpus N on a one-GPU box: every rank runs on cuda:0 over gloo (the numbers "
+                       "describe nothing; the line, the comm block and the collectives are the real ones)")
   ap.add_argument("--launcher-dry-run", action="store_true",
                   help="exercise only the multi-rank launcher and the timing collectives (no GPU "
                        "work: runs on CPU over gloo); prints the JSON line with value null")
@@ -796,11 +805,21 @@ def bench_transformer(args, hvd, dev, rank, world):
   for _ in range(args.warmup):
     model.train_step(batch)
   barrier()
+  reducer = getattr(model, "_reducer", None)
+  if reducer is not None:
+    reducer.timing = True
   t0 = time.perf_counter()
   for _ in range(args.steps):
     loss = model.train_step(batch)
   barrier()
   dt = time.perf_counter() - t0
+  comm = None
+  if reducer is not None:
+    reducer.timing = False
+    comm = reducer.pop_timing()
+    if comm is not None:
+      comm["backend"] = torch.distributed.get_backend()
+      comm["exposed_share_of_step"] = comm["exposed_ms_per_step"] / (1000.0 * dt / args.steps)
   tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
   toks = torch.tensor([float(batch['num_tokens'])], dtype=torch.float64, device=dev)
   if world > 1:
@@ -826,6 +845,8 @@ def bench_transformer(args, hvd, dev, rank, world):
       "params_M": model.store.num_trainable() / 1e6,
       "loss": float(loss.cpu()[0]), "skipped_steps": st["num_skipped"],
   }
+  if comm is not None:
+    res["comm"] = comm
   del model
   torch.cuda.empty_cache()
   return res
@@ -1016,8 +1037,12 @@ def main():
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     sys.exit(spawn_ranks(args.gpus))      # one process per GPU; this process only waits for them
   claim_stdout()
+  if args.bucket_mb is not None:
+    os.environ["OS2S_BUCKET_MB"] = repr(args.bucket_mb)
+  if args.allreduce_dtype is not None:
+    os.environ["OS2S_ALLREDUCE_DTYPE"] = args.allreduce_dtype
   from openseq2seq_amd.utils import distributed as dist_utils
-  hvd = dist_utils.init_from_env()
+  hvd = dist_utils.init_from_env(backend=args.backend, one_device=args.one_device)
   if args.one_rank_group and hvd is None:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
@@ -1033,7 +1058,7 @@ def main():
   if args.launcher_dry_run:
     launcher_dry_run(args, hvd, rank, world)
     return
-  dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+  dev = torch.device("cuda", 0 if args.one_device else int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
   if args.pp_cost:
     import ctypes
@@ -1045,8 +1070,9 @@ def main():
     for n, v in zip(names, args.pp_cost.split(",")):
       assert f(n.encode(), float(v)) == 0
   if rank == 0 and world > 1:
-    print("bench.py: %d ranks, backend %s (RCCL), one process per GPU" % (
-        world, torch.distributed.get_backend()), file=sys.stderr)
+    print("bench.py: %d ranks, backend %s%s" % (
+        world, torch.distributed.get_backend(),
+        ", ALL ON cuda:0 (rehearsal)" if args.one_device else " (RCCL), one process per GPU"), file=sys.stderr)
 
   simple = {
       "quartznet": ("openseq2seq_amd.configs.quartznet", "quartznet15x5_config", {},
@@ -1238,7 +1264,9 @@ def main():
           "workload": "Jasper 10x5 DR (jasper10x5_LibriSpeech_nvgrad_masks) full train step: %s"
                       "fwd+bwd+%sNovoGrad/LARC/Backoff, B=%d/GPU, %s, F=64, V=29" % (
                           "log-mel front end from int16 PCM resident in HBM+" if step_from_pcm is not None else "",
-                          "RCCL all-reduce+" if world > 1 else "",
+                          ("RCCL all-reduce+" if torch.distributed.get_backend() == "nccl"
+                           else "%s all-reduce (rehearsal on one device)+" % torch.distributed.get_backend())
+                          if world > 1 else "",
                           args.batch, ("T=%d fixed" % args.fixed_frames) if args.fixed_frames
                           else "durations U[2,16.7]s padded to the batch max"),
           "front_end_in_timed_step": step_from_pcm is not None,
@@ -1397,9 +1425,15 @@ def with_headline(out):
                                if isinstance(oc.get(k), dict) and oc[k].get("ms_per_step") is not None}
   if isinstance(td, dict) and td.get("us_per_step") is not None:
     head["tacotron_decode_us_per_step"] = td["us_per_step"]
+  keys = ("world_size", "backend", "allreduce_ms_per_step", "exposed_ms_per_step", "bus_GBps", "bucket_mb",
+          "buckets_per_step", "allreduce_dtype")
   if isinstance(out.get("comm"), dict):
-    head["comm"] = pick(out["comm"], "world_size", "allreduce_ms_per_step", "exposed_ms_per_step", "bus_GBps",
-                        "bucket_mb", "allreduce_dtype")
+    head["comm"] = pick(out["comm"], *keys)
+    for k in ("allreduce_ms_per_step", "exposed_ms_per_step", "bus_GBps", "bucket_mb", "allreduce_dtype"):
+      if out["comm"].get(k) is not None:
+        cfg["comm_" + k] = out["comm"][k]
+  if isinstance(sec.get("comm"), dict):
+    head["secondary"]["comm"] = pick(sec["comm"], *keys)
   out.pop("headline", None)
   out["headline"] = head
   return out

@@ -282,9 +282,16 @@ class Model(object):
       tape = Tape(on_done=self._reducer.mark_done if overlap else None)
       loss = self._forward_backward(batch, tape)
       tape.backward()
-      if capi.gru_xcd_launch_count() != launches0:
-        self._gru_guard = True          # this model runs persistent GRU kernels: snapshots from the next step on
-        loss = self._recover_gru_abort(batch, loss, snap, micro, overlap)
+      ran_persistent = capi.gru_xcd_launch_count() != launches0
+      # Whether a rank ran persistent launches depends on ITS batch shape and environment (B <= 32, T >= 2,
+      # OS2S_GRU_XCD), so under data parallelism the decision to enter the status all-reduce must not: every rank
+      # of a model with recurrent layers enters it until the persistent path is known to be off everywhere.
+      world = self._hvd.size() if self._hvd is not None else 1
+      if self._gru_agree is None:          # from the CONFIGURATION (identical on every rank), not from what ran here
+        self._gru_agree = world > 1 and self._has_gru_layers()
+      if ran_persistent or (world > 1 and self._gru_agree):
+        self._gru_guard = ran_persistent   # snapshots from the next step on — only while the persistent path runs
+        loss = self._recover_gru_abort(batch, loss, snap, micro, overlap, ran_persistent)
       self._step_count += 1
       if last_micro:
         if self._reducer is not None:
@@ -294,9 +301,18 @@ class Model(object):
       set_side_stream_enabled(prev)
     return loss
 
-  _gru_guard = False
+  def _has_gru_layers(self):
+    """Does the configuration build cuDNN-form GRU layers (the only ones the persistent kernels take)?"""
+    for part in (getattr(self, "_encoder", None), getattr(self, "_decoder", None)):
+      params = getattr(part, "params", None) or {}
+      if "gru" in str(params.get("rnn_type", "")).lower():
+        return True
+    return False
 
-  def _recover_gru_abort(self, batch, loss, snap, micro, overlap):
+  _gru_guard = False
+  _gru_agree = None      # world > 1: does this model take part in the per-step agreement (set on the first step)
+
+  def _recover_gru_abort(self, batch, loss, snap, micro, overlap, ran_persistent=True):
     """The persistent GRU kernels (csrc/rnn_xcd.hip) need 32 co-resident workgroups per XCD and give up after a
     bounded wait when they do not get them (CUs held by RCCL's resident kernels, a second process on the
     device, a partitioned GPU): the launch sets a sticky word and its outputs are garbage. Instead of raising
@@ -306,15 +322,21 @@ class Model(object):
     process. The first step of a model has no snapshot yet: its BatchNorm statistics are re-initialised by the
     redone forward pass only in so far as the moving average forgets (documented; the abort of a FIRST step was
     never observed — the placement check fails at launch, before any state is written)."""
-    torch.cuda.current_stream().synchronize()
-    code = capi.gru_xcd_status(clear=True)
+    code = 0
+    if ran_persistent:
+      torch.cuda.current_stream().synchronize()
+      code = capi.gru_xcd_status(clear=True)
     world = self._hvd.size() if self._hvd is not None else 1
     if world > 1:
-      t = torch.tensor([code], dtype=torch.int32, device=self._device)
+      # [abort code, "I still run persistent launches"]: MAX over the ranks. Once no rank runs them the
+      # agreement stops on every rank at the same step (the same collective sequence everywhere).
+      t = torch.tensor([code, int(ran_persistent)], dtype=torch.int32, device=self._device)
       torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-      code = int(t.item())
+      code, anyone = int(t[0].item()), int(t[1].item())
+      self._gru_agree = bool(anyone) and code == 0
     if code == 0:
       return loss
+    self._gru_guard = False             # the persistent path is off from here on: no more snapshots
     import warnings
     warnings.warn("a persistent GRU launch gave up (code %d: 1 = poll timeout, 2 = workgroup placement); the step "
                   "is redone on the launch-per-step kernels, which stay selected for this process" % code)

@@ -4,6 +4,9 @@ metric (:356-360) and WER helpers (levenshtein :51-71, sparse_tensor_to_chars)."
 from __future__ import absolute_import, division, print_function
 
 import numpy as np
+import torch
+
+from .. import capi
 
 from .encoder_decoder import EncoderDecoderModel
 
@@ -83,10 +86,31 @@ class Speech2Text(EncoderDecoderModel):
     return loss
 
   def forward(self, batch):
-    """eval / infer forward pass: returns decoder output dict."""
-    enc = self._encoder.encode({'source_tensors': batch['source_tensors'],
-                                'source_lengths_host': batch.get('source_lengths_host')})
-    return self._decoder.decode({'encoder_output': enc})
+    """eval / infer forward pass: returns decoder output dict. A persistent GRU launch that gave up (csrc/
+    rnn_xcd.hip: CUs held by another process, RCCL's resident kernels, a partitioned GPU) leaves garbage in its
+    outputs and a sticky status word; outside train_step nothing else reads that word, so it is read here — the
+    transcripts / WER of this batch come from the pass below or from its repetition on the launch-per-step
+    kernels, never from an aborted launch."""
+    def once():
+      enc = self._encoder.encode({'source_tensors': batch['source_tensors'],
+                                  'source_lengths_host': batch.get('source_lengths_host')})
+      return self._decoder.decode({'encoder_output': enc})
+    launches0 = capi.gru_xcd_launch_count()
+    dec = once()
+    if capi.gru_xcd_launch_count() != launches0:
+      torch.cuda.current_stream().synchronize()
+      code = capi.gru_xcd_status(clear=True)
+      if code:
+        import warnings
+        warnings.warn("a persistent GRU launch gave up in an eval / infer pass (code %d: 1 = poll timeout, 2 = "
+                      "workgroup placement); the batch is redone on the launch-per-step kernels, which stay "
+                      "selected for this process" % code)
+        capi.gru_xcd_set_mode(0)
+        dec = once()
+        torch.cuda.current_stream().synchronize()
+        if capi.gru_xcd_status(clear=True):
+          raise RuntimeError("the launch-per-step recurrent kernels reported a persistent-kernel abort")
+    return dec
 
   def _decoded(self, dec):
     """Decoded label ids of a decoder output: the decoder's own text generation (greedy, or the

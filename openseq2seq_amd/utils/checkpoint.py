@@ -223,6 +223,10 @@ def _half_in_reference(p):
   if p.kind != "vector":
     return True
   n = p.name
+  # tf.contrib.layers.layer_norm / instance_norm create gamma / beta in the dtype of their INPUT (conv_ln_actv /
+  # conv_in_actv, parts/cnns/conv_blocks.py:234-309): half in a mixed-precision graph, with fp32 master twins
+  if re.search(r"/(LayerNorm|InstanceNorm)(_\d+)?/(gamma|beta)$", n):
+    return True
   return (n.endswith("/bias") or n.endswith("/bias_h")) and "/bn/" not in n and "/row_conv/" not in n
 
 
@@ -290,6 +294,7 @@ def save(model, logdir, step=None, format="tf"):
       arrays["OS2S/opt/m2"] = store.m2.detach().cpu().numpy()
     arrays["OS2S/opt/state"] = train_op.state.detach().cpu().numpy()
     arrays["OS2S/opt/t_v"] = store.t_v.detach().cpu().numpy()
+    arrays["OS2S/opt/layout"] = slot_layout(store)
   prefix = "model.ckpt-%d" % int(step)
   if format == "npz":
     np.savez(os.path.join(logdir, prefix + ".npz"), **arrays)
@@ -360,10 +365,63 @@ def load(model, prefix, restore_optimizer=True, strict=True):
   store.refresh_compute_copies()
   train_op = getattr(model, "_train_op", None)
   if restore_optimizer and train_op is not None and "OS2S/opt/state" in data:
-    if data["OS2S/opt/m1"].shape == tuple(store.m1.shape):
-      store.m1.copy_(torch.from_numpy(data["OS2S/opt/m1"]))
-      if store.m2 is not None and "OS2S/opt/m2" in data:
-        store.m2.copy_(torch.from_numpy(data["OS2S/opt/m2"]))
-      train_op.state.copy_(torch.from_numpy(data["OS2S/opt/state"]))
-      store.t_v.copy_(torch.from_numpy(data["OS2S/opt/t_v"]))
+    restore_slots(store, train_op, data, path)
   return missing
+
+
+def slot_layout(store):
+  """[n, 3] int64: (crc32 of the variable name, offset, element count) of every trainable variable in the flat
+  buffers, in creation order — what the optimizer slots (OS2S/opt/m1, m2: flat fp32 buffers; t_v: one value per
+  variable) are laid out by. The total of the chunk-padded sizes does not depend on the creation order, so the
+  shapes of the flat buffers alone cannot tell a file written under a different order (round 5 moved the
+  Transformer decoder's encoder-decoder K / V kernels in front of the per-layer variables)."""
+  import zlib
+  return np.asarray([[zlib.crc32(p.name.encode()) & 0xffffffff, p.offset, p.numel] for p in store.params], np.int64)
+
+
+def restore_slots(store, train_op, data, path=""):
+  """Optimizer moments of a checkpoint into the store: flat copies when the file's layout IS the store's, variable
+  by variable (matched by name hash and size) when the creation order differs, not at all — with a warning; the
+  moments then restart from zero — when the file carries no layout (written before round 6: nothing says which
+  variable a slot element belongs to). The scalar optimizer state (step count, loss scale) is restored in all
+  three cases."""
+  import warnings
+  train_op.state.copy_(torch.from_numpy(data["OS2S/opt/state"]))
+  if "OS2S/opt/m1" not in data:
+    return "none"
+  cur = slot_layout(store)
+  if "OS2S/opt/layout" not in data:
+    warnings.warn("checkpoint %s holds optimizer moments without a layout record (written before round 6): they "
+                  "are NOT restored (moments restart from zero; weights, step count and loss scale are restored)"
+                  % path)
+    return "skipped"
+  old = np.asarray(data["OS2S/opt/layout"], np.int64).reshape(-1, 3)
+  m1 = torch.from_numpy(np.asarray(data["OS2S/opt/m1"], np.float32))
+  m2 = torch.from_numpy(np.asarray(data["OS2S/opt/m2"], np.float32)) if (store.m2 is not None and
+                                                                          "OS2S/opt/m2" in data) else None
+  t_v = torch.from_numpy(np.asarray(data["OS2S/opt/t_v"], np.float32)) if "OS2S/opt/t_v" in data else None
+  if old.shape == cur.shape and np.array_equal(old, cur) and tuple(m1.shape) == tuple(store.m1.shape):
+    store.m1.copy_(m1)
+    if m2 is not None:
+      store.m2.copy_(m2)
+    if t_v is not None:
+      store.t_v.copy_(t_v)
+    return "flat"
+  # a different creation order (or a different set of variables): slot by slot
+  by_key = {(int(h), int(n)): (i, int(off)) for i, (h, off, n) in enumerate(old)}
+  lost = []
+  for i, (h, off, n) in enumerate(cur):
+    hit = by_key.get((int(h), int(n)))
+    if hit is None or hit[1] + int(n) > m1.numel():
+      lost.append(store.params[i].name)
+      continue
+    j, ooff = hit
+    store.m1[int(off):int(off) + int(n)].copy_(m1[ooff:ooff + int(n)])
+    if m2 is not None:
+      store.m2[int(off):int(off) + int(n)].copy_(m2[ooff:ooff + int(n)])
+    if t_v is not None and j < t_v.numel():
+      store.t_v[i] = t_v[j]
+  if lost:
+    warnings.warn("checkpoint %s: no optimizer moments for %d variable(s) (e.g. %s): they restart from zero"
+                  % (path, len(lost), ", ".join(lost[:4])))
+  return "by_name"

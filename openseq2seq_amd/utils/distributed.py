@@ -34,17 +34,20 @@ class HvdAdapter(object):
     return int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, one_device=False):
   """Initialises torch.distributed from torchrun's env (RANK/WORLD_SIZE/MASTER_*).
-  Returns an HvdAdapter, or None for a single-process run."""
+  Returns an HvdAdapter, or None for a single-process run. one_device: every rank uses cuda:0 (the rehearsal of
+  an N-rank run on a one-GPU box: the wire then has to be gloo, two ranks cannot open one device through RCCL)."""
   world = int(os.environ.get("WORLD_SIZE", "1"))
   if world <= 1:
     return None
   if not dist.is_initialized():
     if backend is None:
-      backend = "nccl" if torch.cuda.is_available() else "gloo"
+      backend = "nccl" if (torch.cuda.is_available() and not one_device) else "gloo"
+    if one_device and backend == "nccl":
+      raise ValueError("ranks sharing one device need the gloo backend")
     if torch.cuda.is_available():
-      torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+      torch.cuda.set_device(0 if one_device else int(os.environ.get("LOCAL_RANK", 0)))
     dist.init_process_group(backend=backend)
   return HvdAdapter()
 
@@ -124,8 +127,13 @@ class GradientReducer(object):
   remaining backward kernels keep running on the compute stream. `finish()` reduces
   whatever is left and makes the compute stream wait for the side stream."""
 
-  def __init__(self, store, world_size, bucket_bytes=128 << 20):
+  def __init__(self, store, world_size, bucket_bytes=None):
     self.store, self.world = store, world_size
+    # bucket size: 128 MB of fp32 gradients unless OS2S_BUCKET_MB says otherwise (bench.py --bucket-mb: the size
+    # has never met xGMI — the first 8-GPU run can sweep it without a code change)
+    if bucket_bytes is None:
+      bucket_bytes = int(float(os.environ.get("OS2S_BUCKET_MB", "128")) * (1 << 20))
+    self.bucket_bytes = bucket_bytes
     n = store.grads.numel()
     per = max(bucket_bytes // 4, store.chunk)
     per = (per // store.chunk) * store.chunk
@@ -232,6 +240,8 @@ class GradientReducer(object):
     exposed = sum(a.elapsed_time(b) for a, b in self._exposed) / steps
     f = 2.0 * (self.world - 1) / max(self.world, 1)
     out = {"steps": steps, "world_size": self.world, "wire_dtype": str(self.wire_dtype).replace("torch.", ""),
+           "allreduce_dtype": "bf16" if self.wire_dtype == torch.bfloat16 else "fp32",
+           "bucket_mb": self.bucket_bytes / float(1 << 20), "buckets_per_step": nb,
            "bucket_bytes": [p[1] for p in per],
            "bucket_ms": [p[0] / steps for p in per],
            "allreduce_bytes_per_step": total_bytes, "allreduce_ms_per_step": total_ms,

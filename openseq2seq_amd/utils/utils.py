@@ -45,21 +45,24 @@ def check_params(config, required_dict, optional_dict):
   of the declared kind. Raises ValueError with the reference's wording."""
   if required_dict is None or optional_dict is None:
     return
-  missing = [k for k in required_dict if k not in config]
-  if missing:
-    raise ValueError("{} parameter has to be specified".format(missing[0]))
-  schema = dict(optional_dict)
-  schema.update(required_dict)
-  for key, value in config.items():
-    if key not in schema:
+  # The ORDER in which problems are reported is the reference's (utils.py:407-429): the required table entry by
+  # entry (absent, else of the wrong kind), then the kinds of the optional entries, unknown keys last — a config
+  # with two mistakes raises the same message under both code bases.
+  def kind(key, want):
+    ok, msg = _type_ok(config[key], want)
+    if not ok:
+      shown = want if not (want is str) else (str, type(u""))
+      raise ValueError(msg.format(key, shown))
+  for key, want in required_dict.items():
+    if key not in config:
+      raise ValueError("{} parameter has to be specified".format(key))
+    kind(key, want)
+  for key, want in optional_dict.items():
+    if key in config:
+      kind(key, want)
+  for key in config:
+    if key not in required_dict and key not in optional_dict:
       raise ValueError("Unknown parameter: {}".format(key))
-  for table in (required_dict, optional_dict):
-    for key, want in table.items():
-      if key in config:
-        ok, msg = _type_ok(config[key], want)
-        if not ok:
-          shown = want if not (want is str) else (str, type(u""))
-          raise ValueError(msg.format(key, shown))
 
 
 def nested_update(org_dict, upd_dict):

@@ -305,3 +305,96 @@ def test_tacotron_decoder_checkpoints_carry_the_reference_graphs_variables(monke
       assert torch.equal(p.master[:, :n], before[p.name][:, :n]) and not p.master[:, n:].any(), p.name
     else:
       assert torch.equal(p.master[:n], before[p.name][:n]) and not p.master[n:].any(), p.name
+
+
+def test_sample_norm_vectors_are_half_with_a_master_twin_in_a_mixed_graph():
+  """tf.contrib.layers.layer_norm / instance_norm create gamma / beta in the dtype of their input
+  (conv_ln_actv / conv_in_actv, parts/cnns/conv_blocks.py:234-309): DT_HALF + an fp32 twin in a mixed-precision graph
+  of the reference, unlike the explicitly fp32 BatchNorm vectors."""
+  import torch
+  from openseq2seq_amd.utils import checkpoint as ck
+
+  class P(object):
+    def __init__(self, name, kind, arr):
+      self.name, self.kind, self.shape, self.master = name, kind, arr.shape, torch.from_numpy(arr)
+
+  g = np.linspace(0.5, 1.5, 8).astype(np.float32)
+  names = ["ForwardPass/w2l_encoder/LayerNorm/gamma", "ForwardPass/w2l_encoder/LayerNorm_3/beta",
+           "ForwardPass/w2l_encoder/InstanceNorm_1/gamma", "ForwardPass/w2l_encoder/conv11/bn/gamma",
+           "ForwardPass/transformer_encoder/layer_normalization/layer_norm_scale"]
+
+  class Store(object):
+    params = [P(n, "vector", g) for n in names]
+    state = {}
+
+  class M(object):
+    store = Store()
+    params = {"dtype": "mixed"}
+
+  out = ck.model_variables(M())
+  for n in names[:3]:
+    assert out[n].dtype == np.float16 and out[ck.MASTER_PREFIX + n].dtype == np.float32, n
+  for n in names[3:]:
+    assert out[n].dtype == np.float32 and ck.MASTER_PREFIX + n not in out, n
+
+
+def test_optimizer_slots_follow_the_variables_when_the_creation_order_changes():
+  """OS2S/opt/m1, m2 are flat buffers and t_v one value per variable; their total does not depend on
+  the creation order, so a file written under another order used to load with every moment on the wrong variable.
+  The file now records (name hash, offset, size) per variable: identical layout -> flat copy; a permuted one ->
+  slot by slot; no record (files from before round 6) -> moments are NOT restored, with a warning."""
+  import warnings
+  import torch
+  from openseq2seq_amd.utils import checkpoint as ck
+
+  class P(object):
+    def __init__(self, name, numel):
+      self.name, self.numel, self.offset = name, numel, 0
+
+  def store(order, chunk=8):
+    class S(object):
+      pass
+    s = S()
+    s.params = [P(n, k) for n, k in order]
+    off = 0
+    for p in s.params:
+      p.offset = off
+      off += -(-p.numel // chunk) * chunk
+    s.m1 = torch.zeros(off)
+    s.m2 = torch.zeros(off)
+    s.t_v = torch.zeros(len(s.params))
+    return s
+
+  class Op(object):
+    state = torch.zeros(4)
+
+  a = [("dec/kv/kernel", 24), ("dec/layer_0/q", 10), ("dec/layer_0/ffn", 17), ("enc/emb", 5)]
+  old = store(a)
+  for i, p in enumerate(old.params):                 # slot value = 100 * variable index + element index
+    old.m1[p.offset:p.offset + p.numel] = 100.0 * i + torch.arange(p.numel)
+    old.m2[p.offset:p.offset + p.numel] = -(100.0 * i + torch.arange(p.numel))
+    old.t_v[i] = 7.0 + i
+  data = {"OS2S/opt/m1": old.m1.numpy(), "OS2S/opt/m2": old.m2.numpy(), "OS2S/opt/t_v": old.t_v.numpy(),
+          "OS2S/opt/state": np.arange(4, dtype=np.float32), "OS2S/opt/layout": ck.slot_layout(old)}
+  same = store(a)
+  assert ck.restore_slots(same, Op(), data) == "flat"
+  assert torch.equal(same.m1, old.m1) and torch.equal(same.t_v, old.t_v)
+  b = [a[1], a[2], a[0], a[3]]                       # the round-4 order: per-layer variables first
+  new = store(b)
+  assert new.m1.numel() == old.m1.numel()            # the trap: same total, different layout
+  assert ck.restore_slots(new, Op(), data) == "by_name"
+  for i, p in enumerate(new.params):
+    j = [n for n, _ in a].index(p.name)
+    want = 100.0 * j + torch.arange(p.numel)
+    assert torch.equal(new.m1[p.offset:p.offset + p.numel], want), p.name
+    assert torch.equal(new.m2[p.offset:p.offset + p.numel], -want), p.name
+    assert float(new.t_v[i]) == 7.0 + j
+  legacy = dict(data)
+  del legacy["OS2S/opt/layout"]
+  cold = store(b)
+  op = Op()
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    assert ck.restore_slots(cold, op, legacy, "old.ckpt") == "skipped"
+  assert any("NOT restored" in str(x.message) for x in w)
+  assert float(cold.m1.abs().sum()) == 0.0 and float(op.state[3]) == 3.0     # scalars restored, moments not

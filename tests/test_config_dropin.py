@@ -115,3 +115,23 @@ def test_toy_speech_test_configs_equal_the_reference():
       assert norm(ours[1])["encoder_params"]["activation_fn"] == "activation id 3"      # min(relu(x), 20)
   finally:
     os.chdir(cwd)
+
+
+def test_check_params_reports_problems_in_the_reference_order():
+  """open_seq2seq/utils/utils.py:403-429 walks the required table (absent -> 'has to be specified', wrong kind ->
+  'has to be of type'), then the kinds of the optional entries, unknown keys LAST: with two mistakes in one
+  config both code bases must name the same one (ours named the unknown key first)."""
+  import pytest
+  from openseq2seq_amd.utils.utils import check_params
+  req, opt = {"a": int, "b": str}, {"c": float, "d": ["x", "y"]}
+  with pytest.raises(ValueError, match="a has to be of type"):
+    check_params({"a": "1", "b": "s", "zzz": 1}, req, opt)           # wrong kind beats unknown key
+  with pytest.raises(ValueError, match="d has to be one of"):
+    check_params({"a": 1, "b": "s", "d": "q", "zzz": 1}, req, opt)
+  with pytest.raises(ValueError, match="b parameter has to be specified"):
+    check_params({"a": 1, "zzz": 1}, req, opt)
+  with pytest.raises(ValueError, match="a has to be of type"):
+    check_params({"a": "1"}, req, opt)                               # kind of `a` before the absence of `b`
+  with pytest.raises(ValueError, match="Unknown parameter: zzz"):
+    check_params({"a": 1, "b": "s", "c": 2, "zzz": 1}, req, opt)     # an int where a float is asked for passes
+  check_params({"a": 1, "b": u"s", "d": "y"}, req, opt)

@@ -229,3 +229,46 @@ def test_persistent_gru_abort_is_recovered_by_redoing_the_step(cuda):
   for x, y in zip(sa, sb):
     assert torch.equal(x, y)          # BatchNorm statistics: the aborted pass left no trace
   assert all(l == l and abs(l) < 1e6 for l in la)
+
+
+def test_persistent_gru_abort_in_an_eval_pass_is_redone_not_reported(cuda):
+  """outside train_step nothing read the sticky abort word, so an eval / infer forward pass whose
+  persistent GRU launch gave up returned garbage logits (and WER) silently. Speech2Text.forward now reads the word
+  after every pass that ran persistent launches: the batch is redone on the launch-per-step kernels. The redone
+  logits must equal those of a model that never used the persistent kernels (same kernels => bit-identical)."""
+  import warnings
+  from openseq2seq_amd import capi
+  from openseq2seq_amd.configs.ds2 import ds2_large_config
+
+  def build():
+    cls, p = ds2_large_config(batch_size_per_gpu=4, max_steps=100)
+    p["encoder_params"].update(num_rnn_layers=2, rnn_cell_dim=128, n_hidden=256, dropout_keep_prob=1.0,
+                               row_conv=True, row_conv_width=8)
+    p["use_horovod"] = False
+    torch.manual_seed(11)
+    m = cls(p, mode="eval", hvd=None, device=cuda)
+    m.compile()
+    return m
+
+  try:
+    capi.gru_xcd_set_mode(-1)
+    capi.gru_xcd_status(clear=True)
+    m = build()
+    batch = m.get_data_layer().synthetic_batch(cuda, seed=77)
+    good = m.forward(batch)["logits"].float().clone()            # persistent kernels, no abort
+    capi.gru_xcd_set_mode(2)                                      # the next persistent launch starts aborted
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter("always")
+      redone = m.forward(batch)["logits"].float().clone()
+    assert any("eval / infer pass" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert capi.gru_xcd_status(clear=False) == 0                  # the word was consumed, not left for a train step
+    capi.gru_xcd_set_mode(0)
+    per_step = m.forward(batch)["logits"].float().clone()
+    torch.cuda.synchronize()
+  finally:
+    capi.gru_xcd_set_mode(-1)
+    capi.gru_xcd_status(clear=True)
+  assert torch.isfinite(redone).all()
+  assert torch.equal(redone, per_step)
+  scale = float(good.abs().max())
+  assert float((redone - good).abs().max()) <= 2e-2 * scale      # two kernel families, bf16 activations
