@@ -80,6 +80,9 @@ def parse():
   ap.add_argument("--one-rank-group", action="store_true",
                   help="N=1 only: run the data-parallel path (RCCL process group, bucketed all-reduce on "
                        "the side stream, comm diagnostics) on a one-rank group")
+  ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                  help="os2s_set_option(NAME, VALUE) before anything runs (A/B runs of a library knob, e.g. "
+                       "conv1d_wgrad.xcd_order=0); repeatable")
   ap.add_argument("--bucket-mb", type=float, default=None,
                   help="size of the gradient all-reduce buckets in MB of fp32 (default 128; OS2S_BUCKET_MB)")
   ap.add_argument("--allreduce-dtype", choices=["fp32", "bf16"], default=None,
@@ -1060,6 +1063,10 @@ def main():
     return
   dev = torch.device("cuda", 0 if args.one_device else int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
+  for kv in args.set_option:
+    from openseq2seq_amd import _lib as _l
+    name, _, val = kv.partition("=")
+    _l.set_option(name, float(val))
   if args.pp_cost:
     import ctypes
     from openseq2seq_amd import _lib

@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch):
+@pytest.mark.parametrize("seed", [7, 11, 2024])
+def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch, seed):
+  """Three seeds, each must clear the bar (round 5 drew BLEU 0.86 once under a clock-derived seed: a convergence
+  test that passes on one lucky seed is a flake on the next box)."""
   sys.path.insert(0, REPO)
   import run
   from openseq2seq_amd.test_utils.create_reversed_examples import create_data
@@ -26,7 +29,7 @@ def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch):
   cfg = os.path.join(REPO, "example_configs/text2text/toy-reversal/nmt-small-reversal.py")
   args, base_config, base_model, config_module = get_base_config(
       ["--config_file=" + cfg, "--mode=train_eval", "--max_steps=1000", "--print_loss_steps=100"])
-  base_config["random_seed"] = 7        # (command-line overrides exist only for keys the config file has)
+  base_config["random_seed"] = seed     # (command-line overrides exist only for keys the config file has)
   model = create_model(args, base_config, config_module, base_model, None)
   run.train(model, args)
   res = run.run_eval(model, model.eval_model, 0)

@@ -24,7 +24,18 @@ import ref_exec_util as rx  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def test_device_tdnn_reproduces_the_reference_code(cuda):
+@pytest.fixture
+def deterministic_kernels():
+  """No fp32 atomics in the parameter-gradient kernels: the same numbers every run (the gradient bounds below are
+  measured values with one rounding step of margin, not envelopes of run-to-run noise)."""
+  from openseq2seq_amd import capi
+  was = capi.deterministic()
+  capi.set_deterministic(True)
+  yield
+  capi.set_deterministic(was)
+
+
+def test_device_tdnn_reproduces_the_reference_code(cuda, deterministic_kernels):
   from openseq2seq_amd.optimizers.flat_params import FlatParams
   from openseq2seq_amd.encoders.tdnn_encoder import TDNNEncoder
   from openseq2seq_amd.decoders.fc_decoders import FullyConnectedCTCDecoder, decode_outputs
@@ -86,7 +97,48 @@ def test_device_tdnn_reproduces_the_reference_code(cuda):
   live = np.arange(Tq)[:, None] < d["out_len"][None, :]
   agree = float((lg.argmax(-1) == d["logits"].argmax(-1))[live].mean())
   assert agree >= 0.97, agree
-  ids = decode_outputs(dec, dd)
+  # ... element by element: every live logit within EPS x the largest magnitude of its frame (8 bf16 ulps — measured
+  # worst 0.0293: the logits sit behind nine BatchNorm layers of bf16 activations). A frame whose runner-up reference logits are more
+  # than 2 EPS below the top MUST then decode to the reference's symbol; a close call may go to any symbol within
+  # 2 EPS. The decoded STRINGS (fc_decoders.py:244-251: argmax, merge repeats, drop the blank) are therefore held
+  # against the reference's own tf.nn.ctc_greedy_decoder output exactly: equal on every sample without a close call,
+  # and otherwise a member of the set of strings the close calls allow (enumerated: <= 2^16 per sample; on this
+  # fixture 4 - 12 close frames of 20 - 48 per sample, 24 - 31 104 admissible strings).
+  import itertools
+  EPS = 2.0 ** -5
+  ref_lg = d["logits"]
+  fmax = np.abs(ref_lg).max(-1)
+  err = np.abs(lg - ref_lg).max(-1) / fmax
+  assert float(err[live].max()) <= EPS, float(err[live].max())
+  ids = decode_outputs(dec, dd)[0]            # (dense ids [B, T] padded with -1, lengths [B])
+  dev_ids, dev_len = ids[0].cpu().numpy(), ids[1].cpu().numpy()
+  blank = V - 1
+
+  def collapse(path):
+    out, prev = [], -1
+    for sym in path:
+      if sym != prev and sym != blank:
+        out.append(int(sym))
+      prev = sym
+    return tuple(out)
+
+  exact = close_calls = 0
+  for b in range(B):
+    n = int(d["out_len"][b])
+    mine = tuple(int(v) for v in dev_ids[b, :int(dev_len[b])])
+    ref_ids = tuple(int(v) for v in np.asarray(d["greedy_ids"][b]).ravel() if int(v) >= 0)
+    assert collapse(ref_lg[:n, b].argmax(-1)) == ref_ids           # what the fixture's ids mean
+    cands = [np.nonzero(ref_lg[t, b] >= ref_lg[t, b].max() - 2 * EPS * fmax[t, b])[0].tolist() for t in range(n)]
+    ways = int(np.prod([len(c) for c in cands], dtype=np.float64))
+    close_calls += sum(len(c) > 1 for c in cands)
+    if ways == 1:
+      assert mine == ref_ids, (b, mine, ref_ids)
+      exact += 1
+    else:
+      assert ways <= 1 << 16, (b, ways)
+      allowed = {collapse(path) for path in itertools.product(*cands)}
+      assert mine in allowed, (b, mine, ref_ids, ways)
+  decode_report = "%d of %d strings equal by necessity, %d close frames of %d" % (exact, B, close_calls, int(live.sum()))
   # moving statistics after ONE training-mode forward from 0 / 1 (momentum 0.90, Bessel-corrected batch variance)
   worst_mv = 0.0
   for n in [str(v) for v in d["moving_names"]]:
@@ -125,9 +177,11 @@ def test_device_tdnn_reproduces_the_reference_code(cuda):
       # (three runs: 0.9766 - 0.9797 and 0.9929 - 0.9941; the weight-gradient atomics differ in the last bit run to
       # run and the masks amplify it — bounds with margin)
       assert cos > 0.96 and rx.rel(tf_g, ref) < 0.3, (tf_name, cos, rx.rel(tf_g, ref))
-      assert cos16 > 0.985 and rx.rel(tf_g, leaves16[tf_name].grad.numpy()) < 0.2, \
+      # (round 6: the test runs in deterministic mode — no atomics, the same numbers every run — and the bound
+      # against the storage-emulating oracle is the measured 0.9941 / 0.109 with one rounding step of margin)
+      assert cos16 > 0.99 and rx.rel(tf_g, leaves16[tf_name].grad.numpy()) < 0.12, \
           (tf_name, cos16, rx.rel(tf_g, leaves16[tf_name].grad.numpy()))
   print("device vs the reference's code: CTC loss %.4f vs %.4f, encoder output %.2e, logits %.2e, argmax agreement %.3f, moving statistics "
         "%.2e, worst gradient cosine %.4f (%s) [%.4f with bf16 storage emulated (%s)], worst projection error %.2e; "
         "decoded %s" % (float(ctc.cpu()[0]), float(d["ctc_loss"]), r_enc, r_log, agree, worst_mv, worst_cos[0], worst_cos[1], worst_cos16[0], worst_cos16[1],
-                        worst, type(ids).__name__))
+                        worst, decode_report))

@@ -24,6 +24,10 @@ cp $OUT/kss/jasper_kernel_stats.csv $OUT/${TAG}_jasper_kernel_stats_serial.csv
 P="$J --steps 2 --warmup 1"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o c -- $P > $OUT/f.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -o c -- $P > $OUT/w.log 2>&1
+# the same FETCH_SIZE pass with every kernel alone on the GPU (no L2 sharing with the other stream's kernels), and
+# with the round-5 rank order of the weight-gradient kernels (conv1d_wgrad.xcd_order 0): what moved 357 -> 436 MB
+OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fs -o c -- $P > $OUT/fs.log 2>&1
+OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fx -o c -- $P --set-option conv1d_wgrad.xcd_order=0 > $OUT/fx.log 2>&1
 OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $OUT/m -o c -- $P > $OUT/m.log 2>&1
 python - <<PY
 import csv, glob, json, collections
@@ -44,6 +48,7 @@ def collect(sub):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
     return agg, cnt
 fa, fc = collect("f"); wa, wc = collect("w"); ma, mc = collect("m")
+fsa, fsc = collect("fs"); fxa, fxc = collect("fx")
 per = {}
 tf = tw = n = 0.0
 for k, desc in FAM:
@@ -51,7 +56,10 @@ for k, desc in FAM:
     nf = fc[(k, "FETCH_SIZE")]; nw = wc[(k, "WRITE_SIZE")]
     f = fa[k]["FETCH_SIZE"] / max(nf, 1); w = wa[k]["WRITE_SIZE"] / max(nw, 1)
     per[k] = {"what": desc, "launches": nf, "FETCH_SIZE_KB_per_launch_raw": f, "WRITE_SIZE_KB_per_launch_raw": w,
-              "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+              "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+              "fetch_bytes_per_launch_two_streams": 2.0 * f * 1024.0,
+              "fetch_bytes_per_launch_alone_on_the_gpu": 2.0 * fsa[k]["FETCH_SIZE"] / max(fsc[(k, "FETCH_SIZE")], 1) * 1024.0,
+              "fetch_bytes_per_launch_alone_round5_rank_order": 2.0 * fxa[k]["FETCH_SIZE"] / max(fxc[(k, "FETCH_SIZE")], 1) * 1024.0}
     if "wgrad" not in k:
         tf += fa[k]["FETCH_SIZE"]; tw += wa[k]["WRITE_SIZE"]; n += nf
 out = {"command": "$P", "kernel": "conv1d_pp_kernel + conv1d_igemm_kernel + conv1d_igemm_grouped_kernel (the launches bench.py's roofline block times: fwd + dgrad)",
