@@ -223,10 +223,11 @@ class Tape(object):
     join_side_streams()
 
   # ---- deferred (grouped) weight gradients -----------------------------------------------------
-  def defer_wgrad(self, param, item, group=None):
-    """A Dense weight gradient too small to fill the chip alone is held back until `group` of them
-    can go out in one launch (capi.gemm_wgrad_grouped). Until then `param` does not count as final
-    for the gradient reducer."""
+  def defer_wgrad(self, param, item, group=None, unit_budget=None):
+    """A Dense weight gradient too small to fill the chip alone is held back until `group` of them — or, with
+    `unit_budget`, enough of them to cover that many 256 x 256 output tiles — can go out in one launch
+    (capi.gemm_wgrad_grouped: at most 16 per launch). Until then `param` does not count as final for the
+    gradient reducer."""
     # one grouped launch has ONE row count (os2s_gemm_wgrad_grouped takes a single M): a layer fed by
     # another number of packed rows (the enc-dec attention's k/v projection of the SOURCE tokens among
     # target-row layers) starts a new group
@@ -235,7 +236,11 @@ class Tape(object):
     self._deferred.append((param, item))
     if self._pending is not None and id(param) in self._pending:
       self._pending[id(param)] += 1
-    if len(self._deferred) >= (group if group is not None else SMALL_WGRAD_GROUP):
+    if unit_budget is not None:
+      units = sum(((it["dy"].shape[1] + 255) // 256) * ((it["x"].shape[1] + 255) // 256) for _, it in self._deferred)
+      if units >= unit_budget or len(self._deferred) >= 16:
+        self.flush_deferred()
+    elif len(self._deferred) >= (group if group is not None else SMALL_WGRAD_GROUP):
       self.flush_deferred()
 
   def flush_deferred(self):

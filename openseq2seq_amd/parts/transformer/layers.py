@@ -38,6 +38,23 @@ def _small_wgrad(lin, dz):
       lin.cout % 8 == 0 and lin.cin % 8 == 0
 
 
+# Round 6: EVERY Dense weight gradient with fewer output tiles than the chip has CUs is held back until the
+# collected ones cover WGRAD_UNIT_BUDGET tiles of 256 x 256 (Transformer-big: ffn 64 + 64, q k v 48, the 1024 x 1024
+# projections 16 each — 192 / 224 per encoder / decoder layer), then go out as ONE launch of the ping-pong TN-GEMM
+# kernel: ~200 tiles of 130 reduction steps each and no reduction split, where the single launches were 16 - 64 tiles
+# cut 4 - 16 ways (fill, 256 KB slab per piece, one reducer per tile). Transformer-big, same box, interleaved
+# (ms per step): round-5 policy 18.30, budget 128: 17.56, 192: 17.27 - 17.39, 256: 17.85 — a launch that leaves a
+# quarter of the CUs to the data-gradient chain on the main stream beats one that takes them all.
+# OS2S_WGRAD_UNIT_BUDGET=0: the round-5 policy (1024 x 1024 projections three at a time, the rest alone).
+WGRAD_UNIT_BUDGET = int(_os.environ.get("OS2S_WGRAD_UNIT_BUDGET", "192"))
+
+
+def _groupable_wgrad(lin, dz):
+  units = ((lin.cout + 255) // 256) * ((lin.cin + 255) // 256)
+  return WGRAD_UNIT_BUDGET > 0 and units < 256 and lin.cout >= 128 and lin.cin >= 128 and dz.shape[0] >= 2048 and \
+      lin.cout % 8 == 0 and lin.cin % 8 == 0 and dz.stride(1) == 1
+
+
 SKINNY_LOGITS = False    # [256 x 32768 x 1024]: the LDS-tiled kernel wins (60 vs 139 us)
 
 
@@ -136,7 +153,10 @@ class Dense(object):
       # stream by default (OS2S_DENSE_WGRAD_STREAM): with the in-tree kernels it fills the half of
       # the chip a 132-tile data-gradient GEMM leaves idle, 22.1 -> 20.3 ms/step over 20 AND over
       # 300 steps (with the round-1 vendor GEMMs the same move lost 11 % at the power limit)
-      if DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _small_wgrad(lin, dz) and current_tape() is not None:
+      if DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _groupable_wgrad(lin, dz) and current_tape() is not None:
+        current_tape().defer_wgrad(lin.kernel, dict(x=x.data, dy=dz, dw=lin.kernel.grad.view(lin.cout, lin.cin)),
+                                   unit_budget=WGRAD_UNIT_BUDGET)
+      elif DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _small_wgrad(lin, dz) and current_tape() is not None:
         # 16 output tiles: three of these go out as ONE launch (Tape.defer_wgrad)
         current_tape().defer_wgrad(lin.kernel, dict(x=x.data, dy=dz, dw=lin.kernel.grad.view(lin.cout, lin.cin)))
       elif DENSE_WGRAD_STREAM:
