@@ -181,7 +181,13 @@ int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
  *   conv1x1.variant: the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers): 0 (default) and 1 =
  *     lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows whenever its envelope allows
  *     (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as a measured alternative
- *   conv1d_wgrad.variant: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, -1 = by shape;
+ *   conv1d_wgrad.variant: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, 3 = one wave per SIMD with 16
+ *     accumulator blocks per wave and a hand-written instruction stream (stride 1, K >= 2, dilation <= 5, channel
+ *     counts multiples of 128; opt-in: measured slower than the ping-pong kernel), -1 = by shape;
+ *   conv1d_wgrad.xcd_order: 1 (default) = consecutive ranks of the ping-pong / one-wave weight-gradient kernels —
+ *     the tap quads or ci tiles of one output tile — run behind one XCD's L2; 0 = rank = blockIdx.x (rounds 2 - 5)
+ *   conv1d_wgrad.sw_ablate: read only by measurement builds (-DOS2S_SW_ABLATE, tools/sw_ablate.py): the one-wave
+ *     stream with an ingredient removed (1 LDS-DMA, 2 barrier, 4 transpose reads, 8 MFMAs; results are wrong then)
  *   conv1d_wgrad.split: > 0 forces the reduction split factor of the ping-pong kernels (-1 = cost model)
  *   gemm_nt.split: f > 0 forces the tail split factor of os2s_gemm_nt*, 0 disables the split, < 0 = cost model
  *   depthwise.variant: 0 = the generic depthwise kernels only, < 0 = by shape
@@ -465,6 +471,24 @@ int os2s_opt_step(os2s_stream_t stream, const os2s_opt_config_t* cfg, void* stat
                   const float* tensor_l2, const float* tensor_wd_mask,
                   float* partial, float* tensor_gnorm2, float* tensor_wnorm2,
                   float* tensor_amax, float* tensor_mult, float* tensor_v);
+/* The same step in two halves, so that the update can run on its own stream NEXT TO the following forward pass
+ * (optimizers/optimizers.py TrainOp.run_async; the reference's train_op is one sess.run, optimizers.py:107-160 /
+ * mp_wrapper.py:84-117): os2s_opt_prepare = everything that needs ALL gradients (statistics, overflow / skip decision,
+ * loss-scale update, learning rate, LARC / NovoGrad factors); os2s_opt_apply_range = the update of chunks
+ * [chunk_begin, chunk_end) — the caller records an event behind each range and the forward pass waits for the range
+ * that holds a variable before it first reads it. zero_grads != 0: each gradient chunk is written back as zeros once
+ * it has been read (also on a skipped step), replacing the fill of the gradient buffer that opens the next step.
+ * os2s_opt_step == os2s_opt_prepare + os2s_opt_apply_range(0, nchunks, zero_grads = 0). */
+int os2s_opt_prepare(os2s_stream_t stream, const os2s_opt_config_t* cfg, void* state,
+                     const float* grads, const float* weights, int nchunks, int ntensors,
+                     const int32_t* chunk_tensor, const int32_t* tensor_chunk_begin,
+                     const float* tensor_l2, float* partial, float* tensor_gnorm2, float* tensor_wnorm2,
+                     float* tensor_amax, float* tensor_mult, float* tensor_v);
+int os2s_opt_apply_range(os2s_stream_t stream, const os2s_opt_config_t* cfg, const void* state,
+                         float* grads, float* weights, float* m1, float* m2, uint16_t* w16,
+                         int chunk_begin, int chunk_end, const int32_t* chunk_tensor,
+                         const float* tensor_l2, const float* tensor_mult,
+                         const float* tensor_wd_mask, int zero_grads);
 int os2s_cast_f32_to_bf16(os2s_stream_t stream, const float* src, uint16_t* dst,
                           long long n);
 /* batched dgrad copies of conv weights: wT[k'][ci][co] = w[K-1-k'][co][ci];

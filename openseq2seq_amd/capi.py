@@ -752,6 +752,35 @@ def opt_step(cfg, state, grads, weights, m1, m2, w16, chunk_tensor, tensor_chunk
              "os2s_opt_step")
 
 
+def opt_prepare(cfg, state, grads, weights, chunk_tensor, tensor_chunk_begin, tensor_l2, partial, gnorm2, wnorm2,
+                amax, mult, tensor_v):
+  """First half of opt_step (os2s_opt_prepare): everything that needs all gradients."""
+  nchunks = chunk_tensor.numel()
+  ntensors = tensor_chunk_begin.numel() - 1
+  f = _fn("os2s_opt_prepare",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _lib.ctypes.byref(cfg), _ptr(state, torch.uint8), _ptr(grads, torch.float32),
+               _ptr(weights, torch.float32), nchunks, ntensors, _ptr(chunk_tensor, torch.int32),
+               _ptr(tensor_chunk_begin, torch.int32), _ptr(tensor_l2, torch.float32, True),
+               _ptr(partial, torch.float32), _ptr(gnorm2, torch.float32), _ptr(wnorm2, torch.float32),
+               _ptr(amax, torch.float32), _ptr(mult, torch.float32), _ptr(tensor_v, torch.float32, True)),
+             "os2s_opt_prepare")
+
+
+def opt_apply_range(cfg, state, grads, weights, m1, m2, w16, chunk_begin, chunk_end, chunk_tensor, tensor_l2, mult,
+                    zero_grads=False):
+  """Second half (os2s_opt_apply_range): the update of chunks [chunk_begin, chunk_end) of the flat buffers."""
+  f = _fn("os2s_opt_apply_range",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+           c_void_p, c_void_p, c_void_p, c_void_p, c_int))
+  _lib.check(f(_stream(), _lib.ctypes.byref(cfg), _ptr(state, torch.uint8), _ptr(grads, torch.float32),
+               _ptr(weights, torch.float32), _ptr(m1, torch.float32, True), _ptr(m2, torch.float32, True),
+               _ptr(w16, torch.bfloat16, True), int(chunk_begin), int(chunk_end), _ptr(chunk_tensor, torch.int32),
+               _ptr(tensor_l2, torch.float32, True), _ptr(mult, torch.float32), c_void_p(0), int(bool(zero_grads))),
+             "os2s_opt_apply_range")
+
+
 def cast_f32_to_bf16(src, dst):
   n = src.numel()
   f = _fn("os2s_cast_f32_to_bf16", (c_void_p, c_void_p, c_void_p, c_ll))

@@ -311,16 +311,27 @@ __global__ __launch_bounds__(256) void mt_finalize_kernel(
 // load of the thread (4 x {grad, weight, moments}) is issued before the first use: with the
 // optimizer as a run-time switch hipcc emitted load - s_waitcnt vmcnt(0) - switch - store per 4
 // elements, i.e. 3 loads in flight per thread and a branch per element.
+// chunk0: first chunk of the range this launch covers (os2s_opt_apply_range: the apply pass cut into ranges, an event
+// after each, so that the next step's forward pass can start on the variables already updated). zero_grads: the
+// gradient chunk is written back as zeros once it has been read — the next step needs no separate fill of the
+// gradient buffer, which would have to wait for the whole apply pass (a skipped step zeroes without applying).
 template <int OPT>
 __global__ __launch_bounds__(256) void mt_apply_kernel(
-    const float* __restrict__ grads, float* __restrict__ weights, float* __restrict__ m1,
+    float* __restrict__ grads, float* __restrict__ weights, float* __restrict__ m1,
     float* __restrict__ m2, bf16_t* __restrict__ w16, const int32_t* __restrict__ chunk_tensor,
     const float* __restrict__ tensor_l2, const float* __restrict__ tensor_mult,
     const float* __restrict__ tensor_wd_mask, os2s_opt_config_t cfg,
-    const OptDeviceState* __restrict__ st) {
-  if (st->skip) return;
+    const OptDeviceState* __restrict__ st, int chunk0, int zero_grads) {
   constexpr int N = kChunk / 4 / 256;
-  const int c = blockIdx.x;
+  const int c = blockIdx.x + chunk0;
+  if (st->skip) {
+    if (zero_grads) {
+      const long long b0 = (long long)c * kChunk + (long long)threadIdx.x * 4;
+#pragma unroll
+      for (int i = 0; i < N; ++i) *reinterpret_cast<f32x4*>(grads + b0 + (long long)i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
   const int ti = chunk_tensor[c];
   // st->loss_scale was already updated by the finalize pass; the gradients in
   // the buffer were produced with the PREVIOUS scale, saved in st->grad_scale_latched.
@@ -370,6 +381,7 @@ __global__ __launch_bounds__(256) void mt_apply_kernel(
       }
     }
     *reinterpret_cast<f32x4*>(weights + off) = w[i];
+    if (zero_grads) *reinterpret_cast<f32x4*>(grads + off) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (OPT != 0) *reinterpret_cast<f32x4*>(m1 + off) = m[i];
     if (OPT == 3) *reinterpret_cast<f32x4*>(m2 + off) = v[i];
     if (w16) {
@@ -487,18 +499,16 @@ extern "C" int os2s_opt_init_state(os2s_stream_t stream, void* state, float loss
 // One optimisation step over `nchunks` chunks of kChunk elements.
 //   m1/m2: optimizer state (momentum / Adam m and v), w16: bf16 compute copy (may be NULL)
 //   partial: scratch [nchunks*4]; tensor_* arrays: [ntensors] (tensor_chunk_begin: [ntensors+1])
-extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg, void* state,
-                             const float* grads, float* weights, float* m1, float* m2,
-                             uint16_t* w16, int nchunks, int ntensors,
-                             const int32_t* chunk_tensor, const int32_t* tensor_chunk_begin,
-                             const float* tensor_l2, const float* tensor_wd_mask,
-                             float* partial, float* tensor_gnorm2, float* tensor_wnorm2,
-                             float* tensor_amax, float* tensor_mult, float* tensor_v) {
+// = os2s_opt_prepare (statistics of the gradient, overflow / skip decision, loss-scale update, learning rate, LARC /
+// NovoGrad factors: everything that needs ALL gradients) + os2s_opt_apply_range over all chunks.
+extern "C" int os2s_opt_prepare(os2s_stream_t stream_, const os2s_opt_config_t* cfg, void* state,
+                                const float* grads, const float* weights, int nchunks, int ntensors,
+                                const int32_t* chunk_tensor, const int32_t* tensor_chunk_begin,
+                                const float* tensor_l2, float* partial, float* tensor_gnorm2, float* tensor_wnorm2,
+                                float* tensor_amax, float* tensor_mult, float* tensor_v) {
   OS2S_REQUIRE(cfg && state && grads && weights && chunk_tensor && tensor_chunk_begin);
   OS2S_REQUIRE(partial && tensor_gnorm2 && tensor_wnorm2 && tensor_amax && tensor_mult);
   OS2S_REQUIRE(nchunks >= 1 && ntensors >= 1 && cfg->world_size >= 1);
-  if (cfg->optimizer != 0) OS2S_REQUIRE(m1);
-  if (cfg->optimizer == 3) OS2S_REQUIRE(m2);
   if (cfg->optimizer == 2) OS2S_REQUIRE(tensor_v);
   hipStream_t stream = (hipStream_t)stream_;
   OptDeviceState* st = (OptDeviceState*)state;
@@ -514,9 +524,25 @@ extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg
               tensor_chunk_begin, tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult);
   OS2S_LAUNCH(mt_finalize_kernel, dim3(1), dim3(256), 0, stream, ntensors, *cfg, st,
               tensor_gnorm2, tensor_wnorm2, tensor_amax, tensor_mult, tensor_v);
-#define OS2S_APPLY(OPT)                                                                          \
-  OS2S_LAUNCH(mt_apply_kernel<OPT>, dim3(nchunks), dim3(256), 0, stream, grads, weights, m1, m2, \
-              w16, chunk_tensor, tensor_l2, tensor_mult, tensor_wd_mask, *cfg, st)
+  return OS2S_OK;
+}
+
+extern "C" int os2s_opt_apply_range(os2s_stream_t stream_, const os2s_opt_config_t* cfg, const void* state,
+                                    float* grads, float* weights, float* m1, float* m2, uint16_t* w16,
+                                    int chunk_begin, int chunk_end, const int32_t* chunk_tensor,
+                                    const float* tensor_l2, const float* tensor_mult,
+                                    const float* tensor_wd_mask, int zero_grads) {
+  OS2S_REQUIRE(cfg && state && grads && weights && chunk_tensor && tensor_mult);
+  OS2S_REQUIRE(chunk_begin >= 0 && chunk_end >= chunk_begin);
+  if (cfg->optimizer != 0) OS2S_REQUIRE(m1);
+  if (cfg->optimizer == 3) OS2S_REQUIRE(m2);
+  if (chunk_end == chunk_begin) return OS2S_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const OptDeviceState* st = (const OptDeviceState*)state;
+  const int n = chunk_end - chunk_begin;
+#define OS2S_APPLY(OPT)                                                                    \
+  OS2S_LAUNCH(mt_apply_kernel<OPT>, dim3(n), dim3(256), 0, stream, grads, weights, m1, m2, \
+              w16, chunk_tensor, tensor_l2, tensor_mult, tensor_wd_mask, *cfg, st, chunk_begin, zero_grads ? 1 : 0)
   switch (cfg->optimizer) {
     case 0: OS2S_APPLY(0); break;
     case 1: OS2S_APPLY(1); break;
@@ -525,6 +551,25 @@ extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg
   }
 #undef OS2S_APPLY
   return OS2S_OK;
+}
+
+extern "C" int os2s_opt_step(os2s_stream_t stream_, const os2s_opt_config_t* cfg, void* state,
+                             const float* grads, float* weights, float* m1, float* m2,
+                             uint16_t* w16, int nchunks, int ntensors,
+                             const int32_t* chunk_tensor, const int32_t* tensor_chunk_begin,
+                             const float* tensor_l2, const float* tensor_wd_mask,
+                             float* partial, float* tensor_gnorm2, float* tensor_wnorm2,
+                             float* tensor_amax, float* tensor_mult, float* tensor_v) {
+  OS2S_REQUIRE(cfg);
+  if (cfg->optimizer != 0) OS2S_REQUIRE(m1);
+  if (cfg->optimizer == 3) OS2S_REQUIRE(m2);
+  const int rc = os2s_opt_prepare(stream_, cfg, state, grads, weights, nchunks, ntensors, chunk_tensor,
+                                  tensor_chunk_begin, tensor_l2, partial, tensor_gnorm2, tensor_wnorm2, tensor_amax,
+                                  tensor_mult, tensor_v);
+  if (rc != OS2S_OK) return rc;
+  // (the gradient buffer is const for this entry point's callers: no zeroing)
+  return os2s_opt_apply_range(stream_, cfg, state, const_cast<float*>(grads), weights, m1, m2, w16, 0, nchunks,
+                              chunk_tensor, tensor_l2, tensor_mult, tensor_wd_mask, 0);
 }
 
 extern "C" int os2s_cast_f32_to_bf16(os2s_stream_t stream, const float* src, uint16_t* dst,

@@ -26,6 +26,13 @@ from ..parts.cnns.conv_blocks import Tape, set_side_stream_enabled
 from ..utils import distributed as dist_utils
 from ..utils.utils import check_params
 
+# OS2S_ASYNC_OPT=1 (or 'os2s_async_optimizer': True in the configuration): the optimizer update on its own stream
+# next to the following forward pass (TrainOp.run_async) — bit-identical weights, and measured NEUTRAL on MI355X
+# (Transformer-big 17.2 - 17.5 ms both ways, Jasper 38.4 both ways): the kernel trace shows the update ranges
+# running under the forward GEMMs, each side 1.3 - 5 x slower while they share the memory system
+# (profiles/r06_async_optimizer_overlap.log). Off by default: one stream, one fill of the gradient buffer.
+ASYNC_OPTIMIZER = os.environ.get("OS2S_ASYNC_OPT", "0") == "1"
+
 
 def resolve_lr_params(lr_policy, lr_policy_params, last_step, steps_in_epoch, has_num_epochs):
   """The defaults Model.compile adds to `lr_policy_params` before the policy is built (models/model.py:479-495),
@@ -89,6 +96,7 @@ class Model(object):
         # Tacotron2 configuration turns it off — its many small layers lose more in stream hand-offs
         # than the overlap returns: 131.9 vs 128.9 ms/step)
         'os2s_side_stream': bool,
+        'os2s_async_optimizer': bool,
     }
 
   def __init__(self, params, mode="train", hvd=None, device=None):
@@ -268,7 +276,10 @@ class Model(object):
       iter_size = p.get('iter_size', 1)
       micro = self._step_count % iter_size
       if micro == 0:
-        self._store.zero_grads()
+        if self._store.grads_zeroed:
+          self._store.grads_zeroed = False      # the asynchronous update zeroed each chunk behind its last read
+        else:
+          self._store.zero_grads()
       last_micro = (micro == iter_size - 1)
       overlap = self._reducer is not None and last_micro
       # what a persistent-GRU abort must be able to roll back (see _recover_gru_abort): the non-trainable state
@@ -296,7 +307,12 @@ class Model(object):
       if last_micro:
         if self._reducer is not None:
           self._reducer.finish()
-        self._train_op.run()
+        # the update runs on its own stream next to the NEXT step's forward pass (TrainOp.run_async) unless
+        # the configuration or OS2S_ASYNC_OPT=0 asks for the one-stream form
+        if p.get('os2s_async_optimizer', ASYNC_OPTIMIZER):
+          self._train_op.run_async()
+        else:
+          self._train_op.run()
     finally:
       set_side_stream_enabled(prev)
     return loss

@@ -118,7 +118,44 @@ class TrainOp(object):
                   s.t_gnorm2, s.t_wnorm2, s.t_amax, s.t_mult, s.t_v)
     s.refresh_dgrad_copies()
 
+  def run_async(self, nranges=8):
+    """The same step on the store's optimizer stream, NEXT TO whatever the calling stream does afterwards — the
+    following forward pass: the update is bandwidth-bound, a forward pass of 132-tile GEMMs or 150-unit convolution
+    launches leaves CUs and most of the HBM bandwidth idle. Order on the optimizer stream: wait for the caller's
+    stream (the gradients are final there: backward, the weight-gradient stream and the all-reduce have been
+    joined) -> os2s_opt_prepare -> `nranges` update ranges in flat-buffer order (= the order in which the forward
+    pass needs the variables), an event behind each -> the transposed copies the data-gradient convolutions read.
+    A variable's `w16` / `master` / `grad` attribute makes its reader wait for the range that holds it
+    (FlatParams._ready). Each range zeroes its gradient chunks once they are read (also on a skipped step):
+    `store.grads_zeroed` tells the next step that the fill of the gradient buffer is not needed."""
+    s = self.store
+    s.wait_all()                      # (a previous update still in flight: its ranges come first anyway)
+    main = torch.cuda.current_stream()
+    side = s.opt_stream()
+    side.wait_stream(main)
+    nchunks = s.chunk_tensor.numel()
+    nranges = max(1, min(int(nranges), nchunks))
+    bounds = [(nchunks * i) // nranges for i in range(nranges + 1)]
+    pending = []
+    with torch.cuda.stream(side):
+      capi.opt_prepare(self.cfg, self.state, s._grads, s._master, s.chunk_tensor, s.tensor_chunk_begin,
+                       s.tensor_l2 if s.l2_active else None, s.partial, s.t_gnorm2, s.t_wnorm2, s.t_amax,
+                       s.t_mult, s._t_v)
+      for c0, c1 in zip(bounds[:-1], bounds[1:]):
+        capi.opt_apply_range(self.cfg, self.state, s._grads, s._master, s._m1, s._m2, s._w16, c0, c1,
+                             s.chunk_tensor, s.tensor_l2 if s.l2_active else None, s.t_mult, zero_grads=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        pending.append((c1 * s.chunk, ev))
+      s.version = getattr(s, "version", 0) + 1
+      s._refresh_dgrad_copies_raw()
+      evw = torch.cuda.Event()
+      evw.record(side)
+    s._pending, s._wt_event, s._main_stream, s._done_upto = pending, evw, main, 0
+    s.grads_zeroed = True
+
   def read_state(self):
+    self.store.wait_all()             # (the state block is written by the update's finalize pass)
     return capi.opt_read_state(self.state)
 
 
