@@ -325,8 +325,8 @@ class StepBreakdown(object):
 
   def install(self):
     capi, bd, cache = self.capi, self, {}
-    for name in ("conv1d_wgrad", "conv1x1_wgrad_grouped", "bn_act_fwd", "bn_act_bwd_reduce", "bn_bwd_apply",
-                 "opt_step"):
+    for name in ("conv1d_wgrad", "conv1d_wgrad_grouped", "conv1x1_wgrad_grouped", "bn_act_fwd", "bn_act_bwd_reduce",
+                 "bn_bwd_apply", "opt_step"):
       self.saved[name] = getattr(capi, name)
     o = self.saved
 
@@ -336,6 +336,13 @@ class StepBreakdown(object):
       fl = 2.0 * B * Tout * Cin * Cout * K * bd._live(kw.get("in_len"), Tin, cache, quantum=64)
       return bd._bracket("conv1d weight gradient (conv1d_wgrad_pp_kernel + lockstep conv1d_wgrad_kernel)",
                          fl, lambda: o["conv1d_wgrad"](x, dy, K, **kw))
+
+    def wgrad_same_shape(items, K, **kw):      # several layers of one shape in one launch (round 6)
+      B, Tin, Cin = items[0]["x"].shape
+      _, Tout, Cout = items[0]["dy"].shape
+      fl = 2.0 * B * Tout * Cin * Cout * K * len(items) * bd._live(kw.get("in_len"), Tin, cache, quantum=64)
+      return bd._bracket("conv1d weight gradient (conv1d_wgrad_pp_kernel + lockstep conv1d_wgrad_kernel)",
+                         fl, lambda: o["conv1d_wgrad_grouped"](items, K, **kw))
 
     def wgrad_grouped(items, in_len=None, **kw):
       B, T, _ = items[0]["x"].shape
@@ -370,6 +377,7 @@ class StepBreakdown(object):
 
     capi.conv1d_wgrad, capi.bn_act_fwd, capi.bn_act_bwd_reduce = wgrad, bn_fwd, bn_red
     capi.conv1x1_wgrad_grouped = wgrad_grouped
+    capi.conv1d_wgrad_grouped = wgrad_same_shape
     capi.bn_bwd_apply, capi.opt_step = bn_apply, opt
 
   def remove(self):

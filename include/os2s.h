@@ -241,6 +241,22 @@ typedef struct {
 } os2s_wgrad_group_t;
 int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_group_t* groups, int ngroups,
                                const int32_t* in_len, int B, int T);
+/* The kernel gradients of up to 8 convolution layers of ONE shape (Cin, Cout, K, stride, dilation, padding) over
+ * one ragged batch in one launch: dw_i[K, Cout, Cin] (+)= the weight gradient os2s_conv1d_wgrad_ws computes for
+ * (x_i, dy_i). The `repeat` identical tf.layers.conv1d layers of a Jasper block (parts/cnns/conv_blocks.py:61-168,
+ * encoders/tdnn_encoder.py:150-180) are 12 - 150 units of work each on 256 CUs; ranked together they fill the chip
+ * without cutting every unit's reduction. Deterministic (the ping-pong kernel's one-owner reduction); shapes that
+ * kernel does not take are launched one by one. Workspace: as os2s_conv1d_wgrad_ws. */
+typedef struct {
+  const uint16_t* x;        /* [B, Tin, Cin] bf16, row stride x_row_stride elements (the same for every group) */
+  const uint16_t* dy;       /* [B, Tout, Cout] bf16 */
+  float* dw;                /* [K, Cout, Cin] fp32 */
+  long long x_row_stride;
+} os2s_cwgrad_group_t;
+int os2s_conv1d_wgrad_grouped_ws(os2s_stream_t stream, const os2s_cwgrad_group_t* groups, int ngroups,
+                                 const int32_t* in_len, int B, int Tin, int Cin, int Cout, int K,
+                                 int stride, int dil, int padL, int Tout, int accumulate,
+                                 void* workspace, size_t workspace_bytes);
 /* The same with the conv workspace (os2s_conv1d_workspace_bytes, one per stream): when every group is at
  * least 128 x 128 channels and the batch has >= 2048 rows the launch runs on the K = 1 ping-pong TN-GEMM
  * kernel — 256 x 256 tiles, reduction over the live 64-row chunks only, the tail of the launch cut along

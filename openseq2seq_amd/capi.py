@@ -357,6 +357,36 @@ def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
   return out
 
 
+class _CWgradGroup(_lib.ctypes.Structure):
+  _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("x_row_stride", c_ll)]
+
+
+def conv1d_wgrad_grouped(items, K, *, stride=1, dil=1, pad_left=None, in_len=None, accumulate=True):
+  """items: list (<= 8) of dict(x [B,Tin,Cin] bf16, dy [B,Tout,Cout] bf16, dw [K,Cout,Cin] fp32) of ONE shape over
+  one batch: their weight gradients in one launch (os2s_conv1d_wgrad_grouped_ws)."""
+  n = len(items)
+  assert 1 <= n <= 8
+  x0, dy0 = items[0]["x"], items[0]["dy"]
+  B, Tin, Cin = x0.shape
+  _, Tout, Cout = dy0.shape
+  if pad_left is None:
+    tout, pad_left = same_padding(Tin, K, stride, dil)
+    assert tout == Tout
+  arr = (_CWgradGroup * n)()
+  for g, it in zip(arr, items):
+    x, dy, dw = it["x"], it["dy"], it["dw"]
+    assert tuple(x.shape) == (B, Tin, Cin) and tuple(dy.shape) == (B, Tout, Cout) and tuple(dw.shape) == (K, Cout, Cin)
+    assert x.stride(2) == 1 and x.stride(0) == Tin * x.stride(1) and x.stride(1) == x0.stride(1)
+    g.x, g.dy, g.dw = c_void_p(x.data_ptr()), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32)
+    g.x_row_stride = x.stride(1)
+  ws = conv1d_workspace(x0.device)
+  f = _fn("os2s_conv1d_wgrad_grouped_ws",
+          (c_void_p, _lib.ctypes.POINTER(_CWgradGroup), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+           c_int, c_int, c_int, c_int, c_void_p, c_size_t))
+  _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, Tin, Cin, Cout, K, stride, dil, pad_left, Tout,
+               int(bool(accumulate)), _ptr(ws), ws.numel()), "os2s_conv1d_wgrad_grouped_ws")
+
+
 # --------------------------------------------------------------------------
 # BatchNorm (+ residual sum + activation + dropout + mask)
 # --------------------------------------------------------------------------

@@ -48,6 +48,12 @@ struct WgradArgs {
   int* ws_cnt;
   int ws_nslabs, ncu, force_split;
   int xcd_order;             // 1: consecutive ranks (the tap quads / ci tiles of one tile) share an XCD (wgrad_xcd_rank)
+  // conv1d_wgrad_pp_kernel, grouped launch (os2s_conv1d_wgrad_grouped_ws): NG > 1 layers of ONE shape over one batch;
+  // units are ranked group-major, unit -> (group, co tile, ci tile, tap quad); x / dy / dw of group g below
+  int NG;
+  const bf16_t* gx[8];
+  const bf16_t* gdy[8];
+  float* gdw[8];
   unsigned long long* dbg;   // experiment hook: slot time stamps [4 wg][2 waves][48 steps][10]
   int dbg_mode;              // experiment hook (DBG kernel): 1 no dY DMA, 2 no X DMA, 4 frozen cursor
 };
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   const int total_live = __builtin_amdgcn_readlane(scan, 63);
 
   // ---- block -> (unit, piece) -------------------------------------------------------------
-  const int U = p.NCO * p.NCI * p.NTP, G = p.ncu;
+  const int U = p.NG * p.NCO * p.NCI * p.NTP, G = p.ncu;
   const int q = U / G, r = U - q * G;
   int f = 1;
   {
@@ -428,7 +434,18 @@ __global__ __launch_bounds__(512, 2) void conv1d_wgrad_pp_kernel(WgradArgs p) {
   }
   // tap quads of one (co, ci) tile are adjacent ranks: they stream the same dY / X rows
   const int tp = rank % p.NTP;
-  const int rem = rank / p.NTP;
+  int rem = rank / p.NTP;
+  if (p.NG > 1) {                                          // grouped launch: same-shape layers, group-major ranks
+    const int per = p.NCO * p.NCI;
+    const int g = __builtin_amdgcn_readfirstlane(rem / per);    // wave-uniform: scalar loads from the arguments
+    rem -= g * per;
+    // (selected by compare: a runtime index would move the argument table to private memory)
+    const bf16_t* sx = p.gx[0]; const bf16_t* sdy = p.gdy[0]; float* sdw = p.gdw[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if (i == g) { sx = p.gx[i]; sdy = p.gdy[i]; sdw = p.gdw[i]; }
+    p.x = sx; p.dy = sdy; p.dw = sdw;
+  }
   const int co0 = (rem / p.NCI) * COT, ci0 = (rem % p.NCI) * CIT;
   const int k0 = tp * kWppTaps;
   const int sps = (total_live + npiece - 1) / npiece;
@@ -1172,11 +1189,53 @@ extern "C" int os2s_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x,
                            padL, Tout, accumulate, nullptr, 0);
 }
 
+// groups != nullptr (os2s_conv1d_wgrad_grouped_ws): ngroups layers of this one shape; only the ping-pong kernel takes
+// them — returns OS2S_ERR_UNSUPPORTED when the shape is not its (the caller then launches the layers one by one)
+static int conv1d_wgrad_impl_g(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                               const uint16_t* dy, float* dw, const int32_t* in_len, int B,
+                               int Tin, int Cin, int Cout, int K, int stride, int dil,
+                               int padL, int Tout, int accumulate, void* workspace,
+                               size_t workspace_bytes, const os2s_cwgrad_group_t* groups, int ngroups);
+
 static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
                              const uint16_t* dy, float* dw, const int32_t* in_len, int B,
                              int Tin, int Cin, int Cout, int K, int stride, int dil,
                              int padL, int Tout, int accumulate, void* workspace,
                              size_t workspace_bytes) {
+  return conv1d_wgrad_impl_g(stream, x, x_row_stride, dy, dw, in_len, B, Tin, Cin, Cout, K, stride, dil, padL, Tout,
+                             accumulate, workspace, workspace_bytes, nullptr, 1);
+}
+
+// Up to 8 convolution layers of ONE shape (Cin, Cout, K, dilation, padding) over one batch (B, T, lengths) in one
+// launch of the ping-pong weight-gradient kernel: the repeated sub-blocks of a Jasper block (conv_blocks.py:61-168:
+// `repeat` x the same tf.layers.conv1d) are 12 - 150 units of work each on 256 CUs — alone each is cut up to 16
+// ways along the reduction (fill, 256 KB slab per piece, one reducer per unit); together they fill the chip whole.
+extern "C" int os2s_conv1d_wgrad_grouped_ws(os2s_stream_t stream, const os2s_cwgrad_group_t* groups, int ngroups,
+                                            const int32_t* in_len, int B, int Tin, int Cin, int Cout, int K,
+                                            int stride, int dil, int padL, int Tout, int accumulate,
+                                            void* workspace, size_t workspace_bytes) {
+  OS2S_REQUIRE(groups && ngroups >= 1 && ngroups <= 8);
+  for (int i = 0; i < ngroups; ++i) OS2S_REQUIRE(groups[i].x && groups[i].dy && groups[i].dw);
+  for (int i = 1; i < ngroups; ++i) OS2S_REQUIRE(groups[i].x_row_stride == groups[0].x_row_stride);
+  int rc = OS2S_ERR_UNSUPPORTED;
+  if (ngroups > 1)
+    rc = conv1d_wgrad_impl_g(stream, groups[0].x, groups[0].x_row_stride, groups[0].dy, groups[0].dw, in_len, B, Tin,
+                             Cin, Cout, K, stride, dil, padL, Tout, accumulate, workspace, workspace_bytes, groups,
+                             ngroups);
+  if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  for (int i = 0; i < ngroups; ++i) {
+    rc = conv1d_wgrad_impl(stream, groups[i].x, groups[i].x_row_stride, groups[i].dy, groups[i].dw, in_len, B, Tin,
+                           Cin, Cout, K, stride, dil, padL, Tout, accumulate, workspace, workspace_bytes);
+    if (rc != OS2S_OK) return rc;
+  }
+  return OS2S_OK;
+}
+
+static int conv1d_wgrad_impl_g(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                               const uint16_t* dy, float* dw, const int32_t* in_len, int B,
+                               int Tin, int Cin, int Cout, int K, int stride, int dil,
+                               int padL, int Tout, int accumulate, void* workspace,
+                               size_t workspace_bytes, const os2s_cwgrad_group_t* groups, int ngroups) {
   using namespace os2s;
   OS2S_REQUIRE(x_row_stride >= Cin && x_row_stride % 8 == 0);
   OS2S_REQUIRE(x && dy && dw);
@@ -1189,7 +1248,12 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
   a.stride = stride; a.dil = dil; a.padL = padL; a.x_ld = x_row_stride;
   a.accumulate = accumulate ? 1 : 0;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
-  a.dbg = g_wgrad_dbg; a.dbg_mode = g_wgrad_dbg_mode; a.xcd_order = g_wgrad_xcd;
+  a.dbg = g_wgrad_dbg; a.dbg_mode = g_wgrad_dbg_mode; a.xcd_order = g_wgrad_xcd; a.NG = 1;
+  for (int i = 0; i < 8; ++i) { a.gx[i] = nullptr; a.gdy[i] = nullptr; a.gdw[i] = nullptr; }
+  if (groups) {
+    a.NG = ngroups;
+    for (int i = 0; i < ngroups; ++i) { a.gx[i] = groups[i].x; a.gdy[i] = groups[i].dy; a.gdw[i] = groups[i].dw; }
+  }
 
   // ---- ping-pong kernel ------------------------------------------------------------------
   const bool pp_shape = stride == 1 && K >= 2 && B <= 64 && Cout >= 128 && Cin >= 64 &&
@@ -1206,7 +1270,7 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
   // Opt-in (conv1d_wgrad.variant 3): measured against the ping-pong kernel on the 768 x 768 x 25 layer it needs 3 050
   // cycles per 64-row step at 2.11 GHz where the ping-pong kernel needs 2 400 at 1.75 GHz — 0.648 vs 0.612 ms
   // (profiles/r06_wgrad_sw_ablation.txt, DESIGN.md "Round-6 kernel work").
-  if (sw_shape && g_wgrad_variant == 3) {
+  if (sw_shape && g_wgrad_variant == 3 && !groups) {
     a.NCO = ceil_div(Cout, 128);
     a.NCI = ceil_div(Cin, 128);
     a.NTP = ceil_div(K, kWppTaps);
@@ -1263,7 +1327,7 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
     }
   }
 
-  if (pp_shape && g_wgrad_variant != 0 && (g_wgrad_variant == 1 || pp_units >= wgrad_pp_min_units())) {
+  if (pp_shape && g_wgrad_variant != 0 && (groups || g_wgrad_variant == 1 || pp_units >= wgrad_pp_min_units())) {
     a.NCO = ceil_div(Cout, 128);
     a.NCI = ceil_div(Cin, 128);
     a.NTP = ceil_div(K, kWppTaps);
@@ -1300,7 +1364,7 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
       }
       // upper bound of the grid (the split factor is decided on the device from the live
       // length of the batch): whole units, or up to 16 pieces of each unit of the tail
-      const int U = a.NCO * a.NCI * a.NTP;
+      const int U = a.NG * a.NCO * a.NCI * a.NTP;
       const int r = U % ncu;
       int pieces = a.ws_nslabs < 16 * r ? a.ws_nslabs : 16 * r;
       const int grid = U + pieces;
@@ -1312,6 +1376,8 @@ static int conv1d_wgrad_impl(os2s_stream_t stream, const uint16_t* x, long long 
       return OS2S_OK;
     }
   }
+
+  if (groups) return OS2S_ERR_UNSUPPORTED;               // only the ping-pong kernel ranks units over groups
 
   // ---- ping-pong kernel of the K = 1 case (Dense weight gradients) ----------------------------
   const bool pp1_shape = K == 1 && stride == 1 && padL == 0 && Tin == Tout && B <= 64 &&
@@ -1443,7 +1509,7 @@ extern "C" int os2s_conv1x1_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad
   a.B = B; a.Tin = T; a.Tout = T; a.Cin = 0; a.Cout = 0; a.K = 1;
   a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = 0; a.accumulate = 1;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
-  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd;
+  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd; a.NG = 1;
   a.NCO = 0; a.NCI = 0; a.NTP = 1;
   a.steps_per_split = ceil_div(total_steps, nsplit);
   a.NSPLIT = ceil_div(total_steps, a.steps_per_split);
@@ -1511,7 +1577,7 @@ extern "C" int os2s_conv1x1_wgrad_grouped_ws(os2s_stream_t stream, const os2s_wg
   a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = gt.g[0].x_ld;
   a.accumulate = 1;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
-  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd;
+  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd; a.NG = 1;
   a.NCO = units; a.NCI = 1; a.NTP = 1;                   // U = NCO * NCI = all units of all groups
   a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
   a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;
@@ -1573,7 +1639,7 @@ extern "C" int os2s_gemm_wgrad_grouped(os2s_stream_t stream, const os2s_wgrad_gr
   a.stride = 1; a.dil = 1; a.padL = 0; a.x_ld = gt.g[0].x_ld;
   a.accumulate = accumulate ? 1 : 0;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = g_wgrad_split;
-  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd;
+  a.dbg = nullptr; a.dbg_mode = 0; a.xcd_order = g_wgrad_xcd; a.NG = 1;
   a.NCO = units; a.NCI = 1; a.NTP = 1;                   // U = NCO * NCI = all units of all groups
   a.NSPLIT = 1; a.steps_per_split = 0; a.use_atomic = 0;
   a.xrows = 64; a.xrows_pad = 64; a.xbuf_bytes = 0; a.steptab_bytes = 0;

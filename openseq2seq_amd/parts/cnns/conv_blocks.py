@@ -75,6 +75,13 @@ GROUP_POINTWISE_WGRAD = os.environ.get("OS2S_GROUP_POINTWISE_WGRAD", "1") != "0"
 POINTWISE_WGRAD_GROUP = int(os.environ.get("OS2S_POINTWISE_WGRAD_GROUP", "5"))
 # how many small Dense weight gradients (Transformer: the 1024 x 1024 projections, 16 tiles each) share one launch
 SMALL_WGRAD_GROUP = int(os.environ.get("OS2S_SMALL_WGRAD_GROUP", "3"))
+# Round 6: convolution weight gradients of same-shape layers CAN be collected until they cover this many units of the
+# ping-pong kernel (128 co x 128 ci x 4 taps each; 256 CUs) and go out as one launch (Tape.defer_conv_wgrad,
+# os2s_conv1d_wgrad_grouped_ws). Alone on the GPU the grouped launches save the reduction splits of the 256 - 640
+# channel layers; in the Jasper step — where the weight gradients run next to the data-gradient chain — holding them
+# back costs what it saves: 37.15 / 37.31 ms without, 37.1 - 37.3 at 64 - 128 units, 37.4 - 38.0 at 160 - 192
+# (same box, interleaved). 0 (default) = every layer alone, as in rounds 2 - 5.
+CONV_WGRAD_UNIT_BUDGET = int(os.environ.get("OS2S_CONV_WGRAD_UNIT_BUDGET", "0"))
 # A/B knob: 0 = the grouped K = 1 weight gradients stay on the lockstep kernel with its atomics (round 2 - 4)
 GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 
@@ -183,11 +190,13 @@ class Tape(object):
     capi.zero_arena_enter(depth)   # the previous pass's statistic partials at this depth are dead: one fill
     _TAPE_STACK.append(self)
     self._deferred, self._pending = [], None
+    self._cdeferred, self._ckey = [], None
     try:
       if self.on_done is None:
         for fn, _ in reversed(self.ops):
           fn()
         self.flush_deferred()
+        self.flush_conv_wgrads()
       else:
         pending, by_id = {}, {}
         for _, params in self.ops:
@@ -213,8 +222,9 @@ class Tape(object):
             for p in params:
               pending[id(p)] -= 1
             advance()
-        if self._deferred:
+        if self._deferred or self._cdeferred:
           self.flush_deferred()
+          self.flush_conv_wgrads()
           advance()
     finally:
       _TAPE_STACK.pop()
@@ -242,6 +252,33 @@ class Tape(object):
         self.flush_deferred()
     elif len(self._deferred) >= (group if group is not None else SMALL_WGRAD_GROUP):
       self.flush_deferred()
+
+  def defer_conv_wgrad(self, param, key, item, units, launch_kw):
+    """The weight gradient of a convolution layer is held back while layers of the SAME shape over the same batch
+    follow (the `repeat` sub-blocks of a Jasper block: 12 - 150 units of work each for 256 CUs): they go out as one
+    launch of the ping-pong kernel (capi.conv1d_wgrad_grouped, at most 8) once CONV_WGRAD_UNIT_BUDGET units are
+    collected, when a layer of another shape arrives, or at the end of the pass. `param` is not final for the
+    gradient reducer until then."""
+    if self._cdeferred and self._ckey != key:
+      self.flush_conv_wgrads()
+    self._ckey, self._ckw = key, launch_kw
+    self._cdeferred.append((param, item))
+    if self._pending is not None and id(param) in self._pending:
+      self._pending[id(param)] += 1
+    if units * len(self._cdeferred) >= CONV_WGRAD_UNIT_BUDGET or len(self._cdeferred) >= 8:
+      self.flush_conv_wgrads()
+
+  def flush_conv_wgrads(self):
+    if not self._cdeferred:
+      return
+    items = [it for _, it in self._cdeferred]
+    with on_side_stream(items[0]["x"].device, *([it["x"] for it in items] + [it["dy"] for it in items])):
+      capi.conv1d_wgrad_grouped(items, **self._ckw)
+    if self._pending is not None:
+      for p, _ in self._cdeferred:
+        if id(p) in self._pending:
+          self._pending[id(p)] -= 1
+    self._cdeferred, self._ckey = [], None
 
   def flush_deferred(self):
     if not self._deferred:
@@ -376,6 +413,18 @@ class ConvBN(object):
     return [self.kernel, self.gamma, self.beta]
 
   def backward_weights(self, inp, dy, f):
+    x = inp.data
+    tape = current_tape()
+    units = ((self.cout + 127) // 128) * ((self.cin + 127) // 128) * ((self.k + 3) // 4)
+    if CONV_WGRAD_UNIT_BUDGET > 0 and tape is not None and self.stride == 1 and self.k >= 2 and \
+       units < CONV_WGRAD_UNIT_BUDGET and x.dim() == 3 and x.shape[0] <= 64 and self.cout >= 128 and self.cin >= 64 and \
+       dy.is_contiguous() and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1):
+      # (the envelope of the ping-pong weight-gradient kernel; everything else goes out alone as before)
+      key = (tuple(x.shape), tuple(dy.shape), x.stride(1), self.k, self.dil, f["pad_left"],
+             None if inp.lens is None else inp.lens.data_ptr())
+      tape.defer_conv_wgrad(self.kernel, key, dict(x=x, dy=dy, dw=self.kernel.grad), units,
+                            dict(K=self.k, stride=1, dil=self.dil, pad_left=f["pad_left"], in_len=inp.lens))
+      return
     with on_side_stream(dy.device, inp.data, dy):
       capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
                         pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,

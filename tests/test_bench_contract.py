@@ -101,10 +101,11 @@ def test_step_breakdown_wrappers_accept_every_keyword_of_the_entry_points_they_w
   lens = torch.tensor([8, 5], dtype=torch.int32)
   by_name = {"x": x, "dy": x, "dz": x, "y": x, "out": x, "dout": x, "w": torch.zeros((3, 4, 4)), "K": 3,
              "ys": [x], "scales": [x], "shifts": [x], "means": [x], "rstds": [x], "partial": x,
-             "items": [{"x": x, "dy": x, "w": torch.zeros((1, 4, 4))}], "in_len": lens, "out_len": lens,
+             "items": [{"x": x, "dy": x, "dw": torch.zeros((3, 4, 4)), "w": torch.zeros((1, 4, 4))}], "in_len": lens,
+             "out_len": lens,
              "weights": torch.zeros(16), "grads": torch.zeros(16)}
-  names = ("conv1d_wgrad", "conv1x1_wgrad_grouped", "bn_act_fwd", "bn_act_bwd_reduce", "bn_bwd_apply", "opt_step",
-           "conv1x1_fwd_grouped")
+  names = ("conv1d_wgrad", "conv1d_wgrad_grouped", "conv1x1_wgrad_grouped", "bn_act_fwd", "bn_act_bwd_reduce",
+           "bn_bwd_apply", "opt_step", "conv1x1_fwd_grouped")
   seen = {}
 
   def stand_in(name):

@@ -527,6 +527,48 @@ def test_conv_wgrad_one_wave_per_simd_full_size_vs_lockstep(cuda, C, K, d):
   assert torch.equal(c, c2)
 
 
+@pytest.mark.parametrize("B,T,Cin,Cout,K,d,n", [(4, 300, 256, 256, 11, 1, 5), (3, 420, 384, 384, 13, 1, 4),
+                                                (2, 260, 128, 640, 5, 2, 8), (32, 840, 640, 640, 21, 1, 2),
+                                                (2, 150, 192, 200, 5, 1, 3), (2, 100, 64, 64, 3, 1, 2)])
+def test_conv_wgrad_grouped_equals_single_launches(cuda, B, T, Cin, Cout, K, d, n):
+  """os2s_conv1d_wgrad_grouped_ws: n layers of ONE shape over one ragged batch in one launch of the ping-pong
+  weight-gradient kernel (units ranked group-major; the tail of the launch cut along the reduction) against n single
+  launches: the same fp32 sums up to the order in which split pieces are added (rtol 1e-4), accumulate semantics,
+  run-to-run bitwise reproducibility, tickets left at zero; shapes outside the kernel's envelope (the last two cases:
+  channel tails / fewer than 128 output channels) fall back to single launches and are bit-equal to them."""
+  from openseq2seq_amd import capi
+  g = torch.Generator().manual_seed(B * 31 + T + K + Cout + n)
+  lens = torch.randint(T // 4, T + 1, (B,), generator=g).to(torch.int32)
+  lens[0] = T
+  lens = lens.to(cuda)
+  xs = [_bf(torch.randn(B, T, Cin, generator=g)).to(cuda) for _ in range(n)]
+  dys = [_bf(torch.randn(B, T, Cout, generator=g)).to(cuda) for _ in range(n)]
+  base = [torch.randn(K, Cout, Cin, generator=g).to(cuda) for _ in range(n)]
+  single = [b.clone() for b in base]
+  for x, dy, dw in zip(xs, dys, single):
+    capi.conv1d_wgrad(x, dy, K, dil=d, in_len=lens, out=dw, accumulate=True)
+  outs = []
+  for _ in range(2):
+    grouped = [b.clone() for b in base]
+    capi.conv1d_wgrad_grouped([dict(x=x, dy=dy, dw=dw) for x, dy, dw in zip(xs, dys, grouped)], K, dil=d,
+                              in_len=lens, accumulate=True)
+    outs.append(grouped)
+  fresh = [torch.full_like(b, float("nan")) for b in base]
+  capi.conv1d_wgrad_grouped([dict(x=x, dy=dy, dw=dw) for x, dy, dw in zip(xs, dys, fresh)], K, dil=d,
+                            in_len=lens, accumulate=False)
+  torch.cuda.synchronize()
+  envelope = Cout >= 128 and Cin >= 64
+  for i in range(n):
+    scale = float((single[i] - base[i]).abs().max())
+    if envelope:
+      torch.testing.assert_close(outs[0][i], single[i], rtol=1e-4, atol=1e-4 * scale)
+    else:
+      assert torch.equal(outs[0][i], single[i])
+    assert torch.equal(outs[0][i], outs[1][i])
+    torch.testing.assert_close(fresh[i], single[i] - base[i], rtol=1e-4, atol=1e-4 * scale)
+  assert int(capi.conv1d_workspace(cuda)[:4096].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("B,T,Cin,Cout", [(3, 420, 256, 512), (2, 333, 320, 640), (1, 1111, 1024, 1024),
                                          (4, 200, 128, 264), (5, 97, 520, 136)])
 @pytest.mark.parametrize("split", [1, 3, -1])
