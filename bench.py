@@ -1071,6 +1071,9 @@ def main():
     return
   dev = torch.device("cuda", 0 if args.one_device else int(os.environ.get("LOCAL_RANK", 0)))
   torch.cuda.set_device(dev)
+  if os.environ.get("OS2S_MAIN_PRIO"):        # experiment: the step's own stream at a HIP stream priority (-1 = high)
+    _hp = torch.cuda.stream(torch.cuda.Stream(device=dev, priority=int(os.environ["OS2S_MAIN_PRIO"])))
+    _hp.__enter__()
   for kv in args.set_option:
     from openseq2seq_amd import _lib as _l
     name, _, val = kv.partition("=")

@@ -957,6 +957,86 @@ def tacotron_infer(seed=59):
   return out
 
 
+TACO_DEV = dict(B=4, S=12, M=64, H=64, U=128, P=64, NMEL=16, src_len=[12, 8, 10, 6])
+
+
+def tacotron_infer_dev(seed=67):
+  """The same free-running decode (Tacotron2Decoder._decode in eval mode with TacotronHelper,
+  decoders/tacotron2_decoder.py:378-428, parts/tacotron/tacotron_helper.py:138-226) at widths the device's fused decode
+  kernels take (decoder_cell_units = memory = 64, attention layer 128, 32 location filters of 31 taps, pre-net 2 x 64,
+  16 mel bins, a two-layer post-net): tests/test_ref_exec_tacotron_gpu.py holds the HIP decode against these frames,
+  stop logits, alignments and lengths. The pre-net's always-on dropout (tacotron2_decoder.py: Prenet at keep 0.5) is
+  switched off on both sides — the device draws its masks from a counter hash inside the step kernel, the reference
+  from tf.nn.dropout: the hash is pinned separately (test_tacotron_infer_gpu.py against the oracle). The stop
+  projection's bias / gain are searched until a sample finishes in the middle of the run while another keeps decoding."""
+  D = TACO_DEV
+  B, S, M, H, U, P, NMEL = [D[k] for k in ("B", "S", "M", "H", "U", "P", "NMEL")]
+  tf, imp = _install()
+  tf.reset_default_graph()
+  tf.set_random_seed(seed)
+  Dec = imp("open_seq2seq.decoders.tacotron2_decoder").Tacotron2Decoder
+  rng = np.random.RandomState(seed)
+  src_len = np.array(D["src_len"], np.int32)                  # limit = 10 * 12 = 120 steps
+  enc = (0.5 * rng.standard_normal((B, S, M))).astype(np.float32)
+  enc *= (np.arange(S)[None, :, None] < src_len[:, None, None])
+
+  class _DL(object):
+    params = {"num_audio_features": NMEL, "output_type": "mel"}
+
+  class _Model(object):
+    params = {"dtype": tf.float32}
+
+    def get_data_layer(self):
+      return _DL()
+  postnet = [{"kernel_size": [5], "stride": [1], "num_channels": 64, "padding": "SAME", "activation_fn": tf.nn.tanh},
+             {"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
+  params = dict(attention_layer_size=U, attention_type="location", attention_bias=True, decoder_cell_units=H,
+                decoder_cell_type=tf.nn.rnn_cell.LSTMCell, decoder_layers=2, enable_prenet=True, prenet_layers=2,
+                prenet_units=P, enable_postnet=True, postnet_conv_layers=postnet, postnet_keep_dropout_prob=1.0,
+                mask_decoder_sequence=True, zoneout_prob=0.0, dropout_prob=0.0, dtype=tf.float32)
+  tf.DROPOUT_OFF = True
+  try:
+    with tf.variable_scope("ForwardPass"):
+      dec = Dec(params, _Model(), mode="eval")
+      res = dec.decode({"encoder_output": {"outputs": tf.constant(enc), "src_length": tf.constant(src_len)}})
+    dec_out, post, align, stop_sig, seq_lens, _ = res["outputs"]
+    gvars = tf.trainable_variables()
+    names = [v.name.split(":")[0] for v in gvars]
+    stop_b = [v for v in gvars if v.name.endswith("stop_token_proj/bias:0")][0]
+    stop_k = [v for v in gvars if v.name.endswith("stop_token_proj/kernel:0")][0]
+    out_k = [v for v in gvars if v.name.endswith("output_proj/kernel:0")][0]
+    with tf.Session() as sess:
+      for n, v in zip(names, gvars):
+        if v._var.dim() == 1:
+          v.load(_np(v._var) + 0.2 * rng.standard_normal(tuple(v._var.shape)).astype(np.float32))
+      stop_k0, out_k0 = _np(stop_k._var).copy(), _np(out_k._var).copy()
+      chosen = None
+      # (random LSTM trajectories settle within a few steps and the first step — the all-zero go frame — carries the
+      # largest stop logit: with the frame projection at 16 x its initial scale the fed-back frames keep the state
+      # moving and one sample's logit crosses zero around step 30)
+      for bias, gain in [(b, g) for g in (1.0, 3.0) for b in np.linspace(-0.5, 0.5, 41)]:
+        stop_b.load(np.array([bias], np.float32))
+        stop_k.load(gain * stop_k0)
+        out_k.load(16.0 * out_k0)
+        tf._RNG.manual_seed(seed)
+        vals = sess.run({"mel": dec_out, "post": post, "align": align, "stop": res["stop_token_prediction"],
+                         "lens": seq_lens, "vars": list(gvars)})
+        lens = [int(v) for v in vals["lens"]]
+        if any(8 <= v <= 100 for v in lens) and max(lens) == 10 * int(src_len.max()):
+          chosen = (float(bias), float(gain))
+          break
+  finally:
+    tf.DROPOUT_OFF = False
+  assert chosen is not None, "no stop bias / gain lets a sample finish in the middle of the run while another keeps decoding"
+  steps = vals["mel"].shape[1]
+  out = {"dims": np.array([B, S, M, H, U, P, NMEL], np.int32), "src_len": src_len, "enc": enc, "mel": vals["mel"],
+         "post": vals["post"], "align": vals["align"], "stop": vals["stop"], "lens": vals["lens"].astype(np.int32),
+         "steps": np.int32(steps), "var_names": np.array(names), "stop_search": np.array(chosen, np.float32)}
+  for n, v in zip(names, vals["vars"]):
+    out["var/" + n] = v.astype(np.float32)
+  return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Text2SpeechLoss (losses/text2speech_loss.py:35-209) on synthetic predictions: "both" mode, predictions shorter and
 # longer than the targets (the pad-to-common-length branch), mask on / off, l1 / l2, weights and scale.
@@ -1384,7 +1464,7 @@ def frontend():
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam, "transformer_infer_d512": transformer_infer_d512}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_infer_dev": tacotron_infer_dev, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam, "transformer_infer_d512": transformer_infer_d512}
 
 
 def generate(name):

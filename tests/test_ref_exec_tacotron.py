@@ -145,6 +145,30 @@ def test_oracle_reproduces_the_reference_free_running_decode():
   against) must give the same frames, stop logits, alignments (1e-4 over 30 free-running steps), the same step count
   and the same per-sample lengths."""
   d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_tacotron_infer.npz")))
+  out = _oracle_free_running(d, [torch.from_numpy(d["prenet_mask0"]), torch.from_numpy(d["prenet_mask1"])])
+  assert int(out["steps"]) == int(d["steps"]) == 30
+  assert [int(v) for v in out["lengths"]] == d["lens"].tolist() == [28, 30, 30]
+  assert rx.rel(out["mel"].numpy(), d["mel"]) < 1e-4
+  assert rx.rel(out["stop"].numpy(), d["stop"][:, :, 0]) < 1e-4
+  assert rx.rel(out["align"].numpy(), d["align"]) < 1e-4
+
+
+def test_oracle_reproduces_the_reference_free_running_decode_at_device_widths():
+  """The same at the widths the device's fused decode kernels take (make_ref_exec.py: tacotron_infer_dev — cell and
+  memory 64, attention layer 128, pre-net 2 x 64, 16 mel bins, pre-net dropout off, 120 steps, one sample stopping at
+  step 41): the oracle gives the same frames / stop logits / alignments (1e-4) and the same lengths, so the device
+  test on this fixture (test_ref_exec_tacotron_gpu.py) and the device-vs-oracle tests at full width
+  (test_tacotron_infer_gpu.py) are pinned to the reference's own code through the same restatement."""
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_tacotron_infer_dev.npz")))
+  out = _oracle_free_running(d, None)
+  assert int(out["steps"]) == int(d["steps"]) == 120
+  assert [int(v) for v in out["lengths"]] == d["lens"].tolist() == [120, 41, 120, 120]
+  assert rx.rel(out["mel"].numpy(), d["mel"]) < 1e-4
+  assert rx.rel(out["stop"].numpy(), d["stop"][:, :, 0]) < 1e-4
+  assert rx.rel(out["align"].numpy(), d["align"]) < 1e-4
+
+
+def _oracle_free_running(d, masks):
   B, S, M, H, U, P_, NMEL = [int(v) for v in d["dims"]]
   leaf = {str(n): torch.from_numpy(d["var/" + str(n)].copy()) for n in d["var_names"]}
   k0 = leaf[AW + "multi_rnn_cell/cell_0/lstm_cell/kernel"].t()
@@ -161,14 +185,8 @@ def test_oracle_reproduces_the_reference_free_running_decode():
                   for i in (1, 2)],
        "cell": cell, "out_w": leaf[SC + "decoder/output_proj/kernel"].t(), "out_b": leaf[SC + "decoder/output_proj/bias"],
        "stop_w": leaf[SC + "decoder/stop_token_proj/kernel"].t(), "stop_b": leaf[SC + "decoder/stop_token_proj/bias"]}
-  masks = [torch.from_numpy(d["prenet_mask0"]), torch.from_numpy(d["prenet_mask1"])]
-  out = otaco.decoder_infer(P, torch.from_numpy(d["enc"]), torch.from_numpy(d["src_len"]), prenet_masks=masks,
-                            round_frames_bf16=False)
-  assert int(out["steps"]) == int(d["steps"]) == 30
-  assert [int(v) for v in out["lengths"]] == d["lens"].tolist() == [28, 30, 30]
-  assert rx.rel(out["mel"].numpy(), d["mel"]) < 1e-4
-  assert rx.rel(out["stop"].numpy(), d["stop"][:, :, 0]) < 1e-4
-  assert rx.rel(out["align"].numpy(), d["align"]) < 1e-4
+  return otaco.decoder_infer(P, torch.from_numpy(d["enc"]), torch.from_numpy(d["src_len"]), prenet_masks=masks,
+                             round_frames_bf16=False)
 
 
 @pytest.mark.parametrize("case", sorted(rx.gen.T2S_CASES))
@@ -196,6 +214,6 @@ def test_oracle_reproduces_the_reference_text2speech_loss(case):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check",
-                      "tacotron_decoder", "t2s_loss", "tacotron_infer", "tacotron_encoder"], capture_output=True,
-                     text=True, timeout=900)
-  assert r.returncode == 0 and r.stdout.count("reproduced") == 4, r.stdout + r.stderr
+                      "tacotron_decoder", "t2s_loss", "tacotron_infer", "tacotron_infer_dev", "tacotron_encoder"],
+                     capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 5, r.stdout + r.stderr

@@ -231,3 +231,101 @@ def test_device_tacotron_reproduces_the_reference_code(cuda, monkeypatch):
   assert not bad, bad
   print("device vs the reference's code: loss %.4f vs %.4f, outputs rel-L2 %s, worst gradient projection error %.2e"
         % (float(L.cpu()), float(d["loss"]), {k: "%.1e" % v for k, v in r.items()}, worst))
+
+
+def test_device_free_running_decode_reproduces_the_reference_code(cuda, monkeypatch, tmp_path):
+  """The HIP free-running decode (fused step kernels, stop decision and length bookkeeping on the device) against the
+  reference's OWN Tacotron2Decoder._decode in eval mode with TacotronHelper (decoders/tacotron2_decoder.py:378-428,
+  parts/tacotron/tacotron_helper.py:138-226) executed at widths the fused kernels take
+  (tests/golden/ref_exec_tacotron_infer_dev.npz, make_ref_exec.py: tacotron_infer_dev; pre-net dropout off on both
+  sides): the device model is restored BY THE REFERENCE'S VARIABLE NAMES (utils/checkpoint.load), decodes 120 steps and
+  must reproduce frames, stop logits and alignments over the early trajectory (bf16 bounds; the loop is a recurrence:
+  later steps inherit amplified rounding differences, so the whole run gets a looser bound) and the sequence lengths —
+  with a perturbation-stability window on the stop decision: `finished = round(sigmoid(logit))` flips when the logit
+  crosses zero; a sample whose reference logit stays TAU away from zero at every step up to its finish must finish at
+  exactly the reference's step, any other must finish inside the window the reference's trajectory allows (first step
+  with logit > -TAU ... first step with logit > +TAU)."""
+  from openseq2seq_amd.optimizers.flat_params import FlatParams
+  from openseq2seq_amd.decoders import Tacotron2Decoder
+  from openseq2seq_amd.decoders import tacotron2_decoder as t2d
+  from openseq2seq_amd.parts.cnns.conv_blocks import Act
+  from openseq2seq_amd.utils import checkpoint
+  from openseq2seq_amd import capi
+  monkeypatch.setattr(t2d, "PRENET_KEEP", 1.0)
+  d, names = rx.load("tacotron_infer_dev")
+  B, S, M, H, U, P, NM = [int(v) for v in d["dims"]]
+  post = [{"kernel_size": [5], "stride": [1], "num_channels": 64, "padding": "SAME", "activation_fn": "tanh"},
+          {"kernel_size": [5], "stride": [1], "num_channels": -1, "padding": "SAME", "activation_fn": None}]
+  store = FlatParams(cuda)
+  dec = Tacotron2Decoder({"attention_layer_size": U, "attention_type": "location", "attention_bias": True,
+                          "decoder_cell_units": H, "decoder_cell_type": "LSTMCell", "decoder_layers": 2,
+                          "dropout_prob": 0.0, "enable_prenet": True, "prenet_layers": 2, "prenet_units": P,
+                          "enable_postnet": True, "postnet_keep_dropout_prob": 1.0, "postnet_conv_layers": post,
+                          "mask_decoder_sequence": True, "dtype": "mixed"}, None, mode="eval")
+  dec.build(store, memory_dim=M, num_audio_features=NM, exp_mag=False)
+  store.finalize()
+  # a checkpoint holding exactly the reference's trainable variables (fp32 graph), restored by name
+  np.savez(str(tmp_path / "model.ckpt-0.npz"), **{n: d["var/" + n] for n in names})
+
+  class _Model(object):
+    params = {"dtype": "float32"}
+  _Model.store = store
+  missing = checkpoint.load(_Model(), str(tmp_path / "model.ckpt-0"), restore_optimizer=False, strict=False)
+  assert all("moving_" in m for m in missing), missing          # (BatchNorm moving statistics: initial 0 / 1 on both sides)
+  written = checkpoint.model_variables(_Model())
+  for n in names:                                                # every reference variable went in, value for value
+    assert written[n].shape == d["var/" + n].shape and np.array_equal(written[n], d["var/" + n]), n
+  # ---- decode ---------------------------------------------------------------------------------------------------------
+  fused_calls = []
+  orig = capi.TacotronInfer.steps
+  monkeypatch.setattr(capi.TacotronInfer, "steps", lambda self, a, b: (fused_calls.append((a, b)), orig(self, a, b))[1])
+  mem = torch.from_numpy(d["enc"]).to(torch.bfloat16).to(cuda)
+  lens = torch.from_numpy(d["src_len"]).to(cuda)
+  out = dec.decode({"encoder_output": {"outputs": mem, "outputs_act": Act(mem, None, requires_grad=False),
+                                       "src_length": lens}})
+  torch.cuda.synchronize()
+  assert fused_calls and fused_calls[0][0] == 0, "the fused step kernels did not run"
+  steps = int(d["steps"])
+  assert out["decoder_steps"] == steps == 10 * int(d["src_len"].max())      # a sample never stops: the step limit ends the run
+  mel, stop = out["outputs"][0].float().cpu(), out["stop_token_prediction"][:, :, 0].float().cpu()
+  align, got_len = out["outputs"][2].float().cpu(), out["outputs"][4].cpu().to(torch.int32)
+  r_mel, r_stop, r_align = torch.from_numpy(d["mel"]), torch.from_numpy(d["stop"][:, :, 0]), torch.from_numpy(d["align"])
+  ref_len = torch.from_numpy(d["lens"]).to(torch.int32)
+
+  def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-20))
+  n = 12
+  e_mel, e_stop, e_al = rel(mel[:, :n], r_mel[:, :n]), rel(stop[:, :n], r_stop[:, :n]), rel(align[:, :n], r_align[:, :n])
+  assert e_mel <= 3e-2 and e_stop <= 3e-2 and e_al <= 3e-2, (e_mel, e_stop, e_al)
+  # the reference zeroes the frames past a sample's length (mask_decoder_sequence): compare live frames only
+  live = (torch.arange(steps)[None, :] < torch.minimum(ref_len, got_len)[:, None]).float()[:, :, None]
+  e_all = rel(mel * live, r_mel * live)
+  assert e_all <= 1e-1, e_all
+  # ---- the stop decision ------------------------------------------------------------------------------------------------
+  TAU = 0.1           # absolute stop-logit error allowed where |logit| <= 1 — where a decision can flip (measured: printed)
+  exact = windowed = 0
+  worst = 0.0
+  for b in range(B):
+    lr, traj = int(ref_len[b]), r_stop[b]
+
+    def first(thr):   # the step (1-based) at which a trajectory shifted by -thr first turns positive; `steps` if never
+      return next((t + 1 for t in range(steps) if float(traj[t]) > thr), steps)
+    lo, hi = first(-TAU), first(+TAU)            # earliest / latest finish an error of TAU admits
+    g = int(got_len[b])
+    k = min(g, lr)
+    near = traj[:k].abs() <= 1.0                 # the steps at which a decision could flip at all
+    if bool(near.any()):
+      worst = max(worst, float((stop[b, :k] - traj[:k]).abs()[near].max()))
+    if lo == hi:
+      assert g == lr, (b, g, lr)
+      exact += 1
+    else:
+      assert lo <= g <= hi, (b, g, lr, lo, hi)
+      windowed += 1
+  assert worst <= TAU, worst
+  assert exact >= 2 and exact + windowed == B
+  # a sample that stops in the middle of the run is among them (the fixture's search guarantees one)
+  assert any(8 <= int(v) <= 100 for v in ref_len)
+  print("device free-running decode vs the reference's code: first %d steps mel %.2e stop %.2e alignments %.2e, all live "
+        "frames %.2e; worst stop-logit error where |logit| <= 1: %.3f; lengths %s vs %s (%d exact by necessity, %d inside "
+        "the stability window)" % (n, e_mel, e_stop, e_al, e_all, worst, got_len.tolist(), ref_len.tolist(), exact, windowed))
