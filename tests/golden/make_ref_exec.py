@@ -692,14 +692,26 @@ NMT_ENC_CASES = {"bidir": dict(cls="BidirectionalRNNEncoderWithEmbedding", layer
 
 
 def nmt_encoder(seed=43, B=3, S=7, V=20, E=10, H=12):
+  return _nmt_encoder(seed, B, S, V, E, H, NMT_ENC_CASES, [7, 3, 5])
+
+
+def nmt_encoder_dev(seed=71):
+  """GNMTLikeEncoderWithEmbedding (encoders/rnn_encoders.py:320-470: one bidirectional LSTM layer, then
+  unidirectional layers, residual connections from the third layer on) at widths the device's recurrent kernels
+  take — embedding 64, 64 units, three layers, a ragged batch of 4 x 12: what tests/test_ref_exec_nmt_gpu.py holds
+  the HIP encoder against (outputs and every variable's gradient)."""
+  return _nmt_encoder(seed, 4, 12, 40, 64, 64, {"gnmt_like": NMT_ENC_CASES["gnmt_like"]}, [12, 5, 9, 7])
+
+
+def _nmt_encoder(seed, B, S, V, E, H, cases, lens):
   out = {"dims": np.array([B, S, V, E, H], np.int32)}
-  for case, cfg in NMT_ENC_CASES.items():
+  for case, cfg in cases.items():
     tf, imp = _install()
     tf.reset_default_graph()
     tf.set_random_seed(seed)
     Enc = getattr(imp("open_seq2seq.encoders.rnn_encoders"), cfg["cls"])
     rng = np.random.RandomState(seed)
-    src_len = np.array([7, 3, 5], np.int32)
+    src_len = np.array(lens, np.int32)
     src = rng.randint(3, V, size=(B, S)).astype(np.int32)
     for b in range(B):
       src[b, src_len[b]:] = 0
@@ -1464,7 +1476,7 @@ def frontend():
 
 
 GENERATORS = {"transformer": transformer, "transformer_d512": transformer_d512, "tdnn": tdnn,
-              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_infer_dev": tacotron_infer_dev, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam, "transformer_infer_d512": transformer_infer_d512}
+              "tdnn_wide": tdnn_wide, "optim": optim, "train_op": train_op, "ds2": ds2, "nmt_decoder": nmt_decoder, "nmt_encoder": nmt_encoder, "nmt_encoder_dev": nmt_encoder_dev, "tacotron_decoder": tacotron_decoder, "t2s_loss": t2s_loss, "tacotron_infer": tacotron_infer, "tacotron_infer_dev": tacotron_infer_dev, "tacotron_encoder": tacotron_encoder, "beam_search": beam_search, "transformer_infer": transformer_infer, "nmt_full": nmt_full, "tacotron_full": tacotron_full, "ds2_full": ds2_full, "frontend": frontend, "nmt_beam": nmt_beam, "transformer_infer_d512": transformer_infer_d512}
 
 
 def generate(name):

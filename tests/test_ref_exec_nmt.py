@@ -67,13 +67,15 @@ def test_oracle_reproduces_the_reference_nmt_decoder(case):
   print("%s: worst gradient rel-L2 vs the reference's code %.2e" % (case, worst))
 
 
-@pytest.mark.parametrize("case", sorted(rx.gen.NMT_ENC_CASES))
-def test_oracle_reproduces_the_reference_nmt_encoders(case):
+@pytest.mark.parametrize("case,fixture", [(c, "nmt_encoder") for c in sorted(rx.gen.NMT_ENC_CASES)] +
+                         [("gnmt_like", "nmt_encoder_dev")])
+def test_oracle_reproduces_the_reference_nmt_encoders(case, fixture):
   """BidirectionalRNNEncoderWithEmbedding / GNMTLikeEncoderWithEmbedding (encoders/rnn_encoders.py:221-305, 380-470)
   executed from the reference's file: embedding lookup, stacks of single_cell LSTM cells, bidirectional_dynamic_rnn with
   sequence lengths (outputs zero past each length, the backward direction reversed within each length), the
-  unidirectional upper layers with ResidualWrapper from the second one on. Outputs 1e-5, gradients 1e-4."""
-  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_nmt_encoder.npz")))
+  unidirectional upper layers with ResidualWrapper from the second one on. Outputs 1e-5, gradients 1e-4. Fixture
+  nmt_encoder_dev: the GNMT-like encoder at the widths the device test runs at (embedding 64, 64 units, 4 x 12)."""
+  d = dict(np.load(os.path.join(HERE, "golden", "ref_exec_%s.npz" % fixture)))
   B, S, V, E, H = [int(v) for v in d["dims"]]
   names = [str(n) for n in d[case + "/var_names"]]
   leaf = {n: torch.from_numpy(d["%s/var/%s" % (case, n)].copy()).requires_grad_(True) for n in names}
@@ -108,5 +110,5 @@ def test_oracle_reproduces_the_reference_nmt_encoders(case):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/open_seq2seq"), reason="reference checkout not present")
 def test_generator_reproduces_the_committed_fixture():
   r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_ref_exec.py"), "--check", "nmt_decoder",
-                      "nmt_encoder"], capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0 and r.stdout.count("reproduced") == 2, r.stdout + r.stderr
+                      "nmt_encoder", "nmt_encoder_dev"], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and r.stdout.count("reproduced") == 3, r.stdout + r.stderr
