@@ -745,7 +745,7 @@ def bench_frontend(dev, batch_size, seed=1234, reps=20):
   """The log-mel front end (get_speech_features_librosa, speech_utils.py:322-441) as
   its own timed stage: int16 PCM of the bench batch's durations resident in HBM -> normalised
   bf16 features [B, Tpad, 64]. Algorithmic bytes = PCM read once + features written once (+ the
-  fp32 pass of the per-feature normalisation). At the bench batch (B = 32: 31 MB, three launches)
+  fp32 pass of the per-feature normalisation). At the bench batch (B = 32: 31 MB, four launches since round 6)
   the stage is launch-/latency-bound; `saturated` times the same kernels on 16 bench batches in one
   call (the kernels' rate when the chip is full: ~56 kFLOP of fp32 FFT / mel work per frame make
   the frames kernel VALU-bound, not HBM-bound)."""
@@ -788,8 +788,10 @@ def bench_frontend(dev, batch_size, seed=1234, reps=20):
                       "unit": "GB/s", "frac": algo / (ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic,
                       "traffic_source": traffic_src, "traffic_unit": "HBM bytes per batch (all launches of the stage)",
                       "algorithmic_bytes": algo,
-                      "note": "launch-bound at the bench batch (3 launches, 31 MB); see `saturated`"}}
+                      "note": "launch-bound at the bench batch (4 launches, 31 MB); see `saturated`"}}
   try:
+    if os.environ.get("OS2S_FRONTEND_NO_SATURATED"):      # the PMC pass counts the bench batch alone (tools/pmc_frontend.sh)
+      raise RuntimeError("skipped (OS2S_FRONTEND_NO_SATURATED)")
     ms16, nf16, _, algo16 = run(16 * batch_size)
     out["saturated"] = {"batch": 16 * batch_size, "value": nf16 / (ms16 * 1e-3), "unit": "frames/sec",
                         "ms_per_call": ms16, "hbm_GBps": algo16 / (ms16 * 1e-3) / 1e9,

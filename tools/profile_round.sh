@@ -125,8 +125,10 @@ TP="python bench.py --only-transformer --steps 2 --warmup 1"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/tf -o c -- $TP > $OUT/tf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/tw -o c -- $TP > $OUT/tw.log 2>&1
 FP="python bench.py --only-frontend"
+export OS2S_FRONTEND_NO_SATURATED=1     # the bench batch only: 23 calls (3 warm-up + 20 timed)
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/ff -o c -- $FP > $OUT/ff.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/fw -o c -- $FP > $OUT/fw.log 2>&1
+unset OS2S_FRONTEND_NO_SATURATED
 python - <<PY
 import csv, glob, json, collections
 def collect(sub, match):
@@ -144,16 +146,16 @@ if fn["gemm_pp_kernel"]:
     json.dump({"command": "$TP", "kernel": "gemm_pp_kernel", "launches": fn["gemm_pp_kernel"], "FETCH_SIZE_KB_per_launch_raw": fk,
                "WRITE_SIZE_KB_per_launch_raw": wk, "correction": corr, "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0},
               open("$OUT/${TAG}_pmc_transformer_traffic.json", "w"), indent=1)
-names = ["logmel_frames_kernel", "logmel_normalize_kernel", "absmax_kernel"]
+names = ["logmel_frames_kernel", "logmel_normalize_kernel", "absmax_kernel", "logmel_stats_kernel"]
 f, fn = collect("ff", names); w, wn = collect("fw", names)
 if fn[names[0]]:
-    # bench_frontend runs (3 warm-up + 20 timed) x 2 batch sizes; the per-BATCH figure is taken at the bench batch: the
-    # smaller half of the launches of every kernel
+    # bench_frontend at the bench batch only (OS2S_FRONTEND_NO_SATURATED): 3 warm-up + 20 timed calls
     calls = fn[names[0]]
-    per = {k: {"launches": fn[k], "FETCH_SIZE_KB_total": f[k], "WRITE_SIZE_KB_total": w[k]} for k in names if fn[k]}
-    json.dump({"command": "$FP", "kernels": per, "correction": corr,
-               "note": "totals over both batch sizes of bench_frontend (B = 32: 23 calls, B = 512: 23 calls); bytes per call scale with the batch, so hbm_bytes_per_launch = total / (23 x 17) is the B = 32 batch",
-               "hbm_bytes_per_launch": sum((2.0 * f[k] + w[k]) for k in names) * 1024.0 / (23.0 * 17.0)},
+    per = {k: {"launches": fn[k], "FETCH_SIZE_KB_total": f[k], "WRITE_SIZE_KB_total": w[k],
+               "hbm_bytes_per_batch": (2.0 * f[k] + w[k]) * 1024.0 / max(calls, 1)} for k in names if fn[k]}
+    json.dump({"command": "OS2S_FRONTEND_NO_SATURATED=1 $FP", "kernels": per, "correction": corr,
+               "note": "B = 32 bench batch, %d calls of the stage; hbm_bytes_per_launch = all kernels of ONE call" % calls,
+               "hbm_bytes_per_launch": sum((2.0 * f[k] + w[k]) for k in names) * 1024.0 / max(calls, 1)},
               open("$OUT/${TAG}_pmc_frontend_traffic.json", "w"), indent=1)
 PY
 cp $OUT/${TAG}_pmc_transformer_traffic.json $OUT/${TAG}_pmc_frontend_traffic.json profiles/ 2>/dev/null
