@@ -233,7 +233,7 @@ class Tape(object):
     join_side_streams()
 
   # ---- deferred (grouped) weight gradients -----------------------------------------------------
-  def defer_wgrad(self, param, item, group=None, unit_budget=None):
+  def defer_wgrad(self, param, item, group=None, unit_budget=None, side=True):
     """A Dense weight gradient too small to fill the chip alone is held back until `group` of them — or, with
     `unit_budget`, enough of them to cover that many 256 x 256 output tiles — can go out in one launch
     (capi.gemm_wgrad_grouped: at most 16 per launch). Until then `param` does not count as final for the
@@ -244,6 +244,7 @@ class Tape(object):
     if self._deferred and self._deferred[0][1]["x"].shape[0] != item["x"].shape[0]:
       self.flush_deferred()
     self._deferred.append((param, item))
+    self._deferred_side = side        # False: the grouped launch stays on the current stream (serial profiles)
     if self._pending is not None and id(param) in self._pending:
       self._pending[id(param)] += 1
     if unit_budget is not None:
@@ -284,7 +285,10 @@ class Tape(object):
     if not self._deferred:
       return
     items = [it for _, it in self._deferred]
-    with on_side_stream(items[0]["x"].device, *([it["x"] for it in items] + [it["dy"] for it in items])):
+    if getattr(self, "_deferred_side", True):
+      with on_side_stream(items[0]["x"].device, *([it["x"] for it in items] + [it["dy"] for it in items])):
+        capi.gemm_wgrad_grouped(items, accumulate=True)
+    else:
       capi.gemm_wgrad_grouped(items, accumulate=True)
     if self._pending is not None:
       for p, _ in self._deferred:

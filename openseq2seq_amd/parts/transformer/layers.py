@@ -153,9 +153,10 @@ class Dense(object):
       # stream by default (OS2S_DENSE_WGRAD_STREAM): with the in-tree kernels it fills the half of
       # the chip a 132-tile data-gradient GEMM leaves idle, 22.1 -> 20.3 ms/step over 20 AND over
       # 300 steps (with the round-1 vendor GEMMs the same move lost 11 % at the power limit)
-      if DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _groupable_wgrad(lin, dz) and current_tape() is not None:
+      if GROUP_SMALL_WGRAD and _groupable_wgrad(lin, dz) and current_tape() is not None:
+        # (OS2S_DENSE_WGRAD_STREAM=0 keeps the grouped launch on the main stream: the serial profiles)
         current_tape().defer_wgrad(lin.kernel, dict(x=x.data, dy=dz, dw=lin.kernel.grad.view(lin.cout, lin.cin)),
-                                   unit_budget=WGRAD_UNIT_BUDGET)
+                                   unit_budget=WGRAD_UNIT_BUDGET, side=DENSE_WGRAD_STREAM)
       elif DENSE_WGRAD_STREAM and GROUP_SMALL_WGRAD and _small_wgrad(lin, dz) and current_tape() is not None:
         # 16 output tiles: three of these go out as ONE launch (Tape.defer_wgrad)
         current_tape().defer_wgrad(lin.kernel, dict(x=x.data, dy=dz, dw=lin.kernel.grad.view(lin.cout, lin.cin)))
