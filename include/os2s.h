@@ -190,6 +190,8 @@ int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
  *     stream with an ingredient removed (1 LDS-DMA, 2 barrier, 4 transpose reads, 8 MFMAs; results are wrong then)
  *   conv1d_wgrad.split: > 0 forces the reduction split factor of the ping-pong kernels (-1 = cost model)
  *   gemm_nt.split: f > 0 forces the tail split factor of os2s_gemm_nt*, 0 disables the split, < 0 = cost model
+ *   gemm_nt.tile: 0 (default) = by shape, 256 = always the 256 x 256 tile, 160 = the 160-row x 256-column tile
+ *     (eight waves over the columns; bit-identical results) whenever it is legal (no per-window statistics)
  *   depthwise.variant: 0 = the generic depthwise kernels only, < 0 = by shape
  *   bn.act_fwd.groups, bn.act_fwd.rows, bn.act_bwd_reduce.groups, bn.act_bwd_reduce.rows, bn.bwd_apply.groups,
  *     bn.bwd_apply.rows: tiling of the three BatchNorm kernels (8-channel groups per workgroup 8 .. 256, rows

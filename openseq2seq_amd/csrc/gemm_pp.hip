@@ -270,6 +270,155 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(ConvArgs p, int gm, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6: a SHORTER tile for the launches the 256-row tile cannot spread over the chip. The Transformer's batch is
+// 8 192 +- 222 packed tokens: 33 row blocks of 256, so every N = 1024 product — 90 of the 129 GEMM launches of a
+// Transformer-big step — is 132 tiles on 256 CUs. 160 rows (five MFMA row blocks) make it 52 x 4 = 208 tiles, still one
+// round. Five row blocks do not split over the two wave groups of the tile above, so the 8 waves split the COLUMNS
+// instead: wave w owns all RB * 32 rows x columns [32 w, 32 w + 32) (RB accumulator blocks), group A = waves 0-3,
+// group B = waves 4-7; wave w and w + 4 share a SIMD and alternate, slot by slot, between the RB * 4 MFMAs of a 64-deep
+// step (COMPUTE) and its 4 * (RB + 1) fragment reads + ALL of its LDS-DMA (LOAD) — two slots per step, not four:
+//
+//   LOAD(s)    : W fragments (4) and A fragments (RB * 4) of step s; issue this wave's share of step s + 2 (W: 4
+//                instructions, A: 3 or 2) into ring slot (s + 2) % 3 — last read a step ago by the other group,
+//                which finished before the previous barrier; wait until only these stay in flight (this wave's
+//                share of step s + 1 has landed: the other group reads it two barriers later)
+//   COMPUTE(s) : RB * 4 MFMA 32x32x16
+//
+// Rings of three for both operands: 3 x (RB * 4 KB) + 3 x 32 KB = 156 KB at RB = 5. The reduction runs in the same
+// order as in the 256-row tile: results are bit-identical to it. One round of tiles only (no tail split): the
+// launcher takes this tile when the 256-row tiling would leave more than 40 % of the CUs without a tile.
+// ---------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(512, 2) void gemm_pp_cols_kernel(ConvArgs p, int mblocks) {
+  constexpr int BMT = RB * 32, BN = 256;
+  constexpr int ATILE = BMT * 128, WTILE = 256 * 128;     // bytes of one 64-deep operand tile
+  constexpr int AINSTR = RB * 4;                          // LDS-DMA instructions per A tile (8 rows x 128 B each)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;
+  const int U = mblocks * p.NT;
+  if ((int)blockIdx.x >= U) return;
+  // consecutive ranks = the column tiles of one row block: behind one XCD's L2 (contiguous rank range per XCD)
+  int rank;
+  {
+    const int q = U >> 3, r = U & 7, x = blockIdx.x & 7;
+    rank = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+  }
+  const int m_blk = rank / p.NT, n_idx = rank - m_blk * p.NT;
+  const int m0 = m_blk * BMT, n0 = n_idx * BN;
+  char* const abuf0 = smem;
+  char* const wbuf0 = smem + 3 * ATILE;
+  const bf16_t* const a0 = p.x + (long long)m0 * p.x_st;
+  __amdgpu_buffer_rsrc_t ars;
+  {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)a0);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)a0 >> 32));
+    const long long ab = (long long)(p.Tout - m0) * p.x_st * 2;
+    const long long cl = ab < 0 ? 0 : (ab < 0x7fffffffll ? ab : 0x7fffffffll);
+    ars = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0,
+                                            __builtin_amdgcn_readfirstlane((int)cl), 0x00020000);
+  }
+  const long long w_bytes = (long long)(p.Cout - n0) * p.Cin * 2;
+  const unsigned long long wbs = (unsigned long long)p.w + (unsigned long long)n0 * (unsigned long long)p.Cin * 2ull;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)wbs, 0, (int)(w_bytes < 0x7fffffffll ? w_bytes : 0x7fffffffll), 0x00020000);
+  // this wave's DMA instructions: W 4 (of 32), A up to 3 (of RB * 4): instruction i covers tile rows 8 i .. 8 i + 7
+  int av[3], wv[4];
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) {
+    const int wrow = (pi * 8 + wid) * 8 + (lane >> 3), jj = lane & 7;
+    wv[pi] = (wrow * p.Cin + (jj ^ ((wrow >> 1) & 7)) * 8) * 2;
+    if (pi < 3) {
+      const int arow = (pi * 8 + wid) * 8 + (lane >> 3);
+      av[pi] = (arow * (int)p.x_st + (jj ^ ((arow >> 1) & 7)) * 8) * 2;
+    }
+  }
+  const bool a3 = 16 + wid < AINSTR;                      // waves 0-3 carry a third A instruction at RB = 5
+  auto stage = [&](int kt, int buf) {
+    const int soff = __builtin_amdgcn_readfirstlane(kt * 128);
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(wbuf0 + buf * WTILE + (pi * 8 + wid) * 1024), 16,
+          wv[pi], soff, 0, 0);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          ars, (__attribute__((address_space(3))) void*)(abuf0 + buf * ATILE + (pi * 8 + wid) * 1024), 16,
+          av[pi], soff, 0, 0);
+    if (a3)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          ars, (__attribute__((address_space(3))) void*)(abuf0 + buf * ATILE + (16 + wid) * 1024), 16,
+          av[2], soff, 0, 0);
+  };
+  static_assert(AINSTR > 16 && AINSTR <= 24, "the A tile takes 2 - 3 instructions per wave");
+
+  f32x16 acc[1][RB];
+#pragma unroll
+  for (int im = 0; im < RB; ++im)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][im][e] = 0.f;
+
+  const int nsteps = p.nchunks;
+  {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int sw = ((kk * 2 + lhi) ^ ((l31 >> 1) & 7)) << 4;
+      aoff[kk] = l31 * 128 + sw;
+      woff[kk] = (wid * 32 + l31) * 128 + sw;
+    }
+    stage(0, 0);
+    if (nsteps > 1) {
+      stage(1, 1);
+      if (a3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    gpp_barrier();
+    if (grp) gpp_barrier();                              // group B runs one slot behind group A
+    int bi = 0;                                          // ring slot of the current step
+    for (int s = 0; s < nsteps; ++s) {
+      const char* const as = abuf0 + bi * ATILE;
+      const char* const ws = wbuf0 + bi * WTILE;
+      bf16x8 wf[4], af[RB][4];
+      // ---- LOAD(s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        wf[kk] = *reinterpret_cast<const bf16x8*>(ws + woff[kk]);
+#pragma unroll
+        for (int im = 0; im < RB; ++im)
+          af[im][kk] = *reinterpret_cast<const bf16x8*>(as + aoff[kk] + im * 4096);
+      }
+      if (s + 2 < nsteps) {
+        int b2 = bi + 2;
+        b2 = b2 >= 3 ? b2 - 3 : b2;
+        stage(s + 2, b2);
+        if (a3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bi = bi + 1 >= 3 ? 0 : bi + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      gpp_barrier();
+      // ---- COMPUTE(s)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int im = 0; im < RB; ++im)
+          acc[0][im] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], af[im][kk], acc[0][im], 0, 0, 0);
+      gpp_barrier();
+    }
+    if (!grp) gpp_barrier();
+  }
+  __syncthreads();
+  const int wb[1] = {0}, wt0[1] = {m0}, wmid[1] = {m_blk};
+  conv_epilogue<BMT, BN, 1, 8, 1>(p, acc, smem, tid, lane, wid, wmid, n0, wb, wt0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // 1x1 convolutions of a ragged batch on the same tile: up to kMaxConvGroups independent
 // convolutions with the same batch geometry and lengths (the dense-residual branches of a Jasper
 // block end and their data gradients, conv_blocks.py:78-85; a single group = a plain K = 1 layer)
@@ -427,6 +576,7 @@ int launch_conv1x1_pp(hipStream_t stream, ConvArgs a, ConvGroupTable gt) {
 }  // namespace os2s
 
 static int g_gemm_split = -1;
+static int g_gemm_tile = 0;        // gemm_nt.tile: 0 = by shape, 256 = the 256-row tile always, 160 = the 160-row tile whenever legal
 
 // C[M,N] = A[M,K] . W[N,K]^T with the fused epilogue C = residual + dropout(act(. + bias)),
 // optional accumulation into C (bf16) and fp32 output. lda / ldc / residual row stride in
@@ -481,6 +631,28 @@ static int gemm_nt_impl(os2s_stream_t stream, const uint16_t* A, long long lda, 
   });
   if (attr_rc != hipSuccess) return OS2S_ERR_LAUNCH;
   a.ncu = ncu;
+  // ---- the 160-row tile (gemm_pp_cols_kernel<5>): when the 256-row tiling is ONE round that leaves more than 40 % of
+  // the CUs without a tile and 160-row tiles still fit one round; per-window statistics keep the 128-row windows
+  {
+    const int mb160 = ceil_div(M, 160);
+    const int u160 = mb160 * a.NT, u256 = mblocks * a.NT;
+    // (not for launches of a few tiles — nothing to gain — and not while a test forces the tail split of the 256-row tile)
+    const bool fits = !stats && u160 <= ncu && u256 * 10 <= ncu * 6 && u160 > u256 && u256 >= 32 && g_gemm_split <= 0;
+    if (g_gemm_tile == 160 ? (!stats && u160 <= 4 * ncu) : (g_gemm_tile == 0 && fits)) {
+      static std::once_flag once5;
+      static hipError_t rc5 = hipSuccess;
+      std::call_once(once5, [] {
+        rc5 = hipFuncSetAttribute((const void*)gemm_pp_cols_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+      });
+      if (rc5 != hipSuccess) return OS2S_ERR_LAUNCH;
+      const size_t main5 = (size_t)3 * 160 * 128 + (size_t)3 * 256 * 128;
+      const size_t epi5 = conv_epilogue_lds_bytes<160, 256, 1, 512>();
+      OS2S_LAUNCH(gemm_pp_cols_kernel<5>, dim3(ceil_div(u160, 8) * 8), dim3(512), main5 > epi5 ? main5 : epi5,
+                  (hipStream_t)stream, a, mb160);
+      return OS2S_OK;
+    }
+  }
   // ---- tail split (decided here: nothing about the launch is only known on the device) ---------
   const int U = mblocks * a.NT;
   const int r = U % ncu;
@@ -540,3 +712,5 @@ extern "C" int os2s_gemm_nt(os2s_stream_t stream, const uint16_t* A, long long l
 
 // os2s_set_option("gemm_nt.split", f): > 0 forces the tail split factor, 0 disables the split, < 0 = cost model
 static os2s::OptionReg r_gemm_split("gemm_nt.split", [](double v) { g_gemm_split = (int)v; });
+// os2s_set_option("gemm_nt.tile", t): 0 = by shape, 256 = always the 256 x 256 tile, 160 = the 160 x 256 tile whenever legal
+static os2s::OptionReg r_gemm_tile("gemm_nt.tile", [](double v) { g_gemm_tile = (int)v; });

@@ -161,3 +161,47 @@ def test_gemm_wgrad_grouped(cuda):
     single = torch.zeros_like(a["dw"])
     capi.gemm_wgrad(it["x"], it["dy"], single, accumulate=True)
     torch.testing.assert_close(a["dw"], single, rtol=2e-3, atol=2e-3 * float(single.abs().max()))
+
+
+@pytest.mark.parametrize("M", [1, 31, 159, 160, 161, 319, 320, 321, 479, 480, 481, 8300, 8192, 4095])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (256, 64), (264, 4096), (1024, 3072)])
+def test_gemm_nt_160_row_tile_is_bit_identical_to_the_256_row_tile(cuda, M, N, K):
+  """gemm_pp_cols_kernel<5> (option gemm_nt.tile 160: 160 rows x 256 columns, the eight waves over the columns, two
+  slots per step, rings of three) against the 256 x 256 tile at ragged M around every multiple of 160 and at the
+  Transformer-big batch: the reduction runs in the same order, so EVERY path of the shared epilogue — plain bf16, fp32
+  output, bias + ReLU + dropout, residual, accumulate, the masked data gradient — must agree bit for bit; plus the
+  fp32 reference, and what the default (by shape) picks for the launch."""
+  from openseq2seq_amd import capi, _lib
+  if M * N * K > 8300 * 1024 * 3072 // 2 and (N, K) == (264, 4096):
+    pytest.skip("covered by the other shapes")
+  g = torch.Generator().manual_seed(M * 7 + N + K)
+  a = _bf(torch.randn(M, K, generator=g)).to(cuda)
+  w = _bf(torch.randn(N, K, generator=g) * K ** -0.5).to(cuda)
+  bias = torch.randn(N, generator=g).to(cuda)
+  res = _bf(torch.randn(M, N, generator=g)).to(cuda)
+  base = _bf(torch.randn(M, N, generator=g)).to(cuda)
+  mask = _bf(torch.relu(torch.randn(M, N, generator=g))).to(cuda)
+
+  def run_all():
+    acc = base.clone()
+    capi.gemm_nt(a, w, out=acc, accumulate=True)
+    return [capi.gemm_nt(a, w), capi.gemm_nt(a, w, out_f32=True), capi.gemm_nt(a, w, bias=bias, act=1, keep_prob=0.8, seed=5),
+            capi.gemm_nt(a, w, bias=bias, residual=res), acc, capi.gemm_nt_mask(a, w, mask, 1.25)[0]]
+  try:
+    _lib.set_option("gemm_nt.split", 0)        # (a K-split tail of the 256-row tile sums in another order)
+    _lib.set_option("gemm_nt.tile", 256)
+    want = run_all()
+    _lib.set_option("gemm_nt.tile", 160)
+    got = run_all()
+    _lib.set_option("gemm_nt.tile", 0)
+    auto = capi.gemm_nt(a, w)
+    torch.cuda.synchronize()
+  finally:
+    _lib.set_option("gemm_nt.tile", 0)
+    _lib.set_option("gemm_nt.split", -1)
+  for i, (x, y) in enumerate(zip(got, want)):
+    assert torch.equal(x, y), (i, float((x.float() - y.float()).abs().max()))
+  assert torch.equal(auto, want[0])
+  ref = a.float() @ w.float().t()
+  scale = float(ref.pow(2).mean().sqrt()) + 1e-6
+  torch.testing.assert_close(got[1], ref, rtol=2e-3, atol=2e-3 * scale)
