@@ -181,6 +181,9 @@ int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
  *   conv1x1.variant: the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers): 0 (default) and 1 =
  *     lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows whenever its envelope allows
  *     (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as a measured alternative
+ *   conv1x1.order: os2s_conv1x1_fwd_grouped's workgroup order: 1 (default) = the column tiles of one row tile run
+ *     behind the same XCD at the same time (the activations are fetched from HBM once, not once per column tile;
+ *     a 1x1 weight matrix fits every L2), 0 = all row tiles of a column tile first (rounds 1 - 5)
  *   conv1d_wgrad.variant: 0 = lockstep kernel, 1 = ping-pong, 2 = K = 1 ping-pong, 3 = one wave per SIMD with 16
  *     accumulator blocks per wave and a hand-written instruction stream (stride 1, K >= 2, dilation <= 5, channel
  *     counts multiples of 128; opt-in: measured slower than the ping-pong kernel), -1 = by shape;
@@ -1203,6 +1206,78 @@ int os2s_sample_norm_bwd(os2s_stream_t stream, const uint16_t* dz, const uint16_
  * the upsampled tensor (os2s_conv1d_fwd on the tap-flipped weights). */
 int os2s_upsample_rows_bf16(os2s_stream_t stream, const uint16_t* x, int B, int T, int C, int stride, int Tup,
                             uint16_t* y);
+
+/* ------------------------------------------------------------------------
+ * Dense-residual block ends without branch tensors (csrc/dense_residual.hip).
+ * conv_bn_res_bn_actv (parts/cnns/conv_blocks.py:61-168) adds, at the end of block k, one
+ * tf.layers.conv1d(kernel_size=1) + tf.layers.batch_normalization per dense-residual input (the inputs of
+ * blocks 0 .. k: encoders/tdnn_encoder.py:188-192) to the main branch. Each branch output is a linear image of
+ * its input r_i, so its batch statistics follow from the input's column sums s_i and Gram matrix
+ * G_i = r_i^T r_i, the sum of all branches is ONE GEMM of the channel-concatenated inputs with the BN-scaled,
+ * stacked kernels, and every gradient follows from P_k = [r_0 .. r_k]^T dz_k (formulas: the header of
+ * csrc/dense_residual.hip). These entry points are the small kernels between the GEMMs; the GEMMs themselves
+ * are os2s_conv1x1_cat_fwd, os2s_conv1x1_wgrad_grouped_ws, os2s_conv1x1_fwd_grouped_ex and os2s_gemm_nt_ws.
+ * Results equal the branch-by-branch evaluation up to rounding (no bf16 branch tensor is rounded on the way).
+ * ---------------------------------------------------------------------- */
+/* dst[b, t, 0:C] = t < lens[b] ? src[b, t, 0:C] : 0 for a [B, T, C] bf16 tensor into a channel slice of a wider
+ * one (row strides in elements, multiples of 8; lens NULL = every row); colsum_partial (or NULL):
+ * [os2s_dres_copy_num_parts(B, T), C] fp32 column sums of the copied rows per 128-row block. */
+int os2s_dres_copy_num_parts(int B, int T);
+int os2s_dres_copy_cols(os2s_stream_t stream, const uint16_t* src, long long src_row_stride, uint16_t* dst,
+                        long long dst_row_stride, const int32_t* lens, int B, int T, int C, float* colsum_partial);
+/* s[c] = sum of the partials, m = s / count, and the covariance C = gram / count - m m^T as a bf16 pair:
+ * chl [2C, C]: rows 0 .. C-1 = bf16(C), rows C .. 2C-1 = bf16(C - hi). gram [C, C] fp32 = r^T r. */
+int os2s_dres_cov(os2s_stream_t stream, const float* colsum_partial, int nparts, const float* gram, int C,
+                  long long count, float* s, float* m, uint16_t* chl);
+/* One residual branch of a block end. Arrays of these live in DEVICE memory (built once per model: every pointer
+ * is a parameter, a gradient or a persistent weight-sized buffer). */
+typedef struct {
+  const uint16_t* w;       /* [Cout, c] bf16: the branch's 1x1 kernel (device layout [1, Cout, c]) */
+  const float* tt;         /* [Cout, 2c] fp32: w . [C_hi | C_lo]^T of the branch's input (training) */
+  const float* m;          /* [c] channel means of the input (training) */
+  const float* s;          /* [c] channel sums of the input (backward) */
+  const float* gamma;      /* [Cout] */
+  const float* beta;       /* [Cout] */
+  float* moving_mean;      /* [Cout] updated in training, read otherwise */
+  float* moving_var;       /* [Cout] */
+  float* mean;             /* [Cout] batch statistics: written by os2s_dres_bn_fwd, read by os2s_dres_bn_bwd */
+  float* rstd;             /* [Cout] */
+  float* dgamma;           /* [Cout] accumulated into */
+  float* dbeta;            /* [Cout] accumulated into */
+  float* dw;               /* [Cout, c] fp32 kernel gradient, accumulated into */
+  uint16_t* wd1;           /* the input's stacked transposed matrices, rows = the input's channels (+ 8 for wd2), */
+  uint16_t* wd2;           /*   row stride ld, already offset to this block end's columns: wd1[a][co] = w d1,     */
+  uint16_t* wt;            /*   wd2[a][co] = -w d2 (row c: the constant-row coefficients), wt[a][co] = w          */
+  long long ld;
+  int c, koff;             /* input channels (multiple of 64); first channel of the input in the concatenation */
+} os2s_dres_seg_t;
+/* Forward of block end k over its nseg <= 16 branches (ascending koff): batch (training = 1: from m and tt; the
+ * moving statistics are updated with TF's conventions, see os2s_bn_finalize) or moving statistics -> mean / rstd,
+ * wp [Cout, Kk] = the kernels scaled by gamma rstd, stacked along the concatenated input channels, and
+ * shift [Cout] = sum over the branches of beta - mean gamma rstd. count = B * T. */
+int os2s_dres_bn_fwd(os2s_stream_t stream, const os2s_dres_seg_t* segs_dev, int nseg, int Cout, int Kk,
+                     uint16_t* wp, float* shift, long long count, float eps, float momentum, int training);
+/* Backward of block end k given P [Cout, Kk] fp32 = dz^T [r_0 .. r_k] and mean_dz [Cout] = sum_rows dz / count:
+ * dgamma, dbeta, dw of every branch (accumulated) and the branch's columns of wd1 / wd2 / wt. coef: scratch of
+ * nseg * 4 * Cout floats. Kk and every c multiples of 64, Cout a multiple of 8. Deterministic. */
+int os2s_dres_bn_bwd(os2s_stream_t stream, const os2s_dres_seg_t* segs_dev, int nseg, int Cout, int Kk,
+                     const float* P, const float* mean_dz, long long count, float* coef);
+/* 1x1 convolution between channel slices of wider tensors over a ragged batch:
+ *   y[b, t, 0:Cout] (+)= x[b, t, 0:Cin] . w^T (+ bias),  x rows x_row_stride apart, y rows y_row_stride apart
+ * (elements, multiples of 8; batch strides = T rows), w [Cout, Cin] bf16 contiguous. in_len / out_len as in
+ * os2s_conv1d_fwd_ws. The sum of a block end's residual branches (x = the concatenated block inputs, w = wp of
+ * os2s_dres_bn_fwd) and the data gradients of a dense-residual input (x = the concatenated dz of the block ends
+ * that read it, w = wd1). Runs on the 256 x 256 ping-pong tile over the live windows when Cin % 64 == 0 and
+ * B <= 64, else on the lockstep tile. Workspace: os2s_conv1d_workspace_bytes() (contract of os2s_conv1d_fwd_ws). */
+int os2s_conv1x1_cat_fwd(os2s_stream_t stream, const uint16_t* x, long long x_row_stride, const uint16_t* w,
+                         uint16_t* y, long long y_row_stride, const int32_t* in_len, const int32_t* out_len,
+                         const float* bias, int B, int T, int Cin, int Cout, int accumulate, void* workspace,
+                         size_t workspace_bytes);
+/* os2s_conv1x1_fwd_grouped with fp32 outputs when out_f32 = 1 (y_i [B, T, Cout_i] fp32; no statistics): the
+ * products w . [C_hi | C_lo]^T of a block end's branches in one launch (x_i = the kernel [1, Cout, c_i] read as
+ * Cout rows, w_i = chl_i [2 c_i, c_i]). */
+int os2s_conv1x1_fwd_grouped_ex(os2s_stream_t stream, const os2s_conv_group_t* groups, int ngroups,
+                                const int32_t* in_len, const int32_t* out_len, int B, int T, int out_f32);
 
 #ifdef __cplusplus
 }

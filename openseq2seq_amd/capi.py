@@ -308,13 +308,15 @@ class _ConvGroup(_lib.ctypes.Structure):
               ("Cin", c_int), ("Cout", c_int), ("accumulate", c_int)]
 
 
-def conv1x1_fwd_grouped(items, in_len=None, out_len=None):
+def conv1x1_fwd_grouped(items, in_len=None, out_len=None, out_f32=False):
   """items: list of dict(x [B,T,Cin] bf16, w [1,Cout,Cin] bf16, y [B,T,Cout] bf16, stats or None,
   accumulate) — up to 16 independent 1x1 convolutions over the same (B, T, lengths) in ONE
-  launch (os2s_conv1x1_fwd_grouped); longer lists are cut into several launches."""
+  launch (os2s_conv1x1_fwd_grouped); longer lists are cut into several launches. out_f32: every y is
+  fp32 (os2s_conv1x1_fwd_grouped_ex; no statistics)."""
   B, T, _ = items[0]["x"].shape
-  f = _fn("os2s_conv1x1_fwd_grouped",
-          (c_void_p, _lib.ctypes.POINTER(_ConvGroup), c_int, c_void_p, c_void_p, c_int, c_int))
+  ydt = torch.float32 if out_f32 else torch.bfloat16
+  f = _fn("os2s_conv1x1_fwd_grouped_ex",
+          (c_void_p, _lib.ctypes.POINTER(_ConvGroup), c_int, c_void_p, c_void_p, c_int, c_int, c_int))
   outs = [it["y"].data_ptr() for it in items]
   assert len(set(outs)) == len(outs), "two groups of one launch must not write the same tensor"
   for i0 in range(0, len(items), 16):
@@ -324,11 +326,101 @@ def conv1x1_fwd_grouped(items, in_len=None, out_len=None):
       x, w, y = it["x"], it["w"], it["y"]
       assert x.shape[0] == B and x.shape[1] == T and w.shape[0] == 1 and w.shape[2] == x.shape[2]
       assert tuple(y.shape) == (B, T, w.shape[1]) and x.is_contiguous() and y.is_contiguous()
-      g.x, g.w, g.y = _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16), _ptr(y, torch.bfloat16)
+      g.x, g.w, g.y = _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16), _ptr(y, ydt)
       g.stats = _ptr(it.get("stats"), torch.float32, True)
       g.Cin, g.Cout, g.accumulate = x.shape[2], w.shape[1], int(bool(it.get("accumulate", False)))
     _lib.check(f(_stream(), arr, len(part), _ptr(in_len, torch.int32, True),
-                 _ptr(out_len, torch.int32, True), B, T), "os2s_conv1x1_fwd_grouped")
+                 _ptr(out_len, torch.int32, True), B, T, int(bool(out_f32))), "os2s_conv1x1_fwd_grouped_ex")
+
+
+# --------------------------------------------------------------------------
+# Dense-residual block ends without branch tensors (csrc/dense_residual.hip)
+# --------------------------------------------------------------------------
+def _rows_view_ok(t):
+  """[B, T, C] bf16 whose rows are a channel slice of a wider [B, T, W] tensor (or contiguous)."""
+  return t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1) and t.stride(1) % 8 == 0
+
+
+def dres_copy_cols(src, dst, lens=None, want_colsum=False):
+  """dst[b, t, :] = t < lens[b] ? src[b, t, :] : 0 (both [B, T, C] bf16, either may be a channel-slice view);
+  returns the per-block column sums [nparts, C] fp32 when asked."""
+  B, T, C = src.shape
+  assert tuple(dst.shape) == (B, T, C) and _rows_view_ok(src) and _rows_view_ok(dst)
+  assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16
+  part = None
+  if want_colsum:
+    n = int(_fn("os2s_dres_copy_num_parts", (c_int, c_int))(B, T))
+    part = torch.empty((n, C), dtype=torch.float32, device=src.device)
+  f = _fn("os2s_dres_copy_cols", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_void_p))
+  _lib.check(f(_stream(), c_void_p(src.data_ptr()), src.stride(1), c_void_p(dst.data_ptr()), dst.stride(1),
+               _ptr(lens, torch.int32, True), B, T, C, _ptr(part, torch.float32, True)), "os2s_dres_copy_cols")
+  return part
+
+
+def dres_cov(colsum_partial, gram, count, s, m, chl):
+  """s, m [C] fp32 and chl [2C, C] bf16 (covariance hi / lo) from the column-sum partials and gram [C, C] fp32."""
+  nparts, C = colsum_partial.shape
+  assert tuple(gram.shape[-2:]) == (C, C) and chl.numel() == 2 * C * C and s.numel() == C and m.numel() == C
+  f = _fn("os2s_dres_cov", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p, c_void_p, c_void_p))
+  _lib.check(f(_stream(), _ptr(colsum_partial, torch.float32), nparts, _ptr(gram, torch.float32), C, int(count),
+               _ptr(s, torch.float32), _ptr(m, torch.float32), _ptr(chl, torch.bfloat16)), "os2s_dres_cov")
+
+
+class _DresSeg(_lib.ctypes.Structure):
+  _fields_ = [("w", c_void_p), ("tt", c_void_p), ("m", c_void_p), ("s", c_void_p), ("gamma", c_void_p),
+              ("beta", c_void_p), ("moving_mean", c_void_p), ("moving_var", c_void_p), ("mean", c_void_p),
+              ("rstd", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("dw", c_void_p), ("wd1", c_void_p),
+              ("wd2", c_void_p), ("wt", c_void_p), ("ld", c_ll), ("c", c_int), ("koff", c_int)]
+
+
+def dres_seg_table(segs, device):
+  """segs: list of dict with the fields of os2s_dres_seg_t (tensors -> their data pointers; wd1 / wd2 / wt may be
+  views at a column offset). Returns the table as a DEVICE uint8 tensor (the kernels read it from memory)."""
+  import ctypes
+  arr = (_DresSeg * len(segs))()
+  for g, d in zip(arr, segs):
+    for k, _ in _DresSeg._fields_:
+      v = d[k]
+      if k in ("ld", "c", "koff"):
+        setattr(g, k, int(v))
+      else:
+        setattr(g, k, None if v is None else v.data_ptr())
+  raw = bytes(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr)))
+  return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def dres_bn_fwd(table, nseg, Cout, Kk, wp, shift, count, eps, momentum, training):
+  assert wp.numel() == Cout * Kk and shift.numel() == Cout and table.numel() == nseg * _lib.ctypes.sizeof(_DresSeg)
+  f = _fn("os2s_dres_bn_fwd", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_float, c_float,
+                               c_int))
+  _lib.check(f(_stream(), _ptr(table, torch.uint8), nseg, Cout, Kk, _ptr(wp, torch.bfloat16),
+               _ptr(shift, torch.float32), int(count), float(eps), float(momentum), int(bool(training))),
+             "os2s_dres_bn_fwd")
+
+
+def dres_bn_bwd(table, nseg, Cout, Kk, P, mean_dz, count, coef):
+  assert P.numel() == Cout * Kk and mean_dz.numel() == Cout and coef.numel() >= nseg * 4 * Cout
+  f = _fn("os2s_dres_bn_bwd", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p))
+  _lib.check(f(_stream(), _ptr(table, torch.uint8), nseg, Cout, Kk, _ptr(P, torch.float32),
+               _ptr(mean_dz, torch.float32), int(count), _ptr(coef, torch.float32)), "os2s_dres_bn_bwd")
+
+
+def conv1x1_cat_fwd(x, w, y, in_len=None, out_len=None, bias=None, accumulate=False):
+  """y[b,t,:] (+)= x[b,t,:] . w^T (+ bias): x [B,T,Cin], y [B,T,Cout] bf16, either a channel-slice view of a wider
+  tensor; w [Cout, Cin] bf16 contiguous (os2s_conv1x1_cat_fwd)."""
+  B, T, Cin = x.shape
+  Cout = w.shape[-2]
+  assert w.shape[-1] == Cin and w.is_contiguous() and w.numel() == Cout * Cin and w.dtype == torch.bfloat16
+  assert tuple(y.shape) == (B, T, Cout) and _rows_view_ok(x) and _rows_view_ok(y)
+  assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
+  ws = conv1d_workspace(x.device)
+  f = _fn("os2s_conv1x1_cat_fwd", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t))
+  _lib.check(f(_stream(), c_void_p(x.data_ptr()), x.stride(1), c_void_p(w.data_ptr()), c_void_p(y.data_ptr()),
+               y.stride(1), _ptr(in_len, torch.int32, True), _ptr(out_len, torch.int32, True),
+               _ptr(bias, torch.float32, True), B, T, Cin, Cout, int(bool(accumulate)), _ptr(ws), ws.numel()),
+             "os2s_conv1x1_cat_fwd")
+  return y
 
 
 def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,

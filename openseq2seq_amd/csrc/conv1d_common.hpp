@@ -50,6 +50,10 @@ struct ConvArgs {
   float pp_c256 = 1.19f, pp_c2 = 0.90f, pp_c3 = 1.06f;
   int pp_prio = 0;              // experiment: the loading wave of a ping-pong slot runs at s_setprio 2
   float pp_dgrad_pen = 1.f;     // factor on the narrow tiles' cost in data-gradient launches (out_len given)
+  // lockstep kernel: 0 = the workgroups an XCD holds at one time share a WEIGHT column tile (K > 1: the weights
+  // are the big operand), 1 = they are the column tiles of the same ROW tiles (1x1 convolutions: the whole weight
+  // matrix sits in every XCD's L2, the activations are what would be fetched once per column tile)
+  int tile_order = 0;
 };
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
@@ -79,6 +83,9 @@ struct ConvGroup {
   void* y;
   float* stats;
   int Cin, Cout, accumulate, tile_begin;
+  // row strides (elements) when x / y are channel slices of wider tensors; 0 = contiguous (Cin / Cout).
+  // Ping-pong kernel only (os2s_conv1x1_cat_fwd); batch stride = rows per sample x row stride
+  int x_st = 0, y_st = 0;
 };
 struct ConvGroupTable {
   int ngroups, total_tiles;

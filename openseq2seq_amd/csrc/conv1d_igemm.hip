@@ -63,8 +63,8 @@ __device__ __forceinline__ void conv_tile_body(const ConvArgs& p, const int bid)
 
   // ---- block -> tiles (XCD-aware: see header) ------------------------------
   const int xcd = bid & 7, loc = bid >> 3;
-  const int n_idx = loc / p.MT8;
-  const int m_first = ((loc - n_idx * p.MT8) * 8 + xcd) * NWIN;
+  const int n_idx = p.tile_order ? loc % p.NT : loc / p.MT8;
+  const int m_first = ((p.tile_order ? loc / p.NT : loc - n_idx * p.MT8) * 8 + xcd) * NWIN;
   if (m_first >= p.MT) return;
   const int n0 = n_idx * BN;
   int wb[NWIN], wt0[NWIN], wlen[NWIN], wwin[NWIN];
@@ -1251,6 +1251,8 @@ static os2s::StampReg r_stamps("conv1d", [](void* stamps, int mode) {
 
 static int g_conv1x1_variant = 0;
 static os2s::OptionReg r_1x1("conv1x1.variant", [](double v) { g_conv1x1_variant = (int)v; });
+static int g_conv1x1_order = 1;
+static os2s::OptionReg r_1x1o("conv1x1.order", [](double v) { g_conv1x1_order = v != 0.0; });
 
 extern "C" int os2s_conv1d_num_mtiles(int B, int Tout) {
   return B * os2s::ceil_div(Tout, os2s::kConvBM);
@@ -1384,9 +1386,9 @@ extern "C" int os2s_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const ui
 }
 
 // Grouped 1x1 convolutions (see conv1d_igemm_grouped_kernel). groups is a HOST array.
-extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* groups,
-                                        int ngroups, const int32_t* in_len,
-                                        const int32_t* out_len, int B, int T) {
+static int conv1x1_fwd_grouped_impl(os2s_stream_t stream, const os2s_conv_group_t* groups,
+                                    int ngroups, const int32_t* in_len,
+                                    const int32_t* out_len, int B, int T, int out_f32) {
   using namespace os2s;
   OS2S_REQUIRE(groups && ngroups >= 1 && ngroups <= kMaxConvGroups && B >= 0 && T >= 1);
   if (B == 0) return OS2S_OK;
@@ -1397,7 +1399,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   a.B = B; a.Tin = T; a.Tout = T; a.Cin = 0; a.Cout = 0; a.K = 1;
   a.stride = 1; a.dil = 1; a.padL = 0;
   a.x_sb = 0; a.x_st = 0; a.y_sb = 0; a.y_st = 0;
-  a.out_f32 = 0; a.accumulate = 0; a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
+  a.out_f32 = out_f32 ? 1 : 0; a.accumulate = 0; a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
   a.mask_ref = nullptr; a.mask_scale = 1.f; a.stat_ref = nullptr;
   a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256; a.force_split = -1;
   a.dbg = g_conv_dbg; a.dbg_fixed_w = 0;     // experiment hook (conv1x1_pp_kernel phase stamps)
@@ -1406,12 +1408,14 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   a.MT8 = ceil_div(a.MT, 8);
   a.NT = 0; a.nchunks = 0;
   a.R = BM; a.Rpad = BM;
+  a.tile_order = g_conv1x1_order;
   ConvGroupTable gt;
   gt.ngroups = ngroups;
   int tiles = 0;
   for (int i = 0; i < ngroups; ++i) {
     const os2s_conv_group_t& g = groups[i];
     OS2S_REQUIRE(g.x && g.w && g.y && g.Cin >= 8 && g.Cout >= 8 && g.Cin % 8 == 0 && g.Cout % 8 == 0);
+    if (out_f32) OS2S_REQUIRE(g.stats == nullptr);
     gt.g[i].x = g.x; gt.g[i].w = g.w; gt.g[i].y = g.y; gt.g[i].stats = g.stats;
     gt.g[i].Cin = g.Cin; gt.g[i].Cout = g.Cout; gt.g[i].accumulate = g.accumulate ? 1 : 0;
     gt.g[i].tile_begin = tiles;
@@ -1423,7 +1427,7 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   // only: a 1x1 unit is 4-12 steps of matrix work followed by 128 KB of output, one workgroup per CU
   // cannot overlap the two (measured: epilogue 25 us of a 40 us unit; Jasper step +1 ms), while two
   // or three lockstep workgroups per CU do.
-  if (g_conv1x1_variant == 2) {
+  if (g_conv1x1_variant == 2 && !out_f32) {
     const int rc = launch_conv1x1_pp((hipStream_t)stream, a, gt);
     if (rc != OS2S_ERR_UNSUPPORTED) return rc;
   }
@@ -1441,4 +1445,53 @@ extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_gr
   OS2S_LAUNCH((conv1d_igemm_grouped_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), smem,
               (hipStream_t)stream, a, gt);
   return OS2S_OK;
+}
+
+extern "C" int os2s_conv1x1_fwd_grouped(os2s_stream_t stream, const os2s_conv_group_t* groups,
+                                        int ngroups, const int32_t* in_len,
+                                        const int32_t* out_len, int B, int T) {
+  return conv1x1_fwd_grouped_impl(stream, groups, ngroups, in_len, out_len, B, T, 0);
+}
+
+extern "C" int os2s_conv1x1_fwd_grouped_ex(os2s_stream_t stream, const os2s_conv_group_t* groups,
+                                           int ngroups, const int32_t* in_len,
+                                           const int32_t* out_len, int B, int T, int out_f32) {
+  return conv1x1_fwd_grouped_impl(stream, groups, ngroups, in_len, out_len, B, T, out_f32);
+}
+
+// 1x1 convolution between channel slices of wider tensors (the dense-residual sum and its data gradients,
+// csrc/dense_residual.hip): the one-group case of the 256 x 256 ping-pong launch over the live windows — these
+// products have 4 ... 80 steps of 64 channels, the regime that tile is built for — else the lockstep tile.
+extern "C" int os2s_conv1x1_cat_fwd(os2s_stream_t stream, const uint16_t* x, long long x_row_stride,
+                                    const uint16_t* w, uint16_t* y, long long y_row_stride, const int32_t* in_len,
+                                    const int32_t* out_len, const float* bias, int B, int T, int Cin, int Cout,
+                                    int accumulate, void* workspace, size_t workspace_bytes) {
+  using namespace os2s;
+  OS2S_REQUIRE(x && w && y && B >= 0 && T >= 1 && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0);
+  OS2S_REQUIRE(x_row_stride >= Cin && y_row_stride >= Cout && x_row_stride % 8 == 0 && y_row_stride % 8 == 0);
+  OS2S_REQUIRE(x_row_stride < (1ll << 30) && y_row_stride < (1ll << 30));
+  if (B == 0) return OS2S_OK;
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.in_len = in_len; a.out_len = out_len; a.bias = bias; a.stats = nullptr;
+  a.B = B; a.Tin = T; a.Tout = T; a.Cin = Cin; a.Cout = Cout; a.K = 1; a.stride = 1; a.dil = 1; a.padL = 0;
+  a.x_sb = (long long)T * x_row_stride; a.x_st = x_row_stride;
+  a.y_sb = (long long)T * y_row_stride; a.y_st = y_row_stride;
+  a.out_f32 = 0; a.accumulate = accumulate ? 1 : 0;
+  a.act = 0; a.keep_prob = 1.f; a.seed = 0; a.residual = nullptr;
+  a.mask_ref = nullptr; a.mask_scale = 1.f; a.stat_ref = nullptr;
+  a.ws_slabs = nullptr; a.ws_cnt = nullptr; a.ws_nslabs = 0; a.ncu = 256;
+  a.force_split = -1; a.dbg = nullptr; a.dbg_fixed_w = 0;
+  ConvGroupTable gt;
+  gt.ngroups = 1;
+  gt.g[0].x = x; gt.g[0].w = w; gt.g[0].y = y; gt.g[0].stats = nullptr;
+  gt.g[0].Cin = Cin; gt.g[0].Cout = Cout; gt.g[0].accumulate = a.accumulate; gt.g[0].tile_begin = 0;
+  gt.g[0].x_st = (int)x_row_stride; gt.g[0].y_st = (int)y_row_stride;
+  int rc = launch_conv1x1_pp((hipStream_t)stream, a, gt);
+  if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  (void)workspace; (void)workspace_bytes;
+  if (Cout >= 512 && (long long)B * ceil_div(T, kConvBM) >= 256) {
+    rc = launch_conv<kConvBM, 256, 2, 4, 2, false>((hipStream_t)stream, a);
+    if (rc != OS2S_ERR_UNSUPPORTED) return rc;
+  }
+  return launch_conv<kConvBM, kConvBN, 2, 2, 1>((hipStream_t)stream, a);
 }

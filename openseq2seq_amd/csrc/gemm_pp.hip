@@ -482,9 +482,15 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(ConvArgs p, ConvGrou
       if (j < __shfl(nw, b, 64)) continue;
       const int t0 = j * BM, rows = min(BM, p.Tout - t0);
       if (!g.accumulate) {
-        bf16_t* const yb = reinterpret_cast<bf16_t*>(g.y) + ((long long)b * p.Tout + t0) * g.Cout;
+        const int yst = g.y_st ? g.y_st : g.Cout, c8n = g.Cout >> 3;
+        bf16_t* const yb = reinterpret_cast<bf16_t*>(g.y) + ((long long)b * p.Tout + t0) * yst;
         const u32x4 zv = {0u, 0u, 0u, 0u};
-        for (int e = tid; e < rows * (g.Cout >> 3); e += 512) *reinterpret_cast<u32x4*>(yb + (long long)e * 8) = zv;
+        if (yst == g.Cout) {
+          for (int e = tid; e < rows * c8n; e += 512) *reinterpret_cast<u32x4*>(yb + (long long)e * 8) = zv;
+        } else {
+          for (int e = tid; e < rows * c8n; e += 512)
+            *reinterpret_cast<u32x4*>(yb + (long long)(e / c8n) * yst + (e % c8n) * 8) = zv;
+        }
       }
       if (g.stats)
         for (int e = tid; e < 2 * g.Cout; e += 512) g.stats[(long long)m * 2 * g.Cout + e] = 0.f;
@@ -503,8 +509,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pp_kernel(ConvArgs p, ConvGrou
     if (i == gi) g = gt.g[i];
   p.x = g.x; p.w = g.w; p.y = g.y; p.stats = g.stats;
   p.Cin = g.Cin; p.Cout = g.Cout; p.accumulate = g.accumulate;
-  p.x_sb = (long long)p.Tin * g.Cin; p.x_st = g.Cin;
-  p.y_sb = (long long)p.Tout * g.Cout; p.y_st = g.Cout;
+  p.x_st = g.x_st ? g.x_st : g.Cin; p.x_sb = (long long)p.Tin * p.x_st;
+  p.y_st = g.y_st ? g.y_st : g.Cout; p.y_sb = (long long)p.Tout * p.y_st;
   p.NT = (g.Cout + BN - 1) / BN;
   p.nchunks = g.Cin / 64;
   const int rank = bid - g.tile_begin * P;
@@ -550,7 +556,9 @@ int launch_conv1x1_pp(hipStream_t stream, ConvArgs a, ConvGroupTable gt) {
   for (int i = 0; i < gt.ngroups; ++i) {
     const ConvGroup& g = gt.g[i];
     if (g.Cin % 64 != 0 || g.Cin < 64 || g.Cout % 8 != 0) return OS2S_ERR_UNSUPPORTED;
-    if ((long long)g.Cin * 2 * 256 >= (1ll << 31)) return OS2S_ERR_UNSUPPORTED;
+    if ((long long)(g.x_st ? g.x_st : g.Cin) * 2 * 256 >= (1ll << 31)) return OS2S_ERR_UNSUPPORTED;
+    if (g.x_st % 8 != 0 || g.y_st % 8 != 0 || (g.x_st && g.x_st < g.Cin) || (g.y_st && g.y_st < g.Cout))
+      return OS2S_ERR_UNSUPPORTED;
     gt.g[i].tile_begin = nt;
     nt += ceil_div(g.Cout, 256);
   }

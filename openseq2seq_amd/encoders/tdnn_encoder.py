@@ -15,7 +15,9 @@ from .. import capi
 import os
 
 from ..parts.cnns.conv_blocks import (Act, ConvBN, ConvOnly, ConvSampleNorm, SepConvBN, conv_actv, conv_bn_res_bn_actv,
-                                      xavier_normal_conv, glorot_uniform_conv, launch_residual_early)
+                                      xavier_normal_conv, glorot_uniform_conv, launch_residual_early,
+                                      launch_dense_residual, conv_bn_dres_actv)
+from ..parts.cnns.dense_residual import DenseResidualPlan
 
 # which layer of a residual block starts the block end's residual branches on the side stream
 # (-1 = never: they run in front of the block's last BatchNorm, as in round 2). 2 leaves the first
@@ -125,6 +127,21 @@ class TDNNEncoder(Encoder):
         cin = blk['num_channels']
     self._layers = layers
     self.output_dim = cin
+    # Dense-residual block ends without branch tensors (parts/cnns/dense_residual.py): every residual block is
+    # dense, keeps the frame rate, and its branches are plain 1x1 conv + BatchNorm pairs over channel counts that
+    # are multiples of 64; block dropping keeps the branch-by-branch path
+    self._dres_plan = None
+    res_idx = [i for i, blk in enumerate(p['convnet_layers']) if blk.get('residual', False)]
+    res_blocks = [p['convnet_layers'][i] for i in res_idx]
+    # (every block from the first to the last residual one keeps the frame rate: all block inputs are [B, T, .])
+    span = p['convnet_layers'][res_idx[0]:res_idx[-1] + 1] if res_idx else []
+    ends = [L['res'] for L in layers if L['res']]
+    if res_blocks and all(blk.get('residual_dense', False) for blk in res_blocks) and \
+       all(blk['stride'][0] == 1 and blk['padding'] == "SAME" for blk in span) and \
+       (p.get('drop_block_prob', 0.0) == 0.0 or self._mode != 'train') and p.get('drop_block_index', -1) == -1 and \
+       DenseResidualPlan.eligible(ends):
+      self._dres_ends = ends
+      self._dres_plan = False        # built at the first pass (the store's device buffers exist then)
     return self
 
   def _encode(self, input_dict):
@@ -157,6 +174,11 @@ class TDNNEncoder(Encoder):
     residual_aggregation = []
     layer_res = []
     pending_res = None
+    dpass, pending_dres = None, None
+    if self._dres_plan is not None and x.data.is_cuda and x.data.shape[0] <= 64:
+      if self._dres_plan is False:
+        self._dres_plan = DenseResidualPlan(self._dres_ends, x.data.device)
+      dpass = self._dres_plan.begin(training)
     hint_stale = host_len is not None
     nl = len(self._layers)
     for li, L in enumerate(self._layers):
@@ -168,6 +190,8 @@ class TDNNEncoder(Encoder):
         if blk.get('residual_dense', False):
           residual_aggregation.append(x)
           layer_res = list(residual_aggregation)
+          if dpass is not None:
+            pending_dres = launch_dense_residual(dpass, len(residual_aggregation) - 1, x)
         else:
           layer_res = [x]
       s = blk['stride'][0]
@@ -187,7 +211,7 @@ class TDNNEncoder(Encoder):
       last = (li == nl - 1)
       # the block end's residual branches read the block inputs only: start them RES_EARLY_REP
       # layers into the block, on the side stream (conv_blocks.launch_residual_early)
-      if blk.get('residual', False) and blk['repeat'] > 1 and s == 1 and \
+      if dpass is None and blk.get('residual', False) and blk['repeat'] > 1 and s == 1 and \
          L['rep'] == min(RES_EARLY_REP, blk['repeat'] - 2) and RES_EARLY_REP >= 0:
         end = self._layers[li + blk['repeat'] - 1 - L['rep']]
         if end['res'] and len(end['res']) >= 2:
@@ -198,6 +222,11 @@ class TDNNEncoder(Encoder):
       if isinstance(main, ConvOnly):
         x = conv_actv(main, x, src_length if use_mask else None, act_fn, training, tape, keep_prob=keep,
                       seed=seed0 * 1000003 + li, mask_output=(use_mask and not last))
+        continue
+      if L['res'] and pending_dres is not None:
+        dfw, pending_dres = pending_dres, None
+        x = conv_bn_dres_actv(main, x, dfw, src_length if use_mask else None, act_fn, training, tape,
+                              keep_prob=keep, seed=seed0 * 1000003 + li, mask_output=(use_mask and not last))
         continue
       x = conv_bn_res_bn_actv(main, L['res'], x, res_in, src_length if use_mask else None,
                               act_fn, training, tape, keep_prob=keep,

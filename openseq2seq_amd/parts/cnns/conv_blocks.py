@@ -84,6 +84,9 @@ SMALL_WGRAD_GROUP = int(os.environ.get("OS2S_SMALL_WGRAD_GROUP", "3"))
 CONV_WGRAD_UNIT_BUDGET = int(os.environ.get("OS2S_CONV_WGRAD_UNIT_BUDGET", "0"))
 # A/B knob: 0 = the grouped K = 1 weight gradients stay on the lockstep kernel with its atomics (round 2 - 4)
 GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
+# A/B knob: the forward half of the dense-residual algebra (parts/cnns/dense_residual.py: source copy, Gram matrix,
+# block end's residual GEMM) runs on the side stream next to the block's own layers (1) or in front of them (0)
+DRES_FWD_SIDE = os.environ.get("OS2S_DRES_FWD_SIDE", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
@@ -308,7 +311,7 @@ def current_tape():
 class Act(object):
   """An activation tensor + its valid lengths + (optionally) its gradient."""
   __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad", "res_grad", "mask_scale",
-               "grad_masked", "bias_part", "bn_y", "bn_scale")
+               "grad_masked", "bias_part", "bn_y", "bn_scale", "grad_event")
 
   def __init__(self, data, lens=None, requires_grad=True):
     self.data, self.lens = data, lens
@@ -327,10 +330,20 @@ class Act(object):
     # the BatchNorm-backward partials (sum dz, sum dz * y) in bias_part (capi.conv1d_dgrad_bnact)
     self.bn_y = None
     self.bn_scale = 1.0
+    # set by a data-gradient contribution enqueued on the SIDE stream (dense_residual.backward_end): the next
+    # writer or reader of the gradient on another stream waits for it first
+    self.grad_event = None
+
+  def wait_grad(self):
+    if self.grad_event is not None:
+      torch.cuda.current_stream().wait_event(self.grad_event)
+      self.grad_event = None
 
   def grad_buffer(self):
     # a gradient that already carries its producer's activation backward takes no more addends
     assert not self.grad_masked, "a second consumer wrote to an activation whose gradient was finalised"
+    if self.grad_event is not None:
+      self.wait_grad()
     if self.grad is None:
       self.grad = torch.empty_like(self.data)
       self.grad_init = False
@@ -665,6 +678,7 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
     result.bn_scale = 1.0 / (keep_prob if training else 1.0)
 
   def backward():
+    result.wait_grad()
     dout = result.grad
     if dout is None and drop_block_prob > 0:
       return      # every consumer of this layer sat in a dropped block: its gradient is zero
@@ -739,6 +753,81 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
       capi.conv1x1_fwd_grouped(items, out_len=grouped[0][1].lens)
 
   tape.record(backward, [p for br in [main] + list(res_branches) for p in br.trainable()])
+  return result
+
+
+def launch_dense_residual(dpass, k, x):
+  """Registers block k's input `x` as source k of the dense-residual pass and evaluates block end k's residual
+  sum — it depends on the block INPUTS only — on the side stream, next to the block's own layers. Returns the
+  record conv_bn_dres_actv consumes (it joins the side stream first)."""
+  if not DRES_FWD_SIDE or _side_stream(x.data.device) is None:
+    dpass.add_source(x)
+    return dpass.forward_end(k)
+  global _FWD_SIDE_BUSY
+  _FWD_SIDE_BUSY = True
+  with on_side_stream(x.data.device, x.data) as ctx:
+    dpass.add_source(x)
+    fw = dpass.forward_end(k)
+    ctx.hand_over(fw["y"])
+  return fw
+
+
+def conv_bn_dres_actv(main, x, dfw, out_lens, activation_fn, training, tape, keep_prob=1.0, seed=0,
+                      mask_output=True):
+  """conv_bn_res_bn_actv (conv_blocks.py:61-168) for a dense-residual block end whose residual branches come as
+  ONE tensor: act(BN(conv(x)) + R + shift) -> dropout -> mask, R / shift = dense_residual.forward_end (the sum of
+  the BatchNorm'd 1x1 branches, no branch tensor materialised). Backward hands the gradient at the sum to
+  dense_residual.backward_end (side stream) and runs the main branch as conv_bn_res_bn_actv does."""
+  act = act_id(activation_fn)
+  fw = main.conv_bn_stats(x, training)
+  join_side_streams()
+  global _FWD_SIDE_BUSY
+  _FWD_SIDE_BUSY = False
+  B = x.data.shape[0]
+  tout, C = fw["tout"], main.cout
+  out = torch.empty((B, tout, C), dtype=torch.bfloat16, device=x.data.device)
+  lens = out_lens if mask_output else None
+  capi.bn_act_fwd([fw["y"], dfw["y"]], [fw["scale"], dfw["scale"]], [fw["shift"], dfw["shift"]],
+                  out, lens, act, keep_prob if training else 1.0, seed)
+  result = Act(out, lens)
+  if not (training and tape is not None):
+    return result
+  dpass, k = dfw["dres"], dfw["k"]
+  dfw = None
+
+  def backward():
+    result.wait_grad()
+    dout = result.grad
+    assert dout is not None, "no gradient reached " + main.name
+    rows = B * tout
+    c1 = torch.empty((1, C), dtype=torch.float32, device=out.device)
+    c2 = torch.empty((1, C), dtype=torch.float32, device=out.device)
+    dz = torch.empty_like(out)
+    partial = torch.empty((capi.bn_act_bwd_num_parts(rows), 2, C), dtype=torch.float32, device=out.device)
+    capi.bn_act_bwd_reduce(dout, out, [fw["y"]], [fw["mean"]], [fw["rstd"]], dz, partial, lens, act, keep_prob, seed)
+    capi.bn_bwd_finalize_multi(partial, rows, [main.gamma.grad], [main.beta.grad], True, c1, c2)
+    result.grad = None
+    # every residual branch (kernel / gamma / beta gradients) and the finished data gradient of source k
+    src = dpass.acts[k]
+    with on_side_stream(dz.device, dz, c1) as ctx:
+      dpass.backward_end(k, dz, c1[0])
+      if src.requires_grad:
+        ctx.hand_over(src.grad)
+        if ctx.side is not None:
+          src.grad_event = torch.cuda.Event()
+          src.grad_event.record(ctx.side)
+    dy = torch.empty_like(fw["y"])
+    ragged = lens is not None and type(main) is ConvBN and main.stride == 1
+    capi.bn_bwd_apply(dz, fw["y"], main.gamma.master, fw["mean"], fw["rstd"], c1[0], c2[0], dy,
+                      out_len=lens if ragged else None, margin=(main.k - 1) * main.dil)
+    fw["y"] = None
+    if type(main) is ConvBN:
+      # the last contribution to its input's gradient unless that input is itself a source of this block end
+      main.backward_branch(x, dy, fw, final=all(x is not a for a in dpass.acts[:k + 1]))
+    else:
+      main.backward_branch(x, dy, fw)
+
+  tape.record(backward, [p for br in [main] + list(dpass.plan.ends[k].branches) for p in br.trainable()])
   return result
 
 
