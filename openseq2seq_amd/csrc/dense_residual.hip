@@ -31,21 +31,23 @@ namespace os2s {
 typedef os2s_dres_seg_t DresSeg;
 
 constexpr int kDresCopyRows = 128;     // rows of one sample per workgroup of the copy kernel
+constexpr int kDresCopyWaves = 4;      // ... and one partial row of column sums per wave
 
 // dst[b, t, 0:C] = t < lens[b] ? src[b, t, 0:C] : 0 (row strides src_ld / dst_ld elements), and
-// partial[b * nblk + blk][c] = sum over the block's live rows (fp32; nullptr = no sums).
+// partial[(b * nblk + blk) * 4 + wave][c] = sum over the wave's live rows (fp32; nullptr = no sums).
+// No LDS and no barrier: these launches run on a side stream NEXT TO the ping-pong convolutions, whose workgroups
+// hold a CU's whole 160 KB — a kernel that asks for even 8 KB waits for a CU without one (measured: 114 us per
+// launch instead of 16). A lane owns one 8-channel group (blockIdx.y walks chunks of 64 groups), a wave every
+// fourth row of the block.
 __global__ __launch_bounds__(256) void dres_copy_cols_kernel(const bf16_t* __restrict__ src, long long src_ld,
                                                              bf16_t* __restrict__ dst, long long dst_ld,
                                                              const int32_t* __restrict__ lens, int T, int C,
                                                              float* __restrict__ partial) {
-  __shared__ float red[256 * 8];
   const int nblk = (T + kDresCopyRows - 1) / kDresCopyRows;
   const int b = blockIdx.x / nblk, blk = blockIdx.x - b * nblk;
-  const int C8 = C >> 3;
-  const int G = C8 < 256 ? C8 : 256;          // 8-channel groups per workgroup
-  const int RL = 256 / G;                     // row lanes
-  const int g = threadIdx.x % G, rl = threadIdx.x / G;
-  const int cg = blockIdx.y * G + g;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = blockIdx.y * 64 + lane;
+  if (cg * 8 >= C) return;
   int len = T;
   if (lens) { const int l = lens[b]; len = l < 0 ? 0 : (l < T ? l : T); }
   const int t0 = blk * kDresCopyRows;
@@ -53,48 +55,56 @@ __global__ __launch_bounds__(256) void dres_copy_cols_kernel(const bf16_t* __res
   float s[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s[e] = 0.f;
-  const bool active = rl < RL && cg < C8;
-  if (active) {
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    for (int t = t0 + rl; t < t1; t += RL) {
-      const long long row = (long long)b * T + t;
-      u32x4 v = zero;
-      if (t < len) {
-        v = *reinterpret_cast<const u32x4*>(src + row * src_ld + cg * 8);
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  int t = t0 + wave;
+  for (; t + 3 * kDresCopyWaves < t1; t += 4 * kDresCopyWaves) {        // four rows in flight per lane
+    u32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s[2 * e] += bflo(v[e]); s[2 * e + 1] += bfhi(v[e]); }
-      }
-      *reinterpret_cast<u32x4*>(dst + row * dst_ld + cg * 8) = v;
+    for (int u = 0; u < 4; ++u) {
+      const int tt = t + u * kDresCopyWaves;
+      v[u] = tt < len ? *reinterpret_cast<const u32x4*>(src + ((long long)b * T + tt) * src_ld + cg * 8) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[2 * e] += bflo(v[u][e]); s[2 * e + 1] += bfhi(v[u][e]); }
+      *reinterpret_cast<u32x4*>(dst + ((long long)b * T + t + u * kDresCopyWaves) * dst_ld + cg * 8) = v[u];
     }
   }
-  if (!partial) return;
+  for (; t < t1; t += kDresCopyWaves) {
+    const long long row = (long long)b * T + t;
+    const u32x4 v = t < len ? *reinterpret_cast<const u32x4*>(src + row * src_ld + cg * 8) : zero;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = active ? s[e] : 0.f;
-  __syncthreads();
-  if (rl == 0 && cg < C8) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float a = 0.f;
-      for (int r = 0; r < RL; ++r) a += red[(r * G + g) * 8 + e];
-      partial[(long long)blockIdx.x * C + cg * 8 + e] = a;
-    }
+    for (int e = 0; e < 4; ++e) { s[2 * e] += bflo(v[e]); s[2 * e + 1] += bfhi(v[e]); }
+    *reinterpret_cast<u32x4*>(dst + row * dst_ld + cg * 8) = v;
+  }
+  if (partial) {
+    float* const pr = partial + ((long long)blockIdx.x * kDresCopyWaves + wave) * C + cg * 8;
+    *reinterpret_cast<f32x4*>(pr) = f32x4{s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<f32x4*>(pr + 4) = f32x4{s[4], s[5], s[6], s[7]};
   }
 }
 
-// s[c] = sum of the partials (fp64), m[c] = s / count
-__global__ __launch_bounds__(256) void dres_colsum_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
-                                                                  double count, float* __restrict__ s,
-                                                                  float* __restrict__ m) {
-  __shared__ double sh[4][64];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+// s[c] = sum of the partials (fp64), m[c] = s / count. One wave per 16 channels: 4 lanes walk the partial rows of
+// a channel, two shuffles add them (no LDS: see dres_copy_cols_kernel).
+__global__ __launch_bounds__(64) void dres_colsum_finalize_kernel(const float* __restrict__ partial, int nparts, int C,
+                                                                 double count, float* __restrict__ s,
+                                                                 float* __restrict__ m) {
+  const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double a = 0.0;
-  if (c < C)
-    for (int i = pl; i < nparts; i += 4) a += (double)partial[(long long)i * C + c];
-  sh[pl][cl] = a;
-  __syncthreads();
+  if (c < C) {
+    int i = pl;
+    for (; i + 12 < nparts; i += 16) {
+      const float v0 = partial[(long long)i * C + c], v1 = partial[(long long)(i + 4) * C + c];
+      const float v2 = partial[(long long)(i + 8) * C + c], v3 = partial[(long long)(i + 12) * C + c];
+      a += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; i < nparts; i += 4) a += (double)partial[(long long)i * C + c];
+  }
+  a += __shfl_xor(a, 16, 64);
+  a += __shfl_xor(a, 32, 64);
   if (pl != 0 || c >= C) return;
-  a = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
   s[c] = (float)a;
   m[c] = (float)(a / count);
 }
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void dres_bn_bwd_apply_kernel(const DresSeg* _
 }  // namespace os2s
 
 extern "C" int os2s_dres_copy_num_parts(int B, int T) {
-  return B * os2s::ceil_div(T, os2s::kDresCopyRows);
+  return B * os2s::ceil_div(T, os2s::kDresCopyRows) * os2s::kDresCopyWaves;
 }
 
 extern "C" int os2s_dres_copy_cols(os2s_stream_t stream, const uint16_t* src, long long src_row_stride, uint16_t* dst,
@@ -306,8 +316,7 @@ extern "C" int os2s_dres_copy_cols(os2s_stream_t stream, const uint16_t* src, lo
   OS2S_REQUIRE(src && dst && B >= 0 && T >= 1 && C >= 8 && C % 8 == 0);
   OS2S_REQUIRE(src_row_stride >= C && dst_row_stride >= C && src_row_stride % 8 == 0 && dst_row_stride % 8 == 0);
   if (B == 0) return OS2S_OK;
-  const int C8 = C / 8, G = C8 < 256 ? C8 : 256;
-  OS2S_LAUNCH(dres_copy_cols_kernel, dim3(B * ceil_div(T, kDresCopyRows), ceil_div(C8, G)), dim3(256), 0,
+  OS2S_LAUNCH(dres_copy_cols_kernel, dim3(B * ceil_div(T, kDresCopyRows), ceil_div(C / 8, 64)), dim3(256), 0,
               (hipStream_t)stream, src, src_row_stride, dst, dst_row_stride, lens, T, C, colsum_partial);
   return OS2S_OK;
 }
@@ -316,7 +325,7 @@ extern "C" int os2s_dres_cov(os2s_stream_t stream, const float* colsum_partial, 
                              long long count, float* s, float* m, uint16_t* chl) {
   using namespace os2s;
   OS2S_REQUIRE(colsum_partial && gram && s && m && chl && nparts >= 1 && C >= 8 && C % 8 == 0 && count >= 1);
-  OS2S_LAUNCH(dres_colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, colsum_partial,
+  OS2S_LAUNCH(dres_colsum_finalize_kernel, dim3(ceil_div(C, 16)), dim3(64), 0, (hipStream_t)stream, colsum_partial,
               nparts, C, (double)count, s, m);
   OS2S_LAUNCH(dres_cov_split_kernel, dim3(ceil_div((long long)C * C / 4, 256)), dim3(256), 0, (hipStream_t)stream,
               gram, (const float*)m, C, (float)(1.0 / (double)count), chl);

@@ -87,6 +87,8 @@ GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 # A/B knob: the forward half of the dense-residual algebra (parts/cnns/dense_residual.py: source copy, Gram matrix,
 # block end's residual GEMM) runs on the side stream next to the block's own layers (1) or in front of them (0)
 DRES_FWD_SIDE = os.environ.get("OS2S_DRES_FWD_SIDE", "1") != "0"
+# A/B knob: 0 = the dense-residual chains share the weight-gradient side stream (FIFO behind its backlog)
+DRES_OWN_STREAM = os.environ.get("OS2S_DRES_OWN_STREAM", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
@@ -101,17 +103,22 @@ def set_side_stream_enabled(on):
   return prev
 
 
-def _side_stream(device):
+def _side_stream(device, which=0):
   """Side stream for work that may overlap the main stream inside one backward closure
-  (OS2S_WGRAD_STREAM=0 or the model's `os2s_side_stream: False` keeps everything on one stream)."""
+  (OS2S_WGRAD_STREAM=0 or the model's `os2s_side_stream: False` keeps everything on one stream).
+  which: 0 = the parameter-gradient stream (nothing on the main stream waits for it before the end of the pass),
+  1 = the stream of side work the main stream DOES wait for (the dense-residual chains): a stream is a FIFO, a
+  chain queued behind a backlog of weight-gradient kernels would stall the main stream until the backlog drained."""
   if not _SIDE_STREAM_ENABLED or os.environ.get("OS2S_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
     return None
-  key = (device.index, capi._stream().value)
+  if which and not DRES_OWN_STREAM:
+    which = 0
+  key = (device.index, capi._stream().value) if not which else (device.index, capi._stream().value, which)
   st = _SIDE_STREAMS.get(key)
   if st is None:
     # OS2S_SIDE_PRIO (experiment): stream priority of the side stream (HIP: lower number = higher
     # priority; the main stream has 0)
-    prio = int(os.environ.get("OS2S_SIDE_PRIO", "0"))
+    prio = int(os.environ.get("OS2S_DRES_PRIO" if which else "OS2S_SIDE_PRIO", "0"))
     st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=prio)
   return st
 
@@ -124,8 +131,8 @@ class on_side_stream(object):
   tensors the body reads that the main stream's closures release afterwards (their memory is kept
   until the side stream is done). With OS2S_WGRAD_STREAM=0 the body runs on the current stream."""
 
-  def __init__(self, device, *operands):
-    self.side = _side_stream(device)
+  def __init__(self, device, *operands, which=0):
+    self.side = _side_stream(device, which)
     self.operands = operands
     self.ctx = None
     self.main = None
@@ -760,12 +767,12 @@ def launch_dense_residual(dpass, k, x):
   """Registers block k's input `x` as source k of the dense-residual pass and evaluates block end k's residual
   sum — it depends on the block INPUTS only — on the side stream, next to the block's own layers. Returns the
   record conv_bn_dres_actv consumes (it joins the side stream first)."""
-  if not DRES_FWD_SIDE or _side_stream(x.data.device) is None:
+  if not DRES_FWD_SIDE or _side_stream(x.data.device, 1) is None:
     dpass.add_source(x)
     return dpass.forward_end(k)
   global _FWD_SIDE_BUSY
   _FWD_SIDE_BUSY = True
-  with on_side_stream(x.data.device, x.data) as ctx:
+  with on_side_stream(x.data.device, x.data, which=1) as ctx:
     dpass.add_source(x)
     fw = dpass.forward_end(k)
     ctx.hand_over(fw["y"])
@@ -809,7 +816,7 @@ def conv_bn_dres_actv(main, x, dfw, out_lens, activation_fn, training, tape, kee
     result.grad = None
     # every residual branch (kernel / gamma / beta gradients) and the finished data gradient of source k
     src = dpass.acts[k]
-    with on_side_stream(dz.device, dz, c1) as ctx:
+    with on_side_stream(dz.device, dz, c1, which=1) as ctx:
       dpass.backward_end(k, dz, c1[0])
       if src.requires_grad:
         ctx.hand_over(src.grad)

@@ -111,7 +111,7 @@ def test_device_tdnn_reproduces_the_reference_code(cuda, deterministic_kernels, 
   # than 2 EPS below the top MUST then decode to the reference's symbol; a close call may go to any symbol within
   # 2 EPS. The decoded STRINGS (fc_decoders.py:244-251: argmax, merge repeats, drop the blank) are therefore held
   # against the reference's own tf.nn.ctc_greedy_decoder output exactly: equal on every sample without a close call,
-  # and otherwise a member of the set of strings the close calls allow (enumerated: <= 2^16 per sample; on this
+  # and otherwise a member of the set of strings the close calls allow (enumerated: <= 2^20 per sample; on this
   # fixture 4 - 12 close frames of 20 - 48 per sample, 24 - 31 104 admissible strings).
   import itertools
   EPS = (1.25 if residual_path == "algebra" else 1.0) * 2.0 ** -5
@@ -144,7 +144,7 @@ def test_device_tdnn_reproduces_the_reference_code(cuda, deterministic_kernels, 
       assert mine == ref_ids, (b, mine, ref_ids)
       exact += 1
     else:
-      assert ways <= 1 << 18, (b, ways)
+      assert ways <= 1 << 20, (b, ways)
       allowed = {collapse(path) for path in itertools.product(*cands)}
       assert mine in allowed, (b, mine, ref_ids, ways)
   decode_report = "%d of %d strings equal by necessity, %d close frames of %d" % (exact, B, close_calls, int(live.sum()))
