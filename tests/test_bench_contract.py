@@ -176,7 +176,8 @@ def test_committed_line_breakdown_has_no_error_and_headline_is_last():
     assert abs(h["roofline"]["frac"] - r["frac"]) < 1e-12
     assert h["secondary"]["ms_per_step"] == d["secondary"]["ms_per_step"]
     assert len(json.dumps(h)) < 2000          # fits the tail the driver keeps
-    assert r["sampled_frac"] >= r["frac"] * 0.8 and "frac_is" in r
+    # (None since the dense-residual chains run next to the forward convolutions: no launch is alone to sample)
+    assert (r["sampled_frac"] is None or r["sampled_frac"] >= r["frac"] * 0.8) and "frac_is" in r
 
 
 def test_with_headline_puts_both_metrics_in_the_tail():
