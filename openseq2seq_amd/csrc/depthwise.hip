@@ -429,10 +429,216 @@ __global__ __launch_bounds__(256, 2) void depthwise_wgrad16_kernel(DwArgs p, int
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stride-1, dilation-1 forward / data gradient on the matrix cores (round 6).
+//
+// The register-window kernel above runs at ~37 TFLOP/s of packed fp32 FMAs — 0.13 of what HBM would allow
+// (2 K FLOP per 4 bytes). A depthwise convolution is time-invariant: with the time axis of ONE (sample,
+// channel) cut into 32 segments of 32 steps,
+//     y[32 s + i] = sum_d w[d] x[32 s + i + d - padL]   =   sum_p T[i][p] X[p][s],
+//     T[i][p] = w[p - i]  (a 32 x (32 + K - 1) Toeplitz band),   X[p][s] = x[32 s + p - padL],
+// i.e. a [32 x 16 J] . [16 J x 32] product per channel whose B operand is the channel's time series read at 32
+// overlapping offsets — v_mfma_f32_32x32x16_bf16 with M = position in the segment, N = segment, K = window
+// position. A workgroup owns 32 channels (64 B of every row) x 1024 time steps of one sample: the rows are
+// transposed on the way into LDS (a lane loads 4 rows x 8 channels and writes one 8-byte run of 4 time steps
+// per channel), every channel is a PLANE of consecutive time steps, a B fragment is one aligned ds_read_b128
+// at chunk 4 s + 2 j + lhi, an A fragment one UNALIGNED ds_read_b128 of the zero-padded tap table at
+// 32 + 16 j + 8 lhi - i (gfx950 reads LDS at any 2-byte address). The taps enter as a bf16 hi + lo pair
+// (two MFMAs per step: the result is the fp32-weight convolution the VALU kernel computes, to fp32 rounding).
+// Outputs go back into the wave's own plane (time-contiguous) and leave through the inverse transposition.
+// 8 waves x 4 channels; <= 80 KB of LDS: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDmCh = 32;        // channels per workgroup
+
+struct DmGeom {
+  int Jt;            // 16-wide window steps per segment: ceil((32 + K - 1) / 16)
+  int nseg;          // 32-step segments per workgroup tile (<= 32): as many as fit 128 logical chunks
+  int nchunk;        // logical 16-byte chunks (8 time steps) of a plane
+  int plane_bytes;   // physical: one pad chunk after every 16; plane_bytes % 256 == 128
+  int wt;            // elements of one tap table (index = d + 32)
+};
+__host__ __device__ inline DmGeom dm_geom(int K) {
+  DmGeom g;
+  g.Jt = (32 + K - 1 + 15) / 16;
+  g.nseg = (1056 - 16 * g.Jt) / 32;                  // window of the last segment ends at 32 (nseg - 1) + 16 Jt <= 1024
+  if (g.nseg > 32) g.nseg = 32;
+  g.nchunk = (32 * (g.nseg - 1) + 16 * g.Jt) / 8;    // <= 128
+  int phys = (g.nchunk - 1) + ((g.nchunk - 1) >> 4) + 1;
+  while ((phys * 16) % 256 != 128) ++phys;           // 136 for every K <= 96: 69.6 KB of planes, two workgroups per CU
+  g.plane_bytes = phys * 16;
+  g.wt = 16 * g.Jt + 40;
+  return g;
+}
+__device__ __forceinline__ int dm_chunk_off(int q) { return (q + (q >> 4)) * 16; }   // byte offset of logical chunk q
+__device__ __forceinline__ int dm_plane_of(int ch) { return (ch & 7) * 4 + (ch >> 3); }
+
+__global__ __launch_bounds__(512, 2) void depthwise_mfma_fwd_kernel(DwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  const DmGeom g = dm_geom(p.K);
+  char* const planes = smc;                                            // [32 planes][plane_bytes]
+  bf16_t* const wtab_all = reinterpret_cast<bf16_t*>(smc + kDmCh * g.plane_bytes);   // [8 waves][2][wt]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int Tt = 32 * g.nseg;                                // time steps per workgroup
+  const int ntt = (p.Tout + Tt - 1) / Tt;
+  const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * Tt, c0 = blockIdx.y * kDmCh;
+  int len_b = p.Tin;
+  if (p.in_len) len_b = min(max(p.in_len[b], 0), p.Tin);
+  if (p.out_len && t0 >= p.out_len[b]) return;             // never-read output tile
+  const int rows_out = min(Tt, p.Tout - t0);
+  const int ncg = min(4, (p.C - c0) >> 3);                  // 8-channel groups of this block
+  if (t0 - p.padL >= len_b) {
+    // the whole input window lies past the sequence end: exact zeros
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int q = tid; q < rows_out * ncg; q += 512) {
+      const int r = q / ncg, cg = q - r * ncg;
+      *reinterpret_cast<u32x4*>(p.y + ((long long)b * p.Tout + t0 + r) * p.C + c0 + cg * 8) = z;
+    }
+    return;
+  }
+  // the taps of the wave's four channels: issued in front of the row loads (one memory round trip for both)
+  float wreg[4][2];
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = lane + 64 * r, ch = j4 * 8 + wave;
+      wreg[j4][r] = (k < p.K && c0 + ch < p.C) ? p.w[(long long)(p.flip ? p.K - 1 - k : k) * p.C + c0 + ch] : 0.f;
+    }
+  // ---- stage: rows [t0 - padL, t0 - padL + 8 nchunk) -> planes (time-contiguous per channel) -------------
+  const bf16_t* const xb = p.x + (long long)b * p.Tin * p.C;
+  const int n4 = g.nchunk * 2;                                // groups of 4 positions
+  // positions past the last live row of the tile hold zeros. All row loads of a thread are issued before the
+  // first is consumed (up to 3 items x 4 rows: one memory round trip, not one per loop trip)
+  constexpr int kIt = 2;                                       // 8 nchunk <= 1024 items / 512 threads
+  u32x4 r[kIt][4];
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int q = tid + 512 * it;
+    const int cg = q & 3, p4 = q >> 2;
+    const int tin0 = t0 - p.padL + p4 * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int tin = tin0 + u;
+      r[it][u] = u32x4{0u, 0u, 0u, 0u};
+      if (q < n4 * 4 && cg < ncg && tin >= 0 && tin < len_b && !(p.tile0 & 4))
+        r[it][u] = *reinterpret_cast<const u32x4*>(xb + (long long)tin * p.C + c0 + cg * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kIt; ++it) {
+    const int q = tid + 512 * it;
+    if (q >= n4 * 4) break;
+    const int cg = q & 3, p4 = q >> 2;
+    char* const dst = planes + dm_chunk_off(p4 >> 1) + (p4 & 1) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // channel 2k (low halves) and 2k + 1 (high halves) of the 8-channel group
+      u32x2 lo, hi;
+      lo[0] = (r[it][0][k] & 0xffffu) | (r[it][1][k] << 16);
+      lo[1] = (r[it][2][k] & 0xffffu) | (r[it][3][k] << 16);
+      hi[0] = (r[it][0][k] >> 16) | (r[it][1][k] & 0xffff0000u);
+      hi[1] = (r[it][2][k] >> 16) | (r[it][3][k] & 0xffff0000u);
+      *reinterpret_cast<u32x2*>(dst + dm_plane_of(cg * 8 + 2 * k) * g.plane_bytes) = lo;
+      *reinterpret_cast<u32x2*>(dst + dm_plane_of(cg * 8 + 2 * k + 1) * g.plane_bytes) = hi;
+    }
+  }
+  // the wave's tap table: zeros outside [32, 32 + K)
+  bf16_t* const wt_hi = wtab_all + wave * 2 * g.wt;
+  bf16_t* const wt_lo = wt_hi + g.wt;
+  for (int i = lane; i < 2 * g.wt; i += 64) wt_hi[i] = 0;
+  __syncthreads();
+  // ---- per wave: channels wave, wave + 8, wave + 16, wave + 24 (planes 4 wave .. 4 wave + 3) -------------
+  // (no workgroup barrier inside the loop: table and plane of a channel belong to ONE wave, whose LDS
+  // instructions execute in issue order)
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4) {
+    const int ch = j4 * 8 + wave;
+    const bool live = c0 + ch < p.C && !(p.tile0 & 1);
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int k = lane + 64 * r;
+        if (k < p.K) {
+          const bf16_t h = f2bf(wreg[j4][r]);
+          wt_hi[32 + k] = h;
+          wt_lo[32 + k] = f2bf(wreg[j4][r] - bf2f(h));
+        }
+      }
+    }
+    if (live) {
+      char* const pl = planes + dm_plane_of(ch) * g.plane_bytes;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      // A fragment = 8 taps at element 32 + 16 jj + 8 lhi - l31 of the table: a 2-byte-aligned 16-byte window.
+      // (One unaligned ds_read_b128 does it, but a lane-private misalignment costs ~100 cycles per instruction:
+      // the first version of this kernel was bound by those 32 reads per channel.) Five dword-aligned reads
+      // and a funnel shift by 0 or 16 bits instead.
+      const int seg = l31 < g.nseg ? l31 : 0;       // columns past the last segment recompute segment 0 (never stored)
+      const int e0 = 32 + 8 * lhi - l31;
+      const uint32_t* const ahw = reinterpret_cast<const uint32_t*>(wt_hi) + (e0 >> 1);
+      const uint32_t* const alw = reinterpret_cast<const uint32_t*>(wt_lo) + (e0 >> 1);
+      const uint32_t sh = (e0 & 1) ? 16u : 0u;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        if (jj < g.Jt) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(pl + dm_chunk_off(4 * seg + 2 * jj + lhi));
+          uint32_t dh[5], dl[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { dh[k] = ahw[8 * jj + k]; dl[k] = alw[8 * jj + k]; }
+          u32x4 fh, fl;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            fh[k] = __builtin_amdgcn_alignbit(dh[k + 1], dh[k], sh);
+            fl[k] = __builtin_amdgcn_alignbit(dl[k + 1], dl[k], sh);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fh), bfr, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fl), bfr, acc, 0, 0, 0);
+        }
+      }
+      // outputs back into the plane: acc[4 q + e] = step 32 s + 8 q + 4 lhi + e of segment s = l31
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u32x2 o;
+        o[0] = pack2bf(acc[4 * q], acc[4 * q + 1]);
+        o[1] = pack2bf(acc[4 * q + 2], acc[4 * q + 3]);
+        if (l31 < g.nseg) *reinterpret_cast<u32x2*>(pl + dm_chunk_off(4 * l31 + q) + lhi * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- planes -> rows: 4 time steps x 8 channels per item ------------------------------------------------
+  bf16_t* const yb = p.y + ((long long)b * p.Tout + t0) * p.C + c0;
+  const int n4o = (p.tile0 & 2) ? 0 : (rows_out + 3) >> 2;
+  for (int q = tid; q < n4o * 4; q += 512) {
+    const int cg = q & 3, p4 = q >> 2;
+    if (cg >= ncg) continue;
+    const char* const src = planes + dm_chunk_off(p4 >> 1) + (p4 & 1) * 8;
+    u32x2 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const u32x2*>(src + dm_plane_of(cg * 8 + e) * g.plane_bytes);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p4 * 4 + u >= rows_out) break;
+      u32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t a = v[2 * k][u >> 1], c = v[2 * k + 1][u >> 1];
+        o[k] = (u & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+      }
+      *reinterpret_cast<u32x4*>(yb + (long long)(p4 * 4 + u) * p.C + cg * 8) = o;
+    }
+  }
+}
+
 }  // namespace os2s
 
 using namespace os2s;
 
+static int g_dw_ablate = 0;     // measurement hook (scratch/bench_depthwise.py): parts of the matrix-core kernel switched off
+static os2s::OptionReg r_dw_ablate("depthwise.ablate", [](double v) { g_dw_ablate = (int)v; });
 static int g_dw_variant = -1;   // test / experiment hook: 0 = the generic kernels only
 static os2s::OptionReg r_dw_variant("depthwise.variant", [](double v) { g_dw_variant = (int)v; });
 
@@ -453,6 +659,23 @@ extern "C" int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x
   if (rc != OS2S_OK) return rc;
   a.x = (const bf16_t*)x; a.w = w; a.y = (bf16_t*)y; a.in_len = in_len; a.out_len = out_len;
   a.flip = flip_taps;
+  // matrix-core kernel: stride 1, dilation 1, K <= 96 (depthwise.variant 1 = the register-window kernels only)
+  if (stride == 1 && dil == 1 && K >= 2 && K <= 96 && g_dw_variant != 0 && g_dw_variant != 1) {
+    const DmGeom g = dm_geom(K);
+    const size_t ldsm = (size_t)kDmCh * g.plane_bytes + (size_t)8 * 2 * g.wt * sizeof(bf16_t);
+    if (ldsm <= 160 * 1024) {
+      static bool attrm = false;
+      if (!attrm) {
+        if (hipFuncSetAttribute((const void*)depthwise_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return OS2S_ERR_LAUNCH;
+        attrm = true;
+      }
+      a.tile0 = g_dw_ablate;
+      dim3 gridm(B * ceil_div(Tout, 32 * g.nseg), ceil_div(C, kDmCh));
+      OS2S_LAUNCH(depthwise_mfma_fwd_kernel, gridm, dim3(512), ldsm, (hipStream_t)stream, a);
+      return OS2S_OK;
+    }
+  }
   if (stride == 1 && (dil == 1 || dil == 2 || dil == 4) && g_dw_variant != 0) {
     const size_t lds16 = (((size_t)(kD16BT + (K - 1) * dil) * kD16Pitch + 15) & ~(size_t)15) + (size_t)K * kDwBC * sizeof(float);
     if (lds16 <= 160 * 1024) {             // <= 80 KB: two workgroups per CU (every dilation-1 QuartzNet layer)
