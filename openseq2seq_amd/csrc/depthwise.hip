@@ -633,6 +633,158 @@ __global__ __launch_bounds__(512, 2) void depthwise_mfma_fwd_kernel(DwArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Stride-1, dilation-1 weight gradient on the matrix cores (round 6).
+//   dw[k] = sum_t dy[t] x[t + k - padL]   per (sample, channel), summed over the batch.
+// With the time axis cut into 16-step segments s, H[i][p] = sum_s dy[16 s + i] x[16 s + p - padL] is a product
+// that contracts over the SEGMENT index — both operands are the time-contiguous channel planes of the forward
+// kernel read with the transposing LDS read (ds_read_b64_tr_b16: memory rows = segments, a lane receives 4
+// consecutive segments of one position) — and dw[k] = sum_i H[i][i + k]: v_mfma_f32_16x16x32_bf16, M = position
+// in the segment, N = window position (ceil((K + 15) / 16) tiles of 16), K-dim = 32 segments. H is translation
+// invariant, so a wave keeps the accumulators of its two channels (<= 2 x 7 x 4 registers) over every tile it
+// walks and sums the diagonals once at the end (through LDS, in a fixed order; one atomic per (tap, channel) and
+// workgroup — ONE workgroup per channel block in deterministic mode). A workgroup owns 16 channels (32 B of a row)
+// and tiles of 928 time steps of one sample: x plane 1120 positions, dy plane 1024 (zeros past the tile), 73.7 KB,
+// two workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDwgCh = 16;                 // channels per workgroup
+constexpr int kDwgTt = 928;                // time steps per tile (58 segments of 16; the two K-steps read 64)
+constexpr int kDwgXPlane = 2432;           // 152 chunks: 1120 positions + a pad chunk per 16; % 256 == 128
+constexpr int kDwgYPlane = 2176;           // 136 chunks: 1024 positions
+__device__ __forceinline__ int dwg_plane_of(int ch) { return (ch & 7) * 2 + (ch >> 3); }
+__device__ __forceinline__ int dwg_pos_off(int pos) {        // byte offset of time position pos inside a plane
+  const int q = pos >> 3;
+  return (q + (q >> 4)) * 16 + (pos & 7) * 2;
+}
+
+// rows -> planes for NCG 8-channel groups: position p <-> row first_row + p, rows outside [lo, hi) are zeros
+template <int NIT, int NCG, typename PlaneOf>
+__device__ __forceinline__ void dm_stage_planes(const bf16_t* __restrict__ rows, long long row_stride, int first_row,
+                                                int lo, int hi, int ngroups4, int ncg_live, char* planes,
+                                                int plane_bytes, PlaneOf plane_of) {
+  const int tid = threadIdx.x;
+  u32x4 r[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = tid + 512 * it;
+    const int cg = q % NCG, p4 = q / NCG;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = first_row + p4 * 4 + u;
+      r[it][u] = u32x4{0u, 0u, 0u, 0u};
+      if (p4 < ngroups4 && cg < ncg_live && row >= lo && row < hi)
+        r[it][u] = *reinterpret_cast<const u32x4*>(rows + (long long)row * row_stride + cg * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int q = tid + 512 * it;
+    const int cg = q % NCG, p4 = q / NCG;
+    if (p4 >= ngroups4) break;
+    char* const dst = planes + dm_chunk_off(p4 >> 1) + (p4 & 1) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      u32x2 lo2, hi2;
+      lo2[0] = (r[it][0][k] & 0xffffu) | (r[it][1][k] << 16);
+      lo2[1] = (r[it][2][k] & 0xffffu) | (r[it][3][k] << 16);
+      hi2[0] = (r[it][0][k] >> 16) | (r[it][1][k] & 0xffff0000u);
+      hi2[1] = (r[it][2][k] >> 16) | (r[it][3][k] & 0xffff0000u);
+      *reinterpret_cast<u32x2*>(dst + plane_of(cg * 8 + 2 * k) * plane_bytes) = lo2;
+      *reinterpret_cast<u32x2*>(dst + plane_of(cg * 8 + 2 * k + 1) * plane_bytes) = hi2;
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x4 dm_lds_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+__global__ __launch_bounds__(512, 2) void depthwise_mfma_wgrad_kernel(DwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  char* const xpl = smc;                                   // [16][kDwgXPlane]
+  char* const ypl = smc + kDwgCh * kDwgXPlane;             // [16][kDwgYPlane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t16 = lane & 15, g4 = lane >> 4;
+  const int c0 = blockIdx.y * kDwgCh;
+  const int ncg = min(2, (p.C - c0) >> 3);
+  const int ntt = (p.Tout + kDwgTt - 1) / kDwgTt;
+  const int ntiles = p.B * ntt;
+  const int NT = (p.K + 15 + 15) / 16;                     // window tiles of 16 positions (<= 7)
+  f32x4 acc[2][7];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int n = 0; n < 7; ++n) acc[c][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / ntt, t0 = (tile - b * ntt) * kDwgTt;
+    int len_b = p.Tin;
+    if (p.in_len) len_b = min(max(p.in_len[b], 0), p.Tin);
+    if (t0 - p.padL >= len_b) continue;                    // every x row of the window is masked: no contribution
+    __syncthreads();                                       // the previous tile's planes are no longer read
+    dm_stage_planes<2, 2>(p.x + (long long)b * p.Tin * p.C + c0, p.C, t0 - p.padL, 0, (p.tile0 & 4) ? 0 : len_b, 280, ncg, xpl,
+                          kDwgXPlane, dwg_plane_of);
+    dm_stage_planes<1, 2>(p.dy + (long long)b * p.Tout * p.C + c0, p.C, t0, t0, (p.tile0 & 4) ? 0 : min(p.Tout, t0 + kDwgTt), 256, ncg,
+                          ypl, kDwgYPlane, dwg_plane_of);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = c * 8 + wave;                         // planes 2 wave, 2 wave + 1
+      if (c0 + ch >= p.C || (p.tile0 & 1)) continue;
+      const char* const xp = xpl + dwg_plane_of(ch) * kDwgXPlane;
+      const char* const yp = ypl + dwg_plane_of(ch) * kDwgYPlane;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // the lane supplies segment row 32 ks + 8 g4 + 4 h + (t16 >> 2), positions 4 (t16 & 3) .. + 3 of the tile
+        const int row0 = 32 * ks + 8 * g4 + (t16 >> 2), col0 = 4 * (t16 & 3);
+        const bf16x4 a0 = dm_lds_tr(yp + dwg_pos_off(16 * row0 + col0));
+        const bf16x4 a1 = dm_lds_tr(yp + dwg_pos_off(16 * (row0 + 4) + col0));
+        const bf16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+        for (int n = 0; n < 7; ++n) {
+          if (n < NT) {
+            const bf16x4 b0 = dm_lds_tr(xp + dwg_pos_off(16 * row0 + 16 * n + col0));
+            const bf16x4 b1 = dm_lds_tr(xp + dwg_pos_off(16 * (row0 + 4) + 16 * n + col0));
+            const bf16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            acc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[c][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- diagonal sums: dw[k] = sum_i H[i][i + k], H[i = 4 g4 + e][p = 16 n + t16] = acc[.][n][e] ------------
+  __syncthreads();
+  float* const sc = reinterpret_cast<float*>(smc) + wave * (16 * 112);    // [16 i][112 k] fp32 per wave
+  float* const dwl = reinterpret_cast<float*>(smc) + 8 * (16 * 112);       // [K][16 channels] sums of the workgroup
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int ch = c * 8 + wave;
+    if (c0 + ch < p.C && !(p.tile0 & 2)) {
+#pragma unroll
+      for (int n = 0; n < 7; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g4 + e, k = 16 * n + t16 - i;
+          if (n < NT && k >= 0 && k < p.K) sc[i * 112 + k] = acc[c][n][e];
+        }
+      // (same wave wrote and reads: LDS instructions of a wave execute in order)
+      for (int k = lane; k < p.K; k += 64) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += sc[i * 112 + k];
+        dwl[k * kDwgCh + ch] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  // one atomic per (tap, channel) and workgroup, lanes along the CHANNELS: 16 consecutive floats per tap (a lane per
+  // tap put every atomic of an instruction into a cache line of its own: 35 - 65 us of a 45 - 90 us launch)
+  for (int idx = tid; idx < p.K * kDwgCh; idx += 512) {
+    const int k = idx / kDwgCh, ch = idx - k * kDwgCh;
+    if (c0 + ch < p.C) atomicAdd(p.dw + (long long)k * p.C + c0 + ch, dwl[idx]);
+  }
+}
+
 }  // namespace os2s
 
 using namespace os2s;
@@ -712,6 +864,23 @@ extern "C" int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t*
   const int rc = dw_fill(a, B, Tin, Tout, C, K, stride, dil, padL);
   if (rc != OS2S_OK) return rc;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw; a.in_len = in_len;
+  // matrix-core kernel: stride 1, dilation 1, 2 <= K <= 96 (depthwise.variant 1 = the register-window kernels only)
+  if (stride == 1 && dil == 1 && K >= 2 && K <= 96 && g_dw_variant != 0 && g_dw_variant != 1) {
+    const size_t ldsw = (size_t)kDwgCh * (kDwgXPlane + kDwgYPlane);
+    static bool attrw = false;
+    if (!attrw) {
+      if (hipFuncSetAttribute((const void*)depthwise_mfma_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return OS2S_ERR_LAUNCH;
+      attrw = true;
+    }
+    const int ntiles = B * ceil_div(Tout, kDwgTt), ngroups = ceil_div(C, kDwgCh);
+    // enough workgroups for two per CU; deterministic mode: ONE per channel block (one add per dw element)
+    int gx = os2s_deterministic() ? 1 : ceil_div(512, ngroups);
+    gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+    a.tile0 = g_dw_ablate;
+    OS2S_LAUNCH(depthwise_mfma_wgrad_kernel, dim3(gx, ngroups), dim3(512), ldsw, (hipStream_t)stream, a);
+    return OS2S_OK;
+  }
   if (stride == 1 && (dil == 1 || dil == 2 || dil == 4) && g_dw_variant != 0) {
     const int ngrp = ceil_div(K, 16), ncell = ngrp * 16;
     int nseg = 256 / ncell;
