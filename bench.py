@@ -532,11 +532,13 @@ def other_config_roofline(key, model, batch, res):
                                "depthwise_conv1d_wgrad": ("depthwise weight gradient", dw_bytes)}).run(model, batch)
     ms = sum(v["ms_per_step"] for v in fb.values())
     by = sum(v["work_per_step"] for v in fb.values())
-    return _roofline("hbm", "depthwise_fwd / depthwise_wgrad register-window kernels (csrc/depthwise.hip)",
+    return _roofline("hbm", "depthwise_mfma_fwd_kernel / depthwise_mfma_wgrad_kernel (stride 1, dilation 1: Toeplitz band x "
+                            "segmented time series on the matrix cores) + the register-window kernels of the dilated / "
+                            "strided layers (csrc/depthwise.hip)",
                      by / (ms * 1e-3) / 1e9 if ms else 0.0,
-                     "algorithmic bytes (input + output, bf16) of the bracketed depthwise launches / their time; the "
-                     "kernels are VALU-bound (2 K FLOP per element, K = 33 ... 87), so this is far below the HBM peak "
-                     "by construction", depthwise_ms_per_train_step=ms, share_of_step=ms / res["ms_per_step"],
+                     "algorithmic bytes (input + output, bf16) of the bracketed depthwise launches / their time (event "
+                     "pairs around single launches: the 256-channel ones sit at the ~8 us host floor of a call)",
+                     depthwise_ms_per_train_step=ms, share_of_step=ms / res["ms_per_step"],
                      families=fb)
   if key in ("nmt", "tacotron"):
     # sequential decoder loops: price the loop launches
