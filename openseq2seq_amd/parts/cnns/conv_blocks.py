@@ -89,6 +89,8 @@ GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 DRES_FWD_SIDE = os.environ.get("OS2S_DRES_FWD_SIDE", "1") != "0"
 # A/B knob: 0 = the dense-residual chains share the weight-gradient side stream (FIFO behind its backlog)
 DRES_OWN_STREAM = os.environ.get("OS2S_DRES_OWN_STREAM", "1") != "0"
+# A/B knob: 0 = block ends on the dense-residual algebra keep their own BatchNorm-backward reduction pass
+DRES_FUSE_BN_BWD = os.environ.get("OS2S_DRES_FUSE_BN_BWD", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
@@ -801,6 +803,12 @@ def conv_bn_dres_actv(main, x, dfw, out_lens, activation_fn, training, tape, kee
     return result
   dpass, k = dfw["dres"], dfw["k"]
   dfw = None
+  if FUSE_BN_BWD and DRES_FUSE_BN_BWD and act == 1 and type(main) is ConvBN and (lens is None or main.stride == 1):
+    # ONE BatchNorm'd tensor enters the sum (the residual sum R carries no statistics of its own): as for a
+    # single-input layer, the data gradient that finalises this output's gradient may apply the ReLU / dropout
+    # backward and leave (sum dz, sum dz * y_main) in its epilogue (ConvBN.backward_branch, final=True)
+    result.bn_y = fw["y"]
+    result.bn_scale = 1.0 / (keep_prob if training else 1.0)
 
   def backward():
     result.wait_grad()
@@ -809,15 +817,22 @@ def conv_bn_dres_actv(main, x, dfw, out_lens, activation_fn, training, tape, kee
     rows = B * tout
     c1 = torch.empty((1, C), dtype=torch.float32, device=out.device)
     c2 = torch.empty((1, C), dtype=torch.float32, device=out.device)
-    dz = torch.empty_like(out)
-    partial = torch.empty((capi.bn_act_bwd_num_parts(rows), 2, C), dtype=torch.float32, device=out.device)
-    capi.bn_act_bwd_reduce(dout, out, [fw["y"]], [fw["mean"]], [fw["rstd"]], dz, partial, lens, act, keep_prob, seed)
-    capi.bn_bwd_finalize_multi(partial, rows, [main.gamma.grad], [main.beta.grad], True, c1, c2)
+    dz_to_len = False
+    if result.grad_masked:
+      dz, partial = dout, result.bias_part
+      result.bias_part = None
+      capi.bn_bwd_finalize_raw(partial, rows, fw["mean"], fw["rstd"], main.gamma.grad, main.beta.grad, True, c1[0], c2[0])
+      dz_to_len = lens is not None       # rows past the sequence ends were not written: never read below
+    else:
+      dz = torch.empty_like(out)
+      partial = torch.empty((capi.bn_act_bwd_num_parts(rows), 2, C), dtype=torch.float32, device=out.device)
+      capi.bn_act_bwd_reduce(dout, out, [fw["y"]], [fw["mean"]], [fw["rstd"]], dz, partial, lens, act, keep_prob, seed)
+      capi.bn_bwd_finalize_multi(partial, rows, [main.gamma.grad], [main.beta.grad], True, c1, c2)
     result.grad = None
     # every residual branch (kernel / gamma / beta gradients) and the finished data gradient of source k
     src = dpass.acts[k]
     with on_side_stream(dz.device, dz, c1, which=1) as ctx:
-      dpass.backward_end(k, dz, c1[0])
+      dpass.backward_end(k, dz, c1[0], dz_lens=lens if dz_to_len else None)
       if src.requires_grad:
         ctx.hand_over(src.grad)
         if ctx.side is not None:
@@ -826,7 +841,8 @@ def conv_bn_dres_actv(main, x, dfw, out_lens, activation_fn, training, tape, kee
     dy = torch.empty_like(fw["y"])
     ragged = lens is not None and type(main) is ConvBN and main.stride == 1
     capi.bn_bwd_apply(dz, fw["y"], main.gamma.master, fw["mean"], fw["rstd"], c1[0], c2[0], dy,
-                      out_len=lens if ragged else None, margin=(main.k - 1) * main.dil)
+                      out_len=lens if ragged else None, margin=(main.k - 1) * main.dil,
+                      dz_to_len=dz_to_len and ragged)
     fw["y"] = None
     if type(main) is ConvBN:
       # the last contribution to its input's gradient unless that input is itself a source of this block end

@@ -191,7 +191,7 @@ class DenseResidualPass(object):
     return dict(y=R, scale=plan.ones(E.cout), shift=E.shift, dres=self, k=k)
 
   # ---- backward ----------------------------------------------------------------------------------------------
-  def backward_end(self, k, dz, mean_dz):
+  def backward_end(self, k, dz, mean_dz, dz_lens=None):
     """dz [B, T, Cout_k] = the gradient at the block end's sum (activation / dropout / mask backward applied),
     mean_dz [Cout_k] = its column means: every branch's kernel / gamma / beta gradient, and — block end k is the
     last reader of source k in backward order — the complete residual data gradient of source k."""
@@ -204,7 +204,9 @@ class DenseResidualPass(object):
       self.dzcat = torch.empty((self.B, self.T, plan.dtot), dtype=torch.bfloat16, device=dz.device)
     for br in E.branches:
       br.kernel.grad, br.gamma.grad, br.beta.grad
-    capi.dres_copy_cols(dz, self.dzcat[:, :, E.doff:E.doff + E.cout])
+    # (dz_lens: dz came out of a data-gradient epilogue that writes the live windows only — rows past a sequence
+    # end are unwritten memory: masked here; the TN GEMM below visits live 64-row chunks only)
+    capi.dres_copy_cols(dz, self.dzcat[:, :, E.doff:E.doff + E.cout], dz_lens)
     E.P.zero_()
     capi.conv1x1_wgrad_grouped([dict(x=self.xcat[:, :, :E.kk], dy=dz, dw=E.P.view(1, E.cout, E.kk))],
                                in_len=self.lens)
