@@ -195,7 +195,10 @@ int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
  *   gemm_nt.split: f > 0 forces the tail split factor of os2s_gemm_nt*, 0 disables the split, < 0 = cost model
  *   gemm_nt.tile: 0 (default) = by shape, 256 = always the 256 x 256 tile, 160 = the 160-row x 256-column tile
  *     (eight waves over the columns; bit-identical results) whenever it is legal (no per-window statistics)
- *   depthwise.variant: 0 = the generic depthwise kernels only, < 0 = by shape
+ *   depthwise.variant: 0 = the generic depthwise kernels only, 1 = generic + register-window kernels (rounds 4 - 5),
+ *     < 0 = by shape (stride 1, dilation 1, K <= 96: the matrix-core kernels of round 6)
+ *   depthwise.ablate: measurement only (scratch/bench_depthwise.py): bit mask that switches parts of the matrix-core
+ *     depthwise kernels off (1 compute, 2 output / diagonal sums, 4 loads; results are wrong then)
  *   bn.act_fwd.groups, bn.act_fwd.rows, bn.act_bwd_reduce.groups, bn.act_bwd_reduce.rows, bn.bwd_apply.groups,
  *     bn.bwd_apply.rows: tiling of the three BatchNorm kernels (8-channel groups per workgroup 8 .. 256, rows
  *     per workgroup 8 .. 1024; tools/bench_bn_sweep.py); the reduce tiling also sets what

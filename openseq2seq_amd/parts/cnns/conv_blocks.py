@@ -89,6 +89,8 @@ GROUP_WGRAD_PP = os.environ.get("OS2S_GROUP_WGRAD_PP", "1") != "0"
 DRES_FWD_SIDE = os.environ.get("OS2S_DRES_FWD_SIDE", "1") != "0"
 # A/B knob: 0 = the dense-residual chains share the weight-gradient side stream (FIFO behind its backlog)
 DRES_OWN_STREAM = os.environ.get("OS2S_DRES_OWN_STREAM", "1") != "0"
+WGRAD_STREAMS = int(os.environ.get("OS2S_WGRAD_STREAMS", "1"))
+_WGRAD_RR = 0
 # A/B knob: 0 = block ends on the dense-residual algebra keep their own BatchNorm-backward reduction pass
 DRES_FUSE_BN_BWD = os.environ.get("OS2S_DRES_FUSE_BN_BWD", "1") != "0"
 
@@ -113,7 +115,7 @@ def _side_stream(device, which=0):
   chain queued behind a backlog of weight-gradient kernels would stall the main stream until the backlog drained."""
   if not _SIDE_STREAM_ENABLED or os.environ.get("OS2S_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
     return None
-  if which and not DRES_OWN_STREAM:
+  if which == 1 and not DRES_OWN_STREAM:
     which = 0
   key = (device.index, capi._stream().value) if not which else (device.index, capi._stream().value, which)
   st = _SIDE_STREAMS.get(key)
@@ -451,7 +453,10 @@ class ConvBN(object):
       tape.defer_conv_wgrad(self.kernel, key, dict(x=x, dy=dy, dw=self.kernel.grad), units,
                             dict(K=self.k, stride=1, dil=self.dil, pad_left=f["pad_left"], in_len=inp.lens))
       return
-    with on_side_stream(dy.device, inp.data, dy):
+    global _WGRAD_RR
+    _WGRAD_RR += 1
+    # (experiment, OS2S_WGRAD_STREAMS=2: the layers' weight gradients alternate between two side streams)
+    with on_side_stream(dy.device, inp.data, dy, which=0 if WGRAD_STREAMS < 2 else (0, 2)[_WGRAD_RR & 1]):
       capi.conv1d_wgrad(inp.data, dy, self.k, stride=self.stride, dil=self.dil,
                         pad_left=f["pad_left"], in_len=inp.lens, out=self.kernel.grad,
                         accumulate=True)

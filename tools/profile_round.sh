@@ -32,7 +32,9 @@ OS2S_WGRAD_STREAM=0 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
 python - <<PY
 import csv, glob, json, collections
 FAM = [("conv1d_pp_kernel", "conv fwd+dgrad, ping-pong tile (2 windows x 256 columns)"),
-       ("conv1d_ppn_kernel", "conv fwd, narrow ping-pong tiles (2 / 3 windows x 128 columns)"), ("conv1d_igemm_grouped_kernel", "grouped 1x1 fwd+dgrad, lockstep tile"),
+       ("conv1d_ppn_kernel", "conv fwd, narrow ping-pong tiles (2 / 3 windows x 128 columns)"), ("conv1d_igemm_grouped_kernel", "grouped 1x1, lockstep tile (round 6: the W C products of the dense-residual statistics)"),
+       ("conv1x1_pp_kernel", "dense-residual GEMMs over the concatenated block inputs / gradients (256 x 256 ping-pong tile, row strides)"),
+       ("conv1d_wgrad1x1_pp_kernel", "K = 1 TN GEMMs: dense-residual P_k and Gram matrices"),
        ("conv1d_igemm_kernel", "conv fwd+dgrad, lockstep tile"), ("conv1d_wgrad_pp_kernel", "wgrad, ping-pong tile"),
        ("conv1d_wgrad_kernel", "wgrad, lockstep tile")]
 def fam(name):
@@ -60,9 +62,9 @@ for k, desc in FAM:
               "fetch_bytes_per_launch_two_streams": 2.0 * f * 1024.0,
               "fetch_bytes_per_launch_alone_on_the_gpu": 2.0 * fsa[k]["FETCH_SIZE"] / max(fsc[(k, "FETCH_SIZE")], 1) * 1024.0,
               "fetch_bytes_per_launch_alone_round5_rank_order": 2.0 * fxa[k]["FETCH_SIZE"] / max(fxc[(k, "FETCH_SIZE")], 1) * 1024.0}
-    if "wgrad" not in k:
+    if "wgrad" not in k and "grouped" not in k:
         tf += fa[k]["FETCH_SIZE"]; tw += wa[k]["WRITE_SIZE"]; n += nf
-out = {"command": "$P", "kernel": "conv1d_pp_kernel + conv1d_igemm_kernel + conv1d_igemm_grouped_kernel (the launches bench.py's roofline block times: fwd + dgrad)",
+out = {"command": "$P", "kernel": "conv1d_pp_kernel + conv1d_ppn_kernel + conv1d_igemm_kernel + conv1x1_pp_kernel (the launches bench.py's roofline block times: fwd + dgrad)",
        "launches": n, "FETCH_SIZE_KB_per_launch_raw": tf / max(n, 1), "WRITE_SIZE_KB_per_launch_raw": tw / max(n, 1),
        "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled; WRITE_SIZE as reported (MI355X_MICROARCH.md)",
        "hbm_bytes_per_launch": (2.0 * tf / max(n, 1) + tw / max(n, 1)) * 1024.0, "per_kernel": per}
