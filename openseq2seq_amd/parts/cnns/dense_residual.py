@@ -28,6 +28,9 @@ from ... import capi
 
 # A/B knob: 0 = branch-by-branch residual path everywhere (rounds 1 - 5)
 ENABLED = os.environ.get("OS2S_DENSE_RES_ALGEBRA", "1") != "0"
+# A/B knob: 0 = the Gram matrices on the lockstep TN kernel (fp32 atomics over a wide reduction split) instead of the
+# ping-pong kernel (one owner per tile sums up to 17 slabs)
+GRAM_PINGPONG = os.environ.get("OS2S_DRES_GRAM_PP", "1") != "0"
 
 
 class _End(object):
@@ -166,7 +169,8 @@ class DenseResidualPass(object):
     part = capi.dres_copy_cols(x.data, xs, self.lens, want_colsum=self.training)
     if self.training:
       S.gram.zero_()
-      capi.conv1x1_wgrad_grouped([dict(x=xs, dy=x.data, dw=S.gram.view(1, C, C))], in_len=self.lens)
+      capi.conv1x1_wgrad_grouped([dict(x=xs, dy=x.data, dw=S.gram.view(1, C, C))], in_len=self.lens,
+                                 pingpong=GRAM_PINGPONG or capi.deterministic())
       capi.dres_cov(part, S.gram, B * T, S.s, S.m, S.chl)
 
   def forward_end(self, k):

@@ -30,14 +30,36 @@ LAYERS = [
 @pytest.mark.parametrize("shape", [(3, 200, 72), (4, 700, 200)])
 def test_depthwise_kernels(cuda, K, stride, dil, shape):
   """Depthwise forward / flipped-tap data gradient / weight gradient vs conv1d(groups=C) of the
-  same bf16 inputs. Stride 1 with dilation 1 / 2 / 4 takes the register-window kernels (K = 1, 16,
-  33, 75: one to five 16-tap groups, a partial last group; dilation = residue classes of the rows;
-  T = 700: three 256-step tiles per sample, one of them partial; C = 72 / 200: a partial 64-channel
-  block), stride 2 the generic kernels."""
+  same bf16 inputs. Stride 1, dilation 1, 2 <= K <= 96 takes the matrix-core kernels of round 6 (K = 16, 33, 75:
+  4 / 4 / 7 window steps, 2 / 3 / 6 window tiles of the weight gradient; C = 72 / 200: a partial 32- and
+  16-channel block); stride 1 with dilation 2 / 4 and K = 1 the register-window kernels (dilation = residue
+  classes of the rows; T = 700: three 256-step tiles per sample, one of them partial), stride 2 the generic
+  kernels."""
+  _check_depthwise(cuda, K, stride, dil, shape)
+
+
+@pytest.mark.parametrize("variant", [-1, 1])
+@pytest.mark.parametrize("K", [2, 33, 64, 96])
+@pytest.mark.parametrize("shape", [(2, 2100, 96), (5, 1000, 40), (33, 130, 64)])
+def test_depthwise_matrix_core_kernels_tile_edges(cuda, K, shape, variant):
+  """The matrix-core kernels past one tile: T = 2100 = three 928 / 992-step tiles per sample (the last one partial,
+  the weight gradient's accumulators carried over the tiles a workgroup walks), T = 1000 just past a tile, 33 samples
+  of 130 steps (tiles with 4 - 5 of 29 - 31 segments), the smallest and the largest K the kernels take; variant 1 =
+  the same shapes on the register-window kernels (the two families against the same reference)."""
+  from openseq2seq_amd import _lib
+  import ctypes
+  _lib.lib().os2s_set_option(b"depthwise.variant", ctypes.c_double(variant))
+  try:
+    _check_depthwise(cuda, K, 1, 1, shape)
+  finally:
+    _lib.lib().os2s_set_option(b"depthwise.variant", ctypes.c_double(-1))
+
+
+def _check_depthwise(cuda, K, stride, dil, shape):
   from openseq2seq_amd import capi
   g = torch.Generator().manual_seed(K)
   B, T, C = shape
-  lens = torch.tensor([T, (2 * T) // 3 + 1, T // 4 + 7] + [T // 2] * (B - 3), dtype=torch.int32)
+  lens = torch.tensor(([T, (2 * T) // 3 + 1, T // 4 + 7] + [T // 2] * max(B - 3, 0))[:B], dtype=torch.int32)
   x = torch.randn(B, T, C, generator=g).to(torch.bfloat16)
   x = x * (torch.arange(T)[None, :, None] < lens[:, None, None])      # inputs are stored masked
   w = torch.randn(K, C, generator=g) * 0.3
