@@ -213,6 +213,93 @@ def lstm_kernel_groups(params):
   return {k: [p for _, p in sorted(v, key=lambda t: t[0])] for k, v in groups.items()}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# cuDNN layers (tf.contrib.cudnn_rnn.CudnnGRU / CudnnLSTM: DeepSpeech2's GRU stack, encoders/ds2_encoder.py:294-328;
+# Tacotron 2's encoder LSTM, encoders/tacotron2_encoder.py:254-263). The graph holds ONE opaque buffer per layer
+# stack; its Saveable (tensorflow/contrib/cudnn_rnn/python/ops/cudnn_rnn_ops.py, CudnnOpaqueParamsSaveable) writes
+# the checkpoint in the "canonical" form a CudnnCompatible{GRU,LSTM}Cell restores from:
+#   <layer scope>/stack_bidirectional_rnn/cell_<l>/bidirectional_rnn/{fw,bw}/<cell>/...        (bidirectional)
+#   <layer scope>/rnn/multi_rnn_cell/cell_<l>/<cell>/...                                        (unidirectional)
+#   GRU  (<cell> = cudnn_compatible_gru_cell):  gates/kernel [in + H, 2H] (columns: reset | update; rows: input,
+#        then state), gates/bias [2H] = b_W + b_R of the two gates, candidate/input_projection/{kernel [in, H],
+#        bias}, candidate/hidden_projection/{kernel [H, H], bias} (cuDNN applies the reset gate to R_h h + b_Rh,
+#        so the two candidate biases stay apart)
+#   LSTM (<cell> = cudnn_compatible_lstm_cell): kernel [in + H, 4H] in LSTMBlockCell's gate order i, c, f, o
+#        (cuDNN's is i, f, c, o), bias [4H] = b_W + b_R.
+# The device keeps cuDNN's own form per direction — wx_0 [1, G H, in], wh [1, G H, H], bias (b_W), bias_h (b_R),
+# gate rows r, z, n / i, f, g, o (csrc/rnn.hip) — so the exchange is a stack / split / transpose; on the way IN
+# the summed gate biases are halved over b_W and b_R, as the Saveable does. Canonical tensors are fp32 under the
+# plain names (the Saveable converts the stored fp32 buffer). TensorFlow is not in /root/reference: the layout
+# above is restated from the TF 1.x source; tests/test_checkpoint_shapes.py holds the exported tensors to the
+# CudnnCompatible cells' equations against oracle/rnn.py.
+# ---------------------------------------------------------------------------------------------------------
+_CUDNN_PART = re.compile(r"^(.*/(?:cudnn_gru|cudnn_lstm|cudnn_rnn))/layer_(\d+)/(fw|bw)/(wx_0|wh|bias|bias_h)$")
+_CUDNN_TF_ORDER = {3: (0, 1, 2), 4: (0, 2, 1, 3)}       # device gate index of TF's k-th gate block
+
+
+def cudnn_groups(params):
+  """{(layer scope, layer, 'fw' | 'bw'): {'wx_0': p, 'wh': p, 'bias': p, 'bias_h': p}} for the complete cuDNN-form
+  directions among `params` (objects with .name and .shape)."""
+  groups = {}
+  for p in params:
+    m = _CUDNN_PART.match(p.name)
+    if m:
+      groups.setdefault((m.group(1), int(m.group(2)), m.group(3)), {})[m.group(4)] = p
+  return {k: v for k, v in groups.items() if len(v) == 4}
+
+
+def cudnn_canonical_prefix(scope, layer, tag, bidirectional, gates):
+  cell = "cudnn_compatible_gru_cell" if gates == 3 else "cudnn_compatible_lstm_cell"
+  if bidirectional:
+    return "%s/stack_bidirectional_rnn/cell_%d/bidirectional_rnn/%s/%s" % (scope, layer, tag, cell)
+  return "%s/rnn/multi_rnn_cell/cell_%d/%s" % (scope, layer, cell)
+
+
+def cudnn_to_canonical(wx, wh, bx, bh):
+  """Device arrays of one direction (wx [1, G H, in], wh [1, G H, H], bx / bh [G H]) -> {suffix: TF tensor}."""
+  H = wh.shape[2]
+  G = wh.shape[1] // H
+  wx, wh = wx[0], wh[0]
+  blk = lambda a, g: a[g * H:(g + 1) * H]
+  if G == 3:
+    rz = lambda a: np.concatenate([blk(a, 0), blk(a, 1)], axis=0)
+    return {"gates/kernel": np.concatenate([rz(wx).T, rz(wh).T], axis=0),
+            "gates/bias": rz(bx) + rz(bh),
+            "candidate/input_projection/kernel": blk(wx, 2).T.copy(),
+            "candidate/input_projection/bias": blk(bx, 2).copy(),
+            "candidate/hidden_projection/kernel": blk(wh, 2).T.copy(),
+            "candidate/hidden_projection/bias": blk(bh, 2).copy()}
+  order = _CUDNN_TF_ORDER[4]
+  st = lambda a: np.concatenate([blk(a, g) for g in order], axis=0)
+  return {"kernel": np.concatenate([st(wx).T, st(wh).T], axis=0), "bias": st(bx) + st(bh)}
+
+
+def canonical_to_cudnn(get, gates, n_in, H):
+  """Inverse: get(suffix) -> TF tensor or None. Returns (wx, wh, bx, bh) in device layout, or None when a tensor is
+  missing or mis-shaped."""
+  def stack(blocks):
+    return np.concatenate(blocks, axis=0)
+  if gates == 3:
+    gk, gb = get("gates/kernel"), get("gates/bias")
+    ik, ib = get("candidate/input_projection/kernel"), get("candidate/input_projection/bias")
+    hk, hb = get("candidate/hidden_projection/kernel"), get("candidate/hidden_projection/bias")
+    if any(a is None for a in (gk, gb, ik, ib, hk, hb)):
+      return None
+    if gk.shape != (n_in + H, 2 * H) or ik.shape != (n_in, H) or hk.shape != (H, H) or gb.shape != (2 * H,):
+      return None
+    wx = stack([gk[:n_in].T, ik.T])[None]
+    wh = stack([gk[n_in:].T, hk.T])[None]
+    return wx, wh, stack([0.5 * gb, ib]), stack([0.5 * gb, hb])
+  k, b = get("kernel"), get("bias")
+  if k is None or b is None or k.shape != (n_in + H, 4 * H) or b.shape != (4 * H,):
+    return None
+  order = _CUDNN_TF_ORDER[4]                       # TF block j holds device gate order[j]
+  dev_of = [order.index(g) for g in range(4)]       # device gate g sits in TF block dev_of[g]
+  kt = k.T
+  pick = lambda a: stack([a[j * H:(j + 1) * H] for j in dev_of])
+  return pick(kt[:, :n_in])[None], pick(kt[:, n_in:])[None], pick(0.5 * b), pick(0.5 * b)
+
+
 def _half_in_reference(p):
   """Is this variable DT_HALF with an fp32 master twin in a mixed-precision graph of the reference? Everything
   the mixed-precision wrapper sees (optimizers/mp_wrapper.py:55-82) — kernels AND the biases of dense / recurrent
@@ -238,6 +325,15 @@ def model_variables(model):
   mixed = model.params.get("dtype", "mixed") == "mixed"
   groups = lstm_kernel_groups(store.params)
   grouped = {p.name for ps in groups.values() for p in ps}
+  cgroups = cudnn_groups(store.params)
+  bidir = {scope for scope, _, tag in cgroups if tag == "bw"}
+  for (scope, layer, tag), parts in cgroups.items():
+    dev = {k: parts[k].master.detach().cpu().numpy() for k in parts}
+    gates = parts["wh"].shape[1] // parts["wh"].shape[2]
+    prefix = cudnn_canonical_prefix(scope, layer, tag, scope in bidir, gates)
+    for suffix, arr in cudnn_to_canonical(dev["wx_0"], dev["wh"], dev["bias"], dev["bias_h"]).items():
+      out["%s/%s" % (prefix, suffix)] = np.ascontiguousarray(arr, dtype=np.float32)
+    grouped |= {p.name for p in parts.values()}
   for ref, ps in groups.items():
     # [1, 4H, in_k] blocks -> one [sum in_k, 4H] kernel, the cell's inputs first, h last
     k = np.concatenate([p.master.detach().cpu().numpy()[0].T for p in ps], axis=0)
@@ -345,6 +441,22 @@ def load(model, prefix, restore_optimizer=True, strict=True):
     for p in ps:
       split[p.name] = k[row:row + p.shape[2]].T[None]
       row += p.shape[2]
+  cgroups = cudnn_groups(store.params)
+  bidir = {scope for scope, _, tag in cgroups if tag == "bw"}
+  for (scope, layer, tag), parts in cgroups.items():
+    H = parts["wh"].shape[2]
+    gates, n_in = parts["wh"].shape[1] // H, parts["wx_0"].shape[2]
+    prefix = cudnn_canonical_prefix(scope, layer, tag, scope in bidir, gates)
+
+    def get(suffix, prefix=prefix):
+      for n in (MASTER_PREFIX + prefix + "/" + suffix, prefix + "/" + suffix):
+        if n in data:
+          return np.asarray(data[n], np.float32)
+      return None
+    got = canonical_to_cudnn(get, gates, n_in, H)
+    if got is not None:               # else: the per-parameter names of this repository's older files, below
+      for key, a in zip(("wx_0", "wh", "bias", "bias_h"), got):
+        split[parts[key].name] = a
   for p in store.params:
     a = split.get(p.name)
     if a is None:

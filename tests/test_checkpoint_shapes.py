@@ -297,9 +297,22 @@ def test_tacotron_decoder_checkpoints_carry_the_reference_graphs_variables(monke
   for p in store.params:
     p.master = torch.zeros_like(p.master)
   assert ck.load(m, prefix, restore_optimizer=False) == []
+  # the encoder's CudnnLSTM is written as TF's cuDNN Saveable writes it (canonical kernel / bias per direction):
+  # the two cuDNN bias vectors are stored as their SUM and come back as two halves of it
+  cud = ck.cudnn_groups(store.params)
+  assert len(cud) == 2
+  halves = {}
+  for parts in cud.values():
+    halves[parts["bias"].name] = parts["bias_h"].name
+    halves[parts["bias_h"].name] = parts["bias"].name
+    assert any(k.endswith("/cudnn_compatible_lstm_cell/kernel") for k in arrays)
+  now = {p.name: p.master for p in store.params}
   for p in store.params:
     n = getattr(p, "logical_out", None)
-    if n is None:
+    if p.name in halves:
+      assert torch.equal(p.master + now[halves[p.name]], before[p.name] + before[halves[p.name]]), p.name
+      assert torch.equal(p.master, now[halves[p.name]]), p.name
+    elif n is None:
       assert torch.equal(p.master, before[p.name]), p.name
     elif p.master.dim() == 3:
       assert torch.equal(p.master[:, :n], before[p.name][:, :n]) and not p.master[:, n:].any(), p.name
@@ -398,3 +411,82 @@ def test_optimizer_slots_follow_the_variables_when_the_creation_order_changes():
     assert ck.restore_slots(cold, op, legacy, "old.ckpt") == "skipped"
   assert any("NOT restored" in str(x.message) for x in w)
   assert float(cold.m1.abs().sum()) == 0.0 and float(op.state[3]) == 3.0     # scalars restored, moments not
+
+
+def _tf_cudnn_compatible_gru(x, tf, H):
+  """tf.contrib.cudnn_rnn.CudnnCompatibleGRUCell over a sequence (its call(): gates = sigmoid([x, h] . gates/kernel +
+  gates/bias), r, u = split(gates); candidate = tanh(x . Wc + bc + r * (h . Rc + bRc)); h' = u h + (1 - u) candidate)."""
+  sig = lambda a: 1.0 / (1.0 + np.exp(-a))
+  B, T, _ = x.shape
+  h = np.zeros((B, H))
+  out = []
+  for t in range(T):
+    g = sig(np.concatenate([x[:, t], h], 1) @ tf["gates/kernel"] + tf["gates/bias"])
+    r, u = g[:, :H], g[:, H:]
+    c = np.tanh(x[:, t] @ tf["candidate/input_projection/kernel"] + tf["candidate/input_projection/bias"] +
+                r * (h @ tf["candidate/hidden_projection/kernel"] + tf["candidate/hidden_projection/bias"]))
+    h = u * h + (1 - u) * c
+    out.append(h)
+  return np.stack(out, 1)
+
+
+def _tf_cudnn_compatible_lstm(x, tf, H):
+  """CudnnCompatibleLSTMCell = LSTMBlockCell(forget_bias=0): i, ci, f, o = split([x, h] . kernel + bias);
+  c' = sigmoid(f) c + sigmoid(i) tanh(ci); h' = sigmoid(o) tanh(c')."""
+  sig = lambda a: 1.0 / (1.0 + np.exp(-a))
+  B, T, _ = x.shape
+  h, c = np.zeros((B, H)), np.zeros((B, H))
+  out = []
+  for t in range(T):
+    z = np.concatenate([x[:, t], h], 1) @ tf["kernel"] + tf["bias"]
+    i, ci, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+    c = sig(f) * c + sig(i) * np.tanh(ci)
+    h = sig(o) * np.tanh(c)
+    out.append(h)
+  return np.stack(out, 1)
+
+
+def test_cudnn_layers_exchange_canonical_checkpoint_tensors():
+  """DeepSpeech2's CudnnGRU stack and Tacotron 2's CudnnLSTM encoder are written as the tensors TF's cuDNN Saveable
+  writes (CudnnCompatible{GRU,LSTM}Cell layout: utils/checkpoint.py, cuDNN block). The exported tensors, run through
+  the CudnnCompatible cells' own equations, must reproduce what the device-layout parameters compute (oracle/rnn.py,
+  cuDNN gate form) — and come back unchanged in function (gate biases return as two halves of their sum)."""
+  import torch
+  from collections import namedtuple
+  from oracle import rnn as orn
+  rng = np.random.RandomState(3)
+  B, T, n_in, H = 3, 7, 10, 6
+  x = rng.randn(B, T, n_in)
+  for kind, G, tf_cell in (("gru", 3, _tf_cudnn_compatible_gru), ("lstm", 4, _tf_cudnn_compatible_lstm)):
+    wx = rng.randn(1, G * H, n_in) * 0.4
+    wh = rng.randn(1, G * H, H) * 0.4
+    bx, bh = rng.randn(G * H) * 0.3, rng.randn(G * H) * 0.3
+    tfv = ck.cudnn_to_canonical(wx, wh, bx, bh)
+    if kind == "gru":
+      assert tfv["gates/kernel"].shape == (n_in + H, 2 * H) and tfv["candidate/hidden_projection/kernel"].shape == (H, H)
+    else:
+      assert tfv["kernel"].shape == (n_in + H, 4 * H) and tfv["bias"].shape == (4 * H,)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+    ref = orn.cudnn_rnn(kind, t(x), None, t(wx[0]), t(wh[0]), t(bx), t(bh)).numpy()
+    np.testing.assert_allclose(tf_cell(x, tfv, H), ref, rtol=1e-9, atol=1e-10)
+    back = ck.canonical_to_cudnn(lambda s: tfv.get(s), G, n_in, H)
+    assert back is not None
+    wx2, wh2, bx2, bh2 = back
+    np.testing.assert_array_equal(wx2, wx)
+    np.testing.assert_array_equal(wh2, wh)
+    ref2 = orn.cudnn_rnn(kind, t(x), None, t(wx2[0]), t(wh2[0]), t(bx2), t(bh2)).numpy()
+    np.testing.assert_allclose(ref2, ref, rtol=1e-9, atol=1e-10)
+    assert ck.canonical_to_cudnn(lambda s: None, G, n_in, H) is None
+  # names: the scopes TF's Saveable writes under, per direction and layer
+  P = namedtuple("P", "name shape")
+  names = []
+  for l in range(2):
+    for tag in ("fw", "bw"):
+      base = "ForwardPass/ds2_encoder/cudnn_gru/layer_%d/%s/" % (l, tag)
+      names += [P(base + "wx_0", (1, 18, 10)), P(base + "wh", (1, 18, 6)), P(base + "bias", (18,)), P(base + "bias_h", (18,))]
+  names.append(P("ForwardPass/tacotron2_encoder/cudnn_rnn/layer_0/fw/wx_0", (1, 24, 10)))     # incomplete: not a group
+  groups = ck.cudnn_groups(names)
+  assert sorted(groups) == [("ForwardPass/ds2_encoder/cudnn_gru", l, tag) for l in range(2) for tag in ("bw", "fw")]
+  assert ck.cudnn_canonical_prefix("ForwardPass/ds2_encoder/cudnn_gru", 1, "bw", True, 3) == \
+      "ForwardPass/ds2_encoder/cudnn_gru/stack_bidirectional_rnn/cell_1/bidirectional_rnn/bw/cudnn_compatible_gru_cell"
+  assert ck.cudnn_canonical_prefix("S/cudnn_rnn", 0, "fw", False, 4) == "S/cudnn_rnn/rnn/multi_rnn_cell/cell_0/cudnn_compatible_lstm_cell"
