@@ -1016,6 +1016,21 @@ int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x, const flo
 int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t* x, const uint16_t* dy,
                                 float* dw, const int32_t* in_len, int B, int Tin, int Tout, int C,
                                 int K, int stride, int dil, int padL);
+/* The data gradient of a stride-1 / dilation-1 depthwise convolution (2 <= K <= 96) as the LAST contribution to
+ * the gradient of the output of a conv + BatchNorm + ReLU (+ dropout) layer (conv_bn_actv,
+ * parts/cnns/conv_blocks.py:170-232, followed by a sep_conv1d layer), with that layer's activation backward and
+ * the partial sums of its BatchNorm backward in the kernel's store phase (the depthwise twin of
+ * os2s_conv1d_dgrad_bnact_ws):
+ *   dx = mask(conv(dz, flipped taps) + addend),  mask = (mask_ref > 0) ? mask_scale : 0   (addend may be NULL or dx)
+ *   stats[part, 0, c] = sum over the part's rows of dx,  stats[part, 1, c] = sum of dx * stat_ref
+ * dz [B, Tin, C], dx / addend / mask_ref / stat_ref [B, Tout, C] bf16; stats fp32
+ * [os2s_depthwise_dgrad_bnact_num_parts(B, Tout, K), 2, C], ZERO on entry (tiles past out_len are not visited);
+ * os2s_bn_bwd_finalize_raw turns them into dgamma / dbeta / c1 / c2. padL = (K - 1) - the forward padding. */
+int os2s_depthwise_dgrad_bnact_num_parts(int B, int Tout, int K);
+int os2s_depthwise_dgrad_bnact(os2s_stream_t stream, const uint16_t* dz, const float* w, uint16_t* dx,
+                               const uint16_t* addend, float* stats, const int32_t* out_len, int B, int Tin,
+                               int Tout, int C, int K, int padL, const uint16_t* mask_ref, float mask_scale,
+                               const uint16_t* stat_ref);
 
 /* ------------------------------------------------------------------------
  * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:

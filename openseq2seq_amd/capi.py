@@ -1953,6 +1953,30 @@ def depthwise_conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_
   return y
 
 
+def depthwise_dgrad_bnact_supported(K, stride, dil):
+  return stride == 1 and dil == 1 and 2 <= K <= 96
+
+
+def depthwise_dgrad_bnact(dz, w, dx, *, pad_left, out_len, mask_ref, mask_scale, stat_ref, addend=None):
+  """dx = mask(depthwise_conv(dz, flipped w) + addend), mask = (mask_ref > 0) * mask_scale; returns the
+  BatchNorm-backward partials [nparts, 2, C] = (sum dx, sum dx * stat_ref) (os2s_depthwise_dgrad_bnact). dz [B,Tin,C],
+  dx / addend / mask_ref / stat_ref [B,Tout,C] bf16 contiguous (addend may be dx itself); w fp32 [K,C]."""
+  B, Tin, C = dz.shape
+  K = w.shape[0]
+  Tout = dx.shape[1]
+  assert tuple(dx.shape) == (B, Tout, C) == tuple(mask_ref.shape) == tuple(stat_ref.shape)
+  assert dz.is_contiguous() and dx.is_contiguous() and mask_ref.is_contiguous() and stat_ref.is_contiguous()
+  assert addend is None or (tuple(addend.shape) == tuple(dx.shape) and addend.is_contiguous())
+  n = int(_fn("os2s_depthwise_dgrad_bnact_num_parts", (c_int, c_int, c_int))(B, Tout, K))
+  stats = _zero_arena.take((n, 2, C), dz.device)
+  f = _fn("os2s_depthwise_dgrad_bnact", (c_void_p,) * 7 + (c_int,) * 6 + (c_void_p, c_float, c_void_p))
+  _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(w, torch.float32), _ptr(dx, torch.bfloat16),
+               _ptr(addend, torch.bfloat16, True), _ptr(stats, torch.float32), _ptr(out_len, torch.int32, True),
+               B, Tin, Tout, C, K, int(pad_left), _ptr(mask_ref, torch.bfloat16), float(mask_scale),
+               _ptr(stat_ref, torch.bfloat16)), "os2s_depthwise_dgrad_bnact")
+  return stats
+
+
 def depthwise_conv1d_wgrad(x, dy, dw, *, stride=1, dil=1, pad_left=None, in_len=None):
   """dw fp32 [K,C] += sum dy * shifted x."""
   B, Tin, C = x.shape

@@ -22,6 +22,10 @@ struct DwArgs {
   const int32_t* in_len; const int32_t* out_len;
   int B, Tin, Tout, C, K, stride, dil, padL, flip, R;
   int tile0;      // generic weight gradient: first (sample, time tile) of this launch (deterministic mode: one per launch)
+  // matrix-core forward kernel as the LAST data gradient of a conv + BatchNorm + ReLU (+ dropout) layer's output
+  // (os2s_depthwise_dgrad_bnact): y = mask(conv + addend), mask = (mask_ref > 0) * mask_scale, and
+  // stats[blockIdx.x][0 | 1][c] = sum over the tile's rows of y, y * stat_ref (all in y's layout; addend may be y)
+  const bf16_t* mask_ref; const bf16_t* stat_ref; const bf16_t* addend; float mask_scale; float* stats;
 };
 
 __device__ __forceinline__ void dw_stage_x(const DwArgs& p, int b, int t0, int c0, float* xs, int len_b) {
@@ -485,11 +489,24 @@ __global__ __launch_bounds__(512, 2) void depthwise_mfma_fwd_kernel(DwArgs p) {
   const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * Tt, c0 = blockIdx.y * kDmCh;
   int len_b = p.Tin;
   if (p.in_len) len_b = min(max(p.in_len[b], 0), p.Tin);
-  if (p.out_len && t0 >= p.out_len[b]) return;             // never-read output tile
   const int rows_out = min(Tt, p.Tout - t0);
+  if (p.out_len && t0 >= p.out_len[b]) {                   // never-read output tile
+    if (p.mask_ref) {
+      // fused data gradient: the producer's BatchNorm backward may walk every row (separable producers): zeros
+      const int ncg0 = min(4, (p.C - c0) >> 3);
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      for (int q = tid; q < rows_out * ncg0; q += 512) {
+        const int r = q / ncg0, cg = q - r * ncg0;
+        *reinterpret_cast<u32x4*>(p.y + ((long long)b * p.Tout + t0 + r) * p.C + c0 + cg * 8) = z;
+      }
+    }
+    return;
+  }
   const int ncg = min(4, (p.C - c0) >> 3);                  // 8-channel groups of this block
-  if (t0 - p.padL >= len_b) {
+  if (t0 - p.padL >= len_b && !p.mask_ref) {
     // the whole input window lies past the sequence end: exact zeros
+    // (fused data gradient: the tile still carries the addend and the statistics — the general path, whose row
+    // loads are all masked)
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int q = tid; q < rows_out * ncg; q += 512) {
       const int r = q / ncg, cg = q - r * ncg;
@@ -612,6 +629,11 @@ __global__ __launch_bounds__(512, 2) void depthwise_mfma_fwd_kernel(DwArgs p) {
   // ---- planes -> rows: 4 time steps x 8 channels per item ------------------------------------------------
   bf16_t* const yb = p.y + ((long long)b * p.Tout + t0) * p.C + c0;
   const int n4o = (p.tile0 & 2) ? 0 : (rows_out + 3) >> 2;
+  const bool fused = p.mask_ref != nullptr;
+  const long long tile_off = ((long long)b * p.Tout + t0) * p.C + c0;
+  float sz[8], sy[8];                       // fused: sums of the stored values / of stored value x stat_ref
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sz[e] = 0.f; sy[e] = 0.f; }
   for (int q = tid; q < n4o * 4; q += 512) {
     const int cg = q & 3, p4 = q >> 2;
     if (cg >= ncg) continue;
@@ -628,11 +650,44 @@ __global__ __launch_bounds__(512, 2) void depthwise_mfma_fwd_kernel(DwArgs p) {
         const uint32_t a = v[2 * k][u >> 1], c = v[2 * k + 1][u >> 1];
         o[k] = (u & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
       }
-      *reinterpret_cast<u32x4*>(yb + (long long)(p4 * 4 + u) * p.C + cg * 8) = o;
+      const long long off = (long long)(p4 * 4 + u) * p.C + cg * 8;
+      if (fused) {
+        const u32x4 mk = *reinterpret_cast<const u32x4*>(p.mask_ref + tile_off + off);
+        const u32x4 st = *reinterpret_cast<const u32x4*>(p.stat_ref + tile_off + off);
+        u32x4 ad = {0u, 0u, 0u, 0u};
+        if (p.addend) ad = *reinterpret_cast<const u32x4*>(p.addend + tile_off + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float lo = bflo(o[k]) + bflo(ad[k]), hi = bfhi(o[k]) + bfhi(ad[k]);
+          lo = bflo(mk[k]) > 0.f ? lo * p.mask_scale : 0.f;
+          hi = bfhi(mk[k]) > 0.f ? hi * p.mask_scale : 0.f;
+          o[k] = pack2bf(lo, hi);
+          lo = bflo(o[k]); hi = bfhi(o[k]);            // the statistics see the stored (rounded) values
+          sz[2 * k] += lo; sz[2 * k + 1] += hi;
+          sy[2 * k] += lo * bflo(st[k]); sy[2 * k + 1] += hi * bfhi(st[k]);
+        }
+      }
+      *reinterpret_cast<u32x4*>(yb + off) = o;
+    }
+  }
+  if (!fused) return;
+  // per-channel sums of the tile in a fixed order: thread partials through LDS (the planes are dead), then one
+  // thread per (statistic, channel) adds the 128 partials of its 8-channel group
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(smc);            // [512][16]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = sz[e]; red[tid * 16 + 8 + e] = sy[e]; }
+  __syncthreads();
+  if (tid < 64) {
+    const int ch = tid & 31, which = tid >> 5;
+    if (c0 + ch < p.C) {
+      const int cg = ch >> 3, e = ch & 7;
+      float a = 0.f;
+      for (int t = cg; t < 512; t += 4) a += red[t * 16 + which * 8 + e];
+      p.stats[((long long)blockIdx.x * 2 + which) * p.C + c0 + ch] = a;
     }
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Stride-1, dilation-1 weight gradient on the matrix cores (round 6).
@@ -853,6 +908,41 @@ extern "C" int os2s_depthwise_conv1d_fwd(os2s_stream_t stream, const uint16_t* x
     return OS2S_ERR_LAUNCH;
   dim3 grid(B * ceil_div(Tout, kDwBT), ceil_div(C, kDwBC));
   OS2S_LAUNCH(depthwise_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  return OS2S_OK;
+}
+
+// The data gradient of a stride-1 / dilation-1 depthwise convolution as the LAST contribution to the gradient of a
+// conv + BatchNorm + ReLU (+ dropout) layer's output (QuartzNet: the next separable layer's depthwise half), with
+// that layer's activation backward and BatchNorm-backward partial sums in the store phase of the matrix-core
+// kernel — the depthwise twin of os2s_conv1d_dgrad_bnact_ws.
+extern "C" int os2s_depthwise_dgrad_bnact_num_parts(int B, int Tout, int K) {
+  if (K < 2 || K > 96) return 0;
+  return B * os2s::ceil_div(Tout, 32 * os2s::dm_geom(K).nseg);
+}
+
+extern "C" int os2s_depthwise_dgrad_bnact(os2s_stream_t stream, const uint16_t* dz, const float* w, uint16_t* dx,
+                                          const uint16_t* addend, float* stats, const int32_t* out_len, int B,
+                                          int Tin, int Tout, int C, int K, int padL, const uint16_t* mask_ref,
+                                          float mask_scale, const uint16_t* stat_ref) {
+  OS2S_REQUIRE(dz && w && dx && stats && mask_ref && stat_ref && K >= 2 && K <= 96);
+  DwArgs a{};
+  const int rc = dw_fill(a, B, Tin, Tout, C, K, 1, 1, padL);
+  if (rc != OS2S_OK) return rc;
+  a.x = (const bf16_t*)dz; a.w = w; a.y = (bf16_t*)dx; a.in_len = nullptr; a.out_len = out_len;
+  a.flip = 1;
+  a.mask_ref = (const bf16_t*)mask_ref; a.stat_ref = (const bf16_t*)stat_ref; a.addend = (const bf16_t*)addend;
+  a.mask_scale = mask_scale; a.stats = stats;
+  const DmGeom g = dm_geom(K);
+  const size_t ldsm = (size_t)kDmCh * g.plane_bytes + (size_t)8 * 2 * g.wt * sizeof(bf16_t);
+  OS2S_REQUIRE(ldsm <= 160 * 1024 && ldsm >= 512 * 16 * sizeof(float));
+  static bool attrm = false;
+  if (!attrm) {
+    if (hipFuncSetAttribute((const void*)depthwise_mfma_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return OS2S_ERR_LAUNCH;
+    attrm = true;
+  }
+  dim3 gridm(B * ceil_div(Tout, 32 * g.nseg), ceil_div(C, kDmCh));
+  OS2S_LAUNCH(depthwise_mfma_fwd_kernel, gridm, dim3(512), ldsm, (hipStream_t)stream, a);
   return OS2S_OK;
 }
 

@@ -93,6 +93,9 @@ WGRAD_STREAMS = int(os.environ.get("OS2S_WGRAD_STREAMS", "1"))
 _WGRAD_RR = 0
 # A/B knob: 0 = block ends on the dense-residual algebra keep their own BatchNorm-backward reduction pass
 DRES_FUSE_BN_BWD = os.environ.get("OS2S_DRES_FUSE_BN_BWD", "1") != "0"
+# A/B knob: 0 = separable layers keep their own BatchNorm-backward reduction pass (rounds 4 - 5); default = it rides
+# in the next separable layer's depthwise data gradient (capi.depthwise_dgrad_bnact)
+SEP_FUSE_BN_BWD = os.environ.get("OS2S_SEP_FUSE_BN_BWD", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
@@ -322,7 +325,7 @@ def current_tape():
 class Act(object):
   """An activation tensor + its valid lengths + (optionally) its gradient."""
   __slots__ = ("data", "lens", "grad", "grad_init", "requires_grad", "res_grad", "mask_scale",
-               "grad_masked", "bias_part", "bn_y", "bn_scale", "grad_event")
+               "grad_masked", "bias_part", "bn_y", "bn_scale", "grad_event", "bn_full_rows")
 
   def __init__(self, data, lens=None, requires_grad=True):
     self.data, self.lens = data, lens
@@ -341,6 +344,9 @@ class Act(object):
     # the BatchNorm-backward partials (sum dz, sum dz * y) in bias_part (capi.conv1d_dgrad_bnact)
     self.bn_y = None
     self.bn_scale = 1.0
+    # the producer's backward reads EVERY row of the finalised gradient (separable layers: their BatchNorm-backward
+    # apply pass is not ragged): only a consumer that defines all rows may finalise it
+    self.bn_full_rows = False
     # set by a data-gradient contribution enqueued on the SIDE stream (dense_residual.backward_end): the next
     # writer or reader of the gradient on another stream waits for it first
     self.grad_event = None
@@ -484,7 +490,8 @@ class ConvBN(object):
                         accumulate=inp.grad_init, out_len=inp.lens)
         inp.grad_init = True
         return
-      if final and FUSE_BN_BWD and inp.bn_y is not None and dy.is_contiguous() and g.is_contiguous():
+      if final and FUSE_BN_BWD and inp.bn_y is not None and not inp.bn_full_rows and dy.is_contiguous() and \
+         g.is_contiguous():
         # the producer's ReLU / dropout backward and its BatchNorm-backward partial sums ride in this
         # launch's epilogue: its own reduction pass (bn_act_bwd_reduce) is skipped
         inp.bias_part = capi.conv1d_dgrad_bnact(dy, self.kernel.wt16, g, dil=self.dil, pad_left=pl,
@@ -551,7 +558,10 @@ class SepConvBN(ConvBN):
   def trainable(self):
     return [self.depthwise, self.kernel, self.gamma, self.beta]
 
-  def backward_branch(self, inp, dy, f):
+  def backward_branch(self, inp, dy, f, final=False):
+    """final: as ConvBN.backward_branch — this is the last contribution to inp's gradient; when inp is the output
+    of a single-input conv + BatchNorm + ReLU layer its activation backward and BatchNorm-backward partial sums ride
+    in the store phase of the depthwise data gradient (capi.depthwise_dgrad_bnact)."""
     z = f["z"]
     rows = z.shape[0] * z.shape[1]
     units = ((self.cout + 255) // 256) * ((self.cin + 255) // 256)
@@ -574,6 +584,17 @@ class SepConvBN(ConvBN):
       capi.depthwise_conv1d_wgrad(inp.data, dz, self.depthwise.grad, stride=self.stride, dil=self.dil,
                                   pad_left=f["pad_left"], in_len=inp.lens)
     if inp.requires_grad:
+      if final and FUSE_BN_BWD and SEP_FUSE_BN_BWD and inp.bn_y is not None and dz.is_contiguous() and \
+         capi.depthwise_dgrad_bnact_supported(self.k, self.stride, self.dil) and \
+         (inp.grad is None or not inp.grad_init or inp.grad.is_contiguous()):
+        inp.wait_grad()
+        prev = inp.grad if inp.grad_init else None
+        out = prev if prev is not None else torch.empty_like(inp.data)
+        inp.bias_part = capi.depthwise_dgrad_bnact(dz, self.depthwise.master, out, pad_left=(self.k - 1) - f["pad_left"],
+                                                   out_len=inp.lens, mask_ref=inp.data, mask_scale=inp.bn_scale,
+                                                   stat_ref=inp.bn_y, addend=prev)
+        inp.grad, inp.grad_init, inp.grad_masked = out, True, True
+        return
       if self.stride != 1:      # as ConvBN.backward_branch: the stride-1 data gradient of the zero-upsampled dz
         dz = capi.upsample_rows(dz.contiguous(), self.stride, (dz.shape[1] - 1) * self.stride + 1)
       tin = inp.data.shape[1]
@@ -685,11 +706,12 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
   result = Act(out, out_lens if mask_output else None)
   if not (training and tape is not None):
     return result
-  if FUSE_BN_BWD and len(fw) == 1 and act == 1 and type(main) is ConvBN and not dropped and \
-     (lens is None or main.stride == 1):
+  if FUSE_BN_BWD and len(fw) == 1 and act == 1 and (type(main) is ConvBN or (SEP_FUSE_BN_BWD and type(main) is SepConvBN)) \
+     and not dropped and (lens is None or main.stride == 1):
     # single-input conv + BatchNorm + ReLU (+ dropout): out is zero exactly where the gradient is
     result.bn_y = fw[0]["y"]
     result.bn_scale = 1.0 / (keep_prob if training else 1.0)
+    result.bn_full_rows = type(main) is not ConvBN
 
   def backward():
     result.wait_grad()
@@ -748,6 +770,8 @@ def conv_bn_res_bn_actv(main, res_branches, x, res_inputs, out_lens, activation_
         # residual branch of THIS call (a residual block with repeat = 1), which runs after it.
         # (With the block dropped, branches[0] is a RESIDUAL branch whose input still has
         # later-running consumers: never final.)
+        br.backward_branch(inp, dy, f, final=all(r is not inp for r in inputs[1:]))
+      elif j == 0 and br is main and type(br) is SepConvBN:
         br.backward_branch(inp, dy, f, final=all(r is not inp for r in inputs[1:]))
       else:
         br.backward_branch(inp, dy, f)

@@ -228,8 +228,8 @@ def lstm_kernel_groups(params):
 #        (cuDNN's is i, f, c, o), bias [4H] = b_W + b_R.
 # The device keeps cuDNN's own form per direction — wx_0 [1, G H, in], wh [1, G H, H], bias (b_W), bias_h (b_R),
 # gate rows r, z, n / i, f, g, o (csrc/rnn.hip) — so the exchange is a stack / split / transpose; on the way IN
-# the summed gate biases are halved over b_W and b_R, as the Saveable does. Canonical tensors are fp32 under the
-# plain names (the Saveable converts the stored fp32 buffer). TensorFlow is not in /root/reference: the layout
+# the summed gate biases are halved over b_W and b_R, as the Saveable does. Canonical tensors carry the dtype of the
+# opaque variable (half in a mixed-precision graph, see model_variables). TensorFlow is not in /root/reference: the layout
 # above is restated from the TF 1.x source; tests/test_checkpoint_shapes.py holds the exported tensors to the
 # CudnnCompatible cells' equations against oracle/rnn.py.
 # ---------------------------------------------------------------------------------------------------------
@@ -332,7 +332,17 @@ def model_variables(model):
     gates = parts["wh"].shape[1] // parts["wh"].shape[2]
     prefix = cudnn_canonical_prefix(scope, layer, tag, scope in bidir, gates)
     for suffix, arr in cudnn_to_canonical(dev["wx_0"], dev["wh"], dev["bias"], dev["bias_h"]).items():
-      out["%s/%s" % (prefix, suffix)] = np.ascontiguousarray(arr, dtype=np.float32)
+      arr = np.ascontiguousarray(arr, dtype=np.float32)
+      if mixed:
+        # the opaque buffer of a mixed-precision graph is DT_HALF (the reference counts it among its FP32 master
+        # copies: speech2text_test.py mp_collection_test, 7 for DeepSpeech2), so its Saveable writes half-precision
+        # canonical tensors; the fp32 twin the reference keeps is the OPAQUE master buffer, which has no portable
+        # layout — this repository stores the canonical tensors again in fp32 under the master-copy prefix (exact
+        # round trips of its own files; a TensorFlow-written file simply has no such entries)
+        out["%s/%s" % (prefix, suffix)] = arr.astype(np.float16)
+        out["%s%s/%s" % (MASTER_PREFIX, prefix, suffix)] = arr
+      else:
+        out["%s/%s" % (prefix, suffix)] = arr
     grouped |= {p.name for p in parts.values()}
   for ref, ps in groups.items():
     # [1, 4H, in_k] blocks -> one [sum in_k, 4H] kernel, the cell's inputs first, h last
