@@ -31,6 +31,7 @@ ENABLED = os.environ.get("OS2S_DENSE_RES_ALGEBRA", "1") != "0"
 # A/B knob: 0 = the Gram matrices on the lockstep TN kernel (fp32 atomics over a wide reduction split) instead of the
 # ping-pong kernel (one owner per tile sums up to 17 slabs)
 GRAM_PINGPONG = os.environ.get("OS2S_DRES_GRAM_PP", "1") != "0"
+P_PINGPONG = os.environ.get("OS2S_DRES_P_PP", "1") != "0"     # the same choice for the P_k products
 
 
 class _End(object):
@@ -213,7 +214,7 @@ class DenseResidualPass(object):
     capi.dres_copy_cols(dz, self.dzcat[:, :, E.doff:E.doff + E.cout], dz_lens)
     E.P.zero_()
     capi.conv1x1_wgrad_grouped([dict(x=self.xcat[:, :, :E.kk], dy=dz, dw=E.P.view(1, E.cout, E.kk))],
-                               in_len=self.lens)
+                               in_len=self.lens, pingpong=P_PINGPONG or capi.deterministic())
     capi.dres_bn_bwd(plan.table(E), k + 1, E.cout, E.kk, E.P, mean_dz, N, E.coef)
     inp = self.acts[k]
     if not inp.requires_grad:
