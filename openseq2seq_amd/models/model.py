@@ -290,9 +290,12 @@ class Model(object):
         snap = ([t.clone() for t in self._extra_state_tensors()],
                 self._store.grads.clone() if micro > 0 else None)
       launches0 = capi.gru_xcd_launch_count()
-      tape = Tape(on_done=self._reducer.mark_done if overlap else None)
-      loss = self._forward_backward(batch, tape)
-      tape.backward()
+      if getattr(self, "_halves_enabled", None) is not None and self._halves_enabled():
+        loss = self._forward_backward_halves(batch)          # experiment: two half-batches on two streams
+      else:
+        tape = Tape(on_done=self._reducer.mark_done if overlap else None)
+        loss = self._forward_backward(batch, tape)
+        tape.backward()
       ran_persistent = capi.gru_xcd_launch_count() != launches0
       # Whether a rank ran persistent launches depends on ITS batch shape and environment (B <= 32, T >= 2,
       # OS2S_GRU_XCD), so under data parallelism the decision to enter the status all-reduce must not: every rank

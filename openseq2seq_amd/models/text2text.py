@@ -36,6 +36,70 @@ class Text2Text(EncoderDecoderModel):
         'decoder_output': dec, 'target_tensors': batch['target_tensors'],
         'loss_scale_dev': scale_dev})
 
+  # ---- experiment (os2s_half_batches / OS2S_HALF_BATCHES=1): one step as two half-batches on two streams ------------
+  def _halves_enabled(self):
+    import os
+    return bool(self.params.get('os2s_half_batches', os.environ.get("OS2S_HALF_BATCHES", "0") == "1")) and \
+        self._reducer is None and self.params.get('iter_size', 1) == 1 and hasattr(self._encoder, "embedding_softmax_layer")
+
+  def _split_batch(self, batch):
+    """The two halves of a batch (by sentences), with their packed forms; cached on the batch (the bench batch is
+    reused every step, a data layer would hand the halves over ready-made)."""
+    h = batch.get('_halves')
+    if h is not None:
+      return h
+    from ..parts.transformer import packing
+    (src, slen), (tgt, tlen) = batch['source_tensors'], batch['target_tensors']
+    B = src.shape[0]
+    out = []
+    for sl in (slice(0, B // 2), slice(B // 2, B)):
+      s, sn, t, tn = (v[sl].contiguous() for v in (src, slen, tgt, tlen))
+      ps = packing.pack_ids(s.cpu().numpy(), sn.cpu().numpy())
+      pt = packing.pack_ids(t.cpu().numpy(), tn.cpu().numpy(), shift_right=True)
+      out.append({'source_tensors': [s, sn], 'target_tensors': [t, tn], 'n_tgt': pt["n"],
+                  'packed_source': packing.to_device(ps, s.device), 'packed_target': packing.to_device(pt, s.device)})
+    batch['_halves'] = out
+    return out
+
+  def _forward_backward_halves(self, batch):
+    """Transformer has no batch statistics: the batch's gradient is the token-weighted sum of its halves' gradients.
+    Each half runs forward on its own stream, the two backward passes are issued closure by closure in turn
+    (conv_blocks.backward_interleaved); parameter gradients of both halves queue on ONE side stream."""
+    import torch
+    from ..parts.cnns import conv_blocks
+    from ..parts.cnns.conv_blocks import Tape
+    from .. import capi
+    halves = self._split_batch(batch)
+    main = torch.cuda.current_stream()
+    if getattr(self, "_half_streams", None) is None:
+      self._half_streams = [torch.cuda.Stream(device=main.device) for _ in halves]
+    n_tot = float(sum(h['n_tgt'] for h in halves))
+    scale_dev = self._train_op.loss_scale_view if self._train_op is not None else None
+    tapes, losses = [], []
+    conv_blocks._SIDE_KEY_OVERRIDE = capi._stream().value
+    try:
+      for k, (h, st) in enumerate(zip(halves, self._half_streams)):
+        st.wait_stream(main)
+        torch.cuda.set_stream(st)
+        tape = Tape()
+        w = h['n_tgt'] / n_tot
+        seeds = SeedSeq(self._seed * 7919 + self._step_count + 104729 * k)
+        enc = self._encoder.encode({'source_tensors': h['source_tensors'], 'tape': tape, 'seeds': seeds,
+                                    'packed_source': h['packed_source']})
+        dec = self._decoder.decode({'encoder_output': enc, 'target_tensors': h['target_tensors'], 'tape': tape,
+                                    'packed_target': h['packed_target']})
+        sd = scale_dev * w if scale_dev is not None else torch.full((1,), w, dtype=torch.float32, device=main.device)
+        loss = self._loss_computator.compute_loss({'decoder_output': dec, 'target_tensors': h['target_tensors'],
+                                                   'loss_scale_dev': sd})
+        tapes.append(tape)
+        losses.append(loss * w)
+      torch.cuda.set_stream(main)
+      conv_blocks.backward_interleaved(tapes, self._half_streams)
+    finally:
+      torch.cuda.set_stream(main)
+      conv_blocks._SIDE_KEY_OVERRIDE = None
+    return losses[0] + losses[1]
+
   def infer_batch(self, batch):
     """eval / infer: encoder + greedy (RNN) or beam-search (Transformer) decoding
     (models/text2text.py:98-190 without the printing). Returns (ids int32 [B, steps], lengths [B])."""

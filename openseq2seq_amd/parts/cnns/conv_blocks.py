@@ -99,6 +99,9 @@ SEP_FUSE_BN_BWD = os.environ.get("OS2S_SEP_FUSE_BN_BWD", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
+# set while two half-batches of ONE step run on two main streams (backward_interleaved): both share the side streams
+# of the step's own stream — parameter gradients accumulate into the same buffers, one FIFO keeps them in order
+_SIDE_KEY_OVERRIDE = None
 
 
 def set_side_stream_enabled(on):
@@ -120,7 +123,8 @@ def _side_stream(device, which=0):
     return None
   if which == 1 and not DRES_OWN_STREAM:
     which = 0
-  key = (device.index, capi._stream().value) if not which else (device.index, capi._stream().value, which)
+  base = _SIDE_KEY_OVERRIDE if _SIDE_KEY_OVERRIDE is not None else capi._stream().value
+  key = (device.index, base) if not which else (device.index, base, which)
   st = _SIDE_STREAMS.get(key)
   if st is None:
     # OS2S_SIDE_PRIO (experiment): stream priority of the side stream (HIP: lower number = higher
@@ -315,6 +319,50 @@ class Tape(object):
 
 
 _TAPE_STACK = []
+
+
+def backward_interleaved(tapes, streams):
+  """Tape.backward for several tapes of the SAME structure (the halves of one batch) on several streams: closure i
+  of every tape is issued before closure i + 1 of any, each on its tape's stream — the kernels of one half that keep
+  the matrix pipes idle (LayerNorm, attention, dropout, embedding) run under the other half's GEMMs. The caller has
+  set _SIDE_KEY_OVERRIDE: parameter-gradient launches of all tapes queue on one side stream. Single-process only
+  (no gradient reducer watermark)."""
+  depth = len(_TAPE_STACK)
+  join_side_streams()
+  capi.zero_arena_enter(depth)
+  for t in tapes:
+    assert t.on_done is None
+    t._deferred, t._pending = [], None
+    t._cdeferred, t._ckey = [], None
+  outer = torch.cuda.current_stream()
+  try:
+    n = max(len(t.ops) for t in tapes)
+    for i in range(n):
+      for t, st in zip(tapes, streams):
+        if i < len(t.ops):
+          fn = t.ops[len(t.ops) - 1 - i][0]
+          _TAPE_STACK.append(t)
+          torch.cuda.set_stream(st)
+          try:
+            fn()
+          finally:
+            _TAPE_STACK.pop()
+    for t, st in zip(tapes, streams):
+      _TAPE_STACK.append(t)
+      torch.cuda.set_stream(st)
+      try:
+        t.flush_deferred()
+        t.flush_conv_wgrads()
+      finally:
+        _TAPE_STACK.pop()
+  finally:
+    torch.cuda.set_stream(outer)
+    capi.zero_arena_leave(depth)
+  for t in tapes:
+    t.ops = []
+  for st in streams:
+    outer.wait_stream(st)
+  join_side_streams()
 
 
 def current_tape():
