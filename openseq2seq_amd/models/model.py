@@ -32,6 +32,8 @@ from ..utils.utils import check_params
 # running under the forward GEMMs, each side 1.3 - 5 x slower while they share the memory system
 # (profiles/r06_async_optimizer_overlap.log). Off by default: one stream, one fill of the gradient buffer.
 ASYNC_OPTIMIZER = os.environ.get("OS2S_ASYNC_OPT", "0") == "1"
+# A/B knob: 0 = Tape.backward releases the step's closures before the optimizer is enqueued (rounds 1 - 5)
+DEFER_TAPE_FREE = os.environ.get("OS2S_DEFER_TAPE_FREE", "1") != "0"
 
 
 def resolve_lr_params(lr_policy, lr_policy_params, last_step, steps_in_epoch, has_num_epochs):
@@ -290,10 +292,12 @@ class Model(object):
         snap = ([t.clone() for t in self._extra_state_tensors()],
                 self._store.grads.clone() if micro > 0 else None)
       launches0 = capi.gru_xcd_launch_count()
+      tape = None
       if getattr(self, "_halves_enabled", None) is not None and self._halves_enabled():
         loss = self._forward_backward_halves(batch)          # experiment: two half-batches on two streams
       else:
         tape = Tape(on_done=self._reducer.mark_done if overlap else None)
+        tape.defer_free = DEFER_TAPE_FREE
         loss = self._forward_backward(batch, tape)
         tape.backward()
       ran_persistent = capi.gru_xcd_launch_count() != launches0
@@ -316,6 +320,8 @@ class Model(object):
           self._train_op.run_async()
         else:
           self._train_op.run()
+      if tape is not None:
+        tape.ops = []            # (Tape.defer_free: the step's closures are released behind the optimizer launch)
     finally:
       set_side_stream_enabled(prev)
     return loss

@@ -198,6 +198,10 @@ class Tape(object):
   def __init__(self, on_done=None):
     self.ops = []
     self.on_done = on_done
+    # True: backward() leaves the closures (and the activations they hold) to the caller, who drops them AFTER it has
+    # enqueued what follows the pass — releasing a step's few thousand tensors takes the host ~0.5 ms, during which
+    # the GPU (which has caught up with the host by the end of backward) would wait for the optimizer launch
+    self.defer_free = False
 
   def record(self, fn, params=()):
     self.ops.append((fn, params))
@@ -250,7 +254,8 @@ class Tape(object):
     finally:
       _TAPE_STACK.pop()
       capi.zero_arena_leave(depth)
-    self.ops = []
+    if not self.defer_free:
+      self.ops = []
     join_side_streams()
 
   # ---- deferred (grouped) weight gradients -----------------------------------------------------
