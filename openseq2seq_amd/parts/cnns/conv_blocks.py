@@ -134,31 +134,49 @@ def _side_stream(device, which=0):
   return st
 
 
+_STREAM_OBJ = {}       # raw stream handle -> torch.cuda.Stream (torch.cuda.current_stream() builds a new object: 7 us)
+_FORK_EVENT = {}       # side stream -> the event its forks are ordered by (re-recorded per use: a wait captures the
+                       # record that precedes it)
+
+
+def _current_stream_obj():
+  raw = capi._stream().value
+  st = _STREAM_OBJ.get(raw)
+  if st is None:
+    st = _STREAM_OBJ[raw] = torch.cuda.current_stream()
+  return st
+
+
 class on_side_stream(object):
   """`with on_side_stream(device, *operands):` enqueues the body on the side stream, ordered
   after everything the current stream has enqueued so far. For parameter-gradient kernels:
   nothing in the rest of backward reads their result, the main stream re-joins at the end of
   `Tape.backward` and the gradient reducer waits for the side stream itself. `operands` are the
   tensors the body reads that the main stream's closures release afterwards (their memory is kept
-  until the side stream is done). With OS2S_WGRAD_STREAM=0 the body runs on the current stream."""
+  until the side stream is done). With OS2S_WGRAD_STREAM=0 the body runs on the current stream.
+  (Host cost matters here — QuartzNet's step is bound by the Python thread, and this context is entered ~250 times
+  per step: cached stream objects, one re-recorded event per side stream and torch.cuda.set_stream instead of
+  current_stream() / wait_stream() / the torch.cuda.stream context manager: ~35 -> ~10 us per use.)"""
 
   def __init__(self, device, *operands, which=0):
     self.side = _side_stream(device, which)
     self.operands = operands
-    self.ctx = None
     self.main = None
 
   def __enter__(self):
     if self.side is not None:
-      self.main = torch.cuda.current_stream()
-      self.side.wait_stream(self.main)
-      self.ctx = torch.cuda.stream(self.side)
-      self.ctx.__enter__()
+      self.main = _current_stream_obj()
+      ev = _FORK_EVENT.get(self.side)
+      if ev is None:
+        ev = _FORK_EVENT[self.side] = torch.cuda.Event()
+      ev.record(self.main)
+      self.side.wait_event(ev)
+      torch.cuda.set_stream(self.side)
     return self
 
   def __exit__(self, *exc):
     if self.side is not None:
-      self.ctx.__exit__(*exc)
+      torch.cuda.set_stream(self.main)
       for t in self.operands:
         if t is not None:
           t.record_stream(self.side)
@@ -178,12 +196,19 @@ def side_streams():
   return list(_SIDE_STREAMS.values())
 
 
+_JOIN_EVENT = {}
+
+
 def join_side_streams():
   """The current stream waits for everything enqueued on the side streams so far."""
   if _SIDE_STREAMS:
-    cur = torch.cuda.current_stream()
+    cur = _current_stream_obj()
     for st in _SIDE_STREAMS.values():
-      cur.wait_stream(st)
+      ev = _JOIN_EVENT.get(st)
+      if ev is None:
+        ev = _JOIN_EVENT[st] = torch.cuda.Event()
+      ev.record(st)
+      cur.wait_event(ev)
 
 
 class Tape(object):
@@ -406,7 +431,7 @@ class Act(object):
 
   def wait_grad(self):
     if self.grad_event is not None:
-      torch.cuda.current_stream().wait_event(self.grad_event)
+      _current_stream_obj().wait_event(self.grad_event)
       self.grad_event = None
 
   def grad_buffer(self):
