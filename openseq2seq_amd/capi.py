@@ -27,22 +27,32 @@ def _stream():
 
 
 def _ptr(t, dtype=None, allow_none=False):
+  """Device address of a checked tensor, as the plain int (None for NULL) a c_void_p parameter converts itself —
+  no c_void_p object per argument on the launch path."""
   if t is None:
     if allow_none:
-      return c_void_p(0)
+      return None
     raise ValueError("tensor required")
   if not t.is_cuda:
     raise _lib.Os2sError("os2s kernels need CUDA(HIP) tensors; got %s" % t.device)
-  if dtype is not None and t.dtype != dtype:
+  if dtype is not None and t.dtype is not dtype:
     raise TypeError("expected %s, got %s" % (dtype, t.dtype))
   if not t.is_contiguous():
     raise ValueError("tensor must be contiguous")
-  return c_void_p(t.data_ptr())
+  return t.data_ptr()
 
 
-@functools.lru_cache(maxsize=None)
+_FN_CACHE = {}
+
+
 def _fn(name, argtypes, restype=c_int):
-  return _lib.bind(name, list(argtypes), restype)
+  """The bound entry point `name` (bound once; every call site of a name passes the same argument types). A dict
+  lookup by name: functools.lru_cache hashed the 10 - 25-element argtypes tuple on every call — 1 - 2 us for each
+  of the ~2 000 launches of a step, on the thread whose pace bounds the launch-heavy models."""
+  f = _FN_CACHE.get(name)
+  if f is None:
+    f = _FN_CACHE[name] = _lib.bind(name, list(argtypes), restype)
+  return f
 
 
 def abi_version():
@@ -548,7 +558,7 @@ def gemm_wgrad_grouped(items, accumulate=True):
 def _ptr_array(tensors, dtype):
   arr = (c_void_p * len(tensors))()
   for i, t in enumerate(tensors):
-    arr[i] = _ptr(t, dtype).value
+    arr[i] = _ptr(t, dtype)
   return arr
 
 

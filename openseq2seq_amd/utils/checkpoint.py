@@ -231,7 +231,7 @@ def lstm_kernel_groups(params):
 # the summed gate biases are halved over b_W and b_R, as the Saveable does. Canonical tensors carry the dtype of the
 # opaque variable (half in a mixed-precision graph, see model_variables). TensorFlow is not in /root/reference: the layout
 # above is restated from the TF 1.x source; tests/test_checkpoint_shapes.py holds the exported tensors to the
-# CudnnCompatible cells' equations against oracle/rnn.py.
+# CudnnCompatible cells' equations against the CPU restatement of the cells (tests/).
 # ---------------------------------------------------------------------------------------------------------
 _CUDNN_PART = re.compile(r"^(.*/(?:cudnn_gru|cudnn_lstm|cudnn_rnn))/layer_(\d+)/(fw|bw)/(wx_0|wh|bias|bias_h)$")
 _CUDNN_TF_ORDER = {3: (0, 1, 2), 4: (0, 2, 1, 3)}       # device gate index of TF's k-th gate block
