@@ -178,9 +178,12 @@ int os2s_conv1d_set_host_lens(const int32_t* lens, int B);
  *     they share the chip with the weight-gradient stream)
  *   conv1d.pp_prio: 1 = the loading wave of a narrow-tile slot runs at s_setprio 2
  *   conv1d.pp_min_cout: narrowest layer (output channels) the ping-pong kernels take (default 320)
- *   conv1x1.variant: the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers): 0 (default) and 1 =
- *     lockstep 128x128 tile; 2 = 256x256 ping-pong tile over the live windows whenever its envelope allows
- *     (Cin % 64 == 0, B <= 64) — slower on the Jasper shapes, kept as a measured alternative
+ *   conv1x1.variant: the 1x1 launches (os2s_conv1x1_fwd_grouped and K = 1 layers): 0 and 1 = lockstep 128x128
+ *     tile; 2 = 256x256 ping-pong tile over the live windows whenever its envelope allows (Cin % 64 == 0,
+ *     B <= 64); -1 (default) = the ping-pong tile for a single K = 1 layer of >= conv1d.pp_min_cout output
+ *     channels (the lockstep tile's life there is its steps of exposed load latency: 512 -> 512 channels 33.7 ->
+ *     26.3 us, QuartzNet step -0.8 ms), the lockstep tile for the grouped launches (a grouped 1x1 unit is 4 - 12
+ *     steps of matrix work behind 128 KB of output: slower on the Jasper shapes)
  *   conv1x1.order: os2s_conv1x1_fwd_grouped's workgroup order: 1 (default) = the column tiles of one row tile run
  *     behind the same XCD at the same time (the activations are fetched from HBM once, not once per column tile;
  *     a 1x1 weight matrix fits every L2), 0 = all row tiles of a column tile first (rounds 1 - 5)

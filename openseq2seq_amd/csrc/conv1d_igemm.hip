@@ -1232,7 +1232,9 @@ extern "C" int os2s_conv1d_set_host_lens(const int32_t* lens, int B) {
 //   conv1d.pp_dgrad_penalty   factor on the narrow tiles' cost in data-gradient launches (out_len given)
 //   conv1d.pp_prio            1: the loading wave of a narrow-tile slot runs at s_setprio 2
 //   conv1d.pp_min_cout        narrowest layer (output channels) the ping-pong kernels take (default 320)
-//   conv1x1.variant           the 1x1 launches: 0 / 1 = lockstep 128x128 tile, 2 = 256x256 ping-pong tile
+//   conv1x1.variant           the 1x1 launches: 0 / 1 = lockstep 128x128 tile, 2 = 256x256 ping-pong tile,
+//                             -1 (default) = ping-pong for a single K = 1 layer of >= pp_min_cout output channels,
+//                             lockstep for the grouped launches
 static os2s::OptionReg r_variant("conv1d.variant", [](double v) { g_conv_variant = (int)v; });
 static os2s::OptionReg r_split("conv1d.split", [](double v) { g_conv_split = (int)v; });
 static os2s::OptionReg r_c256("conv1d.pp_cost_256", [](double v) { os2s::g_pp_cost[0] = (float)v; });
@@ -1249,7 +1251,7 @@ static os2s::StampReg r_stamps("conv1d", [](void* stamps, int mode) {
   g_conv_fixed_w = mode;
 });
 
-static int g_conv1x1_variant = 0;
+static int g_conv1x1_variant = -1;
 static os2s::OptionReg r_1x1("conv1x1.variant", [](double v) { g_conv1x1_variant = (int)v; });
 static int g_conv1x1_order = 1;
 static os2s::OptionReg r_1x1o("conv1x1.order", [](double v) { g_conv1x1_order = v != 0.0; });
@@ -1301,7 +1303,10 @@ static int conv1d_fwd_impl(os2s_stream_t stream, const uint16_t* x, const uint16
     if (Cout >= 512 && (long long)B * ceil_div(Tout, kConvBM) >= 256) v = 5;
     if (Cout >= pp_min_cout()) v = 10;
   }
-  if ((v == 10 || v == 11) && K == 1 && g_conv1x1_variant == 2 && residual == nullptr && Cout >= 256 &&
+  // K = 1: the lockstep tile's life is its 4 - 16 steps of exposed load latency (1.1 - 2 us each, one step of
+  // prefetch: 33.7 us at 512 -> 512 channels, 26 752 rows); the ping-pong tile's rings hide it (26.3 us; 1024 ->
+  // 1024: 93 -> 68 us; QuartzNet step -0.8 ms, profiles/r06_quartznet_pointwise_ab.log)
+  if ((v == 10 || v == 11) && K == 1 && g_conv1x1_variant != 0 && g_conv1x1_variant != 1 && residual == nullptr && Cout >= 256 &&
       y_stride_t == Cout && y_stride_b == (long long)Tout * Cout) {
     // a wide 1x1 layer is the one-group case of the grouped ping-pong launch
     ConvGroupTable gt;

@@ -681,7 +681,7 @@ def test_conv1x1_grouped_equals_single_launches(cuda, variant):
     torch.cuda.synchronize()
   finally:
     _lib.set_option("conv1d.variant", -1)
-    _lib.set_option("conv1x1.variant", 0)
+    _lib.set_option("conv1x1.variant", -1)
   for it, (y, st) in zip(items, ref):
     assert torch.equal(it["y"], y)
     if variant == 1:
