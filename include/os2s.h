@@ -1035,6 +1035,18 @@ int os2s_depthwise_dgrad_bnact(os2s_stream_t stream, const uint16_t* dz, const f
                                int Tout, int C, int K, int padL, const uint16_t* mask_ref, float mask_scale,
                                const uint16_t* stat_ref);
 
+/* A separable layer with ONE tap — the residual branches of a separable block (parts/cnns/conv_blocks.py:66,79-85:
+ * tf.layers.separable_conv1d with kernel_size 1) — is a per-channel scale d [Cin] in front of the pointwise
+ * convolution W [Cout, Cin]: y = x (W diag d)^T. os2s_pointwise_fold writes the bf16 operands of the 1x1 kernels,
+ *   w_eff [Cout, Cin] = W diag(d)   (forward),      wt_eff [Cin, Cout] = its transpose   (data gradient),
+ * from the fp32 variables; os2s_pointwise_fold_bwd splits G = dy^T x [Cout, Cin] (os2s_conv1d_wgrad_ws on the
+ * layer's INPUT) into the two variables' gradients, accumulated:
+ *   dw[co, ci] += G[co, ci] d[ci],      dd[ci] += sum_co W[co, ci] G[co, ci]          (one writer per element) */
+int os2s_pointwise_fold(os2s_stream_t stream, const float* w, const float* d, uint16_t* w_eff, uint16_t* wt_eff,
+                        int cout, int cin);
+int os2s_pointwise_fold_bwd(os2s_stream_t stream, const float* g, const float* w, const float* d, float* dw,
+                            float* dd, int cout, int cin);
+
 /* ------------------------------------------------------------------------
  * Text2SpeechLoss terms (losses/text2speech_loss.py:35-209). One call per term:
  *   mode 0: tf.losses.mean_squared_error, 1: absolute_difference (l1_norm), both with

@@ -279,6 +279,11 @@ def zero_arena_reset():
   zero_arena_enter(0)
 
 
+def zero_scratch(shape, device):
+  """Zeroed fp32 scratch that lives until the end of the running backward pass (the pass's arena)."""
+  return _zero_arena.take(tuple(shape), device)
+
+
 def conv1d_dgrad_bnact(dy, wt, dx, *, dil, pad_left, accumulate, out_len, mask_ref, mask_scale, stat_ref):
   """dx (+)= conv(dy, wt) (stride 1), then dz = (mask_ref > 0) ? dx * mask_scale : 0 written to dx;
   returns the BatchNorm-backward partials [num_mtiles(B, T), 2, C] = (sum dz, sum dz * stat_ref) per
@@ -1985,6 +1990,34 @@ def depthwise_dgrad_bnact(dz, w, dx, *, pad_left, out_len, mask_ref, mask_scale,
                B, Tin, Tout, C, K, int(pad_left), _ptr(mask_ref, torch.bfloat16), float(mask_scale),
                _ptr(stat_ref, torch.bfloat16)), "os2s_depthwise_dgrad_bnact")
   return stats
+
+
+def pointwise_fold(w, d, out=None):
+  """The 1x1-kernel operands of a one-tap separable layer (os2s_pointwise_fold): w fp32 [1, Cout, Cin], d fp32
+  [1, Cin] -> (w_eff bf16 [1, Cout, Cin] = w * d, wt_eff bf16 [1, Cin, Cout] = its transpose), into `out` = a pair
+  of such buffers if given."""
+  _, cout, cin = w.shape
+  assert d.numel() == cin
+  if out is not None:
+    w_eff, wt_eff = out
+    assert tuple(w_eff.shape) == (1, cout, cin) and tuple(wt_eff.shape) == (1, cin, cout)
+  else:
+    w_eff = torch.empty((1, cout, cin), dtype=torch.bfloat16, device=w.device)
+    wt_eff = torch.empty((1, cin, cout), dtype=torch.bfloat16, device=w.device)
+  f = _fn("os2s_pointwise_fold", (c_void_p,) * 5 + (c_int, c_int))
+  _lib.check(f(_stream(), _ptr(w, torch.float32), _ptr(d, torch.float32), _ptr(w_eff, torch.bfloat16),
+               _ptr(wt_eff, torch.bfloat16), cout, cin), "os2s_pointwise_fold")
+  return w_eff, wt_eff
+
+
+def pointwise_fold_bwd(g, w, d, dw, dd):
+  """dw += g * d (columns), dd += sum over rows of w * g (os2s_pointwise_fold_bwd): g, w, dw fp32 [1, Cout, Cin],
+  d, dd fp32 [1, Cin]."""
+  _, cout, cin = w.shape
+  assert tuple(g.shape) == tuple(w.shape) == tuple(dw.shape) and d.numel() == cin == dd.numel()
+  f = _fn("os2s_pointwise_fold_bwd", (c_void_p,) * 6 + (c_int, c_int))
+  _lib.check(f(_stream(), _ptr(g, torch.float32), _ptr(w, torch.float32), _ptr(d, torch.float32),
+               _ptr(dw, torch.float32), _ptr(dd, torch.float32), cout, cin), "os2s_pointwise_fold_bwd")
 
 
 def depthwise_conv1d_wgrad(x, dy, dw, *, stride=1, dil=1, pad_left=None, in_len=None):

@@ -840,6 +840,69 @@ __global__ __launch_bounds__(512, 2) void depthwise_mfma_wgrad_kernel(DwArgs p) 
   }
 }
 
+// ---- a K = 1 separable layer folded into its pointwise convolution ------------------------------------------
+// The residual branches of a separable block are separable layers with ONE tap (conv_blocks.py:66,79-85): a
+// per-channel scale d in front of a 1x1 convolution W, y = (x . d) W^T = x (W diag d)^T. The scaled copy of x is
+// never made: the forward runs the 1x1 kernel on x with W diag(d) (and its transpose for the data gradient), the
+// backward takes G = dy^T x from the 1x1 weight-gradient kernel and splits it: dW += G diag(d),
+// dd[ci] += sum_co W[co, ci] G[co, ci].
+__global__ __launch_bounds__(256) void pointwise_fold_kernel(const float* __restrict__ w, const float* __restrict__ d,
+                                                             bf16_t* __restrict__ w_eff, bf16_t* __restrict__ wt_eff,
+                                                             int cout, int cin) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int ci = blockIdx.x * 32 + tx;
+  const float dv = ci < cin ? d[ci] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = ty + j * 8, co = blockIdx.y * 32 + r;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+      v = w[(long long)co * cin + ci] * dv;
+      w_eff[(long long)co * cin + ci] = f2bf(v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  const int co = blockIdx.y * 32 + tx;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = ty + j * 8, ci2 = blockIdx.x * 32 + r;
+    if (co < cout && ci2 < cin) wt_eff[(long long)ci2 * cout + co] = f2bf(tile[tx][r]);
+  }
+}
+
+// one workgroup per 16 input channels: thread (g, c) = (tid / 16, tid % 16) walks the output channels g, g + 16, ...
+// of column c (64-byte row segments), the 16 partial sums of dd meet in LDS in a fixed order (one writer per
+// element of dw and dd: deterministic). 16 - 64 workgroups of 16 - 64 steps: ~10 us where one workgroup per 64
+// columns took 65
+__global__ __launch_bounds__(256) void pointwise_fold_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                                 const float* __restrict__ d, float* __restrict__ dw,
+                                                                 float* __restrict__ dd, int cout, int cin) {
+  __shared__ float part[16][17];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int ci = blockIdx.x * 16 + c;
+  float acc = 0.f;
+  if (ci < cin) {
+    const float dv = d[ci];
+#pragma unroll 4
+    for (int co = grp; co < cout; co += 16) {
+      const long long o = (long long)co * cin + ci;
+      const float gv = g[o];
+      acc = fmaf(w[o], gv, acc);
+      dw[o] += gv * dv;
+    }
+  }
+  part[grp][c] = acc;
+  __syncthreads();
+  if (grp == 0 && ci < cin) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][c];
+    dd[ci] += t;
+  }
+}
+
 }  // namespace os2s
 
 using namespace os2s;
@@ -1011,5 +1074,22 @@ extern "C" int os2s_depthwise_conv1d_wgrad(os2s_stream_t stream, const uint16_t*
     return OS2S_OK;
   }
   OS2S_LAUNCH(depthwise_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_pointwise_fold(os2s_stream_t stream, const float* w, const float* d, uint16_t* w_eff,
+                                   uint16_t* wt_eff, int cout, int cin) {
+  OS2S_REQUIRE(w && d && w_eff && wt_eff && cout >= 1 && cin >= 1);
+  dim3 grid(ceil_div(cin, 32), ceil_div(cout, 32));
+  OS2S_LAUNCH(pointwise_fold_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, d, (bf16_t*)w_eff, (bf16_t*)wt_eff,
+              cout, cin);
+  return OS2S_OK;
+}
+
+extern "C" int os2s_pointwise_fold_bwd(os2s_stream_t stream, const float* g, const float* w, const float* d,
+                                       float* dw, float* dd, int cout, int cin) {
+  OS2S_REQUIRE(g && w && d && dw && dd && cout >= 1 && cin >= 1);
+  OS2S_LAUNCH(pointwise_fold_bwd_kernel, dim3(ceil_div(cin, 16)), dim3(256), 0, (hipStream_t)stream, g, w, d, dw, dd,
+              cout, cin);
   return OS2S_OK;
 }

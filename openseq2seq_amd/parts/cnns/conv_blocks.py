@@ -96,6 +96,9 @@ DRES_FUSE_BN_BWD = os.environ.get("OS2S_DRES_FUSE_BN_BWD", "1") != "0"
 # A/B knob: 0 = separable layers keep their own BatchNorm-backward reduction pass (rounds 4 - 5); default = it rides
 # in the next separable layer's depthwise data gradient (capi.depthwise_dgrad_bnact)
 SEP_FUSE_BN_BWD = os.environ.get("OS2S_SEP_FUSE_BN_BWD", "1") != "0"
+# A/B knob: 0 = a one-tap separable layer (QuartzNet's residual branches) runs its depthwise scale as a launch of
+# its own (rounds 4 - 6); default = one 1x1 convolution with the scale folded into the kernel (SepConvBN.folded)
+FOLD_SEP_K1 = os.environ.get("OS2S_FOLD_SEP_K1", "1") != "0"
 
 
 _SIDE_STREAM_ENABLED = True
@@ -337,14 +340,22 @@ class Tape(object):
       return
     items = [it for _, it in self._deferred]
     if getattr(self, "_deferred_side", True):
-      with on_side_stream(items[0]["x"].device, *([it["x"] for it in items] + [it["dy"] for it in items])):
+      with on_side_stream(items[0]["x"].device, *([it["x"] for it in items] + [it["dy"] for it in items] +
+                                                  [it["dw"] for it in items if "after" in it])):
         capi.gemm_wgrad_grouped(items, accumulate=True)
+        for it in items:
+          if "after" in it:       # behind the launch, on its stream (a folded one-tap separable layer splits its dw)
+            it["after"]()
     else:
       capi.gemm_wgrad_grouped(items, accumulate=True)
+      for it in items:
+        if "after" in it:
+          it["after"]()
     if self._pending is not None:
-      for p, _ in self._deferred:
-        if id(p) in self._pending:
-          self._pending[id(p)] -= 1
+      for p, it in self._deferred:
+        for q in (p,) + tuple(it.get("also", ())):
+          if id(q) in self._pending:
+            self._pending[id(q)] -= 1
     self._deferred = []
 
 
@@ -555,6 +566,10 @@ class ConvBN(object):
     branch of the layer that follows inp's producer: every other consumer of inp is a residual
     branch of a LATER block end, whose backward has already run)."""
     self.backward_weights(inp, dy, f)
+    self.backward_data(inp, dy, f, final, self.kernel.wt16)
+
+  def backward_data(self, inp, dy, f, final, wt16):
+    """The data-gradient half of backward_branch with the transposed kernel wt16 [K, Cin, Cout]."""
     if inp.requires_grad:
       g = inp.grad_buffer()
       tin = inp.data.shape[1]
@@ -564,7 +579,7 @@ class ConvBN(object):
         # zero-upsampled to the input's resolution — the stride-1 data gradient of dy_up (stride x the work of
         # a dedicated kernel; no configuration of the reference strides anywhere but in its first layer)
         dy = capi.upsample_rows(dy.contiguous(), self.stride, (dy.shape[1] - 1) * self.stride + 1)
-        capi.conv1d_fwd(dy, self.kernel.wt16, dil=self.dil, pad_left=pl, tout=tin, out=g,
+        capi.conv1d_fwd(dy, wt16, dil=self.dil, pad_left=pl, tout=tin, out=g,
                         accumulate=inp.grad_init, out_len=inp.lens)
         inp.grad_init = True
         return
@@ -572,13 +587,13 @@ class ConvBN(object):
          g.is_contiguous():
         # the producer's ReLU / dropout backward and its BatchNorm-backward partial sums ride in this
         # launch's epilogue: its own reduction pass (bn_act_bwd_reduce) is skipped
-        inp.bias_part = capi.conv1d_dgrad_bnact(dy, self.kernel.wt16, g, dil=self.dil, pad_left=pl,
+        inp.bias_part = capi.conv1d_dgrad_bnact(dy, wt16, g, dil=self.dil, pad_left=pl,
                                                 accumulate=inp.grad_init, out_len=inp.lens,
                                                 mask_ref=inp.data, mask_scale=inp.bn_scale, stat_ref=inp.bn_y)
         inp.grad_init = True
         inp.grad_masked = True
         return
-      capi.conv1d_fwd(dy, self.kernel.wt16, dil=self.dil, pad_left=pl, tout=tin, out=g,
+      capi.conv1d_fwd(dy, wt16, dil=self.dil, pad_left=pl, tout=tin, out=g,
                       accumulate=inp.grad_init, out_len=inp.lens)
       inp.grad_init = True
 
@@ -615,12 +630,22 @@ class SepConvBN(ConvBN):
     tout, pl = self.out_geometry(Tin)
     dev = x.data.device
     C = self.cout
-    z = capi.depthwise_conv1d_fwd(x.data, self.depthwise.master, stride=self.stride, dil=self.dil,
-                                  pad_left=pl, tout=tout, in_len=x.lens)
     stats = None
     if training:
       stats = torch.empty((capi.conv1d_num_mtiles(B, tout), 2, C), dtype=torch.float32, device=dev)
-    y = capi.conv1d_fwd(z, self.kernel.w16, pad_left=0, tout=tout, stats=stats)
+    wt_eff = None
+    if self.folded():
+      # one tap: the per-channel scale goes into the pointwise kernel (y = x (W diag d)^T), x is not copied
+      if getattr(self, "_fold_bufs", None) is None:       # (the layer's own: rewritten by every forward)
+        self._fold_bufs = (torch.empty((1, C, self.cin), dtype=torch.bfloat16, device=dev),
+                           torch.empty((1, self.cin, C), dtype=torch.bfloat16, device=dev))
+      w_eff, wt_eff = capi.pointwise_fold(self.kernel.master, self.depthwise.master, out=self._fold_bufs)
+      z = None
+      y = capi.conv1d_fwd(x.data, w_eff, pad_left=0, tout=tout, in_len=x.lens, stats=stats)
+    else:
+      z = capi.depthwise_conv1d_fwd(x.data, self.depthwise.master, stride=self.stride, dil=self.dil,
+                                    pad_left=pl, tout=tout, in_len=x.lens)
+      y = capi.conv1d_fwd(z, self.kernel.w16, pad_left=0, tout=tout, stats=stats)
     sc = torch.empty(C, dtype=torch.float32, device=dev)
     sh = torch.empty(C, dtype=torch.float32, device=dev)
     mean = rstd = None
@@ -631,7 +656,13 @@ class SepConvBN(ConvBN):
                      self.momentum, training, self.moving_mean, self.moving_var, mean, rstd,
                      sc, sh)
     return dict(y=y, scale=sc, shift=sh, mean=mean, rstd=rstd, tout=tout, pad_left=pl,
-                z=z if training else None)
+                z=z if training else None, wt_eff=wt_eff if training else None)
+
+  def folded(self):
+    """A one-tap separable layer (the residual branches of a separable block) runs as ONE 1x1 convolution with the
+    depthwise scale folded into the pointwise kernel: no scaled copy of the input, no depthwise launches; the two
+    variables' gradients come out of the 1x1 weight gradient of the layer's input (os2s_pointwise_fold_bwd)."""
+    return FOLD_SEP_K1 and self.k == 1 and self.stride == 1 and self.cin % 8 == 0 and self.cout % 8 == 0
 
   def trainable(self):
     return [self.depthwise, self.kernel, self.gamma, self.beta]
@@ -640,6 +671,31 @@ class SepConvBN(ConvBN):
     """final: as ConvBN.backward_branch — this is the last contribution to inp's gradient; when inp is the output
     of a single-input conv + BatchNorm + ReLU layer its activation backward and BatchNorm-backward partial sums ride
     in the store phase of the depthwise data gradient (capi.depthwise_dgrad_bnact)."""
+    if f.get("wt_eff") is not None:
+      # G = dy^T x joins the block's grouped pointwise weight gradients (below); the launch's tail splits it into
+      # the two variables' gradients
+      x = inp.data
+      rows = x.shape[0] * x.shape[1]
+      gw = capi.zero_scratch(self.kernel.grad.shape, dy.device)
+
+      def split(gw=gw):
+        capi.pointwise_fold_bwd(gw, self.kernel.master, self.depthwise.master, self.kernel.grad, self.depthwise.grad)
+      if GROUP_POINTWISE_WGRAD and current_tape() is not None and self.cin >= 128 and self.cout >= 128 and \
+         rows >= 2048 and x.is_contiguous() and dy.is_contiguous():
+        tape = current_tape()
+        for p in (self.depthwise,):       # the scale's gradient is final with the same launch
+          if tape._pending is not None and id(p) in tape._pending:
+            tape._pending[id(p)] += 1
+        tape.defer_wgrad(self.kernel, dict(x=x.view(rows, self.cin), dy=dy.view(rows, self.cout),
+                                           dw=gw.view(self.cout, self.cin), after=split, also=(self.depthwise,)),
+                         group=POINTWISE_WGRAD_GROUP)
+      else:
+        with on_side_stream(dy.device, x, dy, gw):
+          capi.conv1d_wgrad(x, dy, 1, pad_left=0, in_len=inp.lens, out=gw, accumulate=True)
+          split()
+      wt_eff, f["wt_eff"] = f["wt_eff"], None
+      self.backward_data(inp, dy, f, final, wt_eff)
+      return
     z = f["z"]
     rows = z.shape[0] * z.shape[1]
     units = ((self.cout + 255) // 256) * ((self.cin + 255) // 256)
