@@ -48,7 +48,9 @@ _FN_CACHE = {}
 def _fn(name, argtypes, restype=c_int):
   """The bound entry point `name` (bound once; every call site of a name passes the same argument types). A dict
   lookup by name: functools.lru_cache hashed the 10 - 25-element argtypes tuple on every call — 1 - 2 us for each
-  of the ~2 000 launches of a step, on the thread whose pace bounds the launch-heavy models."""
+  of the ~2 000 launches of a step, on the thread whose pace bounds the launch-heavy models. The call sites read
+  `_FN_CACHE.get(name) or _fn(name, argtypes)`: after the first call not even the argtypes tuple is built (0.2 - 0.4
+  us of LOAD_GLOBALs per launch)."""
   f = _FN_CACHE.get(name)
   if f is None:
     f = _FN_CACHE[name] = _lib.bind(name, list(argtypes), restype)
@@ -64,14 +66,14 @@ def clock_probe_start(spin_cycles):
   returns the device buffer clock_probe_read() reads."""
   out = torch.zeros((2,), dtype=torch.int64, device="cuda")
   torch.cuda.current_stream().synchronize()      # the zero fill lands before the probe stream writes
-  f = _fn("os2s_clock_probe", (c_void_p, c_uint64))
+  f = (_FN_CACHE.get("os2s_clock_probe") or _fn("os2s_clock_probe", (c_void_p, c_uint64)))
   _lib.check(f(_ptr(out), int(spin_cycles)), "os2s_clock_probe")
   return out
 
 
 def clock_probe_read(out):
   """MHz of the shader clock over the probe's run (100 MHz reference counter), or None if it did not run."""
-  _lib.check(_fn("os2s_clock_probe_wait", ())(), "os2s_clock_probe_wait")
+  _lib.check((_FN_CACHE.get("os2s_clock_probe_wait") or _fn("os2s_clock_probe_wait", ()))(), "os2s_clock_probe_wait")
   cyc, ref = (int(v) for v in out.cpu())
   return 100.0 * cyc / ref if ref > 0 else None
 
@@ -92,12 +94,12 @@ def ctc_greedy_decode(logits, seq_len, blank=None, merge_repeated=True):
   ids = torch.empty((B, T), dtype=torch.int32, device=dev)
   lens = torch.empty((B,), dtype=torch.int32, device=dev)
   neg = torch.empty((B,), dtype=torch.float32, device=dev)
-  wsf = _fn("os2s_ctc_greedy_decode_workspace_bytes", (c_int, c_int), c_size_t)
+  wsf = (_FN_CACHE.get("os2s_ctc_greedy_decode_workspace_bytes") or _fn("os2s_ctc_greedy_decode_workspace_bytes", (c_int, c_int), c_size_t))
   nbytes = int(wsf(T, B))
   ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-  f = _fn("os2s_ctc_greedy_decode",
+  f = (_FN_CACHE.get("os2s_ctc_greedy_decode") or _fn("os2s_ctc_greedy_decode",
           (c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(logits, torch.float32), _ptr(seq_len, torch.int32),
                T, B, V, int(blank), int(bool(merge_repeated)), _ptr(ids),
                _ptr(lens), _ptr(neg), _ptr(ws), nbytes),
@@ -123,7 +125,7 @@ def valid_padding(tin, k, stride, dil):
 
 
 def conv1d_num_mtiles(B, tout):
-  return int(_fn("os2s_conv1d_num_mtiles", (c_int, c_int))(B, tout))
+  return int((_FN_CACHE.get("os2s_conv1d_num_mtiles") or _fn("os2s_conv1d_num_mtiles", (c_int, c_int)))(B, tout))
 
 
 _conv_ws = {}
@@ -133,11 +135,11 @@ def set_deterministic(on):
   """Deterministic mode of the library (os2s_set_deterministic; default = environment
   OS2S_DETERMINISTIC): parameter-gradient kernels that use fp32 atomics across workgroups run in a
   single-contributor launch geometry — slower, bit-identical run to run."""
-  _fn("os2s_set_deterministic", (c_int,), None)(int(bool(on)))
+  (_FN_CACHE.get("os2s_set_deterministic") or _fn("os2s_set_deterministic", (c_int,), None))(int(bool(on)))
 
 
 def deterministic():
-  return bool(_fn("os2s_deterministic", (), c_int)())
+  return bool((_FN_CACHE.get("os2s_deterministic") or _fn("os2s_deterministic", (), c_int))())
 
 
 def upsample_rows(x, stride, tup):
@@ -145,7 +147,7 @@ def upsample_rows(x, stride, tup):
   (os2s_upsample_rows_bf16: the output gradient of a strided convolution, made stride-1)."""
   B, T, C = x.shape
   y = torch.empty((B, tup, C), dtype=torch.bfloat16, device=x.device)
-  f = _fn("os2s_upsample_rows_bf16", (c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p))
+  f = (_FN_CACHE.get("os2s_upsample_rows_bf16") or _fn("os2s_upsample_rows_bf16", (c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p)))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), B, T, C, int(stride), int(tup), _ptr(y, torch.bfloat16)),
              "os2s_upsample_rows_bf16")
   return y
@@ -156,7 +158,7 @@ def conv1d_set_host_lens(lens):
   convolutions receive as in_len, or withdraws it (None). See include/os2s.h: a hint that saves the second
   (null) launch of the device-side tile choice; it cannot change results."""
   import ctypes
-  f = _fn("os2s_conv1d_set_host_lens", (c_void_p, c_int))
+  f = (_FN_CACHE.get("os2s_conv1d_set_host_lens") or _fn("os2s_conv1d_set_host_lens", (c_void_p, c_int)))
   if lens is None:
     _lib.check(f(None, 0), "os2s_conv1d_set_host_lens")
     return
@@ -173,7 +175,7 @@ def conv1d_workspace(device):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
   ws = _conv_ws.get(key)
   if ws is None:
-    n = int(_fn("os2s_conv1d_workspace_bytes", (), c_size_t)())
+    n = int((_FN_CACHE.get("os2s_conv1d_workspace_bytes") or _fn("os2s_conv1d_workspace_bytes", (), c_size_t))())
     ws = torch.zeros((n,), dtype=torch.uint8, device=device)
     _conv_ws[key] = ws
   return ws
@@ -200,11 +202,11 @@ def conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_len=None,
   else:
     ysb, yst = tout * Cout, Cout
   ws = conv1d_workspace(x.device) if use_workspace else None
-  f = _fn("os2s_conv1d_fwd_ws",
+  f = (_FN_CACHE.get("os2s_conv1d_fwd_ws") or _fn("os2s_conv1d_fwd_ws",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
            c_ll, c_ll, c_int, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p,
-           c_void_p, c_size_t))
+           c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.bfloat16),
                _ptr(out, dt), _ptr(in_len, torch.int32, True),
                _ptr(bias, torch.float32, True), _ptr(stats, torch.float32, True),
@@ -296,9 +298,9 @@ def conv1d_dgrad_bnact(dy, wt, dx, *, dil, pad_left, accumulate, out_len, mask_r
   assert dx.is_contiguous() and mask_ref.is_contiguous() and stat_ref.is_contiguous() and dy.is_contiguous()
   stats = _zero_arena.take((conv1d_num_mtiles(B, Tout), 2, Cout), dy.device)
   ws = conv1d_workspace(dy.device)
-  f = _fn("os2s_conv1d_dgrad_bnact_ws",
+  f = (_FN_CACHE.get("os2s_conv1d_dgrad_bnact_ws") or _fn("os2s_conv1d_dgrad_bnact_ws",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-           c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t))
+           c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(dy, torch.bfloat16), _ptr(wt, torch.bfloat16), _ptr(dx, torch.bfloat16),
                _ptr(stats, torch.float32), B, Tin, Cin, Cout, K, int(dil), int(pad_left), Tout,
                int(bool(accumulate)), _ptr(out_len, torch.int32, True), _ptr(mask_ref, torch.bfloat16),
@@ -311,8 +313,8 @@ def bn_bwd_finalize_raw(partial, count, mean, rstd, dgamma, dbeta, accumulate, c
   """dgamma / dbeta / c1 / c2 from raw partials [nparts, 2, C] = (sum dz, sum dz * y)."""
   nparts, two, C = partial.shape
   assert two == 2
-  f = _fn("os2s_bn_bwd_finalize_raw", (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_int, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_bn_bwd_finalize_raw") or _fn("os2s_bn_bwd_finalize_raw", (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(partial, torch.float32), nparts, C, int(count), _ptr(mean, torch.float32),
                _ptr(rstd, torch.float32), _ptr(dgamma, torch.float32, True), _ptr(dbeta, torch.float32, True),
                int(accumulate), _ptr(c1, torch.float32), _ptr(c2, torch.float32)), "os2s_bn_bwd_finalize_raw")
@@ -330,8 +332,8 @@ def conv1x1_fwd_grouped(items, in_len=None, out_len=None, out_f32=False):
   fp32 (os2s_conv1x1_fwd_grouped_ex; no statistics)."""
   B, T, _ = items[0]["x"].shape
   ydt = torch.float32 if out_f32 else torch.bfloat16
-  f = _fn("os2s_conv1x1_fwd_grouped_ex",
-          (c_void_p, _lib.ctypes.POINTER(_ConvGroup), c_int, c_void_p, c_void_p, c_int, c_int, c_int))
+  f = (_FN_CACHE.get("os2s_conv1x1_fwd_grouped_ex") or _fn("os2s_conv1x1_fwd_grouped_ex",
+          (c_void_p, _lib.ctypes.POINTER(_ConvGroup), c_int, c_void_p, c_void_p, c_int, c_int, c_int)))
   outs = [it["y"].data_ptr() for it in items]
   assert len(set(outs)) == len(outs), "two groups of one launch must not write the same tensor"
   for i0 in range(0, len(items), 16):
@@ -364,9 +366,9 @@ def dres_copy_cols(src, dst, lens=None, want_colsum=False):
   assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16
   part = None
   if want_colsum:
-    n = int(_fn("os2s_dres_copy_num_parts", (c_int, c_int))(B, T))
+    n = int((_FN_CACHE.get("os2s_dres_copy_num_parts") or _fn("os2s_dres_copy_num_parts", (c_int, c_int)))(B, T))
     part = torch.empty((n, C), dtype=torch.float32, device=src.device)
-  f = _fn("os2s_dres_copy_cols", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_void_p))
+  f = (_FN_CACHE.get("os2s_dres_copy_cols") or _fn("os2s_dres_copy_cols", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_void_p)))
   _lib.check(f(_stream(), c_void_p(src.data_ptr()), src.stride(1), c_void_p(dst.data_ptr()), dst.stride(1),
                _ptr(lens, torch.int32, True), B, T, C, _ptr(part, torch.float32, True)), "os2s_dres_copy_cols")
   return part
@@ -376,7 +378,7 @@ def dres_cov(colsum_partial, gram, count, s, m, chl):
   """s, m [C] fp32 and chl [2C, C] bf16 (covariance hi / lo) from the column-sum partials and gram [C, C] fp32."""
   nparts, C = colsum_partial.shape
   assert tuple(gram.shape[-2:]) == (C, C) and chl.numel() == 2 * C * C and s.numel() == C and m.numel() == C
-  f = _fn("os2s_dres_cov", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_dres_cov") or _fn("os2s_dres_cov", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(colsum_partial, torch.float32), nparts, _ptr(gram, torch.float32), C, int(count),
                _ptr(s, torch.float32), _ptr(m, torch.float32), _ptr(chl, torch.bfloat16)), "os2s_dres_cov")
 
@@ -406,8 +408,8 @@ def dres_seg_table(segs, device):
 
 def dres_bn_fwd(table, nseg, Cout, Kk, wp, shift, count, eps, momentum, training):
   assert wp.numel() == Cout * Kk and shift.numel() == Cout and table.numel() == nseg * _lib.ctypes.sizeof(_DresSeg)
-  f = _fn("os2s_dres_bn_fwd", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_float, c_float,
-                               c_int))
+  f = (_FN_CACHE.get("os2s_dres_bn_fwd") or _fn("os2s_dres_bn_fwd", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_float, c_float,
+                               c_int)))
   _lib.check(f(_stream(), _ptr(table, torch.uint8), nseg, Cout, Kk, _ptr(wp, torch.bfloat16),
                _ptr(shift, torch.float32), int(count), float(eps), float(momentum), int(bool(training))),
              "os2s_dres_bn_fwd")
@@ -415,7 +417,7 @@ def dres_bn_fwd(table, nseg, Cout, Kk, wp, shift, count, eps, momentum, training
 
 def dres_bn_bwd(table, nseg, Cout, Kk, P, mean_dz, count, coef):
   assert P.numel() == Cout * Kk and mean_dz.numel() == Cout and coef.numel() >= nseg * 4 * Cout
-  f = _fn("os2s_dres_bn_bwd", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p))
+  f = (_FN_CACHE.get("os2s_dres_bn_bwd") or _fn("os2s_dres_bn_bwd", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p)))
   _lib.check(f(_stream(), _ptr(table, torch.uint8), nseg, Cout, Kk, _ptr(P, torch.float32),
                _ptr(mean_dz, torch.float32), int(count), _ptr(coef, torch.float32)), "os2s_dres_bn_bwd")
 
@@ -429,8 +431,8 @@ def conv1x1_cat_fwd(x, w, y, in_len=None, out_len=None, bias=None, accumulate=Fa
   assert tuple(y.shape) == (B, T, Cout) and _rows_view_ok(x) and _rows_view_ok(y)
   assert x.dtype == torch.bfloat16 and y.dtype == torch.bfloat16
   ws = conv1d_workspace(x.device)
-  f = _fn("os2s_conv1x1_cat_fwd", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_conv1x1_cat_fwd") or _fn("os2s_conv1x1_cat_fwd", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t)))
   _lib.check(f(_stream(), c_void_p(x.data_ptr()), x.stride(1), c_void_p(w.data_ptr()), c_void_p(y.data_ptr()),
                y.stride(1), _ptr(in_len, torch.int32, True), _ptr(out_len, torch.int32, True),
                _ptr(bias, torch.float32, True), B, T, Cin, Cout, int(bool(accumulate)), _ptr(ws), ws.numel()),
@@ -453,9 +455,9 @@ def conv1d_wgrad(x, dy, K, *, stride=1, dil=1, pad_left=None, in_len=None,
     out = torch.empty((K, Cout, Cin), dtype=torch.float32, device=x.device)
   assert x.stride(2) == 1 and x.stride(0) == Tin * x.stride(1)
   ws = conv1d_workspace(x.device) if use_workspace else None
-  f = _fn("os2s_conv1d_wgrad_ws",
+  f = (_FN_CACHE.get("os2s_conv1d_wgrad_ws") or _fn("os2s_conv1d_wgrad_ws",
           (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t))
+           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t)))
   _lib.check(f(_stream(), c_void_p(x.data_ptr()), x.stride(1), _ptr(dy, torch.bfloat16),
                _ptr(out, torch.float32), _ptr(in_len, torch.int32, True), B, Tin,
                Cin, Cout, K, stride, dil, pad_left, Tout, int(accumulate), _ptr(ws, None, True),
@@ -487,9 +489,9 @@ def conv1d_wgrad_grouped(items, K, *, stride=1, dil=1, pad_left=None, in_len=Non
     g.x, g.dy, g.dw = c_void_p(x.data_ptr()), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32)
     g.x_row_stride = x.stride(1)
   ws = conv1d_workspace(x0.device)
-  f = _fn("os2s_conv1d_wgrad_grouped_ws",
+  f = (_FN_CACHE.get("os2s_conv1d_wgrad_grouped_ws") or _fn("os2s_conv1d_wgrad_grouped_ws",
           (c_void_p, _lib.ctypes.POINTER(_CWgradGroup), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-           c_int, c_int, c_int, c_int, c_void_p, c_size_t))
+           c_int, c_int, c_int, c_int, c_void_p, c_size_t)))
   _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, Tin, Cin, Cout, K, stride, dil, pad_left, Tout,
                int(bool(accumulate)), _ptr(ws), ws.numel()), "os2s_conv1d_wgrad_grouped_ws")
 
@@ -522,14 +524,14 @@ def conv1x1_wgrad_grouped(items, in_len=None, pingpong=True):
     g.x, g.dy, g.dw = c_void_p(x.data_ptr()), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32)
     g.x_row_stride, g.Cin, g.Cout = x.stride(1), x.shape[2], dy.shape[2]
   if not pingpong:
-    f = _fn("os2s_conv1x1_wgrad_grouped",
-            (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int))
+    f = (_FN_CACHE.get("os2s_conv1x1_wgrad_grouped") or _fn("os2s_conv1x1_wgrad_grouped",
+            (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int)))
     _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T), "os2s_conv1x1_wgrad_grouped")
     return
   # wide branches of a big batch: the K = 1 ping-pong TN-GEMM kernel (deterministic), else the lockstep kernel
   ws = conv1d_workspace(items[0]["x"].device)
-  f = _fn("os2s_conv1x1_wgrad_grouped_ws",
-          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_conv1x1_wgrad_grouped_ws") or _fn("os2s_conv1x1_wgrad_grouped_ws",
+          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_void_p, c_int, c_int, c_void_p, c_size_t)))
   _lib.check(f(_stream(), arr, n, _ptr(in_len, torch.int32, True), B, T, _ptr(ws), ws.numel()),
              "os2s_conv1x1_wgrad_grouped_ws")
 
@@ -555,8 +557,8 @@ def gemm_wgrad_grouped(items, accumulate=True):
     g.x, g.dy, g.dw = c_void_p(x.data_ptr()), c_void_p(dy.data_ptr()), _ptr(dw, torch.float32)
     g.x_row_stride, g.Cin, g.Cout = x.stride(0), x.shape[1], dy.shape[1]
   ws = conv1d_workspace(items[0]["x"].device)
-  f = _fn("os2s_gemm_wgrad_grouped",
-          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_ll, c_int, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_gemm_wgrad_grouped") or _fn("os2s_gemm_wgrad_grouped",
+          (c_void_p, _lib.ctypes.POINTER(_WgradGroup), c_int, c_ll, c_int, c_void_p, c_size_t)))
   _lib.check(f(_stream(), arr, n, M, int(bool(accumulate)), _ptr(ws), ws.numel()), "os2s_gemm_wgrad_grouped")
 
 
@@ -571,9 +573,9 @@ def bn_finalize(partial, count, gamma, beta, eps, momentum, training, moving_mea
                 moving_var, mean_out, rstd_out, scale_out, shift_out):
   C = scale_out.numel()
   nparts = 0 if partial is None else partial.shape[0]
-  f = _fn("os2s_bn_finalize",
+  f = (_FN_CACHE.get("os2s_bn_finalize") or _fn("os2s_bn_finalize",
           (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_float,
-           c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p))
+           c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(partial, torch.float32, True), nparts, C, int(count),
                _ptr(gamma, torch.float32, True), _ptr(beta, torch.float32, True),
                float(eps), float(momentum), int(training),
@@ -601,8 +603,8 @@ def bn_finalize_multi(items, count, eps, momentum, training):
       a[j] = None if t is None else t.data_ptr()
     arrs[k] = a
   P = _lib.ctypes.POINTER(c_void_p)
-  f = _fn("os2s_bn_finalize_multi", (c_void_p, c_int, P, c_int, c_int, c_ll, P, P, c_float, c_float, c_int,
-                                     P, P, P, P, P, P))
+  f = (_FN_CACHE.get("os2s_bn_finalize_multi") or _fn("os2s_bn_finalize_multi", (c_void_p, c_int, P, c_int, c_int, c_ll, P, P, c_float, c_float, c_int,
+                                     P, P, P, P, P, P)))
   _lib.check(f(_stream(), J, arrs["partial"], nparts, C, int(count), arrs["gamma"], arrs["beta"], float(eps),
                float(momentum), int(training), arrs["moving_mean"], arrs["moving_var"], arrs["mean_out"],
                arrs["rstd_out"], arrs["scale_out"], arrs["shift_out"]), "os2s_bn_finalize_multi")
@@ -610,9 +612,9 @@ def bn_finalize_multi(items, count, eps, momentum, training):
 
 def bn_stats(y2d):
   rows, C = y2d.shape
-  n = int(_fn("os2s_bn_stats_num_parts", (c_ll,))(rows))
+  n = int((_FN_CACHE.get("os2s_bn_stats_num_parts") or _fn("os2s_bn_stats_num_parts", (c_ll,)))(rows))
   partial = torch.empty((n, 2, C), dtype=torch.float32, device=y2d.device)
-  f = _fn("os2s_bn_stats", (c_void_p, c_void_p, c_ll, c_int, c_void_p))
+  f = (_FN_CACHE.get("os2s_bn_stats") or _fn("os2s_bn_stats", (c_void_p, c_void_p, c_ll, c_int, c_void_p)))
   _lib.check(f(_stream(), _ptr(y2d, torch.bfloat16), rows, C, _ptr(partial)), "os2s_bn_stats")
   return partial
 
@@ -626,10 +628,10 @@ def sample_norm_fwd(x, gamma, beta, mode, eps):
   z = torch.empty_like(x)
   mean = torch.empty((B, C), dtype=torch.float32, device=dev)
   rstd = torch.empty((B, C), dtype=torch.float32, device=dev)
-  nf = int(_fn("os2s_sample_norm_partial_floats", (c_int, c_int), c_size_t)(B, C))
+  nf = int((_FN_CACHE.get("os2s_sample_norm_partial_floats") or _fn("os2s_sample_norm_partial_floats", (c_int, c_int), c_size_t))(B, C))
   part = torch.empty(nf, dtype=torch.float32, device=dev)
-  f = _fn("os2s_sample_norm_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                                  c_void_p, c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_sample_norm_fwd") or _fn("os2s_sample_norm_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(gamma, torch.float32), _ptr(beta, torch.float32), B, T, C,
                int(mode), float(eps), _ptr(z, torch.bfloat16), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
                _ptr(part, torch.float32)), "os2s_sample_norm_fwd")
@@ -642,11 +644,11 @@ def sample_norm_bwd(dz, x, gamma, mean, rstd, mode, dgamma, dbeta):
   assert x.is_contiguous() and dz.is_contiguous()
   dev = x.device
   dx = torch.empty_like(x)
-  nf = int(_fn("os2s_sample_norm_partial_floats", (c_int, c_int), c_size_t)(B, C))
+  nf = int((_FN_CACHE.get("os2s_sample_norm_partial_floats") or _fn("os2s_sample_norm_partial_floats", (c_int, c_int), c_size_t))(B, C))
   part = torch.empty(nf, dtype=torch.float32, device=dev)
   scratch = torch.empty(4 * B * C, dtype=torch.float32, device=dev)
-  f = _fn("os2s_sample_norm_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_sample_norm_bwd") or _fn("os2s_sample_norm_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(x, torch.bfloat16), _ptr(gamma, torch.float32),
                _ptr(mean, torch.float32), _ptr(rstd, torch.float32), B, T, C, int(mode), _ptr(dx, torch.bfloat16),
                _ptr(dgamma, torch.float32), _ptr(dbeta, torch.float32), _ptr(part, torch.float32),
@@ -657,9 +659,9 @@ def sample_norm_bwd(dz, x, gamma, mean, rstd, mode, dgamma, dbeta):
 def bn_act_fwd(ys, scales, shifts, out, out_len, act, keep_prob, seed):
   B, T, C = out.shape
   J = len(ys)
-  f = _fn("os2s_bn_act_fwd",
+  f = (_FN_CACHE.get("os2s_bn_act_fwd") or _fn("os2s_bn_act_fwd",
           (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-           c_int, c_int, c_int, c_float, c_uint64))
+           c_int, c_int, c_int, c_float, c_uint64)))
   _lib.check(f(_stream(), J, _ptr_array(ys, torch.bfloat16),
                _ptr_array(scales, torch.float32), _ptr_array(shifts, torch.float32),
                _ptr(out, torch.bfloat16), _ptr(out_len, torch.int32, True), B, T, C,
@@ -668,16 +670,16 @@ def bn_act_fwd(ys, scales, shifts, out, out_len, act, keep_prob, seed):
 
 
 def bn_act_bwd_num_parts(rows):
-  return int(_fn("os2s_bn_act_bwd_num_parts", (c_ll,))(rows))
+  return int((_FN_CACHE.get("os2s_bn_act_bwd_num_parts") or _fn("os2s_bn_act_bwd_num_parts", (c_ll,)))(rows))
 
 
 def bn_act_bwd_reduce(dout, out, ys, means, rstds, dz, partial, out_len, act, keep_prob,
                       seed):
   B, T, C = out.shape
   J = len(ys)
-  f = _fn("os2s_bn_act_bwd_reduce",
+  f = (_FN_CACHE.get("os2s_bn_act_bwd_reduce") or _fn("os2s_bn_act_bwd_reduce",
           (c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint64))
+           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint64)))
   _lib.check(f(_stream(), J, _ptr(dout, torch.bfloat16), _ptr(out, torch.bfloat16),
                _ptr_array(ys, torch.bfloat16), _ptr_array(means, torch.float32),
                _ptr_array(rstds, torch.float32), _ptr(dz, torch.bfloat16),
@@ -688,9 +690,9 @@ def bn_act_bwd_reduce(dout, out, ys, means, rstds, dz, partial, out_len, act, ke
 
 def bn_bwd_finalize(partial, q, count, dgamma, dbeta, accumulate, c1, c2):
   nparts, nq, C = partial.shape
-  f = _fn("os2s_bn_bwd_finalize",
+  f = (_FN_CACHE.get("os2s_bn_bwd_finalize") or _fn("os2s_bn_bwd_finalize",
           (c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ll, c_void_p, c_void_p,
-           c_int, c_void_p, c_void_p))
+           c_int, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(partial, torch.float32), nparts, nq, q, C, int(count),
                _ptr(dgamma, torch.float32, True), _ptr(dbeta, torch.float32, True),
                int(accumulate), _ptr(c1, torch.float32), _ptr(c2, torch.float32)),
@@ -706,8 +708,8 @@ def bn_bwd_finalize_multi(partial, count, dgammas, dbetas, accumulate, c1, c2):
   arr = ctypes.c_void_p * J
   dg = arr(*[t.data_ptr() if t is not None else None for t in dgammas])
   db = arr(*[t.data_ptr() if t is not None else None for t in dbetas])
-  f = _fn("os2s_bn_bwd_finalize_multi",
-          (c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p, c_void_p, c_int, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_bn_bwd_finalize_multi") or _fn("os2s_bn_bwd_finalize_multi",
+          (c_void_p, c_void_p, c_int, c_int, c_int, c_ll, c_void_p, c_void_p, c_int, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(partial, torch.float32), nparts, J, C, int(count), dg, db,
                int(accumulate), _ptr(c1, torch.float32), _ptr(c2, torch.float32)),
              "os2s_bn_bwd_finalize_multi")
@@ -730,9 +732,9 @@ def bn_bwd_apply(dz, y, gamma, mean, rstd, c1, c2, dy, out_len=None, margin=0, d
                "os2s_bn_bwd_apply_ragged")
     return dy
   assert not dz_to_len
-  f = _fn("os2s_bn_bwd_apply",
+  f = (_FN_CACHE.get("os2s_bn_bwd_apply") or _fn("os2s_bn_bwd_apply",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-           c_void_p, c_void_p, c_ll, c_int))
+           c_void_p, c_void_p, c_ll, c_int)))
   _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(y, torch.bfloat16),
                _ptr(gamma, torch.float32, True), _ptr(mean, torch.float32),
                _ptr(rstd, torch.float32), _ptr(c1, torch.float32), _ptr(c2, torch.float32),
@@ -744,7 +746,7 @@ def dropout_mask(seed, n_elems, keep_prob, device):
   """Test hook: boolean keep mask [n_elems] the fused dropout uses."""
   assert n_elems % 8 == 0
   out = torch.empty((n_elems // 8,), dtype=torch.uint8, device=device)
-  f = _fn("os2s_dropout_mask", (c_void_p, c_uint64, c_ll, c_float, c_void_p))
+  f = (_FN_CACHE.get("os2s_dropout_mask") or _fn("os2s_dropout_mask", (c_void_p, c_uint64, c_ll, c_float, c_void_p)))
   _lib.check(f(_stream(), int(seed) & (2**64 - 1), n_elems // 8, float(keep_prob),
                _ptr(out)), "os2s_dropout_mask")
   bits = (out[:, None].to(torch.int32) >> torch.arange(8, device=device)[None, :]) & 1
@@ -762,18 +764,18 @@ def ctc_loss(logits, in_len, labels, label_len, blank=None, grad_scale=1.0,
   if blank is None:
     blank = V - 1
   dev = logits.device
-  nbytes = int(_fn("os2s_ctc_loss_workspace_bytes", (c_int, c_int, c_int, c_int),
-                   c_size_t)(T, B, V, Lmax))
+  nbytes = int((_FN_CACHE.get("os2s_ctc_loss_workspace_bytes") or _fn("os2s_ctc_loss_workspace_bytes", (c_int, c_int, c_int, c_int),
+                   c_size_t))(T, B, V, Lmax))
   ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
   lps = torch.empty((B,), dtype=torch.float32, device=dev)
   lm = torch.empty((1,), dtype=torch.float32, device=dev)
   dl = torch.empty((T, B, V), dtype=torch.float32, device=dev) if want_grad else None
   dl16 = (torch.empty((B, T, vpad), dtype=torch.bfloat16, device=dev)
           if want_grad_bf16 else None)
-  f = _fn("os2s_ctc_loss",
+  f = (_FN_CACHE.get("os2s_ctc_loss") or _fn("os2s_ctc_loss",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
            c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-           c_void_p, c_size_t))
+           c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(logits, torch.float32), _ptr(in_len, torch.int32),
                _ptr(labels, torch.int32), _ptr(label_len, torch.int32), T, B, V, Lmax,
                int(blank), float(grad_scale), _ptr(grad_scale_dev, torch.float32, True),
@@ -815,18 +817,18 @@ OPT_STATE_FIELDS = [
 
 
 def opt_chunk_elems():
-  return int(_fn("os2s_opt_chunk_elems", ())())
+  return int((_FN_CACHE.get("os2s_opt_chunk_elems") or _fn("os2s_opt_chunk_elems", ()))())
 
 
 def opt_state_bytes():
-  n = int(_fn("os2s_opt_state_bytes", (), c_size_t)())
-  assert int(_fn("os2s_opt_config_bytes", (), c_size_t)()) == _lib.ctypes.sizeof(OptConfig), \
+  n = int((_FN_CACHE.get("os2s_opt_state_bytes") or _fn("os2s_opt_state_bytes", (), c_size_t))())
+  assert int((_FN_CACHE.get("os2s_opt_config_bytes") or _fn("os2s_opt_config_bytes", (), c_size_t))()) == _lib.ctypes.sizeof(OptConfig), \
       "OptConfig ctypes mirror out of sync with os2s_opt_config_t"
   return n
 
 
 def opt_init_state(state, loss_scale):
-  f = _fn("os2s_opt_init_state", (c_void_p, c_void_p, c_float))
+  f = (_FN_CACHE.get("os2s_opt_init_state") or _fn("os2s_opt_init_state", (c_void_p, c_void_p, c_float)))
   _lib.check(f(_stream(), _ptr(state, torch.uint8), float(loss_scale)), "os2s_opt_init_state")
 
 
@@ -844,17 +846,17 @@ def gru_xcd_status(clear=False):
   """The sticky abort word of the persistent GRU kernels (csrc/rnn_xcd.hip): 0, or the OR of 1 = poll timeout,
   2 = workgroup placement. Definite after a stream synchronisation. clear=True resets it (the caller has
   discarded or redone the step)."""
-  return int(_fn("os2s_gru_xcd_status", (c_int,))(int(bool(clear))))
+  return int((_FN_CACHE.get("os2s_gru_xcd_status") or _fn("os2s_gru_xcd_status", (c_int,)))(int(bool(clear))))
 
 
 def gru_xcd_launch_count():
-  f = _fn("os2s_gru_xcd_launch_count", (), c_ll)
+  f = (_FN_CACHE.get("os2s_gru_xcd_launch_count") or _fn("os2s_gru_xcd_launch_count", (), c_ll))
   return int(f())
 
 
 def gru_xcd_set_mode(mode):
   """0: recurrent layers use the launch-per-step kernels, 1: persistent kernels where supported, -1: default."""
-  _fn("os2s_gru_xcd_set_mode", (c_int,), None)(int(mode))
+  (_FN_CACHE.get("os2s_gru_xcd_set_mode") or _fn("os2s_gru_xcd_set_mode", (c_int,), None))(int(mode))
 
 
 def gru_xcd_check(clear=False):
@@ -873,10 +875,10 @@ def opt_step(cfg, state, grads, weights, m1, m2, w16, chunk_tensor, tensor_chunk
              tensor_l2, tensor_wd_mask, partial, gnorm2, wnorm2, amax, mult, tensor_v):
   nchunks = chunk_tensor.numel()
   ntensors = tensor_chunk_begin.numel() - 1
-  f = _fn("os2s_opt_step",
+  f = (_FN_CACHE.get("os2s_opt_step") or _fn("os2s_opt_step",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-           c_void_p, c_void_p, c_void_p, c_void_p))
+           c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _lib.ctypes.byref(cfg), _ptr(state, torch.uint8),
                _ptr(grads, torch.float32), _ptr(weights, torch.float32),
                _ptr(m1, torch.float32, True), _ptr(m2, torch.float32, True),
@@ -894,9 +896,9 @@ def opt_prepare(cfg, state, grads, weights, chunk_tensor, tensor_chunk_begin, te
   """First half of opt_step (os2s_opt_prepare): everything that needs all gradients."""
   nchunks = chunk_tensor.numel()
   ntensors = tensor_chunk_begin.numel() - 1
-  f = _fn("os2s_opt_prepare",
+  f = (_FN_CACHE.get("os2s_opt_prepare") or _fn("os2s_opt_prepare",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p))
+           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _lib.ctypes.byref(cfg), _ptr(state, torch.uint8), _ptr(grads, torch.float32),
                _ptr(weights, torch.float32), nchunks, ntensors, _ptr(chunk_tensor, torch.int32),
                _ptr(tensor_chunk_begin, torch.int32), _ptr(tensor_l2, torch.float32, True),
@@ -908,9 +910,9 @@ def opt_prepare(cfg, state, grads, weights, chunk_tensor, tensor_chunk_begin, te
 def opt_apply_range(cfg, state, grads, weights, m1, m2, w16, chunk_begin, chunk_end, chunk_tensor, tensor_l2, mult,
                     zero_grads=False):
   """Second half (os2s_opt_apply_range): the update of chunks [chunk_begin, chunk_end) of the flat buffers."""
-  f = _fn("os2s_opt_apply_range",
+  f = (_FN_CACHE.get("os2s_opt_apply_range") or _fn("os2s_opt_apply_range",
           (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-           c_void_p, c_void_p, c_void_p, c_void_p, c_int))
+           c_void_p, c_void_p, c_void_p, c_void_p, c_int)))
   _lib.check(f(_stream(), _lib.ctypes.byref(cfg), _ptr(state, torch.uint8), _ptr(grads, torch.float32),
                _ptr(weights, torch.float32), _ptr(m1, torch.float32, True), _ptr(m2, torch.float32, True),
                _ptr(w16, torch.bfloat16, True), int(chunk_begin), int(chunk_end), _ptr(chunk_tensor, torch.int32),
@@ -920,15 +922,15 @@ def opt_apply_range(cfg, state, grads, weights, m1, m2, w16, chunk_begin, chunk_
 
 def cast_f32_to_bf16(src, dst):
   n = src.numel()
-  f = _fn("os2s_cast_f32_to_bf16", (c_void_p, c_void_p, c_void_p, c_ll))
+  f = (_FN_CACHE.get("os2s_cast_f32_to_bf16") or _fn("os2s_cast_f32_to_bf16", (c_void_p, c_void_p, c_void_p, c_ll)))
   _lib.check(f(_stream(), _ptr(src, torch.float32), _ptr(dst, torch.bfloat16), n),
              "os2s_cast_f32_to_bf16")
 
 
 def conv_weight_dgrad_copy(w16, wt16, descs, total_tiles):
   ndesc = descs.shape[0]
-  f = _fn("os2s_conv_weight_dgrad_copy",
-          (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int))
+  f = (_FN_CACHE.get("os2s_conv_weight_dgrad_copy") or _fn("os2s_conv_weight_dgrad_copy",
+          (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int)))
   _lib.check(f(_stream(), _ptr(w16, torch.bfloat16), _ptr(wt16, torch.bfloat16),
                _ptr(descs, torch.uint8), ndesc, int(total_tiles)),
              "os2s_conv_weight_dgrad_copy")
@@ -945,15 +947,15 @@ def logmel(signal, n_samples, window, mel_start, mel_len, mel_wt, *, hop, n_mels
   dev = signal.device
   is_i16 = signal.dtype == torch.int16
   assert is_i16 or signal.dtype == torch.float32
-  nbytes = int(_fn("os2s_logmel_workspace_bytes", (c_int, c_int, c_int), c_size_t)(B, tmax, n_mels))
+  nbytes = int((_FN_CACHE.get("os2s_logmel_workspace_bytes") or _fn("os2s_logmel_workspace_bytes", (c_int, c_int, c_int), c_size_t))(B, tmax, n_mels))
   ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
   out = torch.empty((B, tpad, n_mels), dtype=torch.bfloat16, device=dev)
   out32 = torch.empty((B, tpad, n_mels), dtype=torch.float32, device=dev) if want_f32 else None
   olen = torch.empty((B,), dtype=torch.int32, device=dev)
-  f = _fn("os2s_logmel",
+  f = (_FN_CACHE.get("os2s_logmel") or _fn("os2s_logmel",
           (c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_int, c_int, c_int, c_void_p,
            c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_uint64, c_float, c_float,
-           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(signal), _ptr(n_samples, torch.int32), int(is_i16), B, Nmax,
                n_fft, hop, n_mels, _ptr(window, torch.float32), _ptr(mel_start, torch.int32),
                _ptr(mel_len, torch.int32), _ptr(mel_wt, torch.float32), mel_wt.shape[0],
@@ -970,13 +972,13 @@ def psf_spectrogram(signal, n_samples, *, n_win, n_step, pad_to, num_features, t
   dev = signal.device
   is_i16 = signal.dtype == torch.int16
   assert is_i16 or signal.dtype == torch.float32
-  nbytes = int(_fn("os2s_psf_spectrogram_workspace_bytes", (c_int, c_int, c_int), c_size_t)(B, tpad, num_features))
+  nbytes = int((_FN_CACHE.get("os2s_psf_spectrogram_workspace_bytes") or _fn("os2s_psf_spectrogram_workspace_bytes", (c_int, c_int, c_int), c_size_t))(B, tpad, num_features))
   ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
   out = torch.empty((B, tpad, num_features), dtype=torch.bfloat16, device=dev)
   out32 = torch.empty((B, tpad, num_features), dtype=torch.float32, device=dev) if want_f32 else None
   olen = torch.empty((B,), dtype=torch.int32, device=dev)
-  f = _fn("os2s_psf_spectrogram", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int,
-                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_psf_spectrogram") or _fn("os2s_psf_spectrogram", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(signal), int(is_i16), _ptr(n_samples, torch.int32), B, Nmax, n_win, n_step,
                pad_to, num_features, tpad, _ptr(out), _ptr(out32, None, True), _ptr(olen), _ptr(ws), nbytes),
              "os2s_psf_spectrogram")
@@ -992,13 +994,13 @@ def psf_logfbank(signal, n_samples, fb, *, n_win, n_step, pad_to, nfft, tpad, wa
   assert is_i16 or signal.dtype == torch.float32
   nfilt = fb.shape[0]
   assert fb.is_contiguous() and fb.shape[1] == nfft // 2 + 1
-  nbytes = int(_fn("os2s_psf_spectrogram_workspace_bytes", (c_int, c_int, c_int), c_size_t)(B, tpad, nfilt))
+  nbytes = int((_FN_CACHE.get("os2s_psf_spectrogram_workspace_bytes") or _fn("os2s_psf_spectrogram_workspace_bytes", (c_int, c_int, c_int), c_size_t))(B, tpad, nfilt))
   ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
   out = torch.empty((B, tpad, nfilt), dtype=torch.bfloat16, device=dev)
   out32 = torch.empty((B, tpad, nfilt), dtype=torch.float32, device=dev) if want_f32 else None
   olen = torch.empty((B,), dtype=torch.int32, device=dev)
-  f = _fn("os2s_psf_logfbank", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int,
-                               c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_psf_logfbank") or _fn("os2s_psf_logfbank", (c_void_p, c_void_p, c_int, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int,
+                               c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)))
   _lib.check(f(_stream(), _ptr(signal), int(is_i16), _ptr(n_samples, torch.int32), B, Nmax, n_win, n_step,
                pad_to, nfilt, nfft, _ptr(fb, torch.float32), tpad, _ptr(out), _ptr(out32, None, True),
                _ptr(olen), _ptr(ws), nbytes), "os2s_psf_logfbank")
@@ -1014,9 +1016,9 @@ def augment_signal(signal, n_in, n_out, ratio, noise_amp, interp_win, num_table,
   assert is_i16 or signal.dtype == torch.float32
   out = torch.empty((B, int(nout_max)), dtype=torch.float32, device=dev)
   scratch = torch.empty(B, dtype=torch.int32, device=dev)
-  f = _fn("os2s_augment_signal", (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p,
+  f = (_FN_CACHE.get("os2s_augment_signal") or _fn("os2s_augment_signal", (c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_float, c_void_p, c_int, c_int, c_uint64, c_void_p, c_void_p,
-                                  c_ll))
+                                  c_ll)))
   _lib.check(f(_stream(), _ptr(signal), int(is_i16), B, Nmax, _ptr(n_in, torch.int32),
                _ptr(n_out, torch.int32), _ptr(ratio, torch.float64), _ptr(noise_amp, torch.float32, True),
                float(fixed_gain), _ptr(interp_win, torch.float32), interp_win.numel(), int(num_table),
@@ -1027,7 +1029,7 @@ def augment_signal(signal, n_in, n_out, ratio, noise_amp, interp_win, num_table,
 def spec_augment(feats, masks):
   """feats bf16 [B,T,F] (in place); masks int32 [B, n_masks, 4] = (t0, t1, f0, f1)."""
   B, T, F = feats.shape
-  f = _fn("os2s_spec_augment", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int))
+  f = (_FN_CACHE.get("os2s_spec_augment") or _fn("os2s_spec_augment", (c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int)))
   _lib.check(f(_stream(), _ptr(feats, torch.bfloat16), B, T, F, _ptr(masks, torch.int32), masks.shape[1]),
              "os2s_spec_augment")
   return feats
@@ -1080,8 +1082,8 @@ def gemm_nt(a, w, out=None, bias=None, act=0, keep_prob=1.0, seed=0, residual=No
   assert out.stride(1) == 1 and tuple(out.shape) == (M, N)
   assert residual is None or (residual.stride(1) == 1 and residual.stride(0) == out.stride(0))
   ws = conv1d_workspace(a.device)
-  f = _fn("os2s_gemm_nt_ws", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
-                             c_void_p, c_int, c_float, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_gemm_nt_ws") or _fn("os2s_gemm_nt_ws", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                             c_void_p, c_int, c_float, c_uint64, c_void_p, c_int, c_int, c_void_p, c_size_t)))
   _lib.check(f(_stream(), c_void_p(a.data_ptr()), a.stride(0), c_void_p(w.data_ptr()),
                c_void_p(out.data_ptr()), out.stride(0), M, N, K, _ptr(bias, torch.float32, True),
                int(act), float(keep_prob), int(seed) & (2**64 - 1),
@@ -1103,8 +1105,8 @@ def gemm_nt_mask(a, w, mask_ref, mask_scale, out=None, want_colsum=False):
   assert mask_ref.stride(1) == 1 and mask_ref.stride(0) == out.stride(0) and mask_ref.dtype == torch.bfloat16
   part = torch.empty(((M + 127) // 128, 2, N), dtype=torch.float32, device=a.device) if want_colsum else None
   ws = conv1d_workspace(a.device)
-  f = _fn("os2s_gemm_nt_mask_ws", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
-                                  c_void_p, c_float, c_void_p, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_gemm_nt_mask_ws") or _fn("os2s_gemm_nt_mask_ws", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_int, c_int, c_int,
+                                  c_void_p, c_float, c_void_p, c_void_p, c_size_t)))
   _lib.check(f(_stream(), c_void_p(a.data_ptr()), a.stride(0), c_void_p(w.data_ptr()),
                c_void_p(out.data_ptr()), out.stride(0), M, N, K, c_void_p(mask_ref.data_ptr()),
                float(mask_scale), _ptr(part, torch.float32, True), _ptr(ws), ws.numel()),
@@ -1115,7 +1117,7 @@ def gemm_nt_mask(a, w, mask_ref, mask_scale, out=None, want_colsum=False):
 def dense_epilogue(y, bias=None, act=0, keep_prob=1.0, seed=0, residual=None):
   """In place: y = residual + dropout(act(y + bias)) on bf16 [rows, C]."""
   rows, C = y.shape
-  f = _fn("os2s_dense_epilogue", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_float, c_uint64, c_void_p))
+  f = (_FN_CACHE.get("os2s_dense_epilogue") or _fn("os2s_dense_epilogue", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_float, c_uint64, c_void_p)))
   _lib.check(f(_stream(), _ptr(y, torch.bfloat16), _ptr(bias, torch.float32, True), rows, C, int(act),
                float(keep_prob), int(seed) & (2**64 - 1), _ptr(residual, torch.bfloat16, True)),
              "os2s_dense_epilogue")
@@ -1128,8 +1130,8 @@ def gemm_skinny(x2d, w, bias=None, relu=False, residual=None):
   N = w.shape[0]
   y = torch.empty((M, N), dtype=torch.bfloat16, device=x2d.device)
   assert x2d.stride(1) == 1 and w.stride(1) == 1 and (residual is None or residual.stride(1) == 1)
-  f = _fn("os2s_gemm_skinny", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_ll,
-                               c_int, c_int, c_int, c_int, c_void_p, c_ll))
+  f = (_FN_CACHE.get("os2s_gemm_skinny") or _fn("os2s_gemm_skinny", (c_void_p, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_ll,
+                               c_int, c_int, c_int, c_int, c_void_p, c_ll)))
   _lib.check(f(_stream(), c_void_p(x2d.data_ptr()), x2d.stride(0), c_void_p(w.data_ptr()), w.stride(0),
                _ptr(bias, torch.float32, True),
                c_void_p(residual.data_ptr()) if residual is not None else c_void_p(0),
@@ -1155,8 +1157,8 @@ def embed_fwd(ids, pos, table, emb_scale, keep_prob, seed, plain=False):
   N = ids.numel()
   V, D = table.shape
   out = torch.empty((N, D), dtype=torch.bfloat16, device=ids.device)
-  f = _fn("os2s_embed_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll,
-                             c_float, c_float, c_uint64, c_void_p, c_int))
+  f = (_FN_CACHE.get("os2s_embed_fwd") or _fn("os2s_embed_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll,
+                             c_float, c_float, c_uint64, c_void_p, c_int)))
   _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(pos, torch.int32, plain),
                _ptr(table, torch.bfloat16), V, D, N, float(emb_scale), float(keep_prob),
                int(seed) & (2**64 - 1), _ptr(out), int(plain)), "os2s_embed_fwd")
@@ -1166,8 +1168,8 @@ def embed_fwd(ids, pos, table, emb_scale, keep_prob, seed, plain=False):
 def embed_bwd(ids, dout, dtable, emb_scale, keep_prob, seed, plain=False):
   N = ids.numel()
   V, D = dtable.shape
-  f = _fn("os2s_embed_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_float,
-                             c_float, c_uint64, c_void_p, c_int))
+  f = (_FN_CACHE.get("os2s_embed_bwd") or _fn("os2s_embed_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_float,
+                             c_float, c_uint64, c_void_p, c_int)))
   _lib.check(f(_stream(), _ptr(ids, torch.int32), _ptr(dout, torch.bfloat16), V, D, N,
                float(emb_scale), float(keep_prob), int(seed) & (2**64 - 1),
                _ptr(dtable, torch.float32), int(plain)), "os2s_embed_bwd")
@@ -1178,8 +1180,8 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, save=True):
   y = torch.empty_like(x)
   mean = torch.empty(N, dtype=torch.float32, device=x.device) if save else None
   rstd = torch.empty(N, dtype=torch.float32, device=x.device) if save else None
-  f = _fn("os2s_layernorm_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_ll, c_int,
-                                 c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_layernorm_fwd") or _fn("os2s_layernorm_fwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_ll, c_int,
+                                 c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(gamma, torch.float32),
                _ptr(beta, torch.float32), float(eps), N, D, _ptr(y),
                _ptr(mean, None, True), _ptr(rstd, None, True)), "os2s_layernorm_fwd")
@@ -1192,10 +1194,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer_param_gra
   another stream: nothing in the rest of backward reads a parameter gradient)."""
   N, D = x.shape
   dx = torch.empty_like(x)
-  nparts = int(_fn("os2s_layernorm_bwd_num_parts", (c_ll,))(N))
+  nparts = int((_FN_CACHE.get("os2s_layernorm_bwd_num_parts") or _fn("os2s_layernorm_bwd_num_parts", (c_ll,)))(N))
   partial = torch.empty((nparts, 2, D), dtype=torch.float32, device=x.device)
-  f = _fn("os2s_layernorm_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_ll, c_int, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_layernorm_bwd") or _fn("os2s_layernorm_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_ll, c_int, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(dy, torch.bfloat16), _ptr(x, torch.bfloat16),
                _ptr(gamma, torch.float32), _ptr(mean, torch.float32), _ptr(rstd, torch.float32),
                _ptr(dres, torch.bfloat16, True), N, D, _ptr(dx), _ptr(partial)),
@@ -1213,8 +1215,8 @@ def dropout_bwd(dout, keep_prob, seed=0, out=None, capped=False):
   """mode 0 (hash mask) when out is None, mode 1 (relu+dropout via saved output) otherwise; capped: mode 2,
   the saved output is dropout(min(relu(.), 20)) — no gradient at the cap either."""
   d = torch.empty_like(dout)
-  f = _fn("os2s_dropout_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll,
-                               c_void_p))
+  f = (_FN_CACHE.get("os2s_dropout_bwd") or _fn("os2s_dropout_bwd", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll,
+                               c_void_p)))
   _lib.check(f(_stream(), _ptr(dout, torch.bfloat16), _ptr(out, torch.bfloat16, True),
                0 if out is None else (2 if capped else 1), float(keep_prob), int(seed) & (2**64 - 1),
                dout.numel(), _ptr(d)), "os2s_dropout_bwd")
@@ -1227,10 +1229,10 @@ def dropout_bwd_colsum(dout2d, keep_prob, seed=0, out=None, capped=False):
   rows, C = dout2d.shape
   assert dout2d.is_contiguous()
   d = torch.empty_like(dout2d)
-  n = int(_fn("os2s_dropout_bwd_colsum_num_parts", (c_ll,))(rows))
+  n = int((_FN_CACHE.get("os2s_dropout_bwd_colsum_num_parts") or _fn("os2s_dropout_bwd_colsum_num_parts", (c_ll,)))(rows))
   partial = torch.empty((n, 2, C), dtype=torch.float32, device=dout2d.device)
-  f = _fn("os2s_dropout_bwd_colsum", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll, c_int,
-                                      c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_dropout_bwd_colsum") or _fn("os2s_dropout_bwd_colsum", (c_void_p, c_void_p, c_void_p, c_int, c_float, c_uint64, c_ll, c_int,
+                                      c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(dout2d, torch.bfloat16), _ptr(out, torch.bfloat16, True),
                0 if out is None else (2 if capped else 1), float(keep_prob), int(seed) & (2**64 - 1), rows, C,
                _ptr(d), _ptr(partial)), "os2s_dropout_bwd_colsum")
@@ -1239,7 +1241,7 @@ def dropout_bwd_colsum(dout2d, keep_prob, seed=0, out=None, capped=False):
 
 def add_bf16(a, b, out=None):
   out = torch.empty_like(a) if out is None else out
-  f = _fn("os2s_add_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))
+  f = (_FN_CACHE.get("os2s_add_bf16") or _fn("os2s_add_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p)))
   _lib.check(f(_stream(), _ptr(a, torch.bfloat16), _ptr(b, torch.bfloat16), a.numel(),
                _ptr(out)), "os2s_add_bf16")
   return out
@@ -1253,9 +1255,9 @@ def attention_fwd(q, k, v, cu_q, cu_k, H, max_len, causal, scale, keep_prob=1.0,
   B = cu_q.numel() - 1
   o = torch.empty((Nq, H * dh), dtype=torch.bfloat16, device=q.device)
   lse = torch.empty((Nq, H), dtype=torch.float32, device=q.device)
-  f = _fn("os2s_attention_fwd",
+  f = (_FN_CACHE.get("os2s_attention_fwd") or _fn("os2s_attention_fwd",
           (c_void_p,) * 8 + (c_int, c_int, c_int, c_int, c_ll, c_ll, c_ll, c_ll, c_int, c_float,
-                             c_float, c_uint64))
+                             c_float, c_uint64)))
   _lib.check(f(_stream(), c_void_p(q.data_ptr()), c_void_p(k.data_ptr()), c_void_p(v.data_ptr()),
                _ptr(o), _ptr(lse), _ptr(cu_q, torch.int32), _ptr(cu_k, torch.int32), B, H, dh,
                int(max_len), q.stride(0), k.stride(0), v.stride(0), o.stride(0), int(causal),
@@ -1266,9 +1268,9 @@ def attention_fwd(q, k, v, cu_q, cu_k, H, max_len, causal, scale, keep_prob=1.0,
 def attention_bwd(q, k, v, d_o, lse, dq, dk, dv, cu_q, cu_k, H, max_len, causal, scale,
                   keep_prob=1.0, seed=0):
   B = cu_q.numel() - 1
-  f = _fn("os2s_attention_bwd",
+  f = (_FN_CACHE.get("os2s_attention_bwd") or _fn("os2s_attention_bwd",
           (c_void_p,) * 11 + (c_int, c_int, c_int, c_int) + (c_ll,) * 7 + (c_int, c_float, c_float,
-                                                                         c_uint64))
+                                                                         c_uint64)))
   _lib.check(f(_stream(), c_void_p(q.data_ptr()), c_void_p(k.data_ptr()), c_void_p(v.data_ptr()),
                _ptr(d_o, torch.bfloat16), _ptr(lse, torch.float32), c_void_p(dq.data_ptr()),
                c_void_p(dk.data_ptr()), c_void_p(dv.data_ptr()), _ptr(cu_q, torch.int32),
@@ -1286,8 +1288,8 @@ def xent_smooth(logits, labels, label_smoothing, grad_scale_dev=None, want_grad=
   row_loss = torch.empty(N, dtype=torch.float32, device=dev)
   mean = torch.empty(1, dtype=torch.float32, device=dev)
   dl = torch.empty_like(logits) if want_grad else None
-  f = _fn("os2s_xent_smooth", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_ll, c_float,
-                               c_float, c_void_p, c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_xent_smooth") or _fn("os2s_xent_smooth", (c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_ll, c_float,
+                               c_float, c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(logits, torch.bfloat16), _ptr(labels, torch.int32), N, V,
                V if v_valid is None else int(v_valid), logits.stride(0), float(label_smoothing),
                1.0 / N if grad_scale is None else float(grad_scale),
@@ -1300,7 +1302,7 @@ def argmax_rows(x2d, v_valid=None):
   """bf16 [N, ld] -> int32 [N] argmax over the first v_valid columns."""
   N, V = x2d.shape
   out = torch.empty(N, dtype=torch.int32, device=x2d.device)
-  f = _fn("os2s_argmax_rows", (c_void_p, c_void_p, c_ll, c_int, c_ll, c_void_p))
+  f = (_FN_CACHE.get("os2s_argmax_rows") or _fn("os2s_argmax_rows", (c_void_p, c_void_p, c_ll, c_int, c_ll, c_void_p)))
   _lib.check(f(_stream(), _ptr(x2d, torch.bfloat16), N, V if v_valid is None else int(v_valid),
                x2d.stride(0), _ptr(out)), "os2s_argmax_rows")
   return out
@@ -1328,7 +1330,7 @@ class BeamState(object):
     lengths = np.arange(L1, dtype=np.float32)
     lnorm = np.power(((np.float32(5.0) + lengths) / np.float32(6.0)).astype(np.float32), np.float32(alpha)).astype(np.float32)
     self.lnorm = torch.from_numpy(lnorm).to(dev)
-    wsb = _fn("os2s_beam_workspace_bytes", (c_int, c_int, c_int), c_ll)
+    wsb = (_FN_CACHE.get("os2s_beam_workspace_bytes") or _fn("os2s_beam_workspace_bytes", (c_int, c_int, c_int), c_ll))
     self.ws = torch.empty(max(int(wsb(B, beam, self.V)), 16), dtype=torch.uint8, device=dev)
     self.topk_lp = torch.zeros((B, 2 * beam), dtype=torch.float32, device=dev) if debug else None
     self.topk_idx = torch.zeros((B, 2 * beam), dtype=torch.int32, device=dev) if debug else None
@@ -1339,7 +1341,7 @@ class BeamState(object):
 
   def reset(self):
     """_create_initial_state."""
-    f = _fn("os2s_beam_init", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 9)
+    f = (_FN_CACHE.get("os2s_beam_init") or _fn("os2s_beam_init", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 9))
     _lib.check(f(_stream(), self.B, self.beam, self.max_len, _ptr(self.initial_ids, torch.int32),
                  _ptr(self.status), _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp),
                  _ptr(self.fin_scores), _ptr(self.fin_flags), _ptr(self.last_ids), _ptr(self.pos)),
@@ -1355,8 +1357,8 @@ class BeamState(object):
     assert logits.shape[0] == N and logits.stride(1) == 1 and logits.shape[1] >= self.V
     if logits.dtype not in (torch.float32, torch.bfloat16):
       raise TypeError("logits must be fp32 or bf16")
-    f = _fn("os2s_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int)
-            + (c_void_p,) * 13)
+    f = (_FN_CACHE.get("os2s_beam_step") or _fn("os2s_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int)
+            + (c_void_p,) * 13))
     _lib.check(f(_stream(), c_void_p(logits.data_ptr()), int(logits.dtype == torch.float32),
                  logits.stride(0), self.B, self.beam, self.V, self.max_len, self.eos, _ptr(self.lnorm),
                  _ptr(self.status), _ptr(self.alive_seq), _ptr(self.fin_seq), _ptr(self.alive_lp),
@@ -1371,7 +1373,7 @@ class BeamState(object):
   def finalize(self):
     out_seq = torch.empty((self.B, self.beam, self.max_len + 1), dtype=torch.int32, device=self.status.device)
     out_scores = torch.empty((self.B, self.beam), dtype=torch.float32, device=self.status.device)
-    f = _fn("os2s_beam_finalize", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 8)
+    f = (_FN_CACHE.get("os2s_beam_finalize") or _fn("os2s_beam_finalize", (c_void_p, c_int, c_int, c_int) + (c_void_p,) * 8))
     _lib.check(f(_stream(), self.B, self.beam, self.max_len, _ptr(self.status), _ptr(self.alive_seq),
                  _ptr(self.fin_seq), _ptr(self.alive_lp), _ptr(self.fin_scores), _ptr(self.fin_flags),
                  _ptr(out_seq), _ptr(out_scores)), "os2s_beam_finalize")
@@ -1392,14 +1394,14 @@ class TfBeamState(object):
     self.word_ids = torch.zeros(N, dtype=torch.int32, device=device)
     self.parent = torch.zeros(N, dtype=torch.int32, device=device)
     self.scores = torch.zeros(N, dtype=torch.float32, device=device)
-    wsb = _fn("os2s_tf_beam_workspace_bytes", (c_int, c_int), c_ll)
+    wsb = (_FN_CACHE.get("os2s_tf_beam_workspace_bytes") or _fn("os2s_tf_beam_workspace_bytes", (c_int, c_int), c_ll))
     self.ws = torch.empty(int(wsb(self.B, self.beam)), dtype=torch.uint8, device=device)
 
   def step(self, logits, time):
     N = self.B * self.beam
     assert logits.shape[0] == N and logits.stride(1) == 1 and logits.shape[1] >= self.V
-    f = _fn("os2s_tf_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_float)
-            + (c_void_p,) * 7)
+    f = (_FN_CACHE.get("os2s_tf_beam_step") or _fn("os2s_tf_beam_step", (c_void_p, c_void_p, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_float)
+            + (c_void_p,) * 7))
     _lib.check(f(_stream(), c_void_p(logits.data_ptr()), int(logits.dtype == torch.float32), logits.stride(0),
                  self.B, self.beam, self.V, self.eos, int(time), self.lpw, _ptr(self.log_probs),
                  _ptr(self.finished), _ptr(self.lengths), _ptr(self.word_ids), _ptr(self.parent),
@@ -1413,7 +1415,7 @@ def gather_rows(src, idx, enable=None, out=None):
   row_bytes = src.element_size() * (src.numel() // max(src.shape[0], 1))
   if out is None:
     out = torch.empty((rows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-  f = _fn("os2s_gather_rows", (c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_gather_rows") or _fn("os2s_gather_rows", (c_void_p, c_void_p, c_void_p, c_ll, c_ll, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(src), _ptr(idx), rows, row_bytes, _ptr(enable, allow_none=True),
                _ptr(out)), "os2s_gather_rows")
   return out
@@ -1425,9 +1427,9 @@ def decode_self_attention(q, knew, vnew, kcache, vcache, ancestry, H, step, scal
   Tmax = kcache.shape[1]
   o = torch.empty((N, D), dtype=torch.bfloat16, device=q.device)
   assert knew.stride(0) == vnew.stride(0) and q.stride(1) == 1 and knew.stride(1) == 1
-  f = _fn("os2s_decode_self_attention", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p,
+  f = (_FN_CACHE.get("os2s_decode_self_attention") or _fn("os2s_decode_self_attention", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p,
                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                         c_float, c_void_p, c_ll))
+                                         c_float, c_void_p, c_ll)))
   _lib.check(f(_stream(), c_void_p(q.data_ptr()), q.stride(0), c_void_p(knew.data_ptr()),
                c_void_p(vnew.data_ptr()), knew.stride(0), _ptr(kcache, torch.bfloat16),
                _ptr(vcache, torch.bfloat16), _ptr(ancestry, torch.int32), N, H, D // H, Tmax, int(step),
@@ -1440,8 +1442,8 @@ def decode_cross_attention(q, k, v, cu_k, beam, H, max_len, scale):
   N, D = q.shape
   o = torch.empty((N, D), dtype=torch.bfloat16, device=q.device)
   assert k.stride(0) == v.stride(0) and k.stride(1) == 1 and q.stride(1) == 1
-  f = _fn("os2s_decode_cross_attention", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p,
-                                          c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_ll))
+  f = (_FN_CACHE.get("os2s_decode_cross_attention") or _fn("os2s_decode_cross_attention", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_ll, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_ll)))
   _lib.check(f(_stream(), c_void_p(q.data_ptr()), q.stride(0), c_void_p(k.data_ptr()),
                c_void_p(v.data_ptr()), k.stride(0), _ptr(cu_k, torch.int32), int(beam), N, H, D // H,
                int(max_len), float(scale), _ptr(o), D), "os2s_decode_cross_attention")
@@ -1496,10 +1498,10 @@ def rnn_layer_fwd_multi(cell, dirs, lens, H, forget_bias=1.0, save=True):
     arr[i].gates, arr[i].c_seq = _addr(gates), _addr(c_seq)
     arr[i].reverse = int(bool(d["reverse"]))
     outs.append((y, gates, c_seq))
-  n = nd * int(_fn("os2s_rnn_fwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
+  n = nd * int((_FN_CACHE.get("os2s_rnn_fwd_workspace_bytes") or _fn("os2s_rnn_fwd_workspace_bytes", (c_int, c_int), c_size_t))(B, H))
   ws = torch.empty((n,), dtype=torch.uint8, device=dev)
-  f = _fn("os2s_rnn_layer_fwd_multi", (c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
-                                       c_int, c_float, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_rnn_layer_fwd_multi") or _fn("os2s_rnn_layer_fwd_multi", (c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_float, c_void_p, c_size_t)))
   _lib.check(f(_stream(), int(cell), nd, _lib.ctypes.byref(arr), _ptr(lens, torch.int32, True), B, T,
                H, float(forget_bias), _ptr(ws), n), "os2s_rnn_layer_fwd_multi")
   return outs
@@ -1531,10 +1533,10 @@ def rnn_layer_bwd_multi(cell, dirs, lens, H, forget_bias=1.0):
     arr[i].dgx, arr[i].dgr = dgx.data_ptr(), _addr(dgr)
     arr[i].reverse = int(bool(d["reverse"]))
     outs.append((dgx, dgr if dgr is not None else dgx))
-  n = nd * int(_fn("os2s_rnn_bwd_workspace_bytes", (c_int, c_int), c_size_t)(B, H))
+  n = nd * int((_FN_CACHE.get("os2s_rnn_bwd_workspace_bytes") or _fn("os2s_rnn_bwd_workspace_bytes", (c_int, c_int), c_size_t))(B, H))
   ws = torch.empty((n,), dtype=torch.uint8, device=dev)
-  f = _fn("os2s_rnn_layer_bwd_multi", (c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
-                                       c_int, c_float, c_void_p, c_size_t))
+  f = (_FN_CACHE.get("os2s_rnn_layer_bwd_multi") or _fn("os2s_rnn_layer_bwd_multi", (c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_float, c_void_p, c_size_t)))
   _lib.check(f(_stream(), int(cell), nd, _lib.ctypes.byref(arr), _ptr(lens, torch.int32, True), B, T,
                H, float(forget_bias), _ptr(ws), n), "os2s_rnn_layer_bwd_multi")
   return outs
@@ -1550,7 +1552,7 @@ def rnn_layer_bwd(cell, whT, lens, dy, y, gates, c_seq, H, reverse, forget_bias=
 # --------------------------------------------------------------------------
 def conv2d_toeplitz_expand(w, Fi, Fo, sF, padF, out):
   KT, KF, Cin, Cout = w.shape
-  f = _fn("os2s_conv2d_toeplitz_expand", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,))
+  f = (_FN_CACHE.get("os2s_conv2d_toeplitz_expand") or _fn("os2s_conv2d_toeplitz_expand", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,)))
   _lib.check(f(_stream(), _ptr(w, torch.float32), KT, KF, Cin, Cout, Fi, Fo, sF, padF,
                _ptr(out, torch.bfloat16)), "os2s_conv2d_toeplitz_expand")
   return out
@@ -1558,7 +1560,7 @@ def conv2d_toeplitz_expand(w, Fi, Fo, sF, padF, out):
 
 def conv2d_toeplitz_reduce(dwexp, Fi, Fo, sF, padF, dw):
   KT, KF, Cin, Cout = dw.shape
-  f = _fn("os2s_conv2d_toeplitz_reduce", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,))
+  f = (_FN_CACHE.get("os2s_conv2d_toeplitz_reduce") or _fn("os2s_conv2d_toeplitz_reduce", (c_void_p, c_void_p) + (c_int,) * 8 + (c_void_p,)))
   _lib.check(f(_stream(), _ptr(dwexp, torch.float32), KT, KF, Cin, Cout, Fi, Fo, sF, padF,
                _ptr(dw, torch.float32)), "os2s_conv2d_toeplitz_reduce")
 
@@ -1594,7 +1596,7 @@ def quantize_rows_e4m3(w2d, q=None, scale=None):
   if q is None:
     q = torch.empty((rows, K), dtype=torch.uint8, device=w2d.device)
     scale = torch.empty((rows,), dtype=torch.float32, device=w2d.device)
-  f = _fn("os2s_quantize_rows_e4m3", (c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_quantize_rows_e4m3") or _fn("os2s_quantize_rows_e4m3", (c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p)))
   _lib.check(f(_stream(), _ptr(w2d, torch.bfloat16), rows, K, _ptr(q, torch.uint8), _ptr(scale, torch.float32)),
              "os2s_quantize_rows_e4m3")
   return q, scale
@@ -1685,7 +1687,7 @@ class AttnDecoder(object):
   def forward(self, t_begin=0, t_end=None):
     t_end = self.dims["T"] if t_end is None else t_end
     d = self._desc(t_begin, t_end)
-    f = _fn("os2s_attn_decoder_fwd", (c_void_p, c_void_p))
+    f = (_FN_CACHE.get("os2s_attn_decoder_fwd") or _fn("os2s_attn_decoder_fwd", (c_void_p, c_void_p)))
     _lib.check(f(_stream(), _lib.ctypes.byref(d)), "os2s_attn_decoder_fwd")
 
   def backward(self, wcatT, wqT, dy_top=None, dctx_ext=None, dv=None, dg=None, dconv_w=None,
@@ -1716,9 +1718,9 @@ class AttnDecoder(object):
     g.dv, g.dg_scalar = _addr(dv), _addr(dg)
     g.dconv_w, g.dconv_b, g.ddense_w = _addr(dconv_w), _addr(dconv_b), _addr(ddense_w)
     d = self._desc(0, T)
-    n = int(_fn("os2s_attn_decoder_bwd_workspace_bytes", (c_void_p,), c_size_t)(_lib.ctypes.byref(d)))
+    n = int((_FN_CACHE.get("os2s_attn_decoder_bwd_workspace_bytes") or _fn("os2s_attn_decoder_bwd_workspace_bytes", (c_void_p,), c_size_t))(_lib.ctypes.byref(d)))
     ws = torch.empty((n,), dtype=torch.uint8, device=dev)
-    f = _fn("os2s_attn_decoder_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_size_t))
+    f = (_FN_CACHE.get("os2s_attn_decoder_bwd") or _fn("os2s_attn_decoder_bwd", (c_void_p, c_void_p, c_void_p, c_void_p, c_size_t)))
     _lib.check(f(_stream(), _lib.ctypes.byref(d), _lib.ctypes.byref(g), _ptr(ws), n),
                "os2s_attn_decoder_bwd")
     return out
@@ -1750,7 +1752,7 @@ class TacotronInfer(object):
     self.mel = torch.zeros((B, T, n_mel), dtype=torch.bfloat16, device=dev)
     self.stop = torch.zeros((B, T), dtype=torch.float32, device=dev)
     self.mh = torch.zeros((B, n_mel), dtype=torch.float32, device=dev)
-    n = int(_fn("os2s_tacotron_infer_state_ints", (c_int,), c_size_t)(B))
+    n = int((_FN_CACHE.get("os2s_tacotron_infer_state_ints") or _fn("os2s_tacotron_infer_state_ints", (c_int,), c_size_t))(B))
     self.state = torch.zeros((n,), dtype=torch.int32, device=dev)
     self._keep_alive = None
 
@@ -1773,11 +1775,11 @@ class TacotronInfer(object):
     return x
 
   def supported(self):
-    return bool(_fn("os2s_tacotron_infer_supported", (c_void_p,))(_lib.ctypes.byref(self._desc())))
+    return bool((_FN_CACHE.get("os2s_tacotron_infer_supported") or _fn("os2s_tacotron_infer_supported", (c_void_p,)))(_lib.ctypes.byref(self._desc())))
 
   def steps(self, t_begin, t_end):
     x = self._desc()
-    f = _fn("os2s_tacotron_infer_steps", (c_void_p, c_void_p, c_int, c_int))
+    f = (_FN_CACHE.get("os2s_tacotron_infer_steps") or _fn("os2s_tacotron_infer_steps", (c_void_p, c_void_p, c_int, c_int)))
     _lib.check(f(_stream(), _lib.ctypes.byref(x), int(t_begin), int(t_end)), "os2s_tacotron_infer_steps")
 
   def done_steps(self):
@@ -1821,11 +1823,11 @@ def tts_loss(pred, target, lens, F, mode, weight, loss, grad_scale_dev=None, wan
   assert pred.stride(2) == 1 and pred.stride(0) == Tp * pred.stride(1)
   assert target.stride(2) == 1 and target.stride(0) == Tt * target.stride(1)
   dev = pred.device
-  nparts = int(_fn("os2s_tts_loss_num_parts", (c_int, c_int))(B, max(Tp, Tt)))
+  nparts = int((_FN_CACHE.get("os2s_tts_loss_num_parts") or _fn("os2s_tts_loss_num_parts", (c_int, c_int)))(B, max(Tp, Tt)))
   partial = torch.empty(nparts, dtype=torch.float32, device=dev)
   dpred = torch.zeros((B, Tp, pred.stride(1)), dtype=torch.bfloat16, device=dev) if want_grad else None
-  f = _fn("os2s_tts_loss_padded", (c_void_p, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_float, c_void_p,
-                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_tts_loss_padded") or _fn("os2s_tts_loss_padded", (c_void_p, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_float, c_void_p,
+                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p)))
   _lib.check(f(_stream(), c_void_p(pred.data_ptr()), pred.stride(1), Tp, c_void_p(target.data_ptr()),
                target.stride(1), Tt, float(target_pad), _ptr(lens, torch.int32, True), B, F, mode, float(weight),
                _ptr(grad_scale_dev, torch.float32, True), _ptr(partial), _ptr(loss, torch.float32),
@@ -1835,28 +1837,28 @@ def tts_loss(pred, target, lens, F, mode, weight, loss, grad_scale_dev=None, wan
 
 def exp_fwd(x):
   y = torch.empty_like(x)
-  _lib.check(_fn("os2s_exp_fwd", (c_void_p, c_void_p, c_ll, c_void_p))(
+  _lib.check((_FN_CACHE.get("os2s_exp_fwd") or _fn("os2s_exp_fwd", (c_void_p, c_void_p, c_ll, c_void_p)))(
       _stream(), _ptr(x, torch.bfloat16), x.numel(), _ptr(y)), "os2s_exp_fwd")
   return y
 
 
 def tanh_fwd(x):
   y = torch.empty_like(x)
-  _lib.check(_fn("os2s_tanh_fwd", (c_void_p, c_void_p, c_ll, c_void_p))(
+  _lib.check((_FN_CACHE.get("os2s_tanh_fwd") or _fn("os2s_tanh_fwd", (c_void_p, c_void_p, c_ll, c_void_p)))(
       _stream(), _ptr(x, torch.bfloat16), x.numel(), _ptr(y)), "os2s_tanh_fwd")
   return y
 
 
 def tanh_bwd(dy, y):
   dx = torch.empty_like(y)
-  _lib.check(_fn("os2s_tanh_bwd", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))(
+  _lib.check((_FN_CACHE.get("os2s_tanh_bwd") or _fn("os2s_tanh_bwd", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p)))(
       _stream(), _ptr(dy, torch.bfloat16), _ptr(y, torch.bfloat16), y.numel(), _ptr(dx)), "os2s_tanh_bwd")
   return dx
 
 
 def mul_bf16(a, b):
   y = torch.empty_like(a)
-  _lib.check(_fn("os2s_mul_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p))(
+  _lib.check((_FN_CACHE.get("os2s_mul_bf16") or _fn("os2s_mul_bf16", (c_void_p, c_void_p, c_void_p, c_ll, c_void_p)))(
       _stream(), _ptr(a, torch.bfloat16), _ptr(b, torch.bfloat16), a.numel(), _ptr(y)), "os2s_mul_bf16")
   return y
 
@@ -1865,7 +1867,7 @@ def sum_time(x, out, accumulate=False):
   """x bf16 [B,T,C] (may be a channel-slice view) -> out fp32 [B,C] (+)= sum over T."""
   B, T, C = x.shape
   assert x.stride(2) == 1 and x.stride(0) == T * x.stride(1)
-  _lib.check(_fn("os2s_sum_time", (c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_int))(
+  _lib.check((_FN_CACHE.get("os2s_sum_time") or _fn("os2s_sum_time", (c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_void_p, c_int)))(
       _stream(), c_void_p(x.data_ptr()), x.stride(1), B, T, C, _ptr(out, torch.float32),
       int(accumulate)), "os2s_sum_time")
   return out
@@ -1887,7 +1889,7 @@ def gru_tf_fwd(gxg, gxc, wgh, wch, lens):
             hprev16=torch.empty((B, T, H), dtype=bf, device=dev),
             rh16=torch.empty((B, T, H), dtype=bf, device=dev),
             h_final=torch.empty((B, H), dtype=f32, device=dev))
-  f = _fn("os2s_gru_tf_fwd", (c_void_p,) * 6 + (c_int,) * 3 + (c_void_p,) * 7)
+  f = (_FN_CACHE.get("os2s_gru_tf_fwd") or _fn("os2s_gru_tf_fwd", (c_void_p,) * 6 + (c_int,) * 3 + (c_void_p,) * 7))
   _lib.check(f(_stream(), _ptr(gxg, bf), _ptr(gxc, bf), _ptr(wgh, f32), _ptr(wch, f32),
                _ptr(lens, torch.int32, True), B, T, H, _ptr(sv["h_seq"]), _ptr(sv["r_seq"]),
                _ptr(sv["u_seq"]), _ptr(sv["c_seq"]), _ptr(sv["hprev16"]), _ptr(sv["rh16"]),
@@ -1900,7 +1902,7 @@ def gru_tf_bwd(dh_final, wghT, wchT, lens, sv):
   dev = dh_final.device
   dgxg = torch.empty((B, T, 2 * H), dtype=torch.bfloat16, device=dev)
   dgxc = torch.empty((B, T, H), dtype=torch.bfloat16, device=dev)
-  f = _fn("os2s_gru_tf_bwd", (c_void_p,) * 5 + (c_int,) * 3 + (c_void_p,) * 6)
+  f = (_FN_CACHE.get("os2s_gru_tf_bwd") or _fn("os2s_gru_tf_bwd", (c_void_p,) * 5 + (c_int,) * 3 + (c_void_p,) * 6))
   _lib.check(f(_stream(), _ptr(dh_final, torch.float32), _ptr(wghT, torch.float32),
                _ptr(wchT, torch.float32), _ptr(lens, torch.int32, True), B, T, H, _ptr(sv["h_seq"]),
                _ptr(sv["r_seq"]), _ptr(sv["u_seq"]), _ptr(sv["c_seq"]), _ptr(dgxg), _ptr(dgxc)),
@@ -1913,7 +1915,7 @@ def gst_attention_fwd(q, k, v, att_v, heads):
   N = k.shape[0]
   out = torch.empty_like(q)
   w = torch.empty((B, heads, N), dtype=torch.float32, device=q.device)
-  f = _fn("os2s_gst_attention_fwd", (c_void_p,) * 5 + (c_int,) * 3 + (c_void_p,) * 2)
+  f = (_FN_CACHE.get("os2s_gst_attention_fwd") or _fn("os2s_gst_attention_fwd", (c_void_p,) * 5 + (c_int,) * 3 + (c_void_p,) * 2))
   _lib.check(f(_stream(), _ptr(q, torch.bfloat16), _ptr(k, torch.bfloat16), _ptr(v, torch.bfloat16),
                _ptr(att_v, torch.float32), B, heads, N, _ptr(out), _ptr(w)), "os2s_gst_attention_fwd")
   return out, w
@@ -1923,7 +1925,7 @@ def gst_attention_bwd(dout, q, k, v, att_v, w, heads, dk, dv, datt_v):
   B, D = q.shape
   N = k.shape[0]
   dq = torch.empty_like(q)
-  f = _fn("os2s_gst_attention_bwd", (c_void_p,) * 7 + (c_int,) * 3 + (c_void_p,) * 4)
+  f = (_FN_CACHE.get("os2s_gst_attention_bwd") or _fn("os2s_gst_attention_bwd", (c_void_p,) * 7 + (c_int,) * 3 + (c_void_p,) * 4))
   _lib.check(f(_stream(), _ptr(dout, torch.bfloat16), _ptr(q, torch.bfloat16), _ptr(k, torch.bfloat16),
                _ptr(v, torch.bfloat16), _ptr(att_v, torch.float32), _ptr(w, torch.float32), B, heads,
                N, _ptr(dq), _ptr(dk, torch.float32), _ptr(dv, torch.float32),
@@ -1939,9 +1941,9 @@ def tts_spectrogram(signal, n_samples, window, *, n_fft, hop, T, mag_power, data
   f32 = torch.float32
   mel = torch.empty((B, T, n_mels), dtype=f32, device=dev) if n_mels else None
   mag = torch.empty((B, T, n_mag), dtype=f32, device=dev) if n_mag else None
-  f = _fn("os2s_tts_spectrogram", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_int,
+  f = (_FN_CACHE.get("os2s_tts_spectrogram") or _fn("os2s_tts_spectrogram", (c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
-                                   c_void_p, c_int, c_void_p, c_void_p, c_float, c_float))
+                                   c_void_p, c_int, c_void_p, c_void_p, c_float, c_float)))
   _lib.check(f(_stream(), _ptr(signal, f32), signal.stride(0), _ptr(n_samples, torch.int32),
                _ptr(window, f32), B, n_fft, hop, T, mag_power, float(data_min_mag), float(data_min_mel),
                n_mag or 0, n_mels or 0, _ptr(mel_start, torch.int32, True), _ptr(mel_len, torch.int32, True),
@@ -1961,7 +1963,7 @@ def depthwise_conv1d_fwd(x, w, *, stride=1, dil=1, pad_left=None, tout=None, in_
   if pad_left is None or tout is None:
     tout, pad_left = same_padding(Tin, K, stride, dil)
   y = (torch.zeros if out_len is not None else torch.empty)((B, tout, C), dtype=torch.bfloat16, device=x.device)
-  f = _fn("os2s_depthwise_conv1d_fwd", (c_void_p,) * 6 + (c_int,) * 9)
+  f = (_FN_CACHE.get("os2s_depthwise_conv1d_fwd") or _fn("os2s_depthwise_conv1d_fwd", (c_void_p,) * 6 + (c_int,) * 9))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(w, torch.float32), _ptr(y),
                _ptr(in_len, torch.int32, True), _ptr(out_len, torch.int32, True), B, Tin, tout, C, K,
                stride, dil, pad_left, int(flip)), "os2s_depthwise_conv1d_fwd")
@@ -1982,9 +1984,9 @@ def depthwise_dgrad_bnact(dz, w, dx, *, pad_left, out_len, mask_ref, mask_scale,
   assert tuple(dx.shape) == (B, Tout, C) == tuple(mask_ref.shape) == tuple(stat_ref.shape)
   assert dz.is_contiguous() and dx.is_contiguous() and mask_ref.is_contiguous() and stat_ref.is_contiguous()
   assert addend is None or (tuple(addend.shape) == tuple(dx.shape) and addend.is_contiguous())
-  n = int(_fn("os2s_depthwise_dgrad_bnact_num_parts", (c_int, c_int, c_int))(B, Tout, K))
+  n = int((_FN_CACHE.get("os2s_depthwise_dgrad_bnact_num_parts") or _fn("os2s_depthwise_dgrad_bnact_num_parts", (c_int, c_int, c_int)))(B, Tout, K))
   stats = _zero_arena.take((n, 2, C), dz.device)
-  f = _fn("os2s_depthwise_dgrad_bnact", (c_void_p,) * 7 + (c_int,) * 6 + (c_void_p, c_float, c_void_p))
+  f = (_FN_CACHE.get("os2s_depthwise_dgrad_bnact") or _fn("os2s_depthwise_dgrad_bnact", (c_void_p,) * 7 + (c_int,) * 6 + (c_void_p, c_float, c_void_p)))
   _lib.check(f(_stream(), _ptr(dz, torch.bfloat16), _ptr(w, torch.float32), _ptr(dx, torch.bfloat16),
                _ptr(addend, torch.bfloat16, True), _ptr(stats, torch.float32), _ptr(out_len, torch.int32, True),
                B, Tin, Tout, C, K, int(pad_left), _ptr(mask_ref, torch.bfloat16), float(mask_scale),
@@ -2004,7 +2006,7 @@ def pointwise_fold(w, d, out=None):
   else:
     w_eff = torch.empty((1, cout, cin), dtype=torch.bfloat16, device=w.device)
     wt_eff = torch.empty((1, cin, cout), dtype=torch.bfloat16, device=w.device)
-  f = _fn("os2s_pointwise_fold", (c_void_p,) * 5 + (c_int, c_int))
+  f = (_FN_CACHE.get("os2s_pointwise_fold") or _fn("os2s_pointwise_fold", (c_void_p,) * 5 + (c_int, c_int)))
   _lib.check(f(_stream(), _ptr(w, torch.float32), _ptr(d, torch.float32), _ptr(w_eff, torch.bfloat16),
                _ptr(wt_eff, torch.bfloat16), cout, cin), "os2s_pointwise_fold")
   return w_eff, wt_eff
@@ -2015,7 +2017,7 @@ def pointwise_fold_bwd(g, w, d, dw, dd):
   d, dd fp32 [1, Cin]."""
   _, cout, cin = w.shape
   assert tuple(g.shape) == tuple(w.shape) == tuple(dw.shape) and d.numel() == cin == dd.numel()
-  f = _fn("os2s_pointwise_fold_bwd", (c_void_p,) * 6 + (c_int, c_int))
+  f = (_FN_CACHE.get("os2s_pointwise_fold_bwd") or _fn("os2s_pointwise_fold_bwd", (c_void_p,) * 6 + (c_int, c_int)))
   _lib.check(f(_stream(), _ptr(g, torch.float32), _ptr(w, torch.float32), _ptr(d, torch.float32),
                _ptr(dw, torch.float32), _ptr(dd, torch.float32), cout, cin), "os2s_pointwise_fold_bwd")
 
@@ -2027,7 +2029,7 @@ def depthwise_conv1d_wgrad(x, dy, dw, *, stride=1, dil=1, pad_left=None, in_len=
   tout = dy.shape[1]
   if pad_left is None:
     pad_left = same_padding(Tin, K, stride, dil)[1]
-  f = _fn("os2s_depthwise_conv1d_wgrad", (c_void_p,) * 5 + (c_int,) * 8)
+  f = (_FN_CACHE.get("os2s_depthwise_conv1d_wgrad") or _fn("os2s_depthwise_conv1d_wgrad", (c_void_p,) * 5 + (c_int,) * 8))
   _lib.check(f(_stream(), _ptr(x, torch.bfloat16), _ptr(dy, torch.bfloat16), _ptr(dw, torch.float32),
                _ptr(in_len, torch.int32, True), B, Tin, tout, C, K, stride, dil, pad_left),
              "os2s_depthwise_conv1d_wgrad")
@@ -2042,9 +2044,9 @@ class CtcScorer(object):
   def __init__(self, lm_path, trie_path, alphabet_path, alpha, beta, trie_weight=0.1):
     import ctypes
     self._h = ctypes.c_void_p(0)
-    self._destroy = _fn("os2s_ctc_scorer_destroy", (c_void_p,), None)
-    f = _fn("os2s_ctc_scorer_create", (ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_float,
-                                       c_float, c_float, ctypes.POINTER(ctypes.c_void_p)))
+    self._destroy = (_FN_CACHE.get("os2s_ctc_scorer_destroy") or _fn("os2s_ctc_scorer_destroy", (c_void_p,), None))
+    f = (_FN_CACHE.get("os2s_ctc_scorer_create") or _fn("os2s_ctc_scorer_create", (ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_float,
+                                       c_float, c_float, ctypes.POINTER(ctypes.c_void_p))))
     _lib.check(f(str(lm_path).encode(), str(trie_path).encode(), str(alphabet_path).encode(),
                  float(alpha), float(beta), float(trie_weight), ctypes.byref(self._h)),
                "os2s_ctc_scorer_create(%s, %s, %s)" % (lm_path, trie_path, alphabet_path))
@@ -2054,15 +2056,15 @@ class CtcScorer(object):
     return self._h
 
   def set_weights(self, alpha, beta, trie_weight=0.1):
-    f = _fn("os2s_ctc_scorer_set_weights", (c_void_p, c_float, c_float, c_float))
+    f = (_FN_CACHE.get("os2s_ctc_scorer_set_weights") or _fn("os2s_ctc_scorer_set_weights", (c_void_p, c_float, c_float, c_float)))
     _lib.check(f(self._h, float(alpha), float(beta), float(trie_weight)), "os2s_ctc_scorer_set_weights")
 
   def ngram_score(self, words):
     import ctypes
     arr = (ctypes.c_char_p * len(words))(*[w.encode() for w in words])
     out = c_float(0)
-    f = _fn("os2s_ctc_scorer_ngram_score", (c_void_p, ctypes.POINTER(ctypes.c_char_p), c_int,
-                                            ctypes.POINTER(c_float)))
+    f = (_FN_CACHE.get("os2s_ctc_scorer_ngram_score") or _fn("os2s_ctc_scorer_ngram_score", (c_void_p, ctypes.POINTER(ctypes.c_char_p), c_int,
+                                            ctypes.POINTER(c_float))))
     _lib.check(f(self._h, arr, len(words), ctypes.byref(out)), "os2s_ctc_scorer_ngram_score")
     return out.value
 
@@ -2085,8 +2087,8 @@ def ctc_beam_search(logits, seq_len, beam_width, scorer=None, top_paths=1, merge
   ids = torch.empty((B, top_paths, max(T, 1)), dtype=torch.int32)
   lens = torch.empty((B, top_paths), dtype=torch.int32)
   lp = torch.empty((B, top_paths), dtype=torch.float32)
-  f = _fn("os2s_ctc_beam_search", (c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p))
+  f = (_FN_CACHE.get("os2s_ctc_beam_search") or _fn("os2s_ctc_beam_search", (c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p)))
   if T == 0:
     raise ValueError("empty logits")
   _lib.check(f(logits.data_ptr(), B * C, C, seq_len.data_ptr(), T, B, C, int(beam_width),
@@ -2099,6 +2101,6 @@ def ctc_beam_search(logits, seq_len, beam_width, scorer=None, top_paths=1, merge
 def ctc_generate_trie(alphabet_path, lm_path, vocab_path, trie_path):
   """The reference's generate_trie tool (ctc_decoder_with_lm/generate_trie.cpp)."""
   import ctypes
-  f = _fn("os2s_ctc_generate_trie", (ctypes.c_char_p,) * 4)
+  f = (_FN_CACHE.get("os2s_ctc_generate_trie") or _fn("os2s_ctc_generate_trie", (ctypes.c_char_p,) * 4))
   _lib.check(f(str(alphabet_path).encode(), str(lm_path).encode(), str(vocab_path).encode(),
                str(trie_path).encode()), "os2s_ctc_generate_trie")

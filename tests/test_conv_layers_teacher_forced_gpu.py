@@ -74,8 +74,18 @@ def _one_layer(cuda, ltype, cin, cout, K, stride, dil, B, T, lens):
   torch.cuda.synchronize()
   name = "conv21"
   w = {}
+  folded = ltype != "conv1d" and L.folded()
   if ltype == "conv1d":
     w[name + "/kernel"] = L.kernel.w16.float().cpu().permute(0, 2, 1).contiguous().requires_grad_(True)
+  elif folded:
+    # a one-tap separable layer runs as ONE 1x1 convolution with W diag(d) rounded to bf16 once (SepConvBN.folded,
+    # os2s_pointwise_fold): the oracle layer gets that kernel and a unit scale (x * 1 is exact, so its storage point
+    # between the halves is the identity); the two variables' gradients follow from its kernel gradient G by the
+    # chain rule, dW = G diag(d), dd = sum_co W * G — in fp32 here, by os2s_pointwise_fold_bwd on the device
+    dvec = L.depthwise.master.float().cpu()[0]
+    Wm = L.kernel.master.float().cpu()[0]
+    w[name + "/depthwise_kernel"] = torch.ones(1, cin)
+    w[name + "/pointwise_kernel"] = (Wm * dvec[None, :]).to(torch.bfloat16).float().t()[None].contiguous().requires_grad_(True)
   else:
     w[name + "/depthwise_kernel"] = L.depthwise.master.float().cpu().clone().requires_grad_(True)
     w[name + "/pointwise_kernel"] = L.kernel.w16.float().cpu().permute(0, 2, 1).contiguous().requires_grad_(True)
@@ -107,6 +117,10 @@ def _one_layer(cuda, ltype, cin, cout, K, stride, dil, B, T, lens):
   assert _rel(dx, dxo) <= gb
   if ltype == "conv1d":
     assert _rel(L.kernel.grad.float().cpu().permute(0, 2, 1), w[name + "/kernel"].grad) <= gb
+  elif folded:
+    G = w[name + "/pointwise_kernel"].grad[0].t()                      # [Cout, Cin]
+    assert _rel(L.kernel.grad.float().cpu()[0], G * dvec[None, :]) <= gb
+    assert _rel(L.depthwise.grad.float().cpu()[0], (Wm * G).sum(0)) <= gb
   else:
     assert _rel(L.kernel.grad.float().cpu().permute(0, 2, 1), w[name + "/pointwise_kernel"].grad) <= gb
     assert _rel(L.depthwise.grad.float().cpu(), w[name + "/depthwise_kernel"].grad) <= gb
