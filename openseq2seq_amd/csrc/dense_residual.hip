@@ -17,7 +17,7 @@
 //     d1 = gamma rstd,  d2 = d1 rstd dgamma / N
 //     dW = d1 P - (d1 dbeta / N) s^T - N d2 (W C)
 //     dr_i = sum_k dz_k (W_ik d1)  -  r_i . sum_k W_ik^T d2 W_ik  +  1 . sum_k (mean d2 - d1 dbeta / N)^T W_ik
-// (checked in fp64 against autograd: scratch/dense_res_algebra.py; on the device against the branch-tensor path:
+// (checked in fp64 against autograd: tests/test_dense_residual_algebra.py; on the device against the branch-tensor path:
 // tests/test_dense_residual_gpu.py). This file holds the small kernels between the GEMMs: the masked copy of a
 // source into the concatenated buffer with its column sums, the covariance split into a bf16 hi / lo pair (the
 // product W C runs on the bf16 matrix cores with both halves: 16 mantissa bits), the per-block-end statistics +

@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void pointwise_fold_bwd_kernel(const float* __
 
 using namespace os2s;
 
-static int g_dw_ablate = 0;     // measurement hook (scratch/bench_depthwise.py): parts of the matrix-core kernel switched off
+static int g_dw_ablate = 0;     // measurement hook (tools/bench_depthwise.py): parts of the matrix-core kernel switched off
 static os2s::OptionReg r_dw_ablate("depthwise.ablate", [](double v) { g_dw_ablate = (int)v; });
 static int g_dw_variant = -1;   // test / experiment hook: 0 = the generic kernels only
 static os2s::OptionReg r_dw_variant("depthwise.variant", [](double v) { g_dw_variant = (int)v; });

@@ -104,7 +104,7 @@ def _one_layer(cuda, ltype, cin, cout, K, stride, dil, B, T, lens):
   if ltype != "conv1d" and stride == 1 and dil == 1:
     # round 6: these layers' depthwise halves run on the matrix cores with the taps as a bf16 hi + lo pair — 16
     # mantissa bits instead of the oracle's 24: 0.2 % of the depthwise outputs round to the neighbouring bf16 value
-    # (scratch/check_dw_precision.py: 99.77 % of the elements equal bf16(fp32-tap convolution), the register-window
+    # (tools/check_dw_precision.py: 99.77 % of the elements equal bf16(fp32-tap convolution), the register-window
     # kernel 99.99 %), and the ReLU masks behind the BatchNorm flip with them: d(input) 7.6e-3 where the emulated
     # storage points otherwise give 1.7e-3 (without any emulation: 3.5 - 4 %)
     gb = 1e-2
