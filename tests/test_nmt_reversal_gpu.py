@@ -15,6 +15,21 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _deterministic_kernels():
+  """Convergence tests run with the single-contributor launch geometries (os2s_set_deterministic: no fp32 atomics
+  across workgroups — embedding scatter, narrow weight gradients): a seed's trajectory is then the same on every run
+  and every box, so a seed that clears its bar clears it always. (With the default kernels the same seed drew BLEU
+  0.971 ... 1.0 over nine runs and failed once in a full-suite run of round 6.)"""
+  from openseq2seq_amd import capi
+  prev = capi.deterministic()
+  capi.set_deterministic(True)
+  try:
+    yield
+  finally:
+    capi.set_deterministic(prev)
+
+
 @pytest.mark.parametrize("seed", [7, 11, 2024])
 def test_nmt_small_learns_reversal(cuda, tmp_path, monkeypatch, seed):
   """Three seeds, each must clear the bar (round 5 drew BLEU 0.86 once under a clock-derived seed: a convergence
