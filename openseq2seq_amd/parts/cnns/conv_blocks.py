@@ -291,7 +291,9 @@ class Tape(object):
     """A Dense weight gradient too small to fill the chip alone is held back until `group` of them — or, with
     `unit_budget`, enough of them to cover that many 256 x 256 output tiles — can go out in one launch
     (capi.gemm_wgrad_grouped: at most 16 per launch). Until then `param` does not count as final for the
-    gradient reducer."""
+    gradient reducer. Optional keys of `item`: `after` — a callable run behind the grouped launch, on its stream (a
+    folded one-tap separable layer splits its product into two variables' gradients there); `also` — further
+    parameters that become final with that launch (the caller has raised their pending counts)."""
     # one grouped launch has ONE row count (os2s_gemm_wgrad_grouped takes a single M): a layer fed by
     # another number of packed rows (the enc-dec attention's k/v projection of the SOURCE tokens among
     # target-row layers) starts a new group
